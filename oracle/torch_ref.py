@@ -1,0 +1,183 @@
+"""CPU ORACLE #2 (test infrastructure, NOT product code): torch-CPU restatement.
+
+An independent second restatement of the reference VAE step that uses torch's own
+conv kernels (explicit ``F.pad`` + ``F.conv2d`` / ``F.conv_transpose2d`` + crop) and
+``torch.autograd`` for every gradient, so that it shares no arithmetic code with
+``oracle/vae_oracle.py``.  Uses:
+
+* tests: float64 cross-check of the numpy oracle's forward and hand-written backward;
+* ``bench.py``: the ``cpu_baseline`` leg (``kind: "port"``) -- the same training step in
+  fp32 on all host cores (the reference's TF-CPU path cannot run: no TensorFlow on the
+  box).
+
+PARITY STATUS: parity unpinned vs the TF reference (see oracle/vae_oracle.py header).
+Citations are relative to /root/reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .vae_oracle import same_pads, layer_param_shapes, LOG2PI, SOFTPLUS_INV_1
+
+
+def _act(name, x):
+  if name == 'linear':
+    return x
+  if name == 'elu':
+    return F.elu(x)
+  if name == 'relu':
+    return F.relu(x)
+  raise ValueError(name)
+
+
+def t_conv2d(x, w, b, s):
+  """x NHWC, w HWIO (Keras Conv2D SAME; odin/networks/image_networks.py:166-169)."""
+  B, H, W, C = x.shape
+  kh, kw, _, co = w.shape
+  _, pt, pb = same_pads(H, kh, s)
+  _, pl, pr = same_pads(W, kw, s)
+  xn = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+  y = F.conv2d(xn, w.permute(3, 2, 0, 1), b, stride=s)
+  return y.permute(0, 2, 3, 1)
+
+
+def t_deconv2d(x, w, b, s):
+  """x NHWC, w (kh,kw,Cout,Cin) (Keras Conv2DTranspose SAME; image_networks.py:170-173)."""
+  B, H, W, C = x.shape
+  kh, kw, co, ci = w.shape
+  _, pt, _ = same_pads(H * s, kh, s)
+  _, pl, _ = same_pads(W * s, kw, s)
+  # torch weight for conv_transpose2d: [Cin, Cout, kh, kw]
+  y = F.conv_transpose2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, stride=s)
+  y = y[:, :, pt:pt + H * s, pl:pl + W * s]
+  return y.permute(0, 2, 3, 1)
+
+
+def t_seq(layers, params, x):
+  h = x
+  for li, L in enumerate(layers):
+    k = L[0]
+    if k == 'center':
+      h = 2.0 * h - 1.0
+    elif k == 'conv':
+      h = _act(L[4], t_conv2d(h, params[(li, 'w')], params[(li, 'b')], L[3]))
+    elif k == 'deconv':
+      h = _act(L[4], t_deconv2d(h, params[(li, 'w')], params[(li, 'b')], L[3]))
+    elif k == 'flatten':
+      h = h.reshape(h.shape[0], -1)
+    elif k == 'dense':
+      h = _act(L[2], h @ params[(li, 'w')] + params[(li, 'b')])
+    elif k == 'reshape':
+      h = h.reshape((h.shape[0],) + tuple(L[1]))
+  return h
+
+
+def t_total_correlation(z, loc, scale):
+  """odin/bay/vi/losses.py:101-157."""
+  lp = (-0.5 * ((z[:, None, :] - loc[None]) / scale[None]) ** 2 - torch.log(scale[None])
+        - 0.5 * LOG2PI)
+  return (torch.logsumexp(lp.sum(2), 1) - torch.logsumexp(lp, 1).sum(1)).mean()
+
+
+class TorchVAE:
+  """Same constructor arguments as oracle.vae_oracle.OracleVAE."""
+
+  def __init__(self, enc_layers, dec_layers, in_shape, zdim, observation='bernoulli',
+               analytic=False, free_bits=None, beta=1.0, tc_beta=None,
+               dtype=torch.float64):
+    self.enc, self.dec = list(enc_layers), list(dec_layers)
+    self.in_shape, self.D = tuple(in_shape), int(zdim)
+    self.observation, self.analytic, self.free_bits = observation, analytic, free_bits
+    self.beta, self.tc_beta, self.dtype = float(beta), tc_beta, dtype
+
+  def tensors(self, P: Dict, requires_grad=True):
+    return {k: torch.tensor(np.asarray(v), dtype=self.dtype, requires_grad=requires_grad)
+            for k, v in P.items()}
+
+  @staticmethod
+  def _sub(T, net):
+    return {(k[1], k[2]): v for k, v in T.items() if k[0] == net}
+
+  def forward(self, T, x, eps, extra_loss_fn=None):
+    D = self.D
+    B = x.shape[0]
+    h_e = t_seq(self.enc, self._sub(T, 'enc'), x)
+    p = h_e @ T[('lat', 'w')] + T[('lat', 'b')]
+    loc, scale = p[:, :D], F.softplus(p[:, D:])
+    z = loc + scale * eps
+    h_d = t_seq(self.dec, self._sub(T, 'dec'), z)
+    if self.observation == 'bernoulli':
+      llk = (x * h_d - F.softplus(h_d)).reshape(B, -1).sum(1)
+      recon = torch.sigmoid(h_d)
+    else:
+      C = x.shape[-1]
+      oloc, raw = h_d[..., :C], h_d[..., C:]
+      osc = F.softplus(raw + SOFTPLUS_INV_1) if self.observation == 'gaussian_softplus1' else raw
+      llk = (-0.5 * ((x - oloc) / osc) ** 2 - torch.log(osc) - 0.5 * LOG2PI).reshape(B, -1).sum(1)
+      recon = oloc
+    if self.analytic:
+      kl_raw = 0.5 * (scale ** 2 + loc ** 2 - 1.0 - 2.0 * torch.log(scale)).sum(-1)
+    else:
+      lq = (-0.5 * ((z - loc) / scale) ** 2 - torch.log(scale)).sum(-1) - 0.5 * D * LOG2PI
+      lp = (-0.5 * z ** 2).sum(-1) - 0.5 * D * LOG2PI
+      kl_raw = lq - lp
+    kl = kl_raw
+    if self.free_bits is not None:
+      kl = torch.clamp(kl, min=self.free_bits * D)
+    kl = self.beta * kl
+    elbo = llk - kl
+    out = dict(h_e=h_e, p=p, loc=loc, scale=scale, z=z, h_d=h_d, recon=recon, llk=llk,
+               kl_raw=kl_raw, kl=kl)
+    if self.tc_beta is not None:
+      out['tc'] = (self.tc_beta - 1.0) * t_total_correlation(z, loc, scale)
+      elbo = elbo - out['tc']
+    loss = -elbo.mean()
+    if extra_loss_fn is not None:
+      loss = loss + extra_loss_fn(out)
+    out['elbo'], out['loss'] = elbo, loss
+    return out
+
+  def loss_and_grads(self, P, x, eps, extra_loss_fn=None):
+    T = self.tensors(P)
+    xt = torch.tensor(np.asarray(x), dtype=self.dtype)
+    et = torch.tensor(np.asarray(eps), dtype=self.dtype)
+    out = self.forward(T, xt, et, extra_loss_fn)
+    out['loss'].backward()
+    G = {k: v.grad.detach().numpy() for k, v in T.items()}
+    return {k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}, G
+
+
+class TorchTrainer:
+  """fp32 CPU training step used as bench.py's cpu_baseline ("port"): forward, autograd
+  backward, Keras-Adam (epsilon outside sqrt; odin/networks/base_networks.py:85-112,604)."""
+
+  def __init__(self, model: TorchVAE, P: Dict, lr=1e-3, threads: Optional[int] = None):
+    if threads:
+      torch.set_num_threads(threads)
+    self.model = model
+    self.T = {k: torch.tensor(np.asarray(v), dtype=model.dtype, requires_grad=True)
+              for k, v in P.items()}
+    self.M = {k: torch.zeros_like(v) for k, v in self.T.items()}
+    self.V = {k: torch.zeros_like(v) for k, v in self.T.items()}
+    self.t, self.lr = 0, lr
+
+  def step(self, x: torch.Tensor, eps: torch.Tensor) -> float:
+    for v in self.T.values():
+      v.grad = None
+    out = self.model.forward(self.T, x, eps)
+    out['loss'].backward()
+    self.t += 1
+    b1, b2, e = 0.9, 0.999, 1e-7
+    a = self.lr * math.sqrt(1 - b2 ** self.t) / (1 - b1 ** self.t)
+    with torch.no_grad():
+      for k, p in self.T.items():
+        g = p.grad
+        self.M[k].mul_(b1).add_(g, alpha=1 - b1)
+        self.V[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.addcdiv_(self.M[k], self.V[k].sqrt().add_(e), value=-a)
+    return float(out['loss'])
