@@ -1,0 +1,173 @@
+/* odin_hip.h -- C ABI of libodin_hip.so: the MI355X (gfx950) VAE training-step path.
+ *
+ * The reference (trungnt13/odin-ai) is pure Python: it has no FFI of its own, its device
+ * arithmetic is executed by TensorFlow 2.5 / TFP 0.13 ops called from the Python files
+ * cited below.  Each entry point here replaces one such call site; a maintainer binds
+ * them with ctypes.  Conventions:
+ *   - every pointer is a DEVICE pointer to fp32 (int32 where noted), borrowed for the
+ *     duration of the call; nothing is allocated, freed or retained by the library;
+ *   - activations are NHWC, Conv2D kernels (kh,kw,Cin,Cout), Conv2DTranspose kernels
+ *     (kh,kw,Cout,Cin), Dense kernels (in,out) -- the Keras layouts, never transposed;
+ *   - `stream` is a hipStream_t passed as void*; all work is asynchronous on it;
+ *   - return value 0 = OK, negative = error (odin_last_error() has the text).
+ * File:line citations are relative to the reference repository root.
+ */
+#ifndef ODIN_HIP_H
+#define ODIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ODIN_LINEAR = 0, ODIN_ELU = 1, ODIN_RELU = 2 };
+
+/* Geometry of one Conv2D / Conv2DTranspose layer (TF `SAME` padding resolved by the
+ * caller: pad_t/pad_l are the SAME "before" pads of the strided conv; for a transposed
+ * conv they are the pads of the forward conv on the OUTPUT size). */
+typedef struct odin_conv_desc {
+  int B, H, W, Cin;   /* layer input  [B,H,W,Cin]   */
+  int OH, OW, Cout;   /* layer output [B,OH,OW,Cout] */
+  int KH, KW, stride;
+  int pad_t, pad_l;
+  int act;            /* fused epilogue activation (forward only) */
+  int center;         /* fold CenterAt0 (2x-1) into the input load (image_networks.py:121-126) */
+} odin_conv_desc;
+
+/* ---- runtime ------------------------------------------------------------------------ */
+int odin_version(void);
+const char* odin_last_error(void);
+int odin_max_slab_rows(void);      /* upper bound of the rows any slab-producing call writes */
+
+/* ---- Conv2D (keras.layers.Conv2D, odin/networks/image_networks.py:166-169,463-466) --- */
+int odin_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                    const odin_conv_desc* d, void* stream);
+/* dx = conv2d_backprop_input(dy) * act'(aux);  replaces tape.gradient
+ * (odin/networks/base_networks.py:514-518).  aux = the layer's INPUT activation (post
+ * activation of the previous layer) or NULL.  colsum_slab (optional,
+ * [*slab_rows_out][Cin]) receives per-workgroup column sums of dx (the bias gradient
+ * of the previous layer when that layer is a Conv2DTranspose). */
+int odin_conv2d_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                      float* colsum_slab, int* slab_rows_out, const odin_conv_desc* d,
+                      void* stream);
+/* slab[g][kh,kw,Cin,Cout | Cout] partial (dW | db) per workgroup g < *slab_rows_out;
+ * finish with odin_slab_reduce.  x = layer input, dy = grad wrt pre-activation output. */
+int odin_conv2d_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out,
+                      const odin_conv_desc* d, void* stream);
+
+/* ---- Conv2DTranspose (odin/networks/image_networks.py:170-173,497-505) ---------------- */
+int odin_deconv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                      const odin_conv_desc* d, void* stream);
+int odin_deconv2d_dgrad(const float* dy, const float* w, const float* aux, int aux_act,
+                        float* dx, float* colsum_slab, int* slab_rows_out,
+                        const odin_conv_desc* d, void* stream);
+/* slab[g][kh,kw,Cout,Cin] partial dW (bias grad comes from the producer's colsum slab) */
+int odin_deconv2d_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out,
+                        const odin_conv_desc* d, void* stream);
+
+/* ---- Dense (keras Dense: base_networks.py:1002-1014; DistributionDense projection:
+ * odin/bay/layers/dense_distribution.py:229-238) ------------------------------------- */
+int odin_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K,
+                   int N, int act, void* stream);
+int odin_dense_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                     float* colsum_slab, int* slab_rows_out, int B, int K, int N, void* stream);
+/* slab[g][K*N | N] partial (dW | db) */
+int odin_dense_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out, int B,
+                     int K, int N, void* stream);
+
+/* dst[j][i] = sum_{g<G} src[j][g*n_j + i]; up to 64 jobs per launch. */
+typedef struct odin_reduce_job {
+  const float* src;
+  float* dst;
+  int n;      /* elements per slab row */
+  int rows;   /* G */
+} odin_reduce_job;
+int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* stream);
+
+/* ---- latent posterior q(z|x) = MVNDiag(loc, softplus(raw))
+ * MultivariateNormalLayer.new (odin/bay/layers/continuous.py:459-483), sample =
+ * loc + scale*eps, KL: kl_divergence (odin/bay/helpers.py:177-282): analytic=0 -> MC
+ * log q(z) - log p(z) at the same z; analytic=1 -> closed form; free_bits<0 = disabled,
+ * else max(kl, free_bits*D).   p [B,2D], eps [B,D] -> z [B,D], kl [B] (after free bits),
+ * fbmask [B] (1 where the gradient flows). */
+int odin_latent_fwd(const float* p, const float* eps, float* z, float* kl, float* fbmask, int B,
+                    int D, int analytic, float free_bits, void* stream);
+/* dp [B,2D] of  L = sum_b klw[0]*kl_b  given dz = dL/dz from the decoder (may be NULL) and
+ * optional extra grads (dloc_x, dscale_x: from total correlation).  klw is a DEVICE scalar
+ * (= beta / B) so that graph replays see schedule updates. */
+int odin_latent_bwd(const float* p, const float* eps, const float* z, const float* dz,
+                    const float* fbmask, const float* klw, const float* dloc_x,
+                    const float* dscale_x, float* dp, int B, int D, int analytic, void* stream);
+
+/* ---- observation log-likelihood fused forward+backward
+ * Independent(Bernoulli(logits),3).log_prob(x) (image_networks.py:87-93;
+ * variational_autoencoder.py:528-530): llk_part[b][part] partial sums (n_part per
+ * sample), dlogits = -(x - sigmoid(l)) * scale[0]  (scale = DEVICE scalar 1/B). */
+int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, float* llk_part,
+                                float* dlogits, const float* scale, int B, int n_per_sample,
+                                int* n_part_out, void* stream);
+/* Independent(Normal(loc, scale)) with params = split(h,2,axis=-1)
+ * (image_networks.py:95-102): softplus1 != 0 -> scale = softplus(raw + softplus^-1(1))
+ * (GaussianLayer, odin/bay/layers/continuous.py:196-260; odin/backend/maths.py:279-281). */
+int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float* llk_part, float* dh,
+                               const float* scale, int B, int n_pix, int C, int softplus1,
+                               int* n_part_out, void* stream);
+/* VAEStep.call / VariationalModel.elbo (variational_autoencoder.py:117-126;
+ * odin/bay/vi/_base.py:151-194): llk[b] = sum parts; elbo = llk - beta*kl - tc;
+ * out[0]=loss=-mean(elbo), out[1]=mean llk, out[2]=mean beta*kl, out[3]=tc term.
+ * hyper: DEVICE floats {beta, tc_weighted (added to every sample's kl side)}. */
+int odin_elbo_finalize(const float* llk_part, int n_part, const float* kl, const float* hyper,
+                       float* llk, float* out4, int B, void* stream);
+
+/* ---- beta-TCVAE total correlation (odin/bay/vi/losses.py:101-157), never materialising
+ * the [B,B,D] tensor.  tc_out[0] = TC; grads scaled by coef[0] (DEVICE scalar (beta-1)). */
+int odin_total_correlation_fwd_bwd(const float* z, const float* p, float* tc_out, float* dz,
+                                   float* dloc, float* dscale, const float* coef, int B, int D,
+                                   void* stream);
+/* permute_dims (odin/bay/vi/utils.py:233-269): out[i,l] = z[perm[i,l], l]; perm int32 [B,D] */
+int odin_permute_dims(const float* z, const int32_t* perm, float* out, int B, int D, void* stream);
+/* per-column random permutations generated on device (Philox), perm int32 [B,D] */
+int odin_random_perm(int32_t* perm, int B, int D, uint64_t seed, const int32_t* step_dev,
+                     void* stream);
+/* dtc_loss (odin/bay/vi/autoencoder/factor_discriminator.py:200-235):
+ * out[0] = 0.5*(mean softplus(-lz) + mean softplus(lperm)); grads wrt both logit vectors */
+int odin_dtc_loss_fwd_bwd(const float* logit_z, const float* logit_perm, float* out,
+                          float* dlogit_z, float* dlogit_perm, int n, void* stream);
+
+/* ---- optimiser: tf.optimizers.Adam created at odin/networks/base_networks.py:85-112,
+ * applied at :604 -- Keras form, epsilon outside the bias-corrected sqrt.
+ * hyper (DEVICE): {alpha_t = lr*sqrt(1-b2^t)/(1-b1^t), beta1, beta2, eps, grad_scale};
+ * gnorm2 (optional DEVICE scalar): if non-NULL and clip>0 the gradient is scaled by
+ * clip/max(sqrt(gnorm2),clip) (tf.clip_by_global_norm, base_networks.py:588); if
+ * non-finite the update is skipped (nan_gradients_policy, base_networks.py:519-547) and
+ * flag[0] is set to 1. */
+int odin_adam_step_flat(float* theta, const float* g, float* m, float* v, size_t n,
+                        const float* hyper, const float* gnorm2, float clip, int32_t* flag,
+                        void* stream);
+/* out[0] = sum g^2 (deterministic two-stage); workspace >= 1024 floats */
+int odin_sumsq_flat(const float* g, size_t n, float* workspace, float* out, void* stream);
+
+/* ---- counter-based RNG (the reference uses TF's Philox via tfd.sample; streams are not
+ * reproducible across frameworks, so parity tests pass eps explicitly) ------------------ */
+int odin_rng_normal(float* out, size_t n, uint64_t seed, const int32_t* step_dev, void* stream);
+
+/* ---- speech front-end: pre-emphasis -> STFT -> |.|^2 -> Slaney mel -> dB
+ * (odin/preprocessing/signal.py:955-967,1442-1562,1623-1691,636-680).
+ * y [B,n_samples] -> out [B,n_frames,n_mels]; window [frame_length] (already divided by
+ * its sum), melfb [n_mels, n_fft/2+1]. */
+int odin_stft_mel_db(const float* y, const float* window, const float* melfb, float* out, int B,
+                     int n_samples, int frame_length, int step_length, int n_fft, int n_mels,
+                     float preemph, float top_db, int log_output, void* stream);
+
+/* ---- HIP-graph helpers (capture a sequence of the calls above, replay per step) ------- */
+int odin_graph_begin(void* stream);
+int odin_graph_end(void* stream, void** graph_exec_out);
+int odin_graph_launch(void* graph_exec, void* stream);
+int odin_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODIN_HIP_H */

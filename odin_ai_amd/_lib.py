@@ -1,0 +1,134 @@
+"""ctypes binding of ``libodin_hip.so`` (the C ABI declared in ``include/odin_hip.h``).
+
+The product path has NO fallback: if the gfx950 library is missing or a symbol is absent
+the import of the HIP backend raises.  ``load(path)`` with an explicit path exists so
+that the test-suite can point the very same Python host code at the CPU-simulated build
+of the kernel sources (``tests/sim/libodin_sim.so``) for debugging in containers without
+a GPU; nothing in the package ever selects that library by itself.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, 'libodin_hip.so')
+
+ACT = {'linear': 0, 'elu': 1, 'relu': 2, None: 0}
+
+
+class ConvDesc(C.Structure):
+  """mirror of ``odin_conv_desc`` (include/odin_hip.h)."""
+  _fields_ = [(n, C.c_int) for n in ('B', 'H', 'W', 'Cin', 'OH', 'OW', 'Cout', 'KH', 'KW',
+                                     'stride', 'pad_t', 'pad_l', 'act', 'center')]
+
+
+class ReduceJob(C.Structure):
+  _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('n', C.c_int), ('rows', C.c_int)]
+
+
+P = C.c_void_p
+I = C.c_int
+F = C.c_float
+IP = C.POINTER(C.c_int)
+DP = C.POINTER(ConvDesc)
+
+# name -> argtypes, exactly the declarations of include/odin_hip.h
+SIGNATURES = {
+    'odin_version': [],
+    'odin_max_slab_rows': [],
+    'odin_conv2d_fwd': [P, P, P, P, DP, P],
+    'odin_conv2d_dgrad': [P, P, P, I, P, P, IP, DP, P],
+    'odin_conv2d_wgrad': [P, P, P, IP, DP, P],
+    'odin_deconv2d_fwd': [P, P, P, P, DP, P],
+    'odin_deconv2d_dgrad': [P, P, P, I, P, P, IP, DP, P],
+    'odin_deconv2d_wgrad': [P, P, P, IP, DP, P],
+    'odin_dense_fwd': [P, P, P, P, I, I, I, I, P],
+    'odin_dense_dgrad': [P, P, P, I, P, P, IP, I, I, I, P],
+    'odin_dense_wgrad': [P, P, P, IP, I, I, I, P],
+    'odin_slab_reduce': [C.POINTER(ReduceJob), I, P],
+    'odin_latent_fwd': [P, P, P, P, P, I, I, I, F, P],
+    'odin_latent_bwd': [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    'odin_elbo_bernoulli_fwd_bwd': [P, P, P, P, P, I, I, IP, P],
+    'odin_elbo_gaussian_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
+    'odin_elbo_finalize': [P, I, P, P, P, P, I, P],
+    'odin_total_correlation_fwd_bwd': [P, P, P, P, P, P, P, I, I, P],
+    'odin_permute_dims': [P, P, P, I, I, P],
+    'odin_random_perm': [P, I, I, C.c_uint64, P, P],
+    'odin_dtc_loss_fwd_bwd': [P, P, P, P, P, I, P],
+    'odin_adam_step_flat': [P, P, P, P, C.c_size_t, P, P, F, P, P],
+    'odin_sumsq_flat': [P, C.c_size_t, P, P, P],
+    'odin_rng_normal': [P, C.c_size_t, C.c_uint64, P, P],
+    'odin_stft_mel_db': [P, P, P, P, I, I, I, I, I, I, F, F, I, P],
+    'odin_graph_begin': [P],
+    'odin_graph_end': [P, C.POINTER(C.c_void_p)],
+    'odin_graph_launch': [P, P],
+    'odin_graph_destroy': [P],
+}
+
+
+class OdinError(RuntimeError):
+  pass
+
+
+class Lib:
+
+  def __init__(self, path: str):
+    if not os.path.exists(path):
+      raise OdinError(
+          f"HIP extension not found: {path}. Build it with `python -c 'import "
+          f"__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). There is no "
+          f"CPU fallback.")
+    self.path = path
+    self.c = C.CDLL(path)
+    self.c.odin_last_error.restype = C.c_char_p
+    self.c.odin_last_error.argtypes = []
+    for name, args in SIGNATURES.items():
+      fn = getattr(self.c, name)  # AttributeError if the symbol is missing: fail loudly
+      fn.argtypes = args
+      fn.restype = C.c_int
+
+  def check(self, rc: int, what: str = ''):
+    if rc != 0:
+      raise OdinError(f"{what} failed: {self.c.odin_last_error().decode()} (rc={rc})")
+
+  def __getattr__(self, name):
+    if name.startswith('odin_'):
+      fn = getattr(self.c, name)
+
+      def call(*a):
+        rc = fn(*a)
+        if rc != 0 and name not in ('odin_version', 'odin_max_slab_rows'):
+          raise OdinError(f"{name} failed: {self.c.odin_last_error().decode()} (rc={rc})")
+        return rc
+
+      self.__dict__[name] = call
+      return call
+    raise AttributeError(name)
+
+
+_lib: Optional[Lib] = None
+
+
+def load(path: Optional[str] = None) -> Lib:
+  """Load (once) and return the library.  ``path=None`` -> the in-tree gfx950 build."""
+  global _lib
+  if path is not None:
+    _lib = Lib(path)
+  elif _lib is None:
+    _lib = Lib(DEFAULT_LIB)
+  return _lib
+
+
+def ptr(t) -> Optional[int]:
+  """device (or, under the simulator, host) address of a torch tensor / None."""
+  if t is None:
+    return None
+  assert t.is_contiguous(), 'odin kernels need contiguous buffers'
+  return t.data_ptr()
+
+
+def conv_desc(B, H, W, Cin, OH, OW, Cout, K, stride, pad_t, pad_l, act='linear',
+              center=False) -> ConvDesc:
+  return ConvDesc(B, H, W, Cin, OH, OW, Cout, K, K, stride, pad_t, pad_l, ACT[act], int(center))

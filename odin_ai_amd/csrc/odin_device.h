@@ -1,0 +1,72 @@
+// odin_device.h -- shared device-side helpers for the gfx950 kernels.
+// With -DODIN_SIM the same sources compile as host C++ against tests/sim/hipsim.h
+// (a debugging emulator, test infrastructure only); the product build is hipcc/gfx950.
+#pragma once
+#ifdef ODIN_SIM
+#include "hipsim.h"
+#define ODIN_DYN_SMEM(T, name) T* name = (T*)sim::S().dyn_smem
+#define ODIN_LAUNCH(kern, grid, block, shmem, stream, ...) \
+  sim::launch(grid, block, shmem, [&]() { kern(__VA_ARGS__); })
+#else
+#include <hip/hip_runtime.h>
+#define ODIN_DYN_SMEM(T, name)                                                     \
+  extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw_lds[];   \
+  T* name = (T*)name##_raw_lds
+#define ODIN_LAUNCH(kern, grid, block, shmem, stream, ...) \
+  hipLaunchKernelGGL(kern, grid, block, shmem, (hipStream_t)(stream), __VA_ARGS__)
+#endif
+
+#ifdef ODIN_SIM
+static inline float odin_exp(float x) { return expf(x); }
+static inline float odin_log(float x) { return logf(x); }
+#else
+__device__ __forceinline__ float odin_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float odin_log(float x) { return __logf(x); }
+#endif
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x2_f32: exact f32, k-ordered fmaf chain.  Lane l supplies
+// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; D: col = l&31,
+// row = (r&3) + 8*(r>>2) + 4*(l>>5) for accumulator register r.
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+#ifdef ODIN_SIM
+  return sim::mfma_32x32x2(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ f32x16 f32x16_zero() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+enum { ODIN_ACT_LINEAR = 0, ODIN_ACT_ELU = 1, ODIN_ACT_RELU = 2 };
+
+__device__ __forceinline__ float odin_act(int act, float v) {
+  if (act == ODIN_ACT_ELU) return v > 0.f ? v : expm1f(v);
+  if (act == ODIN_ACT_RELU) return v > 0.f ? v : 0.f;
+  return v;
+}
+// derivative of the activation expressed from its OUTPUT y
+__device__ __forceinline__ float odin_act_grad(int act, float y) {
+  if (act == ODIN_ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+  if (act == ODIN_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+static inline int odin_floordiv(int a, int b) {
+  int q = a / b;
+  if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+  return q;
+}

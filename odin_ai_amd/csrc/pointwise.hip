@@ -1,0 +1,366 @@
+// pointwise.hip -- the HBM-bound kernels of the VAE step: latent reparameterisation + KL,
+// fused observation log-likelihood forward+backward, ELBO finalisation, fused flat
+// Keras-Adam, gradient-norm reduction and the counter-based RNG.
+//
+// Every kernel streams its operands exactly once with 16-byte accesses and reduces with
+// wave shuffles; scalars that change from step to step (beta, 1/B, Adam's alpha_t, RNG
+// step) are read from device memory so that a captured HIP graph can be replayed.
+#include "odin_device.h"
+#include "odin_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float softplus_f(float x) {
+  return fmaxf(x, 0.f) + log1pf(odin_exp(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoid_f(float x) {
+  float e = odin_exp(-fabsf(x));
+  float s = 1.f / (1.f + e);
+  return x >= 0.f ? s : e * s;
+}
+constexpr float LOG2PI_F = 1.8378770664093453f;
+constexpr float SOFTPLUS_INV1 = 0.5413248546129181f;
+
+// block-wide sum of one float per thread (256 threads); result valid in thread 0
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats LDS */) {
+  v = wave_sum64(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0) t = (red[0] + red[1]) + (red[2] + red[3]);
+  return t;
+}
+
+// ------------------------------------------------------------------ latent ----------
+__global__ __launch_bounds__(256) void latent_fwd_kernel(const float* p, const float* eps,
+                                                         float* z, float* kl, float* fbmask,
+                                                         int B, int D, int analytic,
+                                                         float free_bits) {
+  int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float* pb = p + (size_t)b * 2 * D;
+  float acc = 0.f;
+  for (int d = 0; d < D; ++d) {
+    float loc = pb[d], sc = softplus_f(pb[D + d]), e = eps[(size_t)b * D + d];
+    float zz = loc + sc * e;
+    z[(size_t)b * D + d] = zz;
+    float ls = odin_log(sc);
+    if (analytic) acc += 0.5f * (sc * sc + loc * loc - 1.f) - ls;
+    else acc += 0.5f * (zz * zz - e * e) - ls;
+  }
+  float m = 1.f;
+  if (free_bits >= 0.f) {
+    float thr = free_bits * (float)D;
+    if (!(acc > thr)) { acc = thr; m = 0.f; }
+  }
+  kl[b] = acc;
+  fbmask[b] = m;
+}
+
+__global__ __launch_bounds__(256) void latent_bwd_kernel(const float* p, const float* eps,
+                                                         const float* z, const float* dz,
+                                                         const float* fbmask, const float* klw,
+                                                         const float* dloc_x,
+                                                         const float* dscale_x, float* dp, int B,
+                                                         int D, int analytic) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * D) return;
+  int b = i / D, d = i - b * D;
+  const float* pb = p + (size_t)b * 2 * D;
+  float loc = pb[d], raw = pb[D + d], sc = softplus_f(raw), e = eps[i], zz = z[i];
+  float w = klw[0] * fbmask[b];
+  float dloc, dsc;
+  if (analytic) { dloc = w * loc; dsc = w * (sc - 1.f / sc); }
+  else { dloc = w * zz; dsc = w * (zz * e - 1.f / sc); }
+  if (dz != nullptr) { float g = dz[i]; dloc += g; dsc += g * e; }
+  if (dloc_x != nullptr) dloc += dloc_x[i];
+  if (dscale_x != nullptr) dsc += dscale_x[i];
+  dp[(size_t)b * 2 * D + d] = dloc;
+  dp[(size_t)b * 2 * D + D + d] = dsc * sigmoid_f(raw);
+}
+
+// ------------------------------------------------------------------ ELBO ------------
+constexpr int ELBO_CHUNK = 1024;  // elements per workgroup (256 threads x float4)
+
+__global__ __launch_bounds__(256) void elbo_bernoulli_kernel(const float* __restrict__ logits,
+                                                             const float* __restrict__ x,
+                                                             float* __restrict__ llk_part,
+                                                             float* __restrict__ dlogits,
+                                                             const float* __restrict__ scale,
+                                                             int N, int n_part, int vec) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / n_part, part = blockIdx.x - b * n_part;
+  const size_t base = (size_t)b * N;
+  const int i0 = part * ELBO_CHUNK + threadIdx.x * 4;
+  const float sc = scale[0];
+  float acc = 0.f;
+  if (vec && i0 + 3 < N) {
+    float4 l = *reinterpret_cast<const float4*>(logits + base + i0);
+    float4 t = *reinterpret_cast<const float4*>(x + base + i0);
+    float4 g;
+    acc += t.x * l.x - softplus_f(l.x); g.x = (sigmoid_f(l.x) - t.x) * sc;
+    acc += t.y * l.y - softplus_f(l.y); g.y = (sigmoid_f(l.y) - t.y) * sc;
+    acc += t.z * l.z - softplus_f(l.z); g.z = (sigmoid_f(l.z) - t.z) * sc;
+    acc += t.w * l.w - softplus_f(l.w); g.w = (sigmoid_f(l.w) - t.w) * sc;
+    *reinterpret_cast<float4*>(dlogits + base + i0) = g;
+  } else {
+    for (int j = 0; j < 4; ++j) {
+      int i = i0 + j;
+      if (i < N) {
+        float l = logits[base + i], t = x[base + i];
+        acc += t * l - softplus_f(l);
+        dlogits[base + i] = (sigmoid_f(l) - t) * sc;
+      }
+    }
+  }
+  float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) llk_part[blockIdx.x] = s;
+}
+
+// h [B, n_pix, 2C] (loc | raw scale), x [B, n_pix, C]; N = n_pix*C elements per sample
+__global__ __launch_bounds__(256) void elbo_gaussian_kernel(const float* __restrict__ h,
+                                                            const float* __restrict__ x,
+                                                            float* __restrict__ llk_part,
+                                                            float* __restrict__ dh,
+                                                            const float* __restrict__ scale,
+                                                            int N, int C, int n_part,
+                                                            int softplus1) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / n_part, part = blockIdx.x - b * n_part;
+  const float sc = scale[0];
+  float acc = 0.f;
+  for (int j = 0; j < 4; ++j) {
+    int i = part * ELBO_CHUNK + j * 256 + threadIdx.x;
+    if (i < N) {
+      int pix = i / C, c = i - pix * C;
+      size_t hb = ((size_t)b * (N / C) + pix) * 2 * C;
+      float loc = h[hb + c], raw = h[hb + C + c], t = x[(size_t)b * N + i];
+      float sd, dsd;
+      if (softplus1) { sd = softplus_f(raw + SOFTPLUS_INV1); dsd = sigmoid_f(raw + SOFTPLUS_INV1); }
+      else { sd = raw; dsd = 1.f; }
+      float d = (t - loc) / sd;
+      acc += -0.5f * d * d - odin_log(sd) - 0.5f * LOG2PI_F;
+      dh[hb + c] = -(d / sd) * sc;
+      dh[hb + C + c] = -((d * d - 1.f) / sd) * dsd * sc;
+    }
+  }
+  float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) llk_part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void elbo_finalize_kernel(const float* llk_part, int n_part,
+                                                            const float* kl, const float* hyper,
+                                                            float* llk, float* out4, int B) {
+  __shared__ float red[4];
+  float sl = 0.f, sk = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float t = 0.f;
+    for (int j = 0; j < n_part; ++j) t += llk_part[(size_t)b * n_part + j];
+    llk[b] = t;
+    sl += t;
+    sk += kl[b];
+  }
+  float tl = block_sum_256(sl, red);
+  __syncthreads();
+  float tk = block_sum_256(sk, red);
+  if (threadIdx.x == 0) {
+    float beta = hyper[0], tc = hyper[1];
+    float ml = tl / (float)B, mk = beta * tk / (float)B;
+    out4[0] = -(ml - mk - tc);
+    out4[1] = ml;
+    out4[2] = mk;
+    out4[3] = tc;
+  }
+}
+
+// ------------------------------------------------------------------ Adam ------------
+__device__ __forceinline__ float adam1(float& th, float g, float& m, float& v, float a, float b1,
+                                       float b2, float eps) {
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  th = th - a * m / (sqrtf(v) + eps);
+  return th;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta,
+                                                   const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   size_t n, const float* __restrict__ hyper,
+                                                   const float* __restrict__ gnorm2, float clip,
+                                                   int* flag) {
+  const float a = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
+  float gs = hyper[4];
+  if (gnorm2 != nullptr) {
+    float n2 = gnorm2[0];
+    if (!(n2 == n2) || n2 > 3.0e38f) {  // NaN / Inf gradients: skip the update
+      if (flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) flag[0] = 1;
+      return;
+    }
+    if (clip > 0.f) gs *= clip / fmaxf(sqrtf(n2), clip);
+  }
+  const size_t n4 = n >> 2;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 t = reinterpret_cast<float4*>(theta)[i];
+    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    adam1(t.x, gg.x * gs, mm.x, vv.x, a, b1, b2, eps);
+    adam1(t.y, gg.y * gs, mm.y, vv.y, a, b1, b2, eps);
+    adam1(t.z, gg.z * gs, mm.z, vv.z, a, b1, b2, eps);
+    adam1(t.w, gg.w * gs, mm.w, vv.w, a, b1, b2, eps);
+    reinterpret_cast<float4*>(theta)[i] = t;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    size_t i = (n4 << 2) + threadIdx.x;
+    float t = theta[i], mm = m[i], vv = v[i];
+    adam1(t, g[i] * gs, mm, vv, a, b1, b2, eps);
+    theta[i] = t; m[i] = mm; v[i] = vv;
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ g, size_t n,
+                                                    float* __restrict__ part) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 t = reinterpret_cast<const float4*>(g)[i];
+    acc += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    float t = g[(n4 << 2) + threadIdx.x];
+    acc += t * t;
+  }
+  float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void sum_stage2(const float* part, int n, float* out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+  float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+// ------------------------------------------------------------------ RNG -------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                              unsigned k0, unsigned k1, unsigned out[4]) {
+  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    unsigned hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    unsigned hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void rng_normal_kernel(float* out, size_t n, unsigned k0,
+                                                         unsigned k1, const int* step_dev) {
+  const unsigned step = step_dev ? (unsigned)step_dev[0] : 0u;
+  const size_t n4 = (n + 3) >> 2, stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    unsigned r[4];
+    philox4x32_10((unsigned)i, (unsigned)(i >> 32), step, 0u, k0, k1, r);
+    float u0 = ((float)(r[0] >> 8) + 0.5f) * (1.f / 16777216.f);
+    float u1 = ((float)(r[1] >> 8) + 0.5f) * (1.f / 16777216.f);
+    float u2 = ((float)(r[2] >> 8) + 0.5f) * (1.f / 16777216.f);
+    float u3 = ((float)(r[3] >> 8) + 0.5f) * (1.f / 16777216.f);
+    float ra = sqrtf(-2.f * odin_log(u0)), rb = sqrtf(-2.f * odin_log(u2));
+    float v[4];
+    v[0] = ra * cosf(6.2831853071795865f * u1);
+    v[1] = ra * sinf(6.2831853071795865f * u1);
+    v[2] = rb * cosf(6.2831853071795865f * u3);
+    v[3] = rb * sinf(6.2831853071795865f * u3);
+    for (int j = 0; j < 4; ++j)
+      if (i * 4 + j < n) out[i * 4 + j] = v[j];
+  }
+}
+
+inline int grid_for(size_t work_items, int per_block, int cap) {
+  size_t g = (work_items + per_block - 1) / per_block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int odin_latent_fwd(const float* p, const float* eps, float* z, float* kl,
+                               float* fbmask, int B, int D, int analytic, float free_bits,
+                               void* stream) {
+  ODIN_LAUNCH(latent_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, p, eps, z, kl,
+              fbmask, B, D, analytic, free_bits);
+  return odin_check_launch("latent_fwd");
+}
+
+extern "C" int odin_latent_bwd(const float* p, const float* eps, const float* z, const float* dz,
+                               const float* fbmask, const float* klw, const float* dloc_x,
+                               const float* dscale_x, float* dp, int B, int D, int analytic,
+                               void* stream) {
+  ODIN_LAUNCH(latent_bwd_kernel, dim3((B * D + 255) / 256), dim3(256), 0, stream, p, eps, z, dz,
+              fbmask, klw, dloc_x, dscale_x, dp, B, D, analytic);
+  return odin_check_launch("latent_bwd");
+}
+
+extern "C" int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, float* llk_part,
+                                           float* dlogits, const float* scale, int B,
+                                           int n_per_sample, int* n_part_out, void* stream) {
+  int n_part = (n_per_sample + ELBO_CHUNK - 1) / ELBO_CHUNK;
+  if (n_part_out) *n_part_out = n_part;
+  int vec = (n_per_sample % 4 == 0) ? 1 : 0;
+  ODIN_LAUNCH(elbo_bernoulli_kernel, dim3(B * n_part), dim3(256), 0, stream, logits, x, llk_part,
+              dlogits, scale, n_per_sample, n_part, vec);
+  return odin_check_launch("elbo_bernoulli");
+}
+
+extern "C" int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float* llk_part,
+                                          float* dh, const float* scale, int B, int n_pix, int C,
+                                          int softplus1, int* n_part_out, void* stream) {
+  int N = n_pix * C;
+  int n_part = (N + ELBO_CHUNK - 1) / ELBO_CHUNK;
+  if (n_part_out) *n_part_out = n_part;
+  ODIN_LAUNCH(elbo_gaussian_kernel, dim3(B * n_part), dim3(256), 0, stream, h, x, llk_part, dh,
+              scale, N, C, n_part, softplus1);
+  return odin_check_launch("elbo_gaussian");
+}
+
+extern "C" int odin_elbo_finalize(const float* llk_part, int n_part, const float* kl,
+                                  const float* hyper, float* llk, float* out4, int B,
+                                  void* stream) {
+  ODIN_LAUNCH(elbo_finalize_kernel, dim3(1), dim3(256), 0, stream, llk_part, n_part, kl, hyper,
+              llk, out4, B);
+  return odin_check_launch("elbo_finalize");
+}
+
+extern "C" int odin_adam_step_flat(float* theta, const float* g, float* m, float* v, size_t n,
+                                   const float* hyper, const float* gnorm2, float clip,
+                                   int32_t* flag, void* stream) {
+  int grid = grid_for(n / 4 + 1, 256, 2048);
+  ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper, gnorm2,
+              clip, (int*)flag);
+  return odin_check_launch("adam");
+}
+
+extern "C" int odin_sumsq_flat(const float* g, size_t n, float* workspace, float* out,
+                               void* stream) {
+  int grid = grid_for(n / 4 + 1, 256, 1024);
+  ODIN_LAUNCH(sumsq_stage1, dim3(grid), dim3(256), 0, stream, g, n, workspace);
+  ODIN_LAUNCH(sum_stage2, dim3(1), dim3(256), 0, stream, (const float*)workspace, grid, out);
+  return odin_check_launch("sumsq");
+}
+
+extern "C" int odin_rng_normal(float* out, size_t n, uint64_t seed, const int32_t* step_dev,
+                               void* stream) {
+  int grid = grid_for((n + 3) / 4, 256, 2048);
+  ODIN_LAUNCH(rng_normal_kernel, dim3(grid), dim3(256), 0, stream, out, n, (unsigned)seed,
+              (unsigned)(seed >> 32), (const int*)step_dev);
+  return odin_check_launch("rng_normal");
+}

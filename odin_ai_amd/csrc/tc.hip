@@ -1,0 +1,247 @@
+// tc.hip -- batch-coupled regularisers: beta-TCVAE total correlation (forward+backward,
+// the [B,B,D] tensor lives only in LDS, one row at a time), FactorVAE permute_dims and the
+// discriminator's dtc_loss.
+//   total_correlation : odin/bay/vi/losses.py:101-157 (used by beta_vae.py:123-129)
+//   permute_dims      : odin/bay/vi/utils.py:233-269
+//   dtc_loss          : odin/bay/vi/autoencoder/factor_discriminator.py:200-235
+#include "odin_device.h"
+#include "odin_internal.h"
+
+namespace {
+
+constexpr float LOG2PI_F = 1.8378770664093453f;
+
+__device__ __forceinline__ float softplus_t(float x) {
+  return fmaxf(x, 0.f) + log1pf(odin_exp(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoid_t(float x) {
+  float e = odin_exp(-fabsf(x));
+  float s = 1.f / (1.f + e);
+  return x >= 0.f ? s : e * s;
+}
+__device__ __forceinline__ float wave_max64(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+// One workgroup per sample j.  LDS: lp[B][D] (log q(z_j | x_i) per latent), S[B].
+// Outputs: logqz[j], L[j][l] (log-sum-exp over i per latent), tc_part[j], dz[j][l].
+__global__ __launch_bounds__(256) void tc_rows_kernel(const float* z, const float* p,
+                                                      float* logqz, float* Lout, float* tc_part,
+                                                      float* dz, const float* coef, int B, int D) {
+  ODIN_DYN_SMEM(float, smem);
+  float* lp = smem;                 // [B][D]
+  float* S = smem + (size_t)B * D;  // [B]
+  float* Ll = S + B;                // [D]
+  float* misc = Ll + D;             // [8]
+  const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < B; i += 256) {
+    float s = 0.f;
+    for (int l = 0; l < D; ++l) {
+      float mu = p[(size_t)i * 2 * D + l], sg = softplus_t(p[(size_t)i * 2 * D + D + l]);
+      float d = (z[(size_t)j * D + l] - mu) / sg;
+      float v = -0.5f * d * d - odin_log(sg) - 0.5f * LOG2PI_F;
+      lp[(size_t)i * D + l] = v;
+      s += v;
+    }
+    S[i] = s;
+  }
+  __syncthreads();
+  // per-latent log-sum-exp over i: wave w handles l = w, w+4, ...; index D = the joint S
+  for (int l = wave; l <= D; l += 4) {
+    float mx = -3.0e38f;
+    for (int i = lane; i < B; i += 64) mx = fmaxf(mx, l < D ? lp[(size_t)i * D + l] : S[i]);
+    mx = wave_max64(mx);
+    float sm = 0.f;
+    for (int i = lane; i < B; i += 64) sm += odin_exp((l < D ? lp[(size_t)i * D + l] : S[i]) - mx);
+    sm = wave_sum64(sm);
+    if (lane == 0) {
+      float lse = mx + odin_log(sm);
+      if (l < D) Ll[l] = lse; else misc[0] = lse;
+    }
+  }
+  __syncthreads();
+  const float lq = misc[0];
+  if (tid == 0) {
+    float t = 0.f;
+    for (int l = 0; l < D; ++l) t += Ll[l];
+    tc_part[j] = lq - t;
+    logqz[j] = lq;
+  }
+  for (int l = tid; l < D; l += 256) Lout[(size_t)j * D + l] = Ll[l];
+  // dz[j,l] = coef/B * sum_i (wj[i] - wl[i,l]) * (-(z_j - mu_i)/sg_i^2)
+  const float cf = coef[0] / (float)B;
+  for (int l = wave; l < D; l += 4) {
+    float acc = 0.f;
+    const float zz = z[(size_t)j * D + l];
+    for (int i = lane; i < B; i += 64) {
+      float mu = p[(size_t)i * 2 * D + l], sg = softplus_t(p[(size_t)i * 2 * D + D + l]);
+      float g = odin_exp(S[i] - lq) - odin_exp(lp[(size_t)i * D + l] - Ll[l]);
+      acc += g * (-(zz - mu) / (sg * sg));
+    }
+    acc = wave_sum64(acc);
+    if (lane == 0) dz[(size_t)j * D + l] = cf * acc;
+  }
+}
+
+// One workgroup per sample i (posterior owner): sums over j.
+__global__ __launch_bounds__(256) void tc_cols_kernel(const float* z, const float* p,
+                                                      const float* logqz, const float* Lin,
+                                                      float* dloc, float* dscale,
+                                                      const float* coef, int B, int D) {
+  __shared__ float red[8];
+  constexpr int MAXJ = 16;  // B <= 4096
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float Sj[MAXJ];
+#pragma unroll
+  for (int q = 0; q < MAXJ; ++q) {
+    int j = tid + q * 256;
+    float s = 0.f;
+    if (j < B) {
+      for (int l = 0; l < D; ++l) {
+        float mu = p[(size_t)i * 2 * D + l], sg = softplus_t(p[(size_t)i * 2 * D + D + l]);
+        float d = (z[(size_t)j * D + l] - mu) / sg;
+        s += -0.5f * d * d - odin_log(sg) - 0.5f * LOG2PI_F;
+      }
+      s = odin_exp(s - logqz[j]);
+    }
+    Sj[q] = s;  // = wj[j,i]
+  }
+  const float cf = coef[0] / (float)B;
+  for (int l = 0; l < D; ++l) {
+    float mu = p[(size_t)i * 2 * D + l], sg = softplus_t(p[(size_t)i * 2 * D + D + l]);
+    float lsg = odin_log(sg);
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXJ; ++q) {
+      int j = tid + q * 256;
+      if (j < B) {
+        float d = (z[(size_t)j * D + l] - mu) / sg;
+        float v = -0.5f * d * d - lsg - 0.5f * LOG2PI_F;
+        float g = Sj[q] - odin_exp(v - Lin[(size_t)j * D + l]);
+        a1 += g * d / sg;
+        a2 += g * (d * d - 1.f) / sg;
+      }
+    }
+    a1 = wave_sum64(a1);
+    a2 = wave_sum64(a2);
+    __syncthreads();
+    if (lane == 0) { red[wave] = a1; red[4 + wave] = a2; }
+    __syncthreads();
+    if (tid == 0) {
+      dloc[(size_t)i * D + l] = cf * ((red[0] + red[1]) + (red[2] + red[3]));
+      dscale[(size_t)i * D + l] = cf * ((red[4] + red[5]) + (red[6] + red[7]));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const float* part, int n, float* out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+  acc = wave_sum64(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+}
+
+__global__ __launch_bounds__(256) void permute_kernel(const float* z, const int* perm, float* out,
+                                                      int B, int D) {
+  int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * D) return;
+  int l = e % D;
+  out[e] = z[(size_t)perm[e] * D + l];
+}
+
+__device__ __forceinline__ unsigned hash3(unsigned a, unsigned b, unsigned c) {
+  unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x165667B1u) * 0xC2B2AE3Du;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+
+// one workgroup per latent column: random keys -> rank -> permutation (B <= 4096)
+__global__ __launch_bounds__(256) void random_perm_kernel(int* perm, int B, int D, unsigned k0,
+                                                          unsigned k1, const int* step_dev) {
+  ODIN_DYN_SMEM(unsigned, keys);
+  const int l = blockIdx.x;
+  const unsigned step = step_dev ? (unsigned)step_dev[0] : 0u;
+  for (int i = threadIdx.x; i < B; i += 256)
+    keys[i] = hash3(hash3(k0, k1, step), (unsigned)l, (unsigned)i);
+  __syncthreads();
+  for (int i = threadIdx.x; i < B; i += 256) {
+    unsigned k = keys[i];
+    int rank = 0;
+    for (int j = 0; j < B; ++j) {
+      unsigned kj = keys[j];
+      rank += (kj < k || (kj == k && j < i)) ? 1 : 0;
+    }
+    perm[(size_t)rank * D + l] = i;
+  }
+}
+
+__global__ __launch_bounds__(256) void dtc_loss_kernel(const float* lz, const float* lp, float* out,
+                                                       float* dlz, float* dlp, int n) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float inv = 0.5f / (float)n;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float a = lz[i], b = lp[i];
+    acc += softplus_t(-a) + softplus_t(b);
+    dlz[i] = -sigmoid_t(-a) * inv;
+    dlp[i] = sigmoid_t(b) * inv;
+  }
+  acc = wave_sum64(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv;
+}
+
+}  // namespace
+
+// workspace layout inside tc_out: [0]=TC, then logqz[B], L[B*D], tc_part[B]  (B*(D+2)+1 floats)
+extern "C" int odin_total_correlation_fwd_bwd(const float* z, const float* p, float* tc_out,
+                                              float* dz, float* dloc, float* dscale,
+                                              const float* coef, int B, int D, void* stream) {
+  size_t lds = ((size_t)B * D + B + D + 8) * 4;
+  if (lds > 158 * 1024) return odin_fail(-2, "total_correlation: B*D too large for LDS");
+  if (B > 4096) return odin_fail(-2, "total_correlation: B > 4096");
+  float* logqz = tc_out + 1;
+  float* L = logqz + B;
+  float* part = L + (size_t)B * D;
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&tc_rows_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+#endif
+  ODIN_LAUNCH(tc_rows_kernel, dim3(B), dim3(256), lds, stream, z, p, logqz, L, part, dz, coef, B, D);
+  ODIN_LAUNCH(tc_cols_kernel, dim3(B), dim3(256), 0, stream, z, p, (const float*)logqz,
+              (const float*)L, dloc, dscale, coef, B, D);
+  ODIN_LAUNCH(mean_kernel, dim3(1), dim3(256), 0, stream, (const float*)part, B, tc_out);
+  return odin_check_launch("total_correlation");
+}
+
+extern "C" int odin_permute_dims(const float* z, const int32_t* perm, float* out, int B, int D,
+                                 void* stream) {
+  ODIN_LAUNCH(permute_kernel, dim3((B * D + 255) / 256), dim3(256), 0, stream, z, (const int*)perm,
+              out, B, D);
+  return odin_check_launch("permute_dims");
+}
+
+extern "C" int odin_random_perm(int32_t* perm, int B, int D, uint64_t seed,
+                                const int32_t* step_dev, void* stream) {
+  if (B > 16384) return odin_fail(-2, "random_perm: B too large");
+  ODIN_LAUNCH(random_perm_kernel, dim3(D), dim3(256), (size_t)B * 4, stream, (int*)perm, B, D,
+              (unsigned)seed, (unsigned)(seed >> 32), (const int*)step_dev);
+  return odin_check_launch("random_perm");
+}
+
+extern "C" int odin_dtc_loss_fwd_bwd(const float* logit_z, const float* logit_perm, float* out,
+                                     float* dlogit_z, float* dlogit_perm, int n, void* stream) {
+  ODIN_LAUNCH(dtc_loss_kernel, dim3(1), dim3(256), 0, stream, logit_z, logit_perm, out, dlogit_z,
+              dlogit_perm, n);
+  return odin_check_launch("dtc_loss");
+}

@@ -1,0 +1,363 @@
+// wgrad.hip -- weight / bias gradients of Conv2D, Conv2DTranspose and Dense on the f32
+// matrix cores, plus the deterministic slab reduction that finishes them.
+//
+//   dW[kh,kw,ci,co] = sum_{b,oh,ow} IN[b, oh*S-pt+kh, ow*S-pl+kw, ci] * DY[b,oh,ow,co]
+//
+// Conv2D:           IN = layer input x,            DY = dL/d(pre-activation output)
+// Conv2DTranspose:  IN = dL/d(pre-act output) (the LARGE image), DY = layer input x, which
+//                   yields dW directly in Keras' (kh,kw,Cout,Cin) layout
+// Dense:            1x1 images, batch as the image index.
+// Replaces tape.gradient(loss, parameters) (odin/networks/base_networks.py:518) for the
+// kernels created at odin/networks/image_networks.py:166-173 and base_networks.py:1002-1014.
+//
+// MI355X mapping: the reduction dimension of the MFMA is the PIXEL index.  A workgroup
+// stages the IN patch (F-mode geometry, with halo) and the matching DY rows of ~128
+// pixels into LDS, and each wave keeps up to 8 32x32 accumulator tiles of dW
+// (rows = (tap,ci), columns = co) resident in registers across its whole persistent
+// pixel-tile loop; v_mfma_f32_32x32x2_f32 consumes two pixels per instruction.  The bias
+// gradient rides along as one more accumulator whose A operand is the constant 1.
+// Partial results go to a per-workgroup slab; odin_slab_reduce sums the slabs in a fixed
+// order (bit-reproducible, no float atomics).
+#include "odin_device.h"
+#include "odin_internal.h"
+
+namespace {
+
+constexpr int NW_W = 4;
+constexpr int NACC = 8;
+
+struct WParams {
+  const float* in;
+  const float* dy;
+  float* slab;
+  int B, H, W, CI, OH, OW, CO;
+  int KH, KW, S, pt, pl, center;
+  int TR, RPI, NIMG, n_tiles, NRI, PW, P;
+  int CIB, COB, DP, slots;
+  int nrt, ncot, want_bias;
+  int slab_stride;
+  int patch_floats, dy_floats;
+};
+
+__device__ __forceinline__ void w_stage_patch(const WParams& p, float* patch, int b0, int ih_lo,
+                                              int c0, int cib, int tid, int nthreads) {
+  const bool vec = ((p.CI & 3) == 0) && ((p.P & 3) == 0) && ((c0 & 3) == 0) && ((cib & 3) == 0);
+  if (vec) {
+    const int c4n = p.P >> 2;
+    const int total = p.NIMG * p.NRI * p.PW * c4n;
+    for (int e = tid; e < total; e += nthreads) {
+      int c4 = e % c4n, q = e / c4n;
+      int pcol = q % p.PW, q2 = q / p.PW;
+      int prow = q2 % p.NRI, img = q2 / p.NRI;
+      int b = b0 + img, ih = ih_lo + prow, iw = pcol - p.pl, cl = c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < p.B && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && cl < cib) {
+        v = *reinterpret_cast<const float4*>(p.in + (((size_t)b * p.H + ih) * p.W + iw) * p.CI + c0 + cl);
+        if (p.center) {
+          v.x = 2.f * v.x - 1.f; v.y = 2.f * v.y - 1.f;
+          v.z = 2.f * v.z - 1.f; v.w = 2.f * v.w - 1.f;
+        }
+      }
+      *reinterpret_cast<float4*>(patch + ((img * p.NRI + prow) * p.PW + pcol) * p.P + cl) = v;
+    }
+  } else {
+    const int total = p.NIMG * p.NRI * p.PW * p.P;
+    for (int e = tid; e < total; e += nthreads) {
+      int cl = e % p.P, q = e / p.P;
+      int pcol = q % p.PW, q2 = q / p.PW;
+      int prow = q2 % p.NRI, img = q2 / p.NRI;
+      int b = b0 + img, ih = ih_lo + prow, iw = pcol - p.pl;
+      float v = 0.f;
+      if (b < p.B && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && cl < cib) {
+        v = p.in[(((size_t)b * p.H + ih) * p.W + iw) * p.CI + c0 + cl];
+        if (p.center) v = 2.f * v - 1.f;
+      }
+      patch[e] = v;
+    }
+  }
+}
+
+__device__ __forceinline__ void w_stage_dy(const WParams& p, float* dyl, int gr0, int co0,
+                                           int tid, int nthreads) {
+  const long total_pix = (long)p.B * p.OH * p.OW;
+  const long pix0 = (long)gr0 * p.OW;
+  const int real_slots = p.TR * p.OW;
+  const bool vec = ((p.CO & 3) == 0) && ((p.COB & 3) == 0);
+  if (vec) {
+    const int c4n = p.COB >> 2;
+    const int total = p.slots * c4n;
+    for (int e = tid; e < total; e += nthreads) {
+      int c4 = e % c4n, s = e / c4n;
+      int co = co0 + c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (s < real_slots && pix0 + s < total_pix && co < p.CO)
+        v = *reinterpret_cast<const float4*>(p.dy + (size_t)(pix0 + s) * p.CO + co);
+      *reinterpret_cast<float4*>(dyl + s * p.DP + c4 * 4) = v;
+    }
+  } else {
+    const int total = p.slots * p.COB;
+    for (int e = tid; e < total; e += nthreads) {
+      int cl = e % p.COB, s = e / p.COB;
+      int co = co0 + cl;
+      float v = 0.f;
+      if (s < real_slots && pix0 + s < total_pix && co < p.CO) v = p.dy[(size_t)(pix0 + s) * p.CO + co];
+      dyl[s * p.DP + cl] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
+  ODIN_DYN_SMEM(float, smem);
+  float* patch = smem;
+  float* dyl = smem + p.patch_floats;
+  int* tbl = reinterpret_cast<int*>(smem + p.patch_floats + p.dy_floats);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  constexpr int NT = NW_W * 64;
+  const int ci0 = blockIdx.y * p.CIB, co0 = blockIdx.z * p.COB;
+  const int cib = (p.CI - ci0) < p.CIB ? (p.CI - ci0) : p.CIB;
+  const int ntaps = p.KH * p.KW;
+  const int nrows = ntaps * cib;
+  const int n_wt = p.nrt * p.ncot;
+  const int n_bias = (p.want_bias && blockIdx.y == 0) ? p.ncot : 0;
+  const int n_tot = n_wt + n_bias;
+
+  // slot -> patch base table (identical for every tile of this launch)
+  for (int s = tid; s < p.slots; s += NT) {
+    int r = s / p.OW, c = s - r * p.OW;
+    int img = r / p.RPI, rl = r - img * p.RPI;
+    tbl[s] = (r < p.TR) ? ((img * p.NRI + rl * p.S) * p.PW + c * p.S) * p.P : 0;
+  }
+
+  // per-accumulator lane constants
+  int a_off[NACC], b_off[NACC], a_kind[NACC];  // kind 0: zero row, 1: patch, 2: ones (bias)
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    int T = wave + a * NW_W;
+    a_off[a] = 0;
+    b_off[a] = l31;
+    a_kind[a] = 0;
+    if (T < n_wt) {
+      int rt = T / p.ncot, cot = T - rt * p.ncot;
+      int rl = rt * 32 + l31;
+      b_off[a] = cot * 32 + l31;
+      if (rl < nrows) {
+        int tap = rl / cib, cl = rl - tap * cib;
+        int kh = tap / p.KW, kw = tap - kh * p.KW;
+        a_off[a] = (kh * p.PW + kw) * p.P + cl;
+        a_kind[a] = 1;
+      }
+    } else if (T < n_tot) {
+      b_off[a] = (T - n_wt) * 32 + l31;
+      a_kind[a] = 2;
+    }
+  }
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) acc[a] = f32x16_zero();
+
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const int gr0 = tile * p.TR;
+    const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
+    const int ih_lo = oh0 * p.S - p.pt;
+    __syncthreads();
+    w_stage_patch(p, patch, b0, ih_lo, ci0, cib, tid, NT);
+    w_stage_dy(p, dyl, gr0, co0, tid, NT);
+    __syncthreads();
+    const int npairs = p.slots >> 1;
+    for (int kp = 0; kp < npairs; ++kp) {
+      const int s = 2 * kp + h;
+      const int base = tbl[s];
+      const float* brow = dyl + s * p.DP;
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        if (wave + a * NW_W < n_tot) {  // wave-uniform
+          float av = patch[base + a_off[a]];
+          av = (a_kind[a] == 1) ? av : (a_kind[a] == 2 ? 1.f : 0.f);
+          acc[a] = mfma32(av, brow[b_off[a]], acc[a]);
+        }
+      }
+    }
+  }
+
+  // ---- write this workgroup's partial tiles into its slab row ----
+  float* row = p.slab + (size_t)blockIdx.x * p.slab_stride;
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    int T = wave + a * NW_W;
+    if (T < n_wt) {
+      int rt = T / p.ncot, cot = T - rt * p.ncot;
+      int co = co0 + cot * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int rl = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (rl < nrows && co < p.CO && cot * 32 + l31 < p.COB) {
+          int tap = rl / cib, cl = rl - tap * cib;
+          row[((size_t)tap * p.CI + ci0 + cl) * p.CO + co] = acc[a][r];
+        }
+      }
+    } else if (T < n_tot) {
+      int cot = T - n_wt;
+      int co = co0 + cot * 32 + l31;
+      if (h == 0 && co < p.CO && cot * 32 + l31 < p.COB)
+        row[(size_t)ntaps * p.CI * p.CO + co] = acc[a][0];
+    }
+  }
+}
+
+bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
+  const int S = p.S;
+  const int img_pix = p.OH * p.OW;
+  const int TARGET = 128;
+  if (img_pix <= TARGET) {
+    p.NIMG = TARGET / img_pix;
+    if (p.NIMG > p.B) p.NIMG = p.B;
+    if (p.NIMG < 1) p.NIMG = 1;
+    p.RPI = p.OH;
+    p.TR = p.NIMG * p.OH;
+  } else {
+    p.NIMG = 1;
+    int pick = 0;
+    for (int tr = 1; tr <= p.OH; ++tr)
+      if (p.OH % tr == 0 && tr * p.OW <= TARGET) pick = tr;
+    if (pick == 0) pick = 1;
+    p.TR = p.RPI = pick;
+  }
+  p.n_tiles = (p.B * p.OH + p.TR - 1) / p.TR;
+  p.NRI = (p.RPI - 1) * S + p.KH;
+  p.PW = (p.OW - 1) * S + p.KW;
+  p.slots = (p.TR * p.OW + 1) & ~1;
+  const int ntaps = p.KH * p.KW;
+  const int budget = (160 * 1024 - 2048) / 4;
+  const int co32 = (p.CO + 31) / 32 * 32;
+  int cob_c[2] = {co32 < 64 ? co32 : 64, 32};
+  int cib_c[6] = {p.CI, 256, 128, 64, 32, 16};
+  for (int ic = 0; ic < 2; ++ic) {
+    int COB = cob_c[ic];
+    if (COB > co32) continue;
+    int ncot = COB / 32;
+    for (int jc = 0; jc < 6; ++jc) {
+      int CIB = cib_c[jc];
+      if (CIB > p.CI) continue;
+      if (jc > 0 && CIB == p.CI) continue;
+      int nrt = (ntaps * CIB + 31) / 32;
+      if (nrt * ncot + ncot > NACC * NW_W) continue;
+      int P = CIB;
+      if ((p.CI & 3) == 0 && (CIB & 3) != 0) continue;
+      long pf = ((long)p.NIMG * p.NRI * p.PW * P + 3) & ~3L;
+      int DP = COB + 4;
+      long df = (long)p.slots * DP;
+      if (pf + df + p.slots + 16 > budget) continue;
+      p.CIB = CIB; p.COB = COB; p.P = P; p.DP = DP;
+      p.nrt = nrt; p.ncot = ncot;
+      p.patch_floats = (int)pf;
+      p.dy_floats = (int)df;
+      *lds_bytes = (size_t)(pf + df + p.slots + 16) * 4;
+      int g = p.n_tiles < ODIN_MAX_SLAB_BLOCKS ? p.n_tiles : ODIN_MAX_SLAB_BLOCKS;
+      *gx = g < 1 ? 1 : g;
+      *gy = (p.CI + CIB - 1) / CIB;
+      *gz = (p.CO + COB - 1) / COB;
+      return true;
+    }
+  }
+  return false;
+}
+
+int launch_wgrad(WParams& p, int* rows_out, void* stream) {
+  int gx, gy, gz;
+  size_t lds;
+  p.slab_stride = p.KH * p.KW * p.CI * p.CO + (p.want_bias ? p.CO : 0);
+  if (!plan_wgrad(p, &gx, &gy, &gz, &lds)) return odin_fail(-2, "wgrad: no tiling plan");
+  if (rows_out) *rows_out = gx;
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+#endif
+  dim3 grid(gx, gy, gz), block(NW_W * 64);
+  ODIN_LAUNCH(wgrad_kernel, grid, block, lds, stream, p);
+  return odin_check_launch("wgrad");
+}
+
+constexpr int MAX_JOBS = 64;
+struct ReduceJobs {
+  odin_reduce_job j[MAX_JOBS];
+};
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceJobs jobs) {
+  const odin_reduce_job jb = jobs.j[blockIdx.y];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < jb.n; i += gridDim.x * 256) {
+    const float* s = jb.src + i;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int g = 0;
+    for (; g + 3 < jb.rows; g += 4) {
+      a0 += s[(size_t)g * jb.n];
+      a1 += s[(size_t)(g + 1) * jb.n];
+      a2 += s[(size_t)(g + 2) * jb.n];
+      a3 += s[(size_t)(g + 3) * jb.n];
+    }
+    for (; g < jb.rows; ++g) a0 += s[(size_t)g * jb.n];
+    jb.dst[i] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+}  // namespace
+
+extern "C" int odin_conv2d_wgrad(const float* x, const float* dy, float* slab,
+                                 int* slab_rows_out, const odin_conv_desc* d, void* stream) {
+  WParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = x; p.dy = dy; p.slab = slab;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.CI = d->Cin; p.OH = d->OH; p.OW = d->OW; p.CO = d->Cout;
+  p.KH = d->KH; p.KW = d->KW; p.S = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
+  p.center = d->center; p.want_bias = 1;
+  return launch_wgrad(p, slab_rows_out, stream);
+}
+
+// x = deconv input [B,H,W,Cin], dy = grad wrt deconv pre-activation output [B,OH,OW,Cout]
+extern "C" int odin_deconv2d_wgrad(const float* x, const float* dy, float* slab,
+                                   int* slab_rows_out, const odin_conv_desc* d, void* stream) {
+  WParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = dy; p.dy = x; p.slab = slab;
+  p.B = d->B; p.H = d->OH; p.W = d->OW; p.CI = d->Cout; p.OH = d->H; p.OW = d->W; p.CO = d->Cin;
+  p.KH = d->KH; p.KW = d->KW; p.S = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
+  p.center = 0; p.want_bias = 0;
+  return launch_wgrad(p, slab_rows_out, stream);
+}
+
+extern "C" int odin_dense_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out,
+                                int B, int K, int N, void* stream) {
+  WParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = x; p.dy = dy; p.slab = slab;
+  p.B = B; p.H = 1; p.W = 1; p.CI = K; p.OH = 1; p.OW = 1; p.CO = N;
+  p.KH = p.KW = 1; p.S = 1; p.want_bias = 1;
+  return launch_wgrad(p, slab_rows_out, stream);
+}
+
+extern "C" int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* stream) {
+  if (n_jobs <= 0) return 0;
+  for (int j0 = 0; j0 < n_jobs; j0 += MAX_JOBS) {
+    ReduceJobs rj;
+    memset(&rj, 0, sizeof(rj));
+    int nj = n_jobs - j0 < MAX_JOBS ? n_jobs - j0 : MAX_JOBS;
+    int max_n = 0;
+    for (int j = 0; j < nj; ++j) {
+      rj.j[j] = jobs[j0 + j];
+      if (jobs[j0 + j].n > max_n) max_n = jobs[j0 + j].n;
+    }
+    int gx = (max_n + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, nj, 1), block(256);
+    ODIN_LAUNCH(slab_reduce_kernel, grid, block, 0, stream, rj);
+    int rc = odin_check_launch("slab_reduce");
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -1,0 +1,166 @@
+"""Kernel SOURCES executed by the CPU fiber simulator vs the float64 oracle (no GPU).
+
+These tests debug tiling / indexing of the gfx950 kernels in the build container; the
+real parity tests (`-m gpu`) run the hipcc build on an MI355X.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from odin_ai_amd import _lib
+from oracle import vae_oracle as vo
+from tests.simutil import sim_lib
+
+
+@pytest.fixture(scope='module')
+def L():
+  return sim_lib()
+
+
+def T(a):
+  return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32)
+
+
+def reduce_slab(L, slab, rows, n):
+  out = torch.zeros(n)
+  job = (_lib.ReduceJob * 1)(_lib.ReduceJob(slab.data_ptr(), out.data_ptr(), n, rows))
+  L.odin_slab_reduce(job, 1, None)
+  return out.numpy()
+
+
+def close(a, b, tol=2e-5):
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  err = np.abs(a - b).max()
+  ref = max(1.0, np.abs(b).max())
+  assert err <= tol * ref, (err, ref)
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, K, S, act, center
+    (2, 16, 16, 1, 32, 4, 2, 'elu', True),
+    (3, 8, 8, 32, 32, 4, 2, 'elu', False),
+    (2, 8, 8, 32, 64, 4, 2, 'elu', False),
+    (5, 4, 4, 64, 64, 4, 2, 'linear', False),
+    (2, 8, 8, 64, 64, 4, 1, 'elu', False),
+    (2, 14, 14, 3, 8, 5, 2, 'relu', False),
+    (2, 7, 7, 8, 16, 5, 1, 'elu', False),
+    (2, 16, 16, 32, 3, 1, 1, 'linear', False),
+    (37, 4, 4, 8, 8, 4, 2, 'elu', False),      # several whole images per tile, ragged last tile
+    (1, 8, 8, 160, 40, 4, 2, 'linear', False),  # channel-chunked reduction
+]
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co,K,S,act,center', CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(L, B, H, W, Ci, Co, K, S, act, center):
+  rng = np.random.default_rng(0)
+  x = rng.random((B, H, W, Ci))
+  w = rng.standard_normal((K, K, Ci, Co)) * 0.2
+  b = rng.standard_normal(Co) * 0.1
+  OH, pt, _ = vo.same_pads(H, K, S)
+  OW, pl, _ = vo.same_pads(W, K, S)
+  d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, act, center)
+  xin = 2 * x - 1 if center else x
+  y_ref = vo._ACT[act](vo.conv2d(xin, w, b, S))
+  tx, tw, tb = T(x), T(w), T(b)
+  ty = torch.full((B, OH, OW, Co), float('nan'))
+  L.odin_conv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
+  close(ty.numpy(), y_ref)
+  # backward
+  dy = rng.standard_normal((B, OH, OW, Co))
+  tdy = T(dy)
+  dx_ref, dw_ref, db_ref = vo.conv2d_bwd(xin, w, dy, S)
+  if H % S == 0 and W % S == 0:
+    aux = rng.standard_normal((B, H, W, Ci))
+    taux = T(aux)
+    tdx = torch.full((B, H, W, Ci), float('nan'))
+    rows = C.c_int(0)
+    slab = torch.full((L.odin_max_slab_rows(), Ci), float('nan'))
+    L.odin_conv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, tdx.data_ptr(),
+                        slab.data_ptr(), C.byref(rows), C.byref(d), None)
+    g_ref = dx_ref * vo.elu_grad_from_output(aux.astype(np.float32).astype(np.float64))
+    close(tdx.numpy(), g_ref)
+    close(reduce_slab(L, slab, rows.value, Ci), g_ref.sum((0, 1, 2)), 1e-4)
+  rows = C.c_int(0)
+  n = K * K * Ci * Co + Co
+  slab = torch.full((L.odin_max_slab_rows(), n), float('nan'))
+  L.odin_conv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d),
+                      None)
+  g = reduce_slab(L, slab, rows.value, n)
+  close(g[:-Co].reshape(K, K, Ci, Co), dw_ref, 1e-4)
+  close(g[-Co:], db_ref, 1e-4)
+
+
+DECONV_CASES = [
+    (3, 4, 4, 8, 64, 4, 2, 'elu'),
+    (2, 8, 8, 64, 32, 4, 2, 'elu'),
+    (1, 16, 16, 32, 32, 4, 2, 'linear'),
+    (2, 8, 8, 8, 64, 4, 1, 'elu'),
+    (3, 7, 7, 4, 16, 5, 2, 'elu'),
+]
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co,K,S,act', DECONV_CASES)
+def test_deconv2d_fwd_dgrad_wgrad(L, B, H, W, Ci, Co, K, S, act):
+  rng = np.random.default_rng(1)
+  x = rng.standard_normal((B, H, W, Ci))
+  w = rng.standard_normal((K, K, Co, Ci)) * 0.2
+  b = rng.standard_normal(Co) * 0.1
+  OH, OW = H * S, W * S
+  _, pt, _ = vo.same_pads(OH, K, S)
+  _, pl, _ = vo.same_pads(OW, K, S)
+  d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, act)
+  y_ref = vo._ACT[act](vo.conv2d_transpose(x, w, b, S))
+  tx, tw, tb = T(x), T(w), T(b)
+  ty = torch.full((B, OH, OW, Co), float('nan'))
+  L.odin_deconv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
+  close(ty.numpy(), y_ref)
+  dy = rng.standard_normal((B, OH, OW, Co))
+  tdy = T(dy)
+  dx_ref, dw_ref, db_ref = vo.conv2d_transpose_bwd(x, w, dy, S)
+  aux = rng.standard_normal((B, H, W, Ci))
+  taux = T(aux)
+  tdx = torch.full((B, H, W, Ci), float('nan'))
+  rows = C.c_int(0)
+  slab = torch.full((L.odin_max_slab_rows(), Ci), float('nan'))
+  L.odin_deconv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, tdx.data_ptr(),
+                        slab.data_ptr(), C.byref(rows), C.byref(d), None)
+  g_ref = dx_ref * vo.elu_grad_from_output(aux.astype(np.float32).astype(np.float64))
+  close(tdx.numpy(), g_ref)
+  close(reduce_slab(L, slab, rows.value, Ci), g_ref.sum((0, 1, 2)), 1e-4)
+  n = K * K * Co * Ci
+  slab = torch.full((L.odin_max_slab_rows(), n), float('nan'))
+  L.odin_deconv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows),
+                        C.byref(d), None)
+  close(reduce_slab(L, slab, rows.value, n).reshape(K, K, Co, Ci), dw_ref, 1e-4)
+
+
+@pytest.mark.parametrize('B,K,N,act', [(5, 1024, 128, 'linear'), (130, 10, 128, 'linear'),
+                                       (7, 128, 20, 'linear'), (33, 100, 70, 'relu'),
+                                       (3, 4096, 40, 'linear'), (150, 36, 33, 'relu')])
+def test_dense(L, B, K, N, act):
+  rng = np.random.default_rng(2)
+  x = rng.standard_normal((B, K))
+  w = rng.standard_normal((K, N)) / np.sqrt(K)
+  b = rng.standard_normal(N) * 0.1
+  y_ref = vo._ACT[act](vo.dense(x, w, b))
+  ty = torch.full((B, N), float('nan'))
+  tx, tw, tb = T(x), T(w), T(b)
+  L.odin_dense_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), B, K, N,
+                   _lib.ACT[act], None)
+  close(ty.numpy(), y_ref)
+  dy = rng.standard_normal((B, N))
+  tdy = T(dy)
+  dx_ref, dw_ref, db_ref = vo.dense_bwd(x, w, dy)
+  tdx = torch.full((B, K), float('nan'))
+  L.odin_dense_dgrad(tdy.data_ptr(), tw.data_ptr(), None, 0, tdx.data_ptr(), None, None, B, K, N,
+                     None)
+  close(tdx.numpy(), dx_ref)
+  rows = C.c_int(0)
+  n = K * N + N
+  slab = torch.full((L.odin_max_slab_rows(), n), float('nan'))
+  L.odin_dense_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), B, K, N, None)
+  g = reduce_slab(L, slab, rows.value, n)
+  close(g[:-N].reshape(K, N), dw_ref, 1e-4)
+  close(g[-N:], db_ref, 1e-4)
