@@ -52,7 +52,9 @@ int odin_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
 int odin_conv2d_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
                       float* colsum_slab, int* slab_rows_out, const odin_conv_desc* d,
                       void* stream);
-/* slab[g][kh,kw,Cin,Cout | Cout] partial (dW | db) per workgroup g < *slab_rows_out;
+/* Slab-producing calls: passing the output pointer (dx / slab) as NULL is a DRY RUN that only
+ * reports *slab_rows_out (used to size workspaces).
+ * slab[g][kh,kw,Cin,Cout | Cout] partial (dW | db) per workgroup g < *slab_rows_out;
  * finish with odin_slab_reduce.  x = layer input, dy = grad wrt pre-activation output. */
 int odin_conv2d_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out,
                       const odin_conv_desc* d, void* stream);
@@ -94,12 +96,13 @@ int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* stream);
  * fbmask [B] (1 where the gradient flows). */
 int odin_latent_fwd(const float* p, const float* eps, float* z, float* kl, float* fbmask, int B,
                     int D, int analytic, float free_bits, void* stream);
-/* dp [B,2D] of  L = sum_b klw[0]*kl_b  given dz = dL/dz from the decoder (may be NULL) and
- * optional extra grads (dloc_x, dscale_x: from total correlation).  klw is a DEVICE scalar
+/* dp [B,2D] of  L = sum_b klw[0]*kl_b  given dz (+ dz_extra) = dL/dz from the decoder
+ * / regularisers (may be NULL) and optional extra grads (dloc_x, dscale_x: total correlation).  klw is a DEVICE scalar
  * (= beta / B) so that graph replays see schedule updates. */
 int odin_latent_bwd(const float* p, const float* eps, const float* z, const float* dz,
-                    const float* fbmask, const float* klw, const float* dloc_x,
-                    const float* dscale_x, float* dp, int B, int D, int analytic, void* stream);
+                    const float* dz_extra, const float* fbmask, const float* klw,
+                    const float* dloc_x, const float* dscale_x, float* dp, int B, int D,
+                    int analytic, void* stream);
 
 /* ---- observation log-likelihood fused forward+backward
  * Independent(Bernoulli(logits),3).log_prob(x) (image_networks.py:87-93;
@@ -117,9 +120,13 @@ int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float* llk_part, 
 /* VAEStep.call / VariationalModel.elbo (variational_autoencoder.py:117-126;
  * odin/bay/vi/_base.py:151-194): llk[b] = sum parts; elbo = llk - beta*kl - tc;
  * out[0]=loss=-mean(elbo), out[1]=mean llk, out[2]=mean beta*kl, out[3]=tc term.
- * hyper: DEVICE floats {beta, tc_weighted (added to every sample's kl side)}. */
+ * hyper: DEVICE floats {beta, tc_coef}; tc: optional DEVICE scalar (total correlation or
+ * mean discriminator logit), tc term = tc_coef*tc[0] (beta_vae.py:123-129,
+ * factor_vae.py:211-228). */
 int odin_elbo_finalize(const float* llk_part, int n_part, const float* kl, const float* hyper,
-                       float* llk, float* out4, int B, void* stream);
+                       const float* tc, float* llk, float* out4, int B, void* stream);
+/* out[0] = mean(x[0..n)) (deterministic single-workgroup tree) */
+int odin_mean(const float* x, int n, float* out, void* stream);
 
 /* ---- beta-TCVAE total correlation (odin/bay/vi/losses.py:101-157), never materialising
  * the [B,B,D] tensor.  tc_out[0] = TC; grads scaled by coef[0] (DEVICE scalar (beta-1)). */

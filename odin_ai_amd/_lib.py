@@ -49,10 +49,11 @@ SIGNATURES = {
     'odin_dense_wgrad': [P, P, P, IP, I, I, I, P],
     'odin_slab_reduce': [C.POINTER(ReduceJob), I, P],
     'odin_latent_fwd': [P, P, P, P, P, I, I, I, F, P],
-    'odin_latent_bwd': [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    'odin_latent_bwd': [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     'odin_elbo_bernoulli_fwd_bwd': [P, P, P, P, P, I, I, IP, P],
     'odin_elbo_gaussian_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
-    'odin_elbo_finalize': [P, I, P, P, P, P, I, P],
+    'odin_elbo_finalize': [P, I, P, P, P, P, P, I, P],
+    'odin_mean': [P, I, P, P],
     'odin_total_correlation_fwd_bwd': [P, P, P, P, P, P, P, I, I, P],
     'odin_permute_dims': [P, P, P, I, I, P],
     'odin_random_perm': [P, I, I, C.c_uint64, P, P],

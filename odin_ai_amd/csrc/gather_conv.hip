@@ -388,13 +388,14 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
   size_t lds;
   if (!plan_gather(p, mode, max_blocks, &gx, &lds)) return odin_fail(-2, "gather_conv: no tiling plan");
   if (rows_out) *rows_out = gx;
+  if (p.out == nullptr) return 0;  // dry run: planning only
   dim3 grid(gx, (p.CO + 31) / 32, 1), block(NW_G * 64);
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_kernel<MODE_F, NW_G>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_kernel<MODE_F, NW_G>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_kernel<MODE_T, NW_G>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_kernel<MODE_T, NW_G>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }

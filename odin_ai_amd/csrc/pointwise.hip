@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* p, const f
 
 __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* p, const float* eps,
                                                          const float* z, const float* dz,
+                                                         const float* dz2,
                                                          const float* fbmask, const float* klw,
                                                          const float* dloc_x,
                                                          const float* dscale_x, float* dp, int B,
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* p, const f
   if (analytic) { dloc = w * loc; dsc = w * (sc - 1.f / sc); }
   else { dloc = w * zz; dsc = w * (zz * e - 1.f / sc); }
   if (dz != nullptr) { float g = dz[i]; dloc += g; dsc += g * e; }
+  if (dz2 != nullptr) { float g = dz2[i]; dloc += g; dsc += g * e; }
   if (dloc_x != nullptr) dloc += dloc_x[i];
   if (dscale_x != nullptr) dsc += dscale_x[i];
   dp[(size_t)b * 2 * D + d] = dloc;
@@ -151,7 +153,8 @@ __global__ __launch_bounds__(256) void elbo_gaussian_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void elbo_finalize_kernel(const float* llk_part, int n_part,
                                                             const float* kl, const float* hyper,
-                                                            float* llk, float* out4, int B) {
+                                                            const float* tcp, float* llk,
+                                                            float* out4, int B) {
   __shared__ float red[4];
   float sl = 0.f, sk = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) {
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(const float* llk_par
   __syncthreads();
   float tk = block_sum_256(sk, red);
   if (threadIdx.x == 0) {
-    float beta = hyper[0], tc = hyper[1];
+    float beta = hyper[0], tc = (tcp != nullptr) ? hyper[1] * tcp[0] : 0.f;
     float ml = tl / (float)B, mk = beta * tk / (float)B;
     out4[0] = -(ml - mk - tc);
     out4[1] = ml;
@@ -302,11 +305,11 @@ extern "C" int odin_latent_fwd(const float* p, const float* eps, float* z, float
 }
 
 extern "C" int odin_latent_bwd(const float* p, const float* eps, const float* z, const float* dz,
-                               const float* fbmask, const float* klw, const float* dloc_x,
-                               const float* dscale_x, float* dp, int B, int D, int analytic,
-                               void* stream) {
+                               const float* dz_extra, const float* fbmask, const float* klw,
+                               const float* dloc_x, const float* dscale_x, float* dp, int B,
+                               int D, int analytic, void* stream) {
   ODIN_LAUNCH(latent_bwd_kernel, dim3((B * D + 255) / 256), dim3(256), 0, stream, p, eps, z, dz,
-              fbmask, klw, dloc_x, dscale_x, dp, B, D, analytic);
+              dz_extra, fbmask, klw, dloc_x, dscale_x, dp, B, D, analytic);
   return odin_check_launch("latent_bwd");
 }
 
@@ -333,10 +336,10 @@ extern "C" int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float*
 }
 
 extern "C" int odin_elbo_finalize(const float* llk_part, int n_part, const float* kl,
-                                  const float* hyper, float* llk, float* out4, int B,
-                                  void* stream) {
+                                  const float* hyper, const float* tc, float* llk, float* out4,
+                                  int B, void* stream) {
   ODIN_LAUNCH(elbo_finalize_kernel, dim3(1), dim3(256), 0, stream, llk_part, n_part, kl, hyper,
-              llk, out4, B);
+              tc, llk, out4, B);
   return odin_check_launch("elbo_finalize");
 }
 

@@ -53,7 +53,7 @@ extern "C" int odin_graph_end(void* stream, void** graph_exec_out) {
   if (e != hipSuccess) return odin_fail(-100 - (int)e, hipGetErrorString(e));
   hipGraphExec_t ge = nullptr;
   e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-  hipGraphDestroy(g);
+  (void)hipGraphDestroy(g);
   if (e != hipSuccess) return odin_fail(-100 - (int)e, hipGetErrorString(e));
   *graph_exec_out = (void*)ge;
   return 0;
@@ -63,7 +63,7 @@ extern "C" int odin_graph_launch(void* graph_exec, void* stream) {
   return e == hipSuccess ? 0 : odin_fail(-100 - (int)e, hipGetErrorString(e));
 }
 extern "C" int odin_graph_destroy(void* graph_exec) {
-  if (graph_exec) hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
   return 0;
 }
 #endif

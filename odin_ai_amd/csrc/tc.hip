@@ -212,7 +212,7 @@ extern "C" int odin_total_correlation_fwd_bwd(const float* z, const float* p, fl
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&tc_rows_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tc_rows_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
@@ -222,6 +222,11 @@ extern "C" int odin_total_correlation_fwd_bwd(const float* z, const float* p, fl
               (const float*)L, dloc, dscale, coef, B, D);
   ODIN_LAUNCH(mean_kernel, dim3(1), dim3(256), 0, stream, (const float*)part, B, tc_out);
   return odin_check_launch("total_correlation");
+}
+
+extern "C" int odin_mean(const float* x, int n, float* out, void* stream) {
+  ODIN_LAUNCH(mean_kernel, dim3(1), dim3(256), 0, stream, x, n, out);
+  return odin_check_launch("mean");
 }
 
 extern "C" int odin_permute_dims(const float* z, const int32_t* perm, float* out, int B, int D,

@@ -270,10 +270,11 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
   p.slab_stride = p.KH * p.KW * p.CI * p.CO + (p.want_bias ? p.CO : 0);
   if (!plan_wgrad(p, &gx, &gy, &gz, &lds)) return odin_fail(-2, "wgrad: no tiling plan");
   if (rows_out) *rows_out = gx;
+  if (p.slab == nullptr) return 0;  // dry run: planning only
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }

@@ -1,0 +1,545 @@
+"""HIP execution engine for one VAE training step (host side of the C ABI).
+
+`NetProgram` turns a sequential encoder / decoder description (the layer tuples of
+``odin_ai_amd.networks``) into a static list of kernel launches over preallocated HBM
+buffers; `VAEEngine` strings encoder -> latent -> decoder -> ELBO -> backward -> slab
+reduction -> (all-reduce) -> Adam together and can replay the whole step as ONE captured
+HIP graph.  PyTorch is used for device memory, streams and RCCL only: every FLOP of the
+step runs in ``libodin_hip.so``.
+
+Reference path restated: Networks.optimize (odin/networks/base_networks.py:415-624) ->
+VAEStep.call (odin/bay/vi/autoencoder/variational_autoencoder.py:117-126) ->
+elbo_components (:515-542).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT, ConvDesc, ReduceJob
+
+
+def same_pads(n: int, k: int, s: int) -> Tuple[int, int, int]:
+  """TF SAME: (out, pad_before, pad_after)."""
+  out = -(-n // s)
+  total = max((out - 1) * s + k - n, 0)
+  return out, total // 2, total - total // 2
+
+
+# --------------------------------------------------------------------------------------
+# parameter layout
+# --------------------------------------------------------------------------------------
+class ParamLayout:
+  """Flat fp32 parameter buffer: per trainable layer [W (Keras layout) | b] contiguous,
+  so that one wgrad slab reduction writes (dW | db) in place and ONE RCCL all-reduce /
+  ONE Adam launch covers the model."""
+
+  def __init__(self):
+    self.entries: List[Tuple[tuple, Tuple[int, ...], int]] = []  # (key, shape, offset)
+    self.size = 0
+
+  def add(self, key, shape) -> int:
+    off = self.size
+    self.entries.append((key, tuple(shape), off))
+    self.size += int(np.prod(shape))
+    return off
+
+  def pad_to(self, mult=4):
+    self.size = (self.size + mult - 1) // mult * mult
+
+  def views(self, flat: torch.Tensor) -> Dict[tuple, torch.Tensor]:
+    return {k: flat[o:o + int(np.prod(s))].view(s) for k, s, o in self.entries}
+
+
+class LayerRec:
+  __slots__ = ('kind', 'act', 'key', 'w_off', 'b_off', 'w_n', 'b_n', 'in_shape', 'out_shape',
+               'desc', 'K', 'N', 'center')
+
+
+def build_layers(net: str, layers: Sequence[tuple], in_shape: Tuple[int, ...],
+                 layout: ParamLayout) -> Tuple[List[LayerRec], Tuple[int, ...]]:
+  """Resolve shapes / SAME pads and register parameters.  Returns (records, out_shape).
+  Layer tuples: ('center',) ('conv',co,k,s,act) ('deconv',co,k,s,act) ('flatten',)
+  ('dense',units,act) ('reshape',(h,w,c)) -- cf. odin/networks/image_networks.py."""
+  recs: List[LayerRec] = []
+  shp = tuple(in_shape)
+  center = False
+  for li, L in enumerate(layers):
+    kind = L[0]
+    if kind == 'center':
+      center = True
+      continue
+    if kind == 'flatten':
+      shp = (int(np.prod(shp)),)
+      continue
+    if kind == 'reshape':
+      assert int(np.prod(L[1])) == int(np.prod(shp))
+      shp = tuple(L[1])
+      continue
+    r = LayerRec()
+    r.kind, r.key, r.center = kind, (net, li), center
+    r.in_shape = shp
+    r.desc = None
+    r.K = r.N = 0
+    if kind == 'conv':
+      _, co, k, s, act = L
+      H, W, Ci = shp
+      OH, pt, _ = same_pads(H, k, s)
+      OW, pl, _ = same_pads(W, k, s)
+      r.act = act
+      r.out_shape = (OH, OW, co)
+      r.desc = dict(H=H, W=W, Cin=Ci, OH=OH, OW=OW, Cout=co, K=k, stride=s, pad_t=pt, pad_l=pl)
+      wshape = (k, k, Ci, co)
+    elif kind == 'deconv':
+      _, co, k, s, act = L
+      H, W, Ci = shp
+      OH, OW = H * s, W * s
+      _, pt, _ = same_pads(OH, k, s)
+      _, pl, _ = same_pads(OW, k, s)
+      r.act = act
+      r.out_shape = (OH, OW, co)
+      r.desc = dict(H=H, W=W, Cin=Ci, OH=OH, OW=OW, Cout=co, K=k, stride=s, pad_t=pt, pad_l=pl)
+      wshape = (k, k, co, Ci)
+      assert not center
+    elif kind == 'dense':
+      _, u, act = L
+      assert len(shp) == 1, 'dense needs a flat input (add a flatten layer)'
+      r.act, r.K, r.N = act, shp[0], u
+      r.out_shape = (u,)
+      wshape = (shp[0], u)
+      assert not center
+    else:
+      raise ValueError(f'unknown layer kind {kind!r}')
+    r.w_n = int(np.prod(wshape))
+    r.b_n = wshape[-1] if kind != 'deconv' else wshape[2]
+    r.w_off = layout.add((net, li, 'w'), wshape)
+    r.b_off = layout.add((net, li, 'b'), (r.b_n,))
+    center = False
+    shp = r.out_shape
+    recs.append(r)
+  return recs, shp
+
+
+# --------------------------------------------------------------------------------------
+# one sequential network bound to buffers for a fixed batch size
+# --------------------------------------------------------------------------------------
+class NetProgram:
+
+  def __init__(self, lib, recs: List[LayerRec], B: int, device, params: torch.Tensor,
+               grads: torch.Tensor, max_rows: int):
+    self.lib, self.recs, self.B, self.device = lib, recs, B, device
+    self.params, self.grads = params, grads
+    f32 = dict(dtype=torch.float32, device=device)
+    self.outs = [torch.empty((B,) + r.out_shape, **f32) for r in recs]
+    # gradient wrt the PRE-activation output of every layer
+    self.gouts = [torch.empty((B,) + r.out_shape, **f32) for r in recs]
+    self.descs = []
+    for r in recs:
+      if r.desc is not None:
+        d = r.desc
+        self.descs.append(_lib.conv_desc(B, d['H'], d['W'], d['Cin'], d['OH'], d['OW'], d['Cout'],
+                                         d['K'], d['stride'], d['pad_t'], d['pad_l'], r.act,
+                                         r.center))
+      else:
+        self.descs.append(None)
+    self.wslabs: List[Optional[torch.Tensor]] = [None] * len(recs)
+    self.wrows = [0] * len(recs)
+    self.bslabs: List[Optional[torch.Tensor]] = [None] * len(recs)  # deconv bias (colsum)
+    self.brows = [0] * len(recs)
+    self._plan_slabs()
+
+  # -- planning (dry runs report how many slab rows each call will write) --------------
+  def _plan_slabs(self):
+    lib, B = self.lib, self.B
+    f32 = dict(dtype=torch.float32, device=self.device)
+    rows = C.c_int(0)
+    for i, r in enumerate(self.recs):
+      d = self.descs[i]
+      if r.kind == 'conv':
+        lib.odin_conv2d_wgrad(None, None, None, C.byref(rows), C.byref(d), None)
+        n = r.w_n + r.b_n
+      elif r.kind == 'deconv':
+        lib.odin_deconv2d_wgrad(None, None, None, C.byref(rows), C.byref(d), None)
+        n = r.w_n
+      else:
+        lib.odin_dense_wgrad(None, None, None, C.byref(rows), B, r.K, r.N, None)
+        n = r.w_n + r.b_n
+      self.wrows[i] = rows.value
+      self.wslabs[i] = torch.empty((rows.value, n), **f32)
+      if r.kind == 'deconv':
+        # bias gradient = column sums of gouts[i], emitted by whoever produces gouts[i]:
+        # the data-gradient of layer i+1
+        assert i + 1 < len(self.recs), 'a network may not END with a Conv2DTranspose'
+        self.bslabs[i] = torch.empty((lib.odin_max_slab_rows(), r.b_n), **f32)
+
+  def w(self, i):
+    r = self.recs[i]
+    return self.params[r.w_off:r.w_off + r.w_n]
+
+  def b(self, i):
+    r = self.recs[i]
+    return self.params[r.b_off:r.b_off + r.b_n]
+
+  # -- forward --------------------------------------------------------------------------
+  def forward(self, x: torch.Tensor, st):
+    lib, B = self.lib, self.B
+    h = x
+    for i, r in enumerate(self.recs):
+      y = self.outs[i]
+      if r.kind == 'conv':
+        lib.odin_conv2d_fwd(h.data_ptr(), self.w(i).data_ptr(), self.b(i).data_ptr(),
+                            y.data_ptr(), C.byref(self.descs[i]), st)
+      elif r.kind == 'deconv':
+        lib.odin_deconv2d_fwd(h.data_ptr(), self.w(i).data_ptr(), self.b(i).data_ptr(),
+                              y.data_ptr(), C.byref(self.descs[i]), st)
+      else:
+        lib.odin_dense_fwd(h.data_ptr(), self.w(i).data_ptr(), self.b(i).data_ptr(),
+                           y.data_ptr(), B, r.K, r.N, ACT[r.act], st)
+      h = y
+    return h
+
+  # -- backward -------------------------------------------------------------------------
+  def backward(self, x: torch.Tensor, gout_last: torch.Tensor, st,
+               dx_out: Optional[torch.Tensor] = None) -> List[ReduceJob]:
+    """gout_last: dL/d(pre-activation output of the last layer).  If dx_out is given the
+    gradient wrt the network input is written there.  Returns the slab-reduce jobs."""
+    lib, B = self.lib, self.B
+    n = len(self.recs)
+    jobs: List[ReduceJob] = []
+    g = gout_last
+    rows = C.c_int(0)
+    for i in range(n - 1, -1, -1):
+      r, d = self.recs[i], self.descs[i]
+      xin = x if i == 0 else self.outs[i - 1]
+      # ---- weight (and bias) gradient ----
+      slab = self.wslabs[i]
+      if r.kind == 'conv':
+        lib.odin_conv2d_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows),
+                              C.byref(d), st)
+      elif r.kind == 'deconv':
+        lib.odin_deconv2d_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows),
+                                C.byref(d), st)
+      else:
+        lib.odin_dense_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows), B,
+                             r.K, r.N, st)
+      assert rows.value == self.wrows[i]
+      jobs.append(ReduceJob(slab.data_ptr(), self.grads[r.w_off:].data_ptr(), slab.shape[1],
+                            rows.value))
+      # ---- data gradient -> pre-activation gradient of the previous layer ----
+      if i > 0:
+        prev = self.recs[i - 1]
+        dst, aux, aux_act = self.gouts[i - 1], self.outs[i - 1], ACT[prev.act]
+        bslab = self.bslabs[i - 1]
+      elif dx_out is not None:
+        dst, aux, aux_act, bslab = dx_out, None, 0, None
+      else:
+        break
+      auxp = aux.data_ptr() if (aux is not None and aux_act != 0) else None
+      bsp = bslab.data_ptr() if bslab is not None else None
+      if r.kind == 'conv':
+        lib.odin_conv2d_dgrad(g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
+                              bsp, C.byref(rows), C.byref(d), st)
+      elif r.kind == 'deconv':
+        lib.odin_deconv2d_dgrad(g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act,
+                                dst.data_ptr(), bsp, C.byref(rows), C.byref(d), st)
+      else:
+        lib.odin_dense_dgrad(g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
+                             bsp, C.byref(rows), B, r.K, r.N, st)
+      if bslab is not None:
+        pr = self.recs[i - 1]
+        jobs.append(ReduceJob(bslab.data_ptr(), self.grads[pr.b_off:].data_ptr(), pr.b_n,
+                              rows.value))
+      g = dst
+    return jobs
+
+
+# --------------------------------------------------------------------------------------
+# the whole VAE step
+# --------------------------------------------------------------------------------------
+H_ALPHA, H_B1, H_B2, H_EPS, H_GSCALE, H_INVB, H_KLW, H_BETA, H_TCCOEF, H_TCGRAD = range(10)
+N_HYPER = 16
+
+
+class VAEEngine:
+  """encoder -> q(z|x) -> decoder -> ELBO -> backward -> Adam for a FIXED batch size.
+
+  observation: 'bernoulli' | 'gaussian' | 'gaussian_softplus1'
+  tc: None | 'betatc' (total_correlation, weight (beta-1))
+  """
+
+  def __init__(self, enc_layers, dec_layers, in_shape, zdim, batch_size, device,
+               observation='bernoulli', analytic=False, free_bits=None, tc=None, lib=None,
+               params: Optional[torch.Tensor] = None, world_size: int = 1, seed: int = 1):
+    self.lib = lib if lib is not None else _lib.load()
+    self.device = torch.device(device)
+    self.B, self.D = int(batch_size), int(zdim)
+    self.in_shape = tuple(in_shape)
+    self.observation, self.analytic = observation, bool(analytic)
+    self.free_bits = -1.0 if free_bits is None else float(free_bits)
+    self.tc_mode, self.world_size, self.seed = tc, int(world_size), int(seed)
+    f32 = dict(dtype=torch.float32, device=self.device)
+    # ---- parameters ----
+    self.layout = ParamLayout()
+    self.enc_recs, eo = build_layers('enc', enc_layers, self.in_shape, self.layout)
+    assert len(eo) == 1, 'encoder must end with a flat output'
+    self.hdim = eo[0]
+    self.lat_w_off = self.layout.add(('lat', 'w'), (self.hdim, 2 * self.D))
+    self.lat_b_off = self.layout.add(('lat', 'b'), (2 * self.D,))
+    self.dec_recs, do = build_layers('dec', dec_layers, (self.D,), self.layout)
+    self.layout.pad_to(4)
+    self.out_shape = do
+    C_in = self.in_shape[-1]
+    if observation == 'bernoulli':
+      assert tuple(do) == self.in_shape, (do, self.in_shape)
+    else:
+      assert tuple(do) == self.in_shape[:-1] + (2 * C_in,), (do, self.in_shape)
+    n = self.layout.size
+    self.params = params if params is not None else torch.zeros(n, **f32)
+    assert self.params.numel() == n
+    self.grads = torch.zeros(n, **f32)
+    self.m = torch.zeros(n, **f32)
+    self.v = torch.zeros(n, **f32)
+    self.n_params = sum(int(np.prod(s)) for _, s, _ in self.layout.entries)
+    # ---- programs / buffers ----
+    B, D = self.B, self.D
+    mr = self.lib.odin_max_slab_rows()
+    self.enc = NetProgram(self.lib, self.enc_recs, B, self.device, self.params, self.grads, mr)
+    self.dec = NetProgram(self.lib, self.dec_recs, B, self.device, self.params, self.grads, mr)
+    self.p = torch.empty(B, 2 * D, **f32)
+    self.dp = torch.empty(B, 2 * D, **f32)
+    self.eps = torch.zeros(B, D, **f32)
+    self.z = torch.empty(B, D, **f32)
+    self.dz = torch.empty(B, D, **f32)
+    self.kl = torch.empty(B, **f32)
+    self.fbmask = torch.empty(B, **f32)
+    self.dh_e = torch.empty(B, self.hdim, **f32)
+    n_per = int(np.prod(self.in_shape))
+    self.n_per = n_per
+    self.llk_part = torch.empty(B * ((n_per + 1023) // 1024), **f32)
+    self.llk = torch.empty(B, **f32)
+    self.out4 = torch.zeros(4, **f32)
+    self.n_part = 0
+    rows = C.c_int(0)
+    self.lib.odin_dense_wgrad(None, None, None, C.byref(rows), B, self.hdim, 2 * D, None)
+    self.lat_slab = torch.empty(rows.value, self.hdim * 2 * D + 2 * D, **f32)
+    self.lat_rows = rows.value
+    if tc == 'betatc':
+      self.tc_ws = torch.zeros(B * (D + 2) + 1, **f32)
+      self.tc_dz = torch.empty(B, D, **f32)
+      self.tc_dloc = torch.empty(B, D, **f32)
+      self.tc_dscale = torch.empty(B, D, **f32)
+    self.ws = torch.empty(1024, **f32)
+    self.gnorm2 = torch.zeros(1, **f32)
+    self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+    # hyper-parameters that change per step live in device memory (graph replays)
+    # ring of pinned staging buffers: the async H2D copy of step t may still be pending
+    # when the host prepares step t+1
+    self._ring = [torch.zeros(N_HYPER + 4, dtype=torch.float32) for _ in range(8)]
+    self._ring_ev = [None] * 8
+    if self.device.type == 'cuda':
+      self._ring = [t.pin_memory() for t in self._ring]
+    self._ring_i = 0
+    self.hyper = torch.zeros(N_HYPER + 4, **f32)
+    self.step_count = 0
+    self.graph = None
+    self._jobs_keepalive = None
+
+  # ---- helpers -----------------------------------------------------------------------
+  def hp(self, idx):  # device address of one hyper scalar
+    return self.hyper.data_ptr() + 4 * idx
+
+  def stream(self):
+    if self.device.type == 'cuda':
+      return torch.cuda.current_stream(self.device).cuda_stream
+    return None
+
+  def param_views(self) -> Dict[tuple, torch.Tensor]:
+    return self.layout.views(self.params)
+
+  def grad_views(self) -> Dict[tuple, torch.Tensor]:
+    return self.layout.views(self.grads)
+
+  def load_params(self, P: Dict[tuple, np.ndarray]):
+    """P keyed like the oracle: ('enc', li, 'w'|'b'), ('lat', 'w'|'b'), ('dec', li, ...)."""
+    views = self.param_views()
+    assert set(P.keys()) == set(views.keys()), (sorted(P.keys()), sorted(views.keys()))
+    for k, v in P.items():
+      views[k].copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32).to(self.device))
+
+  def set_hyper(self, lr=1e-3, beta=1.0, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0,
+                t: Optional[int] = None):
+    """Host scalars -> device (one small async H2D copy)."""
+    t = self.step_count if t is None else t
+    tt = max(int(t), 1)
+    self._ring_i = (self._ring_i + 1) % len(self._ring)
+    h = self._ring[self._ring_i]
+    if self._ring_ev[self._ring_i] is not None:
+      self._ring_ev[self._ring_i].synchronize()
+    Bg = self.B * self.world_size
+    h[H_ALPHA] = lr * math.sqrt(1.0 - b2 ** tt) / (1.0 - b1 ** tt)
+    h[H_B1], h[H_B2], h[H_EPS], h[H_GSCALE] = b1, b2, eps, grad_scale
+    h[H_INVB] = 1.0 / Bg
+    h[H_KLW] = beta / Bg
+    h[H_BETA] = beta
+    h[H_TCCOEF] = (beta - 1.0) if self.tc_mode == 'betatc' else 0.0
+    h[H_TCGRAD] = (beta - 1.0) / self.world_size if self.tc_mode == 'betatc' else 0.0
+    h[N_HYPER:].view(torch.int32)[0] = int(t)
+    self.hyper.copy_(h, non_blocking=True)
+    if self.device.type == 'cuda':
+      ev = torch.cuda.Event()
+      ev.record(torch.cuda.current_stream(self.device))
+      self._ring_ev[self._ring_i] = ev
+
+  # ---- forward -----------------------------------------------------------------------
+  def forward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, st=None,
+              with_grad_seed: bool = True):
+    """Runs encode -> reparameterise -> decode -> ELBO (+ dlogits).  `eps=None` draws the
+    noise on device from the Philox stream (seed, step)."""
+    lib, B, D = self.lib, self.B, self.D
+    st = self.stream() if st is None else st
+    assert x.shape == (B,) + self.in_shape and x.is_contiguous()
+    self.x = x
+    if eps is None:
+      lib.odin_rng_normal(self.eps.data_ptr(), B * D, self.seed, self.hp(N_HYPER), st)
+    elif eps is not self.eps:
+      self.eps.copy_(eps)
+    h_e = self.enc.forward(x, st)
+    lw = self.params[self.lat_w_off:]
+    lb = self.params[self.lat_b_off:]
+    lib.odin_dense_fwd(h_e.data_ptr(), lw.data_ptr(), lb.data_ptr(), self.p.data_ptr(), B,
+                       self.hdim, 2 * D, 0, st)
+    lib.odin_latent_fwd(self.p.data_ptr(), self.eps.data_ptr(), self.z.data_ptr(),
+                        self.kl.data_ptr(), self.fbmask.data_ptr(), B, D, int(self.analytic),
+                        self.free_bits, st)
+    h_d = self.dec.forward(self.z, st)
+    npart = C.c_int(0)
+    gl = self.dec.gouts[-1]
+    if self.observation == 'bernoulli':
+      lib.odin_elbo_bernoulli_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
+                                      gl.data_ptr(), self.hp(H_INVB), B, self.n_per,
+                                      C.byref(npart), st)
+    else:
+      Cc = self.in_shape[-1]
+      lib.odin_elbo_gaussian_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
+                                     gl.data_ptr(), self.hp(H_INVB), B, self.n_per // Cc, Cc,
+                                     int(self.observation == 'gaussian_softplus1'),
+                                     C.byref(npart), st)
+    self.n_part = npart.value
+    tcp = None
+    if self.tc_mode == 'betatc':
+      lib.odin_total_correlation_fwd_bwd(self.z.data_ptr(), self.p.data_ptr(),
+                                         self.tc_ws.data_ptr(), self.tc_dz.data_ptr(),
+                                         self.tc_dloc.data_ptr(), self.tc_dscale.data_ptr(),
+                                         self.hp(H_TCGRAD), B, D, st)
+      tcp = self.tc_ws.data_ptr()
+    lib.odin_elbo_finalize(self.llk_part.data_ptr(), self.n_part, self.kl.data_ptr(),
+                           self.hp(H_BETA), tcp, self.llk.data_ptr(), self.out4.data_ptr(), B, st)
+    return h_d
+
+  # ---- backward ----------------------------------------------------------------------
+  def backward(self, st=None, extra_dz: Optional[torch.Tensor] = None):
+    lib, B, D = self.lib, self.B, self.D
+    st = self.stream() if st is None else st
+    jobs = self.dec.backward(self.z, self.dec.gouts[-1], st, dx_out=self.dz)
+    dzx = extra_dz.data_ptr() if extra_dz is not None else None
+    if self.tc_mode == 'betatc':
+      assert extra_dz is None
+      dzx = self.tc_dz.data_ptr()
+    tl = self.tc_dloc.data_ptr() if self.tc_mode == 'betatc' else None
+    ts = self.tc_dscale.data_ptr() if self.tc_mode == 'betatc' else None
+    lib.odin_latent_bwd(self.p.data_ptr(), self.eps.data_ptr(), self.z.data_ptr(),
+                        self.dz.data_ptr(), dzx, self.fbmask.data_ptr(), self.hp(H_KLW), tl, ts,
+                        self.dp.data_ptr(), B, D, int(self.analytic), st)
+    h_e = self.enc.outs[-1]
+    rows = C.c_int(0)
+    lib.odin_dense_wgrad(h_e.data_ptr(), self.dp.data_ptr(), self.lat_slab.data_ptr(),
+                         C.byref(rows), B, self.hdim, 2 * D, st)
+    jobs.append(ReduceJob(self.lat_slab.data_ptr(), self.grads[self.lat_w_off:].data_ptr(),
+                          self.lat_slab.shape[1], rows.value))
+    last = self.enc_recs[-1]
+    aux_act = ACT[last.act]
+    auxp = h_e.data_ptr() if aux_act != 0 else None
+    bslab = self.enc.bslabs[-1]
+    lw = self.params[self.lat_w_off:]
+    lib.odin_dense_dgrad(self.dp.data_ptr(), lw.data_ptr(), auxp, aux_act,
+                         self.enc.gouts[-1].data_ptr(),
+                         bslab.data_ptr() if bslab is not None else None, C.byref(rows), B,
+                         self.hdim, 2 * D, st)
+    if bslab is not None:
+      jobs.append(ReduceJob(bslab.data_ptr(), self.grads[last.b_off:].data_ptr(), last.b_n,
+                            rows.value))
+    jobs += self.enc.backward(self.x, self.enc.gouts[-1], st)
+    arr = (ReduceJob * len(jobs))(*jobs)
+    self._jobs_keepalive = arr
+    lib.odin_slab_reduce(arr, len(jobs), st)
+
+  # ---- optimiser ---------------------------------------------------------------------
+  def adam(self, st=None, global_clipnorm: Optional[float] = None, check_nan: bool = True):
+    lib = self.lib
+    st = self.stream() if st is None else st
+    gn = None
+    if global_clipnorm is not None or check_nan:
+      lib.odin_sumsq_flat(self.grads.data_ptr(), self.grads.numel(), self.ws.data_ptr(),
+                          self.gnorm2.data_ptr(), st)
+      gn = self.gnorm2.data_ptr()
+    lib.odin_adam_step_flat(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
+                            self.v.data_ptr(), self.params.numel(), self.hp(H_ALPHA), gn,
+                            float(global_clipnorm or 0.0), self.flag.data_ptr(), st)
+
+  def allreduce(self):
+    if self.world_size > 1:
+      import torch.distributed as dist
+      dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+
+  # ---- one optimisation step ---------------------------------------------------------
+  def train_step(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, lr=1e-3, beta=1.0,
+                 global_clipnorm: Optional[float] = None, use_graph: bool = False):
+    """Networks.optimize for one VAEStep: step += 1, forward, backward, (all-reduce), Adam.
+    Returns the device tensor out4 = [loss, mean llk, mean beta*kl, tc] (no host sync)."""
+    self.step_count += 1
+    self.set_hyper(lr=lr, beta=beta)
+    if use_graph and self.device.type == 'cuda' and self.world_size == 1:
+      self._graph_step(x, eps, global_clipnorm)
+    else:
+      self.forward(x, eps)
+      self.backward()
+      self.allreduce()
+      self.adam(global_clipnorm=global_clipnorm)
+    return self.out4
+
+  def _graph_step(self, x, eps, global_clipnorm):
+    """Capture forward+backward+Adam once into a HIP graph, replay afterwards.  The input
+    batch is copied into a static buffer; eps comes from the on-device Philox stream
+    unless given explicitly."""
+    if self.graph is None:
+      self.x_static = torch.empty_like(x)
+      self.x_static.copy_(x)
+      if eps is not None:
+        self.eps.copy_(eps)
+      # warm-up outside capture (first-call attribute setup, lazy allocations)
+      cap = torch.cuda.Stream(self.device)
+      cap.wait_stream(torch.cuda.current_stream(self.device))
+      saved = (self.params.clone(), self.m.clone(), self.v.clone())
+      with torch.cuda.stream(cap):
+        self.forward(self.x_static, None if eps is None else self.eps)
+        self.backward()
+        self.adam(global_clipnorm=global_clipnorm)
+        # the warm-up step must not count: restore the optimiser state it touched
+        self.params.copy_(saved[0]); self.m.copy_(saved[1]); self.v.copy_(saved[2])
+      torch.cuda.current_stream(self.device).wait_stream(cap)
+      self._graph_eps_explicit = eps is not None
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g, stream=cap):
+        self.forward(self.x_static, self.eps if self._graph_eps_explicit else None)
+        self.backward()
+        self.adam(global_clipnorm=global_clipnorm)
+      self.graph = g
+    self.x_static.copy_(x, non_blocking=True)
+    if eps is not None:
+      self.eps.copy_(eps, non_blocking=True)
+    self.graph.replay()

@@ -1,0 +1,79 @@
+"""Shared helpers of the engine-vs-oracle parity tests (simulator on CPU, HIP on GPU)."""
+import numpy as np
+import torch
+
+from oracle import vae_oracle as vo
+
+
+def make_case(spec, obs, B, seed=7, binary=False):
+  enc, dec, in_shape, zdim = spec
+  rng = np.random.default_rng(seed)
+  if binary:
+    x = (rng.random((B,) + tuple(in_shape)) < 0.13).astype(np.float64)
+  else:
+    x = np.clip(rng.random((B,) + tuple(in_shape)), 1e-6, 1 - 1e-6)
+  eps = rng.standard_normal((B, zdim))
+  return enc, dec, in_shape, zdim, x, eps
+
+
+def relerr(a, b):
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  return np.abs(a - b).max() / max(1e-30, np.abs(b).max())
+
+
+def check_engine_vs_oracle(eng, model: vo.OracleVAE, P, x, eps, beta, lr=1e-3, tol=1e-4,
+                           clip=None, steps=1):
+  """One (or more) full training steps: every tensor the north-star names is compared.
+  Tolerance: absolute 1e-4 on per-latent / per-pixel quantities, relative 1e-4 (of the
+  tensor's max magnitude) on summed quantities and gradients."""
+  dev = eng.device
+  tx = torch.tensor(x, dtype=torch.float32, device=dev)
+  te = torch.tensor(eps, dtype=torch.float32, device=dev)
+  eng.load_params(P)
+  M = {k: np.zeros_like(v) for k, v in P.items()}
+  V = {k: np.zeros_like(v) for k, v in P.items()}
+  report = {}
+  for t in range(1, steps + 1):
+    eng.step_count = t
+    eng.set_hyper(lr=lr, beta=beta)
+    eng.forward(tx, te)
+    eng.backward()
+    if dev.type == 'cuda':
+      torch.cuda.synchronize()
+    f = model.forward(P, x, eps)
+    G, _ = model.backward(P, x, eps, f)
+    D = model.D
+    p = eng.p.cpu().numpy()
+    report['loc'] = np.abs(p[:, :D] - f['loc']).max()
+    report['raw_scale'] = np.abs(p[:, D:] - f['raw_scale']).max()
+    report['z'] = np.abs(eng.z.cpu().numpy() - f['z']).max()
+    hd = eng.dec.outs[-1].cpu().numpy()
+    hd = hd.reshape(f['h_d'].shape)
+    report['h_d'] = relerr(hd, f['h_d'])
+    if model.observation == 'bernoulli':
+      report['recon'] = np.abs(1 / (1 + np.exp(-hd.astype(np.float64))) - f['recon']).max()
+    report['llk'] = relerr(eng.llk.cpu().numpy(), f['llk'])
+    report['kl'] = np.abs(eng.kl.cpu().numpy() * beta - f['kl']).max() / max(1.0, np.abs(f['kl']).max())
+    out4 = eng.out4.cpu().numpy()
+    report['loss'] = abs(out4[0] - f['loss']) / max(1.0, abs(f['loss']))
+    gv = {k: v.cpu().numpy() for k, v in eng.grad_views().items()}
+    for k in G:
+      report['grad' + str(k)] = relerr(gv[k], G[k])
+    for k, v in report.items():
+      assert v <= tol, (t, k, v, report)
+    # optimiser
+    eng.adam(global_clipnorm=clip)
+    keys = [k for k, _ in model.param_shapes()]
+    if clip is not None:
+      gl, _ = vo.clip_by_global_norm([G[k] for k in keys], clip)
+      G = dict(zip(keys, gl))
+    for k in keys:
+      P[k], M[k], V[k] = vo.adam_keras(P[k], G[k], M[k], V[k], t, lr)
+    pv = {k: v.cpu().numpy() for k, v in eng.param_views().items()}
+    for k in keys:
+      # Adam's first steps move every weight by ~lr regardless of the gradient scale, so
+      # compare the UPDATE with an absolute tolerance relative to lr
+      err = np.abs(pv[k] - P[k]).max()
+      assert err <= max(tol * lr * 50, 2e-6), (t, 'param', k, err)
+    # continue from the oracle's parameters so that errors do not compound in the check
+  return report

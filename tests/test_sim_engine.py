@@ -1,0 +1,54 @@
+"""Whole VAE step (engine host code + kernel sources on the CPU simulator) vs oracle."""
+import numpy as np
+import pytest
+import torch
+
+from odin_ai_amd.engine import VAEEngine
+from oracle import vae_oracle as vo
+from tests.parity_util import check_engine_vs_oracle, make_case
+from tests.simutil import sim_lib
+
+
+@pytest.fixture(scope='module')
+def L():
+  return sim_lib()
+
+
+def tiny_conv_spec(C=1, zdim=5):
+  enc = [('center',), ('conv', 8, 4, 2, 'elu'), ('conv', 16, 4, 2, 'elu'), ('flatten',),
+         ('dense', 24, 'linear')]
+  dec = [('dense', 32, 'linear'), ('reshape', (2, 2, 8)), ('deconv', 16, 4, 2, 'elu'),
+         ('deconv', 8, 4, 2, 'elu'), ('conv', C, 1, 1, 'linear')]
+  return enc, dec, (8, 8, C), zdim
+
+
+CASES = [
+    ('tiny', dict(beta=4.0), 'bernoulli', 1),
+    ('tiny', dict(beta=1.0, analytic=True, free_bits=0.3), 'bernoulli', 3),
+    ('tiny_tc', dict(beta=3.0, tc_beta=3.0), 'bernoulli', 3),
+    ('tiny_gauss', dict(beta=2.0), 'gaussian_softplus1', 3),
+    ('mnist_dense', dict(), 'bernoulli', 1),
+]
+
+
+@pytest.mark.parametrize('name,kw,obs,C', CASES)
+def test_engine_step_matches_oracle(L, name, kw, obs, C):
+  B = 6
+  if name == 'mnist_dense':
+    spec = vo.mnist_dense_spec(4)
+    spec = ([('flatten',), ('dense', 40, 'relu'), ('dense', 24, 'relu')],
+            [('dense', 24, 'relu'), ('dense', 784, 'linear'), ('reshape', (28, 28, 1))],
+            (28, 28, 1), 4)
+  elif name == 'tiny_gauss':
+    e, d, s, z = tiny_conv_spec(C)
+    d = d[:-1] + [('conv', 2 * C, 1, 1, 'linear')]
+    spec = (e, d, s, z)
+  else:
+    spec = tiny_conv_spec(C)
+  enc, dec, in_shape, zdim, x, eps = make_case(spec, obs, B)
+  model = vo.OracleVAE(enc, dec, in_shape, zdim, observation=obs, **kw)
+  P = model.init_params(seed=11)
+  eng = VAEEngine(enc, dec, in_shape, zdim, B, 'cpu', observation=obs,
+                  analytic=kw.get('analytic', False), free_bits=kw.get('free_bits'),
+                  tc='betatc' if 'tc_beta' in kw else None, lib=L)
+  check_engine_vs_oracle(eng, model, P, x, eps, beta=kw.get('beta', 1.0), steps=2, clip=100.0)

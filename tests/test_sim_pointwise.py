@@ -1,0 +1,200 @@
+"""Pointwise / reduction kernel sources under the CPU simulator vs the float64 oracle."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vae_oracle as vo
+from tests.simutil import sim_lib
+
+
+@pytest.fixture(scope='module')
+def L():
+  return sim_lib()
+
+
+def T(a, dt=torch.float32):
+  return torch.tensor(np.ascontiguousarray(a), dtype=dt)
+
+
+def close(a, b, tol=2e-5):
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+
+
+@pytest.mark.parametrize('analytic,fb', [(0, -1.0), (1, -1.0), (0, 0.4)])
+def test_latent_fwd_bwd(L, analytic, fb):
+  rng = np.random.default_rng(0)
+  B, D = 37, 10
+  p = rng.standard_normal((B, 2 * D))
+  eps = rng.standard_normal((B, D))
+  loc, sc = vo.mvn_diag_params(p, D)
+  z_ref = loc + sc * eps
+  klr = vo.kl_analytic(loc, sc) if analytic else vo.kl_mc(loc, sc, z_ref)
+  kl_ref, m_ref = vo.free_bits_clamp(klr, None if fb < 0 else fb, D)
+  tp, te = T(p), T(eps)
+  z, kl, m = torch.zeros(B, D), torch.zeros(B), torch.zeros(B)
+  L.odin_latent_fwd(tp.data_ptr(), te.data_ptr(), z.data_ptr(), kl.data_ptr(), m.data_ptr(), B, D,
+                    analytic, fb, None)
+  close(z.numpy(), z_ref)
+  close(kl.numpy(), kl_ref)
+  assert (m.numpy() == m_ref).all()
+  dz = rng.standard_normal((B, D))
+  klw = 4.0 / B
+  w = klw * m_ref[:, None]
+  if analytic:
+    dloc, dsc = w * loc, w * (sc - 1 / sc)
+  else:
+    dloc, dsc = w * z_ref, w * (z_ref * eps - 1 / sc)
+  dloc, dsc = dloc + dz, dsc + dz * eps
+  dp_ref = np.concatenate([dloc, dsc * vo.sigmoid(p[:, D:])], -1)
+  tdz, tk, dp = T(dz), T([klw]), torch.zeros(B, 2 * D)
+  L.odin_latent_bwd(tp.data_ptr(), te.data_ptr(), z.data_ptr(), tdz.data_ptr(), None, m.data_ptr(),
+                    tk.data_ptr(), None, None, dp.data_ptr(), B, D, analytic, None)
+  close(dp.numpy(), dp_ref)
+
+
+@pytest.mark.parametrize('shape', [(3, 8, 8, 1), (2, 64, 64, 3), (5, 7, 3, 1)])
+def test_elbo_bernoulli_and_finalize(L, shape):
+  rng = np.random.default_rng(1)
+  B = shape[0]
+  N = int(np.prod(shape[1:]))
+  lg = rng.standard_normal(shape) * 3
+  x = np.clip(rng.random(shape), 1e-6, 1 - 1e-6)
+  llk_ref = vo.bernoulli_log_prob(lg, x)
+  npart = C.c_int(0)
+  tl, tx, sc = T(lg), T(x), T([1.0 / B])
+  part = torch.zeros(B * ((N + 1023) // 1024))
+  dl = torch.zeros(shape)
+  L.odin_elbo_bernoulli_fwd_bwd(tl.data_ptr(), tx.data_ptr(), part.data_ptr(), dl.data_ptr(),
+                                sc.data_ptr(), B, N, C.byref(npart), None)
+  close(part.reshape(B, -1).sum(1).numpy(), llk_ref, 1e-5)
+  close(dl.numpy(), -(vo.bernoulli_log_prob_grad(lg, x)) / B)
+  kl = rng.random(B) * 5
+  tkl, hyper, ttc = T(kl), T([4.0, 0.5]), T([0.5])
+  llk, out = torch.zeros(B), torch.zeros(4)
+  L.odin_elbo_finalize(part.data_ptr(), npart.value, tkl.data_ptr(), hyper.data_ptr(),
+                       ttc.data_ptr(), llk.data_ptr(), out.data_ptr(), B, None)
+  close(llk.numpy(), llk_ref, 1e-5)
+  loss = -(llk_ref.mean() - 4.0 * kl.mean() - 0.25)
+  close(out.numpy(), [loss, llk_ref.mean(), 4.0 * kl.mean(), 0.25], 1e-5)
+
+
+@pytest.mark.parametrize('sp1', [0, 1])
+def test_elbo_gaussian(L, sp1):
+  rng = np.random.default_rng(2)
+  B, npix, Cc = 3, 50, 3
+  h = rng.standard_normal((B, npix, 2 * Cc))
+  if not sp1:
+    h[..., Cc:] = 0.5 + rng.random((B, npix, Cc))
+  x = rng.random((B, npix, Cc))
+  loc, raw = h[..., :Cc], h[..., Cc:]
+  sd = vo.softplus1(raw) if sp1 else raw
+  llk_ref = vo.gaussian_log_prob(loc, sd, x)
+  d = (x - loc) / sd
+  dsd = vo.sigmoid(raw + vo.SOFTPLUS_INV_1) if sp1 else 1.0
+  dh_ref = -np.concatenate([d / sd, (d * d - 1) / sd * dsd], -1) / B
+  th, tx, sc = T(h), T(x), T([1.0 / B])
+  part, dh = torch.zeros(B), torch.zeros(B, npix, 2 * Cc)
+  npart = C.c_int(0)
+  L.odin_elbo_gaussian_fwd_bwd(th.data_ptr(), tx.data_ptr(), part.data_ptr(), dh.data_ptr(),
+                               sc.data_ptr(), B, npix, Cc, sp1, C.byref(npart), None)
+  assert npart.value == 1
+  close(part.numpy(), llk_ref, 1e-5)
+  close(dh.numpy(), dh_ref)
+
+
+def test_adam_and_sumsq(L):
+  rng = np.random.default_rng(3)
+  n = 1027
+  th, g = rng.standard_normal(n), rng.standard_normal(n)
+  m, v = rng.standard_normal(n) * 0.1, rng.random(n) * 0.1
+  t, lr = 7, 1e-3
+  th_ref, m_ref, v_ref = vo.adam_keras(th, g, m, v, t, lr)
+  a = lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+  tth, tg, tm, tv = T(th), T(g), T(m), T(v)
+  hy = T([a, 0.9, 0.999, 1e-7, 1.0])
+  L.odin_adam_step_flat(tth.data_ptr(), tg.data_ptr(), tm.data_ptr(), tv.data_ptr(), n,
+                        hy.data_ptr(), None, 0.0, None, None)
+  close(tth.numpy(), th_ref, 1e-6)
+  close(tm.numpy(), m_ref, 1e-6)
+  close(tv.numpy(), v_ref, 1e-6)
+  ws, out = torch.zeros(1024), torch.zeros(1)
+  L.odin_sumsq_flat(tg.data_ptr(), n, ws.data_ptr(), out.data_ptr(), None)
+  close(out.numpy(), [(g.astype(np.float32).astype(np.float64) ** 2).sum()], 1e-6)
+  # clipping by global norm + NaN guard
+  tth2, tm2, tv2 = T(th), T(m), T(v)
+  clip = 3.0
+  gc, _ = vo.clip_by_global_norm([g], clip)
+  th2_ref, _, _ = vo.adam_keras(th, gc[0], m, v, t, lr)
+  L.odin_adam_step_flat(tth2.data_ptr(), tg.data_ptr(), tm2.data_ptr(), tv2.data_ptr(), n,
+                        hy.data_ptr(), out.data_ptr(), clip, None, None)
+  close(tth2.numpy(), th2_ref, 1e-6)
+  nan, flag = T([float('nan')]), torch.zeros(1, dtype=torch.int32)
+  before = tth2.clone()
+  L.odin_adam_step_flat(tth2.data_ptr(), tg.data_ptr(), tm2.data_ptr(), tv2.data_ptr(), n,
+                        hy.data_ptr(), nan.data_ptr(), clip, flag.data_ptr(), None)
+  assert flag.item() == 1 and torch.equal(before, tth2)
+
+
+def test_total_correlation(L):
+  rng = np.random.default_rng(4)
+  B, D = 70, 6
+  z = rng.standard_normal((B, D))
+  p = rng.standard_normal((B, 2 * D))
+  loc, sc = vo.mvn_diag_params(p, D)
+  tc_ref = vo.total_correlation(z, loc, sc)
+  gz, gl, gs = vo.total_correlation_bwd(z, loc, sc)
+  coef = 3.0
+  tz, tp, tcf = T(z), T(p), T([coef])
+  ws = torch.zeros(B * (D + 2) + 1)
+  dz, dl, ds = torch.zeros(B, D), torch.zeros(B, D), torch.zeros(B, D)
+  L.odin_total_correlation_fwd_bwd(tz.data_ptr(), tp.data_ptr(), ws.data_ptr(), dz.data_ptr(),
+                                   dl.data_ptr(), ds.data_ptr(), tcf.data_ptr(), B, D, None)
+  close([ws[0].item()], [tc_ref], 1e-5)
+  close(dz.numpy(), coef * gz, 1e-4)
+  close(dl.numpy(), coef * gl, 1e-4)
+  close(ds.numpy(), coef * gs, 1e-4)
+
+
+def test_permute_and_dtc_and_rng(L):
+  rng = np.random.default_rng(5)
+  B, D = 128, 6
+  # reference's own test (tests/bayesian/test_vae.py:112-125): portable properties
+  z = rng.standard_normal((B, D))
+  perm = torch.zeros(B, D, dtype=torch.int32)
+  step = torch.tensor([3], dtype=torch.int32)
+  L.odin_random_perm(perm.data_ptr(), B, D, 1234, step.data_ptr(), None)
+  pn = perm.numpy()
+  for l in range(D):
+    assert sorted(pn[:, l].tolist()) == list(range(B))
+  assert not all((pn[:, l] == np.arange(B)).all() for l in range(D))
+  assert any((pn[:, 0] != pn[:, l]).any() for l in range(1, D))
+  tz, out = T(z), torch.zeros(B, D)
+  L.odin_permute_dims(tz.data_ptr(), perm.data_ptr(), out.data_ptr(), B, D, None)
+  ref = vo.permute_dims(z, pn.astype(np.int64))
+  close(out.numpy(), ref, 1e-7)
+  assert (out.numpy() != z.astype(np.float32)).any()
+  assert np.allclose(np.sort(out.numpy(), 0), np.sort(z.astype(np.float32), 0))
+  # dtc loss
+  lz, lp = rng.standard_normal(B) * 2, rng.standard_normal(B) * 2
+  tlz, tlp = T(lz), T(lp)
+  o, dlz, dlp = torch.zeros(1), torch.zeros(B), torch.zeros(B)
+  L.odin_dtc_loss_fwd_bwd(tlz.data_ptr(), tlp.data_ptr(), o.data_ptr(), dlz.data_ptr(),
+                          dlp.data_ptr(), B, None)
+  close(o.numpy(), [vo.dtc_loss(lz, lp)], 1e-5)
+  a, b = vo.dtc_loss_bwd(lz, lp)
+  close(dlz.numpy(), a, 1e-5)
+  close(dlp.numpy(), b, 1e-5)
+  # rng: moments + determinism + step dependence
+  n = 200001
+  r1, r2, r3 = torch.zeros(n), torch.zeros(n), torch.zeros(n)
+  s2 = torch.tensor([4], dtype=torch.int32)
+  L.odin_rng_normal(r1.data_ptr(), n, 99, step.data_ptr(), None)
+  L.odin_rng_normal(r2.data_ptr(), n, 99, step.data_ptr(), None)
+  L.odin_rng_normal(r3.data_ptr(), n, 99, s2.data_ptr(), None)
+  assert torch.equal(r1, r2) and not torch.equal(r1, r3)
+  assert abs(r1.mean().item()) < 0.01 and abs(r1.std().item() - 1) < 0.01
+  assert abs((r1 ** 3).mean().item()) < 0.05 and abs((r1 ** 4).mean().item() - 3) < 0.1
