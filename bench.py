@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- VAE train images/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload at N=1 = BASELINE.json configs[1]: beta-VAE (beta=4) on dSprites-shaped synthetic
+data, 64x64x1, `dsprites_networks` conv encoder/decoder, batch 256 per GPU (weak scaling:
+per-GPU batch fixed, gradients summed by ONE RCCL all-reduce of the flat fp32 bucket).
+A "step" = forward + backward + slab reduction + (all-reduce) + Adam on one batch already
+resident in HBM.  Prints ONE JSON line (rank 0).
+
+Extra objects in the JSON line:
+  roofline     -- the dominant kernel launch, timed live with HIP events on the launch
+                  stream; algorithmic FLOPs / bytes per launch are stated in DESIGN.md.
+  cpu_baseline -- the same training step as a torch-CPU fp32 port (oracle/torch_ref.py,
+                  all host cores), rank 0 at N=1 only, on a bounded number of steps.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-in MFMA peak
+PEAK_HBM_GBS = 8000.0         # spec (6.3 TB/s achievable with float4 copies)
+
+WORKLOADS = {
+    # name: (get_networks name, kwargs, batch per GPU, beta, vae kind)
+    'dsprites_betavae_b256': ('dsprites', {}, 256, 4.0, None),
+    'shapes3d_vae_b256': ('shapes3d', {}, 256, 1.0, None),
+    'celeba_betatcvae_b512': ('celeba', {}, 512, 4.0, 'betatc'),
+    'mnist_dense_b128': ('dense', {}, 128, 1.0, None),
+}
+
+
+def init_params_(eng, seed):
+  """Random-init weights of the reference's initialisers' scale (HeNormal for elu convs,
+  glorot for dense; odin/networks/image_networks.py:157-174), biases zero."""
+  g = torch.Generator(device='cpu').manual_seed(seed)
+  for (key, shp, off) in eng.layout.entries:
+    n = int(np.prod(shp))
+    if key[-1] == 'b':
+      eng.params[off:off + n].zero_()
+      continue
+    if len(shp) == 4:
+      is_deconv = any(r.kind == 'deconv' and (r.key == key[:2]) for r in eng.enc_recs + eng.dec_recs)
+      fan_in = shp[0] * shp[1] * (shp[3] if is_deconv else shp[2])
+      std = math.sqrt(2.0 / fan_in)
+    else:
+      std = math.sqrt(2.0 / (shp[0] + shp[1]))
+    eng.params[off:off + n] = (torch.randn(n, generator=g) * std).to(eng.device)
+
+
+def synthetic_batch(name, B, in_shape, device, seed):
+  """dSprites-like: sprite masks in {1e-6, 1-1e-6}, ~5% foreground; others U(0,1) clipped
+  (odin/fuel/image_data/_base.py:130-147)."""
+  g = torch.Generator(device='cpu').manual_seed(seed)
+  if name.startswith('dsprites'):
+    x = torch.zeros(B, *in_shape)
+    ys = torch.randint(4, 44, (B,), generator=g)
+    xs = torch.randint(4, 44, (B,), generator=g)
+    hs = torch.randint(6, 18, (B,), generator=g)
+    for b in range(B):
+      x[b, ys[b]:ys[b] + hs[b], xs[b]:xs[b] + hs[b], :] = 1.0
+  elif name.startswith('mnist'):
+    x = (torch.rand(B, *in_shape, generator=g) < 0.13).float()
+    return x.to(device)
+  else:
+    x = torch.rand(B, *in_shape, generator=g)
+  return x.clamp_(1e-6, 1 - 1e-6).to(device)
+
+
+def conv_flops(rec, B):
+  d = rec.desc
+  if rec.kind == 'conv':
+    return 2.0 * B * d['OH'] * d['OW'] * d['K'] * d['K'] * d['Cin'] * d['Cout']
+  if rec.kind == 'deconv':
+    return 2.0 * B * d['H'] * d['W'] * d['K'] * d['K'] * d['Cin'] * d['Cout']
+  return 2.0 * B * rec.K * rec.N
+
+
+def profile_ops(eng, reps=20):
+  """Per-launch timing of every kernel of the step with HIP events on the launch stream."""
+  import ctypes as C
+  from odin_ai_amd._lib import ACT
+  lib, B = eng.lib, eng.B
+  st = eng.stream()
+  rows = C.c_int(0)
+  out = []
+
+  def timeit(fn):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+      fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+  for net, prog, x0 in (('enc', eng.enc, eng.x), ('dec', eng.dec, eng.z)):
+    for i, r in enumerate(prog.recs):
+      xin = x0 if i == 0 else prog.outs[i - 1]
+      y, g, d = prog.outs[i], prog.gouts[i], prog.descs[i]
+      w, b = prog.w(i), prog.b(i)
+      fl = conv_flops(r, B)
+      if r.kind == 'conv':
+        f_fwd = lambda: lib.odin_conv2d_fwd(xin.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), C.byref(d), st)
+        f_wg = lambda: lib.odin_conv2d_wgrad(xin.data_ptr(), g.data_ptr(), prog.wslabs[i].data_ptr(), C.byref(rows), C.byref(d), st)
+        f_dg = None
+        if i > 0:
+          dst, aux = prog.gouts[i - 1], prog.outs[i - 1]
+          f_dg = lambda: lib.odin_conv2d_dgrad(g.data_ptr(), w.data_ptr(), aux.data_ptr(), ACT[prog.recs[i - 1].act], dst.data_ptr(), None, None, C.byref(d), st)
+      elif r.kind == 'deconv':
+        f_fwd = lambda: lib.odin_deconv2d_fwd(xin.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), C.byref(d), st)
+        f_wg = lambda: lib.odin_deconv2d_wgrad(xin.data_ptr(), g.data_ptr(), prog.wslabs[i].data_ptr(), C.byref(rows), C.byref(d), st)
+        f_dg = None
+        if i > 0:
+          dst, aux = prog.gouts[i - 1], prog.outs[i - 1]
+          f_dg = lambda: lib.odin_deconv2d_dgrad(g.data_ptr(), w.data_ptr(), aux.data_ptr(), ACT[prog.recs[i - 1].act], dst.data_ptr(), None, None, C.byref(d), st)
+      else:
+        f_fwd = lambda: lib.odin_dense_fwd(xin.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, r.K, r.N, ACT[r.act], st)
+        f_wg = lambda: lib.odin_dense_wgrad(xin.data_ptr(), g.data_ptr(), prog.wslabs[i].data_ptr(), C.byref(rows), B, r.K, r.N, st)
+        f_dg = None
+        if i > 0:
+          dst, aux = prog.gouts[i - 1], prog.outs[i - 1]
+          f_dg = lambda: lib.odin_dense_dgrad(g.data_ptr(), w.data_ptr(), aux.data_ptr(), ACT[prog.recs[i - 1].act], dst.data_ptr(), None, None, B, r.K, r.N, st)
+      for tag, fn in (('fwd', f_fwd), ('wgrad', f_wg), ('dgrad', f_dg)):
+        if fn is None:
+          continue
+        t = timeit(fn)
+        out.append(dict(layer=f'{net}{i}:{r.kind}', op=tag, us=t * 1e6, gflop=fl * 1e-9,
+                        tflops=fl / t * 1e-12))
+  return out
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=100)
+  ap.add_argument('--warmup', type=int, default=20)
+  ap.add_argument('--workload', default='dsprites_betavae_b256', choices=sorted(WORKLOADS))
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-steps', type=int, default=6)
+  ap.add_argument('--no-graph', action='store_true')
+  ap.add_argument('--profile-ops', action='store_true', help='print a per-kernel timing table')
+  args = ap.parse_args()
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', local_rank))
+  assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+
+  from odin_ai_amd.engine import VAEEngine
+  from odin_ai_amd.networks import get_networks
+  ds, kw, B, beta, kind = WORKLOADS[args.workload]
+  nets = get_networks(ds, **kw)
+  enc, dec = nets['encoder'].layers, nets['decoder'].layers
+  in_shape, zdim = nets['encoder'].input_shape, nets['latents'].event_shape[0]
+  eng = VAEEngine(enc, dec, in_shape, zdim, B, device, observation=nets['observation'].posterior,
+                  tc=kind, world_size=world, seed=1 + rank)
+  init_params_(eng, seed=1)  # identical weights on every rank
+  x = synthetic_batch(args.workload, B, in_shape, device, seed=100 + rank)
+  lr = 1e-3
+  use_graph = (not args.no_graph) and world == 1
+
+  def step():
+    return eng.train_step(x, None, lr=lr, beta=beta, global_clipnorm=100.0, use_graph=use_graph)
+
+  for _ in range(args.warmup):
+    step()
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    out = step()
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    tt = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = tt.item()
+  loss = out[0].item()
+  assert math.isfinite(loss), 'training diverged'
+  assert eng.flag.item() == 0, 'non-finite gradients were skipped during the timed region'
+
+  if rank != 0:
+    if world > 1:
+      dist.destroy_process_group()
+    return
+
+  # ---- roofline of the dominant kernel (per-launch, HIP events on the launch stream) ----
+  ops = profile_ops(eng)
+  dom = max(ops, key=lambda o: o['us'])
+  roofline = dict(bound='mfma', kernel=f"{dom['layer']}:{dom['op']}",
+                  achieved=round(dom['tflops'], 3), peak=PEAK_MFMA_F32_TFLOPS, unit='TFLOP/s',
+                  frac=round(dom['tflops'] / PEAK_MFMA_F32_TFLOPS, 4), traffic=None,
+                  us_per_launch=round(dom['us'], 2), gflop_per_launch=round(dom['gflop'], 4))
+  conv_us = sum(o['us'] for o in ops)
+  conv_gf = sum(o['gflop'] for o in ops)
+  stack = dict(us=round(conv_us, 1), gflop=round(conv_gf, 3),
+               tflops=round(conv_gf / conv_us * 1e-3, 3),
+               frac=round(conv_gf / conv_us * 1e-3 / PEAK_MFMA_F32_TFLOPS, 4))
+  if args.profile_ops:
+    for o in ops:
+      print(f"# {o['layer']:14s} {o['op']:6s} {o['us']:9.1f} us {o['gflop']:8.3f} GF "
+            f"{o['tflops']:7.2f} TF/s", file=sys.stderr)
+    print(f"# conv/dense stack: {stack}", file=sys.stderr)
+
+  # ---- CPU baseline: the same step as a torch-CPU fp32 port, all host cores --------------
+  cpu = None
+  if not args.no_cpu_baseline and world == 1:
+    from oracle.torch_ref import TorchTrainer, TorchVAE
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = TorchVAE(enc, dec, in_shape, zdim, observation=nets['observation'].posterior,
+                     beta=beta, tc_beta=beta if kind == 'betatc' else None, dtype=torch.float32)
+    P = {k: v.detach().cpu().numpy() for k, v in eng.param_views().items()}
+    tr = TorchTrainer(model, P, lr=lr, threads=cores)
+    xc, ec = x.cpu(), torch.randn(B, zdim)
+    tr.step(xc, ec)  # warm-up
+    c0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+      tr.step(xc, ec)
+    cdt = time.perf_counter() - c0
+    cpu = dict(value=round(B * args.cpu_steps / cdt, 1), unit='images/sec', cores=cores,
+               kind='port', sample=f'{args.cpu_steps} training steps of the same workload '
+               f'(batch {B}), torch-CPU fp32 port of the reference step')
+
+  res = dict(metric='VAE train images/sec', value=round(B * world * args.steps / dt, 1),
+             unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
+             ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling='weak',
+             vs_baseline=None, dtype='f32', data='synthetic',
+             config=dict(workload=args.workload, global_batch=B * world, per_gpu_batch=B,
+                         beta=beta, parallelism=f'dp{world}', graph=bool(use_graph),
+                         final_loss=round(loss, 4)),
+             roofline=roofline, conv_stack=stack, cpu_baseline=cpu)
+  print(json.dumps(res))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,186 @@
+"""Per-dataset encoder / decoder stacks, mirroring ``odin.networks.get_networks``.
+
+The reference builds Keras layer objects (odin/networks/image_networks.py:907-933); here
+a network is a plain description (`SequentialNetwork` holding layer tuples) that the HIP
+engine compiles into kernel launches.  Same dataset names, same `zdim` / `qz` / semi-
+supervised / hierarchical arguments, same returned dictionary keys
+(``encoder, decoder, observation, latents``).
+
+Layer tuples: ('center',) | ('conv', filters, k, stride, act) | ('deconv', ...) |
+('flatten',) | ('dense', units, act) | ('reshape', (h, w, c)).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+
+@dataclass
+class SequentialNetwork:
+  """Stand-in for odin.networks.SequentialNetwork (base_networks.py:883-959)."""
+  layers: List[tuple]
+  name: str = 'Sequential'
+  input_shape: Optional[Tuple[int, ...]] = None
+
+  def __iter__(self):
+    return iter(self.layers)
+
+  def __len__(self):
+    return len(self.layers)
+
+
+@dataclass
+class RVconf:
+  """The subset of odin.bay.random_variable.RVconf (random_variable.py:175) the VAE path
+  needs: event shape, posterior alias, whether a Dense projection is added, name."""
+  event_shape: Tuple[int, ...]
+  posterior: str = 'mvndiag'
+  projection: bool = True
+  name: str = 'latents'
+  kwargs: dict = field(default_factory=dict)
+
+  @property
+  def event_size(self) -> int:
+    n = 1
+    for i in self.event_shape:
+      n *= int(i)
+    return n
+
+
+_OBS_PARAMS = {'bernoulli': 1, 'gaussian': 2, 'gaus': 2, 'normal': 2, 'gaussian_softplus1': 2}
+
+
+def _observation(input_shape, distribution: str) -> Tuple[int, RVconf]:
+  """_parse_distribution (image_networks.py:46-102): number of parameter maps the decoder's
+  last 1x1 conv emits and the observation description (projection=False: the logits /
+  (loc, scale) are the decoder output itself)."""
+  distribution = str(distribution).lower()
+  if distribution not in _OBS_PARAMS:
+    raise ValueError(
+        f"observation {distribution!r} is outside this build's scope "
+        f"(supported: bernoulli, gaussian, gaussian_softplus1; QuantizedLogistic is listed "
+        f"as 'next' in SURVEY.md section 8f)")
+  name = {'gaus': 'gaussian', 'normal': 'gaussian'}.get(distribution, distribution)
+  return _OBS_PARAMS[distribution], RVconf(tuple(input_shape), name, projection=False,
+                                           name='image')
+
+
+def dsprites_networks(qz='mvndiag', zdim=None, activation='elu', is_semi_supervised=False,
+                      is_hierarchical=False, centerize_image=True, n_channels=1, proj_dim=None,
+                      distribution='bernoulli', **kwargs) -> Dict[str, object]:
+  """image_networks.py:436-534 (dSprites; Shapes3D via n_channels=3, :560-597)."""
+  if is_hierarchical or is_semi_supervised:
+    raise NotImplementedError('hierarchical / semi-supervised stacks are out of scope (SURVEY 8)')
+  if zdim is None:
+    zdim = 10
+  if proj_dim is None:
+    proj_dim = 128 if n_channels == 1 else 256
+  input_shape = (64, 64, int(n_channels))
+  n_params, observation = _observation(input_shape, distribution)
+  a = activation
+  enc = ([('center',)] if centerize_image else []) + [
+      ('conv', 32, 4, 2, a), ('conv', 32, 4, 2, a), ('conv', 64, 4, 2, a), ('conv', 64, 4, 2, a),
+      ('flatten',), ('dense', proj_dim, 'linear')]
+  dec = [('dense', proj_dim, 'linear'), ('reshape', (4, 4, proj_dim // 16)),
+         ('deconv', 64, 4, 2, a), ('deconv', 64, 4, 2, a), ('deconv', 32, 4, 2, a),
+         ('deconv', 32, 4, 2, a), ('conv', n_channels * n_params, 1, 1, 'linear')]
+  return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape),
+              decoder=SequentialNetwork(dec, 'Decoder', (zdim,)), observation=observation,
+              latents=RVconf((zdim,), qz, projection=True, name='latents'))
+
+
+def shapes3d_networks(qz='mvndiag', zdim=None, **kwargs):
+  """image_networks.py:560-597: dsprites stack with 3 channels, zdim 6, proj 256."""
+  if zdim is None:
+    zdim = 6
+  kwargs.setdefault('n_channels', 3)
+  return dsprites_networks(qz=qz, zdim=zdim, **kwargs)
+
+
+def celeba_networks(qz='mvndiag', zdim=None, activation='elu', is_semi_supervised=False,
+                    is_hierarchical=False, centerize_image=True, distribution='bernoulli',
+                    n_channels=3, **kwargs):
+  """image_networks.py:661-725.  The reference's observation for CelebA is broken as
+  shipped (:714); Bernoulli (3 maps) or Gaussian (6 maps) heads are offered."""
+  if is_hierarchical or is_semi_supervised:
+    raise NotImplementedError('hierarchical / semi-supervised stacks are out of scope (SURVEY 8)')
+  if zdim is None:
+    zdim = 45
+  input_shape = (64, 64, n_channels)
+  n_params, observation = _observation(input_shape, distribution)
+  a = activation
+  enc = ([('center',)] if centerize_image else []) + [
+      ('conv', 32, 4, 2, a), ('conv', 32, 4, 2, a), ('conv', 64, 4, 2, a), ('conv', 64, 4, 1, a),
+      ('flatten',), ('dense', 512, 'linear')]
+  dec = [('dense', 512, 'linear'), ('reshape', (8, 8, 8)), ('deconv', 64, 4, 1, a),
+         ('deconv', 64, 4, 2, a), ('deconv', 32, 4, 2, a), ('deconv', 32, 4, 2, a),
+         ('conv', n_channels * n_params, 1, 1, 'linear')]
+  return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape),
+              decoder=SequentialNetwork(dec, 'Decoder', (zdim,)), observation=observation,
+              latents=RVconf((zdim,), qz, projection=True, name='latents'))
+
+
+def mnist_networks(qz='mvndiag', zdim=None, activation='elu', is_semi_supervised=False,
+                   is_hierarchical=False, centerize_image=True, distribution='bernoulli',
+                   n_channels=1, **kwargs):
+  """image_networks.py:223-292."""
+  if is_hierarchical or is_semi_supervised:
+    raise NotImplementedError('hierarchical / semi-supervised stacks are out of scope (SURVEY 8)')
+  if zdim is None:
+    zdim = 32
+  input_shape = (28, 28, n_channels)
+  n_params, observation = _observation(input_shape, distribution)
+  a = activation
+  enc = ([('center',)] if centerize_image else []) + [
+      ('conv', 32, 5, 1, a), ('conv', 32, 5, 2, a), ('conv', 64, 5, 1, a), ('conv', 64, 5, 2, a),
+      ('flatten',), ('dense', 196, 'linear')]
+  dec = [('dense', 196, 'linear'), ('reshape', (7, 7, 4)), ('deconv', 64, 5, 2, a),
+         ('conv', 64, 5, 1, a), ('deconv', 32, 5, 2, a), ('conv', 32, 5, 1, a),
+         ('conv', n_channels * n_params, 1, 1, 'linear')]
+  return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape),
+              decoder=SequentialNetwork(dec, 'Decoder', (zdim,)), observation=observation,
+              latents=RVconf((zdim,), qz, projection=True, name='latents'))
+
+
+def dense_networks(input_shape=(28, 28, 1), zdim=16, units=(512, 512), activation='relu',
+                   distribution='bernoulli', **kwargs):
+  """VariationalAutoencoder defaults (variational_autoencoder.py:181-185): NetConf((512,512),
+  flatten_inputs=True) encoder/decoder (dense_network, base_networks.py:965-1022),
+  RVconf(16,'mvndiag',projection=True) latents, RVconf(shape,'bernoulli',projection=True)
+  observation (its Dense projection is the decoder's last layer here)."""
+  if zdim is None:
+    zdim = 16
+  n = 1
+  for i in input_shape:
+    n *= i
+  n_params, observation = _observation(input_shape, distribution)
+  observation.projection = True
+  enc = [('flatten',)] + [('dense', u, activation) for u in units]
+  dec = [('dense', u, activation) for u in units] + [
+      ('dense', n * n_params, 'linear'),
+      ('reshape', tuple(input_shape[:-1]) + (input_shape[-1] * n_params,))]
+  return dict(encoder=SequentialNetwork(enc, 'Encoder', tuple(input_shape)),
+              decoder=SequentialNetwork(dec, 'Decoder', (zdim,)), observation=observation,
+              latents=RVconf((zdim,), 'mvndiag', projection=True, name='latents'))
+
+
+_DATASETS = {
+    'mnist': mnist_networks, 'binarizedmnist': mnist_networks, 'fashionmnist': mnist_networks,
+    'dsprites': dsprites_networks, 'dspritesc': dsprites_networks,
+    'shapes3d': shapes3d_networks, 'shapes3dsmall': shapes3d_networks,
+    'celeba': celeba_networks, 'celebasmall': celeba_networks,
+    'dense': dense_networks,
+}
+
+
+def get_networks(dataset_name: str, *, is_semi_supervised: bool = False,
+                 is_hierarchical: bool = False, qz: str = 'mvndiag', zdim: Optional[int] = None,
+                 **kwargs) -> Dict[str, object]:
+  """odin.networks.get_networks (image_networks.py:907-933)."""
+  name = str(dataset_name).lower().strip().replace('_', '')
+  if zdim is not None and zdim <= 0:
+    zdim = None
+  if name not in _DATASETS:
+    raise ValueError(f"Cannot find pre-implemented network for dataset with name='{dataset_name}'")
+  return _DATASETS[name](qz=qz, zdim=zdim, is_semi_supervised=is_semi_supervised,
+                         is_hierarchical=is_hierarchical, **kwargs)

@@ -71,9 +71,12 @@ def check_engine_vs_oracle(eng, model: vo.OracleVAE, P, x, eps, beta, lr=1e-3, t
       P[k], M[k], V[k] = vo.adam_keras(P[k], G[k], M[k], V[k], t, lr)
     pv = {k: v.cpu().numpy() for k, v in eng.param_views().items()}
     for k in keys:
-      # Adam's first steps move every weight by ~lr regardless of the gradient scale, so
-      # compare the UPDATE with an absolute tolerance relative to lr
-      err = np.abs(pv[k] - P[k]).max()
-      assert err <= max(tol * lr * 50, 2e-6), (t, 'param', k, err)
+      # Adam normalises each element's update to ~lr whatever the gradient's scale, so
+      # elements whose gradient is tiny relative to the tensor's max amplify fp32 rounding
+      # (update error ~ lr * dg/|g|).  Bar: the north-star's absolute 1e-4 on every
+      # element, plus a tight bound on the MEAN error in units of the step size.
+      d = np.abs(pv[k] - P[k])
+      assert d.max() <= tol, (t, 'param', k, d.max())
+      assert d.mean() <= 5e-3 * lr, (t, 'param-mean', k, d.mean())
     # continue from the oracle's parameters so that errors do not compound in the check
   return report
