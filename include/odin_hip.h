@@ -69,6 +69,21 @@ int odin_deconv2d_dgrad(const float* dy, const float* w, const float* aux, int a
 int odin_deconv2d_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out,
                         const odin_conv_desc* d, void* stream);
 
+/* ---- fused decoder tail of the TRAINING step: layer (Conv2DTranspose if is_deconv else
+ * Conv2D, activation d->act, Cout<=32) -> Conv2D 1x1 linear with C1<=4 maps (w1 [Cout,C1],
+ * b1 [C1]) -> Independent(Bernoulli(logits),3).log_prob(target), forward AND backward:
+ *   logits (optional out), g_out = dL/d(pre-activation of the layer) for
+ *   L = -scale[0]*sum llk, llk_part[b][part] (n_part per sample), and
+ *   tail_slab[g][Cout*C1 (dW1) | C1 (db1) | Cout (db of the layer)], g < *slab_rows_out.
+ * The [B,OH,OW,Cout] activation never reaches HBM.  Replaces decoder4->decoder6->Bernoulli
+ * (odin/networks/image_networks.py:505-511,87-93) + px.log_prob(x)
+ * (variational_autoencoder.py:528-530) + their tape.gradient.  g_out==NULL = dry run. */
+int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const float* w, const float* bias,
+                                const float* w1, const float* b1, const float* target,
+                                float* logits, float* g_out, float* llk_part, int* n_part_out,
+                                float* tail_slab, int* slab_rows_out, const float* scale,
+                                const odin_conv_desc* d, int C1, void* stream);
+
 /* ---- Dense (keras Dense: base_networks.py:1002-1014; DistributionDense projection:
  * odin/bay/layers/dense_distribution.py:229-238) ------------------------------------- */
 int odin_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K,
@@ -79,12 +94,14 @@ int odin_dense_dgrad(const float* dy, const float* w, const float* aux, int aux_
 int odin_dense_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out, int B,
                      int K, int N, void* stream);
 
-/* dst[j][i] = sum_{g<G} src[j][g*n_j + i]; up to 64 jobs per launch. */
+/* dst[i] = sum_{g<rows} src[g*stride + i], i < n; any number of jobs per call. */
 typedef struct odin_reduce_job {
   const float* src;
   float* dst;
-  int n;      /* elements per slab row */
+  int n;      /* elements reduced per row */
   int rows;   /* G */
+  int stride; /* floats between consecutive slab rows (0 = n) */
+  int pad_;
 } odin_reduce_job;
 int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* stream);
 

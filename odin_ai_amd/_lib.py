@@ -25,7 +25,8 @@ class ConvDesc(C.Structure):
 
 
 class ReduceJob(C.Structure):
-  _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('n', C.c_int), ('rows', C.c_int)]
+  _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('n', C.c_int), ('rows', C.c_int),
+              ('stride', C.c_int), ('pad_', C.c_int)]
 
 
 P = C.c_void_p
@@ -44,6 +45,7 @@ SIGNATURES = {
     'odin_deconv2d_fwd': [P, P, P, P, DP, P],
     'odin_deconv2d_dgrad': [P, P, P, I, P, P, IP, DP, P],
     'odin_deconv2d_wgrad': [P, P, P, IP, DP, P],
+    'odin_bernoulli_tail_fwd_bwd': [I, P, P, P, P, P, P, P, P, P, IP, P, IP, P, DP, I, P],
     'odin_dense_fwd': [P, P, P, P, I, I, I, I, P],
     'odin_dense_dgrad': [P, P, P, I, P, P, IP, I, I, I, P],
     'odin_dense_wgrad': [P, P, P, IP, I, I, I, P],

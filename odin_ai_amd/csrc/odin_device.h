@@ -24,6 +24,16 @@ __device__ __forceinline__ float odin_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float odin_log(float x) { return __logf(x); }
 #endif
 
+#ifdef ODIN_SIM
+#define ODIN_SCHED_GROUP(mask, n) ((void)0)
+#define ODIN_SCHED_FENCE() ((void)0)
+#else
+#define ODIN_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define ODIN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#define ODIN_SG_MFMA 0x8
+#define ODIN_SG_DSREAD 0x100
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -39,73 +39,141 @@ struct WParams {
   int patch_floats, dy_floats;
 };
 
-__device__ __forceinline__ void w_stage_patch(const WParams& p, float* patch, int b0, int ih_lo,
-                                              int c0, int cib, int tid, int nthreads) {
-  const bool vec = ((p.CI & 3) == 0) && ((p.P & 3) == 0) && ((c0 & 3) == 0) && ((cib & 3) == 0);
-  if (vec) {
-    const int c4n = p.P >> 2;
-    const int total = p.NIMG * p.NRI * p.PW * c4n;
-    for (int e = tid; e < total; e += nthreads) {
-      int c4 = e % c4n, q = e / c4n;
-      int pcol = q % p.PW, q2 = q / p.PW;
-      int prow = q2 % p.NRI, img = q2 / p.NRI;
-      int b = b0 + img, ih = ih_lo + prow, iw = pcol - p.pl, cl = c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b < p.B && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && cl < cib) {
-        v = *reinterpret_cast<const float4*>(p.in + (((size_t)b * p.H + ih) * p.W + iw) * p.CI + c0 + cl);
-        if (p.center) {
-          v.x = 2.f * v.x - 1.f; v.y = 2.f * v.y - 1.f;
-          v.z = 2.f * v.z - 1.f; v.w = 2.f * v.w - 1.f;
-        }
-      }
-      *reinterpret_cast<float4*>(patch + ((img * p.NRI + prow) * p.PW + pcol) * p.P + cl) = v;
-    }
+// ---- staging: work items (float4 when channel counts allow) decoded with magic-number
+// divisions; the next tile's IN patch and DY rows are prefetched into registers while the
+// current tile is being multiplied -----------------------------------------------------
+constexpr int MAXV_W = 28;
+
+__device__ __forceinline__ unsigned w_magic(int d) {
+  return d <= 1 ? 0u : (unsigned)(4294967296.0 / d) + 1u;
+}
+__device__ __forceinline__ int w_div(int e, int d, unsigned m) {
+  if (d <= 1) return e;
+  int q = (int)__umulhi((unsigned)e, m);
+  if (q * d > e) --q;
+  return q;
+}
+
+struct WGeom {
+  int pvec, pcpi, prowlen, ptotal;  // patch items
+  unsigned pm_row, pm_cpi;
+  int dvec, dcpi, dtotal;           // dy items
+  unsigned dm_cpi;
+};
+
+__device__ __forceinline__ WGeom w_geom(const WParams& p, int ci0, int cib) {
+  WGeom g;
+  g.pvec = (((p.CI & 3) == 0) && ((p.P & 3) == 0) && ((ci0 & 3) == 0) && ((cib & 3) == 0)) ? 1 : 0;
+  g.pcpi = g.pvec ? (p.P >> 2) : p.P;
+  g.prowlen = p.PW * g.pcpi;
+  g.ptotal = p.NIMG * p.NRI * g.prowlen;
+  g.pm_row = w_magic(g.prowlen);
+  g.pm_cpi = w_magic(g.pcpi);
+  g.dvec = (((p.CO & 3) == 0) && ((p.COB & 3) == 0)) ? 1 : 0;
+  g.dcpi = g.dvec ? (p.COB >> 2) : p.COB;
+  g.dtotal = p.slots * g.dcpi;
+  g.dm_cpi = w_magic(g.dcpi);
+  return g;
+}
+
+// item e of the combined (patch ++ dy) work list -> (LDS float index, global float offset or -1)
+__device__ __forceinline__ void w_item(const WParams& p, const WGeom& g, int e, int b0, int ih_lo,
+                                       int gr0, int ci0, int cib, int co0, int* lds, long* gofs,
+                                       int* is_vec, int* from_dy) {
+  if (e < g.ptotal) {
+    int row = w_div(e, g.prowlen, g.pm_row);
+    int j = e - row * g.prowlen;
+    int pcol = w_div(j, g.pcpi, g.pm_cpi);
+    int cl = (j - pcol * g.pcpi) * (g.pvec ? 4 : 1);
+    int img = (p.NIMG == 1) ? 0 : row / p.NRI;
+    int prow = row - img * p.NRI;
+    int b = b0 + img, ih = ih_lo + prow, iw = pcol - p.pl;
+    *lds = (row * p.PW + pcol) * p.P + cl;
+    bool ok = (b < p.B) && (ih >= 0) && (ih < p.H) && (iw >= 0) && (iw < p.W) && (cl < cib);
+    *gofs = ok ? ((((long)b * p.H + ih) * p.W + iw) * p.CI + ci0 + cl) : -1;
+    *is_vec = g.pvec;
+    *from_dy = 0;
   } else {
-    const int total = p.NIMG * p.NRI * p.PW * p.P;
-    for (int e = tid; e < total; e += nthreads) {
-      int cl = e % p.P, q = e / p.P;
-      int pcol = q % p.PW, q2 = q / p.PW;
-      int prow = q2 % p.NRI, img = q2 / p.NRI;
-      int b = b0 + img, ih = ih_lo + prow, iw = pcol - p.pl;
-      float v = 0.f;
-      if (b < p.B && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && cl < cib) {
-        v = p.in[(((size_t)b * p.H + ih) * p.W + iw) * p.CI + c0 + cl];
-        if (p.center) v = 2.f * v - 1.f;
+    int d = e - g.ptotal;
+    int sl = w_div(d, g.dcpi, g.dm_cpi);
+    int cl = (d - sl * g.dcpi) * (g.dvec ? 4 : 1);
+    const long total_pix = (long)p.B * p.OH * p.OW;
+    const long pix = (long)gr0 * p.OW + sl;
+    bool ok = (sl < p.TR * p.OW) && (pix < total_pix) && (co0 + cl < p.CO);
+    *lds = p.patch_floats + sl * p.DP + cl;
+    *gofs = ok ? (pix * p.CO + co0 + cl) : -1;
+    *is_vec = g.dvec;
+    *from_dy = 1;
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void w_prefetch_issue(const WParams& p, const WGeom& g, float4* pf,
+                                                 int b0, int ih_lo, int gr0, int ci0, int cib,
+                                                 int co0, int tid) {
+  const int total = g.ptotal + g.dtotal;
+#pragma unroll
+  for (int i = 0; i < MAXV_W; ++i) {
+    int e = tid + i * NT;
+    if (e < total) {
+      int lds, isv, fdy;
+      long go;
+      w_item(p, g, e, b0, ih_lo, gr0, ci0, cib, co0, &lds, &go, &isv, &fdy);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (go >= 0) {
+        const float* src = (fdy ? p.dy : p.in) + go;
+        if (isv) v = *reinterpret_cast<const float4*>(src);
+        else v.x = src[0];
+        if (p.center && !fdy)
+          v = make_float4(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f, 2.f * v.w - 1.f);
       }
-      patch[e] = v;
+      pf[i] = v;
     }
   }
 }
 
-__device__ __forceinline__ void w_stage_dy(const WParams& p, float* dyl, int gr0, int co0,
-                                           int tid, int nthreads) {
-  const long total_pix = (long)p.B * p.OH * p.OW;
-  const long pix0 = (long)gr0 * p.OW;
-  const int real_slots = p.TR * p.OW;
-  const bool vec = ((p.CO & 3) == 0) && ((p.COB & 3) == 0);
-  if (vec) {
-    const int c4n = p.COB >> 2;
-    const int total = p.slots * c4n;
-    for (int e = tid; e < total; e += nthreads) {
-      int c4 = e % c4n, s = e / c4n;
-      int co = co0 + c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (s < real_slots && pix0 + s < total_pix && co < p.CO)
-        v = *reinterpret_cast<const float4*>(p.dy + (size_t)(pix0 + s) * p.CO + co);
-      *reinterpret_cast<float4*>(dyl + s * p.DP + c4 * 4) = v;
-    }
-  } else {
-    const int total = p.slots * p.COB;
-    for (int e = tid; e < total; e += nthreads) {
-      int cl = e % p.COB, s = e / p.COB;
-      int co = co0 + cl;
-      float v = 0.f;
-      if (s < real_slots && pix0 + s < total_pix && co < p.CO) v = p.dy[(size_t)(pix0 + s) * p.CO + co];
-      dyl[s * p.DP + cl] = v;
+template <int NT>
+__device__ __forceinline__ void w_prefetch_commit(const WParams& p, const WGeom& g,
+                                                  const float4* pf, float* smem, int ci0, int cib,
+                                                  int co0, int tid) {
+  const int total = g.ptotal + g.dtotal;
+#pragma unroll
+  for (int i = 0; i < MAXV_W; ++i) {
+    int e = tid + i * NT;
+    if (e < total) {
+      int lds, isv, fdy;
+      long go;
+      w_item(p, g, e, 0, 0, 0, ci0, cib, co0, &lds, &go, &isv, &fdy);
+      float4 v = pf[i];
+      if (isv) *reinterpret_cast<float4*>(smem + lds) = v;
+      else smem[lds] = v.x;
     }
   }
 }
 
+// synchronous staging for tiles too large to prefetch through registers
+__device__ __forceinline__ void w_stage_sync(const WParams& p, const WGeom& g, float* smem, int b0,
+                                             int ih_lo, int gr0, int ci0, int cib, int co0, int tid,
+                                             int nthreads) {
+  const int total = g.ptotal + g.dtotal;
+  for (int e = tid; e < total; e += nthreads) {
+    int lds, isv, fdy;
+    long go;
+    w_item(p, g, e, b0, ih_lo, gr0, ci0, cib, co0, &lds, &go, &isv, &fdy);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (go >= 0) {
+      const float* src = (fdy ? p.dy : p.in) + go;
+      if (isv) v = *reinterpret_cast<const float4*>(src);
+      else v.x = src[0];
+      if (p.center && !fdy)
+        v = make_float4(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f, 2.f * v.w - 1.f);
+    }
+    if (isv) *reinterpret_cast<float4*>(smem + lds) = v;
+    else smem[lds] = v.x;
+  }
+}
+
+template <int TNACC>
 __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
@@ -121,6 +189,8 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   const int n_wt = p.nrt * p.ncot;
   const int n_bias = (p.want_bias && blockIdx.y == 0) ? p.ncot : 0;
   const int n_tot = n_wt + n_bias;
+  const WGeom wg = w_geom(p, ci0, cib);
+  const bool pipelined = (wg.ptotal + wg.dtotal) <= MAXV_W * NT;
 
   // slot -> patch base table (identical for every tile of this launch)
   for (int s = tid; s < p.slots; s += NT) {
@@ -130,9 +200,9 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   }
 
   // per-accumulator lane constants
-  int a_off[NACC], b_off[NACC], a_kind[NACC];  // kind 0: zero row, 1: patch, 2: ones (bias)
+  int a_off[TNACC], b_off[TNACC], a_kind[TNACC];  // kind 0: zero row, 1: patch, 2: ones (bias)
 #pragma unroll
-  for (int a = 0; a < NACC; ++a) {
+  for (int a = 0; a < TNACC; ++a) {
     int T = wave + a * NW_W;
     a_off[a] = 0;
     b_off[a] = l31;
@@ -153,38 +223,62 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     }
   }
 
-  f32x16 acc[NACC];
+  f32x16 acc[TNACC];
 #pragma unroll
-  for (int a = 0; a < NACC; ++a) acc[a] = f32x16_zero();
+  for (int a = 0; a < TNACC; ++a) acc[a] = f32x16_zero();
 
-  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+  float4 pf[MAXV_W];
+  int tile = blockIdx.x;
+  if (pipelined && tile < p.n_tiles) {
+    const int gr0 = tile * p.TR;
+    const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
+    w_prefetch_issue<NT>(p, wg, pf, b0, oh0 * p.S - p.pt, gr0, ci0, cib, co0, tid);
+  }
+
+  for (; tile < p.n_tiles; tile += gridDim.x) {
     const int gr0 = tile * p.TR;
     const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
     const int ih_lo = oh0 * p.S - p.pt;
     __syncthreads();
-    w_stage_patch(p, patch, b0, ih_lo, ci0, cib, tid, NT);
-    w_stage_dy(p, dyl, gr0, co0, tid, NT);
-    __syncthreads();
+    if (pipelined) {
+      w_prefetch_commit<NT>(p, wg, pf, smem, ci0, cib, co0, tid);
+      __syncthreads();
+      const int nt = tile + gridDim.x;
+      if (nt < p.n_tiles) {
+        const int g2 = nt * p.TR;
+        const int b2 = g2 / p.OH, o2 = g2 - b2 * p.OH;
+        w_prefetch_issue<NT>(p, wg, pf, b2, o2 * p.S - p.pt, g2, ci0, cib, co0, tid);
+      }
+    } else {
+      w_stage_sync(p, wg, smem, b0, ih_lo, gr0, ci0, cib, co0, tid, NT);
+      __syncthreads();
+    }
     const int npairs = p.slots >> 1;
+    int base_n = tbl[h];
     for (int kp = 0; kp < npairs; ++kp) {
       const int s = 2 * kp + h;
-      const int base = tbl[s];
+      const int base = base_n;
+      if (kp + 1 < npairs) base_n = tbl[s + 2];  // next pair's table entry, off the critical path
       const float* brow = dyl + s * p.DP;
+      float av[TNACC], bv[TNACC];
 #pragma unroll
-      for (int a = 0; a < NACC; ++a) {
+      for (int a = 0; a < TNACC; ++a) {
         if (wave + a * NW_W < n_tot) {  // wave-uniform
-          float av = patch[base + a_off[a]];
-          av = (a_kind[a] == 1) ? av : (a_kind[a] == 2 ? 1.f : 0.f);
-          acc[a] = mfma32(av, brow[b_off[a]], acc[a]);
+          float t = patch[base + a_off[a]];
+          av[a] = (a_kind[a] == 1) ? t : (a_kind[a] == 2 ? 1.f : 0.f);
+          bv[a] = brow[b_off[a]];
         }
       }
+#pragma unroll
+      for (int a = 0; a < TNACC; ++a)
+        if (wave + a * NW_W < n_tot) acc[a] = mfma32(av[a], bv[a], acc[a]);
     }
   }
 
   // ---- write this workgroup's partial tiles into its slab row ----
   float* row = p.slab + (size_t)blockIdx.x * p.slab_stride;
 #pragma unroll
-  for (int a = 0; a < NACC; ++a) {
+  for (int a = 0; a < TNACC; ++a) {
     int T = wave + a * NW_W;
     if (T < n_wt) {
       int rt = T / p.ncot, cot = T - rt * p.ncot;
@@ -274,13 +368,19 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<5>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NACC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
 #endif
   dim3 grid(gx, gy, gz), block(NW_W * 64);
-  ODIN_LAUNCH(wgrad_kernel, grid, block, lds, stream, p);
+  const int tiles_per_block = p.nrt * p.ncot + (p.want_bias ? p.ncot : 0);
+  if ((tiles_per_block + NW_W - 1) / NW_W <= 5)
+    ODIN_LAUNCH(wgrad_kernel<5>, grid, block, lds, stream, p);
+  else
+    ODIN_LAUNCH(wgrad_kernel<NACC>, grid, block, lds, stream, p);
   return odin_check_launch("wgrad");
 }
 
@@ -291,17 +391,18 @@ struct ReduceJobs {
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceJobs jobs) {
   const odin_reduce_job jb = jobs.j[blockIdx.y];
+  const size_t st = jb.stride > 0 ? (size_t)jb.stride : (size_t)jb.n;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < jb.n; i += gridDim.x * 256) {
     const float* s = jb.src + i;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int g = 0;
     for (; g + 3 < jb.rows; g += 4) {
-      a0 += s[(size_t)g * jb.n];
-      a1 += s[(size_t)(g + 1) * jb.n];
-      a2 += s[(size_t)(g + 2) * jb.n];
-      a3 += s[(size_t)(g + 3) * jb.n];
+      a0 += s[(size_t)g * st];
+      a1 += s[(size_t)(g + 1) * st];
+      a2 += s[(size_t)(g + 2) * st];
+      a3 += s[(size_t)(g + 3) * st];
     }
-    for (; g < jb.rows; ++g) a0 += s[(size_t)g * jb.n];
+    for (; g < jb.rows; ++g) a0 += s[(size_t)g * st];
     jb.dst[i] = (a0 + a1) + (a2 + a3);
   }
 }

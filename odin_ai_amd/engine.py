@@ -186,10 +186,11 @@ class NetProgram:
     return self.params[r.b_off:r.b_off + r.b_n]
 
   # -- forward --------------------------------------------------------------------------
-  def forward(self, x: torch.Tensor, st):
+  def forward(self, x: torch.Tensor, st, upto: Optional[int] = None):
+    """run layers [0, upto) (all when None); returns the last output (or x)."""
     lib, B = self.lib, self.B
     h = x
-    for i, r in enumerate(self.recs):
+    for i, r in enumerate(self.recs[:upto]):
       y = self.outs[i]
       if r.kind == 'conv':
         lib.odin_conv2d_fwd(h.data_ptr(), self.w(i).data_ptr(), self.b(i).data_ptr(),
@@ -205,11 +206,12 @@ class NetProgram:
 
   # -- backward -------------------------------------------------------------------------
   def backward(self, x: torch.Tensor, gout_last: torch.Tensor, st,
-               dx_out: Optional[torch.Tensor] = None) -> List[ReduceJob]:
+               dx_out: Optional[torch.Tensor] = None, last: Optional[int] = None,
+               skip_bias_of_last: bool = False) -> List[ReduceJob]:
     """gout_last: dL/d(pre-activation output of the last layer).  If dx_out is given the
     gradient wrt the network input is written there.  Returns the slab-reduce jobs."""
     lib, B = self.lib, self.B
-    n = len(self.recs)
+    n = len(self.recs) if last is None else last + 1
     jobs: List[ReduceJob] = []
     g = gout_last
     rows = C.c_int(0)
@@ -228,8 +230,11 @@ class NetProgram:
         lib.odin_dense_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows), B,
                              r.K, r.N, st)
       assert rows.value == self.wrows[i]
-      jobs.append(ReduceJob(slab.data_ptr(), self.grads[r.w_off:].data_ptr(), slab.shape[1],
-                            rows.value))
+      n_red = slab.shape[1]
+      if skip_bias_of_last and i == n - 1 and r.kind != 'deconv':
+        n_red = r.w_n  # the fused tail already delivers this layer's bias gradient
+      jobs.append(ReduceJob(slab.data_ptr(), self.grads[r.w_off:].data_ptr(), n_red, rows.value,
+                            slab.shape[1], 0))
       # ---- data gradient -> pre-activation gradient of the previous layer ----
       if i > 0:
         prev = self.recs[i - 1]
@@ -253,7 +258,7 @@ class NetProgram:
       if bslab is not None:
         pr = self.recs[i - 1]
         jobs.append(ReduceJob(bslab.data_ptr(), self.grads[pr.b_off:].data_ptr(), pr.b_n,
-                              rows.value))
+                              rows.value, pr.b_n, 0))
       g = dst
     return jobs
 
@@ -333,6 +338,7 @@ class VAEEngine:
       self.tc_dz = torch.empty(B, D, **f32)
       self.tc_dloc = torch.empty(B, D, **f32)
       self.tc_dscale = torch.empty(B, D, **f32)
+    self._plan_fused_tail(f32)
     self.ws = torch.empty(1024, **f32)
     self.gnorm2 = torch.zeros(1, **f32)
     self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -348,6 +354,35 @@ class VAEEngine:
     self.step_count = 0
     self.graph = None
     self._jobs_keepalive = None
+
+  def _plan_fused_tail(self, f32):
+    """Training-step fusion layer[-2](act) -> Conv2D 1x1 -> Bernoulli log-prob + backward
+    (odin_bernoulli_tail_fwd_bwd) when the decoder ends that way."""
+    self.fused_tail = False
+    recs = self.dec_recs
+    if self.observation != 'bernoulli' or len(recs) < 2:
+      return
+    a, b = recs[-2], recs[-1]
+    if not (b.kind == 'conv' and b.desc['K'] == 1 and b.desc['stride'] == 1 and b.act == 'linear'
+            and b.desc['Cout'] <= 4 and a.kind in ('conv', 'deconv') and a.desc['Cout'] <= 32):
+      return
+    rows, npart = C.c_int(0), C.c_int(0)
+    try:
+      self.lib.odin_bernoulli_tail_fwd_bwd(int(a.kind == 'deconv'), None, None, None, None, None,
+                                           None, None, None, None, C.byref(npart), None,
+                                           C.byref(rows), None, C.byref(self.dec.descs[-2]),
+                                           b.desc['Cout'], None)
+    except _lib.OdinError:
+      return
+    # a dry run cannot see the one-image-per-tile requirement; it holds when the layer's
+    # output image has more pixels than one tile (128)
+    if a.desc['OH'] * a.desc['OW'] <= 128:
+      return
+    self.fused_tail = True
+    self.tail_rows, self.tail_npart = rows.value, npart.value
+    co, c1 = a.desc['Cout'], b.desc['Cout']
+    self.tail_slab = torch.empty(rows.value, co * c1 + c1 + co, **f32)
+    self.tail_llk_part = torch.empty(self.B * npart.value, **f32)
 
   # ---- helpers -----------------------------------------------------------------------
   def hp(self, idx):  # device address of one hyper scalar
@@ -397,7 +432,7 @@ class VAEEngine:
 
   # ---- forward -----------------------------------------------------------------------
   def forward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, st=None,
-              with_grad_seed: bool = True):
+              fused: bool = True):
     """Runs encode -> reparameterise -> decode -> ELBO (+ dlogits).  `eps=None` draws the
     noise on device from the Philox stream (seed, step)."""
     lib, B, D = self.lib, self.B, self.D
@@ -416,10 +451,30 @@ class VAEEngine:
     lib.odin_latent_fwd(self.p.data_ptr(), self.eps.data_ptr(), self.z.data_ptr(),
                         self.kl.data_ptr(), self.fbmask.data_ptr(), B, D, int(self.analytic),
                         self.free_bits, st)
-    h_d = self.dec.forward(self.z, st)
     npart = C.c_int(0)
+    if self.fused_tail and fused:
+      nd = len(self.dec_recs)
+      h = self.dec.forward(self.z, st, upto=nd - 2)
+      a, b = self.dec_recs[-2], self.dec_recs[-1]
+      rows = C.c_int(0)
+      lib.odin_bernoulli_tail_fwd_bwd(
+          int(a.kind == 'deconv'), h.data_ptr(), self.dec.w(nd - 2).data_ptr(),
+          self.dec.b(nd - 2).data_ptr(), self.dec.w(nd - 1).data_ptr(),
+          self.dec.b(nd - 1).data_ptr(), x.data_ptr(), self.dec.outs[-1].data_ptr(),
+          self.dec.gouts[-2].data_ptr(), self.tail_llk_part.data_ptr(), C.byref(npart),
+          self.tail_slab.data_ptr(), C.byref(rows), self.hp(H_INVB), C.byref(self.dec.descs[-2]),
+          b.desc['Cout'], st)
+      self._used_fused = True
+      llk_part = self.tail_llk_part
+      h_d = self.dec.outs[-1]
+    else:
+      self._used_fused = False
+      llk_part = self.llk_part
+      h_d = self.dec.forward(self.z, st)
     gl = self.dec.gouts[-1]
-    if self.observation == 'bernoulli':
+    if self._used_fused:
+      pass
+    elif self.observation == 'bernoulli':
       lib.odin_elbo_bernoulli_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
                                       gl.data_ptr(), self.hp(H_INVB), B, self.n_per,
                                       C.byref(npart), st)
@@ -437,7 +492,7 @@ class VAEEngine:
                                          self.tc_dloc.data_ptr(), self.tc_dscale.data_ptr(),
                                          self.hp(H_TCGRAD), B, D, st)
       tcp = self.tc_ws.data_ptr()
-    lib.odin_elbo_finalize(self.llk_part.data_ptr(), self.n_part, self.kl.data_ptr(),
+    lib.odin_elbo_finalize(llk_part.data_ptr(), self.n_part, self.kl.data_ptr(),
                            self.hp(H_BETA), tcp, self.llk.data_ptr(), self.out4.data_ptr(), B, st)
     return h_d
 
@@ -445,7 +500,20 @@ class VAEEngine:
   def backward(self, st=None, extra_dz: Optional[torch.Tensor] = None):
     lib, B, D = self.lib, self.B, self.D
     st = self.stream() if st is None else st
-    jobs = self.dec.backward(self.z, self.dec.gouts[-1], st, dx_out=self.dz)
+    if self._used_fused:
+      nd = len(self.dec_recs)
+      a, b = self.dec_recs[-2], self.dec_recs[-1]
+      co, c1 = a.desc['Cout'], b.desc['Cout']
+      jobs = self.dec.backward(self.z, self.dec.gouts[-2], st, dx_out=self.dz, last=nd - 2,
+                               skip_bias_of_last=True)
+      ts, stride = self.tail_slab, self.tail_slab.shape[1]
+      # (dW1 | db1) of the 1x1 conv, then the bias gradient of the fused layer
+      jobs.append(ReduceJob(ts.data_ptr(), self.grads[b.w_off:].data_ptr(), co * c1 + c1,
+                            self.tail_rows, stride, 0))
+      jobs.append(ReduceJob(ts[:, co * c1 + c1:].data_ptr(), self.grads[a.b_off:].data_ptr(), co,
+                            self.tail_rows, stride, 0))
+    else:
+      jobs = self.dec.backward(self.z, self.dec.gouts[-1], st, dx_out=self.dz)
     dzx = extra_dz.data_ptr() if extra_dz is not None else None
     if self.tc_mode == 'betatc':
       assert extra_dz is None
@@ -460,7 +528,7 @@ class VAEEngine:
     lib.odin_dense_wgrad(h_e.data_ptr(), self.dp.data_ptr(), self.lat_slab.data_ptr(),
                          C.byref(rows), B, self.hdim, 2 * D, st)
     jobs.append(ReduceJob(self.lat_slab.data_ptr(), self.grads[self.lat_w_off:].data_ptr(),
-                          self.lat_slab.shape[1], rows.value))
+                          self.lat_slab.shape[1], rows.value, self.lat_slab.shape[1], 0))
     last = self.enc_recs[-1]
     aux_act = ACT[last.act]
     auxp = h_e.data_ptr() if aux_act != 0 else None
@@ -472,7 +540,7 @@ class VAEEngine:
                          self.hdim, 2 * D, st)
     if bslab is not None:
       jobs.append(ReduceJob(bslab.data_ptr(), self.grads[last.b_off:].data_ptr(), last.b_n,
-                            rows.value))
+                            rows.value, last.b_n, 0))
     jobs += self.enc.backward(self.x, self.enc.gouts[-1], st)
     arr = (ReduceJob * len(jobs))(*jobs)
     self._jobs_keepalive = arr

@@ -22,8 +22,18 @@ def tiny_conv_spec(C=1, zdim=5):
   return enc, dec, (8, 8, C), zdim
 
 
+def tiny16_spec(C=1, zdim=5):
+  enc = [('center',), ('conv', 8, 4, 2, 'elu'), ('conv', 16, 4, 2, 'elu'), ('flatten',),
+         ('dense', 24, 'linear')]
+  dec = [('dense', 128, 'linear'), ('reshape', (4, 4, 8)), ('deconv', 16, 4, 2, 'elu'),
+         ('deconv', 8, 4, 2, 'elu'), ('conv', C, 1, 1, 'linear')]
+  return enc, dec, (16, 16, C), zdim
+
+
 CASES = [
     ('tiny', dict(beta=4.0), 'bernoulli', 1),
+    ('tiny16_fused_tail', dict(beta=4.0), 'bernoulli', 1),
+    ('tiny16_fused_tail', dict(beta=2.0), 'bernoulli', 3),
     ('tiny', dict(beta=1.0, analytic=True, free_bits=0.3), 'bernoulli', 3),
     ('tiny_tc', dict(beta=3.0, tc_beta=3.0), 'bernoulli', 3),
     ('tiny_gauss', dict(beta=2.0), 'gaussian_softplus1', 3),
@@ -43,6 +53,8 @@ def test_engine_step_matches_oracle(L, name, kw, obs, C):
     e, d, s, z = tiny_conv_spec(C)
     d = d[:-1] + [('conv', 2 * C, 1, 1, 'linear')]
     spec = (e, d, s, z)
+  elif name.startswith('tiny16'):
+    spec = tiny16_spec(C)
   else:
     spec = tiny_conv_spec(C)
   enc, dec, in_shape, zdim, x, eps = make_case(spec, obs, B)
@@ -51,4 +63,5 @@ def test_engine_step_matches_oracle(L, name, kw, obs, C):
   eng = VAEEngine(enc, dec, in_shape, zdim, B, 'cpu', observation=obs,
                   analytic=kw.get('analytic', False), free_bits=kw.get('free_bits'),
                   tc='betatc' if 'tc_beta' in kw else None, lib=L)
+  assert eng.fused_tail == name.startswith('tiny16')
   check_engine_vs_oracle(eng, model, P, x, eps, beta=kw.get('beta', 1.0), steps=2, clip=100.0)

@@ -25,7 +25,7 @@ def T(a):
 
 def reduce_slab(L, slab, rows, n):
   out = torch.zeros(n)
-  job = (_lib.ReduceJob * 1)(_lib.ReduceJob(slab.data_ptr(), out.data_ptr(), n, rows))
+  job = (_lib.ReduceJob * 1)(_lib.ReduceJob(slab.data_ptr(), out.data_ptr(), n, rows, slab.shape[1], 0))
   L.odin_slab_reduce(job, 1, None)
   return out.numpy()
 
@@ -164,3 +164,55 @@ def test_dense(L, B, K, N, act):
   g = reduce_slab(L, slab, rows.value, n)
   close(g[:-N].reshape(K, N), dw_ref, 1e-4)
   close(g[-N:], db_ref, 1e-4)
+
+
+@pytest.mark.parametrize('is_deconv,B,H,W,Ci,Co,K,S,C1', [
+    (1, 2, 8, 8, 32, 32, 4, 2, 1),     # specialised <T,4,2,32> instance
+    (1, 3, 8, 8, 8, 16, 4, 2, 3),      # generic transposed
+    (0, 2, 16, 16, 8, 24, 5, 1, 1),    # generic gather conv (MNIST-style decoder tail)
+])
+def test_bernoulli_tail(L, is_deconv, B, H, W, Ci, Co, K, S, C1):
+  rng = np.random.default_rng(3)
+  x = rng.standard_normal((B, H, W, Ci))
+  b = rng.standard_normal(Co) * 0.1
+  w1 = rng.standard_normal((1, 1, Co, C1)) * 0.3
+  b1 = rng.standard_normal(C1) * 0.1
+  if is_deconv:
+    w = rng.standard_normal((K, K, Co, Ci)) * 0.2
+    OH, OW = H * S, W * S
+    _, pt, _ = vo.same_pads(OH, K, S)
+    _, pl, _ = vo.same_pads(OW, K, S)
+    d = vo.elu(vo.conv2d_transpose(x, w, b, S))
+  else:
+    w = rng.standard_normal((K, K, Ci, Co)) * 0.2
+    OH, pt, _ = vo.same_pads(H, K, S)
+    OW, pl, _ = vo.same_pads(W, K, S)
+    d = vo.elu(vo.conv2d(x, w, b, S))
+  desc = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, 'elu')
+  tgt = np.clip(rng.random((B, OH, OW, C1)), 1e-6, 1 - 1e-6)
+  scale = 1.0 / B
+  lg = vo.conv2d(d, w1, b1, 1)
+  llk_ref = vo.bernoulli_log_prob(lg, tgt)
+  dl = -(vo.bernoulli_log_prob_grad(lg, tgt)) * scale
+  dd, dw1_ref, db1_ref = vo.conv2d_bwd(d, w1, dl, 1)
+  g_ref = dd * vo.elu_grad_from_output(d)
+  tx, tw, tb, tw1, tb1, tt, tsc = T(x), T(w), T(b), T(w1), T(b1), T(tgt), T([scale])
+  logits = torch.full((B, OH, OW, C1), float('nan'))
+  g = torch.full((B, OH, OW, Co), float('nan'))
+  rows, npart = C.c_int(0), C.c_int(0)
+  L.odin_bernoulli_tail_fwd_bwd(is_deconv, None, None, None, None, None, None, None, None, None,
+                                C.byref(npart), None, C.byref(rows), None, C.byref(desc), C1, None)
+  part = torch.full((B * npart.value,), float('nan'))
+  n = Co * C1 + C1 + Co
+  slab = torch.full((rows.value, n), float('nan'))
+  L.odin_bernoulli_tail_fwd_bwd(is_deconv, tx.data_ptr(), tw.data_ptr(), tb.data_ptr(),
+                                tw1.data_ptr(), tb1.data_ptr(), tt.data_ptr(), logits.data_ptr(),
+                                g.data_ptr(), part.data_ptr(), C.byref(npart), slab.data_ptr(),
+                                C.byref(rows), tsc.data_ptr(), C.byref(desc), C1, None)
+  close(logits.numpy(), lg)
+  close(part.reshape(B, -1).sum(1).numpy(), llk_ref)
+  close(g.numpy(), g_ref)
+  red = reduce_slab(L, slab, rows.value, n)
+  close(red[:Co * C1].reshape(Co, C1), dw1_ref[0, 0], 1e-4)
+  close(red[Co * C1:Co * C1 + C1], db1_ref, 1e-4)
+  close(red[Co * C1 + C1:], g_ref.sum((0, 1, 2)), 1e-4)
