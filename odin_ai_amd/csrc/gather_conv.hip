@@ -49,27 +49,120 @@ struct GParams {
   int patch_floats, MT, MTP, SPP;  // M-tiles total / per phase, slots per phase
 };
 
+// Weight slice [taps][CIC][32 output channels] -> LDS.  Loads are issued in batches of 8
+// per thread (16-byte loads where the layout allows) so that their latencies overlap; a
+// one-load-per-iteration loop costs a full memory round trip per element.
 __device__ __forceinline__ void stage_weights(const GParams& p, float* wl, int c0, int n0,
                                               int tid, int nthreads) {
   const int ntaps = p.KH * p.KW;
-  const int total = ntaps * p.CIC * 32;
+  constexpr int U = 8;
   if (p.wmode == 0) {
-    for (int e = tid; e < total; e += nthreads) {
-      int co = e & 31, t2 = e >> 5;
-      int ci = t2 % p.CIC, tap = t2 / p.CIC;
-      int c = c0 + ci, n = n0 + co;
-      float v = 0.f;
-      if (c < p.CI && n < p.CO) v = p.w[((size_t)tap * p.CI + c) * p.CO + n];
-      wl[(tap * p.CIC + ci) * p.WP + co] = v;
+    // global [tap][ci][co]: rows of 32 consecutive output channels
+    const bool vec = ((p.CO & 3) == 0);
+    if (vec) {
+      const int total = ntaps * p.CIC * 8;  // float4 items
+      for (int e0 = tid; e0 < total; e0 += nthreads * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int e = e0 + u * nthreads;
+          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (e < total) {
+            int co = (e & 7) * 4, t2 = e >> 3;
+            int ci = t2 % p.CIC, tap = t2 / p.CIC;
+            int c = c0 + ci, n = n0 + co;
+            if (c < p.CI && n < p.CO)
+              v[u] = *reinterpret_cast<const float4*>(p.w + ((size_t)tap * p.CI + c) * p.CO + n);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int e = e0 + u * nthreads;
+          if (e < total) {
+            int co = (e & 7) * 4, t2 = e >> 3;  // t2 = tap*CIC + ci
+            float* d = wl + t2 * p.WP + co;
+            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+          }
+        }
+      }
+    } else {
+      const int total = ntaps * p.CIC * 32;
+      for (int e0 = tid; e0 < total; e0 += nthreads * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int e = e0 + u * nthreads;
+          v[u] = 0.f;
+          if (e < total) {
+            int co = e & 31, t2 = e >> 5;
+            int ci = t2 % p.CIC, tap = t2 / p.CIC;
+            int c = c0 + ci, n = n0 + co;
+            if (c < p.CI && n < p.CO) v[u] = p.w[((size_t)tap * p.CI + c) * p.CO + n];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int e = e0 + u * nthreads;
+          if (e < total) wl[(e >> 5) * p.WP + (e & 31)] = v[u];
+        }
+      }
     }
   } else {
-    for (int e = tid; e < total; e += nthreads) {
-      int ci = e % p.CIC, t2 = e / p.CIC;
-      int co = t2 & 31, tap = t2 >> 5;
-      int c = c0 + ci, n = n0 + co;
-      float v = 0.f;
-      if (c < p.CI && n < p.CO) v = p.w[((size_t)tap * p.CO + n) * p.CI + c];
-      wl[(tap * p.CIC + ci) * p.WP + co] = v;
+    // global [tap][co][ci]: contiguous along the reduction channel; transposed into LDS
+    const bool vec = ((p.CI & 3) == 0) && ((p.CIC & 3) == 0) && ((c0 & 3) == 0);
+    if (vec) {
+      const int c4n = p.CIC >> 2;
+      const int total = ntaps * 32 * c4n;
+      for (int e0 = tid; e0 < total; e0 += nthreads * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int e = e0 + u * nthreads;
+          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (e < total) {
+            int ci = (e % c4n) * 4, t2 = e / c4n;
+            int co = t2 & 31, tap = t2 >> 5;
+            int c = c0 + ci, n = n0 + co;
+            if (c < p.CI && n < p.CO)
+              v[u] = *reinterpret_cast<const float4*>(p.w + ((size_t)tap * p.CO + n) * p.CI + c);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int e = e0 + u * nthreads;
+          if (e < total) {
+            int ci = (e % c4n) * 4, t2 = e / c4n;
+            int co = t2 & 31, tap = t2 >> 5;
+            float* d = wl + (tap * p.CIC + ci) * p.WP + co;
+            d[0] = v[u].x; d[p.WP] = v[u].y; d[2 * p.WP] = v[u].z; d[3 * p.WP] = v[u].w;
+          }
+        }
+      }
+    } else {
+      const int total = ntaps * p.CIC * 32;
+      for (int e0 = tid; e0 < total; e0 += nthreads * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int e = e0 + u * nthreads;
+          v[u] = 0.f;
+          if (e < total) {
+            int ci = e % p.CIC, t2 = e / p.CIC;
+            int co = t2 & 31, tap = t2 >> 5;
+            int c = c0 + ci, n = n0 + co;
+            if (c < p.CI && n < p.CO) v[u] = p.w[((size_t)tap * p.CO + n) * p.CI + c];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int e = e0 + u * nthreads;
+          if (e < total) {
+            int ci = e % p.CIC, t2 = e / p.CIC;
+            int co = t2 & 31, tap = t2 >> 5;
+            wl[(tap * p.CIC + ci) * p.WP + co] = v[u];
+          }
+        }
+      }
     }
   }
 }
@@ -134,26 +227,36 @@ __device__ __forceinline__ float4 center4(float4 v) {
   return make_float4(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f, 2.f * v.w - 1.f);
 }
 
-// synchronous staging (chunked reductions and the first tile)
+// synchronous staging (chunked reductions / patches too large for the register prefetch);
+// loads are batched 8 deep per thread so their latencies overlap
 __device__ __forceinline__ void stage_patch(const GParams& p, const StageGeom& g, float* patch,
                                             int b0, int ih_lo, int c0, int tid, int nthreads) {
-  for (int e = tid; e < g.total; e += nthreads) {
-    StageItem it = stage_item(p, g, e, b0, ih_lo, c0);
-    if (g.vec) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it.gofs >= 0) {
-        v = *reinterpret_cast<const float4*>(p.in + it.gofs);
-        if (p.center) v = center4(v);
+  constexpr int U = 8;
+  for (int e0 = tid; e0 < g.total; e0 += nthreads * U) {
+    float4 v[U];
+    int lds[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int e = e0 + u * nthreads;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      lds[u] = -1;
+      if (e < g.total) {
+        StageItem it = stage_item(p, g, e, b0, ih_lo, c0);
+        lds[u] = it.lds;
+        if (it.gofs >= 0) {
+          if (g.vec) v[u] = *reinterpret_cast<const float4*>(p.in + it.gofs);
+          else v[u].x = p.in[it.gofs];
+          if (p.center) v[u] = center4(v[u]);
+        }
       }
-      float* d = patch + it.lds;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    } else {
-      float v = 0.f;
-      if (it.gofs >= 0) {
-        v = p.in[it.gofs];
-        if (p.center) v = 2.f * v - 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (lds[u] >= 0) {
+        float* d = patch + lds[u];
+        if (g.vec) { d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w; }
+        else d[0] = v[u].x;
       }
-      patch[it.lds] = v;
     }
   }
 }

@@ -42,7 +42,7 @@ struct WParams {
 // ---- staging: work items (float4 when channel counts allow) decoded with magic-number
 // divisions; the next tile's IN patch and DY rows are prefetched into registers while the
 // current tile is being multiplied -----------------------------------------------------
-constexpr int MAXV_W = 28;
+constexpr int MAXV_W = 16;
 
 __device__ __forceinline__ unsigned w_magic(int d) {
   return d <= 1 ? 0u : (unsigned)(4294967296.0 / d) + 1u;
@@ -312,10 +312,18 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
     p.TR = p.NIMG * p.OH;
   } else {
     p.NIMG = 1;
-    int pick = 0;
-    for (int tr = 1; tr <= p.OH; ++tr)
-      if (p.OH % tr == 0 && tr * p.OW <= TARGET) pick = tr;
+    // largest tile (<= TARGET pixels) whose IN patch + DY rows still fit the register
+    // prefetch (MAXV_W float4 per thread at <= 64 channels per block); else the largest
+    int pick = 0, pick_pipe = 0;
+    const int c4 = ((p.CI < 64 ? p.CI : 64) + 3) / 4, o4 = ((p.CO < 64 ? p.CO : 64) + 3) / 4;
+    for (int tr = 1; tr <= p.OH; ++tr) {
+      if (p.OH % tr != 0 || tr * p.OW > TARGET) continue;
+      pick = tr;
+      long items = (long)((tr - 1) * S + p.KH) * ((p.OW - 1) * S + p.KW) * c4 + (long)tr * p.OW * o4;
+      if (items <= 16 * NW_W * 64) pick_pipe = tr;
+    }
     if (pick == 0) pick = 1;
+    if (pick_pipe * 2 >= pick) pick = pick_pipe;
     p.TR = p.RPI = pick;
   }
   p.n_tiles = (p.B * p.OH + p.TR - 1) / p.TR;

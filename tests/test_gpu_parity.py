@@ -77,6 +77,7 @@ def test_full_batch_config2_forward_properties(dev, L):
     fan = max(1, n // shp[-1])
     eng.params[off:off + n] = (torch.randn(n, generator=g) * (2.0 / fan) ** 0.5 * 0.5).to(dev)
   p0 = eng.params.clone()
+  eng.step_count = 0
   eps = torch.randn(B, zdim, device=dev)
   losses = []
   for t in range(4):
