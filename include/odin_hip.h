@@ -185,6 +185,10 @@ int odin_stft_mel_db(const float* y, const float* window, const float* melfb, fl
                      int n_samples, int frame_length, int step_length, int n_fft, int n_mels,
                      float preemph, float top_db, int log_output, void* stream);
 
+/* diagnostics only: device buffer (>= 64 int64) that receives in-kernel cycle stamps of the
+ * conv kernels' workgroup 0 (NULL disables; never set in production) */
+int odin_debug_set_stamps(void* buf);
+
 /* ---- HIP-graph helpers (capture a sequence of the calls above, replay per step) ------- */
 int odin_graph_begin(void* stream);
 int odin_graph_end(void* stream, void** graph_exec_out);

@@ -26,6 +26,7 @@
 // bit-reproducible run to run.
 #include "odin_device.h"
 #include "odin_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -47,6 +48,9 @@ struct GParams {
   int ih_off, iw_lo;           // F: ih_lo = oh0*S + ih_off ; T: ih_lo = oh0/S + ih_off
   int CIC, n_chunks, WP, w_resident;
   int patch_floats, MT, MTP, SPP;  // M-tiles total / per phase, slots per phase
+  int vec, KI, pipelined;          // 16-byte staging items, items per lane per patch row
+  long long* stamps;  // diagnostic: s_memtime stamps of workgroup 0 / wave 0 (env ODIN_STAMPS)
+  int dbg;  // diagnostic ablation mask (env ODIN_DBG): 1 skip MFMA, 2 skip stores, 4 skip patch staging
 };
 
 // Weight slice [taps][CIC][32 output channels] -> LDS.  Loads are issued in batches of 8
@@ -167,157 +171,133 @@ __device__ __forceinline__ void stage_weights(const GParams& p, float* wl, int c
   }
 }
 
-// ---- patch staging ---------------------------------------------------------------
-// The patch is NIMG*NRI rows of PW pixels x CIC channels.  Work item e (float4 when the
-// channel count allows, else one float) -> (row, pcol, c) with one magic-number division;
-// the global loads of tile t+1 are issued into registers (PF) before tile t is computed
-// and written to LDS after it, so HBM/L2 latency hides under the MFMAs.
-
-struct StageGeom {
-  int vec;       // 1: float4 items, 0: float items
-  int cpi;       // items per pixel (CIC/4 or CIC)
-  int rowlen;    // items per patch row = PW*cpi
-  int total;     // items per patch
-  unsigned m_row, m_cpi;  // magic reciprocals
-};
-
-__device__ __forceinline__ unsigned magic_of(int d) {
-  return d <= 1 ? 0u : (unsigned)(4294967296.0 / d) + 1u;
-}
-__device__ __forceinline__ int fast_div(int e, int d, unsigned m) {
-  if (d <= 1) return e;
-  int q = (int)__umulhi((unsigned)e, m);
-  if (q * d > e) --q;
-  return q;
-}
-
-__device__ __forceinline__ StageGeom stage_geom(const GParams& p) {
-  StageGeom g;
-  g.vec = (((p.CI & 3) == 0) && ((p.CIC & 3) == 0)) ? 1 : 0;
-  g.cpi = g.vec ? (p.CIC >> 2) : p.CIC;
-  g.rowlen = p.PW * g.cpi;
-  g.total = p.NIMG * p.NRI * g.rowlen;
-  g.m_row = magic_of(g.rowlen);
-  g.m_cpi = magic_of(g.cpi);
-  return g;
-}
-
-struct StageItem {
-  int lds;   // float index into the patch
-  long gofs; // float index into `in`, or -1 when the item is SAME padding / out of range
-};
-
-__device__ __forceinline__ StageItem stage_item(const GParams& p, const StageGeom& g, int e,
-                                                int b0, int ih_lo, int c0) {
-  StageItem it;
-  int row = fast_div(e, g.rowlen, g.m_row);
-  int j = e - row * g.rowlen;
-  int pcol = fast_div(j, g.cpi, g.m_cpi);
-  int cc = (j - pcol * g.cpi) * (g.vec ? 4 : 1);
-  int img = (p.NIMG == 1) ? 0 : row / p.NRI;
-  int prow = row - img * p.NRI;
-  int b = b0 + img, ih = ih_lo + prow, iw = p.iw_lo + pcol, c = c0 + cc;
-  it.lds = (row * p.PW + pcol) * p.P + cc;
-  bool ok = (b < p.B) && (ih >= 0) && (ih < p.H) && (iw >= 0) && (iw < p.W) && (c < p.CI);
-  it.gofs = ok ? ((((long)b * p.H + ih) * p.W + iw) * p.CI + c) : -1;
-  return it;
-}
-
 __device__ __forceinline__ float4 center4(float4 v) {
   return make_float4(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f, 2.f * v.w - 1.f);
 }
 
-// synchronous staging (chunked reductions / patches too large for the register prefetch);
-// loads are batched 8 deep per thread so their latencies overlap
-__device__ __forceinline__ void stage_patch(const GParams& p, const StageGeom& g, float* patch,
-                                            int b0, int ih_lo, int c0, int tid, int nthreads) {
-  constexpr int U = 8;
-  for (int e0 = tid; e0 < g.total; e0 += nthreads * U) {
-    float4 v[U];
-    int lds[U];
+// ---- patch staging ---------------------------------------------------------------
+// Row-aligned: wave w stages patch rows w, w+NW, ...; inside a row lane l handles items
+// l, l+64, ... (an item = 4 consecutive channels of one patch pixel, or 1 float when the
+// channel count does not allow 16-byte accesses).  Everything that depends only on
+// (lane, k) -- source offset inside the image row, LDS offset inside the patch row, SAME
+// padding mask -- is computed ONCE per kernel; per tile a row costs one scalar base, one
+// scalar bounds test and KI loads with 32-bit offsets.  The loads of tile t+1 are issued
+// into registers before tile t is multiplied and committed to LDS after it.
+#ifdef ODIN_SIM
+#define ODIN_UNIFORM(x) (x)
+#else
+#define ODIN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
+template <int KMAX>
+struct LaneStage {
+  unsigned gofs[KMAX];  // byte offset of the item inside an input image row
+  int ldo[KMAX];        // float offset of the item inside a patch row
+  unsigned jmask;       // bit k: item k exists (inside the patch row)
+  unsigned okmask;      // bit k: item k reads real data (not SAME padding)
+};
+
+template <int KMAX, bool VEC>
+__device__ __forceinline__ LaneStage<KMAX> lane_stage_init(const GParams& p, int lane) {
+  LaneStage<KMAX> L;
+  L.jmask = 0;
+  L.okmask = 0;
+  const int cpi = VEC ? (p.CIC >> 2) : p.CIC;
+  const int rowlen = p.PW * cpi;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int e = e0 + u * nthreads;
-      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      lds[u] = -1;
-      if (e < g.total) {
-        StageItem it = stage_item(p, g, e, b0, ih_lo, c0);
-        lds[u] = it.lds;
-        if (it.gofs >= 0) {
-          if (g.vec) v[u] = *reinterpret_cast<const float4*>(p.in + it.gofs);
-          else v[u].x = p.in[it.gofs];
-          if (p.center) v[u] = center4(v[u]);
-        }
-      }
-    }
+  for (int k = 0; k < KMAX; ++k) {
+    const int j = lane + 64 * k;
+    const int pcol = j / cpi;
+    const int cc = (j - pcol * cpi) * (VEC ? 4 : 1);
+    const int iw = p.iw_lo + pcol;
+    const bool jv = (k < p.KI) && (j < rowlen);
+    const bool ok = jv && (iw >= 0) && (iw < p.W) && (cc < p.CI);
+    L.gofs[k] = ok ? (unsigned)((iw * p.CI + cc) * 4) : 0u;
+    L.ldo[k] = pcol * p.P + cc;
+    if (jv) L.jmask |= 1u << k;
+    if (ok) L.okmask |= 1u << k;
+  }
+  return L;
+}
+
+template <bool VEC>
+struct StageT { typedef float4 type; };
+template <>
+struct StageT<false> { typedef float type; };
+
+template <bool VEC>
+__device__ __forceinline__ typename StageT<VEC>::type stage_zero() {
+  if constexpr (VEC) return make_float4(0.f, 0.f, 0.f, 0.f);
+  else return 0.f;
+}
+
+// issue the loads of patch row r of the tile starting at (b0, ih_lo); c0 = channel chunk
+template <int KMAX, bool VEC>
+__device__ __forceinline__ void stage_row_issue(const GParams& p, const LaneStage<KMAX>& L, int r,
+                                                int b0, int ih_lo, int c0,
+                                                typename StageT<VEC>::type* v) {
+  const int img = (p.NIMG == 1) ? 0 : r / p.NRI;
+  const int prow = r - img * p.NRI;
+  const int b = b0 + img, ih = ih_lo + prow;
+  const bool row_ok = (b < p.B) && (ih >= 0) && (ih < p.H);
+  const char* rowp = reinterpret_cast<const char*>(p.in) +
+                     ((size_t)((b * p.H + ih) * p.W) * p.CI + c0) * 4;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (lds[u] >= 0) {
-        float* d = patch + lds[u];
-        if (g.vec) { d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w; }
-        else d[0] = v[u].x;
+  for (int k = 0; k < KMAX; ++k) {
+    v[k] = stage_zero<VEC>();
+    bool ok = row_ok && ((L.okmask >> k) & 1u);
+    if (c0 != 0) ok = ok && (c0 + (int)((L.gofs[k] >> 2) % (unsigned)p.CI) < p.CI);
+    if (ok) {
+      if constexpr (VEC) {
+        float4 t = *reinterpret_cast<const float4*>(rowp + L.gofs[k]);
+        if (p.center) t = center4(t);
+        v[k] = t;
+      } else {
+        float t = *reinterpret_cast<const float*>(rowp + L.gofs[k]);
+        if (p.center) t = 2.f * t - 1.f;
+        v[k] = t;
       }
     }
   }
 }
 
-template <int NT, int MAXV>
-__device__ __forceinline__ void prefetch_issue(const GParams& p, const StageGeom& g, float4* pf,
-                                               int b0, int ih_lo, int tid) {
+template <int KMAX, bool VEC>
+__device__ __forceinline__ void stage_row_commit(const GParams& p, const LaneStage<KMAX>& L, int r,
+                                                 const typename StageT<VEC>::type* v,
+                                                 float* patch) {
+  float* rowl = patch + r * p.PW * p.P;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    int e = tid + i * NT;
-    if (e < g.total) {
-      StageItem it = stage_item(p, g, e, b0, ih_lo, 0);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it.gofs >= 0) {
-        if (g.vec) v = *reinterpret_cast<const float4*>(p.in + it.gofs);
-        else v.x = p.in[it.gofs];
-        if (p.center) v = center4(v);
-      }
-      pf[i] = v;
+  for (int k = 0; k < KMAX; ++k) {
+    if ((L.jmask >> k) & 1u) {
+      float* d = rowl + L.ldo[k];
+      if constexpr (VEC) { d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w; }
+      else d[0] = v[k];
     }
   }
 }
 
-template <int NT, int MAXV>
-__device__ __forceinline__ void prefetch_commit(const GParams& p, const StageGeom& g,
-                                                const float4* pf, float* patch, int tid) {
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    int e = tid + i * NT;
-    if (e < g.total) {
-      int row = fast_div(e, g.rowlen, g.m_row);
-      int j = e - row * g.rowlen;
-      int pcol = fast_div(j, g.cpi, g.m_cpi);
-      int cc = (j - pcol * g.cpi) * (g.vec ? 4 : 1);
-      float* d = patch + (row * p.PW + pcol) * p.P + cc;
-      float4 v = pf[i];
-      if (g.vec) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
-      else d[0] = v.x;
-    }
-  }
-}
-
-// geometry of the output pixel a lane owns inside M-tile `mt`
+// geometry of the output pixel a lane owns inside M-tile `mt`.  Everything except the
+// tile's first output row is tile-invariant and computed once per kernel.
 struct Slot {
-  int base;    // patch float index of tap (0,0) channel 0
-  int opix;    // linear output pixel index (b*OH+oh)*OW+ow, or -1 if masked
+  int base;      // patch float index of tap (0,0) channel 0
+  int row, col;  // output row inside the tile / output column (row < 0: masked slot)
+  int opix;      // linear output pixel index (b*OH+oh)*OW+ow of the CURRENT tile, or -1
   int kh0, kw0;  // MODE_T: first valid tap of this M-tile's phase
 };
 
 template <int MODE>
-__device__ __forceinline__ Slot slot_geometry(const GParams& p, int mt, int l31, int gr0) {
+__device__ __forceinline__ Slot slot_geometry(const GParams& p, int mt, int l31) {
   Slot s;
   s.kh0 = s.kw0 = 0;
-  const int total_rows = p.B * p.OH;
+  s.opix = -1;
   if (MODE == MODE_F) {
     int sl = mt * 32 + l31;
     int r = sl / p.OW, c = sl - r * p.OW;
-    bool valid = (r < p.TR) && (gr0 + r < total_rows);
+    bool valid = (r < p.TR);
     int img = r / p.RPI, rl = r - img * p.RPI;
     s.base = valid ? ((img * p.NRI + rl * p.S) * p.PW + c * p.S) * p.P : 0;
-    s.opix = valid ? (gr0 + r) * p.OW + c : -1;
+    s.row = valid ? r : -1;
+    s.col = c;
   } else {
     const int S = p.S;
     int phase = mt / p.MTP, mtl = mt - phase * p.MTP;
@@ -327,7 +307,7 @@ __device__ __forceinline__ Slot slot_geometry(const GParams& p, int mt, int l31,
     int img = sl / (RPS * IWs), rem = sl - img * (RPS * IWs);
     int rq = rem / IWs, cq = rem - rq * IWs;
     int row_in_tile = img * p.RPI + ph + S * rq;
-    bool valid = (sl < p.SPP) && (gr0 + row_in_tile < total_rows);
+    bool valid = (sl < p.SPP);
     s.kh0 = (ph + p.pt) % S;
     s.kw0 = (pw + p.pl) % S;
     int dh = (ph + p.pt - s.kh0) / S, dw = (pw + p.pl - s.kw0) / S;
@@ -336,9 +316,15 @@ __device__ __forceinline__ Slot slot_geometry(const GParams& p, int mt, int l31,
     // masked lanes read the last patch pixel (tap offsets are negative in this mode)
     s.base = valid ? ((img * p.NRI + prow) * p.PW + pcol) * p.P
                    : ((p.NIMG * p.NRI - 1) * p.PW + (p.PW - 1)) * p.P;
-    s.opix = valid ? (gr0 + row_in_tile) * p.OW + (pw + S * cq) : -1;
+    s.row = valid ? row_in_tile : -1;
+    s.col = pw + S * cq;
   }
   return s;
+}
+
+__device__ __forceinline__ void slot_set_tile(const GParams& p, Slot& s, int gr0) {
+  const bool live = (s.row >= 0) && (gr0 + s.row < p.B * p.OH);
+  s.opix = live ? (gr0 + s.row) * p.OW + s.col : -1;
 }
 
 // One 32(out-channel) x 32(pixel) accumulator tile over one channel chunk.  TK/TS/TCIC
@@ -355,7 +341,7 @@ __device__ __forceinline__ TapAddr tap_addr(const GParams& p, const float* patch
                                             const Slot& s, int l31, int h, int step) {
   constexpr int SUB = TCIC / 32;            // 32-channel sub-steps per tap
   constexpr int NJ = (MODE == MODE_F) ? TK : TK / TS;
-  constexpr int WP = (MODE == MODE_F) ? 32 : 33;
+  constexpr int WP = 32;
   constexpr int P = TCIC + 1;
   const int tap = step / SUB, sub = step - tap * SUB;
   const int jh = tap / NJ, jw = tap - jh * NJ;
@@ -381,7 +367,7 @@ __device__ __forceinline__ f32x16 mtile_compute(const GParams& p, const float* p
     static_assert(TCIC % 32 == 0 && TK != 0 && TS != 0 && TK % TS == 0, "specialised shape");
     constexpr int NJ = (MODE == MODE_F) ? TK : TK / TS;
     constexpr int NSTEP = NJ * NJ * (TCIC / 32);
-    constexpr int WP = (MODE == MODE_F) ? 32 : 33;
+    constexpr int WP = 32;
     float a0[16], b0[16], a1[16], b1[16];
     {
       TapAddr t = tap_addr<MODE, TK, TS, TCIC>(p, patch, wl, s, l31, h, 0);
@@ -482,19 +468,37 @@ __device__ __forceinline__ float sigmoid_g(float x) {
   return x >= 0.f ? r : e * r;
 }
 
-template <int MODE, int NW, int TK, int TS, int TCIC, bool TAIL, int MAXV>
-__global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailParams tp) {
+#ifdef ODIN_SIM
+#define ODIN_STAMP(k) ((void)0)
+#else
+#define ODIN_STAMP(k)                                                                    \
+  do {                                                                                   \
+    if (p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && \
+        stamp_i < 60)                                                                    \
+      p.stamps[stamp_i++] = ((long long)(k) << 56) | (long long)(clock64() & 0xFFFFFFFFFFFFFFll); \
+  } while (0)
+#endif
+
+template <int MODE, int NW, int TK, int TS, int TCIC, bool VEC, bool TAIL, int KMAX, int RPWMAX, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, TailParams tp) {
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
   float* wl = smem + p.patch_floats;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = ODIN_UNIFORM(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.y * 32;
   constexpr int NT = NW * 64;
-  const StageGeom sg = stage_geom(p);
-  const bool pipelined = (p.n_chunks == 1) && (sg.total <= MAXV * NT);
+  typedef typename StageT<VEC>::type SV;
+  int stamp_i = 0;
+  (void)stamp_i;
+  ODIN_STAMP(1);
+  const bool pipelined = p.pipelined != 0;
+  const int nrows_p = p.NIMG * p.NRI;
+  const LaneStage<KMAX> LS = lane_stage_init<KMAX, VEC>(p, lane);
 
   if (p.w_resident) stage_weights(p, wl, 0, n0, tid, NT);
+  ODIN_STAMP(2);
 
   float bsum[16];
 #pragma unroll
@@ -518,47 +522,86 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
     }
   }
 
-  float4 pf[MAXV];
+  // tile-invariant lane state: slot geometry, bias of this lane's 16 output channels
+  const int mt0 = wave, mt1 = wave + NW;
+  Slot s0 = slot_geometry<MODE>(p, mt0 < p.MT ? mt0 : 0, l31);
+  Slot s1 = slot_geometry<MODE>(p, mt1 < p.MT ? mt1 : 0, l31);
+  float bias_r[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = n0 + 8 * (i >> 2) + 4 * h + (i & 3);
+    bias_r[i] = (p.bias != nullptr && n < p.CO) ? p.bias[n] : 0.f;
+  }
+  const bool co_vec = ((p.CO & 3) == 0);
+
+  SV pf[RPWMAX * KMAX];
   int tile = blockIdx.x;
   if (pipelined && tile < p.n_tiles) {
     const int gr0 = tile * p.TR;
     const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
     const int ih_lo = (MODE == MODE_F) ? oh0 * p.S + p.ih_off : oh0 / p.S + p.ih_off;
-    prefetch_issue<NT, MAXV>(p, sg, pf, b0, ih_lo, tid);
+#pragma unroll
+    for (int q = 0; q < RPWMAX; ++q) {
+      const int r = wave + NW * q;
+      if (r < nrows_p) stage_row_issue<KMAX, VEC>(p, LS, r, b0, ih_lo, 0, pf + q * KMAX);
+    }
   }
+  ODIN_STAMP(3);
 
   for (; tile < p.n_tiles; tile += gridDim.x) {
+    ODIN_STAMP(4);
     const int gr0 = tile * p.TR;
     const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
     const int ih_lo = (MODE == MODE_F) ? oh0 * p.S + p.ih_off : oh0 / p.S + p.ih_off;
     f32x16 acc0 = f32x16_zero(), acc1 = f32x16_zero();
-    const int mt0 = wave, mt1 = wave + NW;
-    Slot s0 = slot_geometry<MODE>(p, mt0 < p.MT ? mt0 : 0, l31, gr0);
-    Slot s1 = slot_geometry<MODE>(p, mt1 < p.MT ? mt1 : 0, l31, gr0);
+    slot_set_tile(p, s0, gr0);
+    slot_set_tile(p, s1, gr0);
     if (pipelined) {
       __syncthreads();  // everyone is done reading the previous patch
-      prefetch_commit<NT, MAXV>(p, sg, pf, patch, tid);
+#pragma unroll
+      for (int q = 0; q < RPWMAX; ++q) {
+        const int r = wave + NW * q;
+        if (r < nrows_p) stage_row_commit<KMAX, VEC>(p, LS, r, pf + q * KMAX, patch);
+      }
       __syncthreads();
+      ODIN_STAMP(5);
       const int nt = tile + gridDim.x;
       if (nt < p.n_tiles) {  // loads of the next tile fly during the MFMAs below
         const int g2 = nt * p.TR;
         const int b2 = g2 / p.OH, o2 = g2 - b2 * p.OH;
         const int ih2 = (MODE == MODE_F) ? o2 * p.S + p.ih_off : o2 / p.S + p.ih_off;
-        prefetch_issue<NT, MAXV>(p, sg, pf, b2, ih2, tid);
+#pragma unroll
+        for (int q = 0; q < RPWMAX; ++q) {
+          const int r = wave + NW * q;
+          if (r < nrows_p) stage_row_issue<KMAX, VEC>(p, LS, r, b2, ih2, 0, pf + q * KMAX);
+        }
       }
+      ODIN_STAMP(6);
       if (mt0 < p.MT) acc0 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s0, l31, h, acc0);
       if (mt1 < p.MT) acc1 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s1, l31, h, acc1);
     } else {
       for (int ch = 0; ch < p.n_chunks; ++ch) {
         const int c0 = ch * p.CIC;
         __syncthreads();
-        stage_patch(p, sg, patch, b0, ih_lo, c0, tid, NT);
+        for (int r0 = wave; r0 < nrows_p; r0 += NW * RPWMAX) {  // RPWMAX rows in flight
+#pragma unroll
+          for (int q = 0; q < RPWMAX; ++q) {
+            const int r = r0 + NW * q;
+            if (r < nrows_p) stage_row_issue<KMAX, VEC>(p, LS, r, b0, ih_lo, c0, pf + q * KMAX);
+          }
+#pragma unroll
+          for (int q = 0; q < RPWMAX; ++q) {
+            const int r = r0 + NW * q;
+            if (r < nrows_p) stage_row_commit<KMAX, VEC>(p, LS, r, pf + q * KMAX, patch);
+          }
+        }
         if (!p.w_resident) stage_weights(p, wl, c0, n0, tid, NT);
         __syncthreads();
         if (mt0 < p.MT) acc0 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s0, l31, h, acc0);
         if (mt1 < p.MT) acc1 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s1, l31, h, acc1);
       }
     }
+    ODIN_STAMP(7);
     // ---- epilogue: bias + activation (+ activation-gradient multiply) + NHWC store ----
     float llk_lane = 0.f;
 #pragma unroll
@@ -568,13 +611,12 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
       const f32x16& acc = mi == 0 ? acc0 : acc1;
       if (mt >= p.MT) continue;  // wave-uniform
       const bool live = s.opix >= 0;
-      const size_t obase = live ? (size_t)s.opix * p.CO : 0;
+      float* outp = p.out + (live ? (size_t)((unsigned)s.opix * (unsigned)p.CO) : 0) + n0 + 4 * h;
       float v[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int n = n0 + 8 * (i >> 2) + 4 * h + (i & 3);
-        float t = acc[i];
-        if (p.bias != nullptr && n < p.CO) t += p.bias[n];
+        const float t = acc[i] + bias_r[i];
         v[i] = (n < p.CO && live) ? odin_act(p.act, t) : 0.f;
       }
       if (TAIL) {
@@ -595,12 +637,13 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
           if (oc < tp.C1 && live) {
             const float x = tp.target[(size_t)s.opix * tp.C1 + oc];
             const float l = lg[oc];
+            const float dsig = (sigmoid_g(l) - x) * sc;
             if (h == 0) {
               llk_lane += x * l - softplus_g(l);
-              db1[oc] += (sigmoid_g(l) - x) * sc;
+              db1[oc] += dsig;
               if (tp.logits != nullptr) tp.logits[(size_t)s.opix * tp.C1 + oc] = l;
             }
-            dl[oc] = (sigmoid_g(l) - x) * sc;
+            dl[oc] = dsig;
           }
         }
 #pragma unroll
@@ -614,10 +657,26 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
           v[i] = g * odin_act_grad(p.act, v[i]);
         }
       } else if (p.aux != nullptr && live) {
+        const float* auxp = p.aux + (size_t)((unsigned)s.opix * (unsigned)p.CO) + n0 + 4 * h;
+        if (co_vec) {
+          float4 ax[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int n = n0 + 8 * (i >> 2) + 4 * h + (i & 3);
-          if (n < p.CO) v[i] *= odin_act_grad(p.aux_act, p.aux[obase + n]);
+          for (int q = 0; q < 4; ++q)
+            ax[q] = (n0 + 8 * q + 4 * h + 3 < p.CO) ? *reinterpret_cast<const float4*>(auxp + 8 * q)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[4 * q + 0] *= odin_act_grad(p.aux_act, ax[q].x);
+            v[4 * q + 1] *= odin_act_grad(p.aux_act, ax[q].y);
+            v[4 * q + 2] *= odin_act_grad(p.aux_act, ax[q].z);
+            v[4 * q + 3] *= odin_act_grad(p.aux_act, ax[q].w);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int nn = 8 * (i >> 2) + (i & 3);
+            if (n0 + 4 * h + nn < p.CO) v[i] *= odin_act_grad(p.aux_act, auxp[nn]);
+          }
         }
       }
       if (live) {
@@ -626,13 +685,13 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n = n0 + 8 * q + 4 * h;
-          if (((p.CO & 3) == 0) && n + 3 < p.CO) {
-            *reinterpret_cast<float4*>(p.out + obase + n) =
+          if (co_vec && n + 3 < p.CO) {
+            *reinterpret_cast<float4*>(outp + 8 * q) =
                 make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (n + j < p.CO) p.out[obase + n + j] = v[4 * q + j];
+              if (n + j < p.CO) outp[8 * q + j] = v[4 * q + j];
           }
         }
       }
@@ -652,6 +711,7 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
     }
   }
 
+  ODIN_STAMP(8);
   if (p.colsum_slab != nullptr || TAIL) {
     // per-workgroup partial sums: column sums of `out` (bias gradient of a
     // Conv2DTranspose layer) and, for the fused tail, dW1 / db1 of the 1x1 conv.
@@ -717,6 +777,7 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
 // --------------------------------------------------------------------------------------
 constexpr int LDS_BUDGET_FLOATS = (160 * 1024 - 2048) / 4;
 constexpr int NW_G = 4;
+constexpr int GENERIC_KMAX = 9;
 
 bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_bytes) {
   const int S = p.S;
@@ -770,16 +831,18 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
   }
   if (p.MT > 2 * NW_G) return false;
   const int CIp = (p.CI + 1) & ~1;
-  p.WP = (p.wmode == 0) ? 32 : 33;
+  p.WP = 32;
   const int ntaps = p.KH * p.KW;
   int cic = CIp;
   // keep float4 staging possible when CI % 4 == 0
   const int gran = ((p.CI & 3) == 0) ? 4 : 2;
+  const bool vec0 = ((p.CI & 3) == 0);
   while (true) {
     int P = cic + 1;
     long pf = (long)p.NIMG * p.NRI * p.PW * P + 8;
     long wf = (long)ntaps * cic * p.WP + 64;
-    if (pf + wf <= LDS_BUDGET_FLOATS) break;
+    long rowlen = (long)p.PW * ((vec0 && (cic & 3) == 0) ? cic / 4 : cic);
+    if (pf + wf <= LDS_BUDGET_FLOATS && rowlen <= 64 * GENERIC_KMAX) break;
     if (cic <= gran) return false;
     // next smaller chunk: halve, rounded up to the granularity
     int nc = (CIp + cic - 1) / cic + 1;
@@ -791,6 +854,9 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
   p.P = cic + 1;
   p.n_chunks = (CIp + cic - 1) / cic;
   p.w_resident = (p.n_chunks == 1) ? 1 : 0;
+  p.vec = (vec0 && (cic & 3) == 0) ? 1 : 0;
+  p.KI = (p.PW * (p.vec ? cic / 4 : cic) + 63) / 64;
+  p.pipelined = 0;
   p.patch_floats = (int)(((long)p.NIMG * p.NRI * p.PW * p.P + 8 + 3) & ~3L);
   long wf = (long)ntaps * cic * p.WP + 64;  // + scratch for per-tile reductions
   long total = p.patch_floats + wf;
@@ -810,19 +876,25 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
   return true;
 }
 
-template <int MODE, int TK, int TS, int TCIC, bool TAIL, int MAXV>
-int launch_inst(const GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* stream) {
+long long* g_stamps = nullptr;
+
+template <int MODE, int TK, int TS, int TCIC, bool VEC, bool TAIL, int KMAX, int RPWMAX, int WPS = 1>
+int launch_inst(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* stream) {
+  if (p.KI > KMAX) return odin_fail(-2, "gather_conv: patch row too long for this instance");
+  const int rpw = (p.NIMG * p.NRI + NW_G - 1) / NW_G;
+  p.pipelined = (p.n_chunks == 1 && rpw <= RPWMAX) ? 1 : 0;
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, TAIL, MAXV>),
+        reinterpret_cast<const void*>(
+            &gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, WPS>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, TAIL, MAXV>), grid, dim3(NW_G * 64), lds,
-              stream, p, tp);
+  ODIN_LAUNCH((gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, WPS>), grid,
+              dim3(NW_G * 64), lds, stream, p, tp);
   return odin_check_launch("gather_conv");
 }
 
@@ -833,27 +905,46 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
   if (!plan_gather(p, mode, max_blocks, &gx, &lds)) return odin_fail(-2, "gather_conv: no tiling plan");
   if (rows_out) *rows_out = gx;
   if (p.out == nullptr) return 0;  // dry run: planning only
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("ODIN_DBG"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+    p.stamps = g_stamps;
+  }
   dim3 grid(gx, (p.CO + 31) / 32, 1);
   TailParams tp;
   memset(&tp, 0, sizeof(tp));
-  const bool k4s2 = (p.KH == 4 && p.KW == 4 && p.S == 2 && p.n_chunks == 1);
+  const bool k4s2 = (p.KH == 4 && p.KW == 4 && p.S == 2 && p.n_chunks == 1 && p.vec);
+  const int rpw = (p.NIMG * p.NRI + NW_G - 1) / NW_G;
+  constexpr int GK = GENERIC_KMAX;
   if (tail != nullptr) {
     tp = *tail;
-    if (p.CO > 32 || tp.C1 > MAXC1 || p.NIMG != 1)
-      return odin_fail(-2, "bernoulli tail: needs Cout<=32, C1<=4 and tiles inside one image");
-    if (mode == MODE_T && k4s2 && p.CIC == 32 && p.wmode == 1)
-      return launch_inst<MODE_T, 4, 2, 32, true, 6>(p, tp, grid, lds, stream);
-    if (mode == MODE_T) return launch_inst<MODE_T, 0, 0, 0, true, 8>(p, tp, grid, lds, stream);
-    return launch_inst<MODE_F, 0, 0, 0, true, 8>(p, tp, grid, lds, stream);
+    if (p.CO > 32 || tp.C1 > MAXC1 || p.NIMG != 1 || !p.vec)
+      return odin_fail(-2, "bernoulli tail: needs Cout<=32, C1<=4, Cin%4==0 and one image per tile");
+    if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5)
+      return launch_inst<MODE_T, 4, 2, 32, true, true, 5, 2>(p, tp, grid, lds, stream);
+    if (mode == MODE_T) return launch_inst<MODE_T, 0, 0, 0, true, true, GK, 2>(p, tp, grid, lds, stream);
+    return launch_inst<MODE_F, 0, 0, 0, true, true, GK, 2>(p, tp, grid, lds, stream);
   }
   if (mode == MODE_F) {
-    if (k4s2 && p.wmode == 0 && p.CIC == 32) return launch_inst<MODE_F, 4, 2, 32, false, 20>(p, tp, grid, lds, stream);
-    if (k4s2 && p.wmode == 0 && p.CIC == 64) return launch_inst<MODE_F, 4, 2, 64, false, 12>(p, tp, grid, lds, stream);
-    return launch_inst<MODE_F, 0, 0, 0, false, 12>(p, tp, grid, lds, stream);
+    if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 5)
+      return launch_inst<MODE_F, 4, 2, 32, true, false, 5, 5>(p, tp, grid, lds, stream);
+    if (k4s2 && p.CIC == 32 && p.KI <= 9)
+      return launch_inst<MODE_F, 4, 2, 32, true, false, 9, 3>(p, tp, grid, lds, stream);
+    if (k4s2 && p.CIC == 64 && p.KI <= 5)
+      return launch_inst<MODE_F, 4, 2, 64, true, false, 5, 3>(p, tp, grid, lds, stream);
+    if (p.vec && p.KI <= 2) return launch_inst<MODE_F, 0, 0, 0, true, false, 2, 8>(p, tp, grid, lds, stream);
+    if (p.vec) return launch_inst<MODE_F, 0, 0, 0, true, false, GK, 2>(p, tp, grid, lds, stream);
+    if (p.KI <= 2) return launch_inst<MODE_F, 0, 0, 0, false, false, 2, 8>(p, tp, grid, lds, stream);
+    return launch_inst<MODE_F, 0, 0, 0, false, false, GK, 2>(p, tp, grid, lds, stream);
   }
-  if (k4s2 && p.wmode == 1 && p.CIC == 32) return launch_inst<MODE_T, 4, 2, 32, false, 6>(p, tp, grid, lds, stream);
-  if (k4s2 && p.wmode == 1 && p.CIC == 64) return launch_inst<MODE_T, 4, 2, 64, false, 6>(p, tp, grid, lds, stream);
-  return launch_inst<MODE_T, 0, 0, 0, false, 12>(p, tp, grid, lds, stream);
+  if (k4s2 && p.CIC == 32 && p.KI <= 5)
+    return launch_inst<MODE_T, 4, 2, 32, true, false, 5, 2, 2>(p, tp, grid, lds, stream);
+  if (k4s2 && p.CIC == 64 && p.KI <= 5)
+    return launch_inst<MODE_T, 4, 2, 64, true, false, 5, 2, 2>(p, tp, grid, lds, stream);
+  if (p.vec && p.KI <= 2) return launch_inst<MODE_T, 0, 0, 0, true, false, 2, 8>(p, tp, grid, lds, stream);
+  if (p.vec) return launch_inst<MODE_T, 0, 0, 0, true, false, GK, 2>(p, tp, grid, lds, stream);
+  return launch_inst<MODE_T, 0, 0, 0, false, false, GK, 2>(p, tp, grid, lds, stream);
 }
 
 void fill_common(GParams& p, const odin_conv_desc* d) {
@@ -963,4 +1054,10 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
                          slab_rows_out, &tp);
   if (n_part_out) *n_part_out = p.OH / (p.TR > 0 ? p.TR : 1);  // log-likelihood parts per sample
   return rc;
+}
+
+// diagnostics: device buffer (>= 64 int64) receiving s_memtime stamps of workgroup 0
+extern "C" int odin_debug_set_stamps(void* buf) {
+  g_stamps = (long long*)buf;
+  return 0;
 }

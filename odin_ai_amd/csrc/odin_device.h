@@ -58,7 +58,7 @@ __device__ __forceinline__ f32x16 f32x16_zero() {
 enum { ODIN_ACT_LINEAR = 0, ODIN_ACT_ELU = 1, ODIN_ACT_RELU = 2 };
 
 __device__ __forceinline__ float odin_act(int act, float v) {
-  if (act == ODIN_ACT_ELU) return v > 0.f ? v : expm1f(v);
+  if (act == ODIN_ACT_ELU) return v > 0.f ? v : odin_exp(v) - 1.f;
   if (act == ODIN_ACT_RELU) return v > 0.f ? v : 0.f;
   return v;
 }

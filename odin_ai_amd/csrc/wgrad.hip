@@ -254,24 +254,34 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
       __syncthreads();
     }
     const int npairs = p.slots >> 1;
-    int base_n = tbl[h];
-    for (int kp = 0; kp < npairs; ++kp) {
+    // two-stage register pipeline over pixel pairs: operands of pair kp+1 are read from
+    // LDS while the MFMAs of pair kp execute
+    float av[2][TNACC], bv[2][TNACC];
+    auto load_pair = [&](int kp, float* a_, float* b_) {
       const int s = 2 * kp + h;
-      const int base = base_n;
-      if (kp + 1 < npairs) base_n = tbl[s + 2];  // next pair's table entry, off the critical path
+      const int base = tbl[s];
       const float* brow = dyl + s * p.DP;
-      float av[TNACC], bv[TNACC];
 #pragma unroll
       for (int a = 0; a < TNACC; ++a) {
         if (wave + a * NW_W < n_tot) {  // wave-uniform
           float t = patch[base + a_off[a]];
-          av[a] = (a_kind[a] == 1) ? t : (a_kind[a] == 2 ? 1.f : 0.f);
-          bv[a] = brow[b_off[a]];
+          a_[a] = (a_kind[a] == 1) ? t : (a_kind[a] == 2 ? 1.f : 0.f);
+          b_[a] = brow[b_off[a]];
         }
       }
+    };
+    load_pair(0, av[0], bv[0]);
+    for (int kp = 0; kp < npairs; kp += 2) {
+      if (kp + 1 < npairs) load_pair(kp + 1, av[1], bv[1]);
 #pragma unroll
       for (int a = 0; a < TNACC; ++a)
-        if (wave + a * NW_W < n_tot) acc[a] = mfma32(av[a], bv[a], acc[a]);
+        if (wave + a * NW_W < n_tot) acc[a] = mfma32(av[0][a], bv[0][a], acc[a]);
+      if (kp + 2 < npairs) load_pair(kp + 2, av[0], bv[0]);
+      if (kp + 1 < npairs) {
+#pragma unroll
+        for (int a = 0; a < TNACC; ++a)
+          if (wave + a * NW_W < n_tot) acc[a] = mfma32(av[1][a], bv[1][a], acc[a]);
+      }
     }
   }
 

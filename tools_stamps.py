@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Diagnostic: in-kernel cycle stamps of one conv launch (workgroup 0, wave 0)."""
+import ctypes as C, sys, torch, numpy as np
+sys.path.insert(0, '.')
+from odin_ai_amd import _lib
+from odin_ai_amd.engine import same_pads
+L = _lib.load()
+dev = torch.device('cuda:0')
+names = {1: 'start', 2: 'weights', 3: 'prefetch0', 4: 'tile', 5: 'commit+sync', 6: 'issue-next', 7: 'mfma', 8: 'end'}
+def run(kind, B, H, W, Ci, Co, K, S, act='elu'):
+  if kind == 'deconv':
+    OH, OW = H * S, W * S
+    _, pt, _ = same_pads(OH, K, S); _, pl, _ = same_pads(OW, K, S)
+    w = torch.randn(K, K, Co, Ci, device=dev) * 0.1
+  else:
+    OH, pt, _ = same_pads(H, K, S); OW, pl, _ = same_pads(W, K, S)
+    w = torch.randn(K, K, Ci, Co, device=dev) * 0.1
+  d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, act)
+  x = torch.randn(B, H, W, Ci, device=dev); b = torch.zeros(Co, device=dev)
+  y = torch.empty(B, OH, OW, Co, device=dev)
+  st = torch.zeros(64, dtype=torch.int64, device=dev)
+  fn = L.odin_deconv2d_fwd if kind == 'deconv' else L.odin_conv2d_fwd
+  for it in range(3):
+    st.zero_()
+    L.odin_debug_set_stamps(st.data_ptr())
+    fn(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), C.byref(d), None)
+    torch.cuda.synchronize()
+  L.odin_debug_set_stamps(None)
+  v = st.cpu().numpy()
+  v = v[v != 0]
+  ks, ts = (v >> 56), (v & ((1 << 56) - 1))
+  print(f'--- {kind} B{B} {H}x{W}x{Ci}->{Co} k{K}s{S}: total {ts[-1]-ts[0]} cycles')
+  for i in range(1, min(len(ks), 30)):
+    print(f'   {names[int(ks[i])]:12s} +{ts[i]-ts[i-1]}')
+run('deconv', 256, 32, 32, 32, 32, 4, 2)
+run('conv', 256, 32, 32, 32, 32, 4, 2)
+run('conv', 256, 1, 1, 128, 20, 1, 1, 'linear')
