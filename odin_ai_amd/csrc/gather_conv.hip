@@ -939,9 +939,9 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     return launch_inst<MODE_F, 0, 0, 0, false, false, GK, 2>(p, tp, grid, lds, stream);
   }
   if (k4s2 && p.CIC == 32 && p.KI <= 5)
-    return launch_inst<MODE_T, 4, 2, 32, true, false, 5, 2, 2>(p, tp, grid, lds, stream);
+    return launch_inst<MODE_T, 4, 2, 32, true, false, 5, 2, 1>(p, tp, grid, lds, stream);
   if (k4s2 && p.CIC == 64 && p.KI <= 5)
-    return launch_inst<MODE_T, 4, 2, 64, true, false, 5, 2, 2>(p, tp, grid, lds, stream);
+    return launch_inst<MODE_T, 4, 2, 64, true, false, 5, 2, 1>(p, tp, grid, lds, stream);
   if (p.vec && p.KI <= 2) return launch_inst<MODE_T, 0, 0, 0, true, false, 2, 8>(p, tp, grid, lds, stream);
   if (p.vec) return launch_inst<MODE_T, 0, 0, 0, true, false, GK, 2>(p, tp, grid, lds, stream);
   return launch_inst<MODE_T, 0, 0, 0, false, false, GK, 2>(p, tp, grid, lds, stream);

@@ -37,149 +37,132 @@ struct WParams {
   int nrt, ncot, want_bias;
   int slab_stride;
   int patch_floats, dy_floats;
+  int pvec, dvec, KI, pipelined;
 };
 
-// ---- staging: work items (float4 when channel counts allow) decoded with magic-number
-// divisions; the next tile's IN patch and DY rows are prefetched into registers while the
-// current tile is being multiplied -----------------------------------------------------
-constexpr int MAXV_W = 16;
+// ---- staging ------------------------------------------------------------------------
+// IN patch: row-aligned like gather_conv (wave w owns patch rows w, w+NW, ...; per-lane
+// source / LDS offsets and SAME-padding masks are computed once per kernel).  DY rows of a
+// tile are one contiguous run in HBM.  Tile t+1 is prefetched into registers while tile t
+// is being multiplied.
+#ifdef ODIN_SIM
+#define W_UNIFORM(x) (x)
+#else
+#define W_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
 
-__device__ __forceinline__ unsigned w_magic(int d) {
-  return d <= 1 ? 0u : (unsigned)(4294967296.0 / d) + 1u;
-}
-__device__ __forceinline__ int w_div(int e, int d, unsigned m) {
-  if (d <= 1) return e;
-  int q = (int)__umulhi((unsigned)e, m);
-  if (q * d > e) --q;
-  return q;
-}
-
-struct WGeom {
-  int pvec, pcpi, prowlen, ptotal;  // patch items
-  unsigned pm_row, pm_cpi;
-  int dvec, dcpi, dtotal;           // dy items
-  unsigned dm_cpi;
+template <int KMAX>
+struct WLane {
+  unsigned gofs[KMAX];
+  int ldo[KMAX];
+  unsigned jmask, okmask;
 };
 
-__device__ __forceinline__ WGeom w_geom(const WParams& p, int ci0, int cib) {
-  WGeom g;
-  g.pvec = (((p.CI & 3) == 0) && ((p.P & 3) == 0) && ((ci0 & 3) == 0) && ((cib & 3) == 0)) ? 1 : 0;
-  g.pcpi = g.pvec ? (p.P >> 2) : p.P;
-  g.prowlen = p.PW * g.pcpi;
-  g.ptotal = p.NIMG * p.NRI * g.prowlen;
-  g.pm_row = w_magic(g.prowlen);
-  g.pm_cpi = w_magic(g.pcpi);
-  g.dvec = (((p.CO & 3) == 0) && ((p.COB & 3) == 0)) ? 1 : 0;
-  g.dcpi = g.dvec ? (p.COB >> 2) : p.COB;
-  g.dtotal = p.slots * g.dcpi;
-  g.dm_cpi = w_magic(g.dcpi);
-  return g;
+template <int KMAX>
+__device__ __forceinline__ WLane<KMAX> wlane_init(const WParams& p, int lane, int cib) {
+  WLane<KMAX> L;
+  L.jmask = L.okmask = 0;
+  const int cpi = p.pvec ? (p.P >> 2) : p.P;
+  const int rowlen = p.PW * cpi;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int j = lane + 64 * k;
+    const int pcol = j / cpi;
+    const int cc = (j - pcol * cpi) * (p.pvec ? 4 : 1);
+    const int iw = pcol - p.pl;
+    const bool jv = (k < p.KI) && (j < rowlen);
+    const bool ok = jv && (iw >= 0) && (iw < p.W) && (cc < cib);
+    L.gofs[k] = ok ? (unsigned)((iw * p.CI + cc) * 4) : 0u;
+    L.ldo[k] = pcol * p.P + cc;
+    if (jv) L.jmask |= 1u << k;
+    if (ok) L.okmask |= 1u << k;
+  }
+  return L;
 }
 
-// item e of the combined (patch ++ dy) work list -> (LDS float index, global float offset or -1)
-__device__ __forceinline__ void w_item(const WParams& p, const WGeom& g, int e, int b0, int ih_lo,
-                                       int gr0, int ci0, int cib, int co0, int* lds, long* gofs,
-                                       int* is_vec, int* from_dy) {
-  if (e < g.ptotal) {
-    int row = w_div(e, g.prowlen, g.pm_row);
-    int j = e - row * g.prowlen;
-    int pcol = w_div(j, g.pcpi, g.pm_cpi);
-    int cl = (j - pcol * g.pcpi) * (g.pvec ? 4 : 1);
-    int img = (p.NIMG == 1) ? 0 : row / p.NRI;
-    int prow = row - img * p.NRI;
-    int b = b0 + img, ih = ih_lo + prow, iw = pcol - p.pl;
-    *lds = (row * p.PW + pcol) * p.P + cl;
-    bool ok = (b < p.B) && (ih >= 0) && (ih < p.H) && (iw >= 0) && (iw < p.W) && (cl < cib);
-    *gofs = ok ? ((((long)b * p.H + ih) * p.W + iw) * p.CI + ci0 + cl) : -1;
-    *is_vec = g.pvec;
-    *from_dy = 0;
-  } else {
-    int d = e - g.ptotal;
-    int sl = w_div(d, g.dcpi, g.dm_cpi);
-    int cl = (d - sl * g.dcpi) * (g.dvec ? 4 : 1);
-    const long total_pix = (long)p.B * p.OH * p.OW;
-    const long pix = (long)gr0 * p.OW + sl;
-    bool ok = (sl < p.TR * p.OW) && (pix < total_pix) && (co0 + cl < p.CO);
-    *lds = p.patch_floats + sl * p.DP + cl;
-    *gofs = ok ? (pix * p.CO + co0 + cl) : -1;
-    *is_vec = g.dvec;
-    *from_dy = 1;
+template <int KMAX>
+__device__ __forceinline__ void wrow_issue(const WParams& p, const WLane<KMAX>& L, int r, int b0,
+                                           int ih_lo, int ci0, float4* v) {
+  const int img = (p.NIMG == 1) ? 0 : r / p.NRI;
+  const int prow = r - img * p.NRI;
+  const int b = b0 + img, ih = ih_lo + prow;
+  const bool row_ok = (b < p.B) && (ih >= 0) && (ih < p.H);
+  const char* rowp = reinterpret_cast<const char*>(p.in) +
+                     ((size_t)((b * p.H + ih) * p.W) * p.CI + ci0) * 4;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row_ok && ((L.okmask >> k) & 1u)) {
+      if (p.pvec) t = *reinterpret_cast<const float4*>(rowp + L.gofs[k]);
+      else t.x = *reinterpret_cast<const float*>(rowp + L.gofs[k]);
+      if (p.center) t = make_float4(2.f * t.x - 1.f, 2.f * t.y - 1.f, 2.f * t.z - 1.f, 2.f * t.w - 1.f);
+    }
+    v[k] = t;
   }
 }
 
-template <int NT>
-__device__ __forceinline__ void w_prefetch_issue(const WParams& p, const WGeom& g, float4* pf,
-                                                 int b0, int ih_lo, int gr0, int ci0, int cib,
-                                                 int co0, int tid) {
-  const int total = g.ptotal + g.dtotal;
+template <int KMAX>
+__device__ __forceinline__ void wrow_commit(const WParams& p, const WLane<KMAX>& L, int r,
+                                            const float4* v, float* patch) {
+  float* rowl = patch + r * p.PW * p.P;
 #pragma unroll
-  for (int i = 0; i < MAXV_W; ++i) {
-    int e = tid + i * NT;
+  for (int k = 0; k < KMAX; ++k) {
+    if ((L.jmask >> k) & 1u) {
+      if (p.pvec) *reinterpret_cast<float4*>(rowl + L.ldo[k]) = v[k];
+      else rowl[L.ldo[k]] = v[k].x;
+    }
+  }
+}
+
+// DY tile: item e < slots*cpd -> (slot = e / cpd, c = (e % cpd) * (vec ? 4 : 1))
+template <int DMAX, int NT>
+__device__ __forceinline__ void wdy_issue(const WParams& p, int gr0, int co0, int tid, float4* v) {
+  const int cpd = p.dvec ? (p.COB >> 2) : p.COB;
+  const int total = p.slots * cpd;
+  const long total_pix = (long)p.B * p.OH * p.OW;
+  const long pix0 = (long)gr0 * p.OW;
+  const int real_slots = p.TR * p.OW;
+#pragma unroll
+  for (int i = 0; i < DMAX; ++i) {
+    const int e = tid + i * NT;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < total) {
-      int lds, isv, fdy;
-      long go;
-      w_item(p, g, e, b0, ih_lo, gr0, ci0, cib, co0, &lds, &go, &isv, &fdy);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (go >= 0) {
-        const float* src = (fdy ? p.dy : p.in) + go;
-        if (isv) v = *reinterpret_cast<const float4*>(src);
-        else v.x = src[0];
-        if (p.center && !fdy)
-          v = make_float4(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f, 2.f * v.w - 1.f);
+      const int sl = e / cpd;
+      const int cl = (e - sl * cpd) * (p.dvec ? 4 : 1);
+      if (sl < real_slots && pix0 + sl < total_pix && co0 + cl < p.CO) {
+        const float* src = p.dy + (size_t)(pix0 + sl) * p.CO + co0 + cl;
+        if (p.dvec) t = *reinterpret_cast<const float4*>(src);
+        else t.x = src[0];
       }
-      pf[i] = v;
     }
+    v[i] = t;
   }
 }
 
-template <int NT>
-__device__ __forceinline__ void w_prefetch_commit(const WParams& p, const WGeom& g,
-                                                  const float4* pf, float* smem, int ci0, int cib,
-                                                  int co0, int tid) {
-  const int total = g.ptotal + g.dtotal;
+template <int DMAX, int NT>
+__device__ __forceinline__ void wdy_commit(const WParams& p, int tid, const float4* v, float* dyl) {
+  const int cpd = p.dvec ? (p.COB >> 2) : p.COB;
+  const int total = p.slots * cpd;
 #pragma unroll
-  for (int i = 0; i < MAXV_W; ++i) {
-    int e = tid + i * NT;
+  for (int i = 0; i < DMAX; ++i) {
+    const int e = tid + i * NT;
     if (e < total) {
-      int lds, isv, fdy;
-      long go;
-      w_item(p, g, e, 0, 0, 0, ci0, cib, co0, &lds, &go, &isv, &fdy);
-      float4 v = pf[i];
-      if (isv) *reinterpret_cast<float4*>(smem + lds) = v;
-      else smem[lds] = v.x;
+      const int sl = e / cpd;
+      const int cl = (e - sl * cpd) * (p.dvec ? 4 : 1);
+      if (p.dvec) *reinterpret_cast<float4*>(dyl + sl * p.DP + cl) = v[i];
+      else dyl[sl * p.DP + cl] = v[i].x;
     }
   }
 }
 
-// synchronous staging for tiles too large to prefetch through registers
-__device__ __forceinline__ void w_stage_sync(const WParams& p, const WGeom& g, float* smem, int b0,
-                                             int ih_lo, int gr0, int ci0, int cib, int co0, int tid,
-                                             int nthreads) {
-  const int total = g.ptotal + g.dtotal;
-  for (int e = tid; e < total; e += nthreads) {
-    int lds, isv, fdy;
-    long go;
-    w_item(p, g, e, b0, ih_lo, gr0, ci0, cib, co0, &lds, &go, &isv, &fdy);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (go >= 0) {
-      const float* src = (fdy ? p.dy : p.in) + go;
-      if (isv) v = *reinterpret_cast<const float4*>(src);
-      else v.x = src[0];
-      if (p.center && !fdy)
-        v = make_float4(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f, 2.f * v.w - 1.f);
-    }
-    if (isv) *reinterpret_cast<float4*>(smem + lds) = v;
-    else smem[lds] = v.x;
-  }
-}
-
-template <int TNACC>
+template <int TNACC, int KMAX, int RPWMAX, int DMAX>
 __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
   float* dyl = smem + p.patch_floats;
   int* tbl = reinterpret_cast<int*>(smem + p.patch_floats + p.dy_floats);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = W_UNIFORM(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   constexpr int NT = NW_W * 64;
   const int ci0 = blockIdx.y * p.CIB, co0 = blockIdx.z * p.COB;
@@ -189,8 +172,9 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   const int n_wt = p.nrt * p.ncot;
   const int n_bias = (p.want_bias && blockIdx.y == 0) ? p.ncot : 0;
   const int n_tot = n_wt + n_bias;
-  const WGeom wg = w_geom(p, ci0, cib);
-  const bool pipelined = (wg.ptotal + wg.dtotal) <= MAXV_W * NT;
+  const int nrows_p = p.NIMG * p.NRI;
+  const bool pipelined = p.pipelined != 0;
+  const WLane<KMAX> WL = wlane_init<KMAX>(p, lane, cib);
 
   // slot -> patch base table (identical for every tile of this launch)
   for (int s = tid; s < p.slots; s += NT) {
@@ -227,12 +211,17 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
 #pragma unroll
   for (int a = 0; a < TNACC; ++a) acc[a] = f32x16_zero();
 
-  float4 pf[MAXV_W];
+  float4 pf[RPWMAX * KMAX], df[DMAX];
   int tile = blockIdx.x;
   if (pipelined && tile < p.n_tiles) {
     const int gr0 = tile * p.TR;
     const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
-    w_prefetch_issue<NT>(p, wg, pf, b0, oh0 * p.S - p.pt, gr0, ci0, cib, co0, tid);
+#pragma unroll
+    for (int q = 0; q < RPWMAX; ++q) {
+      const int r = wave + NW_W * q;
+      if (r < nrows_p) wrow_issue<KMAX>(p, WL, r, b0, oh0 * p.S - p.pt, ci0, pf + q * KMAX);
+    }
+    wdy_issue<DMAX, NT>(p, gr0, co0, tid, df);
   }
 
   for (; tile < p.n_tiles; tile += gridDim.x) {
@@ -241,16 +230,43 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     const int ih_lo = oh0 * p.S - p.pt;
     __syncthreads();
     if (pipelined) {
-      w_prefetch_commit<NT>(p, wg, pf, smem, ci0, cib, co0, tid);
+#pragma unroll
+      for (int q = 0; q < RPWMAX; ++q) {
+        const int r = wave + NW_W * q;
+        if (r < nrows_p) wrow_commit<KMAX>(p, WL, r, pf + q * KMAX, patch);
+      }
+      wdy_commit<DMAX, NT>(p, tid, df, dyl);
       __syncthreads();
       const int nt = tile + gridDim.x;
       if (nt < p.n_tiles) {
         const int g2 = nt * p.TR;
         const int b2 = g2 / p.OH, o2 = g2 - b2 * p.OH;
-        w_prefetch_issue<NT>(p, wg, pf, b2, o2 * p.S - p.pt, g2, ci0, cib, co0, tid);
+#pragma unroll
+        for (int q = 0; q < RPWMAX; ++q) {
+          const int r = wave + NW_W * q;
+          if (r < nrows_p) wrow_issue<KMAX>(p, WL, r, b2, o2 * p.S - p.pt, ci0, pf + q * KMAX);
+        }
+        wdy_issue<DMAX, NT>(p, g2, co0, tid, df);
       }
     } else {
-      w_stage_sync(p, wg, smem, b0, ih_lo, gr0, ci0, cib, co0, tid, NT);
+      for (int r0 = wave; r0 < nrows_p; r0 += NW_W * RPWMAX) {
+#pragma unroll
+        for (int q = 0; q < RPWMAX; ++q) {
+          const int r = r0 + NW_W * q;
+          if (r < nrows_p) wrow_issue<KMAX>(p, WL, r, b0, ih_lo, ci0, pf + q * KMAX);
+        }
+#pragma unroll
+        for (int q = 0; q < RPWMAX; ++q) {
+          const int r = r0 + NW_W * q;
+          if (r < nrows_p) wrow_commit<KMAX>(p, WL, r, pf + q * KMAX, patch);
+        }
+      }
+      const int cpd = p.dvec ? (p.COB >> 2) : p.COB;
+      for (int e0 = 0; e0 < p.slots * cpd; e0 += NT * DMAX) {
+        // DY rows in batches of DMAX items per thread (item index = (tid + e0) + i*NT)
+        wdy_issue<DMAX, NT>(p, gr0, co0, tid + e0, df);
+        wdy_commit<DMAX, NT>(p, tid + e0, df, dyl);
+      }
       __syncthreads();
     }
     const int npairs = p.slots >> 1;
@@ -322,18 +338,10 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
     p.TR = p.NIMG * p.OH;
   } else {
     p.NIMG = 1;
-    // largest tile (<= TARGET pixels) whose IN patch + DY rows still fit the register
-    // prefetch (MAXV_W float4 per thread at <= 64 channels per block); else the largest
-    int pick = 0, pick_pipe = 0;
-    const int c4 = ((p.CI < 64 ? p.CI : 64) + 3) / 4, o4 = ((p.CO < 64 ? p.CO : 64) + 3) / 4;
-    for (int tr = 1; tr <= p.OH; ++tr) {
-      if (p.OH % tr != 0 || tr * p.OW > TARGET) continue;
-      pick = tr;
-      long items = (long)((tr - 1) * S + p.KH) * ((p.OW - 1) * S + p.KW) * c4 + (long)tr * p.OW * o4;
-      if (items <= 16 * NW_W * 64) pick_pipe = tr;
-    }
+    int pick = 0;
+    for (int tr = 1; tr <= p.OH; ++tr)
+      if (p.OH % tr == 0 && tr * p.OW <= TARGET) pick = tr;
     if (pick == 0) pick = 1;
-    if (pick_pipe * 2 >= pick) pick = pick_pipe;
     p.TR = p.RPI = pick;
   }
   p.n_tiles = (p.B * p.OH + p.TR - 1) / p.TR;
@@ -357,12 +365,17 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
       if (nrt * ncot + ncot > NACC * NW_W) continue;
       int P = CIB;
       if ((p.CI & 3) == 0 && (CIB & 3) != 0) continue;
+      const bool pv = ((p.CI & 3) == 0) && ((CIB & 3) == 0);
+      if ((long)p.PW * (pv ? CIB / 4 : CIB) > 64 * 9) continue;  // staging: <= 9 items per lane per row
       long pf = ((long)p.NIMG * p.NRI * p.PW * P + 3) & ~3L;
       int DP = COB + 4;
       long df = (long)p.slots * DP;
       if (pf + df + p.slots + 16 > budget) continue;
       p.CIB = CIB; p.COB = COB; p.P = P; p.DP = DP;
       p.nrt = nrt; p.ncot = ncot;
+      p.pvec = pv ? 1 : 0;
+      p.dvec = (((p.CO & 3) == 0) && ((COB & 3) == 0)) ? 1 : 0;
+      p.KI = (p.PW * (pv ? CIB / 4 : CIB) + 63) / 64;
       p.patch_floats = (int)pf;
       p.dy_floats = (int)df;
       *lds_bytes = (size_t)(pf + df + p.slots + 16) * 4;
@@ -376,6 +389,24 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
   return false;
 }
 
+template <int TNACC, int KMAX, int RPWMAX, int DMAX>
+int launch_winst(WParams& p, dim3 grid, size_t lds, void* stream) {
+  const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
+  const int ditems = p.slots * (p.dvec ? p.COB / 4 : p.COB);
+  p.pipelined = (rpw <= RPWMAX && ditems <= DMAX * NW_W * 64 && p.KI <= KMAX) ? 1 : 0;
+  if (p.KI > KMAX) return odin_fail(-2, "wgrad: patch row too long for this instance");
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+#endif
+  ODIN_LAUNCH((wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX>), grid, dim3(NW_W * 64), lds, stream, p);
+  return odin_check_launch("wgrad");
+}
+
 int launch_wgrad(WParams& p, int* rows_out, void* stream) {
   int gx, gy, gz;
   size_t lds;
@@ -383,23 +414,18 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
   if (!plan_wgrad(p, &gx, &gy, &gz, &lds)) return odin_fail(-2, "wgrad: no tiling plan");
   if (rows_out) *rows_out = gx;
   if (p.slab == nullptr) return 0;  // dry run: planning only
-#ifndef ODIN_SIM
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<5>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NACC>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
-#endif
-  dim3 grid(gx, gy, gz), block(NW_W * 64);
+  dim3 grid(gx, gy, gz);
   const int tiles_per_block = p.nrt * p.ncot + (p.want_bias ? p.ncot : 0);
-  if ((tiles_per_block + NW_W - 1) / NW_W <= 5)
-    ODIN_LAUNCH(wgrad_kernel<5>, grid, block, lds, stream, p);
-  else
-    ODIN_LAUNCH(wgrad_kernel<NACC>, grid, block, lds, stream, p);
-  return odin_check_launch("wgrad");
+  const int nacc = (tiles_per_block + NW_W - 1) / NW_W;
+  const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
+  const int ditems = p.slots * (p.dvec ? p.COB / 4 : p.COB);
+  if (nacc <= 5) {
+    if (p.KI <= 5 && rpw <= 5 && ditems <= 4 * 256) return launch_winst<5, 5, 5, 4>(p, grid, lds, stream);
+    if (rpw <= 3 && ditems <= 4 * 256) return launch_winst<5, 9, 3, 4>(p, grid, lds, stream);
+    return launch_winst<5, 9, 2, 8>(p, grid, lds, stream);
+  }
+  if (p.KI <= 5 && rpw <= 5) return launch_winst<NACC, 5, 5, 8>(p, grid, lds, stream);
+  return launch_winst<NACC, 9, 2, 8>(p, grid, lds, stream);
 }
 
 constexpr int MAX_JOBS = 64;
