@@ -38,6 +38,7 @@ struct WParams {
   int slab_stride;
   int patch_floats, dy_floats;
   int pvec, dvec, KI, pipelined;
+  int bias_mode;  // 0 none, 1 extra MFMA tile with A = 1, 2 summed while staging DY
 };
 
 // ---- staging ------------------------------------------------------------------------
@@ -140,13 +141,16 @@ __device__ __forceinline__ void wdy_issue(const WParams& p, int gr0, int co0, in
 }
 
 template <int DMAX, int NT>
-__device__ __forceinline__ void wdy_commit(const WParams& p, int tid, const float4* v, float* dyl) {
+__device__ __forceinline__ void wdy_commit(const WParams& p, int tid, const float4* v, float* dyl,
+                                           float4& bsum) {
   const int cpd = p.dvec ? (p.COB >> 2) : p.COB;
   const int total = p.slots * cpd;
 #pragma unroll
   for (int i = 0; i < DMAX; ++i) {
     const int e = tid + i * NT;
     if (e < total) {
+      // bias gradient (bias_mode 2): every item of this thread carries the same 4 channels
+      bsum.x += v[i].x; bsum.y += v[i].y; bsum.z += v[i].z; bsum.w += v[i].w;
       const int sl = e / cpd;
       const int cl = (e - sl * cpd) * (p.dvec ? 4 : 1);
       if (p.dvec) *reinterpret_cast<float4*>(dyl + sl * p.DP + cl) = v[i];
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   const int ntaps = p.KH * p.KW;
   const int nrows = ntaps * cib;
   const int n_wt = p.nrt * p.ncot;
-  const int n_bias = (p.want_bias && blockIdx.y == 0) ? p.ncot : 0;
+  const int n_bias = (p.bias_mode == 1 && blockIdx.y == 0) ? p.ncot : 0;
   const int n_tot = n_wt + n_bias;
   const int nrows_p = p.NIMG * p.NRI;
   const bool pipelined = p.pipelined != 0;
@@ -183,14 +187,18 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     tbl[s] = (r < p.TR) ? ((img * p.NRI + rl * p.S) * p.PW + c * p.S) * p.P : 0;
   }
 
-  // per-accumulator lane constants
-  int a_off[TNACC], b_off[TNACC], a_kind[TNACC];  // kind 0: zero row, 1: patch, 2: ones (bias)
+  // per-accumulator lane constants.  A operand = patch value * amul + aadd: (1,0) for a
+  // weight-gradient row, (0,1) for the MFMA bias tile (bias_mode 1), (0,0) for padding
+  // rows / unused accumulators -- branch-free in the hot loop.
+  int a_off[TNACC], b_off[TNACC];
+  float amul[TNACC], aadd[TNACC];
 #pragma unroll
   for (int a = 0; a < TNACC; ++a) {
     int T = wave + a * NW_W;
     a_off[a] = 0;
     b_off[a] = l31;
-    a_kind[a] = 0;
+    amul[a] = 0.f;
+    aadd[a] = 0.f;
     if (T < n_wt) {
       int rt = T / p.ncot, cot = T - rt * p.ncot;
       int rl = rt * 32 + l31;
@@ -199,13 +207,14 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
         int tap = rl / cib, cl = rl - tap * cib;
         int kh = tap / p.KW, kw = tap - kh * p.KW;
         a_off[a] = (kh * p.PW + kw) * p.P + cl;
-        a_kind[a] = 1;
+        amul[a] = 1.f;
       }
     } else if (T < n_tot) {
       b_off[a] = (T - n_wt) * 32 + l31;
-      a_kind[a] = 2;
+      aadd[a] = 1.f;
     }
   }
+  float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   f32x16 acc[TNACC];
 #pragma unroll
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
         const int r = wave + NW_W * q;
         if (r < nrows_p) wrow_commit<KMAX>(p, WL, r, pf + q * KMAX, patch);
       }
-      wdy_commit<DMAX, NT>(p, tid, df, dyl);
+      wdy_commit<DMAX, NT>(p, tid, df, dyl, bsum4);
       __syncthreads();
       const int nt = tile + gridDim.x;
       if (nt < p.n_tiles) {
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
       for (int e0 = 0; e0 < p.slots * cpd; e0 += NT * DMAX) {
         // DY rows in batches of DMAX items per thread (item index = (tid + e0) + i*NT)
         wdy_issue<DMAX, NT>(p, gr0, co0, tid + e0, df);
-        wdy_commit<DMAX, NT>(p, tid + e0, df, dyl);
+        wdy_commit<DMAX, NT>(p, tid + e0, df, dyl, bsum4);
       }
       __syncthreads();
     }
@@ -279,24 +288,19 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
       const float* brow = dyl + s * p.DP;
 #pragma unroll
       for (int a = 0; a < TNACC; ++a) {
-        if (wave + a * NW_W < n_tot) {  // wave-uniform
-          float t = patch[base + a_off[a]];
-          a_[a] = (a_kind[a] == 1) ? t : (a_kind[a] == 2 ? 1.f : 0.f);
-          b_[a] = brow[b_off[a]];
-        }
+        a_[a] = fmaf(patch[base + a_off[a]], amul[a], aadd[a]);
+        b_[a] = brow[b_off[a]];
       }
     };
     load_pair(0, av[0], bv[0]);
     for (int kp = 0; kp < npairs; kp += 2) {
       if (kp + 1 < npairs) load_pair(kp + 1, av[1], bv[1]);
 #pragma unroll
-      for (int a = 0; a < TNACC; ++a)
-        if (wave + a * NW_W < n_tot) acc[a] = mfma32(av[0][a], bv[0][a], acc[a]);
+      for (int a = 0; a < TNACC; ++a) acc[a] = mfma32(av[0][a], bv[0][a], acc[a]);
       if (kp + 2 < npairs) load_pair(kp + 2, av[0], bv[0]);
       if (kp + 1 < npairs) {
 #pragma unroll
-        for (int a = 0; a < TNACC; ++a)
-          if (wave + a * NW_W < n_tot) acc[a] = mfma32(av[1][a], bv[1][a], acc[a]);
+        for (int a = 0; a < TNACC; ++a) acc[a] = mfma32(av[1][a], bv[1][a], acc[a]);
       }
     }
   }
@@ -322,6 +326,22 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
       int co = co0 + cot * 32 + l31;
       if (h == 0 && co < p.CO && cot * 32 + l31 < p.COB)
         row[(size_t)ntaps * p.CI * p.CO + co] = acc[a][0];
+    }
+  }
+  if (p.bias_mode == 2 && blockIdx.y == 0) {
+    // thread t accumulated channels 4*(t % cpd) .. +3 of this block's output-channel slice
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(smem);
+    red[tid] = bsum4;
+    __syncthreads();
+    const int cpd = p.COB >> 2;
+    if (tid < cpd) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = tid; u < NT; u += cpd) {
+        t.x += red[u].x; t.y += red[u].y; t.z += red[u].z; t.w += red[u].w;
+      }
+      float* bp = row + (size_t)ntaps * p.CI * p.CO + co0 + 4 * tid;
+      if (co0 + 4 * tid + 3 < p.CO) { bp[0] = t.x; bp[1] = t.y; bp[2] = t.z; bp[3] = t.w; }
     }
   }
 }
@@ -362,7 +382,9 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
       if (CIB > p.CI) continue;
       if (jc > 0 && CIB == p.CI) continue;
       int nrt = (ntaps * CIB + 31) / 32;
-      if (nrt * ncot + ncot > NACC * NW_W) continue;
+      const bool dv = ((p.CO & 3) == 0) && ((COB & 3) == 0);
+      const int bmode = !p.want_bias ? 0 : ((dv && (256 % (COB / 4)) == 0) ? 2 : 1);
+      if (nrt * ncot + (bmode == 1 ? ncot : 0) > NACC * NW_W) continue;
       int P = CIB;
       if ((p.CI & 3) == 0 && (CIB & 3) != 0) continue;
       const bool pv = ((p.CI & 3) == 0) && ((CIB & 3) == 0);
@@ -373,12 +395,14 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
       if (pf + df + p.slots + 16 > budget) continue;
       p.CIB = CIB; p.COB = COB; p.P = P; p.DP = DP;
       p.nrt = nrt; p.ncot = ncot;
+      p.bias_mode = bmode;
       p.pvec = pv ? 1 : 0;
       p.dvec = (((p.CO & 3) == 0) && ((COB & 3) == 0)) ? 1 : 0;
       p.KI = (p.PW * (pv ? CIB / 4 : CIB) + 63) / 64;
       p.patch_floats = (int)pf;
       p.dy_floats = (int)df;
       *lds_bytes = (size_t)(pf + df + p.slots + 16) * 4;
+      if (*lds_bytes < 4352) *lds_bytes = 4352;  // room for the end-of-kernel bias reduction
       int g = p.n_tiles < ODIN_MAX_SLAB_BLOCKS ? p.n_tiles : ODIN_MAX_SLAB_BLOCKS;
       *gx = g < 1 ? 1 : g;
       *gy = (p.CI + CIB - 1) / CIB;
@@ -415,14 +439,14 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
   if (rows_out) *rows_out = gx;
   if (p.slab == nullptr) return 0;  // dry run: planning only
   dim3 grid(gx, gy, gz);
-  const int tiles_per_block = p.nrt * p.ncot + (p.want_bias ? p.ncot : 0);
+  const int tiles_per_block = p.nrt * p.ncot + (p.bias_mode == 1 ? p.ncot : 0);
   const int nacc = (tiles_per_block + NW_W - 1) / NW_W;
   const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
   const int ditems = p.slots * (p.dvec ? p.COB / 4 : p.COB);
-  if (nacc <= 5) {
-    if (p.KI <= 5 && rpw <= 5 && ditems <= 4 * 256) return launch_winst<5, 5, 5, 4>(p, grid, lds, stream);
-    if (rpw <= 3 && ditems <= 4 * 256) return launch_winst<5, 9, 3, 4>(p, grid, lds, stream);
-    return launch_winst<5, 9, 2, 8>(p, grid, lds, stream);
+  if (nacc <= 4) {
+    if (p.KI <= 5 && rpw <= 5 && ditems <= 4 * 256) return launch_winst<4, 5, 5, 4>(p, grid, lds, stream);
+    if (rpw <= 3 && ditems <= 4 * 256) return launch_winst<4, 9, 3, 4>(p, grid, lds, stream);
+    return launch_winst<4, 9, 2, 8>(p, grid, lds, stream);
   }
   if (p.KI <= 5 && rpw <= 5) return launch_winst<NACC, 5, 5, 8>(p, grid, lds, stream);
   return launch_winst<NACC, 9, 2, 8>(p, grid, lds, stream);
