@@ -207,7 +207,7 @@ class NetProgram:
   # -- backward -------------------------------------------------------------------------
   def backward(self, x: torch.Tensor, gout_last: torch.Tensor, st,
                dx_out: Optional[torch.Tensor] = None, last: Optional[int] = None,
-               skip_bias_of_last: bool = False) -> List[ReduceJob]:
+               skip_bias_of_last: bool = False, data_only: bool = False) -> List[ReduceJob]:
     """gout_last: dL/d(pre-activation output of the last layer).  If dx_out is given the
     gradient wrt the network input is written there.  Returns the slab-reduce jobs."""
     lib, B = self.lib, self.B
@@ -220,7 +220,9 @@ class NetProgram:
       xin = x if i == 0 else self.outs[i - 1]
       # ---- weight (and bias) gradient ----
       slab = self.wslabs[i]
-      if r.kind == 'conv':
+      if data_only:
+        pass
+      elif r.kind == 'conv':
         lib.odin_conv2d_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows),
                               C.byref(d), st)
       elif r.kind == 'deconv':
@@ -229,12 +231,13 @@ class NetProgram:
       else:
         lib.odin_dense_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows), B,
                              r.K, r.N, st)
-      assert rows.value == self.wrows[i]
-      n_red = slab.shape[1]
-      if skip_bias_of_last and i == n - 1 and r.kind != 'deconv':
-        n_red = r.w_n  # the fused tail already delivers this layer's bias gradient
-      jobs.append(ReduceJob(slab.data_ptr(), self.grads[r.w_off:].data_ptr(), n_red, rows.value,
-                            slab.shape[1], 0))
+      if not data_only:
+        assert rows.value == self.wrows[i]
+        n_red = slab.shape[1]
+        if skip_bias_of_last and i == n - 1 and r.kind != 'deconv':
+          n_red = r.w_n  # the fused tail already delivers this layer's bias gradient
+        jobs.append(ReduceJob(slab.data_ptr(), self.grads[r.w_off:].data_ptr(), n_red, rows.value,
+                              slab.shape[1], 0))
       # ---- data gradient -> pre-activation gradient of the previous layer ----
       if i > 0:
         prev = self.recs[i - 1]
@@ -255,7 +258,7 @@ class NetProgram:
       else:
         lib.odin_dense_dgrad(g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
                              bsp, C.byref(rows), B, r.K, r.N, st)
-      if bslab is not None:
+      if bslab is not None and not data_only:
         pr = self.recs[i - 1]
         jobs.append(ReduceJob(bslab.data_ptr(), self.grads[pr.b_off:].data_ptr(), pr.b_n,
                               rows.value, pr.b_n, 0))
@@ -279,7 +282,8 @@ class VAEEngine:
 
   def __init__(self, enc_layers, dec_layers, in_shape, zdim, batch_size, device,
                observation='bernoulli', analytic=False, free_bits=None, tc=None, lib=None,
-               params: Optional[torch.Tensor] = None, world_size: int = 1, seed: int = 1):
+               params: Optional[torch.Tensor] = None, world_size: int = 1, seed: int = 1,
+               optim_state: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     self.lib = lib if lib is not None else _lib.load()
     self.device = torch.device(device)
     self.B, self.D = int(batch_size), int(zdim)
@@ -307,8 +311,11 @@ class VAEEngine:
     self.params = params if params is not None else torch.zeros(n, **f32)
     assert self.params.numel() == n
     self.grads = torch.zeros(n, **f32)
-    self.m = torch.zeros(n, **f32)
-    self.v = torch.zeros(n, **f32)
+    if optim_state is not None:
+      self.m, self.v = optim_state
+    else:
+      self.m = torch.zeros(n, **f32)
+      self.v = torch.zeros(n, **f32)
     self.n_params = sum(int(np.prod(s)) for _, s, _ in self.layout.entries)
     # ---- programs / buffers ----
     B, D = self.B, self.D
@@ -407,7 +414,7 @@ class VAEEngine:
       views[k].copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32).to(self.device))
 
   def set_hyper(self, lr=1e-3, beta=1.0, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0,
-                t: Optional[int] = None):
+                t: Optional[int] = None, tc_coef: Optional[float] = None):
     """Host scalars -> device (one small async H2D copy)."""
     t = self.step_count if t is None else t
     tt = max(int(t), 1)
@@ -423,6 +430,8 @@ class VAEEngine:
     h[H_BETA] = beta
     h[H_TCCOEF] = (beta - 1.0) if self.tc_mode == 'betatc' else 0.0
     h[H_TCGRAD] = (beta - 1.0) / self.world_size if self.tc_mode == 'betatc' else 0.0
+    if tc_coef is not None:  # FactorVAE: tc term = tc_coef * mean(D(z))
+      h[H_TCCOEF] = tc_coef
     h[N_HYPER:].view(torch.int32)[0] = int(t)
     self.hyper.copy_(h, non_blocking=True)
     if self.device.type == 'cuda':
@@ -430,9 +439,35 @@ class VAEEngine:
       ev.record(torch.cuda.current_stream(self.device))
       self._ring_ev[self._ring_i] = ev
 
+  # ---- partial passes used by the model API (encode / decode) ---------------------------
+  def run_encoder(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, st=None):
+    """encoder -> Dense(2D) -> (loc, softplus(raw)) -> z = loc + scale*eps; fills p, z, kl."""
+    lib, B, D = self.lib, self.B, self.D
+    st = self.stream() if st is None else st
+    assert x.shape == (B,) + self.in_shape and x.is_contiguous()
+    self.x = x
+    if eps is None:
+      lib.odin_rng_normal(self.eps.data_ptr(), B * D, self.seed, self.hp(N_HYPER), st)
+    elif eps is not self.eps:
+      self.eps.copy_(eps)
+    h_e = self.enc.forward(x, st)
+    lw = self.params[self.lat_w_off:]
+    lb = self.params[self.lat_b_off:]
+    lib.odin_dense_fwd(h_e.data_ptr(), lw.data_ptr(), lb.data_ptr(), self.p.data_ptr(), B,
+                       self.hdim, 2 * D, 0, st)
+    lib.odin_latent_fwd(self.p.data_ptr(), self.eps.data_ptr(), self.z.data_ptr(),
+                        self.kl.data_ptr(), self.fbmask.data_ptr(), B, D, int(self.analytic),
+                        self.free_bits, st)
+    return self.p, self.z
+
+  def run_decoder(self, z: torch.Tensor, st=None):
+    st = self.stream() if st is None else st
+    assert z.shape == (self.B, self.D) and z.is_contiguous()
+    return self.dec.forward(z, st)
+
   # ---- forward -----------------------------------------------------------------------
   def forward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, st=None,
-              fused: bool = True):
+              fused: bool = True, tc_ptr: Optional[int] = None, finalize: bool = True):
     """Runs encode -> reparameterise -> decode -> ELBO (+ dlogits).  `eps=None` draws the
     noise on device from the Philox stream (seed, step)."""
     lib, B, D = self.lib, self.B, self.D
@@ -492,9 +527,20 @@ class VAEEngine:
                                          self.tc_dloc.data_ptr(), self.tc_dscale.data_ptr(),
                                          self.hp(H_TCGRAD), B, D, st)
       tcp = self.tc_ws.data_ptr()
-    lib.odin_elbo_finalize(llk_part.data_ptr(), self.n_part, self.kl.data_ptr(),
-                           self.hp(H_BETA), tcp, self.llk.data_ptr(), self.out4.data_ptr(), B, st)
+    self._llk_part_used = llk_part
+    if tc_ptr is not None:
+      tcp = tc_ptr
+    if finalize:
+      lib.odin_elbo_finalize(llk_part.data_ptr(), self.n_part, self.kl.data_ptr(),
+                             self.hp(H_BETA), tcp, self.llk.data_ptr(), self.out4.data_ptr(), B,
+                             st)
     return h_d
+
+  def finalize(self, tc_ptr: Optional[int] = None, st=None):
+    st = self.stream() if st is None else st
+    self.lib.odin_elbo_finalize(self._llk_part_used.data_ptr(), self.n_part, self.kl.data_ptr(),
+                                self.hp(H_BETA), tc_ptr, self.llk.data_ptr(),
+                                self.out4.data_ptr(), self.B, st)
 
   # ---- backward ----------------------------------------------------------------------
   def backward(self, st=None, extra_dz: Optional[torch.Tensor] = None):

@@ -1,0 +1,799 @@
+"""VariationalAutoencoder / BetaVAE / AnnealingVAE / BetaTCVAE / FactorVAE on the HIP engine.
+
+Drop-in for the reference's model API on this path (same class names, constructor
+arguments, method names, returned structures and error behaviour):
+
+  odin/bay/vi/autoencoder/variational_autoencoder.py:132 (VariationalAutoencoder, VAEStep)
+  odin/bay/vi/_base.py:21-194                             (ELBO configuration, elbo())
+  odin/bay/vi/autoencoder/beta_vae.py:11,83,110           (BetaVAE, AnnealingVAE, BetaTCVAE)
+  odin/bay/vi/autoencoder/factor_vae.py:99                (FactorVAE, two-step training)
+  odin/networks/base_networks.py:415-812                  (optimize(), fit())
+
+Tensors are torch tensors on the model's device; returned "distributions" are light
+objects exposing what callers of the reference use (mean / stddev / sample / log_prob /
+event_shape / batch_shape / KL_divergence).  Every FLOP of encode / decode / ELBO /
+backward / Adam runs in libodin_hip.so through ``VAEEngine``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import pickle
+from dataclasses import dataclass, field
+from typing import Any, Callable, Dict, Iterator, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import (ACT, H_ALPHA, N_HYPER, NetProgram, ParamLayout, ReduceJob, VAEEngine,
+                     build_layers)
+from .interpolation import Interpolation, linear
+from .networks import RVconf, SequentialNetwork, get_networks
+
+LOG2PI = math.log(2.0 * math.pi)
+
+
+# ======================================================================================
+# light distribution objects
+# ======================================================================================
+class KLdivergence:
+  """odin/bay/helpers.py:285-372: callable attached to the posterior; `.prior` attribute."""
+
+  def __init__(self, posterior: 'MVNDiagPosterior', prior='Independent(Normal(0,1))'):
+    self.posterior, self.prior = posterior, prior
+
+  def __call__(self, analytic=False, reverse=True, free_bits=None, sample_shape=None,
+               keepdims=False):
+    q = self.posterior
+    if not reverse:
+      raise NotImplementedError('reverse=False (KL(p||q)) is outside the HIP path')
+    if analytic:
+      kl = 0.5 * (q.scale ** 2 + q.loc ** 2 - 1.0 - 2.0 * torch.log(q.scale)).sum(-1)
+    else:
+      z = q.z
+      lq = (-0.5 * ((z - q.loc) / q.scale) ** 2 - torch.log(q.scale)).sum(-1)
+      lp = (-0.5 * z ** 2).sum(-1)
+      kl = lq - lp
+    if free_bits is not None:
+      kl = torch.clamp(kl, min=free_bits * q.loc.shape[-1])
+    if analytic and keepdims:
+      kl = kl.unsqueeze(0)  # odin/bay/helpers.py:370-371
+    return kl
+
+
+class MVNDiagPosterior:
+  """MultivariateNormalDiag(loc, softplus(raw)) with its cached sample
+  (odin/bay/layers/continuous.py:459-483; dense_distribution.py:339-380)."""
+
+  def __init__(self, p: torch.Tensor, z: torch.Tensor, D: int):
+    self.loc = p[:, :D]
+    self.raw_scale = p[:, D:]
+    self.scale = torch.nn.functional.softplus(self.raw_scale)
+    self.z = z
+    self.KL_divergence = KLdivergence(self)
+
+  event_shape = property(lambda self: (self.loc.shape[-1],))
+  batch_shape = property(lambda self: tuple(self.loc.shape[:-1]))
+
+  def mean(self):
+    return self.loc
+
+  def stddev(self):
+    return self.scale
+
+  def sample(self, n=None, seed=None):
+    g = None
+    if seed is not None:
+      g = torch.Generator(device=self.loc.device).manual_seed(int(seed))
+    shp = tuple(self.loc.shape) if n is None else (int(n),) + tuple(self.loc.shape)
+    return self.loc + self.scale * torch.randn(shp, device=self.loc.device, generator=g)
+
+  def log_prob(self, z):
+    D = self.loc.shape[-1]
+    return (-0.5 * ((z - self.loc) / self.scale) ** 2 - torch.log(self.scale)).sum(-1) \
+        - 0.5 * D * LOG2PI
+
+  def __array__(self):
+    return self.z.detach().cpu().numpy()
+
+  def tensor(self):
+    """tf.convert_to_tensor(q): the cached sample."""
+    return self.z
+
+
+class BernoulliObservation:
+  """Independent(Bernoulli(logits), 3) (odin/networks/image_networks.py:87-93)."""
+
+  def __init__(self, logits: torch.Tensor):
+    self.logits = logits
+
+  event_shape = property(lambda self: tuple(self.logits.shape[1:]))
+  batch_shape = property(lambda self: (self.logits.shape[0],))
+
+  def mean(self):
+    return torch.sigmoid(self.logits)
+
+  def log_prob(self, x):
+    e = x * self.logits - torch.nn.functional.softplus(self.logits)
+    return e.reshape(e.shape[0], -1).sum(1)
+
+  def sample(self, n=None):
+    p = self.mean()
+    if n is not None:
+      p = p.unsqueeze(0).expand((int(n),) + tuple(p.shape))
+    return torch.bernoulli(p)
+
+
+class GaussianObservation:
+  """Independent(Normal(loc, scale), 3), params split on the channel axis
+  (image_networks.py:95-102); softplus1 scale as GaussianLayer (continuous.py:196-260)."""
+
+  def __init__(self, h: torch.Tensor, softplus1: bool):
+    Cc = h.shape[-1] // 2
+    self.loc = h[..., :Cc]
+    raw = h[..., Cc:]
+    self.scale = torch.nn.functional.softplus(raw + math.log(math.e - 1.0)) if softplus1 else raw
+
+  event_shape = property(lambda self: tuple(self.loc.shape[1:]))
+  batch_shape = property(lambda self: (self.loc.shape[0],))
+
+  def mean(self):
+    return self.loc
+
+  def stddev(self):
+    return self.scale
+
+  def log_prob(self, x):
+    e = -0.5 * ((x - self.loc) / self.scale) ** 2 - torch.log(self.scale) - 0.5 * LOG2PI
+    return e.reshape(e.shape[0], -1).sum(1)
+
+  def sample(self, n=None):
+    shp = tuple(self.loc.shape) if n is None else (int(n),) + tuple(self.loc.shape)
+    return self.loc + self.scale * torch.randn(shp, device=self.loc.device)
+
+
+# ======================================================================================
+# training step objects
+# ======================================================================================
+@dataclass
+class TrainStep:
+  """odin/networks/base_networks.py:130-173"""
+  inputs: Any = None
+  training: bool = True
+  mask: Any = None
+  parameters: Any = None
+  optimizer: Any = None
+  name: str = ''
+
+  def call(self):
+    raise NotImplementedError
+
+  def __call__(self):
+    return self.call()
+
+
+@dataclass
+class VAEStep(TrainStep):
+  """variational_autoencoder.py:111-126: loss = -mean(elbo(llk, kl)); metrics = means."""
+  vae: 'VariationalAutoencoder' = None
+  call_kw: Dict[str, Any] = field(default_factory=dict)
+
+  def call(self):
+    llk, kl = self.vae.elbo_components(self.inputs, training=self.training, mask=self.mask,
+                                       **self.call_kw)
+    loss = -torch.mean(self.vae.elbo(llk, kl))
+    metrics = {k: torch.mean(v) for k, v in llk.items()}
+    metrics.update({k: torch.mean(v) if torch.is_tensor(v) else v for k, v in kl.items()})
+    return loss, metrics
+
+
+# ======================================================================================
+# the model
+# ======================================================================================
+def _as_tensor(x, device):
+  if torch.is_tensor(x):
+    return x.to(device=device, dtype=torch.float32).contiguous()
+  return torch.as_tensor(np.asarray(x), dtype=torch.float32, device=device).contiguous()
+
+
+class VariationalAutoencoder:
+  """See module docstring.  Construction mirrors
+  ``vae_cls(**get_networks(ds_name))`` of the reference (examples/vae/utils.py:231-256)."""
+
+  def __init__(self, observation: RVconf = None, latents: RVconf = None,
+               encoder: SequentialNetwork = None, decoder: SequentialNetwork = None,
+               analytic: bool = False, reverse: bool = True, free_bits: Optional[float] = None,
+               sample_shape=(), allow_negative_kl: bool = True, path: Optional[str] = None,
+               step: int = 0, name: str = 'VariationalAutoencoder', device=None, seed: int = 1,
+               lib=None, **kwargs):
+    if encoder is None or decoder is None or latents is None or observation is None:
+      d = get_networks('dense')
+      encoder = encoder or d['encoder']
+      decoder = decoder or d['decoder']
+      latents = latents or d['latents']
+      observation = observation or d['observation']
+    for n, net in (('encoder', encoder), ('decoder', decoder)):
+      if not isinstance(net, SequentialNetwork):
+        raise ValueError(f'{n} must be a SequentialNetwork description, got {type(net)}')
+    if latents.posterior not in ('mvndiag', 'diag', 'normaldiag'):
+      raise ValueError(f"latents posterior {latents.posterior!r} is outside the HIP path "
+                       f"(supported: 'mvndiag')")
+    if tuple(sample_shape) not in ((), (1,)):
+      raise NotImplementedError('sample_shape != () is outside the HIP path')
+    if not reverse:
+      raise NotImplementedError('reverse=False is outside the HIP path')
+    self.observation, self.latents, self.encoder, self.decoder = observation, latents, encoder, decoder
+    self.analytic, self.reverse, self.free_bits = bool(analytic), bool(reverse), free_bits
+    self.sample_shape, self.allow_negative_kl = tuple(sample_shape), allow_negative_kl
+    self.path, self.name = path, name
+    self._step = int(step)
+    self.seed = int(seed)
+    self.device = torch.device(device if device is not None else
+                               ('cuda' if torch.cuda.is_available() else 'cpu'))
+    self._lib = lib
+    self._engines: Dict[int, VAEEngine] = {}
+    self._params: Optional[torch.Tensor] = None
+    self._optim_state = None
+    self._last_outputs = None
+    self._tc_mode = None
+    self.trainer = None
+    self.input_shape = tuple(encoder.input_shape) if encoder.input_shape else None
+    self.zdim = int(latents.event_size)
+    if self.input_shape is not None:
+      self.build((None,) + self.input_shape)
+
+  # ------------------------------------------------------------------ construction
+  def build(self, input_shape):
+    shape = tuple(input_shape)[1:]
+    self.input_shape = shape
+    eng = self._engine(1)  # validates shapes, allocates + initialises parameters
+    return self
+
+  def _engine(self, B: int) -> VAEEngine:
+    if self.input_shape is None:
+      raise RuntimeError('model is not built: call build((None, H, W, C)) first')
+    if B not in self._engines:
+      eng = VAEEngine(self.encoder.layers, self.decoder.layers, self.input_shape, self.zdim, B,
+                      self.device, observation=self.observation.posterior,
+                      analytic=self.analytic, free_bits=self.free_bits, tc=self._tc_mode,
+                      lib=self._lib, params=self._params, seed=self.seed,
+                      optim_state=self._optim_state, world_size=self._world_size())
+      if self._params is None:
+        self._params = eng.params
+        self._optim_state = (eng.m, eng.v)
+        self._init_parameters(eng)
+      self._engines[B] = eng
+    return self._engines[B]
+
+  def _world_size(self) -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+  def _init_parameters(self, eng: VAEEngine):
+    """HeNormal for elu convs, glorot_uniform for Dense, glorot_normal for the latent
+    projection, zero biases (image_networks.py:157-174; dense_distribution.py:124)."""
+    g = torch.Generator(device='cpu').manual_seed(self.seed)
+    deconv = {r.key for r in eng.enc_recs + eng.dec_recs if r.kind == 'deconv'}
+    for key, shp, off in eng.layout.entries:
+      n = int(np.prod(shp))
+      if key[-1] == 'b':
+        eng.params[off:off + n].zero_()
+        continue
+      if len(shp) == 4:
+        fan_in = shp[0] * shp[1] * (shp[3] if key[:2] in deconv else shp[2])
+        w = torch.nn.init.trunc_normal_(torch.empty(n), 0.0, 1.0, -2.0, 2.0, generator=g)
+        w = w * math.sqrt(2.0 / fan_in) / 0.87962566
+      elif key[0] == 'lat':
+        w = torch.randn(n, generator=g) * math.sqrt(2.0 / (shp[0] + shp[1]))
+      else:
+        lim = math.sqrt(6.0 / (shp[0] + shp[1]))
+        w = (torch.rand(n, generator=g) * 2 - 1) * lim
+      eng.params[off:off + n] = w.to(self.device)
+
+  # ------------------------------------------------------------------ properties
+  @property
+  def step(self) -> int:
+    return self._step
+
+  @property
+  def n_parameters(self) -> int:
+    return self._engine(1).n_params
+
+  @property
+  def last_outputs(self):
+    return self._last_outputs
+
+  @property
+  def trainable_variables(self) -> Dict[tuple, torch.Tensor]:
+    return self._engine(1).param_views()
+
+  def set_elbo_configs(self, analytic=None, reverse=None, free_bits=None, sample_shape=None):
+    """odin/bay/vi/_base.py:51-89"""
+    if analytic is not None:
+      self.analytic = bool(analytic)
+    if free_bits is not None:
+      self.free_bits = free_bits
+    for e in self._engines.values():
+      e.analytic = self.analytic
+      e.free_bits = -1.0 if self.free_bits is None else float(self.free_bits)
+    return self
+
+  @property
+  def beta(self) -> float:
+    return 1.0
+
+  # ------------------------------------------------------------------ forward API
+  def _posterior(self, eng: VAEEngine) -> MVNDiagPosterior:
+    return MVNDiagPosterior(eng.p.clone(), eng.z.clone(), eng.D)
+
+  def _observation_dist(self, h: torch.Tensor):
+    if self.observation.posterior == 'bernoulli':
+      return BernoulliObservation(h)
+    return GaussianObservation(h, self.observation.posterior == 'gaussian_softplus1')
+
+  def encode(self, inputs, training=None, mask=None, only_encoding=False, eps=None, **kwargs):
+    """variational_autoencoder.py:288-314"""
+    x = _as_tensor(inputs, self.device)
+    eng = self._engine(x.shape[0])
+    eng.set_hyper(beta=self.beta, t=self._step)
+    eng.run_encoder(x, None if eps is None else _as_tensor(eps, self.device))
+    if only_encoding:
+      return eng.enc.outs[-1].clone()
+    return self._posterior(eng)
+
+  def decode(self, latents, training=None, mask=None, only_decoding=False, **kwargs):
+    """variational_autoencoder.py:316-360"""
+    z = latents.tensor() if isinstance(latents, MVNDiagPosterior) else latents
+    z = _as_tensor(z, self.device)
+    eng = self._engine(z.shape[0])
+    h = eng.run_decoder(z).clone()
+    return h if only_decoding else self._observation_dist(h)
+
+  def call(self, inputs, training=None, mask=None, eps=None, **kwargs):
+    """variational_autoencoder.py:362-394 -> (p(x|z), q(z|x))"""
+    qz_x = self.encode(inputs, training=training, mask=mask, eps=eps)
+    px_z = self.decode(qz_x, training=training, mask=mask)
+    self._last_outputs = (px_z, qz_x)
+    return px_z, qz_x
+
+  __call__ = call
+
+  def elbo_components(self, inputs, training=None, mask=None, eps=None, **kwargs):
+    """variational_autoencoder.py:515-542.  One fused engine pass: llk [B], kl [B]
+    (already multiplied by beta for the Beta family, beta_vae.py:38-43)."""
+    x = _as_tensor(inputs, self.device)
+    eng = self._engine(x.shape[0])
+    eng.set_hyper(beta=self.beta, t=self._step)
+    eng.forward(x, None if eps is None else _as_tensor(eps, self.device))
+    qz_x = self._posterior(eng)
+    px_z = self._observation_dist(eng.dec.outs[-1].clone())
+    self._last_outputs = (px_z, qz_x)
+    llk = {f'llk_{self.observation.name}': eng.llk.clone()}
+    klv = eng.kl.clone() * self.beta
+    if self.analytic:
+      klv = klv.unsqueeze(0)
+    kl = {f'kl_{self.latents.name}': klv}
+    if self._tc_mode == 'betatc':
+      kl[f'tc_{self.latents.name}'] = (self.beta - 1.0) * eng.tc_ws[0].clone()
+    return llk, kl
+
+  def elbo(self, llk: Dict[str, torch.Tensor], kl: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """odin/bay/vi/_base.py:151-194: sum(llk) - sum(kl), broadcasting scalars / [1,B]."""
+    L = 0.0
+    for v in llk.values():
+      L = L + v
+    K = 0.0
+    for k, v in kl.items():
+      if not self.allow_negative_kl and torch.is_tensor(v):
+        if bool((v < -1e-3).any()):
+          raise AssertionError(f'negative KL for {k}')
+      K = K + v
+    return L - K
+
+  def sample_prior(self, n: int = 1, seed: int = 1) -> torch.Tensor:
+    g = torch.Generator(device='cpu').manual_seed(int(seed))
+    return torch.randn(int(n), self.zdim, generator=g).to(self.device)
+
+  def sample_observation(self, n: int = 1, seed: int = 1, training=False, **kwargs):
+    return self.decode(self.sample_prior(n, seed=seed), training=training)
+
+  def marginal_log_prob(self, inputs, training=None, n_mcmc: int = 100, **kwargs):
+    """IWAE estimate log p(x) ~ logsumexp_k[log p(x|z_k) + log p(z_k) - log q(z_k|x)] - log K
+    (variational_autoencoder.py:396-513)."""
+    x = _as_tensor(inputs, self.device)
+    eng = self._engine(x.shape[0])
+    eng.set_hyper(beta=1.0, t=self._step)
+    ws = []
+    an = eng.analytic
+    eng.analytic = False  # MC form: kl = log q(z) - log p(z)
+    for k in range(int(n_mcmc)):
+      eps = torch.randn(x.shape[0], self.zdim, device=self.device)
+      eng.forward(x, eps)
+      ws.append((eng.llk - eng.kl).clone())
+    eng.analytic = an
+    w = torch.stack(ws, 0)
+    return torch.logsumexp(w, 0) - math.log(float(n_mcmc))
+
+  # ------------------------------------------------------------------ training
+  def train_steps(self, inputs, training=None, mask=None, name: str = '', **kwargs
+                  ) -> Iterator[VAEStep]:
+    """variational_autoencoder.py:545-558"""
+    yield VAEStep(vae=self, parameters=self.trainable_variables, inputs=inputs,
+                  training=training, mask=mask, name=name, call_kw=kwargs)
+
+  def _lr(self, learning_rate) -> float:
+    return float(learning_rate(self._step)) if callable(learning_rate) else float(learning_rate)
+
+  def optimize(self, inputs, training: bool = True, optimizer=None, learning_rate=1e-4,
+               clipnorm=None, clipvalue=None, global_clipnorm=None, skip_update_threshold=None,
+               when_skip_update=None, nan_gradients_policy: str = 'stop',
+               allow_none_gradients=False, aggregate_gradients=False, track_gradients=False,
+               eps=None, use_graph: bool = False):
+    """Networks.optimize (base_networks.py:415-624): step += 1; forward; backward; NaN policy;
+    optional clip_by_global_norm; Adam.  Returns (loss, metrics) as device scalars."""
+    if clipnorm is not None or clipvalue is not None:
+      raise NotImplementedError('per-tensor clipnorm / clipvalue: use global_clipnorm')
+    x = _as_tensor(inputs, self.device)
+    eng = self._engine(x.shape[0])
+    if training:
+      self._step += 1
+    eng.step_count = self._step - 1 if training else self._step
+    if not training:
+      eng.set_hyper(beta=self.beta, t=self._step)
+      eng.forward(x, None if eps is None else _as_tensor(eps, self.device))
+    else:
+      eng.train_step(x, None if eps is None else _as_tensor(eps, self.device),
+                     lr=self._lr(learning_rate), beta=self.beta,
+                     global_clipnorm=global_clipnorm, use_graph=use_graph)
+      self._step = eng.step_count
+    out = eng.out4.clone()
+    metrics = {f'llk_{self.observation.name}': out[1], f'kl_{self.latents.name}': out[2]}
+    if self._tc_mode == 'betatc':
+      metrics[f'tc_{self.latents.name}'] = out[3]
+    return out[0], metrics
+
+  def fit(self, train, *, valid=None, valid_freq: int = 500, valid_interval: float = 0,
+          optimizer='adam', learning_rate=1e-4, clipnorm=None, global_clipnorm=None,
+          clipvalue=None, skip_update_threshold=None, when_skip_update=None, epochs: int = -1,
+          max_iter: int = 1000, batch_size: int = 32, on_batch_end=None, on_valid_end=None,
+          compile_graph: bool = True, autograph: bool = False, logging_interval: float = 5,
+          skip_fitted: Union[bool, int] = False, nan_gradients_policy: str = 'stop',
+          logdir=None, allow_none_gradients=False, track_gradients=False, seed: int = 1):
+    """Networks.fit (base_networks.py:642-812).  `train`: array / tensor [N,H,W,C] or an
+    iterable of batches.  compile_graph -> the step is replayed as one HIP graph."""
+    if optimizer not in ('adam', None) and not callable(optimizer):
+      raise RuntimeError(f'No support for optimizer {optimizer!r} on the HIP path (adam only)')
+    if nan_gradients_policy not in ('stop', 'skip', 'raise', 'ignore'):
+      raise ValueError(nan_gradients_policy)
+    if skip_fitted and self._step >= (max_iter if skip_fitted is True else int(skip_fitted)):
+      return self
+    history = []
+
+    def batches():
+      if torch.is_tensor(train) or isinstance(train, np.ndarray):
+        data = _as_tensor(train, self.device)
+        N = data.shape[0]
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        ep = 0
+        while epochs < 0 or ep < epochs:
+          perm = torch.randperm(N, generator=g).to(self.device)
+          for i in range(0, N - batch_size + 1, batch_size):
+            yield data[perm[i:i + batch_size]].contiguous()
+          ep += 1
+      else:
+        ep = 0
+        while epochs < 0 or ep < epochs:
+          for b in train:
+            yield _as_tensor(b, self.device)
+          ep += 1
+
+    it = 0
+    for xb in batches():
+      if it >= max_iter:
+        break
+      loss, metrics = self.optimize(xb, training=True, learning_rate=learning_rate,
+                                    global_clipnorm=global_clipnorm,
+                                    nan_gradients_policy=nan_gradients_policy,
+                                    use_graph=compile_graph and self.device.type == 'cuda')
+      it += 1
+      eng = self._engine(xb.shape[0])
+      if it % 50 == 0 or it == max_iter:
+        if int(eng.flag.item()) != 0:  # non-finite gradients: the update was skipped on device
+          if nan_gradients_policy == 'raise':
+            raise RuntimeError(f'NaN gradients at step {self._step}')
+          if nan_gradients_policy == 'stop':
+            break
+          eng.flag.zero_()
+        history.append((self._step, float(loss)))
+      if on_batch_end is not None:
+        on_batch_end()
+      if valid is not None and on_valid_end is not None and it % valid_freq == 0:
+        on_valid_end()
+    self.history = history
+    return self
+
+  # ------------------------------------------------------------------ checkpoints
+  def save_weights(self, filepath: Optional[str] = None, overwrite: bool = True):
+    """base_networks.py:373-390: weights + step (optimizer state deliberately not tracked)."""
+    filepath = filepath or self.path
+    if filepath is None:
+      raise ValueError('no path given')
+    if os.path.exists(filepath) and not overwrite:
+      raise RuntimeError(f'{filepath} exists')
+    eng = self._engine(1)
+    W = {'/'.join(map(str, k)): v.detach().cpu().numpy() for k, v in eng.param_views().items()}
+    with open(filepath, 'wb') as f:
+      pickle.dump(dict(weights=W, step=self._step, name=self.name), f)
+    return self
+
+  def load_weights(self, filepath: Optional[str] = None, raise_notfound: bool = False):
+    filepath = filepath or self.path
+    if filepath is None or not os.path.exists(filepath):
+      if raise_notfound:
+        raise FileNotFoundError(filepath)
+      return self
+    with open(filepath, 'rb') as f:
+      d = pickle.load(f)
+    eng = self._engine(1)
+    views = eng.param_views()
+    for k, v in views.items():
+      v.copy_(torch.as_tensor(d['weights']['/'.join(map(str, k))], device=self.device))
+    self._step = int(d['step'])
+    return self
+
+  def __str__(self):
+    return (f'{self.name}(input={self.input_shape}, zdim={self.zdim}, '
+            f'params={self.n_parameters}, step={self._step}, device={self.device})')
+
+
+# ======================================================================================
+# Beta family
+# ======================================================================================
+class BetaVAE(VariationalAutoencoder):
+  """beta_vae.py:11-43: every KL term multiplied by beta (constant or an Interpolation of
+  the training step)."""
+
+  def __init__(self, beta: Union[float, Interpolation] = 1.0, name='BetaVAE', **kwargs):
+    self._beta = beta
+    super().__init__(name=name, **kwargs)
+
+  @property
+  def beta(self) -> float:
+    if isinstance(self._beta, Interpolation):
+      return float(self._beta(self._step))
+    return float(self._beta)
+
+  @beta.setter
+  def beta(self, b):
+    self._beta = b
+
+
+class AnnealingVAE(BetaVAE):
+  """beta_vae.py:83-107: beta = linear(vmin=1e-6, vmax=1, steps=2000)(step)."""
+
+  def __init__(self, vmin: float = 1e-6, vmax: float = 1.0, steps: int = 2000,
+               name='AnnealingVAE', **kwargs):
+    super().__init__(beta=linear(vmin=vmin, vmax=vmax, steps=steps), name=name, **kwargs)
+
+
+class BetaTCVAE(BetaVAE):
+  """beta_vae.py:110-129: + (beta-1) * total_correlation(z, q(z|x)) (losses.py:101-157);
+  the KL is ALSO scaled by beta through BetaVAE.elbo_components (:42)."""
+
+  def __init__(self, beta: float = 1.0, name='BetaTCVAE', **kwargs):
+    super().__init__(beta=beta, name=name, **kwargs)
+    self._tc_mode = 'betatc'
+    self._engines.clear()
+
+
+# ======================================================================================
+# FactorVAE
+# ======================================================================================
+class FactorDiscriminator:
+  """factor_discriminator.py:16-235: Flatten -> [Dense(units, relu)]*n -> Dense(1) logit.
+  Holds its own flat parameter / gradient / Adam buffers and two bound programs: one over
+  B1 samples (TC term inside the VAE step: data-gradient only) and one over 2*B1 samples
+  ([z ; permute_dims(z')], discriminator step)."""
+
+  def __init__(self, lib, zdim: int, units: Sequence[int], activation: str, B1: int, device,
+               seed: int):
+    self.lib, self.device, self.B1, self.D = lib, device, B1, zdim
+    layers = [('dense', int(u), activation) for u in units] + [('dense', 1, 'linear')]
+    self.layout = ParamLayout()
+    self.recs, out = build_layers('disc', layers, (zdim,), self.layout)
+    self.layout.pad_to(4)
+    f32 = dict(dtype=torch.float32, device=device)
+    n = self.layout.size
+    self.params, self.grads = torch.zeros(n, **f32), torch.zeros(n, **f32)
+    self.m, self.v = torch.zeros(n, **f32), torch.zeros(n, **f32)
+    g = torch.Generator(device='cpu').manual_seed(seed + 7)
+    for key, shp, off in self.layout.entries:
+      if key[-1] == 'w':
+        lim = math.sqrt(6.0 / (shp[0] + shp[1]))
+        self.params[off:off + int(np.prod(shp))] = \
+            ((torch.rand(int(np.prod(shp)), generator=g) * 2 - 1) * lim).to(device)
+    mr = lib.odin_max_slab_rows()
+    self.prog1 = NetProgram(lib, self.recs, B1, device, self.params, self.grads, mr)
+    self.prog2 = NetProgram(lib, self.recs, 2 * B1, device, self.params, self.grads, mr)
+    self.tc = torch.zeros(1, **f32)
+    self.dlogit1 = torch.zeros(B1, 1, **f32)
+    self.dz = torch.zeros(B1, zdim, **f32)
+    self.zcat = torch.zeros(2 * B1, zdim, **f32)
+    self.zperm = torch.zeros(B1, zdim, **f32)
+    self.perm = torch.zeros(B1, zdim, dtype=torch.int32, device=device)
+    self.dlogit2 = torch.zeros(2 * B1, 1, **f32)
+    self.dtc = torch.zeros(1, **f32)
+    self.hyper = torch.zeros(8, **f32)
+    self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+    self.t = 0
+    self._keep = None
+
+  @property
+  def n_parameters(self):
+    return sum(int(np.prod(s)) for _, s, _ in self.layout.entries)
+
+
+class FactorVAE(AnnealingVAE):
+  """factor_vae.py:99-293.  Each iteration splits the batch in halves (x1, x2):
+    step 1 (VAE params, fit's Adam): loss = -mean(llk - beta_t*kl) + tc_coef*mean(D(z)),
+            the gradient flows through D into z (total_correlation, factor_discriminator.py:169-198);
+    step 2 (discriminator params, Adam(1e-5, .5, .9)): dtc_loss of D(z) and
+            D(permute_dims(z')) with z' = encode(x2) (factor_discriminator.py:200-235)."""
+
+  def __init__(self, discriminator_units: Sequence[int] = (1000,) * 5, discriminator_optim=None,
+               activation: str = 'relu', batchnorm: bool = False, tc_coef: float = 7.0,
+               maximize_tc: bool = False, name='FactorVAE', **kwargs):
+    if batchnorm:
+      raise NotImplementedError('batchnorm=True is outside the HIP path (reference default False)')
+    super().__init__(name=name, **kwargs)
+    self.tc_coef = float(tc_coef) * (-1.0 if maximize_tc else 1.0)
+    self.disc_units, self.disc_act = tuple(discriminator_units), activation
+    self.disc_lr, self.disc_b1, self.disc_b2 = 1e-5, 0.5, 0.9
+    self._is_pretraining = False
+    self._disc: Dict[int, FactorDiscriminator] = {}
+    self._disc_state = None
+
+  @property
+  def is_pretraining(self):
+    return self._is_pretraining
+
+  def pretrain(self):
+    self._is_pretraining = True
+    return self
+
+  def finetune(self):
+    self._is_pretraining = False
+    return self
+
+  def _discriminator(self, B1: int) -> FactorDiscriminator:
+    if B1 not in self._disc:
+      eng = self._engine(B1)
+      d = FactorDiscriminator(eng.lib, self.zdim, self.disc_units, self.disc_act, B1,
+                              self.device, self.seed)
+      if self._disc_state is not None:  # share parameters / optimiser state across batch sizes
+        d.params.copy_(self._disc_state.params)
+      else:
+        self._disc_state = d
+      self._disc[B1] = d
+    return self._disc[B1]
+
+  # -- the two steps, returning device scalars ------------------------------------------
+  def optimize(self, inputs, training: bool = True, learning_rate=1e-4, global_clipnorm=None,
+               eps=None, eps2=None, perm=None, **kwargs):
+    x = _as_tensor(inputs, self.device)
+    assert x.shape[0] % 2 == 0, 'FactorVAE splits the batch in two halves'
+    B1 = x.shape[0] // 2
+    x1, x2 = x[:B1].contiguous(), x[B1:].contiguous()
+    eng, disc = self._engine(B1), self._discriminator(B1)
+    lib, st = eng.lib, eng.stream()
+    if training:
+      self._step += 1
+    eng.step_count = self._step
+    use_tc = not (self._is_pretraining and training)
+    eng.set_hyper(lr=self._lr(learning_rate), beta=self.beta, tc_coef=self.tc_coef if use_tc else 0.0)
+    # ---- step 1: ELBO with the discriminator's TC estimate ----
+    eng.forward(x1, None if eps is None else _as_tensor(eps, self.device), finalize=False)
+    extra = None
+    if use_tc:
+      lg = disc.prog1.forward(eng.z, st)
+      lib.odin_mean(lg.data_ptr(), B1, disc.tc.data_ptr(), st)
+      eng.finalize(tc_ptr=disc.tc.data_ptr())
+      disc.dlogit1.fill_(self.tc_coef / (B1 * eng.world_size))
+      disc.prog1.backward(eng.z, disc.dlogit1, st, dx_out=disc.dz, data_only=True)
+      extra = disc.dz
+    else:
+      eng.finalize()
+    metrics = {}
+    if training:
+      eng.backward(extra_dz=extra)
+      eng.allreduce()
+      eng.adam(global_clipnorm=global_clipnorm)
+    out = eng.out4.clone()
+    metrics.update({f'elbo/llk_{self.observation.name}': out[1],
+                    f'elbo/kl_{self.latents.name}': out[2], 'elbo/tc': out[3]})
+    loss = out[0]
+    # ---- step 2: discriminator ----
+    if not self._is_pretraining:
+      z1 = eng.z
+      disc.zcat[:B1].copy_(z1)
+      eng2 = self._engine_x2(B1)
+      eng2.set_hyper(beta=self.beta, t=self._step + 100003)
+      eng2.run_encoder(x2, None if eps2 is None else _as_tensor(eps2, self.device))
+      if perm is None:
+        lib.odin_random_perm(disc.perm.data_ptr(), B1, self.zdim, self.seed + 11,
+                             eng.hp(N_HYPER), st)
+      else:
+        disc.perm.copy_(torch.as_tensor(perm, dtype=torch.int32, device=self.device))
+      lib.odin_permute_dims(eng2.z.data_ptr(), disc.perm.data_ptr(), disc.zperm.data_ptr(), B1,
+                            self.zdim, st)
+      disc.zcat[B1:].copy_(disc.zperm)
+      lg2 = disc.prog2.forward(disc.zcat, st)
+      lib.odin_dtc_loss_fwd_bwd(lg2.data_ptr(), lg2[B1:].data_ptr(), disc.dtc.data_ptr(),
+                                disc.dlogit2.data_ptr(), disc.dlogit2[B1:].data_ptr(), B1, st)
+      metrics['disc/dtc_loss'] = disc.dtc[0].clone()
+      if training:
+        jobs = disc.prog2.backward(disc.zcat, disc.dlogit2, st)
+        arr = (ReduceJob * len(jobs))(*jobs)
+        disc._keep = arr
+        lib.odin_slab_reduce(arr, len(jobs), st)
+        if eng.world_size > 1:
+          import torch.distributed as dist
+          disc.grads.div_(eng.world_size)
+          dist.all_reduce(disc.grads)
+        disc.t += 1
+        a = self.disc_lr * math.sqrt(1 - self.disc_b2 ** disc.t) / (1 - self.disc_b1 ** disc.t)
+        disc.hyper.copy_(torch.tensor([a, self.disc_b1, self.disc_b2, 1e-7, 1.0, 0, 0, 0]))
+        lib.odin_adam_step_flat(disc.params.data_ptr(), disc.grads.data_ptr(), disc.m.data_ptr(),
+                                disc.v.data_ptr(), disc.params.numel(), disc.hyper.data_ptr(),
+                                None, 0.0, None, st)
+    return loss, metrics
+
+  def _engine_x2(self, B1: int) -> VAEEngine:
+    key = -B1
+    if key not in self._engines:
+      self._engine(B1)
+      self._engines[key] = VAEEngine(self.encoder.layers, self.decoder.layers, self.input_shape,
+                                     self.zdim, B1, self.device,
+                                     observation=self.observation.posterior,
+                                     analytic=self.analytic, free_bits=self.free_bits,
+                                     lib=self._lib, params=self._params, seed=self.seed + 1)
+    return self._engines[key]
+
+  def total_correlation(self, qz_x, training=None):
+    z = _as_tensor(qz_x.tensor() if isinstance(qz_x, MVNDiagPosterior) else qz_x, self.device)
+    disc = self._discriminator(z.shape[0])
+    lg = disc.prog1.forward(z, self._engine(z.shape[0]).stream())
+    return self.tc_coef * lg.mean()
+
+  def dtc_loss(self, qz_x, qz_xprime=None, training=None, perm=None):
+    z = _as_tensor(qz_x.tensor() if isinstance(qz_x, MVNDiagPosterior) else qz_x, self.device)
+    zp = z if qz_xprime is None else _as_tensor(
+        qz_xprime.tensor() if isinstance(qz_xprime, MVNDiagPosterior) else qz_xprime, self.device)
+    B1 = z.shape[0]
+    disc, eng = self._discriminator(B1), self._engine(B1)
+    lib, st = eng.lib, eng.stream()
+    if perm is None:
+      lib.odin_random_perm(disc.perm.data_ptr(), B1, self.zdim, self.seed + 11, None, st)
+    else:
+      disc.perm.copy_(torch.as_tensor(perm, dtype=torch.int32, device=self.device))
+    lib.odin_permute_dims(zp.data_ptr(), disc.perm.data_ptr(), disc.zperm.data_ptr(), B1,
+                          self.zdim, st)
+    disc.zcat[:B1].copy_(z)
+    disc.zcat[B1:].copy_(disc.zperm)
+    lg2 = disc.prog2.forward(disc.zcat, st)
+    lib.odin_dtc_loss_fwd_bwd(lg2.data_ptr(), lg2[B1:].data_ptr(), disc.dtc.data_ptr(),
+                              disc.dlogit2.data_ptr(), disc.dlogit2[B1:].data_ptr(), B1, st)
+    return disc.dtc[0].clone()
+
+
+def get_vae(name: str):
+  """odin/bay/vi/autoencoder/__init__.py:28"""
+  table = {c.__name__.lower(): c for c in (VariationalAutoencoder, BetaVAE, AnnealingVAE,
+                                           BetaTCVAE, FactorVAE)}
+  table['vae'] = VariationalAutoencoder
+  key = str(name).lower().replace('_', '')
+  if key not in table:
+    raise ValueError(f'Cannot find VAE {name!r}; the HIP path offers {sorted(table)}')
+  return table[key]
