@@ -179,9 +179,10 @@ int odin_rng_normal(float* out, size_t n, uint64_t seed, const int32_t* step_dev
 
 /* ---- speech front-end: pre-emphasis -> STFT -> |.|^2 -> Slaney mel -> dB
  * (odin/preprocessing/signal.py:955-967,1442-1562,1623-1691,636-680).
- * y [B,n_samples] -> out [B,n_frames,n_mels]; window [frame_length] (already divided by
- * its sum), melfb [n_mels, n_fft/2+1]. */
-int odin_stft_mel_db(const float* y, const float* window, const float* melfb, float* out, int B,
+ * y [B,n_samples] -> out [B,n_frames,n_mels], n_frames = 1 + (n_samples-frame_length)/step;
+ * window [frame_length] (already divided by its sum); melfb_t [n_fft/2+1, n_mels] = the
+ * mel_filters basis TRANSPOSED; top_db < 0 disables the floor; log_output=0 returns power. */
+int odin_stft_mel_db(const float* y, const float* window, const float* melfb_t, float* out, int B,
                      int n_samples, int frame_length, int step_length, int n_fft, int n_mels,
                      float preemph, float top_db, int log_output, void* stream);
 

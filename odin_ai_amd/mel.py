@@ -1,0 +1,106 @@
+"""Speech front-end on the HIP path: STFT -> power -> Slaney mel -> dB.
+
+Mirrors the reference's extractor surface (odin/preprocessing/speech.py:655-929
+`STFTExtractor` / `MelsSpecExtractor` / `SpectraExtractor`, which call
+odin/preprocessing/signal.py) for the configuration BASELINE.json names: 25 ms / 10 ms
+frames at 8 kHz (200 / 80 samples), n_fft 512, periodic Hamming window, 80 Slaney mels
+from 64 Hz to 4 kHz, dB with top_db 80.  The window and the filterbank are small host-side
+constants; every per-sample FLOP runs in `odin_stft_mel_db`.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _hz2mel(f):
+  f = np.atleast_1d(np.asarray(f, np.float64)).copy()
+  m = f / (200.0 / 3)
+  t = f >= 1000.0
+  m[t] = 1000.0 / (200.0 / 3) + np.log(f[t] / 1000.0) / (np.log(6.4) / 27.0)
+  return m
+
+
+def _mel2hz(m):
+  m = np.atleast_1d(np.asarray(m, np.float64))
+  f = (200.0 / 3) * m
+  t = m >= 1000.0 / (200.0 / 3)
+  f[t] = 1000.0 * np.exp((np.log(6.4) / 27.0) * (m[t] - 1000.0 / (200.0 / 3)))
+  return f
+
+
+def mel_filters(sr: int, n_fft: int, n_mels: int = 128, fmin: float = 0.0,
+                fmax: Optional[float] = None) -> np.ndarray:
+  """Slaney-scale, area-normalised triangular filterbank [n_mels, n_fft//2+1]
+  (odin/preprocessing/signal.py:735-810)."""
+  fmax = float(sr) / 2 if fmax is None else float(fmax)
+  freqs = np.linspace(0, float(sr) / 2, 1 + n_fft // 2)
+  mel_f = _mel2hz(np.linspace(_hz2mel(fmin)[0], _hz2mel(fmax)[0], n_mels + 2))
+  fdiff = np.diff(mel_f)
+  ramps = mel_f[:, None] - freqs[None, :]
+  W = np.zeros((n_mels, 1 + n_fft // 2))
+  for i in range(n_mels):
+    W[i] = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+  return W * (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+
+
+def periodic_window(name: str, n: int) -> np.ndarray:
+  k = np.arange(n, dtype=np.float64)
+  if name in ('hamm', 'hamming'):
+    return 0.54 - 0.46 * np.cos(2 * np.pi * k / n)
+  if name in ('hann', 'hanning'):
+    return 0.5 - 0.5 * np.cos(2 * np.pi * k / n)
+  raise ValueError(f'window {name!r} is outside the HIP path (hamm / hann)')
+
+
+class MelsSpecExtractor:
+  """Batched log-mel spectrogram on the GPU.  Arguments follow
+  speech.py `STFTExtractor(frame_length, step_length, n_fft, window)` +
+  `MelsSpecExtractor(n_mels, fmin, fmax, top_db)`; `frame_length` / `step_length` are in
+  seconds when < 1 (as in the reference) else in samples."""
+
+  def __init__(self, sr: int = 8000, frame_length=0.025, step_length=0.010, n_fft: int = 512,
+               window: str = 'hamm', n_mels: int = 80, fmin: float = 64, fmax: float = 4000,
+               top_db: Optional[float] = 80.0, preemphasis: Optional[float] = 0.97,
+               log: bool = True, device=None, lib=None):
+    self.sr = int(sr)
+    self.frame_length = int(round(frame_length * sr)) if frame_length < 1 else int(frame_length)
+    self.step_length = int(round(step_length * sr)) if step_length < 1 else int(step_length)
+    self.n_fft, self.n_mels = int(n_fft), int(n_mels)
+    if int(fmin) >= int(fmax):
+      raise ValueError(f'fmin must < fmax, but fmin={int(fmin)} and fmax={int(fmax)}')
+    self.top_db = -1.0 if top_db is None else float(top_db)
+    self.preemph = 0.0 if not preemphasis else float(preemphasis)
+    self.log = bool(log)
+    self.device = torch.device(device if device is not None else
+                               ('cuda' if torch.cuda.is_available() else 'cpu'))
+    self.lib = lib if lib is not None else _lib.load()
+    w = periodic_window(window, self.frame_length)
+    self.window = torch.tensor(w / w.sum(), dtype=torch.float32, device=self.device)
+    fb = mel_filters(self.sr, self.n_fft, self.n_mels, int(fmin), int(fmax))
+    self.melfb_t = torch.tensor(np.ascontiguousarray(fb.T), dtype=torch.float32,
+                                device=self.device)
+
+  def n_frames(self, n_samples: int) -> int:
+    return 1 + (n_samples - self.frame_length) // self.step_length
+
+  def transform(self, y) -> torch.Tensor:
+    """y [B, n_samples] (or [n_samples]) -> [B, n_frames, n_mels] float32 on the device."""
+    y = torch.as_tensor(y, dtype=torch.float32, device=self.device)
+    squeeze = y.ndim == 1
+    if squeeze:
+      y = y[None]
+    y = y.contiguous()
+    B, n = y.shape
+    out = torch.empty(B, self.n_frames(n), self.n_mels, dtype=torch.float32, device=self.device)
+    st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == 'cuda' else None
+    self.lib.odin_stft_mel_db(y.data_ptr(), self.window.data_ptr(), self.melfb_t.data_ptr(),
+                              out.data_ptr(), B, n, self.frame_length, self.step_length,
+                              self.n_fft, self.n_mels, self.preemph, self.top_db, int(self.log), st)
+    return out[0] if squeeze else out
+
+  __call__ = transform

@@ -97,3 +97,40 @@ def test_missing_library_fails_loudly(tmp_path):
   from odin_ai_amd import _lib
   with pytest.raises(_lib.OdinError):
     _lib.Lib(str(tmp_path / 'nope.so'))
+
+
+def test_mel_frontend_matches_reference_golden(dev, L):
+  """Speech front-end (BASELINE config 5 front half) vs arrays produced by the reference's
+  own signal.py (tests/golden/mel_golden.npz).  Tolerance: 2e-3 dB (fp32 FFT vs float64)."""
+  import os
+  from odin_ai_amd.mel import MelsSpecExtractor
+  G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mel_golden.npz'))
+  ex = MelsSpecExtractor(device=dev, lib=L)
+  out = ex(G['y']).cpu().numpy()
+  assert out.shape == (3, 98, 80)
+  for i in range(3):
+    assert np.abs(out[i] - G[f'mel_db_{i}']).max() < 2e-3
+  # batch 256 (BASELINE size): every utterance of a repeated batch gives the same answer
+  yb = torch.tensor(G['y'][:1]).repeat(256, 1).to(dev)
+  ob = ex(yb)
+  assert torch.equal(ob[0], ob[255]) and np.abs(ob[0].cpu().numpy() - G['mel_db_0']).max() < 2e-3
+
+
+def test_model_api_on_gpu(dev, L):
+  """get_networks -> BetaVAE.fit (HIP-graph replay) lowers the loss; FactorVAE iteration
+  runs both optimisers; encode/decode round trip shapes."""
+  from odin_ai_amd.networks import get_networks
+  from odin_ai_amd.vae import BetaVAE, FactorVAE
+  vae = BetaVAE(beta=4.0, device=dev, lib=L, **get_networks('dsprites'))
+  x = (torch.rand(64, 64, 64, 1, device=dev) < 0.1).float().clamp(1e-6, 1 - 1e-6)
+  l0, _ = vae.optimize(x[:32], training=False)
+  vae.fit(x, max_iter=30, batch_size=32, learning_rate=1e-3, compile_graph=True)
+  l1, _ = vae.optimize(x[:32], training=False)
+  assert vae.step == 30 and float(l1) < float(l0)
+  px, qz = vae(x[:8])
+  assert px.mean().shape == (8, 64, 64, 1) and qz.sample().shape == (8, 10)
+  fv = FactorVAE(device=dev, lib=L, **get_networks('shapes3d'))
+  xs = torch.rand(16, 64, 64, 3, device=dev).clamp(1e-6, 1 - 1e-6)
+  loss, m = fv.optimize(xs, learning_rate=1e-4)
+  assert fv.step == 1 and set(m) >= {'elbo/tc', 'disc/dtc_loss'}
+  assert np.isfinite(float(loss)) and abs(float(m['disc/dtc_loss']) - np.log(2.0)) < 0.5

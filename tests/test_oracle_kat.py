@@ -1,0 +1,67 @@
+"""Closed-form known answers for the oracle and the portable
+properties of the reference's own permute_dims test (tests/bayesian/test_vae.py:112-125)."""
+import math
+
+import numpy as np
+
+from oracle import vae_oracle as vo
+
+
+def test_zero_weights_give_ln2_per_pixel():
+  for spec, n in ((vo.dsprites_spec(1), 64 * 64), (vo.dsprites_spec(3), 64 * 64 * 3),
+                  (vo.mnist_dense_spec(), 28 * 28)):
+    enc, dec, shp, D = spec
+    m = vo.OracleVAE(enc, dec, shp, D)
+    P = {k: np.zeros(s) for k, s in m.param_shapes()}
+    x = np.random.default_rng(0).random((2,) + shp)
+    f = m.forward(P, x, np.zeros((2, D)))
+    np.testing.assert_allclose(f['llk'], -n * math.log(2.0), rtol=1e-12)
+  assert abs(-64 * 64 * 3 * math.log(2) - (-8517.39)) < 0.01
+  assert abs(-28 * 28 * math.log(2) - (-543.43)) < 0.01
+
+
+def test_kl_known_answers():
+  B, D = 5, 7
+  loc = np.zeros((B, D))
+  p = np.concatenate([loc, np.full((B, D), vo.SOFTPLUS_INV_1)], -1)
+  l, s = vo.mvn_diag_params(p, D)
+  np.testing.assert_allclose(s, 1.0, atol=1e-12)
+  eps = np.random.default_rng(1).standard_normal((B, D))
+  np.testing.assert_allclose(vo.kl_analytic(l, s), 0.0, atol=1e-12)
+  np.testing.assert_allclose(vo.kl_mc(l, s, l + s * eps), 0.0, atol=1e-12)
+  kl, mask = vo.free_bits_clamp(np.array([0.1, 5.0]), 0.5, 4)
+  np.testing.assert_allclose(kl, [2.0, 5.0])
+  np.testing.assert_allclose(mask, [0.0, 1.0])
+
+
+def test_tc_dtc_schedule_adam_known_answers():
+  B, D = 9, 4
+  z = np.random.default_rng(2).standard_normal((B, D))
+  loc, sc = np.tile(z[:1] * 0 + 0.3, (B, 1)), np.full((B, D), 0.7)
+  zz = np.tile(z[:1], (B, 1))
+  # identical posteriors and identical samples: TC = (1 - D) * ln B
+  assert abs(vo.total_correlation(zz, loc, sc) - (1 - D) * math.log(B)) < 1e-10
+  assert abs(vo.dtc_loss(np.zeros(6), np.zeros(6)) - math.log(2.0)) < 1e-12
+  assert abs(vo.interp_linear(1000) - 0.5000005) < 1e-12
+  g = np.array([0.5, -2.0, 1e-3])
+  th, m, v = vo.adam_keras(np.zeros(3), g, np.zeros(3), np.zeros(3), 1, 1e-3)
+  np.testing.assert_allclose(th, -1e-3 * g / (np.abs(g) + 1e-7 / math.sqrt(1 - 0.999)), rtol=1e-9)
+  assert vo.same_pads(64, 4, 2) == (32, 1, 1) and vo.same_pads(8, 4, 1) == (8, 1, 2)
+  assert vo.same_pads(28, 5, 2) == (14, 1, 2) and vo.same_pads(14, 5, 2) == (7, 1, 2)
+
+
+def test_permute_dims_portable_properties():
+  rng = np.random.default_rng(1)
+  z = rng.standard_normal((128, 64))
+  perm = np.stack([rng.permutation(128) for _ in range(64)], 1)
+  zp = vo.permute_dims(z, perm)
+  assert (zp != z).any()
+  np.testing.assert_array_equal(np.sort(zp, 0), np.sort(z, 0))
+
+
+def test_param_counts_match_survey():
+  for spec, n in ((vo.dsprites_spec(1), 373685), (vo.dsprites_spec(3), 515055),
+                  (vo.mnist_conv_spec(), 999945), (vo.mnist_dense_spec(), 1354544)):
+    enc, dec, shp, D = spec
+    m = vo.OracleVAE(enc, dec, shp, D)
+    assert sum(int(np.prod(s)) for _, s in m.param_shapes()) == n
