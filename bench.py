@@ -227,7 +227,7 @@ def main():
   init_params_(eng, seed=1)  # identical weights on every rank
   x = synthetic_batch(args.workload, B, in_shape, device, seed=100 + rank)
   lr = 1e-3
-  use_graph = (not args.no_graph) and world == 1
+  use_graph = not args.no_graph
 
   def step():
     return eng.train_step(x, None, lr=lr, beta=beta, global_clipnorm=100.0, use_graph=use_graph)

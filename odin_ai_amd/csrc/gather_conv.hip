@@ -49,6 +49,8 @@ struct GParams {
   int CIC, n_chunks, WP, w_resident;
   int patch_floats, MT, MTP, SPP;  // M-tiles total / per phase, slots per phase
   int vec, KI, pipelined;          // 16-byte staging items, items per lane per patch row
+  int n_batches;                   // staging batches per patch (1 when pipelined)
+  int flat;                        // 1x1 images (Dense): the patch is one contiguous [NIMG, CIC] block
   long long* stamps;  // diagnostic: s_memtime stamps of workgroup 0 / wave 0 (env ODIN_STAMPS)
   int dbg;  // diagnostic ablation mask (env ODIN_DBG): 1 skip MFMA, 2 skip stores, 4 skip patch staging
 };
@@ -276,6 +278,70 @@ __device__ __forceinline__ void stage_row_commit(const GParams& p, const LaneSta
   }
 }
 
+// A whole staging batch.  Row mode: rows batch*NW*RPWMAX + wave + NW*q.  Flat mode (Dense:
+// every "image" is one pixel, the tile's input is the contiguous block in[b0 .. b0+NIMG)[CI]):
+// items e = (batch*PFN + i)*NT + tid -> (image, channel group).
+template <int KMAX, int RPWMAX, bool VEC, int NW>
+__device__ __forceinline__ void stage_issue(const GParams& p, const LaneStage<KMAX>& LS, int wave,
+                                            int tid, int batch, int b0, int ih_lo, int c0,
+                                            typename StageT<VEC>::type* pf) {
+  constexpr int PFN = KMAX * RPWMAX, NT = NW * 64;
+  if (p.flat) {
+    const int cpi = VEC ? (p.CIC >> 2) : p.CIC;
+    const int total = p.NIMG * cpi;
+#pragma unroll
+    for (int i = 0; i < PFN; ++i) {
+      const int e = (batch * PFN + i) * NT + tid;
+      pf[i] = stage_zero<VEC>();
+      if (e < total) {
+        const int img = e / cpi;
+        const int cc = (e - img * cpi) * (VEC ? 4 : 1);
+        if (b0 + img < p.B && c0 + cc < p.CI) {
+          const float* src = p.in + (size_t)(b0 + img) * p.CI + c0 + cc;
+          if constexpr (VEC) pf[i] = *reinterpret_cast<const float4*>(src);
+          else pf[i] = src[0];
+        }
+      }
+    }
+  } else {
+    const int nrows_p = p.NIMG * p.NRI;
+#pragma unroll
+    for (int q = 0; q < RPWMAX; ++q) {
+      const int r = batch * NW * RPWMAX + wave + NW * q;
+      if (r < nrows_p) stage_row_issue<KMAX, VEC>(p, LS, r, b0, ih_lo, c0, pf + q * KMAX);
+    }
+  }
+}
+
+template <int KMAX, int RPWMAX, bool VEC, int NW>
+__device__ __forceinline__ void stage_commit(const GParams& p, const LaneStage<KMAX>& LS, int wave,
+                                             int tid, int batch,
+                                             const typename StageT<VEC>::type* pf, float* patch) {
+  constexpr int PFN = KMAX * RPWMAX, NT = NW * 64;
+  if (p.flat) {
+    const int cpi = VEC ? (p.CIC >> 2) : p.CIC;
+    const int total = p.NIMG * cpi;
+#pragma unroll
+    for (int i = 0; i < PFN; ++i) {
+      const int e = (batch * PFN + i) * NT + tid;
+      if (e < total) {
+        const int img = e / cpi;
+        const int cc = (e - img * cpi) * (VEC ? 4 : 1);
+        float* d = patch + img * p.P + cc;
+        if constexpr (VEC) { d[0] = pf[i].x; d[1] = pf[i].y; d[2] = pf[i].z; d[3] = pf[i].w; }
+        else d[0] = pf[i];
+      }
+    }
+  } else {
+    const int nrows_p = p.NIMG * p.NRI;
+#pragma unroll
+    for (int q = 0; q < RPWMAX; ++q) {
+      const int r = batch * NW * RPWMAX + wave + NW * q;
+      if (r < nrows_p) stage_row_commit<KMAX, VEC>(p, LS, r, pf + q * KMAX, patch);
+    }
+  }
+}
+
 // geometry of the output pixel a lane owns inside M-tile `mt`.  Everything except the
 // tile's first output row is tile-invariant and computed once per kernel.
 struct Slot {
@@ -494,7 +560,6 @@ __global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, Ta
   (void)stamp_i;
   ODIN_STAMP(1);
   const bool pipelined = p.pipelined != 0;
-  const int nrows_p = p.NIMG * p.NRI;
   const LaneStage<KMAX> LS = lane_stage_init<KMAX, VEC>(p, lane);
 
   if (p.w_resident) stage_weights(p, wl, 0, n0, tid, NT);
@@ -540,11 +605,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, Ta
     const int gr0 = tile * p.TR;
     const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
     const int ih_lo = (MODE == MODE_F) ? oh0 * p.S + p.ih_off : oh0 / p.S + p.ih_off;
-#pragma unroll
-    for (int q = 0; q < RPWMAX; ++q) {
-      const int r = wave + NW * q;
-      if (r < nrows_p) stage_row_issue<KMAX, VEC>(p, LS, r, b0, ih_lo, 0, pf + q * KMAX);
-    }
+    stage_issue<KMAX, RPWMAX, VEC, NW>(p, LS, wave, tid, 0, b0, ih_lo, 0, pf);
   }
   ODIN_STAMP(3);
 
@@ -558,11 +619,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, Ta
     slot_set_tile(p, s1, gr0);
     if (pipelined) {
       __syncthreads();  // everyone is done reading the previous patch
-#pragma unroll
-      for (int q = 0; q < RPWMAX; ++q) {
-        const int r = wave + NW * q;
-        if (r < nrows_p) stage_row_commit<KMAX, VEC>(p, LS, r, pf + q * KMAX, patch);
-      }
+      stage_commit<KMAX, RPWMAX, VEC, NW>(p, LS, wave, tid, 0, pf, patch);
       __syncthreads();
       ODIN_STAMP(5);
       const int nt = tile + gridDim.x;
@@ -570,11 +627,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, Ta
         const int g2 = nt * p.TR;
         const int b2 = g2 / p.OH, o2 = g2 - b2 * p.OH;
         const int ih2 = (MODE == MODE_F) ? o2 * p.S + p.ih_off : o2 / p.S + p.ih_off;
-#pragma unroll
-        for (int q = 0; q < RPWMAX; ++q) {
-          const int r = wave + NW * q;
-          if (r < nrows_p) stage_row_issue<KMAX, VEC>(p, LS, r, b2, ih2, 0, pf + q * KMAX);
-        }
+        stage_issue<KMAX, RPWMAX, VEC, NW>(p, LS, wave, tid, 0, b2, ih2, 0, pf);
       }
       ODIN_STAMP(6);
       if (mt0 < p.MT) acc0 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s0, l31, h, acc0);
@@ -583,17 +636,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, Ta
       for (int ch = 0; ch < p.n_chunks; ++ch) {
         const int c0 = ch * p.CIC;
         __syncthreads();
-        for (int r0 = wave; r0 < nrows_p; r0 += NW * RPWMAX) {  // RPWMAX rows in flight
-#pragma unroll
-          for (int q = 0; q < RPWMAX; ++q) {
-            const int r = r0 + NW * q;
-            if (r < nrows_p) stage_row_issue<KMAX, VEC>(p, LS, r, b0, ih_lo, c0, pf + q * KMAX);
-          }
-#pragma unroll
-          for (int q = 0; q < RPWMAX; ++q) {
-            const int r = r0 + NW * q;
-            if (r < nrows_p) stage_row_commit<KMAX, VEC>(p, LS, r, pf + q * KMAX, patch);
-          }
+        for (int bt = 0; bt < p.n_batches; ++bt) {  // KMAX*RPWMAX items per thread in flight
+          stage_issue<KMAX, RPWMAX, VEC, NW>(p, LS, wave, tid, bt, b0, ih_lo, c0, pf);
+          stage_commit<KMAX, RPWMAX, VEC, NW>(p, LS, wave, tid, bt, pf, patch);
         }
         if (!p.w_resident) stage_weights(p, wl, c0, n0, tid, NT);
         __syncthreads();
@@ -842,7 +887,8 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
     long pf = (long)p.NIMG * p.NRI * p.PW * P + 8;
     long wf = (long)ntaps * cic * p.WP + 64;
     long rowlen = (long)p.PW * ((vec0 && (cic & 3) == 0) ? cic / 4 : cic);
-    if (pf + wf <= LDS_BUDGET_FLOATS && rowlen <= 64 * GENERIC_KMAX) break;
+    const bool flat0 = (p.PW == 1 && p.NRI == 1);
+    if (pf + wf <= LDS_BUDGET_FLOATS && (flat0 || rowlen <= 64 * GENERIC_KMAX)) break;
     if (cic <= gran) return false;
     // next smaller chunk: halve, rounded up to the granularity
     int nc = (CIp + cic - 1) / cic + 1;
@@ -857,6 +903,8 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
   p.vec = (vec0 && (cic & 3) == 0) ? 1 : 0;
   p.KI = (p.PW * (p.vec ? cic / 4 : cic) + 63) / 64;
   p.pipelined = 0;
+  p.flat = (p.PW == 1 && p.NRI == 1) ? 1 : 0;
+  if (p.flat) p.KI = 1;
   p.patch_floats = (int)(((long)p.NIMG * p.NRI * p.PW * p.P + 8 + 3) & ~3L);
   long wf = (long)ntaps * cic * p.WP + 64;  // + scratch for per-tile reductions
   long total = p.patch_floats + wf;
@@ -882,7 +930,13 @@ template <int MODE, int TK, int TS, int TCIC, bool VEC, bool TAIL, int KMAX, int
 int launch_inst(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* stream) {
   if (p.KI > KMAX) return odin_fail(-2, "gather_conv: patch row too long for this instance");
   const int rpw = (p.NIMG * p.NRI + NW_G - 1) / NW_G;
-  p.pipelined = (p.n_chunks == 1 && rpw <= RPWMAX) ? 1 : 0;
+  if (p.flat) {
+    const int items = p.NIMG * (p.vec ? p.CIC / 4 : p.CIC);
+    p.n_batches = (items + KMAX * RPWMAX * NW_G * 64 - 1) / (KMAX * RPWMAX * NW_G * 64);
+  } else {
+    p.n_batches = (rpw + RPWMAX - 1) / RPWMAX;
+  }
+  p.pipelined = (p.n_chunks == 1 && p.n_batches == 1) ? 1 : 0;
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {

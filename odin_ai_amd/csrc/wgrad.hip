@@ -38,6 +38,7 @@ struct WParams {
   int slab_stride;
   int patch_floats, dy_floats;
   int pvec, dvec, KI, pipelined;
+  int flat, n_batches;  // Dense: IN tile is one contiguous [NIMG, CIB] block
   int bias_mode;  // 0 none, 1 extra MFMA tile with A = 1, 2 summed while staging DY
 };
 
@@ -115,6 +116,66 @@ __device__ __forceinline__ void wrow_commit(const WParams& p, const WLane<KMAX>&
   }
 }
 
+template <int KMAX, int RPWMAX>
+__device__ __forceinline__ void wpatch_issue(const WParams& p, const WLane<KMAX>& L, int wave,
+                                             int tid, int batch, int b0, int ih_lo, int ci0,
+                                             int cib, float4* pf) {
+  constexpr int PFN = KMAX * RPWMAX, NT = NW_W * 64;
+  if (p.flat) {
+    const int cpi = p.pvec ? (p.P >> 2) : p.P;
+    const int total = p.NIMG * cpi;
+#pragma unroll
+    for (int i = 0; i < PFN; ++i) {
+      const int e = (batch * PFN + i) * NT + tid;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < total) {
+        const int img = e / cpi;
+        const int cc = (e - img * cpi) * (p.pvec ? 4 : 1);
+        if (b0 + img < p.B && cc < cib) {
+          const float* src = p.in + (size_t)(b0 + img) * p.CI + ci0 + cc;
+          if (p.pvec) t = *reinterpret_cast<const float4*>(src);
+          else t.x = src[0];
+        }
+      }
+      pf[i] = t;
+    }
+  } else {
+    const int nrows_p = p.NIMG * p.NRI;
+#pragma unroll
+    for (int q = 0; q < RPWMAX; ++q) {
+      const int r = batch * NW_W * RPWMAX + wave + NW_W * q;
+      if (r < nrows_p) wrow_issue<KMAX>(p, L, r, b0, ih_lo, ci0, pf + q * KMAX);
+    }
+  }
+}
+
+template <int KMAX, int RPWMAX>
+__device__ __forceinline__ void wpatch_commit(const WParams& p, const WLane<KMAX>& L, int wave,
+                                              int tid, int batch, const float4* pf, float* patch) {
+  constexpr int PFN = KMAX * RPWMAX, NT = NW_W * 64;
+  if (p.flat) {
+    const int cpi = p.pvec ? (p.P >> 2) : p.P;
+    const int total = p.NIMG * cpi;
+#pragma unroll
+    for (int i = 0; i < PFN; ++i) {
+      const int e = (batch * PFN + i) * NT + tid;
+      if (e < total) {
+        const int img = e / cpi;
+        const int cc = (e - img * cpi) * (p.pvec ? 4 : 1);
+        if (p.pvec) *reinterpret_cast<float4*>(patch + img * p.P + cc) = pf[i];
+        else patch[img * p.P + cc] = pf[i].x;
+      }
+    }
+  } else {
+    const int nrows_p = p.NIMG * p.NRI;
+#pragma unroll
+    for (int q = 0; q < RPWMAX; ++q) {
+      const int r = batch * NW_W * RPWMAX + wave + NW_W * q;
+      if (r < nrows_p) wrow_commit<KMAX>(p, L, r, pf + q * KMAX, patch);
+    }
+  }
+}
+
 // DY tile: item e < slots*cpd -> (slot = e / cpd, c = (e % cpd) * (vec ? 4 : 1))
 template <int DMAX, int NT>
 __device__ __forceinline__ void wdy_issue(const WParams& p, int gr0, int co0, int tid, float4* v) {
@@ -176,7 +237,6 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   const int n_wt = p.nrt * p.ncot;
   const int n_bias = (p.bias_mode == 1 && blockIdx.y == 0) ? p.ncot : 0;
   const int n_tot = n_wt + n_bias;
-  const int nrows_p = p.NIMG * p.NRI;
   const bool pipelined = p.pipelined != 0;
   const WLane<KMAX> WL = wlane_init<KMAX>(p, lane, cib);
 
@@ -225,11 +285,7 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   if (pipelined && tile < p.n_tiles) {
     const int gr0 = tile * p.TR;
     const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
-#pragma unroll
-    for (int q = 0; q < RPWMAX; ++q) {
-      const int r = wave + NW_W * q;
-      if (r < nrows_p) wrow_issue<KMAX>(p, WL, r, b0, oh0 * p.S - p.pt, ci0, pf + q * KMAX);
-    }
+    wpatch_issue<KMAX, RPWMAX>(p, WL, wave, tid, 0, b0, oh0 * p.S - p.pt, ci0, cib, pf);
     wdy_issue<DMAX, NT>(p, gr0, co0, tid, df);
   }
 
@@ -239,36 +295,20 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     const int ih_lo = oh0 * p.S - p.pt;
     __syncthreads();
     if (pipelined) {
-#pragma unroll
-      for (int q = 0; q < RPWMAX; ++q) {
-        const int r = wave + NW_W * q;
-        if (r < nrows_p) wrow_commit<KMAX>(p, WL, r, pf + q * KMAX, patch);
-      }
+      wpatch_commit<KMAX, RPWMAX>(p, WL, wave, tid, 0, pf, patch);
       wdy_commit<DMAX, NT>(p, tid, df, dyl, bsum4);
       __syncthreads();
       const int nt = tile + gridDim.x;
       if (nt < p.n_tiles) {
         const int g2 = nt * p.TR;
         const int b2 = g2 / p.OH, o2 = g2 - b2 * p.OH;
-#pragma unroll
-        for (int q = 0; q < RPWMAX; ++q) {
-          const int r = wave + NW_W * q;
-          if (r < nrows_p) wrow_issue<KMAX>(p, WL, r, b2, o2 * p.S - p.pt, ci0, pf + q * KMAX);
-        }
+        wpatch_issue<KMAX, RPWMAX>(p, WL, wave, tid, 0, b2, o2 * p.S - p.pt, ci0, cib, pf);
         wdy_issue<DMAX, NT>(p, g2, co0, tid, df);
       }
     } else {
-      for (int r0 = wave; r0 < nrows_p; r0 += NW_W * RPWMAX) {
-#pragma unroll
-        for (int q = 0; q < RPWMAX; ++q) {
-          const int r = r0 + NW_W * q;
-          if (r < nrows_p) wrow_issue<KMAX>(p, WL, r, b0, ih_lo, ci0, pf + q * KMAX);
-        }
-#pragma unroll
-        for (int q = 0; q < RPWMAX; ++q) {
-          const int r = r0 + NW_W * q;
-          if (r < nrows_p) wrow_commit<KMAX>(p, WL, r, pf + q * KMAX, patch);
-        }
+      for (int bt = 0; bt < p.n_batches; ++bt) {
+        wpatch_issue<KMAX, RPWMAX>(p, WL, wave, tid, bt, b0, ih_lo, ci0, cib, pf);
+        wpatch_commit<KMAX, RPWMAX>(p, WL, wave, tid, bt, pf, patch);
       }
       const int cpd = p.dvec ? (p.COB >> 2) : p.COB;
       for (int e0 = 0; e0 < p.slots * cpd; e0 += NT * DMAX) {
@@ -388,7 +428,8 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
       int P = CIB;
       if ((p.CI & 3) == 0 && (CIB & 3) != 0) continue;
       const bool pv = ((p.CI & 3) == 0) && ((CIB & 3) == 0);
-      if ((long)p.PW * (pv ? CIB / 4 : CIB) > 64 * 9) continue;  // staging: <= 9 items per lane per row
+      const bool flat0 = (p.PW == 1 && p.NRI == 1);
+      if (!flat0 && (long)p.PW * (pv ? CIB / 4 : CIB) > 64 * 9) continue;  // <= 9 items per lane per row
       long pf = ((long)p.NIMG * p.NRI * p.PW * P + 3) & ~3L;
       int DP = COB + 4;
       long df = (long)p.slots * DP;
@@ -399,6 +440,8 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
       p.pvec = pv ? 1 : 0;
       p.dvec = (((p.CO & 3) == 0) && ((COB & 3) == 0)) ? 1 : 0;
       p.KI = (p.PW * (pv ? CIB / 4 : CIB) + 63) / 64;
+      p.flat = flat0 ? 1 : 0;
+      if (p.flat) p.KI = 1;
       p.patch_floats = (int)pf;
       p.dy_floats = (int)df;
       *lds_bytes = (size_t)(pf + df + p.slots + 16) * 4;
@@ -417,7 +460,13 @@ template <int TNACC, int KMAX, int RPWMAX, int DMAX>
 int launch_winst(WParams& p, dim3 grid, size_t lds, void* stream) {
   const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
   const int ditems = p.slots * (p.dvec ? p.COB / 4 : p.COB);
-  p.pipelined = (rpw <= RPWMAX && ditems <= DMAX * NW_W * 64 && p.KI <= KMAX) ? 1 : 0;
+  if (p.flat) {
+    const int items = p.NIMG * (p.pvec ? p.P / 4 : p.P);
+    p.n_batches = (items + KMAX * RPWMAX * NW_W * 64 - 1) / (KMAX * RPWMAX * NW_W * 64);
+  } else {
+    p.n_batches = (rpw + RPWMAX - 1) / RPWMAX;
+  }
+  p.pipelined = (p.n_batches == 1 && ditems <= DMAX * NW_W * 64 && p.KI <= KMAX) ? 1 : 0;
   if (p.KI > KMAX) return odin_fail(-2, "wgrad: patch row too long for this instance");
 #ifndef ODIN_SIM
   static bool attr_done = false;

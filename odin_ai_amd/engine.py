@@ -619,6 +619,8 @@ class VAEEngine:
     self.set_hyper(lr=lr, beta=beta)
     if use_graph and self.device.type == 'cuda' and self.world_size == 1:
       self._graph_step(x, eps, global_clipnorm)
+    elif use_graph and self.device.type == 'cuda':
+      self._graph_step_dp(x, eps, global_clipnorm)
     else:
       self.forward(x, eps)
       self.backward()
@@ -657,3 +659,35 @@ class VAEEngine:
     if eps is not None:
       self.eps.copy_(eps, non_blocking=True)
     self.graph.replay()
+
+  def _graph_step_dp(self, x, eps, global_clipnorm):
+    """Data-parallel variant: graph A = forward + backward + slab reduction, then ONE RCCL
+    all-reduce of the flat gradient bucket (eager, on the same stream), then graph B = Adam."""
+    if self.graph is None:
+      self.x_static = torch.empty_like(x)
+      self.x_static.copy_(x)
+      if eps is not None:
+        self.eps.copy_(eps)
+      cap = torch.cuda.Stream(self.device)
+      cap.wait_stream(torch.cuda.current_stream(self.device))
+      saved = (self.params.clone(), self.m.clone(), self.v.clone())
+      with torch.cuda.stream(cap):
+        self.forward(self.x_static, None if eps is None else self.eps)
+        self.backward()
+        self.adam(global_clipnorm=global_clipnorm)
+        self.params.copy_(saved[0]); self.m.copy_(saved[1]); self.v.copy_(saved[2])
+      torch.cuda.current_stream(self.device).wait_stream(cap)
+      self._graph_eps_explicit = eps is not None
+      ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+      with torch.cuda.graph(ga, stream=cap):
+        self.forward(self.x_static, self.eps if self._graph_eps_explicit else None)
+        self.backward()
+      with torch.cuda.graph(gb, stream=cap):
+        self.adam(global_clipnorm=global_clipnorm)
+      self.graph, self.graph_b = ga, gb
+    self.x_static.copy_(x, non_blocking=True)
+    if eps is not None:
+      self.eps.copy_(eps, non_blocking=True)
+    self.graph.replay()
+    self.allreduce()
+    self.graph_b.replay()
