@@ -281,12 +281,12 @@ __device__ __forceinline__ void stage_row_commit(const GParams& p, const LaneSta
 // A whole staging batch.  Row mode: rows batch*NW*RPWMAX + wave + NW*q.  Flat mode (Dense:
 // every "image" is one pixel, the tile's input is the contiguous block in[b0 .. b0+NIMG)[CI]):
 // items e = (batch*PFN + i)*NT + tid -> (image, channel group).
-template <int KMAX, int RPWMAX, bool VEC, int NW>
+template <int KMAX, int RPWMAX, bool VEC, int NW, bool FLAT>
 __device__ __forceinline__ void stage_issue(const GParams& p, const LaneStage<KMAX>& LS, int wave,
                                             int tid, int batch, int b0, int ih_lo, int c0,
                                             typename StageT<VEC>::type* pf) {
   constexpr int PFN = KMAX * RPWMAX, NT = NW * 64;
-  if (p.flat) {
+  if constexpr (FLAT) {
     const int cpi = VEC ? (p.CIC >> 2) : p.CIC;
     const int total = p.NIMG * cpi;
 #pragma unroll
@@ -313,12 +313,12 @@ __device__ __forceinline__ void stage_issue(const GParams& p, const LaneStage<KM
   }
 }
 
-template <int KMAX, int RPWMAX, bool VEC, int NW>
+template <int KMAX, int RPWMAX, bool VEC, int NW, bool FLAT>
 __device__ __forceinline__ void stage_commit(const GParams& p, const LaneStage<KMAX>& LS, int wave,
                                              int tid, int batch,
                                              const typename StageT<VEC>::type* pf, float* patch) {
   constexpr int PFN = KMAX * RPWMAX, NT = NW * 64;
-  if (p.flat) {
+  if constexpr (FLAT) {
     const int cpi = VEC ? (p.CIC >> 2) : p.CIC;
     const int total = p.NIMG * cpi;
 #pragma unroll
@@ -545,8 +545,10 @@ __device__ __forceinline__ float sigmoid_g(float x) {
   } while (0)
 #endif
 
-template <int MODE, int NW, int TK, int TS, int TCIC, bool VEC, bool TAIL, int KMAX, int RPWMAX, int WPS>
-__global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, TailParams tp) {
+// EPI: 3 = as 0 but with FLAT (Dense) staging; 0 = runtime activation / aux / channel masking; 1 = ELU, no aux, CO % 32 == 0
+// (forward of the elu stacks); 2 = linear, aux = ELU derivative, CO % 32 == 0 (data-gradients).
+template <int MODE, int NW, int TK, int TS, int TCIC, bool VEC, bool TAIL, int KMAX, int RPWMAX, int EPI>
+__global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailParams tp) {
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
   float* wl = smem + p.patch_floats;
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, Ta
     const int gr0 = tile * p.TR;
     const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
     const int ih_lo = (MODE == MODE_F) ? oh0 * p.S + p.ih_off : oh0 / p.S + p.ih_off;
-    stage_issue<KMAX, RPWMAX, VEC, NW>(p, LS, wave, tid, 0, b0, ih_lo, 0, pf);
+    stage_issue<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, 0, b0, ih_lo, 0, pf);
   }
   ODIN_STAMP(3);
 
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, Ta
     slot_set_tile(p, s1, gr0);
     if (pipelined) {
       __syncthreads();  // everyone is done reading the previous patch
-      stage_commit<KMAX, RPWMAX, VEC, NW>(p, LS, wave, tid, 0, pf, patch);
+      stage_commit<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, 0, pf, patch);
       __syncthreads();
       ODIN_STAMP(5);
       const int nt = tile + gridDim.x;
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, Ta
         const int g2 = nt * p.TR;
         const int b2 = g2 / p.OH, o2 = g2 - b2 * p.OH;
         const int ih2 = (MODE == MODE_F) ? o2 * p.S + p.ih_off : o2 / p.S + p.ih_off;
-        stage_issue<KMAX, RPWMAX, VEC, NW>(p, LS, wave, tid, 0, b2, ih2, 0, pf);
+        stage_issue<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, 0, b2, ih2, 0, pf);
       }
       ODIN_STAMP(6);
       if (mt0 < p.MT) acc0 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s0, l31, h, acc0);
@@ -637,8 +639,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, Ta
         const int c0 = ch * p.CIC;
         __syncthreads();
         for (int bt = 0; bt < p.n_batches; ++bt) {  // KMAX*RPWMAX items per thread in flight
-          stage_issue<KMAX, RPWMAX, VEC, NW>(p, LS, wave, tid, bt, b0, ih_lo, c0, pf);
-          stage_commit<KMAX, RPWMAX, VEC, NW>(p, LS, wave, tid, bt, pf, patch);
+          stage_issue<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, bt, b0, ih_lo, c0, pf);
+          stage_commit<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, bt, pf, patch);
         }
         if (!p.w_resident) stage_weights(p, wl, c0, n0, tid, NT);
         __syncthreads();
@@ -658,11 +660,38 @@ __global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, Ta
       const bool live = s.opix >= 0;
       float* outp = p.out + (live ? (size_t)((unsigned)s.opix * (unsigned)p.CO) : 0) + n0 + 4 * h;
       float v[16];
+      if constexpr (EPI == 1) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int n = n0 + 8 * (i >> 2) + 4 * h + (i & 3);
-        const float t = acc[i] + bias_r[i];
-        v[i] = (n < p.CO && live) ? odin_act(p.act, t) : 0.f;
+        for (int i = 0; i < 16; ++i) {
+          const float t = acc[i] + bias_r[i];
+          v[i] = live ? (t > 0.f ? t : odin_exp(t) - 1.f) : 0.f;
+        }
+      } else if constexpr (EPI == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = live ? acc[i] + bias_r[i] : 0.f;
+      } else {
+        const int act = p.act;
+        if (act == ODIN_ACT_ELU) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int n = n0 + 8 * (i >> 2) + 4 * h + (i & 3);
+            const float t = acc[i] + bias_r[i];
+            v[i] = (n < p.CO && live) ? (t > 0.f ? t : odin_exp(t) - 1.f) : 0.f;
+          }
+        } else if (act == ODIN_ACT_RELU) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int n = n0 + 8 * (i >> 2) + 4 * h + (i & 3);
+            const float t = acc[i] + bias_r[i];
+            v[i] = (n < p.CO && live) ? fmaxf(t, 0.f) : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int n = n0 + 8 * (i >> 2) + 4 * h + (i & 3);
+            v[i] = (n < p.CO && live) ? acc[i] + bias_r[i] : 0.f;
+          }
+        }
       }
       if (TAIL) {
         // 1x1 conv: each pixel's 32 channels live in lanes (l31, h=0) and (l31, h=1)
@@ -699,9 +728,21 @@ __global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, Ta
             g += dl[oc] * w1r[i][oc];
             dw1[i][oc] += v[i] * dl[oc];
           }
-          v[i] = g * odin_act_grad(p.act, v[i]);
+          v[i] = g * ((EPI == 1) ? (v[i] > 0.f ? 1.f : v[i] + 1.f) : odin_act_grad(p.act, v[i]));
         }
-      } else if (p.aux != nullptr && live) {
+      } else if (EPI == 2 && live) {
+        const float* auxp = p.aux + (size_t)((unsigned)s.opix * (unsigned)p.CO) + n0 + 4 * h;
+        float4 ax[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ax[q] = *reinterpret_cast<const float4*>(auxp + 8 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[4 * q + 0] *= ax[q].x > 0.f ? 1.f : ax[q].x + 1.f;
+          v[4 * q + 1] *= ax[q].y > 0.f ? 1.f : ax[q].y + 1.f;
+          v[4 * q + 2] *= ax[q].z > 0.f ? 1.f : ax[q].z + 1.f;
+          v[4 * q + 3] *= ax[q].w > 0.f ? 1.f : ax[q].w + 1.f;
+        }
+      } else if ((EPI == 0 || EPI == 3) && p.aux != nullptr && live) {
         const float* auxp = p.aux + (size_t)((unsigned)s.opix * (unsigned)p.CO) + n0 + 4 * h;
         if (co_vec) {
           float4 ax[4];
@@ -730,7 +771,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gather_conv_kernel(GParams p, Ta
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n = n0 + 8 * q + 4 * h;
-          if (co_vec && n + 3 < p.CO) {
+          if ((EPI == 1 || EPI == 2) || (co_vec && n + 3 < p.CO)) {
             *reinterpret_cast<float4*>(outp + 8 * q) =
                 make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
           } else {
@@ -926,11 +967,11 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
 
 long long* g_stamps = nullptr;
 
-template <int MODE, int TK, int TS, int TCIC, bool VEC, bool TAIL, int KMAX, int RPWMAX, int WPS = 1>
+template <int MODE, int TK, int TS, int TCIC, bool VEC, bool TAIL, int KMAX, int RPWMAX, int EPI = 0>
 int launch_inst(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* stream) {
   if (p.KI > KMAX) return odin_fail(-2, "gather_conv: patch row too long for this instance");
   const int rpw = (p.NIMG * p.NRI + NW_G - 1) / NW_G;
-  if (p.flat) {
+  if (EPI == 3) {
     const int items = p.NIMG * (p.vec ? p.CIC / 4 : p.CIC);
     p.n_batches = (items + KMAX * RPWMAX * NW_G * 64 - 1) / (KMAX * RPWMAX * NW_G * 64);
   } else {
@@ -942,12 +983,12 @@ int launch_inst(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* s
   if (!attr_done) {
     (void)hipFuncSetAttribute(
         reinterpret_cast<const void*>(
-            &gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, WPS>),
+            &gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, WPS>), grid,
+  ODIN_LAUNCH((gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI>), grid,
               dim3(NW_G * 64), lds, stream, p, tp);
   return odin_check_launch("gather_conv");
 }
@@ -971,31 +1012,55 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
   const bool k4s2 = (p.KH == 4 && p.KW == 4 && p.S == 2 && p.n_chunks == 1 && p.vec);
   const int rpw = (p.NIMG * p.NRI + NW_G - 1) / NW_G;
   constexpr int GK = GENERIC_KMAX;
+  static int noepi = -1;
+  if (noepi < 0) { const char* e = getenv("ODIN_NOEPI"); noepi = e ? atoi(e) : 0; }
+  const bool fulln = (p.CO % 32) == 0 && !noepi;
+  const int epi = !fulln ? 0
+                  : (p.act == ODIN_ACT_ELU && p.aux == nullptr) ? 1
+                  : (p.act == ODIN_ACT_LINEAR && p.aux != nullptr && p.aux_act == ODIN_ACT_ELU) ? 2 : 0;
   if (tail != nullptr) {
     tp = *tail;
     if (p.CO > 32 || tp.C1 > MAXC1 || p.NIMG != 1 || !p.vec)
       return odin_fail(-2, "bernoulli tail: needs Cout<=32, C1<=4, Cin%4==0 and one image per tile");
+    if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5 && epi == 1)
+      return launch_inst<MODE_T, 4, 2, 32, true, true, 5, 2, 1>(p, tp, grid, lds, stream);
     if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5)
-      return launch_inst<MODE_T, 4, 2, 32, true, true, 5, 2>(p, tp, grid, lds, stream);
+      return launch_inst<MODE_T, 4, 2, 32, true, true, 5, 2, 0>(p, tp, grid, lds, stream);
     if (mode == MODE_T) return launch_inst<MODE_T, 0, 0, 0, true, true, GK, 2>(p, tp, grid, lds, stream);
     return launch_inst<MODE_F, 0, 0, 0, true, true, GK, 2>(p, tp, grid, lds, stream);
   }
   if (mode == MODE_F) {
-    if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 5)
-      return launch_inst<MODE_F, 4, 2, 32, true, false, 5, 5>(p, tp, grid, lds, stream);
-    if (k4s2 && p.CIC == 32 && p.KI <= 9)
-      return launch_inst<MODE_F, 4, 2, 32, true, false, 9, 3>(p, tp, grid, lds, stream);
-    if (k4s2 && p.CIC == 64 && p.KI <= 5)
-      return launch_inst<MODE_F, 4, 2, 64, true, false, 5, 3>(p, tp, grid, lds, stream);
+    if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 5) {
+      if (epi == 1) return launch_inst<MODE_F, 4, 2, 32, true, false, 5, 5, 1>(p, tp, grid, lds, stream);
+      if (epi == 2) return launch_inst<MODE_F, 4, 2, 32, true, false, 5, 5, 2>(p, tp, grid, lds, stream);
+      return launch_inst<MODE_F, 4, 2, 32, true, false, 5, 5, 0>(p, tp, grid, lds, stream);
+    }
+    if (k4s2 && p.CIC == 32 && p.KI <= 9) {
+      if (epi == 2) return launch_inst<MODE_F, 4, 2, 32, true, false, 9, 3, 2>(p, tp, grid, lds, stream);
+      return launch_inst<MODE_F, 4, 2, 32, true, false, 9, 3, 0>(p, tp, grid, lds, stream);
+    }
+    if (k4s2 && p.CIC == 64 && p.KI <= 5) {
+      if (epi == 1) return launch_inst<MODE_F, 4, 2, 64, true, false, 5, 3, 1>(p, tp, grid, lds, stream);
+      if (epi == 2) return launch_inst<MODE_F, 4, 2, 64, true, false, 5, 3, 2>(p, tp, grid, lds, stream);
+      return launch_inst<MODE_F, 4, 2, 64, true, false, 5, 3, 0>(p, tp, grid, lds, stream);
+    }
+    if (p.flat && p.vec) return launch_inst<MODE_F, 0, 0, 0, true, false, 2, 8, 3>(p, tp, grid, lds, stream);
+    if (p.flat) return launch_inst<MODE_F, 0, 0, 0, false, false, 2, 8, 3>(p, tp, grid, lds, stream);
     if (p.vec && p.KI <= 2) return launch_inst<MODE_F, 0, 0, 0, true, false, 2, 8>(p, tp, grid, lds, stream);
     if (p.vec) return launch_inst<MODE_F, 0, 0, 0, true, false, GK, 2>(p, tp, grid, lds, stream);
     if (p.KI <= 2) return launch_inst<MODE_F, 0, 0, 0, false, false, 2, 8>(p, tp, grid, lds, stream);
     return launch_inst<MODE_F, 0, 0, 0, false, false, GK, 2>(p, tp, grid, lds, stream);
   }
-  if (k4s2 && p.CIC == 32 && p.KI <= 5)
-    return launch_inst<MODE_T, 4, 2, 32, true, false, 5, 2, 1>(p, tp, grid, lds, stream);
-  if (k4s2 && p.CIC == 64 && p.KI <= 5)
-    return launch_inst<MODE_T, 4, 2, 64, true, false, 5, 2, 1>(p, tp, grid, lds, stream);
+  if (k4s2 && p.CIC == 32 && p.KI <= 5) {
+    if (epi == 1) return launch_inst<MODE_T, 4, 2, 32, true, false, 5, 2, 1>(p, tp, grid, lds, stream);
+    if (epi == 2) return launch_inst<MODE_T, 4, 2, 32, true, false, 5, 2, 2>(p, tp, grid, lds, stream);
+    return launch_inst<MODE_T, 4, 2, 32, true, false, 5, 2, 0>(p, tp, grid, lds, stream);
+  }
+  if (k4s2 && p.CIC == 64 && p.KI <= 5) {
+    if (epi == 1) return launch_inst<MODE_T, 4, 2, 64, true, false, 5, 2, 1>(p, tp, grid, lds, stream);
+    if (epi == 2) return launch_inst<MODE_T, 4, 2, 64, true, false, 5, 2, 2>(p, tp, grid, lds, stream);
+    return launch_inst<MODE_T, 4, 2, 64, true, false, 5, 2, 0>(p, tp, grid, lds, stream);
+  }
   if (p.vec && p.KI <= 2) return launch_inst<MODE_T, 0, 0, 0, true, false, 2, 8>(p, tp, grid, lds, stream);
   if (p.vec) return launch_inst<MODE_T, 0, 0, 0, true, false, GK, 2>(p, tp, grid, lds, stream);
   return launch_inst<MODE_T, 0, 0, 0, false, false, GK, 2>(p, tp, grid, lds, stream);

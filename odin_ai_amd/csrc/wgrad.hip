@@ -116,12 +116,12 @@ __device__ __forceinline__ void wrow_commit(const WParams& p, const WLane<KMAX>&
   }
 }
 
-template <int KMAX, int RPWMAX>
+template <int KMAX, int RPWMAX, bool FLAT>
 __device__ __forceinline__ void wpatch_issue(const WParams& p, const WLane<KMAX>& L, int wave,
                                              int tid, int batch, int b0, int ih_lo, int ci0,
                                              int cib, float4* pf) {
   constexpr int PFN = KMAX * RPWMAX, NT = NW_W * 64;
-  if (p.flat) {
+  if constexpr (FLAT) {
     const int cpi = p.pvec ? (p.P >> 2) : p.P;
     const int total = p.NIMG * cpi;
 #pragma unroll
@@ -149,11 +149,11 @@ __device__ __forceinline__ void wpatch_issue(const WParams& p, const WLane<KMAX>
   }
 }
 
-template <int KMAX, int RPWMAX>
+template <int KMAX, int RPWMAX, bool FLAT>
 __device__ __forceinline__ void wpatch_commit(const WParams& p, const WLane<KMAX>& L, int wave,
                                               int tid, int batch, const float4* pf, float* patch) {
   constexpr int PFN = KMAX * RPWMAX, NT = NW_W * 64;
-  if (p.flat) {
+  if constexpr (FLAT) {
     const int cpi = p.pvec ? (p.P >> 2) : p.P;
     const int total = p.NIMG * cpi;
 #pragma unroll
@@ -220,7 +220,7 @@ __device__ __forceinline__ void wdy_commit(const WParams& p, int tid, const floa
   }
 }
 
-template <int TNACC, int KMAX, int RPWMAX, int DMAX>
+template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT>
 __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   if (pipelined && tile < p.n_tiles) {
     const int gr0 = tile * p.TR;
     const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
-    wpatch_issue<KMAX, RPWMAX>(p, WL, wave, tid, 0, b0, oh0 * p.S - p.pt, ci0, cib, pf);
+    wpatch_issue<KMAX, RPWMAX, FLAT>(p, WL, wave, tid, 0, b0, oh0 * p.S - p.pt, ci0, cib, pf);
     wdy_issue<DMAX, NT>(p, gr0, co0, tid, df);
   }
 
@@ -295,20 +295,20 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     const int ih_lo = oh0 * p.S - p.pt;
     __syncthreads();
     if (pipelined) {
-      wpatch_commit<KMAX, RPWMAX>(p, WL, wave, tid, 0, pf, patch);
+      wpatch_commit<KMAX, RPWMAX, FLAT>(p, WL, wave, tid, 0, pf, patch);
       wdy_commit<DMAX, NT>(p, tid, df, dyl, bsum4);
       __syncthreads();
       const int nt = tile + gridDim.x;
       if (nt < p.n_tiles) {
         const int g2 = nt * p.TR;
         const int b2 = g2 / p.OH, o2 = g2 - b2 * p.OH;
-        wpatch_issue<KMAX, RPWMAX>(p, WL, wave, tid, 0, b2, o2 * p.S - p.pt, ci0, cib, pf);
+        wpatch_issue<KMAX, RPWMAX, FLAT>(p, WL, wave, tid, 0, b2, o2 * p.S - p.pt, ci0, cib, pf);
         wdy_issue<DMAX, NT>(p, g2, co0, tid, df);
       }
     } else {
       for (int bt = 0; bt < p.n_batches; ++bt) {
-        wpatch_issue<KMAX, RPWMAX>(p, WL, wave, tid, bt, b0, ih_lo, ci0, cib, pf);
-        wpatch_commit<KMAX, RPWMAX>(p, WL, wave, tid, bt, pf, patch);
+        wpatch_issue<KMAX, RPWMAX, FLAT>(p, WL, wave, tid, bt, b0, ih_lo, ci0, cib, pf);
+        wpatch_commit<KMAX, RPWMAX, FLAT>(p, WL, wave, tid, bt, pf, patch);
       }
       const int cpd = p.dvec ? (p.COB >> 2) : p.COB;
       for (int e0 = 0; e0 < p.slots * cpd; e0 += NT * DMAX) {
@@ -456,11 +456,11 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
   return false;
 }
 
-template <int TNACC, int KMAX, int RPWMAX, int DMAX>
+template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT = false>
 int launch_winst(WParams& p, dim3 grid, size_t lds, void* stream) {
   const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
   const int ditems = p.slots * (p.dvec ? p.COB / 4 : p.COB);
-  if (p.flat) {
+  if (FLAT) {
     const int items = p.NIMG * (p.pvec ? p.P / 4 : p.P);
     p.n_batches = (items + KMAX * RPWMAX * NW_W * 64 - 1) / (KMAX * RPWMAX * NW_W * 64);
   } else {
@@ -471,12 +471,12 @@ int launch_winst(WParams& p, dim3 grid, size_t lds, void* stream) {
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX>), grid, dim3(NW_W * 64), lds, stream, p);
+  ODIN_LAUNCH((wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT>), grid, dim3(NW_W * 64), lds, stream, p);
   return odin_check_launch("wgrad");
 }
 
@@ -492,6 +492,10 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
   const int nacc = (tiles_per_block + NW_W - 1) / NW_W;
   const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
   const int ditems = p.slots * (p.dvec ? p.COB / 4 : p.COB);
+  if (p.flat) {
+    if (nacc <= 4) return launch_winst<4, 2, 8, 8, true>(p, grid, lds, stream);
+    return launch_winst<NACC, 2, 8, 8, true>(p, grid, lds, stream);
+  }
   if (nacc <= 4) {
     if (p.KI <= 5 && rpw <= 5 && ditems <= 4 * 256) return launch_winst<4, 5, 5, 4>(p, grid, lds, stream);
     if (rpw <= 3 && ditems <= 4 * 256) return launch_winst<4, 9, 3, 4>(p, grid, lds, stream);
