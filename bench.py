@@ -210,11 +210,13 @@ def main():
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world,
-                            device_id=torch.device('cuda', local_rank))
+    dist.init_process_group(os.environ.get('ODIN_DIST_BACKEND', 'nccl'), rank=rank,
+                            world_size=world)
   assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
-  torch.cuda.set_device(local_rank)
-  device = torch.device('cuda', local_rank)
+  ndev = torch.cuda.device_count()
+  dev_index = local_rank % max(ndev, 1)
+  torch.cuda.set_device(dev_index)
+  device = torch.device('cuda', dev_index)
 
   from odin_ai_amd.engine import VAEEngine
   from odin_ai_amd.networks import get_networks

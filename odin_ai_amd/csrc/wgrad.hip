@@ -322,26 +322,33 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     // two-stage register pipeline over pixel pairs: operands of pair kp+1 are read from
     // LDS while the MFMAs of pair kp execute
     float av[2][TNACC], bv[2][TNACC];
-    auto load_pair = [&](int kp, float* a_, float* b_) {
-      const int s = 2 * kp + h;
-      const int base = tbl[s];
-      const float* brow = dyl + s * p.DP;
+    // raw LDS operands; the (amul, aadd) fix-up is applied right before the MFMA so that
+    // the reads of pair kp+1 stay in flight under the MFMAs of pair kp.  Table entries are
+    // fetched two pairs ahead (they feed the operand addresses).
+    auto load_pair = [&](int kp, int base, float* a_, float* b_) {
+      const float* brow = dyl + (2 * kp + h) * p.DP;
 #pragma unroll
       for (int a = 0; a < TNACC; ++a) {
-        a_[a] = fmaf(patch[base + a_off[a]], amul[a], aadd[a]);
+        a_[a] = patch[base + a_off[a]];
         b_[a] = brow[b_off[a]];
       }
     };
-    load_pair(0, av[0], bv[0]);
+    int base_b = (npairs > 1) ? tbl[2 + h] : 0;
+    load_pair(0, tbl[h], av[0], bv[0]);
     for (int kp = 0; kp < npairs; kp += 2) {
-      if (kp + 1 < npairs) load_pair(kp + 1, av[1], bv[1]);
+      const int base_c = (kp + 2 < npairs) ? tbl[2 * (kp + 2) + h] : 0;
+      const int base_d = (kp + 3 < npairs) ? tbl[2 * (kp + 3) + h] : 0;
+      if (kp + 1 < npairs) load_pair(kp + 1, base_b, av[1], bv[1]);
 #pragma unroll
-      for (int a = 0; a < TNACC; ++a) acc[a] = mfma32(av[0][a], bv[0][a], acc[a]);
-      if (kp + 2 < npairs) load_pair(kp + 2, av[0], bv[0]);
+      for (int a = 0; a < TNACC; ++a)
+        acc[a] = mfma32(fmaf(av[0][a], amul[a], aadd[a]), bv[0][a], acc[a]);
+      if (kp + 2 < npairs) load_pair(kp + 2, base_c, av[0], bv[0]);
       if (kp + 1 < npairs) {
 #pragma unroll
-        for (int a = 0; a < TNACC; ++a) acc[a] = mfma32(av[1][a], bv[1][a], acc[a]);
+        for (int a = 0; a < TNACC; ++a)
+          acc[a] = mfma32(fmaf(av[1][a], amul[a], aadd[a]), bv[1][a], acc[a]);
       }
+      base_b = base_d;
     }
   }
 
