@@ -241,11 +241,13 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   const WLane<KMAX> WL = wlane_init<KMAX>(p, lane, cib);
 
   // slot -> patch base table (identical for every tile of this launch)
-  for (int s = tid; s < p.slots; s += NT) {
+  for (int s = tid; s < p.slots + 4; s += NT) {
     int r = s / p.OW, c = s - r * p.OW;
     int img = r / p.RPI, rl = r - img * p.RPI;
-    tbl[s] = (r < p.TR) ? ((img * p.NRI + rl * p.S) * p.PW + c * p.S) * p.P : 0;
+    tbl[s] = (s < p.slots && r < p.TR) ? ((img * p.NRI + rl * p.S) * p.PW + c * p.S) * p.P : 0;
   }
+  // zero pad rows of the DY tile (read by the pipeline's look-ahead, multiplied into nothing)
+  for (int e = tid; e < 4 * p.DP; e += NT) dyl[p.slots * p.DP + e] = 0.f;
 
   // per-accumulator lane constants.  A operand = patch value * amul + aadd: (1,0) for a
   // weight-gradient row, (0,1) for the MFMA bias tile (bias_mode 1), (0,0) for padding
@@ -333,21 +335,21 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
         b_[a] = brow[b_off[a]];
       }
     };
-    int base_b = (npairs > 1) ? tbl[2 + h] : 0;
+    // slots is a multiple of 4 and both dyl and tbl carry two zero pad slots, so the
+    // pipeline below needs no bounds tests (exact lgkmcnt accounting by the compiler)
+    int base_b = tbl[2 + h];
     load_pair(0, tbl[h], av[0], bv[0]);
     for (int kp = 0; kp < npairs; kp += 2) {
-      const int base_c = (kp + 2 < npairs) ? tbl[2 * (kp + 2) + h] : 0;
-      const int base_d = (kp + 3 < npairs) ? tbl[2 * (kp + 3) + h] : 0;
-      if (kp + 1 < npairs) load_pair(kp + 1, base_b, av[1], bv[1]);
+      const int base_c = tbl[2 * (kp + 2) + h];
+      const int base_d = tbl[2 * (kp + 3) + h];
+      load_pair(kp + 1, base_b, av[1], bv[1]);
 #pragma unroll
       for (int a = 0; a < TNACC; ++a)
         acc[a] = mfma32(fmaf(av[0][a], amul[a], aadd[a]), bv[0][a], acc[a]);
-      if (kp + 2 < npairs) load_pair(kp + 2, base_c, av[0], bv[0]);
-      if (kp + 1 < npairs) {
+      load_pair(kp + 2, base_c, av[0], bv[0]);
 #pragma unroll
-        for (int a = 0; a < TNACC; ++a)
-          acc[a] = mfma32(fmaf(av[1][a], amul[a], aadd[a]), bv[1][a], acc[a]);
-      }
+      for (int a = 0; a < TNACC; ++a)
+        acc[a] = mfma32(fmaf(av[1][a], amul[a], aadd[a]), bv[1][a], acc[a]);
       base_b = base_d;
     }
   }
@@ -414,7 +416,7 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
   p.n_tiles = (p.B * p.OH + p.TR - 1) / p.TR;
   p.NRI = (p.RPI - 1) * S + p.KH;
   p.PW = (p.OW - 1) * S + p.KW;
-  p.slots = (p.TR * p.OW + 1) & ~1;
+  p.slots = (p.TR * p.OW + 3) & ~3;
   const int ntaps = p.KH * p.KW;
   const int budget = (160 * 1024 - 2048) / 4;
   const int co32 = (p.CO + 31) / 32 * 32;
@@ -439,7 +441,7 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
       if (!flat0 && (long)p.PW * (pv ? CIB / 4 : CIB) > 64 * 9) continue;  // <= 9 items per lane per row
       long pf = ((long)p.NIMG * p.NRI * p.PW * P + 3) & ~3L;
       int DP = COB + 4;
-      long df = (long)p.slots * DP;
+      long df = (long)(p.slots + 4) * DP;
       if (pf + df + p.slots + 16 > budget) continue;
       p.CIB = CIB; p.COB = COB; p.P = P; p.DP = DP;
       p.nrt = nrt; p.ncot = ncot;
