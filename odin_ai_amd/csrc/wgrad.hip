@@ -325,32 +325,78 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     // LDS while the MFMAs of pair kp execute
     float av[2][TNACC], bv[2][TNACC];
     // raw LDS operands; the (amul, aadd) fix-up is applied right before the MFMA so that
-    // the reads of pair kp+1 stay in flight under the MFMAs of pair kp.  Table entries are
-    // fetched two pairs ahead (they feed the operand addresses).
-    auto load_pair = [&](int kp, int base, float* a_, float* b_) {
-      const float* brow = dyl + (2 * kp + h) * p.DP;
+    // the reads of pair kp+1 stay in flight under the MFMAs of pair kp.
+    if ((p.OW & 1) == 0) {
+      // fast path: both pixels of a pair lie in one output row, so the patch base is a
+      // wave-uniform running value (no table look-up on the critical path)
+      int pb = 0, pc = 0, prl = 0, pimg = 0, pslot = 0;
+      const int lane_h = h * p.S * p.P;
+      const int real_slots = p.TR * p.OW;
+      auto load_next = [&](float* a_, float* b_) {
+        const int base = (pslot < real_slots) ? pb : 0;
+        const float* brow = dyl + (pslot + h) * p.DP;
 #pragma unroll
-      for (int a = 0; a < TNACC; ++a) {
-        a_[a] = patch[base + a_off[a]];
-        b_[a] = brow[b_off[a]];
+        for (int a = 0; a < TNACC; ++a) {
+          a_[a] = patch[base + lane_h + a_off[a]];
+          b_[a] = brow[b_off[a]];
+        }
+        pslot += 2;
+        pc += 2;
+        pb += 2 * p.S * p.P;
+        if (pc >= p.OW) {
+          pc = 0;
+          ++prl;
+          pb += (p.S * p.PW - p.OW * p.S) * p.P;
+          if (prl == p.RPI) { prl = 0; ++pimg; pb = pimg * p.NRI * p.PW * p.P; }
+        }
+      };
+      load_next(av[0], bv[0]);
+      for (int kp = 0; kp < npairs; kp += 2) {
+        load_next(av[1], bv[1]);
+#pragma unroll
+        for (int a = 0; a < TNACC; ++a)
+          acc[a] = mfma32(fmaf(av[0][a], amul[a], aadd[a]), bv[0][a], acc[a]);
+#pragma unroll
+        for (int a = 0; a < TNACC; ++a) {
+          ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
+          ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 2);
+        }
+        ODIN_SCHED_FENCE();
+        load_next(av[0], bv[0]);
+#pragma unroll
+        for (int a = 0; a < TNACC; ++a)
+          acc[a] = mfma32(fmaf(av[1][a], amul[a], aadd[a]), bv[1][a], acc[a]);
+#pragma unroll
+        for (int a = 0; a < TNACC; ++a) {
+          ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
+          ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 2);
+        }
+        ODIN_SCHED_FENCE();
       }
-    };
-    // slots is a multiple of 4 and both dyl and tbl carry two zero pad slots, so the
-    // pipeline below needs no bounds tests (exact lgkmcnt accounting by the compiler)
-    int base_b = tbl[2 + h];
-    load_pair(0, tbl[h], av[0], bv[0]);
-    for (int kp = 0; kp < npairs; kp += 2) {
-      const int base_c = tbl[2 * (kp + 2) + h];
-      const int base_d = tbl[2 * (kp + 3) + h];
-      load_pair(kp + 1, base_b, av[1], bv[1]);
+    } else {
+      auto load_pair = [&](int kp, int base, float* a_, float* b_) {
+        const float* brow = dyl + (2 * kp + h) * p.DP;
 #pragma unroll
-      for (int a = 0; a < TNACC; ++a)
-        acc[a] = mfma32(fmaf(av[0][a], amul[a], aadd[a]), bv[0][a], acc[a]);
-      load_pair(kp + 2, base_c, av[0], bv[0]);
+        for (int a = 0; a < TNACC; ++a) {
+          a_[a] = patch[base + a_off[a]];
+          b_[a] = brow[b_off[a]];
+        }
+      };
+      int base_b = tbl[2 + h];
+      load_pair(0, tbl[h], av[0], bv[0]);
+      for (int kp = 0; kp < npairs; kp += 2) {
+        const int base_c = tbl[2 * (kp + 2) + h];
+        const int base_d = tbl[2 * (kp + 3) + h];
+        load_pair(kp + 1, base_b, av[1], bv[1]);
 #pragma unroll
-      for (int a = 0; a < TNACC; ++a)
-        acc[a] = mfma32(fmaf(av[1][a], amul[a], aadd[a]), bv[1][a], acc[a]);
-      base_b = base_d;
+        for (int a = 0; a < TNACC; ++a)
+          acc[a] = mfma32(fmaf(av[0][a], amul[a], aadd[a]), bv[0][a], acc[a]);
+        load_pair(kp + 2, base_c, av[0], bv[0]);
+#pragma unroll
+        for (int a = 0; a < TNACC; ++a)
+          acc[a] = mfma32(fmaf(av[1][a], amul[a], aadd[a]), bv[1][a], acc[a]);
+        base_b = base_d;
+      }
     }
   }
 
