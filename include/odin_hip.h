@@ -189,6 +189,7 @@ int odin_stft_mel_db(const float* y, const float* window, const float* melfb_t, 
 /* diagnostics only: device buffer (>= 64 int64) that receives in-kernel cycle stamps of the
  * conv kernels' workgroup 0 (NULL disables; never set in production) */
 int odin_debug_set_stamps(void* buf);
+int odin_debug_set_wgrad_stamps(void* buf);
 
 /* ---- HIP-graph helpers (capture a sequence of the calls above, replay per step) ------- */
 int odin_graph_begin(void* stream);

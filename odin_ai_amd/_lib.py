@@ -65,6 +65,7 @@ SIGNATURES = {
     'odin_rng_normal': [P, C.c_size_t, C.c_uint64, P, P],
     'odin_stft_mel_db': [P, P, P, P, I, I, I, I, I, I, F, F, I, P],
     'odin_debug_set_stamps': [P],
+    'odin_debug_set_wgrad_stamps': [P],
     'odin_graph_begin': [P],
     'odin_graph_end': [P, C.POINTER(C.c_void_p)],
     'odin_graph_launch': [P, P],

@@ -39,6 +39,7 @@ struct WParams {
   int patch_floats, dy_floats;
   int pvec, dvec, KI, pipelined;
   int flat, n_batches;  // Dense: IN tile is one contiguous [NIMG, CIB] block
+  long long* stamps;
   int bias_mode;  // 0 none, 1 extra MFMA tile with A = 1, 2 summed while staging DY
 };
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ WLane<KMAX> wlane_init(const WParams& p, int lane, in
   return L;
 }
 
-template <int KMAX>
+template <int KMAX, bool PVEC>
 __device__ __forceinline__ void wrow_issue(const WParams& p, const WLane<KMAX>& L, int r, int b0,
                                            int ih_lo, int ci0, float4* v) {
   const int img = (p.NIMG == 1) ? 0 : r / p.NRI;
@@ -95,7 +96,7 @@ __device__ __forceinline__ void wrow_issue(const WParams& p, const WLane<KMAX>& 
   for (int k = 0; k < KMAX; ++k) {
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row_ok && ((L.okmask >> k) & 1u)) {
-      if (p.pvec) t = *reinterpret_cast<const float4*>(rowp + L.gofs[k]);
+      if constexpr (PVEC) t = *reinterpret_cast<const float4*>(rowp + L.gofs[k]);
       else t.x = *reinterpret_cast<const float*>(rowp + L.gofs[k]);
       if (p.center) t = make_float4(2.f * t.x - 1.f, 2.f * t.y - 1.f, 2.f * t.z - 1.f, 2.f * t.w - 1.f);
     }
@@ -103,26 +104,26 @@ __device__ __forceinline__ void wrow_issue(const WParams& p, const WLane<KMAX>& 
   }
 }
 
-template <int KMAX>
+template <int KMAX, bool PVEC>
 __device__ __forceinline__ void wrow_commit(const WParams& p, const WLane<KMAX>& L, int r,
                                             const float4* v, float* patch) {
   float* rowl = patch + r * p.PW * p.P;
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     if ((L.jmask >> k) & 1u) {
-      if (p.pvec) *reinterpret_cast<float4*>(rowl + L.ldo[k]) = v[k];
+      if constexpr (PVEC) *reinterpret_cast<float4*>(rowl + L.ldo[k]) = v[k];
       else rowl[L.ldo[k]] = v[k].x;
     }
   }
 }
 
-template <int KMAX, int RPWMAX, bool FLAT>
+template <int KMAX, int RPWMAX, bool FLAT, bool PVEC>
 __device__ __forceinline__ void wpatch_issue(const WParams& p, const WLane<KMAX>& L, int wave,
                                              int tid, int batch, int b0, int ih_lo, int ci0,
                                              int cib, float4* pf) {
   constexpr int PFN = KMAX * RPWMAX, NT = NW_W * 64;
   if constexpr (FLAT) {
-    const int cpi = p.pvec ? (p.P >> 2) : p.P;
+    const int cpi = PVEC ? (p.P >> 2) : p.P;
     const int total = p.NIMG * cpi;
 #pragma unroll
     for (int i = 0; i < PFN; ++i) {
@@ -130,10 +131,10 @@ __device__ __forceinline__ void wpatch_issue(const WParams& p, const WLane<KMAX>
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       if (e < total) {
         const int img = e / cpi;
-        const int cc = (e - img * cpi) * (p.pvec ? 4 : 1);
+        const int cc = (e - img * cpi) * (PVEC ? 4 : 1);
         if (b0 + img < p.B && cc < cib) {
           const float* src = p.in + (size_t)(b0 + img) * p.CI + ci0 + cc;
-          if (p.pvec) t = *reinterpret_cast<const float4*>(src);
+          if constexpr (PVEC) t = *reinterpret_cast<const float4*>(src);
           else t.x = src[0];
         }
       }
@@ -144,25 +145,25 @@ __device__ __forceinline__ void wpatch_issue(const WParams& p, const WLane<KMAX>
 #pragma unroll
     for (int q = 0; q < RPWMAX; ++q) {
       const int r = batch * NW_W * RPWMAX + wave + NW_W * q;
-      if (r < nrows_p) wrow_issue<KMAX>(p, L, r, b0, ih_lo, ci0, pf + q * KMAX);
+      if (r < nrows_p) wrow_issue<KMAX, PVEC>(p, L, r, b0, ih_lo, ci0, pf + q * KMAX);
     }
   }
 }
 
-template <int KMAX, int RPWMAX, bool FLAT>
+template <int KMAX, int RPWMAX, bool FLAT, bool PVEC>
 __device__ __forceinline__ void wpatch_commit(const WParams& p, const WLane<KMAX>& L, int wave,
                                               int tid, int batch, const float4* pf, float* patch) {
   constexpr int PFN = KMAX * RPWMAX, NT = NW_W * 64;
   if constexpr (FLAT) {
-    const int cpi = p.pvec ? (p.P >> 2) : p.P;
+    const int cpi = PVEC ? (p.P >> 2) : p.P;
     const int total = p.NIMG * cpi;
 #pragma unroll
     for (int i = 0; i < PFN; ++i) {
       const int e = (batch * PFN + i) * NT + tid;
       if (e < total) {
         const int img = e / cpi;
-        const int cc = (e - img * cpi) * (p.pvec ? 4 : 1);
-        if (p.pvec) *reinterpret_cast<float4*>(patch + img * p.P + cc) = pf[i];
+        const int cc = (e - img * cpi) * (PVEC ? 4 : 1);
+        if constexpr (PVEC) *reinterpret_cast<float4*>(patch + img * p.P + cc) = pf[i];
         else patch[img * p.P + cc] = pf[i].x;
       }
     }
@@ -171,14 +172,29 @@ __device__ __forceinline__ void wpatch_commit(const WParams& p, const WLane<KMAX
 #pragma unroll
     for (int q = 0; q < RPWMAX; ++q) {
       const int r = batch * NW_W * RPWMAX + wave + NW_W * q;
-      if (r < nrows_p) wrow_commit<KMAX>(p, L, r, pf + q * KMAX, patch);
+      if (r < nrows_p) wrow_commit<KMAX, PVEC>(p, L, r, pf + q * KMAX, patch);
     }
   }
 }
 
 // DY tile: item e < slots*cpd -> (slot = e / cpd, c = (e % cpd) * (vec ? 4 : 1))
-template <int DMAX, int NT>
+template <int DMAX, int NT, bool DCONT>
 __device__ __forceinline__ void wdy_issue(const WParams& p, int gr0, int co0, int tid, float4* v) {
+  if constexpr (DCONT) {
+    // COB == CO, DP == COB, CO % 4 == 0: the tile's DY rows are one contiguous float4 run
+    const int cpd = p.CO >> 2;
+    const int total = p.TR * p.OW * cpd;
+    const long lim = ((long)p.B * p.OH * p.OW - (long)gr0 * p.OW) * cpd;  // items left in the tensor
+    const float4* src = reinterpret_cast<const float4*>(p.dy + (size_t)gr0 * p.OW * p.CO);
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) {
+      const int e = tid + i * NT;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < total && e < lim) t = src[e];
+      v[i] = t;
+    }
+    return;
+  }
   const int cpd = p.dvec ? (p.COB >> 2) : p.COB;
   const int total = p.slots * cpd;
   const long total_pix = (long)p.B * p.OH * p.OW;
@@ -201,9 +217,21 @@ __device__ __forceinline__ void wdy_issue(const WParams& p, int gr0, int co0, in
   }
 }
 
-template <int DMAX, int NT>
+template <int DMAX, int NT, bool DCONT>
 __device__ __forceinline__ void wdy_commit(const WParams& p, int tid, const float4* v, float* dyl,
                                            float4& bsum) {
+  if constexpr (DCONT) {
+    const int total = p.slots * (p.CO >> 2);
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) {
+      const int e = tid + i * NT;
+      if (e < total) {
+        bsum.x += v[i].x; bsum.y += v[i].y; bsum.z += v[i].z; bsum.w += v[i].w;
+        reinterpret_cast<float4*>(dyl)[e] = v[i];
+      }
+    }
+    return;
+  }
   const int cpd = p.dvec ? (p.COB >> 2) : p.COB;
   const int total = p.slots * cpd;
 #pragma unroll
@@ -220,7 +248,18 @@ __device__ __forceinline__ void wdy_commit(const WParams& p, int tid, const floa
   }
 }
 
-template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT>
+#ifdef ODIN_SIM
+#define W_STAMP(k) ((void)0)
+#else
+#define W_STAMP(k)                                                                       \
+  do {                                                                                   \
+    if (p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 &&  \
+        threadIdx.x == 0 && stamp_i < 60)                                                \
+      p.stamps[stamp_i++] = ((long long)(k) << 56) | (long long)(clock64() & 0xFFFFFFFFFFFFFFll); \
+  } while (0)
+#endif
+
+template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT, bool PVEC, bool DCONT>
 __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
@@ -237,6 +276,9 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   const int n_wt = p.nrt * p.ncot;
   const int n_bias = (p.bias_mode == 1 && blockIdx.y == 0) ? p.ncot : 0;
   const int n_tot = n_wt + n_bias;
+  int stamp_i = 0;
+  (void)stamp_i;
+  W_STAMP(1);
   const bool pipelined = p.pipelined != 0;
   const WLane<KMAX> WL = wlane_init<KMAX>(p, lane, cib);
 
@@ -287,39 +329,43 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   if (pipelined && tile < p.n_tiles) {
     const int gr0 = tile * p.TR;
     const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
-    wpatch_issue<KMAX, RPWMAX, FLAT>(p, WL, wave, tid, 0, b0, oh0 * p.S - p.pt, ci0, cib, pf);
-    wdy_issue<DMAX, NT>(p, gr0, co0, tid, df);
+    wpatch_issue<KMAX, RPWMAX, FLAT, PVEC>(p, WL, wave, tid, 0, b0, oh0 * p.S - p.pt, ci0, cib, pf);
+    wdy_issue<DMAX, NT, DCONT>(p, gr0, co0, tid, df);
   }
 
+  W_STAMP(3);
   for (; tile < p.n_tiles; tile += gridDim.x) {
+    W_STAMP(4);
     const int gr0 = tile * p.TR;
     const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
     const int ih_lo = oh0 * p.S - p.pt;
     __syncthreads();
     if (pipelined) {
-      wpatch_commit<KMAX, RPWMAX, FLAT>(p, WL, wave, tid, 0, pf, patch);
-      wdy_commit<DMAX, NT>(p, tid, df, dyl, bsum4);
+      wpatch_commit<KMAX, RPWMAX, FLAT, PVEC>(p, WL, wave, tid, 0, pf, patch);
+      wdy_commit<DMAX, NT, DCONT>(p, tid, df, dyl, bsum4);
       __syncthreads();
+      W_STAMP(5);
       const int nt = tile + gridDim.x;
       if (nt < p.n_tiles) {
         const int g2 = nt * p.TR;
         const int b2 = g2 / p.OH, o2 = g2 - b2 * p.OH;
-        wpatch_issue<KMAX, RPWMAX, FLAT>(p, WL, wave, tid, 0, b2, o2 * p.S - p.pt, ci0, cib, pf);
-        wdy_issue<DMAX, NT>(p, g2, co0, tid, df);
+        wpatch_issue<KMAX, RPWMAX, FLAT, PVEC>(p, WL, wave, tid, 0, b2, o2 * p.S - p.pt, ci0, cib, pf);
+        wdy_issue<DMAX, NT, DCONT>(p, g2, co0, tid, df);
       }
     } else {
       for (int bt = 0; bt < p.n_batches; ++bt) {
-        wpatch_issue<KMAX, RPWMAX, FLAT>(p, WL, wave, tid, bt, b0, ih_lo, ci0, cib, pf);
-        wpatch_commit<KMAX, RPWMAX, FLAT>(p, WL, wave, tid, bt, pf, patch);
+        wpatch_issue<KMAX, RPWMAX, FLAT, PVEC>(p, WL, wave, tid, bt, b0, ih_lo, ci0, cib, pf);
+        wpatch_commit<KMAX, RPWMAX, FLAT, PVEC>(p, WL, wave, tid, bt, pf, patch);
       }
       const int cpd = p.dvec ? (p.COB >> 2) : p.COB;
       for (int e0 = 0; e0 < p.slots * cpd; e0 += NT * DMAX) {
         // DY rows in batches of DMAX items per thread (item index = (tid + e0) + i*NT)
-        wdy_issue<DMAX, NT>(p, gr0, co0, tid + e0, df);
-        wdy_commit<DMAX, NT>(p, tid + e0, df, dyl, bsum4);
+        wdy_issue<DMAX, NT, DCONT>(p, gr0, co0, tid + e0, df);
+        wdy_commit<DMAX, NT, DCONT>(p, tid + e0, df, dyl, bsum4);
       }
       __syncthreads();
     }
+    W_STAMP(6);
     const int npairs = p.slots >> 1;
     // two-stage register pipeline over pixel pairs: operands of pair kp+1 are read from
     // LDS while the MFMAs of pair kp execute
@@ -400,6 +446,7 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     }
   }
 
+  W_STAMP(8);
   // ---- write this workgroup's partial tiles into its slab row ----
   float* row = p.slab + (size_t)blockIdx.x * p.slab_stride;
 #pragma unroll
@@ -486,7 +533,7 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
       const bool flat0 = (p.PW == 1 && p.NRI == 1);
       if (!flat0 && (long)p.PW * (pv ? CIB / 4 : CIB) > 64 * 9) continue;  // <= 9 items per lane per row
       long pf = ((long)p.NIMG * p.NRI * p.PW * P + 3) & ~3L;
-      int DP = COB + 4;
+      int DP = (COB == p.CO && (p.CO & 3) == 0) ? COB : COB + 4;
       long df = (long)(p.slots + 4) * DP;
       if (pf + df + p.slots + 16 > budget) continue;
       p.CIB = CIB; p.COB = COB; p.P = P; p.DP = DP;
@@ -511,8 +558,10 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
   return false;
 }
 
-template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT = false>
-int launch_winst(WParams& p, dim3 grid, size_t lds, void* stream) {
+long long* g_wstamps = nullptr;
+
+template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT, bool PVEC, bool DCONT>
+int launch_winst2(WParams& p, dim3 grid, size_t lds, void* stream) {
   const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
   const int ditems = p.slots * (p.dvec ? p.COB / 4 : p.COB);
   if (FLAT) {
@@ -526,13 +575,22 @@ int launch_winst(WParams& p, dim3 grid, size_t lds, void* stream) {
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT>), grid, dim3(NW_W * 64), lds, stream, p);
+  ODIN_LAUNCH((wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT>), grid, dim3(NW_W * 64), lds, stream, p);
   return odin_check_launch("wgrad");
+}
+
+// fast variant (16-byte patch items, contiguous DY) when the shape allows, generic otherwise
+template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT = false>
+int launch_winst(WParams& p, dim3 grid, size_t lds, void* stream) {
+  const bool dcont = p.dvec && p.COB == p.CO && p.DP == p.COB;
+  if (p.pvec && dcont) return launch_winst2<TNACC, KMAX, RPWMAX, DMAX, FLAT, true, true>(p, grid, lds, stream);
+  if (p.pvec) return launch_winst2<TNACC, KMAX, RPWMAX, DMAX, FLAT, true, false>(p, grid, lds, stream);
+  return launch_winst2<TNACC, KMAX, RPWMAX, DMAX, FLAT, false, false>(p, grid, lds, stream);
 }
 
 int launch_wgrad(WParams& p, int* rows_out, void* stream) {
@@ -542,6 +600,7 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
   if (!plan_wgrad(p, &gx, &gy, &gz, &lds)) return odin_fail(-2, "wgrad: no tiling plan");
   if (rows_out) *rows_out = gx;
   if (p.slab == nullptr) return 0;  // dry run: planning only
+  p.stamps = g_wstamps;
   dim3 grid(gx, gy, gz);
   const int tiles_per_block = p.nrt * p.ncot + (p.bias_mode == 1 ? p.ncot : 0);
   const int nacc = (tiles_per_block + NW_W - 1) / NW_W;
@@ -637,5 +696,10 @@ extern "C" int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* s
     int rc = odin_check_launch("slab_reduce");
     if (rc) return rc;
   }
+  return 0;
+}
+
+extern "C" int odin_debug_set_wgrad_stamps(void* buf) {
+  g_wstamps = (long long*)buf;
   return 0;
 }

@@ -35,3 +35,28 @@ def run(kind, B, H, W, Ci, Co, K, S, act='elu'):
 run('deconv', 256, 32, 32, 32, 32, 4, 2)
 run('conv', 256, 32, 32, 32, 32, 4, 2)
 run('conv', 256, 1, 1, 128, 20, 1, 1, 'linear')
+
+
+def run_w(B, H, W, Ci, Co, K, S):
+  """deconv wgrad: x [B,H,W,Ci], dy [B,H*S,W*S,Co]"""
+  OH, OW = H * S, W * S
+  _, pt, _ = same_pads(OH, K, S); _, pl, _ = same_pads(OW, K, S)
+  d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, 'elu')
+  x = torch.randn(B, H, W, Ci, device=dev); g = torch.randn(B, OH, OW, Co, device=dev)
+  rows = C.c_int(0)
+  L.odin_deconv2d_wgrad(None, None, None, C.byref(rows), C.byref(d), None)
+  slab = torch.empty(rows.value, K * K * Co * Ci, device=dev)
+  st = torch.zeros(64, dtype=torch.int64, device=dev)
+  for it in range(3):
+    st.zero_()
+    L.odin_debug_set_wgrad_stamps(st.data_ptr())
+    L.odin_deconv2d_wgrad(x.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d), None)
+    torch.cuda.synchronize()
+  L.odin_debug_set_wgrad_stamps(None)
+  v = st.cpu().numpy(); v = v[v != 0]
+  ks, ts = (v >> 56), (v & ((1 << 56) - 1))
+  nm = {1: 'start', 3: 'prefetch0', 4: 'tile(mfma+top)', 5: 'commit+sync', 6: 'issue-next', 8: 'end'}
+  print(f'--- deconv wgrad B{B} {H}x{W}x{Ci}->{Co}: total {ts[-1]-ts[0]} cycles, rows {rows.value}')
+  for i in range(1, min(len(ks), 24)):
+    print(f'   {nm[int(ks[i])]:14s} +{ts[i]-ts[i-1]}')
+run_w(256, 32, 32, 32, 32, 4, 2)
