@@ -259,7 +259,10 @@ __device__ __forceinline__ void wdy_commit(const WParams& p, int tid, const floa
   } while (0)
 #endif
 
-template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT, bool PVEC, bool DCONT>
+// FAST: one output-channel tile per workgroup (all accumulators share the DY operand), every
+// accumulator row is a real weight row (no padding rows, no MFMA bias tile): the hot loop
+// is 1 DY read + TNACC patch reads + TNACC MFMAs per pixel pair.
+template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT, bool PVEC, bool DCONT, bool FAST>
 __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
@@ -381,10 +384,16 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
       auto load_next = [&](float* a_, float* b_) {
         const int base = (pslot < real_slots) ? pb : 0;
         const float* brow = dyl + (pslot + h) * p.DP;
+        if constexpr (FAST) {
+          b_[0] = brow[l31];
 #pragma unroll
-        for (int a = 0; a < TNACC; ++a) {
-          a_[a] = patch[base + lane_h + a_off[a]];
-          b_[a] = brow[b_off[a]];
+          for (int a = 0; a < TNACC; ++a) a_[a] = patch[base + lane_h + a_off[a]];
+        } else {
+#pragma unroll
+          for (int a = 0; a < TNACC; ++a) {
+            a_[a] = patch[base + lane_h + a_off[a]];
+            b_[a] = brow[b_off[a]];
+          }
         }
         pslot += 2;
         pc += 2;
@@ -396,28 +405,28 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
           if (prl == p.RPI) { prl = 0; ++pimg; pb = pimg * p.NRI * p.PW * p.P; }
         }
       };
+      auto mfma_all = [&](const float* a_, const float* b_) {
+        if constexpr (FAST) {
+#pragma unroll
+          for (int a = 0; a < TNACC; ++a) acc[a] = mfma32(a_[a], b_[0], acc[a]);
+        } else {
+#pragma unroll
+          for (int a = 0; a < TNACC; ++a)
+            acc[a] = mfma32(fmaf(a_[a], amul[a], aadd[a]), b_[a], acc[a]);
+        }
+#pragma unroll
+        for (int a = 0; a < TNACC; ++a) {
+          ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
+          ODIN_SCHED_GROUP(ODIN_SG_DSREAD, FAST ? 1 : 2);
+        }
+        ODIN_SCHED_FENCE();
+      };
       load_next(av[0], bv[0]);
       for (int kp = 0; kp < npairs; kp += 2) {
         load_next(av[1], bv[1]);
-#pragma unroll
-        for (int a = 0; a < TNACC; ++a)
-          acc[a] = mfma32(fmaf(av[0][a], amul[a], aadd[a]), bv[0][a], acc[a]);
-#pragma unroll
-        for (int a = 0; a < TNACC; ++a) {
-          ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
-          ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 2);
-        }
-        ODIN_SCHED_FENCE();
+        mfma_all(av[0], bv[0]);
         load_next(av[0], bv[0]);
-#pragma unroll
-        for (int a = 0; a < TNACC; ++a)
-          acc[a] = mfma32(fmaf(av[1][a], amul[a], aadd[a]), bv[1][a], acc[a]);
-#pragma unroll
-        for (int a = 0; a < TNACC; ++a) {
-          ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
-          ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 2);
-        }
-        ODIN_SCHED_FENCE();
+        mfma_all(av[1], bv[1]);
       }
     } else {
       auto load_pair = [&](int kp, int base, float* a_, float* b_) {
@@ -560,8 +569,8 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
 
 long long* g_wstamps = nullptr;
 
-template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT, bool PVEC, bool DCONT>
-int launch_winst2(WParams& p, dim3 grid, size_t lds, void* stream) {
+template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT, bool PVEC, bool DCONT, bool FAST>
+int launch_winst3(WParams& p, dim3 grid, size_t lds, void* stream) {
   const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
   const int ditems = p.slots * (p.dvec ? p.COB / 4 : p.COB);
   if (FLAT) {
@@ -575,13 +584,25 @@ int launch_winst2(WParams& p, dim3 grid, size_t lds, void* stream) {
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, FAST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT>), grid, dim3(NW_W * 64), lds, stream, p);
+  ODIN_LAUNCH((wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, FAST>), grid, dim3(NW_W * 64), lds, stream, p);
   return odin_check_launch("wgrad");
+}
+
+template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT, bool PVEC, bool DCONT>
+int launch_winst2(WParams& p, dim3 grid, size_t lds, void* stream) {
+  const int ntaps = p.KH * p.KW;
+  const bool rows_full = (p.CI % p.CIB == 0) && ((ntaps * p.CIB) % 32 == 0);
+  const bool all_used = (p.nrt * p.ncot) % NW_W == 0 && (p.nrt * p.ncot) / NW_W == TNACC;
+  if (PVEC && DCONT && !FLAT && p.ncot == 1 && p.bias_mode != 1 && rows_full && all_used &&
+      (p.OW & 1) == 0)
+    return launch_winst3<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, (PVEC && DCONT && !FLAT)>(
+        p, grid, lds, stream);
+  return launch_winst3<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, false>(p, grid, lds, stream);
 }
 
 // fast variant (16-byte patch items, contiguous DY) when the shape allows, generic otherwise
