@@ -547,7 +547,7 @@ __device__ __forceinline__ float sigmoid_g(float x) {
 
 // EPI: 3 = as 0 but with FLAT (Dense) staging; 0 = runtime activation / aux / channel masking; 1 = ELU, no aux, CO % 32 == 0
 // (forward of the elu stacks); 2 = linear, aux = ELU derivative, CO % 32 == 0 (data-gradients).
-template <int MODE, int NW, int TK, int TS, int TCIC, bool VEC, bool TAIL, int KMAX, int RPWMAX, int EPI>
+template <int MODE, int NW, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI>
 __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailParams tp) {
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
@@ -571,19 +571,21 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
 #pragma unroll
   for (int i = 0; i < 16; ++i) bsum[i] = 0.f;
   // fused-tail state
-  float w1r[TAIL ? 16 : 1][MAXC1], dw1[TAIL ? 16 : 1][MAXC1], db1[MAXC1], b1r[MAXC1];
+  // TAIL = number of 1x1 output maps evaluated by the fused tail (0: no tail)
+  constexpr int NC1 = TAIL > 0 ? TAIL : 1;
+  float w1r[TAIL ? 16 : 1][NC1], dw1[TAIL ? 16 : 1][NC1], db1[NC1], b1r[NC1];
   if (TAIL) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int n = 8 * (i >> 2) + 4 * h + (i & 3);
 #pragma unroll
-      for (int oc = 0; oc < MAXC1; ++oc) {
+      for (int oc = 0; oc < NC1; ++oc) {
         w1r[i][oc] = (oc < tp.C1 && n < p.CO) ? tp.w1[n * tp.C1 + oc] : 0.f;
         dw1[i][oc] = 0.f;
       }
     }
 #pragma unroll
-    for (int oc = 0; oc < MAXC1; ++oc) {
+    for (int oc = 0; oc < NC1; ++oc) {
       db1[oc] = 0.f;
       b1r[oc] = oc < tp.C1 ? tp.b1[oc] : 0.f;
     }
@@ -695,9 +697,9 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
       }
       if (TAIL) {
         // 1x1 conv: each pixel's 32 channels live in lanes (l31, h=0) and (l31, h=1)
-        float lg[MAXC1], dl[MAXC1];
+        float lg[NC1], dl[NC1];
 #pragma unroll
-        for (int oc = 0; oc < MAXC1; ++oc) {
+        for (int oc = 0; oc < NC1; ++oc) {
           float t = 0.f;
 #pragma unroll
           for (int i = 0; i < 16; ++i) t += v[i] * w1r[i][oc];
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
         }
         const float sc = tp.scale[0];
 #pragma unroll
-        for (int oc = 0; oc < MAXC1; ++oc) {
+        for (int oc = 0; oc < NC1; ++oc) {
           dl[oc] = 0.f;
           if (oc < tp.C1 && live) {
             const float x = tp.target[(size_t)s.opix * tp.C1 + oc];
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
         for (int i = 0; i < 16; ++i) {
           float g = 0.f;
 #pragma unroll
-          for (int oc = 0; oc < MAXC1; ++oc) {
+          for (int oc = 0; oc < NC1; ++oc) {
             g += dl[oc] * w1r[i][oc];
             dw1[i][oc] += v[i] * dl[oc];
           }
@@ -816,7 +818,7 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
 #pragma unroll
-        for (int oc = 0; oc < MAXC1; ++oc) {
+        for (int oc = 0; oc < NC1; ++oc) {
           float v = dw1[i][oc];
 #pragma unroll
           for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
         }
       }
 #pragma unroll
-      for (int oc = 0; oc < MAXC1; ++oc) {
+      for (int oc = 0; oc < NC1; ++oc) {
         float v = db1[oc];
 #pragma unroll
         for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -967,7 +969,7 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
 
 long long* g_stamps = nullptr;
 
-template <int MODE, int TK, int TS, int TCIC, bool VEC, bool TAIL, int KMAX, int RPWMAX, int EPI = 0>
+template <int MODE, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI = 0>
 int launch_inst(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* stream) {
   if (p.KI > KMAX) return odin_fail(-2, "gather_conv: patch row too long for this instance");
   const int rpw = (p.NIMG * p.NRI + NW_G - 1) / NW_G;
@@ -1022,48 +1024,50 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     tp = *tail;
     if (p.CO > 32 || tp.C1 > MAXC1 || p.NIMG != 1 || !p.vec)
       return odin_fail(-2, "bernoulli tail: needs Cout<=32, C1<=4, Cin%4==0 and one image per tile");
-    if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5 && epi == 1)
-      return launch_inst<MODE_T, 4, 2, 32, true, true, 5, 2, 1>(p, tp, grid, lds, stream);
+    if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5 && epi == 1 && tp.C1 == 1)
+      return launch_inst<MODE_T, 4, 2, 32, true, 1, 5, 2, 1>(p, tp, grid, lds, stream);
+    if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5 && epi == 1 && tp.C1 == 3)
+      return launch_inst<MODE_T, 4, 2, 32, true, 3, 5, 2, 1>(p, tp, grid, lds, stream);
     if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5)
-      return launch_inst<MODE_T, 4, 2, 32, true, true, 5, 2, 0>(p, tp, grid, lds, stream);
-    if (mode == MODE_T) return launch_inst<MODE_T, 0, 0, 0, true, true, GK, 2>(p, tp, grid, lds, stream);
-    return launch_inst<MODE_F, 0, 0, 0, true, true, GK, 2>(p, tp, grid, lds, stream);
+      return launch_inst<MODE_T, 4, 2, 32, true, 4, 5, 2, 0>(p, tp, grid, lds, stream);
+    if (mode == MODE_T) return launch_inst<MODE_T, 0, 0, 0, true, 4, GK, 2>(p, tp, grid, lds, stream);
+    return launch_inst<MODE_F, 0, 0, 0, true, 4, GK, 2>(p, tp, grid, lds, stream);
   }
   if (mode == MODE_F) {
     if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 5) {
-      if (epi == 1) return launch_inst<MODE_F, 4, 2, 32, true, false, 5, 5, 1>(p, tp, grid, lds, stream);
-      if (epi == 2) return launch_inst<MODE_F, 4, 2, 32, true, false, 5, 5, 2>(p, tp, grid, lds, stream);
-      return launch_inst<MODE_F, 4, 2, 32, true, false, 5, 5, 0>(p, tp, grid, lds, stream);
+      if (epi == 1) return launch_inst<MODE_F, 4, 2, 32, true, 0, 5, 5, 1>(p, tp, grid, lds, stream);
+      if (epi == 2) return launch_inst<MODE_F, 4, 2, 32, true, 0, 5, 5, 2>(p, tp, grid, lds, stream);
+      return launch_inst<MODE_F, 4, 2, 32, true, 0, 5, 5, 0>(p, tp, grid, lds, stream);
     }
     if (k4s2 && p.CIC == 32 && p.KI <= 9) {
-      if (epi == 2) return launch_inst<MODE_F, 4, 2, 32, true, false, 9, 3, 2>(p, tp, grid, lds, stream);
-      return launch_inst<MODE_F, 4, 2, 32, true, false, 9, 3, 0>(p, tp, grid, lds, stream);
+      if (epi == 2) return launch_inst<MODE_F, 4, 2, 32, true, 0, 9, 3, 2>(p, tp, grid, lds, stream);
+      return launch_inst<MODE_F, 4, 2, 32, true, 0, 9, 3, 0>(p, tp, grid, lds, stream);
     }
     if (k4s2 && p.CIC == 64 && p.KI <= 5) {
-      if (epi == 1) return launch_inst<MODE_F, 4, 2, 64, true, false, 5, 3, 1>(p, tp, grid, lds, stream);
-      if (epi == 2) return launch_inst<MODE_F, 4, 2, 64, true, false, 5, 3, 2>(p, tp, grid, lds, stream);
-      return launch_inst<MODE_F, 4, 2, 64, true, false, 5, 3, 0>(p, tp, grid, lds, stream);
+      if (epi == 1) return launch_inst<MODE_F, 4, 2, 64, true, 0, 5, 3, 1>(p, tp, grid, lds, stream);
+      if (epi == 2) return launch_inst<MODE_F, 4, 2, 64, true, 0, 5, 3, 2>(p, tp, grid, lds, stream);
+      return launch_inst<MODE_F, 4, 2, 64, true, 0, 5, 3, 0>(p, tp, grid, lds, stream);
     }
-    if (p.flat && p.vec) return launch_inst<MODE_F, 0, 0, 0, true, false, 2, 8, 3>(p, tp, grid, lds, stream);
-    if (p.flat) return launch_inst<MODE_F, 0, 0, 0, false, false, 2, 8, 3>(p, tp, grid, lds, stream);
-    if (p.vec && p.KI <= 2) return launch_inst<MODE_F, 0, 0, 0, true, false, 2, 8>(p, tp, grid, lds, stream);
-    if (p.vec) return launch_inst<MODE_F, 0, 0, 0, true, false, GK, 2>(p, tp, grid, lds, stream);
-    if (p.KI <= 2) return launch_inst<MODE_F, 0, 0, 0, false, false, 2, 8>(p, tp, grid, lds, stream);
-    return launch_inst<MODE_F, 0, 0, 0, false, false, GK, 2>(p, tp, grid, lds, stream);
+    if (p.flat && p.vec) return launch_inst<MODE_F, 0, 0, 0, true, 0, 2, 8, 3>(p, tp, grid, lds, stream);
+    if (p.flat) return launch_inst<MODE_F, 0, 0, 0, false, 0, 2, 8, 3>(p, tp, grid, lds, stream);
+    if (p.vec && p.KI <= 2) return launch_inst<MODE_F, 0, 0, 0, true, 0, 2, 8>(p, tp, grid, lds, stream);
+    if (p.vec) return launch_inst<MODE_F, 0, 0, 0, true, 0, GK, 2>(p, tp, grid, lds, stream);
+    if (p.KI <= 2) return launch_inst<MODE_F, 0, 0, 0, false, 0, 2, 8>(p, tp, grid, lds, stream);
+    return launch_inst<MODE_F, 0, 0, 0, false, 0, GK, 2>(p, tp, grid, lds, stream);
   }
   if (k4s2 && p.CIC == 32 && p.KI <= 5) {
-    if (epi == 1) return launch_inst<MODE_T, 4, 2, 32, true, false, 5, 2, 1>(p, tp, grid, lds, stream);
-    if (epi == 2) return launch_inst<MODE_T, 4, 2, 32, true, false, 5, 2, 2>(p, tp, grid, lds, stream);
-    return launch_inst<MODE_T, 4, 2, 32, true, false, 5, 2, 0>(p, tp, grid, lds, stream);
+    if (epi == 1) return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 2, 1>(p, tp, grid, lds, stream);
+    if (epi == 2) return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 2, 2>(p, tp, grid, lds, stream);
+    return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 2, 0>(p, tp, grid, lds, stream);
   }
   if (k4s2 && p.CIC == 64 && p.KI <= 5) {
-    if (epi == 1) return launch_inst<MODE_T, 4, 2, 64, true, false, 5, 2, 1>(p, tp, grid, lds, stream);
-    if (epi == 2) return launch_inst<MODE_T, 4, 2, 64, true, false, 5, 2, 2>(p, tp, grid, lds, stream);
-    return launch_inst<MODE_T, 4, 2, 64, true, false, 5, 2, 0>(p, tp, grid, lds, stream);
+    if (epi == 1) return launch_inst<MODE_T, 4, 2, 64, true, 0, 5, 2, 1>(p, tp, grid, lds, stream);
+    if (epi == 2) return launch_inst<MODE_T, 4, 2, 64, true, 0, 5, 2, 2>(p, tp, grid, lds, stream);
+    return launch_inst<MODE_T, 4, 2, 64, true, 0, 5, 2, 0>(p, tp, grid, lds, stream);
   }
-  if (p.vec && p.KI <= 2) return launch_inst<MODE_T, 0, 0, 0, true, false, 2, 8>(p, tp, grid, lds, stream);
-  if (p.vec) return launch_inst<MODE_T, 0, 0, 0, true, false, GK, 2>(p, tp, grid, lds, stream);
-  return launch_inst<MODE_T, 0, 0, 0, false, false, GK, 2>(p, tp, grid, lds, stream);
+  if (p.vec && p.KI <= 2) return launch_inst<MODE_T, 0, 0, 0, true, 0, 2, 8>(p, tp, grid, lds, stream);
+  if (p.vec) return launch_inst<MODE_T, 0, 0, 0, true, 0, GK, 2>(p, tp, grid, lds, stream);
+  return launch_inst<MODE_T, 0, 0, 0, false, 0, GK, 2>(p, tp, grid, lds, stream);
 }
 
 void fill_common(GParams& p, const odin_conv_desc* d) {
@@ -1083,6 +1087,7 @@ extern "C" int odin_max_slab_rows(void) { return ODIN_MAX_SLAB_BLOCKS; }
 // ---- Conv2D -------------------------------------------------------------------------
 extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                                const odin_conv_desc* d, void* stream) {
+  if (odin_smallc_applicable(d)) return odin_smallc_fwd(x, w, bias, y, d, stream);
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = y;

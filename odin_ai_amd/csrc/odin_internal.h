@@ -9,3 +9,10 @@
 int odin_fail(int code, const char* msg);
 int odin_check_launch(const char* what);
 int odin_num_cus();
+
+// first-layer (Cin <= 4) convolutions on the vector ALUs (smallc_conv.hip)
+bool odin_smallc_applicable(const odin_conv_desc* d);
+int odin_smallc_fwd(const float* x, const float* w, const float* bias, float* y,
+                    const odin_conv_desc* d, void* stream);
+int odin_smallc_wgrad(const float* x, const float* dy, float* slab, int* rows_out,
+                      const odin_conv_desc* d, void* stream);

@@ -1,0 +1,184 @@
+// smallc_conv.hip -- first-layer convolutions (Cin <= 4: grey / RGB images) forward and
+// weight-gradient.  These layers are HBM-bound (dSprites conv1: 0.27 GFLOP against 37 MB
+// of traffic at batch 256), far below the MFMA ridge, so they run on the vector ALUs with
+// perfectly coalesced 16-byte output stores instead of wasting 32-wide MFMA tiles on a
+// reduction depth of 16.  (Reference: first Conv2D of every get_networks encoder,
+// odin/networks/image_networks.py:244,463,679; `CenterAt0` :121-126 folded into the load.)
+#include "odin_device.h"
+#include "odin_internal.h"
+
+namespace {
+
+struct SCParams {
+  const float* x;
+  const float* w;     // [KH][KW][CI][CO]
+  const float* bias;
+  const float* dy;    // wgrad: [B,OH,OW,CO]
+  float* y;           // fwd out / wgrad slab
+  int B, H, W, CI, OH, OW, CO, KH, KW, S, pt, pl, act, center;
+  int pix_per_block, slab_stride;
+};
+
+// forward: thread = (output pixel, 4 consecutive output channels)
+__global__ __launch_bounds__(256) void smallc_fwd_kernel(SCParams p) {
+  ODIN_DYN_SMEM(float, wl);  // [KH*KW*CI][CO] + bias[CO]
+  const int K = p.KH * p.KW * p.CI;
+  for (int e = threadIdx.x; e < K * p.CO; e += 256) wl[e] = p.w[e];
+  for (int e = threadIdx.x; e < p.CO; e += 256) wl[K * p.CO + e] = p.bias ? p.bias[e] : 0.f;
+  __syncthreads();
+  const int cg = p.CO >> 2;  // channel groups per pixel
+  const long total = (long)p.B * p.OH * p.OW * cg;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int g4 = (int)(t % cg);
+    const long pix = t / cg;
+    const int ow = (int)(pix % p.OW);
+    const long r = pix / p.OW;
+    const int oh = (int)(r % p.OH), b = (int)(r / p.OH);
+    const float4 bb = *reinterpret_cast<const float4*>(wl + K * p.CO + 4 * g4);
+    float4 acc = bb;
+    for (int kh = 0; kh < p.KH; ++kh) {
+      const int ih = oh * p.S - p.pt + kh;
+      if (ih < 0 || ih >= p.H) continue;
+      for (int kw = 0; kw < p.KW; ++kw) {
+        const int iw = ow * p.S - p.pl + kw;
+        if (iw < 0 || iw >= p.W) continue;
+        const float* xp = p.x + (((size_t)b * p.H + ih) * p.W + iw) * p.CI;
+        const float* wp = wl + ((kh * p.KW + kw) * p.CI) * p.CO + 4 * g4;
+        for (int c = 0; c < p.CI; ++c) {
+          float xv = xp[c];
+          if (p.center) xv = 2.f * xv - 1.f;
+          const float4 wv = *reinterpret_cast<const float4*>(wp + c * p.CO);
+          acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);
+          acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+        }
+      }
+    }
+    acc.x = odin_act(p.act, acc.x); acc.y = odin_act(p.act, acc.y);
+    acc.z = odin_act(p.act, acc.z); acc.w = odin_act(p.act, acc.w);
+    *reinterpret_cast<float4*>(p.y + (size_t)pix * p.CO + 4 * g4) = acc;
+  }
+}
+
+// weight gradient.  Workgroup = 16 waves; a wave owns 64/CW pixels per iteration (CW = 32
+// or 64 lanes per pixel = output channels), every lane keeps all TK = KH*KW*CI rows of dW for
+// its channel in registers; the x taps of a pixel are wave-broadcast loads.  Partial sums are
+// combined across the lane halves by a shuffle and across waves through LDS; one slab row
+// [TK*CO | CO] per workgroup.
+template <int TK>
+__global__ __launch_bounds__(1024) void smallc_wgrad_kernel(SCParams p) {
+  ODIN_DYN_SMEM(float, red);  // [16 waves][(TK + 1) * CO]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cw = p.CO <= 32 ? 32 : 64;
+  const int ppw = 64 / cw;                   // pixels per wave per iteration
+  const int co = lane % cw, sub = lane / cw;
+  const bool live = co < p.CO;
+  float acc[TK];
+#pragma unroll
+  for (int k = 0; k < TK; ++k) acc[k] = 0.f;
+  float bacc = 0.f;
+  const long total = (long)p.B * p.OH * p.OW;
+  const long p0 = (long)blockIdx.x * p.pix_per_block;
+  long p1 = p0 + p.pix_per_block;
+  if (p1 > total) p1 = total;
+  for (long pix = p0 + wave * ppw + sub; pix < p1; pix += 16 * ppw) {
+    const int ow = (int)(pix % p.OW);
+    const long r = pix / p.OW;
+    const int oh = (int)(r % p.OH), b = (int)(r / p.OH);
+    const float g = live ? p.dy[(size_t)pix * p.CO + co] : 0.f;
+    bacc += g;
+    const float* xb = p.x + (size_t)b * p.H * p.W * p.CI;
+#pragma unroll
+    for (int k = 0; k < TK; ++k) {
+      const int tap = k / p.CI, c = k - tap * p.CI;   // CI, KW are small runtime values
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      const int ih = oh * p.S - p.pt + kh, iw = ow * p.S - p.pl + kw;
+      float xv = 0.f;
+      if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+        xv = xb[((size_t)ih * p.W + iw) * p.CI + c];
+        if (p.center) xv = 2.f * xv - 1.f;
+      }
+      acc[k] = fmaf(xv, g, acc[k]);
+    }
+  }
+  // combine the pixel halves of a wave (CW = 32), then the 16 waves
+  if (cw == 32) {
+#pragma unroll
+    for (int k = 0; k < TK; ++k) acc[k] += __shfl_xor(acc[k], 32);
+    bacc += __shfl_xor(bacc, 32);
+  }
+  const int n_out = (TK + 1) * p.CO;
+  if (live && sub == 0) {
+#pragma unroll
+    for (int k = 0; k < TK; ++k) red[wave * n_out + k * p.CO + co] = acc[k];
+    red[wave * n_out + TK * p.CO + co] = bacc;
+  }
+  __syncthreads();
+  float* row = p.y + (size_t)blockIdx.x * p.slab_stride;
+  for (int e = tid; e < n_out; e += 1024) {
+    float t = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; ++w2) t += red[w2 * n_out + e];
+    row[e] = t;
+  }
+}
+
+}  // namespace
+
+bool odin_smallc_applicable(const odin_conv_desc* d) {
+  const int K = d->KH * d->KW * d->Cin;
+  return d->Cin <= 4 && (d->Cout % 4) == 0 && d->Cout <= 64 && (K == 16 || K == 25 || K == 48) &&
+         (size_t)16 * (K + 1) * d->Cout * 4 <= 150 * 1024;
+}
+
+static void sc_fill(SCParams& p, const odin_conv_desc* d) {
+  memset(&p, 0, sizeof(p));
+  p.B = d->B; p.H = d->H; p.W = d->W; p.CI = d->Cin; p.OH = d->OH; p.OW = d->OW; p.CO = d->Cout;
+  p.KH = d->KH; p.KW = d->KW; p.S = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
+  p.act = d->act; p.center = d->center;
+}
+
+int odin_smallc_fwd(const float* x, const float* w, const float* bias, float* y,
+                    const odin_conv_desc* d, void* stream) {
+  SCParams p;
+  sc_fill(p, d);
+  p.x = x; p.w = w; p.bias = bias; p.y = y;
+  const long total = (long)d->B * d->OH * d->OW * (d->Cout / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  size_t lds = (size_t)(d->KH * d->KW * d->Cin + 1) * d->Cout * 4;
+  ODIN_LAUNCH(smallc_fwd_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  return odin_check_launch("smallc_fwd");
+}
+
+int odin_smallc_wgrad(const float* x, const float* dy, float* slab, int* rows_out,
+                      const odin_conv_desc* d, void* stream) {
+  SCParams p;
+  sc_fill(p, d);
+  p.x = x; p.dy = dy; p.y = slab;
+  const long total = (long)d->B * d->OH * d->OW;
+  int rows = ODIN_MAX_SLAB_BLOCKS;
+  if (total < rows * 64L) rows = (int)((total + 63) / 64);
+  p.pix_per_block = (int)((total + rows - 1) / rows);
+  rows = (int)((total + p.pix_per_block - 1) / p.pix_per_block);
+  p.slab_stride = d->KH * d->KW * d->Cin * d->Cout + d->Cout;
+  if (rows_out) *rows_out = rows;
+  if (slab == nullptr) return 0;
+  const int K = d->KH * d->KW * d->Cin;
+  size_t lds = (size_t)16 * (K + 1) * d->Cout * 4;
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallc_wgrad_kernel<16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallc_wgrad_kernel<25>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallc_wgrad_kernel<48>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+#endif
+  if (K == 16) ODIN_LAUNCH(smallc_wgrad_kernel<16>, dim3(rows), dim3(1024), lds, stream, p);
+  else if (K == 25) ODIN_LAUNCH(smallc_wgrad_kernel<25>, dim3(rows), dim3(1024), lds, stream, p);
+  else ODIN_LAUNCH(smallc_wgrad_kernel<48>, dim3(rows), dim3(1024), lds, stream, p);
+  return odin_check_launch("smallc_wgrad");
+}
