@@ -27,13 +27,12 @@ __global__ __launch_bounds__(256) void smallc_fwd_kernel(SCParams p) {
   for (int e = threadIdx.x; e < p.CO; e += 256) wl[K * p.CO + e] = p.bias ? p.bias[e] : 0.f;
   __syncthreads();
   const int cg = p.CO >> 2;  // channel groups per pixel
-  const long total = (long)p.B * p.OH * p.OW * cg;
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-    const int g4 = (int)(t % cg);
-    const long pix = t / cg;
-    const int ow = (int)(pix % p.OW);
-    const long r = pix / p.OW;
-    const int oh = (int)(r % p.OH), b = (int)(r / p.OH);
+  const int total = p.B * p.OH * p.OW * cg;  // < 2^31 (checked on the host)
+  const int ohw = p.OH * p.OW;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+    const int pix = t / cg, g4 = t - pix * cg;
+    const int b = pix / ohw, rem = pix - b * ohw;
+    const int oh = rem / p.OW, ow = rem - oh * p.OW;
     const float4 bb = *reinterpret_cast<const float4*>(wl + K * p.CO + 4 * g4);
     float4 acc = bb;
     for (int kh = 0; kh < p.KH; ++kh) {
@@ -73,28 +72,34 @@ __global__ __launch_bounds__(1024) void smallc_wgrad_kernel(SCParams p) {
   const int co = lane % cw, sub = lane / cw;
   const bool live = co < p.CO;
   float acc[TK];
+  int tkh[TK], tkw[TK], tc[TK];  // tap decomposition, once per kernel (no divisions in the loop)
 #pragma unroll
-  for (int k = 0; k < TK; ++k) acc[k] = 0.f;
+  for (int k = 0; k < TK; ++k) {
+    acc[k] = 0.f;
+    const int tap = k / p.CI;
+    tc[k] = k - tap * p.CI;
+    tkh[k] = tap / p.KW;
+    tkw[k] = tap - tkh[k] * p.KW;
+  }
   float bacc = 0.f;
-  const long total = (long)p.B * p.OH * p.OW;
-  const long p0 = (long)blockIdx.x * p.pix_per_block;
-  long p1 = p0 + p.pix_per_block;
+  const int total = p.B * p.OH * p.OW;
+  const int p0 = blockIdx.x * p.pix_per_block;
+  int p1 = p0 + p.pix_per_block;
   if (p1 > total) p1 = total;
-  for (long pix = p0 + wave * ppw + sub; pix < p1; pix += 16 * ppw) {
-    const int ow = (int)(pix % p.OW);
-    const long r = pix / p.OW;
-    const int oh = (int)(r % p.OH), b = (int)(r / p.OH);
+  const int ohw = p.OH * p.OW;
+  for (int pix = p0 + wave * ppw + sub; pix < p1; pix += 16 * ppw) {
+    const int b = pix / ohw, rem = pix - b * ohw;
+    const int oh = rem / p.OW, ow = rem - oh * p.OW;
     const float g = live ? p.dy[(size_t)pix * p.CO + co] : 0.f;
     bacc += g;
     const float* xb = p.x + (size_t)b * p.H * p.W * p.CI;
+    const int ih0 = oh * p.S - p.pt, iw0 = ow * p.S - p.pl;
 #pragma unroll
     for (int k = 0; k < TK; ++k) {
-      const int tap = k / p.CI, c = k - tap * p.CI;   // CI, KW are small runtime values
-      const int kh = tap / p.KW, kw = tap - kh * p.KW;
-      const int ih = oh * p.S - p.pt + kh, iw = ow * p.S - p.pl + kw;
+      const int ih = ih0 + tkh[k], iw = iw0 + tkw[k];
       float xv = 0.f;
       if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-        xv = xb[((size_t)ih * p.W + iw) * p.CI + c];
+        xv = xb[(ih * p.W + iw) * p.CI + tc[k]];
         if (p.center) xv = 2.f * xv - 1.f;
       }
       acc[k] = fmaf(xv, g, acc[k]);
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(1024) void smallc_wgrad_kernel(SCParams p) {
 
 bool odin_smallc_applicable(const odin_conv_desc* d) {
   const int K = d->KH * d->KW * d->Cin;
+  if ((long)d->B * d->OH * d->OW * d->Cout >= (1L << 31)) return false;
   return d->Cin <= 4 && (d->Cout % 4) == 0 && d->Cout <= 64 && (K == 16 || K == 25 || K == 48) &&
          (size_t)16 * (K + 1) * d->Cout * 4 <= 150 * 1024;
 }

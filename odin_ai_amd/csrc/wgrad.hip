@@ -38,6 +38,7 @@ struct WParams {
   int slab_stride;
   int patch_floats, dy_floats;
   int pvec, dvec, KI, pipelined;
+  int dlog;             // log2(COB/4) when COB/4 is a power of two (fast DY staging), else -1
   int flat, n_batches;  // Dense: IN tile is one contiguous [NIMG, CIB] block
   long long* stamps;
   int bias_mode;  // 0 none, 1 extra MFMA tile with A = 1, 2 summed while staging DY
@@ -181,16 +182,18 @@ __device__ __forceinline__ void wpatch_commit(const WParams& p, const WLane<KMAX
 template <int DMAX, int NT, bool DCONT>
 __device__ __forceinline__ void wdy_issue(const WParams& p, int gr0, int co0, int tid, float4* v) {
   if constexpr (DCONT) {
-    // COB == CO, DP == COB, CO % 4 == 0: the tile's DY rows are one contiguous float4 run
-    const int cpd = p.CO >> 2;
+    // DP == COB, COB/4 a power of two: item e -> slot e >> lg, channel group e & (cpd-1);
+    // with COB == CO the tile's DY rows are one contiguous float4 run
+    const int lg = p.dlog, cpd = 1 << lg;
     const int total = p.TR * p.OW * cpd;
     const long lim = ((long)p.B * p.OH * p.OW - (long)gr0 * p.OW) * cpd;  // items left in the tensor
-    const float4* src = reinterpret_cast<const float4*>(p.dy + (size_t)gr0 * p.OW * p.CO);
+    const float* src0 = p.dy + (size_t)gr0 * p.OW * p.CO + co0;
 #pragma unroll
     for (int i = 0; i < DMAX; ++i) {
       const int e = tid + i * NT;
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < total && e < lim) t = src[e];
+      if (e < total && e < lim)
+        t = *reinterpret_cast<const float4*>(src0 + (size_t)(e >> lg) * p.CO + ((e & (cpd - 1)) << 2));
       v[i] = t;
     }
     return;
@@ -221,7 +224,7 @@ template <int DMAX, int NT, bool DCONT>
 __device__ __forceinline__ void wdy_commit(const WParams& p, int tid, const float4* v, float* dyl,
                                            float4& bsum) {
   if constexpr (DCONT) {
-    const int total = p.slots * (p.CO >> 2);
+    const int total = p.slots << p.dlog;
 #pragma unroll
     for (int i = 0; i < DMAX; ++i) {
       const int e = tid + i * NT;
@@ -522,7 +525,9 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
   const int ntaps = p.KH * p.KW;
   const int budget = (160 * 1024 - 2048) / 4;
   const int co32 = (p.CO + 31) / 32 * 32;
-  int cob_c[2] = {co32 < 64 ? co32 : 64, 32};
+  // 32 output channels per workgroup first: all accumulators then share the DY operand
+  // (FAST loop); the IN patch is re-read once per channel block (L2-resident)
+  int cob_c[2] = {32, co32 < 64 ? co32 : 64};
   int cib_c[6] = {p.CI, 256, 128, 64, 32, 16};
   for (int ic = 0; ic < 2; ++ic) {
     int COB = cob_c[ic];
@@ -542,11 +547,15 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
       const bool flat0 = (p.PW == 1 && p.NRI == 1);
       if (!flat0 && (long)p.PW * (pv ? CIB / 4 : CIB) > 64 * 9) continue;  // <= 9 items per lane per row
       long pf = ((long)p.NIMG * p.NRI * p.PW * P + 3) & ~3L;
-      int DP = (COB == p.CO && (p.CO & 3) == 0) ? COB : COB + 4;
+      const int cpd0 = COB / 4;
+      const bool pow2 = ((p.CO & 3) == 0) && (cpd0 & (cpd0 - 1)) == 0;
+      int DP = pow2 ? COB : COB + 4;
       long df = (long)(p.slots + 4) * DP;
       if (pf + df + p.slots + 16 > budget) continue;
       p.CIB = CIB; p.COB = COB; p.P = P; p.DP = DP;
       p.nrt = nrt; p.ncot = ncot;
+      p.dlog = -1;
+      if (pow2) { int l = 0; while ((1 << l) < cpd0) ++l; p.dlog = l; }
       p.bias_mode = bmode;
       p.pvec = pv ? 1 : 0;
       p.dvec = (((p.CO & 3) == 0) && ((COB & 3) == 0)) ? 1 : 0;
@@ -608,7 +617,7 @@ int launch_winst2(WParams& p, dim3 grid, size_t lds, void* stream) {
 // fast variant (16-byte patch items, contiguous DY) when the shape allows, generic otherwise
 template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT = false>
 int launch_winst(WParams& p, dim3 grid, size_t lds, void* stream) {
-  const bool dcont = p.dvec && p.COB == p.CO && p.DP == p.COB;
+  const bool dcont = p.dvec && p.dlog >= 0 && p.DP == p.COB;
   if (p.pvec && dcont) return launch_winst2<TNACC, KMAX, RPWMAX, DMAX, FLAT, true, true>(p, grid, lds, stream);
   if (p.pvec) return launch_winst2<TNACC, KMAX, RPWMAX, DMAX, FLAT, true, false>(p, grid, lds, stream);
   return launch_winst2<TNACC, KMAX, RPWMAX, DMAX, FLAT, false, false>(p, grid, lds, stream);
