@@ -72,14 +72,20 @@ __global__ __launch_bounds__(1024) void smallc_wgrad_kernel(SCParams p) {
   const int co = lane % cw, sub = lane / cw;
   const bool live = co < p.CO;
   float acc[TK];
-  int tkh[TK], tkw[TK], tc[TK];  // tap decomposition, once per kernel (no divisions in the loop)
 #pragma unroll
-  for (int k = 0; k < TK; ++k) {
-    acc[k] = 0.f;
+  for (int k = 0; k < TK; ++k) acc[k] = 0.f;
+  // cooperative tap loads: lane j of a pixel's lane group fetches tap j (+cw, ...) of that
+  // pixel with ONE vector load; the taps are then broadcast inside the group by shuffles
+  // (16 broadcast loads per pixel would saturate the vector-memory issue rate).
+  constexpr int NL = (TK + 31) / 32;  // loads per lane (cw >= 32)
+  int lkh[NL], lkw[NL], lc[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int k = co + j * cw;
     const int tap = k / p.CI;
-    tc[k] = k - tap * p.CI;
-    tkh[k] = tap / p.KW;
-    tkw[k] = tap - tkh[k] * p.KW;
+    lc[j] = k - tap * p.CI;
+    lkh[j] = (k < TK) ? tap / p.KW : -100000;
+    lkw[j] = tap % p.KW;
   }
   float bacc = 0.f;
   const int total = p.B * p.OH * p.OW;
@@ -87,21 +93,34 @@ __global__ __launch_bounds__(1024) void smallc_wgrad_kernel(SCParams p) {
   int p1 = p0 + p.pix_per_block;
   if (p1 > total) p1 = total;
   const int ohw = p.OH * p.OW;
-  for (int pix = p0 + wave * ppw + sub; pix < p1; pix += 16 * ppw) {
-    const int b = pix / ohw, rem = pix - b * ohw;
+  const int lbase = lane - co;  // first lane of this pixel's group
+  const int n_it = (p1 - p0 + 16 * ppw - 1) / (16 * ppw);
+  for (int it = 0; it < n_it; ++it) {  // uniform trip count: shuffles need every lane
+    const int pix = p0 + (it * 16 + wave) * ppw + sub;
+    const bool pv = pix < p1;
+    const int pc = pv ? pix : p0;
+    const int b = pc / ohw, rem = pc - b * ohw;
     const int oh = rem / p.OW, ow = rem - oh * p.OW;
-    const float g = live ? p.dy[(size_t)pix * p.CO + co] : 0.f;
+    const float g = (live && pv) ? p.dy[(size_t)pc * p.CO + co] : 0.f;
     bacc += g;
     const float* xb = p.x + (size_t)b * p.H * p.W * p.CI;
     const int ih0 = oh * p.S - p.pt, iw0 = ow * p.S - p.pl;
+    float xt[NL];
 #pragma unroll
-    for (int k = 0; k < TK; ++k) {
-      const int ih = ih0 + tkh[k], iw = iw0 + tkw[k];
+    for (int j = 0; j < NL; ++j) {
+      const int ih = ih0 + lkh[j], iw = iw0 + lkw[j];
       float xv = 0.f;
       if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-        xv = xb[(ih * p.W + iw) * p.CI + tc[k]];
+        xv = xb[(ih * p.W + iw) * p.CI + lc[j]];
         if (p.center) xv = 2.f * xv - 1.f;
       }
+      xt[j] = xv;
+    }
+#pragma unroll
+    for (int k = 0; k < TK; ++k) {
+      // tap k lives in load k / cw of lane lbase + k % cw; cw is 32 or 64
+      const float xv = (cw == 32) ? __shfl(xt[k >> 5 < NL ? k >> 5 : 0], lbase + (k & 31))
+                                  : __shfl(xt[0], lbase + (k & 63));
       acc[k] = fmaf(xv, g, acc[k]);
     }
   }

@@ -40,6 +40,8 @@ def close(a, b, tol=2e-5):
 CONV_CASES = [
     # B, H, W, Cin, Cout, K, S, act, center
     (2, 16, 16, 1, 32, 4, 2, 'elu', True),
+    (2, 16, 16, 3, 32, 4, 2, 'elu', True),     # small-Cin VALU kernels, 48 taps
+    (3, 12, 12, 1, 64, 5, 1, 'elu', False),    # small-Cin VALU kernels, 25 taps, 64 lanes per pixel
     (3, 8, 8, 32, 32, 4, 2, 'elu', False),
     (2, 8, 8, 32, 64, 4, 2, 'elu', False),
     (5, 4, 4, 64, 64, 4, 2, 'linear', False),
