@@ -402,10 +402,10 @@ struct TapAddr {
   const float* wp;
 };
 
-template <int MODE, int TK, int TS, int TCIC>
+template <int MODE, int TK, int TS, int TCIC, int SG>
 __device__ __forceinline__ TapAddr tap_addr(const GParams& p, const float* patch, const float* wl,
                                             const Slot& s, int l31, int h, int step) {
-  constexpr int SUB = TCIC / 32;            // 32-channel sub-steps per tap
+  constexpr int SUB = TCIC / (2 * SG);      // sub-steps (2*SG channels each) per tap
   constexpr int NJ = (MODE == MODE_F) ? TK : TK / TS;
   constexpr int WP = 32;
   constexpr int P = TCIC + 1;
@@ -420,53 +420,53 @@ __device__ __forceinline__ TapAddr tap_addr(const GParams& p, const float* patch
     wt = (s.kh0 + TS * jh) * TK + (s.kw0 + TS * jw);
   }
   TapAddr t;
-  t.ap = patch + s.base + tapoff + h + sub * 32;
-  t.wp = wl + (wt * TCIC + h + sub * 32) * WP + l31;
+  t.ap = patch + s.base + tapoff + h + sub * (2 * SG);
+  t.wp = wl + (wt * TCIC + h + sub * (2 * SG)) * WP + l31;
   return t;
 }
 
-template <int MODE, int TK, int TS, int TCIC>
+template <int MODE, int TK, int TS, int TCIC, int SG = 16>
 __device__ __forceinline__ f32x16 mtile_compute(const GParams& p, const float* patch,
                                                 const float* wl, const Slot& s, int l31, int h,
                                                 f32x16 acc) {
   if constexpr (TCIC != 0) {
     static_assert(TCIC % 32 == 0 && TK != 0 && TS != 0 && TK % TS == 0, "specialised shape");
     constexpr int NJ = (MODE == MODE_F) ? TK : TK / TS;
-    constexpr int NSTEP = NJ * NJ * (TCIC / 32);
+    constexpr int NSTEP = NJ * NJ * (TCIC / (2 * SG));
     constexpr int WP = 32;
-    float a0[16], b0[16], a1[16], b1[16];
+    float a0[SG], b0[SG], a1[SG], b1[SG];
     {
-      TapAddr t = tap_addr<MODE, TK, TS, TCIC>(p, patch, wl, s, l31, h, 0);
+      TapAddr t = tap_addr<MODE, TK, TS, TCIC, SG>(p, patch, wl, s, l31, h, 0);
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { a0[u] = t.wp[u * 2 * WP]; b0[u] = t.ap[2 * u]; }
+      for (int u = 0; u < SG; ++u) { a0[u] = t.wp[u * 2 * WP]; b0[u] = t.ap[2 * u]; }
     }
     ODIN_SCHED_FENCE();
 #pragma unroll
     for (int st = 0; st < NSTEP; st += 2) {
       if (st + 1 < NSTEP) {
-        TapAddr t = tap_addr<MODE, TK, TS, TCIC>(p, patch, wl, s, l31, h, st + 1);
+        TapAddr t = tap_addr<MODE, TK, TS, TCIC, SG>(p, patch, wl, s, l31, h, st + 1);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { a1[u] = t.wp[u * 2 * WP]; b1[u] = t.ap[2 * u]; }
+        for (int u = 0; u < SG; ++u) { a1[u] = t.wp[u * 2 * WP]; b1[u] = t.ap[2 * u]; }
       }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) acc = mfma32(a0[u], b0[u], acc);
+      for (int u = 0; u < SG; ++u) acc = mfma32(a0[u], b0[u], acc);
       // issue the next step's LDS reads in the shadow of this step's MFMAs
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < SG; ++u) {
         ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
         ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 2);
       }
       ODIN_SCHED_FENCE();
       if (st + 2 < NSTEP) {
-        TapAddr t = tap_addr<MODE, TK, TS, TCIC>(p, patch, wl, s, l31, h, st + 2);
+        TapAddr t = tap_addr<MODE, TK, TS, TCIC, SG>(p, patch, wl, s, l31, h, st + 2);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { a0[u] = t.wp[u * 2 * WP]; b0[u] = t.ap[2 * u]; }
+        for (int u = 0; u < SG; ++u) { a0[u] = t.wp[u * 2 * WP]; b0[u] = t.ap[2 * u]; }
       }
       if (st + 1 < NSTEP) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc = mfma32(a1[u], b1[u], acc);
+        for (int u = 0; u < SG; ++u) acc = mfma32(a1[u], b1[u], acc);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < SG; ++u) {
           ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
           ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 2);
         }
@@ -547,8 +547,9 @@ __device__ __forceinline__ float sigmoid_g(float x) {
 
 // EPI: 3 = as 0 but with FLAT (Dense) staging; 0 = runtime activation / aux / channel masking; 1 = ELU, no aux, CO % 32 == 0
 // (forward of the elu stacks); 2 = linear, aux = ELU derivative, CO % 32 == 0 (data-gradients).
-template <int MODE, int NW, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI>
-__global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailParams tp) {
+template <int MODE, int NW, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI, int NMT>
+__global__ __launch_bounds__(NW * 64, (MODE == MODE_T && TK == 4 && TCIC == 32 && RPWMAX == 1) ? 2 : 1)
+void gather_conv_kernel(GParams p, TailParams tp) {
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
   float* wl = smem + p.patch_floats;
@@ -634,8 +635,9 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
         stage_issue<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, 0, b2, ih2, 0, pf);
       }
       ODIN_STAMP(6);
-      if (mt0 < p.MT) acc0 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s0, l31, h, acc0);
-      if (mt1 < p.MT) acc1 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s1, l31, h, acc1);
+      constexpr int SGK = (TAIL > 0 && RPWMAX == 1) ? 8 : 16;
+      if (mt0 < p.MT) acc0 = mtile_compute<MODE, TK, TS, TCIC, SGK>(p, patch, wl, s0, l31, h, acc0);
+      if (NMT > 1 && mt1 < p.MT) acc1 = mtile_compute<MODE, TK, TS, TCIC, SGK>(p, patch, wl, s1, l31, h, acc1);
     } else {
       for (int ch = 0; ch < p.n_chunks; ++ch) {
         const int c0 = ch * p.CIC;
@@ -647,14 +649,14 @@ __global__ __launch_bounds__(NW * 64) void gather_conv_kernel(GParams p, TailPar
         if (!p.w_resident) stage_weights(p, wl, c0, n0, tid, NT);
         __syncthreads();
         if (mt0 < p.MT) acc0 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s0, l31, h, acc0);
-        if (mt1 < p.MT) acc1 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s1, l31, h, acc1);
+        if (NMT > 1 && mt1 < p.MT) acc1 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s1, l31, h, acc1);
       }
     }
     ODIN_STAMP(7);
     // ---- epilogue: bias + activation (+ activation-gradient multiply) + NHWC store ----
     float llk_lane = 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < NMT; ++mi) {
       const int mt = mi == 0 ? mt0 : mt1;
       const Slot& s = mi == 0 ? s0 : s1;
       const f32x16& acc = mi == 0 ? acc0 : acc1;
@@ -969,8 +971,8 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
 
 long long* g_stamps = nullptr;
 
-template <int MODE, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI = 0>
-int launch_inst(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* stream) {
+template <int MODE, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI, int NMT>
+int launch_inst2(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* stream) {
   if (p.KI > KMAX) return odin_fail(-2, "gather_conv: patch row too long for this instance");
   const int rpw = (p.NIMG * p.NRI + NW_G - 1) / NW_G;
   if (EPI == 3) {
@@ -985,14 +987,22 @@ int launch_inst(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* s
   if (!attr_done) {
     (void)hipFuncSetAttribute(
         reinterpret_cast<const void*>(
-            &gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI>),
+            &gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, NMT>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI>), grid,
+  ODIN_LAUNCH((gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, NMT>), grid,
               dim3(NW_G * 64), lds, stream, p, tp);
   return odin_check_launch("gather_conv");
+}
+
+template <int MODE, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI = 0>
+int launch_inst(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* stream) {
+  // one M-tile per wave (tiles of <= 128 pixels) drops the second accumulator and epilogue
+  if (p.MT <= NW_G)
+    return launch_inst2<MODE, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, 1>(p, tp, grid, lds, stream);
+  return launch_inst2<MODE, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, 2>(p, tp, grid, lds, stream);
 }
 
 int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_out = nullptr,
@@ -1055,6 +1065,10 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     if (p.KI <= 2) return launch_inst<MODE_F, 0, 0, 0, false, 0, 2, 8>(p, tp, grid, lds, stream);
     return launch_inst<MODE_F, 0, 0, 0, false, 0, GK, 2>(p, tp, grid, lds, stream);
   }
+  if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 1 && !getenv("ODIN_NO2WG"))
+    return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 1, 1>(p, tp, grid, lds, stream);
+  if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 2 && !getenv("ODIN_NO2WG"))
+    return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 1, 2>(p, tp, grid, lds, stream);
   if (k4s2 && p.CIC == 32 && p.KI <= 5) {
     if (epi == 1) return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 2, 1>(p, tp, grid, lds, stream);
     if (epi == 2) return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 2, 2>(p, tp, grid, lds, stream);
