@@ -49,6 +49,7 @@ struct GParams {
   int CIC, n_chunks, WP, w_resident;
   int patch_floats, MT, MTP, SPP;  // M-tiles total / per phase, slots per phase
   int vec, KI, pipelined;          // 16-byte staging items, items per lane per patch row
+  int KS;                          // intra-workgroup split of the reduction (1, 2 or 4 waves per M-tile)
   int n_batches;                   // staging batches per patch (1 when pipelined)
   int flat;                        // 1x1 images (Dense): the patch is one contiguous [NIMG, CIC] block
   long long* stamps;  // diagnostic: s_memtime stamps of workgroup 0 / wave 0 (env ODIN_STAMPS)
@@ -428,7 +429,7 @@ __device__ __forceinline__ TapAddr tap_addr(const GParams& p, const float* patch
 template <int MODE, int TK, int TS, int TCIC, int SG = 16>
 __device__ __forceinline__ f32x16 mtile_compute(const GParams& p, const float* patch,
                                                 const float* wl, const Slot& s, int l31, int h,
-                                                f32x16 acc) {
+                                                f32x16 acc, int kc0 = 0, int kc1 = -1) {
   if constexpr (TCIC != 0) {
     static_assert(TCIC % 32 == 0 && TK != 0 && TS != 0 && TK % TS == 0, "specialised shape");
     constexpr int NJ = (MODE == MODE_F) ? TK : TK / TS;
@@ -491,15 +492,16 @@ __device__ __forceinline__ f32x16 mtile_compute(const GParams& p, const float* p
         }
         const float* ap = patch + s.base + tapoff + h;
         const float* wp = wl + (wt * CIC + h) * WP + l31;
-        int c = 0;
-        for (; c + 16 <= CIC; c += 16) {
+        int c = kc0;
+        const int cend = kc1 < 0 ? CIC : kc1;
+        for (; c + 16 <= cend; c += 16) {
           float a[8], b[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) { a[u] = wp[(c + 2 * u) * WP]; b[u] = ap[c + 2 * u]; }
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc = mfma32(a[u], b[u], acc);
         }
-        for (; c < CIC; c += 2) acc = mfma32(wp[c * WP], ap[c], acc);
+        for (; c < cend; c += 2) acc = mfma32(wp[c * WP], ap[c], acc);
       }
     }
     return acc;
@@ -593,7 +595,12 @@ void gather_conv_kernel(GParams p, TailParams tp) {
   }
 
   // tile-invariant lane state: slot geometry, bias of this lane's 16 output channels
-  const int mt0 = wave, mt1 = wave + NW;
+  // KS > 1: KS waves share one M-tile and split the reduction channels (small-M layers)
+  const int KS = p.KS;
+  const int kpart = (KS > 1) ? wave % KS : 0;
+  const int kc0 = (KS > 1) ? kpart * (p.CIC / KS) : 0;
+  const int kc1 = (KS > 1) ? kc0 + p.CIC / KS : -1;
+  const int mt0 = (KS > 1) ? wave / KS : wave, mt1 = wave + NW;
   Slot s0 = slot_geometry<MODE>(p, mt0 < p.MT ? mt0 : 0, l31);
   Slot s1 = slot_geometry<MODE>(p, mt1 < p.MT ? mt1 : 0, l31);
   float bias_r[16];
@@ -636,7 +643,7 @@ void gather_conv_kernel(GParams p, TailParams tp) {
       }
       ODIN_STAMP(6);
       constexpr int SGK = (TAIL > 0 && RPWMAX == 1) ? 8 : 16;
-      if (mt0 < p.MT) acc0 = mtile_compute<MODE, TK, TS, TCIC, SGK>(p, patch, wl, s0, l31, h, acc0);
+      if (mt0 < p.MT) acc0 = mtile_compute<MODE, TK, TS, TCIC, SGK>(p, patch, wl, s0, l31, h, acc0, kc0, kc1);
       if (NMT > 1 && mt1 < p.MT) acc1 = mtile_compute<MODE, TK, TS, TCIC, SGK>(p, patch, wl, s1, l31, h, acc1);
     } else {
       for (int ch = 0; ch < p.n_chunks; ++ch) {
@@ -648,11 +655,25 @@ void gather_conv_kernel(GParams p, TailParams tp) {
         }
         if (!p.w_resident) stage_weights(p, wl, c0, n0, tid, NT);
         __syncthreads();
-        if (mt0 < p.MT) acc0 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s0, l31, h, acc0);
+        if (mt0 < p.MT) acc0 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s0, l31, h, acc0, kc0, kc1);
         if (NMT > 1 && mt1 < p.MT) acc1 = mtile_compute<MODE, TK, TS, TCIC>(p, patch, wl, s1, l31, h, acc1);
       }
     }
     ODIN_STAMP(7);
+    if (TCIC == 0 && KS > 1) {
+      // combine the KS partial accumulators of each M-tile through LDS (patch area is free)
+      __syncthreads();
+      float* red = smem;  // [NW][16][64]
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc0[i];
+      __syncthreads();
+      if (kpart == 0) {
+        for (int k = 1; k < KS; ++k) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc0[i] += red[((wave + k) * 16 + i) * 64 + lane];
+        }
+      }
+    }
     // ---- epilogue: bias + activation (+ activation-gradient multiply) + NHWC store ----
     float llk_lane = 0.f;
 #pragma unroll
@@ -660,7 +681,7 @@ void gather_conv_kernel(GParams p, TailParams tp) {
       const int mt = mi == 0 ? mt0 : mt1;
       const Slot& s = mi == 0 ? s0 : s1;
       const f32x16& acc = mi == 0 ? acc0 : acc1;
-      if (mt >= p.MT) continue;  // wave-uniform
+      if (mt >= p.MT || kpart != 0) continue;  // wave-uniform
       const bool live = s.opix >= 0;
       float* outp = p.out + (live ? (size_t)((unsigned)s.opix * (unsigned)p.CO) : 0) + n0 + 4 * h;
       float v[16];
@@ -869,11 +890,13 @@ constexpr int LDS_BUDGET_FLOATS = (160 * 1024 - 2048) / 4;
 constexpr int NW_G = 4;
 constexpr int GENERIC_KMAX = 9;
 
-bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_bytes) {
+bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_bytes,
+                 int target = 32 * NW_G) {
   const int S = p.S;
   if (mode == MODE_T && (p.OW % S != 0 || p.OH % S != 0)) return false;
   const int img_pix = p.OH * p.OW;
-  const int TARGET = 32 * NW_G;  // one M-tile per wave
+  const int TARGET = target;  // 128: one M-tile per wave; 32 / 64: waves split the reduction
+  p.KS = 1;
   if (img_pix <= TARGET) {
     p.NIMG = TARGET / img_pix;
     if (p.NIMG > p.B) p.NIMG = p.B;
@@ -953,7 +976,7 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
   p.patch_floats = (int)(((long)p.NIMG * p.NRI * p.PW * p.P + 8 + 3) & ~3L);
   long wf = (long)ntaps * cic * p.WP + 64;  // + scratch for per-tile reductions
   long total = p.patch_floats + wf;
-  if (total < 1024) total = 1024;
+  if (total < 4096 + 64) total = 4096 + 64;  // room for the split-K / tail reductions
   *lds_bytes = (size_t)total * 4;
   if (max_blocks < 0) {  // slab-producing launch: rows are bounded
     int cap = -max_blocks;
@@ -1010,6 +1033,26 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
   int gx;
   size_t lds;
   if (!plan_gather(p, mode, max_blocks, &gx, &lds)) return odin_fail(-2, "gather_conv: no tiling plan");
+  // small-M layers: with 128-pixel tiles only a few workgroups exist while each carries a long
+  // reduction -> use 32- (or 64-) pixel tiles and let 4 (2) waves split the channels
+  if (mode == MODE_F && tail == nullptr && !getenv("ODIN_NOKSPLIT")) {
+    const int blocks = p.n_tiles * ((p.CO + 31) / 32);
+    const long kdepth = (long)p.KH * p.KW * p.CI;
+    if (blocks * 2 <= odin_num_cus() && kdepth >= 256) {
+      for (int tgt = 32; tgt <= 64; tgt *= 2) {
+        GParams q = p;
+        int gx2;
+        size_t lds2;
+        if (!plan_gather(q, mode, max_blocks, &gx2, &lds2, tgt)) continue;
+        const int ks = NW_G / (q.MT > 0 ? q.MT : 1);
+        if (q.MT * ks != NW_G || ks < 2 || (q.CIC % (2 * ks)) != 0) continue;
+        if (q.n_tiles * ((q.CO + 31) / 32) <= blocks) continue;
+        q.KS = ks;
+        p = q; gx = gx2; lds = lds2;
+        break;
+      }
+    }
+  }
   if (rows_out) *rows_out = gx;
   if (p.out == nullptr) return 0;  // dry run: planning only
   {

@@ -20,7 +20,7 @@ int odin_check_launch(const char* what) {
 
 int odin_num_cus() {
 #ifdef ODIN_SIM
-  return 4;
+  return 16;
 #else
   static int n = 0;
   if (n == 0) {

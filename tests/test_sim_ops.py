@@ -49,6 +49,7 @@ CONV_CASES = [
     (2, 14, 14, 3, 8, 5, 2, 'relu', False),
     (2, 7, 7, 8, 16, 5, 1, 'elu', False),
     (2, 16, 16, 32, 3, 1, 1, 'linear', False),
+    (16, 8, 8, 64, 64, 4, 2, 'elu', False),    # small-M: waves split the reduction (KS=4)
     (37, 4, 4, 8, 8, 4, 2, 'elu', False),      # several whole images per tile, ragged last tile
     (1, 8, 8, 160, 40, 4, 2, 'linear', False),  # channel-chunked reduction
 ]
@@ -140,7 +141,8 @@ def test_deconv2d_fwd_dgrad_wgrad(L, B, H, W, Ci, Co, K, S, act):
 
 @pytest.mark.parametrize('B,K,N,act', [(5, 1024, 128, 'linear'), (130, 10, 128, 'linear'),
                                        (7, 128, 20, 'linear'), (33, 100, 70, 'relu'),
-                                       (3, 4096, 40, 'linear'), (150, 36, 33, 'relu')])
+                                       (3, 4096, 40, 'linear'), (150, 36, 33, 'relu'),
+                                       (100, 256, 40, 'linear'), (70, 512, 64, 'relu')])
 def test_dense(L, B, K, N, act):
   rng = np.random.default_rng(2)
   x = rng.standard_normal((B, K))
