@@ -378,27 +378,35 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     float av[2][TNACC], bv[2][TNACC];
     // raw LDS operands; the (amul, aadd) fix-up is applied right before the MFMA so that
     // the reads of pair kp+1 stay in flight under the MFMAs of pair kp.
-    if ((p.OW & 1) == 0) {
+    const bool dense11 = (p.OW == 1 && p.OH == 1);  // Dense: slots are consecutive images
+    if ((p.OW & 1) == 0 || dense11) {
       // fast path: both pixels of a pair lie in one output row, so the patch base is a
       // wave-uniform running value (no table look-up on the critical path)
       int pb = 0, pc = 0, prl = 0, pimg = 0, pslot = 0;
-      const int lane_h = h * p.S * p.P;
+      const int img_stride = p.NRI * p.PW * p.P;
+      const int lane_h = dense11 ? h * img_stride : h * p.S * p.P;
       const int real_slots = p.TR * p.OW;
       auto load_next = [&](float* a_, float* b_) {
-        const int base = (pslot < real_slots) ? pb : 0;
+        // per-lane: the odd pixel of the last pair may be a pad slot (its DY row is zero, but
+        // the patch beyond the staged images must not be read)
+        const int base = (pslot + h < real_slots) ? pb + lane_h : 0;
         const float* brow = dyl + (pslot + h) * p.DP;
         if constexpr (FAST) {
           b_[0] = brow[l31];
 #pragma unroll
-          for (int a = 0; a < TNACC; ++a) a_[a] = patch[base + lane_h + a_off[a]];
+          for (int a = 0; a < TNACC; ++a) a_[a] = patch[base + a_off[a]];
         } else {
 #pragma unroll
           for (int a = 0; a < TNACC; ++a) {
-            a_[a] = patch[base + lane_h + a_off[a]];
+            a_[a] = patch[base + a_off[a]];
             b_[a] = brow[b_off[a]];
           }
         }
         pslot += 2;
+        if (dense11) {
+          pb += 2 * img_stride;
+          return;
+        }
         pc += 2;
         pb += 2 * p.S * p.P;
         if (pc >= p.OW) {
@@ -566,7 +574,9 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
       p.dy_floats = (int)df;
       *lds_bytes = (size_t)(pf + df + p.slots + 16) * 4;
       if (*lds_bytes < 4352) *lds_bytes = 4352;  // room for the end-of-kernel bias reduction
-      int g = p.n_tiles < ODIN_MAX_SLAB_BLOCKS ? p.n_tiles : ODIN_MAX_SLAB_BLOCKS;
+      int cap = ODIN_MAX_SLAB_BLOCKS / (((p.CI + CIB - 1) / CIB) * ((p.CO + COB - 1) / COB));
+      if (cap < 32) cap = 32;
+      int g = p.n_tiles < cap ? p.n_tiles : cap;
       *gx = g < 1 ? 1 : g;
       *gy = (p.CI + CIB - 1) / CIB;
       *gz = (p.CO + COB - 1) / COB;
@@ -607,9 +617,9 @@ int launch_winst2(WParams& p, dim3 grid, size_t lds, void* stream) {
   const int ntaps = p.KH * p.KW;
   const bool rows_full = (p.CI % p.CIB == 0) && ((ntaps * p.CIB) % 32 == 0);
   const bool all_used = (p.nrt * p.ncot) % NW_W == 0 && (p.nrt * p.ncot) / NW_W == TNACC;
-  if (PVEC && DCONT && !FLAT && p.ncot == 1 && p.bias_mode != 1 && rows_full && all_used &&
-      (p.OW & 1) == 0)
-    return launch_winst3<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, (PVEC && DCONT && !FLAT)>(
+  if (PVEC && DCONT && p.ncot == 1 && p.bias_mode != 1 && rows_full && all_used &&
+      ((p.OW & 1) == 0 || (p.OW == 1 && p.OH == 1)))
+    return launch_winst3<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, (PVEC && DCONT)>(
         p, grid, lds, stream);
   return launch_winst3<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, false>(p, grid, lds, stream);
 }

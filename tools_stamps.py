@@ -60,3 +60,25 @@ def run_w(B, H, W, Ci, Co, K, S):
   for i in range(1, min(len(ks), 24)):
     print(f'   {nm[int(ks[i])]:14s} +{ts[i]-ts[i-1]}')
 run_w(256, 32, 32, 32, 32, 4, 2)
+
+
+def run_wd(B, K, N):
+  x = torch.randn(B, K, device=dev); g = torch.randn(B, N, device=dev)
+  rows = C.c_int(0)
+  L.odin_dense_wgrad(None, None, None, C.byref(rows), B, K, N, None)
+  slab = torch.empty(rows.value, K * N + N, device=dev)
+  st = torch.zeros(64, dtype=torch.int64, device=dev)
+  for it in range(3):
+    st.zero_()
+    L.odin_debug_set_wgrad_stamps(st.data_ptr())
+    L.odin_dense_wgrad(x.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows), B, K, N, None)
+    torch.cuda.synchronize()
+  L.odin_debug_set_wgrad_stamps(None)
+  v = st.cpu().numpy(); v = v[v != 0]
+  ks, ts = (v >> 56), (v & ((1 << 56) - 1))
+  nm = {1: 'start', 3: 'prefetch0', 4: 'tile(mfma+top)', 5: 'commit+sync', 6: 'issue-next', 8: 'end'}
+  print(f'--- dense wgrad B{B} {K}->{N}: total {ts[-1]-ts[0]} cycles, rows {rows.value}')
+  for i in range(1, min(len(ks), 24)):
+    print(f'   {nm[int(ks[i])]:14s} +{ts[i]-ts[i-1]}')
+run_wd(256, 10, 128)
+run_wd(256, 1024, 128)
