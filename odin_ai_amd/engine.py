@@ -207,7 +207,8 @@ class NetProgram:
   # -- backward -------------------------------------------------------------------------
   def backward(self, x: torch.Tensor, gout_last: torch.Tensor, st,
                dx_out: Optional[torch.Tensor] = None, last: Optional[int] = None,
-               skip_bias_of_last: bool = False, data_only: bool = False) -> List[ReduceJob]:
+               skip_bias_of_last: bool = False, data_only: bool = False,
+               fork=None) -> List[ReduceJob]:
     """gout_last: dL/d(pre-activation output of the last layer).  If dx_out is given the
     gradient wrt the network input is written there.  Returns the slab-reduce jobs."""
     lib, B = self.lib, self.B
@@ -218,19 +219,21 @@ class NetProgram:
     for i in range(n - 1, -1, -1):
       r, d = self.recs[i], self.descs[i]
       xin = x if i == 0 else self.outs[i - 1]
-      # ---- weight (and bias) gradient ----
+      # ---- weight (and bias) gradient: independent of the data-gradient chain, so it is
+      # issued on the side stream (fork) and overlaps the next layers' data-gradients ----
       slab = self.wslabs[i]
+      wst = st if fork is None else fork(i)
       if data_only:
         pass
       elif r.kind == 'conv':
         lib.odin_conv2d_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows),
-                              C.byref(d), st)
+                              C.byref(d), wst)
       elif r.kind == 'deconv':
         lib.odin_deconv2d_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows),
-                                C.byref(d), st)
+                                C.byref(d), wst)
       else:
         lib.odin_dense_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows), B,
-                             r.K, r.N, st)
+                             r.K, r.N, wst)
       if not data_only:
         assert rows.value == self.wrows[i]
         n_red = slab.shape[1]
@@ -359,6 +362,9 @@ class VAEEngine:
     self._ring_i = 0
     self.hyper = torch.zeros(N_HYPER + 4, **f32)
     self.step_count = 0
+    self.side_stream = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
+    import os as _os
+    self.overlap_wgrad = _os.environ.get('ODIN_NO_OVERLAP', '0') != '1'
     self.graph = None
     self._jobs_keepalive = None
 
@@ -543,15 +549,35 @@ class VAEEngine:
                                 self.out4.data_ptr(), self.B, st)
 
   # ---- backward ----------------------------------------------------------------------
+  def _fork(self):
+    """Returns (fork(i) -> raw side-stream handle ordered after everything issued so far on
+    the current stream, join()).  None on CPU / when overlap is disabled."""
+    if self.side_stream is None or not self.overlap_wgrad:
+      return None, (lambda: None)
+    cur = torch.cuda.current_stream(self.device)
+    side = self.side_stream
+
+    def fork(i):
+      ev = torch.cuda.Event()
+      ev.record(cur)
+      side.wait_event(ev)
+      return side.cuda_stream
+
+    def join():
+      cur.wait_stream(side)
+
+    return fork, join
+
   def backward(self, st=None, extra_dz: Optional[torch.Tensor] = None):
     lib, B, D = self.lib, self.B, self.D
     st = self.stream() if st is None else st
+    fork, join = self._fork()
     if self._used_fused:
       nd = len(self.dec_recs)
       a, b = self.dec_recs[-2], self.dec_recs[-1]
       co, c1 = a.desc['Cout'], b.desc['Cout']
       jobs = self.dec.backward(self.z, self.dec.gouts[-2], st, dx_out=self.dz, last=nd - 2,
-                               skip_bias_of_last=True)
+                               skip_bias_of_last=True, fork=fork)
       ts, stride = self.tail_slab, self.tail_slab.shape[1]
       # (dW1 | db1) of the 1x1 conv, then the bias gradient of the fused layer
       jobs.append(ReduceJob(ts.data_ptr(), self.grads[b.w_off:].data_ptr(), co * c1 + c1,
@@ -559,7 +585,7 @@ class VAEEngine:
       jobs.append(ReduceJob(ts[:, co * c1 + c1:].data_ptr(), self.grads[a.b_off:].data_ptr(), co,
                             self.tail_rows, stride, 0))
     else:
-      jobs = self.dec.backward(self.z, self.dec.gouts[-1], st, dx_out=self.dz)
+      jobs = self.dec.backward(self.z, self.dec.gouts[-1], st, dx_out=self.dz, fork=fork)
     dzx = extra_dz.data_ptr() if extra_dz is not None else None
     if self.tc_mode == 'betatc':
       assert extra_dz is None
@@ -572,7 +598,7 @@ class VAEEngine:
     h_e = self.enc.outs[-1]
     rows = C.c_int(0)
     lib.odin_dense_wgrad(h_e.data_ptr(), self.dp.data_ptr(), self.lat_slab.data_ptr(),
-                         C.byref(rows), B, self.hdim, 2 * D, st)
+                         C.byref(rows), B, self.hdim, 2 * D, st if fork is None else fork(-1))
     jobs.append(ReduceJob(self.lat_slab.data_ptr(), self.grads[self.lat_w_off:].data_ptr(),
                           self.lat_slab.shape[1], rows.value, self.lat_slab.shape[1], 0))
     last = self.enc_recs[-1]
@@ -587,7 +613,8 @@ class VAEEngine:
     if bslab is not None:
       jobs.append(ReduceJob(bslab.data_ptr(), self.grads[last.b_off:].data_ptr(), last.b_n,
                             rows.value, last.b_n, 0))
-    jobs += self.enc.backward(self.x, self.enc.gouts[-1], st)
+    jobs += self.enc.backward(self.x, self.enc.gouts[-1], st, fork=fork)
+    join()
     arr = (ReduceJob * len(jobs))(*jobs)
     self._jobs_keepalive = arr
     lib.odin_slab_reduce(arr, len(jobs), st)
