@@ -364,7 +364,9 @@ class VAEEngine:
     self.step_count = 0
     self.side_stream = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
     import os as _os
-    self.overlap_wgrad = _os.environ.get('ODIN_NO_OVERLAP', '0') != '1'
+    # weight gradients on a side stream: measured neutral-to-negative on MI355X (the kernels
+    # are LDS-limited to one workgroup per CU and contend), so it is opt-in
+    self.overlap_wgrad = _os.environ.get('ODIN_OVERLAP_WGRAD', '0') == '1'
     self.graph = None
     self._jobs_keepalive = None
 
