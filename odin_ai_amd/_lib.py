@@ -102,8 +102,19 @@ class Lib:
     if name.startswith('odin_'):
       fn = getattr(self.c, name)
 
+      trace = os.environ.get('ODIN_TRACE', '0') == '1'
+
       def call(*a):
+        if trace:  # diagnostics: serialise and name every launch
+          import sys
+          import torch
+          print('odin>', name, [x if isinstance(x, int) else '.' for x in a][-6:], flush=True,
+                file=sys.stderr)
         rc = fn(*a)
+        if trace:
+          import torch
+          if torch.cuda.is_available():
+            torch.cuda.synchronize()
         if rc != 0 and name not in ('odin_version', 'odin_max_slab_rows'):
           raise OdinError(f"{name} failed: {self.c.odin_last_error().decode()} (rc={rc})")
         return rc

@@ -192,8 +192,9 @@ __device__ __forceinline__ void wdy_issue(const WParams& p, int gr0, int co0, in
     for (int i = 0; i < DMAX; ++i) {
       const int e = tid + i * NT;
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < total && e < lim)
-        t = *reinterpret_cast<const float4*>(src0 + (size_t)(e >> lg) * p.CO + ((e & (cpd - 1)) << 2));
+      const int cl = (e & (cpd - 1)) << 2;
+      if (e < total && e < lim && co0 + cl < p.CO)  // channel groups beyond CO stay zero
+        t = *reinterpret_cast<const float4*>(src0 + (size_t)(e >> lg) * p.CO + cl);
       v[i] = t;
     }
     return;
