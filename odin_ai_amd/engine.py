@@ -679,7 +679,7 @@ class VAEEngine:
       torch.cuda.current_stream(self.device).wait_stream(cap)
       self._graph_eps_explicit = eps is not None
       g = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(g, stream=cap):
+      with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
         self.forward(self.x_static, self.eps if self._graph_eps_explicit else None)
         self.backward()
         self.adam(global_clipnorm=global_clipnorm)
@@ -708,10 +708,10 @@ class VAEEngine:
       torch.cuda.current_stream(self.device).wait_stream(cap)
       self._graph_eps_explicit = eps is not None
       ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-      with torch.cuda.graph(ga, stream=cap):
+      with torch.cuda.graph(ga, stream=cap, capture_error_mode='thread_local'):
         self.forward(self.x_static, self.eps if self._graph_eps_explicit else None)
         self.backward()
-      with torch.cuda.graph(gb, stream=cap):
+      with torch.cuda.graph(gb, stream=cap, capture_error_mode='thread_local'):
         self.adam(global_clipnorm=global_clipnorm)
       self.graph, self.graph_b = ga, gb
     self.x_static.copy_(x, non_blocking=True)
