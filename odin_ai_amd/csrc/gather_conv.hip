@@ -550,7 +550,7 @@ __device__ __forceinline__ float sigmoid_g(float x) {
 // EPI: 3 = as 0 but with FLAT (Dense) staging; 0 = runtime activation / aux / channel masking; 1 = ELU, no aux, CO % 32 == 0
 // (forward of the elu stacks); 2 = linear, aux = ELU derivative, CO % 32 == 0 (data-gradients).
 template <int MODE, int NW, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI, int NMT>
-__global__ __launch_bounds__(NW * 64, (MODE == MODE_T && TK == 4 && TCIC == 32 && RPWMAX == 1) ? 2 : 1)
+__global__ __launch_bounds__(NW * 64, (MODE == MODE_T && TK == 4 && TCIC == 32 && RPWMAX == 1 && TAIL <= 1) ? 2 : 1)
 void gather_conv_kernel(GParams p, TailParams tp) {
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
@@ -576,16 +576,25 @@ void gather_conv_kernel(GParams p, TailParams tp) {
   // fused-tail state
   // TAIL = number of 1x1 output maps evaluated by the fused tail (0: no tail)
   constexpr int NC1 = TAIL > 0 ? TAIL : 1;
-  float w1r[TAIL ? 16 : 1][NC1], dw1[TAIL ? 16 : 1][NC1], db1[NC1], b1r[NC1];
+  float dw1[TAIL ? 16 : 1][NC1], db1[NC1], b1r[NC1];
+  // the tail's per-channel constants (bias of this layer, 1x1 weights) stay in LDS and are
+  // re-read by every epilogue: 32 + 32*NC1 fewer live registers across the MFMA loop
+  float* tailc = wl + (p.KH * p.KW * p.CIC * p.WP) + 64;  // [32 bias | NC1 x 32 w1]
   if (TAIL) {
+    for (int e = tid; e < 32 * (1 + NC1); e += NT) {
+      float val;
+      if (e < 32) {
+        val = (p.bias != nullptr && n0 + e < p.CO) ? p.bias[n0 + e] : 0.f;
+      } else {
+        const int oc = (e - 32) >> 5, n = (e - 32) & 31;
+        val = (oc < tp.C1 && n < p.CO) ? tp.w1[n * tp.C1 + oc] : 0.f;
+      }
+      tailc[e] = val;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int n = 8 * (i >> 2) + 4 * h + (i & 3);
 #pragma unroll
-      for (int oc = 0; oc < NC1; ++oc) {
-        w1r[i][oc] = (oc < tp.C1 && n < p.CO) ? tp.w1[n * tp.C1 + oc] : 0.f;
-        dw1[i][oc] = 0.f;
-      }
+      for (int oc = 0; oc < NC1; ++oc) dw1[i][oc] = 0.f;
     }
 #pragma unroll
     for (int oc = 0; oc < NC1; ++oc) {
@@ -603,11 +612,13 @@ void gather_conv_kernel(GParams p, TailParams tp) {
   const int mt0 = (KS > 1) ? wave / KS : wave, mt1 = wave + NW;
   Slot s0 = slot_geometry<MODE>(p, mt0 < p.MT ? mt0 : 0, l31);
   Slot s1 = slot_geometry<MODE>(p, mt1 < p.MT ? mt1 : 0, l31);
-  float bias_r[16];
+  float bias_r[TAIL ? 1 : 16];
+  if constexpr (TAIL == 0) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int n = n0 + 8 * (i >> 2) + 4 * h + (i & 3);
-    bias_r[i] = (p.bias != nullptr && n < p.CO) ? p.bias[n] : 0.f;
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + 8 * (i >> 2) + 4 * h + (i & 3);
+      bias_r[i] = (p.bias != nullptr && n < p.CO) ? p.bias[n] : 0.f;
+    }
   }
   const bool co_vec = ((p.CO & 3) == 0);
 
@@ -685,42 +696,64 @@ void gather_conv_kernel(GParams p, TailParams tp) {
       const bool live = s.opix >= 0;
       float* outp = p.out + (live ? (size_t)((unsigned)s.opix * (unsigned)p.CO) : 0) + n0 + 4 * h;
       float v[16];
+      float bias_l[16];
+      if constexpr (TAIL > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 t4 = *reinterpret_cast<const float4*>(tailc + 8 * q + 4 * h);
+          bias_l[4 * q] = t4.x; bias_l[4 * q + 1] = t4.y; bias_l[4 * q + 2] = t4.z; bias_l[4 * q + 3] = t4.w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bias_l[i] = bias_r[i];
+      }
       if constexpr (EPI == 1) {
+        // branch-free ELU: exp of min(t, 0) for every element
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float t = acc[i] + bias_r[i];
-          v[i] = live ? (t > 0.f ? t : odin_exp(t) - 1.f) : 0.f;
+          const float t = acc[i] + bias_l[i];
+          const float e = odin_exp(fminf(t, 0.f)) - 1.f;
+          v[i] = live ? (t > 0.f ? t : e) : 0.f;
         }
       } else if constexpr (EPI == 2) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = live ? acc[i] + bias_r[i] : 0.f;
+        for (int i = 0; i < 16; ++i) v[i] = live ? acc[i] + bias_l[i] : 0.f;
       } else {
         const int act = p.act;
         if (act == ODIN_ACT_ELU) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int n = n0 + 8 * (i >> 2) + 4 * h + (i & 3);
-            const float t = acc[i] + bias_r[i];
+            const float t = acc[i] + bias_l[i];
             v[i] = (n < p.CO && live) ? (t > 0.f ? t : odin_exp(t) - 1.f) : 0.f;
           }
         } else if (act == ODIN_ACT_RELU) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int n = n0 + 8 * (i >> 2) + 4 * h + (i & 3);
-            const float t = acc[i] + bias_r[i];
+            const float t = acc[i] + bias_l[i];
             v[i] = (n < p.CO && live) ? fmaxf(t, 0.f) : 0.f;
           }
         } else {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int n = n0 + 8 * (i >> 2) + 4 * h + (i & 3);
-            v[i] = (n < p.CO && live) ? acc[i] + bias_r[i] : 0.f;
+            v[i] = (n < p.CO && live) ? acc[i] + bias_l[i] : 0.f;
           }
         }
       }
       if (TAIL) {
         // 1x1 conv: each pixel's 32 channels live in lanes (l31, h=0) and (l31, h=1)
         float lg[NC1], dl[NC1];
+        float w1r[16][NC1];
+#pragma unroll
+        for (int oc = 0; oc < NC1; ++oc) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(tailc + 32 + 32 * oc + 8 * q + 4 * h);
+            w1r[4 * q][oc] = t4.x; w1r[4 * q + 1][oc] = t4.y; w1r[4 * q + 2][oc] = t4.z; w1r[4 * q + 3][oc] = t4.w;
+          }
+        }
 #pragma unroll
         for (int oc = 0; oc < NC1; ++oc) {
           float t = 0.f;
@@ -889,6 +922,7 @@ void gather_conv_kernel(GParams p, TailParams tp) {
 constexpr int LDS_BUDGET_FLOATS = (160 * 1024 - 2048) / 4;
 constexpr int NW_G = 4;
 constexpr int GENERIC_KMAX = 9;
+constexpr int W_SCRATCH = 64 + 32 * (1 + 4);  // floats after the weight slice (MAXC1 = 4)
 
 bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_bytes,
                  int target = 32 * NW_G) {
@@ -953,7 +987,7 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
   while (true) {
     int P = cic + 1;
     long pf = (long)p.NIMG * p.NRI * p.PW * P + 8;
-    long wf = (long)ntaps * cic * p.WP + 64;
+    long wf = (long)ntaps * cic * p.WP + W_SCRATCH;
     long rowlen = (long)p.PW * ((vec0 && (cic & 3) == 0) ? cic / 4 : cic);
     const bool flat0 = (p.PW == 1 && p.NRI == 1);
     if (pf + wf <= LDS_BUDGET_FLOATS && (flat0 || rowlen <= 64 * GENERIC_KMAX)) break;
@@ -974,12 +1008,14 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
   p.flat = (p.PW == 1 && p.NRI == 1) ? 1 : 0;
   if (p.flat) p.KI = 1;
   p.patch_floats = (int)(((long)p.NIMG * p.NRI * p.PW * p.P + 8 + 3) & ~3L);
-  long wf = (long)ntaps * cic * p.WP + 64;  // + scratch for per-tile reductions
+  long wf = (long)ntaps * cic * p.WP + W_SCRATCH;  // + scratch: per-tile reductions, tail constants
   long total = p.patch_floats + wf;
   if (total < 4096 + 64) total = 4096 + 64;  // room for the split-K / tail reductions
   *lds_bytes = (size_t)total * 4;
   if (max_blocks < 0) {  // slab-producing launch: rows are bounded
     int cap = -max_blocks;
+    // one slab row per workgroup; two workgroups per CU only where the LDS allows it
+    if (*lds_bytes * 2 > 160 * 1024 && cap > odin_num_cus()) cap = odin_num_cus();
     *grid_x = p.n_tiles < cap ? p.n_tiles : cap;
   } else {
     int per_cu = (int)((160 * 1024) / (*lds_bytes));
@@ -1077,15 +1113,23 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     tp = *tail;
     if (p.CO > 32 || tp.C1 > MAXC1 || p.NIMG != 1 || !p.vec)
       return odin_fail(-2, "bernoulli tail: needs Cout<=32, C1<=4, Cin%4==0 and one image per tile");
+    if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 1 && tp.C1 == 1 &&
+        !getenv("ODIN_NOTAIL2WG"))  // two workgroups per CU
+      return launch_inst<MODE_T, 4, 2, 32, true, 1, 5, 1, 1>(p, tp, grid, lds, stream);
     if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5 && epi == 1 && tp.C1 == 1)
       return launch_inst<MODE_T, 4, 2, 32, true, 1, 5, 2, 1>(p, tp, grid, lds, stream);
+#ifndef ODIN_DEV_TAIL_ONLY  // (developer switch: compile only the dSprites tail instances)
     if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5 && epi == 1 && tp.C1 == 3)
       return launch_inst<MODE_T, 4, 2, 32, true, 3, 5, 2, 1>(p, tp, grid, lds, stream);
     if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5)
       return launch_inst<MODE_T, 4, 2, 32, true, 4, 5, 2, 0>(p, tp, grid, lds, stream);
     if (mode == MODE_T) return launch_inst<MODE_T, 0, 0, 0, true, 4, GK, 2>(p, tp, grid, lds, stream);
     return launch_inst<MODE_F, 0, 0, 0, true, 4, GK, 2>(p, tp, grid, lds, stream);
+#endif
   }
+#ifdef ODIN_DEV_TAIL_ONLY
+  return -1;
+#else
   if (mode == MODE_F) {
     if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 5) {
       if (epi == 1) return launch_inst<MODE_F, 4, 2, 32, true, 0, 5, 5, 1>(p, tp, grid, lds, stream);
@@ -1125,6 +1169,7 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
   if (p.vec && p.KI <= 2) return launch_inst<MODE_T, 0, 0, 0, true, 0, 2, 8>(p, tp, grid, lds, stream);
   if (p.vec) return launch_inst<MODE_T, 0, 0, 0, true, 0, GK, 2>(p, tp, grid, lds, stream);
   return launch_inst<MODE_T, 0, 0, 0, false, 0, GK, 2>(p, tp, grid, lds, stream);
+#endif
 }
 
 void fill_common(GParams& p, const odin_conv_desc* d) {
@@ -1139,7 +1184,7 @@ void fill_common(GParams& p, const odin_conv_desc* d) {
 
 }  // namespace
 
-extern "C" int odin_max_slab_rows(void) { return ODIN_MAX_SLAB_BLOCKS; }
+extern "C" int odin_max_slab_rows(void) { return ODIN_MAX_COLSUM_BLOCKS; }
 
 // ---- Conv2D -------------------------------------------------------------------------
 extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
@@ -1163,7 +1208,7 @@ extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* a
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;
   p.H = d->OH; p.W = d->OW; p.CI = d->Cout; p.OH = d->H; p.OW = d->W; p.CO = d->Cin;
   p.wmode = 1;
-  return launch_gather(MODE_T, p, stream, colsum_slab ? -ODIN_MAX_SLAB_BLOCKS : odin_num_cus(),
+  return launch_gather(MODE_T, p, stream, colsum_slab ? -ODIN_MAX_COLSUM_BLOCKS : odin_num_cus(),
                        slab_rows_out);
 }
 
@@ -1187,7 +1232,7 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;
   p.H = d->OH; p.W = d->OW; p.CI = d->Cout; p.OH = d->H; p.OW = d->W; p.CO = d->Cin;
   p.wmode = 0;
-  return launch_gather(MODE_F, p, stream, colsum_slab ? -ODIN_MAX_SLAB_BLOCKS : odin_num_cus(),
+  return launch_gather(MODE_F, p, stream, colsum_slab ? -ODIN_MAX_COLSUM_BLOCKS : odin_num_cus(),
                        slab_rows_out);
 }
 
@@ -1211,7 +1256,7 @@ extern "C" int odin_dense_dgrad(const float* dy, const float* w, const float* au
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;
   p.B = B; p.H = 1; p.W = 1; p.CI = N; p.OH = 1; p.OW = 1; p.CO = K;
   p.KH = p.KW = 1; p.S = 1; p.wmode = 1;
-  return launch_gather(MODE_F, p, stream, colsum_slab ? -ODIN_MAX_SLAB_BLOCKS : odin_num_cus(),
+  return launch_gather(MODE_F, p, stream, colsum_slab ? -ODIN_MAX_COLSUM_BLOCKS : odin_num_cus(),
                        slab_rows_out);
 }
 
@@ -1231,7 +1276,7 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
   TailParams tp;
   tp.w1 = w1; tp.b1 = b1; tp.target = target; tp.logits = logits; tp.llk_part = llk_part;
   tp.slab = tail_slab; tp.scale = scale; tp.C1 = C1;
-  int rc = launch_gather(is_deconv ? MODE_T : MODE_F, p, stream, -ODIN_MAX_SLAB_BLOCKS,
+  int rc = launch_gather(is_deconv ? MODE_T : MODE_F, p, stream, -ODIN_MAX_COLSUM_BLOCKS,
                          slab_rows_out, &tp);
   if (n_part_out) *n_part_out = p.OH / (p.TR > 0 ? p.TR : 1);  // log-likelihood parts per sample
   return rc;

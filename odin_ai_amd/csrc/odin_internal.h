@@ -4,7 +4,8 @@
 #include <cstring>
 #include "../../include/odin_hip.h"
 
-#define ODIN_MAX_SLAB_BLOCKS 256
+#define ODIN_MAX_SLAB_BLOCKS 256     // weight-gradient slabs: rows per (ci, co) block set
+#define ODIN_MAX_COLSUM_BLOCKS 512   // column-sum / fused-tail slabs (two workgroups per CU)
 
 int odin_fail(int code, const char* msg);
 int odin_check_launch(const char* what);
