@@ -20,6 +20,7 @@
 // order (bit-reproducible, no float atomics).
 #include "odin_device.h"
 #include "odin_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -266,7 +267,10 @@ __device__ __forceinline__ void wdy_commit(const WParams& p, int tid, const floa
 // FAST: one output-channel tile per workgroup (all accumulators share the DY operand), every
 // accumulator row is a real weight row (no padding rows, no MFMA bias tile): the hot loop
 // is 1 DY read + TNACC patch reads + TNACC MFMAs per pixel pair.
-template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT, bool PVEC, bool DCONT, bool FAST>
+// TSP > 0 (= S * P floats, FAST only): the tile is walked in chunks of 4 pixel pairs of one output
+// row; all LDS operand addresses of a chunk are one per-lane base + compile-time offsets, so the
+// hot loop is 16 MFMAs + 20 LDS reads + 5 address adds per chunk (no per-pair control flow).
+template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT, bool PVEC, bool DCONT, bool FAST, int TSP>
 __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
@@ -380,7 +384,62 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     // raw LDS operands; the (amul, aadd) fix-up is applied right before the MFMA so that
     // the reads of pair kp+1 stay in flight under the MFMAs of pair kp.
     const bool dense11 = (p.OW == 1 && p.OH == 1);  // Dense: slots are consecutive images
-    if ((p.OW & 1) == 0 || dense11) {
+    if constexpr (TSP > 0) {
+      constexpr int UN = (TNACC > 4) ? 2 : 4;  // pixel pairs per pipeline stage
+      constexpr int PS2 = 2 * TSP;  // patch floats between consecutive pairs of a row
+      const int nchunks = npairs / UN;
+      const int cpr = p.OW / (2 * UN);          // chunks per output row
+      const int row_stride = p.S * p.PW * p.P;  // patch floats between output rows
+      const float* abase[TNACC];
+#pragma unroll
+      for (int a = 0; a < TNACC; ++a) abase[a] = patch + h * TSP + a_off[a];
+      const float* bbase = dyl + h * 32 + l31;
+      int crow = 0, ccol = 0, rl = 0, img = 0, dyo = 0;  // wave-uniform chunk iterator
+      float a0[UN][TNACC], b0[UN], a1[UN][TNACC], b1[UN];
+      auto chunk_load = [&](float (&a_)[UN][TNACC], float (&b_)[UN]) {
+        const int ao = crow + ccol * (UN * PS2);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) b_[u] = bbase[dyo + u * 64];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+          for (int a = 0; a < TNACC; ++a) a_[u][a] = abase[a][ao + u * PS2];
+        }
+        dyo += UN * 64;
+        if (++ccol == cpr) {
+          ccol = 0;
+          crow += row_stride;
+          if (++rl == p.RPI) { rl = 0; ++img; crow = img * p.NRI * p.PW * p.P; }
+        }
+      };
+      auto chunk_mfma = [&](const float (&a_)[UN][TNACC], const float (&b_)[UN]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+          for (int a = 0; a < TNACC; ++a) acc[a] = mfma32(a_[u][a], b_[u], acc[a]);
+        }
+        // the next chunk's UN * (TNACC + 1) LDS reads go into the shadow of these MFMAs
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
+          ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 2);
+#pragma unroll
+          for (int a = 1; a < TNACC; ++a) {
+            ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
+            ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 1);
+          }
+        }
+        ODIN_SCHED_FENCE();
+      };
+      chunk_load(a0, b0);
+      ODIN_SCHED_FENCE();
+      for (int ch = 0; ch < nchunks; ch += 2) {
+        if (ch + 1 < nchunks) chunk_load(a1, b1);
+        chunk_mfma(a0, b0);
+        if (ch + 2 < nchunks) chunk_load(a0, b0);
+        if (ch + 1 < nchunks) chunk_mfma(a1, b1);
+      }
+    } else if ((p.OW & 1) == 0 || dense11) {
       // fast path: both pixels of a pair lie in one output row, so the patch base is a
       // wave-uniform running value (no table look-up on the critical path)
       int pb = 0, pc = 0, prl = 0, pimg = 0, pslot = 0;
@@ -589,7 +648,7 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
 
 long long* g_wstamps = nullptr;
 
-template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT, bool PVEC, bool DCONT, bool FAST>
+template <int TNACC, int KMAX, int RPWMAX, int DMAX, bool FLAT, bool PVEC, bool DCONT, bool FAST, int TSP = 0>
 int launch_winst3(WParams& p, dim3 grid, size_t lds, void* stream) {
   const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
   const int ditems = p.slots * (p.dvec ? p.COB / 4 : p.COB);
@@ -604,12 +663,12 @@ int launch_winst3(WParams& p, dim3 grid, size_t lds, void* stream) {
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, FAST>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, FAST, TSP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, FAST>), grid, dim3(NW_W * 64), lds, stream, p);
+  ODIN_LAUNCH((wgrad_kernel<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, FAST, TSP>), grid, dim3(NW_W * 64), lds, stream, p);
   return odin_check_launch("wgrad");
 }
 
@@ -618,9 +677,21 @@ int launch_winst2(WParams& p, dim3 grid, size_t lds, void* stream) {
   // FAST needs only: one output-channel tile per workgroup and no MFMA bias tile.  Padding
   // rows / unused accumulators then hold garbage that is never written to the slab.
   if (PVEC && DCONT && p.ncot == 1 && p.bias_mode != 1 &&
-      ((p.OW & 1) == 0 || (p.OW == 1 && p.OH == 1)))
+      ((p.OW & 1) == 0 || (p.OW == 1 && p.OH == 1))) {
+    if constexpr (PVEC && DCONT && !FLAT) {
+      // row-chunk loop: whole chunks of 4 pixel pairs per output row, no pad slots
+      static int norow = -1;
+      if (norow < 0) norow = getenv("ODIN_NOROWCHUNK") ? 1 : 0;
+      if (!norow && (p.OW % 8) == 0 && p.TR * p.OW == p.slots && p.COB == 32 && p.DP == 32) {
+        const int sp = p.S * p.P;
+        if (sp == 32) return launch_winst3<TNACC, KMAX, RPWMAX, DMAX, FLAT, true, true, true, 32>(p, grid, lds, stream);
+        if (sp == 64) return launch_winst3<TNACC, KMAX, RPWMAX, DMAX, FLAT, true, true, true, 64>(p, grid, lds, stream);
+        if (sp == 128) return launch_winst3<TNACC, KMAX, RPWMAX, DMAX, FLAT, true, true, true, 128>(p, grid, lds, stream);
+      }
+    }
     return launch_winst3<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, (PVEC && DCONT)>(
         p, grid, lds, stream);
+  }
   return launch_winst3<TNACC, KMAX, RPWMAX, DMAX, FLAT, PVEC, DCONT, false>(p, grid, lds, stream);
 }
 

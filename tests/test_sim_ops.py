@@ -52,6 +52,9 @@ CONV_CASES = [
     (16, 8, 8, 64, 64, 4, 2, 'elu', False),    # small-M: waves split the reduction (KS=4)
     (37, 4, 4, 8, 8, 4, 2, 'elu', False),      # several whole images per tile, ragged last tile
     (1, 8, 8, 160, 40, 4, 2, 'linear', False),  # channel-chunked reduction
+    (3, 16, 16, 32, 32, 4, 2, 'elu', False),   # wgrad row-chunk loop (S*P = 64), two images per tile, ragged
+    (2, 16, 16, 64, 32, 4, 2, 'elu', False),   # wgrad row-chunk loop (S*P = 128)
+    (1, 16, 16, 32, 32, 3, 1, 'relu', False),  # wgrad row-chunk loop (S*P = 32), 16-wide rows
 ]
 
 
