@@ -568,10 +568,201 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
   }
 }
 
-bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes) {
+// --------------------------------------------------------------------------------------
+// Producer / consumer variant (FAST + row-chunk shapes).  The workgroup has 8 waves, two per
+// SIMD: waves 0-3 own the dW accumulators and do nothing but LDS reads + MFMAs; waves 4-7
+// stage the NEXT tile (IN patch + DY rows) from HBM into the other half of a double-buffered
+// LDS area.  One barrier per tile.  Staging cost and HBM latency disappear behind the matrix
+// pipe instead of adding to it (at one wave per SIMD they are ~1/3 of the tile time).
+// Tiles are 64 pixels so that two buffers fit the 160 KB LDS.
+// --------------------------------------------------------------------------------------
+#ifdef ODIN_SIM
+#define WS_STAMP(base, k) ((void)0)
+#else
+#define WS_STAMP(base, k)                                                                 \
+  do {                                                                                    \
+    if (p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 &&   \
+        lane == 0 && stamp_i < 31)                                                        \
+      p.stamps[(base) + stamp_i++] = ((long long)(k) << 56) | (long long)(clock64() & 0xFFFFFFFFFFFFFFll); \
+  } while (0)
+#endif
+
+template <int TNACC, int KMAX, int RPWMAX, int DMAX, int TSP>
+__global__ __launch_bounds__(2 * NW_W * 64) void wgrad_ws_kernel(WParams p) {
+  ODIN_DYN_SMEM(float, smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = W_UNIFORM(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  constexpr int NT = NW_W * 64;  // threads per role
+  const bool loader = wave >= NW_W;
+  const int buf_floats = p.patch_floats + p.dy_floats;
+  const int ci0 = blockIdx.y * p.CIB, co0 = blockIdx.z * p.COB;
+  const int cib = (p.CI - ci0) < p.CIB ? (p.CI - ci0) : p.CIB;
+  const int ntaps = p.KH * p.KW;
+  const int nrows = ntaps * cib;
+  const int n_wt = p.nrt * p.ncot;
+  const int n_my = ((int)blockIdx.x < p.n_tiles)
+                       ? (p.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x16 acc[TNACC];
+#pragma unroll
+  for (int a = 0; a < TNACC; ++a) acc[a] = f32x16_zero();
+  int stamp_i = 0;
+  (void)stamp_i;
+
+  if (loader) {
+    // ---------------- producer waves ----------------
+    const int lw = wave - NW_W, ltid = tid - NT;
+#ifndef ODIN_SIM
+    // VALU issue on a SIMD is arbitrated by priority, then age: as the younger wave the
+    // producer would only get the slots the MFMA wave leaves over (measured: its ~300
+    // staging instructions took 10.9k cycles instead of 2.6k) and the consumer then waits
+    // at the barrier.  Static priority for the producer half.
+    __builtin_amdgcn_s_setprio(2);
+#endif
+    const WLane<KMAX> WL = wlane_init<KMAX>(p, lane, cib);
+    for (int k = 0; k <= n_my; ++k) {
+      if (lw == 0) WS_STAMP(32, 20);
+      if (k < n_my) {
+        const int tile = blockIdx.x + k * gridDim.x;
+        float* patch = smem + (k & 1) * buf_floats;
+        float* dyl = patch + p.patch_floats;
+        const int gr0 = tile * p.TR;
+        const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
+        const int ih_lo = oh0 * p.S - p.pt;
+        float4 pf[RPWMAX * KMAX], df[DMAX];
+        wdy_issue<DMAX, NT, true>(p, gr0, co0, ltid, df);
+        for (int bt = 0; bt < p.n_batches; ++bt) {
+          wpatch_issue<KMAX, RPWMAX, false, true>(p, WL, lw, ltid, bt, b0, ih_lo, ci0, cib, pf);
+          if (lw == 0) WS_STAMP(32, 21);
+          wpatch_commit<KMAX, RPWMAX, false, true>(p, WL, lw, ltid, bt, pf, patch);
+        }
+        wdy_commit<DMAX, NT, true>(p, ltid, df, dyl, bsum4);
+        if (lw == 0) WS_STAMP(32, 22);
+      }
+      __syncthreads();
+    }
+  } else {
+    // ---------------- consumer waves ----------------
+    int a_off[TNACC];
+#pragma unroll
+    for (int a = 0; a < TNACC; ++a) {
+      const int T = wave + a * NW_W;
+      a_off[a] = 0;
+      if (T < n_wt) {
+        const int rl = T * 32 + l31;  // ncot == 1
+        if (rl < nrows) {
+          const int tap = rl / cib, cl = rl - tap * cib;
+          const int kh = tap / p.KW, kw = tap - kh * p.KW;
+          a_off[a] = (kh * p.PW + kw) * p.P + cl;
+        }
+      }
+    }
+    constexpr int UN = 4;
+    constexpr int PS2 = 2 * TSP;
+    const int npairs = p.slots >> 1;
+    const int nchunks = npairs / UN;
+    const int cpr = p.OW / (2 * UN);
+    const int row_stride = p.S * p.PW * p.P;
+    for (int k = 0; k <= n_my; ++k) {
+      if (wave == 0) WS_STAMP(0, 10);
+      if (k >= 1) {
+        const float* patch = smem + ((k - 1) & 1) * buf_floats;
+        const float* dyl = patch + p.patch_floats;
+        const float* abase[TNACC];
+#pragma unroll
+        for (int a = 0; a < TNACC; ++a) abase[a] = patch + h * TSP + a_off[a];
+        const float* bbase = dyl + h * 32 + l31;
+        int crow = 0, ccol = 0, rl = 0, img = 0, dyo = 0;
+        float a0[UN][TNACC], b0[UN], a1[UN][TNACC], b1[UN];
+        auto chunk_load = [&](float (&a_)[UN][TNACC], float (&b_)[UN]) {
+          const int ao = crow + ccol * (UN * PS2);
+#pragma unroll
+          for (int u = 0; u < UN; ++u) b_[u] = bbase[dyo + u * 64];
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+#pragma unroll
+            for (int a = 0; a < TNACC; ++a) a_[u][a] = abase[a][ao + u * PS2];
+          }
+          dyo += UN * 64;
+          if (++ccol == cpr) {
+            ccol = 0;
+            crow += row_stride;
+            if (++rl == p.RPI) { rl = 0; ++img; crow = img * p.NRI * p.PW * p.P; }
+          }
+        };
+        auto chunk_mfma = [&](const float (&a_)[UN][TNACC], const float (&b_)[UN]) {
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+#pragma unroll
+            for (int a = 0; a < TNACC; ++a) acc[a] = mfma32(a_[u][a], b_[u], acc[a]);
+          }
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
+            ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 2);
+#pragma unroll
+            for (int a = 1; a < TNACC; ++a) {
+              ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
+              ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 1);
+            }
+          }
+          ODIN_SCHED_FENCE();
+        };
+        chunk_load(a0, b0);
+        ODIN_SCHED_FENCE();
+        for (int ch = 0; ch < nchunks; ch += 2) {
+          if (ch + 1 < nchunks) chunk_load(a1, b1);
+          chunk_mfma(a0, b0);
+          if (ch + 2 < nchunks) chunk_load(a0, b0);
+          if (ch + 1 < nchunks) chunk_mfma(a1, b1);
+        }
+        if (wave == 0) WS_STAMP(0, 11);
+      }
+      __syncthreads();
+    }
+  }
+
+  float* row = p.slab + (size_t)blockIdx.x * p.slab_stride;
+  if (!loader) {
+#pragma unroll
+    for (int a = 0; a < TNACC; ++a) {
+      const int T = wave + a * NW_W;
+      if (T < n_wt) {
+        const int co = co0 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = T * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (rl < nrows && co < p.CO) {
+            const int tap = rl / cib, cl = rl - tap * cib;
+            row[((size_t)tap * p.CI + ci0 + cl) * p.CO + co] = acc[a][r];
+          }
+        }
+      }
+    }
+  }
+  if (p.bias_mode == 2 && blockIdx.y == 0) {
+    // producer thread t accumulated channels 4*(t % cpd) .. +3 while staging DY
+    float4* red = reinterpret_cast<float4*>(smem);
+    if (loader) red[tid - NT] = bsum4;
+    __syncthreads();
+    const int cpd = p.COB >> 2;
+    if (tid < cpd) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = tid; u < NT; u += cpd) {
+        t.x += red[u].x; t.y += red[u].y; t.z += red[u].z; t.w += red[u].w;
+      }
+      float* bp = row + (size_t)ntaps * p.CI * p.CO + co0 + 4 * tid;
+      if (co0 + 4 * tid + 3 < p.CO) { bp[0] = t.x; bp[1] = t.y; bp[2] = t.z; bp[3] = t.w; }
+    }
+  }
+}
+
+
+bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes, int target = 128) {
   const int S = p.S;
   const int img_pix = p.OH * p.OW;
-  const int TARGET = 128;
+  const int TARGET = target;
   if (img_pix <= TARGET) {
     p.NIMG = TARGET / img_pix;
     if (p.NIMG > p.B) p.NIMG = p.B;
@@ -704,10 +895,64 @@ int launch_winst(WParams& p, dim3 grid, size_t lds, void* stream) {
   return launch_winst2<TNACC, KMAX, RPWMAX, DMAX, FLAT, false, false>(p, grid, lds, stream);
 }
 
+template <int KMAX, int RPWMAX, int TSP>
+int launch_ws_inst(WParams& p, dim3 grid, size_t lds, void* stream) {
+  const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
+  p.n_batches = (rpw + RPWMAX - 1) / RPWMAX;
+  p.pipelined = 0;
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<4, KMAX, RPWMAX, 2, TSP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+#endif
+  ODIN_LAUNCH((wgrad_ws_kernel<4, KMAX, RPWMAX, 2, TSP>), grid, dim3(2 * NW_W * 64), lds, stream, p);
+  return odin_check_launch("wgrad_ws");
+}
+
+// Try the producer/consumer kernel: 64-pixel tiles, double-buffered LDS.  Returns 1 when the
+// shape does not qualify (caller falls back to the single-role kernel).
+int try_launch_ws(const WParams& p0, int* rows_out, void* stream) {
+  static int nows = -1;
+  if (nows < 0) nows = getenv("ODIN_NOWS") ? 1 : 0;
+  if (nows) return 1;
+  WParams p = p0;
+  int gx, gy, gz;
+  size_t lds1;
+  if (!plan_wgrad(p, &gx, &gy, &gz, &lds1, 64)) return 1;
+  const bool dcont = p.dvec && p.dlog >= 0 && p.DP == p.COB;
+  const int nacc = (p.nrt * p.ncot + NW_W - 1) / NW_W;
+  const int sp = p.S * p.P;
+  if (!(p.pvec && dcont && !p.flat && p.ncot == 1 && p.bias_mode != 1 && nacc <= 4 &&
+        (p.OW % 8) == 0 && p.TR * p.OW == p.slots && p.COB == 32 && p.DP == 32 && p.KI <= 9 &&
+        p.slots * 8 <= 2 * 256 && (sp == 32 || sp == 64 || sp == 128)))
+    return 1;
+  const size_t lds = (size_t)2 * (p.patch_floats + p.dy_floats) * 4;
+  if (lds > 158 * 1024 || lds < 4352) return 1;
+  if (rows_out) *rows_out = gx;
+  if (p.slab == nullptr) return 0;  // dry run
+  p.stamps = g_wstamps;
+  dim3 grid(gx, gy, gz);
+  if (p.KI <= 5) {
+    if (sp == 32) return launch_ws_inst<5, 5, 32>(p, grid, lds, stream);
+    if (sp == 64) return launch_ws_inst<5, 5, 64>(p, grid, lds, stream);
+    return launch_ws_inst<5, 5, 128>(p, grid, lds, stream);
+  }
+  if (sp == 32) return launch_ws_inst<9, 3, 32>(p, grid, lds, stream);
+  if (sp == 64) return launch_ws_inst<9, 3, 64>(p, grid, lds, stream);
+  return launch_ws_inst<9, 3, 128>(p, grid, lds, stream);
+}
+
 int launch_wgrad(WParams& p, int* rows_out, void* stream) {
   int gx, gy, gz;
   size_t lds;
   p.slab_stride = p.KH * p.KW * p.CI * p.CO + (p.want_bias ? p.CO : 0);
+  {
+    const int rc = try_launch_ws(p, rows_out, stream);
+    if (rc != 1) return rc;
+  }
   if (!plan_wgrad(p, &gx, &gy, &gz, &lds)) return odin_fail(-2, "wgrad: no tiling plan");
   if (rows_out) *rows_out = gx;
   if (p.slab == nullptr) return 0;  // dry run: planning only

@@ -53,12 +53,18 @@ def run_w(B, H, W, Ci, Co, K, S):
     L.odin_deconv2d_wgrad(x.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d), None)
     torch.cuda.synchronize()
   L.odin_debug_set_wgrad_stamps(None)
-  v = st.cpu().numpy(); v = v[v != 0]
-  ks, ts = (v >> 56), (v & ((1 << 56) - 1))
-  nm = {1: 'start', 3: 'prefetch0', 4: 'tile(mfma+top)', 5: 'commit+sync', 6: 'issue-next', 8: 'end'}
-  print(f'--- deconv wgrad B{B} {H}x{W}x{Ci}->{Co}: total {ts[-1]-ts[0]} cycles, rows {rows.value}')
-  for i in range(1, min(len(ks), 24)):
-    print(f'   {nm[int(ks[i])]:14s} +{ts[i]-ts[i-1]}')
+  va = st.cpu().numpy()
+  nm = {1: 'start', 3: 'prefetch0', 4: 'tile(mfma+top)', 5: 'commit+sync', 6: 'issue-next', 8: 'end',
+        10: 'C:phase-start', 11: 'C:mfma-done', 20: 'P:phase-start', 21: 'P:loads-issued', 22: 'P:committed'}
+  t0 = None
+  for half, lab in ((va[:32], 'consumer wave 0 / single-role'), (va[32:], 'producer wave 4')):
+    v = half[half != 0]
+    if len(v) == 0: continue
+    ks, ts = (v >> 56), (v & ((1 << 56) - 1))
+    t0 = ts[0] if t0 is None else t0
+    print(f'--- deconv wgrad B{B} {H}x{W}x{Ci}->{Co} [{lab}]: total {ts[-1]-ts[0]} cycles, rows {rows.value}')
+    for i in range(0, min(len(ks), 24)):
+      print(f'   {nm[int(ks[i])]:16s} @{ts[i]-t0:8d}  +{ts[i]-ts[i-1] if i else 0}')
 run_w(256, 32, 32, 32, 32, 4, 2)
 
 
