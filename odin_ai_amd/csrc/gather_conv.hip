@@ -63,6 +63,8 @@ __device__ __forceinline__ void stage_weights(const GParams& p, float* wl, int c
                                               int tid, int nthreads) {
   const int ntaps = p.KH * p.KW;
   constexpr int U = 8;
+  // one range-checked run over the whole weight tensor: masked items read zeros
+  const OdinRun WR = odin_run(p.w, (unsigned)((size_t)ntaps * p.CI * p.CO * 4));
   if (p.wmode == 0) {
     // global [tap][ci][co]: rows of 32 consecutive output channels
     const bool vec = ((p.CO & 3) == 0);
@@ -73,14 +75,11 @@ __device__ __forceinline__ void stage_weights(const GParams& p, float* wl, int c
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           int e = e0 + u * nthreads;
-          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (e < total) {
-            int co = (e & 7) * 4, t2 = e >> 3;
-            int ci = t2 % p.CIC, tap = t2 / p.CIC;
-            int c = c0 + ci, n = n0 + co;
-            if (c < p.CI && n < p.CO)
-              v[u] = *reinterpret_cast<const float4*>(p.w + ((size_t)tap * p.CI + c) * p.CO + n);
-          }
+          int co = (e & 7) * 4, t2 = e >> 3;
+          int ci = t2 % p.CIC, tap = t2 / p.CIC;
+          int c = c0 + ci, n = n0 + co;
+          const bool ok = e < total && c < p.CI && n < p.CO;
+          v[u] = odin_run_load4(WR, ok ? (unsigned)(((tap * p.CI + c) * p.CO + n) * 4) : ODIN_OOB);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -99,13 +98,11 @@ __device__ __forceinline__ void stage_weights(const GParams& p, float* wl, int c
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           int e = e0 + u * nthreads;
-          v[u] = 0.f;
-          if (e < total) {
-            int co = e & 31, t2 = e >> 5;
-            int ci = t2 % p.CIC, tap = t2 / p.CIC;
-            int c = c0 + ci, n = n0 + co;
-            if (c < p.CI && n < p.CO) v[u] = p.w[((size_t)tap * p.CI + c) * p.CO + n];
-          }
+          int co = e & 31, t2 = e >> 5;
+          int ci = t2 % p.CIC, tap = t2 / p.CIC;
+          int c = c0 + ci, n = n0 + co;
+          const bool ok = e < total && c < p.CI && n < p.CO;
+          v[u] = odin_run_load1(WR, ok ? (unsigned)(((tap * p.CI + c) * p.CO + n) * 4) : ODIN_OOB);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -125,14 +122,11 @@ __device__ __forceinline__ void stage_weights(const GParams& p, float* wl, int c
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           int e = e0 + u * nthreads;
-          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (e < total) {
-            int ci = (e % c4n) * 4, t2 = e / c4n;
-            int co = t2 & 31, tap = t2 >> 5;
-            int c = c0 + ci, n = n0 + co;
-            if (c < p.CI && n < p.CO)
-              v[u] = *reinterpret_cast<const float4*>(p.w + ((size_t)tap * p.CO + n) * p.CI + c);
-          }
+          int ci = (e % c4n) * 4, t2 = e / c4n;
+          int co = t2 & 31, tap = t2 >> 5;
+          int c = c0 + ci, n = n0 + co;
+          const bool ok = e < total && c < p.CI && n < p.CO;
+          v[u] = odin_run_load4(WR, ok ? (unsigned)(((tap * p.CO + n) * p.CI + c) * 4) : ODIN_OOB);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -152,13 +146,11 @@ __device__ __forceinline__ void stage_weights(const GParams& p, float* wl, int c
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           int e = e0 + u * nthreads;
-          v[u] = 0.f;
-          if (e < total) {
-            int ci = e % p.CIC, t2 = e / p.CIC;
-            int co = t2 & 31, tap = t2 >> 5;
-            int c = c0 + ci, n = n0 + co;
-            if (c < p.CI && n < p.CO) v[u] = p.w[((size_t)tap * p.CO + n) * p.CI + c];
-          }
+          int ci = e % p.CIC, t2 = e / p.CIC;
+          int co = t2 & 31, tap = t2 >> 5;
+          int c = c0 + ci, n = n0 + co;
+          const bool ok = e < total && c < p.CI && n < p.CO;
+          v[u] = odin_run_load1(WR, ok ? (unsigned)(((tap * p.CO + n) * p.CI + c) * 4) : ODIN_OOB);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -215,7 +207,7 @@ __device__ __forceinline__ LaneStage<KMAX> lane_stage_init(const GParams& p, int
     const int iw = p.iw_lo + pcol;
     const bool jv = (k < p.KI) && (j < rowlen);
     const bool ok = jv && (iw >= 0) && (iw < p.W) && (cc < p.CI);
-    L.gofs[k] = ok ? (unsigned)((iw * p.CI + cc) * 4) : 0u;
+    L.gofs[k] = ok ? (unsigned)((iw * p.CI + cc) * 4) : ODIN_OOB;
     L.ldo[k] = pcol * p.P + cc;
     if (jv) L.jmask |= 1u << k;
     if (ok) L.okmask |= 1u << k;
@@ -234,7 +226,9 @@ __device__ __forceinline__ typename StageT<VEC>::type stage_zero() {
   else return 0.f;
 }
 
-// issue the loads of patch row r of the tile starting at (b0, ih_lo); c0 = channel chunk
+// issue the loads of patch row r of the tile starting at (b0, ih_lo); c0 = channel chunk.
+// Branch-free: the row is one range-checked run (zero bytes when the row is SAME padding or
+// beyond the batch), padding lanes carry an out-of-range offset.
 template <int KMAX, bool VEC>
 __device__ __forceinline__ void stage_row_issue(const GParams& p, const LaneStage<KMAX>& L, int r,
                                                 int b0, int ih_lo, int c0,
@@ -243,38 +237,42 @@ __device__ __forceinline__ void stage_row_issue(const GParams& p, const LaneStag
   const int prow = r - img * p.NRI;
   const int b = b0 + img, ih = ih_lo + prow;
   const bool row_ok = (b < p.B) && (ih >= 0) && (ih < p.H);
-  const char* rowp = reinterpret_cast<const char*>(p.in) +
-                     ((size_t)((b * p.H + ih) * p.W) * p.CI + c0) * 4;
+  const float* rowp = p.in + (row_ok ? ((size_t)((b * p.H + ih) * p.W) * p.CI + c0) : (size_t)0);
+  const OdinRun R = odin_run(rowp, row_ok ? (unsigned)((p.W * p.CI - c0) * 4) : 0u);
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
-    v[k] = stage_zero<VEC>();
-    bool ok = row_ok && ((L.okmask >> k) & 1u);
-    if (c0 != 0) ok = ok && (c0 + (int)((L.gofs[k] >> 2) % (unsigned)p.CI) < p.CI);
-    if (ok) {
-      if constexpr (VEC) {
-        float4 t = *reinterpret_cast<const float4*>(rowp + L.gofs[k]);
-        if (p.center) t = center4(t);
-        v[k] = t;
-      } else {
-        float t = *reinterpret_cast<const float*>(rowp + L.gofs[k]);
-        if (p.center) t = 2.f * t - 1.f;
-        v[k] = t;
-      }
-    }
+    unsigned off = L.gofs[k];
+    // ragged last channel chunk: lanes beyond the real channels read zeros
+    if (c0 != 0 && c0 + (int)((off >> 2) % (unsigned)p.CI) >= p.CI) off = ODIN_OOB;
+    if constexpr (VEC) v[k] = odin_run_load4(R, off);
+    else v[k] = odin_run_load1(R, off);
   }
 }
 
 template <int KMAX, bool VEC>
 __device__ __forceinline__ void stage_row_commit(const GParams& p, const LaneStage<KMAX>& L, int r,
+                                                 int b0, int ih_lo,
                                                  const typename StageT<VEC>::type* v,
                                                  float* patch) {
   float* rowl = patch + r * p.PW * p.P;
+  bool cen = false;
+  if (p.center) {  // CenterAt0 folded into the first layer: real pixels only, padding stays 0
+    const int img = (p.NIMG == 1) ? 0 : r / p.NRI;
+    const int prow = r - img * p.NRI;
+    const int b = b0 + img, ih = ih_lo + prow;
+    cen = (b < p.B) && (ih >= 0) && (ih < p.H);
+  }
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     if ((L.jmask >> k) & 1u) {
       float* d = rowl + L.ldo[k];
-      if constexpr (VEC) { d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w; }
-      else d[0] = v[k];
+      typename StageT<VEC>::type t = v[k];
+      if (cen && ((L.okmask >> k) & 1u)) {
+        if constexpr (VEC) t = center4(t);
+        else t = 2.f * t - 1.f;
+      }
+      if constexpr (VEC) { d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
+      else d[0] = t;
     }
   }
 }
@@ -290,19 +288,19 @@ __device__ __forceinline__ void stage_issue(const GParams& p, const LaneStage<KM
   if constexpr (FLAT) {
     const int cpi = VEC ? (p.CIC >> 2) : p.CIC;
     const int total = p.NIMG * cpi;
+    // the tile's input is the contiguous block in[b0 .. B)[CI]; samples beyond the batch fall
+    // outside the run and read zeros
+    const long left = ((long)(p.B - b0) * p.CI - c0) * 4;
+    const OdinRun R = odin_run(p.in + (b0 < p.B ? (size_t)b0 * p.CI + c0 : (size_t)0),
+                               left <= 0 ? 0u : (left > 0x7FFFFFF0L ? 0x7FFFFFF0u : (unsigned)left));
 #pragma unroll
     for (int i = 0; i < PFN; ++i) {
       const int e = (batch * PFN + i) * NT + tid;
-      pf[i] = stage_zero<VEC>();
-      if (e < total) {
-        const int img = e / cpi;
-        const int cc = (e - img * cpi) * (VEC ? 4 : 1);
-        if (b0 + img < p.B && c0 + cc < p.CI) {
-          const float* src = p.in + (size_t)(b0 + img) * p.CI + c0 + cc;
-          if constexpr (VEC) pf[i] = *reinterpret_cast<const float4*>(src);
-          else pf[i] = src[0];
-        }
-      }
+      const int img = e / cpi;
+      const int cc = (e - img * cpi) * (VEC ? 4 : 1);
+      const unsigned off = (e < total && c0 + cc < p.CI) ? (unsigned)((img * p.CI + cc) * 4) : ODIN_OOB;
+      if constexpr (VEC) pf[i] = odin_run_load4(R, off);
+      else pf[i] = odin_run_load1(R, off);
     }
   } else {
     const int nrows_p = p.NIMG * p.NRI;
@@ -316,7 +314,7 @@ __device__ __forceinline__ void stage_issue(const GParams& p, const LaneStage<KM
 
 template <int KMAX, int RPWMAX, bool VEC, int NW, bool FLAT>
 __device__ __forceinline__ void stage_commit(const GParams& p, const LaneStage<KMAX>& LS, int wave,
-                                             int tid, int batch,
+                                             int tid, int batch, int b0, int ih_lo,
                                              const typename StageT<VEC>::type* pf, float* patch) {
   constexpr int PFN = KMAX * RPWMAX, NT = NW * 64;
   if constexpr (FLAT) {
@@ -338,7 +336,7 @@ __device__ __forceinline__ void stage_commit(const GParams& p, const LaneStage<K
 #pragma unroll
     for (int q = 0; q < RPWMAX; ++q) {
       const int r = batch * NW * RPWMAX + wave + NW * q;
-      if (r < nrows_p) stage_row_commit<KMAX, VEC>(p, LS, r, pf + q * KMAX, patch);
+      if (r < nrows_p) stage_row_commit<KMAX, VEC>(p, LS, r, b0, ih_lo, pf + q * KMAX, patch);
     }
   }
 }
@@ -642,7 +640,7 @@ void gather_conv_kernel(GParams p, TailParams tp) {
     slot_set_tile(p, s1, gr0);
     if (pipelined) {
       __syncthreads();  // everyone is done reading the previous patch
-      stage_commit<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, 0, pf, patch);
+      stage_commit<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, 0, b0, ih_lo, pf, patch);
       __syncthreads();
       ODIN_STAMP(5);
       const int nt = tile + gridDim.x;
@@ -662,7 +660,7 @@ void gather_conv_kernel(GParams p, TailParams tp) {
         __syncthreads();
         for (int bt = 0; bt < p.n_batches; ++bt) {  // KMAX*RPWMAX items per thread in flight
           stage_issue<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, bt, b0, ih_lo, c0, pf);
-          stage_commit<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, bt, pf, patch);
+          stage_commit<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, bt, b0, ih_lo, pf, patch);
         }
         if (!p.w_resident) stage_weights(p, wl, c0, n0, tid, NT);
         __syncthreads();

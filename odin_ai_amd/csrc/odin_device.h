@@ -55,6 +55,56 @@ __device__ __forceinline__ f32x16 f32x16_zero() {
   return z;
 }
 
+// Range-checked staging loads.  A run of HBM (one patch row, one DY tile, a weight slice) is
+// described by a wave-uniform (base, valid bytes) pair; a lane whose byte offset falls outside
+// [0, bytes) reads zeros (give masked lanes the offset ODIN_OOB).  On gfx950 this is a buffer
+// descriptor + buffer_load with the hardware range check: no exec-mask branch and no zero
+// pre-initialisation around the load, so every load of a tile issues back to back and nothing
+// makes the compiler drain vmcnt early (branchy `if (ok) v = *p` staging serialised one memory
+// latency per patch row).
+#define ODIN_OOB 0x7FFFFFF0u
+struct OdinRun {
+#ifdef ODIN_SIM
+  const char* base;
+  unsigned bytes;
+#else
+  __amdgpu_buffer_rsrc_t r;
+#endif
+};
+__device__ __forceinline__ OdinRun odin_run(const void* base, unsigned bytes) {
+  OdinRun R;
+#ifdef ODIN_SIM
+  R.base = (const char*)base;
+  R.bytes = bytes;
+#else
+  const unsigned long long a = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* pu = (void*)(((unsigned long long)hi << 32) | lo);
+  R.r = __builtin_amdgcn_make_buffer_rsrc(pu, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+#endif
+  return R;
+}
+__device__ __forceinline__ float4 odin_run_load4(const OdinRun& R, unsigned off) {
+#ifdef ODIN_SIM
+  if ((unsigned long long)off + 16 > R.bytes) return make_float4(0.f, 0.f, 0.f, 0.f);
+  return *reinterpret_cast<const float4*>(R.base + off);
+#else
+  typedef unsigned int odin_u32x4 __attribute__((ext_vector_type(4)));
+  const odin_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(R.r, off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                     __uint_as_float(v.w));
+#endif
+}
+__device__ __forceinline__ float odin_run_load1(const OdinRun& R, unsigned off) {
+#ifdef ODIN_SIM
+  if ((unsigned long long)off + 4 > R.bytes) return 0.f;
+  return *reinterpret_cast<const float*>(R.base + off);
+#else
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R.r, off, 0, 0));
+#endif
+}
+
 enum { ODIN_ACT_LINEAR = 0, ODIN_ACT_ELU = 1, ODIN_ACT_RELU = 2 };
 
 __device__ __forceinline__ float odin_act(int act, float v) {

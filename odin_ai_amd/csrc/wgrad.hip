@@ -77,7 +77,7 @@ __device__ __forceinline__ WLane<KMAX> wlane_init(const WParams& p, int lane, in
     const int iw = pcol - p.pl;
     const bool jv = (k < p.KI) && (j < rowlen);
     const bool ok = jv && (iw >= 0) && (iw < p.W) && (cc < cib);
-    L.gofs[k] = ok ? (unsigned)((iw * p.CI + cc) * 4) : 0u;
+    L.gofs[k] = ok ? (unsigned)((iw * p.CI + cc) * 4) : ODIN_OOB;
     L.ldo[k] = pcol * p.P + cc;
     if (jv) L.jmask |= 1u << k;
     if (ok) L.okmask |= 1u << k;
@@ -85,6 +85,8 @@ __device__ __forceinline__ WLane<KMAX> wlane_init(const WParams& p, int lane, in
   return L;
 }
 
+// Branch-free row staging (odin_device.h, OdinRun): a patch row is one range-checked run, zero
+// bytes long when the row is SAME padding or beyond the batch.
 template <int KMAX, bool PVEC>
 __device__ __forceinline__ void wrow_issue(const WParams& p, const WLane<KMAX>& L, int r, int b0,
                                            int ih_lo, int ci0, float4* v) {
@@ -92,29 +94,34 @@ __device__ __forceinline__ void wrow_issue(const WParams& p, const WLane<KMAX>& 
   const int prow = r - img * p.NRI;
   const int b = b0 + img, ih = ih_lo + prow;
   const bool row_ok = (b < p.B) && (ih >= 0) && (ih < p.H);
-  const char* rowp = reinterpret_cast<const char*>(p.in) +
-                     ((size_t)((b * p.H + ih) * p.W) * p.CI + ci0) * 4;
+  const float* rowp = p.in + (row_ok ? ((size_t)((b * p.H + ih) * p.W) * p.CI + ci0) : (size_t)0);
+  const OdinRun R = odin_run(rowp, row_ok ? (unsigned)((p.W * p.CI - ci0) * 4) : 0u);
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row_ok && ((L.okmask >> k) & 1u)) {
-      if constexpr (PVEC) t = *reinterpret_cast<const float4*>(rowp + L.gofs[k]);
-      else t.x = *reinterpret_cast<const float*>(rowp + L.gofs[k]);
-      if (p.center) t = make_float4(2.f * t.x - 1.f, 2.f * t.y - 1.f, 2.f * t.z - 1.f, 2.f * t.w - 1.f);
-    }
-    v[k] = t;
+    if constexpr (PVEC) v[k] = odin_run_load4(R, L.gofs[k]);
+    else v[k] = make_float4(odin_run_load1(R, L.gofs[k]), 0.f, 0.f, 0.f);
   }
 }
 
 template <int KMAX, bool PVEC>
-__device__ __forceinline__ void wrow_commit(const WParams& p, const WLane<KMAX>& L, int r,
-                                            const float4* v, float* patch) {
+__device__ __forceinline__ void wrow_commit(const WParams& p, const WLane<KMAX>& L, int r, int b0,
+                                            int ih_lo, const float4* v, float* patch) {
   float* rowl = patch + r * p.PW * p.P;
+  bool cen = false;
+  if (p.center) {  // CenterAt0 on real pixels only (padding stays 0)
+    const int img = (p.NIMG == 1) ? 0 : r / p.NRI;
+    const int prow = r - img * p.NRI;
+    const int b = b0 + img, ih = ih_lo + prow;
+    cen = (b < p.B) && (ih >= 0) && (ih < p.H);
+  }
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     if ((L.jmask >> k) & 1u) {
-      if constexpr (PVEC) *reinterpret_cast<float4*>(rowl + L.ldo[k]) = v[k];
-      else rowl[L.ldo[k]] = v[k].x;
+      float4 t = v[k];
+      if (cen && ((L.okmask >> k) & 1u))
+        t = make_float4(2.f * t.x - 1.f, 2.f * t.y - 1.f, 2.f * t.z - 1.f, 2.f * t.w - 1.f);
+      if constexpr (PVEC) *reinterpret_cast<float4*>(rowl + L.ldo[k]) = t;
+      else rowl[L.ldo[k]] = t.x;
     }
   }
 }
@@ -127,20 +134,17 @@ __device__ __forceinline__ void wpatch_issue(const WParams& p, const WLane<KMAX>
   if constexpr (FLAT) {
     const int cpi = PVEC ? (p.P >> 2) : p.P;
     const int total = p.NIMG * cpi;
+    const long left = ((long)(p.B - b0) * p.CI - ci0) * 4;
+    const OdinRun R = odin_run(p.in + (b0 < p.B ? (size_t)b0 * p.CI + ci0 : (size_t)0),
+                               left <= 0 ? 0u : (left > 0x7FFFFFF0L ? 0x7FFFFFF0u : (unsigned)left));
 #pragma unroll
     for (int i = 0; i < PFN; ++i) {
       const int e = (batch * PFN + i) * NT + tid;
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < total) {
-        const int img = e / cpi;
-        const int cc = (e - img * cpi) * (PVEC ? 4 : 1);
-        if (b0 + img < p.B && cc < cib) {
-          const float* src = p.in + (size_t)(b0 + img) * p.CI + ci0 + cc;
-          if constexpr (PVEC) t = *reinterpret_cast<const float4*>(src);
-          else t.x = src[0];
-        }
-      }
-      pf[i] = t;
+      const int img = e / cpi;
+      const int cc = (e - img * cpi) * (PVEC ? 4 : 1);
+      const unsigned off = (e < total && cc < cib) ? (unsigned)((img * p.CI + cc) * 4) : ODIN_OOB;
+      if constexpr (PVEC) pf[i] = odin_run_load4(R, off);
+      else pf[i] = make_float4(odin_run_load1(R, off), 0.f, 0.f, 0.f);
     }
   } else {
     const int nrows_p = p.NIMG * p.NRI;
@@ -154,7 +158,8 @@ __device__ __forceinline__ void wpatch_issue(const WParams& p, const WLane<KMAX>
 
 template <int KMAX, int RPWMAX, bool FLAT, bool PVEC>
 __device__ __forceinline__ void wpatch_commit(const WParams& p, const WLane<KMAX>& L, int wave,
-                                              int tid, int batch, const float4* pf, float* patch) {
+                                              int tid, int batch, int b0, int ih_lo,
+                                              const float4* pf, float* patch) {
   constexpr int PFN = KMAX * RPWMAX, NT = NW_W * 64;
   if constexpr (FLAT) {
     const int cpi = PVEC ? (p.P >> 2) : p.P;
@@ -174,7 +179,7 @@ __device__ __forceinline__ void wpatch_commit(const WParams& p, const WLane<KMAX
 #pragma unroll
     for (int q = 0; q < RPWMAX; ++q) {
       const int r = batch * NW_W * RPWMAX + wave + NW_W * q;
-      if (r < nrows_p) wrow_commit<KMAX, PVEC>(p, L, r, pf + q * KMAX, patch);
+      if (r < nrows_p) wrow_commit<KMAX, PVEC>(p, L, r, b0, ih_lo, pf + q * KMAX, patch);
     }
   }
 }
@@ -187,38 +192,36 @@ __device__ __forceinline__ void wdy_issue(const WParams& p, int gr0, int co0, in
     // with COB == CO the tile's DY rows are one contiguous float4 run
     const int lg = p.dlog, cpd = 1 << lg;
     const int total = p.TR * p.OW * cpd;
-    const long lim = ((long)p.B * p.OH * p.OW - (long)gr0 * p.OW) * cpd;  // items left in the tensor
-    const float* src0 = p.dy + (size_t)gr0 * p.OW * p.CO + co0;
+    // run = the rest of the DY tensor from this tile's first pixel: rows beyond the tensor
+    // (ragged last tile) fall outside it and read zeros
+    const long left = (((long)p.B * p.OH * p.OW - (long)gr0 * p.OW) * p.CO - co0) * 4;
+    const OdinRun R = odin_run(p.dy + (left > 0 ? (size_t)gr0 * p.OW * p.CO + co0 : (size_t)0),
+                               left <= 0 ? 0u : (left > 0x7FFFFFF0L ? 0x7FFFFFF0u : (unsigned)left));
 #pragma unroll
     for (int i = 0; i < DMAX; ++i) {
       const int e = tid + i * NT;
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       const int cl = (e & (cpd - 1)) << 2;
-      if (e < total && e < lim && co0 + cl < p.CO)  // channel groups beyond CO stay zero
-        t = *reinterpret_cast<const float4*>(src0 + (size_t)(e >> lg) * p.CO + cl);
-      v[i] = t;
+      // channel groups beyond CO stay zero
+      const bool ok = e < total && co0 + cl < p.CO;
+      v[i] = odin_run_load4(R, ok ? (unsigned)(((e >> lg) * p.CO + cl) * 4) : ODIN_OOB);
     }
     return;
   }
   const int cpd = p.dvec ? (p.COB >> 2) : p.COB;
   const int total = p.slots * cpd;
-  const long total_pix = (long)p.B * p.OH * p.OW;
-  const long pix0 = (long)gr0 * p.OW;
   const int real_slots = p.TR * p.OW;
+  const long left = (((long)p.B * p.OH * p.OW - (long)gr0 * p.OW) * p.CO - co0) * 4;
+  const OdinRun R = odin_run(p.dy + (left > 0 ? (size_t)gr0 * p.OW * p.CO + co0 : (size_t)0),
+                             left <= 0 ? 0u : (left > 0x7FFFFFF0L ? 0x7FFFFFF0u : (unsigned)left));
 #pragma unroll
   for (int i = 0; i < DMAX; ++i) {
     const int e = tid + i * NT;
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < total) {
-      const int sl = e / cpd;
-      const int cl = (e - sl * cpd) * (p.dvec ? 4 : 1);
-      if (sl < real_slots && pix0 + sl < total_pix && co0 + cl < p.CO) {
-        const float* src = p.dy + (size_t)(pix0 + sl) * p.CO + co0 + cl;
-        if (p.dvec) t = *reinterpret_cast<const float4*>(src);
-        else t.x = src[0];
-      }
-    }
-    v[i] = t;
+    const int sl = e / cpd;
+    const int cl = (e - sl * cpd) * (p.dvec ? 4 : 1);
+    const bool ok = e < total && sl < real_slots && co0 + cl < p.CO;
+    const unsigned off = ok ? (unsigned)((sl * p.CO + cl) * 4) : ODIN_OOB;
+    if (p.dvec) v[i] = odin_run_load4(R, off);
+    else v[i] = make_float4(odin_run_load1(R, off), 0.f, 0.f, 0.f);
   }
 }
 
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     const int ih_lo = oh0 * p.S - p.pt;
     __syncthreads();
     if (pipelined) {
-      wpatch_commit<KMAX, RPWMAX, FLAT, PVEC>(p, WL, wave, tid, 0, pf, patch);
+      wpatch_commit<KMAX, RPWMAX, FLAT, PVEC>(p, WL, wave, tid, 0, b0, ih_lo, pf, patch);
       wdy_commit<DMAX, NT, DCONT>(p, tid, df, dyl, bsum4);
       __syncthreads();
       W_STAMP(5);
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     } else {
       for (int bt = 0; bt < p.n_batches; ++bt) {
         wpatch_issue<KMAX, RPWMAX, FLAT, PVEC>(p, WL, wave, tid, bt, b0, ih_lo, ci0, cib, pf);
-        wpatch_commit<KMAX, RPWMAX, FLAT, PVEC>(p, WL, wave, tid, bt, pf, patch);
+        wpatch_commit<KMAX, RPWMAX, FLAT, PVEC>(p, WL, wave, tid, bt, b0, ih_lo, pf, patch);
       }
       const int cpd = p.dvec ? (p.COB >> 2) : p.COB;
       for (int e0 = 0; e0 < p.slots * cpd; e0 += NT * DMAX) {
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(2 * NW_W * 64) void wgrad_ws_kernel(WParams p) {
         for (int bt = 0; bt < p.n_batches; ++bt) {
           wpatch_issue<KMAX, RPWMAX, false, true>(p, WL, lw, ltid, bt, b0, ih_lo, ci0, cib, pf);
           if (lw == 0) WS_STAMP(32, 21);
-          wpatch_commit<KMAX, RPWMAX, false, true>(p, WL, lw, ltid, bt, pf, patch);
+          wpatch_commit<KMAX, RPWMAX, false, true>(p, WL, lw, ltid, bt, b0, ih_lo, pf, patch);
         }
         wdy_commit<DMAX, NT, true>(p, ltid, df, dyl, bsum4);
         if (lw == 0) WS_STAMP(32, 22);
