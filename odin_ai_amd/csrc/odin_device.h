@@ -105,6 +105,26 @@ __device__ __forceinline__ float odin_run_load1(const OdinRun& R, unsigned off) 
 #endif
 }
 
+// LDS-DMA: every active lane moves 16 bytes from the run straight into LDS at
+// lds_base + lane*16 (lds_base wave-uniform, 16-byte aligned); no VGPR destination, no ds_write.
+// Completion is tracked by the issuing wave's vmcnt.  Never issued with out-of-range offsets
+// (mask those lanes off instead).
+__device__ __forceinline__ void odin_run_dma16(const OdinRun& R, float* lds_base, unsigned off,
+                                               int lane) {
+#ifdef ODIN_SIM
+  *reinterpret_cast<float4*>(lds_base + 4 * lane) = odin_run_load4(R, off);
+#else
+  (void)lane;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(
+      R.r, (__attribute__((address_space(3))) void*)lds_base, 16, off, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ void odin_wait_vmem() {
+#ifndef ODIN_SIM
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 enum { ODIN_ACT_LINEAR = 0, ODIN_ACT_ELU = 1, ODIN_ACT_RELU = 2 };
 
 __device__ __forceinline__ float odin_act(int act, float v) {

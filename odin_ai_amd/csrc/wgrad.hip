@@ -22,6 +22,9 @@
 #include "odin_internal.h"
 #include <cstdlib>
 
+// 16 KB of zeros in HBM: the DMA source for SAME-padding rows
+__device__ float odin_zero_row[4096];
+
 namespace {
 
 constexpr int NW_W = 4;
@@ -594,7 +597,10 @@ template <int TNACC, int KMAX, int RPWMAX, int DMAX, int TSP>
 __global__ __launch_bounds__(2 * NW_W * 64) void wgrad_ws_kernel(WParams p) {
   ODIN_DYN_SMEM(float, smem);
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = W_UNIFORM(tid >> 6);
+  // producers are waves 0-3 (dispatched first = older: VALU/LDS issue arbitration on a SIMD goes
+  // by age), consumers waves 4-7
+  const int wave_hw = W_UNIFORM(tid >> 6);
+  const int wave = wave_hw ^ NW_W;  // role index: 0-3 consumer, 4-7 producer
   const int l31 = lane & 31, h = lane >> 5;
   constexpr int NT = NW_W * 64;  // threads per role
   const bool loader = wave >= NW_W;
@@ -607,46 +613,99 @@ __global__ __launch_bounds__(2 * NW_W * 64) void wgrad_ws_kernel(WParams p) {
   const int n_my = ((int)blockIdx.x < p.n_tiles)
                        ? (p.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  f32x16 acc[TNACC];
-#pragma unroll
-  for (int a = 0; a < TNACC; ++a) acc[a] = f32x16_zero();
   int stamp_i = 0;
   (void)stamp_i;
+  float* row = p.slab + (size_t)blockIdx.x * p.slab_stride;
+  // SAME-padding columns / unused channel slots of both buffers are zero for the whole kernel
+  for (int e = tid; e < (2 * buf_floats) >> 2; e += 2 * NT)
+    reinterpret_cast<float4*>(smem)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
 
   if (loader) {
-    // ---------------- producer waves ----------------
-    const int lw = wave - NW_W, ltid = tid - NT;
-#ifndef ODIN_SIM
-    // VALU issue on a SIMD is arbitrated by priority, then age: as the younger wave the
-    // producer would only get the slots the MFMA wave leaves over (measured: its ~300
-    // staging instructions took 10.9k cycles instead of 2.6k) and the consumer then waits
-    // at the barrier.  Static priority for the producer half.
-    __builtin_amdgcn_s_setprio(2);
-#endif
-    const WLane<KMAX> WL = wlane_init<KMAX>(p, lane, cib);
+    // ---------------- producer waves: LDS-DMA ----------------
+    // (staging through registers starves under the consumers' MFMA stream: the ds_write pass of
+    // one tile took ~10k cycles beside it, 2.6k alone.)  The patch row span that holds real
+    // pixels, columns [pl, pl + W), is contiguous in LDS, so a row is ceil(W*P/256) DMA
+    // instructions; SAME-padding columns and channel slots beyond the block are zeroed once
+    // (nothing ever writes them), SAME-padding rows are DMA'd from a zero row.
+    const int lw = wave - NW_W, ltid = tid;
+    const int c4n = p.P >> 2;                 // 16-byte pieces per pixel
+    const int npieces = p.W * c4n;            // pieces of the real-pixel span of a row
+    unsigned gofs[KMAX];
+    bool gok[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      const int j = lane + 64 * i;
+      const int iw = j / c4n, cc = (j - iw * c4n) * 4;
+      gok[i] = j < npieces && cc < cib;
+      gofs[i] = (unsigned)((iw * p.CI + cc) * 4);
+    }
+    const OdinRun ZR = odin_run(odin_zero_row, (unsigned)sizeof(odin_zero_row));
+    const int span0 = p.pl * p.P;  // float offset of the span inside a patch row
     for (int k = 0; k <= n_my; ++k) {
       if (lw == 0) WS_STAMP(32, 20);
       if (k < n_my) {
-        const int tile = blockIdx.x + k * gridDim.x;
         float* patch = smem + (k & 1) * buf_floats;
         float* dyl = patch + p.patch_floats;
-        const int gr0 = tile * p.TR;
-        const int b0 = gr0 / p.OH, oh0 = gr0 - b0 * p.OH;
-        const int ih_lo = oh0 * p.S - p.pt;
-        float4 pf[RPWMAX * KMAX], df[DMAX];
-        wdy_issue<DMAX, NT, true>(p, gr0, co0, ltid, df);
-        for (int bt = 0; bt < p.n_batches; ++bt) {
-          wpatch_issue<KMAX, RPWMAX, false, true>(p, WL, lw, ltid, bt, b0, ih_lo, ci0, cib, pf);
-          if (lw == 0) WS_STAMP(32, 21);
-          wpatch_commit<KMAX, RPWMAX, false, true>(p, WL, lw, ltid, bt, b0, ih_lo, pf, patch);
+        const int gr0 = (blockIdx.x + k * gridDim.x) * p.TR;
+        const int b0 = gr0 / p.OH;
+        const int ih_lo = (gr0 - b0 * p.OH) * p.S - p.pt;
+        // DY rows of the tile: slots * 8 pieces, lane-linear
+        {
+          const OdinRun RD = odin_run(p.dy + (size_t)gr0 * p.OW * p.CO + co0,
+                                      (unsigned)((p.TR * p.OW * p.CO - co0) * 4));
+#pragma unroll
+          for (int i = 0; i < DMAX; ++i) {
+            const int j = i * NT + lw * 64 + lane;
+            if (j < p.slots * 8)
+              odin_run_dma16(RD, dyl + (i * NT + lw * 64) * 4,
+                             (unsigned)(((j >> 3) * p.CO + (j & 7) * 4) * 4), lane);
+          }
         }
-        wdy_commit<DMAX, NT, true>(p, ltid, df, dyl, bsum4);
+#pragma unroll
+        for (int q = 0; q < RPWMAX; ++q) {
+          const int r = lw + NW_W * q;
+          if (r < p.NRI) {
+            const int ih = ih_lo + r;
+            const bool row_ok = (ih >= 0) && (ih < p.H);
+            float* dst = patch + r * p.PW * p.P + span0;
+            if (row_ok) {
+              const OdinRun R = odin_run(p.in + ((size_t)((b0 * p.H + ih) * p.W) * p.CI + ci0),
+                                         (unsigned)((p.W * p.CI - ci0) * 4));
+#pragma unroll
+              for (int i = 0; i < KMAX; ++i)
+                if (gok[i]) odin_run_dma16(R, dst + i * 256, gofs[i], lane);
+            } else {
+#pragma unroll
+              for (int i = 0; i < KMAX; ++i)
+                if (gok[i]) odin_run_dma16(ZR, dst + i * 256, (unsigned)((lane + 64 * i) * 16), lane);
+            }
+          }
+        }
+        if (lw == 0) WS_STAMP(32, 21);
+        if (p.bias_mode == 2) {
+          // bias gradient: read this thread's DY pieces back once they have landed
+          odin_wait_vmem();
+#pragma unroll
+          for (int i = 0; i < DMAX; ++i) {
+            const int j = i * NT + ltid;
+            if (j < p.slots * 8) {
+              const float4 t = reinterpret_cast<const float4*>(dyl)[j];
+              bsum4.x += t.x; bsum4.y += t.y; bsum4.z += t.z; bsum4.w += t.w;
+            }
+          }
+        }
         if (lw == 0) WS_STAMP(32, 22);
       }
       __syncthreads();
     }
   } else {
     // ---------------- consumer waves ----------------
+    // (the accumulators live only in this role: the producer's staging registers and the
+    // consumer's accumulators then share the 256-register budget of a 2-waves-per-SIMD kernel)
+    f32x16 acc[TNACC];
+#pragma unroll
+    for (int a = 0; a < TNACC; ++a) acc[a] = f32x16_zero();
     int a_off[TNACC];
 #pragma unroll
     for (int a = 0; a < TNACC; ++a) {
@@ -724,10 +783,6 @@ __global__ __launch_bounds__(2 * NW_W * 64) void wgrad_ws_kernel(WParams p) {
       }
       __syncthreads();
     }
-  }
-
-  float* row = p.slab + (size_t)blockIdx.x * p.slab_stride;
-  if (!loader) {
 #pragma unroll
     for (int a = 0; a < TNACC; ++a) {
       const int T = wave + a * NW_W;
@@ -747,7 +802,7 @@ __global__ __launch_bounds__(2 * NW_W * 64) void wgrad_ws_kernel(WParams p) {
   if (p.bias_mode == 2 && blockIdx.y == 0) {
     // producer thread t accumulated channels 4*(t % cpd) .. +3 while staging DY
     float4* red = reinterpret_cast<float4*>(smem);
-    if (loader) red[tid - NT] = bsum4;
+    if (loader) red[tid] = bsum4;
     __syncthreads();
     const int cpd = p.COB >> 2;
     if (tid < cpd) {
@@ -902,7 +957,12 @@ template <int KMAX, int RPWMAX, int TSP>
 int launch_ws_inst(WParams& p, dim3 grid, size_t lds, void* stream) {
   const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
   p.n_batches = (rpw + RPWMAX - 1) / RPWMAX;
-  p.pipelined = 0;
+  if (p.n_batches != 1 || p.KI > KMAX) return 1;  // not this instance: single-role kernel
+  // one image per tile, whole tiles only (no ragged batch end), zero row long enough
+  if (p.NIMG != 1 || (p.OH % p.TR) != 0 || (size_t)p.W * p.P * 4 > 16384 || p.pl < 0 ||
+      (p.CO % 32) != 0)
+    return 1;
+  p.pipelined = 1;
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
@@ -934,6 +994,11 @@ int try_launch_ws(const WParams& p0, int* rows_out, void* stream) {
     return 1;
   const size_t lds = (size_t)2 * (p.patch_floats + p.dy_floats) * 4;
   if (lds > 158 * 1024 || lds < 4352) return 1;
+  {
+    const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
+    const int rmax = p.KI <= 5 ? 5 : 3;
+    if (rpw > rmax) return 1;  // more than one staging batch per tile
+  }
   if (rows_out) *rows_out = gx;
   if (p.slab == nullptr) return 0;  // dry run
   p.stamps = g_wstamps;

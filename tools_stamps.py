@@ -55,7 +55,7 @@ def run_w(B, H, W, Ci, Co, K, S):
   L.odin_debug_set_wgrad_stamps(None)
   va = st.cpu().numpy()
   nm = {1: 'start', 3: 'prefetch0', 4: 'tile(mfma+top)', 5: 'commit+sync', 6: 'issue-next', 8: 'end',
-        10: 'C:phase-start', 11: 'C:mfma-done', 20: 'P:phase-start', 21: 'P:loads-issued', 22: 'P:committed'}
+        10: 'C:phase-start', 11: 'C:mfma-done', 20: 'P:phase-start', 21: 'P:loads-issued', 22: 'P:committed', 23: 'P:data-arrived'}
   t0 = None
   for half, lab in ((va[:32], 'consumer wave 0 / single-role'), (va[32:], 'producer wave 4')):
     v = half[half != 0]
