@@ -151,6 +151,17 @@ class NetProgram:
     self.wrows = [0] * len(recs)
     self.bslabs: List[Optional[torch.Tensor]] = [None] * len(recs)  # deconv bias (colsum)
     self.brows = [0] * len(recs)
+    # layers whose weight gradient is a small launch (few workgroups, long per-workgroup
+    # latency): these can run beside the data-gradient chain on a side stream
+    self.small_wgrad = []
+    for r in recs:
+      if r.desc is not None:
+        d = r.desc
+        mac = B * (d['OH'] * d['OW'] if r.kind == 'conv' else d['H'] * d['W']) * d['K'] ** 2 * \
+            d['Cin'] * d['Cout']
+      else:
+        mac = B * r.K * r.N
+      self.small_wgrad.append(2 * mac < 0.8e9)
     self._plan_slabs()
 
   # -- planning (dry runs report how many slab rows each call will write) --------------
@@ -222,7 +233,7 @@ class NetProgram:
       # ---- weight (and bias) gradient: independent of the data-gradient chain, so it is
       # issued on the side stream (fork) and overlaps the next layers' data-gradients ----
       slab = self.wslabs[i]
-      wst = st if fork is None else fork(i)
+      wst = st if (fork is None or not fork.wants(self.small_wgrad[i])) else fork(i)
       if data_only:
         pass
       elif r.kind == 'conv':
@@ -363,10 +374,15 @@ class VAEEngine:
     self.hyper = torch.zeros(N_HYPER + 4, **f32)
     self.step_count = 0
     self.side_stream = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
+    n_side = int(__import__('os').environ.get('ODIN_SIDE_STREAMS', '2'))
+    self.side_streams = ([self.side_stream] + [torch.cuda.Stream(self.device) for _ in range(n_side - 1)]
+                         if self.side_stream is not None else [])
     import os as _os
-    # weight gradients on a side stream: measured neutral-to-negative on MI355X (the kernels
-    # are LDS-limited to one workgroup per CU and contend), so it is opt-in
-    self.overlap_wgrad = _os.environ.get('ODIN_OVERLAP_WGRAD', '0') == '1'
+    # weight gradients on a side stream.  'all': measured neutral-to-negative on MI355X (the
+    # big kernels are LDS-limited to one workgroup per CU and contend); 'small': only the
+    # launches that leave most CUs idle (bottleneck layers) run beside the data-gradient chain
+    self.overlap_wgrad = {'0': None, '1': 'all', 'all': 'all', 'small': 'small'}.get(
+        _os.environ.get('ODIN_OVERLAP_WGRAD', 'small'), None)
     self.graph = None
     self._jobs_keepalive = None
 
@@ -557,16 +573,23 @@ class VAEEngine:
     if self.side_stream is None or not self.overlap_wgrad:
       return None, (lambda: None)
     cur = torch.cuda.current_stream(self.device)
-    side = self.side_stream
+    sides = self.side_streams
+    mode = self.overlap_wgrad
+    nxt = [0]
 
     def fork(i):
+      side = sides[nxt[0] % len(sides)]  # round robin: small launches also overlap each other
+      nxt[0] += 1
       ev = torch.cuda.Event()
       ev.record(cur)
       side.wait_event(ev)
       return side.cuda_stream
 
+    fork.wants = lambda small: mode == 'all' or small
+
     def join():
-      cur.wait_stream(side)
+      for side in sides:
+        cur.wait_stream(side)
 
     return fork, join
 
@@ -600,7 +623,7 @@ class VAEEngine:
     h_e = self.enc.outs[-1]
     rows = C.c_int(0)
     lib.odin_dense_wgrad(h_e.data_ptr(), self.dp.data_ptr(), self.lat_slab.data_ptr(),
-                         C.byref(rows), B, self.hdim, 2 * D, st if fork is None else fork(-1))
+                         C.byref(rows), B, self.hdim, 2 * D, st if fork is None else fork(-1))  # small
     jobs.append(ReduceJob(self.lat_slab.data_ptr(), self.grads[self.lat_w_off:].data_ptr(),
                           self.lat_slab.shape[1], rows.value, self.lat_slab.shape[1], 0))
     last = self.enc_recs[-1]
