@@ -817,7 +817,8 @@ __global__ __launch_bounds__(2 * NW_W * 64) void wgrad_ws_kernel(WParams p) {
 }
 
 
-bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes, int target = 128) {
+bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes, int target = 128,
+                int lds_budget_bytes = 160 * 1024 - 2048) {
   const int S = p.S;
   const int img_pix = p.OH * p.OW;
   const int TARGET = target;
@@ -840,7 +841,7 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes, int ta
   p.PW = (p.OW - 1) * S + p.KW;
   p.slots = (p.TR * p.OW + 3) & ~3;
   const int ntaps = p.KH * p.KW;
-  const int budget = (160 * 1024 - 2048) / 4;
+  const int budget = lds_budget_bytes / 4;
   const int co32 = (p.CO + 31) / 32 * 32;
   // 32 output channels per workgroup first: all accumulators then share the DY operand
   // (FAST loop); the IN patch is re-read once per channel block (L2-resident)
@@ -984,7 +985,8 @@ int try_launch_ws(const WParams& p0, int* rows_out, void* stream) {
   WParams p = p0;
   int gx, gy, gz;
   size_t lds1;
-  if (!plan_wgrad(p, &gx, &gy, &gz, &lds1, 64)) return 1;
+  // two buffers must fit: plan against half of the LDS (this may pick a smaller channel block)
+  if (!plan_wgrad(p, &gx, &gy, &gz, &lds1, 64, (158 * 1024) / 2)) return 1;
   const bool dcont = p.dvec && p.dlog >= 0 && p.DP == p.COB;
   const int nacc = (p.nrt * p.ncot + NW_W - 1) / NW_W;
   const int sp = p.S * p.P;
@@ -1022,6 +1024,19 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
     if (rc != 1) return rc;
   }
   if (!plan_wgrad(p, &gx, &gy, &gz, &lds)) return odin_fail(-2, "wgrad: no tiling plan");
+  // bottleneck layers: 128-pixel tiles give only a few dozen workgroups, each with a long serial
+  // reduction.  Smaller pixel tiles split the reduction over more slab rows.
+  if (gx * gy * gz < 128 && !getenv("ODIN_NOWSPLIT")) {
+    for (int tgt = 64; tgt >= 32; tgt >>= 1) {
+      WParams q = p;
+      int gx2, gy2, gz2;
+      size_t lds2;
+      if (!plan_wgrad(q, &gx2, &gy2, &gz2, &lds2, tgt)) break;
+      if (gx2 * gy2 * gz2 <= gx * gy * gz) break;
+      p = q; gx = gx2; gy = gy2; gz = gz2; lds = lds2;
+      if (gx * gy * gz >= 128) break;
+    }
+  }
   if (rows_out) *rows_out = gx;
   if (p.slab == nullptr) return 0;  // dry run: planning only
   p.stamps = g_wstamps;
@@ -1048,9 +1063,57 @@ struct ReduceJobs {
   odin_reduce_job j[MAX_JOBS];
 };
 
+// Vector jobs (n, stride multiples of 4, 16-byte aligned): a block owns 64 consecutive floats of
+// the result; thread (tx = tid & 15, ty = tid >> 4) sums rows ty, ty + 16, ... of float4 column tx
+// with four independent partial sums, the 16 row phases are combined through LDS in a fixed
+// order.  Parallelism is rows x n, not n: a 16 K-float gradient over 256 slab rows is 256 blocks
+// of 16-byte loads instead of 64 blocks of serial 4-byte loads.  Other jobs (bias rows, the
+// tail's 65-float row): one thread per result element.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceJobs jobs) {
   const odin_reduce_job jb = jobs.j[blockIdx.y];
   const size_t st = jb.stride > 0 ? (size_t)jb.stride : (size_t)jb.n;
+  const bool vec = ((jb.n & 3) == 0) && ((st & 3) == 0) &&
+                   ((((size_t)jb.src | (size_t)jb.dst) & 15) == 0);
+  if (vec) {
+    __shared__ float4 part[256];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int n4 = jb.n >> 2;
+    for (int c0 = blockIdx.x * 16; c0 < n4; c0 += gridDim.x * 16) {  // block-uniform
+      const int c = c0 + tx;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+      if (c < n4) {
+        const float4* s = reinterpret_cast<const float4*>(jb.src) + c;
+        const size_t st4 = st >> 2;
+        int g = ty;
+        for (; g + 48 < jb.rows; g += 64) {
+          const float4 v0 = s[(size_t)g * st4], v1 = s[(size_t)(g + 16) * st4];
+          const float4 v2 = s[(size_t)(g + 32) * st4], v3 = s[(size_t)(g + 48) * st4];
+          a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+          a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+          a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+          a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        }
+        for (; g < jb.rows; g += 16) {
+          const float4 v0 = s[(size_t)g * st4];
+          a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        }
+      }
+      part[threadIdx.x] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                                      (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+      __syncthreads();
+      if (ty == 0 && c < n4) {
+        float4 t = part[tx];
+#pragma unroll
+        for (int u = 1; u < 16; ++u) {
+          const float4 q = part[u * 16 + tx];
+          t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+        }
+        reinterpret_cast<float4*>(jb.dst)[c] = t;
+      }
+      __syncthreads();
+    }
+    return;
+  }
   for (int i = blockIdx.x * 256 + threadIdx.x; i < jb.n; i += gridDim.x * 256) {
     const float* s = jb.src + i;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -1113,8 +1176,8 @@ extern "C" int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* s
       rj.j[j] = jobs[j0 + j];
       if (jobs[j0 + j].n > max_n) max_n = jobs[j0 + j].n;
     }
-    int gx = (max_n + 255) / 256;
-    if (gx > 1024) gx = 1024;
+    int gx = (max_n + 63) / 64;  // vector jobs: 64 floats per block
+    if (gx > 4096) gx = 4096;
     if (gx < 1) gx = 1;
     dim3 grid(gx, nj, 1), block(256);
     ODIN_LAUNCH(slab_reduce_kernel, grid, block, 0, stream, rj);
