@@ -525,12 +525,22 @@ struct TailParams {
 };
 constexpr int MAXC1 = 4;
 
+// Hardware log / reciprocal (1 ulp): log(1 + e) for e in (0, 1] has an absolute error below
+// 1.2e-7 per pixel (the IEEE log1pf / division sequences are ~50 instructions per pixel, a tenth
+// of this kernel's epilogue).
+__device__ __forceinline__ float odin_rcp(float x) {
+#ifdef ODIN_SIM
+  return 1.f / x;
+#else
+  return __builtin_amdgcn_rcpf(x);
+#endif
+}
 __device__ __forceinline__ float softplus_g(float x) {
-  return fmaxf(x, 0.f) + log1pf(odin_exp(-fabsf(x)));
+  return fmaxf(x, 0.f) + odin_log(1.f + odin_exp(-fabsf(x)));
 }
 __device__ __forceinline__ float sigmoid_g(float x) {
   float e = odin_exp(-fabsf(x));
-  float r = 1.f / (1.f + e);
+  float r = odin_rcp(1.f + e);
   return x >= 0.f ? r : e * r;
 }
 
@@ -709,13 +719,15 @@ void gather_conv_kernel(GParams p, TailParams tp) {
         // branch-free ELU: exp of min(t, 0) for every element
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+          // (masked lanes compute finite garbage: every use below is guarded by `live` or
+          // multiplied by a zero gradient)
           const float t = acc[i] + bias_l[i];
           const float e = odin_exp(fminf(t, 0.f)) - 1.f;
-          v[i] = live ? (t > 0.f ? t : e) : 0.f;
+          v[i] = t > 0.f ? t : e;
         }
       } else if constexpr (EPI == 2) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = live ? acc[i] + bias_l[i] : 0.f;
+        for (int i = 0; i < 16; ++i) v[i] = acc[i] + bias_l[i];
       } else {
         const int act = p.act;
         if (act == ODIN_ACT_ELU) {
@@ -784,7 +796,9 @@ void gather_conv_kernel(GParams p, TailParams tp) {
             g += dl[oc] * w1r[i][oc];
             dw1[i][oc] += v[i] * dl[oc];
           }
-          v[i] = g * ((EPI == 1) ? (v[i] > 0.f ? 1.f : v[i] + 1.f) : odin_act_grad(p.act, v[i]));
+          // ELU' from the output y: 1 (y > 0) or y + 1 (y <= 0) == 1 + min(y, 0)
+          if constexpr (EPI == 1) v[i] = fmaf(g, fminf(v[i], 0.f), g);
+          else v[i] = g * odin_act_grad(p.act, v[i]);
         }
       } else if (EPI == 2 && live) {
         const float* auxp = p.aux + (size_t)((unsigned)s.opix * (unsigned)p.CO) + n0 + 4 * h;
@@ -793,10 +807,11 @@ void gather_conv_kernel(GParams p, TailParams tp) {
         for (int q = 0; q < 4; ++q) ax[q] = *reinterpret_cast<const float4*>(auxp + 8 * q);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          v[4 * q + 0] *= ax[q].x > 0.f ? 1.f : ax[q].x + 1.f;
-          v[4 * q + 1] *= ax[q].y > 0.f ? 1.f : ax[q].y + 1.f;
-          v[4 * q + 2] *= ax[q].z > 0.f ? 1.f : ax[q].z + 1.f;
-          v[4 * q + 3] *= ax[q].w > 0.f ? 1.f : ax[q].w + 1.f;
+          // ELU'(y) = 1 + min(y, 0)
+          v[4 * q + 0] = fmaf(v[4 * q + 0], fminf(ax[q].x, 0.f), v[4 * q + 0]);
+          v[4 * q + 1] = fmaf(v[4 * q + 1], fminf(ax[q].y, 0.f), v[4 * q + 1]);
+          v[4 * q + 2] = fmaf(v[4 * q + 2], fminf(ax[q].z, 0.f), v[4 * q + 2]);
+          v[4 * q + 3] = fmaf(v[4 * q + 3], fminf(ax[q].w, 0.f), v[4 * q + 3]);
         }
       } else if ((EPI == 0 || EPI == 3) && p.aux != nullptr && live) {
         const float* auxp = p.aux + (size_t)((unsigned)s.opix * (unsigned)p.CO) + n0 + 4 * h;

@@ -33,6 +33,36 @@ def run(kind, B, H, W, Ci, Co, K, S, act='elu'):
   for i in range(1, min(len(ks), 30)):
     print(f'   {names[int(ks[i])]:12s} +{ts[i]-ts[i-1]}')
 run('deconv', 256, 32, 32, 32, 32, 4, 2)
+
+
+def run_tail(B, H, W, Ci, Co, K, S, C1=1):
+  """fused decoder tail: deconv(Co, elu) -> conv1x1(C1) -> Bernoulli fwd+bwd"""
+  OH, OW = H * S, W * S
+  _, pt, _ = same_pads(OH, K, S); _, pl, _ = same_pads(OW, K, S)
+  d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, 'elu')
+  x = torch.randn(B, H, W, Ci, device=dev); w = torch.randn(K, K, Co, Ci, device=dev) * 0.1
+  b = torch.zeros(Co, device=dev); w1 = torch.randn(Co, C1, device=dev) * 0.1; b1 = torch.zeros(C1, device=dev)
+  tgt = torch.rand(B, OH, OW, C1, device=dev); g = torch.empty(B, OH, OW, Co, device=dev)
+  npart, rows = C.c_int(0), C.c_int(0)
+  L.odin_bernoulli_tail_fwd_bwd(1, None, None, None, None, None, None, None, None, None, C.byref(npart),
+                                None, C.byref(rows), None, C.byref(d), C1, None)
+  llk = torch.empty(B * npart.value, device=dev); slab = torch.empty(rows.value, Co * C1 + C1 + Co, device=dev)
+  scale = torch.full((1,), 1.0 / B, device=dev)
+  st = torch.zeros(64, dtype=torch.int64, device=dev)
+  for it in range(3):
+    st.zero_()
+    L.odin_debug_set_stamps(st.data_ptr())
+    L.odin_bernoulli_tail_fwd_bwd(1, x.data_ptr(), w.data_ptr(), b.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                  tgt.data_ptr(), None, g.data_ptr(), llk.data_ptr(), C.byref(npart),
+                                  slab.data_ptr(), C.byref(rows), scale.data_ptr(), C.byref(d), C1, None)
+    torch.cuda.synchronize()
+  L.odin_debug_set_stamps(None)
+  v = st.cpu().numpy(); v = v[v != 0]
+  ks, ts = (v >> 56), (v & ((1 << 56) - 1))
+  print(f'--- fused tail B{B} {H}x{W}x{Ci}->{Co}->{C1}: total {ts[-1]-ts[0]} cycles, rows {rows.value}')
+  for i in range(1, min(len(ks), 30)):
+    print(f'   {names[int(ks[i])]:12s} +{ts[i]-ts[i-1]}')
+run_tail(256, 32, 32, 32, 32, 4, 2)
 run('conv', 256, 32, 32, 32, 32, 4, 2)
 run('conv', 256, 1, 1, 128, 20, 1, 1, 'linear')
 
