@@ -584,7 +584,8 @@ void gather_conv_kernel(GParams p, TailParams tp) {
   // fused-tail state
   // TAIL = number of 1x1 output maps evaluated by the fused tail (0: no tail)
   constexpr int NC1 = TAIL > 0 ? TAIL : 1;
-  float dw1[TAIL ? 16 : 1][NC1], db1[NC1], b1r[NC1];
+  f32x2 dw1[TAIL ? 8 : 1][NC1];  // pairs (i, i+1) of the lane's 16 channels
+  float db1[NC1], b1r[NC1];
   // the tail's per-channel constants (bias of this layer, 1x1 weights) stay in LDS and are
   // re-read by every epilogue: 32 + 32*NC1 fewer live registers across the MFMA loop
   float* tailc = wl + (p.KH * p.KW * p.CIC * p.WP) + 64;  // [32 bias | NC1 x 32 w1]
@@ -600,9 +601,9 @@ void gather_conv_kernel(GParams p, TailParams tp) {
       tailc[e] = val;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < 8; ++i) {
 #pragma unroll
-      for (int oc = 0; oc < NC1; ++oc) dw1[i][oc] = 0.f;
+      for (int oc = 0; oc < NC1; ++oc) dw1[i][oc] = odin_f2(0.f, 0.f);
     }
 #pragma unroll
     for (int oc = 0; oc < NC1; ++oc) {
@@ -716,14 +717,17 @@ void gather_conv_kernel(GParams p, TailParams tp) {
         for (int i = 0; i < 16; ++i) bias_l[i] = bias_r[i];
       }
       if constexpr (EPI == 1) {
-        // branch-free ELU: exp of min(t, 0) for every element
+        // branch-free ELU on channel pairs: max(t, 0) + (2^(min(t, 0) * log2 e) - 1); the second
+        // term is exactly 0 for t > 0.  (Masked lanes compute finite garbage: every use below is
+        // guarded by `live` or multiplied by a zero gradient.)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          // (masked lanes compute finite garbage: every use below is guarded by `live` or
-          // multiplied by a zero gradient)
-          const float t = acc[i] + bias_l[i];
-          const float e = odin_exp(fminf(t, 0.f)) - 1.f;
-          v[i] = t > 0.f ? t : e;
+        for (int j = 0; j < 8; ++j) {
+          const f32x2 t = odin_f2(acc[2 * j], acc[2 * j + 1]) + odin_f2(bias_l[2 * j], bias_l[2 * j + 1]);
+          const f32x2 u = odin_f2(fminf(t.x, 0.f), fminf(t.y, 0.f)) * 1.44269504088896341f;
+          const f32x2 e = odin_f2(odin_exp2(u.x), odin_exp2(u.y)) - 1.f;
+          const f32x2 y = odin_f2(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f)) + e;
+          v[2 * j] = y.x;
+          v[2 * j + 1] = y.y;
         }
       } else if constexpr (EPI == 2) {
 #pragma unroll
@@ -755,20 +759,24 @@ void gather_conv_kernel(GParams p, TailParams tp) {
       if (TAIL) {
         // 1x1 conv: each pixel's 32 channels live in lanes (l31, h=0) and (l31, h=1)
         float lg[NC1], dl[NC1];
-        float w1r[16][NC1];
+        f32x2 w1r[8][NC1], vp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vp[j] = odin_f2(v[2 * j], v[2 * j + 1]);
 #pragma unroll
         for (int oc = 0; oc < NC1; ++oc) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float4 t4 = *reinterpret_cast<const float4*>(tailc + 32 + 32 * oc + 8 * q + 4 * h);
-            w1r[4 * q][oc] = t4.x; w1r[4 * q + 1][oc] = t4.y; w1r[4 * q + 2][oc] = t4.z; w1r[4 * q + 3][oc] = t4.w;
+            w1r[2 * q][oc] = odin_f2(t4.x, t4.y);
+            w1r[2 * q + 1][oc] = odin_f2(t4.z, t4.w);
           }
         }
 #pragma unroll
         for (int oc = 0; oc < NC1; ++oc) {
-          float t = 0.f;
+          f32x2 t2 = odin_f2(0.f, 0.f);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) t += v[i] * w1r[i][oc];
+          for (int j = 0; j < 8; ++j) t2 += vp[j] * w1r[j][oc];
+          float t = t2.x + t2.y;
           t += __shfl_xor(t, 32);
           lg[oc] = t + b1r[oc];
         }
@@ -789,16 +797,22 @@ void gather_conv_kernel(GParams p, TailParams tp) {
           }
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float g = 0.f;
+        for (int j = 0; j < 8; ++j) {
+          f32x2 g = odin_f2(0.f, 0.f);
 #pragma unroll
           for (int oc = 0; oc < NC1; ++oc) {
-            g += dl[oc] * w1r[i][oc];
-            dw1[i][oc] += v[i] * dl[oc];
+            g += w1r[j][oc] * dl[oc];
+            dw1[j][oc] += vp[j] * dl[oc];
           }
-          // ELU' from the output y: 1 (y > 0) or y + 1 (y <= 0) == 1 + min(y, 0)
-          if constexpr (EPI == 1) v[i] = fmaf(g, fminf(v[i], 0.f), g);
-          else v[i] = g * odin_act_grad(p.act, v[i]);
+          if constexpr (EPI == 1) {
+            // ELU' from the output y: 1 (y > 0) or y + 1 (y <= 0) == 1 + min(y, 0)
+            const f32x2 gp = g * odin_f2(fminf(vp[j].x, 0.f), fminf(vp[j].y, 0.f)) + g;
+            v[2 * j] = gp.x;
+            v[2 * j + 1] = gp.y;
+          } else {
+            v[2 * j] = g.x * odin_act_grad(p.act, vp[j].x);
+            v[2 * j + 1] = g.y * odin_act_grad(p.act, vp[j].y);
+          }
         }
       } else if (EPI == 2 && live) {
         const float* auxp = p.aux + (size_t)((unsigned)s.opix * (unsigned)p.CO) + n0 + 4 * h;
@@ -888,7 +902,7 @@ void gather_conv_kernel(GParams p, TailParams tp) {
       for (int i = 0; i < 16; ++i) {
 #pragma unroll
         for (int oc = 0; oc < NC1; ++oc) {
-          float v = dw1[i][oc];
+          float v = dw1[i >> 1][oc][i & 1];
 #pragma unroll
           for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
           if (l31 == 0) red[wave * RW + 32 + (8 * (i >> 2) + 4 * h + (i & 3)) * MAXC1 + oc] = v;

@@ -35,6 +35,22 @@ __device__ __forceinline__ float odin_log(float x) { return __logf(x); }
 #define ODIN_SG_DSREAD 0x100
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// pairs of floats: arithmetic on them compiles to the packed v_pk_{add,mul,fma}_f32 instructions
+// (two results per issue slot -- epilogues are VALU-issue bound)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 odin_f2(float a, float b) {
+  f32x2 r;
+  r.x = a;
+  r.y = b;
+  return r;
+}
+__device__ __forceinline__ float odin_exp2(float x) {
+#ifdef ODIN_SIM
+  return exp2f(x);
+#else
+  return __builtin_amdgcn_exp2f(x);
+#endif
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // v_mfma_f32_32x32x2_f32: exact f32, k-ordered fmaf chain.  Lane l supplies
