@@ -649,6 +649,29 @@ void gather_conv_kernel(GParams p, TailParams tp) {
     f32x16 acc0 = f32x16_zero(), acc1 = f32x16_zero();
     slot_set_tile(p, s0, gr0);
     slot_set_tile(p, s1, gr0);
+    // epilogue operands that come from HBM (activation-derivative operand of the
+    // data-gradients, Bernoulli target of the fused tail) are requested BEFORE the MFMA
+    // loop: a load issued in the epilogue exposes its full latency every tile
+    float4 axp[(EPI == 2) ? NMT : 1][4];
+    float tgt[TAIL ? NMT : 1][NC1];
+    if constexpr (EPI == 2 || TAIL > 0) {
+#pragma unroll
+      for (int mi = 0; mi < NMT; ++mi) {
+        const int mt = mi == 0 ? mt0 : mt1;
+        const Slot& s = mi == 0 ? s0 : s1;
+        const bool lv = mt < p.MT && s.opix >= 0;
+        if constexpr (EPI == 2) {
+          const float* auxp = p.aux + (lv ? (size_t)((unsigned)s.opix * (unsigned)p.CO) : 0) + n0 + 4 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) axp[mi][q] = *reinterpret_cast<const float4*>(auxp + 8 * q);
+        }
+        if constexpr (TAIL > 0) {
+#pragma unroll
+          for (int oc = 0; oc < NC1; ++oc)
+            tgt[mi][oc] = tp.target[(lv ? (size_t)s.opix * tp.C1 : 0) + (oc < tp.C1 ? oc : 0)];
+        }
+      }
+    }
     if (pipelined) {
       __syncthreads();  // everyone is done reading the previous patch
       stage_commit<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, 0, b0, ih_lo, pf, patch);
@@ -785,7 +808,7 @@ void gather_conv_kernel(GParams p, TailParams tp) {
         for (int oc = 0; oc < NC1; ++oc) {
           dl[oc] = 0.f;
           if (oc < tp.C1 && live) {
-            const float x = tp.target[(size_t)s.opix * tp.C1 + oc];
+            const float x = tgt[TAIL ? mi : 0][oc];
             const float l = lg[oc];
             const float dsig = (sigmoid_g(l) - x) * sc;
             if (h == 0) {
@@ -815,10 +838,7 @@ void gather_conv_kernel(GParams p, TailParams tp) {
           }
         }
       } else if (EPI == 2 && live) {
-        const float* auxp = p.aux + (size_t)((unsigned)s.opix * (unsigned)p.CO) + n0 + 4 * h;
-        float4 ax[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ax[q] = *reinterpret_cast<const float4*>(auxp + 8 * q);
+        const float4* ax = axp[(EPI == 2) ? mi : 0];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           // ELU'(y) = 1 + min(y, 0)
