@@ -234,6 +234,17 @@ def main():
   def step():
     return eng.train_step(x, None, lr=lr, beta=beta, global_clipnorm=100.0, use_graph=use_graph)
 
+  # Steady-state conditioning before the W warm-up steps: on a freshly started process the first
+  # ~100 ms of replays can run 20-30 % slow (clock / power ramp from idle; measured as one slow
+  # first block of 100 steps in about 1 process out of 8, steady afterwards), so the GPU is kept
+  # busy for ~0.6 s first.  Untimed, like the graph capture itself.
+  step()
+  torch.cuda.synchronize()
+  t_pw = time.perf_counter()
+  while time.perf_counter() - t_pw < 0.6:
+    for _ in range(20):
+      step()
+    torch.cuda.synchronize()
   for _ in range(args.warmup):
     step()
   torch.cuda.synchronize()
