@@ -279,6 +279,19 @@ def main():
                   achieved=round(dom['tflops'], 3), peak=PEAK_MFMA_F32_TFLOPS, unit='TFLOP/s',
                   frac=round(dom['tflops'] / PEAK_MFMA_F32_TFLOPS, 4), traffic=None,
                   us_per_launch=round(dom['us'], 2), gflop_per_launch=round(dom['gflop'], 4))
+  # HBM traffic of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
+  # collected inside this process); null when no measurement for this kernel is on file
+  try:
+    import json as _json
+    pmc = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                                       'r01_pmc_traffic.json')))
+    ent = pmc.get(roofline['kernel'])
+    if ent is not None and args.workload == 'dsprites_betavae_b256':
+      roofline['traffic'] = ent['traffic_bytes']
+      roofline['traffic_unit'] = 'bytes'
+      roofline['traffic_source'] = 'profiles/r01_pmc_traffic.json'
+  except (OSError, ValueError):
+    pass
   conv_us = sum(o['us'] for o in ops)
   conv_gf = sum(o['gflop'] for o in ops)
   stack = dict(us=round(conv_us, 1), gflop=round(conv_gf, 3),
