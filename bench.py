@@ -240,11 +240,17 @@ def main():
   # busy for ~0.6 s first.  Untimed, like the graph capture itself.
   step()
   torch.cuda.synchronize()
-  t_pw = time.perf_counter()
-  while time.perf_counter() - t_pw < 0.6:
-    for _ in range(20):
+  if world > 1:
+    # every step contains a collective: all ranks must run the SAME number of steps
+    for _ in range(400):
       step()
     torch.cuda.synchronize()
+  else:
+    t_pw = time.perf_counter()
+    while time.perf_counter() - t_pw < 0.6:
+      for _ in range(20):
+        step()
+      torch.cuda.synchronize()
   for _ in range(args.warmup):
     step()
   torch.cuda.synchronize()
