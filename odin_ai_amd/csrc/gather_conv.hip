@@ -184,10 +184,16 @@ __device__ __forceinline__ float4 center4(float4 v) {
 #define ODIN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
+// Split layout (fp32 through the bf16 matrix pipe, odin_device.h): the patch is three bf16 planes
+// [pixel][32 channels], pixel pitch 80 bytes (64 + 16: the 16-byte B-operand reads of 8 lanes
+// then cover 8 distinct bank quads for pixel strides 1 and 2).
+constexpr int SPLIT_PITCH = 80;
+
 template <int KMAX>
 struct LaneStage {
   unsigned gofs[KMAX];  // byte offset of the item inside an input image row
   int ldo[KMAX];        // float offset of the item inside a patch row
+  int ldo2[KMAX];       // split (3 x bf16 plane) layout: byte offset inside a patch row
   unsigned jmask;       // bit k: item k exists (inside the patch row)
   unsigned okmask;      // bit k: item k reads real data (not SAME padding)
 };
@@ -209,6 +215,7 @@ __device__ __forceinline__ LaneStage<KMAX> lane_stage_init(const GParams& p, int
     const bool ok = jv && (iw >= 0) && (iw < p.W) && (cc < p.CI);
     L.gofs[k] = ok ? (unsigned)((iw * p.CI + cc) * 4) : ODIN_OOB;
     L.ldo[k] = pcol * p.P + cc;
+    L.ldo2[k] = pcol * SPLIT_PITCH + cc * 2;
     if (jv) L.jmask |= 1u << k;
     if (ok) L.okmask |= 1u << k;
   }
@@ -506,6 +513,92 @@ __device__ __forceinline__ f32x16 mtile_compute(const GParams& p, const float* p
   }
 }
 
+// ---- split path: staging commit and compute -------------------------------------------
+// One patch row: every float4 item becomes three 8-byte writes (bf16 pieces of 4 channels).
+template <int KMAX>
+__device__ __forceinline__ void stage_row_commit_split(const GParams& p, const LaneStage<KMAX>& L,
+                                                       int r, const float4* v, char* patch,
+                                                       int pls) {
+  char* rowl = patch + r * p.PW * SPLIT_PITCH;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    if ((L.jmask >> k) & 1u) {
+      const float4 t = v[k];
+      const float4 m = make_float4(odin_bf16_rest(t.x), odin_bf16_rest(t.y), odin_bf16_rest(t.z),
+                                   odin_bf16_rest(t.w));
+      const float4 l = make_float4(odin_bf16_rest(m.x), odin_bf16_rest(m.y), odin_bf16_rest(m.z),
+                                   odin_bf16_rest(m.w));
+      char* d = rowl + L.ldo2[k];
+      *reinterpret_cast<u32x2*>(d) = odin_u2(odin_pack_bf16(t.x, t.y), odin_pack_bf16(t.z, t.w));
+      *reinterpret_cast<u32x2*>(d + pls) = odin_u2(odin_pack_bf16(m.x, m.y), odin_pack_bf16(m.z, m.w));
+      *reinterpret_cast<u32x2*>(d + 2 * pls) = odin_u2(odin_pack_bf16(l.x, l.y), odin_pack_bf16(l.z, l.w));
+    }
+  }
+}
+
+// eight fp32 weights (consecutive reduction channels of one (tap, output channel)) -> one
+// A fragment per bf16 plane
+__device__ __forceinline__ void split_fragment(const float* f, u32x4& a0, u32x4& a1, u32x4& a2) {
+  float m[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    m[j] = odin_bf16_rest(f[j]);
+    l[j] = odin_bf16_rest(m[j]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    a0[q] = odin_pack_bf16(f[2 * q], f[2 * q + 1]);
+    a1[q] = odin_pack_bf16(m[2 * q], m[2 * q + 1]);
+    a2[q] = odin_pack_bf16(l[2 * q], l[2 * q + 1]);
+  }
+}
+
+// MODE_T, 4x4 / stride 2, 32 reduction channels: the 4 taps of this wave's phase x 2 k-groups of
+// 16 channels; the weight fragments A[plane][tap][kgroup] live in registers for the whole kernel
+// (no LDS traffic for weights), per step 3 B reads of 16 bytes feed 6 MFMAs.
+__device__ __forceinline__ f32x16 mtile_compute_split(const GParams& p, const char* patch, int pls,
+                                                      int pix0, int h, const u32x4 (&A)[3][4][2]) {
+  f32x16 accE = f32x16_zero(), accO = f32x16_zero();
+  const char* bp = patch + pix0 * SPLIT_PITCH + h * 16;
+  u32x4 b0[3], b1[3];
+  auto bload = [&](int step, u32x4 (&b)[3]) {
+    const int tap = step >> 1, kg = step & 1;
+    const int jh = tap >> 1, jw = tap & 1;
+    const char* q = bp - (jh * p.PW + jw) * SPLIT_PITCH + kg * 32;
+    b[0] = *reinterpret_cast<const u32x4*>(q);
+    b[1] = *reinterpret_cast<const u32x4*>(q + pls);
+    b[2] = *reinterpret_cast<const u32x4*>(q + 2 * pls);
+  };
+  auto mm = [&](int step, const u32x4 (&b)[3]) {
+    const int tap = step >> 1, kg = step & 1;
+    // smallest terms first; two accumulator chains
+    accE = mfma32_bf16(A[2][tap][kg], b[0], accE);
+    accO = mfma32_bf16(A[0][tap][kg], b[2], accO);
+    accE = mfma32_bf16(A[1][tap][kg], b[1], accE);
+    accO = mfma32_bf16(A[1][tap][kg], b[0], accO);
+    accE = mfma32_bf16(A[0][tap][kg], b[1], accE);
+    accO = mfma32_bf16(A[0][tap][kg], b[0], accO);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      ODIN_SCHED_GROUP(ODIN_SG_MFMA, 2);
+      ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 1);
+    }
+    ODIN_SCHED_FENCE();
+  };
+  bload(0, b0);
+  ODIN_SCHED_FENCE();
+#pragma unroll
+  for (int st = 0; st < 8; st += 2) {
+    bload(st + 1, b1);
+    mm(st, b0);
+    if (st + 2 < 8) bload(st + 2, b0);
+    mm(st + 1, b1);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accE[i] += accO[i];
+  return accE;
+}
+
 // Fused decoder tail (training step): this kernel's layer is a Conv2DTranspose whose
 // output feeds a 1x1 linear Conv2D with C1 <= 4 maps that parameterise
 // Independent(Bernoulli(logits)).  The epilogue evaluates the 1x1 conv, the Bernoulli
@@ -557,9 +650,14 @@ __device__ __forceinline__ float sigmoid_g(float x) {
 
 // EPI: 3 = as 0 but with FLAT (Dense) staging; 0 = runtime activation / aux / channel masking; 1 = ELU, no aux, CO % 32 == 0
 // (forward of the elu stacks); 2 = linear, aux = ELU derivative, CO % 32 == 0 (data-gradients).
-template <int MODE, int NW, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI, int NMT>
-__global__ __launch_bounds__(NW * 64, (MODE == MODE_T && TK == 4 && TCIC == 32 && RPWMAX == 1 && TAIL <= 1) ? 2 : 1)
+// SPL: split path (three bf16 planes, weights in registers; MODE_T k4/s2 32-channel instances).
+template <int MODE, int NW, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI, int NMT,
+          bool SPL = false>
+__global__ __launch_bounds__(NW * 64, (MODE == MODE_T && TK == 4 && TCIC == 32 && RPWMAX == 1 && TAIL <= 1 &&
+                                       !(SPL && TAIL > 0)) ? 2 : 1)
 void gather_conv_kernel(GParams p, TailParams tp) {
+  static_assert(!SPL || (MODE == MODE_T && TK == 4 && TS == 2 && TCIC == 32 && VEC && NMT == 1 && RPWMAX == 1),
+                "split path: transposed 4x4/s2 gather, 32 reduction channels, one M-tile per wave");
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
   float* wl = smem + p.patch_floats;
@@ -575,7 +673,8 @@ void gather_conv_kernel(GParams p, TailParams tp) {
   const bool pipelined = p.pipelined != 0;
   const LaneStage<KMAX> LS = lane_stage_init<KMAX, VEC>(p, lane);
 
-  if (p.w_resident) stage_weights(p, wl, 0, n0, tid, NT);
+  const int wfloats = SPL ? 0 : p.KH * p.KW * p.CIC * p.WP;  // LDS floats of the weight slice
+  if (p.w_resident && !SPL) stage_weights(p, wl, 0, n0, tid, NT);
   ODIN_STAMP(2);
 
   float bsum[16];
@@ -588,7 +687,7 @@ void gather_conv_kernel(GParams p, TailParams tp) {
   float db1[NC1], b1r[NC1];
   // the tail's per-channel constants (bias of this layer, 1x1 weights) stay in LDS and are
   // re-read by every epilogue: 32 + 32*NC1 fewer live registers across the MFMA loop
-  float* tailc = wl + (p.KH * p.KW * p.CIC * p.WP) + 64;  // [32 bias | NC1 x 32 w1]
+  float* tailc = wl + wfloats + 64;  // [32 bias | NC1 x 32 w1]
   if (TAIL) {
     for (int e = tid; e < 32 * (1 + NC1); e += NT) {
       float val;
@@ -630,6 +729,36 @@ void gather_conv_kernel(GParams p, TailParams tp) {
     }
   }
   const bool co_vec = ((p.CO & 3) == 0);
+
+  // split path: this wave's weight fragments (its M-tile has a fixed tap phase) and patch geometry
+  u32x4 Afr[SPL ? 3 : 1][SPL ? 4 : 1][SPL ? 2 : 1];
+  const int pls = p.NIMG * p.NRI * p.PW * SPLIT_PITCH;  // bytes per bf16 plane
+  int pix0 = 0;
+  if constexpr (SPL) {
+    pix0 = s0.base / p.P;
+    const OdinRun WR = odin_run(p.w, (unsigned)((size_t)p.KH * p.KW * p.CI * p.CO * 4));
+    const int co = n0 + l31;
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+      const int wt = (s0.kh0 + 2 * (tap >> 1)) * 4 + (s0.kw0 + 2 * (tap & 1));
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        const int ci0 = kg * 16 + h * 8;
+        float f[8];
+        if (p.wmode == 1) {  // [tap][out][reduce]: 8 consecutive floats
+          const unsigned off = co < p.CO ? (unsigned)(((wt * p.CO + co) * p.CI + ci0) * 4) : ODIN_OOB;
+          const float4 u0 = odin_run_load4(WR, off), u1 = odin_run_load4(WR, off == ODIN_OOB ? off : off + 16);
+          f[0] = u0.x; f[1] = u0.y; f[2] = u0.z; f[3] = u0.w;
+          f[4] = u1.x; f[5] = u1.y; f[6] = u1.z; f[7] = u1.w;
+        } else {             // [tap][reduce][out]
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            f[j] = odin_run_load1(WR, co < p.CO ? (unsigned)(((wt * p.CI + ci0 + j) * p.CO + co) * 4) : ODIN_OOB);
+        }
+        split_fragment(f, Afr[0][tap][kg], Afr[1][tap][kg], Afr[2][tap][kg]);
+      }
+    }
+  }
 
   SV pf[RPWMAX * KMAX];
   int tile = blockIdx.x;
@@ -674,7 +803,13 @@ void gather_conv_kernel(GParams p, TailParams tp) {
     }
     if (pipelined) {
       __syncthreads();  // everyone is done reading the previous patch
-      stage_commit<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, 0, b0, ih_lo, pf, patch);
+      if constexpr (SPL) {
+        if (wave < p.NIMG * p.NRI)
+          stage_row_commit_split<KMAX>(p, LS, wave, reinterpret_cast<const float4*>(pf),
+                                       reinterpret_cast<char*>(patch), pls);
+      } else {
+        stage_commit<KMAX, RPWMAX, VEC, NW, (EPI == 3)>(p, LS, wave, tid, 0, b0, ih_lo, pf, patch);
+      }
       __syncthreads();
       ODIN_STAMP(5);
       const int nt = tile + gridDim.x;
@@ -686,7 +821,12 @@ void gather_conv_kernel(GParams p, TailParams tp) {
       }
       ODIN_STAMP(6);
       constexpr int SGK = (TAIL > 0 && RPWMAX == 1) ? 8 : 16;
-      if (mt0 < p.MT) acc0 = mtile_compute<MODE, TK, TS, TCIC, SGK>(p, patch, wl, s0, l31, h, acc0, kc0, kc1);
+      if constexpr (SPL) {
+        if (mt0 < p.MT)
+          acc0 = mtile_compute_split(p, reinterpret_cast<const char*>(patch), pls, pix0, h, Afr);
+      } else if (mt0 < p.MT) {
+        acc0 = mtile_compute<MODE, TK, TS, TCIC, SGK>(p, patch, wl, s0, l31, h, acc0, kc0, kc1);
+      }
       if (NMT > 1 && mt1 < p.MT) acc1 = mtile_compute<MODE, TK, TS, TCIC, SGK>(p, patch, wl, s1, l31, h, acc1);
     } else {
       for (int ch = 0; ch < p.n_chunks; ++ch) {
@@ -891,7 +1031,7 @@ void gather_conv_kernel(GParams p, TailParams tp) {
       // one log-likelihood partial per tile (a tile lies inside one sample)
       float t = wave_sum64(llk_lane);
       __syncthreads();
-      float* red = wl + (p.KH * p.KW * p.CIC * p.WP);  // scratch after the weights
+      float* red = wl + wfloats;  // scratch after the weights
       if (lane == 0) red[wave] = t;
       __syncthreads();
       if (tid == 0) {
@@ -1077,7 +1217,8 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
 
 long long* g_stamps = nullptr;
 
-template <int MODE, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI, int NMT>
+template <int MODE, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI, int NMT,
+          bool SPL = false>
 int launch_inst2(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* stream) {
   if (p.KI > KMAX) return odin_fail(-2, "gather_conv: patch row too long for this instance");
   const int rpw = (p.NIMG * p.NRI + NW_G - 1) / NW_G;
@@ -1093,12 +1234,12 @@ int launch_inst2(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* 
   if (!attr_done) {
     (void)hipFuncSetAttribute(
         reinterpret_cast<const void*>(
-            &gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, NMT>),
+            &gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, NMT, SPL>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, NMT>), grid,
+  ODIN_LAUNCH((gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, NMT, SPL>), grid,
               dim3(NW_G * 64), lds, stream, p, tp);
   return odin_check_launch("gather_conv");
 }
@@ -1109,6 +1250,23 @@ int launch_inst(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* s
   if (p.MT <= NW_G)
     return launch_inst2<MODE, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, 1>(p, tp, grid, lds, stream);
   return launch_inst2<MODE, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, 2>(p, tp, grid, lds, stream);
+}
+
+// Split path (three bf16 planes, register-resident weights): eligibility and LDS size.
+// Opt-in (ODIN_SPLIT=1): correct to fp32-class accuracy and 2.7x lighter on the matrix pipe, but
+// measured SLOWER than the fp32 instances on MI355X in this form -- the 96 registers of weight
+// fragments push the two-workgroups-per-CU variants into scratch (103-122 spilled registers) and
+// the one-workgroup fused tail loses the wait hiding of its partner (144.6 vs 121.8 us).  Needs an
+// 8-wave workgroup sharing LDS-resident weight planes (DESIGN.md section 5, next levers).
+bool split_ok(const GParams& p) {
+  const char* e = getenv("ODIN_SPLIT");
+  return e != nullptr && e[0] == '1' && p.CI == 32 && !p.center && p.MT <= NW_G && p.w_resident;
+}
+size_t split_lds(GParams& p) {
+  p.patch_floats = (int)((((long)3 * p.NIMG * p.NRI * p.PW * SPLIT_PITCH) / 4 + 3) & ~3L);
+  long total = p.patch_floats + W_SCRATCH;
+  if (total < 4096 + 64) total = 4096 + 64;
+  return (size_t)total * 4;
 }
 
 int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_out = nullptr,
@@ -1162,7 +1320,11 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
       return odin_fail(-2, "bernoulli tail: needs Cout<=32, C1<=4, Cin%4==0 and one image per tile");
     if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 1 && tp.C1 == 1 &&
         !getenv("ODIN_NOTAIL2WG"))  // two workgroups per CU
+    {
+      if (split_ok(p))
+        return launch_inst2<MODE_T, 4, 2, 32, true, 1, 5, 1, 1, 1, true>(p, tp, grid, split_lds(p), stream);
       return launch_inst<MODE_T, 4, 2, 32, true, 1, 5, 1, 1>(p, tp, grid, lds, stream);
+    }
     if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5 && epi == 1 && tp.C1 == 1)
       return launch_inst<MODE_T, 4, 2, 32, true, 1, 5, 2, 1>(p, tp, grid, lds, stream);
 #ifndef ODIN_DEV_TAIL_ONLY  // (developer switch: compile only the dSprites tail instances)
@@ -1199,10 +1361,16 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     if (p.KI <= 2) return launch_inst<MODE_F, 0, 0, 0, false, 0, 2, 8>(p, tp, grid, lds, stream);
     return launch_inst<MODE_F, 0, 0, 0, false, 0, GK, 2>(p, tp, grid, lds, stream);
   }
-  if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 1 && !getenv("ODIN_NO2WG"))
+  if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 1 && !getenv("ODIN_NO2WG")) {
+    if (split_ok(p))
+      return launch_inst2<MODE_T, 4, 2, 32, true, 0, 5, 1, 1, 1, true>(p, tp, grid, split_lds(p), stream);
     return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 1, 1>(p, tp, grid, lds, stream);
-  if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 2 && !getenv("ODIN_NO2WG"))
+  }
+  if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 2 && !getenv("ODIN_NO2WG")) {
+    if (split_ok(p))
+      return launch_inst2<MODE_T, 4, 2, 32, true, 0, 5, 1, 2, 1, true>(p, tp, grid, split_lds(p), stream);
     return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 1, 2>(p, tp, grid, lds, stream);
+  }
   if (k4s2 && p.CIC == 32 && p.KI <= 5) {
     if (epi == 1) return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 2, 1>(p, tp, grid, lds, stream);
     if (epi == 2) return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 2, 2>(p, tp, grid, lds, stream);

@@ -64,6 +64,48 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 #endif
 }
 
+// ---- fp32 through the bf16 matrix pipe -------------------------------------------------
+// An fp32 value splits EXACTLY into three bf16 pieces by truncation (8 + 8 + 8 mantissa bits):
+// x = x0 + x1 + x2.  A product x*w is then the sum of 9 exact bf16 x bf16 products; the six with
+// piece indices i + j <= 2 carry everything above 2^-24 relative, and v_mfma_f32_32x32x16_bf16
+// (16 k-values in 8 passes: 16x the fp32 MFMA rate) accumulates them in fp32.  6 bf16 MFMAs per
+// 16 k-values replace 8 fp32 MFMAs: 2.7x less matrix-pipe time at fp32-class accuracy
+// (error <= 3 * 2^-24 per product; the dropped terms are x1*w2, x2*w1, x2*w2).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 8 bf16: element j in bits 16*(j&1) of word j>>1
+__device__ __forceinline__ unsigned odin_fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float odin_bitsf(unsigned u) { return __builtin_bit_cast(float, u); }
+// pack the bf16 (upper) halves of two floats: a -> low half, b -> high half
+__device__ __forceinline__ unsigned odin_pack_bf16(float a, float b) {
+  return (odin_fbits(a) >> 16) | (odin_fbits(b) & 0xFFFF0000u);
+}
+__device__ __forceinline__ u32x2 odin_u2(unsigned a, unsigned b) {
+  u32x2 r;
+  r.x = a;
+  r.y = b;
+  return r;
+}
+// remainder after removing the leading bf16 piece (exact)
+__device__ __forceinline__ float odin_bf16_rest(float x) {
+  return x - odin_bitsf(odin_fbits(x) & 0xFFFF0000u);
+}
+// D = A(32 x 16) * B(16 x 32) + C.  Lane l supplies A[row l&31][k = 8*(l>>5) + j] and
+// B[k = 8*(l>>5) + j][col l&31] in element j; the C/D layout is that of mfma32 above.
+__device__ __forceinline__ f32x16 mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef ODIN_SIM
+  for (int j = 0; j < 8; ++j) {
+    const float af = odin_bitsf((a[j >> 1] >> (16 * (j & 1))) << 16);
+    const float bf = odin_bitsf((b[j >> 1] >> (16 * (j & 1))) << 16);
+    c = sim::mfma_32x32x2(af, bf, c);
+  }
+  return c;
+#else
+  typedef __bf16 odin_bf16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(odin_bf16x8, a),
+                                                 __builtin_bit_cast(odin_bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ f32x16 f32x16_zero() {
   f32x16 z;
 #pragma unroll

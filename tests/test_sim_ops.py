@@ -55,6 +55,7 @@ CONV_CASES = [
     (3, 16, 16, 32, 32, 4, 2, 'elu', False),   # wgrad row-chunk loop (S*P = 64), two images per tile, ragged
     (2, 16, 16, 64, 32, 4, 2, 'elu', False),   # wgrad row-chunk loop (S*P = 128)
     (1, 16, 16, 32, 32, 3, 1, 'relu', False),  # wgrad row-chunk loop (S*P = 32), 16-wide rows
+    (1, 32, 32, 32, 32, 4, 2, 'elu', False),   # two-workgroup data-gradient instance (EPI 2)
 ]
 
 
@@ -99,6 +100,7 @@ def test_conv2d_fwd_dgrad_wgrad(L, B, H, W, Ci, Co, K, S, act, center):
 
 
 DECONV_CASES = [
+    (1, 16, 16, 32, 32, 4, 2, 'elu'),          # two-workgroup forward instance (EPI 1)
     (3, 4, 4, 8, 64, 4, 2, 'elu'),
     (2, 8, 8, 64, 32, 4, 2, 'elu'),
     (1, 16, 16, 32, 32, 4, 2, 'linear'),
@@ -175,6 +177,7 @@ def test_dense(L, B, K, N, act):
 
 @pytest.mark.parametrize('is_deconv,B,H,W,Ci,Co,K,S,C1', [
     (1, 2, 8, 8, 32, 32, 4, 2, 1),     # specialised <T,4,2,32> instance
+    (1, 1, 16, 16, 32, 32, 4, 2, 1),   # two-workgroup fused tail instance (also the shape of the opt-in bf16-plane path)
     (1, 3, 8, 8, 8, 16, 4, 2, 3),      # generic transposed
     (0, 2, 16, 16, 8, 24, 5, 1, 1),    # generic gather conv (MNIST-style decoder tail)
 ])
@@ -223,3 +226,29 @@ def test_bernoulli_tail(L, is_deconv, B, H, W, Ci, Co, K, S, C1):
   close(red[:Co * C1].reshape(Co, C1), dw1_ref[0, 0], 1e-4)
   close(red[Co * C1:Co * C1 + C1], db1_ref, 1e-4)
   close(red[Co * C1 + C1:], g_ref.sum((0, 1, 2)), 1e-4)
+
+
+def test_split_bf16_path_matches_fp32(L, monkeypatch):
+  """ODIN_SPLIT=1 routes the transposed 4x4/s2 32-channel instances through the bf16-plane path
+  (fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per 16 k-values): results must
+  agree with the fp32 MFMA path to fp32-class accuracy (<= 2e-6 of the tensor maximum)."""
+  import os
+  rng = np.random.default_rng(11)
+  B, H, W, Ci, Co, K, S = 1, 16, 16, 32, 32, 4, 2
+  OH, OW = H * S, W * S
+  _, pt, _ = vo.same_pads(OH, K, S)
+  _, pl, _ = vo.same_pads(OW, K, S)
+  d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, 'elu')
+  tx, tw = T(rng.standard_normal((B, H, W, Ci))), T(rng.standard_normal((K, K, Co, Ci)) * 0.1)
+  tb = T(rng.standard_normal(Co) * 0.1)
+  outs = []
+  for flag in ('0', '1'):
+    monkeypatch.setenv('ODIN_SPLIT', flag)
+    os.putenv('ODIN_SPLIT', flag)
+    ty = torch.zeros(B, OH, OW, Co)
+    L.odin_deconv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
+    outs.append(ty.numpy().copy())
+  os.putenv('ODIN_SPLIT', '0')
+  assert np.abs(outs[0]).max() > 0.5
+  assert np.abs(outs[0] - outs[1]).max() <= 2e-6 * np.abs(outs[0]).max()
+  assert not np.array_equal(outs[0], outs[1])  # the split path really ran (different rounding)
