@@ -58,6 +58,55 @@ __global__ __launch_bounds__(256) void smallc_fwd_kernel(SCParams p) {
   }
 }
 
+// forward, compile-time taps: all KH*KW*CI input taps of a thread are requested up front as
+// range-checked loads over the whole input tensor (padding taps carry an out-of-range offset
+// and read zeros) -- no branch between the loads, so they overlap instead of paying one memory
+// latency each.
+template <int KH, int KW, int CI>
+__global__ __launch_bounds__(256) void smallc_fwd_kernel_t(SCParams p) {
+  ODIN_DYN_SMEM(float, wl);  // [KH*KW*CI][CO] + bias[CO]
+  constexpr int K = KH * KW * CI;
+  for (int e = threadIdx.x; e < K * p.CO; e += 256) wl[e] = p.w[e];
+  for (int e = threadIdx.x; e < p.CO; e += 256) wl[K * p.CO + e] = p.bias ? p.bias[e] : 0.f;
+  __syncthreads();
+  const OdinRun XR = odin_run(p.x, (unsigned)((size_t)p.B * p.H * p.W * CI * 4));
+  const int cg = p.CO >> 2;
+  const int total = p.B * p.OH * p.OW * cg;
+  const int ohw = p.OH * p.OW;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+    const int pix = t / cg, g4 = t - pix * cg;
+    const int b = pix / ohw, rem = pix - b * ohw;
+    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+    const int ih0 = oh * p.S - p.pt, iw0 = ow * p.S - p.pl;
+    float xv[K];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw) {
+        const int ih = ih0 + kh, iw = iw0 + kw;
+        const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        const unsigned off = ok ? (unsigned)((((b * p.H + ih) * p.W + iw) * CI) * 4) : ODIN_OOB;
+#pragma unroll
+        for (int c = 0; c < CI; ++c) {
+          float v = odin_run_load1(XR, ok ? off + 4 * c : ODIN_OOB);
+          if (p.center) v = ok ? 2.f * v - 1.f : 0.f;
+          xv[(kh * KW + kw) * CI + c] = v;
+        }
+      }
+    }
+    float4 acc = *reinterpret_cast<const float4*>(wl + K * p.CO + 4 * g4);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float4 wv = *reinterpret_cast<const float4*>(wl + k * p.CO + 4 * g4);
+      acc.x = fmaf(xv[k], wv.x, acc.x); acc.y = fmaf(xv[k], wv.y, acc.y);
+      acc.z = fmaf(xv[k], wv.z, acc.z); acc.w = fmaf(xv[k], wv.w, acc.w);
+    }
+    acc.x = odin_act(p.act, acc.x); acc.y = odin_act(p.act, acc.y);
+    acc.z = odin_act(p.act, acc.z); acc.w = odin_act(p.act, acc.w);
+    *reinterpret_cast<float4*>(p.y + (size_t)pix * p.CO + 4 * g4) = acc;
+  }
+}
+
 // weight gradient.  Workgroup = 16 waves; a wave owns 64/CW pixels per iteration (CW = 32
 // or 64 lanes per pixel = output channels), every lane keeps all TK = KH*KW*CI rows of dW for
 // its channel in registers; the x taps of a pixel are wave-broadcast loads.  Partial sums are
@@ -89,6 +138,8 @@ __global__ __launch_bounds__(1024) void smallc_wgrad_kernel(SCParams p) {
   }
   float bacc = 0.f;
   const int total = p.B * p.OH * p.OW;
+  const OdinRun XR = odin_run(p.x, (unsigned)((size_t)p.B * p.H * p.W * p.CI * 4));
+  const OdinRun DR = odin_run(p.dy, (unsigned)((size_t)total * p.CO * 4));
   const int p0 = blockIdx.x * p.pix_per_block;
   int p1 = p0 + p.pix_per_block;
   if (p1 > total) p1 = total;
@@ -101,19 +152,17 @@ __global__ __launch_bounds__(1024) void smallc_wgrad_kernel(SCParams p) {
     const int pc = pv ? pix : p0;
     const int b = pc / ohw, rem = pc - b * ohw;
     const int oh = rem / p.OW, ow = rem - oh * p.OW;
-    const float g = (live && pv) ? p.dy[(size_t)pc * p.CO + co] : 0.f;
+    // branch-free range-checked loads (masked lanes / padding taps read zeros)
+    const float g = odin_run_load1(DR, (live && pv) ? (unsigned)((pc * p.CO + co) * 4) : ODIN_OOB);
     bacc += g;
-    const float* xb = p.x + (size_t)b * p.H * p.W * p.CI;
     const int ih0 = oh * p.S - p.pt, iw0 = ow * p.S - p.pl;
     float xt[NL];
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int ih = ih0 + lkh[j], iw = iw0 + lkw[j];
-      float xv = 0.f;
-      if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-        xv = xb[(ih * p.W + iw) * p.CI + lc[j]];
-        if (p.center) xv = 2.f * xv - 1.f;
-      }
+      const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+      float xv = odin_run_load1(XR, ok ? (unsigned)((((b * p.H + ih) * p.W + iw) * p.CI + lc[j]) * 4) : ODIN_OOB);
+      if (p.center) xv = ok ? 2.f * xv - 1.f : 0.f;
       xt[j] = xv;
     }
 #pragma unroll
@@ -150,7 +199,8 @@ __global__ __launch_bounds__(1024) void smallc_wgrad_kernel(SCParams p) {
 
 bool odin_smallc_applicable(const odin_conv_desc* d) {
   const int K = d->KH * d->KW * d->Cin;
-  if ((long)d->B * d->OH * d->OW * d->Cout >= (1L << 31)) return false;
+  if ((long)d->B * d->OH * d->OW * d->Cout >= (1L << 29)) return false;  // byte offsets fit 31 bits
+  if ((long)d->B * d->H * d->W * d->Cin >= (1L << 29)) return false;
   return d->Cin <= 4 && (d->Cout % 4) == 0 && d->Cout <= 64 && (K == 16 || K == 25 || K == 48) &&
          (size_t)16 * (K + 1) * d->Cout * 4 <= 150 * 1024;
 }
@@ -171,7 +221,15 @@ int odin_smallc_fwd(const float* x, const float* w, const float* bias, float* y,
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   size_t lds = (size_t)(d->KH * d->KW * d->Cin + 1) * d->Cout * 4;
-  ODIN_LAUNCH(smallc_fwd_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  const bool small_x = (size_t)d->B * d->H * d->W * d->Cin * 4 < 0x7FFFFFF0u;
+  if (small_x && d->KH == 4 && d->KW == 4 && d->Cin == 1)
+    ODIN_LAUNCH((smallc_fwd_kernel_t<4, 4, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  else if (small_x && d->KH == 4 && d->KW == 4 && d->Cin == 3)
+    ODIN_LAUNCH((smallc_fwd_kernel_t<4, 4, 3>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  else if (small_x && d->KH == 5 && d->KW == 5 && d->Cin == 1)
+    ODIN_LAUNCH((smallc_fwd_kernel_t<5, 5, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  else
+    ODIN_LAUNCH(smallc_fwd_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, p);
   return odin_check_launch("smallc_fwd");
 }
 
