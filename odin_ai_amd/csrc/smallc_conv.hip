@@ -6,6 +6,7 @@
 // odin/networks/image_networks.py:244,463,679; `CenterAt0` :121-126 folded into the load.)
 #include "odin_device.h"
 #include "odin_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -195,6 +196,112 @@ __global__ __launch_bounds__(1024) void smallc_wgrad_kernel(SCParams p) {
   }
 }
 
+// Weight gradient on the matrix cores, operands straight from HBM/L2 (no LDS staging): with
+// K = KH*KW*Cin <= 63 the whole dW is RB x CB accumulator tiles (rows = taps (+ one bias row whose
+// A operand is the constant 1), columns = output channels) and the MFMA reduction index is the
+// pixel: per pixel pair a lane loads ONE x tap per row block (a gather: tap l31 of pixel p + h) and
+// ONE dy value per column block (coalesced).  U pixel pairs are requested before their MFMAs.
+// 262144 pixels of the dSprites first layer = 128 MFMAs per SIMD.
+template <int RB, int CB>
+__global__ __launch_bounds__(256) void smallc_wgrad_mfma_kernel(SCParams p) {
+  ODIN_DYN_SMEM(float, red);  // [4 waves][RB*CB][16][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef ODIN_SIM
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int l31 = lane & 31, h = lane >> 5;
+  const int K = p.KH * p.KW * p.CI;
+  const int total = p.B * p.OH * p.OW;
+  const OdinRun XR = odin_run(p.x, (unsigned)((size_t)p.B * p.H * p.W * p.CI * 4));
+  const OdinRun DR = odin_run(p.dy, (unsigned)((size_t)total * p.CO * 4));
+  // row (tap) geometry of this lane for each row block
+  int tkh[RB], tkw[RB], tc[RB];
+  float aone[RB];
+  bool arow[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int k = rb * 32 + l31;
+    const int tap = k / p.CI;
+    tc[rb] = k - tap * p.CI;
+    tkh[rb] = tap / p.KW;
+    tkw[rb] = tap - tkh[rb] * p.KW;
+    arow[rb] = k < K;
+    aone[rb] = (k == K) ? 1.f : 0.f;  // bias row
+  }
+  f32x16 acc[RB][CB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = f32x16_zero();
+  // a block owns whole output rows (pix_per_block is a multiple of OW, OW even): the row decode
+  // is wave-uniform scalar work, per pixel pair only the column changes
+  const int r0 = blockIdx.x * (p.pix_per_block / p.OW);
+  int r1 = r0 + p.pix_per_block / p.OW;
+  if (r1 > p.B * p.OH) r1 = p.B * p.OH;
+  constexpr int U = 4;
+  for (int r = r0 + wave; r < r1; r += 4) {  // wave-uniform
+    const int bb = r / p.OH, oh = r - bb * p.OH;
+    const int ih0 = oh * p.S - p.pt;
+    unsigned rowoff[RB];
+    bool rowok[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int ih = ih0 + tkh[rb];
+      rowok[rb] = arow[rb] && ih >= 0 && ih < p.H;
+      rowoff[rb] = (unsigned)((((bb * p.H + ih) * p.W) * p.CI + tc[rb]) * 4);
+    }
+    const unsigned dyoff = (unsigned)((r * p.OW) * p.CO * 4);
+    for (int q0 = 0; q0 < p.OW; q0 += 2 * U) {
+      float a[U][RB], b[U][CB];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ow = q0 + 2 * u + h;
+        const bool pv = ow < p.OW;
+        const int iw0 = ow * p.S - p.pl;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          const int iw = iw0 + tkw[rb];
+          const bool ok = pv && rowok[rb] && iw >= 0 && iw < p.W;
+          float v = odin_run_load1(XR, ok ? rowoff[rb] + (unsigned)(iw * p.CI * 4) : ODIN_OOB);
+          if (p.center) v = ok ? 2.f * v - 1.f : 0.f;
+          a[u][rb] = v + (pv ? aone[rb] : 0.f);
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          const int co = cb * 32 + l31;
+          b[u][cb] = odin_run_load1(DR, (pv && co < p.CO) ? dyoff + (unsigned)((ow * p.CO + co) * 4) : ODIN_OOB);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = mfma32(a[u][rb], b[u][cb], acc[rb][cb]);
+    }
+  }
+  // combine the 4 waves in a fixed order, then write the slab row [K*CO | CO]
+  float* mine = red + wave * (RB * CB * 16 * 64);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[((rb * CB + cb) * 16 + r) * 64 + lane] = acc[rb][cb][r];
+  __syncthreads();
+  float* row = p.y + (size_t)blockIdx.x * p.slab_stride;
+  for (int e = tid; e < RB * CB * 16 * 64; e += 256) {
+    const float t = (red[e] + red[e + RB * CB * 1024]) + (red[e + 2 * RB * CB * 1024] + red[e + 3 * RB * CB * 1024]);
+    const int ln = e & 63, r = (e >> 6) & 15, blk = e >> 10;
+    const int rb = blk / CB, cb = blk - rb * CB;
+    const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+    const int co = cb * 32 + (ln & 31);
+    if (co < p.CO && k <= K) row[(size_t)k * p.CO + co] = t;  // k == K: the bias row
+  }
+}
+
 }  // namespace
 
 bool odin_smallc_applicable(const odin_conv_desc* d) {
@@ -242,11 +349,32 @@ int odin_smallc_wgrad(const float* x, const float* dy, float* slab, int* rows_ou
   int rows = ODIN_MAX_SLAB_BLOCKS;
   if (total < rows * 64L) rows = (int)((total + 63) / 64);
   p.pix_per_block = (int)((total + rows - 1) / rows);
+  const bool use_mfma = !getenv("ODIN_SMALLC_VALU") && (d->OW % 2) == 0;
+  if (use_mfma)  // whole output rows per block
+    p.pix_per_block = (p.pix_per_block + d->OW - 1) / d->OW * d->OW;
   rows = (int)((total + p.pix_per_block - 1) / p.pix_per_block);
   p.slab_stride = d->KH * d->KW * d->Cin * d->Cout + d->Cout;
   if (rows_out) *rows_out = rows;
   if (slab == nullptr) return 0;
   const int K = d->KH * d->KW * d->Cin;
+  if (use_mfma) {
+    // matrix-core kernel: RB row blocks of 32 (taps + the bias row), CB column blocks of 32
+    const int RB = (K + 1 + 31) / 32, CB = (d->Cout + 31) / 32;
+    const size_t l2 = (size_t)4 * RB * CB * 1024 * 4;
+#ifndef ODIN_SIM
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallc_wgrad_mfma_kernel<2, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr2 = true;
+    }
+#endif
+    if (RB == 1 && CB == 1) ODIN_LAUNCH((smallc_wgrad_mfma_kernel<1, 1>), dim3(rows), dim3(256), l2, stream, p);
+    else if (RB == 1 && CB == 2) ODIN_LAUNCH((smallc_wgrad_mfma_kernel<1, 2>), dim3(rows), dim3(256), l2, stream, p);
+    else if (RB == 2 && CB == 1) ODIN_LAUNCH((smallc_wgrad_mfma_kernel<2, 1>), dim3(rows), dim3(256), l2, stream, p);
+    else ODIN_LAUNCH((smallc_wgrad_mfma_kernel<2, 2>), dim3(rows), dim3(256), l2, stream, p);
+    return odin_check_launch("smallc_wgrad_mfma");
+  }
   size_t lds = (size_t)16 * (K + 1) * d->Cout * 4;
 #ifndef ODIN_SIM
   static bool attr_done = false;
