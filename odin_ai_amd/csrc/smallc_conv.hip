@@ -196,6 +196,79 @@ __global__ __launch_bounds__(1024) void smallc_wgrad_kernel(SCParams p) {
   }
 }
 
+// Forward on the matrix cores: Y[co][pixel] = W^T[co][k] * X[k][pixel] with k = (kh, kw, c)
+// padded to an even count.  A = weights (NK2 registers per 32 output channels, loaded once),
+// B = one gathered x tap per lane per k-pair (tap 2u + h of pixel l31), straight from HBM/L2.
+// A wave owns 32 consecutive pixels of one output row per iteration (OW % 32 == 0).
+template <int NK2, int RB>
+__global__ __launch_bounds__(256) void smallc_fwd_mfma_kernel(SCParams p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int K = p.KH * p.KW * p.CI;
+  const OdinRun XR = odin_run(p.x, (unsigned)((size_t)p.B * p.H * p.W * p.CI * 4));
+  const OdinRun WR = odin_run(p.w, (unsigned)((size_t)K * p.CO * 4));
+  float a[NK2][RB];
+  int tkh[NK2], tkw[NK2], tc[NK2];
+  bool tok[NK2];
+#pragma unroll
+  for (int u = 0; u < NK2; ++u) {
+    const int k = 2 * u + h;
+    const int tap = k / p.CI;
+    tc[u] = k - tap * p.CI;
+    tkh[u] = tap / p.KW;
+    tkw[u] = tap - tkh[u] * p.KW;
+    tok[u] = k < K;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int co = rb * 32 + l31;
+      a[u][rb] = odin_run_load1(WR, (k < K && co < p.CO) ? (unsigned)((k * p.CO + co) * 4) : ODIN_OOB);
+    }
+  }
+  float bias_r[RB][16];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+      bias_r[rb][i] = (p.bias != nullptr && n < p.CO) ? p.bias[n] : 0.f;
+    }
+  const int cpr = p.OW >> 5;  // 32-pixel column blocks per output row
+  const int n_it = p.B * p.OH * cpr;
+  const int gw = (blockIdx.x * 256 + tid) >> 6, nw = (gridDim.x * 256) >> 6;
+  for (int it = gw; it < n_it; it += nw) {  // wave-uniform
+    const int r = it / cpr, q0 = (it - r * cpr) << 5;
+    const int bb = r / p.OH, oh = r - bb * p.OH;
+    const int ow = q0 + l31;
+    const int ih0 = oh * p.S - p.pt, iw0 = ow * p.S - p.pl;
+    float b[NK2];
+#pragma unroll
+    for (int u = 0; u < NK2; ++u) {
+      const int ih = ih0 + tkh[u], iw = iw0 + tkw[u];
+      const bool ok = tok[u] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+      float v = odin_run_load1(XR, ok ? (unsigned)((((bb * p.H + ih) * p.W + iw) * p.CI + tc[u]) * 4) : ODIN_OOB);
+      if (p.center) v = ok ? 2.f * v - 1.f : 0.f;
+      b[u] = v;
+    }
+    float* outp = p.y + ((size_t)(r * p.OW + ow)) * p.CO + 4 * h;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      f32x16 acc = f32x16_zero();
+#pragma unroll
+      for (int u = 0; u < NK2; ++u) acc = mfma32(a[u][rb], b[u], acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = rb * 32 + 8 * q + 4 * h;
+        if (n + 3 < p.CO)
+          *reinterpret_cast<float4*>(outp + rb * 32 + 8 * q) =
+              make_float4(odin_act(p.act, acc[4 * q] + bias_r[rb][4 * q]),
+                          odin_act(p.act, acc[4 * q + 1] + bias_r[rb][4 * q + 1]),
+                          odin_act(p.act, acc[4 * q + 2] + bias_r[rb][4 * q + 2]),
+                          odin_act(p.act, acc[4 * q + 3] + bias_r[rb][4 * q + 3]));
+      }
+    }
+  }
+}
+
 // Weight gradient on the matrix cores, operands straight from HBM/L2 (no LDS staging): with
 // K = KH*KW*Cin <= 63 the whole dW is RB x CB accumulator tiles (rows = taps (+ one bias row whose
 // A operand is the constant 1), columns = output channels) and the MFMA reduction index is the
@@ -329,6 +402,17 @@ int odin_smallc_fwd(const float* x, const float* w, const float* bias, float* y,
   if (blocks > 16384) blocks = 16384;
   size_t lds = (size_t)(d->KH * d->KW * d->Cin + 1) * d->Cout * 4;
   const bool small_x = (size_t)d->B * d->H * d->W * d->Cin * 4 < 0x7FFFFFF0u;
+  if (small_x && (d->OW % 32) == 0 && !getenv("ODIN_SMALLC_VALU")) {
+    const int K = d->KH * d->KW * d->Cin;
+    const int nk2 = (K + 1) / 2, rb = (d->Cout + 31) / 32;
+    const long n_it = (long)d->B * d->OH * (d->OW / 32);
+    long bl = (n_it + 3) / 4;
+    if (bl > 2048) bl = 2048;
+    if (nk2 == 8 && rb == 1) { ODIN_LAUNCH((smallc_fwd_mfma_kernel<8, 1>), dim3((unsigned)bl), dim3(256), 0, stream, p); return odin_check_launch("smallc_fwd_mfma"); }
+    if (nk2 == 8 && rb == 2) { ODIN_LAUNCH((smallc_fwd_mfma_kernel<8, 2>), dim3((unsigned)bl), dim3(256), 0, stream, p); return odin_check_launch("smallc_fwd_mfma"); }
+    if (nk2 == 24 && rb == 1) { ODIN_LAUNCH((smallc_fwd_mfma_kernel<24, 1>), dim3((unsigned)bl), dim3(256), 0, stream, p); return odin_check_launch("smallc_fwd_mfma"); }
+    if (nk2 == 24 && rb == 2) { ODIN_LAUNCH((smallc_fwd_mfma_kernel<24, 2>), dim3((unsigned)bl), dim3(256), 0, stream, p); return odin_check_launch("smallc_fwd_mfma"); }
+  }
   if (small_x && d->KH == 4 && d->KW == 4 && d->Cin == 1)
     ODIN_LAUNCH((smallc_fwd_kernel_t<4, 4, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
   else if (small_x && d->KH == 4 && d->KW == 4 && d->Cin == 3)

@@ -41,6 +41,8 @@ CONV_CASES = [
     # B, H, W, Cin, Cout, K, S, act, center
     (2, 16, 16, 1, 32, 4, 2, 'elu', True),
     (2, 16, 16, 3, 32, 4, 2, 'elu', True),     # small-Cin VALU kernels, 48 taps
+    (1, 64, 64, 1, 32, 4, 2, 'elu', True),     # first-layer matrix-core kernels (32-pixel row blocks)
+    (1, 64, 64, 3, 64, 4, 2, 'elu', True),     # first-layer matrix-core kernels, 48 taps, 64 channels
     (3, 12, 12, 1, 64, 5, 1, 'elu', False),    # small-Cin VALU kernels, 25 taps, 64 lanes per pixel
     (3, 8, 8, 32, 32, 4, 2, 'elu', False),
     (2, 8, 8, 32, 64, 4, 2, 'elu', False),
