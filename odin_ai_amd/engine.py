@@ -680,13 +680,22 @@ class VAEEngine:
       self.adam(global_clipnorm=global_clipnorm)
     return self.out4
 
+  def input_buffer(self) -> torch.Tensor:
+    """The static [B, H, W, C] input tensor the captured step graph reads.  A data pipeline that
+    writes the next batch straight into it (and passes it to train_step) saves the per-step
+    device-to-device copy."""
+    if getattr(self, 'x_static', None) is None:
+      self.x_static = torch.empty((self.B,) + self.in_shape, dtype=torch.float32, device=self.device)
+    return self.x_static
+
   def _graph_step(self, x, eps, global_clipnorm):
     """Capture forward+backward+Adam once into a HIP graph, replay afterwards.  The input
     batch is copied into a static buffer; eps comes from the on-device Philox stream
     unless given explicitly."""
     if self.graph is None:
-      self.x_static = torch.empty_like(x)
-      self.x_static.copy_(x)
+      self.input_buffer()
+      if x.data_ptr() != self.x_static.data_ptr():
+        self.x_static.copy_(x)
       if eps is not None:
         self.eps.copy_(eps)
       # warm-up outside capture (first-call attribute setup, lazy allocations)
@@ -707,7 +716,8 @@ class VAEEngine:
         self.backward()
         self.adam(global_clipnorm=global_clipnorm)
       self.graph = g
-    self.x_static.copy_(x, non_blocking=True)
+    if x.data_ptr() != self.x_static.data_ptr():  # a producer may write the static buffer directly
+      self.x_static.copy_(x, non_blocking=True)
     if eps is not None:
       self.eps.copy_(eps, non_blocking=True)
     self.graph.replay()
@@ -716,8 +726,9 @@ class VAEEngine:
     """Data-parallel variant: graph A = forward + backward + slab reduction, then ONE RCCL
     all-reduce of the flat gradient bucket (eager, on the same stream), then graph B = Adam."""
     if self.graph is None:
-      self.x_static = torch.empty_like(x)
-      self.x_static.copy_(x)
+      self.input_buffer()
+      if x.data_ptr() != self.x_static.data_ptr():
+        self.x_static.copy_(x)
       if eps is not None:
         self.eps.copy_(eps)
       cap = torch.cuda.Stream(self.device)
@@ -737,7 +748,8 @@ class VAEEngine:
       with torch.cuda.graph(gb, stream=cap, capture_error_mode='thread_local'):
         self.adam(global_clipnorm=global_clipnorm)
       self.graph, self.graph_b = ga, gb
-    self.x_static.copy_(x, non_blocking=True)
+    if x.data_ptr() != self.x_static.data_ptr():  # a producer may write the static buffer directly
+      self.x_static.copy_(x, non_blocking=True)
     if eps is not None:
       self.eps.copy_(eps, non_blocking=True)
     self.graph.replay()
