@@ -1,8 +1,10 @@
 // smallc_conv.hip -- first-layer convolutions (Cin <= 4: grey / RGB images) forward and
 // weight-gradient.  These layers are HBM-bound (dSprites conv1: 0.27 GFLOP against 37 MB
-// of traffic at batch 256), far below the MFMA ridge, so they run on the vector ALUs with
-// perfectly coalesced 16-byte output stores instead of wasting 32-wide MFMA tiles on a
-// reduction depth of 16.  (Reference: first Conv2D of every get_networks encoder,
+// of traffic at batch 256) with a reduction depth of only 16-48, so nothing is staged in LDS:
+// the matrix-core kernels below gather their operands straight from HBM/L2 (one tap per lane
+// per MFMA) and store 16-byte NHWC pieces; vector-ALU kernels cover the shapes the row-block
+// mapping does not (output widths that are not a multiple of 32 / odd).
+// (Reference: first Conv2D of every get_networks encoder,
 // odin/networks/image_networks.py:244,463,679; `CenterAt0` :121-126 folded into the load.)
 #include "odin_device.h"
 #include "odin_internal.h"
