@@ -52,6 +52,7 @@ struct GParams {
   int KS;                          // intra-workgroup split of the reduction (1, 2 or 4 waves per M-tile)
   int n_batches;                   // staging batches per patch (1 when pipelined)
   int flat;                        // 1x1 images (Dense): the patch is one contiguous [NIMG, CIC] block
+  int wdma;                        // weight slice staged by LDS-DMA (wmode 0, full blocks)
   long long* stamps;  // diagnostic: s_memtime stamps of workgroup 0 / wave 0 (env ODIN_STAMPS)
   int dbg;  // diagnostic ablation mask (env ODIN_DBG): 1 skip MFMA, 2 skip stores, 4 skip patch staging
 };
@@ -68,6 +69,24 @@ __device__ __forceinline__ void stage_weights(const GParams& p, float* wl, int c
   if (p.wmode == 0) {
     // global [tap][ci][co]: rows of 32 consecutive output channels
     const bool vec = ((p.CO & 3) == 0);
+    if (vec && p.wdma) {
+      // full 32-channel block, whole reduction in one chunk: the LDS image [tap*CIC + ci][32] is
+      // lane-linear in 16-byte pieces, so the slice goes HBM -> LDS by DMA (no registers, no
+      // ds_write; for a workgroup that computes one or two tiles the register-staged copy costs
+      // as much as the tiles).  The issuing wave's vmcnt covers it before the first barrier.
+      const int total = ntaps * p.CIC * 8;  // 16-byte pieces
+      const int lane = tid & 63, w0 = tid - lane;
+      for (int e0 = w0; e0 < total; e0 += nthreads) {  // wave-uniform
+        const int e = e0 + lane;
+        if (e < total) {
+          const int t2 = e >> 3;
+          const int ci = t2 % p.CIC, tap = t2 / p.CIC;
+          odin_run_dma16(WR, wl + (size_t)e0 * 4,
+                         (unsigned)((((tap * p.CI + c0 + ci) * p.CO) + n0 + (e & 7) * 4) * 4), lane);
+        }
+      }
+      return;
+    }
     if (vec) {
       const int total = ntaps * p.CIC * 8;  // float4 items
       for (int e0 = tid; e0 < total; e0 += nthreads * U) {
@@ -1294,6 +1313,8 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
       }
     }
   }
+  p.wdma = (p.wmode == 0 && p.w_resident && (p.CO % 32) == 0 && p.CI == p.CIC && (p.CIC % 8) == 0 &&
+            !getenv("ODIN_NOWDMA")) ? 1 : 0;
   if (rows_out) *rows_out = gx;
   if (p.out == nullptr) return 0;  // dry run: planning only
   {
