@@ -177,6 +177,15 @@ int odin_sumsq_flat(const float* g, size_t n, float* workspace, float* out, void
  * reproducible across frameworks, so parity tests pass eps explicitly) ------------------ */
 int odin_rng_normal(float* out, size_t n, uint64_t seed, const int32_t* step_dev, void* stream);
 
+/* ---- on-device input pipeline: batch gather from an HBM-resident uint8 dataset
+ * [N, n_per] + ImageDataset.normalize (odin/fuel/image_data/_base.py:130-147), replacing the
+ * tf.data map/batch of create_dataset (:338-395).  out[b, e] = normalize(premul * data[idx[b], e]);
+ * mode 0 'probs': clip(x,0,255)/255 clipped to [1e-6, 1-1e-6]; 1 'tanh': clip(x/255*2-1);
+ * 2 'raster': clip(x,0,255); 3: binarised data, premul * x unchanged.  dSprites stores 0/1
+ * and uses premul = 255 (fuel/image_data/shapes.py:69-72,80).  n_per % 16 == 0. */
+int odin_gather_normalize_u8(const uint8_t* data, const int32_t* idx, float* out, int B, int n_per,
+                             float premul, int mode, void* stream);
+
 /* ---- speech front-end: pre-emphasis -> STFT -> |.|^2 -> Slaney mel -> dB
  * (odin/preprocessing/signal.py:955-967,1442-1562,1623-1691,636-680).
  * y [B,n_samples] -> out [B,n_frames,n_mels], n_frames = 1 + (n_samples-frame_length)/step;

@@ -360,6 +360,51 @@ extern "C" int odin_sumsq_flat(const float* g, size_t n, float* workspace, float
   return odin_check_launch("sumsq");
 }
 
+// ------------------------------------------------------------------ input pipeline ----
+// batch gather + ImageDataset.normalize from an HBM-resident uint8 dataset
+// (odin/fuel/image_data/_base.py:130-147; dSprites pre-multiplies its 0/1 pixels by 255,
+// fuel/image_data/shapes.py:69-72,80).  16 pixels (one 16-byte load) per thread.
+__global__ __launch_bounds__(256) void gather_normalize_u8_kernel(const unsigned char* __restrict__ data,
+                                                                  const int* __restrict__ idx,
+                                                                  float* __restrict__ out, int B,
+                                                                  int n_per, float premul, int mode) {
+  const int per16 = n_per >> 4;
+  const long total = (long)B * per16;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int b = (int)(t / per16), q = (int)(t - (long)b * per16);
+    const uint4 raw = *reinterpret_cast<const uint4*>(data + (size_t)idx[b] * n_per + (size_t)q * 16);
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+    float* o = out + (size_t)b * n_per + (size_t)q * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = (float)((w[k] >> (8 * j)) & 0xFFu) * premul;
+        if (mode == 3) {
+          v[j] = x;  // binarised data passes through
+        } else {
+          x = fminf(fmaxf(x, 0.f), 255.f);
+          if (mode == 0) x = fminf(fmaxf(x / 255.f, 1e-6f), 1.f - 1e-6f);                  // 'probs'
+          else if (mode == 1) x = fminf(fmaxf(x / 255.f * 2.f - 1.f, -1.f + 1e-6f), 1.f - 1e-6f);  // 'tanh'
+          v[j] = x;                                                                           // 'raster'
+        }
+      }
+      *reinterpret_cast<float4*>(o + 4 * k) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+extern "C" int odin_gather_normalize_u8(const uint8_t* data, const int32_t* idx, float* out, int B,
+                                        int n_per, float premul, int mode, void* stream) {
+  if (n_per % 16 != 0) return odin_fail(-2, "gather_normalize_u8: pixels per image must be a multiple of 16");
+  if (mode < 0 || mode > 3) return odin_fail(-2, "gather_normalize_u8: mode must be 0..3");
+  int grid = grid_for((size_t)B * (n_per / 16), 256, 4096);
+  ODIN_LAUNCH(gather_normalize_u8_kernel, dim3(grid), dim3(256), 0, stream, data, (const int*)idx, out,
+              B, n_per, premul, mode);
+  return odin_check_launch("gather_normalize_u8");
+}
+
 extern "C" int odin_rng_normal(float* out, size_t n, uint64_t seed, const int32_t* step_dev,
                                void* stream) {
   int grid = grid_for((n + 3) / 4, 256, 2048);

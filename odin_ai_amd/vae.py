@@ -251,6 +251,12 @@ class VariationalAutoencoder:
     eng = self._engine(1)  # validates shapes, allocates + initialises parameters
     return self
 
+  def input_buffer(self, batch_size: int) -> torch.Tensor:
+    """The float32 [B, H, W, C] tensor the captured training-step graph for this batch size
+    reads: hand it to `odin_ai_amd.data.DeviceImageDataset(out=...)` (or fill it in place) and
+    pass the batches it yields to `fit` / `optimize` -- no per-step input copy."""
+    return self._engine(int(batch_size)).input_buffer()
+
   def _engine(self, B: int) -> VAEEngine:
     if self.input_shape is None:
       raise RuntimeError('model is not built: call build((None, H, W, C)) first')

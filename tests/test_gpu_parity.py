@@ -159,3 +159,32 @@ def test_full_size_configs_3_and_4(dev, L):
     l0 = float(loss) if l0 is None else l0
   assert np.isfinite(float(loss)) and float(loss) < l0
   assert np.isfinite(float(m['tc_latents']))
+
+
+def test_device_input_pipeline(dev, L):
+  """uint8 dataset resident in HBM -> batch gather + ImageDataset.normalize on the
+  device, bit-exact against the numpy restatement at dSprites size; the batches land in the
+  tensor the step graph reads and fit() trains from them."""
+  from odin_ai_amd.data import DeviceImageDataset
+  from odin_ai_amd.networks import get_networks
+  from odin_ai_amd.vae import BetaVAE
+  from oracle import data_oracle as do
+  rng = np.random.default_rng(0)
+  imgs = (rng.random((1024, 64, 64, 1)) < 0.15).astype(np.uint8)  # dSprites-like 0/1 pixels
+  ds = DeviceImageDataset(imgs, batch_size=256, normalize='probs', premul=255.0, device=dev, lib=L)
+  idx = rng.permutation(1024)[:256].astype(np.int32)
+  got = ds.gather(torch.from_numpy(idx)).cpu().numpy()
+  assert np.array_equal(got, do.gather_normalize(imgs, idx, 'probs', 255.0))
+  g8 = rng.integers(0, 256, size=(64, 64, 64, 3), dtype=np.uint8)
+  for mode in ('probs', 'tanh', 'raster'):
+    d2 = DeviceImageDataset(g8, batch_size=8, normalize=mode, device=dev, lib=L)
+    i2 = np.arange(8, dtype=np.int32)[::-1].copy()
+    assert np.array_equal(d2.gather(torch.from_numpy(i2)).cpu().numpy(), do.gather_normalize(g8, i2, mode))
+  vae = BetaVAE(beta=4.0, device=dev, lib=L, **get_networks('dsprites'))
+  ds = DeviceImageDataset(imgs, batch_size=64, normalize='probs', premul=255.0, device=dev, lib=L,
+                          out=vae.input_buffer(64))
+  x0 = ds.gather(torch.arange(64, dtype=torch.int32)).clone()
+  l0, _ = vae.optimize(x0, training=False)
+  vae.fit(ds, max_iter=40, batch_size=64, learning_rate=1e-3, compile_graph=True)
+  l1, _ = vae.optimize(x0, training=False)
+  assert vae.step == 40 and float(l1) < float(l0)
