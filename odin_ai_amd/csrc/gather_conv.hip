@@ -140,9 +140,12 @@ __device__ __forceinline__ void stage_weights(const GParams& p, float* wl, int c
         float4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+          // item -> (output channel fastest, then channel group, then tap): the four
+          // transposed LDS writes of a wave then hit consecutive banks (a channel-group-fastest
+          // order put all 64 lanes on 4 banks: 16-way conflicts on every write)
           int e = e0 + u * nthreads;
-          int ci = (e % c4n) * 4, t2 = e / c4n;
-          int co = t2 & 31, tap = t2 >> 5;
+          int co = e & 31, t2 = e >> 5;
+          int ci = (t2 % c4n) * 4, tap = t2 / c4n;
           int c = c0 + ci, n = n0 + co;
           const bool ok = e < total && c < p.CI && n < p.CO;
           v[u] = odin_run_load4(WR, ok ? (unsigned)(((tap * p.CO + n) * p.CI + c) * 4) : ODIN_OOB);
@@ -151,8 +154,8 @@ __device__ __forceinline__ void stage_weights(const GParams& p, float* wl, int c
         for (int u = 0; u < U; ++u) {
           int e = e0 + u * nthreads;
           if (e < total) {
-            int ci = (e % c4n) * 4, t2 = e / c4n;
-            int co = t2 & 31, tap = t2 >> 5;
+            int co = e & 31, t2 = e >> 5;
+            int ci = (t2 % c4n) * 4, tap = t2 / c4n;
             float* d = wl + (tap * p.CIC + ci) * p.WP + co;
             d[0] = v[u].x; d[p.WP] = v[u].y; d[2 * p.WP] = v[u].z; d[3 * p.WP] = v[u].w;
           }
