@@ -621,6 +621,83 @@ __device__ __forceinline__ f32x16 mtile_compute_split(const GParams& p, const ch
   return accE;
 }
 
+// ---- split path, 8-wave workgroups: the bf16 weight planes live in LDS ---------------------
+// [plane 3][tap 16][kgroup 2][k-half 2][out channel 32][8 bf16] = 96 KB, shared by the 8 waves
+// (two per SIMD) of the workgroup; fragment (tap, kg, h, co) is one 16-byte read.
+constexpr int SPLIT_WPLANE = 16 * 2 * 2 * 32 * 16;  // bytes per plane
+
+__device__ __forceinline__ void stage_weights_split(const GParams& p, char* wlb, int n0, int tid,
+                                                    int nthreads) {
+  const OdinRun WR = odin_run(p.w, (unsigned)((size_t)p.KH * p.KW * p.CI * p.CO * 4));
+  for (int i = tid; i < 16 * 2 * 2 * 32; i += nthreads) {
+    const int co = n0 + (i & 31), hh = (i >> 5) & 1, kg = (i >> 6) & 1, wt = i >> 7;
+    const int ci0 = kg * 16 + hh * 8;
+    float f[8];
+    if (p.wmode == 1) {
+      const unsigned off = co < p.CO ? (unsigned)(((wt * p.CO + co) * p.CI + ci0) * 4) : ODIN_OOB;
+      const float4 u0 = odin_run_load4(WR, off), u1 = odin_run_load4(WR, off == ODIN_OOB ? off : off + 16);
+      f[0] = u0.x; f[1] = u0.y; f[2] = u0.z; f[3] = u0.w;
+      f[4] = u1.x; f[5] = u1.y; f[6] = u1.z; f[7] = u1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        f[j] = odin_run_load1(WR, co < p.CO ? (unsigned)(((wt * p.CI + ci0 + j) * p.CO + co) * 4) : ODIN_OOB);
+    }
+    u32x4 a0, a1, a2;
+    split_fragment(f, a0, a1, a2);
+    *reinterpret_cast<u32x4*>(wlb + i * 16) = a0;
+    *reinterpret_cast<u32x4*>(wlb + SPLIT_WPLANE + i * 16) = a1;
+    *reinterpret_cast<u32x4*>(wlb + 2 * SPLIT_WPLANE + i * 16) = a2;
+  }
+}
+
+__device__ __forceinline__ f32x16 mtile_compute_split_lds(const GParams& p, const char* patch, int pls,
+                                                          int pix0, int l31, int h, int kh0, int kw0,
+                                                          const char* wlb) {
+  f32x16 accE = f32x16_zero(), accO = f32x16_zero();
+  const char* bp = patch + pix0 * SPLIT_PITCH + h * 16;
+  const char* ap = wlb + (h * 32 + l31) * 16;
+  u32x4 a0[3], b0[3], a1[3], b1[3];
+  auto loads = [&](int step, u32x4 (&a)[3], u32x4 (&b)[3]) {
+    const int tap = step >> 1, kg = step & 1;
+    const int jh = tap >> 1, jw = tap & 1;
+    const int wt = (kh0 + 2 * jh) * 4 + (kw0 + 2 * jw);
+    const char* qa = ap + ((wt * 2 + kg) * 2) * 32 * 16;
+    const char* qb = bp - (jh * p.PW + jw) * SPLIT_PITCH + kg * 32;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      a[pl] = *reinterpret_cast<const u32x4*>(qa + pl * SPLIT_WPLANE);
+      b[pl] = *reinterpret_cast<const u32x4*>(qb + pl * pls);
+    }
+  };
+  auto mm = [&](const u32x4 (&a)[3], const u32x4 (&b)[3]) {
+    accE = mfma32_bf16(a[2], b[0], accE);
+    accO = mfma32_bf16(a[0], b[2], accO);
+    accE = mfma32_bf16(a[1], b[1], accE);
+    accO = mfma32_bf16(a[1], b[0], accO);
+    accE = mfma32_bf16(a[0], b[1], accE);
+    accO = mfma32_bf16(a[0], b[0], accO);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
+      ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 1);
+    }
+    ODIN_SCHED_FENCE();
+  };
+  loads(0, a0, b0);
+  ODIN_SCHED_FENCE();
+#pragma unroll
+  for (int st = 0; st < 8; st += 2) {
+    loads(st + 1, a1, b1);
+    mm(a0, b0);
+    if (st + 2 < 8) loads(st + 2, a0, b0);
+    mm(a1, b1);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accE[i] += accO[i];
+  return accE;
+}
+
 // Fused decoder tail (training step): this kernel's layer is a Conv2DTranspose whose
 // output feeds a 1x1 linear Conv2D with C1 <= 4 maps that parameterise
 // Independent(Bernoulli(logits)).  The epilogue evaluates the 1x1 conv, the Bernoulli
@@ -675,11 +752,12 @@ __device__ __forceinline__ float sigmoid_g(float x) {
 // SPL: split path (three bf16 planes, weights in registers; MODE_T k4/s2 32-channel instances).
 template <int MODE, int NW, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI, int NMT,
           bool SPL = false>
-__global__ __launch_bounds__(NW * 64, (MODE == MODE_T && TK == 4 && TCIC == 32 && RPWMAX == 1 && TAIL <= 1 &&
-                                       !(SPL && TAIL > 0)) ? 2 : 1)
+__global__ __launch_bounds__(NW * 64, (NW == 4 && MODE == MODE_T && TK == 4 && TCIC == 32 && RPWMAX == 1 &&
+                                       TAIL <= 1 && !(SPL && TAIL > 0)) ? 2 : 1)
 void gather_conv_kernel(GParams p, TailParams tp) {
   static_assert(!SPL || (MODE == MODE_T && TK == 4 && TS == 2 && TCIC == 32 && VEC && NMT == 1 && RPWMAX == 1),
                 "split path: transposed 4x4/s2 gather, 32 reduction channels, one M-tile per wave");
+  constexpr bool SPLW = SPL && NW == 8;  // 8 waves: bf16 weight planes in LDS instead of registers
   ODIN_DYN_SMEM(float, smem);
   float* patch = smem;
   float* wl = smem + p.patch_floats;
@@ -695,8 +773,10 @@ void gather_conv_kernel(GParams p, TailParams tp) {
   const bool pipelined = p.pipelined != 0;
   const LaneStage<KMAX> LS = lane_stage_init<KMAX, VEC>(p, lane);
 
-  const int wfloats = SPL ? 0 : p.KH * p.KW * p.CIC * p.WP;  // LDS floats of the weight slice
+  // LDS floats of the weight slice
+  const int wfloats = SPLW ? (3 * SPLIT_WPLANE) / 4 : (SPL ? 0 : p.KH * p.KW * p.CIC * p.WP);
   if (p.w_resident && !SPL) stage_weights(p, wl, 0, n0, tid, NT);
+  if constexpr (SPLW) stage_weights_split(p, reinterpret_cast<char*>(wl), n0, tid, NT);
   ODIN_STAMP(2);
 
   float bsum[16];
@@ -753,11 +833,11 @@ void gather_conv_kernel(GParams p, TailParams tp) {
   const bool co_vec = ((p.CO & 3) == 0);
 
   // split path: this wave's weight fragments (its M-tile has a fixed tap phase) and patch geometry
-  u32x4 Afr[SPL ? 3 : 1][SPL ? 4 : 1][SPL ? 2 : 1];
+  u32x4 Afr[(SPL && !SPLW) ? 3 : 1][(SPL && !SPLW) ? 4 : 1][(SPL && !SPLW) ? 2 : 1];
   const int pls = p.NIMG * p.NRI * p.PW * SPLIT_PITCH;  // bytes per bf16 plane
   int pix0 = 0;
-  if constexpr (SPL) {
-    pix0 = s0.base / p.P;
+  if constexpr (SPL) pix0 = s0.base / p.P;
+  if constexpr (SPL && !SPLW) {
     const OdinRun WR = odin_run(p.w, (unsigned)((size_t)p.KH * p.KW * p.CI * p.CO * 4));
     const int co = n0 + l31;
 #pragma unroll
@@ -843,7 +923,12 @@ void gather_conv_kernel(GParams p, TailParams tp) {
       }
       ODIN_STAMP(6);
       constexpr int SGK = (TAIL > 0 && RPWMAX == 1) ? 8 : 16;
-      if constexpr (SPL) {
+      if constexpr (SPLW) {
+        if (mt0 < p.MT)
+          acc0 = mtile_compute_split_lds(p, reinterpret_cast<const char*>(patch), pls, pix0, l31, h,
+                                         ODIN_UNIFORM(s0.kh0), ODIN_UNIFORM(s0.kw0),
+                                         reinterpret_cast<const char*>(wl));
+      } else if constexpr (SPL) {
         if (mt0 < p.MT)
           acc0 = mtile_compute_split(p, reinterpret_cast<const char*>(patch), pls, pix0, h, Afr);
       } else if (mt0 < p.MT) {
@@ -1240,13 +1325,13 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
 long long* g_stamps = nullptr;
 
 template <int MODE, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI, int NMT,
-          bool SPL = false>
+          bool SPL = false, int NWL = 4>
 int launch_inst2(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* stream) {
   if (p.KI > KMAX) return odin_fail(-2, "gather_conv: patch row too long for this instance");
-  const int rpw = (p.NIMG * p.NRI + NW_G - 1) / NW_G;
+  const int rpw = (p.NIMG * p.NRI + NWL - 1) / NWL;
   if (EPI == 3) {
     const int items = p.NIMG * (p.vec ? p.CIC / 4 : p.CIC);
-    p.n_batches = (items + KMAX * RPWMAX * NW_G * 64 - 1) / (KMAX * RPWMAX * NW_G * 64);
+    p.n_batches = (items + KMAX * RPWMAX * NWL * 64 - 1) / (KMAX * RPWMAX * NWL * 64);
   } else {
     p.n_batches = (rpw + RPWMAX - 1) / RPWMAX;
   }
@@ -1256,13 +1341,13 @@ int launch_inst2(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* 
   if (!attr_done) {
     (void)hipFuncSetAttribute(
         reinterpret_cast<const void*>(
-            &gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, NMT, SPL>),
+            &gather_conv_kernel<MODE, NWL, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, NMT, SPL>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((gather_conv_kernel<MODE, NW_G, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, NMT, SPL>), grid,
-              dim3(NW_G * 64), lds, stream, p, tp);
+  ODIN_LAUNCH((gather_conv_kernel<MODE, NWL, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, NMT, SPL>), grid,
+              dim3(NWL * 64), lds, stream, p, tp);
   return odin_check_launch("gather_conv");
 }
 
@@ -1275,11 +1360,11 @@ int launch_inst(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* s
 }
 
 // Split path (three bf16 planes, register-resident weights): eligibility and LDS size.
-// Opt-in (ODIN_SPLIT=1): correct to fp32-class accuracy and 2.7x lighter on the matrix pipe, but
-// measured SLOWER than the fp32 instances on MI355X in this form -- the 96 registers of weight
-// fragments push the two-workgroups-per-CU variants into scratch (103-122 spilled registers) and
-// the one-workgroup fused tail loses the wait hiding of its partner (144.6 vs 121.8 us).  Needs an
-// 8-wave workgroup sharing LDS-resident weight planes (DESIGN.md section 5, next levers).
+// ODIN_SPLIT=1 selects the first form of the split path (4-wave workgroups, weight fragments in 96
+// registers): correct, but slower than the fp32 instances -- the two-workgroups-per-CU variants
+// spill (103-122 registers) and the one-workgroup fused tail loses the wait hiding of its partner
+// (144.6 vs 121.8 us).  The default is the 8-wave form with the weight planes in LDS (split8 in
+// launch_gather: fused tail 116.7 -> 89.4 us).
 bool split_ok(const GParams& p) {
   const char* e = getenv("ODIN_SPLIT");
   return e != nullptr && e[0] == '1' && p.CI == 32 && !p.center && p.MT <= NW_G && p.w_resident;
@@ -1318,6 +1403,35 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
   }
   p.wdma = (p.wmode == 0 && p.w_resident && (p.CO % 32) == 0 && p.CI == p.CIC && (p.CIC % 8) == 0 &&
             !getenv("ODIN_NOWDMA")) ? 1 : 0;
+  // opt-in ODIN_SPLIT=8: 8-wave workgroups (two waves per SIMD) on 256-pixel tiles, fp32 through
+  // the bf16 pipe with the three weight planes shared in LDS
+  int split8 = 0;  // 1: EPI 1, 2: EPI 2, 3: fused tail (EPI 1, one logit map)
+  {
+    const char* e = getenv("ODIN_SPLIT");
+    const bool on8 = e == nullptr || e[0] == '8';  // default; ODIN_SPLIT=0: fp32 MFMA instances
+    const bool elu_fwd = p.act == ODIN_ACT_ELU && p.aux == nullptr;
+    const bool lin_bwd = p.act == ODIN_ACT_LINEAR && p.aux != nullptr && p.aux_act == ODIN_ACT_ELU;
+    if (on8 && mode == MODE_T && p.KH == 4 && p.KW == 4 && p.S == 2 &&
+        p.CI == 32 && (p.CO % 32) == 0 && !p.center && (elu_fwd || lin_bwd) &&
+        (tail == nullptr || (elu_fwd && (tail->C1 == 1 || tail->C1 == 3) && p.CO == 32))) {
+      GParams q = p;
+      int gx2;
+      size_t l2;
+      if (plan_gather(q, mode, max_blocks, &gx2, &l2, 256) && q.MT == 8 && q.n_chunks == 1 && q.vec &&
+          q.KI <= 5 && q.NIMG * q.NRI <= 8 && q.NIMG == 1) {
+        q.patch_floats = (int)((((long)3 * q.NIMG * q.NRI * q.PW * SPLIT_PITCH) / 4 + 3) & ~3L);
+        const long total = (long)q.patch_floats + (3 * SPLIT_WPLANE) / 4 + W_SCRATCH;
+        if (total * 4 <= 158 * 1024) {
+          int cap = odin_num_cus();
+          if (max_blocks < 0 && -max_blocks < cap) cap = -max_blocks;
+          p = q;
+          gx = p.n_tiles < cap ? p.n_tiles : cap;
+          lds = (size_t)total * 4;
+          split8 = tail != nullptr ? (tail->C1 == 1 ? 3 : 4) : (elu_fwd ? 1 : 2);
+        }
+      }
+    }
+  }
   if (rows_out) *rows_out = gx;
   if (p.out == nullptr) return 0;  // dry run: planning only
   {
@@ -1338,6 +1452,13 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
   const int epi = !fulln ? 0
                   : (p.act == ODIN_ACT_ELU && p.aux == nullptr) ? 1
                   : (p.act == ODIN_ACT_LINEAR && p.aux != nullptr && p.aux_act == ODIN_ACT_ELU) ? 2 : 0;
+  if (split8 != 0) {
+    if (tail != nullptr) tp = *tail;
+    if (split8 == 3) return launch_inst2<MODE_T, 4, 2, 32, true, 1, 5, 1, 1, 1, true, 8>(p, tp, grid, lds, stream);
+    if (split8 == 4) return launch_inst2<MODE_T, 4, 2, 32, true, 3, 5, 1, 1, 1, true, 8>(p, tp, grid, lds, stream);
+    if (split8 == 1) return launch_inst2<MODE_T, 4, 2, 32, true, 0, 5, 1, 1, 1, true, 8>(p, tp, grid, lds, stream);
+    return launch_inst2<MODE_T, 4, 2, 32, true, 0, 5, 1, 2, 1, true, 8>(p, tp, grid, lds, stream);
+  }
   if (tail != nullptr) {
     tp = *tail;
     if (p.CO > 32 || tp.C1 > MAXC1 || p.NIMG != 1 || !p.vec)
