@@ -290,7 +290,12 @@ def main():
   roofline = dict(bound='mfma', kernel=f"{dom['layer']}:{dom['op']}",
                   achieved=round(dom['tflops'], 3), peak=PEAK_MFMA_F32_TFLOPS, unit='TFLOP/s',
                   frac=round(dom['tflops'] / PEAK_MFMA_F32_TFLOPS, 4), traffic=None,
-                  us_per_launch=round(dom['us'], 2), gflop_per_launch=round(dom['gflop'], 4))
+                  us_per_launch=round(dom['us'], 2), gflop_per_launch=round(dom['gflop'], 4),
+                  # fp32 MFMA kernels are priced against the fp32 MFMA peak.  The transposed 4x4/s2
+                  # 32-channel layers (fused tail, conv2 data-gradient) run fp32 through the bf16
+                  # pipe (exact 3 x bf16 split, 6 bf16 MFMAs per 16 k-values: pipe-equivalent
+                  # peak 2.67 x 157.3); their rate is still quoted in fp32 FLOPs
+                  note='fp32 FLOPs / fp32 MFMA peak; ODIN_SPLIT=0 disables the bf16-split instances')
   # HBM traffic of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
   # collected inside this process); null when no measurement for this kernel is on file
   try:
