@@ -1432,6 +1432,31 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
       }
     }
   }
+  // 64 reduction channels (weight slice 128 KB, one 4-wave workgroup per CU): an 8-wave workgroup
+  // on a 256-pixel tile shares the slice, so each SIMD holds two waves that hide each other's
+  // staging and barrier waits (what two workgroups per CU do for the 32-channel instances)
+  int wave8 = 0;  // 1: forward (ELU epilogue)
+  if (split8 == 0 && tail == nullptr && mode == MODE_T && p.KH == 4 && p.KW == 4 && p.S == 2 &&
+      p.CI == 64 && (p.CO % 32) == 0 && !p.center && !getenv("ODIN_NOWAVE8")) {
+    const bool elu_fwd = p.act == ODIN_ACT_ELU && p.aux == nullptr;
+    GParams q = p;
+    int gx2;
+    size_t l2;
+    // (the data-gradient epilogue variant does not fit 256 registers without spilling: measured
+    // slower, so only the forward instance is routed here)
+    if (elu_fwd && plan_gather(q, mode, max_blocks, &gx2, &l2, 256) && q.MT == 8 &&
+        q.n_chunks == 1 && q.CIC == 64 && q.vec && q.KI <= 5 && (q.NIMG * q.NRI + 7) / 8 <= 2 &&
+        l2 <= 158 * 1024) {
+      const int gy = (q.CO + 31) / 32;
+      int cap = odin_num_cus() / gy;
+      if (cap < 1) cap = 1;
+      if (max_blocks < 0 && -max_blocks < cap) cap = -max_blocks;
+      p = q;
+      gx = p.n_tiles < cap ? p.n_tiles : cap;
+      lds = l2;
+      wave8 = elu_fwd ? 1 : 2;
+    }
+  }
   if (rows_out) *rows_out = gx;
   if (p.out == nullptr) return 0;  // dry run: planning only
   {
@@ -1452,6 +1477,7 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
   const int epi = !fulln ? 0
                   : (p.act == ODIN_ACT_ELU && p.aux == nullptr) ? 1
                   : (p.act == ODIN_ACT_LINEAR && p.aux != nullptr && p.aux_act == ODIN_ACT_ELU) ? 2 : 0;
+  if (wave8 == 1) return launch_inst2<MODE_T, 4, 2, 64, true, 0, 5, 2, 1, 1, false, 8>(p, tp, grid, lds, stream);
   if (split8 != 0) {
     if (tail != nullptr) tp = *tail;
     if (split8 == 3) return launch_inst2<MODE_T, 4, 2, 32, true, 1, 5, 1, 1, 1, true, 8>(p, tp, grid, lds, stream);
