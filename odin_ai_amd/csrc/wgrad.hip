@@ -722,9 +722,8 @@ __global__ __launch_bounds__(2 * NW_W * 64) void wgrad_ws_kernel(WParams p) {
     }
     constexpr int UN = 4;
     constexpr int PS2 = 2 * TSP;
-    const int npairs = p.slots >> 1;
-    const int nchunks = npairs / UN;
-    const int cpr = p.OW / (2 * UN);
+    const int cpr = p.OW / (2 * UN);  // chunks per output row: 1, 2 or 4 (launcher)
+    const int cshift = cpr == 1 ? 0 : (cpr == 2 ? 1 : 2);
     const int row_stride = p.S * p.PW * p.P;
     for (int k = 0; k <= n_my; ++k) {
       if (wave == 0) WS_STAMP(0, 10);
@@ -735,10 +734,15 @@ __global__ __launch_bounds__(2 * NW_W * 64) void wgrad_ws_kernel(WParams p) {
 #pragma unroll
         for (int a = 0; a < TNACC; ++a) abase[a] = patch + h * TSP + a_off[a];
         const float* bbase = dyl + h * 32 + l31;
-        int crow = 0, ccol = 0, rl = 0, img = 0, dyo = 0;
+        // The tile is exactly 8 chunks (64 slots, enforced by the launcher) and one image: the
+        // chunk loop is fully unrolled and branch-free (chunk c -> row c >> cshift, column block
+        // c & (cpr - 1), pure scalar arithmetic), so that the LDS reads of chunk c + 1 really sit
+        // between the MFMAs of chunk c; with `if (c + 1 < nchunks)` guards the loads landed in
+        // their own basic blocks and the 16 MFMAs ran back to back behind them.
         float a0[UN][TNACC], b0[UN], a1[UN][TNACC], b1[UN];
-        auto chunk_load = [&](float (&a_)[UN][TNACC], float (&b_)[UN]) {
-          const int ao = crow + ccol * (UN * PS2);
+        auto chunk_load = [&](int c, float (&a_)[UN][TNACC], float (&b_)[UN]) {
+          const int ao = (c >> cshift) * row_stride + (c & (cpr - 1)) * (UN * PS2);
+          const int dyo = c * (UN * 64);
 #pragma unroll
           for (int u = 0; u < UN; ++u) b_[u] = bbase[dyo + u * 64];
 #pragma unroll
@@ -746,38 +750,35 @@ __global__ __launch_bounds__(2 * NW_W * 64) void wgrad_ws_kernel(WParams p) {
 #pragma unroll
             for (int a = 0; a < TNACC; ++a) a_[u][a] = abase[a][ao + u * PS2];
           }
-          dyo += UN * 64;
-          if (++ccol == cpr) {
-            ccol = 0;
-            crow += row_stride;
-            if (++rl == p.RPI) { rl = 0; ++img; crow = img * p.NRI * p.PW * p.P; }
-          }
         };
-        auto chunk_mfma = [&](const float (&a_)[UN][TNACC], const float (&b_)[UN]) {
+        auto chunk_mfma = [&](const float (&a_)[UN][TNACC], const float (&b_)[UN], bool with_loads) {
 #pragma unroll
           for (int u = 0; u < UN; ++u) {
 #pragma unroll
             for (int a = 0; a < TNACC; ++a) acc[a] = mfma32(a_[u][a], b_[u], acc[a]);
           }
+          if (with_loads) {
 #pragma unroll
-          for (int u = 0; u < UN; ++u) {
-            ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
-            ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 2);
-#pragma unroll
-            for (int a = 1; a < TNACC; ++a) {
+            for (int u = 0; u < UN; ++u) {
               ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
-              ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 1);
+              ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 2);
+#pragma unroll
+              for (int a = 1; a < TNACC; ++a) {
+                ODIN_SCHED_GROUP(ODIN_SG_MFMA, 1);
+                ODIN_SCHED_GROUP(ODIN_SG_DSREAD, 1);
+              }
             }
           }
           ODIN_SCHED_FENCE();
         };
-        chunk_load(a0, b0);
+        chunk_load(0, a0, b0);
         ODIN_SCHED_FENCE();
-        for (int ch = 0; ch < nchunks; ch += 2) {
-          if (ch + 1 < nchunks) chunk_load(a1, b1);
-          chunk_mfma(a0, b0);
-          if (ch + 2 < nchunks) chunk_load(a0, b0);
-          if (ch + 1 < nchunks) chunk_mfma(a1, b1);
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {
+          chunk_load(c + 1, a1, b1);
+          chunk_mfma(a0, b0, true);
+          if (c + 2 < 8) chunk_load(c + 2, a0, b0);
+          chunk_mfma(a1, b1, c + 2 < 8);
         }
         if (wave == 0) WS_STAMP(0, 11);
       }
@@ -992,7 +993,8 @@ int try_launch_ws(const WParams& p0, int* rows_out, void* stream) {
   const int sp = p.S * p.P;
   if (!(p.pvec && dcont && !p.flat && p.ncot == 1 && p.bias_mode != 1 && nacc <= 4 &&
         (p.OW % 8) == 0 && p.TR * p.OW == p.slots && p.COB == 32 && p.DP == 32 && p.KI <= 9 &&
-        p.slots * 8 <= 2 * 256 && (sp == 32 || sp == 64 || sp == 128)))
+        p.slots == 64 && (p.OW == 8 || p.OW == 16 || p.OW == 32) &&
+        (sp == 32 || sp == 64 || sp == 128)))
     return 1;
   const size_t lds = (size_t)2 * (p.patch_floats + p.dy_floats) * 4;
   if (lds > 158 * 1024 || lds < 4352) return 1;
