@@ -1625,6 +1625,7 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
 // ---- Dense: y[B,N] = act(x[B,K] @ w[K,N] + b) ----------------------------------------
 extern "C" int odin_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B,
                               int K, int N, int act, void* stream) {
+  if (odin_tiny_dense_ok(B, K, N)) return odin_tiny_dense_fwd(x, w, bias, y, B, K, N, act, stream);
   GParams p;
   memset(&p, 0, sizeof(p));
   p.in = x; p.w = w; p.bias = bias; p.out = y;
@@ -1637,6 +1638,8 @@ extern "C" int odin_dense_fwd(const float* x, const float* w, const float* bias,
 extern "C" int odin_dense_dgrad(const float* dy, const float* w, const float* aux, int aux_act,
                                 float* dx, float* colsum_slab, int* slab_rows_out, int B, int K,
                                 int N, void* stream) {
+  if (odin_tiny_dense_ok(B, K, N))
+    return odin_tiny_dense_dgrad(dy, w, aux, aux_act, dx, colsum_slab, slab_rows_out, B, K, N, stream);
   GParams p;
   memset(&p, 0, sizeof(p));
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;

@@ -17,3 +17,10 @@ int odin_smallc_fwd(const float* x, const float* w, const float* bias, float* y,
                     const odin_conv_desc* d, void* stream);
 int odin_smallc_wgrad(const float* x, const float* dy, float* slab, int* rows_out,
                       const odin_conv_desc* d, void* stream);
+
+// tiny Dense layers on the vector ALUs (pointwise.hip)
+bool odin_tiny_dense_ok(int B, int K, int N);
+int odin_tiny_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K,
+                        int N, int act, void* stream);
+int odin_tiny_dense_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                          float* colsum_slab, int* slab_rows_out, int B, int K, int N, void* stream);

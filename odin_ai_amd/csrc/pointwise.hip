@@ -7,6 +7,7 @@
 // step) are read from device memory so that a captured HIP graph can be replayed.
 #include "odin_device.h"
 #include "odin_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -358,6 +359,98 @@ extern "C" int odin_sumsq_flat(const float* g, size_t n, float* workspace, float
   ODIN_LAUNCH(sumsq_stage1, dim3(grid), dim3(256), 0, stream, g, n, workspace);
   ODIN_LAUNCH(sum_stage2, dim3(1), dim3(256), 0, stream, (const float*)workspace, grid, out);
   return odin_check_launch("sumsq");
+}
+
+// ------------------------------------------------------------------ tiny Dense layers ---
+// The bottleneck projections (latent 128 -> 2D, first decoder layer D -> 128 and their
+// data-gradients: K*N <= 4096 weights, batch 256) are ~0.1 MFLOP each.  On the MFMA path they
+// are two workgroups staging tiles for 15 us; here the whole weight matrix sits in LDS, a thread
+// owns one output element, and the launch costs its floor.
+//   forward:        y[b][n]  = act(sum_k x[b][k] w[k][n] + bias[n])
+//   data-gradient:  dx[b][k] = (sum_n dy[b][n] w[k][n]) * act'(aux[b][k]), plus per-block column
+//                   sums of dx (the bias gradient of the producing layer) into slab[blockIdx.x][K]
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void tiny_dense_kernel(const float* __restrict__ in,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ bias_or_aux,
+                                                         float* __restrict__ out,
+                                                         float* __restrict__ colsum, int B, int K,
+                                                         int N, int act, int nop, int sb) {
+  ODIN_DYN_SMEM(float, sm);  // w [K][N + 1] | in [sb][NR] | red [sb][nop]
+  const int NR = DGRAD ? N : K, NO = DGRAD ? K : N;
+  const int WS = N + 1;
+  float* wl = sm;
+  float* xl = sm + K * WS;
+  float* red = xl + sb * NR;
+  for (int e = threadIdx.x; e < K * N; e += 256) wl[(e / N) * WS + (e % N)] = w[e];
+  const int b0 = blockIdx.x * sb;
+  for (int e = threadIdx.x; e < sb * NR; e += 256) {
+    const int s = e / NR, r = e - s * NR;
+    xl[e] = (b0 + s < B) ? in[(size_t)(b0 + s) * NR + r] : 0.f;
+  }
+  __syncthreads();
+  const int s = threadIdx.x / nop, o = threadIdx.x - s * nop;
+  float v = 0.f;
+  const bool live = s < sb && o < NO && b0 + s < B;
+  if (live) {
+    const float* xr = xl + s * NR;
+    float acc = 0.f;
+    if (DGRAD) {
+      const float* wr = wl + o * WS;
+      for (int r = 0; r < NR; ++r) acc = fmaf(xr[r], wr[r], acc);
+      if (bias_or_aux != nullptr) acc *= odin_act_grad(act, bias_or_aux[(size_t)(b0 + s) * NO + o]);
+    } else {
+      for (int r = 0; r < NR; ++r) acc = fmaf(xr[r], wl[r * WS + o], acc);
+      acc = odin_act(act, acc + (bias_or_aux != nullptr ? bias_or_aux[o] : 0.f));
+    }
+    out[(size_t)(b0 + s) * NO + o] = acc;
+    v = acc;
+  }
+  if (DGRAD && colsum != nullptr) {
+    if (threadIdx.x < sb * nop) red[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < NO) {
+      float t = 0.f;
+      for (int q = 0; q < sb; ++q) t += red[q * nop + threadIdx.x];
+      colsum[(size_t)blockIdx.x * NO + threadIdx.x] = t;
+    }
+  }
+}
+
+// geometry shared by the launcher and the dry run: outputs padded to a power of two <= 256
+static void tiny_dense_geom(int NO, int B, int* nop, int* sb, int* blocks) {
+  int p2 = 1;
+  while (p2 < NO) p2 <<= 1;
+  *nop = p2;
+  *sb = 256 / p2;
+  *blocks = (B + *sb - 1) / *sb;
+}
+
+bool odin_tiny_dense_ok(int B, int K, int N) {
+  return (long)K * N <= 4096 && K <= 256 && N <= 256 && B >= 1 && B <= 1024 && !getenv("ODIN_NOTINYDENSE");
+}
+
+int odin_tiny_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K,
+                        int N, int act, void* stream) {
+  int nop, sb, blocks;
+  tiny_dense_geom(N, B, &nop, &sb, &blocks);
+  const size_t lds = (size_t)(K * (N + 1) + sb * K + 256) * 4;
+  ODIN_LAUNCH((tiny_dense_kernel<false>), dim3(blocks), dim3(256), lds, stream, x, w, bias, y,
+              (float*)nullptr, B, K, N, act, nop, sb);
+  return odin_check_launch("tiny_dense_fwd");
+}
+
+int odin_tiny_dense_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                          float* colsum_slab, int* slab_rows_out, int B, int K, int N, void* stream) {
+  int nop, sb, blocks;
+  tiny_dense_geom(K, B, &nop, &sb, &blocks);
+  if (slab_rows_out) *slab_rows_out = blocks;
+  if (dx == nullptr) return 0;  // dry run
+  const size_t lds = (size_t)(K * (N + 1) + sb * N + 256) * 4;
+  ODIN_LAUNCH((tiny_dense_kernel<true>), dim3(blocks), dim3(256), lds, stream, dy, w,
+              (aux != nullptr && aux_act != 0) ? aux : (const float*)nullptr, dx, colsum_slab, B, K, N,
+              aux_act, nop, sb);
+  return odin_check_launch("tiny_dense_dgrad");
 }
 
 // ------------------------------------------------------------------ input pipeline ----
