@@ -172,6 +172,12 @@ int odin_adam_step_flat(float* theta, const float* g, float* m, float* v, size_t
                         void* stream);
 /* out[0] = sum g^2 (deterministic two-stage); workspace >= 1024 floats */
 int odin_sumsq_flat(const float* g, size_t n, float* workspace, float* out, void* stream);
+/* odin_sumsq_flat + odin_adam_step_flat in two launches instead of three: the Adam launch sums
+ * the stage-1 partials itself (same fixed order, bit-identical norm) and writes it to gnorm2_out.
+ * workspace: >= 1024 floats. */
+int odin_sumsq_adam_flat(float* theta, const float* g, float* m, float* v, size_t n,
+                         const float* hyper, float* workspace, float* gnorm2_out, float clip,
+                         int32_t* flag, void* stream);
 
 /* ---- counter-based RNG (the reference uses TF's Philox via tfd.sample; streams are not
  * reproducible across frameworks, so parity tests pass eps explicitly) ------------------ */

@@ -62,6 +62,7 @@ SIGNATURES = {
     'odin_dtc_loss_fwd_bwd': [P, P, P, P, P, I, P],
     'odin_adam_step_flat': [P, P, P, P, C.c_size_t, P, P, F, P, P],
     'odin_sumsq_flat': [P, C.c_size_t, P, P, P],
+    'odin_sumsq_adam_flat': [P, P, P, P, C.c_size_t, P, P, P, F, P, P],
     'odin_rng_normal': [P, C.c_size_t, C.c_uint64, P, P],
     'odin_gather_normalize_u8': [P, P, P, I, I, F, I, P],
     'odin_stft_mel_db': [P, P, P, P, I, I, I, I, I, I, F, F, I, P],

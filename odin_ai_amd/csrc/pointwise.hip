@@ -192,11 +192,26 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    size_t n, const float* __restrict__ hyper,
                                                    const float* __restrict__ gnorm2, float clip,
-                                                   int* flag) {
+                                                   int* flag, const float* __restrict__ parts,
+                                                   int n_parts, float* __restrict__ gnorm2_out) {
   const float a = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   float gs = hyper[4];
-  if (gnorm2 != nullptr) {
-    float n2 = gnorm2[0];
+  __shared__ float red[4];
+  __shared__ float n2_sh;
+  if (parts != nullptr) {
+    // fused second stage of the gradient-norm reduction: every block sums the stage-1 partials
+    // in the same fixed order as sum_stage2 (one launch less on the critical path)
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n_parts; i += 256) acc += parts[i];
+    const float t = block_sum_256(acc, red);
+    if (threadIdx.x == 0) {
+      n2_sh = t;
+      if (blockIdx.x == 0 && gnorm2_out != nullptr) gnorm2_out[0] = t;
+    }
+    __syncthreads();
+  }
+  if (gnorm2 != nullptr || parts != nullptr) {
+    float n2 = parts != nullptr ? n2_sh : gnorm2[0];
     if (!(n2 == n2) || n2 > 3.0e38f) {  // NaN / Inf gradients: skip the update
       if (flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) flag[0] = 1;
       return;
@@ -349,8 +364,19 @@ extern "C" int odin_adam_step_flat(float* theta, const float* g, float* m, float
                                    int32_t* flag, void* stream) {
   int grid = grid_for(n / 4 + 1, 256, 2048);
   ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper, gnorm2,
-              clip, (int*)flag);
+              clip, (int*)flag, (const float*)nullptr, 0, (float*)nullptr);
   return odin_check_launch("adam");
+}
+
+extern "C" int odin_sumsq_adam_flat(float* theta, const float* g, float* m, float* v, size_t n,
+                                    const float* hyper, float* workspace, float* gnorm2_out,
+                                    float clip, int32_t* flag, void* stream) {
+  int g1 = grid_for(n / 4 + 1, 256, 1024);
+  ODIN_LAUNCH(sumsq_stage1, dim3(g1), dim3(256), 0, stream, g, n, workspace);
+  int grid = grid_for(n / 4 + 1, 256, 2048);
+  ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper,
+              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out);
+  return odin_check_launch("sumsq_adam");
 }
 
 extern "C" int odin_sumsq_flat(const float* g, size_t n, float* workspace, float* out,

@@ -648,14 +648,17 @@ class VAEEngine:
   def adam(self, st=None, global_clipnorm: Optional[float] = None, check_nan: bool = True):
     lib = self.lib
     st = self.stream() if st is None else st
-    gn = None
     if global_clipnorm is not None or check_nan:
-      lib.odin_sumsq_flat(self.grads.data_ptr(), self.grads.numel(), self.ws.data_ptr(),
-                          self.gnorm2.data_ptr(), st)
-      gn = self.gnorm2.data_ptr()
+      # gradient norm (clip scale, NaN guard) + update: stage-1 partial sums, then ONE launch that
+      # finishes the norm and applies Adam
+      lib.odin_sumsq_adam_flat(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
+                               self.v.data_ptr(), self.params.numel(), self.hp(H_ALPHA),
+                               self.ws.data_ptr(), self.gnorm2.data_ptr(),
+                               float(global_clipnorm or 0.0), self.flag.data_ptr(), st)
+      return
     lib.odin_adam_step_flat(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
-                            self.v.data_ptr(), self.params.numel(), self.hp(H_ALPHA), gn,
-                            float(global_clipnorm or 0.0), self.flag.data_ptr(), st)
+                            self.v.data_ptr(), self.params.numel(), self.hp(H_ALPHA), None,
+                            0.0, self.flag.data_ptr(), st)
 
   def allreduce(self):
     if self.world_size > 1:

@@ -137,6 +137,21 @@ def test_adam_and_sumsq(L):
   L.odin_adam_step_flat(tth2.data_ptr(), tg.data_ptr(), tm2.data_ptr(), tv2.data_ptr(), n,
                         hy.data_ptr(), nan.data_ptr(), clip, flag.data_ptr(), None)
   assert flag.item() == 1 and torch.equal(before, tth2)
+  # fused norm + update (two launches): bit-identical to sumsq_flat followed by adam_step_flat
+  tth3, tm3, tv3 = T(th), T(m), T(v)
+  tth4, tm4, tv4 = T(th), T(m), T(v)
+  ws3, out3, flag3 = torch.zeros(1024), torch.zeros(1), torch.zeros(1, dtype=torch.int32)
+  L.odin_sumsq_adam_flat(tth3.data_ptr(), tg.data_ptr(), tm3.data_ptr(), tv3.data_ptr(), n,
+                         hy.data_ptr(), ws3.data_ptr(), out3.data_ptr(), clip, flag3.data_ptr(), None)
+  L.odin_adam_step_flat(tth4.data_ptr(), tg.data_ptr(), tm4.data_ptr(), tv4.data_ptr(), n,
+                        hy.data_ptr(), out.data_ptr(), clip, None, None)
+  assert torch.equal(out3, out) and flag3.item() == 0
+  assert torch.equal(tth3, tth4) and torch.equal(tm3, tm4) and torch.equal(tv3, tv4)
+  gbad = T(np.where(np.arange(n) == 5, np.inf, g))
+  before = tth3.clone()
+  L.odin_sumsq_adam_flat(tth3.data_ptr(), gbad.data_ptr(), tm3.data_ptr(), tv3.data_ptr(), n,
+                         hy.data_ptr(), ws3.data_ptr(), out3.data_ptr(), clip, flag3.data_ptr(), None)
+  assert flag3.item() == 1 and torch.equal(before, tth3)
 
 
 def test_total_correlation(L):
