@@ -219,7 +219,7 @@ class NetProgram:
   def backward(self, x: torch.Tensor, gout_last: torch.Tensor, st,
                dx_out: Optional[torch.Tensor] = None, last: Optional[int] = None,
                skip_bias_of_last: bool = False, data_only: bool = False,
-               fork=None) -> List[ReduceJob]:
+               fork=None, side_jobs: Optional[list] = None) -> List[ReduceJob]:
     """gout_last: dL/d(pre-activation output of the last layer).  If dx_out is given the
     gradient wrt the network input is written there.  Returns the slab-reduce jobs."""
     lib, B = self.lib, self.B
@@ -250,8 +250,11 @@ class NetProgram:
         n_red = slab.shape[1]
         if skip_bias_of_last and i == n - 1 and r.kind != 'deconv':
           n_red = r.w_n  # the fused tail already delivers this layer's bias gradient
-        jobs.append(ReduceJob(slab.data_ptr(), self.grads[r.w_off:].data_ptr(), n_red, rows.value,
-                              slab.shape[1], 0))
+        # (jobs whose slab was written on a side stream are kept apart: only the final reduction,
+        # after the join, may read them)
+        tgt = side_jobs if (side_jobs is not None and wst is not st) else jobs
+        tgt.append(ReduceJob(slab.data_ptr(), self.grads[r.w_off:].data_ptr(), n_red, rows.value,
+                             slab.shape[1], 0))
       # ---- data gradient -> pre-activation gradient of the previous layer ----
       if i > 0:
         prev = self.recs[i - 1]
@@ -381,6 +384,7 @@ class VAEEngine:
     # weight gradients on a side stream.  'all': measured neutral-to-negative on MI355X (the
     # big kernels are LDS-limited to one workgroup per CU and contend); 'small': only the
     # launches that leave most CUs idle (bottleneck layers) run beside the data-gradient chain
+    self.early_reduce = _os.environ.get('ODIN_EARLY_REDUCE', '1') == '1'
     self.overlap_wgrad = {'0': None, '1': 'all', 'all': 'all', 'small': 'small'}.get(
         _os.environ.get('ODIN_OVERLAP_WGRAD', 'small'), None)
     self.graph = None
@@ -597,12 +601,15 @@ class VAEEngine:
     lib, B, D = self.lib, self.B, self.D
     st = self.stream() if st is None else st
     fork, join = self._fork()
+    late_jobs: list = []  # slabs written on side streams
+    early = fork is not None and self.early_reduce
     if self._used_fused:
       nd = len(self.dec_recs)
       a, b = self.dec_recs[-2], self.dec_recs[-1]
       co, c1 = a.desc['Cout'], b.desc['Cout']
       jobs = self.dec.backward(self.z, self.dec.gouts[-2], st, dx_out=self.dz, last=nd - 2,
-                               skip_bias_of_last=True, fork=fork)
+                               skip_bias_of_last=True, fork=fork,
+                               side_jobs=late_jobs if early else None)
       ts, stride = self.tail_slab, self.tail_slab.shape[1]
       # (dW1 | db1) of the 1x1 conv, then the bias gradient of the fused layer
       jobs.append(ReduceJob(ts.data_ptr(), self.grads[b.w_off:].data_ptr(), co * c1 + c1,
@@ -610,7 +617,15 @@ class VAEEngine:
       jobs.append(ReduceJob(ts[:, co * c1 + c1:].data_ptr(), self.grads[a.b_off:].data_ptr(), co,
                             self.tail_rows, stride, 0))
     else:
-      jobs = self.dec.backward(self.z, self.dec.gouts[-1], st, dx_out=self.dz, fork=fork)
+      jobs = self.dec.backward(self.z, self.dec.gouts[-1], st, dx_out=self.dz, fork=fork,
+                               side_jobs=late_jobs if early else None)
+    if early and jobs:
+      # the decoder's slabs (most of the slab bytes) are complete: reduce them on a side stream
+      # while the encoder's backward pass keeps the matrix cores busy (the reduction is HBM-bound)
+      arr0 = (ReduceJob * len(jobs))(*jobs)
+      self._jobs_keepalive0 = arr0
+      lib.odin_slab_reduce(arr0, len(jobs), fork(-3))
+      jobs = []
     dzx = extra_dz.data_ptr() if extra_dz is not None else None
     if self.tc_mode == 'betatc':
       assert extra_dz is None
@@ -639,6 +654,7 @@ class VAEEngine:
       jobs.append(ReduceJob(bslab.data_ptr(), self.grads[last.b_off:].data_ptr(), last.b_n,
                             rows.value, last.b_n, 0))
     jobs += self.enc.backward(self.x, self.enc.gouts[-1], st, fork=fork)
+    jobs += late_jobs
     join()
     arr = (ReduceJob * len(jobs))(*jobs)
     self._jobs_keepalive = arr
