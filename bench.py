@@ -192,6 +192,83 @@ def profile_elbo(eng, reps=50):
               us_per_launch=round(t * 1e6, 2), mbytes_per_launch=round(nbytes * 1e-6, 2))
 
 
+def _free_port():
+  import socket
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def launch_ranks(n, argv):
+  """`python bench.py --gpus N` without a launcher: start N fresh children (one process per
+  GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torchrun would set them) BEFORE this
+  process touches the GPU.  The parent never initialises HIP; rank 0's stdout (the one JSON
+  line) passes through; exit status is non-zero if any rank fails."""
+  import subprocess
+  env0 = dict(os.environ)
+  env0.setdefault('MASTER_ADDR', '127.0.0.1')
+  env0.setdefault('MASTER_PORT', str(_free_port()))
+  env0.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  env0['WORLD_SIZE'] = str(n)
+  env0['LOCAL_WORLD_SIZE'] = str(n)
+  procs = []
+  for r in range(n):
+    env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                  stdout=None if r == 0 else subprocess.DEVNULL))
+  rc = 0
+  pending = list(procs)
+  while pending:
+    for p in list(pending):
+      r = p.poll()
+      if r is None:
+        continue
+      pending.remove(p)
+      if r != 0 and rc == 0:
+        rc = r
+        for q in pending:  # one rank died: the others would hang in the next collective
+          q.terminate()
+    time.sleep(0.05)
+  return rc
+
+
+def dry_run(args, world, rank):
+  """Launcher / rendezvous self-test without a GPU: gloo process group, one all-reduce, the
+  JSON line of rank 0 names the ranks that answered.  No kernel runs; the metric name says so."""
+  import torch.distributed as dist
+  seen = 1
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    seen = int(t.item())
+    dist.barrier()
+    dist.destroy_process_group()
+  if rank == 0:
+    print(json.dumps(dict(metric='launcher dry run (no kernels executed)', value=0.0,
+                          unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                          rccl=dict(ranks_seen=seen, backend='gloo'))))
+
+
+def time_allreduce(eng, reps=20):
+  """Gradient-bucket all-reduce alone (RCCL, on the stream the step uses), HIP events."""
+  import torch.distributed as dist
+  for _ in range(3):
+    eng.allreduce()
+  torch.cuda.synchronize()
+  dist.barrier()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    eng.allreduce()
+  e1.record()
+  torch.cuda.synchronize()
+  return e0.elapsed_time(e1) / reps * 1e3
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -202,21 +279,41 @@ def main():
   ap.add_argument('--cpu-steps', type=int, default=25)
   ap.add_argument('--no-graph', action='store_true')
   ap.add_argument('--profile-ops', action='store_true', help='print a per-kernel timing table')
+  ap.add_argument('--dry-run', action='store_true',
+                  help='launcher / rendezvous self-test on CPU (gloo): no kernels, no GPU')
+  ap.add_argument('--force-dist', action='store_true',
+                  help='initialise the RCCL process group even at world size 1, so that the '
+                  'data-parallel step (graph A, RCCL all-reduce, graph B) runs on a 1-GPU box')
   args = ap.parse_args()
 
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    # no launcher around us: become one.  Nothing in this process has touched the GPU yet.
+    sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  if world > 1:
-    import torch.distributed as dist
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group(os.environ.get('ODIN_DIST_BACKEND', 'nccl'), rank=rank,
-                            world_size=world)
+  if world != args.gpus:
+    print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line '
+          f'whose n_gpus differs from what was asked for', file=sys.stderr)
+    sys.exit(2)
+  if args.dry_run:
+    return dry_run(args, world, rank)
+  use_dist = world > 1 or args.force_dist
   assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
   ndev = torch.cuda.device_count()
-  dev_index = local_rank % max(ndev, 1)
+  if world > ndev:
+    print(f'bench.py: {world} ranks but {ndev} GPU(s) visible (one process per GPU)',
+          file=sys.stderr)
+    sys.exit(2)
+  dev_index = local_rank
   torch.cuda.set_device(dev_index)
   device = torch.device('cuda', dev_index)
+  if use_dist:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(_free_port()))
+    dist.init_process_group(os.environ.get('ODIN_DIST_BACKEND', 'nccl'), rank=rank,
+                            world_size=world, device_id=device)
 
   from odin_ai_amd.engine import VAEEngine
   from odin_ai_amd.networks import get_networks
@@ -225,8 +322,21 @@ def main():
   enc, dec = nets['encoder'].layers, nets['decoder'].layers
   in_shape, zdim = nets['encoder'].input_shape, nets['latents'].event_shape[0]
   eng = VAEEngine(enc, dec, in_shape, zdim, B, device, observation=nets['observation'].posterior,
-                  tc=kind, world_size=world, seed=1 + rank)
-  init_params_(eng, seed=1)  # identical weights on every rank
+                  tc=kind, world_size=world, seed=1 + rank, force_dp=use_dist)
+  init_params_(eng, seed=1 + 1000 * rank)  # rank 0's weights win: broadcast below
+  rccl = None
+  if use_dist:
+    from odin_ai_amd.dist import broadcast_parameters
+    broadcast_parameters(eng.params, src=0, force=True)
+    chk = eng.params.double().sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    assert lo.item() == hi.item(), 'parameter broadcast failed: replicas differ'
+    seen = torch.ones(1, device=device)
+    dist.all_reduce(seen)
+    rccl = dict(ranks_seen=int(seen.item()), backend=dist.get_backend(),
+                bucket_bytes=eng.grads.numel() * 4)
   x = synthetic_batch(args.workload, B, in_shape, device, seed=100 + rank)
   if not args.no_graph:
     # the batch is resident in HBM in the buffer the step graph reads (what an on-device input
@@ -246,7 +356,7 @@ def main():
   # busy for ~0.6 s first.  Untimed, like the graph capture itself.
   step()
   torch.cuda.synchronize()
-  if world > 1:
+  if use_dist:
     # every step contains a collective: all ranks must run the SAME number of steps
     for _ in range(400):
       step()
@@ -260,28 +370,34 @@ def main():
   for _ in range(args.warmup):
     step()
   torch.cuda.synchronize()
-  if world > 1:
+  if use_dist:
     dist.barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for _ in range(args.steps):
     out = step()
   torch.cuda.synchronize()
-  if world > 1:
+  if use_dist:
     dist.barrier()
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
-  if world > 1:
+  if use_dist:
     tt = torch.tensor([dt], device=device, dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = tt.item()
+    # replicas must still agree after the timed steps (same all-reduced gradients, same Adam)
+    chk = eng.params.double().sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    rccl['replicas_in_sync'] = bool(lo.item() == hi.item())
+    rccl['allreduce_us'] = round(time_allreduce(eng), 2)
   loss = out[0].item()
   assert math.isfinite(loss), 'training diverged'
   assert eng.flag.item() == 0, 'non-finite gradients were skipped during the timed region'
 
   if rank != 0:
-    if world > 1:
-      dist.destroy_process_group()
+    dist.destroy_process_group()
     return
 
   # ---- roofline of the dominant kernel (per-launch, HIP events on the launch stream) ----
@@ -351,8 +467,10 @@ def main():
                          beta=beta, parallelism=f'dp{world}', graph=bool(use_graph),
                          final_loss=round(loss, 4)),
              roofline=roofline, cpu_baseline=cpu, conv_stack=stack, elbo_kernel=elbo_roof)
-  print(json.dumps(res))
-  if world > 1:
+  if rccl is not None:
+    res['rccl'] = rccl
+  print(json.dumps(res), flush=True)
+  if use_dist:
     dist.destroy_process_group()
 
 

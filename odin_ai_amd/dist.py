@@ -40,6 +40,7 @@ def shard_batch(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
   return x[rank * n:(rank + 1) * n].contiguous()
 
 
-def broadcast_parameters(flat_params: torch.Tensor, src: int = 0):
-  if dist.is_initialized() and dist.get_world_size() > 1:
+def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, force: bool = False):
+  """Replicas start from rank `src`'s parameters (never rely on identical seeds)."""
+  if dist.is_initialized() and (dist.get_world_size() > 1 or force):
     dist.broadcast(flat_params, src=src)

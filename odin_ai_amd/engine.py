@@ -300,7 +300,8 @@ class VAEEngine:
   def __init__(self, enc_layers, dec_layers, in_shape, zdim, batch_size, device,
                observation='bernoulli', analytic=False, free_bits=None, tc=None, lib=None,
                params: Optional[torch.Tensor] = None, world_size: int = 1, seed: int = 1,
-               optim_state: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+               optim_state: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+               force_dp: bool = False):
     self.lib = lib if lib is not None else _lib.load()
     self.device = torch.device(device)
     self.B, self.D = int(batch_size), int(zdim)
@@ -308,6 +309,9 @@ class VAEEngine:
     self.observation, self.analytic = observation, bool(analytic)
     self.free_bits = -1.0 if free_bits is None else float(free_bits)
     self.tc_mode, self.world_size, self.seed = tc, int(world_size), int(seed)
+    # data-parallel step (gradient-bucket all-reduce between backward and Adam); `force_dp` runs
+    # that path at world size 1 too (RCCL on a 1-GPU box)
+    self.is_dp = self.world_size > 1 or bool(force_dp)
     f32 = dict(dtype=torch.float32, device=self.device)
     # ---- parameters ----
     self.layout = ParamLayout()
@@ -677,7 +681,7 @@ class VAEEngine:
                             0.0, self.flag.data_ptr(), st)
 
   def allreduce(self):
-    if self.world_size > 1:
+    if self.is_dp:
       import torch.distributed as dist
       dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
 
@@ -688,7 +692,7 @@ class VAEEngine:
     Returns the device tensor out4 = [loss, mean llk, mean beta*kl, tc] (no host sync)."""
     self.step_count += 1
     self.set_hyper(lr=lr, beta=beta)
-    if use_graph and self.device.type == 'cuda' and self.world_size == 1:
+    if use_graph and self.device.type == 'cuda' and not self.is_dp:
       self._graph_step(x, eps, global_clipnorm)
     elif use_graph and self.device.type == 'cuda':
       self._graph_step_dp(x, eps, global_clipnorm)

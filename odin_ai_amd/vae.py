@@ -264,18 +264,26 @@ class VariationalAutoencoder:
       eng = VAEEngine(self.encoder.layers, self.decoder.layers, self.input_shape, self.zdim, B,
                       self.device, observation=self.observation.posterior,
                       analytic=self.analytic, free_bits=self.free_bits, tc=self._tc_mode,
-                      lib=self._lib, params=self._params, seed=self.seed,
+                      lib=self._lib, params=self._params, seed=self.seed + self._rank(),
                       optim_state=self._optim_state, world_size=self._world_size())
       if self._params is None:
         self._params = eng.params
         self._optim_state = (eng.m, eng.v)
         self._init_parameters(eng)
+        # data parallel: every replica starts from rank 0's weights; the noise streams differ
+        # per rank (seed + rank above), the weights must not
+        from .dist import broadcast_parameters
+        broadcast_parameters(eng.params, src=0)
       self._engines[B] = eng
     return self._engines[B]
 
   def _world_size(self) -> int:
     import torch.distributed as dist
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+  def _rank(self) -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
   def _init_parameters(self, eng: VAEEngine):
     """HeNormal for elu convs, glorot_uniform for Dense, glorot_normal for the latent

@@ -77,3 +77,38 @@ def test_two_gloo_ranks_match_single_rank(tmp_path):
   # identical maths, different fp32 summation order (per-rank partial sums): Adam's
   # normalisation bounds the per-step drift by a fraction of lr
   assert d.max().item() < 2e-4 and d.mean().item() < 2e-6, (d.max().item(), d.mean().item())
+
+
+def _run_bench(*argv, env=None):
+  import json
+  import subprocess
+  e = dict(os.environ)
+  for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+    e.pop(k, None)
+  e.update(env or {})
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), env=e,
+                     capture_output=True, text=True, timeout=300)
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+  """`python bench.py --gpus 2` (no torchrun around it) must start 2 ranks that find each other
+  and report n_gpus=2: the launcher, the rendezvous and one collective, on CPU (gloo)."""
+  rc, line, err = _run_bench('--gpus', '2', '--dry-run')
+  assert rc == 0, err[-500:]
+  assert line['n_gpus'] == 2 and line['rccl']['ranks_seen'] == 2
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+  rc, line, err = _run_bench('--gpus', '2', '--dry-run', env={'WORLD_SIZE': '1', 'RANK': '0'})
+  assert rc != 0 and line is None and 'refusing' in err
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+  """No GPU here: the real (non-dry) children must fail loudly (no CPU fallback), and the
+  launcher's exit status must be non-zero with no JSON line printed."""
+  if torch.cuda.is_available():
+    pytest.skip('needs a machine without a GPU')
+  rc, line, err = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '0')
+  assert rc != 0 and line is None
