@@ -165,31 +165,63 @@ def profile_ops(eng, reps=20):
   return out
 
 
-def profile_elbo(eng, reps=50):
-  """Stand-alone fused Bernoulli ELBO kernel (fwd+bwd): algorithmic 12 B per element."""
+def profile_hbm_kernels(eng, reps=50):
+  """The HBM-bound kernels on the shape north_star quotes (64x64x3, batch 256) and on this
+  workload's own shape: fused Bernoulli ELBO fwd+bwd (12 B/element), Gaussian head (20 B/element),
+  flat Adam (28 B/parameter).  HIP events on the launch stream, `reps` back-to-back launches."""
   import ctypes as C
-  lib, B = eng.lib, eng.B
+  lib, dev = eng.lib, eng.device
   st = eng.stream()
-  n = eng.n_per
-  lg = torch.randn(B, n, device=eng.device)
-  dl = torch.empty_like(lg)
-  x = eng.x.reshape(B, n)
+
+  def timeit(fn):
+    for _ in range(3):
+      fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+      fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+  def entry(kernel, shape, nbytes, t):
+    return dict(bound='hbm', kernel=kernel, shape=shape, achieved=round(nbytes / t * 1e-9, 1),
+                peak=PEAK_HBM_GBS, unit='GB/s', frac=round(nbytes / t * 1e-9 / PEAK_HBM_GBS, 4),
+                us_per_launch=round(t * 1e6, 2), mbytes_per_launch=round(nbytes * 1e-6, 2))
+
+  out = []
   npart = C.c_int(0)
-  fn = lambda: lib.odin_elbo_bernoulli_fwd_bwd(lg.data_ptr(), x.data_ptr(), eng.llk_part.data_ptr(),
-                                               dl.data_ptr(), eng.hp(5), B, n, C.byref(npart), st)
-  fn()
-  torch.cuda.synchronize()
-  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  e0.record()
-  for _ in range(reps):
-    fn()
-  e1.record()
-  torch.cuda.synchronize()
-  t = e0.elapsed_time(e1) / reps * 1e-3
-  nbytes = 12.0 * B * n
-  return dict(bound='hbm', kernel='elbo_bernoulli_fwd_bwd', achieved=round(nbytes / t * 1e-9, 1),
-              peak=PEAK_HBM_GBS, unit='GB/s', frac=round(nbytes / t * 1e-9 / PEAK_HBM_GBS, 4),
-              us_per_launch=round(t * 1e6, 2), mbytes_per_launch=round(nbytes * 1e-6, 2))
+  sc = eng.hp(5)
+  shapes = [(256, 64 * 64, 3)]
+  own = (eng.B, int(np.prod(eng.in_shape[:-1])), eng.in_shape[-1])
+  if own not in shapes:
+    shapes.append(own)
+  for (B, npix, Cc) in shapes:
+    n = npix * Cc
+    lg = torch.randn(B, n, device=dev)
+    x = torch.rand(B, n, device=dev)
+    dl = torch.empty_like(lg)
+    lib.odin_elbo_bernoulli_fwd_bwd(None, None, None, None, None, B, n, C.byref(npart), None)
+    part = torch.empty(B * npart.value, device=dev)
+    t = timeit(lambda: lib.odin_elbo_bernoulli_fwd_bwd(lg.data_ptr(), x.data_ptr(), part.data_ptr(),
+                                                       dl.data_ptr(), sc, B, n, C.byref(npart), st))
+    out.append(entry('elbo_bernoulli_fwd_bwd', [B, npix, Cc], 12.0 * B * n, t))
+    h = torch.randn(B, npix, 2 * Cc, device=dev)
+    dh = torch.empty_like(h)
+    lib.odin_elbo_gaussian_fwd_bwd(None, None, None, None, None, B, npix, Cc, 1, C.byref(npart), None)
+    part = torch.empty(B * npart.value, device=dev)
+    t = timeit(lambda: lib.odin_elbo_gaussian_fwd_bwd(h.data_ptr(), x.data_ptr(), part.data_ptr(),
+                                                      dh.data_ptr(), sc, B, npix, Cc, 1,
+                                                      C.byref(npart), st))
+    out.append(entry('elbo_gaussian_fwd_bwd(softplus1)', [B, npix, Cc], 20.0 * B * n, t))
+  for n in (eng.params.numel(), 4012004):  # this model; the FactorVAE discriminator (a18)
+    th, g = torch.randn(n, device=dev), torch.randn(n, device=dev) * 1e-3
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    t = timeit(lambda: lib.odin_adam_step_flat(th.data_ptr(), g.data_ptr(), m.data_ptr(),
+                                               v.data_ptr(), n, eng.hp(0), None, 0.0, None, st))
+    out.append(entry('adam_step_flat', [n], 28.0 * n, t))
+  return out
 
 
 def _free_port():
@@ -430,7 +462,7 @@ def main():
   stack = dict(us=round(conv_us, 1), gflop=round(conv_gf, 3),
                tflops=round(conv_gf / conv_us * 1e3, 3),
                frac=round(conv_gf / conv_us * 1e3 / PEAK_MFMA_F32_TFLOPS, 4))
-  elbo_roof = profile_elbo(eng) if eng.observation == 'bernoulli' else None
+  hbm = profile_hbm_kernels(eng)
   if args.profile_ops:
     for o in ops:
       print(f"# {o['layer']:14s} {o['op']:6s} {o['us']:9.1f} us {o['gflop']:8.3f} GF "
@@ -466,7 +498,8 @@ def main():
              config=dict(workload=args.workload, global_batch=B * world, per_gpu_batch=B,
                          beta=beta, parallelism=f'dp{world}', graph=bool(use_graph),
                          final_loss=round(loss, 4)),
-             roofline=roofline, cpu_baseline=cpu, conv_stack=stack, elbo_kernel=elbo_roof)
+             roofline=roofline, cpu_baseline=cpu, conv_stack=stack, elbo_kernel=hbm[0],
+             hbm_kernels=hbm)
   if rccl is not None:
     res['rccl'] = rccl
   print(json.dumps(res), flush=True)

@@ -51,6 +51,20 @@ __device__ __forceinline__ float odin_exp2(float x) {
   return __builtin_amdgcn_exp2f(x);
 #endif
 }
+__device__ __forceinline__ float odin_log2(float x) {
+#ifdef ODIN_SIM
+  return log2f(x);
+#else
+  return __builtin_amdgcn_logf(x);  // v_log_f32
+#endif
+}
+__device__ __forceinline__ float odin_rcp(float x) {
+#ifdef ODIN_SIM
+  return 1.f / x;
+#else
+  return __builtin_amdgcn_rcpf(x);  // v_rcp_f32 (1 ulp)
+#endif
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // v_mfma_f32_32x32x2_f32: exact f32, k-ordered fmaf chain.  Lane l supplies

@@ -8,6 +8,7 @@
 #include "odin_device.h"
 #include "odin_internal.h"
 #include <cstdlib>
+#include <cstdint>
 
 namespace {
 
@@ -121,6 +122,49 @@ __global__ __launch_bounds__(256) void elbo_bernoulli_kernel(const float* __rest
   if (threadIdx.x == 0) llk_part[blockIdx.x] = s;
 }
 
+
+// ---- streaming form (HBM roofline): one WAVE owns U*256 contiguous elements of one sample.
+// All 2*U 16-byte loads of a lane are issued before the first use (U >= 3: >= 6 loads in flight
+// per lane, ~100 KB per CU at 16 waves), there is no workgroup barrier and no LDS: the
+// per-sample partial is reduced with wave shuffles and stored once per wave; a sample's
+// N / (256*U) partials are summed by elbo_finalize.  12 B per element (read logits, x; write
+// dlogits).  softplus / sigmoid share one v_exp, one v_log and one v_rcp per element.
+__device__ __forceinline__ void bern1(float l, float t, float sc, float& acc, float& g) {
+  const float e = odin_exp2(-1.4426950408889634f * fabsf(l));   // exp(-|l|) in (0, 1]
+  const float r = odin_rcp(1.f + e);
+  acc += t * l - (fmaxf(l, 0.f) + 0.6931471805599453f * odin_log2(1.f + e));
+  const float sg = l >= 0.f ? r : e * r;
+  g = (sg - t) * sc;
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void elbo_bernoulli_stream_kernel(
+    const float4* __restrict__ logits, const float4* __restrict__ x, float* __restrict__ llk_part,
+    float4* __restrict__ dlogits, const float* __restrict__ scale, size_t n_waves) {
+  const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_waves) return;
+  const int lane = threadIdx.x & 63;
+  const size_t base = w * (size_t)(64 * U) + lane;
+  float4 l[U], t[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) l[u] = logits[base + 64 * u];
+#pragma unroll
+  for (int u = 0; u < U; ++u) t[u] = x[base + 64 * u];
+  const float sc = scale[0];
+  float acc = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float4 g;
+    bern1(l[u].x, t[u].x, sc, acc, g.x);
+    bern1(l[u].y, t[u].y, sc, acc, g.y);
+    bern1(l[u].z, t[u].z, sc, acc, g.z);
+    bern1(l[u].w, t[u].w, sc, acc, g.w);
+    dlogits[base + 64 * u] = g;
+  }
+  acc = wave_sum64(acc);
+  if (lane == 0) llk_part[w] = acc;
+}
+
 // h [B, n_pix, 2C] (loc | raw scale), x [B, n_pix, C]; N = n_pix*C elements per sample
 __global__ __launch_bounds__(256) void elbo_gaussian_kernel(const float* __restrict__ h,
                                                             const float* __restrict__ x,
@@ -150,6 +194,76 @@ __global__ __launch_bounds__(256) void elbo_gaussian_kernel(const float* __restr
   }
   float s = block_sum_256(acc, red);
   if (threadIdx.x == 0) llk_part[blockIdx.x] = s;
+}
+
+
+// Gaussian head, streaming form: a lane owns G groups of 4 consecutive pixels = 8*C contiguous
+// floats of h (loc | raw per pixel) and 4*C of x; every 16-byte load of the lane is issued before
+// the first use; wave-shuffle reduction, one partial per wave (256*G pixels of one sample).
+// 20 B per element: read loc, raw, x; write dloc, draw.
+template <int C, int G, int SP1>
+__global__ __launch_bounds__(256) void elbo_gaussian_stream_kernel(
+    const float4* __restrict__ h, const float4* __restrict__ x, float* __restrict__ llk_part,
+    float4* __restrict__ dh, const float* __restrict__ scale, size_t n_waves) {
+  const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_waves) return;
+  const int lane = threadIdx.x & 63;
+  float hv[G][8 * C], xv[G][4 * C];
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    const size_t grp = (w * G + q) * 64 + lane;  // group of 4 pixels
+#pragma unroll
+    for (int j = 0; j < 2 * C; ++j) {
+      const float4 v = h[grp * (2 * C) + j];
+      hv[q][4 * j] = v.x; hv[q][4 * j + 1] = v.y; hv[q][4 * j + 2] = v.z; hv[q][4 * j + 3] = v.w;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    const size_t grp = (w * G + q) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      const float4 v = x[grp * C + j];
+      xv[q][4 * j] = v.x; xv[q][4 * j + 1] = v.y; xv[q][4 * j + 2] = v.z; xv[q][4 * j + 3] = v.w;
+    }
+  }
+  const float sc = scale[0];
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    float o[8 * C];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float loc = hv[q][pp * 2 * C + c], raw = hv[q][pp * 2 * C + C + c];
+        const float t = xv[q][pp * C + c];
+        float sd, dsd;
+        if (SP1) {
+          // softplus1(raw) = softplus(raw + softplus^-1(1)); its derivative = sigmoid(same)
+          const float a = raw + SOFTPLUS_INV1;
+          const float e = odin_exp2(-1.4426950408889634f * fabsf(a));
+          const float r = odin_rcp(1.f + e);
+          sd = fmaxf(a, 0.f) + 0.6931471805599453f * odin_log2(1.f + e);
+          dsd = a >= 0.f ? r : e * r;
+        } else {
+          sd = raw;
+          dsd = 1.f;
+        }
+        const float inv = 1.f / sd;
+        const float d = (t - loc) * inv;
+        acc += -0.5f * d * d - 0.6931471805599453f * odin_log2(sd) - 0.5f * LOG2PI_F;
+        o[pp * 2 * C + c] = -(d * inv) * sc;
+        o[pp * 2 * C + C + c] = -((d * d - 1.f) * inv) * dsd * sc;
+      }
+    }
+    const size_t grp = (w * G + q) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 2 * C; ++j)
+      dh[grp * (2 * C) + j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+  }
+  acc = wave_sum64(acc);
+  if (lane == 0) llk_part[w] = acc;
 }
 
 __global__ __launch_bounds__(256) void elbo_finalize_kernel(const float* llk_part, int n_part,
@@ -329,11 +443,42 @@ extern "C" int odin_latent_bwd(const float* p, const float* eps, const float* z,
   return odin_check_launch("latent_bwd");
 }
 
+// partial layout: llk_part[b * n_part + j]; n_part is reported to the caller (elbo_finalize sums)
+static int elbo_stream_unroll(int n_per_sample) {
+  // elements per wave = 256 * U must divide the sample; prefer >= 6 loads in flight per lane
+  static const int cand[] = {3, 4, 2, 1};
+  if (const char* e = getenv("ODIN_ELBO_U")) {  // diagnostics: A/B the loads in flight per lane
+    const int u = atoi(e);
+    return (u >= 1 && u <= 4 && n_per_sample % (256 * u) == 0) ? u : 0;
+  }
+  for (int u : cand)
+    if (n_per_sample % (256 * u) == 0) return u;
+  return 0;
+}
+
 extern "C" int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, float* llk_part,
                                            float* dlogits, const float* scale, int B,
                                            int n_per_sample, int* n_part_out, void* stream) {
+  const int U = elbo_stream_unroll(n_per_sample);
+  if (U > 0 && (((uintptr_t)logits | (uintptr_t)x | (uintptr_t)dlogits) & 15) == 0) {
+    const int n_part = n_per_sample / (256 * U);
+    if (n_part_out) *n_part_out = n_part;
+    if (logits == nullptr) return 0;  // dry run: reports the partial count
+    const size_t n_waves = (size_t)B * n_part;
+    const dim3 grid((unsigned)((n_waves + 3) / 4));
+#define ODIN_ELBO_STREAM(UU)                                                                    \
+  ODIN_LAUNCH((elbo_bernoulli_stream_kernel<UU>), grid, dim3(256), 0, stream,                   \
+              (const float4*)logits, (const float4*)x, llk_part, (float4*)dlogits, scale, n_waves)
+    if (U == 3) ODIN_ELBO_STREAM(3);
+    else if (U == 4) ODIN_ELBO_STREAM(4);
+    else if (U == 2) ODIN_ELBO_STREAM(2);
+    else ODIN_ELBO_STREAM(1);
+#undef ODIN_ELBO_STREAM
+    return odin_check_launch("elbo_bernoulli");
+  }
   int n_part = (n_per_sample + ELBO_CHUNK - 1) / ELBO_CHUNK;
   if (n_part_out) *n_part_out = n_part;
+  if (logits == nullptr) return 0;
   int vec = (n_per_sample % 4 == 0) ? 1 : 0;
   ODIN_LAUNCH(elbo_bernoulli_kernel, dim3(B * n_part), dim3(256), 0, stream, logits, x, llk_part,
               dlogits, scale, n_per_sample, n_part, vec);
@@ -344,8 +489,28 @@ extern "C" int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float*
                                           float* dh, const float* scale, int B, int n_pix, int C,
                                           int softplus1, int* n_part_out, void* stream) {
   int N = n_pix * C;
+  // streaming form: C in {1, 3}, whole waves of 256*G pixels per sample
+  const int G = (C == 1) ? 2 : 1;
+  if ((C == 1 || C == 3) && n_pix % (256 * G) == 0 &&
+      (((uintptr_t)h | (uintptr_t)x | (uintptr_t)dh) & 15) == 0) {
+    const int n_part = n_pix / (256 * G);
+    if (n_part_out) *n_part_out = n_part;
+    if (h == nullptr) return 0;  // dry run
+    const size_t n_waves = (size_t)B * n_part;
+    const dim3 grid((unsigned)((n_waves + 3) / 4));
+#define ODIN_GAUSS_STREAM(CC, GG, SP)                                                           \
+  ODIN_LAUNCH((elbo_gaussian_stream_kernel<CC, GG, SP>), grid, dim3(256), 0, stream,            \
+              (const float4*)h, (const float4*)x, llk_part, (float4*)dh, scale, n_waves)
+    if (C == 3 && softplus1) ODIN_GAUSS_STREAM(3, 1, 1);
+    else if (C == 3) ODIN_GAUSS_STREAM(3, 1, 0);
+    else if (softplus1) ODIN_GAUSS_STREAM(1, 2, 1);
+    else ODIN_GAUSS_STREAM(1, 2, 0);
+#undef ODIN_GAUSS_STREAM
+    return odin_check_launch("elbo_gaussian");
+  }
   int n_part = (N + ELBO_CHUNK - 1) / ELBO_CHUNK;
   if (n_part_out) *n_part_out = n_part;
+  if (h == nullptr) return 0;  // dry run
   ODIN_LAUNCH(elbo_gaussian_kernel, dim3(B * n_part), dim3(256), 0, stream, h, x, llk_part, dh,
               scale, N, C, n_part, softplus1);
   return odin_check_launch("elbo_gaussian");
@@ -443,12 +608,19 @@ __global__ __launch_bounds__(256) void tiny_dense_kernel(const float* __restrict
   }
 }
 
-// geometry shared by the launcher and the dry run: outputs padded to a power of two <= 256
-static void tiny_dense_geom(int NO, int B, int* nop, int* sb, int* blocks) {
+// geometry shared by the launcher and the dry run: outputs padded to a power of two <= 256;
+// samples per block capped so that the staged input rows (sb x NR floats) stay within 32 KB:
+// with the <= 17 KB weight image the launch fits the default 64 KB dynamic-LDS limit for every
+// shape odin_tiny_dense_ok admits (narrow heads such as Dense(128 -> 1) or Dense(256 -> 4))
+static void tiny_dense_geom(int NO, int NR, int B, int* nop, int* sb, int* blocks) {
   int p2 = 1;
   while (p2 < NO) p2 <<= 1;
   *nop = p2;
-  *sb = 256 / p2;
+  int s = 256 / p2;
+  const int cap = 8192 / (NR > 0 ? NR : 1);
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  *sb = s;
   *blocks = (B + *sb - 1) / *sb;
 }
 
@@ -459,7 +631,7 @@ bool odin_tiny_dense_ok(int B, int K, int N) {
 int odin_tiny_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K,
                         int N, int act, void* stream) {
   int nop, sb, blocks;
-  tiny_dense_geom(N, B, &nop, &sb, &blocks);
+  tiny_dense_geom(N, K, B, &nop, &sb, &blocks);
   const size_t lds = (size_t)(K * (N + 1) + sb * K + 256) * 4;
   ODIN_LAUNCH((tiny_dense_kernel<false>), dim3(blocks), dim3(256), lds, stream, x, w, bias, y,
               (float*)nullptr, B, K, N, act, nop, sb);
@@ -469,7 +641,7 @@ int odin_tiny_dense_fwd(const float* x, const float* w, const float* bias, float
 int odin_tiny_dense_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
                           float* colsum_slab, int* slab_rows_out, int B, int K, int N, void* stream) {
   int nop, sb, blocks;
-  tiny_dense_geom(K, B, &nop, &sb, &blocks);
+  tiny_dense_geom(K, N, B, &nop, &sb, &blocks);
   if (slab_rows_out) *slab_rows_out = blocks;
   if (dx == nullptr) return 0;  // dry run
   const size_t lds = (size_t)(K * (N + 1) + sb * N + 256) * 4;

@@ -353,7 +353,17 @@ class VAEEngine:
     self.dh_e = torch.empty(B, self.hdim, **f32)
     n_per = int(np.prod(self.in_shape))
     self.n_per = n_per
-    self.llk_part = torch.empty(B * ((n_per + 1023) // 1024), **f32)
+    # per-sample partial log-likelihoods: the kernel reports how many it writes per sample
+    npart = C.c_int(0)
+    if observation == 'bernoulli':
+      self.lib.odin_elbo_bernoulli_fwd_bwd(None, None, None, None, None, B, n_per, C.byref(npart),
+                                           None)
+    else:
+      Cc = self.in_shape[-1]
+      self.lib.odin_elbo_gaussian_fwd_bwd(None, None, None, None, None, B, n_per // Cc, Cc,
+                                          int(observation == 'gaussian_softplus1'),
+                                          C.byref(npart), None)
+    self.llk_part = torch.empty(B * max(npart.value, (n_per + 1023) // 1024), **f32)
     self.llk = torch.empty(B, **f32)
     self.out4 = torch.zeros(4, **f32)
     self.n_part = 0

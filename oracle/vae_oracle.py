@@ -616,6 +616,67 @@ def disc_backward(layers, DP, acts, dlogit, need_dz=False):
   return seq_backward(layers, DP, acts, dlogit[:, None], need_dx=need_dz)
 
 
+def factor_vae_iteration(model: 'OracleVAE', P, M, V, t: int, dlayers, DP, DM, DV, td: int, x,
+                         eps1, eps2, perm, lr: float, tc_coef: float = 7.0,
+                         global_clipnorm=None, pretraining: bool = False, disc_lr=1e-5,
+                         disc_b1=0.5, disc_b2=0.9):
+  """One FactorVAE training iteration = the two TrainSteps of
+  odin/bay/vi/autoencoder/factor_vae.py:239-287 run by Networks.optimize
+  (odin/networks/base_networks.py:415-624) one after the other:
+
+  step 1 (VAEStep on x1, VAE parameters): loss = -mean(llk - beta*kl) + tc_coef*mean(D(z))
+      (factor_vae.py:202-223; factor_discriminator.py:169-198: the gradient flows through D
+      into z, D's own parameters are not in this step's parameter list), Adam of `fit`.
+  step 2 (FactorDiscriminatorStep on x2, discriminator parameters, factor_vae.py:66-93):
+      z' = encode(x2) with the ALREADY UPDATED encoder, z = the cached sample of step 1;
+      dtc_loss (factor_discriminator.py:200-235) with stop_gradient on both;
+      Adam(1e-5, beta_1=.5, beta_2=.9) (factor_vae.py:173-176).
+
+  `model.beta` must hold the annealed beta of this step (AnnealingVAE, beta_vae.py:99-107).
+  Returns a dict with every intermediate the parity tests compare."""
+  x = np.asarray(x, F64)
+  B1 = x.shape[0] // 2
+  x1, x2 = x[:B1], x[B1:]
+  f = model.forward(P, x1, eps1)
+  out = dict(fwd=f)
+  extra = None
+  tc = 0.0
+  if not pretraining:
+    logit, acts = disc_forward(dlayers, DP, f['z'])
+    tc = tc_coef * float(np.mean(logit))
+    extra, _ = disc_backward(dlayers, DP, acts, np.full(B1, tc_coef / B1), need_dz=True)
+  out['tc'], out['loss'], out['extra_dz'] = tc, f['loss'] + tc, extra
+  G, _ = model.backward(P, x1, eps1, f, extra_dz=extra)
+  out['G'] = G
+  keys = [k for k, _ in model.param_shapes()]
+  Gc = G
+  if global_clipnorm is not None:
+    gl, _ = clip_by_global_norm([G[k] for k in keys], global_clipnorm)
+    Gc = dict(zip(keys, gl))
+  P2, M2, V2 = {}, {}, {}
+  for k in keys:
+    P2[k], M2[k], V2[k] = adam_keras(P[k], Gc[k], M[k], V[k], t, lr)
+  out.update(P=P2, M=M2, V=V2)
+  if pretraining:
+    return out
+  f2 = model.forward(P2, x2, eps2)
+  zp = permute_dims(f2['z'], np.asarray(perm, np.int64))
+  l1, a1 = disc_forward(dlayers, DP, f['z'])
+  l2, a2 = disc_forward(dlayers, DP, zp)
+  out['z2'], out['zperm'], out['dtc_loss'] = f2['z'], zp, dtc_loss(l1, l2)
+  d1, d2 = dtc_loss_bwd(l1, l2)
+  _, g1 = disc_backward(dlayers, DP, a1, d1)
+  _, g2 = disc_backward(dlayers, DP, a2, d2)
+  DG = {k: g1[k] + g2[k] for k in g1}
+  out['DG'] = DG
+  DP2, DM2, DV2 = {}, {}, {}
+  for k in DG:
+    DP2[k], DM2[k], DV2[k] = adam_keras(DP[k], DG[k], DM[k], DV[k], td, disc_lr, b1=disc_b1,
+                                        b2=disc_b2)
+  out.update(DP=DP2, DM=DM2, DV=DV2)
+  return out
+
+
 # --------------------------------------------------------------------------------------
 # Network specs restating odin/networks/image_networks.py (used by tests to drive both
 # the oracle and the product with identical architectures)

@@ -60,7 +60,8 @@ def check_engine_vs_oracle(eng, model: vo.OracleVAE, P, x, eps, beta, lr=1e-3, t
     for k in G:
       report['grad' + str(k)] = relerr(gv[k], G[k])
     for k, v in report.items():
-      assert v <= tol, (t, k, v, report)
+      if k != 'param_unmasked_max':
+        assert v <= tol, (t, k, v, report)
     # optimiser.  (a) the Adam kernel itself: oracle Keras-Adam applied to the ENGINE's own
     # fp32 gradients must reproduce the engine's parameters tightly.  (b) end to end vs the
     # float64 trajectory: Adam normalises every element's update to ~lr whatever the
@@ -82,6 +83,7 @@ def check_engine_vs_oracle(eng, model: vo.OracleVAE, P, x, eps, beta, lr=1e-3, t
     else:
       Gc = G
     pv = {k: v.cpu().numpy() for k, v in eng.param_views().items()}
+    unmasked = report.get('param_unmasked_max', 0.0)
     for k in keys:
       pk, _, _ = vo.adam_keras(p_before[k], gv[k].astype(np.float64) * gs, m_before[k],
                                v_before[k], t, lr)
@@ -92,5 +94,11 @@ def check_engine_vs_oracle(eng, model: vo.OracleVAE, P, x, eps, beta, lr=1e-3, t
       good = np.abs(G[k]) > 1e-3 * np.abs(G[k]).max()
       assert d[good].max() <= tol, (t, 'param', k, d[good].max())
       assert d.mean() <= 5e-3 * lr, (t, 'param-mean', k, d.mean())
+      # reported next to the masked check: the UNMASKED maximum; bounded by ~2*lr
+      # (an ill-conditioned element can at worst flip the sign of its normalised update)
+      unmasked = max(unmasked, float(d.max()))
+      assert d.max() <= 2.5 * lr * t, (t, 'param-unmasked', k, d.max())
+    report_unmasked = unmasked
     # continue from the oracle's parameters so that errors do not compound in the check
+  report['param_unmasked_max'] = report_unmasked
   return report

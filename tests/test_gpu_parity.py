@@ -188,3 +188,131 @@ def test_device_input_pipeline(dev, L):
   vae.fit(ds, max_iter=40, batch_size=64, learning_rate=1e-3, compile_graph=True)
   l1, _ = vae.optimize(x0, training=False)
   assert vae.step == 40 and float(l1) < float(l0)
+
+
+# ------------------------------------------------------------------------------------------
+# round 2: FactorVAE backward, raw-scale Gaussian, NaN policy on device, full-size gradients
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('units', [(1000,) * 5, (128, 128)], ids=['5x1000', '2x128'])
+def test_factor_vae_iteration_parity(dev, L, units):
+  """BASELINE config 3's iteration (factor_vae.py:239-287) on the Shapes3D stack: VAE gradients
+  with the term that flows through D into z, discriminator gradients, dtc_loss, permute_dims
+  bit-exact, and BOTH post-Adam parameter sets (Adam(lr) and Adam(1e-5,.5,.9)) vs the oracle.
+  (128,128) ends in Dense(128 -> 1): the narrow-head tiny-Dense path."""
+  from odin_ai_amd.networks import get_networks
+  from odin_ai_amd.vae import FactorVAE
+  from tests.factor_util import check_factor_vae_iteration
+  nets = get_networks('shapes3d')
+  B1, D = 4, 6
+  fv = FactorVAE(discriminator_units=units, tc_coef=7.0, device=dev, lib=L, **nets)
+  rng = np.random.default_rng(21)
+  x = np.clip(rng.random((2 * B1, 64, 64, 3)), 1e-6, 1 - 1e-6).astype(np.float32)
+  eps, eps2 = (rng.standard_normal((B1, D)).astype(np.float32) for _ in range(2))
+  perm = np.stack([rng.permutation(B1) for _ in range(D)], 1).astype(np.int32)
+  rep = check_factor_vae_iteration(fv, nets, units, B1, x, eps, eps2, perm, lr=1e-3, clip=100.0)
+  print('factor_vae', units, {k: f'{v:.2e}' for k, v in rep.items() if 'grad' not in k})
+
+
+def test_gaussian_raw_scale_parity(dev, L):
+  """a11's primary branch (image_networks.py:95-102): Normal(loc, scale) with the scale taken RAW
+  from the decoder (no positivity transform).  The scale maps' bias is set positive so that the
+  log-prob is finite, as a trained model's would be."""
+  from odin_ai_amd.engine import VAEEngine
+  enc, dec, in_shape, zdim, x, eps = make_case(vo.celeba_spec(45, 6), 'gaussian', 4)
+  model = vo.OracleVAE(enc, dec, in_shape, zdim, observation='gaussian', beta=2.0)
+  P = model.init_params(seed=3)
+  last = max(k[1] for k in P if k[0] == 'dec')
+  P[('dec', last, 'w')] = P[('dec', last, 'w')] * 0.05
+  P[('dec', last, 'b')][3:] = 1.5
+  f = model.forward(P, x, eps)
+  assert f['h_d'][..., 3:].min() > 0.5, 'test premise: raw scales must be positive'
+  eng = VAEEngine(enc, dec, in_shape, zdim, 4, dev, observation='gaussian', lib=L)
+  rep = check_engine_vs_oracle(eng, model, P, x, eps, beta=2.0, clip=100.0)
+  print('gaussian_raw', {k: f'{v:.2e}' for k, v in rep.items() if not k.startswith('grad')})
+
+
+def test_nan_gradients_skip_the_update_on_device(dev, L):
+  """Networks.optimize NaN policy (base_networks.py:519-547): a non-finite gradient must leave
+  parameters, m and v untouched and raise the device flag -- eager and graph-replayed."""
+  from odin_ai_amd.engine import VAEEngine
+  enc, dec, in_shape, zdim = vo.dsprites_spec(1)
+  for use_graph in (False, True):
+    eng = VAEEngine(enc, dec, in_shape, zdim, 8, dev, lib=L)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    eng.params.copy_((torch.randn(eng.params.numel(), generator=g) * 0.05).to(dev))
+    x = torch.rand(8, *in_shape, device=dev).clamp_(1e-6, 1 - 1e-6)
+    eng.train_step(x, None, lr=1e-3, beta=4.0, global_clipnorm=100.0, use_graph=use_graph)
+    torch.cuda.synchronize()
+    assert eng.flag.item() == 0
+    p, m, v = eng.params.clone(), eng.m.clone(), eng.v.clone()
+    xb = x.clone()
+    xb[3, 10, 10, 0] = float('nan')
+    eng.train_step(xb, None, lr=1e-3, beta=4.0, global_clipnorm=100.0, use_graph=use_graph)
+    torch.cuda.synchronize()
+    assert eng.flag.item() == 1
+    assert torch.equal(p, eng.params) and torch.equal(m, eng.m) and torch.equal(v, eng.v)
+    eng.flag.zero_()
+    eng.train_step(x, None, lr=1e-3, beta=4.0, global_clipnorm=100.0, use_graph=use_graph)
+    torch.cuda.synchronize()
+    assert eng.flag.item() == 0 and not torch.equal(p, eng.params)
+
+
+FULL = [
+    # name, spec, B, kwargs, env
+    ('dsprites_b256_default', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0), {}),
+    ('dsprites_b256_fp32_mfma_only', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0),
+     {'ODIN_SPLIT': '0'}),
+    ('dsprites_b256_no_overlap', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0),
+     {'ODIN_OVERLAP_WGRAD': '0', 'ODIN_EARLY_REDUCE': '0'}),
+    ('shapes3d_b128', lambda: vo.dsprites_spec(3), 128, dict(beta=1.0), {}),
+    ('celeba_b512', lambda: vo.celeba_spec(45, 3), 512, dict(beta=4.0), {}),
+    ('celeba_betatc_b512', lambda: vo.celeba_spec(45, 3), 512, dict(beta=4.0, tc_beta=4.0), {}),
+]
+
+
+@pytest.mark.parametrize('name,spec,B,kw,env', FULL, ids=[c[0] for c in FULL])
+def test_full_batch_gradients_vs_f64_autograd(dev, L, monkeypatch, name, spec, B, kw, env):
+  """the kernel variants picked at BASELINE batch sizes (producer/consumer wgrad, tile
+  splitting, intra-workgroup split-K, side-stream early reduce, bf16-split instances) compared
+  with an independent float64 restatement (torch autograd on the host, oracle/torch_ref.py):
+  loss, llk[B], kl[B] and EVERY gradient tensor within 1e-4 of the tensor's maximum."""
+  import os
+  from odin_ai_amd.engine import VAEEngine
+  from oracle.torch_ref import TorchVAE
+  for k, v in env.items():
+    monkeypatch.setenv(k, v)
+    os.putenv(k, v)
+  enc, dec, in_shape, zdim = spec()
+  rng = np.random.default_rng(5)
+  x = np.clip(rng.random((B,) + tuple(in_shape)), 1e-6, 1 - 1e-6).astype(np.float32)
+  eps = rng.standard_normal((B, zdim)).astype(np.float32)
+  ref = TorchVAE(enc, dec, in_shape, zdim, **kw)
+  om = vo.OracleVAE(enc, dec, in_shape, zdim, **kw)
+  P = om.init_params(seed=9)
+  P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
+  torch.set_num_threads(min(32, os.cpu_count() or 1))
+  out, G = ref.loss_and_grads(P, x.astype(np.float64), eps.astype(np.float64))
+  eng = VAEEngine(enc, dec, in_shape, zdim, B, dev, tc='betatc' if 'tc_beta' in kw else None,
+                  lib=L)
+  eng.load_params(P)
+  eng.step_count = 1
+  eng.set_hyper(lr=1e-3, beta=kw['beta'])
+  eng.forward(torch.tensor(x, device=dev), torch.tensor(eps, device=dev))
+  eng.backward()
+  torch.cuda.synchronize()
+  for k in env:
+    os.unsetenv(k)
+  from tests.parity_util import relerr
+  rep = dict(loss=abs(eng.out4[0].item() - float(out['loss'])) / abs(float(out['loss'])),
+             llk=relerr(eng.llk.cpu().numpy(), out['llk']),
+             kl=relerr(eng.kl.cpu().numpy() * kw['beta'], out['kl']))
+  gv = {k: v.cpu().numpy() for k, v in eng.grad_views().items()}
+  worst = ('', 0.0)
+  for k in G:
+    e = relerr(gv[k], G[k])
+    rep['grad' + str(k)] = e
+    if e > worst[1]:
+      worst = (k, e)
+  print(name, f"loss {rep['loss']:.2e} llk {rep['llk']:.2e} kl {rep['kl']:.2e} worst grad {worst}")
+  for k, v in rep.items():
+    assert v <= 1e-4, (k, v)

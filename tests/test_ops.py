@@ -1,7 +1,8 @@
-"""Kernel SOURCES executed by the CPU fiber simulator vs the float64 oracle (no GPU).
-
-These tests debug tiling / indexing of the gfx950 kernels in the build container; the
-real parity tests (`-m gpu`) run the hipcc build on an MI355X.
+"""Op-level parity of every conv / deconv / dense / fused-tail entry point of the C ABI vs the
+float64 oracle, on two backends (fixture `bk`, tests/conftest.py):
+  'sim' -- the kernel SOURCES built for the CPU fiber simulator (debugs tiling / indexing in the
+           build container, `-m "not gpu"`);
+  'hip' -- the hipcc gfx950 build on an MI355X (`-m gpu`): the parity tests proper.
 """
 import ctypes as C
 
@@ -11,23 +12,14 @@ import torch
 
 from odin_ai_amd import _lib
 from oracle import vae_oracle as vo
-from tests.simutil import sim_lib
 
 
-@pytest.fixture(scope='module')
-def L():
-  return sim_lib()
-
-
-def T(a):
-  return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32)
-
-
-def reduce_slab(L, slab, rows, n):
-  out = torch.zeros(n)
+def reduce_slab(bk, slab, rows, n):
+  L = bk.L
+  out = bk.zeros(n)
   job = (_lib.ReduceJob * 1)(_lib.ReduceJob(slab.data_ptr(), out.data_ptr(), n, rows, slab.shape[1], 0))
   L.odin_slab_reduce(job, 1, None)
-  return out.numpy()
+  return out.cpu().numpy()
 
 
 def close(a, b, tol=2e-5):
@@ -62,7 +54,8 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize('B,H,W,Ci,Co,K,S,act,center', CONV_CASES)
-def test_conv2d_fwd_dgrad_wgrad(L, B, H, W, Ci, Co, K, S, act, center):
+def test_conv2d_fwd_dgrad_wgrad(bk, B, H, W, Ci, Co, K, S, act, center):
+  L, T = bk.L, bk.T
   rng = np.random.default_rng(0)
   x = rng.random((B, H, W, Ci))
   w = rng.standard_normal((K, K, Ci, Co)) * 0.2
@@ -73,9 +66,9 @@ def test_conv2d_fwd_dgrad_wgrad(L, B, H, W, Ci, Co, K, S, act, center):
   xin = 2 * x - 1 if center else x
   y_ref = vo._ACT[act](vo.conv2d(xin, w, b, S))
   tx, tw, tb = T(x), T(w), T(b)
-  ty = torch.full((B, OH, OW, Co), float('nan'))
+  ty = bk.full((B, OH, OW, Co), float('nan'))
   L.odin_conv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
-  close(ty.numpy(), y_ref)
+  close(ty.cpu().numpy(), y_ref)
   # backward
   dy = rng.standard_normal((B, OH, OW, Co))
   tdy = T(dy)
@@ -83,20 +76,20 @@ def test_conv2d_fwd_dgrad_wgrad(L, B, H, W, Ci, Co, K, S, act, center):
   if H % S == 0 and W % S == 0:
     aux = rng.standard_normal((B, H, W, Ci))
     taux = T(aux)
-    tdx = torch.full((B, H, W, Ci), float('nan'))
+    tdx = bk.full((B, H, W, Ci), float('nan'))
     rows = C.c_int(0)
-    slab = torch.full((L.odin_max_slab_rows(), Ci), float('nan'))
+    slab = bk.full((L.odin_max_slab_rows(), Ci), float('nan'))
     L.odin_conv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, tdx.data_ptr(),
                         slab.data_ptr(), C.byref(rows), C.byref(d), None)
     g_ref = dx_ref * vo.elu_grad_from_output(aux.astype(np.float32).astype(np.float64))
-    close(tdx.numpy(), g_ref)
-    close(reduce_slab(L, slab, rows.value, Ci), g_ref.sum((0, 1, 2)), 1e-4)
+    close(tdx.cpu().numpy(), g_ref)
+    close(reduce_slab(bk, slab, rows.value, Ci), g_ref.sum((0, 1, 2)), 1e-4)
   rows = C.c_int(0)
   n = K * K * Ci * Co + Co
-  slab = torch.full((L.odin_max_slab_rows(), n), float('nan'))
+  slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
   L.odin_conv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d),
                       None)
-  g = reduce_slab(L, slab, rows.value, n)
+  g = reduce_slab(bk, slab, rows.value, n)
   close(g[:-Co].reshape(K, K, Ci, Co), dw_ref, 1e-4)
   close(g[-Co:], db_ref, 1e-4)
 
@@ -112,7 +105,8 @@ DECONV_CASES = [
 
 
 @pytest.mark.parametrize('B,H,W,Ci,Co,K,S,act', DECONV_CASES)
-def test_deconv2d_fwd_dgrad_wgrad(L, B, H, W, Ci, Co, K, S, act):
+def test_deconv2d_fwd_dgrad_wgrad(bk, B, H, W, Ci, Co, K, S, act):
+  L, T = bk.L, bk.T
   rng = np.random.default_rng(1)
   x = rng.standard_normal((B, H, W, Ci))
   w = rng.standard_normal((K, K, Co, Ci)) * 0.2
@@ -123,56 +117,63 @@ def test_deconv2d_fwd_dgrad_wgrad(L, B, H, W, Ci, Co, K, S, act):
   d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, act)
   y_ref = vo._ACT[act](vo.conv2d_transpose(x, w, b, S))
   tx, tw, tb = T(x), T(w), T(b)
-  ty = torch.full((B, OH, OW, Co), float('nan'))
+  ty = bk.full((B, OH, OW, Co), float('nan'))
   L.odin_deconv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
-  close(ty.numpy(), y_ref)
+  close(ty.cpu().numpy(), y_ref)
   dy = rng.standard_normal((B, OH, OW, Co))
   tdy = T(dy)
   dx_ref, dw_ref, db_ref = vo.conv2d_transpose_bwd(x, w, dy, S)
   aux = rng.standard_normal((B, H, W, Ci))
   taux = T(aux)
-  tdx = torch.full((B, H, W, Ci), float('nan'))
+  tdx = bk.full((B, H, W, Ci), float('nan'))
   rows = C.c_int(0)
-  slab = torch.full((L.odin_max_slab_rows(), Ci), float('nan'))
+  slab = bk.full((L.odin_max_slab_rows(), Ci), float('nan'))
   L.odin_deconv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, tdx.data_ptr(),
                         slab.data_ptr(), C.byref(rows), C.byref(d), None)
   g_ref = dx_ref * vo.elu_grad_from_output(aux.astype(np.float32).astype(np.float64))
-  close(tdx.numpy(), g_ref)
-  close(reduce_slab(L, slab, rows.value, Ci), g_ref.sum((0, 1, 2)), 1e-4)
+  close(tdx.cpu().numpy(), g_ref)
+  close(reduce_slab(bk, slab, rows.value, Ci), g_ref.sum((0, 1, 2)), 1e-4)
   n = K * K * Co * Ci
-  slab = torch.full((L.odin_max_slab_rows(), n), float('nan'))
+  slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
   L.odin_deconv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows),
                         C.byref(d), None)
-  close(reduce_slab(L, slab, rows.value, n).reshape(K, K, Co, Ci), dw_ref, 1e-4)
+  close(reduce_slab(bk, slab, rows.value, n).reshape(K, K, Co, Ci), dw_ref, 1e-4)
 
 
 @pytest.mark.parametrize('B,K,N,act', [(5, 1024, 128, 'linear'), (130, 10, 128, 'linear'),
                                        (7, 128, 20, 'linear'), (33, 100, 70, 'relu'),
                                        (3, 4096, 40, 'linear'), (150, 36, 33, 'relu'),
-                                       (100, 256, 40, 'linear'), (70, 512, 64, 'relu')])
-def test_dense(L, B, K, N, act):
+                                       (100, 256, 40, 'linear'), (70, 512, 64, 'relu'),
+                                       # narrow heads on the tiny-Dense path (staged rows capped to
+                                       # 32 KB of LDS): FactorVAE(discriminator_units=(128,128)) ends
+                                       # in Dense(128 -> 1)
+                                       (128, 128, 1, 'linear'), (256, 256, 1, 'linear'),
+                                       (200, 256, 4, 'relu'), (64, 128, 2, 'linear'),
+                                       (300, 1, 256, 'linear'), (256, 2, 200, 'relu')])
+def test_dense(bk, B, K, N, act):
+  L, T = bk.L, bk.T
   rng = np.random.default_rng(2)
   x = rng.standard_normal((B, K))
   w = rng.standard_normal((K, N)) / np.sqrt(K)
   b = rng.standard_normal(N) * 0.1
   y_ref = vo._ACT[act](vo.dense(x, w, b))
-  ty = torch.full((B, N), float('nan'))
+  ty = bk.full((B, N), float('nan'))
   tx, tw, tb = T(x), T(w), T(b)
   L.odin_dense_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), B, K, N,
                    _lib.ACT[act], None)
-  close(ty.numpy(), y_ref)
+  close(ty.cpu().numpy(), y_ref)
   dy = rng.standard_normal((B, N))
   tdy = T(dy)
   dx_ref, dw_ref, db_ref = vo.dense_bwd(x, w, dy)
-  tdx = torch.full((B, K), float('nan'))
+  tdx = bk.full((B, K), float('nan'))
   L.odin_dense_dgrad(tdy.data_ptr(), tw.data_ptr(), None, 0, tdx.data_ptr(), None, None, B, K, N,
                      None)
-  close(tdx.numpy(), dx_ref)
+  close(tdx.cpu().numpy(), dx_ref)
   rows = C.c_int(0)
   n = K * N + N
-  slab = torch.full((L.odin_max_slab_rows(), n), float('nan'))
+  slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
   L.odin_dense_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), B, K, N, None)
-  g = reduce_slab(L, slab, rows.value, n)
+  g = reduce_slab(bk, slab, rows.value, n)
   close(g[:-N].reshape(K, N), dw_ref, 1e-4)
   close(g[-N:], db_ref, 1e-4)
 
@@ -183,7 +184,8 @@ def test_dense(L, B, K, N, act):
     (1, 3, 8, 8, 8, 16, 4, 2, 3),      # generic transposed
     (0, 2, 16, 16, 8, 24, 5, 1, 1),    # generic gather conv (MNIST-style decoder tail)
 ])
-def test_bernoulli_tail(L, is_deconv, B, H, W, Ci, Co, K, S, C1):
+def test_bernoulli_tail(bk, is_deconv, B, H, W, Ci, Co, K, S, C1):
+  L, T = bk.L, bk.T
   rng = np.random.default_rng(3)
   x = rng.standard_normal((B, H, W, Ci))
   b = rng.standard_normal(Co) * 0.1
@@ -209,28 +211,29 @@ def test_bernoulli_tail(L, is_deconv, B, H, W, Ci, Co, K, S, C1):
   dd, dw1_ref, db1_ref = vo.conv2d_bwd(d, w1, dl, 1)
   g_ref = dd * vo.elu_grad_from_output(d)
   tx, tw, tb, tw1, tb1, tt, tsc = T(x), T(w), T(b), T(w1), T(b1), T(tgt), T([scale])
-  logits = torch.full((B, OH, OW, C1), float('nan'))
-  g = torch.full((B, OH, OW, Co), float('nan'))
+  logits = bk.full((B, OH, OW, C1), float('nan'))
+  g = bk.full((B, OH, OW, Co), float('nan'))
   rows, npart = C.c_int(0), C.c_int(0)
   L.odin_bernoulli_tail_fwd_bwd(is_deconv, None, None, None, None, None, None, None, None, None,
                                 C.byref(npart), None, C.byref(rows), None, C.byref(desc), C1, None)
-  part = torch.full((B * npart.value,), float('nan'))
+  part = bk.full((B * npart.value,), float('nan'))
   n = Co * C1 + C1 + Co
-  slab = torch.full((rows.value, n), float('nan'))
+  slab = bk.full((rows.value, n), float('nan'))
   L.odin_bernoulli_tail_fwd_bwd(is_deconv, tx.data_ptr(), tw.data_ptr(), tb.data_ptr(),
                                 tw1.data_ptr(), tb1.data_ptr(), tt.data_ptr(), logits.data_ptr(),
                                 g.data_ptr(), part.data_ptr(), C.byref(npart), slab.data_ptr(),
                                 C.byref(rows), tsc.data_ptr(), C.byref(desc), C1, None)
-  close(logits.numpy(), lg)
-  close(part.reshape(B, -1).sum(1).numpy(), llk_ref)
-  close(g.numpy(), g_ref)
-  red = reduce_slab(L, slab, rows.value, n)
+  close(logits.cpu().numpy(), lg)
+  close(part.reshape(B, -1).sum(1).cpu().numpy(), llk_ref)
+  close(g.cpu().numpy(), g_ref)
+  red = reduce_slab(bk, slab, rows.value, n)
   close(red[:Co * C1].reshape(Co, C1), dw1_ref[0, 0], 1e-4)
   close(red[Co * C1:Co * C1 + C1], db1_ref, 1e-4)
   close(red[Co * C1 + C1:], g_ref.sum((0, 1, 2)), 1e-4)
 
 
-def test_split_bf16_path_matches_fp32(L, monkeypatch):
+def test_split_bf16_path_matches_fp32(bk, monkeypatch):
+  L, T = bk.L, bk.T
   """ODIN_SPLIT=1 routes the transposed 4x4/s2 32-channel instances through the bf16-plane path
   (fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per 16 k-values): results must
   agree with the fp32 MFMA path to fp32-class accuracy (<= 2e-6 of the tensor maximum)."""
@@ -247,9 +250,9 @@ def test_split_bf16_path_matches_fp32(L, monkeypatch):
   for flag in ('0', '1', '8'):  # fp32 MFMA / weights in registers / 8-wave, weight planes in LDS
     monkeypatch.setenv('ODIN_SPLIT', flag)
     os.putenv('ODIN_SPLIT', flag)
-    ty = torch.zeros(B, OH, OW, Co)
+    ty = bk.zeros(B, OH, OW, Co)
     L.odin_deconv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
-    outs.append(ty.numpy().copy())
+    outs.append(ty.cpu().numpy().copy())
   os.putenv('ODIN_SPLIT', '0')
   assert np.abs(outs[0]).max() > 0.5
   for o in outs[1:]:

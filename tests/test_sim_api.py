@@ -142,3 +142,19 @@ def test_factor_vae_two_steps_match_oracle(L):
   fv.optimize(x, training=True, learning_rate=1e-3, eps=eps, eps2=eps2, perm=perm)
   assert fv.step == 1 and not torch.equal(p_before, fv._params)
   assert not torch.equal(d_before, disc.params)
+
+
+@pytest.mark.parametrize('units', [(16, 16), (40,)])
+def test_factor_vae_iteration_gradients_and_both_adams(L, units):
+  """the step-1 dz through D, the discriminator gradients and the
+  Adam(1e-5, .5, .9) update against the oracle (simulator build of the kernels)."""
+  from tests.factor_util import check_factor_vae_iteration
+  nets = tiny_nets()
+  B1, D = 4, 4
+  fv = FactorVAE(discriminator_units=units, tc_coef=7.0, device='cpu', lib=L, **nets)
+  rng = np.random.default_rng(11)
+  x = np.clip(rng.random((2 * B1, 8, 8, 1)), 1e-6, 1 - 1e-6).astype(np.float32)
+  eps, eps2 = (rng.standard_normal((B1, D)).astype(np.float32) for _ in range(2))
+  perm = np.stack([rng.permutation(B1) for _ in range(D)], 1).astype(np.int32)
+  rep = check_factor_vae_iteration(fv, nets, units, B1, x, eps, eps2, perm, clip=100.0)
+  assert fv.step == 1000
