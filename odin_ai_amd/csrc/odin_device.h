@@ -211,6 +211,19 @@ __device__ __forceinline__ float odin_act_grad(int act, float y) {
   return 1.f;
 }
 
+// rendezvous of the lanes of ONE wave around wave-private LDS traffic.  On the hardware the DS
+// pipe executes a wave's LDS instructions in order, so only the compiler has to be kept from
+// moving accesses across; the simulator runs lanes as fibers and needs a real rendezvous.
+__device__ __forceinline__ void odin_wave_sync() {
+#ifdef ODIN_SIM
+  (void)sim::wave_deposit(0.f, 0.f);
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

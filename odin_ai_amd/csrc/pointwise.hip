@@ -197,47 +197,59 @@ __global__ __launch_bounds__(256) void elbo_gaussian_kernel(const float* __restr
 }
 
 
-// Gaussian head, streaming form: a lane owns G groups of 4 consecutive pixels = 8*C contiguous
-// floats of h (loc | raw per pixel) and 4*C of x; every 16-byte load of the lane is issued before
-// the first use; wave-shuffle reduction, one partial per wave (256*G pixels of one sample).
-// 20 B per element: read loc, raw, x; write dloc, draw.
+// Gaussian head, streaming form.  h is pixel-interleaved ([pixel][loc_0..loc_C-1 | raw_0..raw_C-1]),
+// so the lane that owns a pixel needs 2C consecutive floats: loading them per lane (96-byte
+// lane stride at C = 3) touches every 128-byte line from several wave-instructions and thrashes
+// the 32 KB L1 (measured 4.2 TB/s).  Instead a wave moves its 256*G pixels with lane-linear
+// 16-byte loads (every line requested once), transposes through a wave-private LDS image so that
+// each lane ends up with whole groups of 4 pixels, and sends the gradients back the same way.
+// No workgroup barrier (wave-private LDS, in-order DS pipe); one partial per wave.  20 B/element.
 template <int C, int G, int SP1>
 __global__ __launch_bounds__(256) void elbo_gaussian_stream_kernel(
     const float4* __restrict__ h, const float4* __restrict__ x, float* __restrict__ llk_part,
     float4* __restrict__ dh, const float* __restrict__ scale, size_t n_waves) {
+  constexpr int NH = 2 * C * G, NX = C * G;  // float4 per lane
+  __shared__ float4 lds[4][(NH + NX) * 64];
   const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= n_waves) return;
   const int lane = threadIdx.x & 63;
-  float hv[G][8 * C], xv[G][4 * C];
+  float4* hs = lds[threadIdx.x >> 6];
+  float4* xs = hs + NH * 64;
+  const size_t bh = w * (size_t)(NH * 64), bx = w * (size_t)(NX * 64);
+  float4 hv[NH], xv[NX];
 #pragma unroll
-  for (int q = 0; q < G; ++q) {
-    const size_t grp = (w * G + q) * 64 + lane;  // group of 4 pixels
+  for (int j = 0; j < NH; ++j) hv[j] = h[bh + j * 64 + lane];
 #pragma unroll
-    for (int j = 0; j < 2 * C; ++j) {
-      const float4 v = h[grp * (2 * C) + j];
-      hv[q][4 * j] = v.x; hv[q][4 * j + 1] = v.y; hv[q][4 * j + 2] = v.z; hv[q][4 * j + 3] = v.w;
-    }
-  }
+  for (int j = 0; j < NX; ++j) xv[j] = x[bx + j * 64 + lane];
 #pragma unroll
-  for (int q = 0; q < G; ++q) {
-    const size_t grp = (w * G + q) * 64 + lane;
+  for (int j = 0; j < NH; ++j) hs[j * 64 + lane] = hv[j];
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-      const float4 v = x[grp * C + j];
-      xv[q][4 * j] = v.x; xv[q][4 * j + 1] = v.y; xv[q][4 * j + 2] = v.z; xv[q][4 * j + 3] = v.w;
-    }
-  }
+  for (int j = 0; j < NX; ++j) xs[j * 64 + lane] = xv[j];
+  odin_wave_sync();
   const float sc = scale[0];
   float acc = 0.f;
+  float4 o[NH];
 #pragma unroll
   for (int q = 0; q < G; ++q) {
-    float o[8 * C];
+    // group q of this lane: 4 pixels = float4 [2C*(q*64+lane), +2C) of the h image
+    float hf[8 * C], xf[4 * C];
+#pragma unroll
+    for (int j = 0; j < 2 * C; ++j) {
+      const float4 v = hs[(q * 64 + lane) * 2 * C + j];
+      hf[4 * j] = v.x; hf[4 * j + 1] = v.y; hf[4 * j + 2] = v.z; hf[4 * j + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      const float4 v = xs[(q * 64 + lane) * C + j];
+      xf[4 * j] = v.x; xf[4 * j + 1] = v.y; xf[4 * j + 2] = v.z; xf[4 * j + 3] = v.w;
+    }
+    float of[8 * C];
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        const float loc = hv[q][pp * 2 * C + c], raw = hv[q][pp * 2 * C + C + c];
-        const float t = xv[q][pp * C + c];
+        const float loc = hf[pp * 2 * C + c], raw = hf[pp * 2 * C + C + c];
+        const float t = xf[pp * C + c];
         float sd, dsd;
         if (SP1) {
           // softplus1(raw) = softplus(raw + softplus^-1(1)); its derivative = sigmoid(same)
@@ -253,15 +265,22 @@ __global__ __launch_bounds__(256) void elbo_gaussian_stream_kernel(
         const float inv = 1.f / sd;
         const float d = (t - loc) * inv;
         acc += -0.5f * d * d - 0.6931471805599453f * odin_log2(sd) - 0.5f * LOG2PI_F;
-        o[pp * 2 * C + c] = -(d * inv) * sc;
-        o[pp * 2 * C + C + c] = -((d * d - 1.f) * inv) * dsd * sc;
+        of[pp * 2 * C + c] = -(d * inv) * sc;
+        of[pp * 2 * C + C + c] = -((d * d - 1.f) * inv) * dsd * sc;
       }
     }
-    const size_t grp = (w * G + q) * 64 + lane;
 #pragma unroll
     for (int j = 0; j < 2 * C; ++j)
-      dh[grp * (2 * C) + j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+      o[q * 2 * C + j] = make_float4(of[4 * j], of[4 * j + 1], of[4 * j + 2], of[4 * j + 3]);
   }
+  odin_wave_sync();  // every lane has read its pixels: the image can be overwritten
+#pragma unroll
+  for (int q = 0; q < G; ++q)
+#pragma unroll
+    for (int j = 0; j < 2 * C; ++j) hs[(q * 64 + lane) * 2 * C + j] = o[q * 2 * C + j];
+  odin_wave_sync();
+#pragma unroll
+  for (int j = 0; j < NH; ++j) dh[bh + j * 64 + lane] = hs[j * 64 + lane];
   acc = wave_sum64(acc);
   if (lane == 0) llk_part[w] = acc;
 }

@@ -314,5 +314,22 @@ def test_full_batch_gradients_vs_f64_autograd(dev, L, monkeypatch, name, spec, B
     if e > worst[1]:
       worst = (k, e)
   print(name, f"loss {rep['loss']:.2e} llk {rep['llk']:.2e} kl {rep['kl']:.2e} worst grad {worst}")
+  gtol = 1e-4
+  if 'tc_beta' in kw:
+    # The minibatch TC estimator is ILL-CONDITIONED in (loc, scale, z) at random initialisation
+    # (posterior scales down to 4e-3 beside locations of order 1-7): perturbing the float64
+    # oracle's own inputs by the fp32 rounding of p (<= 1e-5 absolute) moves its TC gradients by
+    # 2-3e-4 of their maximum (measured: profiles/r02_tc_conditioning.txt).  Any fp32 evaluation
+    # -- the TF reference included -- sits that far from float64.  So (a) the TC kernels are
+    # held to 1e-5 against the oracle evaluated on the ENGINE's own (p, z), and (b) the
+    # end-to-end gradients, which inherit the conditioning, to 1e-3.
+    pz = eng.p.cpu().numpy().astype(np.float64), eng.z.cpu().numpy().astype(np.float64)
+    loc, sc = vo.mvn_diag_params(pz[0], zdim)
+    c = kw['tc_beta'] - 1.0
+    for got, want in zip((eng.tc_dz, eng.tc_dloc, eng.tc_dscale),
+                         vo.total_correlation_bwd(pz[1], loc, sc)):
+      assert relerr(got.cpu().numpy(), c * want) <= 1e-5
+    assert abs(eng.tc_ws[0].item() - vo.total_correlation(pz[1], loc, sc)) <= 1e-5 * 300
+    gtol = 1e-3
   for k, v in rep.items():
-    assert v <= 1e-4, (k, v)
+    assert v <= (gtol if k.startswith('grad') else 1e-4), (k, v)

@@ -12,6 +12,6 @@ for f in files:
            r.get('VGPR_Count', '?'), r.get('Accum_VGPR_Count', '?'), r.get('SGPR_Count', '?'), r.get('Scratch_Size', '?'))
     rows[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 tot = sum(sum(v) for v in rows.values())
-print(f'{"kernel":60s} {"grid":>8s} {"lds":>7s} {"vgpr":>5s} {"agpr":>5s} {"sgpr":>5s} {"scr":>5s} {"n":>6s} {"avg_us":>9s} {"total_us":>10s} {"%":>5s}')
+print(f'{"kernel":100s} {"grid":>8s} {"lds":>7s} {"vgpr":>5s} {"agpr":>5s} {"sgpr":>5s} {"scr":>5s} {"n":>6s} {"avg_us":>9s} {"total_us":>10s} {"%":>5s}')
 for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
-  print(f'{k[0][:60]:60s} {k[1]:>8s} {k[2]:>7s} {k[3]:>5s} {k[4]:>5s} {k[5]:>5s} {k[6]:>5s} {len(v):6d} {sum(v)/len(v):9.2f} {sum(v):10.1f} {100*sum(v)/tot:5.1f}')
+  print(f'{k[0][:100]:100s} {k[1]:>8s} {k[2]:>7s} {k[3]:>5s} {k[4]:>5s} {k[5]:>5s} {k[6]:>5s} {len(v):6d} {sum(v)/len(v):9.2f} {sum(v):10.1f} {100*sum(v)/tot:5.1f}')
