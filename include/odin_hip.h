@@ -108,7 +108,8 @@ int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* stream);
 /* ---- latent posterior q(z|x) = MVNDiag(loc, softplus(raw))
  * MultivariateNormalLayer.new (odin/bay/layers/continuous.py:459-483), sample =
  * loc + scale*eps, KL: kl_divergence (odin/bay/helpers.py:177-282): analytic=0 -> MC
- * log q(z) - log p(z) at the same z; analytic=1 -> closed form; free_bits<0 = disabled,
+ * log q(z) - log p(z) at the same z; analytic=1 -> closed form KL(q||p); analytic=2 -> closed
+ * form KL(p||q) (`reverse=False`, helpers.py:261-262); free_bits<0 = disabled,
  * else max(kl, free_bits*D).   p [B,2D], eps [B,D] -> z [B,D], kl [B] (after free bits),
  * fbmask [B] (1 where the gradient flows). */
 int odin_latent_fwd(const float* p, const float* eps, float* z, float* kl, float* fbmask, int B,
@@ -170,6 +171,37 @@ int odin_dtc_loss_fwd_bwd(const float* logit_z, const float* logit_perm, float* 
 int odin_adam_step_flat(float* theta, const float* g, float* m, float* v, size_t n,
                         const float* hyper, const float* gnorm2, float clip, int32_t* flag,
                         void* stream);
+/* ---- VariationalAutoencoder.marginal_log_prob (variational_autoencoder.py:396-513):
+ * n posterior samples per input from one encoder pass: z[k,b,:] = loc_b + softplus(raw_b)*eps[k,b,:],
+ * logq[k,b] = log q(z_kb | x_b), logp[k,b] = log N(z_kb; 0, I)   (p: [B,2D], eps/z: [n,B,D]);
+ * odin_logmeanexp_rows: out[b] = logsumexp_k in[k,b] - log n  (tf.reduce_logsumexp(axis=0) - C). */
+int odin_latent_sample_logprob(const float* p, const float* eps, float* z, float* logq,
+                               float* logp, int n, int B, int D, void* stream);
+int odin_logmeanexp_rows(const float* in, float* out, int n, int B, void* stream);
+/* out[b] = sum_j llk_part[b*n_part + j]: the per-sample log p(x|z) from the partial sums the
+ * fused observation kernels write (Distribution.log_prob, variational_autoencoder.py:530) */
+int odin_sum_parts(const float* llk_part, int n_part, float* out, int B, void* stream);
+
+/* ---- gradient policies of Networks.optimize (odin/networks/base_networks.py:549-596), applied
+ * to the flat gradient buffer between the backward pass and the Adam launch, in this order:
+ *  odin_grad_skip_threshold : `skip_update_threshold` (:549-578) -- if ANY gradient element is
+ *      >= threshold (and enable[0] != 0, = `step >= when_skip_update`), every gradient of the
+ *      step becomes 0 (the reference forms g - g) and skipped_count[0] += 1; the optimiser still
+ *      runs (momentum-only update), exactly like apply_gradients on the zeroed list.
+ *      hit: DEVICE int scratch (1 = threshold reached), enable / skipped_count may be NULL.
+ *  odin_clip_by_norm_segments : `clipnorm` (:579-583), tf.clip_by_norm per variable; seg_offsets
+ *      (DEVICE, n_segments + 1 int64) delimit the variables inside the flat buffer.
+ *  odin_clip_by_value : `clipvalue` (:592-596), tf.clip_by_value(g, -c, c).  The reference clips
+ *      by global norm BEFORE by value (:584-591): when both are requested pass the DEVICE scalar
+ *      gnorm2 = sum g^2 (odin_sumsq_flat) and global_clipnorm, and the kernel first scales g by
+ *      global_clipnorm / max(sqrt(gnorm2), global_clipnorm); gnorm2 = NULL: value clip only. */
+int odin_grad_skip_threshold(float* g, size_t n, float threshold, const int32_t* enable,
+                             int32_t* hit, int32_t* skipped_count, void* stream);
+int odin_clip_by_norm_segments(float* g, const int64_t* seg_offsets, int n_segments, float clipnorm,
+                               void* stream);
+int odin_clip_by_value(float* g, size_t n, float clipvalue, const float* gnorm2,
+                       float global_clipnorm, void* stream);
+
 /* out[0] = sum g^2 (deterministic two-stage); workspace >= 1024 floats */
 int odin_sumsq_flat(const float* g, size_t n, float* workspace, float* out, void* stream);
 /* odin_sumsq_flat + odin_adam_step_flat in two launches instead of three: the Adam launch sums

@@ -62,6 +62,12 @@ SIGNATURES = {
     'odin_dtc_loss_fwd_bwd': [P, P, P, P, P, I, P],
     'odin_adam_step_flat': [P, P, P, P, C.c_size_t, P, P, F, P, P],
     'odin_sumsq_flat': [P, C.c_size_t, P, P, P],
+    'odin_latent_sample_logprob': [P, P, P, P, P, I, I, I, P],
+    'odin_logmeanexp_rows': [P, P, I, I, P],
+    'odin_sum_parts': [P, I, P, I, P],
+    'odin_grad_skip_threshold': [P, C.c_size_t, F, P, P, P, P],
+    'odin_clip_by_norm_segments': [P, P, I, F, P],
+    'odin_clip_by_value': [P, C.c_size_t, F, P, F, P],
     'odin_sumsq_adam_flat': [P, P, P, P, C.c_size_t, P, P, P, F, P, P],
     'odin_rng_normal': [P, C.c_size_t, C.c_uint64, P, P],
     'odin_gather_normalize_u8': [P, P, P, I, I, F, I, P],

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* p, const f
     float zz = loc + sc * e;
     z[(size_t)b * D + d] = zz;
     float ls = odin_log(sc);
-    if (analytic) acc += 0.5f * (sc * sc + loc * loc - 1.f) - ls;
+    if (analytic == 2) acc += ls + 0.5f * (1.f + loc * loc) / (sc * sc) - 0.5f;  // KL(p || q), reverse=False
+    else if (analytic) acc += 0.5f * (sc * sc + loc * loc - 1.f) - ls;
     else acc += 0.5f * (zz * zz - e * e) - ls;
   }
   float m = 1.f;
@@ -74,7 +75,11 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* p, const f
   float loc = pb[d], raw = pb[D + d], sc = softplus_f(raw), e = eps[i], zz = z[i];
   float w = klw[0] * fbmask[b];
   float dloc, dsc;
-  if (analytic) { dloc = w * loc; dsc = w * (sc - 1.f / sc); }
+  if (analytic == 2) {
+    const float i2 = 1.f / (sc * sc);
+    dloc = w * loc * i2;
+    dsc = w * (1.f / sc - (1.f + loc * loc) * i2 / sc);
+  } else if (analytic) { dloc = w * loc; dsc = w * (sc - 1.f / sc); }
   else { dloc = w * zz; dsc = w * (zz * e - 1.f / sc); }
   if (dz != nullptr) { float g = dz[i]; dloc += g; dsc += g * e; }
   if (dz2 != nullptr) { float g = dz2[i]; dloc += g; dsc += g * e; }
@@ -436,6 +441,112 @@ __global__ __launch_bounds__(256) void rng_normal_kernel(float* out, size_t n, u
   }
 }
 
+
+
+// ------------------------------------------------------------------ marginal_log_prob --
+// VariationalAutoencoder.marginal_log_prob (variational_autoencoder.py:396-513): n samples
+// z_k ~ q(z|x) per input, log q(z_k|x), log p(z_k); log-mean-exp over k on device.
+__global__ __launch_bounds__(256) void latent_sample_logprob_kernel(
+    const float* __restrict__ p, const float* __restrict__ eps, float* __restrict__ z,
+    float* __restrict__ logq, float* __restrict__ logp, int n, int B, int D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;  // (k, b)
+  if (i >= n * B) return;
+  const int b = i % B;
+  const float* pb = p + (size_t)b * 2 * D;
+  float lq = 0.f, lp = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float loc = pb[d], sc = softplus_f(pb[D + d]), e = eps[(size_t)i * D + d];
+    const float zz = loc + sc * e;
+    z[(size_t)i * D + d] = zz;
+    lq += -0.5f * e * e - odin_log(sc);
+    lp += -0.5f * zz * zz;
+  }
+  const float c = 0.5f * LOG2PI_F * (float)D;
+  logq[i] = lq - c;
+  logp[i] = lp - c;
+}
+
+// out[b] = sum_j part[b * n_part + j]  (per-sample log-likelihood from the ELBO kernels' partials)
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, int n_part,
+                                                        float* __restrict__ out, int B) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float t = 0.f;
+  for (int j = 0; j < n_part; ++j) t += part[(size_t)b * n_part + j];
+  out[b] = t;
+}
+
+// out[b] = log sum_k exp(in[k][b]) - log n   (column-wise, rows of B contiguous floats)
+__global__ __launch_bounds__(256) void logmeanexp_rows_kernel(const float* __restrict__ in,
+                                                              float* __restrict__ out, int n, int B) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float mx = -3.0e38f;
+  for (int k = 0; k < n; ++k) mx = fmaxf(mx, in[(size_t)k * B + b]);
+  float s = 0.f;
+  for (int k = 0; k < n; ++k) s += expf(in[(size_t)k * B + b] - mx);
+  out[b] = mx + logf(s) - logf((float)n);
+}
+
+// ------------------------------------------------------------------ gradient policies --
+// Networks.optimize between tape.gradient and apply_gradients (odin/networks/base_networks.py:
+// 549-596), on the flat gradient buffer, in the reference's order: skip_update_threshold (any
+// element >= threshold zeroes EVERY gradient of the step; Adam still runs on the zeros) ->
+// per-tensor tf.clip_by_norm -> [tf.clip_by_global_norm: odin_sumsq_adam_flat] ->
+// tf.clip_by_value.
+__global__ __launch_bounds__(256) void grad_any_ge_kernel(const float* __restrict__ g, size_t n,
+                                                          float thr, int* __restrict__ hit) {
+  int h = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    h |= (g[i] >= thr) ? 1 : 0;
+  // an integer OR: order-independent, so the atomic keeps the step reproducible
+  if (h) atomicOr(hit, 1);
+}
+
+__global__ __launch_bounds__(256) void grad_zero_if_kernel(float* __restrict__ g, size_t n,
+                                                           const int* __restrict__ hit,
+                                                           const int* __restrict__ enable,
+                                                           int* __restrict__ skipped) {
+  if (hit[0] == 0 || (enable != nullptr && enable[0] == 0)) return;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    g[i] = 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && skipped != nullptr) skipped[0] += 1;
+}
+
+// one workgroup per tensor: ||g||_2 in a fixed order, then g *= clip / max(||g||, clip)
+__global__ __launch_bounds__(1024) void clip_by_norm_segments_kernel(float* __restrict__ g,
+                                                                     const long long* __restrict__ seg,
+                                                                     float clip) {
+  __shared__ float red[16];
+  __shared__ float sc_sh;
+  const long long a = seg[blockIdx.x], b = seg[blockIdx.x + 1];
+  float acc = 0.f;
+  for (long long i = a + threadIdx.x; i < b; i += 1024) acc += g[i] * g[i];
+  acc = wave_sum64(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    sc_sh = clip / fmaxf(sqrtf(t), clip);
+  }
+  __syncthreads();
+  const float sc = sc_sh;
+  if (sc == 1.f) return;
+  for (long long i = a + threadIdx.x; i < b; i += 1024) g[i] *= sc;
+}
+
+// g = clip_by_value(g * global_scale, -c, c); global_scale = gclip / max(sqrt(gnorm2), gclip) when
+// a global-norm clip precedes the value clip (the reference's order), 1 otherwise
+__global__ __launch_bounds__(256) void clip_by_value_kernel(float* __restrict__ g, size_t n, float c,
+                                                            const float* __restrict__ gnorm2,
+                                                            float gclip) {
+  float gs = 1.f;
+  if (gnorm2 != nullptr && gclip > 0.f) gs = gclip / fmaxf(sqrtf(gnorm2[0]), gclip);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    g[i] = fminf(fmaxf(g[i] * gs, -c), c);
+}
+
 inline int grid_for(size_t work_items, int per_block, int cap) {
   size_t g = (work_items + per_block - 1) / per_block;
   if (g > (size_t)cap) g = cap;
@@ -550,6 +661,53 @@ extern "C" int odin_adam_step_flat(float* theta, const float* g, float* m, float
   ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper, gnorm2,
               clip, (int*)flag, (const float*)nullptr, 0, (float*)nullptr);
   return odin_check_launch("adam");
+}
+
+
+
+extern "C" int odin_latent_sample_logprob(const float* p, const float* eps, float* z, float* logq,
+                                          float* logp, int n, int B, int D, void* stream) {
+  ODIN_LAUNCH(latent_sample_logprob_kernel, dim3((n * B + 255) / 256), dim3(256), 0, stream, p, eps,
+              z, logq, logp, n, B, D);
+  return odin_check_launch("latent_sample_logprob");
+}
+
+extern "C" int odin_sum_parts(const float* part, int n_part, float* out, int B, void* stream) {
+  ODIN_LAUNCH(sum_parts_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, part, n_part, out, B);
+  return odin_check_launch("sum_parts");
+}
+
+extern "C" int odin_logmeanexp_rows(const float* in, float* out, int n, int B, void* stream) {
+  ODIN_LAUNCH(logmeanexp_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, in, out, n, B);
+  return odin_check_launch("logmeanexp_rows");
+}
+
+extern "C" int odin_grad_skip_threshold(float* g, size_t n, float threshold, const int32_t* enable,
+                                        int32_t* hit, int32_t* skipped_count, void* stream) {
+  if (hipMemsetAsync(hit, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
+    return odin_fail(-3, "grad_skip_threshold: memset failed");
+  int grid = grid_for(n, 256 * 4, 2048);
+  ODIN_LAUNCH(grad_any_ge_kernel, dim3(grid), dim3(256), 0, stream, (const float*)g, n, threshold,
+              (int*)hit);
+  ODIN_LAUNCH(grad_zero_if_kernel, dim3(grid), dim3(256), 0, stream, g, n, (const int*)hit,
+              (const int*)enable, (int*)skipped_count);
+  return odin_check_launch("grad_skip_threshold");
+}
+
+extern "C" int odin_clip_by_norm_segments(float* g, const int64_t* seg_offsets, int n_segments,
+                                          float clipnorm, void* stream) {
+  if (n_segments <= 0) return 0;
+  ODIN_LAUNCH(clip_by_norm_segments_kernel, dim3(n_segments), dim3(1024), 0, stream, g,
+              (const long long*)seg_offsets, clipnorm);
+  return odin_check_launch("clip_by_norm_segments");
+}
+
+extern "C" int odin_clip_by_value(float* g, size_t n, float clipvalue, const float* gnorm2,
+                                  float global_clipnorm, void* stream) {
+  int grid = grid_for(n, 256 * 4, 2048);
+  ODIN_LAUNCH(clip_by_value_kernel, dim3(grid), dim3(256), 0, stream, g, n, clipvalue, gnorm2,
+              global_clipnorm);
+  return odin_check_launch("clip_by_value");
 }
 
 extern "C" int odin_sumsq_adam_flat(float* theta, const float* g, float* m, float* v, size_t n,

@@ -301,12 +301,15 @@ class VAEEngine:
                observation='bernoulli', analytic=False, free_bits=None, tc=None, lib=None,
                params: Optional[torch.Tensor] = None, world_size: int = 1, seed: int = 1,
                optim_state: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-               force_dp: bool = False):
+               force_dp: bool = False, reverse: bool = True):
     self.lib = lib if lib is not None else _lib.load()
     self.device = torch.device(device)
     self.B, self.D = int(batch_size), int(zdim)
     self.in_shape = tuple(in_shape)
-    self.observation, self.analytic = observation, bool(analytic)
+    # KL form handed to the latent kernels: 0 = Monte-Carlo, 1 = closed-form KL(q||p),
+    # 2 = closed-form KL(p||q) (`reverse=False`, odin/bay/helpers.py:261-265)
+    self.observation = observation
+    self.set_kl_form(analytic, reverse)
     self.free_bits = -1.0 if free_bits is None else float(free_bits)
     self.tc_mode, self.world_size, self.seed = tc, int(world_size), int(seed)
     # data-parallel step (gradient-bucket all-reduce between backward and Adam); `force_dp` runs
@@ -380,6 +383,11 @@ class VAEEngine:
     self.ws = torch.empty(1024, **f32)
     self.gnorm2 = torch.zeros(1, **f32)
     self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+    # Networks.optimize gradient policies (skip_update_threshold / clipnorm / clipvalue)
+    self.skip_hit = torch.zeros(1, dtype=torch.int32, device=self.device)
+    self.skipped_update = torch.zeros(1, dtype=torch.int32, device=self.device)
+    offs = [o for _, _, o in self.layout.entries] + [self.n_params_end()]
+    self.seg_offsets = torch.tensor(offs, dtype=torch.int64, device=self.device)
     # hyper-parameters that change per step live in device memory (graph replays)
     # ring of pinned staging buffers: the async H2D copy of step t may still be pending
     # when the host prepares step t+1
@@ -403,6 +411,18 @@ class VAEEngine:
         _os.environ.get('ODIN_OVERLAP_WGRAD', 'small'), None)
     self.graph = None
     self._jobs_keepalive = None
+
+  def set_kl_form(self, analytic, reverse=True):
+    if not reverse and not analytic:
+      # the reference cannot evaluate this combination either: after swapping the arguments it
+      # calls tf.convert_to_tensor on the prior (helpers.py:267-276 with q_sample=None)
+      raise TypeError('reverse=False needs analytic=True: the Monte-Carlo form would draw the '
+                      'cached sample from the prior, which has none')
+    self.analytic = 2 if not reverse else int(bool(analytic))
+
+  def n_params_end(self) -> int:
+    k, shp, off = self.layout.entries[-1]
+    return off + int(np.prod(shp))
 
   def _plan_fused_tail(self, f32):
     """Training-step fusion layer[-2](act) -> Conv2D 1x1 -> Bernoulli log-prob + backward
@@ -456,7 +476,8 @@ class VAEEngine:
       views[k].copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32).to(self.device))
 
   def set_hyper(self, lr=1e-3, beta=1.0, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0,
-                t: Optional[int] = None, tc_coef: Optional[float] = None):
+                t: Optional[int] = None, tc_coef: Optional[float] = None,
+                skip_enable: bool = True, extra: Optional[Sequence[float]] = None):
     """Host scalars -> device (one small async H2D copy)."""
     t = self.step_count if t is None else t
     tt = max(int(t), 1)
@@ -474,7 +495,11 @@ class VAEEngine:
     h[H_TCGRAD] = (beta - 1.0) / self.world_size if self.tc_mode == 'betatc' else 0.0
     if tc_coef is not None:  # FactorVAE: tc term = tc_coef * mean(D(z))
       h[H_TCCOEF] = tc_coef
+    if extra is not None:  # second optimiser's Adam block (FactorVAE discriminator), slots 10..14
+      for i, val in enumerate(extra):
+        h[10 + i] = float(val)
     h[N_HYPER:].view(torch.int32)[0] = int(t)
+    h[N_HYPER:].view(torch.int32)[1] = int(skip_enable)
     self.hyper.copy_(h, non_blocking=True)
     if self.device.type == 'cuda':
       ev = torch.cuda.Event()
@@ -506,6 +531,26 @@ class VAEEngine:
     st = self.stream() if st is None else st
     assert z.shape == (self.B, self.D) and z.is_contiguous()
     return self.dec.forward(z, st)
+
+  def observation_llk(self, h_d: torch.Tensor, x: torch.Tensor, out: torch.Tensor, st=None):
+    """out[b] = log p(x_b | decoder output h_d_b) through the fused observation kernel (its
+    gradient output lands in the decoder's gradient buffer and is ignored)."""
+    lib, B = self.lib, self.B
+    st = self.stream() if st is None else st
+    npart = C.c_int(0)
+    gl = self.dec.gouts[-1]
+    if self.observation == 'bernoulli':
+      lib.odin_elbo_bernoulli_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
+                                      gl.data_ptr(), self.hp(H_INVB), B, self.n_per,
+                                      C.byref(npart), st)
+    else:
+      Cc = self.in_shape[-1]
+      lib.odin_elbo_gaussian_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
+                                     gl.data_ptr(), self.hp(H_INVB), B, self.n_per // Cc, Cc,
+                                     int(self.observation == 'gaussian_softplus1'),
+                                     C.byref(npart), st)
+    lib.odin_sum_parts(self.llk_part.data_ptr(), npart.value, out.data_ptr(), B, st)
+    return out
 
   # ---- forward -----------------------------------------------------------------------
   def forward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, st=None,
@@ -675,9 +720,39 @@ class VAEEngine:
     lib.odin_slab_reduce(arr, len(jobs), st)
 
   # ---- optimiser ---------------------------------------------------------------------
-  def adam(self, st=None, global_clipnorm: Optional[float] = None, check_nan: bool = True):
+  def grad_policies(self, st=None, clipnorm: Optional[float] = None,
+                    skip_update_threshold: Optional[float] = None):
+    """skip_update_threshold, then per-variable clip_by_norm (base_networks.py:549-583), on the
+    flat (already all-reduced) gradient buffer.  `step >= when_skip_update` is the device flag
+    written by set_hyper(skip_enable=...)."""
     lib = self.lib
     st = self.stream() if st is None else st
+    if skip_update_threshold is not None:
+      lib.odin_grad_skip_threshold(self.grads.data_ptr(), self.grads.numel(),
+                                   float(skip_update_threshold), self.hp(N_HYPER + 1),
+                                   self.skip_hit.data_ptr(), self.skipped_update.data_ptr(), st)
+    if clipnorm is not None:
+      lib.odin_clip_by_norm_segments(self.grads.data_ptr(), self.seg_offsets.data_ptr(),
+                                     self.seg_offsets.numel() - 1, float(clipnorm), st)
+
+  def adam(self, st=None, global_clipnorm: Optional[float] = None, check_nan: bool = True,
+           clipvalue: Optional[float] = None):
+    lib = self.lib
+    st = self.stream() if st is None else st
+    if clipvalue is not None:
+      # reference order: clip_by_global_norm, THEN clip_by_value (base_networks.py:584-596): the
+      # norm is taken first, one elementwise launch scales and clamps, Adam runs unscaled (its
+      # NaN guard still reads the norm)
+      lib.odin_sumsq_flat(self.grads.data_ptr(), self.grads.numel(), self.ws.data_ptr(),
+                          self.gnorm2.data_ptr(), st)
+      lib.odin_clip_by_value(self.grads.data_ptr(), self.grads.numel(), float(clipvalue),
+                             self.gnorm2.data_ptr() if global_clipnorm else None,
+                             float(global_clipnorm or 0.0), st)
+      lib.odin_adam_step_flat(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
+                              self.v.data_ptr(), self.params.numel(), self.hp(H_ALPHA),
+                              self.gnorm2.data_ptr() if check_nan else None, 0.0,
+                              self.flag.data_ptr(), st)
+      return
     if global_clipnorm is not None or check_nan:
       # gradient norm (clip scale, NaN guard) + update: stage-1 partial sums, then ONE launch that
       # finishes the norm and applies Adam
@@ -697,21 +772,29 @@ class VAEEngine:
 
   # ---- one optimisation step ---------------------------------------------------------
   def train_step(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, lr=1e-3, beta=1.0,
-                 global_clipnorm: Optional[float] = None, use_graph: bool = False):
-    """Networks.optimize for one VAEStep: step += 1, forward, backward, (all-reduce), Adam.
-    Returns the device tensor out4 = [loss, mean llk, mean beta*kl, tc] (no host sync)."""
+                 global_clipnorm: Optional[float] = None, use_graph: bool = False,
+                 clipnorm: Optional[float] = None, clipvalue: Optional[float] = None,
+                 skip_update_threshold: Optional[float] = None, when_skip_update: int = 0,
+                 check_nan: bool = True):
+    """Networks.optimize for one VAEStep: step += 1, forward, backward, (all-reduce), gradient
+    policies, Adam.  Returns the device tensor out4 = [loss, mean llk, mean beta*kl, tc] (no host
+    sync)."""
     self.step_count += 1
-    self.set_hyper(lr=lr, beta=beta)
-    if use_graph and self.device.type == 'cuda' and not self.is_dp:
-      self._graph_step(x, eps, global_clipnorm)
-    elif use_graph and self.device.type == 'cuda':
-      self._graph_step_dp(x, eps, global_clipnorm)
+    self.set_hyper(lr=lr, beta=beta, skip_enable=self.step_count >= int(when_skip_update))
+    pol = (global_clipnorm, clipnorm, clipvalue, skip_update_threshold, bool(check_nan))
+    if use_graph and self.device.type == 'cuda':
+      self._graph_step(x, eps, pol)
     else:
       self.forward(x, eps)
       self.backward()
       self.allreduce()
-      self.adam(global_clipnorm=global_clipnorm)
+      self._update(pol)
     return self.out4
+
+  def _update(self, pol):
+    gclip, clipnorm, clipvalue, skip_thr, check_nan = pol
+    self.grad_policies(clipnorm=clipnorm, skip_update_threshold=skip_thr)
+    self.adam(global_clipnorm=gclip, clipvalue=clipvalue, check_nan=check_nan)
 
   def input_buffer(self) -> torch.Tensor:
     """The static [B, H, W, C] input tensor the captured step graph reads.  A data pipeline that
@@ -721,11 +804,18 @@ class VAEEngine:
       self.x_static = torch.empty((self.B,) + self.in_shape, dtype=torch.float32, device=self.device)
     return self.x_static
 
-  def _graph_step(self, x, eps, global_clipnorm):
-    """Capture forward+backward+Adam once into a HIP graph, replay afterwards.  The input
-    batch is copied into a static buffer; eps comes from the on-device Philox stream
-    unless given explicitly."""
-    if self.graph is None:
+  def _graph_step(self, x, eps, pol):
+    """Capture the step once into HIP graphs, replay afterwards.  Single GPU: ONE graph
+    (forward + backward + slab reduction + policies + Adam).  Data parallel: graph A = forward +
+    backward + slab reduction, then ONE RCCL all-reduce of the flat gradient bucket (eager, on the
+    same stream), then graph B = policies + Adam.  The input batch is read from a static buffer;
+    eps comes from the on-device Philox stream unless given explicitly.  Everything a capture
+    bakes in (clip values, KL form, free bits, explicit-eps mode) is part of the graph's key:
+    changing any of them captures a new graph instead of silently replaying the old one."""
+    key = (pol, self.analytic, self.free_bits, eps is not None)
+    if not hasattr(self, '_graphs'):
+      self._graphs = {}
+    if key not in self._graphs:
       self.input_buffer()
       if x.data_ptr() != self.x_static.data_ptr():
         self.x_static.copy_(x)
@@ -734,57 +824,36 @@ class VAEEngine:
       # warm-up outside capture (first-call attribute setup, lazy allocations)
       cap = torch.cuda.Stream(self.device)
       cap.wait_stream(torch.cuda.current_stream(self.device))
-      saved = (self.params.clone(), self.m.clone(), self.v.clone())
+      saved = (self.params.clone(), self.m.clone(), self.v.clone(), self.flag.clone(),
+               self.skipped_update.clone())
+      ex = eps is not None
       with torch.cuda.stream(cap):
-        self.forward(self.x_static, None if eps is None else self.eps)
+        self.forward(self.x_static, self.eps if ex else None)
         self.backward()
-        self.adam(global_clipnorm=global_clipnorm)
+        self._update(pol)
         # the warm-up step must not count: restore the optimiser state it touched
         self.params.copy_(saved[0]); self.m.copy_(saved[1]); self.v.copy_(saved[2])
+        self.flag.copy_(saved[3]); self.skipped_update.copy_(saved[4])
       torch.cuda.current_stream(self.device).wait_stream(cap)
-      self._graph_eps_explicit = eps is not None
-      g = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
-        self.forward(self.x_static, self.eps if self._graph_eps_explicit else None)
-        self.backward()
-        self.adam(global_clipnorm=global_clipnorm)
-      self.graph = g
-    if x.data_ptr() != self.x_static.data_ptr():  # a producer may write the static buffer directly
-      self.x_static.copy_(x, non_blocking=True)
-    if eps is not None:
-      self.eps.copy_(eps, non_blocking=True)
-    self.graph.replay()
-
-  def _graph_step_dp(self, x, eps, global_clipnorm):
-    """Data-parallel variant: graph A = forward + backward + slab reduction, then ONE RCCL
-    all-reduce of the flat gradient bucket (eager, on the same stream), then graph B = Adam."""
-    if self.graph is None:
-      self.input_buffer()
-      if x.data_ptr() != self.x_static.data_ptr():
-        self.x_static.copy_(x)
-      if eps is not None:
-        self.eps.copy_(eps)
-      cap = torch.cuda.Stream(self.device)
-      cap.wait_stream(torch.cuda.current_stream(self.device))
-      saved = (self.params.clone(), self.m.clone(), self.v.clone())
-      with torch.cuda.stream(cap):
-        self.forward(self.x_static, None if eps is None else self.eps)
-        self.backward()
-        self.adam(global_clipnorm=global_clipnorm)
-        self.params.copy_(saved[0]); self.m.copy_(saved[1]); self.v.copy_(saved[2])
-      torch.cuda.current_stream(self.device).wait_stream(cap)
-      self._graph_eps_explicit = eps is not None
-      ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+      ga = torch.cuda.CUDAGraph()
+      gb = None
       with torch.cuda.graph(ga, stream=cap, capture_error_mode='thread_local'):
-        self.forward(self.x_static, self.eps if self._graph_eps_explicit else None)
+        self.forward(self.x_static, self.eps if ex else None)
         self.backward()
-      with torch.cuda.graph(gb, stream=cap, capture_error_mode='thread_local'):
-        self.adam(global_clipnorm=global_clipnorm)
-      self.graph, self.graph_b = ga, gb
+        if not self.is_dp:
+          self._update(pol)
+      if self.is_dp:
+        gb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gb, stream=cap, capture_error_mode='thread_local'):
+          self._update(pol)
+      self._graphs[key] = (ga, gb)
+      self.graph = ga
+    ga, gb = self._graphs[key]
     if x.data_ptr() != self.x_static.data_ptr():  # a producer may write the static buffer directly
       self.x_static.copy_(x, non_blocking=True)
     if eps is not None:
       self.eps.copy_(eps, non_blocking=True)
-    self.graph.replay()
-    self.allreduce()
-    self.graph_b.replay()
+    ga.replay()
+    if gb is not None:
+      self.allreduce()
+      gb.replay()

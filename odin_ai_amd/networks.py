@@ -21,12 +21,23 @@ class SequentialNetwork:
   layers: List[tuple]
   name: str = 'Sequential'
   input_shape: Optional[Tuple[int, ...]] = None
+  # Keras layer names of the trainable layers, in order (image_networks.py:248-268,463-511,
+  # 678-703): they are what a TF checkpoint of the reference model calls its variables
+  layer_names: Optional[List[str]] = None
 
   def __iter__(self):
     return iter(self.layers)
 
   def __len__(self):
     return len(self.layers)
+
+
+def layer_names(net: 'SequentialNetwork', prefix: str) -> Dict[int, str]:
+  """{index into net.layers: Keras layer name} for the trainable layers."""
+  idx = [i for i, L in enumerate(net.layers) if L[0] in ('conv', 'deconv', 'dense')]
+  if net.layer_names is not None and len(net.layer_names) == len(idx):
+    return dict(zip(idx, net.layer_names))
+  return {i: f'{prefix}{j}' for j, i in enumerate(idx)}
 
 
 @dataclass
@@ -84,8 +95,11 @@ def dsprites_networks(qz='mvndiag', zdim=None, activation='elu', is_semi_supervi
   dec = [('dense', proj_dim, 'linear'), ('reshape', (4, 4, proj_dim // 16)),
          ('deconv', 64, 4, 2, a), ('deconv', 64, 4, 2, a), ('deconv', 32, 4, 2, a),
          ('deconv', 32, 4, 2, a), ('conv', n_channels * n_params, 1, 1, 'linear')]
-  return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape),
-              decoder=SequentialNetwork(dec, 'Decoder', (zdim,)), observation=observation,
+  enc_names = ['encoder0', 'encoder1', 'encoder2', 'encoder3', 'encoder_proj']
+  dec_names = ['decoder_proj', 'decoder1', 'decoder2', 'decoder3', 'decoder4', 'decoder6']
+  return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape, enc_names),
+              decoder=SequentialNetwork(dec, 'Decoder', (zdim,), dec_names),
+              observation=observation,
               latents=RVconf((zdim,), qz, projection=True, name='latents'))
 
 
@@ -115,8 +129,11 @@ def celeba_networks(qz='mvndiag', zdim=None, activation='elu', is_semi_supervise
   dec = [('dense', 512, 'linear'), ('reshape', (8, 8, 8)), ('deconv', 64, 4, 1, a),
          ('deconv', 64, 4, 2, a), ('deconv', 32, 4, 2, a), ('deconv', 32, 4, 2, a),
          ('conv', n_channels * n_params, 1, 1, 'linear')]
-  return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape),
-              decoder=SequentialNetwork(dec, 'Decoder', (zdim,)), observation=observation,
+  enc_names = ['encoder0', 'encoder1', 'encoder2', 'encoder3', 'encoder_proj']
+  dec_names = ['decoder_proj', 'decoder1', 'decoder2', 'decoder3', 'decoder4', 'decoder5']
+  return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape, enc_names),
+              decoder=SequentialNetwork(dec, 'Decoder', (zdim,), dec_names),
+              observation=observation,
               latents=RVconf((zdim,), qz, projection=True, name='latents'))
 
 
@@ -137,8 +154,11 @@ def mnist_networks(qz='mvndiag', zdim=None, activation='elu', is_semi_supervised
   dec = [('dense', 196, 'linear'), ('reshape', (7, 7, 4)), ('deconv', 64, 5, 2, a),
          ('conv', 64, 5, 1, a), ('deconv', 32, 5, 2, a), ('conv', 32, 5, 1, a),
          ('conv', n_channels * n_params, 1, 1, 'linear')]
-  return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape),
-              decoder=SequentialNetwork(dec, 'Decoder', (zdim,)), observation=observation,
+  enc_names = ['encoder0', 'encoder1', 'encoder2', 'encoder3', 'encoder_proj']
+  dec_names = ['decoder_proj', 'decoder2', 'decoder3', 'decoder4', 'decoder5', 'decoder6']
+  return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape, enc_names),
+              decoder=SequentialNetwork(dec, 'Decoder', (zdim,), dec_names),
+              observation=observation,
               latents=RVconf((zdim,), qz, projection=True, name='latents'))
 
 

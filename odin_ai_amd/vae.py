@@ -19,7 +19,6 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
-import pickle
 from dataclasses import dataclass, field
 from typing import Any, Callable, Dict, Iterator, List, Optional, Sequence, Tuple, Union
 
@@ -30,7 +29,7 @@ from . import _lib
 from .engine import (ACT, H_ALPHA, N_HYPER, NetProgram, ParamLayout, ReduceJob, VAEEngine,
                      build_layers)
 from .interpolation import Interpolation, linear
-from .networks import RVconf, SequentialNetwork, get_networks
+from .networks import RVconf, SequentialNetwork, get_networks, layer_names
 
 LOG2PI = math.log(2.0 * math.pi)
 
@@ -47,9 +46,12 @@ class KLdivergence:
   def __call__(self, analytic=False, reverse=True, free_bits=None, sample_shape=None,
                keepdims=False):
     q = self.posterior
-    if not reverse:
-      raise NotImplementedError('reverse=False (KL(p||q)) is outside the HIP path')
-    if analytic:
+    if not reverse and not analytic:
+      raise TypeError('reverse=False needs analytic=True (helpers.py:261-276: the swapped '
+                      '"posterior" is the prior, which carries no cached sample)')
+    if not reverse:  # KL(p || q), helpers.py:261-265
+      kl = (torch.log(q.scale) + 0.5 * (1.0 + q.loc ** 2) / q.scale ** 2 - 0.5).sum(-1)
+    elif analytic:
       kl = 0.5 * (q.scale ** 2 + q.loc ** 2 - 1.0 - 2.0 * torch.log(q.scale)).sum(-1)
     else:
       z = q.z
@@ -220,10 +222,12 @@ class VariationalAutoencoder:
     if latents.posterior not in ('mvndiag', 'diag', 'normaldiag'):
       raise ValueError(f"latents posterior {latents.posterior!r} is outside the HIP path "
                        f"(supported: 'mvndiag')")
-    if tuple(sample_shape) not in ((), (1,)):
-      raise NotImplementedError('sample_shape != () is outside the HIP path')
-    if not reverse:
-      raise NotImplementedError('reverse=False is outside the HIP path')
+    sample_shape = (sample_shape,) if isinstance(sample_shape, int) else tuple(sample_shape)
+    if len(sample_shape) > 1:
+      raise ValueError(f'sample_shape={sample_shape}: at most one sample axis')
+    if not reverse and not analytic:
+      raise TypeError('reverse=False needs analytic=True (the reference cannot evaluate the '
+                      'Monte-Carlo form of KL(p||q) either, helpers.py:261-276)')
     self.observation, self.latents, self.encoder, self.decoder = observation, latents, encoder, decoder
     self.analytic, self.reverse, self.free_bits = bool(analytic), bool(reverse), free_bits
     self.sample_shape, self.allow_negative_kl = tuple(sample_shape), allow_negative_kl
@@ -263,7 +267,8 @@ class VariationalAutoencoder:
     if B not in self._engines:
       eng = VAEEngine(self.encoder.layers, self.decoder.layers, self.input_shape, self.zdim, B,
                       self.device, observation=self.observation.posterior,
-                      analytic=self.analytic, free_bits=self.free_bits, tc=self._tc_mode,
+                      analytic=self.analytic, reverse=self.reverse, free_bits=self.free_bits,
+                      tc=self._tc_mode,
                       lib=self._lib, params=self._params, seed=self.seed + self._rank(),
                       optim_state=self._optim_state, world_size=self._world_size())
       if self._params is None:
@@ -327,12 +332,32 @@ class VariationalAutoencoder:
     """odin/bay/vi/_base.py:51-89"""
     if analytic is not None:
       self.analytic = bool(analytic)
+    if reverse is not None:
+      self.reverse = bool(reverse)
     if free_bits is not None:
       self.free_bits = free_bits
+    if sample_shape is not None:
+      self.sample_shape = (sample_shape,) if isinstance(sample_shape, int) else tuple(sample_shape)
     for e in self._engines.values():
-      e.analytic = self.analytic
+      e.set_kl_form(self.analytic, self.reverse)
       e.free_bits = -1.0 if self.free_bits is None else float(self.free_bits)
     return self
+
+  @property
+  def n_samples(self) -> int:
+    """prod(sample_shape): MC samples of z per input (variational_autoencoder.py:288-314)."""
+    n = 1
+    for i in self.sample_shape:
+      n *= int(i)
+    return n
+
+  def _tile(self, x: torch.Tensor) -> torch.Tensor:
+    """sample_shape = (n,): the reference draws z of shape [n, B, D] from one encoder pass and
+    decodes n*B codes; llk / kl come out as [n, B] and the loss is their overall mean.  Here
+    the batch is tiled n times (each copy gets its own noise): the same [n, B] values and the
+    same gradients, at the price of n encoder passes."""
+    n = self.n_samples
+    return x if n == 1 else x.repeat((n,) + (1,) * (x.dim() - 1))
 
   @property
   def beta(self) -> float:
@@ -377,17 +402,19 @@ class VariationalAutoencoder:
   def elbo_components(self, inputs, training=None, mask=None, eps=None, **kwargs):
     """variational_autoencoder.py:515-542.  One fused engine pass: llk [B], kl [B]
     (already multiplied by beta for the Beta family, beta_vae.py:38-43)."""
-    x = _as_tensor(inputs, self.device)
+    x = self._tile(_as_tensor(inputs, self.device))
+    n = self.n_samples
     eng = self._engine(x.shape[0])
     eng.set_hyper(beta=self.beta, t=self._step)
-    eng.forward(x, None if eps is None else _as_tensor(eps, self.device))
+    eng.forward(x, None if eps is None else _as_tensor(eps, self.device).reshape(x.shape[0], -1))
     qz_x = self._posterior(eng)
     px_z = self._observation_dist(eng.dec.outs[-1].clone())
     self._last_outputs = (px_z, qz_x)
-    llk = {f'llk_{self.observation.name}': eng.llk.clone()}
-    klv = eng.kl.clone() * self.beta
+    shp = (lambda t: t.reshape(n, -1)) if n > 1 else (lambda t: t)
+    llk = {f'llk_{self.observation.name}': shp(eng.llk.clone())}
+    klv = shp(eng.kl.clone() * self.beta)
     if self.analytic:
-      klv = klv.unsqueeze(0)
+      klv = klv[:1] if n > 1 else klv.unsqueeze(0)  # [1, B] (helpers.py:370-371)
     kl = {f'kl_{self.latents.name}': klv}
     if self._tc_mode == 'betatc':
       kl[f'tc_{self.latents.name}'] = (self.beta - 1.0) * eng.tc_ws[0].clone()
@@ -413,22 +440,54 @@ class VariationalAutoencoder:
   def sample_observation(self, n: int = 1, seed: int = 1, training=False, **kwargs):
     return self.decode(self.sample_prior(n, seed=seed), training=training)
 
-  def marginal_log_prob(self, inputs, training=None, n_mcmc: int = 100, **kwargs):
-    """IWAE estimate log p(x) ~ logsumexp_k[log p(x|z_k) + log p(z_k) - log q(z_k|x)] - log K
-    (variational_autoencoder.py:396-513)."""
-    x = _as_tensor(inputs, self.device)
-    eng = self._engine(x.shape[0])
-    eng.set_hyper(beta=1.0, t=self._step)
-    ws = []
-    an = eng.analytic
-    eng.analytic = False  # MC form: kl = log q(z) - log p(z)
-    for k in range(int(n_mcmc)):
-      eps = torch.randn(x.shape[0], self.zdim, device=self.device)
-      eng.forward(x, eps)
-      ws.append((eng.llk - eng.kl).clone())
-    eng.analytic = an
-    w = torch.stack(ws, 0)
-    return torch.logsumexp(w, 0) - math.log(float(n_mcmc))
+  def marginal_log_prob(self, inputs, training=None, n_mcmc: Optional[int] = 100,
+                        reduce: Optional[Callable] = torch.mean, batch_size: int = 32,
+                        verbose: bool = False, eps=None, **kwargs):
+    """variational_autoencoder.py:396-513: per batch ONE encoder pass, n_mcmc posterior samples
+    per input, one decoder pass over the n_mcmc*B codes, log-mean-exp over the samples on
+    device.  Returns the reference's structure: ({name: llk}, {name: (log q, log p)}) with
+    llk = logsumexp_k log p(x|z_k) - log n and the same log-mean-exp of log q(z_k|x), log p(z_k);
+    `reduce` (default mean over inputs) is applied to each, None keeps the per-input vectors.
+    `eps` ([n_mcmc, N, D], optional) fixes the noise for parity tests."""
+    x_all = _as_tensor(inputs, self.device)
+    n = int(n_mcmc) if n_mcmc is not None else self.n_samples
+    N, D = x_all.shape[0], self.zdim
+    outs = {'llk': [], 'lq': [], 'lp': []}
+    f32 = dict(dtype=torch.float32, device=self.device)
+    for i0 in range(0, N, int(batch_size)):
+      x = x_all[i0:i0 + int(batch_size)].contiguous()
+      B = x.shape[0]
+      eng = self._engine(B)
+      lib, st = eng.lib, eng.stream()
+      eng.set_hyper(beta=1.0, t=self._step)
+      eng.run_encoder(x)  # fills eng.p = (loc | raw scale)
+      if eps is None:
+        e = torch.empty(n, B, D, **f32)
+        lib.odin_rng_normal(e.data_ptr(), n * B * D, self.seed + 7919 + i0, eng.hp(N_HYPER), st)
+      else:
+        e = _as_tensor(eps, self.device)[:, i0:i0 + B].contiguous()
+      z = torch.empty(n, B, D, **f32)
+      lq, lp, llk = torch.empty(n, B, **f32), torch.empty(n, B, **f32), torch.empty(n, B, **f32)
+      lib.odin_latent_sample_logprob(eng.p.data_ptr(), e.data_ptr(), z.data_ptr(), lq.data_ptr(),
+                                     lp.data_ptr(), n, B, D, st)
+      # decode the n*B codes in chunks of whole sample-rows (bounded activation memory)
+      rows = max(1, min(n, 2048 // max(B, 1)))
+      for k0 in range(0, n, rows):
+        r = min(rows, n - k0)
+        de = self._engine(r * B)
+        de.set_hyper(beta=1.0, t=self._step)
+        h = de.run_decoder(z[k0:k0 + r].reshape(r * B, D))
+        xt = x.repeat((r,) + (1,) * (x.dim() - 1))
+        de.observation_llk(h, xt, llk[k0:k0 + r].reshape(r * B))
+      for key, src in (('llk', llk), ('lq', lq), ('lp', lp)):
+        o = torch.empty(B, **f32)
+        lib.odin_logmeanexp_rows(src.data_ptr(), o.data_ptr(), n, B, st)
+        outs[key].append(o)
+    cat = {k: torch.cat(v) for k, v in outs.items()}
+    if reduce is not None:
+      cat = {k: reduce(v) for k, v in cat.items()}
+    return ({self.observation.name: cat['llk']},
+            {self.latents.name: (cat['lq'], cat['lp'])})
 
   # ------------------------------------------------------------------ training
   def train_steps(self, inputs, training=None, mask=None, name: str = '', **kwargs
@@ -442,31 +501,69 @@ class VariationalAutoencoder:
 
   def optimize(self, inputs, training: bool = True, optimizer=None, learning_rate=1e-4,
                clipnorm=None, clipvalue=None, global_clipnorm=None, skip_update_threshold=None,
-               when_skip_update=None, nan_gradients_policy: str = 'stop',
+               when_skip_update: int = 0, nan_gradients_policy: str = 'skip',
                allow_none_gradients=False, aggregate_gradients=False, track_gradients=False,
                eps=None, use_graph: bool = False):
     """Networks.optimize (base_networks.py:415-624): step += 1; forward; backward; NaN policy;
-    optional clip_by_global_norm; Adam.  Returns (loss, metrics) as device scalars."""
-    if clipnorm is not None or clipvalue is not None:
-      raise NotImplementedError('per-tensor clipnorm / clipvalue: use global_clipnorm')
-    x = _as_tensor(inputs, self.device)
+    skip_update_threshold -> per-variable clipnorm -> clip_by_global_norm -> clipvalue (the
+    reference's order, :549-596); Adam.  Returns (loss, metrics) as device scalars.
+
+    nan_gradients_policy: 'ignore' applies the update whatever the gradients hold; every other
+    policy leaves parameters and optimiser state untouched on device when a gradient is not
+    finite and raises `nan_flag` (polled by `fit`, which stops / raises / restores the last
+    checkpoint).  (The reference zeroes the gradients with `g - g`, which is NaN again for a NaN
+    gradient, and hands them to Adam: a step it cannot survive.  Not reproduced.)
+    aggregate_gradients only matters for multi-step models (FactorVAE); track_gradients adds the
+    gradient tensors as `_grad/<variable>` metrics (:609-611)."""
+    if nan_gradients_policy not in ('stop', 'skip', 'raise', 'ignore', 'restore'):
+      raise ValueError(f'nan_gradients_policy={nan_gradients_policy!r}')
+    x = self._tile(_as_tensor(inputs, self.device))
     eng = self._engine(x.shape[0])
+    if eps is not None:
+      eps = _as_tensor(eps, self.device).reshape(x.shape[0], -1)
     if training:
       self._step += 1
     eng.step_count = self._step - 1 if training else self._step
     if not training:
       eng.set_hyper(beta=self.beta, t=self._step)
-      eng.forward(x, None if eps is None else _as_tensor(eps, self.device))
+      eng.forward(x, eps)
     else:
-      eng.train_step(x, None if eps is None else _as_tensor(eps, self.device),
+      eng.train_step(x, eps,
                      lr=self._lr(learning_rate), beta=self.beta,
-                     global_clipnorm=global_clipnorm, use_graph=use_graph)
+                     global_clipnorm=global_clipnorm, use_graph=use_graph, clipnorm=clipnorm,
+                     clipvalue=clipvalue, skip_update_threshold=skip_update_threshold,
+                     when_skip_update=when_skip_update,
+                     check_nan=nan_gradients_policy != 'ignore')
       self._step = eng.step_count
     out = eng.out4.clone()
     metrics = {f'llk_{self.observation.name}': out[1], f'kl_{self.latents.name}': out[2]}
     if self._tc_mode == 'betatc':
       metrics[f'tc_{self.latents.name}'] = out[3]
+    if training and track_gradients:
+      for k, g in eng.grad_views().items():
+        metrics['_grad/' + self.variable_name(k)] = g.clone()
     return out[0], metrics
+
+  @property
+  def nan_flag(self) -> bool:
+    """True when a training step met non-finite gradients and skipped its update (host sync)."""
+    return any(int(e.flag.item()) != 0 for e in self._engines.values())
+
+  @property
+  def skipped_update(self) -> int:
+    """Networks.skipped_update (base_networks.py:573-577): updates zeroed by skip_update_threshold."""
+    return sum(int(e.skipped_update.item()) for e in self._engines.values())
+
+  def variable_name(self, key: tuple) -> str:
+    """Keras variable name of a parameter key: the reference's layer names
+    (image_networks.py:248-268,463-511: encoder0.., encoder_proj, decoder_proj, decoder1..;
+    DistributionDense 'latents', dense_distribution.py:229-238) + /kernel | /bias."""
+    suffix = 'kernel' if key[-1] == 'w' else 'bias'
+    if key[0] == 'lat':
+      return f'{self.latents.name}/{suffix}'
+    net = self.encoder if key[0] == 'enc' else self.decoder
+    names = layer_names(net, 'encoder' if key[0] == 'enc' else 'decoder')
+    return f'{names[key[1]]}/{suffix}'
 
   def fit(self, train, *, valid=None, valid_freq: int = 500, valid_interval: float = 0,
           optimizer='adam', learning_rate=1e-4, clipnorm=None, global_clipnorm=None,
@@ -474,12 +571,13 @@ class VariationalAutoencoder:
           max_iter: int = 1000, batch_size: int = 32, on_batch_end=None, on_valid_end=None,
           compile_graph: bool = True, autograph: bool = False, logging_interval: float = 5,
           skip_fitted: Union[bool, int] = False, nan_gradients_policy: str = 'stop',
-          logdir=None, allow_none_gradients=False, track_gradients=False, seed: int = 1):
+          logdir=None, allow_none_gradients=False, track_gradients=False, seed: int = 1,
+          nan_check_interval: int = 50):
     """Networks.fit (base_networks.py:642-812).  `train`: array / tensor [N,H,W,C] or an
     iterable of batches.  compile_graph -> the step is replayed as one HIP graph."""
     if optimizer not in ('adam', None) and not callable(optimizer):
       raise RuntimeError(f'No support for optimizer {optimizer!r} on the HIP path (adam only)')
-    if nan_gradients_policy not in ('stop', 'skip', 'raise', 'ignore'):
+    if nan_gradients_policy not in ('stop', 'skip', 'raise', 'ignore', 'restore'):
       raise ValueError(nan_gradients_policy)
     if skip_fitted and self._step >= (max_iter if skip_fitted is True else int(skip_fitted)):
       return self
@@ -508,17 +606,25 @@ class VariationalAutoencoder:
       if it >= max_iter:
         break
       loss, metrics = self.optimize(xb, training=True, learning_rate=learning_rate,
+                                    clipnorm=clipnorm, clipvalue=clipvalue,
                                     global_clipnorm=global_clipnorm,
+                                    skip_update_threshold=skip_update_threshold,
+                                    when_skip_update=when_skip_update or 0,
                                     nan_gradients_policy=nan_gradients_policy,
+                                    track_gradients=track_gradients,
                                     use_graph=compile_graph and self.device.type == 'cuda')
       it += 1
       eng = self._engine(xb.shape[0])
-      if it % 50 == 0 or it == max_iter:
+      # the NaN flag is sticky on device; polling it costs a host sync, so it is read every
+      # `nan_check_interval` iterations (and at the end) unless the policy must act at once
+      if it % nan_check_interval == 0 or it == max_iter:
         if int(eng.flag.item()) != 0:  # non-finite gradients: the update was skipped on device
           if nan_gradients_policy == 'raise':
-            raise RuntimeError(f'NaN gradients at step {self._step}')
+            raise RuntimeError(f'NaNs gradient! (step {self._step})')
           if nan_gradients_policy == 'stop':
             break
+          if nan_gradients_policy == 'restore':  # fall back to the last checkpoint (:543-545)
+            self.load_weights(raise_notfound=False)
           eng.flag.zero_()
         history.append((self._step, float(loss)))
       if on_batch_end is not None:
@@ -530,31 +636,39 @@ class VariationalAutoencoder:
 
   # ------------------------------------------------------------------ checkpoints
   def save_weights(self, filepath: Optional[str] = None, overwrite: bool = True):
-    """base_networks.py:373-390: weights + step (optimizer state deliberately not tracked)."""
+    """base_networks.py:373-390: weights + step (optimizer state deliberately not tracked).
+    Written as a plain `.npz` (no pickle): one array per variable under its Keras name
+    (`encoder0/kernel`, ..., `latents/bias`) plus `__step__`."""
     filepath = filepath or self.path
     if filepath is None:
-      raise ValueError('no path given')
-    if os.path.exists(filepath) and not overwrite:
+      raise ValueError('No path is given for saving weights')
+    if os.path.exists(self._npz_path(filepath)) and not overwrite:
       raise RuntimeError(f'{filepath} exists')
     eng = self._engine(1)
-    W = {'/'.join(map(str, k)): v.detach().cpu().numpy() for k, v in eng.param_views().items()}
-    with open(filepath, 'wb') as f:
-      pickle.dump(dict(weights=W, step=self._step, name=self.name), f)
+    W = {self.variable_name(k): v.detach().cpu().numpy() for k, v in eng.param_views().items()}
+    W['__step__'] = np.asarray(self._step, np.int64)
+    with open(self._npz_path(filepath), 'wb') as f:
+      np.savez(f, **W)
     return self
+
+  @staticmethod
+  def _npz_path(filepath: str) -> str:
+    return filepath if filepath.endswith('.npz') else filepath + '.npz'
 
   def load_weights(self, filepath: Optional[str] = None, raise_notfound: bool = False):
     filepath = filepath or self.path
-    if filepath is None or not os.path.exists(filepath):
+    if filepath is None or not os.path.exists(self._npz_path(filepath)):
       if raise_notfound:
-        raise FileNotFoundError(filepath)
+        raise FileNotFoundError(f'Cannot find saved weights at path: {filepath}')
       return self
-    with open(filepath, 'rb') as f:
-      d = pickle.load(f)
+    d = np.load(self._npz_path(filepath), allow_pickle=False)
     eng = self._engine(1)
-    views = eng.param_views()
-    for k, v in views.items():
-      v.copy_(torch.as_tensor(d['weights']['/'.join(map(str, k))], device=self.device))
-    self._step = int(d['step'])
+    for k, v in eng.param_views().items():
+      a = d[self.variable_name(k)]
+      if tuple(a.shape) != tuple(v.shape):
+        raise ValueError(f'{self.variable_name(k)}: checkpoint shape {a.shape} != {tuple(v.shape)}')
+      v.copy_(torch.as_tensor(a, dtype=torch.float32, device=self.device))
+    self._step = int(d['__step__'])
     return self
 
   def __str__(self):
@@ -607,13 +721,13 @@ class BetaTCVAE(BetaVAE):
 # ======================================================================================
 class FactorDiscriminator:
   """factor_discriminator.py:16-235: Flatten -> [Dense(units, relu)]*n -> Dense(1) logit.
-  Holds its own flat parameter / gradient / Adam buffers and two bound programs: one over
-  B1 samples (TC term inside the VAE step: data-gradient only) and one over 2*B1 samples
-  ([z ; permute_dims(z')], discriminator step)."""
+  ONE set of flat parameter / gradient / Adam buffers (and one Adam iteration counter) for the
+  model; `bind(B1)` adds the launch programs of a batch size: one over B1 samples (TC term
+  inside the VAE step: data-gradient only) and one over 2*B1 samples ([z ; permute_dims(z')],
+  discriminator step)."""
 
-  def __init__(self, lib, zdim: int, units: Sequence[int], activation: str, B1: int, device,
-               seed: int):
-    self.lib, self.device, self.B1, self.D = lib, device, B1, zdim
+  def __init__(self, lib, zdim: int, units: Sequence[int], activation: str, device, seed: int):
+    self.lib, self.device, self.D = lib, device, zdim
     layers = [('dense', int(u), activation) for u in units] + [('dense', 1, 'linear')]
     self.layout = ParamLayout()
     self.recs, out = build_layers('disc', layers, (zdim,), self.layout)
@@ -624,29 +738,51 @@ class FactorDiscriminator:
     self.m, self.v = torch.zeros(n, **f32), torch.zeros(n, **f32)
     g = torch.Generator(device='cpu').manual_seed(seed + 7)
     for key, shp, off in self.layout.entries:
-      if key[-1] == 'w':
+      if key[-1] == 'w':  # glorot_uniform (dense_network default, base_networks.py:968)
         lim = math.sqrt(6.0 / (shp[0] + shp[1]))
         self.params[off:off + int(np.prod(shp))] = \
             ((torch.rand(int(np.prod(shp)), generator=g) * 2 - 1) * lim).to(device)
-    mr = lib.odin_max_slab_rows()
-    self.prog1 = NetProgram(lib, self.recs, B1, device, self.params, self.grads, mr)
-    self.prog2 = NetProgram(lib, self.recs, 2 * B1, device, self.params, self.grads, mr)
-    self.tc = torch.zeros(1, **f32)
-    self.dlogit1 = torch.zeros(B1, 1, **f32)
-    self.dz = torch.zeros(B1, zdim, **f32)
-    self.zcat = torch.zeros(2 * B1, zdim, **f32)
-    self.zperm = torch.zeros(B1, zdim, **f32)
-    self.perm = torch.zeros(B1, zdim, dtype=torch.int32, device=device)
-    self.dlogit2 = torch.zeros(2 * B1, 1, **f32)
-    self.dtc = torch.zeros(1, **f32)
-    self.hyper = torch.zeros(8, **f32)
     self.flag = torch.zeros(1, dtype=torch.int32, device=device)
-    self.t = 0
-    self._keep = None
+    self.t = 0  # iterations of the discriminator's own Adam
+    self.bound: Dict[int, 'DiscPrograms'] = {}
 
   @property
   def n_parameters(self):
     return sum(int(np.prod(s)) for _, s, _ in self.layout.entries)
+
+  def bind(self, B1: int) -> 'DiscPrograms':
+    if B1 not in self.bound:
+      self.bound[B1] = DiscPrograms(self, B1)
+    return self.bound[B1]
+
+
+class DiscPrograms:
+  """Launch programs + activation buffers of the discriminator for one half-batch size."""
+
+  def __init__(self, disc: FactorDiscriminator, B1: int):
+    lib, device, zdim = disc.lib, disc.device, disc.D
+    f32 = dict(dtype=torch.float32, device=device)
+    self.disc, self.B1 = disc, B1
+    self.params, self.grads, self.layout = disc.params, disc.grads, disc.layout
+    mr = lib.odin_max_slab_rows()
+    self.prog1 = NetProgram(lib, disc.recs, B1, device, disc.params, disc.grads, mr)
+    self.prog2 = NetProgram(lib, disc.recs, 2 * B1, device, disc.params, disc.grads, mr)
+    self.tc = torch.zeros(1, **f32)
+    self.dlogit1 = torch.zeros(B1, 1, **f32)
+    self.dlogit1_value = None
+    self.dz = torch.zeros(B1, zdim, **f32)
+    self.zcat = torch.zeros(2 * B1, zdim, **f32)  # [z (step 1's sample) ; permute_dims(z')]
+    self.zperm = self.zcat[B1:]
+    self.perm = torch.zeros(B1, zdim, dtype=torch.int32, device=device)
+    self.dlogit2 = torch.zeros(2 * B1, 1, **f32)
+    self.dtc = torch.zeros(1, **f32)
+    self._keep = None
+
+  m = property(lambda self: self.disc.m)
+  v = property(lambda self: self.disc.v)
+
+
+H_DALPHA = 10  # discriminator Adam block {alpha_t, beta1, beta2, eps, grad_scale} in the hyper buffer
 
 
 class FactorVAE(AnnealingVAE):
@@ -654,7 +790,9 @@ class FactorVAE(AnnealingVAE):
     step 1 (VAE params, fit's Adam): loss = -mean(llk - beta_t*kl) + tc_coef*mean(D(z)),
             the gradient flows through D into z (total_correlation, factor_discriminator.py:169-198);
     step 2 (discriminator params, Adam(1e-5, .5, .9)): dtc_loss of D(z) and
-            D(permute_dims(z')) with z' = encode(x2) (factor_discriminator.py:200-235)."""
+            D(permute_dims(z')) with z' = encode(x2) (factor_discriminator.py:200-235).
+  On one GPU the whole iteration (both steps, both optimisers) is replayed as ONE HIP graph
+  when `use_graph` / `fit(compile_graph=True)`."""
 
   def __init__(self, discriminator_units: Sequence[int] = (1000,) * 5, discriminator_optim=None,
                activation: str = 'relu', batchnorm: bool = False, tc_coef: float = 7.0,
@@ -665,9 +803,13 @@ class FactorVAE(AnnealingVAE):
     self.tc_coef = float(tc_coef) * (-1.0 if maximize_tc else 1.0)
     self.disc_units, self.disc_act = tuple(discriminator_units), activation
     self.disc_lr, self.disc_b1, self.disc_b2 = 1e-5, 0.5, 0.9
+    if discriminator_optim is not None:  # dict(learning_rate=, beta_1=, beta_2=) accepted
+      self.disc_lr = float(discriminator_optim.get('learning_rate', self.disc_lr))
+      self.disc_b1 = float(discriminator_optim.get('beta_1', self.disc_b1))
+      self.disc_b2 = float(discriminator_optim.get('beta_2', self.disc_b2))
     self._is_pretraining = False
-    self._disc: Dict[int, FactorDiscriminator] = {}
-    self._disc_state = None
+    self._disc_state: Optional[FactorDiscriminator] = None
+    self._fgraphs: Dict[tuple, Any] = {}
 
   @property
   def is_pretraining(self):
@@ -681,88 +823,177 @@ class FactorVAE(AnnealingVAE):
     self._is_pretraining = False
     return self
 
-  def _discriminator(self, B1: int) -> FactorDiscriminator:
-    if B1 not in self._disc:
-      eng = self._engine(B1)
-      d = FactorDiscriminator(eng.lib, self.zdim, self.disc_units, self.disc_act, B1,
-                              self.device, self.seed)
-      if self._disc_state is not None:  # share parameters / optimiser state across batch sizes
-        d.params.copy_(self._disc_state.params)
-      else:
-        self._disc_state = d
-      self._disc[B1] = d
-    return self._disc[B1]
+  @property
+  def discriminator(self) -> FactorDiscriminator:
+    if self._disc_state is None:
+      eng = self._engine(1)
+      self._disc_state = FactorDiscriminator(eng.lib, self.zdim, self.disc_units, self.disc_act,
+                                             self.device, self.seed)
+      from .dist import broadcast_parameters
+      broadcast_parameters(self._disc_state.params, src=0)
+    return self._disc_state
+
+  def _discriminator(self, B1: int) -> DiscPrograms:
+    dp = self.discriminator.bind(B1)
+    eng = self._engine(B1)
+    if eng.z.data_ptr() != dp.zcat.data_ptr():
+      # step 1's cached sample IS the first half of the discriminator step's input: the engine
+      # writes z there directly (no per-iteration copy); must happen before any graph capture
+      assert not getattr(eng, '_graphs', None), 'bind the discriminator before capturing graphs'
+      eng.z = dp.zcat[:B1]
+    return dp
 
   # -- the two steps, returning device scalars ------------------------------------------
-  def optimize(self, inputs, training: bool = True, learning_rate=1e-4, global_clipnorm=None,
-               eps=None, eps2=None, perm=None, **kwargs):
-    x = _as_tensor(inputs, self.device)
-    assert x.shape[0] % 2 == 0, 'FactorVAE splits the batch in two halves'
-    B1 = x.shape[0] // 2
-    x1, x2 = x[:B1].contiguous(), x[B1:].contiguous()
-    eng, disc = self._engine(B1), self._discriminator(B1)
-    lib, st = eng.lib, eng.stream()
-    if training:
-      self._step += 1
-    eng.step_count = self._step
-    use_tc = not (self._is_pretraining and training)
-    eng.set_hyper(lr=self._lr(learning_rate), beta=self.beta, tc_coef=self.tc_coef if use_tc else 0.0)
+  def _set_hyper(self, eng, disc, lr, use_tc, training):
+    h_extra = None
+    if training and not self._is_pretraining:
+      t = disc.disc.t + 1
+      a = self.disc_lr * math.sqrt(1 - self.disc_b2 ** t) / (1 - self.disc_b1 ** t)
+      h_extra = (a, self.disc_b1, self.disc_b2, 1e-7, 1.0)
+    eng.set_hyper(lr=lr, beta=self.beta, tc_coef=self.tc_coef if use_tc else 0.0, extra=h_extra)
+
+  def _iteration(self, eng, eng2, disc, x1, x2, eps, eps2, perm, training, use_tc, pol,
+                 aggregate_gradients):
+    """The launch sequence of one FactorVAE iteration on the current stream (eager or captured)."""
+    lib, st, B1 = eng.lib, eng.stream(), disc.B1
     # ---- step 1: ELBO with the discriminator's TC estimate ----
-    eng.forward(x1, None if eps is None else _as_tensor(eps, self.device), finalize=False)
+    eng.forward(x1, eps, finalize=False)
     extra = None
     if use_tc:
       lg = disc.prog1.forward(eng.z, st)
       lib.odin_mean(lg.data_ptr(), B1, disc.tc.data_ptr(), st)
       eng.finalize(tc_ptr=disc.tc.data_ptr())
-      disc.dlogit1.fill_(self.tc_coef / (B1 * eng.world_size))
       disc.prog1.backward(eng.z, disc.dlogit1, st, dx_out=disc.dz, data_only=True)
       extra = disc.dz
     else:
       eng.finalize()
-    metrics = {}
     if training:
       eng.backward(extra_dz=extra)
       eng.allreduce()
-      eng.adam(global_clipnorm=global_clipnorm)
-    out = eng.out4.clone()
-    metrics.update({f'elbo/llk_{self.observation.name}': out[1],
-                    f'elbo/kl_{self.latents.name}': out[2], 'elbo/tc': out[3]})
-    loss = out[0]
-    # ---- step 2: discriminator ----
+      if not aggregate_gradients:
+        eng._update(pol)
+    # ---- step 2: discriminator (skipped while pretraining, factor_vae.py:279) ----
     if not self._is_pretraining:
-      z1 = eng.z
-      disc.zcat[:B1].copy_(z1)
-      eng2 = self._engine_x2(B1)
-      eng2.set_hyper(beta=self.beta, t=self._step + 100003)
-      eng2.run_encoder(x2, None if eps2 is None else _as_tensor(eps2, self.device))
+      eng2.run_encoder(x2, eps2)  # z' with the encoder as step 1 left it
       if perm is None:
         lib.odin_random_perm(disc.perm.data_ptr(), B1, self.zdim, self.seed + 11,
                              eng.hp(N_HYPER), st)
-      else:
-        disc.perm.copy_(torch.as_tensor(perm, dtype=torch.int32, device=self.device))
       lib.odin_permute_dims(eng2.z.data_ptr(), disc.perm.data_ptr(), disc.zperm.data_ptr(), B1,
                             self.zdim, st)
-      disc.zcat[B1:].copy_(disc.zperm)
       lg2 = disc.prog2.forward(disc.zcat, st)
       lib.odin_dtc_loss_fwd_bwd(lg2.data_ptr(), lg2[B1:].data_ptr(), disc.dtc.data_ptr(),
                                 disc.dlogit2.data_ptr(), disc.dlogit2[B1:].data_ptr(), B1, st)
-      metrics['disc/dtc_loss'] = disc.dtc[0].clone()
       if training:
         jobs = disc.prog2.backward(disc.zcat, disc.dlogit2, st)
         arr = (ReduceJob * len(jobs))(*jobs)
         disc._keep = arr
         lib.odin_slab_reduce(arr, len(jobs), st)
-        if eng.world_size > 1:
+        if eng.is_dp:
           import torch.distributed as dist
-          disc.grads.div_(eng.world_size)
+          if eng.world_size > 1:
+            disc.grads.div_(eng.world_size)
           dist.all_reduce(disc.grads)
-        disc.t += 1
-        a = self.disc_lr * math.sqrt(1 - self.disc_b2 ** disc.t) / (1 - self.disc_b1 ** disc.t)
-        disc.hyper.copy_(torch.tensor([a, self.disc_b1, self.disc_b2, 1e-7, 1.0, 0, 0, 0]))
         lib.odin_adam_step_flat(disc.params.data_ptr(), disc.grads.data_ptr(), disc.m.data_ptr(),
-                                disc.v.data_ptr(), disc.params.numel(), disc.hyper.data_ptr(),
+                                disc.v.data_ptr(), disc.params.numel(), eng.hp(H_DALPHA),
                                 None, 0.0, None, st)
-    return loss, metrics
+    if training and aggregate_gradients:
+      eng._update(pol)
+
+  def optimize(self, inputs, training: bool = True, optimizer=None, learning_rate=1e-4,
+               clipnorm=None, clipvalue=None, global_clipnorm=None, skip_update_threshold=None,
+               when_skip_update: int = 0, nan_gradients_policy: str = 'skip',
+               allow_none_gradients=False, aggregate_gradients=False, track_gradients=False,
+               eps=None, eps2=None, perm=None, use_graph: bool = False, **kwargs):
+    """Networks.optimize over FactorVAE.train_steps (factor_vae.py:239-287): the gradient
+    policies apply to the VAE step's gradients (the discriminator step has its own optimiser
+    and, as in the reference's default call, no clipping is configured for it separately --
+    the same clip arguments are NOT applied to it here; state otherwise if you need them)."""
+    x = _as_tensor(inputs, self.device)
+    assert x.shape[0] % 2 == 0, 'FactorVAE splits the batch in two halves'
+    B1 = x.shape[0] // 2
+    eng, disc = self._engine(B1), self._discriminator(B1)
+    eng2 = self._engine_x2(B1)
+    if training:
+      self._step += 1
+    eng.step_count = self._step
+    eng2.hyper = eng.hyper  # one hyper buffer (RNG step, beta) for both halves
+    use_tc = not (self._is_pretraining and training)
+    self._set_hyper(eng, disc, self._lr(learning_rate), use_tc, training)
+    val = self.tc_coef / (B1 * eng.world_size)
+    if disc.dlogit1_value != val:
+      disc.dlogit1.fill_(val)
+      disc.dlogit1_value = val
+    if perm is not None:
+      disc.perm.copy_(torch.as_tensor(perm, dtype=torch.int32, device=self.device))
+    pol = (global_clipnorm, clipnorm, clipvalue, skip_update_threshold,
+           nan_gradients_policy != 'ignore')
+    te = None if eps is None else _as_tensor(eps, self.device)
+    te2 = None if eps2 is None else _as_tensor(eps2, self.device)
+    graphable = (use_graph and self.device.type == 'cuda' and not eng.is_dp)
+    if graphable:
+      self._graph_iteration(eng, eng2, disc, x, te, te2, perm is not None, training, use_tc, pol,
+                            aggregate_gradients)
+    else:
+      x1, x2 = x[:B1], x[B1:]
+      self._iteration(eng, eng2, disc, x1, x2, te, te2, perm, training, use_tc, pol,
+                      aggregate_gradients)
+    if training and not self._is_pretraining:
+      disc.disc.t += 1
+    out = eng.out4.clone()
+    metrics = {f'elbo/llk_{self.observation.name}': out[1],
+               f'elbo/kl_{self.latents.name}': out[2], 'elbo/tc': out[3]}
+    if not self._is_pretraining:
+      metrics['disc/dtc_loss'] = disc.dtc[0].clone()
+    if training and track_gradients:
+      for k, g in eng.grad_views().items():
+        metrics['_grad/elbo/' + self.variable_name(k)] = g.clone()
+    return out[0], metrics
+
+  def _graph_iteration(self, eng, eng2, disc, x, eps, eps2, explicit_perm, training, use_tc, pol,
+                       aggregate_gradients):
+    """One captured HIP graph per (batch size, configuration): both steps, both Adams."""
+    B1 = disc.B1
+    key = (B1, pol, eps is not None, eps2 is not None, explicit_perm, training, use_tc,
+           aggregate_gradients, self._is_pretraining, eng.analytic, eng.free_bits)
+    if key not in self._fgraphs:
+      xs = torch.empty_like(x)
+      xs.copy_(x)
+      if eps is not None:
+        eng.eps.copy_(eps)
+      if eps2 is not None:
+        eng2.eps.copy_(eps2)
+      run = lambda: self._iteration(eng, eng2, disc, xs[:B1], xs[B1:],
+                                    eng.eps if eps is not None else None,
+                                    eng2.eps if eps2 is not None else None,
+                                    True if explicit_perm else None, training, use_tc, pol,
+                                    aggregate_gradients)
+      cap = torch.cuda.Stream(self.device)
+      cap.wait_stream(torch.cuda.current_stream(self.device))
+      D = disc.disc
+      saved = [t.clone() for t in (eng.params, eng.m, eng.v, D.params, D.m, D.v, eng.flag,
+                                   eng.skipped_update)]
+      with torch.cuda.stream(cap):
+        run()  # warm-up outside capture; must not count
+        for t, sv in zip((eng.params, eng.m, eng.v, D.params, D.m, D.v, eng.flag,
+                          eng.skipped_update), saved):
+          t.copy_(sv)
+      torch.cuda.current_stream(self.device).wait_stream(cap)
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
+        run()
+      self._fgraphs[key] = (g, xs)
+    g, xs = self._fgraphs[key]
+    if x.data_ptr() != xs.data_ptr():
+      xs.copy_(x, non_blocking=True)
+    if eps is not None:
+      eng.eps.copy_(eps, non_blocking=True)
+    if eps2 is not None:
+      eng2.eps.copy_(eps2, non_blocking=True)
+    g.replay()
+
+  def input_buffer(self, batch_size: int) -> torch.Tensor:
+    """Static [B, H, W, C] tensor read by the captured iteration graph with default settings."""
+    raise NotImplementedError('FactorVAE copies the batch into its graph-owned buffer')
 
   def _engine_x2(self, B1: int) -> VAEEngine:
     key = -B1
@@ -772,7 +1003,8 @@ class FactorVAE(AnnealingVAE):
                                      self.zdim, B1, self.device,
                                      observation=self.observation.posterior,
                                      analytic=self.analytic, free_bits=self.free_bits,
-                                     lib=self._lib, params=self._params, seed=self.seed + 1)
+                                     lib=self._lib, params=self._params,
+                                     seed=self.seed + 1000003 + self._rank())
     return self._engines[key]
 
   def total_correlation(self, qz_x, training=None):
@@ -792,10 +1024,10 @@ class FactorVAE(AnnealingVAE):
       lib.odin_random_perm(disc.perm.data_ptr(), B1, self.zdim, self.seed + 11, None, st)
     else:
       disc.perm.copy_(torch.as_tensor(perm, dtype=torch.int32, device=self.device))
+    zp = zp.clone()  # (zp may alias the buffer permute_dims writes)
+    disc.zcat[:B1].copy_(z)
     lib.odin_permute_dims(zp.data_ptr(), disc.perm.data_ptr(), disc.zperm.data_ptr(), B1,
                           self.zdim, st)
-    disc.zcat[:B1].copy_(z)
-    disc.zcat[B1:].copy_(disc.zperm)
     lg2 = disc.prog2.forward(disc.zcat, st)
     lib.odin_dtc_loss_fwd_bwd(lg2.data_ptr(), lg2[B1:].data_ptr(), disc.dtc.data_ptr(),
                               disc.dlogit2.data_ptr(), disc.dlogit2[B1:].data_ptr(), B1, st)

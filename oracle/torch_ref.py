@@ -89,7 +89,8 @@ class TorchVAE:
 
   def __init__(self, enc_layers, dec_layers, in_shape, zdim, observation='bernoulli',
                analytic=False, free_bits=None, beta=1.0, tc_beta=None,
-               dtype=torch.float64):
+               dtype=torch.float64, reverse=True):
+    self.reverse = bool(reverse)
     self.enc, self.dec = list(enc_layers), list(dec_layers)
     self.in_shape, self.D = tuple(in_shape), int(zdim)
     self.observation, self.analytic, self.free_bits = observation, analytic, free_bits
@@ -120,7 +121,9 @@ class TorchVAE:
       osc = F.softplus(raw + SOFTPLUS_INV_1) if self.observation == 'gaussian_softplus1' else raw
       llk = (-0.5 * ((x - oloc) / osc) ** 2 - torch.log(osc) - 0.5 * LOG2PI).reshape(B, -1).sum(1)
       recon = oloc
-    if self.analytic:
+    if not self.reverse:  # KL(p || q), closed form (odin/bay/helpers.py:261-265)
+      kl_raw = (torch.log(scale) + 0.5 * (1.0 + loc ** 2) / scale ** 2 - 0.5).sum(-1)
+    elif self.analytic:
       kl_raw = 0.5 * (scale ** 2 + loc ** 2 - 1.0 - 2.0 * torch.log(scale)).sum(-1)
     else:
       lq = (-0.5 * ((z - loc) / scale) ** 2 - torch.log(scale)).sum(-1) - 0.5 * D * LOG2PI

@@ -237,6 +237,12 @@ def kl_analytic(loc, scale):
   return 0.5 * (scale ** 2 + loc ** 2 - 1.0 - 2.0 * np.log(scale)).sum(-1)
 
 
+def kl_analytic_reverse(loc, scale):
+  """reverse=False swaps the arguments (odin/bay/helpers.py:261-262): tfd.kl_divergence(prior,
+  posterior) = KL(N(0,I) || N(loc, scale)) = sum log s + (1 + m^2) / (2 s^2) - 1/2."""
+  return (np.log(scale) + 0.5 * (1.0 + loc ** 2) / scale ** 2 - 0.5).sum(-1)
+
+
 def free_bits_clamp(kl, free_bits: Optional[float], D: int):
   """max(kl, free_bits * D) on the per-sample summed KL (odin/bay/helpers.py:278-280).
   Returns (kl, mask) with mask=1 where the gradient flows."""
@@ -327,6 +333,25 @@ def clip_by_global_norm(grads, clip: float):
   n = global_norm(grads)
   sc = clip / max(n, clip)
   return [g * sc for g in grads], n
+
+
+def gradient_policies(grads: Sequence[np.ndarray], clipnorm=None, global_clipnorm=None,
+                      clipvalue=None, skip_update_threshold=None, skip_enabled=True):
+  """Networks.optimize between tape.gradient and apply_gradients
+  (odin/networks/base_networks.py:549-596), in the reference's order.  Returns (grads, skipped)."""
+  g = [np.asarray(x, F64) for x in grads]
+  skipped = False
+  if skip_update_threshold is not None:
+    skipped = bool(any((x >= skip_update_threshold).any() for x in g)) and skip_enabled
+    if skipped:
+      g = [x - x for x in g]                                  # :561-569
+  if clipnorm is not None:                                    # tf.clip_by_norm per variable
+    g = [x * (clipnorm / max(math.sqrt(float((x ** 2).sum())), clipnorm)) for x in g]
+  if global_clipnorm is not None:
+    g, _ = clip_by_global_norm(g, global_clipnorm)
+  if clipvalue is not None:
+    g = [np.clip(x, -clipvalue, clipvalue) for x in g]
+  return g, skipped
 
 
 def exponential_decay(step, init_lr, decay_steps=10000, rate=0.996, staircase=True):
@@ -451,7 +476,9 @@ class OracleVAE:
   """
 
   def __init__(self, enc_layers, dec_layers, in_shape, zdim, observation='bernoulli',
-               analytic=False, free_bits=None, beta=1.0, tc_beta: Optional[float] = None):
+               analytic=False, free_bits=None, beta=1.0, tc_beta: Optional[float] = None,
+               reverse: bool = True):
+    self.reverse = bool(reverse)
     self.enc, self.dec = list(enc_layers), list(dec_layers)
     self.in_shape, self.D = tuple(in_shape), int(zdim)
     self.observation, self.analytic, self.free_bits = observation, analytic, free_bits
@@ -510,7 +537,14 @@ class OracleVAE:
       oscale = softplus1(raw) if self.observation == 'gaussian_softplus1' else raw
       llk = gaussian_log_prob(oloc, oscale, x)
       recon = oloc
-    kl_raw = kl_analytic(loc, scale) if self.analytic else kl_mc(loc, scale, z)
+    if not self.reverse:
+      # reverse=False with the Monte-Carlo form cannot be evaluated by the reference either:
+      # after the swap `tf.convert_to_tensor(prior)` is called on a plain tfd.Independent
+      # (helpers.py:267-276 with q_sample=None from variational_autoencoder.py:535-539)
+      assert self.analytic, 'reverse=False needs analytic=True'
+      kl_raw = kl_analytic_reverse(loc, scale)
+    else:
+      kl_raw = kl_analytic(loc, scale) if self.analytic else kl_mc(loc, scale, z)
     kl_c, fb_mask = free_bits_clamp(kl_raw, self.free_bits, self.D)
     kl = self.beta * kl_c
     elbo = llk - kl
@@ -557,7 +591,10 @@ class OracleVAE:
     loc, scale, z = f['loc'], f['scale'], f['z']
     # KL term: L += (beta/B) * sum_b clamp(kl_raw_b)
     wkl = (self.beta / B) * f['fb_mask'][:, None]
-    if self.analytic:
+    if not self.reverse:
+      dloc = wkl * loc / scale ** 2
+      dscale = wkl * (1.0 / scale - (1.0 + loc ** 2) / scale ** 3)
+    elif self.analytic:
       dloc = wkl * loc
       dscale = wkl * (scale - 1.0 / scale)
     else:
@@ -582,6 +619,32 @@ class OracleVAE:
     G.update({('enc',) + k: v for k, v in genc.items()})
     G.update({('dec',) + k: v for k, v in gdec.items()})
     return G, dict(dh_d=dh_d, dz=dz, dp=dp, dh_e=dh_e)
+
+
+def marginal_log_prob(model: OracleVAE, P, x, eps_n):
+  """VariationalAutoencoder.marginal_log_prob (variational_autoencoder.py:396-513) with
+  reduce=None: one encoder pass, z = q.sample(n) from the given eps_n [n,B,D], decode n*B codes;
+  returns (llk [B] = logsumexp_k log p(x|z_k) - log n,
+           (lq [B], lp [B]) = the same log-mean-exp of log q(z_k|x) and of log p(z_k))."""
+  x = np.asarray(x, F64)
+  eps_n = np.asarray(eps_n, F64)
+  n, B, D = eps_n.shape
+  h_e, _ = seq_forward(model.enc, model._sub(P, 'enc'), x)
+  loc, scale = mvn_diag_params(dense(h_e, P[('lat', 'w')], P[('lat', 'b')]), D)
+  z = loc[None] + scale[None] * eps_n
+  h_d, _ = seq_forward(model.dec, model._sub(P, 'dec'), z.reshape(n * B, D))
+  xt = np.tile(x, (n,) + (1,) * (x.ndim - 1))
+  if model.observation == 'bernoulli':
+    llk = bernoulli_log_prob(h_d, xt)
+  else:
+    C = x.shape[-1]
+    oloc, raw = h_d[..., :C], h_d[..., C:]
+    llk = gaussian_log_prob(oloc, softplus1(raw) if model.observation == 'gaussian_softplus1'
+                            else raw, xt)
+  lq = (-0.5 * eps_n ** 2 - np.log(scale)[None]).sum(-1) - 0.5 * D * LOG2PI
+  lp = (-0.5 * z ** 2).sum(-1) - 0.5 * D * LOG2PI
+  lme = lambda a: _logsumexp(a, 0) - math.log(n)
+  return lme(llk.reshape(n, B)), (lme(lq), lme(lp))
 
 
 def train_step(model: OracleVAE, P, M, V, t, x, eps, lr, global_clipnorm=None):

@@ -24,6 +24,7 @@ CASES = [
     ('dsprites', dict(beta=4.0)),
     ('dsprites', dict(beta=1.0, analytic=True)),
     ('dsprites', dict(beta=2.0, free_bits=0.5)),
+    ('dsprites', dict(beta=3.0, analytic=True, reverse=False)),
     ('shapes3d', dict(beta=1.0, tc_beta=4.0)),
     ('celeba_gauss', dict(beta=4.0, tc_beta=4.0)),
     ('mnist_conv', dict()),

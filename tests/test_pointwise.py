@@ -237,3 +237,43 @@ def test_permute_and_dtc_and_rng(bk):
   assert torch.equal(r1, r2) and not torch.equal(r1, r3)
   assert abs(r1.mean().item()) < 0.01 and abs(r1.std().item() - 1) < 0.01
   assert abs((r1 ** 3).mean().item()) < 0.05 and abs((r1 ** 4).mean().item() - 3) < 0.1
+
+
+def test_gradient_policies(bk):
+  """skip_update_threshold / per-variable clipnorm / clipvalue after global-norm scaling
+  (base_networks.py:549-596) on a flat buffer of 4 variables."""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(8)
+  sizes = [37, 1200, 5, 4100]
+  offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+  n = int(offs[-1])
+  g = rng.standard_normal(n) * np.repeat([0.1, 3.0, 10.0, 0.01], sizes)
+  parts = lambda a: [a[offs[i]:offs[i + 1]] for i in range(4)]
+  seg = bk.T(offs, torch.int64)
+  # per-variable clip_by_norm
+  tg = T(g)
+  L.odin_clip_by_norm_segments(tg.data_ptr(), seg.data_ptr(), 4, 2.5, None)
+  ref, _ = vo.gradient_policies(parts(g), clipnorm=2.5)
+  close(tg.cpu().numpy(), np.concatenate(ref), 1e-6)
+  # clip_by_value alone, and after clip_by_global_norm
+  tg = T(g)
+  L.odin_clip_by_value(tg.data_ptr(), n, 0.7, None, 0.0, None)
+  close(tg.cpu().numpy(), np.clip(g, -0.7, 0.7), 1e-7)
+  tg, ws, n2 = T(g), bk.zeros(1024), bk.zeros(1)
+  L.odin_sumsq_flat(tg.data_ptr(), n, ws.data_ptr(), n2.data_ptr(), None)
+  L.odin_clip_by_value(tg.data_ptr(), n, 0.05, n2.data_ptr(), 20.0, None)
+  ref, _ = vo.gradient_policies(parts(g), global_clipnorm=20.0, clipvalue=0.05)
+  close(tg.cpu().numpy(), np.concatenate(ref), 1e-6)
+  # skip_update_threshold
+  hit, cnt = bk.zeros(1, dtype=torch.int32), bk.zeros(1, dtype=torch.int32)
+  on, off = bk.T([1], torch.int32), bk.T([0], torch.int32)
+  tg = T(g)
+  L.odin_grad_skip_threshold(tg.data_ptr(), n, float(g.max()) + 1.0, on.data_ptr(), hit.data_ptr(),
+                             cnt.data_ptr(), None)
+  assert hit.item() == 0 and cnt.item() == 0 and np.array_equal(tg.cpu().numpy(), g.astype(np.float32))
+  L.odin_grad_skip_threshold(tg.data_ptr(), n, float(g.max()) - 1e-3, off.data_ptr(), hit.data_ptr(),
+                             cnt.data_ptr(), None)  # threshold reached but step < when_skip_update
+  assert hit.item() == 1 and cnt.item() == 0 and np.array_equal(tg.cpu().numpy(), g.astype(np.float32))
+  L.odin_grad_skip_threshold(tg.data_ptr(), n, float(g.max()) - 1e-3, on.data_ptr(), hit.data_ptr(),
+                             cnt.data_ptr(), None)
+  assert hit.item() == 1 and cnt.item() == 1 and not tg.cpu().numpy().any()

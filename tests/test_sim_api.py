@@ -68,12 +68,12 @@ def test_api_call_elbo_and_optimize(L):
 
 def test_fit_save_load_and_errors(L, tmp_path):
   nets = tiny_nets()
-  vae = VariationalAutoencoder(device='cpu', lib=L, path=str(tmp_path / 'w.pkl'), **nets)
+  vae = VariationalAutoencoder(device='cpu', lib=L, path=str(tmp_path / 'w'), **nets)
   x = (np.random.default_rng(1).random((24, 8, 8, 1)) < 0.3).astype(np.float32)
   vae.fit(x, max_iter=6, batch_size=8, learning_rate=1e-3, compile_graph=False)
   assert vae.step == 6 and len(vae.history) >= 1
   vae.save_weights()
-  vae2 = VariationalAutoencoder(device='cpu', lib=L, path=str(tmp_path / 'w.pkl'), **tiny_nets())
+  vae2 = VariationalAutoencoder(device='cpu', lib=L, path=str(tmp_path / 'w'), **tiny_nets())
   vae2.load_weights()
   assert vae2.step == 6
   for k, v in vae.trainable_variables.items():
@@ -158,3 +158,121 @@ def test_factor_vae_iteration_gradients_and_both_adams(L, units):
   perm = np.stack([rng.permutation(B1) for _ in range(D)], 1).astype(np.int32)
   rep = check_factor_vae_iteration(fv, nets, units, B1, x, eps, eps2, perm, clip=100.0)
   assert fv.step == 1000
+
+
+@pytest.mark.parametrize('kw', [dict(clipnorm=0.05), dict(clipvalue=0.002),
+                                dict(global_clipnorm=0.5, clipvalue=0.01),
+                                dict(clipnorm=0.2, global_clipnorm=0.3),
+                                dict(skip_update_threshold=1e-3),
+                                dict(skip_update_threshold=1e-3, when_skip_update=5),
+                                dict(skip_update_threshold=1e9)])
+def test_optimize_gradient_policies_match_oracle(L, kw):
+  """Every clipping / skipping argument of Networks.optimize (base_networks.py:549-596) changes
+  the Adam update exactly as the oracle's restatement says -- none is silently ignored."""
+  nets = tiny_nets()
+  vae = BetaVAE(beta=2.0, device='cpu', lib=L, **nets)
+  B = 6
+  rng = np.random.default_rng(4)
+  x = np.clip(rng.random((B, 8, 8, 1)), 1e-6, 1 - 1e-6).astype(np.float32)
+  eps = rng.standard_normal((B, 4)).astype(np.float32)
+  model = vo.OracleVAE(nets['encoder'].layers, nets['decoder'].layers, (8, 8, 1), 4, beta=2.0)
+  P = oracle_params(vae)
+  f = model.forward(P, x.astype(np.float64), eps.astype(np.float64))
+  G, _ = model.backward(P, x.astype(np.float64), eps.astype(np.float64), f)
+  keys = [k for k, _ in model.param_shapes()]
+  okw = {k: v for k, v in kw.items() if k != 'when_skip_update'}
+  gl, skipped = vo.gradient_policies([G[k] for k in keys],
+                                     skip_enabled=1 >= kw.get('when_skip_update', 0), **okw)
+  lr = 1e-3
+  vae.optimize(x, eps=eps, learning_rate=lr, **kw)
+  assert vae.skipped_update == int(skipped)
+  pv = {k: v.numpy() for k, v in vae.trainable_variables.items()}
+  for k, g in zip(keys, gl):
+    want, _, _ = vo.adam_keras(P[k], g, 0.0, 0.0, 1, lr)
+    well = np.abs(g) > 1e-3 * max(np.abs(g).max(), 1e-30)
+    d = np.abs(pv[k] - want)
+    assert d[well].max() <= 2e-5 if well.any() else True, (k, d.max())
+    if skipped:
+      assert np.array_equal(pv[k], P[k].astype(np.float32)), k  # Adam on zeros from zero state
+  with pytest.raises(ValueError):
+    vae.optimize(x, nan_gradients_policy='nope')
+
+
+def test_track_gradients_and_checkpoint_names(L, tmp_path):
+  nets = get_networks('dsprites')
+  names = ['encoder0', 'encoder3', 'encoder_proj', 'decoder_proj', 'decoder1', 'decoder6']
+  from odin_ai_amd.networks import layer_names
+  en, dn = layer_names(nets['encoder'], 'encoder'), layer_names(nets['decoder'], 'decoder')
+  assert set(names) <= set(en.values()) | set(dn.values())
+  vae = VariationalAutoencoder(device='cpu', lib=L, path=str(tmp_path / 'ck'), **tiny_nets())
+  x = (np.random.default_rng(1).random((4, 8, 8, 1)) < 0.3).astype(np.float32)
+  _, m = vae.optimize(x, track_gradients=True)
+  gk = [k for k in m if k.startswith('_grad/')]
+  assert len(gk) == len(vae.trainable_variables) and '_grad/latents/kernel' in gk
+  vae.save_weights()
+  d = np.load(str(tmp_path / 'ck.npz'), allow_pickle=False)
+  assert 'latents/kernel' in d.files and int(d['__step__']) == 1
+
+
+def test_marginal_log_prob_matches_oracle(L):
+  """variational_autoencoder.py:396-513: one encoder pass, n posterior samples, n*B decodes,
+  log-mean-exp over the samples -- against the oracle with the same noise."""
+  nets = tiny_nets()
+  vae = VariationalAutoencoder(device='cpu', lib=L, **nets)
+  rng = np.random.default_rng(9)
+  N, n, D = 10, 7, 4
+  x = np.clip(rng.random((N, 8, 8, 1)), 1e-6, 1 - 1e-6).astype(np.float32)
+  eps = rng.standard_normal((n, N, D)).astype(np.float32)
+  model = vo.OracleVAE(nets['encoder'].layers, nets['decoder'].layers, (8, 8, 1), D)
+  llk_ref, (lq_ref, lp_ref) = vo.marginal_log_prob(model, oracle_params(vae), x, eps)
+  llk, kl = vae.marginal_log_prob(x, n_mcmc=n, reduce=None, batch_size=4, eps=eps)
+  assert set(llk) == {'image'} and set(kl) == {'latents'}
+  np.testing.assert_allclose(llk['image'].numpy(), llk_ref, rtol=2e-5)
+  np.testing.assert_allclose(kl['latents'][0].numpy(), lq_ref, rtol=2e-5, atol=2e-5)
+  np.testing.assert_allclose(kl['latents'][1].numpy(), lp_ref, rtol=2e-5, atol=2e-5)
+  llk_m, _ = vae.marginal_log_prob(x, n_mcmc=n, batch_size=4, eps=eps)  # reduce = mean
+  assert abs(float(llk_m['image']) - llk_ref.mean()) < 1e-4 * abs(llk_ref.mean())
+  # without explicit noise: finite, and more samples tighten the bound on average
+  a, _ = vae.marginal_log_prob(x, n_mcmc=2, batch_size=5)
+  b, _ = vae.marginal_log_prob(x, n_mcmc=50, batch_size=5)
+  assert np.isfinite(float(a['image'])) and float(b['image']) >= float(a['image']) - 1.0
+
+
+def test_reverse_kl_and_sample_shape(L):
+  nets = tiny_nets()
+  rng = np.random.default_rng(10)
+  B, D = 5, 4
+  x = np.clip(rng.random((B, 8, 8, 1)), 1e-6, 1 - 1e-6).astype(np.float32)
+  eps = rng.standard_normal((B, D)).astype(np.float32)
+  with pytest.raises(TypeError):
+    BetaVAE(beta=2.0, reverse=False, device='cpu', lib=L, **nets)
+  vae = BetaVAE(beta=2.0, reverse=False, analytic=True, device='cpu', lib=L, **nets)
+  model = vo.OracleVAE(nets['encoder'].layers, nets['decoder'].layers, (8, 8, 1), D, beta=2.0,
+                       analytic=True, reverse=False)
+  P = oracle_params(vae)
+  f = model.forward(P, x.astype(np.float64), eps.astype(np.float64))
+  G, _ = model.backward(P, x.astype(np.float64), eps.astype(np.float64), f)
+  llk, kl = vae.elbo_components(x, eps=eps)
+  assert kl['kl_latents'].shape == (1, B)
+  np.testing.assert_allclose(kl['kl_latents'][0].numpy(), f['kl'], rtol=1e-4, atol=1e-4)
+  px, qz = vae.last_outputs
+  np.testing.assert_allclose(qz.KL_divergence(analytic=True, reverse=False).numpy() * 2.0, f['kl'],
+                             rtol=1e-4, atol=1e-4)
+  with pytest.raises(TypeError):
+    qz.KL_divergence(analytic=False, reverse=False)
+  _, m = vae.optimize(x, eps=eps, track_gradients=True, learning_rate=1e-3)
+  for k, g in G.items():
+    got = m['_grad/' + vae.variable_name(k)].numpy()
+    assert np.abs(got - g).max() <= 1e-4 * np.abs(g).max(), k
+  # sample_shape=(3,): [3, B] components, loss = overall mean
+  n = 3
+  v3 = VariationalAutoencoder(sample_shape=(n,), device='cpu', lib=L, **tiny_nets())
+  v3._engine(1).load_params(P)
+  eps3 = rng.standard_normal((n, B, D)).astype(np.float32)
+  llk3, kl3 = v3.elbo_components(x, eps=eps3)
+  assert llk3['llk_image'].shape == (n, B) and kl3['kl_latents'].shape == (n, B)
+  m1 = vo.OracleVAE(nets['encoder'].layers, nets['decoder'].layers, (8, 8, 1), D)
+  for k in range(n):
+    fk = m1.forward(P, x.astype(np.float64), eps3[k].astype(np.float64))
+    np.testing.assert_allclose(llk3['llk_image'][k].numpy(), fk['llk'], rtol=1e-5)
+    np.testing.assert_allclose(kl3['kl_latents'][k].numpy(), fk['kl'], rtol=1e-4, atol=1e-4)
