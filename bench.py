@@ -39,6 +39,10 @@ WORKLOADS = {
     'shapes3d_vae_b256': ('shapes3d', {}, 256, 1.0, None),
     'celeba_betatcvae_b512': ('celeba', {}, 512, 4.0, 'betatc'),
     'mnist_dense_b128': ('dense', {}, 128, 1.0, None),
+    # BASELINE config 3: both optimisers, batch split 128 + 128, whole iteration as one graph
+    'factorvae_shapes3d_b256': ('shapes3d', {}, 256, None, 'factor'),
+    # BASELINE config 5: audio [256, 8000] -> log-mel front-end -> conv VAE, front-end INSIDE the step
+    'speech_vae_b256': ('speech', {}, 256, 1.0, 'speech'),
 }
 
 
@@ -353,8 +357,21 @@ def main():
   nets = get_networks(ds, **kw)
   enc, dec = nets['encoder'].layers, nets['decoder'].layers
   in_shape, zdim = nets['encoder'].input_shape, nets['latents'].event_shape[0]
-  eng = VAEEngine(enc, dec, in_shape, zdim, B, device, observation=nets['observation'].posterior,
-                  tc=kind, world_size=world, seed=1 + rank, force_dp=use_dist)
+  lr = 1e-3
+  use_graph = not args.no_graph
+  fv = None
+  if kind == 'factor':
+    # FactorVAE through the model API (vae.py): x split 128 + 128, VAE step with the
+    # discriminator's TC estimate, discriminator step with its own Adam; one graph per iteration
+    from odin_ai_amd.vae import FactorVAE
+    fv = FactorVAE(device=device, seed=1 + rank, **nets)
+    eng = fv._engine(B // 2)
+    fv._discriminator(B // 2)
+    beta = 1.0
+  else:
+    eng = VAEEngine(enc, dec, in_shape, zdim, B, device, observation=nets['observation'].posterior,
+                    tc=kind if kind == 'betatc' else None, world_size=world, seed=1 + rank,
+                    force_dp=use_dist)
   init_params_(eng, seed=1 + 1000 * rank)  # rank 0's weights win: broadcast below
   rccl = None
   if use_dist:
@@ -369,18 +386,40 @@ def main():
     dist.all_reduce(seen)
     rccl = dict(ranks_seen=int(seen.item()), backend=dist.get_backend(),
                 bucket_bytes=eng.grads.numel() * 4)
-  x = synthetic_batch(args.workload, B, in_shape, device, seed=100 + rank)
-  if not args.no_graph:
-    # the batch is resident in HBM in the buffer the step graph reads (what an on-device input
-    # pipeline would fill), so no per-step device-to-device copy sits in the timed region
+  if kind == 'speech':
+    # raw audio resident in HBM; every step runs the front-end (pre-emphasis, STFT, mel, dB) and
+    # hands the first 96 frames to the VAE step
+    from odin_ai_amd.mel import MelsSpecExtractor
+    g = torch.Generator(device='cpu').manual_seed(100 + rank)
+    t = torch.arange(8000) / 8000.0
+    y = (0.1 * torch.randn(B, 8000, generator=g) +
+         0.5 * torch.sin(2 * math.pi * (200.0 + 1500.0 * t[None] * torch.rand(B, 1, generator=g)) * t[None])
+         ).to(device)
+    ex = MelsSpecExtractor(device=device)
     xb = eng.input_buffer()
-    xb.copy_(x)
-    x = xb
-  lr = 1e-3
-  use_graph = not args.no_graph
+    T = in_shape[0]
 
-  def step():
-    return eng.train_step(x, None, lr=lr, beta=beta, global_clipnorm=100.0, use_graph=use_graph)
+    def step():
+      mel = ex(y)
+      xb.copy_(mel[:, :T].reshape(B, T, in_shape[1], 1))
+      return eng.train_step(xb, None, lr=lr, beta=beta, global_clipnorm=100.0, use_graph=use_graph)
+  elif fv is not None:
+    x = synthetic_batch(args.workload, B, in_shape, device, seed=100 + rank)
+
+    def step():
+      loss, _ = fv.optimize(x, learning_rate=lr, global_clipnorm=100.0, use_graph=use_graph)
+      return eng.out4
+  else:
+    x = synthetic_batch(args.workload, B, in_shape, device, seed=100 + rank)
+    if use_graph:
+      # the batch is resident in HBM in the buffer the step graph reads (what an on-device input
+      # pipeline would fill), so no per-step device-to-device copy sits in the timed region
+      xb = eng.input_buffer()
+      xb.copy_(x)
+      x = xb
+
+    def step():
+      return eng.train_step(x, None, lr=lr, beta=beta, global_clipnorm=100.0, use_graph=use_graph)
 
   # Steady-state conditioning before the W warm-up steps: on a freshly started process the first
   # ~100 ms of replays can run 20-30 % slow (clock / power ramp from idle; measured as one slow
@@ -462,7 +501,7 @@ def main():
   stack = dict(us=round(conv_us, 1), gflop=round(conv_gf, 3),
                tflops=round(conv_gf / conv_us * 1e3, 3),
                frac=round(conv_gf / conv_us * 1e3 / PEAK_MFMA_F32_TFLOPS, 4))
-  hbm = profile_hbm_kernels(eng)
+  hbm = profile_hbm_kernels(eng) if eng.in_shape[-1] in (1, 3) else [None]
   if args.profile_ops:
     for o in ops:
       print(f"# {o['layer']:14s} {o['op']:6s} {o['us']:9.1f} us {o['gflop']:8.3f} GF "
@@ -471,7 +510,7 @@ def main():
 
   # ---- CPU baseline: the same step as a torch-CPU fp32 port, all host cores --------------
   cpu = None
-  if not args.no_cpu_baseline and world == 1:
+  if not args.no_cpu_baseline and world == 1 and kind in (None, 'betatc'):
     from oracle.torch_ref import TorchTrainer, TorchVAE
     # torch-CPU scales to ~32 threads on this step (measured 8..128 on the GPU box's host:
     # 32 is the fastest), so the baseline uses min(32, cores) threads and reports that count

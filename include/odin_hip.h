@@ -125,13 +125,19 @@ int odin_latent_bwd(const float* p, const float* eps, const float* z, const floa
 /* ---- observation log-likelihood fused forward+backward
  * Independent(Bernoulli(logits),3).log_prob(x) (image_networks.py:87-93;
  * variational_autoencoder.py:528-530): llk_part[b][part] partial sums (n_part per
- * sample), dlogits = -(x - sigmoid(l)) * scale[0]  (scale = DEVICE scalar 1/B). */
+ * sample), dlogits = -(x - sigmoid(l)) * scale[0]  (scale = DEVICE scalar 1/B).
+ * A NULL logits pointer is a dry run that only reports n_part. */
 int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, float* llk_part,
                                 float* dlogits, const float* scale, int B, int n_per_sample,
                                 int* n_part_out, void* stream);
 /* Independent(Normal(loc, scale)) with params = split(h,2,axis=-1)
- * (image_networks.py:95-102): softplus1 != 0 -> scale = softplus(raw + softplus^-1(1))
- * (GaussianLayer, odin/bay/layers/continuous.py:196-260; odin/backend/maths.py:279-281). */
+ * (image_networks.py:95-102): softplus1 = 1 -> scale = softplus(raw + softplus^-1(1))
+ * (GaussianLayer, odin/bay/layers/continuous.py:196-260; odin/backend/maths.py:279-281);
+ * softplus1 = 2 -> the same (loc | raw) split parameterises
+ * QuantizedLogistic(loc, softplus(raw) + e^-7, low=0, high=255, inputs_domain='sigmoid')
+ * (image_networks.py:55-71; odin/bay/distributions/quantized.py:50-204): x in [0,1], pixel value
+ * y = x*255, log P[Y = y] of the discretised logistic, gradients wrt loc and raw.
+ * A NULL h is a dry run that only reports n_part (partials per sample). */
 int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float* llk_part, float* dh,
                                const float* scale, int B, int n_pix, int C, int softplus1,
                                int* n_part_out, void* stream);
@@ -225,13 +231,18 @@ int odin_gather_normalize_u8(const uint8_t* data, const int32_t* idx, float* out
                              float premul, int mode, void* stream);
 
 /* ---- speech front-end: pre-emphasis -> STFT -> |.|^2 -> Slaney mel -> dB
- * (odin/preprocessing/signal.py:955-967,1442-1562,1623-1691,636-680).
+ * (odin/preprocessing/signal.py:955-967,1442-1562,1623-1691,636-680), computed in float64 like
+ * the reference, stored as float32.
  * y [B,n_samples] -> out [B,n_frames,n_mels], n_frames = 1 + (n_samples-frame_length)/step;
- * window [frame_length] (already divided by its sum); melfb_t [n_fft/2+1, n_mels] = the
- * mel_filters basis TRANSPOSED; top_db < 0 disables the floor; log_output=0 returns power. */
-int odin_stft_mel_db(const float* y, const float* window, const float* melfb_t, float* out, int B,
+ * window [frame_length] float64 (already divided by its sum); twiddles [n_fft/2][2] float64 =
+ * (cos, -sin)(2 pi k / n_fft); the mel_filters basis [n_mels, n_fft/2+1] as its non-zero band
+ * per filter: fb_band [n_mels][3] = {first bin, count, offset into fb_vals}, fb_vals float64;
+ * n_fft in {32, 128, 512, 2048}; top_db < 0 disables the per-utterance floor; log_output=0
+ * returns the mel power. */
+int odin_stft_mel_db(const float* y, const double* window, const double* twiddles,
+                     const double* fb_vals, const int32_t* fb_band, float* out, int B,
                      int n_samples, int frame_length, int step_length, int n_fft, int n_mels,
-                     float preemph, float top_db, int log_output, void* stream);
+                     double preemph, double top_db, int log_output, void* stream);
 
 /* diagnostics only: device buffer (>= 64 int64) that receives in-kernel cycle stamps of the
  * conv kernels' workgroup 0 (NULL disables; never set in production) */

@@ -1,140 +1,200 @@
-// mel.hip -- speech front-end on the GPU: pre-emphasis -> framing -> window -> 512-point
-// FFT -> |.|^2 -> Slaney mel filterbank -> dB, batched over utterances.
+// mel.hip -- speech front-end on the GPU: pre-emphasis -> framing -> window -> real FFT ->
+// |.|^2 -> Slaney mel filterbank -> dB with the per-utterance top_db floor, batched over
+// utterances, ONE launch.
 //
 // Restates the reference's offline numpy path (odin/preprocessing/signal.py: pre_emphasis
 // :955-967, stft :1442-1562, power_spectrogram :1623-1648, mels_spectrogram :1650-1691,
-// power2db :636-680; wrapped by speech.py:655-929).  The reference runs one utterance at
-// a time on CPU workers; here a workgroup transforms FPB frames at once entirely in LDS:
-//   1. samples are pre-emphasised, windowed (window already carries the 1/sum(w) scale) and
-//      written to LDS in bit-reversed order (zero padded to n_fft),
-//   2. radix-2 decimation-in-time butterflies, twiddles from an LDS table,
-//   3. the power spectrum stays in LDS and is contracted with the [bins, n_mels] filterbank
-//      (stored transposed so that lanes read consecutive mel bands),
-//   4. 10*log10(max(1e-10, .)) is written; a second launch applies the per-utterance
-//      `max - top_db` floor (a global maximum over the utterance, as power2db does).
-// HBM-bound by design: reads 4 B/sample, writes 4 B/(frame, band).
+// power2db :636-680; wrapped by speech.py:655-929).  The reference computes in FLOAT64
+// throughout (fp32 samples promoted by the float64 window) and its dB output spans 80 dB of
+// dynamic range: an fp32 FFT cannot hold the weak bins to 1e-4 (its error floor sits ~1e-7 of
+// the strongest bin's amplitude).  So this path computes in float64 too -- the whole front-end
+// is ~1.3 GFLOP per 256 utterances, noise beside the training step, and MI355X runs fp64 vector
+// code at half its fp32 rate -- and only the stored result is fp32.
+//
+// One workgroup per utterance (the top_db floor needs the utterance's global maximum):
+//   1. FPB frames at a time: samples are pre-emphasised, windowed (the window carries 1/sum(w))
+//      and packed two real samples per complex point, z[n] = x[2n] + i x[2n+1], into LDS in base-4
+//      digit-reversed order;
+//   2. an N/2-point complex FFT, radix-4 decimation in time, twiddles from a float64 table in
+//      LDS; the real-input spectrum X[k], k = 0..N/2, follows from Z[k] and conj(Z[N/2-k]);
+//   3. the power spectrum stays in LDS and is contracted with the mel filterbank, stored as its
+//      non-zero band per filter (Slaney triangles touch 2..40 of the 257 bins);
+//   4. 10*log10(max(1e-10, .)) is written and the running maximum kept; after the last frame the
+//      workgroup re-reads its own [n_frames, n_mels] block (L2-hot) and applies max - top_db.
+// HBM traffic: 4 B/sample read, 4 B/(frame, band) written (+ the same again through L2).
 #include "odin_device.h"
 #include "odin_internal.h"
 
 namespace {
 
-constexpr int FPB = 4;  // frames per workgroup pass
+struct cplx {
+  double re, im;
+};
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+  return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
 
-__global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__ y,
-                                                       const float* __restrict__ window,
-                                                       const float* __restrict__ fbT,
-                                                       float* __restrict__ out, int n_samples,
-                                                       int frame_length, int step, int n_fft,
-                                                       int log2n, int n_frames, int n_mels,
-                                                       float preemph, int log_output) {
-  ODIN_DYN_SMEM(float, smem);
-  const int nb = n_fft / 2 + 1;
-  float* re = smem;                       // [FPB][n_fft]
-  float* im = re + FPB * n_fft;           // [FPB][n_fft]
-  float* twc = im + FPB * n_fft;          // [n_fft/2]
-  float* tws = twc + n_fft / 2;           // [n_fft/2]
-  float* pw = tws + n_fft / 2;            // [FPB][nb]
-  const int tid = threadIdx.x;
-  const int b = blockIdx.y, t0 = blockIdx.x * FPB;
-  const float* yb = y + (size_t)b * n_samples;
-  for (int k = tid; k < n_fft / 2; k += 256) {
-    float s, c;
-    sincosf(-6.283185307179586f * (float)k / (float)n_fft, &s, &c);
-    twc[k] = c;
-    tws[k] = s;
+// base-4 digit reversal of an index of 2*LOG4 bits
+__device__ __forceinline__ int rev4(int n, int log4) {
+  int r = 0;
+  for (int d = 0; d < log4; ++d) {
+    r = (r << 2) | (n & 3);
+    n >>= 2;
   }
-  for (int e = tid; e < FPB * n_fft; e += 256) {
-    const int f = e / n_fft, n = e - f * n_fft;
-    const int t = t0 + f;
-    float v = 0.f;
-    if (t < n_frames && n < frame_length) {
-      const int i = t * step + n;
-      float s = yb[i];
-      if (preemph > 0.f && i > 0) s -= preemph * yb[i - 1];
-      v = s * window[n];
-    }
-    unsigned r = __brev((unsigned)n) >> (32 - log2n);
-    re[f * n_fft + r] = v;
-    im[f * n_fft + r] = 0.f;
-  }
-  __syncthreads();
-  for (int s = 1; s <= log2n; ++s) {
-    const int half = 1 << (s - 1);
-    for (int e = tid; e < FPB * (n_fft / 2); e += 256) {
-      const int f = e / (n_fft / 2), j = e - f * (n_fft / 2);
-      const int k = j & (half - 1);
-      const int i0 = ((j >> (s - 1)) << s) + k, i1 = i0 + half;
-      const int tw = k * (n_fft >> s);
-      const float c = twc[tw], sn = tws[tw];
-      float* R = re + f * n_fft;
-      float* I = im + f * n_fft;
-      const float xr = R[i1], xi = I[i1];
-      const float tr = c * xr - sn * xi, ti = c * xi + sn * xr;
-      const float ur = R[i0], ui = I[i0];
-      R[i1] = ur - tr; I[i1] = ui - ti;
-      R[i0] = ur + tr; I[i0] = ui + ti;
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < FPB * nb; e += 256) {
-    const int f = e / nb, k = e - f * nb;
-    const float a = re[f * n_fft + k], c = im[f * n_fft + k];
-    pw[e] = a * a + c * c;
-  }
-  __syncthreads();
-  for (int o = tid; o < FPB * n_mels; o += 256) {
-    const int f = o / n_mels, m = o - f * n_mels;
-    const int t = t0 + f;
-    if (t >= n_frames) continue;
-    const float* P = pw + f * nb;
-    float acc = 0.f;
-    for (int k = 0; k < nb; ++k) acc = fmaf(fbT[(size_t)k * n_mels + m], P[k], acc);
-    if (log_output) acc = 10.f * log10f(fmaxf(1e-10f, acc));
-    out[((size_t)b * n_frames + t) * n_mels + m] = acc;
-  }
+  return r;
 }
 
-// one workgroup per utterance: global max, then floor at max - top_db (power2db)
-__global__ __launch_bounds__(256) void topdb_kernel(float* out, int n, float top_db) {
+// tw: e^{-2 pi i k / n_fft}, k = 0 .. n_fft/2 - 1 (float64, host-computed): serves both the
+// N/2-point FFT (W_{N/2}^k = tw[2k]) and the real-input split (W_N^k = tw[k]).
+__global__ __launch_bounds__(256) void stft_mel_f64_kernel(
+    const float* __restrict__ y, const double* __restrict__ window, const double* __restrict__ tw_g,
+    const double* __restrict__ fb_vals, const int* __restrict__ fb_band, float* __restrict__ out,
+    int n_samples, int frame_length, int step, int n_fft, int log4, int fpb, int n_frames,
+    int n_mels, double preemph, double top_db, int log_output) {
+  ODIN_DYN_SMEM(double, smem);
+  const int H = n_fft / 2, nb = H + 1;
+  cplx* tw = reinterpret_cast<cplx*>(smem);                 // [H]
+  cplx* Z = tw + H;                                          // [fpb][H]
+  double* pw = reinterpret_cast<double*>(Z + (size_t)fpb * H);  // [fpb][nb | pad]
+  const int nbp = nb | 1;                                    // odd pitch
   __shared__ float red[4];
-  float* o = out + (size_t)blockIdx.x * n;
-  float m = -3.0e38f;
-  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, o[i]);
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const float* yb = y + (size_t)b * n_samples;
+  float* ob = out + (size_t)b * n_frames * n_mels;
+  for (int k = tid; k < H; k += 256) tw[k] = {tw_g[2 * k], tw_g[2 * k + 1]};
+  float vmax = -3.0e38f;
+  for (int t0 = 0; t0 < n_frames; t0 += fpb) {
+    __syncthreads();  // previous pass is done with Z / pw (and tw is staged)
+    // ---- 1. stage: pre-emphasis, window, pack, digit-reverse ----
+    for (int e = tid; e < fpb * H; e += 256) {
+      const int f = e / H, n = e - f * H;
+      const int t = t0 + f;
+      cplx v = {0.0, 0.0};
+      if (t < n_frames) {
+        const int j0 = 2 * n, j1 = 2 * n + 1;
+        if (j0 < frame_length) {
+          const int i = t * step + j0;
+          double s = (double)yb[i];
+          if (preemph > 0.0 && i > 0) s -= preemph * (double)yb[i - 1];
+          v.re = s * window[j0];
+        }
+        if (j1 < frame_length) {
+          const int i = t * step + j1;
+          double s = (double)yb[i];
+          if (preemph > 0.0) s -= preemph * (double)yb[i - 1];
+          v.im = s * window[j1];
+        }
+      }
+      Z[(size_t)f * H + rev4(n, log4)] = v;
+    }
+    __syncthreads();
+    // ---- 2. radix-4 DIT stages: L = 4, 16, .., H ----
+    for (int s = 1; s <= log4; ++s) {
+      const int L = 1 << (2 * s), Q = L >> 2;
+      const int tstep = H / L * 2;  // W_L^j = e^{-2 pi i j / L} = tw[j * n_fft / L / ... ] -> index j * (n_fft / L)
+      for (int e = tid; e < fpb * (H / 4); e += 256) {
+        const int f = e / (H / 4), q = e - f * (H / 4);
+        const int j = q % Q, base = (q / Q) * L;
+        cplx* zf = Z + (size_t)f * H + base + j;
+        // W_L^{r j}: tw holds e^{-2 pi i k / n_fft}; W_L^j = tw[j * n_fft / L], n_fft / L = 2H / L
+        const int ti = j * tstep;
+        const cplx a = zf[0];
+        cplx bq = zf[Q], c = zf[2 * Q], d = zf[3 * Q];
+        if (j != 0) {
+          bq = cmul(bq, tw[ti]);
+          c = cmul(c, tw[2 * ti]);
+          // 3 * ti can reach 3/2 H > H: W^{k + H} = -W^k ... for an n_fft-periodic table of H
+          // entries: tw index k >= H means e^{-2 pi i k / n_fft} = -tw[k - H]
+          const int t3 = 3 * ti;
+          cplx w3 = t3 < H ? tw[t3] : cplx{-tw[t3 - H].re, -tw[t3 - H].im};
+          d = cmul(d, w3);
+        }
+        const cplx apc = cadd(a, c), amc = csub(a, c), bpd = cadd(bq, d), bmd = csub(bq, d);
+        // -i * (b - d) = (bmd.im, -bmd.re)
+        const cplx mi_bmd = {bmd.im, -bmd.re};
+        zf[0] = cadd(apc, bpd);
+        zf[Q] = cadd(amc, mi_bmd);
+        zf[2 * Q] = csub(apc, bpd);
+        zf[3 * Q] = csub(amc, mi_bmd);
+      }
+      __syncthreads();
+    }
+    // ---- 3. real-input split and power spectrum: X[k] = E[k] + W_N^k O[k] ----
+    for (int e = tid; e < fpb * nb; e += 256) {
+      const int f = e / nb, k = e - f * nb;
+      const cplx* zf = Z + (size_t)f * H;
+      const cplx zk = zf[k == H ? 0 : k];
+      const cplx zc = zf[(H - k) % H];  // conj taken below
+      const cplx E = {0.5 * (zk.re + zc.re), 0.5 * (zk.im - zc.im)};
+      // O = -i/2 (Z[k] - conj(Z[H-k])) = ( (zk.im + zc.im)/2 , -(zk.re - zc.re)/2 )
+      const cplx O = {0.5 * (zk.im + zc.im), -0.5 * (zk.re - zc.re)};
+      const cplx w = k < H ? tw[k] : cplx{-1.0, 0.0};
+      const cplx X = cadd(E, cmul(w, O));
+      pw[(size_t)f * nbp + k] = X.re * X.re + X.im * X.im;
+    }
+    __syncthreads();
+    // ---- 4. mel bands, dB ----
+    for (int o = tid; o < fpb * n_mels; o += 256) {
+      const int f = o / n_mels, m = o - f * n_mels;
+      const int t = t0 + f;
+      if (t >= n_frames) continue;
+      const int k0 = fb_band[3 * m], cnt = fb_band[3 * m + 1], off = fb_band[3 * m + 2];
+      const double* P = pw + (size_t)f * nbp + k0;
+      double acc = 0.0;
+      for (int k = 0; k < cnt; ++k) acc = fma(fb_vals[off + k], P[k], acc);
+      float r;
+      if (log_output) r = (float)(10.0 * log10(fmax(1e-10, acc)));
+      else r = (float)acc;
+      ob[(size_t)t * n_mels + m] = r;
+      vmax = fmaxf(vmax, r);
+    }
+  }
+  if (!log_output || top_db < 0.0) return;
+  // ---- per-utterance top_db floor (power2db: log_spec.max() - top_db over the whole utterance)
 #pragma unroll
-  for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  const float floor_ = m - top_db;
-  for (int i = threadIdx.x; i < n; i += 256) o[i] = fmaxf(o[i], floor_);
+  for (int k = 32; k >= 1; k >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, k));
+  if ((tid & 63) == 0) red[tid >> 6] = vmax;
+  __syncthreads();  // also orders this workgroup's stores before its re-reads below
+  const float floor_ = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - (float)top_db;
+  const int n = n_frames * n_mels;
+  for (int i = tid; i < n; i += 256) {
+    const float v = ob[i];
+    if (v < floor_) ob[i] = floor_;
+  }
 }
 
 }  // namespace
 
-extern "C" int odin_stft_mel_db(const float* y, const float* window, const float* melfb_t,
-                                float* out, int B, int n_samples, int frame_length,
-                                int step_length, int n_fft, int n_mels, float preemph,
-                                float top_db, int log_output, void* stream) {
-  int log2n = 0;
-  while ((1 << log2n) < n_fft) ++log2n;
-  if ((1 << log2n) != n_fft || n_fft < frame_length || n_fft > 2048)
-    return odin_fail(-2, "stft_mel_db: n_fft must be a power of two in [frame_length, 2048]");
+extern "C" int odin_stft_mel_db(const float* y, const double* window, const double* twiddles,
+                                const double* fb_vals, const int32_t* fb_band, float* out, int B,
+                                int n_samples, int frame_length, int step_length, int n_fft,
+                                int n_mels, double preemph, double top_db, int log_output,
+                                void* stream) {
+  int log4 = 0;
+  while ((1 << (2 * log4)) < n_fft / 2) ++log4;
+  if (2 * (1 << (2 * log4)) != n_fft || n_fft < frame_length || n_fft > 2048 || n_fft < 32)
+    return odin_fail(-2, "stft_mel_db: n_fft must be 2 * 4^k in [32, 2048] and >= frame_length "
+                         "(32, 128, 512, 2048)");
   if (n_samples < frame_length) return odin_fail(-2, "stft_mel_db: utterance shorter than a frame");
   const int n_frames = 1 + (n_samples - frame_length) / step_length;
-  const int nb = n_fft / 2 + 1;
-  size_t lds = (size_t)(2 * FPB * n_fft + n_fft + FPB * nb) * 4;
-  dim3 grid((n_frames + FPB - 1) / FPB, B, 1);
+  const int H = n_fft / 2, nbp = (H + 1) | 1;
+  int fpb = 4096 / H;  // complex points per pass: 64 KB of float64 pairs
+  if (fpb > 16) fpb = 16;
+  if (fpb < 1) fpb = 1;
+  const size_t lds = ((size_t)2 * H + (size_t)2 * fpb * H + (size_t)fpb * nbp) * 8;
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_mel_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_mel_f64_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH(stft_mel_kernel, grid, dim3(256), lds, stream, y, window, melfb_t, out, n_samples,
-              frame_length, step_length, n_fft, log2n, n_frames, n_mels, preemph, log_output);
-  if (log_output && top_db >= 0.f)
-    ODIN_LAUNCH(topdb_kernel, dim3(B), dim3(256), 0, stream, out, n_frames * n_mels, top_db);
+  ODIN_LAUNCH(stft_mel_f64_kernel, dim3(B), dim3(256), lds, stream, y, window, twiddles, fb_vals,
+              (const int*)fb_band, out, n_samples, frame_length, step_length, n_fft, log4, fpb,
+              n_frames, n_mels, preemph, top_db, log_output);
   return odin_check_launch("stft_mel_db");
 }

@@ -128,6 +128,65 @@ __global__ __launch_bounds__(256) void elbo_bernoulli_kernel(const float* __rest
 }
 
 
+
+// ---- QuantizedLogistic(loc, softplus(raw) + e^-7, low=0, high=255, 'sigmoid') -------------
+// odin/bay/distributions/quantized.py:50-204 over TFP's QuantizedDistribution (restated in
+// oracle/vae_oracle.py: qlogistic_log_prob_elem): log P[Y = y] = log(exp(big) - exp(small)) with
+// the survival-function pair right of the median and the cdf pair left of it; floor / ceil are
+// taken of y = x * 255 formed in fp32, as the reference does.  Returns the element's log-prob and
+// its derivatives wrt (loc, raw).
+constexpr float QL_LOW = 0.f, QL_HIGH = 255.f, QL_SUPPORT = 127.5f, QL_MIN_SCALE = 9.1188196555451624e-4f;
+__device__ __forceinline__ float softplus_acc(float u) { return fmaxf(u, 0.f) + log1pf(expf(-fabsf(u))); }
+__device__ __forceinline__ float sigmoid_acc(float u) {
+  const float e = expf(-fabsf(u));
+  const float r = 1.f / (1.f + e);
+  return u >= 0.f ? r : e * r;
+}
+__device__ __forceinline__ float qlogistic_elem(float loc, float raw, float t, float& dloc, float& draw) {
+  const float m = QL_LOW + QL_SUPPORT * (loc + 1.f);
+  const float s = (softplus_acc(raw) + QL_MIN_SCALE) * QL_SUPPORT;
+  const float inv_s = 1.f / s;
+  const float y = t * QL_HIGH;
+  const float NINF = -__builtin_inff();
+  // survival side: j = ceil(y), ceil(y - 1); cdf side: j = floor(y), floor(y - 1)
+  const float jc = ceilf(y), jc1 = ceilf(y - 1.f), jf = floorf(y), jf1 = floorf(y - 1.f);
+  const float u_s = (jc + 0.5f - m) * inv_s, u_s1 = (jc1 + 0.5f - m) * inv_s;
+  const float u_c = (jf + 0.5f - m) * inv_s, u_c1 = (jf1 + 0.5f - m) * inv_s;
+  const float lsy = jc < QL_HIGH ? (jc < QL_LOW ? 0.f : -softplus_acc(u_s)) : NINF;
+  const float lcy = jf < QL_HIGH ? (jf < QL_LOW ? NINF : -softplus_acc(-u_c)) : 0.f;
+  const bool use_sf = lsy < lcy;
+  float big, small, gb, gs, ub, us;  // g* = d(term)/du (0 on the clamped branches)
+  if (use_sf) {
+    big = jc1 < QL_HIGH ? (jc1 < QL_LOW ? 0.f : -softplus_acc(u_s1)) : NINF;
+    small = lsy;
+    gb = (jc1 >= QL_LOW && jc1 < QL_HIGH) ? -sigmoid_acc(u_s1) : 0.f;
+    gs = (jc >= QL_LOW && jc < QL_HIGH) ? -sigmoid_acc(u_s) : 0.f;
+    ub = u_s1; us = u_s;
+  } else {
+    big = lcy;
+    small = jf1 < QL_HIGH ? (jf1 < QL_LOW ? NINF : -softplus_acc(-u_c1)) : 0.f;
+    gb = (jf >= QL_LOW && jf < QL_HIGH) ? sigmoid_acc(-u_c) : 0.f;
+    gs = (jf1 >= QL_LOW && jf1 < QL_HIGH) ? sigmoid_acc(-u_c1) : 0.f;
+    ub = u_c; us = u_c1;
+  }
+  float res, wb, ws;
+  if (small == NINF) {
+    res = big; wb = 1.f; ws = 0.f;
+  } else {
+    const float d = big - small;                        // >= 0
+    const float l1m = d < 0.6931471805599453f ? logf(-expm1f(-d)) : log1pf(-expf(-d));
+    res = big + l1m;
+    const float r = expf(-d);                           // e^small / e^big
+    wb = 1.f / (1.f - r);
+    ws = -r * wb;
+  }
+  const float dm = (wb * gb + ws * gs) * (-inv_s);
+  const float ds = (wb * gb * ub + ws * gs * us) * (-inv_s);
+  dloc = dm * QL_SUPPORT;
+  draw = ds * QL_SUPPORT * sigmoid_acc(raw);
+  return res;
+}
+
 // ---- streaming form (HBM roofline): one WAVE owns U*256 contiguous elements of one sample.
 // All 2*U 16-byte loads of a lane are issued before the first use (U >= 3: >= 6 loads in flight
 // per lane, ~100 KB per CU at 16 waves), there is no workgroup barrier and no LDS: the
@@ -188,8 +247,15 @@ __global__ __launch_bounds__(256) void elbo_gaussian_kernel(const float* __restr
       int pix = i / C, c = i - pix * C;
       size_t hb = ((size_t)b * (N / C) + pix) * 2 * C;
       float loc = h[hb + c], raw = h[hb + C + c], t = x[(size_t)b * N + i];
+      if (softplus1 == 2) {  // QuantizedLogistic head
+        float gl, gr;
+        acc += qlogistic_elem(loc, raw, t, gl, gr);
+        dh[hb + c] = -gl * sc;
+        dh[hb + C + c] = -gr * sc;
+        continue;
+      }
       float sd, dsd;
-      if (softplus1) { sd = softplus_f(raw + SOFTPLUS_INV1); dsd = sigmoid_f(raw + SOFTPLUS_INV1); }
+      if (softplus1 == 1) { sd = softplus_f(raw + SOFTPLUS_INV1); dsd = sigmoid_f(raw + SOFTPLUS_INV1); }
       else { sd = raw; dsd = 1.f; }
       float d = (t - loc) / sd;
       acc += -0.5f * d * d - odin_log(sd) - 0.5f * LOG2PI_F;
@@ -255,8 +321,15 @@ __global__ __launch_bounds__(256) void elbo_gaussian_stream_kernel(
       for (int c = 0; c < C; ++c) {
         const float loc = hf[pp * 2 * C + c], raw = hf[pp * 2 * C + C + c];
         const float t = xf[pp * C + c];
+        if (SP1 == 2) {  // QuantizedLogistic head
+          float gl, gr;
+          acc += qlogistic_elem(loc, raw, t, gl, gr);
+          of[pp * 2 * C + c] = -gl * sc;
+          of[pp * 2 * C + C + c] = -gr * sc;
+          continue;
+        }
         float sd, dsd;
-        if (SP1) {
+        if (SP1 == 1) {
           // softplus1(raw) = softplus(raw + softplus^-1(1)); its derivative = sigmoid(same)
           const float a = raw + SOFTPLUS_INV1;
           const float e = odin_exp2(-1.4426950408889634f * fabsf(a));
@@ -631,9 +704,11 @@ extern "C" int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float*
 #define ODIN_GAUSS_STREAM(CC, GG, SP)                                                           \
   ODIN_LAUNCH((elbo_gaussian_stream_kernel<CC, GG, SP>), grid, dim3(256), 0, stream,            \
               (const float4*)h, (const float4*)x, llk_part, (float4*)dh, scale, n_waves)
-    if (C == 3 && softplus1) ODIN_GAUSS_STREAM(3, 1, 1);
+    if (C == 3 && softplus1 == 2) ODIN_GAUSS_STREAM(3, 1, 2);
+    else if (C == 3 && softplus1 == 1) ODIN_GAUSS_STREAM(3, 1, 1);
     else if (C == 3) ODIN_GAUSS_STREAM(3, 1, 0);
-    else if (softplus1) ODIN_GAUSS_STREAM(1, 2, 1);
+    else if (softplus1 == 2) ODIN_GAUSS_STREAM(1, 2, 2);
+    else if (softplus1 == 1) ODIN_GAUSS_STREAM(1, 2, 1);
     else ODIN_GAUSS_STREAM(1, 2, 0);
 #undef ODIN_GAUSS_STREAM
     return odin_check_launch("elbo_gaussian");

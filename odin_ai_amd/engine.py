@@ -286,6 +286,8 @@ class NetProgram:
 # --------------------------------------------------------------------------------------
 # the whole VAE step
 # --------------------------------------------------------------------------------------
+# `softplus1` argument of odin_elbo_gaussian_fwd_bwd per two-parameter observation
+OBS_MODE = {'gaussian': 0, 'gaussian_softplus1': 1, 'qlogistic': 2}
 H_ALPHA, H_B1, H_B2, H_EPS, H_GSCALE, H_INVB, H_KLW, H_BETA, H_TCCOEF, H_TCGRAD = range(10)
 N_HYPER = 16
 
@@ -293,7 +295,7 @@ N_HYPER = 16
 class VAEEngine:
   """encoder -> q(z|x) -> decoder -> ELBO -> backward -> Adam for a FIXED batch size.
 
-  observation: 'bernoulli' | 'gaussian' | 'gaussian_softplus1'
+  observation: 'bernoulli' | 'gaussian' | 'gaussian_softplus1' | 'qlogistic'
   tc: None | 'betatc' (total_correlation, weight (beta-1))
   """
 
@@ -364,7 +366,7 @@ class VAEEngine:
     else:
       Cc = self.in_shape[-1]
       self.lib.odin_elbo_gaussian_fwd_bwd(None, None, None, None, None, B, n_per // Cc, Cc,
-                                          int(observation == 'gaussian_softplus1'),
+                                          OBS_MODE[observation],
                                           C.byref(npart), None)
     self.llk_part = torch.empty(B * max(npart.value, (n_per + 1023) // 1024), **f32)
     self.llk = torch.empty(B, **f32)
@@ -547,7 +549,7 @@ class VAEEngine:
       Cc = self.in_shape[-1]
       lib.odin_elbo_gaussian_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
                                      gl.data_ptr(), self.hp(H_INVB), B, self.n_per // Cc, Cc,
-                                     int(self.observation == 'gaussian_softplus1'),
+                                     OBS_MODE[self.observation],
                                      C.byref(npart), st)
     lib.odin_sum_parts(self.llk_part.data_ptr(), npart.value, out.data_ptr(), B, st)
     return out
@@ -604,7 +606,7 @@ class VAEEngine:
       Cc = self.in_shape[-1]
       lib.odin_elbo_gaussian_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
                                      gl.data_ptr(), self.hp(H_INVB), B, self.n_per // Cc, Cc,
-                                     int(self.observation == 'gaussian_softplus1'),
+                                     OBS_MODE[self.observation],
                                      C.byref(npart), st)
     self.n_part = npart.value
     tcp = None

@@ -80,10 +80,22 @@ class MelsSpecExtractor:
                                ('cuda' if torch.cuda.is_available() else 'cpu'))
     self.lib = lib if lib is not None else _lib.load()
     w = periodic_window(window, self.frame_length)
-    self.window = torch.tensor(w / w.sum(), dtype=torch.float32, device=self.device)
+    f64 = dict(dtype=torch.float64, device=self.device)
+    self.window = torch.tensor(w / w.sum(), **f64)
+    k = np.arange(self.n_fft // 2, dtype=np.float64)
+    ang = 2.0 * np.pi * k / self.n_fft
+    self.twiddles = torch.tensor(np.stack([np.cos(ang), -np.sin(ang)], 1), **f64).contiguous()
     fb = mel_filters(self.sr, self.n_fft, self.n_mels, int(fmin), int(fmax))
-    self.melfb_t = torch.tensor(np.ascontiguousarray(fb.T), dtype=torch.float32,
-                                device=self.device)
+    self.mel_basis = fb
+    # the kernel contracts each filter over its non-zero band only
+    band, vals = [], []
+    for m in range(self.n_mels):
+      nz = np.nonzero(fb[m])[0]
+      k0, k1 = (int(nz[0]), int(nz[-1]) + 1) if len(nz) else (0, 0)
+      band.append((k0, k1 - k0, len(vals)))
+      vals.extend(fb[m, k0:k1].tolist())
+    self.fb_vals = torch.tensor(np.asarray(vals if vals else [0.0]), **f64)
+    self.fb_band = torch.tensor(np.asarray(band, np.int32), dtype=torch.int32, device=self.device)
 
   def n_frames(self, n_samples: int) -> int:
     return 1 + (n_samples - self.frame_length) // self.step_length
@@ -98,9 +110,24 @@ class MelsSpecExtractor:
     B, n = y.shape
     out = torch.empty(B, self.n_frames(n), self.n_mels, dtype=torch.float32, device=self.device)
     st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == 'cuda' else None
-    self.lib.odin_stft_mel_db(y.data_ptr(), self.window.data_ptr(), self.melfb_t.data_ptr(),
-                              out.data_ptr(), B, n, self.frame_length, self.step_length,
-                              self.n_fft, self.n_mels, self.preemph, self.top_db, int(self.log), st)
+    self.lib.odin_stft_mel_db(y.data_ptr(), self.window.data_ptr(), self.twiddles.data_ptr(),
+                              self.fb_vals.data_ptr(), self.fb_band.data_ptr(), out.data_ptr(), B,
+                              n, self.frame_length, self.step_length, self.n_fft, self.n_mels,
+                              self.preemph, self.top_db, int(self.log), st)
     return out[0] if squeeze else out
 
   __call__ = transform
+
+
+def spectrogram_batch(mel: torch.Tensor, n_frames: int, pad_value: Optional[float] = None
+                      ) -> torch.Tensor:
+  """[B, T, n_mels] log-mel -> the [B, n_frames, n_mels, 1] input of `speech_networks`: the first
+  n_frames frames, or right-padded with `pad_value` (default: the batch minimum, i.e. the top_db
+  floor) when the utterances are shorter (fuel/audio_data.py:236-260 crops / pads to max_length)."""
+  B, T, M = mel.shape
+  if T >= n_frames:
+    return mel[:, :n_frames].reshape(B, n_frames, M, 1).contiguous()
+  pv = float(mel.min()) if pad_value is None else float(pad_value)
+  out = torch.full((B, n_frames, M), pv, dtype=mel.dtype, device=mel.device)
+  out[:, :T] = mel
+  return out.reshape(B, n_frames, M, 1)

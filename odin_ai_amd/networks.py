@@ -58,7 +58,8 @@ class RVconf:
     return n
 
 
-_OBS_PARAMS = {'bernoulli': 1, 'gaussian': 2, 'gaus': 2, 'normal': 2, 'gaussian_softplus1': 2}
+_OBS_PARAMS = {'bernoulli': 1, 'gaussian': 2, 'gaus': 2, 'normal': 2, 'gaussian_softplus1': 2,
+               'qlogistic': 2}
 
 
 def _observation(input_shape, distribution: str) -> Tuple[int, RVconf]:
@@ -69,8 +70,8 @@ def _observation(input_shape, distribution: str) -> Tuple[int, RVconf]:
   if distribution not in _OBS_PARAMS:
     raise ValueError(
         f"observation {distribution!r} is outside this build's scope "
-        f"(supported: bernoulli, gaussian, gaussian_softplus1; QuantizedLogistic is listed "
-        f"as 'next' in SURVEY.md section 8f)")
+        f"(supported: bernoulli, gaussian, gaussian_softplus1, qlogistic; the 10-component "
+        f"'mixqlogistic' (quantized.py:206-330) is not built)")
   name = {'gaus': 'gaussian', 'normal': 'gaussian'}.get(distribution, distribution)
   return _OBS_PARAMS[distribution], RVconf(tuple(input_shape), name, projection=False,
                                            name='image')
@@ -114,8 +115,11 @@ def shapes3d_networks(qz='mvndiag', zdim=None, **kwargs):
 def celeba_networks(qz='mvndiag', zdim=None, activation='elu', is_semi_supervised=False,
                     is_hierarchical=False, centerize_image=True, distribution='bernoulli',
                     n_channels=3, **kwargs):
-  """image_networks.py:661-725.  The reference's observation for CelebA is broken as
-  shipped (:714); Bernoulli (3 maps) or Gaussian (6 maps) heads are offered."""
+  """image_networks.py:661-725.  The reference means `distribution='qlogistic'` here (decoder5
+  emits 2*C maps, :697; `_parse_distribution(input_shape, 'qlogistic')`, :714) but stores the
+  3-tuple that call returns as the observation, so the model cannot be built as shipped (SURVEY
+  a12).  `distribution='qlogistic'` gives the intended model; Bernoulli (3 maps) and Gaussian
+  (6 maps) heads are offered too."""
   if is_hierarchical or is_semi_supervised:
     raise NotImplementedError('hierarchical / semi-supervised stacks are out of scope (SURVEY 8)')
   if zdim is None:
@@ -184,12 +188,51 @@ def dense_networks(input_shape=(28, 28, 1), zdim=16, units=(512, 512), activatio
               latents=RVconf((zdim,), 'mvndiag', projection=True, name='latents'))
 
 
+def speech_networks(qz='mvndiag', zdim=None, activation='elu', n_frames: int = 96, n_mels: int = 80,
+                    distribution='gaus', proj_dim: Optional[int] = None, **kwargs):
+  """Speech VAE of BASELINE config 5: the log-mel spectrogram [T, n_mels, 1] produced by the
+  odin.preprocessing front-end (`odin_ai_amd.mel.MelsSpecExtractor`) through the image conv
+  stack of `dsprites_networks` (image_networks.py:460-520: 4 x conv k4 s2 32/32/64/64 -> Dense;
+  Dense -> 4 x deconv k4 s2 64/64/32/32 -> conv 1x1), with the observation of the reference's
+  audio example: RVconf(event_shape, 'gaus', projection=False) = GaussianLayer with a
+  softplus1 scale (examples/vae/vae_audio.py:84-90; layers/continuous.py:196-260), zdim 32
+  (:44).  T and n_mels must be multiples of 16 (four stride-2 stages)."""
+  if zdim is None:
+    zdim = 32
+  if n_frames % 16 or n_mels % 16:
+    raise ValueError(f'n_frames={n_frames}, n_mels={n_mels}: both must be multiples of 16')
+  h, w = n_frames // 16, n_mels // 16
+  if proj_dim is None:
+    proj_dim = 8 * h * w
+  if proj_dim % (h * w):
+    raise ValueError(f'proj_dim={proj_dim} must be a multiple of {h * w}')
+  input_shape = (int(n_frames), int(n_mels), 1)
+  name = {'gaus': 'gaussian_softplus1', 'gaussian_softplus1': 'gaussian_softplus1',
+          'gaussian': 'gaussian', 'normal': 'gaussian'}.get(str(distribution).lower())
+  if name is None:
+    raise ValueError(f'speech_networks: observation {distribution!r} (gaus | gaussian)')
+  observation = RVconf(input_shape, name, projection=False, name='Spectrogram')
+  a = activation
+  enc = [('conv', 32, 4, 2, a), ('conv', 32, 4, 2, a), ('conv', 64, 4, 2, a), ('conv', 64, 4, 2, a),
+         ('flatten',), ('dense', proj_dim, 'linear')]
+  dec = [('dense', proj_dim, 'linear'), ('reshape', (h, w, proj_dim // (h * w))),
+         ('deconv', 64, 4, 2, a), ('deconv', 64, 4, 2, a), ('deconv', 32, 4, 2, a),
+         ('deconv', 32, 4, 2, a), ('conv', 2, 1, 1, 'linear')]
+  enc_names = ['encoder0', 'encoder1', 'encoder2', 'encoder3', 'encoder_proj']
+  dec_names = ['decoder_proj', 'decoder1', 'decoder2', 'decoder3', 'decoder4', 'decoder6']
+  return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape, enc_names),
+              decoder=SequentialNetwork(dec, 'Decoder', (zdim,), dec_names),
+              observation=observation,
+              latents=RVconf((zdim,), qz, projection=True, name='Latents'))
+
+
 _DATASETS = {
     'mnist': mnist_networks, 'binarizedmnist': mnist_networks, 'fashionmnist': mnist_networks,
     'dsprites': dsprites_networks, 'dspritesc': dsprites_networks,
     'shapes3d': shapes3d_networks, 'shapes3dsmall': shapes3d_networks,
     'celeba': celeba_networks, 'celebasmall': celeba_networks,
     'dense': dense_networks,
+    'fsdd': speech_networks, 'speech': speech_networks,
 }
 
 

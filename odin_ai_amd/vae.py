@@ -156,6 +156,53 @@ class GaussianObservation:
     return self.loc + self.scale * torch.randn(shp, device=self.loc.device)
 
 
+class QuantizedLogisticObservation:
+  """QuantizedLogistic(loc, softplus(raw) + e^-7, low=0, high=255, inputs_domain='sigmoid',
+  reinterpreted_batch_ndims=3) (image_networks.py:55-71; distributions/quantized.py:50-204)."""
+
+  def __init__(self, h: torch.Tensor):
+    Cc = h.shape[-1] // 2
+    self.loc = 127.5 * (h[..., :Cc] + 1.0)                                      # pixel units
+    self.scale = (torch.nn.functional.softplus(h[..., Cc:]) + math.exp(-7.0)) * 127.5
+
+  event_shape = property(lambda self: tuple(self.loc.shape[1:]))
+  batch_shape = property(lambda self: (self.loc.shape[0],))
+
+  def mean(self):
+    return self.loc / 255.0      # quantized.py:185-187 (`_pixels_to`, sigmoid domain)
+
+  def stddev(self):
+    return self.scale * (math.pi / math.sqrt(3.0))
+
+  def _logcdf(self, j):
+    r = -torch.nn.functional.softplus(-(j + 0.5 - self.loc) / self.scale)
+    r = torch.where(j < 0.0, torch.full_like(r, -float('inf')), r)
+    return torch.where(j < 255.0, r, torch.zeros_like(r))
+
+  def _logsf(self, j):
+    r = -torch.nn.functional.softplus((j + 0.5 - self.loc) / self.scale)
+    r = torch.where(j < 0.0, torch.zeros_like(r), r)
+    return torch.where(j < 255.0, r, torch.full_like(r, -float('inf')))
+
+  def log_prob(self, x):
+    y = x * 255.0
+    lsy, lsy1 = self._logsf(torch.ceil(y)), self._logsf(torch.ceil(y - 1.0))
+    lcy, lcy1 = self._logcdf(torch.floor(y)), self._logcdf(torch.floor(y - 1.0))
+    use_sf = lsy < lcy
+    big, small = torch.where(use_sf, lsy1, lcy), torch.where(use_sf, lsy, lcy1)
+    fin = torch.isfinite(small)
+    d = torch.where(fin, big - small, torch.ones_like(big))
+    l1m = torch.where(d < math.log(2.0), torch.log(-torch.expm1(-d)), torch.log1p(-torch.exp(-d)))
+    e = big + torch.where(fin, l1m, torch.zeros_like(l1m))
+    return e.reshape(e.shape[0], -1).sum(1)
+
+  def sample(self, n=None):
+    shp = tuple(self.loc.shape) if n is None else (int(n),) + tuple(self.loc.shape)
+    u = torch.rand(shp, device=self.loc.device).clamp_(1e-6, 1 - 1e-6)
+    xs = self.loc + self.scale * (torch.log(u) - torch.log1p(-u)) - 0.5  # Logistic shifted by -1/2
+    return torch.ceil(xs).clamp_(0.0, 255.0) / 255.0
+
+
 # ======================================================================================
 # training step objects
 # ======================================================================================
@@ -370,6 +417,8 @@ class VariationalAutoencoder:
   def _observation_dist(self, h: torch.Tensor):
     if self.observation.posterior == 'bernoulli':
       return BernoulliObservation(h)
+    if self.observation.posterior == 'qlogistic':
+      return QuantizedLogisticObservation(h)
     return GaussianObservation(h, self.observation.posterior == 'gaussian_softplus1')
 
   def encode(self, inputs, training=None, mask=None, only_encoding=False, eps=None, **kwargs):

@@ -84,6 +84,36 @@ def t_total_correlation(z, loc, scale):
   return (torch.logsumexp(lp.sum(2), 1) - torch.logsumexp(lp, 1).sum(1)).mean()
 
 
+def t_qlogistic_log_prob(loc, raw, x, low=0.0, high=255.0):
+  """QuantizedLogistic.log_prob (odin/bay/distributions/quantized.py:50-204 over TFP's
+  QuantizedDistribution), torch autograd version; x*high is rounded to float32 like the reference."""
+  support = 0.5 * (high - low)
+  m = low + support * (loc + 1.0)
+  s = (F.softplus(raw) + math.exp(-7.0)) * support
+  y = (x.to(torch.float32) * torch.tensor(high, dtype=torch.float32)).to(loc.dtype)
+  ninf = torch.full_like(m, -float('inf'))
+  zero = torch.zeros_like(m)
+
+  def logcdf(j):
+    r = -F.softplus(-(j + 0.5 - m) / s)
+    return torch.where(j < high, torch.where(j < low, ninf, r), zero)
+
+  def logsf(j):
+    r = -F.softplus((j + 0.5 - m) / s)
+    return torch.where(j < high, torch.where(j < low, zero, r), ninf)
+
+  lsy, lsy1 = logsf(torch.ceil(y)), logsf(torch.ceil(y - 1.0))
+  lcy, lcy1 = logcdf(torch.floor(y)), logcdf(torch.floor(y - 1.0))
+  use_sf = lsy < lcy
+  big = torch.where(use_sf, lsy1, lcy)
+  small = torch.where(use_sf, lsy, lcy1)
+  # log(exp(big) - exp(small)); small = -inf contributes nothing (and no gradient)
+  fin = torch.isfinite(small)
+  d = torch.where(fin, big - small, torch.ones_like(big))
+  l1m = torch.where(d < math.log(2.0), torch.log(-torch.expm1(-d)), torch.log1p(-torch.exp(-d)))
+  return big + torch.where(fin, l1m, torch.zeros_like(l1m))
+
+
 class TorchVAE:
   """Same constructor arguments as oracle.vae_oracle.OracleVAE."""
 
@@ -115,6 +145,10 @@ class TorchVAE:
     if self.observation == 'bernoulli':
       llk = (x * h_d - F.softplus(h_d)).reshape(B, -1).sum(1)
       recon = torch.sigmoid(h_d)
+    elif self.observation == 'qlogistic':
+      C = x.shape[-1]
+      llk = t_qlogistic_log_prob(h_d[..., :C], h_d[..., C:], x).reshape(B, -1).sum(1)
+      recon = (127.5 * (h_d[..., :C] + 1.0)) / 255.0
     else:
       C = x.shape[-1]
       oloc, raw = h_d[..., :C], h_d[..., C:]

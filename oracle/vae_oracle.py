@@ -217,6 +217,93 @@ def gaussian_log_prob(loc, scale, x):
   return e.reshape(e.shape[0], -1).sum(1)
 
 
+# ---- QuantizedLogistic (odin/bay/distributions/quantized.py:50-204; TFP 0.13
+# QuantizedDistribution._log_prob_with_logsf_and_logcdf, third-party, restated from its published
+# source): PixelCNN-style discretised logistic over the pixel values low..high ------------------
+QL_MIN_SCALE = math.exp(-7.0)
+
+
+def qlogistic_params(loc, raw, low=0.0, high=255.0):
+  """image_networks.py:55-71 + quantized.py:104-108: scale = softplus(raw) + e^-7, then both are
+  mapped to pixel units: m = low + (high-low)/2 * (loc + 1), s = scale * (high-low)/2."""
+  support = 0.5 * (high - low)
+  return low + support * (loc + 1.0), (softplus(raw) + QL_MIN_SCALE) * support
+
+
+def _ql_terms(m, s, x, low, high):
+  # y = x * high is formed in FLOAT32 by the reference (`_switch_domain`, 'sigmoid'): the
+  # floor / ceil below are discontinuous, so the oracle rounds exactly where TF does
+  y = (np.asarray(x, np.float32) * np.float32(high)).astype(F64)
+  ninf = -np.inf
+
+  def logcdf(j):  # P[Y <= j], QuantizedDistribution._log_cdf on X = Logistic - 0.5
+    r = -softplus(-(j + 0.5 - m) / s)
+    r = np.where(j < low, ninf, r)
+    return np.where(j < high, r, 0.0)
+
+  def logsf(j):   # P[Y > j], QuantizedDistribution._log_survival_function
+    r = -softplus((j + 0.5 - m) / s)
+    r = np.where(j < low, 0.0, r)
+    return np.where(j < high, r, ninf)
+
+  jf, jc = np.floor(y), np.ceil(y)
+  logsf_y, logsf_y1 = logsf(jc), logsf(np.ceil(y - 1.0))
+  logcdf_y, logcdf_y1 = logcdf(jf), logcdf(np.floor(y - 1.0))
+  use_sf = logsf_y < logcdf_y
+  return y, jf, jc, use_sf, logsf_y, logsf_y1, logcdf_y, logcdf_y1
+
+
+def qlogistic_log_prob_elem(loc, raw, x, low=0.0, high=255.0):
+  """Per-element log P[Y = y]: log(exp(big) - exp(small)), on the survival side right of the
+  median and on the cdf side left of it (TFP's numerically safe choice)."""
+  m, s = qlogistic_params(loc, raw, low, high)
+  _, _, _, use_sf, lsy, lsy1, lcy, lcy1 = _ql_terms(m, s, x, low, high)
+  big = np.where(use_sf, lsy1, lcy)
+  small = np.where(use_sf, lsy, lcy1)
+  with np.errstate(divide='ignore', invalid='ignore'):
+    d = big - small  # >= 0 (inf when small = -inf)
+    l1m = np.where(d < math.log(2.0), np.log(-np.expm1(-d)), np.log1p(-np.exp(-d)))
+  return big + l1m
+
+
+def qlogistic_log_prob(loc, raw, x, low=0.0, high=255.0):
+  e = qlogistic_log_prob_elem(loc, raw, x, low, high)
+  return e.reshape(e.shape[0], -1).sum(1)
+
+
+def qlogistic_log_prob_grad(loc, raw, x, low=0.0, high=255.0):
+  """(d log_prob / d loc, d log_prob / d raw), elementwise."""
+  m, s = qlogistic_params(loc, raw, low, high)
+  y, jf, jc, use_sf, lsy, lsy1, lcy, lcy1 = _ql_terms(m, s, x, low, high)
+  support = 0.5 * (high - low)
+
+  def d_logcdf(j):  # d/du of -softplus(-u) = sigmoid(-u); zero on the clamped branches
+    u = (j + 0.5 - m) / s
+    live = (j >= low) & (j < high)
+    return np.where(live, sigmoid(-u), 0.0), u
+
+  def d_logsf(j):   # d/du of -softplus(u) = -sigmoid(u)
+    u = (j + 0.5 - m) / s
+    live = (j >= low) & (j < high)
+    return np.where(live, -sigmoid(u), 0.0), u
+
+  gb_sf, ub_sf = d_logsf(np.ceil(y - 1.0))
+  gs_sf, us_sf = d_logsf(jc)
+  gb_cf, ub_cf = d_logcdf(jf)
+  gs_cf, us_cf = d_logcdf(np.floor(y - 1.0))
+  big = np.where(use_sf, lsy1, lcy)
+  small = np.where(use_sf, lsy, lcy1)
+  gb, ub = np.where(use_sf, gb_sf, gb_cf), np.where(use_sf, ub_sf, ub_cf)
+  gs, us = np.where(use_sf, gs_sf, gs_cf), np.where(use_sf, us_sf, us_cf)
+  with np.errstate(invalid='ignore'):
+    r = np.where(np.isneginf(small), 0.0, np.exp(small - big))  # e^small / e^big in [0, 1)
+  wb, ws = 1.0 / (1.0 - r), -r / (1.0 - r)  # d result / d big, d result / d small
+  # du/dm = -1/s, du/ds = -u/s
+  dm = (wb * gb + ws * gs) * (-1.0 / s)
+  ds = (wb * gb * ub + ws * gs * us) * (-1.0 / s)
+  return dm * support, ds * support * sigmoid(raw)
+
+
 def mvn_diag_params(p, D: int):
   """MultivariateNormalLayer.new: loc = p[..., :D], scale = softplus(p[..., D:])
   (odin/bay/layers/continuous.py:459-483)."""
@@ -531,6 +618,11 @@ class OracleVAE:
     if self.observation == 'bernoulli':
       llk = bernoulli_log_prob(h_d, x)
       recon = sigmoid(h_d)
+    elif self.observation == 'qlogistic':
+      C = x.shape[-1]
+      oloc, raw = h_d[..., :C], h_d[..., C:]
+      llk = qlogistic_log_prob(oloc, raw, x)
+      recon = qlogistic_params(oloc, raw)[0] / 255.0  # QuantizedLogistic.mean (quantized.py:185-187)
     else:
       C = x.shape[-1]
       oloc, raw = h_d[..., :C], h_d[..., C:]
@@ -574,6 +666,10 @@ class OracleVAE:
     # dL/dh_d, L = -(1/B) sum llk + ...
     if self.observation == 'bernoulli':
       dh_d = -(bernoulli_log_prob_grad(h_d, x)) / B
+    elif self.observation == 'qlogistic':
+      C = x.shape[-1]
+      gl, gr = qlogistic_log_prob_grad(h_d[..., :C], h_d[..., C:], x)
+      dh_d = -np.concatenate([gl, gr], -1) / B
     else:
       C = x.shape[-1]
       oloc, raw = h_d[..., :C], h_d[..., C:]

@@ -65,3 +65,18 @@ def test_param_counts_match_survey():
     enc, dec, shp, D = spec
     m = vo.OracleVAE(enc, dec, shp, D)
     assert sum(int(np.prod(s)) for _, s in m.param_shapes()) == n
+
+
+def test_quantized_logistic_is_a_distribution_over_the_256_pixel_levels():
+  """Known answer: whatever (loc, scale), the discretised logistic sums to one over y = 0..255, the
+  edge bins carry the tails, and a very narrow logistic centred on pixel k puts its mass on k."""
+  ys = np.arange(256) / 255.0
+  for loc, raw in ((0.3, -1.0), (-1.2, 2.0), (0.99, -5.0), (-3.0, 0.0)):
+    lp = vo.qlogistic_log_prob_elem(np.full(256, loc), np.full(256, raw), ys)
+    assert abs(np.exp(lp).sum() - 1.0) < 1e-12
+  k = 77
+  loc = (k - 0.0) / 127.5 - 1.0              # m = 127.5 (loc + 1) = k
+  lp = vo.qlogistic_log_prob_elem(np.full(256, loc), np.full(256, -30.0), ys)  # scale = e^-7 * 127.5
+  assert np.argmax(lp) == k and abs(np.exp(lp[k]) - np.tanh(0.25 / (np.exp(-7.0) * 127.5))) < 1e-9
+  far = vo.qlogistic_log_prob_elem(np.array([-5.0]), np.array([0.0]), np.array([0.0]))
+  assert far[0] > -0.1                        # all mass below 0 lands in the y = 0 bin

@@ -11,6 +11,8 @@ def _small_spec(kind):
     return vo.dsprites_spec(1), 'bernoulli'
   if kind == 'shapes3d':
     return vo.dsprites_spec(3), 'bernoulli'
+  if kind == 'celeba_qlogistic':
+    return vo.celeba_spec(45, 6), 'qlogistic'
   if kind == 'celeba_gauss':
     return vo.celeba_spec(45, 6), 'gaussian_softplus1'
   if kind == 'mnist_conv':
@@ -27,6 +29,7 @@ CASES = [
     ('dsprites', dict(beta=3.0, analytic=True, reverse=False)),
     ('shapes3d', dict(beta=1.0, tc_beta=4.0)),
     ('celeba_gauss', dict(beta=4.0, tc_beta=4.0)),
+    ('celeba_qlogistic', dict(beta=2.0)),
     ('mnist_conv', dict()),
     ('mnist_dense', dict(analytic=True)),
 ]

@@ -277,3 +277,32 @@ def test_gradient_policies(bk):
   L.odin_grad_skip_threshold(tg.data_ptr(), n, float(g.max()) - 1e-3, on.data_ptr(), hit.data_ptr(),
                              cnt.data_ptr(), None)
   assert hit.item() == 1 and cnt.item() == 1 and not tg.cpu().numpy().any()
+
+
+@pytest.mark.parametrize('npix,Cc', [(50, 3), (1024, 3), (512, 1)])
+def test_elbo_quantized_logistic(bk, npix, Cc):
+  """QuantizedLogistic head (image_networks.py:55-71; quantized.py:50-204): log-prob and its
+  gradient wrt (loc, raw), including the edge bins (x*255 at 0 / 255), values that sit exactly
+  on a pixel level, wide and very narrow scales."""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(12)
+  B = 3
+  h = rng.standard_normal((B, npix, 2 * Cc))
+  h[..., Cc:] *= 3.0                                     # scales from ~1e-3 to ~4 (x 127.5 pixels)
+  x = rng.random((B, npix, Cc)).astype(np.float32)
+  x[0, :8] = np.array([1e-6, 1 - 1e-6, 0.0, 1.0, 0.5, 200 / 255, 3 / 255, 254 / 255],
+                      np.float32)[:, None]
+  x = x.astype(np.float64)
+  loc, raw = h[..., :Cc], h[..., Cc:]
+  loc32, raw32 = loc.astype(np.float32).astype(np.float64), raw.astype(np.float32).astype(np.float64)
+  llk_ref = vo.qlogistic_log_prob(loc32, raw32, x)
+  gl, gr = vo.qlogistic_log_prob_grad(loc32, raw32, x)
+  dh_ref = -np.concatenate([gl, gr], -1) / B
+  th, tx, sc = T(h), T(x), T([1.0 / B])
+  npart = C.c_int(0)
+  L.odin_elbo_gaussian_fwd_bwd(None, None, None, None, None, B, npix, Cc, 2, C.byref(npart), None)
+  part, dh = bk.zeros(B * npart.value), bk.zeros(B, npix, 2 * Cc)
+  L.odin_elbo_gaussian_fwd_bwd(th.data_ptr(), tx.data_ptr(), part.data_ptr(), dh.data_ptr(),
+                               sc.data_ptr(), B, npix, Cc, 2, C.byref(npart), None)
+  close(part.reshape(B, -1).sum(1).cpu().numpy(), llk_ref, 2e-5)
+  close(dh.cpu().numpy(), dh_ref, 1e-4)

@@ -37,6 +37,8 @@ CASES = [
     ('tiny', dict(beta=1.0, analytic=True, free_bits=0.3), 'bernoulli', 3),
     ('tiny_tc', dict(beta=3.0, tc_beta=3.0), 'bernoulli', 3),
     ('tiny_gauss', dict(beta=2.0), 'gaussian_softplus1', 3),
+    ('tiny_gauss', dict(beta=2.0), 'qlogistic', 3),
+    ('tiny', dict(beta=2.0, analytic=True, reverse=False), 'bernoulli', 1),
     ('mnist_dense', dict(), 'bernoulli', 1),
 ]
 
@@ -62,6 +64,6 @@ def test_engine_step_matches_oracle(L, name, kw, obs, C):
   P = model.init_params(seed=11)
   eng = VAEEngine(enc, dec, in_shape, zdim, B, 'cpu', observation=obs,
                   analytic=kw.get('analytic', False), free_bits=kw.get('free_bits'),
-                  tc='betatc' if 'tc_beta' in kw else None, lib=L)
+                  tc='betatc' if 'tc_beta' in kw else None, lib=L, reverse=kw.get('reverse', True))
   assert eng.fused_tail == name.startswith('tiny16')
   check_engine_vs_oracle(eng, model, P, x, eps, beta=kw.get('beta', 1.0), steps=2, clip=100.0)
