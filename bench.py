@@ -395,7 +395,7 @@ def main():
     y = (0.1 * torch.randn(B, 8000, generator=g) +
          0.5 * torch.sin(2 * math.pi * (200.0 + 1500.0 * t[None] * torch.rand(B, 1, generator=g)) * t[None])
          ).to(device)
-    ex = MelsSpecExtractor(device=device)
+    ex = MelsSpecExtractor(device=device, unit_range=True)
     xb = eng.input_buffer()
     T = in_shape[0]
 

@@ -157,6 +157,15 @@ int odin_mean(const float* x, int n, float* out, void* stream);
 int odin_total_correlation_fwd_bwd(const float* z, const float* p, float* tc_out, float* dz,
                                    float* dloc, float* dscale, const float* coef, int B, int D,
                                    void* stream);
+/* The same estimator with the batch sharded over ranks (losses.py:136-157 couples every
+ * pair (j, i) of the GLOBAL batch): this rank evaluates its own rows j (z_local [B_local, D])
+ * against ALL posteriors i (p_global [B_global, 2D], all-gathered): tc_out[0] = this rank's share
+ * sum_j(...) / B_global (sum the shares of the ranks), dz_local [B_local, D] is complete, and
+ * dloc_part / dscale_part [B_global, D] hold this rank's partial sums over its j for EVERY
+ * posterior i (reduce-scatter them).  Workspace as above with B = B_local. */
+int odin_total_correlation_shard(const float* z_local, const float* p_global, float* tc_out,
+                                 float* dz_local, float* dloc_part, float* dscale_part,
+                                 const float* coef, int B_local, int B_global, int D, void* stream);
 /* permute_dims (odin/bay/vi/utils.py:233-269): out[i,l] = z[perm[i,l], l]; perm int32 [B,D] */
 int odin_permute_dims(const float* z, const int32_t* perm, float* out, int B, int D, void* stream);
 /* per-column random permutations generated on device (Philox), perm int32 [B,D] */
@@ -237,8 +246,12 @@ int odin_gather_normalize_u8(const uint8_t* data, const int32_t* idx, float* out
  * window [frame_length] float64 (already divided by its sum); twiddles [n_fft/2][2] float64 =
  * (cos, -sin)(2 pi k / n_fft); the mel_filters basis [n_mels, n_fft/2+1] as its non-zero band
  * per filter: fb_band [n_mels][3] = {first bin, count, offset into fb_vals}, fb_vals float64;
- * n_fft in {32, 128, 512, 2048}; top_db < 0 disables the per-utterance floor; log_output=0
- * returns the mel power. */
+ * n_fft a power of two in [16, 2048]; top_db < 0 disables the per-utterance floor.
+ * log_output: 0 = mel power; 1 = dB (power2db / amplitude_to_DB); 2 = the floored dB mapped to
+ * [0, 1] by (dB - max)/top_db + 1 (input scaling for networks without batch normalisation);
+ * 3 = ln(mel + 1e-6) (`AudioFeatureLoader(log_mels=True)`, odin/fuel/audio_data.py:222-223).
+ * The same launch serves the TF variant (fuel/audio_data.py:17-101,210-270): un-normalised
+ * periodic Hann window, preemph = 0, the HTK filterbank of tf.signal.linear_to_mel_weight_matrix. */
 int odin_stft_mel_db(const float* y, const double* window, const double* twiddles,
                      const double* fb_vals, const int32_t* fb_band, float* out, int B,
                      int n_samples, int frame_length, int step_length, int n_fft, int n_mels,

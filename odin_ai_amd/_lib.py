@@ -57,6 +57,7 @@ SIGNATURES = {
     'odin_elbo_finalize': [P, I, P, P, P, P, P, I, P],
     'odin_mean': [P, I, P, P],
     'odin_total_correlation_fwd_bwd': [P, P, P, P, P, P, P, I, I, P],
+    'odin_total_correlation_shard': [P, P, P, P, P, P, P, I, I, I, P],
     'odin_permute_dims': [P, P, P, I, I, P],
     'odin_random_perm': [P, I, I, C.c_uint64, P, P],
     'odin_dtc_loss_fwd_bwd': [P, P, P, P, P, I, P],

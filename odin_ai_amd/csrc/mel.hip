@@ -51,8 +51,8 @@ __device__ __forceinline__ int rev4(int n, int log4) {
 __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
     const float* __restrict__ y, const double* __restrict__ window, const double* __restrict__ tw_g,
     const double* __restrict__ fb_vals, const int* __restrict__ fb_band, float* __restrict__ out,
-    int n_samples, int frame_length, int step, int n_fft, int log4, int fpb, int n_frames,
-    int n_mels, double preemph, double top_db, int log_output) {
+    int n_samples, int frame_length, int step, int n_fft, int log4, int radix2, int fpb,
+    int n_frames, int n_mels, double preemph, double top_db, int log_output) {
   ODIN_DYN_SMEM(double, smem);
   const int H = n_fft / 2, nb = H + 1;
   cplx* tw = reinterpret_cast<cplx*>(smem);                 // [H]
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
   __shared__ float red[4];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
+  const double ref_value = 1.0;
   const float* yb = y + (size_t)b * n_samples;
   float* ob = out + (size_t)b * n_frames * n_mels;
   for (int k = tid; k < H; k += 256) tw[k] = {tw_g[2 * k], tw_g[2 * k + 1]};
@@ -88,13 +89,16 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
           v.im = s * window[j1];
         }
       }
-      Z[(size_t)f * H + rev4(n, log4)] = v;
+      // H = 4^log4, or 2 * 4^log4: then even points go to the first half, odd points to the
+      // second (each base-4 digit-reversed) and one radix-2 stage combines the halves at the end
+      const int dst = radix2 ? (n & 1) * (H >> 1) + rev4(n >> 1, log4) : rev4(n, log4);
+      Z[(size_t)f * H + dst] = v;
     }
     __syncthreads();
     // ---- 2. radix-4 DIT stages: L = 4, 16, .., H ----
     for (int s = 1; s <= log4; ++s) {
       const int L = 1 << (2 * s), Q = L >> 2;
-      const int tstep = H / L * 2;  // W_L^j = e^{-2 pi i j / L} = tw[j * n_fft / L / ... ] -> index j * (n_fft / L)
+      const int tstep = 2 * H / L;  // W_L^j = e^{-2 pi i j / L} = tw[j * n_fft / L]
       for (int e = tid; e < fpb * (H / 4); e += 256) {
         const int f = e / (H / 4), q = e - f * (H / 4);
         const int j = q % Q, base = (q / Q) * L;
@@ -122,6 +126,18 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
       }
       __syncthreads();
     }
+    if (radix2) {  // X[k] = A[k] + W_H^k B[k], X[k + H/2] = A[k] - W_H^k B[k]
+      const int Hh = H >> 1;
+      for (int e = tid; e < fpb * Hh; e += 256) {
+        const int f = e / Hh, k = e - f * Hh;
+        cplx* zf = Z + (size_t)f * H + k;
+        const cplx a = zf[0];
+        const cplx bq = k ? cmul(zf[Hh], tw[2 * k]) : zf[Hh];
+        zf[0] = cadd(a, bq);
+        zf[Hh] = csub(a, bq);
+      }
+      __syncthreads();
+    }
     // ---- 3. real-input split and power spectrum: X[k] = E[k] + W_N^k O[k] ----
     for (int e = tid; e < fpb * nb; e += 256) {
       const int f = e / nb, k = e - f * nb;
@@ -146,13 +162,14 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
       double acc = 0.0;
       for (int k = 0; k < cnt; ++k) acc = fma(fb_vals[off + k], P[k], acc);
       float r;
-      if (log_output) r = (float)(10.0 * log10(fmax(1e-10, acc)));
+      if (log_output == 3) r = (float)log(acc + 1e-6);  // AudioFeatureLoader(log_mels=True)
+      else if (log_output) r = (float)(10.0 * log10(fmax(1e-10, acc) / ref_value));
       else r = (float)acc;
       ob[(size_t)t * n_mels + m] = r;
       vmax = fmaxf(vmax, r);
     }
   }
-  if (!log_output || top_db < 0.0) return;
+  if (!log_output || log_output == 3 || top_db < 0.0) return;
   // ---- per-utterance top_db floor (power2db: log_spec.max() - top_db over the whole utterance)
 #pragma unroll
   for (int k = 32; k >= 1; k >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, k));
@@ -160,6 +177,12 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
   __syncthreads();  // also orders this workgroup's stores before its re-reads below
   const float floor_ = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - (float)top_db;
   const int n = n_frames * n_mels;
+  if (log_output == 2) {
+    // unit range: the floored dB values span [max - top_db, max] -> (v - max) / top_db + 1 in [0, 1]
+    const float mx = floor_ + (float)top_db, inv = 1.f / (float)top_db;
+    for (int i = tid; i < n; i += 256) ob[i] = (fmaxf(ob[i], floor_) - mx) * inv + 1.f;
+    return;
+  }
   for (int i = tid; i < n; i += 256) {
     const float v = ob[i];
     if (v < floor_) ob[i] = floor_;
@@ -173,11 +196,16 @@ extern "C" int odin_stft_mel_db(const float* y, const double* window, const doub
                                 int n_samples, int frame_length, int step_length, int n_fft,
                                 int n_mels, double preemph, double top_db, int log_output,
                                 void* stream) {
-  int log4 = 0;
-  while ((1 << (2 * log4)) < n_fft / 2) ++log4;
-  if (2 * (1 << (2 * log4)) != n_fft || n_fft < frame_length || n_fft > 2048 || n_fft < 32)
-    return odin_fail(-2, "stft_mel_db: n_fft must be 2 * 4^k in [32, 2048] and >= frame_length "
-                         "(32, 128, 512, 2048)");
+  const int Hc = n_fft / 2;
+  int log4 = 0, radix2 = 0;
+  while ((1 << (2 * log4 + 2)) <= Hc) ++log4;
+  if ((1 << (2 * log4)) == Hc) radix2 = 0;
+  else if (2 * (1 << (2 * log4)) == Hc) radix2 = 1;
+  else radix2 = -1;
+  if (radix2 < 0 || n_fft < frame_length || n_fft > 2048 || n_fft < 16)
+    return odin_fail(-2, "stft_mel_db: n_fft must be a power of two in [16, 2048] and >= frame_length");
+  if (log_output == 2 && top_db <= 0.0)
+    return odin_fail(-2, "stft_mel_db: the unit-range output (log_output=2) needs top_db > 0");
   if (n_samples < frame_length) return odin_fail(-2, "stft_mel_db: utterance shorter than a frame");
   const int n_frames = 1 + (n_samples - frame_length) / step_length;
   const int H = n_fft / 2, nbp = (H + 1) | 1;
@@ -188,13 +216,16 @@ extern "C" int odin_stft_mel_db(const float* y, const double* window, const doub
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_mel_f64_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (the kernel also has 16 bytes of static LDS: asking for the full 160 KB of DYNAMIC LDS is
+    // rejected and leaves a sticky hipErrorInvalidValue behind)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_mel_f64_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
+      (void)hipGetLastError();
     attr_done = true;
   }
 #endif
   ODIN_LAUNCH(stft_mel_f64_kernel, dim3(B), dim3(256), lds, stream, y, window, twiddles, fb_vals,
-              (const int*)fb_band, out, n_samples, frame_length, step_length, n_fft, log4, fpb,
-              n_frames, n_mels, preemph, top_db, log_output);
+              (const int*)fb_band, out, n_samples, frame_length, step_length, n_fft, log4, radix2,
+              fpb, n_frames, n_mels, preemph, top_db, log_output);
   return odin_check_launch("stft_mel_db");
 }

@@ -25,8 +25,10 @@ __device__ __forceinline__ float wave_max64(float v) {
   return v;
 }
 
-// One workgroup per sample j.  LDS: lp[B][D] (log q(z_j | x_i) per latent), S[B].
-// Outputs: logqz[j], L[j][l] (log-sum-exp over i per latent), tc_part[j], dz[j][l].
+// One workgroup per sample j (gridDim.x rows: the LOCAL shard under data parallelism); B = number
+// of posteriors i the log-sum-exps run over (the GLOBAL batch).  LDS: lp[B][D] (log q(z_j | x_i)
+// per latent), S[B].  Outputs: logqz[j], L[j][l] (log-sum-exp over i per latent), tc_part[j],
+// dz[j][l].
 __global__ __launch_bounds__(256) void tc_rows_kernel(const float* z, const float* p,
                                                       float* logqz, float* Lout, float* tc_part,
                                                       float* dz, const float* coef, int B, int D) {
@@ -85,11 +87,13 @@ __global__ __launch_bounds__(256) void tc_rows_kernel(const float* z, const floa
   }
 }
 
-// One workgroup per sample i (posterior owner): sums over j.
+// One workgroup per posterior i (gridDim.x = global batch): sums over the Bj rows j this rank
+// evaluated (all of them on one GPU; the local shard under data parallelism, where the partial
+// sums of the ranks are then reduce-scattered).  Bn = global batch (the estimator's 1/B).
 __global__ __launch_bounds__(256) void tc_cols_kernel(const float* z, const float* p,
                                                       const float* logqz, const float* Lin,
                                                       float* dloc, float* dscale,
-                                                      const float* coef, int B, int D) {
+                                                      const float* coef, int B, int D, int Bn) {
   __shared__ float red[8];
   constexpr int MAXJ = 16;  // B <= 4096
   const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void tc_cols_kernel(const float* z, const floa
     }
     Sj[q] = s;  // = wj[j,i]
   }
-  const float cf = coef[0] / (float)B;
+  const float cf = coef[0] / (float)Bn;
   for (int l = 0; l < D; ++l) {
     float mu = p[(size_t)i * 2 * D + l], sg = softplus_t(p[(size_t)i * 2 * D + D + l]);
     float lsg = odin_log(sg);
@@ -134,6 +138,16 @@ __global__ __launch_bounds__(256) void tc_cols_kernel(const float* z, const floa
       dscale[(size_t)i * D + l] = cf * ((red[4] + red[5]) + (red[6] + red[7]));
     }
   }
+}
+
+__global__ __launch_bounds__(256) void sum_div_kernel(const float* part, int n, float* out, float div) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+  acc = wave_sum64(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / div;
 }
 
 __global__ __launch_bounds__(256) void mean_kernel(const float* part, int n, float* out) {
@@ -199,16 +213,15 @@ __global__ __launch_bounds__(256) void dtc_loss_kernel(const float* lz, const fl
 
 }  // namespace
 
-// workspace layout inside tc_out: [0]=TC, then logqz[B], L[B*D], tc_part[B]  (B*(D+2)+1 floats)
-extern "C" int odin_total_correlation_fwd_bwd(const float* z, const float* p, float* tc_out,
-                                              float* dz, float* dloc, float* dscale,
-                                              const float* coef, int B, int D, void* stream) {
-  size_t lds = ((size_t)B * D + B + D + 8) * 4;
+// workspace layout inside tc_out: [0]=TC, then logqz[Bj], L[Bj*D], tc_part[Bj]  (Bj*(D+2)+1 floats)
+static int tc_launch(const float* z, const float* p, float* tc_out, float* dz, float* dloc,
+                     float* dscale, const float* coef, int Bj, int Bi, int D, void* stream) {
+  size_t lds = ((size_t)Bi * D + Bi + D + 8) * 4;
   if (lds > 158 * 1024) return odin_fail(-2, "total_correlation: B*D too large for LDS");
-  if (B > 4096) return odin_fail(-2, "total_correlation: B > 4096");
+  if (Bj > 4096 || Bi > 4096) return odin_fail(-2, "total_correlation: B > 4096");
   float* logqz = tc_out + 1;
-  float* L = logqz + B;
-  float* part = L + (size_t)B * D;
+  float* L = logqz + Bj;
+  float* part = L + (size_t)Bj * D;
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
@@ -217,11 +230,26 @@ extern "C" int odin_total_correlation_fwd_bwd(const float* z, const float* p, fl
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH(tc_rows_kernel, dim3(B), dim3(256), lds, stream, z, p, logqz, L, part, dz, coef, B, D);
-  ODIN_LAUNCH(tc_cols_kernel, dim3(B), dim3(256), 0, stream, z, p, (const float*)logqz,
-              (const float*)L, dloc, dscale, coef, B, D);
-  ODIN_LAUNCH(mean_kernel, dim3(1), dim3(256), 0, stream, (const float*)part, B, tc_out);
+  // rows: coefficient coef/Bi inside (cf = coef[0] / B with B = Bi)
+  ODIN_LAUNCH(tc_rows_kernel, dim3(Bj), dim3(256), lds, stream, z, p, logqz, L, part, dz, coef, Bi, D);
+  ODIN_LAUNCH(tc_cols_kernel, dim3(Bi), dim3(256), 0, stream, z, p, (const float*)logqz,
+              (const float*)L, dloc, dscale, coef, Bj, D, Bi);
+  ODIN_LAUNCH(sum_div_kernel, dim3(1), dim3(256), 0, stream, (const float*)part, Bj, tc_out, (float)Bi);
   return odin_check_launch("total_correlation");
+}
+
+extern "C" int odin_total_correlation_fwd_bwd(const float* z, const float* p, float* tc_out,
+                                              float* dz, float* dloc, float* dscale,
+                                              const float* coef, int B, int D, void* stream) {
+  return tc_launch(z, p, tc_out, dz, dloc, dscale, coef, B, B, D, stream);
+}
+
+extern "C" int odin_total_correlation_shard(const float* z_local, const float* p_global,
+                                            float* tc_out, float* dz_local, float* dloc_part,
+                                            float* dscale_part, const float* coef, int B_local,
+                                            int B_global, int D, void* stream) {
+  return tc_launch(z_local, p_global, tc_out, dz_local, dloc_part, dscale_part, coef, B_local,
+                   B_global, D, stream);
 }
 
 extern "C" int odin_mean(const float* x, int n, float* out, void* stream) {

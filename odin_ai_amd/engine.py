@@ -381,6 +381,14 @@ class VAEEngine:
       self.tc_dz = torch.empty(B, D, **f32)
       self.tc_dloc = torch.empty(B, D, **f32)
       self.tc_dscale = torch.empty(B, D, **f32)
+      if self.world_size > 1:
+        # global-batch estimator under data parallelism: all-gather (p | z), this rank's
+        # rows against every posterior, reduce-scatter of the posterior-side partial gradients
+        Bg = B * self.world_size
+        self.tc_pz_local = torch.empty(B, 3 * D, **f32)
+        self.tc_pz_all = torch.empty(Bg, 3 * D, **f32)
+        self.tc_p_all = torch.empty(Bg, 2 * D, **f32)
+        self.tc_part_all = torch.empty(2, Bg, D, **f32)    # dloc / dscale partials for every i
     self._plan_fused_tail(f32)
     self.ws = torch.empty(1024, **f32)
     self.gnorm2 = torch.zeros(1, **f32)
@@ -494,7 +502,10 @@ class VAEEngine:
     h[H_KLW] = beta / Bg
     h[H_BETA] = beta
     h[H_TCCOEF] = (beta - 1.0) if self.tc_mode == 'betatc' else 0.0
-    h[H_TCGRAD] = (beta - 1.0) / self.world_size if self.tc_mode == 'betatc' else 0.0
+    # the TC gradient coefficient: with the batch sharded, every rank back-propagates the FULL
+    # d(TC_global)/d(its own z, loc, scale) -- the sum all-reduce of the parameter gradients then
+    # assembles d/dtheta exactly once per sample
+    h[H_TCGRAD] = (beta - 1.0) if self.tc_mode == 'betatc' else 0.0
     if tc_coef is not None:  # FactorVAE: tc term = tc_coef * mean(D(z))
       h[H_TCCOEF] = tc_coef
     if extra is not None:  # second optimiser's Adam block (FactorVAE discriminator), slots 10..14
@@ -610,7 +621,10 @@ class VAEEngine:
                                      C.byref(npart), st)
     self.n_part = npart.value
     tcp = None
-    if self.tc_mode == 'betatc':
+    if self.tc_mode == 'betatc' and self.world_size > 1:
+      self._total_correlation_sharded(st)
+      tcp = self.tc_ws.data_ptr()
+    elif self.tc_mode == 'betatc':
       lib.odin_total_correlation_fwd_bwd(self.z.data_ptr(), self.p.data_ptr(),
                                          self.tc_ws.data_ptr(), self.tc_dz.data_ptr(),
                                          self.tc_dloc.data_ptr(), self.tc_dscale.data_ptr(),
@@ -624,6 +638,37 @@ class VAEEngine:
                              self.hp(H_BETA), tcp, self.llk.data_ptr(), self.out4.data_ptr(), B,
                              st)
     return h_d
+
+  def _total_correlation_sharded(self, st):
+    """total_correlation over the GLOBAL batch (losses.py:136-157 couples all pairs): one
+    all-gather of [B, 3D], the shard kernel, a reduce-scatter of the two [B_global, D]
+    posterior-side gradient planes and a scalar all-reduce for the reported value.  Identical
+    to a single GPU holding the whole batch."""
+    import torch.distributed as dist
+    lib, B, D, W = self.lib, self.B, self.D, self.world_size
+    gloo = dist.get_backend() == 'gloo'  # (CPU tests: gloo has no reduce_scatter)
+    self.tc_pz_local[:, :2 * D].copy_(self.p)
+    self.tc_pz_local[:, 2 * D:].copy_(self.z)
+    if gloo:
+      parts = list(self.tc_pz_all.view(W, B, 3 * D).unbind(0))
+      dist.all_gather(parts, self.tc_pz_local)
+    else:
+      dist.all_gather_into_tensor(self.tc_pz_all, self.tc_pz_local)
+    self.tc_p_all.copy_(self.tc_pz_all[:, :2 * D])
+    Bg = B * W
+    dl, ds = self.tc_part_all[0], self.tc_part_all[1]  # [Bg, D] planes
+    lib.odin_total_correlation_shard(self.z.data_ptr(), self.tc_p_all.data_ptr(),
+                                     self.tc_ws.data_ptr(), self.tc_dz.data_ptr(), dl.data_ptr(),
+                                     ds.data_ptr(), self.hp(H_TCGRAD), B, Bg, D, st)
+    if gloo:
+      dist.all_reduce(self.tc_part_all)
+      r = dist.get_rank()
+      self.tc_dloc.copy_(dl[r * B:(r + 1) * B])
+      self.tc_dscale.copy_(ds[r * B:(r + 1) * B])
+    else:
+      dist.reduce_scatter_tensor(self.tc_dloc, dl, op=dist.ReduceOp.SUM)
+      dist.reduce_scatter_tensor(self.tc_dscale, ds, op=dist.ReduceOp.SUM)
+    dist.all_reduce(self.tc_ws[:1], op=dist.ReduceOp.SUM)
 
   def finalize(self, tc_ptr: Optional[int] = None, st=None):
     st = self.stream() if st is None else st
@@ -784,7 +829,9 @@ class VAEEngine:
     self.step_count += 1
     self.set_hyper(lr=lr, beta=beta, skip_enable=self.step_count >= int(when_skip_update))
     pol = (global_clipnorm, clipnorm, clipvalue, skip_update_threshold, bool(check_nan))
-    if use_graph and self.device.type == 'cuda':
+    if use_graph and self.device.type == 'cuda' and not (self.tc_mode == 'betatc' and
+                                                          self.world_size > 1):
+      # (beta-TC under data parallelism has collectives INSIDE its forward pass: eager launches)
       self._graph_step(x, eps, pol)
     else:
       self.forward(x, eps)

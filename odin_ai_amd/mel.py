@@ -66,7 +66,9 @@ class MelsSpecExtractor:
   def __init__(self, sr: int = 8000, frame_length=0.025, step_length=0.010, n_fft: int = 512,
                window: str = 'hamm', n_mels: int = 80, fmin: float = 64, fmax: float = 4000,
                top_db: Optional[float] = 80.0, preemphasis: Optional[float] = 0.97,
-               log: bool = True, device=None, lib=None):
+               log: bool = True, device=None, lib=None, unit_range: bool = False,
+               mel_basis: Optional[np.ndarray] = None, normalize_window: bool = True,
+               natural_log: bool = False):
     self.sr = int(sr)
     self.frame_length = int(round(frame_length * sr)) if frame_length < 1 else int(frame_length)
     self.step_length = int(round(step_length * sr)) if step_length < 1 else int(step_length)
@@ -76,16 +78,22 @@ class MelsSpecExtractor:
     self.top_db = -1.0 if top_db is None else float(top_db)
     self.preemph = 0.0 if not preemphasis else float(preemphasis)
     self.log = bool(log)
+    # output mode of odin_stft_mel_db: 0 power, 1 dB, 2 dB mapped to [0, 1], 3 ln(mel + 1e-6)
+    self.mode = 3 if natural_log else ((2 if unit_range else 1) if log else 0)
+    if unit_range and (top_db is None or top_db <= 0 or not log):
+      raise ValueError('unit_range=True needs log=True and top_db > 0')
     self.device = torch.device(device if device is not None else
                                ('cuda' if torch.cuda.is_available() else 'cpu'))
     self.lib = lib if lib is not None else _lib.load()
     w = periodic_window(window, self.frame_length)
     f64 = dict(dtype=torch.float64, device=self.device)
-    self.window = torch.tensor(w / w.sum(), **f64)
+    self.window = torch.tensor(w / w.sum() if normalize_window else w, **f64)
     k = np.arange(self.n_fft // 2, dtype=np.float64)
     ang = 2.0 * np.pi * k / self.n_fft
     self.twiddles = torch.tensor(np.stack([np.cos(ang), -np.sin(ang)], 1), **f64).contiguous()
-    fb = mel_filters(self.sr, self.n_fft, self.n_mels, int(fmin), int(fmax))
+    fb = (mel_filters(self.sr, self.n_fft, self.n_mels, int(fmin), int(fmax))
+          if mel_basis is None else np.asarray(mel_basis, np.float64))
+    assert fb.shape == (self.n_mels, self.n_fft // 2 + 1), fb.shape
     self.mel_basis = fb
     # the kernel contracts each filter over its non-zero band only
     band, vals = [], []
@@ -113,7 +121,7 @@ class MelsSpecExtractor:
     self.lib.odin_stft_mel_db(y.data_ptr(), self.window.data_ptr(), self.twiddles.data_ptr(),
                               self.fb_vals.data_ptr(), self.fb_band.data_ptr(), out.data_ptr(), B,
                               n, self.frame_length, self.step_length, self.n_fft, self.n_mels,
-                              self.preemph, self.top_db, int(self.log), st)
+                              self.preemph, self.top_db, self.mode, st)
     return out[0] if squeeze else out
 
   __call__ = transform
@@ -131,3 +139,52 @@ def spectrogram_batch(mel: torch.Tensor, n_frames: int, pad_value: Optional[floa
   out = torch.full((B, n_frames, M), pv, dtype=mel.dtype, device=mel.device)
   out[:, :T] = mel
   return out.reshape(B, n_frames, M, 1)
+
+
+def htk_mel_weight_matrix(num_mel_bins=20, num_spectrogram_bins=129, sample_rate=8000,
+                          lower_edge_hertz=125.0, upper_edge_hertz=3800.0) -> np.ndarray:
+  """tf.signal.linear_to_mel_weight_matrix ([num_spectrogram_bins, num_mel_bins]) as used by the
+  reference's AudioFeatureLoader (odin/fuel/audio_data.py:94-100).  THIRD-PARTY algorithm
+  (tensorflow==2.5.0, python/ops/signal/mel_ops.py) restated from its published definition: HTK
+  mel scale 1127 ln(1 + f/700), triangles linear in mel between num_mel_bins + 2 equally spaced
+  edges, NOT area-normalised, the DC bin zeroed."""
+  hz2mel = lambda f: 1127.0 * np.log1p(np.asarray(f, np.float64) / 700.0)
+  lin = np.linspace(0.0, sample_rate / 2.0, num_spectrogram_bins)[1:]
+  bins_mel = hz2mel(lin)[:, None]
+  edges = np.linspace(hz2mel(lower_edge_hertz), hz2mel(upper_edge_hertz), num_mel_bins + 2)
+  lower, center, upper = edges[None, :-2], edges[None, 1:-1], edges[None, 2:]
+  W = np.maximum(0.0, np.minimum((bins_mel - lower) / (center - lower),
+                                 (upper - bins_mel) / (upper - center)))
+  return np.pad(W, [[1, 0], [0, 0]])
+
+
+class AudioFeatureLoader:
+  """The TF front-end variant of the reference (odin/fuel/audio_data.py:17-101,210-270; used by
+  examples/vae/vae_audio.py:64-79) on the same HIP kernel: tf.signal.stft(frame 256, step 80,
+  fft 256, periodic Hann, no padding) -> |.|^power -> HTK mel (20 bins, 125-3800 Hz) -> dB with
+  `top_DB` relative to the utterance's maximum (or ln(mel + 1e-6) when `log_mels`)."""
+
+  def __init__(self, frame_length=256, frame_step=80, fft_length=None, sample_rate=8000,
+               power=2.0, top_DB=80.0, pad_end=False, num_mel_bins=20, log_mels=False,
+               lower_edge_hertz=125.0, upper_edge_hertz=3800.0, device=None, lib=None):
+    if power != 2.0:
+      raise NotImplementedError('power != 2.0 (magnitude spectrogram) is outside the HIP path')
+    if pad_end:
+      raise NotImplementedError('pad_end=True is outside the HIP path')
+    if fft_length is None:
+      fft_length = frame_length
+    fft_length = 2 ** int(np.ceil(np.log2(fft_length)))                      # :73
+    self.frame_length, self.frame_step, self.fft_length = int(frame_length), int(frame_step), fft_length
+    self.sample_rate, self.top_DB, self.log_mels = int(sample_rate), top_DB, bool(log_mels)
+    self.num_mel_bins = int(num_mel_bins)
+    self.mel_weight = htk_mel_weight_matrix(num_mel_bins, fft_length // 2 + 1, sample_rate,
+                                            lower_edge_hertz, upper_edge_hertz)
+    self._ex = MelsSpecExtractor(sr=sample_rate, frame_length=frame_length, step_length=frame_step,
+                                 n_fft=fft_length, window='hann', n_mels=num_mel_bins, fmin=0,
+                                 fmax=sample_rate / 2, top_db=top_DB, preemphasis=None, log=True,
+                                 device=device, lib=lib, mel_basis=self.mel_weight.T,
+                                 normalize_window=False, natural_log=self.log_mels)
+
+  def melspec(self, y) -> torch.Tensor:
+    """y [B, n_samples] -> [B, n_frames, num_mel_bins] (:216-226)."""
+    return self._ex(y)

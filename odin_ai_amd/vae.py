@@ -823,6 +823,14 @@ class DiscPrograms:
     self.zcat = torch.zeros(2 * B1, zdim, **f32)  # [z (step 1's sample) ; permute_dims(z')]
     self.zperm = self.zcat[B1:]
     self.perm = torch.zeros(B1, zdim, dtype=torch.int32, device=device)
+    self.world, self.rank = 1, 0
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+      # permute_dims shuffles across the GLOBAL batch (vi/utils.py:262-267): all ranks draw the
+      # same [B1_global, D] permutation, z' is all-gathered and every rank gathers its own rows
+      self.world, self.rank = dist.get_world_size(), dist.get_rank()
+      self.perm = torch.zeros(B1 * self.world, zdim, dtype=torch.int32, device=device)
+      self.z2_all = torch.zeros(B1 * self.world, zdim, **f32)
     self.dlogit2 = torch.zeros(2 * B1, 1, **f32)
     self.dtc = torch.zeros(1, **f32)
     self._keep = None
@@ -925,9 +933,18 @@ class FactorVAE(AnnealingVAE):
     if not self._is_pretraining:
       eng2.run_encoder(x2, eps2)  # z' with the encoder as step 1 left it
       if perm is None:
-        lib.odin_random_perm(disc.perm.data_ptr(), B1, self.zdim, self.seed + 11,
+        lib.odin_random_perm(disc.perm.data_ptr(), B1 * disc.world, self.zdim, self.seed + 11,
                              eng.hp(N_HYPER), st)
-      lib.odin_permute_dims(eng2.z.data_ptr(), disc.perm.data_ptr(), disc.zperm.data_ptr(), B1,
+      if disc.world > 1:
+        import torch.distributed as dist
+        if dist.get_backend() == 'gloo':
+          dist.all_gather(list(disc.z2_all.view(disc.world, B1, self.zdim).unbind(0)), eng2.z)
+        else:
+          dist.all_gather_into_tensor(disc.z2_all, eng2.z)
+        src, prm = disc.z2_all, disc.perm[disc.rank * B1:(disc.rank + 1) * B1]
+      else:
+        src, prm = eng2.z, disc.perm
+      lib.odin_permute_dims(src.data_ptr(), prm.data_ptr(), disc.zperm.data_ptr(), B1,
                             self.zdim, st)
       lg2 = disc.prog2.forward(disc.zcat, st)
       lib.odin_dtc_loss_fwd_bwd(lg2.data_ptr(), lg2[B1:].data_ptr(), disc.dtc.data_ptr(),

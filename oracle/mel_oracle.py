@@ -104,3 +104,40 @@ def mel_frontend(y, sr=8000, frame_length=200, step_length=80, n_fft=512, n_mels
   P = np.abs(S) ** 2
   M = (mel_filters(sr, n_fft, n_mels, int(fmin), int(fmax)) @ P.T).T
   return power2db(M, top_db=top_db) if log else M
+
+
+# ---- TF variant (odin/fuel/audio_data.py:17-101,210-270).  PARITY UNPINNED: the arithmetic lives
+# in tensorflow==2.5.0 (tf.signal.stft / linear_to_mel_weight_matrix, absent here); restated from
+# the published definitions of those ops and from the reference's own amplitude_to_DB (:258-268).
+def tf_hann_window(n):
+  """tf.signal.hann_window(n, periodic=True)."""
+  return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)
+
+
+def tf_linear_to_mel_weight_matrix(num_mel_bins=20, num_spectrogram_bins=129, sample_rate=8000,
+                                   lower_edge_hertz=125.0, upper_edge_hertz=3800.0):
+  def h2m(f):
+    return 1127.0 * np.log(1.0 + np.asarray(f, np.float64) / 700.0)
+  lin = np.linspace(0.0, sample_rate / 2.0, num_spectrogram_bins)[1:]
+  sm = h2m(lin)[:, None]
+  edges = np.linspace(h2m(lower_edge_hertz), h2m(upper_edge_hertz), num_mel_bins + 2)
+  W = np.zeros((num_spectrogram_bins - 1, num_mel_bins))
+  for i in range(num_mel_bins):
+    lo, ce, up = edges[i], edges[i + 1], edges[i + 2]
+    W[:, i] = np.maximum(0.0, np.minimum((sm[:, 0] - lo) / (ce - lo), (up - sm[:, 0]) / (up - ce)))
+  return np.concatenate([np.zeros((1, num_mel_bins)), W], 0)
+
+
+def tf_audio_melspec(y, frame_length=256, frame_step=80, fft_length=256, sample_rate=8000,
+                     num_mel_bins=20, lower=125.0, upper=3800.0, top_db=80.0, log_mels=False):
+  """AudioFeatureLoader.stft -> magnitude (power 2) -> melspec for one utterance."""
+  y = np.asarray(y, np.float64)
+  n_frames = 1 + (y.shape[-1] - frame_length) // frame_step
+  idx = np.arange(frame_length)[None, :] + frame_step * np.arange(n_frames)[:, None]
+  S = np.fft.rfft(y[idx] * tf_hann_window(frame_length)[None, :], n=fft_length, axis=-1)
+  mel = (np.abs(S) ** 2) @ tf_linear_to_mel_weight_matrix(num_mel_bins, fft_length // 2 + 1,
+                                                          sample_rate, lower, upper)
+  if log_mels:
+    return np.log(mel + 1e-6)
+  db = 10.0 * np.log10(np.maximum(mel, 1e-10))
+  return np.maximum(db, db.max() - top_db) if top_db is not None else db

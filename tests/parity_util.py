@@ -27,7 +27,7 @@ def check_engine_vs_oracle(eng, model: vo.OracleVAE, P, x, eps, beta, lr=1e-3, t
   Tolerance: absolute 1e-4 on per-latent / per-pixel quantities, relative 1e-4 (of the
   tensor's max magnitude) on summed quantities and gradients."""
   dev = eng.device
-  tx = torch.tensor(x, dtype=torch.float32, device=dev)
+  tx = torch.tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev).contiguous()
   te = torch.tensor(eps, dtype=torch.float32, device=dev)
   eng.load_params(P)
   M = {k: np.zeros_like(v) for k, v in P.items()}

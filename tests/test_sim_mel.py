@@ -36,3 +36,28 @@ def test_mel_kernel_matches_reference_golden():
     assert np.abs(o2 - r2).max() <= 1e-6 * np.abs(r2).max(), (n_fft, np.abs(o2 - r2).max())
   with pytest.raises(ValueError):
     MelsSpecExtractor(fmin=5000, fmax=4000, device='cpu', lib=L)
+
+
+def test_unit_range_output_and_tf_variant():
+  """log_output=2 maps the floored dB into [0, 1]; the TF AudioFeatureLoader variant (fft 256:
+  radix-4 stages + one radix-2 stage, HTK filterbank, un-normalised Hann window) matches its
+  numpy restatement."""
+  from odin_ai_amd.mel import AudioFeatureLoader
+  from oracle import mel_oracle as mo
+  L = sim_lib()
+  y = G['y'][:2, :1600]
+  ex = MelsSpecExtractor(device='cpu', lib=L, unit_range=True)
+  out = ex(y).numpy()
+  for i in range(2):
+    ref = mo.mel_frontend(y[i])
+    want = (ref - ref.max()) / 80.0 + 1.0
+    assert np.abs(out[i] - want).max() < 1e-6 and out[i].min() >= 0.0 and out[i].max() == 1.0
+  for log_mels in (False, True):
+    al = AudioFeatureLoader(device='cpu', lib=L, log_mels=log_mels)
+    o = al.melspec(y).numpy()
+    assert o.shape == (2, 17, 20)
+    for i in range(2):
+      r = mo.tf_audio_melspec(y[i], log_mels=log_mels)
+      assert np.abs(o[i] - r).max() < 2e-5, (log_mels, np.abs(o[i] - r).max())
+  from odin_ai_amd.mel import htk_mel_weight_matrix
+  np.testing.assert_allclose(htk_mel_weight_matrix(), mo.tf_linear_to_mel_weight_matrix(), atol=1e-14)
