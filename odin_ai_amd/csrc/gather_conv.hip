@@ -1576,6 +1576,7 @@ extern "C" int odin_max_slab_rows(void) { return ODIN_MAX_COLSUM_BLOCKS; }
 extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                                const odin_conv_desc* d, void* stream) {
   if (odin_smallc_applicable(d)) return odin_smallc_fwd(x, w, bias, y, d, stream);
+  if (odin_pw1x1_applicable(d)) return odin_pw1x1_fwd(x, w, bias, y, d, stream);
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = y;
@@ -1589,6 +1590,8 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
 extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* aux, int aux_act,
                                  float* dx, float* colsum_slab, int* slab_rows_out,
                                  const odin_conv_desc* d, void* stream) {
+  if (odin_pw1x1_applicable(d))
+    return odin_pw1x1_dgrad(dy, w, aux, aux_act, dx, colsum_slab, slab_rows_out, d, stream);
   GParams p;
   fill_common(p, d);
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;

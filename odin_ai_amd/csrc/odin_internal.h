@@ -24,3 +24,12 @@ int odin_tiny_dense_fwd(const float* x, const float* w, const float* bias, float
                         int N, int act, void* stream);
 int odin_tiny_dense_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
                           float* colsum_slab, int* slab_rows_out, int B, int K, int N, void* stream);
+
+// 1x1 convolutions with <= 8 output maps as streaming kernels (pw1x1.hip)
+bool odin_pw1x1_applicable(const odin_conv_desc* d);
+int odin_pw1x1_fwd(const float* x, const float* w, const float* bias, float* y,
+                   const odin_conv_desc* d, void* stream);
+int odin_pw1x1_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                     float* colsum_slab, int* slab_rows_out, const odin_conv_desc* d, void* stream);
+int odin_pw1x1_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out,
+                     const odin_conv_desc* d, void* stream);

@@ -1136,6 +1136,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceJobs jobs) {
 extern "C" int odin_conv2d_wgrad(const float* x, const float* dy, float* slab,
                                  int* slab_rows_out, const odin_conv_desc* d, void* stream) {
   if (odin_smallc_applicable(d)) return odin_smallc_wgrad(x, dy, slab, slab_rows_out, d, stream);
+  if (odin_pw1x1_applicable(d)) return odin_pw1x1_wgrad(x, dy, slab, slab_rows_out, d, stream);
   WParams p;
   memset(&p, 0, sizeof(p));
   p.in = x; p.dy = dy; p.slab = slab;

@@ -42,7 +42,11 @@ CONV_CASES = [
     (2, 8, 8, 64, 64, 4, 1, 'elu', False),
     (2, 14, 14, 3, 8, 5, 2, 'relu', False),
     (2, 7, 7, 8, 16, 5, 1, 'elu', False),
-    (2, 16, 16, 32, 3, 1, 1, 'linear', False),
+    (2, 16, 16, 32, 3, 1, 1, 'linear', False),  # streaming 1x1 kernels (pw1x1.hip)
+    (3, 12, 20, 32, 2, 1, 1, 'linear', False),  # Gaussian head: 2 maps, ragged pixel count
+    (2, 9, 7, 64, 6, 1, 1, 'linear', False),    # CelebA two-parameter head: 6 maps over 64 channels
+    (1, 8, 8, 16, 8, 1, 1, 'elu', False),
+    (5, 4, 4, 8, 1, 1, 1, 'relu', False),
     (16, 8, 8, 64, 64, 4, 2, 'elu', False),    # small-M: waves split the reduction (KS=4)
     (37, 4, 4, 8, 8, 4, 2, 'elu', False),      # several whole images per tile, ragged last tile
     (1, 8, 8, 160, 40, 4, 2, 'linear', False),  # channel-chunked reduction
