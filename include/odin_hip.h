@@ -38,6 +38,10 @@ typedef struct odin_conv_desc {
 
 /* ---- runtime ------------------------------------------------------------------------ */
 int odin_version(void);
+/* CRC-32C (Castagnoli) of host bytes, continuing from `crc` (0 to start): the checksum of the
+ * TensorFlow checkpoint / event-file formats the reference saves (base_networks.py:373-390,
+ * training/trainer.py:52-71).  Returns the checksum (not an error code). */
+uint32_t odin_crc32c(uint32_t crc, const void* data, size_t n);
 const char* odin_last_error(void);
 int odin_max_slab_rows(void);      /* upper bound of the rows any slab-producing call writes */
 

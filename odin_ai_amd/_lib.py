@@ -38,6 +38,7 @@ DP = C.POINTER(ConvDesc)
 # name -> argtypes, exactly the declarations of include/odin_hip.h
 SIGNATURES = {
     'odin_version': [],
+    'odin_crc32c': [C.c_uint32, P, C.c_size_t],
     'odin_max_slab_rows': [],
     'odin_conv2d_fwd': [P, P, P, P, DP, P],
     'odin_conv2d_dgrad': [P, P, P, I, P, P, IP, DP, P],
@@ -82,6 +83,10 @@ SIGNATURES = {
 }
 
 
+# entry points whose return value is a result, not an error code
+VALUE_RETURNING = ('odin_version', 'odin_max_slab_rows', 'odin_crc32c')
+
+
 class OdinError(RuntimeError):
   pass
 
@@ -101,7 +106,7 @@ class Lib:
     for name, args in SIGNATURES.items():
       fn = getattr(self.c, name)  # AttributeError if the symbol is missing: fail loudly
       fn.argtypes = args
-      fn.restype = C.c_int
+      fn.restype = C.c_uint32 if name in VALUE_RETURNING else C.c_int
 
   def check(self, rc: int, what: str = ''):
     if rc != 0:
@@ -124,7 +129,7 @@ class Lib:
           import torch
           if torch.cuda.is_available():
             torch.cuda.synchronize()
-        if rc != 0 and name not in ('odin_version', 'odin_max_slab_rows'):
+        if rc != 0 and name not in VALUE_RETURNING:
           raise OdinError(f"{name} failed: {self.c.odin_last_error().decode()} (rc={rc})")
         return rc
 

@@ -1,6 +1,7 @@
 // runtime.hip -- error reporting, device query and HIP-graph capture helpers.
 #include "odin_device.h"
 #include "odin_internal.h"
+#include <cstdint>
 
 static thread_local char g_err[512] = "";
 
@@ -34,7 +35,41 @@ int odin_num_cus() {
 #endif
 }
 
-extern "C" int odin_version(void) { return 100; }
+// CRC-32C (Castagnoli), slicing-by-8, host side: the checksum of TensorFlow's checkpoint
+// (TensorBundle) and event-file formats (odin_ai_amd/tf_checkpoint.py).
+static uint32_t g_crc_tab[8][256];
+static bool g_crc_ready = false;
+static void crc_init() {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+    g_crc_tab[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; ++i)
+    for (int t = 1; t < 8; ++t)
+      g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xFF];
+  g_crc_ready = true;
+}
+extern "C" uint32_t odin_crc32c(uint32_t crc, const void* data, size_t n) {
+  if (!g_crc_ready) crc_init();
+  const unsigned char* p = (const unsigned char*)data;
+  uint32_t c = ~crc;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = g_crc_tab[7][lo & 0xFF] ^ g_crc_tab[6][(lo >> 8) & 0xFF] ^ g_crc_tab[5][(lo >> 16) & 0xFF] ^
+        g_crc_tab[4][lo >> 24] ^ g_crc_tab[3][hi & 0xFF] ^ g_crc_tab[2][(hi >> 8) & 0xFF] ^
+        g_crc_tab[1][(hi >> 16) & 0xFF] ^ g_crc_tab[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = (c >> 8) ^ g_crc_tab[0][(c ^ *p++) & 0xFF];
+  return ~c;
+}
+
+extern "C" int odin_version(void) { return 101; }
 extern "C" const char* odin_last_error(void) { return g_err; }
 
 #ifdef ODIN_SIM

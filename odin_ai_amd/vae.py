@@ -676,6 +676,15 @@ class VariationalAutoencoder:
             self.load_weights(raise_notfound=False)
           eng.flag.zero_()
         history.append((self._step, float(loss)))
+        if logdir is not None:  # Trainer's TensorBoard scalars (training/trainer.py:52-71)
+          if getattr(self, '_events', None) is None or self._events_dir != logdir:
+            from .tf_checkpoint import ScalarEventWriter
+            self._events, self._events_dir = ScalarEventWriter(logdir, lib=eng.lib), logdir
+          self._events.scalar('train/loss', float(loss), self._step)
+          for mk, mv in metrics.items():
+            if not mk.startswith('_grad/'):
+              self._events.scalar(f'train/{mk}', float(mv), self._step)
+          self._events.flush()
       if on_batch_end is not None:
         on_batch_end()
       if valid is not None and on_valid_end is not None and it % valid_freq == 0:
@@ -684,20 +693,32 @@ class VariationalAutoencoder:
     return self
 
   # ------------------------------------------------------------------ checkpoints
-  def save_weights(self, filepath: Optional[str] = None, overwrite: bool = True):
+  def save_weights(self, filepath: Optional[str] = None, overwrite: bool = True,
+                   save_format: str = 'tf'):
     """base_networks.py:373-390: weights + step (optimizer state deliberately not tracked).
-    Written as a plain `.npz` (no pickle): one array per variable under its Keras name
-    (`encoder0/kernel`, ..., `latents/bias`) plus `__step__`."""
+    save_format='tf' (the reference's, :386): a TensorFlow checkpoint `<filepath>.index` +
+    `<filepath>.data-00000-of-00001` whose object graph names every variable by its Keras name
+    (`encoder0/kernel`, ..., `latents/bias`, `Step`) -- readable by `tf.train.load_checkpoint`;
+    save_format='npz': one plain `.npz` with the same names.  No pickle either way."""
     filepath = filepath or self.path
     if filepath is None:
       raise ValueError('No path is given for saving weights')
-    if os.path.exists(self._npz_path(filepath)) and not overwrite:
-      raise RuntimeError(f'{filepath} exists')
     eng = self._engine(1)
     W = {self.variable_name(k): v.detach().cpu().numpy() for k, v in eng.param_views().items()}
-    W['__step__'] = np.asarray(self._step, np.int64)
-    with open(self._npz_path(filepath), 'wb') as f:
-      np.savez(f, **W)
+    if save_format == 'tf':
+      if os.path.exists(filepath + '.index') and not overwrite:
+        raise RuntimeError(f'{filepath} exists')
+      from . import tf_checkpoint
+      W['Step'] = np.asarray(self._step, np.int64)   # base_networks.py:212
+      tf_checkpoint.save_checkpoint(filepath, W, lib=eng.lib)
+    elif save_format == 'npz':
+      if os.path.exists(self._npz_path(filepath)) and not overwrite:
+        raise RuntimeError(f'{filepath} exists')
+      W['__step__'] = np.asarray(self._step, np.int64)
+      with open(self._npz_path(filepath), 'wb') as f:
+        np.savez(f, **W)
+    else:
+      raise ValueError(f"save_format={save_format!r} ('tf' | 'npz')")
     return self
 
   @staticmethod
@@ -705,19 +726,33 @@ class VariationalAutoencoder:
     return filepath if filepath.endswith('.npz') else filepath + '.npz'
 
   def load_weights(self, filepath: Optional[str] = None, raise_notfound: bool = False):
+    """base_networks.py:338-371.  Reads a TensorFlow checkpoint (also one written by the
+    reference: variables are found by their Keras names inside the checkpoint's object graph,
+    whatever the object paths) or the `.npz` form."""
     filepath = filepath or self.path
-    if filepath is None or not os.path.exists(self._npz_path(filepath)):
+    if filepath is not None and os.path.exists(filepath + '.index'):
+      from . import tf_checkpoint
+      d = tf_checkpoint.load_checkpoint(filepath, lib=self._engine(1).lib)
+      step_keys = [k for k in d if k == 'Step' or k.endswith('/Step')]
+      step = int(d[step_keys[0]]) if step_keys else self._step
+    elif filepath is not None and os.path.exists(self._npz_path(filepath)):
+      d = dict(np.load(self._npz_path(filepath), allow_pickle=False))
+      step = int(d.pop('__step__'))
+    else:
       if raise_notfound:
         raise FileNotFoundError(f'Cannot find saved weights at path: {filepath}')
       return self
-    d = np.load(self._npz_path(filepath), allow_pickle=False)
     eng = self._engine(1)
     for k, v in eng.param_views().items():
-      a = d[self.variable_name(k)]
+      name = self.variable_name(k)
+      hits = [n for n in d if n == name or n.endswith('/' + name)]
+      if len(hits) != 1:
+        raise KeyError(f'{name}: {len(hits)} matching variables in the checkpoint ({hits[:3]})')
+      a = d[hits[0]]
       if tuple(a.shape) != tuple(v.shape):
-        raise ValueError(f'{self.variable_name(k)}: checkpoint shape {a.shape} != {tuple(v.shape)}')
-      v.copy_(torch.as_tensor(a, dtype=torch.float32, device=self.device))
-    self._step = int(d['__step__'])
+        raise ValueError(f'{name}: checkpoint shape {a.shape} != {tuple(v.shape)}')
+      v.copy_(torch.as_tensor(np.asarray(a), dtype=torch.float32, device=self.device))
+    self._step = step
     return self
 
   def __str__(self):
