@@ -1629,6 +1629,7 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
 extern "C" int odin_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B,
                               int K, int N, int act, void* stream) {
   if (odin_tiny_dense_ok(B, K, N)) return odin_tiny_dense_fwd(x, w, bias, y, B, K, N, act, stream);
+  if (odin_dense_gemm_ok(B, K, N)) return odin_dense_gemm_fwd(x, w, bias, y, B, K, N, act, stream);
   GParams p;
   memset(&p, 0, sizeof(p));
   p.in = x; p.w = w; p.bias = bias; p.out = y;
@@ -1643,6 +1644,11 @@ extern "C" int odin_dense_dgrad(const float* dy, const float* w, const float* au
                                 int N, void* stream) {
   if (odin_tiny_dense_ok(B, K, N))
     return odin_tiny_dense_dgrad(dy, w, aux, aux_act, dx, colsum_slab, slab_rows_out, B, K, N, stream);
+  if (colsum_slab == nullptr && odin_dense_gemm_ok(B, K, N)) {
+    if (slab_rows_out) *slab_rows_out = 0;
+    if (dx == nullptr) return 0;
+    return odin_dense_gemm_dgrad(dy, w, aux, aux_act, dx, B, K, N, stream);
+  }
   GParams p;
   memset(&p, 0, sizeof(p));
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;

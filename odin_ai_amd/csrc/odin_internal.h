@@ -33,3 +33,12 @@ int odin_pw1x1_dgrad(const float* dy, const float* w, const float* aux, int aux_
                      float* colsum_slab, int* slab_rows_out, const odin_conv_desc* d, void* stream);
 int odin_pw1x1_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out,
                      const odin_conv_desc* d, void* stream);
+
+// Dense layers as small matrix-core GEMMs with operands straight from L2 (dense_gemm.hip)
+bool odin_dense_gemm_ok(int B, int K, int N);
+int odin_dense_gemm_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K,
+                        int N, int act, void* stream);
+int odin_dense_gemm_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                          int B, int K, int N, void* stream);
+int odin_dense_gemm_wgrad(const float* x, const float* dy, float* slab, int B, int K, int N,
+                          void* stream);

@@ -541,13 +541,17 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
     if (T < n_wt) {
       int rt = T / p.ncot, cot = T - rt * p.ncot;
       int co = co0 + cot * 32 + l31;
+      // (tap, channel) of the tile's first row by ONE division; the 16 rows of this lane then step
+      // from it (a per-element `rl / cib` cost ~9 us of integer division on the small layers)
+      const int tap0 = (rt * 32) / cib, cl0 = rt * 32 - tap0 * cib;
+      const bool col_ok = co < p.CO && cot * 32 + l31 < p.COB;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int rl = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (rl < nrows && co < p.CO && cot * 32 + l31 < p.COB) {
-          int tap = rl / cib, cl = rl - tap * cib;
+        const int off = (r & 3) + 8 * (r >> 2) + 4 * h;
+        int tap = tap0, cl = cl0 + off;
+        while (cl >= cib) { cl -= cib; ++tap; }
+        if (rt * 32 + off < nrows && col_ok)
           row[((size_t)tap * p.CI + ci0 + cl) * p.CO + co] = acc[a][r];
-        }
       }
     } else if (T < n_tot) {
       int cot = T - n_wt;
@@ -556,6 +560,7 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
         row[(size_t)ntaps * p.CI * p.CO + co] = acc[a][0];
     }
   }
+  W_STAMP(9);
   if (p.bias_mode == 2 && blockIdx.y == 0) {
     // thread t accumulated channels 4*(t % cpd) .. +3 of this block's output-channel slice
     __syncthreads();
@@ -789,13 +794,15 @@ __global__ __launch_bounds__(2 * NW_W * 64) void wgrad_ws_kernel(WParams p) {
       const int T = wave + a * NW_W;
       if (T < n_wt) {
         const int co = co0 + l31;
+        // one division per tile instead of one per element (see wgrad_kernel's epilogue)
+        const int tap0 = (T * 32) / cib, cl0 = T * 32 - tap0 * cib;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int rl = T * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (rl < nrows && co < p.CO) {
-            const int tap = rl / cib, cl = rl - tap * cib;
+          const int off = (r & 3) + 8 * (r >> 2) + 4 * h;
+          int tap = tap0, cl = cl0 + off;
+          while (cl >= cib) { cl -= cib; ++tap; }
+          if (T * 32 + off < nrows && co < p.CO)
             row[((size_t)tap * p.CI + ci0 + cl) * p.CO + co] = acc[a][r];
-          }
         }
       }
     }
@@ -819,7 +826,7 @@ __global__ __launch_bounds__(2 * NW_W * 64) void wgrad_ws_kernel(WParams p) {
 
 
 bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes, int target = 128,
-                int lds_budget_bytes = 160 * 1024 - 2048) {
+                int lds_budget_bytes = 160 * 1024 - 2048, int cib_limit = 1 << 30) {
   const int S = p.S;
   const int img_pix = p.OH * p.OW;
   const int TARGET = target;
@@ -854,7 +861,7 @@ bool plan_wgrad(WParams& p, int* gx, int* gy, int* gz, size_t* lds_bytes, int ta
     int ncot = COB / 32;
     for (int jc = 0; jc < 6; ++jc) {
       int CIB = cib_c[jc];
-      if (CIB > p.CI) continue;
+      if (CIB > p.CI || CIB > cib_limit) continue;
       if (jc > 0 && CIB == p.CI) continue;
       int nrt = (ntaps * CIB + 31) / 32;
       const bool dv = ((p.CO & 3) == 0) && ((COB & 3) == 0);
@@ -1039,6 +1046,22 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
       if (gx * gy * gz >= 128) break;
     }
   }
+  // tiny images (patch rows of a few pixels: KI <= 2 items per lane): a 128-pixel tile spans many
+  // short rows, and staging them RPWMAX rows per wave at a time costs one HBM round trip per
+  // batch (enc3 / dec1 weight gradients: 10 batches, ~40 us for 0.07-0.5 GFLOP).  Pick the tile
+  // whose rows fit ONE batch of the 12-rows-per-wave instance, so that the staging pipelines.
+  if (!p.flat && p.KI <= 2 && (p.NIMG * p.NRI + NW_W - 1) / NW_W > 12 && !getenv("ODIN_NOWSPLIT")) {
+    for (int tgt = 64; tgt >= 16; tgt >>= 1) {
+      WParams q = p;
+      int gx2, gy2, gz2;
+      size_t lds2;
+      // (same channel block: a smaller pixel tile must not be traded for a wider channel block)
+      if (!plan_wgrad(q, &gx2, &gy2, &gz2, &lds2, tgt, 160 * 1024 - 2048, p.CIB)) break;
+      if (q.KI > 2) break;
+      p = q; gx = gx2; gy = gy2; gz = gz2; lds = lds2;
+      if ((p.NIMG * p.NRI + NW_W - 1) / NW_W <= 12) break;
+    }
+  }
   if (rows_out) *rows_out = gx;
   if (p.slab == nullptr) return 0;  // dry run: planning only
   p.stamps = g_wstamps;
@@ -1052,6 +1075,8 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
     return launch_winst<NACC, 2, 8, 8, true>(p, grid, lds, stream);
   }
   if (nacc <= 4) {
+    if (p.KI <= 2 && rpw > 5 && rpw <= 12 && ditems <= 8 * 256)
+      return launch_winst<4, 2, 12, 8>(p, grid, lds, stream);
     if (p.KI <= 5 && rpw <= 5 && ditems <= 4 * 256) return launch_winst<4, 5, 5, 4>(p, grid, lds, stream);
     if (rpw <= 3 && ditems <= 4 * 256) return launch_winst<4, 9, 3, 4>(p, grid, lds, stream);
     return launch_winst<4, 9, 2, 8>(p, grid, lds, stream);
@@ -1076,6 +1101,54 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceJobs jobs) {
   const size_t st = jb.stride > 0 ? (size_t)jb.stride : (size_t)jb.n;
   const bool vec = ((jb.n & 3) == 0) && ((st & 3) == 0) &&
                    ((((size_t)jb.src | (size_t)jb.dst) & 15) == 0);
+  if (vec && (jb.n >> 2) >= 1024) {
+    // wide jobs (weight tensors): a block owns 256 consecutive floats; every wave-instruction
+    // reads one full KB of a slab row, 8 rows in flight per lane, the 4 waves split the rows
+    __shared__ float4 partw[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n4 = jb.n >> 2;
+    const size_t st4 = st >> 2;
+    for (int c0 = blockIdx.x * 64; c0 < n4; c0 += gridDim.x * 64) {  // block-uniform
+      const int c = c0 + tx;
+      float4 a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < n4) {
+        const float4* s = reinterpret_cast<const float4*>(jb.src) + c;
+        int g = ty;
+        for (; g + 28 < jb.rows; g += 32) {
+          float4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = s[(size_t)(g + 4 * u) * st4];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            a[u].x += v[u].x; a[u].y += v[u].y; a[u].z += v[u].z; a[u].w += v[u].w;
+          }
+        }
+        for (; g < jb.rows; g += 4) {
+          const float4 v0 = s[(size_t)g * st4];
+          a[0].x += v0.x; a[0].y += v0.y; a[0].z += v0.z; a[0].w += v0.w;
+        }
+      }
+      float4 t;
+      t.x = ((a[0].x + a[1].x) + (a[2].x + a[3].x)) + ((a[4].x + a[5].x) + (a[6].x + a[7].x));
+      t.y = ((a[0].y + a[1].y) + (a[2].y + a[3].y)) + ((a[4].y + a[5].y) + (a[6].y + a[7].y));
+      t.z = ((a[0].z + a[1].z) + (a[2].z + a[3].z)) + ((a[4].z + a[5].z) + (a[6].z + a[7].z));
+      t.w = ((a[0].w + a[1].w) + (a[2].w + a[3].w)) + ((a[4].w + a[5].w) + (a[6].w + a[7].w));
+      partw[threadIdx.x] = t;
+      __syncthreads();
+      if (ty == 0 && c < n4) {
+        const float4 q1 = partw[64 + tx], q2 = partw[128 + tx], q3 = partw[192 + tx];
+        t.x = (t.x + q1.x) + (q2.x + q3.x);
+        t.y = (t.y + q1.y) + (q2.y + q3.y);
+        t.z = (t.z + q1.z) + (q2.z + q3.z);
+        t.w = (t.w + q1.w) + (q2.w + q3.w);
+        reinterpret_cast<float4*>(jb.dst)[c] = t;
+      }
+      __syncthreads();
+    }
+    return;
+  }
   if (vec) {
     __shared__ float4 part[256];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -1160,6 +1233,12 @@ extern "C" int odin_deconv2d_wgrad(const float* x, const float* dy, float* slab,
 
 extern "C" int odin_dense_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out,
                                 int B, int K, int N, void* stream) {
+  if (!odin_tiny_dense_ok(B, K, N) && odin_dense_gemm_ok(B, K, N)) {
+    // small GEMM: the waves of a workgroup split the batch, the result is complete: ONE slab row
+    if (slab_rows_out) *slab_rows_out = 1;
+    if (slab == nullptr) return 0;  // dry run
+    return odin_dense_gemm_wgrad(x, dy, slab, B, K, N, stream);
+  }
   WParams p;
   memset(&p, 0, sizeof(p));
   p.in = x; p.dy = dy; p.slab = slab;

@@ -153,7 +153,11 @@ def test_deconv2d_fwd_dgrad_wgrad(bk, B, H, W, Ci, Co, K, S, act):
                                        # in Dense(128 -> 1)
                                        (128, 128, 1, 'linear'), (256, 256, 1, 'linear'),
                                        (200, 256, 4, 'relu'), (64, 128, 2, 'linear'),
-                                       (300, 1, 256, 'linear'), (256, 2, 200, 'relu')])
+                                       (300, 1, 256, 'linear'), (256, 2, 200, 'relu'),
+                                       # small matrix-core GEMMs straight from L2 (dense_gemm.hip): ragged
+                                       # M / N / K, 1..16 waves per tile
+                                       (256, 1024, 128, 'linear'), (37, 1000, 75, 'relu'),
+                                       (128, 70, 1000, 'relu'), (64, 784, 512, 'relu'), (9, 2052, 33, 'linear')])
 def test_dense(bk, B, K, N, act):
   L, T = bk.L, bk.T
   rng = np.random.default_rng(2)

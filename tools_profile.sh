@@ -10,4 +10,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out -o prof -- python3 
 cd $root
 python tools_prof_summary.py $out > gpurun_out/${tag}_summary.txt
 find $out -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} gpurun_out/${tag}_kernel_stats.csv
+python tools_timeline.py $out > gpurun_out/${tag}_timeline.txt 2>&1
 rm -rf $out

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""One training step as a timeline from a rocprofv3 --kernel-trace CSV: start offset, duration,
+stream/queue, kernel (short).  usage: tools_timeline.py <dir> [step_index]"""
+import csv, glob, re, sys
+root = sys.argv[1]
+which = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+rows = []
+for f in glob.glob(root + '/**/*kernel_trace.csv', recursive=True):
+  for r in csv.DictReader(open(f)):
+    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r.get('Queue_Id', '?'), r.get('Stream_Id', '?'),
+                 re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name']), r.get('Grid_Size_X', r.get('Grid_Size', '?'))))
+rows.sort()
+# a step starts at each rng_normal_kernel
+starts = [i for i, r in enumerate(rows) if r[4].startswith('rng_normal_kernel')]
+i0, i1 = starts[which], starts[which + 1]
+t0 = rows[i0][0]
+busy_end = t0
+gaps = 0
+print(f'{"start_us":>9s} {"dur_us":>8s} {"q":>3s} kernel')
+for r in rows[i0:i1]:
+  name = re.sub(r'^void ', '', r[4])
+  name = re.sub(r'\(.*', '', name)[:90]
+  ov = '' if r[0] >= busy_end else f'  (overlaps {min(busy_end, r[1]) - r[0]:.0f} ns)'
+  if r[0] > busy_end:
+    gaps += r[0] - busy_end
+  busy_end = max(busy_end, r[1])
+  print(f'{(r[0]-t0)/1e3:9.1f} {(r[1]-r[0])/1e3:8.1f} {r[2]:>3s} {name} g={r[5]}{ov}')
+print(f'step span {(rows[i1][0]-t0)/1e3:.1f} us, idle gaps inside {gaps/1e3:.1f} us')
