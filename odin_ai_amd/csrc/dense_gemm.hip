@@ -41,7 +41,28 @@ struct DGParams {
 
 constexpr int DG_U = 8;  // k-groups (of 8 k-values) in flight per wave
 
-template <int NW>
+// Unconditional, branch-free operand loads: a masked element carries the out-of-range offset and
+// reads zero through the buffer descriptor's range check.  (With run-time layout flags the
+// compiler built exec-mask branches around every load and drained vmcnt between them: one L2
+// round trip per load.)
+template <bool KC, bool VEC>
+__device__ __forceinline__ void dg_load4(const OdinRun& R, bool ok, int idx, int ld, int k, int K,
+                                         float (&v)[4]) {
+  if constexpr (KC && VEC) {  // K % 4 == 0 and k % 4 == 0: the 4 values are all valid or all beyond K
+    const float4 t = odin_run_load4(R, (ok && k < K) ? (unsigned)((idx * ld + k) * 4) : ODIN_OOB);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (KC) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      v[q] = odin_run_load1(R, (ok && k + q < K) ? (unsigned)((idx * ld + k + q) * 4) : ODIN_OOB);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      v[q] = odin_run_load1(R, (ok && k + q < K) ? (unsigned)(((k + q) * ld + idx) * 4) : ODIN_OOB);
+  }
+}
+
+template <int NW, bool A_KC, bool B_KC, bool VEC>
 __global__ __launch_bounds__(NW * 64) void dense_gemm_kernel(DGParams p) {
   __shared__ float red[NW > 1 ? (NW - 1) * 16 * 64 : 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -51,44 +72,17 @@ __global__ __launch_bounds__(NW * 64) void dense_gemm_kernel(DGParams p) {
   const bool a_ok = ia < p.M, b_ok = jb < p.N;
   // this wave's k range: groups of 8 k-values, dealt round-robin in blocks of DG_U groups
   const int ngroups = (p.K + 7) >> 3;
-  const OdinRun RA = odin_run(p.A, (unsigned)((size_t)(p.a_kc ? p.M * p.lda : p.K * p.lda) * 4));
-  const OdinRun RB = odin_run(p.B, (unsigned)((size_t)(p.b_kc ? p.N * p.ldb : p.K * p.ldb) * 4));
-  const bool a_vec = p.a_kc && ((p.lda & 3) == 0) && ((((size_t)p.A) & 15) == 0);
-  const bool b_vec = p.b_kc && ((p.ldb & 3) == 0) && ((((size_t)p.B) & 15) == 0);
+  const OdinRun RA = odin_run(p.A, (unsigned)((size_t)(A_KC ? p.M * p.lda : p.K * p.lda) * 4));
+  const OdinRun RB = odin_run(p.B, (unsigned)((size_t)(B_KC ? p.N * p.ldb : p.K * p.ldb) * 4));
   f32x16 acc = f32x16_zero();
   float csum = 0.f;  // wgrad bias: column sum of B over this wave's k range (lane j = l31, half h)
-
-  auto load_op = [&](const OdinRun& R, bool kc, bool vec, bool ok, int idx, int ld, int kb,
-                     float (&v)[4]) {
-    const int k = kb + 4 * h;
-    if (kc) {
-      if (vec && k + 3 < p.K) {
-        const float4 t = odin_run_load4(R, ok ? (unsigned)((idx * ld + k) * 4) : ODIN_OOB);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          v[q] = odin_run_load1(R, (ok && k + q < p.K) ? (unsigned)((idx * ld + k + q) * 4) : ODIN_OOB);
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        v[q] = odin_run_load1(R, (ok && k + q < p.K) ? (unsigned)(((k + q) * ld + idx) * 4) : ODIN_OOB);
-    }
-  };
-
   for (int g0 = wave * DG_U; g0 < ngroups; g0 += NW * DG_U) {
     float av[DG_U][4], bv[DG_U][4];
 #pragma unroll
     for (int u = 0; u < DG_U; ++u) {
-      const int kb = (g0 + u) * 8;
-      if (g0 + u < ngroups) {
-        load_op(RA, p.a_kc != 0, a_vec, a_ok, ia, p.lda, kb, av[u]);
-        load_op(RB, p.b_kc != 0, b_vec, b_ok, jb, p.ldb, kb, bv[u]);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { av[u][q] = 0.f; bv[u][q] = 0.f; }
-      }
+      const int k = (g0 + u) * 8 + 4 * h;  // groups beyond K read zeros
+      dg_load4<A_KC, VEC>(RA, a_ok, ia, p.lda, k, p.K, av[u]);
+      dg_load4<B_KC, VEC>(RB, b_ok, jb, p.ldb, k, p.K, bv[u]);
     }
 #pragma unroll
     for (int u = 0; u < DG_U; ++u) {
@@ -140,6 +134,16 @@ __global__ __launch_bounds__(NW * 64) void dense_gemm_kernel(DGParams p) {
   }
 }
 
+template <bool A_KC, bool B_KC, bool VEC>
+int dg_launch_t(DGParams& p, dim3 grid, int nw, void* stream) {
+  if (nw >= 16) ODIN_LAUNCH((dense_gemm_kernel<16, A_KC, B_KC, VEC>), grid, dim3(1024), 0, stream, p);
+  else if (nw == 8) ODIN_LAUNCH((dense_gemm_kernel<8, A_KC, B_KC, VEC>), grid, dim3(512), 0, stream, p);
+  else if (nw == 4) ODIN_LAUNCH((dense_gemm_kernel<4, A_KC, B_KC, VEC>), grid, dim3(256), 0, stream, p);
+  else if (nw == 2) ODIN_LAUNCH((dense_gemm_kernel<2, A_KC, B_KC, VEC>), grid, dim3(128), 0, stream, p);
+  else ODIN_LAUNCH((dense_gemm_kernel<1, A_KC, B_KC, VEC>), grid, dim3(64), 0, stream, p);
+  return odin_check_launch("dense_gemm");
+}
+
 int dg_launch(DGParams& p, void* stream) {
   dim3 grid((p.N + 31) / 32, (p.M + 31) / 32, 1);
   const long tiles = (long)grid.x * grid.y;
@@ -147,12 +151,16 @@ int dg_launch(DGParams& p, void* stream) {
   // waves per tile: enough k-groups per wave to amortise the launch, enough waves to fill the chip
   int nw = 1;
   while (nw < 16 && tiles * nw < 2 * 256 && ngroups / (nw * 2) >= DG_U) nw *= 2;
-  if (nw >= 16) ODIN_LAUNCH((dense_gemm_kernel<16>), grid, dim3(1024), 0, stream, p);
-  else if (nw == 8) ODIN_LAUNCH((dense_gemm_kernel<8>), grid, dim3(512), 0, stream, p);
-  else if (nw == 4) ODIN_LAUNCH((dense_gemm_kernel<4>), grid, dim3(256), 0, stream, p);
-  else if (nw == 2) ODIN_LAUNCH((dense_gemm_kernel<2>), grid, dim3(128), 0, stream, p);
-  else ODIN_LAUNCH((dense_gemm_kernel<1>), grid, dim3(64), 0, stream, p);
-  return odin_check_launch("dense_gemm");
+  // 16-byte loads along k: every k-contiguous operand has rows of a multiple of 4 floats
+  const bool vec = (p.K % 4 == 0) && (!p.a_kc || ((p.lda & 3) == 0 && (((size_t)p.A) & 15) == 0)) &&
+                   (!p.b_kc || ((p.ldb & 3) == 0 && (((size_t)p.B) & 15) == 0));
+  if (p.a_kc && p.b_kc)
+    return vec ? dg_launch_t<true, true, true>(p, grid, nw, stream)
+               : dg_launch_t<true, true, false>(p, grid, nw, stream);
+  if (p.a_kc)
+    return vec ? dg_launch_t<true, false, true>(p, grid, nw, stream)
+               : dg_launch_t<true, false, false>(p, grid, nw, stream);
+  return dg_launch_t<false, false, false>(p, grid, nw, stream);
 }
 
 }  // namespace

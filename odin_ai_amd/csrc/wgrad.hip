@@ -1160,6 +1160,20 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceJobs jobs) {
         const float4* s = reinterpret_cast<const float4*>(jb.src) + c;
         const size_t st4 = st >> 2;
         int g = ty;
+        for (; g + 112 < jb.rows; g += 128) {  // 8 rows in flight
+          const float4 v0 = s[(size_t)g * st4], v1 = s[(size_t)(g + 16) * st4];
+          const float4 v2 = s[(size_t)(g + 32) * st4], v3 = s[(size_t)(g + 48) * st4];
+          const float4 v4 = s[(size_t)(g + 64) * st4], v5 = s[(size_t)(g + 80) * st4];
+          const float4 v6 = s[(size_t)(g + 96) * st4], v7 = s[(size_t)(g + 112) * st4];
+          a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+          a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+          a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+          a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+          a0.x += v4.x; a0.y += v4.y; a0.z += v4.z; a0.w += v4.w;
+          a1.x += v5.x; a1.y += v5.y; a1.z += v5.z; a1.w += v5.w;
+          a2.x += v6.x; a2.y += v6.y; a2.z += v6.z; a2.w += v6.w;
+          a3.x += v7.x; a3.y += v7.y; a3.z += v7.z; a3.w += v7.w;
+        }
         for (; g + 48 < jb.rows; g += 64) {
           const float4 v0 = s[(size_t)g * st4], v1 = s[(size_t)(g + 16) * st4];
           const float4 v2 = s[(size_t)(g + 32) * st4], v3 = s[(size_t)(g + 48) * st4];
@@ -1189,18 +1203,39 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceJobs jobs) {
     }
     return;
   }
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < jb.n; i += gridDim.x * 256) {
-    const float* s = jb.src + i;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int g = 0;
-    for (; g + 3 < jb.rows; g += 4) {
-      a0 += s[(size_t)g * st];
-      a1 += s[(size_t)(g + 1) * st];
-      a2 += s[(size_t)(g + 2) * st];
-      a3 += s[(size_t)(g + 3) * st];
+  // odd-sized jobs (the fused tail's 65-float rows, 33-float heads): 32 result elements per block,
+  // 8 row phases per element, 8 loads in flight per thread -- a one-thread-per-element loop walks
+  // 256+ rows serially (dozens of dependent L2 round trips: it set the duration of the whole launch)
+  {
+    __shared__ float parts[256];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i0 = blockIdx.x * 32; i0 < jb.n; i0 += gridDim.x * 32) {  // block-uniform
+      const int i = i0 + tx;
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = 0.f;
+      if (i < jb.n) {
+        const float* s = jb.src + i;
+        int g = ty;
+        for (; g + 56 < jb.rows; g += 64) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = s[(size_t)(g + 8 * u) * st];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] += v[u];
+        }
+        for (; g < jb.rows; g += 8) a[0] += s[(size_t)g * st];
+      }
+      parts[threadIdx.x] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      __syncthreads();
+      if (ty == 0 && i < jb.n) {
+        float t = parts[tx];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) t += parts[u * 32 + tx];
+        jb.dst[i] = t;
+      }
+      __syncthreads();
     }
-    for (; g < jb.rows; ++g) a0 += s[(size_t)g * st];
-    jb.dst[i] = (a0 + a1) + (a2 + a3);
   }
 }
 
