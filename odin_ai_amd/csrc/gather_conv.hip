@@ -1577,6 +1577,11 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
                                const odin_conv_desc* d, void* stream) {
   if (odin_smallc_applicable(d)) return odin_smallc_fwd(x, w, bias, y, d, stream);
   if (odin_pw1x1_applicable(d)) return odin_pw1x1_fwd(x, w, bias, y, d, stream);
+  if (d->act == ODIN_ACT_ELU && bias != nullptr &&
+      odin_fconv_ring_applicable(d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
+                                 d->pad_t, d->pad_l, d->center))
+    return odin_fconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->OH,
+                                  d->OW, d->Cout, 1, stream);
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = y;
@@ -1616,6 +1621,12 @@ extern "C" int odin_deconv2d_fwd(const float* x, const float* w, const float* bi
 extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float* aux,
                                    int aux_act, float* dx, float* colsum_slab,
                                    int* slab_rows_out, const odin_conv_desc* d, void* stream) {
+  // data gradient of a Conv2DTranspose = strided gather over dY: input (OH, OW, Cout), output (H, W, Cin)
+  if (aux_act == ODIN_ACT_ELU && (aux != nullptr || dx == nullptr) &&
+      odin_fconv_ring_applicable(d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
+                                 d->pad_t, d->pad_l, 0))
+    return odin_fconv_ring_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, d->B, d->OH,
+                                  d->OW, d->H, d->W, d->Cin, 2, stream);
   GParams p;
   fill_common(p, d);
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;
@@ -1683,5 +1694,6 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
 // diagnostics: device buffer (>= 64 int64) receiving s_memtime stamps of workgroup 0
 extern "C" int odin_debug_set_stamps(void* buf) {
   g_stamps = (long long*)buf;
+  odin_fconv_ring_set_stamps(buf);
   return 0;
 }

@@ -42,3 +42,11 @@ int odin_dense_gemm_dgrad(const float* dy, const float* w, const float* aux, int
                           int B, int K, int N, void* stream);
 int odin_dense_gemm_wgrad(const float* x, const float* dy, float* slab, int B, int K, int N,
                           void* stream);
+
+// 4x4 / stride-2 gather convolution over 32 channels with a rolling LDS row window (fconv_ring.hip)
+bool odin_fconv_ring_applicable(int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
+                                int pt, int pl, int center);
+int odin_fconv_ring_launch(const float* in, const float* w, const float* bias, const float* aux,
+                           float* out, float* colsum, int* rows_out, int B, int H, int W, int OH,
+                           int OW, int CO, int epi, void* stream);
+void odin_fconv_ring_set_stamps(void* buf);

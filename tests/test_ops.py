@@ -53,7 +53,10 @@ CONV_CASES = [
     (3, 16, 16, 32, 32, 4, 2, 'elu', False),   # wgrad row-chunk loop (S*P = 64), two images per tile, ragged
     (2, 16, 16, 64, 32, 4, 2, 'elu', False),   # wgrad row-chunk loop (S*P = 128)
     (1, 16, 16, 32, 32, 3, 1, 'relu', False),  # wgrad row-chunk loop (S*P = 32), 16-wide rows
-    (1, 32, 32, 32, 32, 4, 2, 'elu', False),   # two-workgroup data-gradient instance (EPI 2)
+    (1, 32, 32, 32, 32, 4, 2, 'elu', False),   # two-workgroup data-gradient instance (EPI 2); fwd: rolling-window kernel
+    (5, 32, 32, 32, 32, 4, 2, 'elu', False),   # fconv_ring forward: several tiles per workgroup across image boundaries
+    (2, 64, 64, 32, 32, 4, 2, 'elu', False),   # fconv_ring forward, 32-pixel output rows (2-row tiles)
+    (3, 32, 32, 32, 64, 4, 2, 'elu', False),   # fconv_ring forward, two 32-channel output blocks
 ]
 
 
@@ -99,7 +102,10 @@ def test_conv2d_fwd_dgrad_wgrad(bk, B, H, W, Ci, Co, K, S, act, center):
 
 
 DECONV_CASES = [
-    (1, 16, 16, 32, 32, 4, 2, 'elu'),          # two-workgroup forward instance (EPI 1)
+    (1, 16, 16, 32, 32, 4, 2, 'elu'),          # two-workgroup forward instance (EPI 1); dgrad: rolling-window kernel
+    (5, 16, 16, 32, 32, 4, 2, 'elu'),          # fconv_ring data gradient across image boundaries
+    (2, 32, 32, 32, 32, 4, 2, 'elu'),          # fconv_ring data gradient, 32-pixel rows (decoder4)
+    (3, 16, 16, 64, 32, 4, 2, 'elu'),          # fconv_ring data gradient into 64 channels (decoder3)
     (3, 4, 4, 8, 64, 4, 2, 'elu'),
     (2, 8, 8, 64, 32, 4, 2, 'elu'),
     (1, 16, 16, 32, 32, 4, 2, 'linear'),
