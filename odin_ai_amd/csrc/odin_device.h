@@ -33,6 +33,7 @@ __device__ __forceinline__ float odin_log(float x) { return __logf(x); }
 #endif
 #define ODIN_SG_MFMA 0x8
 #define ODIN_SG_DSREAD 0x100
+#define ODIN_SG_VALU 0x402  // VALU | TRANS (everything on the vector ALU except MFMA)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // pairs of floats: arithmetic on them compiles to the packed v_pk_{add,mul,fma}_f32 instructions
@@ -177,6 +178,17 @@ __device__ __forceinline__ float odin_run_load1(const OdinRun& R, unsigned off) 
 #endif
 }
 
+// range-checked store: lanes with an offset outside [0, bytes) (ODIN_OOB) write nothing -- a
+// predicated store without an exec-mask branch, so it stays inside one scheduling region
+__device__ __forceinline__ void odin_run_store1(const OdinRun& R, unsigned off, float v) {
+#ifdef ODIN_SIM
+  if ((unsigned long long)off + 4 <= R.bytes)
+    *reinterpret_cast<float*>(const_cast<char*>(R.base) + off) = v;
+#else
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), R.r, off, 0, 0);
+#endif
+}
+
 // LDS-DMA: every active lane moves 16 bytes from the run straight into LDS at
 // lds_base + lane*16 (lds_base wave-uniform, 16-byte aligned); no VGPR destination, no ds_write.
 // Completion is tracked by the issuing wave's vmcnt.  Never issued with out-of-range offsets
@@ -221,6 +233,23 @@ __device__ __forceinline__ void odin_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+// Sum over the 4 rows of 16 lanes (lanes l, l ^ 16, l ^ 32, l ^ 48); every lane receives the
+// total.  gfx950 row swaps (v_permlane32_swap / v_permlane16_swap) keep it on the vector ALU: no
+// LDS round trip (ds_bpermute + lgkmcnt wait) in the middle of an MFMA stream.
+__device__ __forceinline__ float odin_rowsum4(float x) {
+#ifdef ODIN_SIM
+  const float y = x + __shfl_xor(x, 32);
+  return y + __shfl_xor(y, 16);
+#else
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float y = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const unsigned w = __float_as_uint(y);
+  const auto q = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 #endif
 }
 

@@ -50,3 +50,13 @@ int odin_fconv_ring_launch(const float* in, const float* w, const float* bias, c
                            float* out, float* colsum, int* rows_out, int B, int H, int W, int OH,
                            int OW, int CO, int epi, void* stream);
 void odin_fconv_ring_set_stamps(void* buf);
+
+// transposed 4x4 / stride-2 gather over 32 channels, rolling LDS row window (tconv_ring.hip)
+void odin_tconv_ring_set_stamps(void* buf);
+bool odin_tconv_ring_applicable(int H, int W, int CI, int CO, int KH, int KW, int S, int pt, int pl,
+                                int center);
+int odin_tconv_ring_launch(const float* in, const float* w, const float* bias, const float* aux,
+                           float* out, float* colsum, int* rows_out, const float* w1, const float* b1,
+                           const float* target, float* logits, float* llk_part, int* n_part_out,
+                           float* slab, const float* scale, int C1, int B, int H, int W, int CO,
+                           int epi, void* stream);

@@ -109,6 +109,8 @@ DECONV_CASES = [
     (3, 4, 4, 8, 64, 4, 2, 'elu'),
     (2, 8, 8, 64, 32, 4, 2, 'elu'),
     (1, 16, 16, 32, 32, 4, 2, 'linear'),
+    (3, 32, 32, 32, 32, 4, 2, 'elu'),          # tconv_ring forward, 32-pixel rows, several images
+    (2, 16, 16, 32, 64, 4, 2, 'elu'),          # tconv_ring forward, two 32-channel output blocks
     (2, 8, 8, 8, 64, 4, 1, 'elu'),
     (3, 7, 7, 4, 16, 5, 2, 'elu'),
 ]
@@ -197,6 +199,8 @@ def test_dense(bk, B, K, N, act):
     (1, 1, 16, 16, 32, 32, 4, 2, 1),   # two-workgroup fused tail instance (also the shape of the opt-in bf16-plane path)
     (1, 3, 8, 8, 8, 16, 4, 2, 3),      # generic transposed
     (0, 2, 16, 16, 8, 24, 5, 1, 1),    # generic gather conv (MNIST-style decoder tail)
+    (1, 3, 16, 16, 32, 32, 4, 2, 3),   # tconv_ring fused tail: 3 logit maps, tiles across image boundaries
+    (1, 2, 32, 32, 32, 32, 4, 2, 1),   # tconv_ring fused tail, 32-pixel input rows (dSprites / Shapes3D decoder4)
 ])
 def test_bernoulli_tail(bk, is_deconv, B, H, W, Ci, Co, K, S, C1):
   L, T = bk.L, bk.T
@@ -272,3 +276,28 @@ def test_split_bf16_path_matches_fp32(bk, monkeypatch):
   for o in outs[1:]:
     assert np.abs(outs[0] - o).max() <= 2e-6 * np.abs(outs[0]).max()
     assert not np.array_equal(outs[0], o)  # the split path really ran (different rounding)
+
+
+@pytest.mark.parametrize('kind,args', [
+    ('tail', (1, 3, 16, 16, 32, 32, 4, 2, 3)),
+    ('tail', (1, 2, 32, 32, 32, 32, 4, 2, 1)),
+    ('deconv', (3, 32, 32, 32, 32, 4, 2, 'elu')),
+    ('deconv', (2, 16, 16, 32, 64, 4, 2, 'elu')),
+    ('conv', (5, 32, 32, 32, 32, 4, 2, 'elu', False)),
+    ('conv', (2, 64, 64, 32, 32, 4, 2, 'elu', False)),
+])
+def test_tconv_ring_fp32_opt_in(bk, kind, args):
+  """ODIN_TRING=1: the all-fp32 rolling-window kernel for transposed 4x4/s2 gathers over 32 channels
+  (tconv_ring.hip: LDS-DMA row ring, 8 consumer + 4 producer waves meeting through LDS counters)
+  -- deconv forward, Conv2D data gradient and the fused Bernoulli tail with 1 / 3 logit maps."""
+  import os
+  os.putenv('ODIN_TRING', '1')
+  try:
+    if kind == 'tail':
+      test_bernoulli_tail(bk, *args)
+    elif kind == 'deconv':
+      test_deconv2d_fwd_dgrad_wgrad(bk, *args)
+    else:
+      test_conv2d_fwd_dgrad_wgrad(bk, *args)
+  finally:
+    os.unsetenv('ODIN_TRING')

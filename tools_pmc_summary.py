@@ -7,7 +7,7 @@ for f in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
   for r in csv.DictReader(open(f)):
     name = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
     name = re.sub(r'\(.*', '', name)[:70]
-    key = (name, r.get('Grid_Size', '?'))
+    key = (name, r.get('Grid_Size', '?') + '/lds' + r.get('LDS_Block_Size', '?'))
     acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
 names = sorted({c for v in acc.values() for c in v})
 print('kernel | grid | n | ' + ' | '.join(names))
