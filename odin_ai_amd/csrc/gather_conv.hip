@@ -1600,6 +1600,13 @@ extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* a
   // data gradient of a Conv2D = transposed gather over dY: input (OH, OW, Cout), output (H, W, Cin)
   if (aux_act == ODIN_ACT_ELU && (aux != nullptr || dx == nullptr) && d->H == 2 * d->OH &&
       d->W == 2 * d->OW &&
+      odin_tconv_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t,
+                                   d->pad_l, 0, 2, 1))
+    return odin_tconv_planes_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->OH,
+                                    d->OW, d->Cin, 2, stream);
+  if (aux_act == ODIN_ACT_ELU && (aux != nullptr || dx == nullptr) && d->H == 2 * d->OH &&
+      d->W == 2 * d->OW &&
       odin_tconv_ring_applicable(d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t,
                                  d->pad_l, 0))
     return odin_tconv_ring_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, nullptr, nullptr,
@@ -1618,6 +1625,12 @@ extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* a
 // SAME pads of the forward conv on the OUTPUT size) ------------------------------------
 extern "C" int odin_deconv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                                  const odin_conv_desc* d, void* stream) {
+  if (d->act == ODIN_ACT_ELU && bias != nullptr && d->OH == 2 * d->H && d->OW == 2 * d->W &&
+      odin_tconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
+                                   d->pad_l, d->center, 1, 1))
+    return odin_tconv_planes_launch(x, w, bias, nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->H, d->W,
+                                    d->Cout, 1, stream);
   if (d->act == ODIN_ACT_ELU && bias != nullptr && d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_tconv_ring_applicable(d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
                                  d->pad_l, d->center))
@@ -1691,6 +1704,12 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
                                            float* llk_part, int* n_part_out, float* tail_slab,
                                            int* slab_rows_out, const float* scale,
                                            const odin_conv_desc* d, int C1, void* stream) {
+  if (is_deconv && d->act == ODIN_ACT_ELU && d->OH == 2 * d->H && d->OW == 2 * d->W &&
+      odin_tconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
+                                   d->pad_l, d->center, 3, C1))
+    return odin_tconv_planes_launch(x, w, bias, nullptr, g_out, nullptr, slab_rows_out, w1, b1, target,
+                                    logits, llk_part, n_part_out, tail_slab, scale, C1, d->B, d->H, d->W,
+                                    d->Cout, 3, stream);
   if (is_deconv && d->act == ODIN_ACT_ELU && d->Cout == 32 && (C1 == 1 || C1 == 3) &&
       d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_tconv_ring_applicable(d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
@@ -1717,5 +1736,6 @@ extern "C" int odin_debug_set_stamps(void* buf) {
   g_stamps = (long long*)buf;
   odin_fconv_ring_set_stamps(buf);
   odin_tconv_ring_set_stamps(buf);
+  odin_tconv_planes_set_stamps(buf);
   return 0;
 }

@@ -60,3 +60,14 @@ int odin_tconv_ring_launch(const float* in, const float* w, const float* bias, c
                            const float* target, float* logits, float* llk_part, int* n_part_out,
                            float* slab, const float* scale, int C1, int B, int H, int W, int CO,
                            int epi, void* stream);
+
+// the same transposed gathers through the bf16 matrix pipe: fp32 operands as three exact bf16 planes,
+// split once on the way into LDS (tconv_planes.hip)
+void odin_tconv_planes_set_stamps(void* buf);
+bool odin_tconv_planes_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt,
+                                  int pl, int center, int epi, int C1);
+int odin_tconv_planes_launch(const float* in, const float* w, const float* bias, const float* aux,
+                             float* out, float* colsum, int* rows_out, const float* w1, const float* b1,
+                             const float* target, float* logits, float* llk_part, int* n_part_out,
+                             float* slab, const float* scale, int C1, int B, int H, int W, int CO,
+                             int epi, void* stream);

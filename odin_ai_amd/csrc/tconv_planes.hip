@@ -1,0 +1,626 @@
+// tconv_planes.hip -- TRANSPOSED gather convolution 4x4 / stride 2 over 32 reduction channels with
+// fp32 operands carried through the bf16 matrix pipe as three exact bf16 planes (odin_device.h:
+// x = x0 + x1 + x2 by truncation; the six plane products with i + j <= 2 are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16 -- error <= 3 * 2^-24 per product, fp32-class).
+//
+// Serves (TF `SAME`, pads (1, 1)):
+//   Conv2DTranspose(k4, s2) forward from 32 channels          (image_networks.py:503-506, decoder4)
+//   Conv2D(k4, s2) DATA GRADIENT into 32-channel inputs       (tape.gradient of encoder1)
+//   the fused decoder tail: decoder4 -> Conv2D 1x1 (decoder6) -> Independent(Bernoulli) log-prob AND
+//   its backward in the epilogue (image_networks.py:505-511, 87-93; variational_autoencoder.py:528-530)
+// i.e.  out[b, oh, ow, n] = sum over (kh, kw) with (oh + 1 - kh), (ow + 1 - kw) even, c < 32 of
+//       in[b, (oh + 1 - kh) / 2, (ow + 1 - kw) / 2, c] * W[kh, kw, n, c]
+//
+// Why planes, and why split ONCE: measured on gfx950 (tools_micro/mfma_fillers.hip,
+// mfma_bf16_fillers.hip) v_mfma_f32_*_f32 shares the vector ALU's issue -- every VALU instruction of
+// an epilogue adds its full time to an fp32 MFMA stream, from the same wave or from a partner wave --
+// while bf16 MFMAs run beside the VALU (5 VALU instructions per 32-cycle MFMA are free) at 16x the
+// fp32 MFMA rate.  Six bf16 plane products per 16 k-values take 2.7x less matrix time than the
+// fp32 MFMAs of the same block, and the epilogue hides behind them.  Splitting costs ~6 VALU instructions per element, so every input element is split
+// exactly once per workgroup, on its way from HBM into LDS: global_load -> registers -> three
+// ds_write_b64 (no LDS-DMA: DMA cannot convert).  The weights are split once per workgroup too.
+//
+// Structure: 8 waves, all alike.  LDS = weight planes [tap][plane][k-piece][co][8 bf16] (96 KB) +
+// a rolling window of input rows, slot = global padded row mod NSLOT, each [plane][pixel][32 bf16]
+// with the 16-byte k-pieces XOR-swizzled by (pixel >> 2) so that the 16-lane groups of ds_read_b128
+// (MI355X_MICROARCH.md, LDS) hit 16 distinct slots of the 256-byte bank row.  A tile = RP input
+// rows (RP * W = 64) = 2 RP output rows; a wave owns one (column parity, row parity) class and one
+// 32-pixel group of the tile: 4 taps x 2 k-halves x 6 plane products = 48 MFMAs per tile, with the
+// previous tile's epilogue, the split + store of the next tile's rows and the loads of the one after
+// scheduled into the same MFMA stream.  One workgroup barrier per tile.
+#include "odin_device.h"
+#include "odin_internal.h"
+#include <cstdlib>
+
+namespace {
+
+struct TPParams {
+  const float* in;     // [B, H, W, 32]
+  const float* w;      // [16 taps][CO][32]
+  const float* bias;   // EPI 1 / 3: [CO]
+  const float* aux;    // EPI 2: [B, 2H, 2W, CO], out *= ELU'(aux)
+  float* out;          // [B, 2H, 2W, CO]  (EPI 3: dL/d pre-activation of this layer)
+  float* colsum;       // EPI 2: [gridDim.x][CO]
+  // fused tail (EPI 3)
+  const float* w1;     // [CO][C1]
+  const float* b1;     // [C1]
+  const float* target; // [B, 2H, 2W, C1]
+  float* logits;       // optional [B, 2H, 2W, C1]
+  float* llk_part;     // [n_tiles][8 waves]
+  float* slab;         // [gridDim.x][CO * C1 + C1 + CO]
+  const float* scale;  // device scalar 1/B
+  int B, H, CO;
+  int tiles_per_img, n_tiles, tiles_per_wg;
+  long long* stamps;   // diagnostics: s_memtime stamps of workgroup 0 (wave 0: [0,32), wave 4: [32,64))
+};
+
+#ifdef ODIN_SIM
+#define TP_STAMP(k) ((void)0)
+#else
+#define TP_STAMP(k)                                                                               \
+  do {                                                                                            \
+    if (p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0 && \
+        stamp_i < 31)                                                                             \
+      p.stamps[8 * wave + stamp_i++] = ((long long)(k) << 56) | (long long)(clock64() & 0xFFFFFFFFFFFFFFll); \
+  } while (0)
+#endif
+
+struct TpYes { static constexpr bool value = true; };
+struct TpNo { static constexpr bool value = false; };
+
+constexpr int TP_WBYTES = 16 * 3 * 4 * 512;  // weight planes: 96 KB
+
+// x + the value of lane ^ 32
+__device__ __forceinline__ float tp_pairsum32(float x) {
+#ifdef ODIN_SIM
+  return x + __shfl_xor(x, 32);
+#else
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
+}
+
+// four consecutive fp32 values -> their three bf16 planes (4 bf16 = 8 bytes each), exact
+__device__ __forceinline__ void tp_split4(const float4& v, u32x2& h, u32x2& m, u32x2& l) {
+  h = odin_u2(odin_pack_bf16(v.x, v.y), odin_pack_bf16(v.z, v.w));
+  const float r0 = odin_bf16_rest(v.x), r1 = odin_bf16_rest(v.y), r2 = odin_bf16_rest(v.z),
+              r3 = odin_bf16_rest(v.w);
+  m = odin_u2(odin_pack_bf16(r0, r1), odin_pack_bf16(r2, r3));
+  l = odin_u2(odin_pack_bf16(odin_bf16_rest(r0), odin_bf16_rest(r1)),
+              odin_pack_bf16(odin_bf16_rest(r2), odin_bf16_rest(r3)));
+}
+
+struct TpItem {
+  float4 v;
+  int dst;  // byte offset of the hi-plane store inside the ring (no item: inside the spare slot)
+};
+
+// EPI 1: bias + ELU; EPI 2: x ELU'(aux) + column sums; EPI 3: fused Bernoulli tail with C1 logit maps
+// DBG (diagnostics only, ODIN_TP_DBG): 1 = no global stores of `out`, 2 = no LDS reads in the MFMA loop,
+// 4 = no epilogue micro-ops
+template <int EPI, int C1, int W, int DBG = 0>
+__global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
+  constexpr int RP = 64 / W;              // input rows per tile
+  constexpr int NSLOT = 2 * RP + 3;       // live rows of a tile (RP + 2) + the next tile's (RP + 1 at an image seam)
+  constexpr int PB = (W + 2) * 64;        // one plane of a row: W + 2 pixels x 32 bf16
+  constexpr int RB = 3 * PB;
+  constexpr int CPR = W / 8;              // 1 KB load items (8 pixels x 32 channels fp32) per row
+  constexpr int CSHIFT = (W == 32) ? 2 : 1;
+  ODIN_DYN_SMEM(char, smem);
+  char* wl = smem;
+  char* ring = smem + TP_WBYTES;
+  constexpr int NRED = 32 * (1 + (EPI == 3 ? C1 : 0)) + 4;  // per-wave reduction row
+  __shared__ float cred[8 * NRED];
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef ODIN_SIM
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int l31 = lane & 31, half = lane >> 5;
+  int stamp_i = 0;
+  (void)stamp_i;
+  TP_STAMP(1);
+  const int n0 = blockIdx.y * 32;
+  const int HP = p.H + 1;
+  const int OH = 2 * p.H, OW = 2 * W;
+  const int T0 = blockIdx.x * p.tiles_per_wg;
+  int T1 = T0 + p.tiles_per_wg;
+  if (T1 > p.n_tiles) T1 = p.n_tiles;
+  if (T0 >= T1) return;
+
+  // ---- weights: fp32 [tap][co][32] -> planes [tap][plane][k-piece][co][8 bf16] ----
+  {
+    float4 wv[8];  // all 8 loads of a thread in flight before the first split
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + 512 * j;
+      const int ci4 = e & 7, co = (e >> 3) & 31, tap = e >> 8;
+      wv[j] = *reinterpret_cast<const float4*>(p.w + ((size_t)(tap * p.CO + n0 + co) * 32 + 4 * ci4));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + 512 * j;
+      const int ci4 = e & 7, co = (e >> 3) & 31, tap = e >> 8;
+      u32x2 h, m, l;
+      tp_split4(wv[j], h, m, l);
+      char* d = wl + tap * 6144 + (ci4 >> 1) * 512 + co * 16 + (ci4 & 1) * 8;
+      *reinterpret_cast<u32x2*>(d) = h;
+      *reinterpret_cast<u32x2*>(d + 2048) = m;
+      *reinterpret_cast<u32x2*>(d + 4096) = l;
+    }
+  }
+  // ---- SAME-padding pixels (pc = 0 and pc = W + 1) of every ring row and plane: zero for ever ----
+  for (int e = tid; e < NSLOT * 24; e += 512) {
+    const int sl = e / 24, rem = e - sl * 24;
+    const int pl = rem >> 3, side = (rem >> 2) & 1, piece = rem & 3;
+    *reinterpret_cast<float4*>(ring + sl * RB + pl * PB + (side ? (W + 1) * 64 : 0) + piece * 16) =
+        make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- row fills: wave-uniform walk over the padded rows; a wave moves up to two 1 KB items ----
+  const OdinRun IN = odin_run(p.in, (unsigned)((size_t)p.B * p.H * W * 32 * 4));
+  int f_gi, f_b, f_slot, f_g, need_g0, ft_t;
+  {
+    const int b0 = T0 / p.tiles_per_img, t0 = T0 - b0 * p.tiles_per_img;
+    f_g = HP * b0 + RP * t0;
+    f_gi = RP * t0;
+    f_b = b0;
+    f_slot = f_g % NSLOT;
+    need_g0 = f_g;
+    ft_t = t0;
+  }
+  // loads the rows tile `need` still misses into registers; advances the walk
+  auto load_fill = [&](TpItem (&it)[2], bool live) {
+    const int nrows = live ? need_g0 + RP + 2 - f_g : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = wave + 8 * j;
+      const int r = idx >> CSHIFT, c = idx & (CPR - 1);
+      const bool valid = r < nrows;
+      int gi = f_gi + r, b = f_b;
+      if (gi >= HP) { gi -= HP; ++b; }
+      int slot = f_slot + r;
+      if (slot >= NSLOT) slot -= NSLOT;
+      const int px = 8 * c + (lane >> 3), ch4 = lane & 7;
+      const int pc = px + 1;
+      it[j].dst = valid ? slot * RB + pc * 64 + ((((ch4 >> 1) ^ ((pc >> 2) & 3))) << 4) + (ch4 & 1) * 8
+                        : NSLOT * RB + lane * 8;  // spare slot
+      const bool real = valid && gi != 0 && b < p.B;  // gi == 0: the zero row between images
+      it[j].v = odin_run_load4(IN, real ? (unsigned)(((((size_t)b * p.H + gi - 1) * W + px) * 32 + 4 * ch4) * 4)
+                                        : ODIN_OOB);
+    }
+    if (live) {
+      f_g += nrows;
+      f_gi += nrows;
+      if (f_gi >= HP) { f_gi -= HP; ++f_b; }
+      f_slot += nrows;
+      if (f_slot >= NSLOT) f_slot -= NSLOT;
+      need_g0 += RP;
+      if (++ft_t == p.tiles_per_img) { ft_t = 0; need_g0 += 1; }
+    }
+  };
+  // (no branch: a wave without an item splits zeros into the spare slot behind the ring, so the
+  // split stays inside the scheduling region of its MFMA step)
+  auto store_fill1 = [&](const TpItem& it) {
+    u32x2 h, m, l;
+    tp_split4(it.v, h, m, l);
+    char* d = ring + it.dst;
+    *reinterpret_cast<u32x2*>(d) = h;
+    *reinterpret_cast<u32x2*>(d + PB) = m;
+    *reinterpret_cast<u32x2*>(d + 2 * PB) = l;
+  };
+  auto store_fill = [&](const TpItem (&it)[2]) {
+    store_fill1(it[0]);
+    store_fill1(it[1]);
+  };
+
+  // ---- this wave's pixel class: column parity x row parity, 32 pixels of the tile ----
+  const int role = wave & 3, grp = wave >> 2;
+  const int cpw = role & 1, rpar = role >> 1;
+  const int rp = (W == 32) ? grp : 2 * grp + (l31 >> 4);  // input row of the tile (per lane when W = 16)
+  const int i_in = (W == 32) ? l31 : (l31 & 15);          // input column: ow = 2 i + cpw
+  // column taps: parity 0 -> kw = 1 (padded column pc = i + 1), kw = 3 (pc = i); parity 1 -> kw = 0
+  // (pc = i + 2), kw = 2 (pc = i + 1); row taps alike with kh / padded rows
+  const int kw_a = cpw ? 0 : 1, kw_b = kw_a + 2;
+  const int kh_a = rpar ? 0 : 1, kh_b = kh_a + 2;
+  const int d_a = cpw ? 2 : 1;
+  int offA[2], offB[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int pa = i_in + d_a, pb = pa - 1;
+    offA[kk] = pa * 64 + (((2 * kk + half) ^ ((pa >> 2) & 3)) << 4);
+    offB[kk] = pb * 64 + (((2 * kk + half) ^ ((pb >> 2) & 3)) << 4);
+  }
+  const int roff_a = rp + (rpar ? 2 : 1);  // padded row of row tap a relative to the tile's first
+  const char* wlane = wl + half * 512 + l31 * 16;
+  const int tap_aa = (kh_a * 4 + kw_a) * 6144, tap_ab = (kh_a * 4 + kw_b) * 6144;
+  const int tap_ba = (kh_b * 4 + kw_a) * 6144, tap_bb = (kh_b * 4 + kw_b) * 6144;
+
+  // ---- epilogue constants: accumulator register r holds channel n0 + (r & 3) + 8 (r >> 2) + 4 half.
+  // Plain (unpacked) VALU arithmetic only: v_pk_*_f32 serialises with the bf16 matrix pipe, plain VALU
+  // instructions run beside it, ~5.5 per 32-cycle MFMA per SIMD (tools_micro/mfma_bf16_mix.hip).
+  auto ch_of = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * half; };
+  constexpr float LOG2E = 1.44269504088896341f;
+  float bias_r[(EPI == 1 || EPI == 3) ? 16 : 1], bl_r[(EPI == 1 || EPI == 3) ? 16 : 1];
+  if (EPI == 1 || EPI == 3) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      bias_r[r] = p.bias[n0 + ch_of(r)];
+      bl_r[r] = bias_r[r] * LOG2E;
+    }
+  }
+  float w1r[(EPI == 3) ? 16 : 1][(EPI == 3) ? C1 : 1];
+  float dw1[(EPI == 3) ? 16 : 1][(EPI == 3) ? C1 : 1];
+  float b1r[(EPI == 3) ? C1 : 1];
+  float db1[(EPI == 3) ? C1 : 1];
+  if (EPI == 3) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int oc = 0; oc < C1; ++oc) {
+        w1r[r][oc] = p.w1[(n0 + ch_of(r)) * C1 + oc];
+        dw1[r][oc] = 0.f;
+      }
+#pragma unroll
+    for (int oc = 0; oc < C1; ++oc) { b1r[oc] = p.b1[oc]; db1[oc] = 0.f; }
+  }
+  float csum[(EPI >= 2) ? 16 : 1];
+#pragma unroll
+  for (int r = 0; r < ((EPI >= 2) ? 16 : 1); ++r) csum[r] = 0.f;
+  const float sc = (EPI == 3) ? p.scale[0] : 0.f;
+  float llk_lane = 0.f;
+  const OdinRun LG = odin_run(EPI == 3 ? p.logits : nullptr,
+                              (EPI == 3 && p.logits != nullptr) ? (unsigned)((size_t)p.B * OH * OW * C1 * 4) : 0u);
+
+  // ---- prologue: rows of the first tile, then the second tile's into registers ----
+  TpItem itA[2], itB[2];
+  load_fill(itA, true);
+  store_fill(itA);
+  load_fill(itA, T0 + 1 < T1);
+  TP_STAMP(2);
+  __syncthreads();  // weights, pads and the first tile's rows are in LDS
+  TP_STAMP(10);
+
+  int b_cur = T0 / p.tiles_per_img, t_cur = T0 - b_cur * p.tiles_per_img;
+  int sl0 = (HP * b_cur + RP * t_cur) % NSLOT;  // ring slot of the tile's first padded row
+  // state of the PREVIOUS tile, whose epilogue rides in the current tile's MFMA stream
+  f32x16 pa = f32x16_zero();
+  size_t opixP = 0;
+  float4 axP[4];
+  float tgtP[(EPI == 3) ? C1 : 1] = {};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) axP[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dl[(EPI == 3) ? C1 : 1] = {};
+
+  // The epilogue of one tile (lane = pixel (oh, 2 i + cpw) x 16 channels) as a list of micro-ops of a
+  // few VALU instructions each: op k is issued right behind MFMA k of the next tile's stream (the
+  // compiler's own interleaving bunched the MFMAs and left the VALU work exposed; sched_group_barrier
+  // pipelines of this size are not honoured, so the order is fixed in the source, fence by fence).
+  // It works in place on `pa`, two accumulator registers per op.
+  auto elu_r = [&](int r) {
+    const float t = pa[r] + bias_r[(EPI == 1 || EPI == 3) ? r : 0];
+    const float em1 = odin_exp2(fmaf(pa[r], LOG2E, bl_r[(EPI == 1 || EPI == 3) ? r : 0])) - 1.f;
+    pa[r] = t > 0.f ? t : em1;
+  };
+  auto store_q = [&](int q) {
+    if (DBG & 1) return;
+    *reinterpret_cast<float4*>(p.out + opixP * p.CO + n0 + 8 * q + 4 * half) =
+        make_float4(pa[4 * q], pa[4 * q + 1], pa[4 * q + 2], pa[4 * q + 3]);
+  };
+  float t_dot = 0.f, lgt = 0.f, eabs = 0.f;  // dot product, logit, exp(-|logit|) of the logit map in flight
+  constexpr int N_EPI_OPS = (EPI == 3) ? 12 + 4 * C1 + 8 : 12;
+  auto epi_op = [&](int k) {
+    if (k < 8) {
+      const int r0 = 2 * k, r1 = r0 + 1;
+      if (EPI == 1 || EPI == 3) { elu_r(r0); elu_r(r1); }
+      if (EPI == 2) {
+        const int q = k >> 1;
+        const float a0 = (k & 1) ? axP[q].z : axP[q].x, a1 = (k & 1) ? axP[q].w : axP[q].y;
+        pa[r0] = fmaf(pa[r0], fminf(a0, 0.f), pa[r0]);  // x ELU'(aux) = 1 + min(aux, 0)
+        pa[r1] = fmaf(pa[r1], fminf(a1, 0.f), pa[r1]);
+        csum[r0] += pa[r0];
+        csum[r1] += pa[r1];
+      }
+    }
+    if (EPI == 1 || EPI == 2) {
+      if (k >= 8 && k < 12) store_q(k - 8);
+    }
+    if (EPI == 3) {
+      // per logit map oc: 4 ops (dot, logistic terms, likelihood, its gradient)
+      if (k >= 8 && k < 8 + 4 * C1) {
+        const int oc = (k - 8) >> 2, ph = (k - 8) & 3;
+        if (ph == 0) {
+          t_dot = pa[0] * w1r[0][oc];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) t_dot = fmaf(pa[r], w1r[r][oc], t_dot);
+        }
+        if (ph == 1) {
+          lgt = tp_pairsum32(t_dot) + b1r[oc];  // the other 16 channels live in lane ^ 32
+          eabs = odin_exp2(-LOG2E * fabsf(lgt));
+          odin_run_store1(LG, half == 0 ? (unsigned)((opixP * C1 + oc) * 4) : ODIN_OOB, lgt);
+        }
+        if (ph == 2) {
+          // log p(x | logit) = x l - softplus(l); the half == 0 lane of a pixel owns the scalar results
+          const float sp = fmaxf(lgt, 0.f) + 0.6931471805599453f * odin_log2(1.f + eabs);
+          llk_lane += half == 0 ? tgtP[oc] * lgt - sp : 0.f;
+        }
+        if (ph == 3) {
+          const float rr = odin_rcp(1.f + eabs);
+          const float sg = lgt >= 0.f ? rr : eabs * rr;
+          const float dsig = (sg - tgtP[oc]) * sc;
+          db1[oc] += half == 0 ? dsig : 0.f;
+          dl[oc] = dsig;
+        }
+      }
+      constexpr int G0 = 8 + 4 * C1;
+      if (k >= G0 && k < G0 + 8) {
+#pragma unroll
+        for (int r = 2 * (k - G0); r < 2 * (k - G0) + 2; ++r) {
+          float gs = w1r[r][0] * dl[0];
+          dw1[r][0] = fmaf(pa[r], dl[0], dw1[r][0]);
+#pragma unroll
+          for (int oc = 1; oc < C1; ++oc) {
+            gs = fmaf(w1r[r][oc], dl[oc], gs);
+            dw1[r][oc] = fmaf(pa[r], dl[oc], dw1[r][oc]);
+          }
+          pa[r] = fmaf(gs, fminf(pa[r], 0.f), gs);  // x ELU'(y) = 1 + min(y, 0)
+          csum[r] += pa[r];
+        }
+      }
+      if (k >= G0 + 8 && k < G0 + 12) store_q(k - G0 - 8);
+    }
+  };
+  static_assert(N_EPI_OPS + 8 <= 32, "epilogue micro-ops must fit before the row stores (steps 6, 7)");
+
+  // one log-likelihood partial per (tile, wave): a tile lies inside one sample
+  auto flush_llk = [&](int T) {
+    if (EPI == 3) {
+#ifndef ODIN_SIM
+      asm volatile("; llk flush" ::: "memory");
+#endif
+      const float tt = odin_wave_sum64_valu(llk_lane);
+      if (lane == 0) p.llk_part[(size_t)T * 8 + wave] = tt;
+      llk_lane = 0.f;
+    }
+  };
+
+  // one tile: loads of tile T + 2's rows, then 8 steps of [6 LDS reads of the next step, 6 MFMAs,
+  // slice s of the previous tile's epilogue / of the row stores for tile T + 1]
+  auto run_tile = [&](auto with_epi, int T) {
+    constexpr bool WE = decltype(with_epi)::value;
+    int sa = sl0 + roff_a, sb = sa - 1;
+    if (sa >= NSLOT) sa -= NSLOT;
+    if (sb >= NSLOT) sb -= NSLOT;
+    const char* row_a = ring + sa * RB;
+    const char* row_b = ring + sb * RB;
+    // (one accumulator chain: a second one measured no faster -- 5888 vs 5808 cycles per tile -- and
+    // costs 16 registers + 16 adds)
+    f32x16 acc = f32x16_zero();
+    u32x4 fa[2][3], fb[2][3];
+    // 8 steps = 4 taps (a/a, a/b, b/a, b/b) x 2 k-halves of 16 channels
+    auto loads = [&](int s, u32x4 (&A)[3], u32x4 (&Bf)[3]) {
+      const int tp = s >> 1, kk = s & 1;
+      const bool ra = tp < 2, ca = (tp & 1) == 0;
+      const char* bp = (ra ? row_a : row_b) + (ca ? offA[kk] : offB[kk]);
+      const char* ap = wlane + (ra ? (ca ? tap_aa : tap_ab) : (ca ? tap_ba : tap_bb)) + kk * 1024;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        A[pl] = *reinterpret_cast<const u32x4*>(ap + pl * 2048);
+        Bf[pl] = *reinterpret_cast<const u32x4*>(bp + pl * PB);
+      }
+    };
+    loads(0, fa[0], fb[0]);  // first thing after the barrier: everything else waits behind the MFMAs
+    ODIN_SCHED_FENCE();
+    const int oh = 2 * (RP * t_cur + rp) + rpar;
+    const size_t opix = ((size_t)b_cur * OH + oh) * OW + 2 * i_in + cpw;
+    float4 axN[4];
+    float tgtN[(EPI == 3) ? C1 : 1] = {};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) axN[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ODIN_SCHED_FENCE();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int cur = s & 1, nxt = cur ^ 1;
+      // the six reads of step s + 1 go out before the MFMAs of step s (a read issued one MFMA before its
+      // use exposes the LDS latency)
+      if (s + 1 < 8 && !(DBG & 2)) loads(s + 1, fa[nxt], fb[nxt]);
+      if (s + 1 < 8 && (DBG & 2)) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { fa[nxt][pl] = fa[cur][pl]; fb[nxt][pl] = fb[cur][pl]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        // plane products, smallest first: 0*2, 2*0, 1*1, 0*1, 1*0, 0*0 (weights x pixels)
+        if (u == 0) acc = mfma32_bf16(fa[cur][0], fb[cur][2], acc);
+        if (u == 1) acc = mfma32_bf16(fa[cur][2], fb[cur][0], acc);
+        if (u == 2) acc = mfma32_bf16(fa[cur][1], fb[cur][1], acc);
+        if (u == 3) acc = mfma32_bf16(fa[cur][0], fb[cur][1], acc);
+        if (u == 4) acc = mfma32_bf16(fa[cur][1], fb[cur][0], acc);
+        if (u == 5) acc = mfma32_bf16(fa[cur][0], fb[cur][0], acc);
+        // MFMA m carries: the 8 activation ops (2 x ~6 VALU + 2 transcendentals each) behind every
+        // other MFMA of the first 16, the remaining ops one per MFMA, the row stores in steps 6 and 7
+        const int m = 6 * s + u;
+        const int k = m < 16 ? ((m & 1) ? -1 : m / 2) : m - 8;
+        if (WE && k >= 0 && k < N_EPI_OPS && !(DBG & 4)) epi_op(k);
+        if (m == 32) load_fill(itB, T + 2 < T1);  // global loads of tile T + 2's rows
+        if (m == 33) {                            // this tile's epilogue operands (used one tile later)
+          if (EPI == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              axN[q] = *reinterpret_cast<const float4*>(p.aux + opix * p.CO + n0 + 8 * q + 4 * half);
+          }
+          if (EPI == 3) {
+#pragma unroll
+            for (int oc = 0; oc < C1; ++oc) tgtN[oc] = p.target[opix * C1 + oc];
+          }
+        }
+        if (WE && m == 34) flush_llk(T - 1);
+        if (m == 36) store_fill1(itA[0]);
+        if (m == 42) store_fill1(itA[1]);
+        ODIN_SCHED_FENCE();
+        if (DBG != 0 && (m == 0 || m == 11 || m == 23 || m == 35 || m == 47)) TP_STAMP(12 + (m + 1) / 12);
+      }
+    }
+    pa = acc;
+    opixP = opix;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) axP[q] = axN[q];
+#pragma unroll
+    for (int oc = 0; oc < ((EPI == 3) ? C1 : 1); ++oc) tgtP[oc] = tgtN[oc];
+    itA[0] = itB[0];
+    itA[1] = itB[1];
+  };
+
+  run_tile(TpNo{}, T0);
+  TP_STAMP(11);
+  __syncthreads();
+  TP_STAMP(10);
+#pragma unroll 1
+  for (int T = T0 + 1; T < T1; ++T) {
+    sl0 += RP;
+    if (++t_cur == p.tiles_per_img) { t_cur = 0; ++b_cur; ++sl0; }
+    if (sl0 >= NSLOT) sl0 -= NSLOT;
+    run_tile(TpYes{}, T);
+    TP_STAMP(11);
+    __syncthreads();  // every wave is past tile T's rows; tile T + 1's rows are stored
+    TP_STAMP(10);
+  }
+#pragma unroll
+  for (int k = 0; k < N_EPI_OPS; ++k) epi_op(k);
+  flush_llk(T1 - 1);
+
+  // ---- per-workgroup partial sums: 32 pixel lanes by shuffles, then the 8 waves through LDS ----
+  if (EPI >= 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
+      float vv = csum[r];
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) vv += __shfl_xor(vv, m);
+      if (l31 == 0) cred[wave * NRED + ch] = vv;
+      if (EPI == 3) {
+#pragma unroll
+        for (int oc = 0; oc < C1; ++oc) {
+          float ww = dw1[r][oc];
+#pragma unroll
+          for (int m = 16; m >= 1; m >>= 1) ww += __shfl_xor(ww, m);
+          if (l31 == 0) cred[wave * NRED + 32 + ch * C1 + oc] = ww;
+        }
+      }
+    }
+  }
+  if (EPI == 3) {
+#pragma unroll
+    for (int oc = 0; oc < C1; ++oc) {
+      float vv = db1[oc];  // non-zero in the half == 0 lanes only
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) vv += __shfl_xor(vv, m);
+      if (lane == 0) cred[wave * NRED + 32 + 32 * C1 + oc] = vv;
+    }
+  }
+  if (EPI == 2 && p.colsum != nullptr) {
+    __syncthreads();
+    if (tid < 32) {
+      float tt = 0.f;
+      for (int wv = 0; wv < 8; ++wv) tt += cred[wv * NRED + tid];
+      p.colsum[(size_t)blockIdx.x * p.CO + n0 + tid] = tt;
+    }
+  }
+  if (EPI == 3) {
+    __syncthreads();
+    // slab row: [dW1 (CO, C1) | db1 (C1) | column sums of out (CO)]
+    float* row = p.slab + (size_t)blockIdx.x * (p.CO * C1 + C1 + p.CO);
+    for (int e = tid; e < 32 + 32 * C1 + C1; e += 512) {
+      float tt = 0.f;
+      for (int wv = 0; wv < 8; ++wv) tt += cred[wv * NRED + e];
+      if (e < 32) {
+        row[p.CO * C1 + C1 + e] = tt;
+      } else if (e < 32 + 32 * C1) {
+        const int ch = (e - 32) / C1, oc = (e - 32) - ch * C1;
+        row[ch * C1 + oc] = tt;
+      } else {
+        row[p.CO * C1 + (e - 32 - 32 * C1)] = tt;
+      }
+    }
+  }
+}
+
+template <int EPI, int C1>
+int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
+  const size_t lds = (size_t)TP_WBYTES + (size_t)(2 * (64 / W) + 3 + 1) * 3 * (W + 2) * 64;  // ring + spare slot
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    const void* fns[6] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 16>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 1>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 2>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 4>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 7>)};
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+        (void)hipGetLastError();
+    attr_done = true;
+  }
+#endif
+  if (W == 32 && EPI == 3) {
+    const char* e = getenv("ODIN_TP_DBG");
+    const int dbg = e ? atoi(e) : 0;
+    if (dbg == 1) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 1>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes"); }
+    if (dbg == 2) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 2>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes"); }
+    if (dbg == 4) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 4>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes"); }
+    if (dbg == 7) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 7>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes"); }
+  }
+  if (W == 32) ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32>), grid, dim3(512), lds, stream, p);
+  else ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 16>), grid, dim3(512), lds, stream, p);
+  return odin_check_launch("tconv_planes");
+}
+
+}  // namespace
+
+static long long* g_tp_stamps = nullptr;
+void odin_tconv_planes_set_stamps(void* buf) { g_tp_stamps = (long long*)buf; }
+
+// ODIN_SPLIT (any value) and ODIN_NOPLANES select the older instances (gather_conv.hip)
+bool odin_tconv_planes_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt,
+                                  int pl, int center, int epi, int C1) {
+  if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT")) return false;
+  if (epi == 3 && (CO != 32 || C1 != 1)) return false;
+  return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && CI == 32 && (CO % 32) == 0 && !center &&
+         (W == 16 || W == 32) && (H % (64 / W)) == 0 && (size_t)B * H * W * 32 * 4 < (1ull << 31) &&
+         (size_t)B * H * W * 4 * C1 * 4 < (1ull << 31);
+}
+
+// epi 1: deconv forward (bias + ELU); 2: conv data gradient (x ELU'(aux), column sums); 3: fused tail
+int odin_tconv_planes_launch(const float* in, const float* w, const float* bias, const float* aux,
+                             float* out, float* colsum, int* rows_out, const float* w1, const float* b1,
+                             const float* target, float* logits, float* llk_part, int* n_part_out,
+                             float* slab, const float* scale, int C1, int B, int H, int W, int CO,
+                             int epi, void* stream) {
+  TPParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = in; p.w = w; p.bias = bias; p.aux = aux; p.out = out; p.colsum = colsum;
+  p.w1 = w1; p.b1 = b1; p.target = target; p.logits = logits; p.llk_part = llk_part; p.slab = slab;
+  p.scale = scale;
+  p.B = B; p.H = H; p.CO = CO;
+  p.stamps = g_tp_stamps;
+  const int RP = 64 / W;
+  p.tiles_per_img = H / RP;
+  p.n_tiles = B * p.tiles_per_img;
+  const int gy = CO / 32;
+  int cap = odin_num_cus() / gy;
+  if (cap < 1) cap = 1;
+  if (cap > ODIN_MAX_COLSUM_BLOCKS) cap = ODIN_MAX_COLSUM_BLOCKS;
+  p.tiles_per_wg = (p.n_tiles + cap - 1) / cap;
+  const int gx = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+  if (rows_out) *rows_out = gx;
+  if (n_part_out) *n_part_out = 8 * p.tiles_per_img;
+  if (out == nullptr) return 0;  // dry run
+  dim3 grid(gx, gy, 1);
+  if (epi == 1) return tp_launch_w<1, 1>(p, W, grid, stream);
+  if (epi == 2) return tp_launch_w<2, 1>(p, W, grid, stream);
+  if (C1 == 1) return tp_launch_w<3, 1>(p, W, grid, stream);
+  return odin_fail(-2, "tconv_planes tail: one logit map only");
+}

@@ -109,8 +109,8 @@ DECONV_CASES = [
     (3, 4, 4, 8, 64, 4, 2, 'elu'),
     (2, 8, 8, 64, 32, 4, 2, 'elu'),
     (1, 16, 16, 32, 32, 4, 2, 'linear'),
-    (3, 32, 32, 32, 32, 4, 2, 'elu'),          # tconv_ring forward, 32-pixel rows, several images
-    (2, 16, 16, 32, 64, 4, 2, 'elu'),          # tconv_ring forward, two 32-channel output blocks
+    (3, 32, 32, 32, 32, 4, 2, 'elu'),          # tconv_planes forward, 32-pixel rows, several images
+    (2, 16, 16, 32, 64, 4, 2, 'elu'),          # tconv_planes forward, two 32-channel output blocks
     (2, 8, 8, 8, 64, 4, 1, 'elu'),
     (3, 7, 7, 4, 16, 5, 2, 'elu'),
 ]
@@ -199,8 +199,9 @@ def test_dense(bk, B, K, N, act):
     (1, 1, 16, 16, 32, 32, 4, 2, 1),   # two-workgroup fused tail instance (also the shape of the opt-in bf16-plane path)
     (1, 3, 8, 8, 8, 16, 4, 2, 3),      # generic transposed
     (0, 2, 16, 16, 8, 24, 5, 1, 1),    # generic gather conv (MNIST-style decoder tail)
-    (1, 3, 16, 16, 32, 32, 4, 2, 3),   # tconv_ring fused tail: 3 logit maps, tiles across image boundaries
-    (1, 2, 32, 32, 32, 32, 4, 2, 1),   # tconv_ring fused tail, 32-pixel input rows (dSprites / Shapes3D decoder4)
+    (1, 3, 16, 16, 32, 32, 4, 2, 1),   # tconv_planes fused tail (bf16 planes), 16-pixel rows, tiles across image seams
+    (1, 3, 16, 16, 32, 32, 4, 2, 3),   # 3 logit maps (bf16-plane instances of gather_conv.hip; tconv_ring when opted in)
+    (1, 2, 32, 32, 32, 32, 4, 2, 1),   # tconv_planes fused tail, 32-pixel input rows (dSprites decoder4)
 ])
 def test_bernoulli_tail(bk, is_deconv, B, H, W, Ci, Co, K, S, C1):
   L, T = bk.L, bk.T

@@ -6,7 +6,7 @@ sys.path.insert(0, '.')
 from odin_ai_amd import _lib
 L = _lib.load()
 dev = torch.device('cuda:0')
-names = {1: 'start', 2: 'setup', 10: 'C:barrier wait', 11: 'C:group (mfma + prev epilogue)', 12: 'C:tile end',
+names = {1: 'start', 2: 'setup', 10: 'C:barrier wait', 12: 'mfma 0 issued', 13: 'mfma 11', 14: 'mfma 23', 15: 'mfma 35', 16: 'mfma 47', 11: 'C:group / tile (mfma + prev epilogue)', 12: 'C:tile end',
          20: 'P:after-barrier', 21: 'P:issued', 22: 'P:landed'}
 
 
@@ -35,7 +35,7 @@ def stamps(fn, title):
     v = half[half != 0]
     if len(v) == 0: continue
     ks, ts = (v >> 56), (v & ((1 << 56) - 1))
-    print(f'   [{len(ks)} stamps, span {ts[-1]-ts[0]} ticks]')
+    print(f'   [{len(ks)} stamps, span {ts[-1]-ts[0]} ticks; steady period {(ts[-1]-ts[4])/((len(ks)-5)/2):.0f} ticks per tile]')
     for i in range(1, min(len(ks), 24)):
       print(f'   {names[int(ks[i])]:32s} +{ts[i]-ts[i-1]}')
 
@@ -69,5 +69,6 @@ def dgrad(B, H, W):
 
 
 tail(256, 32, 32, 1)
-tail(256, 32, 32, 3)
+import os
+if os.environ.get("ODIN_TP_DBG"): sys.exit(0)
 dgrad(256, 32, 32)
