@@ -38,6 +38,9 @@ typedef struct odin_conv_desc {
 
 /* ---- runtime ------------------------------------------------------------------------ */
 int odin_version(void);
+/* diagnostics: kernel family launched last by the calling thread ("...(bf16x3)": fp32 operands through
+ * the bf16 matrix pipe as three exact planes); used by bench.py to price kernels against the right peak */
+const char* odin_debug_last_path(void);
 /* CRC-32C (Castagnoli) of host bytes, continuing from `crc` (0 to start): the checksum of the
  * TensorFlow checkpoint / event-file formats the reference saves (base_networks.py:373-390,
  * training/trainer.py:52-71).  Returns the checksum (not an error code). */

@@ -38,6 +38,7 @@ DP = C.POINTER(ConvDesc)
 # name -> argtypes, exactly the declarations of include/odin_hip.h
 SIGNATURES = {
     'odin_version': [],
+    'odin_debug_last_path': [],
     'odin_crc32c': [C.c_uint32, P, C.c_size_t],
     'odin_max_slab_rows': [],
     'odin_conv2d_fwd': [P, P, P, P, DP, P],
@@ -84,7 +85,7 @@ SIGNATURES = {
 
 
 # entry points whose return value is a result, not an error code
-VALUE_RETURNING = ('odin_version', 'odin_max_slab_rows', 'odin_crc32c')
+VALUE_RETURNING = ('odin_version', 'odin_max_slab_rows', 'odin_crc32c', 'odin_debug_last_path')
 
 
 class OdinError(RuntimeError):
@@ -106,7 +107,8 @@ class Lib:
     for name, args in SIGNATURES.items():
       fn = getattr(self.c, name)  # AttributeError if the symbol is missing: fail loudly
       fn.argtypes = args
-      fn.restype = C.c_uint32 if name in VALUE_RETURNING else C.c_int
+      fn.restype = (C.c_char_p if name == 'odin_debug_last_path' else
+                    C.c_uint32 if name in VALUE_RETURNING else C.c_int)
 
   def check(self, rc: int, what: str = ''):
     if rc != 0:

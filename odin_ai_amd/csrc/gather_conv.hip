@@ -1348,7 +1348,7 @@ int launch_inst2(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* 
 #endif
   ODIN_LAUNCH((gather_conv_kernel<MODE, NWL, TK, TS, TCIC, VEC, TAIL, KMAX, RPWMAX, EPI, NMT, SPL>), grid,
               dim3(NWL * 64), lds, stream, p, tp);
-  return odin_check_launch("gather_conv");
+  return odin_check_launch(SPL ? "gather_conv(bf16x3)" : "gather_conv");
 }
 
 template <int MODE, int TK, int TS, int TCIC, bool VEC, int TAIL, int KMAX, int RPWMAX, int EPI = 0>

@@ -10,7 +10,10 @@ int odin_fail(int code, const char* msg) {
   return code;
 }
 
+static thread_local const char* g_last_path = "";
+
 int odin_check_launch(const char* what) {
+  g_last_path = what;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
@@ -69,7 +72,11 @@ extern "C" uint32_t odin_crc32c(uint32_t crc, const void* data, size_t n) {
   return ~c;
 }
 
-extern "C" int odin_version(void) { return 101; }
+extern "C" int odin_version(void) { return 102; }
+
+// diagnostics: name of the kernel family the calling thread launched last; a "(bf16x3)" suffix marks
+// fp32 work carried through the bf16 matrix pipe (priced separately by bench.py's roofline_split)
+extern "C" const char* odin_debug_last_path(void) { return g_last_path; }
 extern "C" const char* odin_last_error(void) { return g_err; }
 
 #ifdef ODIN_SIM

@@ -46,7 +46,7 @@ struct TPParams {
   const float* b1;     // [C1]
   const float* target; // [B, 2H, 2W, C1]
   float* logits;       // optional [B, 2H, 2W, C1]
-  float* llk_part;     // [n_tiles][8 waves]
+  float* llk_part;     // [n_tiles]
   float* slab;         // [gridDim.x][CO * C1 + C1 + CO]
   const float* scale;  // device scalar 1/B
   int B, H, CO;
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   char* ring = smem + TP_WBYTES;
   constexpr int NRED = 32 * (1 + (EPI == 3 ? C1 : 0)) + 4;  // per-wave reduction row
   __shared__ float cred[8 * NRED];
+  __shared__ float llk_red[2][8];  // per-wave log-likelihood partials of a tile, by tile parity
   const int tid = threadIdx.x, lane = tid & 63;
 #ifdef ODIN_SIM
   const int wave = tid >> 6;
@@ -374,14 +375,14 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   };
   static_assert(N_EPI_OPS + 8 <= 32, "epilogue micro-ops must fit before the row stores (steps 6, 7)");
 
-  // one log-likelihood partial per (tile, wave): a tile lies inside one sample
+  // one log-likelihood partial per tile (a tile lies inside one sample): wave sums through LDS
   auto flush_llk = [&](int T) {
     if (EPI == 3) {
 #ifndef ODIN_SIM
       asm volatile("; llk flush" ::: "memory");
 #endif
       const float tt = odin_wave_sum64_valu(llk_lane);
-      if (lane == 0) p.llk_part[(size_t)T * 8 + wave] = tt;
+      if (lane == 0) llk_red[T & 1][wave] = tt;  // summed over the 8 waves behind the next barrier
       llk_lane = 0.f;
     }
   };
@@ -486,6 +487,10 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     TP_STAMP(11);
     __syncthreads();  // every wave is past tile T's rows; tile T + 1's rows are stored
     TP_STAMP(10);
+    if (EPI == 3 && tid == 0) {
+      const float* q = llk_red[(T - 1) & 1];
+      p.llk_part[T - 1] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    }
   }
 #pragma unroll
   for (int k = 0; k < N_EPI_OPS; ++k) epi_op(k);
@@ -530,6 +535,10 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   }
   if (EPI == 3) {
     __syncthreads();
+    if (tid == 0) {
+      const float* q = llk_red[(T1 - 1) & 1];
+      p.llk_part[T1 - 1] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    }
     // slab row: [dW1 (CO, C1) | db1 (C1) | column sums of out (CO)]
     float* row = p.slab + (size_t)blockIdx.x * (p.CO * C1 + C1 + p.CO);
     for (int e = tid; e < 32 + 32 * C1 + C1; e += 512) {
@@ -568,14 +577,14 @@ int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
   if (W == 32 && EPI == 3) {
     const char* e = getenv("ODIN_TP_DBG");
     const int dbg = e ? atoi(e) : 0;
-    if (dbg == 1) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 1>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes"); }
-    if (dbg == 2) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 2>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes"); }
-    if (dbg == 4) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 4>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes"); }
-    if (dbg == 7) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 7>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes"); }
+    if (dbg == 1) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 1>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
+    if (dbg == 2) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 2>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
+    if (dbg == 4) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 4>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
+    if (dbg == 7) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 7>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
   }
   if (W == 32) ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32>), grid, dim3(512), lds, stream, p);
   else ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 16>), grid, dim3(512), lds, stream, p);
-  return odin_check_launch("tconv_planes");
+  return odin_check_launch("tconv_planes(bf16x3)");
 }
 
 }  // namespace
@@ -616,7 +625,7 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
   p.tiles_per_wg = (p.n_tiles + cap - 1) / cap;
   const int gx = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
   if (rows_out) *rows_out = gx;
-  if (n_part_out) *n_part_out = 8 * p.tiles_per_img;
+  if (n_part_out) *n_part_out = p.tiles_per_img;
   if (out == nullptr) return 0;  // dry run
   dim3 grid(gx, gy, 1);
   if (epi == 1) return tp_launch_w<1, 1>(p, W, grid, stream);
