@@ -161,7 +161,7 @@ class NetProgram:
             d['Cin'] * d['Cout']
       else:
         mac = B * r.K * r.N
-      self.small_wgrad.append(2 * mac < 0.8e9)
+      self.small_wgrad.append(2 * mac < float(__import__('os').environ.get('ODIN_SMALL_WGRAD_GF', '0.8')) * 1e9)
     self._plan_slabs()
 
   # -- planning (dry runs report how many slab rows each call will write) --------------

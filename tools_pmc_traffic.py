@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""profiles/r02_pmc_traffic.json from the separate rocprofv3 --pmc passes (tools_pmc.sh r02):
+HBM traffic per launch of the three largest kernels of the dsprites_betavae_b256 step, corrected as
+MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts 128-byte reads at 64 bytes: doubled;
+WRITE_SIZE exact), next to the algorithmic bytes of the launch."""
+import json, re, sys
+B = 256
+
+
+def read(fn):
+  out = {}
+  for ln in open(fn):
+    f = [x.strip() for x in ln.split('|')]
+    if len(f) >= 4 and f[0] != 'kernel':
+      out[(f[0].replace('void ', ''), f[1])] = float(f[3])
+  return out
+
+
+fetch, write = read('gpurun_out/r02_pmc_FETCH_SIZE.txt'), read('gpurun_out/r02_pmc_WRITE_SIZE.txt')
+f4 = 4
+kernels = {
+    # bench op name: (kernel, grid/lds key, description, algorithmic bytes)
+    'dec4:deconv:wgrad': ('wgrad_ws_kernel<4, 9, 3, 2, 64>', '131072/lds0',
+                          'weight gradient of the last Conv2DTranspose (fp32 MFMA), dSprites B=256',
+                          # x [B,32,32,32] + dY [B,64,64,32] read once, slabs [256 rows][16*32*32] written
+                          (B * 32 * 32 * 32 + B * 64 * 64 * 32) * f4 + 256 * 16 * 32 * 32 * f4),
+    'dec4:deconv:dgrad': ('fconv_ring_kernel<2>', '131072/lds512',
+                          'data gradient of the last Conv2DTranspose (fconv_ring, fp32 MFMA)',
+                          # dY [B,64,64,32] + aux [B,32,32,32] read, dx [B,32,32,32] written
+                          (B * 64 * 64 * 32 + 2 * B * 32 * 32 * 32) * f4),
+    'dec4+5:tail:fwd+elbo': ('tconv_planes_kernel<3, 1, 32, 0>', '131072/lds2560',
+                             'fused decoder tail (tconv_planes, fp32 operands as 3 bf16 planes)',
+                             # x [B,32,32,32] + target [B,64,64,1] read; logits + d(pre-activation) [B,64,64,32] written
+                             (B * 32 * 32 * 32 + 2 * B * 64 * 64 + B * 64 * 64 * 32) * f4),
+}
+res = {}
+for op, (k, key, desc, alg) in kernels.items():
+  fk = fetch.get((k, key))
+  wk = write.get((k, key))
+  if fk is None or wk is None:
+    print('missing', op, k, key, file=sys.stderr)
+    continue
+  res[op] = dict(kernel=f'{k} ({desc})', FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk,
+                 traffic_bytes=int((2 * fk + wk) * 1024), algorithmic_bytes=int(alg),
+                 source='profiles/r02_pmc_FETCH_SIZE.txt + r02_pmc_WRITE_SIZE.txt (separate --pmc passes of '
+                        '`bench.py --steps 20 --warmup 5`); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 '
+                        'reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM section)')
+json.dump(res, open('profiles/r02_pmc_traffic.json', 'w'), indent=1)
+print(json.dumps(res, indent=1))
