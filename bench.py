@@ -512,9 +512,9 @@ def main():
     so = max(split_ops, key=lambda o: o['us'])
     bf16_gflop = 6.0 * so.get('mfma_gflop', so['gflop'])
     roofline_split = dict(bound='mfma', kernel=f"{so['layer']}:{so['op']}", path=so.get('path'),
-                          achieved=round(bf16_gflop / so['us'] * 1e-3, 3), peak=PEAK_MFMA_BF16_TFLOPS,
+                          achieved=round(bf16_gflop / so['us'] * 1e3, 3), peak=PEAK_MFMA_BF16_TFLOPS,
                           unit='TFLOP/s (bf16 FLOPs executed)',
-                          frac=round(bf16_gflop / so['us'] * 1e-3 / PEAK_MFMA_BF16_TFLOPS, 4),
+                          frac=round(bf16_gflop / so['us'] * 1e3 / PEAK_MFMA_BF16_TFLOPS, 4),
                           fp32_equivalent_tflops=round(so['tflops'], 3), traffic=None,
                           us_per_launch=round(so['us'], 2), gflop_per_launch=round(bf16_gflop, 4),
                           note='fp32 operands as 3 exact bf16 planes: 6 v_mfma_f32_32x32x16_bf16 per 16 '
