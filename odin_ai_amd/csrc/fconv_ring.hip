@@ -59,6 +59,7 @@ struct FRParams {
   float* out;          // [B, OH, OW, CO]
   float* colsum;       // EPI 2: [gridDim.x][CO] partial column sums of out (may be null)
   int B, H, W, OH, OW, CO;
+  int CS, ci_off;      // channels per input pixel in memory (32 or 64) and the first of this pass's 32
   int TRO;             // output rows per tile (TRO * OW == 64)
   int NSLOT, RB;       // ring slots, bytes per ring row
   int tiles_per_img, n_tiles, tiles_per_wg;
@@ -77,8 +78,10 @@ constexpr int FR_WBYTES = 16 * 8 * 32 * 16;  // weight image: 64 KB
   } while (0)
 #endif
 
-// EPI 1: bias + ELU (Conv2D forward); EPI 2: linear, x ELU'(aux), column sums (deconv data-gradient)
-template <int EPI>
+// EPI 1: bias + ELU (Conv2D forward); EPI 2: linear, x ELU'(aux), column sums (deconv data-gradient);
+// EPI 0: raw partial sums (first of two reduction passes over 64 input channels).  ACC: add the partial
+// sums the previous pass left in `out` before the epilogue.
+template <int EPI, bool ACC>
 __global__ __launch_bounds__(512) void fconv_ring_kernel(FRParams p) {
   ODIN_DYN_SMEM(char, smem);
   char* wl = smem;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(512) void fconv_ring_kernel(FRParams p) {
     const int pw = wave - 4;
     const int cpr = (p.W / 2) / 8;          // 1 KB DMA chunks per parity plane of a row: 4 (W 64) or 2 (W 32)
     const int ipr = 2 * cpr;                // DMA instructions per row: 8 or 4
-    const int ipw = ipr / 4;                // ... per producer wave: 2 or 1
+    const int ipw = (ipr - pw + 3) / 4;     // ... of this producer wave: 2, 1 or (16-pixel rows, waves 2, 3) 0
     unsigned gofs[2];                       // byte offset inside an input row of this lane's 16 bytes
     int dofs[2];                            // byte offset inside a ring row of the item's 1 KB
 #pragma unroll
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(512) void fconv_ring_kernel(FRParams p) {
       const int j = par ? jrel : jrel + 1;
       const int iw = par ? 2 * jrel : 2 * jrel + 1;
       const int c4 = pos ^ ((j >> 1) & 7);
-      gofs[k] = (unsigned)((iw * 32 + 4 * c4) * 4);
+      gofs[k] = (unsigned)((iw * p.CS + 4 * c4) * 4);
       dofs[k] = (par * hs + (par ? 0 : 1)) * 128 + ch * 1024;
     }
     const OdinRun ZR = odin_run(odin_fr_zero_row, (unsigned)sizeof(odin_fr_zero_row));
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(512) void fconv_ring_kernel(FRParams p) {
             for (int k = 0; k < ipw; ++k)
               odin_run_dma16(ZR, reinterpret_cast<float*>(rowl + dofs[k]), (unsigned)(lane * 16), lane);
           } else {
-            const OdinRun R = odin_run(p.in + (size_t)(bimg * p.H + gi - 1) * p.W * 32,
-                                       (unsigned)(p.W * 32 * 4));
+            const OdinRun R = odin_run(p.in + (size_t)(bimg * p.H + gi - 1) * p.W * p.CS + p.ci_off,
+                                       (unsigned)((p.W * p.CS - p.ci_off) * 4));
             for (int k = 0; k < ipw; ++k)
               odin_run_dma16(R, reinterpret_cast<float*>(rowl + dofs[k]), gofs[k], lane);
           }
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(512) void fconv_ring_kernel(FRParams p) {
     reinterpret_cast<float4*>(rowl)[q & 7] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   {
-    const OdinRun WR = odin_run(p.w, (unsigned)((size_t)16 * 32 * p.CO * 4));
+    const OdinRun WR = odin_run(p.w, (unsigned)((size_t)16 * p.CS * p.CO * 4));
 #pragma unroll 1
     for (int e0 = tid; e0 < 16 * 8 * 32; e0 += 256 * 8) {
       float v[8][4];
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(512) void fconv_ring_kernel(FRParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           v[u][k] = odin_run_load1(WR, n0 + co < p.CO
-                                           ? (unsigned)(((tap * 32 + 4 * c4 + k) * p.CO + n0 + co) * 4)
+                                           ? (unsigned)(((tap * p.CS + p.ci_off + 4 * c4 + k) * p.CO + n0 + co) * 4)
                                            : ODIN_OOB);
       }
 #pragma unroll
@@ -203,8 +206,10 @@ __global__ __launch_bounds__(512) void fconv_ring_kernel(FRParams p) {
   if (wave == 0) FR_STAMP(0, 2);
   const int l15 = lane & 15, kq = lane >> 4;
   // this lane's output pixel inside the tile
-  const int orow = (p.OW == 32) ? (wave >> 1) : wave;
-  const int ocol = (p.OW == 32) ? 16 * (wave & 1) + l15 : l15;
+  // (8-pixel output rows: a wave's 16 pixels are two rows -> the row is a per-lane quantity)
+  const int orow = (p.OW == 32) ? (wave >> 1) : (p.OW == 16) ? wave : 2 * wave + (l15 >> 3);
+  const int ocol = (p.OW == 32) ? 16 * (wave & 1) + l15 : (p.OW == 16) ? l15 : (l15 & 7);
+  const int orow_w = (p.OW == 32) ? (wave >> 1) : (p.OW == 16) ? wave : 2 * wave;  // wave-uniform part
   // lane-constant byte offsets inside a ring row: [column shift 0 / 1][channel group 0 / 1]
   int lo[2][2];
 #pragma unroll
@@ -234,19 +239,26 @@ __global__ __launch_bounds__(512) void fconv_ring_kernel(FRParams p) {
     const int g0 = HP * b + 2 * p.TRO * t;
     const int oh = p.TRO * t + orow;
     const size_t opix = ((size_t)b * p.OH + oh) * p.OW + ocol;
-    float4 ax[2];
+    float4 ax[2], pv[2];
     if (EPI == 2) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
         ax[cb] = *reinterpret_cast<const float4*>(p.aux + opix * p.CO + n0 + cb * 16 + 4 * kq);
     }
+    if (ACC) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+        pv[cb] = *reinterpret_cast<const float4*>(p.out + opix * p.CO + n0 + cb * 16 + 4 * kq);
+    }
     f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     // 32 steps = 16 taps x 2 channel groups; operands of step s + 1 are read under the MFMAs of step s
     float4 bq[2], a0[2], a1[2];
-    // ring rows of this wave's 4 tap rows (wave-uniform; one modulo per row per tile)
+    // ring rows of this lane's 4 tap rows (one wave-uniform modulo per tile; the lane's own two rows
+    // further down when a wave spans two 8-pixel output rows)
     const char* rowb[4];
     {
-      int sl = (g0 + 2 * orow) % p.NSLOT;
+      int sl = (g0 + 2 * orow_w) % p.NSLOT + 2 * (orow - orow_w);
+      if (sl >= p.NSLOT) sl -= p.NSLOT;
 #pragma unroll
       for (int kh = 0; kh < 4; ++kh) {
         rowb[kh] = ring + (size_t)sl * p.RB;
@@ -294,6 +306,9 @@ __global__ __launch_bounds__(512) void fconv_ring_kernel(FRParams p) {
     for (int cb = 0; cb < 2; ++cb) {
       const f32x4v a = cb == 0 ? acc0 : acc1;
       float v[4] = {a[0], a[1], a[2], a[3]};
+      if (ACC) {
+        v[0] += pv[cb].x; v[1] += pv[cb].y; v[2] += pv[cb].z; v[3] += pv[cb].w;
+      }
       if (EPI == 1) {
         const float bb[4] = {bias4[cb].x, bias4[cb].y, bias4[cb].z, bias4[cb].w};
 #pragma unroll
@@ -301,7 +316,7 @@ __global__ __launch_bounds__(512) void fconv_ring_kernel(FRParams p) {
           const float tt = v[k] + bb[k];
           v[k] = fmaxf(tt, 0.f) + (odin_exp2(fminf(tt, 0.f) * 1.44269504088896341f) - 1.f);
         }
-      } else {
+      } else if (EPI == 2) {
         const float aa[4] = {ax[cb].x, ax[cb].y, ax[cb].z, ax[cb].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = fmaf(v[k], fminf(aa[k], 0.f), v[k]);  // x (1 + min(y, 0))
@@ -341,13 +356,40 @@ void odin_fconv_ring_set_stamps(void* buf) { g_fr_stamps = (long long*)buf; }
 // consumers and producers meet at __syncthreads(): both roles execute the same number of them
 // (1 after the weights, then T1 - T0 + 1, then 1 for the column sums)
 
+static int fr_launch_pass(FRParams p, int epi, bool acc, dim3 grid, size_t lds, void* stream) {
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    const void* fns[5] = {reinterpret_cast<const void*>(&fconv_ring_kernel<1, false>),
+                          reinterpret_cast<const void*>(&fconv_ring_kernel<2, false>),
+                          reinterpret_cast<const void*>(&fconv_ring_kernel<0, false>),
+                          reinterpret_cast<const void*>(&fconv_ring_kernel<1, true>),
+                          reinterpret_cast<const void*>(&fconv_ring_kernel<2, true>)};
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess)
+        (void)hipGetLastError();
+    attr_done = true;
+  }
+#endif
+  if (epi == 0) ODIN_LAUNCH((fconv_ring_kernel<0, false>), grid, dim3(512), lds, stream, p);
+  else if (epi == 1 && !acc) ODIN_LAUNCH((fconv_ring_kernel<1, false>), grid, dim3(512), lds, stream, p);
+  else if (epi == 1) ODIN_LAUNCH((fconv_ring_kernel<1, true>), grid, dim3(512), lds, stream, p);
+  else if (!acc) ODIN_LAUNCH((fconv_ring_kernel<2, false>), grid, dim3(512), lds, stream, p);
+  else ODIN_LAUNCH((fconv_ring_kernel<2, true>), grid, dim3(512), lds, stream, p);
+  return odin_check_launch("fconv_ring");
+}
+
+// CI = 32: one launch.  CI = 64: two reduction passes over 32 channels each (the weight image of 64
+// channels, 128 KB, does not fit beside the row window): the first leaves raw partial sums in `out`,
+// the second adds them and runs the epilogue.
 int odin_fconv_ring_launch(const float* in, const float* w, const float* bias, const float* aux,
-                           float* out, float* colsum, int* rows_out, int B, int H, int W, int OH,
-                           int OW, int CO, int epi, void* stream) {
+                           float* out, float* colsum, int* rows_out, int B, int H, int W, int CI,
+                           int OH, int OW, int CO, int epi, void* stream) {
   FRParams p;
   memset(&p, 0, sizeof(p));
   p.in = in; p.w = w; p.bias = bias; p.aux = aux; p.out = out; p.colsum = colsum;
   p.B = B; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.CO = CO;
+  p.CS = CI; p.ci_off = 0;
   p.TRO = 64 / OW;
   p.NSLOT = 4 * p.TRO + 3;
   p.RB = (W + 2) * 128;
@@ -364,27 +406,21 @@ int odin_fconv_ring_launch(const float* in, const float* w, const float* bias, c
   p.stamps = g_fr_stamps;
   const size_t lds = (size_t)FR_WBYTES + (size_t)p.NSLOT * p.RB;
   if (lds > 159 * 1024) return odin_fail(-2, "fconv_ring: ring does not fit the LDS");
-#ifndef ODIN_SIM
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fconv_ring_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&fconv_ring_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess)
-      (void)hipGetLastError();
-    attr_done = true;
-  }
-#endif
   dim3 grid(gx, gy, 1);
-  if (epi == 1) ODIN_LAUNCH((fconv_ring_kernel<1>), grid, dim3(512), lds, stream, p);
-  else ODIN_LAUNCH((fconv_ring_kernel<2>), grid, dim3(512), lds, stream, p);
-  return odin_check_launch("fconv_ring");
+  if (CI == 32) return fr_launch_pass(p, epi, false, grid, lds, stream);
+  FRParams q = p;
+  q.colsum = nullptr;
+  int rc = fr_launch_pass(q, 0, false, grid, lds, stream);
+  if (rc != 0) return rc;
+  p.ci_off = 32;
+  return fr_launch_pass(p, epi, true, grid, lds, stream);
 }
 
 bool odin_fconv_ring_applicable(int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
                                 int pt, int pl, int center) {
   static int off = -1;
   if (off < 0) off = getenv("ODIN_NOFRING") ? 1 : 0;
-  return !off && KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && CI == 32 && (CO % 32) == 0 &&
-         !center && H == 2 * OH && W == 2 * OW && (OW == 16 || OW == 32) && (OH % (64 / OW)) == 0;
+  return !off && KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && (CI == 32 || CI == 64) &&
+         (CO % 32) == 0 && !center && H == 2 * OH && W == 2 * OW && (OW == 8 || OW == 16 || OW == 32) &&
+         (OH % (64 / OW)) == 0;
 }

@@ -1580,8 +1580,8 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
   if (d->act == ODIN_ACT_ELU && bias != nullptr &&
       odin_fconv_ring_applicable(d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                                  d->pad_t, d->pad_l, d->center))
-    return odin_fconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->OH,
-                                  d->OW, d->Cout, 1, stream);
+    return odin_fconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->Cin,
+                                  d->OH, d->OW, d->Cout, 1, stream);
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = y;
@@ -1653,7 +1653,7 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
       odin_fconv_ring_applicable(d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
                                  d->pad_t, d->pad_l, 0))
     return odin_fconv_ring_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, d->B, d->OH,
-                                  d->OW, d->H, d->W, d->Cin, 2, stream);
+                                  d->OW, d->Cout, d->H, d->W, d->Cin, 2, stream);
   GParams p;
   fill_common(p, d);
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;

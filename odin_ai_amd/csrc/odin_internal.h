@@ -47,8 +47,8 @@ int odin_dense_gemm_wgrad(const float* x, const float* dy, float* slab, int B, i
 bool odin_fconv_ring_applicable(int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
                                 int pt, int pl, int center);
 int odin_fconv_ring_launch(const float* in, const float* w, const float* bias, const float* aux,
-                           float* out, float* colsum, int* rows_out, int B, int H, int W, int OH,
-                           int OW, int CO, int epi, void* stream);
+                           float* out, float* colsum, int* rows_out, int B, int H, int W, int CI,
+                           int OH, int OW, int CO, int epi, void* stream);
 void odin_fconv_ring_set_stamps(void* buf);
 
 // transposed 4x4 / stride-2 gather over 32 channels, rolling LDS row window (tconv_ring.hip)

@@ -57,6 +57,8 @@ CONV_CASES = [
     (5, 32, 32, 32, 32, 4, 2, 'elu', False),   # fconv_ring forward: several tiles per workgroup across image boundaries
     (2, 64, 64, 32, 32, 4, 2, 'elu', False),   # fconv_ring forward, 32-pixel output rows (2-row tiles)
     (3, 32, 32, 32, 64, 4, 2, 'elu', False),   # fconv_ring forward, two 32-channel output blocks
+    (3, 16, 16, 32, 64, 4, 2, 'elu', False),   # fconv_ring forward, 8-pixel output rows (a wave spans two rows; encoder2)
+    (2, 32, 32, 64, 32, 4, 2, 'elu', False),   # fconv_ring forward over 64 channels: two reduction passes
 ]
 
 
@@ -106,6 +108,7 @@ DECONV_CASES = [
     (5, 16, 16, 32, 32, 4, 2, 'elu'),          # fconv_ring data gradient across image boundaries
     (2, 32, 32, 32, 32, 4, 2, 'elu'),          # fconv_ring data gradient, 32-pixel rows (decoder4)
     (3, 16, 16, 64, 32, 4, 2, 'elu'),          # fconv_ring data gradient into 64 channels (decoder3)
+    (3, 8, 8, 64, 64, 4, 2, 'elu'),            # fconv_ring data gradient: 8-pixel rows, 64 reduction channels in two passes (decoder2)
     (3, 4, 4, 8, 64, 4, 2, 'elu'),
     (2, 8, 8, 64, 32, 4, 2, 'elu'),
     (1, 16, 16, 32, 32, 4, 2, 'linear'),
