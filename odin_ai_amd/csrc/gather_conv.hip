@@ -1604,7 +1604,7 @@ extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* a
                                    d->pad_l, 0, 2, 1))
     return odin_tconv_planes_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->OH,
-                                    d->OW, d->Cin, 2, stream);
+                                    d->OW, d->Cout, d->Cin, 2, stream);
   if (aux_act == ODIN_ACT_ELU && (aux != nullptr || dx == nullptr) && d->H == 2 * d->OH &&
       d->W == 2 * d->OW &&
       odin_tconv_ring_applicable(d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t,
@@ -1630,7 +1630,7 @@ extern "C" int odin_deconv2d_fwd(const float* x, const float* w, const float* bi
                                    d->pad_l, d->center, 1, 1))
     return odin_tconv_planes_launch(x, w, bias, nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->H, d->W,
-                                    d->Cout, 1, stream);
+                                    d->Cin, d->Cout, 1, stream);
   if (d->act == ODIN_ACT_ELU && bias != nullptr && d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_tconv_ring_applicable(d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
                                  d->pad_l, d->center))
@@ -1709,7 +1709,7 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
                                    d->pad_l, d->center, 3, C1))
     return odin_tconv_planes_launch(x, w, bias, nullptr, g_out, nullptr, slab_rows_out, w1, b1, target,
                                     logits, llk_part, n_part_out, tail_slab, scale, C1, d->B, d->H, d->W,
-                                    d->Cout, 3, stream);
+                                    d->Cin, d->Cout, 3, stream);
   if (is_deconv && d->act == ODIN_ACT_ELU && d->Cout == 32 && (C1 == 1 || C1 == 3) &&
       d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_tconv_ring_applicable(d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,

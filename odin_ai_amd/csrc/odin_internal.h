@@ -69,5 +69,5 @@ bool odin_tconv_planes_applicable(int B, int H, int W, int CI, int CO, int KH, i
 int odin_tconv_planes_launch(const float* in, const float* w, const float* bias, const float* aux,
                              float* out, float* colsum, int* rows_out, const float* w1, const float* b1,
                              const float* target, float* logits, float* llk_part, int* n_part_out,
-                             float* slab, const float* scale, int C1, int B, int H, int W, int CO,
-                             int epi, void* stream);
+                             float* slab, const float* scale, int C1, int B, int H, int W, int CI,
+                             int CO, int epi, void* stream);

@@ -50,6 +50,7 @@ struct TPParams {
   float* slab;         // [gridDim.x][CO * C1 + C1 + CO]
   const float* scale;  // device scalar 1/B
   int B, H, CO;
+  int CS, ci_off;      // channels per input pixel in memory (32 or 64) and the first of this pass's 32
   int tiles_per_img, n_tiles, tiles_per_wg;
   long long* stamps;   // diagnostics: s_memtime stamps of workgroup 0 (wave 0: [0,32), wave 4: [32,64))
 };
@@ -99,7 +100,9 @@ struct TpItem {
 // EPI 1: bias + ELU; EPI 2: x ELU'(aux) + column sums; EPI 3: fused Bernoulli tail with C1 logit maps
 // DBG (diagnostics only, ODIN_TP_DBG): 1 = no global stores of `out`, 2 = no LDS reads in the MFMA loop,
 // 4 = no epilogue micro-ops
-template <int EPI, int C1, int W, int DBG = 0>
+// EPI 0: raw partial sums (first of two reduction passes over 64 input channels); ACC: add the partial
+// sums the previous pass left in `out` before the epilogue.
+template <int EPI, int C1, int W, int DBG = 0, bool ACC = false>
 __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   constexpr int RP = 64 / W;              // input rows per tile
   constexpr int NSLOT = 2 * RP + 3;       // live rows of a tile (RP + 2) + the next tile's (RP + 1 at an image seam)
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     for (int j = 0; j < 8; ++j) {
       const int e = tid + 512 * j;
       const int ci4 = e & 7, co = (e >> 3) & 31, tap = e >> 8;
-      wv[j] = *reinterpret_cast<const float4*>(p.w + ((size_t)(tap * p.CO + n0 + co) * 32 + 4 * ci4));
+      wv[j] = *reinterpret_cast<const float4*>(p.w + ((size_t)(tap * p.CO + n0 + co) * p.CS + p.ci_off + 4 * ci4));
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   }
 
   // ---- row fills: wave-uniform walk over the padded rows; a wave moves up to two 1 KB items ----
-  const OdinRun IN = odin_run(p.in, (unsigned)((size_t)p.B * p.H * W * 32 * 4));
+  const OdinRun IN = odin_run(p.in, (unsigned)((size_t)p.B * p.H * W * p.CS * 4));
   int f_gi, f_b, f_slot, f_g, need_g0, ft_t;
   {
     const int b0 = T0 / p.tiles_per_img, t0 = T0 - b0 * p.tiles_per_img;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
       it[j].dst = valid ? slot * RB + pc * 64 + ((((ch4 >> 1) ^ ((pc >> 2) & 3))) << 4) + (ch4 & 1) * 8
                         : NSLOT * RB + lane * 8;  // spare slot
       const bool real = valid && gi != 0 && b < p.B;  // gi == 0: the zero row between images
-      it[j].v = odin_run_load4(IN, real ? (unsigned)(((((size_t)b * p.H + gi - 1) * W + px) * 32 + 4 * ch4) * 4)
+      it[j].v = odin_run_load4(IN, real ? (unsigned)((((((size_t)b * p.H + gi - 1) * W + px) * p.CS + p.ci_off + 4 * ch4) * 4))
                                         : ODIN_OOB);
     }
     if (live) {
@@ -289,10 +292,10 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   // state of the PREVIOUS tile, whose epilogue rides in the current tile's MFMA stream
   f32x16 pa = f32x16_zero();
   size_t opixP = 0;
-  float4 axP[4];
+  float4 axP[4], pvP[4];
   float tgtP[(EPI == 3) ? C1 : 1] = {};
 #pragma unroll
-  for (int q = 0; q < 4; ++q) axP[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = 0; q < 4; ++q) axP[q] = pvP[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   float dl[(EPI == 3) ? C1 : 1] = {};
 
   // The epilogue of one tile (lane = pixel (oh, 2 i + cpw) x 16 channels) as a list of micro-ops of a
@@ -315,6 +318,11 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   auto epi_op = [&](int k) {
     if (k < 8) {
       const int r0 = 2 * k, r1 = r0 + 1;
+      if (ACC) {
+        const int q = k >> 1;
+        pa[r0] += (k & 1) ? pvP[q].z : pvP[q].x;
+        pa[r1] += (k & 1) ? pvP[q].w : pvP[q].y;
+      }
       if (EPI == 1 || EPI == 3) { elu_r(r0); elu_r(r1); }
       if (EPI == 2) {
         const int q = k >> 1;
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
         csum[r1] += pa[r1];
       }
     }
-    if (EPI == 1 || EPI == 2) {
+    if (EPI <= 2) {
       if (k >= 8 && k < 12) store_q(k - 8);
     }
     if (EPI == 3) {
@@ -416,10 +424,10 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     ODIN_SCHED_FENCE();
     const int oh = 2 * (RP * t_cur + rp) + rpar;
     const size_t opix = ((size_t)b_cur * OH + oh) * OW + 2 * i_in + cpw;
-    float4 axN[4];
+    float4 axN[4], pvN[4];
     float tgtN[(EPI == 3) ? C1 : 1] = {};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) axN[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 4; ++q) axN[q] = pvN[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     ODIN_SCHED_FENCE();
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -456,6 +464,11 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
 #pragma unroll
             for (int oc = 0; oc < C1; ++oc) tgtN[oc] = p.target[opix * C1 + oc];
           }
+          if (ACC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              pvN[q] = *reinterpret_cast<const float4*>(p.out + opix * p.CO + n0 + 8 * q + 4 * half);
+          }
         }
         if (WE && m == 34) flush_llk(T - 1);
         if (m == 36) store_fill1(itA[0]);
@@ -467,7 +480,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     pa = acc;
     opixP = opix;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) axP[q] = axN[q];
+    for (int q = 0; q < 4; ++q) { axP[q] = axN[q]; pvP[q] = pvN[q]; }
 #pragma unroll
     for (int oc = 0; oc < ((EPI == 3) ? C1 : 1); ++oc) tgtP[oc] = tgtN[oc];
     itA[0] = itB[0];
@@ -556,20 +569,20 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   }
 }
 
-template <int EPI, int C1>
+template <int EPI, int C1, bool ACC>
 int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
   const size_t lds = (size_t)TP_WBYTES + (size_t)(2 * (64 / W) + 3 + 1) * 3 * (W + 2) * 64;  // ring + spare slot
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    const void* fns[6] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32>),
-                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 16>),
-                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 1>),
-                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 2>),
-                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 4>),
-                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 7>)};
-    for (const void* f : fns)
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+    const void* fns[6] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 0, ACC>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 16, 0, ACC>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 1 : 0), ACC>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 2 : 0), ACC>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 4 : 0), ACC>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 7 : 0), ACC>)};
+    for (int i = 0; i < ((EPI == 3) ? 6 : 2); ++i)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
         (void)hipGetLastError();
     attr_done = true;
   }
@@ -577,13 +590,13 @@ int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
   if (W == 32 && EPI == 3) {
     const char* e = getenv("ODIN_TP_DBG");
     const int dbg = e ? atoi(e) : 0;
-    if (dbg == 1) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 1>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
-    if (dbg == 2) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 2>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
-    if (dbg == 4) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 4>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
-    if (dbg == 7) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 7>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
+    if (dbg == 1) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 1 : 0), ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
+    if (dbg == 2) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 2 : 0), ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
+    if (dbg == 4) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 4 : 0), ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
+    if (dbg == 7) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 7 : 0), ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
   }
-  if (W == 32) ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32>), grid, dim3(512), lds, stream, p);
-  else ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 16>), grid, dim3(512), lds, stream, p);
+  if (W == 32) ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 0, ACC>), grid, dim3(512), lds, stream, p);
+  else ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 16, 0, ACC>), grid, dim3(512), lds, stream, p);
   return odin_check_launch("tconv_planes(bf16x3)");
 }
 
@@ -596,24 +609,27 @@ void odin_tconv_planes_set_stamps(void* buf) { g_tp_stamps = (long long*)buf; }
 bool odin_tconv_planes_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt,
                                   int pl, int center, int epi, int C1) {
   if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT")) return false;
-  if (epi == 3 && (CO != 32 || C1 != 1)) return false;
-  return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && CI == 32 && (CO % 32) == 0 && !center &&
-         (W == 16 || W == 32) && (H % (64 / W)) == 0 && (size_t)B * H * W * 32 * 4 < (1ull << 31) &&
+  if (epi == 3 && (CO != 32 || C1 != 1 || CI != 32)) return false;
+  return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && (CI == 32 || CI == 64) && (CO % 32) == 0 &&
+         !center && (W == 16 || W == 32) && (H % (64 / W)) == 0 && (size_t)B * H * W * CI * 4 < (1ull << 31) &&
          (size_t)B * H * W * 4 * C1 * 4 < (1ull << 31);
 }
 
-// epi 1: deconv forward (bias + ELU); 2: conv data gradient (x ELU'(aux), column sums); 3: fused tail
+// epi 1: deconv forward (bias + ELU); 2: conv data gradient (x ELU'(aux), column sums); 3: fused tail.
+// CI = 64: two reduction passes over 32 channels each (weight planes of 64 channels: 192 KB): the first
+// leaves raw partial sums in `out`, the second adds them and runs the epilogue.
 int odin_tconv_planes_launch(const float* in, const float* w, const float* bias, const float* aux,
                              float* out, float* colsum, int* rows_out, const float* w1, const float* b1,
                              const float* target, float* logits, float* llk_part, int* n_part_out,
-                             float* slab, const float* scale, int C1, int B, int H, int W, int CO,
-                             int epi, void* stream) {
+                             float* slab, const float* scale, int C1, int B, int H, int W, int CI,
+                             int CO, int epi, void* stream) {
   TPParams p;
   memset(&p, 0, sizeof(p));
   p.in = in; p.w = w; p.bias = bias; p.aux = aux; p.out = out; p.colsum = colsum;
   p.w1 = w1; p.b1 = b1; p.target = target; p.logits = logits; p.llk_part = llk_part; p.slab = slab;
   p.scale = scale;
   p.B = B; p.H = H; p.CO = CO;
+  p.CS = CI; p.ci_off = 0;
   p.stamps = g_tp_stamps;
   const int RP = 64 / W;
   p.tiles_per_img = H / RP;
@@ -628,8 +644,17 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
   if (n_part_out) *n_part_out = p.tiles_per_img;
   if (out == nullptr) return 0;  // dry run
   dim3 grid(gx, gy, 1);
-  if (epi == 1) return tp_launch_w<1, 1>(p, W, grid, stream);
-  if (epi == 2) return tp_launch_w<2, 1>(p, W, grid, stream);
-  if (C1 == 1) return tp_launch_w<3, 1>(p, W, grid, stream);
+  if (CI == 64) {
+    if (epi == 3) return odin_fail(-2, "tconv_planes tail: 32 input channels only");
+    TPParams q = p;
+    q.colsum = nullptr;
+    const int rc = tp_launch_w<0, 1, false>(q, W, grid, stream);
+    if (rc != 0) return rc;
+    p.ci_off = 32;
+    return epi == 1 ? tp_launch_w<1, 1, true>(p, W, grid, stream) : tp_launch_w<2, 1, true>(p, W, grid, stream);
+  }
+  if (epi == 1) return tp_launch_w<1, 1, false>(p, W, grid, stream);
+  if (epi == 2) return tp_launch_w<2, 1, false>(p, W, grid, stream);
+  if (C1 == 1) return tp_launch_w<3, 1, false>(p, W, grid, stream);
   return odin_fail(-2, "tconv_planes tail: one logit map only");
 }

@@ -59,6 +59,7 @@ CONV_CASES = [
     (3, 32, 32, 32, 64, 4, 2, 'elu', False),   # fconv_ring forward, two 32-channel output blocks
     (3, 16, 16, 32, 64, 4, 2, 'elu', False),   # fconv_ring forward, 8-pixel output rows (a wave spans two rows; encoder2)
     (2, 32, 32, 64, 32, 4, 2, 'elu', False),   # fconv_ring forward over 64 channels: two reduction passes
+    (2, 32, 32, 32, 64, 4, 2, 'elu', False),   # data gradient = tconv_planes over 64 reduction channels (two passes)
 ]
 
 
@@ -107,13 +108,14 @@ DECONV_CASES = [
     (1, 16, 16, 32, 32, 4, 2, 'elu'),          # two-workgroup forward instance (EPI 1); dgrad: rolling-window kernel
     (5, 16, 16, 32, 32, 4, 2, 'elu'),          # fconv_ring data gradient across image boundaries
     (2, 32, 32, 32, 32, 4, 2, 'elu'),          # fconv_ring data gradient, 32-pixel rows (decoder4)
-    (3, 16, 16, 64, 32, 4, 2, 'elu'),          # fconv_ring data gradient into 64 channels (decoder3)
+    (3, 16, 16, 64, 32, 4, 2, 'elu'),          # fconv_ring data gradient into 64 channels; forward: tconv_planes over 64 channels in two passes (decoder3)
     (3, 8, 8, 64, 64, 4, 2, 'elu'),            # fconv_ring data gradient: 8-pixel rows, 64 reduction channels in two passes (decoder2)
     (3, 4, 4, 8, 64, 4, 2, 'elu'),
     (2, 8, 8, 64, 32, 4, 2, 'elu'),
     (1, 16, 16, 32, 32, 4, 2, 'linear'),
     (3, 32, 32, 32, 32, 4, 2, 'elu'),          # tconv_planes forward, 32-pixel rows, several images
     (2, 16, 16, 32, 64, 4, 2, 'elu'),          # tconv_planes forward, two 32-channel output blocks
+    (2, 32, 32, 64, 32, 4, 2, 'elu'),          # tconv_planes forward over 64 channels (two reduction passes), 32-pixel rows
     (2, 8, 8, 8, 64, 4, 1, 'elu'),
     (3, 7, 7, 4, 16, 5, 2, 'elu'),
 ]
