@@ -109,7 +109,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   constexpr int PB = (W + 2) * 64;        // one plane of a row: W + 2 pixels x 32 bf16
   constexpr int RB = 3 * PB;
   constexpr int CPR = W / 8;              // 1 KB load items (8 pixels x 32 channels fp32) per row
-  constexpr int CSHIFT = (W == 32) ? 2 : 1;
+  constexpr int CSHIFT = (W == 32) ? 2 : (W == 16) ? 1 : 0;
   ODIN_DYN_SMEM(char, smem);
   char* wl = smem;
   char* ring = smem + TP_WBYTES;
@@ -223,8 +223,9 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   // ---- this wave's pixel class: column parity x row parity, 32 pixels of the tile ----
   const int role = wave & 3, grp = wave >> 2;
   const int cpw = role & 1, rpar = role >> 1;
-  const int rp = (W == 32) ? grp : 2 * grp + (l31 >> 4);  // input row of the tile (per lane when W = 16)
-  const int i_in = (W == 32) ? l31 : (l31 & 15);          // input column: ow = 2 i + cpw
+  // input row of the tile (per lane when a 32-pixel group spans 2 or 4 rows) and input column: ow = 2 i + cpw
+  const int rp = (W == 32) ? grp : (W == 16) ? 2 * grp + (l31 >> 4) : 4 * grp + (l31 >> 3);
+  const int i_in = (W == 32) ? l31 : (W == 16) ? (l31 & 15) : (l31 & 7);
   // column taps: parity 0 -> kw = 1 (padded column pc = i + 1), kw = 3 (pc = i); parity 1 -> kw = 0
   // (pc = i + 2), kw = 2 (pc = i + 1); row taps alike with kh / padded rows
   const int kw_a = cpw ? 0 : 1, kw_b = kw_a + 2;
@@ -575,13 +576,14 @@ int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    const void* fns[6] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 0, ACC>),
+    const void* fns[7] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 0, ACC>),
                           reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 16, 0, ACC>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, (EPI == 3 ? 16 : 8), 0, ACC>),
                           reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 1 : 0), ACC>),
                           reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 2 : 0), ACC>),
                           reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 4 : 0), ACC>),
                           reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 7 : 0), ACC>)};
-    for (int i = 0; i < ((EPI == 3) ? 6 : 2); ++i)
+    for (int i = 0; i < ((EPI == 3) ? 7 : 3); ++i)
       if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
         (void)hipGetLastError();
     attr_done = true;
@@ -596,7 +598,8 @@ int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
     if (dbg == 7) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 7 : 0), ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
   }
   if (W == 32) ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 0, ACC>), grid, dim3(512), lds, stream, p);
-  else ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 16, 0, ACC>), grid, dim3(512), lds, stream, p);
+  else if (W == 16) ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 16, 0, ACC>), grid, dim3(512), lds, stream, p);
+  else ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, (EPI == 3 ? 16 : 8), 0, ACC>), grid, dim3(512), lds, stream, p);
   return odin_check_launch("tconv_planes(bf16x3)");
 }
 
@@ -609,9 +612,9 @@ void odin_tconv_planes_set_stamps(void* buf) { g_tp_stamps = (long long*)buf; }
 bool odin_tconv_planes_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt,
                                   int pl, int center, int epi, int C1) {
   if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT")) return false;
-  if (epi == 3 && (CO != 32 || C1 != 1 || CI != 32)) return false;
+  if (epi == 3 && (CO != 32 || C1 != 1 || CI != 32 || W == 8)) return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && (CI == 32 || CI == 64) && (CO % 32) == 0 &&
-         !center && (W == 16 || W == 32) && (H % (64 / W)) == 0 && (size_t)B * H * W * CI * 4 < (1ull << 31) &&
+         !center && (W == 8 || W == 16 || W == 32) && (H % (64 / W)) == 0 && (size_t)B * H * W * CI * 4 < (1ull << 31) &&
          (size_t)B * H * W * 4 * C1 * 4 < (1ull << 31);
 }
 

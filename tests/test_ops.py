@@ -109,7 +109,8 @@ DECONV_CASES = [
     (5, 16, 16, 32, 32, 4, 2, 'elu'),          # fconv_ring data gradient across image boundaries
     (2, 32, 32, 32, 32, 4, 2, 'elu'),          # fconv_ring data gradient, 32-pixel rows (decoder4)
     (3, 16, 16, 64, 32, 4, 2, 'elu'),          # fconv_ring data gradient into 64 channels; forward: tconv_planes over 64 channels in two passes (decoder3)
-    (3, 8, 8, 64, 64, 4, 2, 'elu'),            # fconv_ring data gradient: 8-pixel rows, 64 reduction channels in two passes (decoder2)
+    (3, 8, 8, 64, 64, 4, 2, 'elu'),            # fconv_ring data gradient: 8-pixel rows, 64 reduction channels in two passes; forward: tconv_planes, 8-pixel input rows (decoder2)
+    (5, 8, 8, 32, 32, 4, 2, 'elu'),            # tconv_planes forward, 8-pixel input rows, one pass
     (3, 4, 4, 8, 64, 4, 2, 'elu'),
     (2, 8, 8, 64, 32, 4, 2, 'elu'),
     (1, 16, 16, 32, 32, 4, 2, 'linear'),
