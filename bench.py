@@ -255,7 +255,7 @@ def launch_ranks(n, argv):
   for r in range(n):
     env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                  stdout=None if r == 0 else subprocess.DEVNULL))
+                                  stdout=json_out() if r == 0 else subprocess.DEVNULL))
   rc = 0
   pending = list(procs)
   while pending:
@@ -288,7 +288,7 @@ def dry_run(args, world, rank):
   if rank == 0:
     print(json.dumps(dict(metric='launcher dry run (no kernels executed)', value=0.0,
                           unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
-                          rccl=dict(ranks_seen=seen, backend='gloo'))))
+                          rccl=dict(ranks_seen=seen, backend='gloo'))), file=json_out(), flush=True)
 
 
 def time_allreduce(eng, reps=20):
@@ -307,7 +307,23 @@ def time_allreduce(eng, reps=20):
   return e0.elapsed_time(e1) / reps * 1e3
 
 
+_JSON_OUT = None
+
+
+def json_out():
+  """The process's ORIGINAL stdout, for the one JSON line.  File descriptor 1 itself is pointed at
+  stderr for the rest of the run: RCCL prints a version banner to fd 1 from C, which would otherwise
+  land next to the JSON line the driver parses."""
+  global _JSON_OUT
+  if _JSON_OUT is None:
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+  return _JSON_OUT
+
+
 def main():
+  json_out()
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=100)
@@ -566,7 +582,7 @@ def main():
              hbm_kernels=hbm)
   if rccl is not None:
     res['rccl'] = rccl
-  print(json.dumps(res), flush=True)
+  print(json.dumps(res), file=json_out(), flush=True)
   if use_dist:
     dist.destroy_process_group()
 

@@ -24,11 +24,11 @@ kernels = {
                           'weight gradient of the last Conv2DTranspose (fp32 MFMA), dSprites B=256',
                           # x [B,32,32,32] + dY [B,64,64,32] read once, slabs [256 rows][16*32*32] written
                           (B * 32 * 32 * 32 + B * 64 * 64 * 32) * f4 + 256 * 16 * 32 * 32 * f4),
-    'dec4:deconv:dgrad': ('fconv_ring_kernel<2>', '131072/lds512',
+    'dec4:deconv:dgrad': ('fconv_ring_kernel<2, false>', '131072/lds512',
                           'data gradient of the last Conv2DTranspose (fconv_ring, fp32 MFMA)',
                           # dY [B,64,64,32] + aux [B,32,32,32] read, dx [B,32,32,32] written
                           (B * 64 * 64 * 32 + 2 * B * 32 * 32 * 32) * f4),
-    'dec4+5:tail:fwd+elbo': ('tconv_planes_kernel<3, 1, 32, 0>', '131072/lds2560',
+    'dec4+5:tail:fwd+elbo': ('tconv_planes_kernel<3, 1, 32, 0, false>', '131072/lds2560',
                              'fused decoder tail (tconv_planes, fp32 operands as 3 bf16 planes)',
                              # x [B,32,32,32] + target [B,64,64,1] read; logits + d(pre-activation) [B,64,64,32] written
                              (B * 32 * 32 * 32 + 2 * B * 64 * 64 + B * 64 * 64 * 32) * f4),
