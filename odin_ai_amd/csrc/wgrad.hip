@@ -966,11 +966,10 @@ template <int KMAX, int RPWMAX, int TSP>
 int launch_ws_inst(WParams& p, dim3 grid, size_t lds, void* stream) {
   const int rpw = (p.NIMG * p.NRI + NW_W - 1) / NW_W;
   p.n_batches = (rpw + RPWMAX - 1) / RPWMAX;
-  if (p.n_batches != 1 || p.KI > KMAX) return 1;  // not this instance: single-role kernel
-  // one image per tile, whole tiles only (no ragged batch end), zero row long enough
-  if (p.NIMG != 1 || (p.OH % p.TR) != 0 || (size_t)p.W * p.P * 4 > 16384 || p.pl < 0 ||
-      (p.CO % 32) != 0)
-    return 1;
+  // (try_launch_ws has checked every qualifier already; these can no longer trigger)
+  if (p.n_batches != 1 || p.KI > KMAX || p.NIMG != 1 || (p.OH % p.TR) != 0 ||
+      (size_t)p.W * p.P * 4 > 16384 || p.pl < 0 || (p.CO % 32) != 0)
+    return odin_fail(-2, "wgrad_ws: plan and launch disagree");
   p.pipelined = 1;
 #ifndef ODIN_SIM
   static bool attr_done = false;
@@ -1010,6 +1009,12 @@ int try_launch_ws(const WParams& p0, int* rows_out, void* stream) {
     const int rmax = p.KI <= 5 ? 5 : 3;
     if (rpw > rmax) return 1;  // more than one staging batch per tile
   }
+  // every disqualifier of launch_ws_inst is decided HERE, before the dry-run return: the dry run and
+  // the launch must pick the same plan (the caller sizes the slab from the dry run's row count):
+  // one image per tile, whole tiles only (no ragged batch end), zero row long enough
+  if (p.NIMG != 1 || (p.OH % p.TR) != 0 || (size_t)p.W * p.P * 4 > 16384 || p.pl < 0 ||
+      (p.CO % 32) != 0)
+    return 1;
   if (rows_out) *rows_out = gx;
   if (p.slab == nullptr) return 0;  // dry run
   p.stamps = g_wstamps;

@@ -308,3 +308,29 @@ def test_tconv_ring_fp32_opt_in(bk, kind, args):
       test_conv2d_fwd_dgrad_wgrad(bk, *args)
   finally:
     os.unsetenv('ODIN_TRING')
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co', [(2, 16, 16, 32, 48), (1, 32, 32, 32, 80), (3, 16, 16, 32, 32),
+                                         (2, 64, 64, 32, 32)])
+def test_wgrad_dry_run_reports_the_rows_the_launch_writes(bk, B, H, W, Ci, Co):
+  """The slab is sized from the dry run (NULL slab pointer): the real launch must pick the same
+  plan -- also for channel counts that disqualify the producer/consumer kernel (Cout % 32 != 0)."""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(5)
+  K, S = 4, 2
+  OH, pt, _ = vo.same_pads(H, K, S)
+  OW, pl, _ = vo.same_pads(W, K, S)
+  d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, 'elu', False)
+  dry = C.c_int(0)
+  L.odin_conv2d_wgrad(None, None, None, C.byref(dry), C.byref(d), None)
+  x, dy = rng.random((B, H, W, Ci)), rng.standard_normal((B, OH, OW, Co))
+  n = K * K * Ci * Co + Co
+  slab = bk.full((dry.value, n), float('nan'))   # exactly the rows the dry run promised
+  rows = C.c_int(0)
+  tx, tdy = T(x), T(dy)
+  L.odin_conv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d), None)
+  assert rows.value == dry.value
+  _, dw_ref, db_ref = vo.conv2d_bwd(x, rng.standard_normal((K, K, Ci, Co)), dy, S)
+  g = reduce_slab(bk, slab, rows.value, n)
+  close(g[:-Co].reshape(K, K, Ci, Co), dw_ref, 1e-4)
+  close(g[-Co:], db_ref, 1e-4)
