@@ -71,3 +71,10 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
                              const float* target, float* logits, float* llk_part, int* n_part_out,
                              float* slab, const float* scale, int C1, int B, int H, int W, int CI,
                              int CO, int epi, void* stream);
+
+// weight gradients of the 4x4 / stride-2 layers with both operands as bf16 planes, transposing LDS reads
+// (wgrad_planes.hip)
+bool odin_wgrad_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
+                                  int S, int pt, int pl, int center);
+int odin_wgrad_planes_launch(const float* U, const float* V, float* slab, int* rows_out, int B, int OH,
+                             int OW, int CI, int CO, int want_bias, void* stream);

@@ -1033,6 +1033,10 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
   int gx, gy, gz;
   size_t lds;
   p.slab_stride = p.KH * p.KW * p.CI * p.CO + (p.want_bias ? p.CO : 0);
+  if (odin_wgrad_planes_applicable(p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO, p.KH, p.KW, p.S, p.pt, p.pl,
+                                   p.center))
+    return odin_wgrad_planes_launch(p.in, p.dy, p.slab, rows_out, p.B, p.OH, p.OW, p.CI, p.CO,
+                                    p.want_bias, stream);
   {
     const int rc = try_launch_ws(p, rows_out, stream);
     if (rc != 1) return rc;

@@ -1,0 +1,385 @@
+// wgrad_planes.hip -- WEIGHT GRADIENT of the 4x4 / stride-2 layers (Conv2D and Conv2DTranspose, TF
+// `SAME`, pads (1, 1)) with BOTH fp32 operands carried through the bf16 matrix pipe as three exact bf16
+// planes (odin_device.h: x = x0 + x1 + x2 by truncation; six plane products per 16 k-values,
+// fp32 accumulation, <= 3 * 2^-24 per product).
+//
+// One formulation serves both layer kinds.  With a FINE tensor U [B, 2h, 2w, CU] and a COARSE tensor
+// V [B, h, w, CV] related by coarse pixel (i, j) <-> fine pixel (2 i - 1 + kh, 2 j - 1 + kw):
+//       dW[kh][kw][cu][cv] = sum over (b, i, j) of U[b, 2 i - 1 + kh, 2 j - 1 + kw, cu] * V[b, i, j, cv]
+//   Conv2D          (image_networks.py:462-468): U = layer input,            V = dL/d pre-activation,
+//                                                dW in Keras' (kh, kw, Cin, Cout); db = column sums of V
+//   Conv2DTranspose (image_networks.py:499-506): U = dL/d pre-activation,    V = layer input,
+//                                                dW in Keras' (kh, kw, Cout, Cin)
+// (tape.gradient of the step, base_networks.py:549.)  The MFMA reduction index is the PIXEL: a
+// v_mfma_f32_32x32x16_bf16 multiplies A = U^T [32 cu][16 pixels] by B = V [16 pixels][32 cv].  Both
+// operands are channel-major fragments of pixel-major data: the LDS images stay [pixel][32 channels]
+// (written exactly as in tconv_planes.hip: global_load -> split once -> three ds_write_b64) and the
+// fragments are fetched with ds_read_b64_tr_b16, the transposing LDS read of gfx950 (a 16-lane group
+// reads 4 pixels x 16 channels and every lane receives one channel's 4 pixels).  A shift by one
+// coarse column (kw >= 2) is a shift by one 64-byte pixel slot: always aligned.
+//
+// Structure: 8 waves, all alike; wave v owns the taps (kh = v >> 1, kw = 2 (v & 1) + {0, 1}) and keeps
+// their two 32 x 32 accumulators in registers over the whole persistent tile loop.  A tile = 32
+// coarse pixels (1, 2 or 4 coarse rows) = 2 chunks of 16: per chunk 6 transposed reads of V (shared by
+// the wave's two taps), 12 of U, 12 MFMAs.  Rolling row windows in LDS (slot = global padded row mod
+// NS), fine rows as two column-parity planes so that the 16 pixels of a chunk are consecutive slots;
+// the split + store of the next tile's rows and the global loads of the one after ride in the MFMA
+// stream; one workgroup barrier per tile.  No epilogue: the accumulators go to this workgroup's slab
+// row once, at the end (odin_slab_reduce sums the rows in fixed order).
+#include "odin_device.h"
+#include "odin_internal.h"
+#include <cstdlib>
+
+namespace {
+
+struct WPParams {
+  const float* U;      // [B, 2h, 2w, CUt]
+  const float* V;      // [B, h, w, CVt]
+  float* slab;         // [gridDim.x][16 * CUt * CVt (+ CVt)]
+  int B, h;
+  int CUt, CVt;        // channels per pixel in memory; this workgroup's 32 start at 32 * blockIdx.y / .z
+  int want_bias;
+  int slab_stride;
+  int tiles_per_img, n_tiles, tiles_per_wg;
+};
+
+// four consecutive fp32 values -> their three bf16 planes (4 bf16 = 8 bytes each), exact
+__device__ __forceinline__ void wp_split4(const float4& v, u32x2& h, u32x2& m, u32x2& l) {
+  h = odin_u2(odin_pack_bf16(v.x, v.y), odin_pack_bf16(v.z, v.w));
+  const float r0 = odin_bf16_rest(v.x), r1 = odin_bf16_rest(v.y), r2 = odin_bf16_rest(v.z),
+              r3 = odin_bf16_rest(v.w);
+  m = odin_u2(odin_pack_bf16(r0, r1), odin_pack_bf16(r2, r3));
+  l = odin_u2(odin_pack_bf16(odin_bf16_rest(r0), odin_bf16_rest(r1)),
+              odin_pack_bf16(odin_bf16_rest(r2), odin_bf16_rest(r3)));
+}
+
+// ds_read_b64_tr_b16: `blk` = byte address of a block of 4 rows (`stride` bytes apart) x 16 bf16 columns;
+// lane l16 of the 16-lane group receives column l16 of the 4 rows (row q in element q).  On the
+// hardware lane 4 q + p supplies the address of row q, columns 4 p .. 4 p + 3.
+__device__ __forceinline__ u32x2 wp_tr_read(const char* blk, int stride, int l16) {
+#ifdef ODIN_SIM
+  unsigned short e[4];
+  for (int q = 0; q < 4; ++q) e[q] = *reinterpret_cast<const unsigned short*>(blk + q * stride + 2 * l16);
+  return odin_u2((unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16));
+#else
+  typedef short wp_s4 __attribute__((ext_vector_type(4)));
+  const char* a = blk + (l16 >> 2) * stride + (l16 & 3) * 8;
+  const wp_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wp_s4*)a);
+  return __builtin_bit_cast(u32x2, v);
+#endif
+}
+
+struct WpItem {
+  float4 v;
+  int dst;  // byte offset of the hi-plane store inside the LDS image; < 0: no item (wave-uniform)
+};
+
+constexpr int WP_MAXU = 4;  // 1 KB load items (8 pixels x 32 channels) of fine rows per wave and fill
+
+// W = coarse row length (8, 16 or 32)
+template <int W>
+__global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
+  constexpr int TC = 32 / W;             // coarse rows per tile
+  constexpr int WU = 2 * W;              // fine row length
+  constexpr int SU = W + 1;              // slots per column-parity plane of a fine row
+  constexpr int PARB = SU * 64;          // one parity plane
+  constexpr int PBU = 2 * PARB;          // one bf16 plane of a fine row
+  constexpr int RBU = 3 * PBU;
+  constexpr int NSU = 4 * TC + 3;        // live fine rows (2 TC + 2) + the next tile's (2 TC + 1 at an image seam)
+  constexpr int PBV = W * 64;
+  constexpr int RBV = 3 * PBV;
+  constexpr int NSV = 2 * TC;
+  constexpr int IPU = WU / 8;            // load items per fine row: 8, 4, 2
+  constexpr int IPV = W / 8;             // per coarse row: 4, 2, 1
+  ODIN_DYN_SMEM(char, smem);
+  char* uring = smem;
+  char* vring = smem + NSU * RBU;
+  __shared__ float bred[8 * 32];
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef ODIN_SIM
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int l31 = lane & 31, half = lane >> 5, l16 = lane & 15;
+  const int cu0 = blockIdx.y * 32, cv0 = blockIdx.z * 32;
+  const int HU = 2 * p.h, HPU = HU + 1;
+  const int T0 = blockIdx.x * p.tiles_per_wg;
+  int T1 = T0 + p.tiles_per_wg;
+  if (T1 > p.n_tiles) T1 = p.n_tiles;
+  if (T0 >= T1) return;
+
+  // ---- SAME-padding slots of every fine ring row and plane: parity plane 0 slot 0 (padded column 0)
+  // and parity plane 1 slot W (padded column 2 w + 1): zero for ever ----
+  for (int e = tid; e < NSU * 24; e += 512) {
+    const int sl = e / 24, rem = e - sl * 24;
+    const int pl = rem >> 3, side = (rem >> 2) & 1, piece = rem & 3;
+    *reinterpret_cast<float4*>(uring + sl * RBU + pl * PBU + (side ? PARB + W * 64 : 0) + piece * 16) =
+        make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- row fills (wave-uniform walks; a wave moves up to WP_MAXU fine-row items and one coarse-row item) ----
+  const OdinRun RU = odin_run(p.U, (unsigned)((size_t)p.B * HU * WU * p.CUt * 4));
+  const OdinRun RV = odin_run(p.V, (unsigned)((size_t)p.B * p.h * W * p.CVt * 4));
+  // fine rows: global padded row g = HPU * b + (fine row + 1); gi = g mod HPU (0: the zero row)
+  int fu_g, fu_gi, fu_b, fu_slot, need_gu0, ft_t;
+  int fv_row;  // next coarse row (global index h * b + i) to fill
+  {
+    const int b0 = T0 / p.tiles_per_img, t0 = T0 - b0 * p.tiles_per_img;
+    fu_g = HPU * b0 + 2 * TC * t0;
+    fu_gi = 2 * TC * t0;
+    fu_b = b0;
+    fu_slot = fu_g % NSU;
+    need_gu0 = fu_g;
+    ft_t = t0;
+    fv_row = p.h * b0 + TC * t0;
+  }
+  float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);  // column sums of V (channels 4 (lane & 7) ..) for the bias
+  auto load_fill = [&](WpItem (&iu)[WP_MAXU], WpItem& iv, bool live) {
+    const int nrows = live ? need_gu0 + 2 * TC + 2 - fu_g : 0;
+    const int ch4 = lane & 7;
+#pragma unroll
+    for (int j = 0; j < WP_MAXU; ++j) {
+      const int idx = wave + 8 * j;
+      const int r = idx / IPU, c = idx - r * IPU;
+      const bool valid = r < nrows;
+      int gi = fu_gi + r, b = fu_b;
+      if (gi >= HPU) { gi -= HPU; ++b; }
+      int slot = fu_slot + r;
+      if (slot >= NSU) slot -= NSU;
+      const int px = 8 * c + (lane >> 3);
+      const int pc = px + 1;  // padded column: parity pc & 1, slot pc >> 1
+      iu[j].dst = valid ? slot * RBU + (pc & 1) * PARB + (pc >> 1) * 64 + ch4 * 8 : -1;
+      const bool real = valid && gi != 0 && b < p.B;
+      iu[j].v = odin_run_load4(
+          RU, real ? (unsigned)((((((size_t)b * HU + gi - 1) * WU + px) * p.CUt + cu0 + 4 * ch4) * 4)) : ODIN_OOB);
+    }
+    {
+      // coarse rows of the tile: TC rows x IPV items = 4 items, waves 0-3
+      const int r = wave / IPV, c = wave - r * IPV;
+      const bool valid = live && wave < 4;
+      const int grow = fv_row + r;
+      const int b = grow / p.h;
+      const int px = 8 * c + (lane >> 3);
+      iv.dst = valid ? NSU * RBU + (grow % NSV) * RBV + px * 64 + ch4 * 8 : -1;
+      iv.v = odin_run_load4(RV, (valid && b < p.B)
+                                    ? (unsigned)(((((size_t)grow * W + px) * p.CVt + cv0 + 4 * ch4) * 4))
+                                    : ODIN_OOB);
+    }
+    if (live) {
+      fu_g += nrows;
+      fu_gi += nrows;
+      if (fu_gi >= HPU) { fu_gi -= HPU; ++fu_b; }
+      fu_slot += nrows;
+      if (fu_slot >= NSU) fu_slot -= NSU;
+      need_gu0 += 2 * TC;
+      if (++ft_t == p.tiles_per_img) { ft_t = 0; need_gu0 += 1; }
+      fv_row += TC;
+    }
+  };
+  auto store_item = [&](const WpItem& it, int plane_bytes) {
+#ifdef ODIN_SIM
+    if (it.dst < 0) return;
+#else
+    if (__builtin_amdgcn_readfirstlane(it.dst) < 0) return;  // wave-uniform: a scalar branch
+#endif
+    u32x2 h, m, l;
+    wp_split4(it.v, h, m, l);
+    char* d = smem + it.dst;
+    *reinterpret_cast<u32x2*>(d) = h;
+    *reinterpret_cast<u32x2*>(d + plane_bytes) = m;
+    *reinterpret_cast<u32x2*>(d + 2 * plane_bytes) = l;
+  };
+  // item k of a fill: 0 .. WP_MAXU - 1 fine-row items, WP_MAXU: the coarse-row item (+ its bias sums)
+  auto store_fill_item = [&](const WpItem (&iu)[WP_MAXU], const WpItem& iv, int k) {
+    if (k < WP_MAXU) {
+      store_item(iu[k], PBU);
+    } else {
+      store_item(iv, PBV);
+      bsum4.x += iv.v.x; bsum4.y += iv.v.y; bsum4.z += iv.v.z; bsum4.w += iv.v.w;  // (absent items hold zeros)
+    }
+  };
+  auto store_fill = [&](const WpItem (&iu)[WP_MAXU], const WpItem& iv) {
+#pragma unroll
+    for (int k = 0; k <= WP_MAXU; ++k) store_fill_item(iu, iv, k);
+  };
+
+  // ---- this wave's taps and this lane's part of a transposed read ----
+  const int kh = wave >> 1, kw0 = 2 * (wave & 1);  // taps (kh, kw0) and (kh, kw0 + 1)
+  // pixel k of a 16-pixel chunk supplied by this lane: block blk (0, 1) of its half, row q = l16 >> 2
+  int kpix[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) kpix[blk] = 8 * half + 4 * blk + (l16 >> 2);
+  const int colb = (16 * ((lane >> 4) & 1) + 4 * (l16 & 3)) * 2;  // byte offset of this lane's 4 columns
+  // (coarse row inside the chunk, coarse column) of that pixel
+  int krow[2], kcol[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    krow[blk] = (W >= 16) ? 0 : (kpix[blk] >> 3);
+    kcol[blk] = (W >= 16) ? kpix[blk] : (kpix[blk] & 7);
+  }
+
+  f32x16 acc[2] = {f32x16_zero(), f32x16_zero()};
+  WpItem iuA[WP_MAXU], iuB[WP_MAXU], ivA, ivB;
+
+  // ---- prologue: rows of the first tile, then the second tile's into registers ----
+  load_fill(iuA, ivA, true);
+  store_fill(iuA, ivA);
+  load_fill(iuA, ivA, T0 + 1 < T1);
+  __syncthreads();
+
+  int b_cur = T0 / p.tiles_per_img, t_cur = T0 - b_cur * p.tiles_per_img;
+  int su0 = (HPU * b_cur + 2 * TC * t_cur) % NSU;  // ring slot of the tile's first padded fine row
+  int sv0 = (p.h * b_cur + TC * t_cur) % NSV;
+
+  // fragments of one 16-pixel chunk: V (3 planes) and U for the wave's two taps
+  struct Frags { u32x4 fv[3]; u32x4 fu[2][3]; };
+  auto read_chunk = [&](int c, Frags& F) {
+    // chunk c: coarse rows row0 (+ krow), columns j0 + kcol
+    const int row0 = (W == 32) ? 0 : (W == 16) ? c : 2 * c;
+    const int j0 = (W == 32) ? 16 * c : 0;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      int sv = sv0 + row0 + krow[blk];
+      if (sv >= NSV) sv -= NSV;
+      int su = su0 + 2 * (row0 + krow[blk]) + kh;
+      if (su >= NSU) su -= NSU;
+      // the block's first row is this lane's pixel minus its row index q: pass the block base
+      const int q = l16 >> 2;
+      const char* vb = vring + sv * RBV + (j0 + kcol[blk] - q) * 64 + colb - (l16 & 3) * 8;
+      const char* ub = uring + su * RBU + (j0 + kcol[blk] - q) * 64 + colb - (l16 & 3) * 8;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const u32x2 tv = wp_tr_read(vb + pl * PBV, 64, l16);
+        F.fv[pl][2 * blk] = tv.x; F.fv[pl][2 * blk + 1] = tv.y;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int kw = kw0 + t;  // padded column 2 j + kw: parity kw & 1, slot j + (kw >> 1)
+          const u32x2 tu = wp_tr_read(ub + pl * PBU + (kw & 1) * PARB + (kw >> 1) * 64, 64, l16);
+          F.fu[t][pl][2 * blk] = tu.x; F.fu[t][pl][2 * blk + 1] = tu.y;
+        }
+      }
+    }
+  };
+  // the 12 MFMAs of a chunk (plane products, smallest first: 0*2, 2*0, 1*1, 0*1, 1*0, 0*0; the two taps
+  // alternate so that consecutive MFMAs are independent); behind MFMA m one item of the next tile's
+  // rows is split and stored (bf16 MFMAs run beside plain VALU work)
+  auto mfma_chunk = [&](const Frags& F, int item0) {
+#pragma unroll
+    for (int m = 0; m < 12; ++m) {
+      const int t = m & 1, pp = m >> 1;
+      const int ia = (pp == 0) ? 0 : (pp == 1) ? 2 : (pp == 2) ? 1 : (pp == 3) ? 0 : (pp == 4) ? 1 : 0;
+      const int ib = (pp == 0) ? 2 : (pp == 1) ? 0 : (pp == 2) ? 1 : (pp == 3) ? 1 : (pp == 4) ? 0 : 0;
+      acc[t] = mfma32_bf16(F.fu[t][ia], F.fv[ib], acc[t]);
+      if ((m & 3) == 1) {
+        const int k = item0 + (m >> 2);
+        if (k <= WP_MAXU) store_fill_item(iuA, ivA, k);
+      }
+      ODIN_SCHED_FENCE();
+    }
+  };
+
+#pragma unroll 1
+  for (int T = T0; T < T1; ++T) {
+    Frags F0, F1;
+    read_chunk(0, F0);   // first thing behind the barrier
+    ODIN_SCHED_FENCE();
+    load_fill(iuB, ivB, T + 2 < T1);
+    read_chunk(1, F1);
+    ODIN_SCHED_FENCE();
+    mfma_chunk(F0, 0);   // items 0, 1, 2
+    mfma_chunk(F1, 3);   // items 3, 4
+#pragma unroll
+    for (int j = 0; j < WP_MAXU; ++j) iuA[j] = iuB[j];
+    ivA = ivB;
+    su0 += 2 * TC;
+    sv0 += TC;
+    if (++t_cur == p.tiles_per_img) { t_cur = 0; ++b_cur; ++su0; }
+    if (su0 >= NSU) su0 -= NSU;
+    if (sv0 >= NSV) sv0 -= NSV;
+    __syncthreads();  // every wave is past tile T's rows; tile T + 1's rows are stored
+  }
+
+  // ---- this workgroup's slab row: dW[tap][cu0 + cu][cv0 + cv], lane = column cv = l31 ----
+  float* row = p.slab + (size_t)blockIdx.x * p.slab_stride;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int tap = kh * 4 + kw0 + t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cu = (r & 3) + 8 * (r >> 2) + 4 * half;
+      row[((size_t)tap * p.CUt + cu0 + cu) * p.CVt + cv0 + l31] = acc[t][r];
+    }
+  }
+  if (p.want_bias && blockIdx.y == 0) {
+    // column sums of V: lanes with the same channel quad (lane & 7), then the 8 waves through LDS
+    float s[4] = {bsum4.x, bsum4.y, bsum4.z, bsum4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int m = 8; m <= 32; m <<= 1) s[k] += __shfl_xor(s[k], m);
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bred[wave * 32 + 4 * lane + k] = s[k];
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float t = 0.f;
+      for (int wv = 0; wv < 8; ++wv) t += bred[wv * 32 + tid];
+      row[(size_t)16 * p.CUt * p.CVt + cv0 + tid] = t;
+    }
+  }
+}
+
+template <int W>
+int wp_launch(const WPParams& p, dim3 grid, void* stream) {
+  constexpr int TC = 32 / W;
+  const size_t lds = (size_t)(4 * TC + 3) * 3 * 2 * (W + 1) * 64 + (size_t)(2 * TC) * 3 * W * 64;
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<W>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+      (void)hipGetLastError();
+    attr_done = true;
+  }
+#endif
+  ODIN_LAUNCH((wgrad_planes_kernel<W>), grid, dim3(512), lds, stream, p);
+  return odin_check_launch("wgrad_planes(bf16x3)");
+}
+
+}  // namespace
+
+// fine tensor U [B, H, W, CI], coarse tensor V [B, OH, OW, CO] (the argument order of wgrad.hip's WParams)
+bool odin_wgrad_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
+                                  int S, int pt, int pl, int center) {
+  if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT") || getenv("ODIN_NOWPLANES")) return false;
+  return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && !center && (CI % 32) == 0 && (CO % 32) == 0 &&
+         H == 2 * OH && W == 2 * OW && (OW == 8 || OW == 16 || OW == 32) && (OH % (32 / OW)) == 0 &&
+         (size_t)B * H * W * CI * 4 < (1ull << 31) && (size_t)B * OH * OW * CO * 4 < (1ull << 31);
+}
+
+int odin_wgrad_planes_launch(const float* U, const float* V, float* slab, int* rows_out, int B, int OH,
+                             int OW, int CI, int CO, int want_bias, void* stream) {
+  WPParams p;
+  memset(&p, 0, sizeof(p));
+  p.U = U; p.V = V; p.slab = slab;
+  p.B = B; p.h = OH; p.CUt = CI; p.CVt = CO; p.want_bias = want_bias;
+  p.slab_stride = 16 * CI * CO + (want_bias ? CO : 0);
+  const int TC = 32 / OW;
+  p.tiles_per_img = OH / TC;
+  p.n_tiles = B * p.tiles_per_img;
+  const int gy = CI / 32, gz = CO / 32;
+  int cap = odin_num_cus() / (gy * gz);
+  if (cap < 1) cap = 1;
+  if (cap > ODIN_MAX_SLAB_BLOCKS) cap = ODIN_MAX_SLAB_BLOCKS;
+  p.tiles_per_wg = (p.n_tiles + cap - 1) / cap;
+  const int gx = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+  if (rows_out) *rows_out = gx;
+  if (slab == nullptr) return 0;  // dry run
+  dim3 grid(gx, gy, gz);
+  if (OW == 32) return wp_launch<32>(p, grid, stream);
+  if (OW == 16) return wp_launch<16>(p, grid, stream);
+  return wp_launch<8>(p, grid, stream);
+}
