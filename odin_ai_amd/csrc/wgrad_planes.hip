@@ -76,8 +76,9 @@ struct WpItem {
 
 constexpr int WP_MAXU = 4;  // 1 KB load items (8 pixels x 32 channels) of fine rows per wave and fill
 
-// W = coarse row length (8, 16 or 32)
-template <int W>
+// W = coarse row length (8, 16 or 32); DBG (diagnostics, ODIN_WP_DBG): 1 no MFMAs, 2 no LDS reads in the loop,
+// 4 no row fills after the prologue
+template <int W, int DBG = 0>
 __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   constexpr int TC = 32 / W;             // coarse rows per tile
   constexpr int WU = 2 * W;              // fine row length
@@ -135,36 +136,50 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
     fv_row = p.h * b0 + TC * t0;
   }
   float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);  // column sums of V (channels 4 (lane & 7) ..) for the bias
+  // lane-constant parts of an item: pixel inside the 8-pixel item, channel quad, LDS / global offsets
+  const int ch4 = lane & 7, pxl = lane >> 3;
+  const int pcl = pxl + 1;  // padded column of the item's pixel when the item starts at column 0
+  // a fine-row item at columns 8 c ..: padded column 8 c + pcl -> parity pcl & 1, slot 4 c + (pcl >> 1)
+  const int u_lds_lane = (pcl & 1) * PARB + (pcl >> 1) * 64 + ch4 * 8;
+  const int v_lds_lane = pxl * 64 + ch4 * 8;
+  const unsigned u_g_lane = (unsigned)((pxl * p.CUt + cu0 + 4 * ch4) * 4);
+  const unsigned v_g_lane = (unsigned)((pxl * p.CVt + cv0 + 4 * ch4) * 4);
+  // item j of this wave: row r0 + RJ j of the fill, 8-pixel column block cu_blk (all wave constants;
+  // 32-bit offsets throughout -- the applicability test bounds the tensors to 2 GB -- because this is
+  // SCALAR work of every wave on every tile: with 64-bit products it cost ~1000 cycles per tile)
+  constexpr int RJ = 8 / IPU > 0 ? 8 / IPU : 1;
+  const int r0 = wave / IPU, cu_blk = wave - r0 * IPU;
+  const unsigned u_rowbytes = (unsigned)(WU * p.CUt * 4), v_rowbytes = (unsigned)(W * p.CVt * 4);
+  const unsigned u_colb = (unsigned)(8 * cu_blk * p.CUt * 4) + u_g_lane;
+  const int u_lds_item = 4 * cu_blk * 64 + u_lds_lane;
+  const int vr = (wave & 3) / IPV, vc = (wave & 3) - vr * IPV;
+  const unsigned v_colb = (unsigned)(8 * vc * p.CVt * 4) + v_g_lane;
+  const int v_lds_item = NSU * RBU + 8 * vc * 64 + v_lds_lane;
+  const int n_vrows = p.B * p.h;
   auto load_fill = [&](WpItem (&iu)[WP_MAXU], WpItem& iv, bool live) {
     const int nrows = live ? need_gu0 + 2 * TC + 2 - fu_g : 0;
-    const int ch4 = lane & 7;
 #pragma unroll
     for (int j = 0; j < WP_MAXU; ++j) {
-      const int idx = wave + 8 * j;
-      const int r = idx / IPU, c = idx - r * IPU;
+      // (the load itself is unconditional -- an absent item reads zeros through the range check -- so
+      // that the number of loads in flight is a compile-time constant: the wait before a store is
+      // vmcnt(N), not vmcnt(0))
+      const int r = r0 + RJ * j;
       const bool valid = r < nrows;
       int gi = fu_gi + r, b = fu_b;
       if (gi >= HPU) { gi -= HPU; ++b; }
       int slot = fu_slot + r;
       if (slot >= NSU) slot -= NSU;
-      const int px = 8 * c + (lane >> 3);
-      const int pc = px + 1;  // padded column: parity pc & 1, slot pc >> 1
-      iu[j].dst = valid ? slot * RBU + (pc & 1) * PARB + (pc >> 1) * 64 + ch4 * 8 : -1;
-      const bool real = valid && gi != 0 && b < p.B;
-      iu[j].v = odin_run_load4(
-          RU, real ? (unsigned)((((((size_t)b * HU + gi - 1) * WU + px) * p.CUt + cu0 + 4 * ch4) * 4)) : ODIN_OOB);
+      iu[j].dst = valid ? slot * RBU + u_lds_item : -1;
+      const bool real = valid && gi != 0 && b < p.B;   // gi == 0: the zero row between images
+      const unsigned rowb = (unsigned)(b * HU + gi - 1) * u_rowbytes;
+      iu[j].v = odin_run_load4(RU, real ? rowb + u_colb : ODIN_OOB);
     }
     {
       // coarse rows of the tile: TC rows x IPV items = 4 items, waves 0-3
-      const int r = wave / IPV, c = wave - r * IPV;
       const bool valid = live && wave < 4;
-      const int grow = fv_row + r;
-      const int b = grow / p.h;
-      const int px = 8 * c + (lane >> 3);
-      iv.dst = valid ? NSU * RBU + (grow % NSV) * RBV + px * 64 + ch4 * 8 : -1;
-      iv.v = odin_run_load4(RV, (valid && b < p.B)
-                                    ? (unsigned)(((((size_t)grow * W + px) * p.CVt + cv0 + 4 * ch4) * 4))
-                                    : ODIN_OOB);
+      const int grow = fv_row + vr;
+      iv.dst = valid ? (grow & (NSV - 1)) * RBV + v_lds_item : -1;
+      iv.v = odin_run_load4(RV, (valid && grow < n_vrows) ? (unsigned)grow * v_rowbytes + v_colb : ODIN_OOB);
     }
     if (live) {
       fu_g += nrows;
@@ -220,12 +235,13 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   }
 
   f32x16 acc[2] = {f32x16_zero(), f32x16_zero()};
-  WpItem iuA[WP_MAXU], iuB[WP_MAXU], ivA, ivB;
+  WpItem iuA[WP_MAXU], iuB[WP_MAXU], iuC[WP_MAXU], ivA, ivB, ivC;
 
   // ---- prologue: rows of the first tile, then the second tile's into registers ----
   load_fill(iuA, ivA, true);
   store_fill(iuA, ivA);
   load_fill(iuA, ivA, T0 + 1 < T1);
+  load_fill(iuB, ivB, T0 + 2 < T1);
   __syncthreads();
 
   int b_cur = T0 / p.tiles_per_img, t_cur = T0 - b_cur * p.tiles_per_img;
@@ -264,40 +280,52 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   // the 12 MFMAs of a chunk (plane products, smallest first: 0*2, 2*0, 1*1, 0*1, 1*0, 0*0; the two taps
   // alternate so that consecutive MFMAs are independent); behind MFMA m one item of the next tile's
   // rows is split and stored (bf16 MFMAs run beside plain VALU work)
-  auto mfma_chunk = [&](const Frags& F, int item0) {
+  auto mfma_chunk = [&](const Frags& F, int item0, const WpItem (&stu)[WP_MAXU], const WpItem& stv) {
 #pragma unroll
     for (int m = 0; m < 12; ++m) {
       const int t = m & 1, pp = m >> 1;
       const int ia = (pp == 0) ? 0 : (pp == 1) ? 2 : (pp == 2) ? 1 : (pp == 3) ? 0 : (pp == 4) ? 1 : 0;
       const int ib = (pp == 0) ? 2 : (pp == 1) ? 0 : (pp == 2) ? 1 : (pp == 3) ? 1 : (pp == 4) ? 0 : 0;
-      acc[t] = mfma32_bf16(F.fu[t][ia], F.fv[ib], acc[t]);
+      if (!(DBG & 1)) acc[t] = mfma32_bf16(F.fu[t][ia], F.fv[ib], acc[t]);
+      else acc[t][m] += odin_bitsf(F.fu[t][ia][0] ^ F.fv[ib][1]);
       if ((m & 3) == 1) {
         const int k = item0 + (m >> 2);
-        if (k <= WP_MAXU) store_fill_item(iuA, ivA, k);
+        if (k <= WP_MAXU && !(DBG & 4) && !(DBG & 16)) store_fill_item(stu, stv, k);
+        if (k <= WP_MAXU && (DBG & 16)) {  // keep the loads alive without the split / LDS stores
+          const float4 t = k < WP_MAXU ? stu[k].v : stv.v;
+          bsum4.x += t.x; bsum4.y += t.y; bsum4.z += t.z; bsum4.w += t.w;
+        }
       }
       ODIN_SCHED_FENCE();
     }
   };
 
-#pragma unroll 1
-  for (int T = T0; T < T1; ++T) {
-    Frags F0, F1;
-    read_chunk(0, F0);   // first thing behind the barrier
+  // one tile: `ld` receives the loads of tile T + 3's rows, the rows of tile T + 1 (loaded two tiles ago into
+  // `st`) are split and stored behind the MFMAs.  The two register sets swap roles every tile (no
+  // register copies: a copy of a freshly loaded register would wait for the load, vmcnt(0), every tile).
+  Frags F0, F1;
+  auto run_tile = [&](int T, WpItem (&ldu)[WP_MAXU], WpItem& ldv, const WpItem (&stu)[WP_MAXU], const WpItem& stv) {
+    if (!(DBG & 2) || T == T0) read_chunk(0, F0);   // first thing behind the barrier
     ODIN_SCHED_FENCE();
-    load_fill(iuB, ivB, T + 2 < T1);
-    read_chunk(1, F1);
+    load_fill(ldu, ldv, T + 3 < T1 && !(DBG & 4) && !(DBG & 8));
+    if (!(DBG & 2) || T == T0) read_chunk(1, F1);
     ODIN_SCHED_FENCE();
-    mfma_chunk(F0, 0);   // items 0, 1, 2
-    mfma_chunk(F1, 3);   // items 3, 4
-#pragma unroll
-    for (int j = 0; j < WP_MAXU; ++j) iuA[j] = iuB[j];
-    ivA = ivB;
+    mfma_chunk(F0, 0, stu, stv);   // items 0, 1, 2
+    mfma_chunk(F1, 3, stu, stv);   // items 3, 4
     su0 += 2 * TC;
     sv0 += TC;
     if (++t_cur == p.tiles_per_img) { t_cur = 0; ++b_cur; ++su0; }
     if (su0 >= NSU) su0 -= NSU;
     if (sv0 >= NSV) sv0 -= NSV;
     __syncthreads();  // every wave is past tile T's rows; tile T + 1's rows are stored
+  };
+  // (loads run TWO tiles ahead of their stores: one tile, ~2 us, did not cover the HBM latency under
+  // load -- 16 of 64 us went to waiting for them)
+#pragma unroll 1
+  for (int T = T0; T < T1; T += 3) {
+    run_tile(T, iuC, ivC, iuA, ivA);
+    if (T + 1 < T1) run_tile(T + 1, iuA, ivA, iuB, ivB);
+    if (T + 2 < T1) run_tile(T + 2, iuB, ivB, iuC, ivC);
   }
 
   // ---- this workgroup's slab row: dW[tap][cu0 + cu][cv0 + cv], lane = column cv = l31 ----
@@ -339,12 +367,27 @@ int wp_launch(const WPParams& p, dim3 grid, void* stream) {
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<W>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
-      (void)hipGetLastError();
+    const void* fns[6] = {reinterpret_cast<const void*>(&wgrad_planes_kernel<W>),
+                          reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 1 : 0)>),
+                          reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 2 : 0)>),
+                          reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 4 : 0)>),
+                          reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 8 : 0)>),
+                          reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 16 : 0)>)};
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+        (void)hipGetLastError();
     attr_done = true;
   }
 #endif
+  if (W == 32) {
+    const char* e = getenv("ODIN_WP_DBG");
+    const int dbg = e ? atoi(e) : 0;
+    if (dbg == 1) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 1 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
+    if (dbg == 2) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 2 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
+    if (dbg == 4) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 4 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
+    if (dbg == 8) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 8 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
+    if (dbg == 16) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 16 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
+  }
   ODIN_LAUNCH((wgrad_planes_kernel<W>), grid, dim3(512), lds, stream, p);
   return odin_check_launch("wgrad_planes(bf16x3)");
 }
