@@ -20,8 +20,8 @@ fetch, write = read('gpurun_out/r02_pmc_FETCH_SIZE.txt'), read('gpurun_out/r02_p
 f4 = 4
 kernels = {
     # bench op name: (kernel, grid/lds key, description, algorithmic bytes)
-    'dec4:deconv:wgrad': ('wgrad_ws_kernel<4, 9, 3, 2, 64>', '131072/lds0',
-                          'weight gradient of the last Conv2DTranspose (fp32 MFMA), dSprites B=256',
+    'dec4:deconv:wgrad': ('wgrad_planes_kernel<32, 0>', '131072/lds1024',
+                          'weight gradient of the last Conv2DTranspose (wgrad_planes, both operands as 3 bf16 planes), dSprites B=256',
                           # x [B,32,32,32] + dY [B,64,64,32] read once, slabs [256 rows][16*32*32] written
                           (B * 32 * 32 * 32 + B * 64 * 64 * 32) * f4 + 256 * 16 * 32 * 32 * f4),
     'dec4:deconv:dgrad': ('fconv_ring_kernel<2, false>', '131072/lds512',

@@ -10,6 +10,8 @@ python tools_pmc_traffic.py > /dev/null 2> gpurun_out/r02_final_pmc_traffic.err
 python bench.py --no-cpu-baseline > gpurun_out/r02_final_bench2.json 2>/dev/null   # picks up the fresh traffic file
 timeout 200 python tools_stamps_t.py > gpurun_out/r02_final_stamps_tconv_planes.txt 2>&1
 timeout 200 python tools_stamps_dg.py > gpurun_out/r02_final_stamps_fconv_ring.txt 2>&1
+timeout 200 python tools_wp_dbg.py > gpurun_out/r02_final_wgrad_planes_dbg.txt 2>&1
+ODIN_TP_DBG=x DBGS="0 1 2 4 7" ./tools_tp_dbg.sh > gpurun_out/r02_final_tconv_planes_dbg.txt 2>&1
 ./tools_micro/run_all.sh
 for w in shapes3d_vae_b256 celeba_betatcvae_b512 mnist_dense_b128 factorvae_shapes3d_b256 speech_vae_b256; do
   timeout 600 python bench.py --workload $w --no-cpu-baseline > gpurun_out/r02_final_$w.json 2>/dev/null
