@@ -175,25 +175,28 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     need_g0 = f_g;
     ft_t = t0;
   }
-  // loads the rows tile `need` still misses into registers; advances the walk
+  // loads the rows tile `need` still misses into registers; advances the walk.  The row part of an
+  // item is wave-uniform (scalar, 32-bit: the applicability test bounds the tensor to 2 GB), the lane part
+  // is computed once.
+  const int f_c = wave & (CPR - 1), f_r0 = wave >> CSHIFT;
+  constexpr int F_RJ = 8 >> CSHIFT;  // rows between a wave's two items
+  const int f_px = 8 * f_c + (lane >> 3), f_ch4 = lane & 7, f_pc = f_px + 1;
+  const int f_lds_lane = f_pc * 64 + ((((f_ch4 >> 1) ^ ((f_pc >> 2) & 3))) << 4) + (f_ch4 & 1) * 8;
+  const unsigned f_g_lane = (unsigned)((f_px * p.CS + p.ci_off + 4 * f_ch4) * 4);
+  const unsigned f_rowbytes = (unsigned)(W * p.CS * 4);
   auto load_fill = [&](TpItem (&it)[2], bool live) {
     const int nrows = live ? need_g0 + RP + 2 - f_g : 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int idx = wave + 8 * j;
-      const int r = idx >> CSHIFT, c = idx & (CPR - 1);
+      const int r = f_r0 + F_RJ * j;
       const bool valid = r < nrows;
       int gi = f_gi + r, b = f_b;
       if (gi >= HP) { gi -= HP; ++b; }
       int slot = f_slot + r;
       if (slot >= NSLOT) slot -= NSLOT;
-      const int px = 8 * c + (lane >> 3), ch4 = lane & 7;
-      const int pc = px + 1;
-      it[j].dst = valid ? slot * RB + pc * 64 + ((((ch4 >> 1) ^ ((pc >> 2) & 3))) << 4) + (ch4 & 1) * 8
-                        : NSLOT * RB + lane * 8;  // spare slot
+      it[j].dst = valid ? slot * RB + f_lds_lane : NSLOT * RB + lane * 8;  // (no item: the spare slot)
       const bool real = valid && gi != 0 && b < p.B;  // gi == 0: the zero row between images
-      it[j].v = odin_run_load4(IN, real ? (unsigned)((((((size_t)b * p.H + gi - 1) * W + px) * p.CS + p.ci_off + 4 * ch4) * 4))
-                                        : ODIN_OOB);
+      it[j].v = odin_run_load4(IN, real ? (unsigned)(b * p.H + gi - 1) * f_rowbytes + f_g_lane : ODIN_OOB);
     }
     if (live) {
       f_g += nrows;
