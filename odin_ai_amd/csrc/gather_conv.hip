@@ -1578,6 +1578,11 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
   if (odin_smallc_applicable(d)) return odin_smallc_fwd(x, w, bias, y, d, stream);
   if (odin_pw1x1_applicable(d)) return odin_pw1x1_fwd(x, w, bias, y, d, stream);
   if (d->act == ODIN_ACT_ELU && bias != nullptr &&
+      odin_fconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
+                                   d->pad_t, d->pad_l, d->center))
+    return odin_fconv_planes_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->OH, d->OW, d->Cout, 1,
+                                    stream);
+  if (d->act == ODIN_ACT_ELU && bias != nullptr &&
       odin_fconv_ring_applicable(d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                                  d->pad_t, d->pad_l, d->center))
     return odin_fconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->Cin,
@@ -1649,6 +1654,11 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
                                    int aux_act, float* dx, float* colsum_slab,
                                    int* slab_rows_out, const odin_conv_desc* d, void* stream) {
   // data gradient of a Conv2DTranspose = strided gather over dY: input (OH, OW, Cout), output (H, W, Cin)
+  if (aux_act == ODIN_ACT_ELU && (aux != nullptr || dx == nullptr) &&
+      odin_fconv_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
+                                   d->pad_t, d->pad_l, 0))
+    return odin_fconv_planes_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, d->B, d->H, d->W,
+                                    d->Cin, 2, stream);
   if (aux_act == ODIN_ACT_ELU && (aux != nullptr || dx == nullptr) &&
       odin_fconv_ring_applicable(d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
                                  d->pad_t, d->pad_l, 0))

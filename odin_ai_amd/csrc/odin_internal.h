@@ -78,3 +78,10 @@ bool odin_wgrad_planes_applicable(int B, int H, int W, int CI, int OH, int OW, i
                                   int S, int pt, int pl, int center);
 int odin_wgrad_planes_launch(const float* U, const float* V, float* slab, int* rows_out, int B, int OH,
                              int OW, int CI, int CO, int want_bias, void* stream);
+
+// the same strided gathers through the bf16 matrix pipe, reduction split over the waves (fconv_planes.hip)
+bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
+                                  int pt, int pl, int center);
+int odin_fconv_planes_launch(const float* in, const float* w, const float* bias, const float* aux,
+                             float* out, float* colsum, int* rows_out, int B, int OH, int OW, int CO,
+                             int epi, void* stream);
