@@ -19,27 +19,41 @@ def read(fn):
 fetch, write = read('gpurun_out/r02_pmc_FETCH_SIZE.txt'), read('gpurun_out/r02_pmc_WRITE_SIZE.txt')
 f4 = 4
 kernels = {
-    # bench op name: (kernel, grid/lds key, description, algorithmic bytes)
-    'dec4:deconv:wgrad': ('wgrad_planes_kernel<32, 0>', '131072/lds1024',
+    # bench op name: (kernel-name prefix, grid, description, algorithmic bytes)
+    'dec4:deconv:wgrad': ('wgrad_planes_kernel<32', '131072',
                           'weight gradient of the last Conv2DTranspose (wgrad_planes, both operands as 3 bf16 planes), dSprites B=256',
                           # x [B,32,32,32] + dY [B,64,64,32] read once, slabs [256 rows][16*32*32] written
                           (B * 32 * 32 * 32 + B * 64 * 64 * 32) * f4 + 256 * 16 * 32 * 32 * f4),
-    'dec4:deconv:dgrad': ('fconv_ring_kernel<2, false>', '131072/lds512',
-                          'data gradient of the last Conv2DTranspose (fconv_ring, fp32 MFMA)',
+    'dec4:deconv:dgrad': ('fconv_planes_kernel<2, 32', '131072',
+                          'data gradient of the last Conv2DTranspose (fconv_planes, fp32 operands as 3 bf16 planes)',
                           # dY [B,64,64,32] + aux [B,32,32,32] read, dx [B,32,32,32] written
                           (B * 64 * 64 * 32 + 2 * B * 32 * 32 * 32) * f4),
-    'dec4+5:tail:fwd+elbo': ('tconv_planes_kernel<3, 1, 32, 0, false>', '131072/lds2560',
+    'dec4+5:tail:fwd+elbo': ('tconv_planes_kernel<3, 1, 32, 0', '131072',
                              'fused decoder tail (tconv_planes, fp32 operands as 3 bf16 planes)',
                              # x [B,32,32,32] + target [B,64,64,1] read; logits + d(pre-activation) [B,64,64,32] written
                              (B * 32 * 32 * 32 + 2 * B * 64 * 64 + B * 64 * 64 * 32) * f4),
+    'dec2:deconv:dgrad': ('fconv_ring_kernel<2, true', '131072',
+                          'data gradient of decoder2, second of the two 32-channel passes (fconv_ring, fp32 MFMA)',
+                          # dY [B,16,16,64]: 32 of 64 channels read + partial sums read + aux read + dx written, [B,8,8,64] each
+                          (B * 16 * 16 * 32 + 3 * B * 8 * 8 * 64) * f4),
 }
+
+
+def find(tab, prefix, grid):
+  for (k, key), v in tab.items():
+    if k.startswith(prefix) and key.split('/')[0] == grid:
+      return k, v
+  return None, None
+
+
 res = {}
 for op, (k, key, desc, alg) in kernels.items():
-  fk = fetch.get((k, key))
-  wk = write.get((k, key))
+  kn, fk = find(fetch, k, key)
+  _, wk = find(write, k, key)
   if fk is None or wk is None:
     print('missing', op, k, key, file=sys.stderr)
     continue
+  k = kn
   res[op] = dict(kernel=f'{k} ({desc})', FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk,
                  traffic_bytes=int((2 * fk + wk) * 1024), algorithmic_bytes=int(alg),
                  source='profiles/r02_pmc_FETCH_SIZE.txt + r02_pmc_WRITE_SIZE.txt (separate --pmc passes of '
