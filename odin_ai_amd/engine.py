@@ -415,10 +415,14 @@ class VAEEngine:
     import os as _os
     # weight gradients on a side stream.  'all': measured neutral-to-negative on MI355X (the
     # big kernels are LDS-limited to one workgroup per CU and contend); 'small': only the
-    # launches that leave most CUs idle (bottleneck layers) run beside the data-gradient chain
-    self.early_reduce = _os.environ.get('ODIN_EARLY_REDUCE', '1') == '1'
+    # launches that leave most CUs idle (bottleneck layers) run beside the data-gradient chain.
+    # Both overlaps are OFF by default since round 2: they paid at 1.1 ms per step (+2-3 %), but each
+    # cross-stream dependency of the captured graph costs 5-18 us of idle time on the main chain
+    # (profiles/r02_step_timeline.txt) and with the round-2 kernels the same A/B reads
+    # 0.819 ms (both on) / 0.808 (no side-stream wgrads) / 0.815 (no early slab reduce) / 0.804 (both off)
+    self.early_reduce = _os.environ.get('ODIN_EARLY_REDUCE', '0') == '1'
     self.overlap_wgrad = {'0': None, '1': 'all', 'all': 'all', 'small': 'small'}.get(
-        _os.environ.get('ODIN_OVERLAP_WGRAD', 'small'), None)
+        _os.environ.get('ODIN_OVERLAP_WGRAD', '0'), None)
     self.graph = None
     self._jobs_keepalive = None
 
