@@ -277,9 +277,13 @@ __global__ __launch_bounds__(256) void smallc_fwd_mfma_kernel(SCParams p) {
 // pixel: per pixel pair a lane loads ONE x tap per row block (a gather: tap l31 of pixel p + h) and
 // ONE dy value per column block (coalesced).  U pixel pairs are requested before their MFMAs.
 // 262144 pixels of the dSprites first layer = 128 MFMAs per SIMD.
-template <int RB, int CB>
-__global__ __launch_bounds__(256) void smallc_wgrad_mfma_kernel(SCParams p) {
-  ODIN_DYN_SMEM(float, red);  // [4 waves][RB*CB][16][64]
+// NW waves per workgroup: the kernel is a stream over DY (33.5 MB for the dSprites first layer) with
+// 4-byte loads, 8 of them in flight per wave -- latency-bound at one wave per SIMD (4 waves: 22 us =
+// 1.7 TB/s); the slab-row cap fixes the number of workgroups, so the occupancy comes from 16-wave
+// workgroups whose partial tiles meet in LDS.
+template <int RB, int CB, int NW>
+__global__ __launch_bounds__(NW * 64) void smallc_wgrad_mfma_kernel(SCParams p) {
+  ODIN_DYN_SMEM(float, red);  // [NW waves][RB*CB][16][64]
   const int tid = threadIdx.x, lane = tid & 63;
 #ifdef ODIN_SIM
   const int wave = tid >> 6;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(256) void smallc_wgrad_mfma_kernel(SCParams p) {
   int r1 = r0 + p.pix_per_block / p.OW;
   if (r1 > p.B * p.OH) r1 = p.B * p.OH;
   constexpr int U = 4;
-  for (int r = r0 + wave; r < r1; r += 4) {  // wave-uniform
+  for (int r = r0 + wave; r < r1; r += NW) {  // wave-uniform
     const int bb = r / p.OH, oh = r - bb * p.OH;
     const int ih0 = oh * p.S - p.pt;
     unsigned rowoff[RB];
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256) void smallc_wgrad_mfma_kernel(SCParams p) {
           for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = mfma32(a[u][rb], b[u][cb], acc[rb][cb]);
     }
   }
-  // combine the 4 waves in a fixed order, then write the slab row [K*CO | CO]
+  // combine the NW waves in a fixed order, then write the slab row [K*CO | CO]
   float* mine = red + wave * (RB * CB * 16 * 64);
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
@@ -367,8 +371,12 @@ __global__ __launch_bounds__(256) void smallc_wgrad_mfma_kernel(SCParams p) {
       for (int r = 0; r < 16; ++r) mine[((rb * CB + cb) * 16 + r) * 64 + lane] = acc[rb][cb][r];
   __syncthreads();
   float* row = p.y + (size_t)blockIdx.x * p.slab_stride;
-  for (int e = tid; e < RB * CB * 16 * 64; e += 256) {
-    const float t = (red[e] + red[e + RB * CB * 1024]) + (red[e + 2 * RB * CB * 1024] + red[e + 3 * RB * CB * 1024]);
+  for (int e = tid; e < RB * CB * 16 * 64; e += NW * 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NW; wv += 4)
+      t += (red[e + wv * RB * CB * 1024] + red[e + (wv + 1) * RB * CB * 1024]) +
+           (red[e + (wv + 2) * RB * CB * 1024] + red[e + (wv + 3) * RB * CB * 1024]);
     const int ln = e & 63, r = (e >> 6) & 15, blk = e >> 10;
     const int rb = blk / CB, cb = blk - rb * CB;
     const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
@@ -446,19 +454,25 @@ int odin_smallc_wgrad(const float* x, const float* dy, float* slab, int* rows_ou
   if (use_mfma) {
     // matrix-core kernel: RB row blocks of 32 (taps + the bias row), CB column blocks of 32
     const int RB = (K + 1 + 31) / 32, CB = (d->Cout + 31) / 32;
-    const size_t l2 = (size_t)4 * RB * CB * 1024 * 4;
+    const int NW = (RB * CB == 4) ? 8 : 16;   // NW x RB x CB x 4 KB of LDS for the partial tiles
+    const size_t l2 = (size_t)NW * RB * CB * 1024 * 4;
 #ifndef ODIN_SIM
     static bool attr2 = false;
     if (!attr2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallc_wgrad_mfma_kernel<2, 2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      const void* fns[4] = {reinterpret_cast<const void*>(&smallc_wgrad_mfma_kernel<1, 1, 16>),
+                            reinterpret_cast<const void*>(&smallc_wgrad_mfma_kernel<1, 2, 16>),
+                            reinterpret_cast<const void*>(&smallc_wgrad_mfma_kernel<2, 1, 16>),
+                            reinterpret_cast<const void*>(&smallc_wgrad_mfma_kernel<2, 2, 8>)};
+      for (const void* f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+          (void)hipGetLastError();
       attr2 = true;
     }
 #endif
-    if (RB == 1 && CB == 1) ODIN_LAUNCH((smallc_wgrad_mfma_kernel<1, 1>), dim3(rows), dim3(256), l2, stream, p);
-    else if (RB == 1 && CB == 2) ODIN_LAUNCH((smallc_wgrad_mfma_kernel<1, 2>), dim3(rows), dim3(256), l2, stream, p);
-    else if (RB == 2 && CB == 1) ODIN_LAUNCH((smallc_wgrad_mfma_kernel<2, 1>), dim3(rows), dim3(256), l2, stream, p);
-    else ODIN_LAUNCH((smallc_wgrad_mfma_kernel<2, 2>), dim3(rows), dim3(256), l2, stream, p);
+    if (RB == 1 && CB == 1) ODIN_LAUNCH((smallc_wgrad_mfma_kernel<1, 1, 16>), dim3(rows), dim3(1024), l2, stream, p);
+    else if (RB == 1 && CB == 2) ODIN_LAUNCH((smallc_wgrad_mfma_kernel<1, 2, 16>), dim3(rows), dim3(1024), l2, stream, p);
+    else if (RB == 2 && CB == 1) ODIN_LAUNCH((smallc_wgrad_mfma_kernel<2, 1, 16>), dim3(rows), dim3(1024), l2, stream, p);
+    else ODIN_LAUNCH((smallc_wgrad_mfma_kernel<2, 2, 8>), dim3(rows), dim3(512), l2, stream, p);
     return odin_check_launch("smallc_wgrad_mfma");
   }
   size_t lds = (size_t)16 * (K + 1) * d->Cout * 4;
