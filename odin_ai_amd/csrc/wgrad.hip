@@ -1277,7 +1277,9 @@ extern "C" int odin_deconv2d_wgrad(const float* x, const float* dy, float* slab,
 
 extern "C" int odin_dense_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out,
                                 int B, int K, int N, void* stream) {
-  if (!odin_tiny_dense_ok(B, K, N) && odin_dense_gemm_ok(B, K, N)) {
+  // (also the tiny layers: their forward / data gradient run on the vector ALUs, but the weight gradient
+  // through the generic kernel was a 14.5 us launch for 0.001 GFLOP)
+  if (odin_dense_gemm_ok(B, K, N) && !getenv("ODIN_NOTINYWGRADGEMM")) {
     // small GEMM: the waves of a workgroup split the batch, the result is complete: ONE slab row
     if (slab_rows_out) *slab_rows_out = 1;
     if (slab == nullptr) return 0;  // dry run
