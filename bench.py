@@ -582,6 +582,9 @@ def main():
              vs_baseline=None, dtype='f32', data='synthetic',
              config=dict(workload=args.workload, global_batch=B * world, per_gpu_batch=B,
                          beta=beta, parallelism=f'dp{world}', graph=bool(use_graph),
+                         arithmetic='fp32 results; the 4x4/s2 32-channel layers carry their fp32 operands through '
+                                    'the bf16 matrix pipe as 3 exact bf16 planes (6 MFMAs per 16 k-values, fp32 '
+                                    'accumulation, <= 3*2^-24 per product), fp32 MFMA / VALU elsewhere',
                          final_loss=round(loss, 4)),
              roofline=roofline, roofline_split=roofline_split, roofline_fp32=roofline_fp32, cpu_baseline=cpu,
              conv_stack=stack,
