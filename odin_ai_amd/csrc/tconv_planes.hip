@@ -134,27 +134,6 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   if (T1 > p.n_tiles) T1 = p.n_tiles;
   if (T0 >= T1) return;
 
-  // ---- weights: fp32 [tap][co][32] -> planes [tap][plane][k-piece][co][8 bf16] ----
-  {
-    float4 wv[8];  // all 8 loads of a thread in flight before the first split
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int e = tid + 512 * j;
-      const int ci4 = e & 7, co = (e >> 3) & 31, tap = e >> 8;
-      wv[j] = *reinterpret_cast<const float4*>(p.w + ((size_t)(tap * p.CO + n0 + co) * p.CS + p.ci_off + 4 * ci4));
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int e = tid + 512 * j;
-      const int ci4 = e & 7, co = (e >> 3) & 31, tap = e >> 8;
-      u32x2 h, m, l;
-      tp_split4(wv[j], h, m, l);
-      char* d = wl + tap * 6144 + (ci4 >> 1) * 512 + co * 16 + (ci4 & 1) * 8;
-      *reinterpret_cast<u32x2*>(d) = h;
-      *reinterpret_cast<u32x2*>(d + 2048) = m;
-      *reinterpret_cast<u32x2*>(d + 4096) = l;
-    }
-  }
   // ---- SAME-padding pixels (pc = 0 and pc = W + 1) of every ring row and plane: zero for ever ----
   for (int e = tid; e < NSLOT * 24; e += 512) {
     const int sl = e / 24, rem = e - sl * 24;
@@ -284,7 +263,28 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
 
   // ---- prologue: rows of the first tile, then the second tile's into registers ----
   TpItem itA[2], itB[2];
-  load_fill(itA, true);
+  load_fill(itA, true);  // (in flight while the weights are split)
+  // ---- weights: fp32 [tap][co][32] -> planes [tap][plane][k-piece][co][8 bf16] ----
+  {
+    float4 wv[8];  // all 8 loads of a thread in flight before the first split
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + 512 * j;
+      const int ci4 = e & 7, co = (e >> 3) & 31, tap = e >> 8;
+      wv[j] = *reinterpret_cast<const float4*>(p.w + ((size_t)(tap * p.CO + n0 + co) * p.CS + p.ci_off + 4 * ci4));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + 512 * j;
+      const int ci4 = e & 7, co = (e >> 3) & 31, tap = e >> 8;
+      u32x2 h, m, l;
+      tp_split4(wv[j], h, m, l);
+      char* d = wl + tap * 6144 + (ci4 >> 1) * 512 + co * 16 + (ci4 & 1) * 8;
+      *reinterpret_cast<u32x2*>(d) = h;
+      *reinterpret_cast<u32x2*>(d + 2048) = m;
+      *reinterpret_cast<u32x2*>(d + 4096) = l;
+    }
+  }
   store_fill(itA);
   load_fill(itA, T0 + 1 < T1);
   TP_STAMP(2);
