@@ -87,24 +87,6 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 
   // ---- this wave's weight fragments: taps (kh, kw0), (kh, kw0 + 1); lane = output channel l31, k = 8 half + e ----
   const int kh = wave >> 1, kw0 = 2 * (wave & 1);
-  u32x4 wf[2][2][3];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int tap = kh * 4 + kw0 + t;
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        v[e] = p.w[((size_t)(tap * 32 + 16 * kk + 8 * half + e)) * p.CO + n0 + l31];
-      u32x2 h0, m0, l0, h1, m1, l1;
-      fp_split4(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
-      fp_split4(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
-      wf[t][kk][0][0] = h0.x; wf[t][kk][0][1] = h0.y; wf[t][kk][0][2] = h1.x; wf[t][kk][0][3] = h1.y;
-      wf[t][kk][1][0] = m0.x; wf[t][kk][1][1] = m0.y; wf[t][kk][1][2] = m1.x; wf[t][kk][1][3] = m1.y;
-      wf[t][kk][2][0] = l0.x; wf[t][kk][2][1] = l0.y; wf[t][kk][2][2] = l1.x; wf[t][kk][2][3] = l1.y;
-    }
-
   // ---- row fills (as wgrad_planes.hip; the k-pieces of a pixel slot are swizzled by the slot) ----
   const OdinRun RU = odin_run(p.in, (unsigned)((size_t)p.B * HU * WU * 32 * 4));
   int fu_g, fu_gi, fu_b, fu_slot, need_gu0, ft_t;
@@ -180,7 +162,25 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   float csum[2] = {0.f, 0.f};
 
   FpItem iuA[FP_MAXU], iuB[FP_MAXU], iuC[FP_MAXU];
-  load_fill(iuA, true);
+  load_fill(iuA, true);  // (in flight while the weight fragments are fetched and split)
+  u32x4 wf[2][2][3];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int tap = kh * 4 + kw0 + t;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] = p.w[((size_t)(tap * 32 + 16 * kk + 8 * half + e)) * p.CO + n0 + l31];
+      u32x2 h0, m0, l0, h1, m1, l1;
+      fp_split4(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
+      fp_split4(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+      wf[t][kk][0][0] = h0.x; wf[t][kk][0][1] = h0.y; wf[t][kk][0][2] = h1.x; wf[t][kk][0][3] = h1.y;
+      wf[t][kk][1][0] = m0.x; wf[t][kk][1][1] = m0.y; wf[t][kk][1][2] = m1.x; wf[t][kk][1][3] = m1.y;
+      wf[t][kk][2][0] = l0.x; wf[t][kk][2][1] = l0.y; wf[t][kk][2][2] = l1.x; wf[t][kk][2][3] = l1.y;
+    }
+
 #pragma unroll
   for (int j = 0; j < FP_MAXU; ++j) store_item(iuA[j]);
   load_fill(iuA, T0 + 1 < T1);
