@@ -11,7 +11,7 @@
 // i.e.  out[b, oh, ow, n] = sum over (kh, kw) with (oh + 1 - kh), (ow + 1 - kw) even, c < 32 of
 //       in[b, (oh + 1 - kh) / 2, (ow + 1 - kw) / 2, c] * W[kh, kw, n, c]
 //
-// Why planes, and why split ONCE: measured on gfx950 (tools_micro/mfma_fillers.hip,
+// Why planes, and why split ONCE: measured on gfx950 (tools/micro/mfma_fillers.hip,
 // mfma_bf16_fillers.hip) v_mfma_f32_*_f32 shares the vector ALU's issue -- every VALU instruction of
 // an epilogue adds its full time to an fp32 MFMA stream, from the same wave or from a partner wave --
 // while bf16 MFMAs run beside the VALU (5 VALU instructions per 32-cycle MFMA are free) at 16x the
@@ -31,6 +31,7 @@
 #include "odin_device.h"
 #include "odin_internal.h"
 #include <cstdlib>
+#include <utility>
 
 namespace {
 
@@ -65,6 +66,26 @@ struct TPParams {
       p.stamps[8 * wave + stamp_i++] = ((long long)(k) << 56) | (long long)(clock64() & 0xFFFFFFFFFFFFFFll); \
   } while (0)
 #endif
+
+// index of MFMA slot m among the slots >= g0 that run_tile does not reserve for its own row fills,
+// operand loads and log-likelihood flush (32-34, 36, 42); -1 for a reserved or earlier slot
+__host__ __device__ constexpr int tp_late_index(int g0, int m) {  // (g0 <= 32; loop-free so that it folds early)
+  return (m < g0 || m == 32 || m == 33 || m == 34 || m == 36 || m == 42)
+             ? -1
+             : (m - g0) - ((m > 32) + (m > 33) + (m > 34) + (m > 36) + (m > 42));
+}
+static_assert(tp_late_index(25, 47) >= 11, "three logit maps: 8 gradient + 4 store slots must fit");
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): the slot index of the tile's MFMA
+// stream is a compile-time constant inside f (no dead branches for the optimiser to clear away)
+template <int... Is, class F>
+__device__ __forceinline__ void tp_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void tp_static_for(F&& f) {
+  tp_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
 
 struct TpYes { static constexpr bool value = true; };
 struct TpNo { static constexpr bool value = false; };
@@ -227,18 +248,27 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
 
   // ---- epilogue constants: accumulator register r holds channel n0 + (r & 3) + 8 (r >> 2) + 4 half.
   // Plain (unpacked) VALU arithmetic only: v_pk_*_f32 serialises with the bf16 matrix pipe, plain VALU
-  // instructions run beside it, ~5.5 per 32-cycle MFMA per SIMD (tools_micro/mfma_bf16_mix.hip).
+  // instructions run beside it, ~5.5 per 32-cycle MFMA per SIMD (tools/micro/mfma_bf16_mix.hip).
   auto ch_of = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * half; };
   constexpr float LOG2E = 1.44269504088896341f;
-  float bias_r[(EPI == 1 || EPI == 3) ? 16 : 1], bl_r[(EPI == 1 || EPI == 3) ? 16 : 1];
-  if (EPI == 1 || EPI == 3) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      bias_r[r] = p.bias[n0 + ch_of(r)];
-      bl_r[r] = bias_r[r] * LOG2E;
+  // EPI 3 with several logit maps: the per-channel constants (bias | w1[oc][ch]) live in LDS and are
+  // fetched four channels at a time right before their use (48 + 16 registers would not fit beside the
+  // 16 C1 dW1 accumulators under 256 registers)
+  constexpr bool CL = (EPI == 3 && C1 > 1);
+  __shared__ float cst[CL ? 32 * (1 + C1) : 4];
+  if (CL) {
+    for (int e = tid; e < 32 * (1 + C1); e += 512) {
+      const int ch = e & 31, oc = (e >> 5) - 1;
+      cst[e] = e < 32 ? p.bias[n0 + ch] : p.w1[(n0 + ch) * C1 + oc];
     }
   }
-  float w1r[(EPI == 3) ? 16 : 1][(EPI == 3) ? C1 : 1];
+  const float* cl = cst + 4 * half;  // this lane's channels of group q: cl[8 q .. 8 q + 3]
+  float bias_r[((EPI == 1 || EPI == 3) && !CL) ? 16 : 1];
+  if ((EPI == 1 || EPI == 3) && !CL) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = p.bias[n0 + ch_of(r)];
+  }
+  float w1r[(EPI == 3 && !CL) ? 16 : 1][(EPI == 3 && !CL) ? C1 : 1];
   float dw1[(EPI == 3) ? 16 : 1][(EPI == 3) ? C1 : 1];
   float b1r[(EPI == 3) ? C1 : 1];
   float db1[(EPI == 3) ? C1 : 1];
@@ -247,7 +277,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     for (int r = 0; r < 16; ++r)
 #pragma unroll
       for (int oc = 0; oc < C1; ++oc) {
-        w1r[r][oc] = p.w1[(n0 + ch_of(r)) * C1 + oc];
+        if (!CL) w1r[r][oc] = p.w1[(n0 + ch_of(r)) * C1 + oc];
         dw1[r][oc] = 0.f;
       }
 #pragma unroll
@@ -307,12 +337,13 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   // compiler's own interleaving bunched the MFMAs and left the VALU work exposed; sched_group_barrier
   // pipelines of this size are not honoured, so the order is fixed in the source, fence by fence).
   // It works in place on `pa`, two accumulator registers per op.
-  auto elu_r = [&](int r) {
-    const float t = pa[r] + bias_r[(EPI == 1 || EPI == 3) ? r : 0];
-    const float em1 = odin_exp2(fmaf(pa[r], LOG2E, bl_r[(EPI == 1 || EPI == 3) ? r : 0])) - 1.f;
+  auto elu_b = [&](int r, float b) __attribute__((always_inline)) {
+    const float t = pa[r] + b;
+    const float em1 = odin_exp2(t * LOG2E) - 1.f;
     pa[r] = t > 0.f ? t : em1;
   };
-  auto store_q = [&](int q) {
+  auto elu_r = [&](int r) { elu_b(r, bias_r[((EPI == 1 || EPI == 3) && !CL) ? r : 0]); };
+  auto store_q = [&](int q) __attribute__((always_inline)) {
     if (DBG & 1) return;
     *reinterpret_cast<float4*>(p.out + opixP * p.CO + n0 + 8 * q + 4 * half) =
         make_float4(pa[4 * q], pa[4 * q + 1], pa[4 * q + 2], pa[4 * q + 3]);
@@ -385,7 +416,100 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
       if (k >= G0 + 8 && k < G0 + 12) store_q(k - G0 - 8);
     }
   };
-  static_assert(N_EPI_OPS + 8 <= 32, "epilogue micro-ops must fit before the row stores (steps 6, 7)");
+  static_assert(CL || N_EPI_OPS + 8 <= 32, "epilogue micro-ops must fit before the row stores (steps 6, 7)");
+
+  // ---- several logit maps (CL): the same epilogue with its constants fetched from LDS, laid out
+  // slot by slot over the 48 MFMAs of the next tile.  A constant vector is read at least two MFMAs
+  // before its use; wqA / wqB alternate between the channel groups q (4 channels of this lane each).
+  float4 cbq = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 wqA[CL ? C1 : 1], wqB[CL ? C1 : 1];
+  float t3[CL ? C1 : 1] = {}, lg3[CL ? C1 : 1] = {}, ea3[CL ? C1 : 1] = {};
+  auto f4c = [](const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
+  auto ld_bias = [&](int q) { cbq = *reinterpret_cast<const float4*>(cl + 8 * q); };
+  auto ld_w = [&](float4 (&wq)[CL ? C1 : 1], int q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int oc = 0; oc < (CL ? C1 : 1); ++oc)
+      wq[oc] = *reinterpret_cast<const float4*>(cl + 32 + 32 * oc + 8 * q);
+  };
+  auto cl_elu2 = [&](int k) __attribute__((always_inline)) {  // accumulator registers 2 k, 2 k + 1
+    elu_b(2 * k, (k & 1) ? cbq.z : cbq.x);
+    elu_b(2 * k + 1, (k & 1) ? cbq.w : cbq.y);
+  };
+  auto cl_dot = [&](int q, const float4 (&wq)[CL ? C1 : 1]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int oc = 0; oc < (CL ? C1 : 1); ++oc) {
+      float t = (q == 0) ? pa[0] * wq[oc].x : fmaf(pa[4 * q], wq[oc].x, t3[oc]);
+      t = fmaf(pa[4 * q + 1], wq[oc].y, t);
+      t = fmaf(pa[4 * q + 2], wq[oc].z, t);
+      t3[oc] = fmaf(pa[4 * q + 3], wq[oc].w, t);
+    }
+  };
+  auto cl_lg = [&](int ph, int oc) __attribute__((always_inline)) {
+    if (ph == 0) {
+      lg3[oc] = tp_pairsum32(t3[oc]) + b1r[oc];  // the other 16 channels live in lane ^ 32
+      ea3[oc] = odin_exp2(-LOG2E * fabsf(lg3[oc]));
+      odin_run_store1(LG, half == 0 ? (unsigned)((opixP * C1 + oc) * 4) : ODIN_OOB, lg3[oc]);
+    }
+    if (ph == 1) {
+      const float sp = fmaxf(lg3[oc], 0.f) + 0.6931471805599453f * odin_log2(1.f + ea3[oc]);
+      llk_lane += half == 0 ? tgtP[oc] * lg3[oc] - sp : 0.f;
+    }
+    if (ph == 2) {
+      const float rr = odin_rcp(1.f + ea3[oc]);
+      const float sg = lg3[oc] >= 0.f ? rr : ea3[oc] * rr;
+      const float dsig = (sg - tgtP[oc]) * sc;
+      db1[oc] += half == 0 ? dsig : 0.f;
+      dl[oc] = dsig;
+    }
+  };
+  auto cl_grad2 = [&](int i, const float4 (&wq)[CL ? C1 : 1]) __attribute__((always_inline)) {  // accumulator registers 2 i, 2 i + 1
+#pragma unroll
+    for (int r = 2 * i; r < 2 * i + 2; ++r) {
+      float gs = f4c(wq[0], r & 3) * dl[0];
+      dw1[r][0] = fmaf(pa[r], dl[0], dw1[r][0]);
+#pragma unroll
+      for (int oc = 1; oc < (CL ? C1 : 1); ++oc) {
+        gs = fmaf(f4c(wq[oc], r & 3), dl[oc], gs);
+        dw1[r][oc] = fmaf(pa[r], dl[oc], dw1[r][oc]);
+      }
+      pa[r] = fmaf(gs, fminf(pa[r], 0.f), gs);  // x ELU'(y) = 1 + min(y, 0)
+      csum[r] += pa[r];
+    }
+  };
+  auto cl_top = [&]() __attribute__((always_inline)) {
+    ld_bias(0);
+    ld_w(wqA, 0);
+  };
+  // slots 32-34, 36 and 42 belong to the row fills / operand loads / llk flush of run_tile
+  auto cl_slot = [&](auto M) __attribute__((always_inline)) {
+    constexpr int m = decltype(M)::value;
+    if constexpr (m < 16) {
+      if constexpr ((m & 1) == 0) {
+        cl_elu2(m >> 1);
+        if constexpr ((m & 3) == 2 && m < 14) ld_bias((m >> 2) + 1);
+      } else if constexpr ((m & 3) == 3) {
+        constexpr int q = m >> 2;
+        if constexpr (q & 1) cl_dot(q, wqB); else cl_dot(q, wqA);
+        if constexpr (q == 0) ld_w(wqA, 2);
+        if constexpr (q == 1) ld_w(wqB, 3);
+        if constexpr (q == 3) ld_w(wqA, 0);
+      } else if constexpr (m == 1) {
+        ld_w(wqB, 1);
+      }
+    } else if constexpr (m < 16 + 3 * C1) {
+      cl_lg((m - 16) / C1, (m - 16) % C1);
+      if constexpr (m == 16 + 3 * C1 - 1) ld_w(wqB, 1);
+    } else {
+      // the free slots behind the logistic terms, in order: 8 gradient slots, then the 4 output stores
+      constexpr int n = tp_late_index(16 + 3 * C1, m);
+      if constexpr (n >= 0 && n < 8) {
+        if constexpr ((n >> 1) & 1) cl_grad2(n, wqB); else cl_grad2(n, wqA);
+        if constexpr (n == 1) ld_w(wqA, 2);
+        if constexpr (n == 3) ld_w(wqB, 3);
+      }
+      if constexpr (n >= 8 && n < 12) store_q(n - 8);
+    }
+  };
 
   // one log-likelihood partial per tile (a tile lies inside one sample): wave sums through LDS
   auto flush_llk = [&](int T) {
@@ -425,6 +549,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
       }
     };
     loads(0, fa[0], fb[0]);  // first thing after the barrier: everything else waits behind the MFMAs
+    if (WE && CL) cl_top();
     ODIN_SCHED_FENCE();
     const int oh = 2 * (RP * t_cur + rp) + rpar;
     const size_t opix = ((size_t)b_cur * OH + oh) * OW + 2 * i_in + cpw;
@@ -433,54 +558,53 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) axN[q] = pvN[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     ODIN_SCHED_FENCE();
+    tp_static_for<48>([&](auto M) __attribute__((always_inline)) {
+      constexpr int m = decltype(M)::value;
+      constexpr int s = m / 6, u = m % 6, cur = s & 1, nxt = cur ^ 1;
+      if constexpr (u == 0) {
+        // the six reads of step s + 1 go out before the MFMAs of step s (a read issued one MFMA before its
+        // use exposes the LDS latency)
+        if (s + 1 < 8 && !(DBG & 2)) loads(s + 1, fa[nxt], fb[nxt]);
+        if (s + 1 < 8 && (DBG & 2)) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int cur = s & 1, nxt = cur ^ 1;
-      // the six reads of step s + 1 go out before the MFMAs of step s (a read issued one MFMA before its
-      // use exposes the LDS latency)
-      if (s + 1 < 8 && !(DBG & 2)) loads(s + 1, fa[nxt], fb[nxt]);
-      if (s + 1 < 8 && (DBG & 2)) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) { fa[nxt][pl] = fa[cur][pl]; fb[nxt][pl] = fb[cur][pl]; }
-      }
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        // plane products, smallest first: 0*2, 2*0, 1*1, 0*1, 1*0, 0*0 (weights x pixels)
-        if (u == 0) acc = mfma32_bf16(fa[cur][0], fb[cur][2], acc);
-        if (u == 1) acc = mfma32_bf16(fa[cur][2], fb[cur][0], acc);
-        if (u == 2) acc = mfma32_bf16(fa[cur][1], fb[cur][1], acc);
-        if (u == 3) acc = mfma32_bf16(fa[cur][0], fb[cur][1], acc);
-        if (u == 4) acc = mfma32_bf16(fa[cur][1], fb[cur][0], acc);
-        if (u == 5) acc = mfma32_bf16(fa[cur][0], fb[cur][0], acc);
-        // MFMA m carries: the 8 activation ops (2 x ~6 VALU + 2 transcendentals each) behind every
-        // other MFMA of the first 16, the remaining ops one per MFMA, the row stores in steps 6 and 7
-        const int m = 6 * s + u;
-        const int k = m < 16 ? ((m & 1) ? -1 : m / 2) : m - 8;
-        if (WE && k >= 0 && k < N_EPI_OPS && !(DBG & 4)) epi_op(k);
-        if (m == 32) load_fill(itB, T + 2 < T1);  // global loads of tile T + 2's rows
-        if (m == 33) {                            // this tile's epilogue operands (used one tile later)
-          if (EPI == 2) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              axN[q] = *reinterpret_cast<const float4*>(p.aux + opix * p.CO + n0 + 8 * q + 4 * half);
-          }
-          if (EPI == 3) {
-#pragma unroll
-            for (int oc = 0; oc < C1; ++oc) tgtN[oc] = p.target[opix * C1 + oc];
-          }
-          if (ACC) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              pvN[q] = *reinterpret_cast<const float4*>(p.out + opix * p.CO + n0 + 8 * q + 4 * half);
-          }
+          for (int pl = 0; pl < 3; ++pl) { fa[nxt][pl] = fa[cur][pl]; fb[nxt][pl] = fb[cur][pl]; }
         }
-        if (WE && m == 34) flush_llk(T - 1);
-        if (m == 36) store_fill1(itA[0]);
-        if (m == 42) store_fill1(itA[1]);
-        ODIN_SCHED_FENCE();
-        if (DBG != 0 && (m == 0 || m == 11 || m == 23 || m == 35 || m == 47)) TP_STAMP(12 + (m + 1) / 12);
       }
-    }
+      // plane products, smallest first: 0*2, 2*0, 1*1, 0*1, 1*0, 0*0 (weights x pixels)
+      if (u == 0) acc = mfma32_bf16(fa[cur][0], fb[cur][2], acc);
+      if (u == 1) acc = mfma32_bf16(fa[cur][2], fb[cur][0], acc);
+      if (u == 2) acc = mfma32_bf16(fa[cur][1], fb[cur][1], acc);
+      if (u == 3) acc = mfma32_bf16(fa[cur][0], fb[cur][1], acc);
+      if (u == 4) acc = mfma32_bf16(fa[cur][1], fb[cur][0], acc);
+      if (u == 5) acc = mfma32_bf16(fa[cur][0], fb[cur][0], acc);
+      // MFMA m carries: the 8 activation ops (2 x ~6 VALU + 2 transcendentals each) behind every
+      // other MFMA of the first 16, the remaining ops one per MFMA, the row stores in steps 6 and 7
+      constexpr int k = m < 16 ? ((m & 1) ? -1 : m / 2) : m - 8;
+      if constexpr (WE && !CL && k >= 0 && k < N_EPI_OPS && !(DBG & 4)) epi_op(k);
+      if constexpr (WE && CL && !(DBG & 4)) cl_slot(M);
+      if (m == 32) load_fill(itB, T + 2 < T1);  // global loads of tile T + 2's rows
+      if (m == 33) {                            // this tile's epilogue operands (used one tile later)
+        if (EPI == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            axN[q] = *reinterpret_cast<const float4*>(p.aux + opix * p.CO + n0 + 8 * q + 4 * half);
+        }
+        if (EPI == 3) {
+#pragma unroll
+          for (int oc = 0; oc < C1; ++oc) tgtN[oc] = p.target[opix * C1 + oc];
+        }
+        if (ACC) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            pvN[q] = *reinterpret_cast<const float4*>(p.out + opix * p.CO + n0 + 8 * q + 4 * half);
+        }
+      }
+      if (WE && m == 34) flush_llk(T - 1);
+      if (m == 36) store_fill1(itA[0]);
+      if (m == 42) store_fill1(itA[1]);
+      ODIN_SCHED_FENCE();
+      if (DBG != 0 && (m == 0 || m == 11 || m == 23 || m == 35 || m == 47)) TP_STAMP(12 + (m + 1) / 12);
+    });
     pa = acc;
     opixP = opix;
 #pragma unroll
@@ -509,8 +633,13 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
       p.llk_part[T - 1] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
     }
   }
+  if (CL) {
+    cl_top();
+    tp_static_for<48>([&](auto M) __attribute__((always_inline)) { cl_slot(M); });
+  } else {
 #pragma unroll
-  for (int k = 0; k < N_EPI_OPS; ++k) epi_op(k);
+    for (int k = 0; k < N_EPI_OPS; ++k) epi_op(k);
+  }
   flush_llk(T1 - 1);
 
   // ---- per-workgroup partial sums: 32 pixel lanes by shuffles, then the 8 waves through LDS ----
@@ -576,33 +705,44 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
 template <int EPI, int C1, bool ACC>
 int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
   const size_t lds = (size_t)TP_WBYTES + (size_t)(2 * (64 / W) + 3 + 1) * 3 * (W + 2) * 64;  // ring + spare slot
+  constexpr int W3 = (EPI == 3 ? 16 : 8);  // (the fused tail has no 8-pixel geometry)
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    const void* fns[7] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 0, ACC>),
+    const void* fns[3] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 0, ACC>),
                           reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 16, 0, ACC>),
-                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, (EPI == 3 ? 16 : 8), 0, ACC>),
-                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 1 : 0), ACC>),
-                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 2 : 0), ACC>),
-                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 4 : 0), ACC>),
-                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 7 : 0), ACC>)};
-    for (int i = 0; i < ((EPI == 3) ? 7 : 3); ++i)
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, W3, 0, ACC>)};
+    for (int i = 0; i < 3; ++i)
       if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
         (void)hipGetLastError();
     attr_done = true;
   }
-#endif
-  if (W == 32 && EPI == 3) {
-    const char* e = getenv("ODIN_TP_DBG");
-    const int dbg = e ? atoi(e) : 0;
-    if (dbg == 1) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 1 : 0), ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
-    if (dbg == 2) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 2 : 0), ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
-    if (dbg == 4) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 4 : 0), ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
-    if (dbg == 7) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, (EPI == 3 ? 7 : 0), ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
+#ifdef ODIN_DIAG
+  // diagnostics build only (make FLAGS_tconv_planes+=-DODIN_DIAG): instances with parts of the kernel
+  // switched off, selected by ODIN_TP_DBG -- they compute WRONG results and are not in the product library
+  if (W == 32 && EPI == 3 && C1 == 1) {
+    static const int dbg = [] { const char* e = getenv("ODIN_TP_DBG"); return e ? atoi(e) : 0; }();
+    static bool dattr = false;
+    if (!dattr) {
+      const void* dfn[4] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 1, ACC>),
+                            reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 2, ACC>),
+                            reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 4, ACC>),
+                            reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 7, ACC>)};
+      for (int i = 0; i < 4; ++i)
+        if (hipFuncSetAttribute(dfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+          (void)hipGetLastError();
+      dattr = true;
+    }
+    if (dbg == 1) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 1, ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
+    if (dbg == 2) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 2, ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
+    if (dbg == 4) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 4, ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
+    if (dbg == 7) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 7, ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
   }
+#endif
+#endif
   if (W == 32) ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 0, ACC>), grid, dim3(512), lds, stream, p);
   else if (W == 16) ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 16, 0, ACC>), grid, dim3(512), lds, stream, p);
-  else ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, (EPI == 3 ? 16 : 8), 0, ACC>), grid, dim3(512), lds, stream, p);
+  else ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, W3, 0, ACC>), grid, dim3(512), lds, stream, p);
   return odin_check_launch("tconv_planes(bf16x3)");
 }
 
@@ -614,8 +754,9 @@ void odin_tconv_planes_set_stamps(void* buf) { g_tp_stamps = (long long*)buf; }
 // ODIN_SPLIT (any value) and ODIN_NOPLANES select the older instances (gather_conv.hip)
 bool odin_tconv_planes_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt,
                                   int pl, int center, int epi, int C1) {
-  if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT")) return false;
-  if (epi == 3 && (CO != 32 || C1 != 1 || CI != 32 || W == 8)) return false;
+  static const bool off = getenv("ODIN_NOPLANES") != nullptr || getenv("ODIN_SPLIT") != nullptr;
+  if (off) return false;
+  if (epi == 3 && (CO != 32 || (C1 != 1 && C1 != 3) || CI != 32 || W == 8)) return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && (CI == 32 || CI == 64) && (CO % 32) == 0 &&
          !center && (W == 8 || W == 16 || W == 32) && (H % (64 / W)) == 0 && (size_t)B * H * W * CI * 4 < (1ull << 31) &&
          (size_t)B * H * W * 4 * C1 * 4 < (1ull << 31);
@@ -662,5 +803,6 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
   if (epi == 1) return tp_launch_w<1, 1, false>(p, W, grid, stream);
   if (epi == 2) return tp_launch_w<2, 1, false>(p, W, grid, stream);
   if (C1 == 1) return tp_launch_w<3, 1, false>(p, W, grid, stream);
-  return odin_fail(-2, "tconv_planes tail: one logit map only");
+  if (C1 == 3) return tp_launch_w<3, 3, false>(p, W, grid, stream);
+  return odin_fail(-2, "tconv_planes tail: one or three logit maps only");
 }

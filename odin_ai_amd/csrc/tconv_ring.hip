@@ -74,7 +74,7 @@ struct TRParams {
   } while (0)
 #endif
 
-// 8 consumer waves (two per SIMD) + 4 producer waves.  Measured on gfx950 (tools_micro/mfma_valu.hip):
+// 8 consumer waves (two per SIMD) + 4 producer waves.  Measured on gfx950 (tools/micro/mfma_valu.hip):
 // a wave's own VALU instructions ADD to its MFMA stream (32 -> 45 ticks per MFMA with 4 FMAs in
 // the gap), while a second wave on the same SIMD issues ~4 VALU instructions per MFMA of its
 // partner at no cost to it.  So the epilogues are hidden by the SIMD's other consumer wave, not by
@@ -525,7 +525,7 @@ bool odin_tconv_ring_applicable(int H, int W, int CI, int CO, int KH, int KW, in
   // Opt-in (ODIN_TRING=1): measured on MI355X this all-fp32 form is not faster than the bf16-plane
   // instances of gather_conv.hip (fused tail 105 vs 90 us, encoder1 data gradient 25.7 vs 25.5 us):
   // v_mfma_f32_*_f32 shares the vector ALU's issue with every other VALU instruction (nothing of an
-  // epilogue hides behind it -- tools_micro/mfma_fillers.hip), while bf16 MFMAs run beside the VALU.
+  // epilogue hides behind it -- tools/micro/mfma_fillers.hip), while bf16 MFMAs run beside the VALU.
   const char* e = getenv("ODIN_TRING");
   if (e == nullptr || e[0] != '1') return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && CI == 32 && (CO % 32) == 0 &&

@@ -705,6 +705,7 @@ class VariationalAutoencoder:
       raise ValueError('No path is given for saving weights')
     eng = self._engine(1)
     W = {self.variable_name(k): v.detach().cpu().numpy() for k, v in eng.param_views().items()}
+    W.update(self._extra_checkpoint_variables())
     if save_format == 'tf':
       if os.path.exists(filepath + '.index') and not overwrite:
         raise RuntimeError(f'{filepath} exists')
@@ -745,15 +746,31 @@ class VariationalAutoencoder:
     eng = self._engine(1)
     for k, v in eng.param_views().items():
       name = self.variable_name(k)
-      hits = [n for n in d if n == name or n.endswith('/' + name)]
-      if len(hits) != 1:
-        raise KeyError(f'{name}: {len(hits)} matching variables in the checkpoint ({hits[:3]})')
-      a = d[hits[0]]
+      a = self._find_variable(d, name)
       if tuple(a.shape) != tuple(v.shape):
         raise ValueError(f'{name}: checkpoint shape {a.shape} != {tuple(v.shape)}')
       v.copy_(torch.as_tensor(np.asarray(a), dtype=torch.float32, device=self.device))
+    self._load_extra_checkpoint_variables(d)
     self._step = step
     return self
+
+  def _extra_checkpoint_variables(self) -> Dict[str, np.ndarray]:
+    """Variables beyond encoder / latents / decoder that Keras would track on this model
+    (sub-layers and optimizers held as attributes): {checkpoint name: array}."""
+    return {}
+
+  def _load_extra_checkpoint_variables(self, d: Dict[str, np.ndarray]):
+    pass
+
+  @staticmethod
+  def _find_variable(d: Dict[str, np.ndarray], name: str):
+    """exact name first, then a unique '<prefix>/name' (a model nested in another)."""
+    if name in d:
+      return d[name]
+    hits = [n for n in d if n.endswith('/' + name)]
+    if len(hits) != 1:
+      raise KeyError(f'{name}: {len(hits)} matching variables in the checkpoint ({hits[:3]})')
+    return d[hits[0]]
 
   def __str__(self):
     return (f'{self.name}(input={self.input_shape}, zdim={self.zdim}, '
@@ -925,6 +942,49 @@ class FactorVAE(AnnealingVAE):
       broadcast_parameters(self._disc_state.params, src=0)
     return self._disc_state
 
+  def _disc_names(self):
+    """[(checkpoint name, flat offset, shape)] of the discriminator's variables: Keras names of
+    `dense_network` inside the `FactorDiscriminator` sub-layer (factor_discriminator.py:60-95)."""
+    D = self.discriminator
+    return [(f"discriminator/dense_{key[1]}/{'kernel' if key[-1] == 'w' else 'bias'}", off, shp)
+            for key, shp, off in D.layout.entries]
+
+  def _extra_checkpoint_variables(self) -> Dict[str, np.ndarray]:
+    """The reference keeps `self.discriminator` (a Keras layer) and `self.disc_optimizer` as
+    attributes of the model (factor_vae.py:137-160), so `save_weights` tracks both: the
+    discriminator's kernels / biases, its Adam's iteration count and moment slots.  A restored
+    FactorVAE continues with the SAME discriminator and bias correction."""
+    D = self.discriminator
+    W = {}
+    for name, off, shp in self._disc_names():
+      n = int(np.prod(shp))
+      W[name] = D.params[off:off + n].view(shp).detach().cpu().numpy()
+      W[f'disc_optimizer/{name}/m'] = D.m[off:off + n].view(shp).detach().cpu().numpy()
+      W[f'disc_optimizer/{name}/v'] = D.v[off:off + n].view(shp).detach().cpu().numpy()
+    W['disc_optimizer/iter'] = np.asarray(D.t, np.int64)
+    return W
+
+  def _load_extra_checkpoint_variables(self, d: Dict[str, np.ndarray]):
+    names = self._disc_names()
+    have = [any(n == nm or n.endswith('/' + nm) for n in d) for nm, _, _ in names]
+    if not any(have):
+      if self._is_pretraining:
+        return  # a checkpoint of the pretraining phase may predate the discriminator
+      raise KeyError('the checkpoint holds no discriminator variables (discriminator/dense_*/kernel): '
+                     'a FactorVAE restored from it would continue with a re-initialised discriminator; '
+                     'call pretrain() first if that is intended')
+    D = self.discriminator
+    as_t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32, device=self.device)
+    for name, off, shp in names:
+      n = int(np.prod(shp))
+      a = self._find_variable(d, name)
+      if tuple(a.shape) != tuple(shp):
+        raise ValueError(f'{name}: checkpoint shape {a.shape} != {tuple(shp)}')
+      D.params[off:off + n].view(shp).copy_(as_t(a))
+      for slot, buf in (('m', D.m), ('v', D.v)):
+        buf[off:off + n].view(shp).copy_(as_t(self._find_variable(d, f'disc_optimizer/{name}/{slot}')))
+    D.t = int(self._find_variable(d, 'disc_optimizer/iter'))
+
   def _discriminator(self, B1: int) -> DiscPrograms:
     dp = self.discriminator.bind(B1)
     eng = self._engine(B1)
@@ -936,13 +996,14 @@ class FactorVAE(AnnealingVAE):
     return dp
 
   # -- the two steps, returning device scalars ------------------------------------------
-  def _set_hyper(self, eng, disc, lr, use_tc, training):
+  def _set_hyper(self, eng, disc, lr, use_tc, training, when_skip_update: int = 0):
     h_extra = None
     if training and not self._is_pretraining:
       t = disc.disc.t + 1
       a = self.disc_lr * math.sqrt(1 - self.disc_b2 ** t) / (1 - self.disc_b1 ** t)
       h_extra = (a, self.disc_b1, self.disc_b2, 1e-7, 1.0)
-    eng.set_hyper(lr=lr, beta=self.beta, tc_coef=self.tc_coef if use_tc else 0.0, extra=h_extra)
+    eng.set_hyper(lr=lr, beta=self.beta, tc_coef=self.tc_coef if use_tc else 0.0, extra=h_extra,
+                  skip_enable=self._step >= int(when_skip_update or 0))
 
   def _iteration(self, eng, eng2, disc, x1, x2, eps, eps2, perm, training, use_tc, pol,
                  aggregate_gradients):
@@ -1011,6 +1072,10 @@ class FactorVAE(AnnealingVAE):
     the same clip arguments are NOT applied to it here; state otherwise if you need them)."""
     x = _as_tensor(inputs, self.device)
     assert x.shape[0] % 2 == 0, 'FactorVAE splits the batch in two halves'
+    if self.n_samples != 1:
+      raise NotImplementedError('FactorVAE on the HIP path draws one posterior sample per input '
+                                '(sample_shape=()); the batch-tiling of VariationalAutoencoder.optimize '
+                                'is not wired through the two-step iteration')
     B1 = x.shape[0] // 2
     eng, disc = self._engine(B1), self._discriminator(B1)
     eng2 = self._engine_x2(B1)
@@ -1019,7 +1084,7 @@ class FactorVAE(AnnealingVAE):
     eng.step_count = self._step
     eng2.hyper = eng.hyper  # one hyper buffer (RNG step, beta) for both halves
     use_tc = not (self._is_pretraining and training)
-    self._set_hyper(eng, disc, self._lr(learning_rate), use_tc, training)
+    self._set_hyper(eng, disc, self._lr(learning_rate), use_tc, training, when_skip_update)
     val = self.tc_coef / (B1 * eng.world_size)
     if disc.dlogit1_value != val:
       disc.dlogit1.fill_(val)

@@ -1,4 +1,7 @@
-"""Model API (VariationalAutoencoder & friends) on the CPU simulator vs the oracle."""
+"""Model API (VariationalAutoencoder & friends) vs the oracle, on both backends of the `bk` fixture
+(tests/conftest.py): the CPU fiber simulator build of the kernel sources (`-m "not gpu"`) and the
+gfx950 build on an MI355X through the C ABI (`-m gpu`): marginal_log_prob (f2), sample_shape,
+every Networks.optimize gradient policy, track_gradients, checkpoints, FactorVAE iterations."""
 import numpy as np
 import pytest
 import torch
@@ -7,12 +10,16 @@ from odin_ai_amd.networks import RVconf, SequentialNetwork, get_networks
 from odin_ai_amd.vae import (AnnealingVAE, BetaTCVAE, BetaVAE, FactorVAE, VariationalAutoencoder,
                              get_vae)
 from oracle import vae_oracle as vo
-from tests.simutil import sim_lib
 
 
 @pytest.fixture(scope='module')
-def L():
-  return sim_lib()
+def L(bk):
+  return bk.L
+
+
+@pytest.fixture(scope='module')
+def DEV(bk):
+  return bk.dev
 
 
 def tiny_nets(C=1, zdim=4, hw=8):
@@ -27,12 +34,12 @@ def tiny_nets(C=1, zdim=4, hw=8):
 
 
 def oracle_params(vae):
-  return {k: v.detach().cpu().numpy().astype(np.float64) for k, v in vae.trainable_variables.items()}
+  return {k: v.detach().cpu().numpy(force=True).astype(np.float64) for k, v in vae.trainable_variables.items()}
 
 
-def test_api_call_elbo_and_optimize(L):
+def test_api_call_elbo_and_optimize(L, DEV):
   nets = tiny_nets()
-  vae = BetaVAE(beta=4.0, device='cpu', lib=L, **nets)
+  vae = BetaVAE(beta=4.0, device=DEV, lib=L, **nets)
   B = 6
   rng = np.random.default_rng(0)
   x = np.clip(rng.random((B, 8, 8, 1)), 1e-6, 1 - 1e-6).astype(np.float32)
@@ -43,16 +50,16 @@ def test_api_call_elbo_and_optimize(L):
   model = vo.OracleVAE(nets['encoder'].layers, nets['decoder'].layers, (8, 8, 1), 4, beta=4.0)
   P = oracle_params(vae)
   f = model.forward(P, x.astype(np.float64), eps.astype(np.float64))
-  np.testing.assert_allclose(qz.mean().numpy(), f['loc'], atol=1e-5)
-  np.testing.assert_allclose(qz.stddev().numpy(), f['scale'], atol=1e-5)
-  np.testing.assert_allclose(px.mean().numpy(), f['recon'], atol=1e-5)
+  np.testing.assert_allclose(qz.mean().numpy(force=True), f['loc'], atol=1e-5)
+  np.testing.assert_allclose(qz.stddev().numpy(force=True), f['scale'], atol=1e-5)
+  np.testing.assert_allclose(px.mean().numpy(force=True), f['recon'], atol=1e-5)
   llk, kl = vae.elbo_components(x, eps=eps)
   assert set(llk) == {'llk_image'} and set(kl) == {'kl_latents'}
-  np.testing.assert_allclose(llk['llk_image'].numpy(), f['llk'], rtol=1e-5)
-  np.testing.assert_allclose(kl['kl_latents'].numpy(), f['kl'], rtol=1e-4, atol=1e-4)
-  np.testing.assert_allclose(vae.elbo(llk, kl).numpy(), f['elbo'], rtol=1e-5)
+  np.testing.assert_allclose(llk['llk_image'].numpy(force=True), f['llk'], rtol=1e-5)
+  np.testing.assert_allclose(kl['kl_latents'].numpy(force=True), f['kl'], rtol=1e-4, atol=1e-4)
+  np.testing.assert_allclose(vae.elbo(llk, kl).numpy(force=True), f['elbo'], rtol=1e-5)
   # the reference's KL_divergence closure on the posterior object
-  np.testing.assert_allclose(qz.KL_divergence(analytic=False).numpy() * 4.0, f['kl'], rtol=1e-4,
+  np.testing.assert_allclose(qz.KL_divergence(analytic=False).numpy(force=True) * 4.0, f['kl'], rtol=1e-4,
                              atol=1e-4)
   assert qz.KL_divergence(analytic=True, keepdims=True).shape == (1, B)
   step = next(iter(vae.train_steps(x, training=True, eps=eps)))
@@ -66,14 +73,14 @@ def test_api_call_elbo_and_optimize(L):
   assert float(l1) < float(l0)
 
 
-def test_fit_save_load_and_errors(L, tmp_path):
+def test_fit_save_load_and_errors(L, DEV, tmp_path):
   nets = tiny_nets()
-  vae = VariationalAutoencoder(device='cpu', lib=L, path=str(tmp_path / 'w'), **nets)
+  vae = VariationalAutoencoder(device=DEV, lib=L, path=str(tmp_path / 'w'), **nets)
   x = (np.random.default_rng(1).random((24, 8, 8, 1)) < 0.3).astype(np.float32)
   vae.fit(x, max_iter=6, batch_size=8, learning_rate=1e-3, compile_graph=False)
   assert vae.step == 6 and len(vae.history) >= 1
   vae.save_weights()
-  vae2 = VariationalAutoencoder(device='cpu', lib=L, path=str(tmp_path / 'w'), **tiny_nets())
+  vae2 = VariationalAutoencoder(device=DEV, lib=L, path=str(tmp_path / 'w'), **tiny_nets())
   vae2.load_weights()
   assert vae2.step == 6
   for k, v in vae.trainable_variables.items():
@@ -81,7 +88,7 @@ def test_fit_save_load_and_errors(L, tmp_path):
   with pytest.raises(ValueError):
     get_networks('no_such_dataset')
   with pytest.raises(ValueError):
-    VariationalAutoencoder(device='cpu', lib=L, **dict(tiny_nets(), encoder='not a network'))
+    VariationalAutoencoder(device=DEV, lib=L, **dict(tiny_nets(), encoder='not a network'))
   with pytest.raises(RuntimeError):
     vae.fit(x, optimizer='sgd', max_iter=1)
   with pytest.raises(ValueError):
@@ -89,12 +96,12 @@ def test_fit_save_load_and_errors(L, tmp_path):
   assert get_vae('betavae') is BetaVAE
 
 
-def test_annealing_and_betatc(L):
-  a = AnnealingVAE(device='cpu', lib=L, **tiny_nets())
+def test_annealing_and_betatc(L, DEV):
+  a = AnnealingVAE(device=DEV, lib=L, **tiny_nets())
   a._step = 1000
   assert abs(a.beta - 0.5000005) < 1e-9  # linear(1e-6, 1, 2000) at step 1000 (SURVEY KAT)
   nets = tiny_nets()
-  tcv = BetaTCVAE(beta=3.0, device='cpu', lib=L, **nets)
+  tcv = BetaTCVAE(beta=3.0, device=DEV, lib=L, **nets)
   B = 6
   rng = np.random.default_rng(2)
   x = np.clip(rng.random((B, 8, 8, 1)), 1e-6, 1 - 1e-6).astype(np.float32)
@@ -105,20 +112,20 @@ def test_annealing_and_betatc(L):
                        tc_beta=3.0)
   f = model.forward(oracle_params(tcv), x.astype(np.float64), eps.astype(np.float64))
   assert abs(float(kl['tc_latents']) - f['tc']) < 1e-4 * max(1.0, abs(f['tc']))
-  np.testing.assert_allclose(tcv.elbo(llk, kl).numpy(), f['elbo'], rtol=1e-5)
+  np.testing.assert_allclose(tcv.elbo(llk, kl).numpy(force=True), f['elbo'], rtol=1e-5)
 
 
-def test_factor_vae_two_steps_match_oracle(L):
+def test_factor_vae_two_steps_match_oracle(L, DEV):
   nets = tiny_nets()
   B1, D = 4, 4
-  fv = FactorVAE(discriminator_units=(16, 16), tc_coef=7.0, device='cpu', lib=L, **nets)
+  fv = FactorVAE(discriminator_units=(16, 16), tc_coef=7.0, device=DEV, lib=L, **nets)
   rng = np.random.default_rng(3)
   x = np.clip(rng.random((2 * B1, 8, 8, 1)), 1e-6, 1 - 1e-6).astype(np.float32)
   eps, eps2 = (rng.standard_normal((B1, D)).astype(np.float32) for _ in range(2))
   perm = np.stack([rng.permutation(B1) for _ in range(D)], 1).astype(np.int32)
   P = oracle_params(fv)
   disc = fv._discriminator(B1)
-  DP = {(k[1], k[2]): v.detach().numpy().astype(np.float64)
+  DP = {(k[1], k[2]): v.detach().numpy(force=True).astype(np.float64)
         for k, v in disc.layout.views(disc.params).items()}
   loss, metrics = fv.optimize(x, training=False, eps=eps, eps2=eps2, perm=perm)
   # oracle: step 1
@@ -145,13 +152,13 @@ def test_factor_vae_two_steps_match_oracle(L):
 
 
 @pytest.mark.parametrize('units', [(16, 16), (40,)])
-def test_factor_vae_iteration_gradients_and_both_adams(L, units):
+def test_factor_vae_iteration_gradients_and_both_adams(L, DEV, units):
   """the step-1 dz through D, the discriminator gradients and the
   Adam(1e-5, .5, .9) update against the oracle (simulator build of the kernels)."""
   from tests.factor_util import check_factor_vae_iteration
   nets = tiny_nets()
   B1, D = 4, 4
-  fv = FactorVAE(discriminator_units=units, tc_coef=7.0, device='cpu', lib=L, **nets)
+  fv = FactorVAE(discriminator_units=units, tc_coef=7.0, device=DEV, lib=L, **nets)
   rng = np.random.default_rng(11)
   x = np.clip(rng.random((2 * B1, 8, 8, 1)), 1e-6, 1 - 1e-6).astype(np.float32)
   eps, eps2 = (rng.standard_normal((B1, D)).astype(np.float32) for _ in range(2))
@@ -166,11 +173,11 @@ def test_factor_vae_iteration_gradients_and_both_adams(L, units):
                                 dict(skip_update_threshold=1e-3),
                                 dict(skip_update_threshold=1e-3, when_skip_update=5),
                                 dict(skip_update_threshold=1e9)])
-def test_optimize_gradient_policies_match_oracle(L, kw):
+def test_optimize_gradient_policies_match_oracle(L, DEV, kw):
   """Every clipping / skipping argument of Networks.optimize (base_networks.py:549-596) changes
   the Adam update exactly as the oracle's restatement says -- none is silently ignored."""
   nets = tiny_nets()
-  vae = BetaVAE(beta=2.0, device='cpu', lib=L, **nets)
+  vae = BetaVAE(beta=2.0, device=DEV, lib=L, **nets)
   B = 6
   rng = np.random.default_rng(4)
   x = np.clip(rng.random((B, 8, 8, 1)), 1e-6, 1 - 1e-6).astype(np.float32)
@@ -186,7 +193,7 @@ def test_optimize_gradient_policies_match_oracle(L, kw):
   lr = 1e-3
   vae.optimize(x, eps=eps, learning_rate=lr, **kw)
   assert vae.skipped_update == int(skipped)
-  pv = {k: v.numpy() for k, v in vae.trainable_variables.items()}
+  pv = {k: v.numpy(force=True) for k, v in vae.trainable_variables.items()}
   for k, g in zip(keys, gl):
     want, _, _ = vo.adam_keras(P[k], g, 0.0, 0.0, 1, lr)
     well = np.abs(g) > 1e-3 * max(np.abs(g).max(), 1e-30)
@@ -198,13 +205,13 @@ def test_optimize_gradient_policies_match_oracle(L, kw):
     vae.optimize(x, nan_gradients_policy='nope')
 
 
-def test_track_gradients_and_checkpoint_names(L, tmp_path):
+def test_track_gradients_and_checkpoint_names(L, DEV, tmp_path):
   nets = get_networks('dsprites')
   names = ['encoder0', 'encoder3', 'encoder_proj', 'decoder_proj', 'decoder1', 'decoder6']
   from odin_ai_amd.networks import layer_names
   en, dn = layer_names(nets['encoder'], 'encoder'), layer_names(nets['decoder'], 'decoder')
   assert set(names) <= set(en.values()) | set(dn.values())
-  vae = VariationalAutoencoder(device='cpu', lib=L, path=str(tmp_path / 'ck'), **tiny_nets())
+  vae = VariationalAutoencoder(device=DEV, lib=L, path=str(tmp_path / 'ck'), **tiny_nets())
   x = (np.random.default_rng(1).random((4, 8, 8, 1)) < 0.3).astype(np.float32)
   _, m = vae.optimize(x, track_gradients=True)
   gk = [k for k in m if k.startswith('_grad/')]
@@ -217,14 +224,14 @@ def test_track_gradients_and_checkpoint_names(L, tmp_path):
   vae.save_weights(str(tmp_path / 'tfck' / 'model'))
   ck = tf_checkpoint.load_checkpoint(str(tmp_path / 'tfck' / 'model'))
   assert int(ck['Step']) == 1 and ck['latents/kernel'].shape == (24, 8)
-  v2 = VariationalAutoencoder(device='cpu', lib=L, **tiny_nets()).load_weights(str(tmp_path / 'tfck' / 'model'))
+  v2 = VariationalAutoencoder(device=DEV, lib=L, **tiny_nets()).load_weights(str(tmp_path / 'tfck' / 'model'))
   assert v2.step == 1
   for k, v in vae.trainable_variables.items():
     assert torch.equal(v, v2.trainable_variables[k])
   # a checkpoint whose object graph prefixes the names (as a Keras model nested in another would)
   W = {'vae/' + k: v for k, v in ck.items()}
   tf_checkpoint.save_checkpoint(str(tmp_path / 'nested'), W)
-  v3 = VariationalAutoencoder(device='cpu', lib=L, **tiny_nets()).load_weights(str(tmp_path / 'nested'))
+  v3 = VariationalAutoencoder(device=DEV, lib=L, **tiny_nets()).load_weights(str(tmp_path / 'nested'))
   assert torch.equal(v3.trainable_variables[('lat', 'w')], vae.trainable_variables[('lat', 'w')])
   # fit(logdir=...) writes the scalars the reference's Trainer logs
   vae.fit(x, max_iter=4, batch_size=4, compile_graph=False, logdir=str(tmp_path / 'tb'),
@@ -233,11 +240,11 @@ def test_track_gradients_and_checkpoint_names(L, tmp_path):
   assert {t for _, t, _ in ev} >= {'train/loss', 'train/llk_image', 'train/kl_latents'}
 
 
-def test_marginal_log_prob_matches_oracle(L):
+def test_marginal_log_prob_matches_oracle(L, DEV):
   """variational_autoencoder.py:396-513: one encoder pass, n posterior samples, n*B decodes,
   log-mean-exp over the samples -- against the oracle with the same noise."""
   nets = tiny_nets()
-  vae = VariationalAutoencoder(device='cpu', lib=L, **nets)
+  vae = VariationalAutoencoder(device=DEV, lib=L, **nets)
   rng = np.random.default_rng(9)
   N, n, D = 10, 7, 4
   x = np.clip(rng.random((N, 8, 8, 1)), 1e-6, 1 - 1e-6).astype(np.float32)
@@ -246,9 +253,9 @@ def test_marginal_log_prob_matches_oracle(L):
   llk_ref, (lq_ref, lp_ref) = vo.marginal_log_prob(model, oracle_params(vae), x, eps)
   llk, kl = vae.marginal_log_prob(x, n_mcmc=n, reduce=None, batch_size=4, eps=eps)
   assert set(llk) == {'image'} and set(kl) == {'latents'}
-  np.testing.assert_allclose(llk['image'].numpy(), llk_ref, rtol=2e-5)
-  np.testing.assert_allclose(kl['latents'][0].numpy(), lq_ref, rtol=2e-5, atol=2e-5)
-  np.testing.assert_allclose(kl['latents'][1].numpy(), lp_ref, rtol=2e-5, atol=2e-5)
+  np.testing.assert_allclose(llk['image'].numpy(force=True), llk_ref, rtol=2e-5)
+  np.testing.assert_allclose(kl['latents'][0].numpy(force=True), lq_ref, rtol=2e-5, atol=2e-5)
+  np.testing.assert_allclose(kl['latents'][1].numpy(force=True), lp_ref, rtol=2e-5, atol=2e-5)
   llk_m, _ = vae.marginal_log_prob(x, n_mcmc=n, batch_size=4, eps=eps)  # reduce = mean
   assert abs(float(llk_m['image']) - llk_ref.mean()) < 1e-4 * abs(llk_ref.mean())
   # without explicit noise: finite, and more samples tighten the bound on average
@@ -257,15 +264,15 @@ def test_marginal_log_prob_matches_oracle(L):
   assert np.isfinite(float(a['image'])) and float(b['image']) >= float(a['image']) - 1.0
 
 
-def test_reverse_kl_and_sample_shape(L):
+def test_reverse_kl_and_sample_shape(L, DEV):
   nets = tiny_nets()
   rng = np.random.default_rng(10)
   B, D = 5, 4
   x = np.clip(rng.random((B, 8, 8, 1)), 1e-6, 1 - 1e-6).astype(np.float32)
   eps = rng.standard_normal((B, D)).astype(np.float32)
   with pytest.raises(TypeError):
-    BetaVAE(beta=2.0, reverse=False, device='cpu', lib=L, **nets)
-  vae = BetaVAE(beta=2.0, reverse=False, analytic=True, device='cpu', lib=L, **nets)
+    BetaVAE(beta=2.0, reverse=False, device=DEV, lib=L, **nets)
+  vae = BetaVAE(beta=2.0, reverse=False, analytic=True, device=DEV, lib=L, **nets)
   model = vo.OracleVAE(nets['encoder'].layers, nets['decoder'].layers, (8, 8, 1), D, beta=2.0,
                        analytic=True, reverse=False)
   P = oracle_params(vae)
@@ -273,19 +280,19 @@ def test_reverse_kl_and_sample_shape(L):
   G, _ = model.backward(P, x.astype(np.float64), eps.astype(np.float64), f)
   llk, kl = vae.elbo_components(x, eps=eps)
   assert kl['kl_latents'].shape == (1, B)
-  np.testing.assert_allclose(kl['kl_latents'][0].numpy(), f['kl'], rtol=1e-4, atol=1e-4)
+  np.testing.assert_allclose(kl['kl_latents'][0].numpy(force=True), f['kl'], rtol=1e-4, atol=1e-4)
   px, qz = vae.last_outputs
-  np.testing.assert_allclose(qz.KL_divergence(analytic=True, reverse=False).numpy() * 2.0, f['kl'],
+  np.testing.assert_allclose(qz.KL_divergence(analytic=True, reverse=False).numpy(force=True) * 2.0, f['kl'],
                              rtol=1e-4, atol=1e-4)
   with pytest.raises(TypeError):
     qz.KL_divergence(analytic=False, reverse=False)
   _, m = vae.optimize(x, eps=eps, track_gradients=True, learning_rate=1e-3)
   for k, g in G.items():
-    got = m['_grad/' + vae.variable_name(k)].numpy()
+    got = m['_grad/' + vae.variable_name(k)].numpy(force=True)
     assert np.abs(got - g).max() <= 1e-4 * np.abs(g).max(), k
   # sample_shape=(3,): [3, B] components, loss = overall mean
   n = 3
-  v3 = VariationalAutoencoder(sample_shape=(n,), device='cpu', lib=L, **tiny_nets())
+  v3 = VariationalAutoencoder(sample_shape=(n,), device=DEV, lib=L, **tiny_nets())
   v3._engine(1).load_params(P)
   eps3 = rng.standard_normal((n, B, D)).astype(np.float32)
   llk3, kl3 = v3.elbo_components(x, eps=eps3)
@@ -293,5 +300,5 @@ def test_reverse_kl_and_sample_shape(L):
   m1 = vo.OracleVAE(nets['encoder'].layers, nets['decoder'].layers, (8, 8, 1), D)
   for k in range(n):
     fk = m1.forward(P, x.astype(np.float64), eps3[k].astype(np.float64))
-    np.testing.assert_allclose(llk3['llk_image'][k].numpy(), fk['llk'], rtol=1e-5)
-    np.testing.assert_allclose(kl3['kl_latents'][k].numpy(), fk['kl'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(llk3['llk_image'][k].numpy(force=True), fk['llk'], rtol=1e-5)
+    np.testing.assert_allclose(kl3['kl_latents'][k].numpy(force=True), fk['kl'], rtol=1e-4, atol=1e-4)

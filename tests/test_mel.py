@@ -1,11 +1,12 @@
-"""Mel front-end kernel sources on the CPU simulator vs the reference-generated goldens."""
+"""Mel front-end kernel vs the reference-generated goldens and the numpy restatements, on both
+backends of the `bk` fixture (CPU simulator build / gfx950 build on an MI355X): numpy front-end
+(a24) and the TF AudioFeatureLoader variant (a25)."""
 import os
 
 import numpy as np
 import pytest
 
 from odin_ai_amd.mel import MelsSpecExtractor, mel_filters
-from tests.simutil import sim_lib
 
 G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mel_golden.npz'))
 
@@ -14,11 +15,11 @@ def test_product_filterbank_matches_reference():
   np.testing.assert_allclose(mel_filters(8000, 512, 80, 64, 4000), G['mel_basis'], atol=1e-13)
 
 
-def test_mel_kernel_matches_reference_golden():
-  L = sim_lib()
-  ex = MelsSpecExtractor(device='cpu', lib=L)
+def test_mel_kernel_matches_reference_golden(bk):
+  L, DEV = bk.L, bk.dev
+  ex = MelsSpecExtractor(device=DEV, lib=L)
   y = G['y'][:2, :2000]  # 23 frames per utterance keeps the simulator fast
-  out = ex(y).numpy()
+  out = ex(y).numpy(force=True)
   assert out.shape == (2, 23, 80)
   from oracle import mel_oracle as mo
   for i in range(2):
@@ -29,32 +30,32 @@ def test_mel_kernel_matches_reference_golden():
   # other FFT sizes of the radix-4 family, no pre-emphasis, hann window, power output
   for n_fft, fl in ((128, 100), (2048, 400)):
     ex2 = MelsSpecExtractor(frame_length=fl, step_length=80, n_fft=n_fft, window='hann', n_mels=24,
-                            preemphasis=None, log=False, device='cpu', lib=L)
-    o2 = ex2(y[:1, :1200]).numpy()[0]
+                            preemphasis=None, log=False, device=DEV, lib=L)
+    o2 = ex2(y[:1, :1200]).numpy(force=True)[0]
     r2 = mo.mel_frontend(y[0, :1200], frame_length=fl, n_fft=n_fft, n_mels=24, preemph=None,
                          window='hann', log=False)
     assert np.abs(o2 - r2).max() <= 1e-6 * np.abs(r2).max(), (n_fft, np.abs(o2 - r2).max())
   with pytest.raises(ValueError):
-    MelsSpecExtractor(fmin=5000, fmax=4000, device='cpu', lib=L)
+    MelsSpecExtractor(fmin=5000, fmax=4000, device=DEV, lib=L)
 
 
-def test_unit_range_output_and_tf_variant():
+def test_unit_range_output_and_tf_variant(bk):
   """log_output=2 maps the floored dB into [0, 1]; the TF AudioFeatureLoader variant (fft 256:
   radix-4 stages + one radix-2 stage, HTK filterbank, un-normalised Hann window) matches its
   numpy restatement."""
   from odin_ai_amd.mel import AudioFeatureLoader
   from oracle import mel_oracle as mo
-  L = sim_lib()
+  L, DEV = bk.L, bk.dev
   y = G['y'][:2, :1600]
-  ex = MelsSpecExtractor(device='cpu', lib=L, unit_range=True)
-  out = ex(y).numpy()
+  ex = MelsSpecExtractor(device=DEV, lib=L, unit_range=True)
+  out = ex(y).numpy(force=True)
   for i in range(2):
     ref = mo.mel_frontend(y[i])
     want = (ref - ref.max()) / 80.0 + 1.0
     assert np.abs(out[i] - want).max() < 1e-6 and out[i].min() >= 0.0 and out[i].max() == 1.0
   for log_mels in (False, True):
-    al = AudioFeatureLoader(device='cpu', lib=L, log_mels=log_mels)
-    o = al.melspec(y).numpy()
+    al = AudioFeatureLoader(device=DEV, lib=L, log_mels=log_mels)
+    o = al.melspec(y).numpy(force=True)
     assert o.shape == (2, 17, 20)
     for i in range(2):
       r = mo.tf_audio_melspec(y[i], log_mels=log_mels)

@@ -205,8 +205,9 @@ def test_dense(bk, B, K, N, act):
     (1, 3, 8, 8, 8, 16, 4, 2, 3),      # generic transposed
     (0, 2, 16, 16, 8, 24, 5, 1, 1),    # generic gather conv (MNIST-style decoder tail)
     (1, 3, 16, 16, 32, 32, 4, 2, 1),   # tconv_planes fused tail (bf16 planes), 16-pixel rows, tiles across image seams
-    (1, 3, 16, 16, 32, 32, 4, 2, 3),   # 3 logit maps (bf16-plane instances of gather_conv.hip; tconv_ring when opted in)
+    (1, 3, 16, 16, 32, 32, 4, 2, 3),   # 3 logit maps, 16-pixel rows, tiles across image seams (tconv_planes; tconv_ring when opted in)
     (1, 2, 32, 32, 32, 32, 4, 2, 1),   # tconv_planes fused tail, 32-pixel input rows (dSprites decoder4)
+    (1, 2, 32, 32, 32, 32, 4, 2, 3),   # tconv_planes fused tail with 3 logit maps (Shapes3D / CelebA decoder4 -> 64x64x3)
 ])
 def test_bernoulli_tail(bk, is_deconv, B, H, W, Ci, Co, K, S, C1):
   L, T = bk.L, bk.T

@@ -2,6 +2,8 @@
 properties of the reference's own permute_dims test (tests/bayesian/test_vae.py:112-125)."""
 import math
 
+import pytest
+
 import numpy as np
 
 from oracle import vae_oracle as vo
@@ -80,3 +82,21 @@ def test_quantized_logistic_is_a_distribution_over_the_256_pixel_levels():
   assert np.argmax(lp) == k and abs(np.exp(lp[k]) - np.tanh(0.25 / (np.exp(-7.0) * 127.5))) < 1e-9
   far = vo.qlogistic_log_prob_elem(np.array([-5.0]), np.array([0.0]), np.array([0.0]))
   assert far[0] > -0.1                        # all mass below 0 lands in the y = 0 bin
+
+
+def test_interpolation_cyclical_and_curves_known_answers():
+  """Interpolation.apply (odin/backend/interpolation.py:82-99): the cyclical branch shifts the phase
+  by one step and holds vmax for `delay_out` steps at the end of every cycle; hand-evaluated."""
+  from odin_ai_amd import interpolation as ip
+  f = ip.linear(0.0, 1.0, steps=10, delay_in=2, delay_out=3, cyclical=True)
+  want = {0: 0.0, 1: 0.0, 2: 0.1, 5: 0.4, 11: 1.0, 12: 1.0, 14: 1.0, 15: 0.0, 20: 0.4, 29: 1.0, 30: 0.0}
+  for step, v in want.items():
+    assert abs(f(step) - v) < 1e-7, (step, f(step), v)
+  g = ip.linear(1e-6, 1.0, steps=2000)  # AnnealingVAE (beta_vae.py:99-107)
+  assert abs(g(1000) - 0.5000005) < 1e-12 and g(0) == pytest.approx(1e-6, abs=1e-11) and g(5000) == 1.0
+  h = ip.linear(0.0, 2.0, steps=4, delay_in=2)  # non-cyclical: delay, then ramp, then hold
+  assert [round(h(s), 6) for s in (0, 2, 3, 4, 6, 9)] == [0.0, 0.0, 0.5, 1.0, 2.0, 2.0]
+  assert ip.smooth(steps=4)(2) == pytest.approx(0.5) and ip.fade(steps=4)(1) == pytest.approx(0.103515625)
+  assert ip.sine(steps=2)(1) == pytest.approx(0.5) and ip.const(vmax=3.0)(7) == 3.0
+  assert ip.power(length=4, power=2.0)(1) == pytest.approx(0.125) and ip.power(length=4, power=2.0)(3) == pytest.approx(0.875)
+  assert ip.circleIn(steps=5)(3) == pytest.approx(0.2) and ip.powerIn(length=2, power=3.0)(1) == pytest.approx(0.125)

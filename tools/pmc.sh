@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 PMC passes (one counter group per pass) of a short bench.py run
-# usage: tools_pmc.sh <tag> [bench args...]
+# usage: tools/pmc.sh <tag> [bench args...]
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
@@ -9,6 +9,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_
   out=$root/gpurun_out/${tag}_pmc_$name
   mkdir -p $out
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out -o pmc -- python3 $root/bench.py --no-cpu-baseline --steps 20 --warmup 5 "$@" > $out.log 2>&1
-  (cd $root && python tools_pmc_summary.py $out > gpurun_out/${tag}_pmc_$name.txt)
+  (cd $root && python tools/pmc_summary.py $out > gpurun_out/${tag}_pmc_$name.txt)
   rm -rf $out
 done

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02_pmc_traffic.json from the separate rocprofv3 --pmc passes (tools_pmc.sh r02):
+"""profiles/r02_pmc_traffic.json from the separate rocprofv3 --pmc passes (tools/pmc.sh r02):
 HBM traffic per launch of the three largest kernels of the dsprites_betavae_b256 step, corrected as
 MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts 128-byte reads at 64 bytes: doubled;
 WRITE_SIZE exact), next to the algorithmic bytes of the launch."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One training step as a timeline from a rocprofv3 --kernel-trace CSV: start offset, duration,
-stream/queue, kernel (short).  usage: tools_timeline.py <dir> [step_index]"""
+stream/queue, kernel (short).  usage: tools/timeline.py <dir> [step_index]"""
 import csv, glob, re, sys
 root = sys.argv[1]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 200
