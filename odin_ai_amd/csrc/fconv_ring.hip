@@ -68,7 +68,7 @@ struct FRParams {
 
 constexpr int FR_WBYTES = 16 * 8 * 32 * 16;  // weight image: 64 KB
 
-#ifdef ODIN_SIM
+#if defined(ODIN_SIM) || !defined(ODIN_DIAG)  // in-kernel stamps: diagnostics build only (make diag)
 #define FR_STAMP(base, k) ((void)0)
 #else
 #define FR_STAMP(base, k)                                                                        \

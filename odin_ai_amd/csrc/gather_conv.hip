@@ -736,7 +736,7 @@ __device__ __forceinline__ float sigmoid_g(float x) {
   return x >= 0.f ? r : e * r;
 }
 
-#ifdef ODIN_SIM
+#if defined(ODIN_SIM) || !defined(ODIN_DIAG)  // in-kernel stamps: diagnostics build only (make diag)
 #define ODIN_STAMP(k) ((void)0)
 #else
 #define ODIN_STAMP(k)                                                                    \

@@ -178,6 +178,49 @@ __device__ __forceinline__ float odin_run_load1(const OdinRun& R, unsigned off) 
 #endif
 }
 
+// The same with a wave-uniform byte offset added by the scalar unit (buffer `soffset`): the per-lane part
+// of an address is computed ONCE per kernel, the per-tile part is one scalar.  Only the per-lane offset
+// takes part in the range check (as on the hardware): give masked lanes ODIN_OOB_V.
+#define ODIN_OOB_V 0xFFFF0000u
+__device__ __forceinline__ float4 odin_run_load4s(const OdinRun& R, unsigned voff, unsigned soff) {
+#ifdef ODIN_SIM
+  if ((unsigned long long)voff + 16 > R.bytes) return make_float4(0.f, 0.f, 0.f, 0.f);
+  return *reinterpret_cast<const float4*>(R.base + voff + soff);
+#else
+  typedef unsigned int odin_u32x4 __attribute__((ext_vector_type(4)));
+  const odin_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(R.r, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                     __uint_as_float(v.w));
+#endif
+}
+__device__ __forceinline__ float odin_run_load1s(const OdinRun& R, unsigned voff, unsigned soff) {
+#ifdef ODIN_SIM
+  if ((unsigned long long)voff + 4 > R.bytes) return 0.f;
+  return *reinterpret_cast<const float*>(R.base + voff + soff);
+#else
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R.r, voff, soff, 0));
+#endif
+}
+__device__ __forceinline__ void odin_run_store4s(const OdinRun& R, unsigned voff, unsigned soff, float4 v) {
+#ifdef ODIN_SIM
+  if ((unsigned long long)voff + 16 <= R.bytes)
+    *reinterpret_cast<float4*>(const_cast<char*>(R.base) + voff + soff) = v;
+#else
+  typedef unsigned int odin_u32x4 __attribute__((ext_vector_type(4)));
+  odin_u32x4 u;
+  u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(u, R.r, voff, soff, 0);
+#endif
+}
+__device__ __forceinline__ void odin_run_store1s(const OdinRun& R, unsigned voff, unsigned soff, float v) {
+#ifdef ODIN_SIM
+  if ((unsigned long long)voff + 4 <= R.bytes)
+    *reinterpret_cast<float*>(const_cast<char*>(R.base) + voff + soff) = v;
+#else
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), R.r, voff, soff, 0);
+#endif
+}
+
 // range-checked store: lanes with an offset outside [0, bytes) (ODIN_OOB) write nothing -- a
 // predicated store without an exec-mask branch, so it stays inside one scheduling region
 __device__ __forceinline__ void odin_run_store1(const OdinRun& R, unsigned off, float v) {

@@ -56,7 +56,7 @@ struct TPParams {
   long long* stamps;   // diagnostics: s_memtime stamps of workgroup 0 (wave 0: [0,32), wave 4: [32,64))
 };
 
-#ifdef ODIN_SIM
+#if defined(ODIN_SIM) || !defined(ODIN_DIAG)  // in-kernel stamps: diagnostics build only (make diag)
 #define TP_STAMP(k) ((void)0)
 #else
 #define TP_STAMP(k)                                                                               \
@@ -115,7 +115,8 @@ __device__ __forceinline__ void tp_split4(const float4& v, u32x2& h, u32x2& m, u
 
 struct TpItem {
   float4 v;
-  int dst;  // byte offset of the hi-plane store inside the ring (no item: inside the spare slot)
+  int dst;  // byte offset of the hi-plane store inside the ring
+  int ok;   // wave-uniform: this wave has an item (no item: nothing is split or stored)
 };
 
 // EPI 1: bias + ELU; EPI 2: x ELU'(aux) + column sums; EPI 3: fused Bernoulli tail with C1 logit maps
@@ -147,6 +148,12 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   int stamp_i = 0;
   (void)stamp_i;
   TP_STAMP(1);
+#if defined(ODIN_DIAG) && !defined(ODIN_SIM)
+  if (p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    p.stamps[64] = clock64();
+    p.stamps[65] = wall_clock64();
+  }
+#endif
   const int n0 = blockIdx.y * 32;
   const int HP = p.H + 1;
   const int OH = 2 * p.H, OW = 2 * W;
@@ -184,39 +191,50 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   const int f_lds_lane = f_pc * 64 + ((((f_ch4 >> 1) ^ ((f_pc >> 2) & 3))) << 4) + (f_ch4 & 1) * 8;
   const unsigned f_g_lane = (unsigned)((f_px * p.CS + p.ci_off + 4 * f_ch4) * 4);
   const unsigned f_rowbytes = (unsigned)(W * p.CS * 4);
+  // (branch-free on purpose: selects on wave-uniform integers become s_cselect; the compiler turned the
+  // `if`-form of this walk into ~150 scalar instructions with 8 branches per tile, which both waves of a
+  // SIMD executed at the same time -- the matrix pipe idled behind them)
   auto load_fill = [&](TpItem (&it)[2], bool live) {
     const int nrows = live ? need_g0 + RP + 2 - f_g : 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = f_r0 + F_RJ * j;
-      const bool valid = r < nrows;
-      int gi = f_gi + r, b = f_b;
-      if (gi >= HP) { gi -= HP; ++b; }
+      const int valid = r < nrows;
+      int gi = f_gi + r;
+      const int wrap = gi >= HP;
+      gi -= wrap ? HP : 0;
+      const int b = f_b + wrap;
       int slot = f_slot + r;
-      if (slot >= NSLOT) slot -= NSLOT;
-      it[j].dst = valid ? slot * RB + f_lds_lane : NSLOT * RB + lane * 8;  // (no item: the spare slot)
-      const bool real = valid && gi != 0 && b < p.B;  // gi == 0: the zero row between images
-      it[j].v = odin_run_load4(IN, real ? (unsigned)(b * p.H + gi - 1) * f_rowbytes + f_g_lane : ODIN_OOB);
+      slot -= slot >= NSLOT ? NSLOT : 0;
+      // (no item: the spare slot behind the ring, same lane pattern)
+      it[j].dst = (valid ? slot : NSLOT) * RB + f_lds_lane;
+      it[j].ok = valid;
+      const int real = valid & (gi != 0) & (b < p.B);  // gi == 0: the zero row between images
+      const unsigned row_off = real ? (unsigned)(b * p.H + gi - 1) * f_rowbytes : 0xFFFF0000u;
+      it[j].v = odin_run_load4(IN, row_off + f_g_lane);
     }
-    if (live) {
-      f_g += nrows;
-      f_gi += nrows;
-      if (f_gi >= HP) { f_gi -= HP; ++f_b; }
-      f_slot += nrows;
-      if (f_slot >= NSLOT) f_slot -= NSLOT;
-      need_g0 += RP;
-      if (++ft_t == p.tiles_per_img) { ft_t = 0; need_g0 += 1; }
-    }
+    f_g += nrows;
+    f_gi += nrows;
+    const int w2 = f_gi >= HP;
+    f_gi -= w2 ? HP : 0;
+    f_b += w2;
+    f_slot += nrows;
+    f_slot -= f_slot >= NSLOT ? NSLOT : 0;
+    const int seam = live & (ft_t + 1 == p.tiles_per_img);
+    need_g0 += live ? RP + seam : 0;
+    ft_t = live ? (seam ? 0 : ft_t + 1) : ft_t;
   };
-  // (no branch: a wave without an item splits zeros into the spare slot behind the ring, so the
-  // split stays inside the scheduling region of its MFMA step)
+  // (a wave-uniform branch: ~30 VALU + 3 LDS stores per item, and half of the 16 item slots of a tile are
+  // empty -- the kernel is bound by instruction issue, profiles/r03_kpmc_planes_8wave.txt)
   auto store_fill1 = [&](const TpItem& it) {
-    u32x2 h, m, l;
-    tp_split4(it.v, h, m, l);
-    char* d = ring + it.dst;
-    *reinterpret_cast<u32x2*>(d) = h;
-    *reinterpret_cast<u32x2*>(d + PB) = m;
-    *reinterpret_cast<u32x2*>(d + 2 * PB) = l;
+    if (it.ok) {
+      u32x2 h, m, l;
+      tp_split4(it.v, h, m, l);
+      char* d = ring + it.dst;
+      *reinterpret_cast<u32x2*>(d) = h;
+      *reinterpret_cast<u32x2*>(d + PB) = m;
+      *reinterpret_cast<u32x2*>(d + 2 * PB) = l;
+    }
   };
   auto store_fill = [&](const TpItem (&it)[2]) {
     store_fill1(it[0]);
@@ -288,8 +306,14 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   for (int r = 0; r < ((EPI >= 2) ? 16 : 1); ++r) csum[r] = 0.f;
   const float sc = (EPI == 3) ? p.scale[0] : 0.f;
   float llk_lane = 0.f;
-  const OdinRun LG = odin_run(EPI == 3 ? p.logits : nullptr,
-                              (EPI == 3 && p.logits != nullptr) ? (unsigned)((size_t)p.B * OH * OW * C1 * 4) : 0u);
+  // global tensors behind buffer descriptors: the per-lane part of an address once per kernel, one scalar
+  // (`soffset`) per tile
+  const unsigned out_bytes = (unsigned)((size_t)p.B * OH * OW * p.CO * 4);
+  const OdinRun OUT = odin_run(p.out, out_bytes);
+  const OdinRun AUX = odin_run(EPI == 2 ? p.aux : nullptr, EPI == 2 ? out_bytes : 0u);
+  const unsigned tgt_bytes = (EPI == 3) ? (unsigned)((size_t)p.B * OH * OW * C1 * 4) : 0u;
+  const OdinRun TG = odin_run(EPI == 3 ? p.target : nullptr, tgt_bytes);
+  const OdinRun LG = odin_run(EPI == 3 ? p.logits : nullptr, (EPI == 3 && p.logits != nullptr) ? tgt_bytes : 0u);
 
   // ---- prologue: rows of the first tile, then the second tile's into registers ----
   TpItem itA[2], itB[2];
@@ -323,9 +347,13 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
 
   int b_cur = T0 / p.tiles_per_img, t_cur = T0 - b_cur * p.tiles_per_img;
   int sl0 = (HP * b_cur + RP * t_cur) % NSLOT;  // ring slot of the tile's first padded row
+  // this lane's pixel inside the tile's 2 RP output rows: (2 rp + rpar, 2 i + cpw)
+  const unsigned pix_lane = (unsigned)((2 * rp + rpar) * OW + 2 * i_in + cpw);
+  const unsigned out_lane = (pix_lane * p.CO + n0 + 4 * half) * 4, tgt_lane = pix_lane * C1 * 4;
+  const unsigned lg_lane = (half == 0) ? tgt_lane : ODIN_OOB_V;  // the half == 0 lane of a pixel stores its logits
+  unsigned tileP_out = 0, tileP_tgt = 0;  // scalar byte offsets of the previous tile in out / target
   // state of the PREVIOUS tile, whose epilogue rides in the current tile's MFMA stream
   f32x16 pa = f32x16_zero();
-  size_t opixP = 0;
   float4 axP[4], pvP[4];
   float tgtP[(EPI == 3) ? C1 : 1] = {};
 #pragma unroll
@@ -345,8 +373,8 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   auto elu_r = [&](int r) { elu_b(r, bias_r[((EPI == 1 || EPI == 3) && !CL) ? r : 0]); };
   auto store_q = [&](int q) __attribute__((always_inline)) {
     if (DBG & 1) return;
-    *reinterpret_cast<float4*>(p.out + opixP * p.CO + n0 + 8 * q + 4 * half) =
-        make_float4(pa[4 * q], pa[4 * q + 1], pa[4 * q + 2], pa[4 * q + 3]);
+    odin_run_store4s(OUT, out_lane + 32 * q, tileP_out,
+                     make_float4(pa[4 * q], pa[4 * q + 1], pa[4 * q + 2], pa[4 * q + 3]));
   };
   float t_dot = 0.f, lgt = 0.f, eabs = 0.f;  // dot product, logit, exp(-|logit|) of the logit map in flight
   constexpr int N_EPI_OPS = (EPI == 3) ? 12 + 4 * C1 + 8 : 12;
@@ -383,7 +411,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
         if (ph == 1) {
           lgt = tp_pairsum32(t_dot) + b1r[oc];  // the other 16 channels live in lane ^ 32
           eabs = odin_exp2(-LOG2E * fabsf(lgt));
-          odin_run_store1(LG, half == 0 ? (unsigned)((opixP * C1 + oc) * 4) : ODIN_OOB, lgt);
+          odin_run_store1s(LG, lg_lane + 4 * oc, tileP_tgt, lgt);
         }
         if (ph == 2) {
           // log p(x | logit) = x l - softplus(l); the half == 0 lane of a pixel owns the scalar results
@@ -448,7 +476,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     if (ph == 0) {
       lg3[oc] = tp_pairsum32(t3[oc]) + b1r[oc];  // the other 16 channels live in lane ^ 32
       ea3[oc] = odin_exp2(-LOG2E * fabsf(lg3[oc]));
-      odin_run_store1(LG, half == 0 ? (unsigned)((opixP * C1 + oc) * 4) : ODIN_OOB, lg3[oc]);
+      odin_run_store1s(LG, lg_lane + 4 * oc, tileP_tgt, lg3[oc]);
     }
     if (ph == 1) {
       const float sp = fmaxf(lg3[oc], 0.f) + 0.6931471805599453f * odin_log2(1.f + ea3[oc]);
@@ -518,15 +546,21 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
       asm volatile("; llk flush" ::: "memory");
 #endif
       const float tt = odin_wave_sum64_valu(llk_lane);
-      if (lane == 0) llk_red[T & 1][wave] = tt;  // summed over the 8 waves behind the next barrier
+      llk_red[T & 1][wave] = tt;  // (every lane holds the sum) summed over the 8 waves behind the next barrier
       llk_lane = 0.f;
     }
   };
 
   // one tile: loads of tile T + 2's rows, then 8 steps of [6 LDS reads of the next step, 6 MFMAs,
   // slice s of the previous tile's epilogue / of the row stores for tile T + 1]
-  auto run_tile = [&](auto with_epi, int T) {
+  // GB (waves 4-7, the SIMD partners of waves 0-3): the same work with the epilogue ops 16 slots later
+  // and the row stores early, so that the two waves of a SIMD are not in their VALU-dense / scalar
+  // phases at the same time (MI355X_MICROARCH.md, two waves per SIMD, item 9)
+  auto run_tile = [&](auto with_epi, auto group_b, int T) {
     constexpr bool WE = decltype(with_epi)::value;
+    constexpr bool GB = decltype(group_b)::value && !CL;
+    constexpr int ESH = GB ? 16 : 0;                                    // epilogue shift
+    constexpr int SF0 = GB ? 4 : 36, SF1 = GB ? 10 : 42, FL = GB ? 47 : 34;  // row stores, llk flush
     int sa = sl0 + roff_a, sb = sa - 1;
     if (sa >= NSLOT) sa -= NSLOT;
     if (sb >= NSLOT) sb -= NSLOT;
@@ -551,8 +585,8 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     loads(0, fa[0], fb[0]);  // first thing after the barrier: everything else waits behind the MFMAs
     if (WE && CL) cl_top();
     ODIN_SCHED_FENCE();
-    const int oh = 2 * (RP * t_cur + rp) + rpar;
-    const size_t opix = ((size_t)b_cur * OH + oh) * OW + 2 * i_in + cpw;
+    const unsigned tile_pix = (unsigned)((b_cur * OH + 2 * RP * t_cur) * OW);
+    const unsigned tile_out = tile_pix * (unsigned)p.CO * 4u, tile_tgt = tile_pix * (unsigned)C1 * 4u;
     float4 axN[4], pvN[4];
     float tgtN[(EPI == 3) ? C1 : 1] = {};
 #pragma unroll
@@ -579,7 +613,8 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
       if (u == 5) acc = mfma32_bf16(fa[cur][0], fb[cur][0], acc);
       // MFMA m carries: the 8 activation ops (2 x ~6 VALU + 2 transcendentals each) behind every
       // other MFMA of the first 16, the remaining ops one per MFMA, the row stores in steps 6 and 7
-      constexpr int k = m < 16 ? ((m & 1) ? -1 : m / 2) : m - 8;
+      constexpr int me = m - ESH;
+      constexpr int k = me < 0 ? -1 : (me < 16 ? ((me & 1) ? -1 : me / 2) : me - 8);
       if constexpr (WE && !CL && k >= 0 && k < N_EPI_OPS && !(DBG & 4)) epi_op(k);
       if constexpr (WE && CL && !(DBG & 4)) cl_slot(M);
       if (m == 32) load_fill(itB, T + 2 < T1);  // global loads of tile T + 2's rows
@@ -587,26 +622,30 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
         if (EPI == 2) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            axN[q] = *reinterpret_cast<const float4*>(p.aux + opix * p.CO + n0 + 8 * q + 4 * half);
+            axN[q] = odin_run_load4s(AUX, out_lane + 32 * q, tile_out);
         }
         if (EPI == 3) {
 #pragma unroll
-          for (int oc = 0; oc < C1; ++oc) tgtN[oc] = p.target[opix * C1 + oc];
+          for (int oc = 0; oc < C1; ++oc) tgtN[oc] = odin_run_load1s(TG, tgt_lane + 4 * oc, tile_tgt);
         }
         if (ACC) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            pvN[q] = *reinterpret_cast<const float4*>(p.out + opix * p.CO + n0 + 8 * q + 4 * half);
+            pvN[q] = odin_run_load4s(OUT, out_lane + 32 * q, tile_out);
         }
       }
-      if (WE && m == 34) flush_llk(T - 1);
-      if (m == 36) store_fill1(itA[0]);
-      if (m == 42) store_fill1(itA[1]);
+      // (the log-likelihood partial of a sample is flushed once, behind its last tile)
+      if (WE && m == FL && t_cur == 0) flush_llk(T - 1);
+      if (m == SF0) store_fill1(itA[0]);
+      if (m == SF1) store_fill1(itA[1]);
       ODIN_SCHED_FENCE();
-      if (DBG != 0 && (m == 0 || m == 11 || m == 23 || m == 35 || m == 47)) TP_STAMP(12 + (m + 1) / 12);
+#ifdef ODIN_DIAG
+      if (m == 0 || m == 11 || m == 23 || m == 35 || m == 47) TP_STAMP(12 + (m + 1) / 12);
+#endif
     });
     pa = acc;
-    opixP = opix;
+    tileP_out = tile_out;
+    tileP_tgt = tile_tgt;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { axP[q] = axN[q]; pvP[q] = pvN[q]; }
 #pragma unroll
@@ -615,24 +654,32 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     itA[1] = itB[1];
   };
 
-  run_tile(TpNo{}, T0);
-  TP_STAMP(11);
-  __syncthreads();
-  TP_STAMP(10);
-#pragma unroll 1
-  for (int T = T0 + 1; T < T1; ++T) {
-    sl0 += RP;
-    if (++t_cur == p.tiles_per_img) { t_cur = 0; ++b_cur; ++sl0; }
-    if (sl0 >= NSLOT) sl0 -= NSLOT;
-    run_tile(TpYes{}, T);
+  // the persistent tile loop, once per wave group: the branch on the group sits OUTSIDE the loop (a branch
+  // per tile made the register allocator keep both variants' state apart: +45 registers)
+  auto tile_loop = [&](auto group_b) __attribute__((always_inline)) {
+    run_tile(TpNo{}, group_b, T0);
     TP_STAMP(11);
-    __syncthreads();  // every wave is past tile T's rows; tile T + 1's rows are stored
+    __syncthreads();
     TP_STAMP(10);
-    if (EPI == 3 && tid == 0) {
-      const float* q = llk_red[(T - 1) & 1];
-      p.llk_part[T - 1] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+#pragma unroll 1
+    for (int T = T0 + 1; T < T1; ++T) {
+      sl0 += RP;
+      if (++t_cur == p.tiles_per_img) { t_cur = 0; ++b_cur; ++sl0; }
+      if (sl0 >= NSLOT) sl0 -= NSLOT;
+      run_tile(TpYes{}, group_b, T);
+      TP_STAMP(11);
+      __syncthreads();  // every wave is past tile T's rows; tile T + 1's rows are stored
+      TP_STAMP(10);
+      if (EPI == 3 && tid == 0) {
+        // tile T - 1 closed a sample: its slot carries the sample's (this workgroup's share of the) sum,
+        // the other tiles' slots a zero
+        const float* q = llk_red[(T - 1) & 1];
+        p.llk_part[T - 1] =
+            t_cur == 0 ? ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7])) : 0.f;
+      }
     }
-  }
+  };
+  if (!CL && wave >= 4) tile_loop(TpYes{}); else tile_loop(TpNo{});
   if (CL) {
     cl_top();
     tp_static_for<48>([&](auto M) __attribute__((always_inline)) { cl_slot(M); });
@@ -642,6 +689,12 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   }
   flush_llk(T1 - 1);
 
+#if defined(ODIN_DIAG) && !defined(ODIN_SIM)
+  if (p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    p.stamps[66] = clock64();
+    p.stamps[67] = wall_clock64();
+  }
+#endif
   // ---- per-workgroup partial sums: 32 pixel lanes by shuffles, then the 8 waves through LDS ----
   if (EPI >= 2) {
 #pragma unroll
@@ -754,8 +807,8 @@ void odin_tconv_planes_set_stamps(void* buf) { g_tp_stamps = (long long*)buf; }
 // ODIN_SPLIT (any value) and ODIN_NOPLANES select the older instances (gather_conv.hip)
 bool odin_tconv_planes_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt,
                                   int pl, int center, int epi, int C1) {
-  static const bool off = getenv("ODIN_NOPLANES") != nullptr || getenv("ODIN_SPLIT") != nullptr;
-  if (off) return false;
+  // (read per call: the A/B tests switch paths inside one process; a captured graph never comes here)
+  if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT")) return false;
   if (epi == 3 && (CO != 32 || (C1 != 1 && C1 != 3) || CI != 32 || W == 8)) return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && (CI == 32 || CI == 64) && (CO % 32) == 0 &&
          !center && (W == 8 || W == 16 || W == 32) && (H % (64 / W)) == 0 && (size_t)B * H * W * CI * 4 < (1ull << 31) &&

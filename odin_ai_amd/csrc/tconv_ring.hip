@@ -64,7 +64,7 @@ struct TRParams {
   long long* stamps;   // diagnostics: s_memtime stamps of workgroup 0 (consumer wave 0: [0,32), producer wave 8: [32,64))
 };
 
-#ifdef ODIN_SIM
+#if defined(ODIN_SIM) || !defined(ODIN_DIAG)  // in-kernel stamps: diagnostics build only (make diag)
 #define TR_STAMP(base, k) ((void)0)
 #else
 #define TR_STAMP(base, k)                                                                        \

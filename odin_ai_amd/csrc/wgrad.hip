@@ -259,7 +259,7 @@ __device__ __forceinline__ void wdy_commit(const WParams& p, int tid, const floa
   }
 }
 
-#ifdef ODIN_SIM
+#if defined(ODIN_SIM) || !defined(ODIN_DIAG)  // in-kernel stamps: diagnostics build only (make diag)
 #define W_STAMP(k) ((void)0)
 #else
 #define W_STAMP(k)                                                                       \
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(NW_W * 64) void wgrad_kernel(WParams p) {
 // pipe instead of adding to it (at one wave per SIMD they are ~1/3 of the tile time).
 // Tiles are 64 pixels so that two buffers fit the 160 KB LDS.
 // --------------------------------------------------------------------------------------
-#ifdef ODIN_SIM
+#if defined(ODIN_SIM) || !defined(ODIN_DIAG)  // in-kernel stamps: diagnostics build only (make diag)
 #define WS_STAMP(base, k) ((void)0)
 #else
 #define WS_STAMP(base, k)                                                                 \

@@ -367,27 +367,36 @@ int wp_launch(const WPParams& p, dim3 grid, void* stream) {
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    const void* fns[6] = {reinterpret_cast<const void*>(&wgrad_planes_kernel<W>),
-                          reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 1 : 0)>),
-                          reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 2 : 0)>),
-                          reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 4 : 0)>),
-                          reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 8 : 0)>),
-                          reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 16 : 0)>)};
-    for (const void* f : fns)
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
-        (void)hipGetLastError();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<W>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+      (void)hipGetLastError();
     attr_done = true;
   }
-#endif
+#ifdef ODIN_DIAG
+  // diagnostics build only (make diag): instances with parts of the kernel switched off, selected by
+  // ODIN_WP_DBG -- they compute WRONG results and are not in the product library
   if (W == 32) {
-    const char* e = getenv("ODIN_WP_DBG");
-    const int dbg = e ? atoi(e) : 0;
+    static const int dbg = [] { const char* e = getenv("ODIN_WP_DBG"); return e ? atoi(e) : 0; }();
+    static bool dattr = false;
+    if (!dattr) {
+      const void* fns[5] = {reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 1 : 0)>),
+                            reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 2 : 0)>),
+                            reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 4 : 0)>),
+                            reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 8 : 0)>),
+                            reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 16 : 0)>)};
+      for (const void* f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+          (void)hipGetLastError();
+      dattr = true;
+    }
     if (dbg == 1) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 1 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
     if (dbg == 2) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 2 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
     if (dbg == 4) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 4 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
     if (dbg == 8) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 8 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
     if (dbg == 16) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 16 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
   }
+#endif
+#endif
   ODIN_LAUNCH((wgrad_planes_kernel<W>), grid, dim3(512), lds, stream, p);
   return odin_check_launch("wgrad_planes(bf16x3)");
 }
@@ -397,6 +406,7 @@ int wp_launch(const WPParams& p, dim3 grid, void* stream) {
 // fine tensor U [B, H, W, CI], coarse tensor V [B, OH, OW, CO] (the argument order of wgrad.hip's WParams)
 bool odin_wgrad_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
                                   int S, int pt, int pl, int center) {
+  // (read per call: the A/B tests switch paths inside one process; a captured graph never comes here)
   if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT") || getenv("ODIN_NOWPLANES")) return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && !center && (CI % 32) == 0 && (CO % 32) == 0 &&
          H == 2 * OH && W == 2 * OW && (OW == 8 || OW == 16 || OW == 32) && (OH % (32 / OW)) == 0 &&

@@ -18,7 +18,7 @@ def run(kind, B, H, W, Ci, Co, K, S, act='elu'):
   d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, act)
   x = torch.randn(B, H, W, Ci, device=dev); b = torch.zeros(Co, device=dev)
   y = torch.empty(B, OH, OW, Co, device=dev)
-  st = torch.zeros(64, dtype=torch.int64, device=dev)
+  st = torch.zeros(72, dtype=torch.int64, device=dev)
   fn = L.odin_deconv2d_fwd if kind == 'deconv' else L.odin_conv2d_fwd
   for it in range(3):
     st.zero_()
@@ -48,7 +48,7 @@ def run_tail(B, H, W, Ci, Co, K, S, C1=1):
                                 None, C.byref(rows), None, C.byref(d), C1, None)
   llk = torch.empty(B * npart.value, device=dev); slab = torch.empty(rows.value, Co * C1 + C1 + Co, device=dev)
   scale = torch.full((1,), 1.0 / B, device=dev)
-  st = torch.zeros(64, dtype=torch.int64, device=dev)
+  st = torch.zeros(72, dtype=torch.int64, device=dev)
   for it in range(3):
     st.zero_()
     L.odin_debug_set_stamps(st.data_ptr())
@@ -76,7 +76,7 @@ def run_w(B, H, W, Ci, Co, K, S):
   rows = C.c_int(0)
   L.odin_deconv2d_wgrad(None, None, None, C.byref(rows), C.byref(d), None)
   slab = torch.empty(rows.value, K * K * Co * Ci, device=dev)
-  st = torch.zeros(64, dtype=torch.int64, device=dev)
+  st = torch.zeros(72, dtype=torch.int64, device=dev)
   for it in range(3):
     st.zero_()
     L.odin_debug_set_wgrad_stamps(st.data_ptr())
@@ -103,7 +103,7 @@ def run_wd(B, K, N):
   rows = C.c_int(0)
   L.odin_dense_wgrad(None, None, None, C.byref(rows), B, K, N, None)
   slab = torch.empty(rows.value, K * N + N, device=dev)
-  st = torch.zeros(64, dtype=torch.int64, device=dev)
+  st = torch.zeros(72, dtype=torch.int64, device=dev)
   for it in range(3):
     st.zero_()
     L.odin_debug_set_wgrad_stamps(st.data_ptr())

@@ -29,7 +29,7 @@ def run(B, H, W, Ci, Co, K, S):
   for _ in range(20): fn()
   e1.record(); torch.cuda.synchronize()
   us = e0.elapsed_time(e1) / 20 * 1e3
-  st = torch.zeros(64, dtype=torch.int64, device=dev)
+  st = torch.zeros(72, dtype=torch.int64, device=dev)
   for it in range(2):
     st.zero_()
     L.odin_debug_set_stamps(st.data_ptr())

@@ -22,7 +22,7 @@ def timed(fn, n=20):
 
 def stamps(fn, title):
   us = timed(fn)
-  st = torch.zeros(64, dtype=torch.int64, device=dev)
+  st = torch.zeros(72, dtype=torch.int64, device=dev)
   for it in range(2):
     st.zero_()
     L.odin_debug_set_stamps(st.data_ptr())

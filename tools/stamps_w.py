@@ -24,7 +24,7 @@ def run(kind, B, H, W, Ci, Co, K, S):
   rows = C.c_int(0)
   fn(None, None, None, C.byref(rows), C.byref(d), None)
   slab = torch.empty(rows.value, n, device=dev)
-  st = torch.zeros(64, dtype=torch.int64, device=dev)
+  st = torch.zeros(72, dtype=torch.int64, device=dev)
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   for it in range(3):
     fn(x.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d), None)
