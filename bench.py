@@ -171,30 +171,44 @@ def profile_ops(eng, reps=20):
   return out
 
 
-def profile_hbm_kernels(eng, reps=50):
+def profile_hbm_kernels(eng, reps=48):
   """The HBM-bound kernels on the shape north_star quotes (64x64x3, batch 256) and on this
   workload's own shape: fused Bernoulli ELBO fwd+bwd (12 B/element), Gaussian head (20 B/element),
-  flat Adam (28 B/parameter).  HIP events on the launch stream, `reps` back-to-back launches."""
+  flat Adam (28 B/parameter).  HIP events on the launch stream.  Every kernel is timed twice:
+    * `achieved` / `frac`: launches ROTATE through enough distinct buffer sets that the footprint
+      touched between two uses of a line exceeds the 256 MB Infinity Cache (MI355X_MICROARCH.md,
+      Infinity Cache): the bytes really come from and go to HBM;
+    * `cache_hot_*`: the same launch repeated on ONE buffer set (working set < 256 MB: served by the
+      Infinity Cache / L2) -- what the kernel sees inside the training step when its operands were
+      just produced, NOT an HBM figure."""
   import ctypes as C
   lib, dev = eng.lib, eng.device
   st = eng.stream()
+  LLC = 256 * 1024 * 1024
 
-  def timeit(fn):
-    for _ in range(3):
-      fn()
+  def timeit(fns):
+    for f in fns:
+      f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = max(reps // len(fns), 1) * len(fns)
     e0.record()
-    for _ in range(reps):
-      fn()
+    for i in range(n):
+      fns[i % len(fns)]()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e-3
+    return e0.elapsed_time(e1) / n * 1e-3
 
-  def entry(kernel, shape, nbytes, t):
-    return dict(bound='hbm', kernel=kernel, shape=shape, achieved=round(nbytes / t * 1e-9, 1),
-                peak=PEAK_HBM_GBS, unit='GB/s', frac=round(nbytes / t * 1e-9 / PEAK_HBM_GBS, 4),
-                us_per_launch=round(t * 1e6, 2), mbytes_per_launch=round(nbytes * 1e-6, 2))
+  def entry(kernel, shape, nbytes, t_hbm, t_hot, nsets):
+    return dict(bound='hbm', kernel=kernel, shape=shape, achieved=round(nbytes / t_hbm * 1e-9, 1),
+                peak=PEAK_HBM_GBS, unit='GB/s', frac=round(nbytes / t_hbm * 1e-9 / PEAK_HBM_GBS, 4),
+                us_per_launch=round(t_hbm * 1e6, 2), mbytes_per_launch=round(nbytes * 1e-6, 2),
+                buffer_sets=nsets, footprint_mb=round(nsets * nbytes * 1e-6, 1),
+                cache_hot_gbs=round(nbytes / t_hot * 1e-9, 1), cache_hot_us=round(t_hot * 1e6, 2),
+                cache_hot_frac_of_hbm_peak=round(nbytes / t_hot * 1e-9 / PEAK_HBM_GBS, 4))
+
+  def nsets_for(nbytes):
+    return max(2, int(math.ceil(1.25 * LLC / nbytes)))
 
   out = []
   npart = C.c_int(0)
@@ -205,29 +219,95 @@ def profile_hbm_kernels(eng, reps=50):
     shapes.append(own)
   for (B, npix, Cc) in shapes:
     n = npix * Cc
-    lg = torch.randn(B, n, device=dev)
-    x = torch.rand(B, n, device=dev)
-    dl = torch.empty_like(lg)
+    ns = nsets_for(12.0 * B * n)
+    sets = [(torch.randn(B, n, device=dev), torch.rand(B, n, device=dev), torch.empty(B, n, device=dev))
+            for _ in range(ns)]
     lib.odin_elbo_bernoulli_fwd_bwd(None, None, None, None, None, B, n, C.byref(npart), None)
     part = torch.empty(B * npart.value, device=dev)
-    t = timeit(lambda: lib.odin_elbo_bernoulli_fwd_bwd(lg.data_ptr(), x.data_ptr(), part.data_ptr(),
-                                                       dl.data_ptr(), sc, B, n, C.byref(npart), st))
-    out.append(entry('elbo_bernoulli_fwd_bwd', [B, npix, Cc], 12.0 * B * n, t))
-    h = torch.randn(B, npix, 2 * Cc, device=dev)
-    dh = torch.empty_like(h)
+    mk = lambda lg, x, dl: (lambda: lib.odin_elbo_bernoulli_fwd_bwd(
+        lg.data_ptr(), x.data_ptr(), part.data_ptr(), dl.data_ptr(), sc, B, n, C.byref(npart), st))
+    fns = [mk(*t) for t in sets]
+    out.append(entry('elbo_bernoulli_fwd_bwd', [B, npix, Cc], 12.0 * B * n, timeit(fns), timeit(fns[:1]), ns))
+    del sets, fns
+    ns = nsets_for(20.0 * B * n)
+    sets = [(torch.randn(B, npix, 2 * Cc, device=dev), torch.rand(B, n, device=dev),
+             torch.empty(B, npix, 2 * Cc, device=dev)) for _ in range(ns)]
     lib.odin_elbo_gaussian_fwd_bwd(None, None, None, None, None, B, npix, Cc, 1, C.byref(npart), None)
     part = torch.empty(B * npart.value, device=dev)
-    t = timeit(lambda: lib.odin_elbo_gaussian_fwd_bwd(h.data_ptr(), x.data_ptr(), part.data_ptr(),
-                                                      dh.data_ptr(), sc, B, npix, Cc, 1,
-                                                      C.byref(npart), st))
-    out.append(entry('elbo_gaussian_fwd_bwd(softplus1)', [B, npix, Cc], 20.0 * B * n, t))
+    mk = lambda h, x, dh: (lambda: lib.odin_elbo_gaussian_fwd_bwd(
+        h.data_ptr(), x.data_ptr(), part.data_ptr(), dh.data_ptr(), sc, B, npix, Cc, 1, C.byref(npart), st))
+    fns = [mk(*t) for t in sets]
+    out.append(entry('elbo_gaussian_fwd_bwd(softplus1)', [B, npix, Cc], 20.0 * B * n, timeit(fns),
+                     timeit(fns[:1]), ns))
+    del sets, fns
   for n in (eng.params.numel(), 4012004):  # this model; the FactorVAE discriminator (a18)
-    th, g = torch.randn(n, device=dev), torch.randn(n, device=dev) * 1e-3
-    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
-    t = timeit(lambda: lib.odin_adam_step_flat(th.data_ptr(), g.data_ptr(), m.data_ptr(),
-                                               v.data_ptr(), n, eng.hp(0), None, 0.0, None, st))
-    out.append(entry('adam_step_flat', [n], 28.0 * n, t))
+    ns = nsets_for(28.0 * n)
+    sets = [(torch.randn(n, device=dev), torch.randn(n, device=dev) * 1e-3, torch.zeros(n, device=dev),
+             torch.zeros(n, device=dev)) for _ in range(ns)]
+    mk = lambda th, g, m, v: (lambda: lib.odin_adam_step_flat(th.data_ptr(), g.data_ptr(), m.data_ptr(),
+                                                              v.data_ptr(), n, eng.hp(0), None, 0.0, None, st))
+    fns = [mk(*t) for t in sets]
+    out.append(entry('adam_step_flat', [n], 28.0 * n, timeit(fns), timeit(fns[:1]), ns))
+    del sets, fns
+  torch.cuda.empty_cache()
   return out
+
+
+def dominant_rooflines(ops):
+  """(roofline of the dominant kernel, priced on the pipe it executes on; conv/dense stack summary)."""
+  is_split = lambda o: o.get('path', '').endswith('(bf16x3)')
+  dom = max(ops, key=lambda o: o['us'])
+  if is_split(dom):
+    bf16_gflop = 6.0 * dom.get('mfma_gflop', dom['gflop'])
+    roof = dict(bound='mfma', kernel=f"{dom['layer']}:{dom['op']}", path=dom.get('path'),
+                achieved=round(bf16_gflop / dom['us'] * 1e3, 3), peak=PEAK_MFMA_BF16_TFLOPS,
+                unit='TFLOP/s (bf16 FLOPs executed)',
+                frac=round(bf16_gflop / dom['us'] * 1e3 / PEAK_MFMA_BF16_TFLOPS, 4),
+                fp32_equivalent_frac=round(dom['tflops'] / PEAK_MFMA_F32_TFLOPS, 4),
+                us_per_launch=round(dom['us'], 2))
+  else:
+    roof = dict(bound='mfma', kernel=f"{dom['layer']}:{dom['op']}", path=dom.get('path'),
+                achieved=round(dom['tflops'], 3), peak=PEAK_MFMA_F32_TFLOPS, unit='TFLOP/s',
+                frac=round(dom['tflops'] / PEAK_MFMA_F32_TFLOPS, 4), us_per_launch=round(dom['us'], 2))
+  conv_us = sum(o['us'] for o in ops)
+  conv_gf = sum(o['gflop'] for o in ops)
+  stack = dict(us=round(conv_us, 1), gflop=round(conv_gf, 3), tflops=round(conv_gf / conv_us * 1e3, 3),
+               frac=round(conv_gf / conv_us * 1e3 / PEAK_MFMA_F32_TFLOPS, 4))
+  return roof, stack
+
+
+def north_star_3ch(device, steps=50):
+  """The shape north_star states its roofline targets on -- 64x64x3 beta-VAE (beta = 4) at batch 256 =
+  the Shapes3D networks (image_networks.py:560-597) -- measured in the SAME process as the headline
+  workload: step time (HIP-graph replay), conv/dense stack, dominant kernel.  (The ELBO kernel on this
+  shape is `elbo_kernel` / `hbm_kernels[0]` of the main line.)"""
+  from odin_ai_amd.engine import VAEEngine
+  from odin_ai_amd.networks import get_networks
+  nets = get_networks('shapes3d')
+  enc, dec = nets['encoder'].layers, nets['decoder'].layers
+  in_shape, zdim = nets['encoder'].input_shape, nets['latents'].event_shape[0]
+  B = 256
+  eng = VAEEngine(enc, dec, in_shape, zdim, B, device, observation=nets['observation'].posterior, seed=3)
+  init_params_(eng, seed=3)
+  xb = eng.input_buffer()
+  xb.copy_(synthetic_batch('shapes3d', B, in_shape, device, seed=103))
+  step = lambda: eng.train_step(xb, None, lr=1e-3, beta=4.0, global_clipnorm=100.0, use_graph=True)
+  for _ in range(30):
+    step()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    out = step()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  assert math.isfinite(out[0].item()) and eng.flag.item() == 0
+  roof, stack = dominant_rooflines(profile_ops(eng))
+  res = dict(workload='shapes3d_betavae_b256 (64x64x3, beta=4, batch 256)', images_per_sec=round(B * steps / dt, 1),
+             ms_per_step=round(dt / steps * 1e3, 4), steps=steps, conv_stack=stack, roofline=roof,
+             in_step_conv_frac=round(stack['gflop'] / (dt / steps) * 1e-3 / PEAK_MFMA_F32_TFLOPS, 4))
+  del eng
+  torch.cuda.empty_cache()
+  return res
 
 
 def _free_port():
@@ -332,9 +412,14 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-steps', type=int, default=25)
   ap.add_argument('--no-graph', action='store_true')
+  ap.add_argument('--no-north-star-3ch', action='store_true',
+                  help='skip the 64x64x3 beta-VAE (Shapes3D networks) measurement added to the default line')
   ap.add_argument('--profile-ops', action='store_true', help='print a per-kernel timing table')
   ap.add_argument('--dry-run', action='store_true',
                   help='launcher / rendezvous self-test on CPU (gloo): no kernels, no GPU')
+  ap.add_argument('--dp-buckets', type=int, default=0,
+                  help='gradient buckets of the data-parallel step (2: the decoder bucket is all-reduced on a '
+                  'side stream beside the encoder backward; default 1 below 4 ranks, 2 from 4 ranks up)')
   ap.add_argument('--force-dist', action='store_true',
                   help='initialise the RCCL process group even at world size 1, so that the '
                   'data-parallel step (graph A, RCCL all-reduce, graph B) runs on a 1-GPU box')
@@ -369,6 +454,8 @@ def main():
     dist.init_process_group(os.environ.get('ODIN_DIST_BACKEND', 'nccl'), rank=rank,
                             world_size=world, device_id=device)
 
+  if args.dp_buckets:
+    os.environ['ODIN_DP_BUCKETS'] = str(args.dp_buckets)
   from odin_ai_amd.engine import VAEEngine
   from odin_ai_amd.networks import get_networks
   ds, kw, B, beta, kind = WORKLOADS[args.workload]
@@ -383,6 +470,7 @@ def main():
     # discriminator's TC estimate, discriminator step with its own Adam; one graph per iteration
     from odin_ai_amd.vae import FactorVAE
     fv = FactorVAE(device=device, seed=1 + rank, **nets)
+    fv.force_dp = use_dist
     eng = fv._engine(B // 2)
     fv._discriminator(B // 2)
     beta = 1.0
@@ -481,6 +569,13 @@ def main():
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     rccl['replicas_in_sync'] = bool(lo.item() == hi.item())
     rccl['allreduce_us'] = round(time_allreduce(eng), 2)
+    rccl['transport'] = ('RCCL through the C ABI (odin_allreduce_flat, own communicator)'
+                         if eng._comm().native else 'torch.distributed ' + dist.get_backend())
+    rccl['dp_buckets'] = eng.dp_buckets
+    sgs = list(getattr(eng, '_graphs', {}).values()) + [v[0] for v in getattr(fv, '_fgraphs', {}).values()] \
+        if use_graph else []
+    if sgs:
+      rccl['step_segments'] = ''.join('G' if k == 'k' else 'c' for k, _ in sgs[-1].segs)  # G = HIP graph, c = collective
   loss = out[0].item()
   assert math.isfinite(loss), 'training diverged'
   assert eng.flag.item() == 0, 'non-finite gradients were skipped during the timed region'
@@ -576,6 +671,9 @@ def main():
                kind='port', sample=f'{args.cpu_steps} training steps of the same workload '
                f'(batch {B}), torch-CPU fp32 port of the reference step')
 
+  ns3 = None
+  if world == 1 and args.workload == 'dsprites_betavae_b256' and not args.no_north_star_3ch:
+    ns3 = north_star_3ch(device)
   res = dict(metric='VAE train images/sec', value=round(B * world * args.steps / dt, 1),
              unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
              ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling='weak',
@@ -588,8 +686,10 @@ def main():
                          final_loss=round(loss, 4)),
              roofline=roofline, roofline_split=roofline_split, roofline_fp32=roofline_fp32, cpu_baseline=cpu,
              conv_stack=stack,
+             in_step_conv_frac=round(stack['gflop'] / (dt / args.steps) * 1e-3 / PEAK_MFMA_F32_TFLOPS, 4),
              elbo_kernel=hbm[0],
-             hbm_kernels=hbm)
+             hbm_kernels=hbm,
+             north_star_3ch=ns3)
   if rccl is not None:
     res['rccl'] = rccl
   print(json.dumps(res), file=json_out(), flush=True)

@@ -148,6 +148,15 @@ int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, float* llk_
 int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float* llk_part, float* dh,
                                const float* scale, int B, int n_pix, int C, int softplus1,
                                int* n_part_out, void* stream);
+/* MixtureQuantizedLogistic(params, n_components=K, n_channels=C, low=0, high=255,
+ * inputs_domain='sigmoid') (odin/bay/distributions/quantized.py:206-349; built by
+ * _parse_distribution 'mixqlogistic', image_networks.py:72-85): h [B, n_pix, K*n_out] with
+ * n_out = 1 + 2C + C(C-1)/2 (mixture logit | loc | raw scale | channel coefficients per component),
+ * scale = softplus(raw) + e^-7 (:280-282); llk partials per sample, dh = -scale * d log p / d h.
+ * C in {1, 3}, K = 10.  A NULL h is a dry run that only reports n_part. */
+int odin_elbo_mixqlogistic_fwd_bwd(const float* h, const float* x, float* llk_part, float* dh,
+                                   const float* scale, int B, int n_pix, int C, int K,
+                                   int* n_part_out, void* stream);
 /* VAEStep.call / VariationalModel.elbo (variational_autoencoder.py:117-126;
  * odin/bay/vi/_base.py:151-194): llk[b] = sum parts; elbo = llk - beta*kl - tc;
  * out[0]=loss=-mean(elbo), out[1]=mean llk, out[2]=mean beta*kl, out[3]=tc term.
@@ -263,6 +272,26 @@ int odin_stft_mel_db(const float* y, const double* window, const double* twiddle
                      const double* fb_vals, const int32_t* fb_band, float* out, int B,
                      int n_samples, int frame_length, int step_length, int n_fft, int n_mels,
                      double preemph, double top_db, int log_output, void* stream);
+
+/* ---- data parallel (the reference has no distributed path) --------------------
+ * Thin RCCL entry points: one process per GPU, every collective is enqueued on the caller's stream.
+ * The 128-byte id of rank 0 (odin_comm_unique_id = ncclGetUniqueId) is handed to the other ranks by the
+ * launcher (odin_ai_amd/dist.py broadcasts it through the torch.distributed store); odin_comm_init =
+ * ncclCommInitRank.  RCCL is bound at the first call (dlopen of librccl; ODIN_RCCL_LIB overrides the
+ * name): a process that never calls these needs no RCCL.
+ *   odin_allreduce_flat      in-place SUM of the flat fp32 gradient bucket (Networks.optimize would apply
+ *                            ONE gradient per variable, base_networks.py:415-624: the bucket makes the
+ *                            replicas' gradients the global-batch gradient);
+ *   odin_allgather_flat      recv[world * n] <- every rank's send[n] ([B, 3D] posterior rows for
+ *                            total_correlation over the global batch, losses.py:136-157; z' rows for
+ *                            permute_dims, vi/utils.py:262-267);
+ *   odin_reduce_scatter_flat recv[n] <- sum over ranks of send[rank * n ...] (posterior-side TC gradients). */
+int odin_comm_unique_id(void* id128);
+int odin_comm_init(void** comm_out, const void* id128, int rank, int world_size);
+int odin_comm_destroy(void* comm);
+int odin_allreduce_flat(void* comm, float* buf, size_t n, void* stream);
+int odin_allgather_flat(void* comm, const float* send, float* recv, size_t n_per_rank, void* stream);
+int odin_reduce_scatter_flat(void* comm, const float* send, float* recv, size_t n_per_rank, void* stream);
 
 /* diagnostics only: device buffer (>= 64 int64) that receives in-kernel cycle stamps of the
  * conv kernels' workgroup 0 (NULL disables; never set in production) */

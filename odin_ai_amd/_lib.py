@@ -41,6 +41,12 @@ SIGNATURES = {
     'odin_debug_last_path': [],
     'odin_crc32c': [C.c_uint32, P, C.c_size_t],
     'odin_max_slab_rows': [],
+    'odin_comm_unique_id': [P],
+    'odin_comm_init': [C.POINTER(C.c_void_p), P, I, I],
+    'odin_comm_destroy': [P],
+    'odin_allreduce_flat': [P, P, C.c_size_t, P],
+    'odin_allgather_flat': [P, P, P, C.c_size_t, P],
+    'odin_reduce_scatter_flat': [P, P, P, C.c_size_t, P],
     'odin_conv2d_fwd': [P, P, P, P, DP, P],
     'odin_conv2d_dgrad': [P, P, P, I, P, P, IP, DP, P],
     'odin_conv2d_wgrad': [P, P, P, IP, DP, P],
@@ -56,6 +62,7 @@ SIGNATURES = {
     'odin_latent_bwd': [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     'odin_elbo_bernoulli_fwd_bwd': [P, P, P, P, P, I, I, IP, P],
     'odin_elbo_gaussian_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
+    'odin_elbo_mixqlogistic_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
     'odin_elbo_finalize': [P, I, P, P, P, P, P, I, P],
     'odin_mean': [P, I, P, P],
     'odin_total_correlation_fwd_bwd': [P, P, P, P, P, P, P, I, I, P],

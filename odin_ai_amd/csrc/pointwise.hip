@@ -732,6 +732,95 @@ extern "C" int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float*
   return odin_check_launch("elbo_gaussian");
 }
 
+// ---- MixtureQuantizedLogistic(params, n_components = K, n_channels = C, low = 0, high = 255, 'sigmoid')
+// (odin/bay/distributions/quantized.py:206-349; image_networks.py:72-85): h [B, n_pix, K * n_out],
+// n_out = 1 + C + C + C (C - 1) / 2 = (mixture logit | loc | raw scale | channel coefficients) per
+// component.  One lane owns one pixel: log p = logsumexp_k(log_softmax(logit)_k + sum_c log QL_kc(x_c))
+// with loc_ki += sum_{j<i} coef * (2 x_j - 1); the gradient is written through the responsibilities.
+// HBM-bound: 8 B per parameter (read h, write dh) + 4 B per target value.
+template <int C, int K>
+__global__ __launch_bounds__(256) void elbo_mixql_kernel(const float* __restrict__ h,
+                                                        const float* __restrict__ x,
+                                                        float* __restrict__ llk_part,
+                                                        float* __restrict__ dh,
+                                                        const float* __restrict__ scale, int n_pix,
+                                                        int n_part) {
+  constexpr int NCO = C * (C - 1) / 2, NO = 2 * C + NCO + 1;
+  __shared__ float red[4];
+  const int b = blockIdx.x / n_part, part = blockIdx.x - b * n_part;
+  const int pix = part * 256 + threadIdx.x;
+  const float sc = scale[0];
+  float acc = 0.f;
+  if (pix < n_pix) {
+    const size_t pb = (size_t)b * n_pix + pix;
+    const float* hp = h + pb * (K * NO);
+    float* dp = dh + pb * (K * NO);
+    float t[C], xt[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { t[c] = x[pb * C + c]; xt[c] = 2.f * t[c] - 1.f; }
+    float lg[K], comp[K], gl[K][C], gr[K][C];
+    float lmax = -__builtin_inff();
+#pragma unroll
+    for (int k = 0; k < K; ++k) { lg[k] = hp[k * NO]; lmax = fmaxf(lmax, lg[k]); }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) se += expf(lg[k] - lmax);
+    const float lse = lmax + logf(se);
+    float cmax = -__builtin_inff();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float loc = hp[k * NO + 1 + c];
+        const float raw = hp[k * NO + 1 + C + c];
+        // coefficient index of (channel c, earlier channel j): c (c - 1) / 2 + j (the reference's loop order)
+#pragma unroll
+        for (int j = 0; j < c; ++j) loc = fmaf(xt[j], hp[k * NO + 1 + 2 * C + c * (c - 1) / 2 + j], loc);
+        q += qlogistic_elem(loc, raw, t[c], gl[k][c], gr[k][c]);
+      }
+      comp[k] = lg[k] - lse + q;
+      cmax = fmaxf(cmax, comp[k]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) s += expf(comp[k] - cmax);
+    acc = cmax + logf(s);
+    const float inv_s = 1.f / s;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float r = expf(comp[k] - cmax) * inv_s;  // responsibility of component k
+      dp[k * NO] = -(r - expf(lg[k] - lse)) * sc;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        dp[k * NO + 1 + c] = -r * gl[k][c] * sc;
+        dp[k * NO + 1 + C + c] = -r * gr[k][c] * sc;
+#pragma unroll
+        for (int j = 0; j < c; ++j) dp[k * NO + 1 + 2 * C + c * (c - 1) / 2 + j] = -r * gl[k][c] * xt[j] * sc;
+      }
+    }
+  }
+  const float tot = block_sum_256(acc, red);
+  if (threadIdx.x == 0) llk_part[blockIdx.x] = tot;
+}
+
+extern "C" int odin_elbo_mixqlogistic_fwd_bwd(const float* h, const float* x, float* llk_part,
+                                              float* dh, const float* scale, int B, int n_pix, int C,
+                                              int K, int* n_part_out, void* stream) {
+  if (!((C == 1 || C == 3) && K == 10))
+    return odin_fail(-2, "odin_elbo_mixqlogistic_fwd_bwd: 1 or 3 channels, 10 components");
+  const int n_part = (n_pix + 255) / 256;
+  if (n_part_out) *n_part_out = n_part;
+  if (h == nullptr) return 0;  // dry run
+  if (C == 1)
+    ODIN_LAUNCH((elbo_mixql_kernel<1, 10>), dim3(B * n_part), dim3(256), 0, stream, h, x, llk_part, dh, scale,
+                n_pix, n_part);
+  else
+    ODIN_LAUNCH((elbo_mixql_kernel<3, 10>), dim3(B * n_part), dim3(256), 0, stream, h, x, llk_part, dh, scale,
+                n_pix, n_part);
+  return odin_check_launch("elbo_mixqlogistic");
+}
+
 extern "C" int odin_elbo_finalize(const float* llk_part, int n_part, const float* kl,
                                   const float* hyper, const float* tc, float* llk, float* out4,
                                   int B, void* stream) {

@@ -288,6 +288,16 @@ class NetProgram:
 # --------------------------------------------------------------------------------------
 # `softplus1` argument of odin_elbo_gaussian_fwd_bwd per two-parameter observation
 OBS_MODE = {'gaussian': 0, 'gaussian_softplus1': 1, 'qlogistic': 2}
+MIXQL_K = 10  # components of the 'mixqlogistic' observation (image_networks.py:48)
+
+
+def observation_maps(observation: str, C: int) -> int:
+  """parameter maps the decoder emits per pixel for an observation over C channels."""
+  if observation == 'bernoulli':
+    return C
+  if observation == 'mixqlogistic':
+    return MIXQL_K * (2 * C + C * (C - 1) // 2 + 1)
+  return 2 * C
 H_ALPHA, H_B1, H_B2, H_EPS, H_GSCALE, H_INVB, H_KLW, H_BETA, H_TCCOEF, H_TCGRAD = range(10)
 N_HYPER = 16
 
@@ -295,7 +305,7 @@ N_HYPER = 16
 class VAEEngine:
   """encoder -> q(z|x) -> decoder -> ELBO -> backward -> Adam for a FIXED batch size.
 
-  observation: 'bernoulli' | 'gaussian' | 'gaussian_softplus1' | 'qlogistic'
+  observation: 'bernoulli' | 'gaussian' | 'gaussian_softplus1' | 'qlogistic' | 'mixqlogistic'
   tc: None | 'betatc' (total_correlation, weight (beta-1))
   """
 
@@ -317,6 +327,9 @@ class VAEEngine:
     # data-parallel step (gradient-bucket all-reduce between backward and Adam); `force_dp` runs
     # that path at world size 1 too (RCCL on a 1-GPU box)
     self.is_dp = self.world_size > 1 or bool(force_dp)
+    # beta-TC: the global-batch estimator (all-gather | shard kernel | reduce-scatter) whenever the step is
+    # data parallel -- also at world size 1 under `force_dp`, which is how a 1-GPU box exercises it
+    self.tc_sharded = tc == 'betatc' and self.is_dp
     f32 = dict(dtype=torch.float32, device=self.device)
     # ---- parameters ----
     self.layout = ParamLayout()
@@ -329,10 +342,7 @@ class VAEEngine:
     self.layout.pad_to(4)
     self.out_shape = do
     C_in = self.in_shape[-1]
-    if observation == 'bernoulli':
-      assert tuple(do) == self.in_shape, (do, self.in_shape)
-    else:
-      assert tuple(do) == self.in_shape[:-1] + (2 * C_in,), (do, self.in_shape)
+    assert tuple(do) == self.in_shape[:-1] + (observation_maps(observation, C_in),), (do, self.in_shape)
     n = self.layout.size
     self.params = params if params is not None else torch.zeros(n, **f32)
     assert self.params.numel() == n
@@ -363,6 +373,10 @@ class VAEEngine:
     if observation == 'bernoulli':
       self.lib.odin_elbo_bernoulli_fwd_bwd(None, None, None, None, None, B, n_per, C.byref(npart),
                                            None)
+    elif observation == 'mixqlogistic':
+      Cc = self.in_shape[-1]
+      self.lib.odin_elbo_mixqlogistic_fwd_bwd(None, None, None, None, None, B, n_per // Cc, Cc,
+                                              MIXQL_K, C.byref(npart), None)
     else:
       Cc = self.in_shape[-1]
       self.lib.odin_elbo_gaussian_fwd_bwd(None, None, None, None, None, B, n_per // Cc, Cc,
@@ -381,7 +395,7 @@ class VAEEngine:
       self.tc_dz = torch.empty(B, D, **f32)
       self.tc_dloc = torch.empty(B, D, **f32)
       self.tc_dscale = torch.empty(B, D, **f32)
-      if self.world_size > 1:
+      if self.tc_sharded:
         # global-batch estimator under data parallelism: all-gather (p | z), this rank's
         # rows against every posterior, reduce-scatter of the posterior-side partial gradients
         Bg = B * self.world_size
@@ -425,6 +439,19 @@ class VAEEngine:
         _os.environ.get('ODIN_OVERLAP_WGRAD', '0'), None)
     self.graph = None
     self._jobs_keepalive = None
+    # data parallel: collectives through `dist.Comm` (RCCL via the C ABI on a GPU); gradient buckets:
+    # 2 = the decoder's share of the flat gradient buffer is all-reduced on a side stream while the
+    # encoder's backward pass runs (ring all-reduce over xGMI is latency-bound at these sizes: worth it
+    # from 4 ranks up; ODIN_DP_BUCKETS overrides)
+    self.comm = None
+    self.dp_buckets = int(_os.environ.get('ODIN_DP_BUCKETS', '0')) or (2 if self.world_size >= 4 else 1)
+    self.dec_start = min(o for k, _, o in self.layout.entries if k[0] == 'dec')
+
+  def _comm(self):
+    if self.comm is None:
+      from .dist import Comm
+      self.comm = Comm(self.lib, self.device)
+    return self.comm
 
   def set_kl_form(self, analytic, reverse=True):
     if not reverse and not analytic:
@@ -560,6 +587,11 @@ class VAEEngine:
       lib.odin_elbo_bernoulli_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
                                       gl.data_ptr(), self.hp(H_INVB), B, self.n_per,
                                       C.byref(npart), st)
+    elif self.observation == 'mixqlogistic':
+      Cc = self.in_shape[-1]
+      lib.odin_elbo_mixqlogistic_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
+                                         gl.data_ptr(), self.hp(H_INVB), B, self.n_per // Cc, Cc,
+                                         MIXQL_K, C.byref(npart), st)
     else:
       Cc = self.in_shape[-1]
       lib.odin_elbo_gaussian_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
@@ -571,7 +603,8 @@ class VAEEngine:
 
   # ---- forward -----------------------------------------------------------------------
   def forward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, st=None,
-              fused: bool = True, tc_ptr: Optional[int] = None, finalize: bool = True):
+              fused: bool = True, tc_ptr: Optional[int] = None, finalize: bool = True,
+              tc_split: bool = False):
     """Runs encode -> reparameterise -> decode -> ELBO (+ dlogits).  `eps=None` draws the
     noise on device from the Philox stream (seed, step)."""
     lib, B, D = self.lib, self.B, self.D
@@ -617,6 +650,11 @@ class VAEEngine:
       lib.odin_elbo_bernoulli_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
                                       gl.data_ptr(), self.hp(H_INVB), B, self.n_per,
                                       C.byref(npart), st)
+    elif self.observation == 'mixqlogistic':
+      Cc = self.in_shape[-1]
+      lib.odin_elbo_mixqlogistic_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
+                                         gl.data_ptr(), self.hp(H_INVB), B, self.n_per // Cc, Cc,
+                                         MIXQL_K, C.byref(npart), st)
     else:
       Cc = self.in_shape[-1]
       lib.odin_elbo_gaussian_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
@@ -625,8 +663,17 @@ class VAEEngine:
                                      C.byref(npart), st)
     self.n_part = npart.value
     tcp = None
-    if self.tc_mode == 'betatc' and self.world_size > 1:
-      self._total_correlation_sharded(st)
+    if self.tc_sharded and tc_split:
+      # segmented step: only the local part here; the caller runs tc_gather | tc_shard | tc_scatter and
+      # then finalize(tc_ptr) (train_step's program)
+      self._tc_pack()
+      self._llk_part_used = llk_part
+      return h_d
+    if self.tc_sharded:
+      self._tc_pack()
+      self._tc_gather()
+      self._tc_shard(st)
+      self._tc_scatter()
       tcp = self.tc_ws.data_ptr()
     elif self.tc_mode == 'betatc':
       lib.odin_total_correlation_fwd_bwd(self.z.data_ptr(), self.p.data_ptr(),
@@ -643,36 +690,32 @@ class VAEEngine:
                              st)
     return h_d
 
-  def _total_correlation_sharded(self, st):
-    """total_correlation over the GLOBAL batch (losses.py:136-157 couples all pairs): one
-    all-gather of [B, 3D], the shard kernel, a reduce-scatter of the two [B_global, D]
-    posterior-side gradient planes and a scalar all-reduce for the reported value.  Identical
-    to a single GPU holding the whole batch."""
-    import torch.distributed as dist
-    lib, B, D, W = self.lib, self.B, self.D, self.world_size
-    gloo = dist.get_backend() == 'gloo'  # (CPU tests: gloo has no reduce_scatter)
+  # total_correlation over the GLOBAL batch (losses.py:136-157 couples all pairs): one all-gather of
+  # [B, 3D], the shard kernel, a reduce-scatter of the two [B_global, D] posterior-side gradient planes and a
+  # scalar all-reduce for the reported value.  Identical to a single GPU holding the whole batch.  Four
+  # pieces so that the step can be replayed as graphs around the two collectives.
+  def _tc_pack(self):
+    D = self.D
     self.tc_pz_local[:, :2 * D].copy_(self.p)
     self.tc_pz_local[:, 2 * D:].copy_(self.z)
-    if gloo:
-      parts = list(self.tc_pz_all.view(W, B, 3 * D).unbind(0))
-      dist.all_gather(parts, self.tc_pz_local)
-    else:
-      dist.all_gather_into_tensor(self.tc_pz_all, self.tc_pz_local)
+
+  def _tc_gather(self):
+    self._comm().all_gather(self.tc_pz_all.view(-1), self.tc_pz_local.view(-1))
+
+  def _tc_shard(self, st=None):
+    lib, B, D, W = self.lib, self.B, self.D, self.world_size
+    st = self.stream() if st is None else st
     self.tc_p_all.copy_(self.tc_pz_all[:, :2 * D])
-    Bg = B * W
     dl, ds = self.tc_part_all[0], self.tc_part_all[1]  # [Bg, D] planes
     lib.odin_total_correlation_shard(self.z.data_ptr(), self.tc_p_all.data_ptr(),
                                      self.tc_ws.data_ptr(), self.tc_dz.data_ptr(), dl.data_ptr(),
-                                     ds.data_ptr(), self.hp(H_TCGRAD), B, Bg, D, st)
-    if gloo:
-      dist.all_reduce(self.tc_part_all)
-      r = dist.get_rank()
-      self.tc_dloc.copy_(dl[r * B:(r + 1) * B])
-      self.tc_dscale.copy_(ds[r * B:(r + 1) * B])
-    else:
-      dist.reduce_scatter_tensor(self.tc_dloc, dl, op=dist.ReduceOp.SUM)
-      dist.reduce_scatter_tensor(self.tc_dscale, ds, op=dist.ReduceOp.SUM)
-    dist.all_reduce(self.tc_ws[:1], op=dist.ReduceOp.SUM)
+                                     ds.data_ptr(), self.hp(H_TCGRAD), B, B * W, D, st)
+
+  def _tc_scatter(self):
+    c = self._comm()
+    c.reduce_scatter(self.tc_dloc.view(-1), self.tc_part_all[0].view(-1))
+    c.reduce_scatter(self.tc_dscale.view(-1), self.tc_part_all[1].view(-1))
+    c.all_reduce(self.tc_ws[:1])
 
   def finalize(self, tc_ptr: Optional[int] = None, st=None):
     st = self.stream() if st is None else st
@@ -707,10 +750,28 @@ class VAEEngine:
 
     return fork, join
 
-  def backward(self, st=None, extra_dz: Optional[torch.Tensor] = None):
+  def backward(self, st=None, extra_dz: Optional[torch.Tensor] = None, phase: Optional[str] = None):
+    """phase None: the whole backward pass and ONE slab reduction.  'dec' / 'enc': the decoder's share
+    (down to dz) / the rest, each followed by the reduction of its own slabs -- the two-bucket
+    data-parallel step all-reduces the decoder's gradients while 'enc' runs."""
     lib, B, D = self.lib, self.B, self.D
     st = self.stream() if st is None else st
-    fork, join = self._fork()
+    fork, join = self._fork() if phase is None else (None, (lambda: None))
+    if phase == 'enc':
+      jobs = []
+      late_jobs = []
+      early = False
+    else:
+      jobs, late_jobs, early = self._backward_dec(st, fork)
+      if phase == 'dec':
+        arr = (ReduceJob * len(jobs))(*jobs)
+        self._jobs_keepalive0 = arr
+        lib.odin_slab_reduce(arr, len(jobs), st)
+        return
+    self._backward_enc(st, extra_dz, fork, join, jobs, late_jobs, early)
+
+  def _backward_dec(self, st, fork):
+    lib, B, D = self.lib, self.B, self.D
     late_jobs: list = []  # slabs written on side streams
     early = fork is not None and self.early_reduce
     if self._used_fused:
@@ -736,6 +797,10 @@ class VAEEngine:
       self._jobs_keepalive0 = arr0
       lib.odin_slab_reduce(arr0, len(jobs), fork(-3))
       jobs = []
+    return jobs, late_jobs, early
+
+  def _backward_enc(self, st, extra_dz, fork, join, jobs, late_jobs, early):
+    lib, B, D = self.lib, self.B, self.D
     dzx = extra_dz.data_ptr() if extra_dz is not None else None
     if self.tc_mode == 'betatc':
       assert extra_dz is None
@@ -816,12 +881,54 @@ class VAEEngine:
                             self.v.data_ptr(), self.params.numel(), self.hp(H_ALPHA), None,
                             0.0, self.flag.data_ptr(), st)
 
-  def allreduce(self):
+  def allreduce(self, lo: int = 0, hi: Optional[int] = None):
+    """SUM all-reduce of (a range of) the flat gradient buffer over the ranks"""
     if self.is_dp:
-      import torch.distributed as dist
-      dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+      self._comm().all_reduce(self.grads[lo:hi])
 
   # ---- one optimisation step ---------------------------------------------------------
+  def step_program(self, x, eps, pol):
+    """The launch program of one step: [('k', fn) kernels | ('c', fn) collective].  Single GPU: all
+    kernels.  Data parallel: ... backward | all-reduce | update, with the decoder's gradient bucket
+    reduced on a side stream beside the encoder's backward pass when dp_buckets == 2; beta-TC under
+    data parallelism adds all-gather and reduce-scatter around the total-correlation shard kernel."""
+    P = []
+    tc_dp = self.tc_sharded
+    if tc_dp:
+      P.append(('k', lambda: self.forward(x, eps, tc_split=True)))
+      P.append(('c', self._tc_gather))
+      P.append(('k', self._tc_shard))
+      P.append(('c', self._tc_scatter))
+      P.append(('k', lambda: self.finalize(self.tc_ws.data_ptr())))
+    else:
+      P.append(('k', lambda: self.forward(x, eps)))
+    if self.is_dp and self.dp_buckets >= 2:
+      cur = lambda: torch.cuda.current_stream(self.device)
+      side = self.side_stream  # (None on the CPU: the two buckets reduce one after the other)
+
+      def reduce_dec_async():
+        if side is None:
+          return self.allreduce(self.dec_start, None)
+        side.wait_stream(cur())
+        with torch.cuda.stream(side):
+          self.allreduce(self.dec_start, None)
+
+      def reduce_enc_and_join():
+        self.allreduce(0, self.dec_start)
+        if side is not None:
+          cur().wait_stream(side)
+
+      P.append(('k', lambda: self.backward(phase='dec')))
+      P.append(('c', reduce_dec_async))
+      P.append(('k', lambda: self.backward(phase='enc')))
+      P.append(('c', reduce_enc_and_join))
+    else:
+      P.append(('k', self.backward))
+      if self.is_dp:
+        P.append(('c', self.allreduce))
+    P.append(('k', lambda: self._update(pol)))
+    return P
+
   def train_step(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, lr=1e-3, beta=1.0,
                  global_clipnorm: Optional[float] = None, use_graph: bool = False,
                  clipnorm: Optional[float] = None, clipvalue: Optional[float] = None,
@@ -833,15 +940,11 @@ class VAEEngine:
     self.step_count += 1
     self.set_hyper(lr=lr, beta=beta, skip_enable=self.step_count >= int(when_skip_update))
     pol = (global_clipnorm, clipnorm, clipvalue, skip_update_threshold, bool(check_nan))
-    if use_graph and self.device.type == 'cuda' and not (self.tc_mode == 'betatc' and
-                                                          self.world_size > 1):
-      # (beta-TC under data parallelism has collectives INSIDE its forward pass: eager launches)
+    if use_graph and self.device.type == 'cuda':
       self._graph_step(x, eps, pol)
     else:
-      self.forward(x, eps)
-      self.backward()
-      self.allreduce()
-      self._update(pol)
+      for _, fn in self.step_program(x, eps, pol):
+        fn()
     return self.out4
 
   def _update(self, pol):
@@ -858,14 +961,16 @@ class VAEEngine:
     return self.x_static
 
   def _graph_step(self, x, eps, pol):
-    """Capture the step once into HIP graphs, replay afterwards.  Single GPU: ONE graph
-    (forward + backward + slab reduction + policies + Adam).  Data parallel: graph A = forward +
-    backward + slab reduction, then ONE RCCL all-reduce of the flat gradient bucket (eager, on the
-    same stream), then graph B = policies + Adam.  The input batch is read from a static buffer;
-    eps comes from the on-device Philox stream unless given explicitly.  Everything a capture
-    bakes in (clip values, KL form, free bits, explicit-eps mode) is part of the graph's key:
-    changing any of them captures a new graph instead of silently replaying the old one."""
-    key = (pol, self.analytic, self.free_bits, eps is not None)
+    """Capture the step once into HIP graphs, replay afterwards.  Single GPU: ONE graph (forward +
+    backward + slab reduction + policies + Adam).  Data parallel: the kernel segments of
+    `step_program` as one graph each, the RCCL collectives between them eager on the same stream
+    (A | all-reduce | B; with beta-TC: A | all-gather | B | reduce-scatter | C | all-reduce | D).  The input
+    batch is read from a static buffer; eps comes from the on-device Philox stream unless given
+    explicitly.  Everything a capture bakes in (clip values, KL form, free bits, explicit-eps mode,
+    bucket count) is part of the graph's key: changing any of them captures a new graph instead of
+    silently replaying the old one."""
+    from .dist import SegmentedGraph
+    key = (pol, self.analytic, self.free_bits, eps is not None, self.dp_buckets)
     if not hasattr(self, '_graphs'):
       self._graphs = {}
     if key not in self._graphs:
@@ -874,39 +979,27 @@ class VAEEngine:
         self.x_static.copy_(x)
       if eps is not None:
         self.eps.copy_(eps)
-      # warm-up outside capture (first-call attribute setup, lazy allocations)
+      ex = eps is not None
+      sg = SegmentedGraph(self.device, self.step_program(self.x_static, self.eps if ex else None, pol))
+      # warm-up outside capture (first-call attribute setup, lazy allocations, communicator set-up)
       cap = torch.cuda.Stream(self.device)
       cap.wait_stream(torch.cuda.current_stream(self.device))
       saved = (self.params.clone(), self.m.clone(), self.v.clone(), self.flag.clone(),
                self.skipped_update.clone())
-      ex = eps is not None
       with torch.cuda.stream(cap):
-        self.forward(self.x_static, self.eps if ex else None)
-        self.backward()
-        self._update(pol)
+        sg.run_eager()
         # the warm-up step must not count: restore the optimiser state it touched
         self.params.copy_(saved[0]); self.m.copy_(saved[1]); self.v.copy_(saved[2])
         self.flag.copy_(saved[3]); self.skipped_update.copy_(saved[4])
       torch.cuda.current_stream(self.device).wait_stream(cap)
-      ga = torch.cuda.CUDAGraph()
-      gb = None
-      with torch.cuda.graph(ga, stream=cap, capture_error_mode='thread_local'):
-        self.forward(self.x_static, self.eps if ex else None)
-        self.backward()
-        if not self.is_dp:
-          self._update(pol)
-      if self.is_dp:
-        gb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gb, stream=cap, capture_error_mode='thread_local'):
-          self._update(pol)
-      self._graphs[key] = (ga, gb)
-      self.graph = ga
-    ga, gb = self._graphs[key]
+      if self.side_stream is not None:
+        torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
+      sg.capture(cap)
+      self._graphs[key] = sg
+      self.graph = sg.graphs[0]
+    sg = self._graphs[key]
     if x.data_ptr() != self.x_static.data_ptr():  # a producer may write the static buffer directly
       self.x_static.copy_(x, non_blocking=True)
     if eps is not None:
       self.eps.copy_(eps, non_blocking=True)
-    ga.replay()
-    if gb is not None:
-      self.allreduce()
-      gb.replay()
+    sg.replay()

@@ -59,22 +59,37 @@ class RVconf:
 
 
 _OBS_PARAMS = {'bernoulli': 1, 'gaussian': 2, 'gaus': 2, 'normal': 2, 'gaussian_softplus1': 2,
-               'qlogistic': 2}
+               'qlogistic': 2, 'mixqlogistic': None}
 
 
-def _observation(input_shape, distribution: str) -> Tuple[int, RVconf]:
-  """_parse_distribution (image_networks.py:46-102): number of parameter maps the decoder's
-  last 1x1 conv emits and the observation description (projection=False: the logits /
-  (loc, scale) are the decoder output itself)."""
+def mixqlogistic_params_size(n_components: int, n_channels: int) -> int:
+  """MixtureQuantizedLogistic.params_size (quantized.py:288-292)."""
+  return int((n_channels * 2 + n_channels * (n_channels - 1) // 2 + 1) * n_components)
+
+
+def _observation(input_shape, distribution: str, n_components: int = 10) -> Tuple[int, RVconf]:
+  """_parse_distribution (image_networks.py:46-102): number of maps the decoder's last 1x1 conv
+  emits IN TOTAL and the observation description (projection=False: the logits / (loc, scale) /
+  mixture parameters are the decoder output itself).
+
+  'mixqlogistic': the reference sizes the head as n_channels * (params_size // n_channels)
+  (:73-75,:261 `filters=n_channels * n_params`), which equals params_size for 1-channel images
+  (30 maps) but gives 99 maps for RGB where MixtureQuantizedLogistic asserts 100 (quantized.py:262-265)
+  -- the RGB model cannot be built as shipped; the head here emits params_size maps, the intended
+  model."""
   distribution = str(distribution).lower()
   if distribution not in _OBS_PARAMS:
     raise ValueError(
         f"observation {distribution!r} is outside this build's scope "
-        f"(supported: bernoulli, gaussian, gaussian_softplus1, qlogistic; the 10-component "
-        f"'mixqlogistic' (quantized.py:206-330) is not built)")
+        f"(supported: bernoulli, gaussian, gaussian_softplus1, qlogistic, mixqlogistic)")
   name = {'gaus': 'gaussian', 'normal': 'gaussian'}.get(distribution, distribution)
-  return _OBS_PARAMS[distribution], RVconf(tuple(input_shape), name, projection=False,
-                                           name='image')
+  C = int(input_shape[-1])
+  if distribution == 'mixqlogistic':
+    if C not in (1, 3) or int(n_components) != 10:
+      raise ValueError('mixqlogistic: 1 or 3 channels, 10 components (the HIP kernel instances)')
+    return mixqlogistic_params_size(n_components, C), RVconf(
+        tuple(input_shape), name, projection=False, name='image', kwargs=dict(n_components=int(n_components)))
+  return C * _OBS_PARAMS[distribution], RVconf(tuple(input_shape), name, projection=False, name='image')
 
 
 def dsprites_networks(qz='mvndiag', zdim=None, activation='elu', is_semi_supervised=False,
@@ -88,14 +103,14 @@ def dsprites_networks(qz='mvndiag', zdim=None, activation='elu', is_semi_supervi
   if proj_dim is None:
     proj_dim = 128 if n_channels == 1 else 256
   input_shape = (64, 64, int(n_channels))
-  n_params, observation = _observation(input_shape, distribution)
+  n_params, observation = _observation(input_shape, distribution, kwargs.get('n_components', 10))
   a = activation
   enc = ([('center',)] if centerize_image else []) + [
       ('conv', 32, 4, 2, a), ('conv', 32, 4, 2, a), ('conv', 64, 4, 2, a), ('conv', 64, 4, 2, a),
       ('flatten',), ('dense', proj_dim, 'linear')]
   dec = [('dense', proj_dim, 'linear'), ('reshape', (4, 4, proj_dim // 16)),
          ('deconv', 64, 4, 2, a), ('deconv', 64, 4, 2, a), ('deconv', 32, 4, 2, a),
-         ('deconv', 32, 4, 2, a), ('conv', n_channels * n_params, 1, 1, 'linear')]
+         ('deconv', 32, 4, 2, a), ('conv', n_params, 1, 1, 'linear')]
   enc_names = ['encoder0', 'encoder1', 'encoder2', 'encoder3', 'encoder_proj']
   dec_names = ['decoder_proj', 'decoder1', 'decoder2', 'decoder3', 'decoder4', 'decoder6']
   return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape, enc_names),
@@ -125,14 +140,14 @@ def celeba_networks(qz='mvndiag', zdim=None, activation='elu', is_semi_supervise
   if zdim is None:
     zdim = 45
   input_shape = (64, 64, n_channels)
-  n_params, observation = _observation(input_shape, distribution)
+  n_params, observation = _observation(input_shape, distribution, kwargs.get('n_components', 10))
   a = activation
   enc = ([('center',)] if centerize_image else []) + [
       ('conv', 32, 4, 2, a), ('conv', 32, 4, 2, a), ('conv', 64, 4, 2, a), ('conv', 64, 4, 1, a),
       ('flatten',), ('dense', 512, 'linear')]
   dec = [('dense', 512, 'linear'), ('reshape', (8, 8, 8)), ('deconv', 64, 4, 1, a),
          ('deconv', 64, 4, 2, a), ('deconv', 32, 4, 2, a), ('deconv', 32, 4, 2, a),
-         ('conv', n_channels * n_params, 1, 1, 'linear')]
+         ('conv', n_params, 1, 1, 'linear')]
   enc_names = ['encoder0', 'encoder1', 'encoder2', 'encoder3', 'encoder_proj']
   dec_names = ['decoder_proj', 'decoder1', 'decoder2', 'decoder3', 'decoder4', 'decoder5']
   return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape, enc_names),
@@ -150,14 +165,14 @@ def mnist_networks(qz='mvndiag', zdim=None, activation='elu', is_semi_supervised
   if zdim is None:
     zdim = 32
   input_shape = (28, 28, n_channels)
-  n_params, observation = _observation(input_shape, distribution)
+  n_params, observation = _observation(input_shape, distribution, kwargs.get('n_components', 10))
   a = activation
   enc = ([('center',)] if centerize_image else []) + [
       ('conv', 32, 5, 1, a), ('conv', 32, 5, 2, a), ('conv', 64, 5, 1, a), ('conv', 64, 5, 2, a),
       ('flatten',), ('dense', 196, 'linear')]
   dec = [('dense', 196, 'linear'), ('reshape', (7, 7, 4)), ('deconv', 64, 5, 2, a),
          ('conv', 64, 5, 1, a), ('deconv', 32, 5, 2, a), ('conv', 32, 5, 1, a),
-         ('conv', n_channels * n_params, 1, 1, 'linear')]
+         ('conv', n_params, 1, 1, 'linear')]
   enc_names = ['encoder0', 'encoder1', 'encoder2', 'encoder3', 'encoder_proj']
   dec_names = ['decoder_proj', 'decoder2', 'decoder3', 'decoder4', 'decoder5', 'decoder6']
   return dict(encoder=SequentialNetwork(enc, 'Encoder', input_shape, enc_names),
@@ -177,12 +192,12 @@ def dense_networks(input_shape=(28, 28, 1), zdim=16, units=(512, 512), activatio
   n = 1
   for i in input_shape:
     n *= i
-  n_params, observation = _observation(input_shape, distribution)
+  n_params, observation = _observation(input_shape, distribution, kwargs.get('n_components', 10))
   observation.projection = True
   enc = [('flatten',)] + [('dense', u, activation) for u in units]
   dec = [('dense', u, activation) for u in units] + [
-      ('dense', n * n_params, 'linear'),
-      ('reshape', tuple(input_shape[:-1]) + (input_shape[-1] * n_params,))]
+      ('dense', (n // input_shape[-1]) * n_params, 'linear'),
+      ('reshape', tuple(input_shape[:-1]) + (n_params,))]
   return dict(encoder=SequentialNetwork(enc, 'Encoder', tuple(input_shape)),
               decoder=SequentialNetwork(dec, 'Decoder', (zdim,)), observation=observation,
               latents=RVconf((zdim,), 'mvndiag', projection=True, name='latents'))

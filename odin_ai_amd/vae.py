@@ -185,6 +185,10 @@ class QuantizedLogisticObservation:
     return torch.where(j < 255.0, r, torch.full_like(r, -float('inf')))
 
   def log_prob(self, x):
+    e = self.log_prob_elem(x)
+    return e.reshape(e.shape[0], -1).sum(1)
+
+  def log_prob_elem(self, x):
     y = x * 255.0
     lsy, lsy1 = self._logsf(torch.ceil(y)), self._logsf(torch.ceil(y - 1.0))
     lcy, lcy1 = self._logcdf(torch.floor(y)), self._logcdf(torch.floor(y - 1.0))
@@ -193,14 +197,69 @@ class QuantizedLogisticObservation:
     fin = torch.isfinite(small)
     d = torch.where(fin, big - small, torch.ones_like(big))
     l1m = torch.where(d < math.log(2.0), torch.log(-torch.expm1(-d)), torch.log1p(-torch.exp(-d)))
-    e = big + torch.where(fin, l1m, torch.zeros_like(l1m))
-    return e.reshape(e.shape[0], -1).sum(1)
+    return big + torch.where(fin, l1m, torch.zeros_like(l1m))
 
   def sample(self, n=None):
     shp = tuple(self.loc.shape) if n is None else (int(n),) + tuple(self.loc.shape)
     u = torch.rand(shp, device=self.loc.device).clamp_(1e-6, 1 - 1e-6)
     xs = self.loc + self.scale * (torch.log(u) - torch.log1p(-u)) - 0.5  # Logistic shifted by -1/2
     return torch.ceil(xs).clamp_(0.0, 255.0) / 255.0
+
+
+class MixtureQuantizedLogisticObservation:
+  """MixtureQuantizedLogistic(params, n_components=10, n_channels=C, low=0, high=255,
+  inputs_domain='sigmoid') (distributions/quantized.py:206-381; image_networks.py:72-85): the
+  decoder's K * (1 + 2C + C(C-1)/2) maps are (mixture logit | loc | raw scale | channel coefficients)
+  per component."""
+
+  def __init__(self, h: torch.Tensor, n_channels: int, n_components: int = 10):
+    C, K = int(n_channels), int(n_components)
+    no = 2 * C + C * (C - 1) // 2 + 1
+    assert h.shape[-1] == K * no, (h.shape, K, no)
+    hh = h.reshape(tuple(h.shape[:-1]) + (K, no))
+    self.C, self.K = C, K
+    self.logits, self.locs = hh[..., 0], hh[..., 1:1 + C]
+    self.scales = torch.nn.functional.softplus(hh[..., 1 + C:1 + 2 * C]) + math.exp(-7.0)
+    self.coefs = hh[..., 1 + 2 * C:]
+    self._shape = tuple(h.shape[1:-1]) + (C,)
+
+  event_shape = property(lambda self: self._shape)
+  batch_shape = property(lambda self: (self.logits.shape[0],))
+
+  def _chain(self, base):
+    """loc_i += sum_{j<i} base_j * coef (quantized.py:315-320 with the transformed pixel values,
+    :360-364 with the component means)."""
+    cols = [self.locs[..., i] for i in range(self.C)]
+    cnt = 0
+    for i in range(self.C):
+      for j in range(i):
+        cols[i] = cols[i] + (base[..., None, j] if base is not None else cols[j]) * self.coefs[..., cnt]
+        cnt += 1
+    return torch.stack(cols, -1)
+
+  def mean(self):
+    m = 127.5 * (self._chain(None) + 1.0) - 0.5     # Shift(-0.5) of the base logistic (:373-375)
+    pi = torch.softmax(self.logits, -1)
+    return (pi[..., None] * m).sum(-2) / 255.0      # `_pixels_to`, sigmoid domain
+
+  def log_prob(self, x):
+    le = self._chain(2.0 * x - 1.0)
+    comp = QuantizedLogisticObservation.__new__(QuantizedLogisticObservation)
+    comp.loc, comp.scale = 127.5 * (le + 1.0), self.scales * 127.5
+    xb = x[..., None, :].expand(le.shape)
+    B = x.shape[0]
+    # per (pixel, component, channel) terms, then the mixture over components, then the pixels
+    q = comp.log_prob_elem(xb)
+    pix = torch.logsumexp(torch.log_softmax(self.logits, -1) + q.sum(-1), -1)
+    return pix.reshape(B, -1).sum(1)
+
+  def sample(self, n=None):
+    """The reference leaves sampling as a TODO that returns uniform noise of the image shape
+    (quantized.py:383-386); restated as such."""
+    shp = (self.logits.shape[0],) + self._shape
+    if n is not None:
+      shp = (int(n),) + shp
+    return torch.rand(shp, device=self.logits.device)
 
 
 # ======================================================================================
@@ -317,7 +376,8 @@ class VariationalAutoencoder:
                       analytic=self.analytic, reverse=self.reverse, free_bits=self.free_bits,
                       tc=self._tc_mode,
                       lib=self._lib, params=self._params, seed=self.seed + self._rank(),
-                      optim_state=self._optim_state, world_size=self._world_size())
+                      optim_state=self._optim_state, world_size=self._world_size(),
+                      force_dp=bool(getattr(self, 'force_dp', False)))
       if self._params is None:
         self._params = eng.params
         self._optim_state = (eng.m, eng.v)
@@ -419,6 +479,9 @@ class VariationalAutoencoder:
       return BernoulliObservation(h)
     if self.observation.posterior == 'qlogistic':
       return QuantizedLogisticObservation(h)
+    if self.observation.posterior == 'mixqlogistic':
+      return MixtureQuantizedLogisticObservation(h, self.input_shape[-1],
+                                                 self.observation.kwargs.get('n_components', 10))
     return GaussianObservation(h, self.observation.posterior == 'gaussian_softplus1')
 
   def encode(self, inputs, training=None, mask=None, only_encoding=False, eps=None, **kwargs):
@@ -851,16 +914,16 @@ class FactorDiscriminator:
   def n_parameters(self):
     return sum(int(np.prod(s)) for _, s, _ in self.layout.entries)
 
-  def bind(self, B1: int) -> 'DiscPrograms':
+  def bind(self, B1: int, force_dp: bool = False) -> 'DiscPrograms':
     if B1 not in self.bound:
-      self.bound[B1] = DiscPrograms(self, B1)
+      self.bound[B1] = DiscPrograms(self, B1, force_dp)
     return self.bound[B1]
 
 
 class DiscPrograms:
   """Launch programs + activation buffers of the discriminator for one half-batch size."""
 
-  def __init__(self, disc: FactorDiscriminator, B1: int):
+  def __init__(self, disc: FactorDiscriminator, B1: int, force_dp: bool = False):
     lib, device, zdim = disc.lib, disc.device, disc.D
     f32 = dict(dtype=torch.float32, device=device)
     self.disc, self.B1 = disc, B1
@@ -876,8 +939,10 @@ class DiscPrograms:
     self.zperm = self.zcat[B1:]
     self.perm = torch.zeros(B1, zdim, dtype=torch.int32, device=device)
     self.world, self.rank = 1, 0
+    self.gather = False  # z' is all-gathered before permute_dims (data parallel; also at world size 1 under force_dp)
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_dp):
+      self.gather = True
       # permute_dims shuffles across the GLOBAL batch (vi/utils.py:262-267): all ranks draw the
       # same [B1_global, D] permutation, z' is all-gathered and every rank gathers its own rows
       self.world, self.rank = dist.get_world_size(), dist.get_rank()
@@ -986,7 +1051,7 @@ class FactorVAE(AnnealingVAE):
     D.t = int(self._find_variable(d, 'disc_optimizer/iter'))
 
   def _discriminator(self, B1: int) -> DiscPrograms:
-    dp = self.discriminator.bind(B1)
+    dp = self.discriminator.bind(B1, bool(getattr(self, 'force_dp', False)))
     eng = self._engine(B1)
     if eng.z.data_ptr() != dp.zcat.data_ptr():
       # step 1's cached sample IS the first half of the discriminator step's input: the engine
@@ -1001,65 +1066,87 @@ class FactorVAE(AnnealingVAE):
     if training and not self._is_pretraining:
       t = disc.disc.t + 1
       a = self.disc_lr * math.sqrt(1 - self.disc_b2 ** t) / (1 - self.disc_b1 ** t)
-      h_extra = (a, self.disc_b1, self.disc_b2, 1e-7, 1.0)
+      # (grad_scale 1 / world: the discriminator's bucket is SUMMED over the ranks, its loss is a mean
+      # over the global batch)
+      h_extra = (a, self.disc_b1, self.disc_b2, 1e-7, 1.0 / eng.world_size)
     eng.set_hyper(lr=lr, beta=self.beta, tc_coef=self.tc_coef if use_tc else 0.0, extra=h_extra,
                   skip_enable=self._step >= int(when_skip_update or 0))
 
-  def _iteration(self, eng, eng2, disc, x1, x2, eps, eps2, perm, training, use_tc, pol,
-                 aggregate_gradients):
-    """The launch sequence of one FactorVAE iteration on the current stream (eager or captured)."""
-    lib, st, B1 = eng.lib, eng.stream(), disc.B1
-    # ---- step 1: ELBO with the discriminator's TC estimate ----
-    eng.forward(x1, eps, finalize=False)
-    extra = None
-    if use_tc:
-      lg = disc.prog1.forward(eng.z, st)
-      lib.odin_mean(lg.data_ptr(), B1, disc.tc.data_ptr(), st)
-      eng.finalize(tc_ptr=disc.tc.data_ptr())
-      disc.prog1.backward(eng.z, disc.dlogit1, st, dx_out=disc.dz, data_only=True)
-      extra = disc.dz
-    else:
-      eng.finalize()
-    if training:
-      eng.backward(extra_dz=extra)
-      eng.allreduce()
-      if not aggregate_gradients:
-        eng._update(pol)
+  def _program(self, eng, eng2, disc, x1, x2, eps, eps2, perm, training, use_tc, pol,
+               aggregate_gradients):
+    """The launch program of one FactorVAE iteration: [('k', fn) kernels | ('c', fn) collective]
+    (engine.VAEEngine.step_program).  On one GPU there is no 'c' entry: one graph per iteration.  Data
+    parallel: A | all-reduce (VAE bucket) | B | all-gather (z' for the global permute_dims) | C |
+    all-reduce (discriminator bucket) | D."""
+    lib, B1 = eng.lib, disc.B1
+    dp = eng.is_dp
+    P = []
+
+    def step1():  # ELBO with the discriminator's TC estimate, backward
+      st = eng.stream()
+      eng.forward(x1, eps, finalize=False)
+      extra = None
+      if use_tc:
+        lg = disc.prog1.forward(eng.z, st)
+        lib.odin_mean(lg.data_ptr(), B1, disc.tc.data_ptr(), st)
+        eng.finalize(tc_ptr=disc.tc.data_ptr())
+        disc.prog1.backward(eng.z, disc.dlogit1, st, dx_out=disc.dz, data_only=True)
+        extra = disc.dz
+      else:
+        eng.finalize()
+      if training:
+        eng.backward(extra_dz=extra)
+
+    P.append(('k', step1))
+    if training and dp:
+      P.append(('c', eng.allreduce))
+    if training and not aggregate_gradients:
+      P.append(('k', lambda: eng._update(pol)))
     # ---- step 2: discriminator (skipped while pretraining, factor_vae.py:279) ----
     if not self._is_pretraining:
-      eng2.run_encoder(x2, eps2)  # z' with the encoder as step 1 left it
-      if perm is None:
-        lib.odin_random_perm(disc.perm.data_ptr(), B1 * disc.world, self.zdim, self.seed + 11,
-                             eng.hp(N_HYPER), st)
-      if disc.world > 1:
-        import torch.distributed as dist
-        if dist.get_backend() == 'gloo':
-          dist.all_gather(list(disc.z2_all.view(disc.world, B1, self.zdim).unbind(0)), eng2.z)
+      def encode2():
+        st = eng.stream()
+        eng2.run_encoder(x2, eps2)  # z' with the encoder as step 1 left it
+        if perm is None:
+          lib.odin_random_perm(disc.perm.data_ptr(), B1 * disc.world, self.zdim, self.seed + 11,
+                               eng.hp(N_HYPER), st)
+
+      P.append(('k', encode2))
+      if disc.gather:
+        P.append(('c', lambda: eng._comm().all_gather(disc.z2_all.view(-1), eng2.z.view(-1))))
+
+      def disc_step():
+        st = eng.stream()
+        if disc.gather:
+          src, prm = disc.z2_all, disc.perm[disc.rank * B1:(disc.rank + 1) * B1]
         else:
-          dist.all_gather_into_tensor(disc.z2_all, eng2.z)
-        src, prm = disc.z2_all, disc.perm[disc.rank * B1:(disc.rank + 1) * B1]
-      else:
-        src, prm = eng2.z, disc.perm
-      lib.odin_permute_dims(src.data_ptr(), prm.data_ptr(), disc.zperm.data_ptr(), B1,
-                            self.zdim, st)
-      lg2 = disc.prog2.forward(disc.zcat, st)
-      lib.odin_dtc_loss_fwd_bwd(lg2.data_ptr(), lg2[B1:].data_ptr(), disc.dtc.data_ptr(),
-                                disc.dlogit2.data_ptr(), disc.dlogit2[B1:].data_ptr(), B1, st)
+          src, prm = eng2.z, disc.perm
+        lib.odin_permute_dims(src.data_ptr(), prm.data_ptr(), disc.zperm.data_ptr(), B1,
+                              self.zdim, st)
+        lg2 = disc.prog2.forward(disc.zcat, st)
+        lib.odin_dtc_loss_fwd_bwd(lg2.data_ptr(), lg2[B1:].data_ptr(), disc.dtc.data_ptr(),
+                                  disc.dlogit2.data_ptr(), disc.dlogit2[B1:].data_ptr(), B1, st)
+        if training:
+          jobs = disc.prog2.backward(disc.zcat, disc.dlogit2, st)
+          arr = (ReduceJob * len(jobs))(*jobs)
+          disc._keep = arr
+          lib.odin_slab_reduce(arr, len(jobs), st)
+
+      P.append(('k', disc_step))
       if training:
-        jobs = disc.prog2.backward(disc.zcat, disc.dlogit2, st)
-        arr = (ReduceJob * len(jobs))(*jobs)
-        disc._keep = arr
-        lib.odin_slab_reduce(arr, len(jobs), st)
-        if eng.is_dp:
-          import torch.distributed as dist
-          if eng.world_size > 1:
-            disc.grads.div_(eng.world_size)
-          dist.all_reduce(disc.grads)
-        lib.odin_adam_step_flat(disc.params.data_ptr(), disc.grads.data_ptr(), disc.m.data_ptr(),
-                                disc.v.data_ptr(), disc.params.numel(), eng.hp(H_DALPHA),
-                                None, 0.0, None, st)
+        if dp:
+          P.append(('c', lambda: eng._comm().all_reduce(disc.grads)))
+        P.append(('k', lambda: lib.odin_adam_step_flat(
+            disc.params.data_ptr(), disc.grads.data_ptr(), disc.m.data_ptr(), disc.v.data_ptr(),
+            disc.params.numel(), eng.hp(H_DALPHA), None, 0.0, None, eng.stream())))
     if training and aggregate_gradients:
-      eng._update(pol)
+      P.append(('k', lambda: eng._update(pol)))
+    return P
+
+  def _iteration(self, *args):
+    """eager launch of one iteration on the current stream"""
+    for _, fn in self._program(*args):
+      fn()
 
   def optimize(self, inputs, training: bool = True, optimizer=None, learning_rate=1e-4,
                clipnorm=None, clipvalue=None, global_clipnorm=None, skip_update_threshold=None,
@@ -1095,7 +1182,7 @@ class FactorVAE(AnnealingVAE):
            nan_gradients_policy != 'ignore')
     te = None if eps is None else _as_tensor(eps, self.device)
     te2 = None if eps2 is None else _as_tensor(eps2, self.device)
-    graphable = (use_graph and self.device.type == 'cuda' and not eng.is_dp)
+    graphable = use_graph and self.device.type == 'cuda'
     if graphable:
       self._graph_iteration(eng, eng2, disc, x, te, te2, perm is not None, training, use_tc, pol,
                             aggregate_gradients)
@@ -1117,7 +1204,9 @@ class FactorVAE(AnnealingVAE):
 
   def _graph_iteration(self, eng, eng2, disc, x, eps, eps2, explicit_perm, training, use_tc, pol,
                        aggregate_gradients):
-    """One captured HIP graph per (batch size, configuration): both steps, both Adams."""
+    """HIP graphs per (batch size, configuration): both steps, both Adams -- ONE graph on one GPU, the
+    kernel segments between the collectives under data parallelism (dist.SegmentedGraph)."""
+    from .dist import SegmentedGraph
     B1 = disc.B1
     key = (B1, pol, eps is not None, eps2 is not None, explicit_perm, training, use_tc,
            aggregate_gradients, self._is_pretraining, eng.analytic, eng.free_bits)
@@ -1128,34 +1217,31 @@ class FactorVAE(AnnealingVAE):
         eng.eps.copy_(eps)
       if eps2 is not None:
         eng2.eps.copy_(eps2)
-      run = lambda: self._iteration(eng, eng2, disc, xs[:B1], xs[B1:],
-                                    eng.eps if eps is not None else None,
-                                    eng2.eps if eps2 is not None else None,
-                                    True if explicit_perm else None, training, use_tc, pol,
-                                    aggregate_gradients)
+      sg = SegmentedGraph(self.device, self._program(
+          eng, eng2, disc, xs[:B1], xs[B1:], eng.eps if eps is not None else None,
+          eng2.eps if eps2 is not None else None, True if explicit_perm else None, training, use_tc,
+          pol, aggregate_gradients))
       cap = torch.cuda.Stream(self.device)
       cap.wait_stream(torch.cuda.current_stream(self.device))
       D = disc.disc
       saved = [t.clone() for t in (eng.params, eng.m, eng.v, D.params, D.m, D.v, eng.flag,
                                    eng.skipped_update)]
       with torch.cuda.stream(cap):
-        run()  # warm-up outside capture; must not count
+        sg.run_eager()  # warm-up outside capture; must not count
         for t, sv in zip((eng.params, eng.m, eng.v, D.params, D.m, D.v, eng.flag,
                           eng.skipped_update), saved):
           t.copy_(sv)
       torch.cuda.current_stream(self.device).wait_stream(cap)
-      g = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
-        run()
-      self._fgraphs[key] = (g, xs)
-    g, xs = self._fgraphs[key]
+      sg.capture(cap)
+      self._fgraphs[key] = (sg, xs)
+    sg, xs = self._fgraphs[key]
     if x.data_ptr() != xs.data_ptr():
       xs.copy_(x, non_blocking=True)
     if eps is not None:
       eng.eps.copy_(eps, non_blocking=True)
     if eps2 is not None:
       eng2.eps.copy_(eps2, non_blocking=True)
-    g.replay()
+    sg.replay()
 
   def input_buffer(self, batch_size: int) -> torch.Tensor:
     """Static [B, H, W, C] tensor read by the captured iteration graph with default settings."""

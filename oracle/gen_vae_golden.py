@@ -38,6 +38,8 @@ CASES = {
     'shapes3d_factor': (lambda: vo.dsprites_spec(3), 'bernoulli', 4, dict(), False),
     'celeba_betatc': (lambda: vo.celeba_spec(45, 3), 'bernoulli', 4, dict(beta=4.0, tc_beta=4.0), False),
     'celeba_qlogistic': (lambda: vo.celeba_spec(45, 6), 'qlogistic', 2, dict(beta=2.0), False),
+    # f1: MixtureQuantizedLogistic head, 1 channel (30 maps), dSprites-shaped conv stack
+    'dsprites_mixql': (lambda: vo.dsprites_spec(1, n_out_params=30), 'mixqlogistic', 2, dict(beta=2.0), False),
 }
 
 

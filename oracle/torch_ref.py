@@ -114,13 +114,33 @@ def t_qlogistic_log_prob(loc, raw, x, low=0.0, high=255.0):
   return big + torch.where(fin, l1m, torch.zeros_like(l1m))
 
 
+def t_mixql_log_prob_pix(h, x, C, K=10):
+  """MixtureQuantizedLogistic.log_prob per pixel (odin/bay/distributions/quantized.py:284-349): K
+  components, channel chain on the transformed values, MixtureSameFamily over Independent(QL, 1)."""
+  no = 2 * C + C * (C - 1) // 2 + 1
+  hh = h.reshape(h.shape[:-1] + (K, no))
+  logits, locs, raw, coefs = hh[..., 0], hh[..., 1:1 + C], hh[..., 1 + C:1 + 2 * C], hh[..., 1 + 2 * C:]
+  xt = 2.0 * x - 1.0
+  cols = [locs[..., i] for i in range(C)]
+  cnt = 0
+  for i in range(C):
+    for j in range(i):
+      cols[i] = cols[i] + xt[..., None, j] * coefs[..., cnt]
+      cnt += 1
+  le = torch.stack(cols, -1)
+  q = t_qlogistic_log_prob(le, raw, x[..., None, :].expand(le.shape))
+  comp = torch.log_softmax(logits, -1) + q.sum(-1)
+  return torch.logsumexp(comp, -1)
+
+
 class TorchVAE:
   """Same constructor arguments as oracle.vae_oracle.OracleVAE."""
 
   def __init__(self, enc_layers, dec_layers, in_shape, zdim, observation='bernoulli',
                analytic=False, free_bits=None, beta=1.0, tc_beta=None,
-               dtype=torch.float64, reverse=True):
+               dtype=torch.float64, reverse=True, n_components=10):
     self.reverse = bool(reverse)
+    self.n_components = int(n_components)
     self.enc, self.dec = list(enc_layers), list(dec_layers)
     self.in_shape, self.D = tuple(in_shape), int(zdim)
     self.observation, self.analytic, self.free_bits = observation, analytic, free_bits
@@ -149,6 +169,10 @@ class TorchVAE:
       C = x.shape[-1]
       llk = t_qlogistic_log_prob(h_d[..., :C], h_d[..., C:], x).reshape(B, -1).sum(1)
       recon = (127.5 * (h_d[..., :C] + 1.0)) / 255.0
+    elif self.observation == 'mixqlogistic':
+      C = x.shape[-1]
+      llk = t_mixql_log_prob_pix(h_d, x, C, self.n_components).reshape(B, -1).sum(1)
+      recon = None
     else:
       C = x.shape[-1]
       oloc, raw = h_d[..., :C], h_d[..., C:]

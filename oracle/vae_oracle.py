@@ -217,6 +217,89 @@ def gaussian_log_prob(loc, scale, x):
   return e.reshape(e.shape[0], -1).sum(1)
 
 
+# ---- MixtureQuantizedLogistic (odin/bay/distributions/quantized.py:206-349): PixelCNN++ mixture of
+# K discretised logistics per pixel; with C > 1 channels the component means of channel i receive a
+# linear term in the (transformed) values of the channels j < i.  `h` [..., K * n_out] is reshaped to
+# [..., K, n_out] and split into (logit 1 | loc C | raw scale C | coefficient C (C - 1) / 2) (:266-282).
+def mixql_n_out(C: int) -> int:
+  return 2 * C + C * (C - 1) // 2 + 1
+
+
+def mixql_split(h, C: int, K: int):
+  no = mixql_n_out(C)
+  hh = np.asarray(h, F64).reshape(h.shape[:-1] + (K, no))
+  return hh[..., 0], hh[..., 1:1 + C], hh[..., 1 + C:1 + 2 * C], hh[..., 1 + 2 * C:]
+
+
+def _mixql_locs(locs, coefs, xt, C):
+  """loc_i += sum_{j < i} x_j * coef[count], count running over (i, j) in the reference's loop order
+  (:315-320); x_j the pixel value mapped to [-1, 1] (`_switch_domain`, 'sigmoid': 2 v - 1)."""
+  if C == 1:
+    return locs
+  out = [locs[..., i] for i in range(C)]
+  cnt = 0
+  for i in range(C):
+    for j in range(i):
+      out[i] = out[i] + xt[..., None, j] * coefs[..., cnt]
+      cnt += 1
+  return np.stack(out, -1)
+
+
+def mixql_log_prob_pix(h, x, C: int, K: int = 10):
+  """log-probability of every pixel [..]: logsumexp_k(log_softmax(logits)_k + sum_c log QL_kc(x_c))."""
+  logits, locs, raw, coefs = mixql_split(h, C, K)
+  x = np.asarray(x, F64)
+  xt = 2.0 * x - 1.0
+  le = _mixql_locs(locs, coefs, xt, C)
+  q = qlogistic_log_prob_elem(le, raw, np.broadcast_to(x[..., None, :], le.shape))
+  comp = logits - _logsumexp(logits, -1)[..., None] + q.sum(-1)
+  return _logsumexp(comp, -1)
+
+
+def mixql_log_prob(h, x, C: int, K: int = 10):
+  e = mixql_log_prob_pix(h, x, C, K)
+  return e.reshape(e.shape[0], -1).sum(1)
+
+
+def mixql_log_prob_grad(h, x, C: int, K: int = 10):
+  """d log_prob / d h, elementwise, same shape as h."""
+  logits, locs, raw, coefs = mixql_split(h, C, K)
+  x = np.asarray(x, F64)
+  xt = 2.0 * x - 1.0
+  le = _mixql_locs(locs, coefs, xt, C)
+  xb = np.broadcast_to(x[..., None, :], le.shape)
+  q = qlogistic_log_prob_elem(le, raw, xb)
+  gl, gr = qlogistic_log_prob_grad(le, raw, xb)
+  la = logits - _logsumexp(logits, -1)[..., None]
+  comp = la + q.sum(-1)
+  r = np.exp(comp - _logsumexp(comp, -1)[..., None])     # responsibilities
+  g = np.zeros(h.shape[:-1] + (K, mixql_n_out(C)))
+  g[..., 0] = r - np.exp(la)
+  g[..., 1:1 + C] = r[..., None] * gl
+  g[..., 1 + C:1 + 2 * C] = r[..., None] * gr
+  cnt = 0
+  for i in range(C):
+    for j in range(i):
+      g[..., 1 + 2 * C + cnt] = r * gl[..., i] * xt[..., None, j]
+      cnt += 1
+  return g.reshape(h.shape)
+
+
+def mixql_mean(h, C: int, K: int = 10):
+  """MixtureQuantizedLogistic._mean (:351-381): the channel chain runs on the component MEANS, the
+  Shift(-0.5) of the base distribution stays, `_pixels_to`(sigmoid) divides by `high`."""
+  logits, locs, raw, coefs = mixql_split(h, C, K)
+  out = [locs[..., i] for i in range(C)]
+  cnt = 0
+  for i in range(C):
+    for j in range(i):
+      out[i] = out[i] + out[j] * coefs[..., cnt]
+      cnt += 1
+  m = 127.5 * (np.stack(out, -1) + 1.0) - 0.5
+  pi = np.exp(logits - _logsumexp(logits, -1)[..., None])
+  return (pi[..., None] * m).sum(-2) / 255.0
+
+
 # ---- QuantizedLogistic (odin/bay/distributions/quantized.py:50-204; TFP 0.13
 # QuantizedDistribution._log_prob_with_logsf_and_logcdf, third-party, restated from its published
 # source): PixelCNN-style discretised logistic over the pixel values low..high ------------------
@@ -559,13 +642,15 @@ class OracleVAE:
   (DistributionDense projection, odin/bay/layers/dense_distribution.py:339-380).
   observation: 'bernoulli' (decoder emits C logits) | 'gaussian' (raw loc,scale split,
   image_networks.py:95-102) | 'gaussian_softplus1' (GaussianLayer,
-  odin/bay/layers/continuous.py:196-260).
+  odin/bay/layers/continuous.py:196-260) | 'qlogistic' | 'mixqlogistic' (decoder emits
+  n_components * (2C + C(C-1)/2 + 1) maps, image_networks.py:72-85).
   """
 
   def __init__(self, enc_layers, dec_layers, in_shape, zdim, observation='bernoulli',
                analytic=False, free_bits=None, beta=1.0, tc_beta: Optional[float] = None,
-               reverse: bool = True):
+               reverse: bool = True, n_components: int = 10):
     self.reverse = bool(reverse)
+    self.n_components = int(n_components)  # 'mixqlogistic' (image_networks.py:48, default 10)
     self.enc, self.dec = list(enc_layers), list(dec_layers)
     self.in_shape, self.D = tuple(in_shape), int(zdim)
     self.observation, self.analytic, self.free_bits = observation, analytic, free_bits
@@ -623,6 +708,10 @@ class OracleVAE:
       oloc, raw = h_d[..., :C], h_d[..., C:]
       llk = qlogistic_log_prob(oloc, raw, x)
       recon = qlogistic_params(oloc, raw)[0] / 255.0  # QuantizedLogistic.mean (quantized.py:185-187)
+    elif self.observation == 'mixqlogistic':
+      C = x.shape[-1]
+      llk = mixql_log_prob(h_d, x, C, self.n_components)
+      recon = mixql_mean(h_d, C, self.n_components)
     else:
       C = x.shape[-1]
       oloc, raw = h_d[..., :C], h_d[..., C:]
@@ -670,6 +759,8 @@ class OracleVAE:
       C = x.shape[-1]
       gl, gr = qlogistic_log_prob_grad(h_d[..., :C], h_d[..., C:], x)
       dh_d = -np.concatenate([gl, gr], -1) / B
+    elif self.observation == 'mixqlogistic':
+      dh_d = -mixql_log_prob_grad(h_d, x, x.shape[-1], self.n_components) / B
     else:
       C = x.shape[-1]
       oloc, raw = h_d[..., :C], h_d[..., C:]

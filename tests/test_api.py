@@ -302,3 +302,41 @@ def test_reverse_kl_and_sample_shape(L, DEV):
     fk = m1.forward(P, x.astype(np.float64), eps3[k].astype(np.float64))
     np.testing.assert_allclose(llk3['llk_image'][k].numpy(force=True), fk['llk'], rtol=1e-5)
     np.testing.assert_allclose(kl3['kl_latents'][k].numpy(force=True), fk['kl'], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('C', [1, 3])
+def test_mixture_quantized_logistic_model(L, DEV, C):
+  """f1: _parse_distribution('mixqlogistic') (image_networks.py:72-85) -> MixtureQuantizedLogistic head
+  (quantized.py:206-381): decoder head sizes, call / elbo / mean against the oracle, and the model trains."""
+  assert get_networks('mnist', distribution='mixqlogistic')['decoder'].layers[-1][1] == 30
+  assert get_networks('celeba', distribution='mixqlogistic')['decoder'].layers[-1][1] == 100
+  with pytest.raises(ValueError):
+    get_networks('mnist', distribution='mixqlogistic', n_components=5)
+  nets = tiny_nets(C=C)
+  n_maps = 10 * vo.mixql_n_out(C)
+  nets['decoder'] = SequentialNetwork(nets['decoder'].layers[:-1] + [('conv', n_maps, 1, 1, 'linear')],
+                                      'Decoder', (4,))
+  nets['observation'] = RVconf((8, 8, C), 'mixqlogistic', projection=False, name='image',
+                               kwargs=dict(n_components=10))
+  vae = BetaVAE(beta=2.0, device=DEV, lib=L, **nets)
+  B = 6
+  rng = np.random.default_rng(5)
+  x = np.clip(rng.random((B, 8, 8, C)), 1e-6, 1 - 1e-6).astype(np.float32)
+  eps = rng.standard_normal((B, 4)).astype(np.float32)
+  model = vo.OracleVAE(nets['encoder'].layers, nets['decoder'].layers, (8, 8, C), 4, beta=2.0,
+                       observation='mixqlogistic')
+  P = oracle_params(vae)
+  f = model.forward(P, x.astype(np.float64), eps.astype(np.float64))
+  px, qz = vae(x, eps=eps)
+  assert px.event_shape == (8, 8, C) and px.mean().shape == (B, 8, 8, C)
+  np.testing.assert_allclose(px.mean().numpy(force=True), f['recon'], atol=2e-5)
+  import torch as _t
+  np.testing.assert_allclose(px.log_prob(_t.as_tensor(x, device=DEV)).numpy(force=True), f['llk'], rtol=2e-5)
+  llk, kl = vae.elbo_components(x, eps=eps)
+  np.testing.assert_allclose(llk['llk_image'].numpy(force=True), f['llk'], rtol=2e-5)
+  l0, _ = vae.optimize(x, eps=eps, learning_rate=1e-3)
+  assert abs(float(l0) - f['loss']) < 1e-4 * abs(f['loss'])
+  for _ in range(3):
+    l1, _ = vae.optimize(x, eps=eps, learning_rate=1e-3)
+  assert float(l1) < float(l0)
+  assert px.sample().shape == (B, 8, 8, C)

@@ -34,8 +34,10 @@ def _init(eng):
   eng.params.copy_(torch.randn(eng.params.numel(), generator=g) * 0.1)
 
 
-def _worker(rank, world, port, out_path, tc=None):
+def _worker(rank, world, port, out_path, tc=None, buckets=None, segmented=False):
   sys.path.insert(0, ROOT)
+  if buckets is not None:
+    os.environ['ODIN_DP_BUCKETS'] = str(buckets)
   from odin_ai_amd import _lib
   from odin_ai_amd.dist import shard_batch
   from odin_ai_amd.engine import VAEEngine
@@ -49,10 +51,21 @@ def _worker(rank, world, port, out_path, tc=None):
   eng = VAEEngine(enc, dec, shp, D, B // world, 'cpu', lib=L, world_size=world, tc=tc)
   _init(eng)
   xs, es = shard_batch(x, rank, world), shard_batch(eps, rank, world)
+  kinds = None
   for _ in range(3):
-    eng.train_step(xs, es, lr=1e-3, beta=4.0, global_clipnorm=100.0)
+    if segmented:
+      # the graph-replayed step's own machinery (dist.SegmentedGraph over step_program), with the kernel
+      # segments launched instead of replayed (no HIP graphs on the CPU)
+      from odin_ai_amd.dist import SegmentedGraph
+      eng.step_count += 1
+      eng.set_hyper(lr=1e-3, beta=4.0)
+      sg = SegmentedGraph('cpu', eng.step_program(xs, es, (100.0, None, None, None, True)))
+      kinds = ''.join(k for k, _ in sg.segs)
+      sg.run_eager()
+    else:
+      eng.train_step(xs, es, lr=1e-3, beta=4.0, global_clipnorm=100.0)
   if rank == 0:
-    torch.save(dict(params=eng.params.clone(), out4=eng.out4.clone()), out_path)
+    torch.save(dict(params=eng.params.clone(), out4=eng.out4.clone(), kinds=kinds), out_path)
   dist.destroy_process_group()
 
 
@@ -103,6 +116,32 @@ def test_beta_tc_two_ranks_match_single_rank(tmp_path):
   # out4 = [loss, mean llk, mean beta*kl, tc]: llk / kl are per-rank means (ranks differ), the TC
   # term is global and must agree
   assert abs(eng.out4[3].item() - r2['out4'][3].item()) < 1e-4 * max(1.0, abs(eng.out4[3].item()))
+  d = (eng.params - r2['params']).abs()
+  assert d.max().item() < 2e-4 and d.mean().item() < 2e-6, (d.max().item(), d.mean().item())
+
+
+@pytest.mark.parametrize('tc,buckets,kinds', [(None, 2, 'kckck'), ('betatc', 1, 'kckckck'), ('betatc', 2, 'kckckckck')])
+def test_segmented_program_two_ranks_match_single_rank(tmp_path, tc, buckets, kinds):
+  """the data-parallel step as kernel segments around its collectives
+  (A | all-gather | B | reduce-scatter | C | all-reduce | D; two gradient buckets: decoder bucket reduced
+  before the encoder's backward pass ends) gives the single-rank result."""
+  from odin_ai_amd.engine import VAEEngine
+  from tests.simutil import sim_lib
+  L = sim_lib()
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  out = str(tmp_path / 'seg.pt')
+  mp.spawn(_worker, args=(2, port, out, tc, buckets, True), nprocs=2, join=True)
+  r2 = torch.load(out)
+  assert r2['kinds'] == kinds, r2['kinds']
+  enc, dec, shp, D = _spec()
+  x, eps = _data(8)
+  eng = VAEEngine(enc, dec, shp, D, 8, 'cpu', lib=L, world_size=1, tc=tc)
+  _init(eng)
+  for _ in range(3):
+    eng.train_step(x, eps, lr=1e-3, beta=4.0, global_clipnorm=100.0)
   d = (eng.params - r2['params']).abs()
   assert d.max().item() < 2e-4 and d.mean().item() < 2e-6, (d.max().item(), d.mean().item())
 

@@ -37,6 +37,9 @@ CASES = [
     ('celeba_betatc', lambda: vo.celeba_spec(45, 3), 'bernoulli', 8, dict(beta=4.0, tc_beta=4.0), 1),
     ('celeba_gauss', lambda: vo.celeba_spec(45, 6), 'gaussian_softplus1', 4, dict(beta=2.0), 1),
     ('celeba_qlogistic', lambda: vo.celeba_spec(45, 6), 'qlogistic', 4, dict(beta=2.0), 1),
+    ('dsprites_mixql', lambda: vo.dsprites_spec(1, n_out_params=30), 'mixqlogistic', 4, dict(beta=2.0), 1),
+    ('shapes3d_mixql', lambda: (lambda e, d, s, z: (e, d[:-1] + [('conv', 100, 1, 1, 'linear')], s, z))(*vo.dsprites_spec(3)),
+     'mixqlogistic', 3, dict(beta=1.0), 1),
     ('dsprites_reverse_kl', lambda: vo.dsprites_spec(1), 'bernoulli', 5,
      dict(beta=2.0, analytic=True, reverse=False), 1),
     ('mnist_conv', lambda: vo.mnist_conv_spec(), 'bernoulli', 6, dict(), 1),

@@ -100,3 +100,41 @@ def test_interpolation_cyclical_and_curves_known_answers():
   assert ip.sine(steps=2)(1) == pytest.approx(0.5) and ip.const(vmax=3.0)(7) == 3.0
   assert ip.power(length=4, power=2.0)(1) == pytest.approx(0.125) and ip.power(length=4, power=2.0)(3) == pytest.approx(0.875)
   assert ip.circleIn(steps=5)(3) == pytest.approx(0.2) and ip.powerIn(length=2, power=3.0)(1) == pytest.approx(0.125)
+
+
+def test_mixture_quantized_logistic_known_answers():
+  """MixtureQuantizedLogistic (quantized.py:284-349): K identical components with equal logits reduce
+  to ONE QuantizedLogistic; a dominant logit selects its component; the channel chain only moves the
+  means of the later channels; the pixel probabilities of a 1-channel mixture sum to one."""
+  rng = np.random.default_rng(0)
+  K = 10
+  for C in (1, 3):
+    no = vo.mixql_n_out(C)
+    loc, raw = rng.standard_normal((2, 5, C)), rng.standard_normal((2, 5, C))
+    x = np.clip(rng.random((2, 5, C)), 1e-6, 1 - 1e-6)
+    h = np.zeros((2, 5, K, no))
+    h[..., 1:1 + C], h[..., 1 + C:1 + 2 * C] = loc[..., None, :], raw[..., None, :]
+    want = vo.qlogistic_log_prob_elem(loc, raw, x).sum(-1)
+    got = vo.mixql_log_prob_pix(h.reshape(2, 5, K * no), x, C, K)
+    np.testing.assert_allclose(got, want, atol=1e-12)
+    # component 3 differs and carries (almost) all the mass
+    h2 = h.copy()
+    h2[..., 3, 1:1 + C] += 0.7
+    h2[..., 3, 0] = 60.0
+    want2 = vo.qlogistic_log_prob_elem(loc + 0.7, raw, x).sum(-1)
+    np.testing.assert_allclose(vo.mixql_log_prob_pix(h2.reshape(2, 5, K * no), x, C, K), want2, atol=1e-9)
+    if C == 3:  # coefficient (1, 0) shifts the mean of channel 1 by coef * (2 x_0 - 1), nothing else
+      h3 = h.copy()
+      h3[..., 1 + 2 * C] = 0.4
+      le = loc.copy()
+      le[..., 1] += 0.4 * (2 * x[..., 0] - 1)
+      want3 = vo.qlogistic_log_prob_elem(le, raw, x).sum(-1)
+      np.testing.assert_allclose(vo.mixql_log_prob_pix(h3.reshape(2, 5, K * no), x, C, K), want3, atol=1e-12)
+  # normalisation over the 256 pixel levels (1 channel)
+  h = rng.standard_normal((1, 1, K * 3))
+  lev = (np.arange(256) / 255.0).astype(np.float32).astype(np.float64)
+  tot = sum(np.exp(vo.mixql_log_prob_pix(h, np.full((1, 1, 1), v), 1, K))[0, 0] for v in lev)
+  assert abs(tot - 1.0) < 1e-9
+  # mean of identical components = the component mean shifted by -1/2 pixel
+  hm = np.zeros((1, 1, K, 3)); hm[..., 1] = 0.2
+  assert abs(vo.mixql_mean(hm.reshape(1, 1, 30), 1, K)[0, 0, 0] - (127.5 * 1.2 - 0.5) / 255.0) < 1e-12

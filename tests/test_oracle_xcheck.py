@@ -15,6 +15,11 @@ def _small_spec(kind):
     return vo.celeba_spec(45, 6), 'qlogistic'
   if kind == 'celeba_gauss':
     return vo.celeba_spec(45, 6), 'gaussian_softplus1'
+  if kind == 'mixql_1ch':   # mnist-style single channel: 10 x (1 + 1 + 1) parameter maps
+    return vo.dsprites_spec(1, n_out_params=30), 'mixqlogistic'
+  if kind == 'mixql_3ch':   # RGB: 10 x (1 + 3 + 3 + 3) maps with the channel chain
+    e, d, s_, z = vo.dsprites_spec(3)
+    return (e, d[:-1] + [('conv', 100, 1, 1, 'linear')], s_, z), 'mixqlogistic'
   if kind == 'mnist_conv':
     return vo.mnist_conv_spec(), 'bernoulli'
   if kind == 'mnist_dense':
@@ -30,6 +35,8 @@ CASES = [
     ('shapes3d', dict(beta=1.0, tc_beta=4.0)),
     ('celeba_gauss', dict(beta=4.0, tc_beta=4.0)),
     ('celeba_qlogistic', dict(beta=2.0)),
+    ('mixql_1ch', dict(beta=2.0)),
+    ('mixql_3ch', dict(beta=1.0)),
     ('mnist_conv', dict()),
     ('mnist_dense', dict(analytic=True)),
 ]

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+from odin_ai_amd import _lib
 from oracle import vae_oracle as vo
 
 
@@ -306,3 +307,36 @@ def test_elbo_quantized_logistic(bk, npix, Cc):
                                sc.data_ptr(), B, npix, Cc, 2, C.byref(npart), None)
   close(part.reshape(B, -1).sum(1).cpu().numpy(), llk_ref, 2e-5)
   close(dh.cpu().numpy(), dh_ref, 1e-4)
+
+
+@pytest.mark.parametrize('npix,Cc', [(784, 1), (12 * 20, 3), (300, 3)])
+def test_elbo_mixture_quantized_logistic(bk, npix, Cc):
+  """MixtureQuantizedLogistic head (quantized.py:206-349; image_networks.py:72-85): 10 components of
+  (logit | loc | raw | channel coefficients), log-prob and gradient wrt every parameter map, ragged
+  pixel counts, edge bins, one dominant component and near-uniform mixtures."""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(21)
+  B, K = 3, 10
+  no = vo.mixql_n_out(Cc)
+  h = rng.standard_normal((B, npix, K, no))
+  h[..., 1 + Cc:1 + 2 * Cc] *= 2.0          # scales from ~1e-2 to ~4 (x 127.5 pixels)
+  h[..., 1 + 2 * Cc:] *= 0.5                # channel coefficients
+  h[0, :16, :, 0] *= 8.0                    # sharply peaked mixtures
+  h[1, :16, :, 0] *= 0.01                   # near-uniform mixtures
+  h = h.reshape(B, npix, K * no)
+  x = rng.random((B, npix, Cc)).astype(np.float32)
+  x[0, :8] = np.array([1e-6, 1 - 1e-6, 0.0, 1.0, 0.5, 200 / 255, 3 / 255, 254 / 255], np.float32)[:, None]
+  x = x.astype(np.float64)
+  h32 = h.astype(np.float32).astype(np.float64)
+  llk_ref = vo.mixql_log_prob(h32, x, Cc, K)
+  dh_ref = -vo.mixql_log_prob_grad(h32, x, Cc, K) / B
+  th, tx, sc = T(h), T(x), T([1.0 / B])
+  npart = C.c_int(0)
+  L.odin_elbo_mixqlogistic_fwd_bwd(None, None, None, None, None, B, npix, Cc, K, C.byref(npart), None)
+  part, dh = bk.zeros(B * npart.value), bk.full((B, npix, K * no), float('nan'))
+  L.odin_elbo_mixqlogistic_fwd_bwd(th.data_ptr(), tx.data_ptr(), part.data_ptr(), dh.data_ptr(),
+                                   sc.data_ptr(), B, npix, Cc, K, C.byref(npart), None)
+  close(part.reshape(B, -1).sum(1).cpu().numpy(), llk_ref, 2e-5)
+  close(dh.cpu().numpy(), dh_ref, 1e-4)
+  with pytest.raises(_lib.OdinError):
+    L.odin_elbo_mixqlogistic_fwd_bwd(None, None, None, None, None, B, npix, 2, K, C.byref(npart), None)

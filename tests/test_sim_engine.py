@@ -39,6 +39,8 @@ CASES = [
     ('tiny_gauss', dict(beta=2.0), 'gaussian_softplus1', 3),
     ('tiny_gauss', dict(beta=2.0), 'qlogistic', 3),
     ('tiny', dict(beta=2.0, analytic=True, reverse=False), 'bernoulli', 1),
+    ('tiny_mixql', dict(beta=2.0), 'mixqlogistic', 1),
+    ('tiny_mixql', dict(beta=1.0), 'mixqlogistic', 3),
     ('mnist_dense', dict(), 'bernoulli', 1),
 ]
 
@@ -54,6 +56,10 @@ def test_engine_step_matches_oracle(L, name, kw, obs, C):
   elif name == 'tiny_gauss':
     e, d, s, z = tiny_conv_spec(C)
     d = d[:-1] + [('conv', 2 * C, 1, 1, 'linear')]
+    spec = (e, d, s, z)
+  elif name == 'tiny_mixql':
+    e, d, s, z = tiny_conv_spec(C)
+    d = d[:-1] + [('conv', 10 * vo.mixql_n_out(C), 1, 1, 'linear')]
     spec = (e, d, s, z)
   elif name.startswith('tiny16'):
     spec = tiny16_spec(C)
