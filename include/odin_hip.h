@@ -129,6 +129,30 @@ int odin_latent_bwd(const float* p, const float* eps, const float* z, const floa
                     const float* dloc_x, const float* dscale_x, float* dp, int B, int D,
                     int analytic, void* stream);
 
+/* ---- the bottleneck as one launch per direction (latent_block.hip): DistributionDense(P -> 2D) ->
+ * MVNDiag(loc, softplus(raw)) -> reparameterised sample + KL term -> the decoder's first Dense(D -> N0)
+ * (dense_distribution.py DistributionDense; variational_autoencoder.py:515-542; helpers.py:236-286;
+ * image_networks.py:494-497), i.e. odin_rng_normal + odin_dense_fwd + odin_latent_fwd + odin_dense_fwd,
+ * and in the backward pass odin_dense_dgrad/wgrad + odin_latent_bwd + odin_dense_wgrad/dgrad.
+ * odin_latent_block_rows: workgroups (= slab rows the backward launch writes), 0 when the shapes are
+ * outside the fused regime (both weight matrices must fit in LDS).
+ * forward: h [B,P] encoder output, wl [P,2D], bl [2D]; eps_in [B,D] or NULL = draw the noise from the
+ * Philox stream of odin_rng_normal(seed, step_dev) and store it in eps_out; writes p [B,2D], z [B,D],
+ * kl [B], fbmask [B] exactly like odin_latent_fwd and y0 = act0(z w0 + b0) [B,N0].
+ * backward: g0 [B,N0] = dL/d(pre-activation of that Dense); klw / dz_extra / dloc_x / dscale_x as in
+ * odin_latent_bwd; writes dz [B,D], dp [B,2D], dh = (dp wl^T) * act'(h) [B,P] and one partial row per
+ * workgroup of slab0 [rows][D*N0 + N0] = (dW0 | db0) and slabl [rows][P*2D + 2D] = (dWl | dbl). */
+int odin_latent_block_rows(int B, int P, int D, int N0);
+int odin_latent_block_fwd(const float* h, const float* wl, const float* bl, const float* eps_in,
+                          float* eps_out, uint64_t seed, const int32_t* step_dev, float* p, float* z,
+                          float* kl, float* fbmask, const float* w0, const float* b0, float* y0, int B,
+                          int P, int D, int N0, int act0, int analytic, float free_bits, void* stream);
+int odin_latent_block_bwd(const float* g0, const float* w0, const float* z, const float* p,
+                          const float* eps, const float* fbmask, const float* klw, const float* dz_extra,
+                          const float* dloc_x, const float* dscale_x, const float* wl, const float* h,
+                          int h_act, float* dz, float* dp, float* dh, float* slab0, float* slabl, int B,
+                          int P, int D, int N0, int analytic, void* stream);
+
 /* ---- observation log-likelihood fused forward+backward
  * Independent(Bernoulli(logits),3).log_prob(x) (image_networks.py:87-93;
  * variational_autoencoder.py:528-530): llk_part[b][part] partial sums (n_part per

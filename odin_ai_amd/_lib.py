@@ -60,6 +60,9 @@ SIGNATURES = {
     'odin_slab_reduce': [C.POINTER(ReduceJob), I, P],
     'odin_latent_fwd': [P, P, P, P, P, I, I, I, F, P],
     'odin_latent_bwd': [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    'odin_latent_block_rows': [I, I, I, I],
+    'odin_latent_block_fwd': [P, P, P, P, P, C.c_uint64, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
+    'odin_latent_block_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, I, I, P],
     'odin_elbo_bernoulli_fwd_bwd': [P, P, P, P, P, I, I, IP, P],
     'odin_elbo_gaussian_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
     'odin_elbo_mixqlogistic_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
@@ -92,7 +95,8 @@ SIGNATURES = {
 
 
 # entry points whose return value is a result, not an error code
-VALUE_RETURNING = ('odin_version', 'odin_max_slab_rows', 'odin_crc32c', 'odin_debug_last_path')
+VALUE_RETURNING = ('odin_version', 'odin_max_slab_rows', 'odin_crc32c', 'odin_debug_last_path',
+                   'odin_latent_block_rows')
 
 
 class OdinError(RuntimeError):

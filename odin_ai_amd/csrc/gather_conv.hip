@@ -1587,6 +1587,10 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
                                  d->pad_t, d->pad_l, d->center))
     return odin_fconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->Cin,
                                   d->OH, d->OW, d->Cout, 1, stream);
+  if (odin_igemm_applicable(0, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
+                            d->center))
+    return odin_igemm_launch(0, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
+                             d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, stream);
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = y;
@@ -1617,6 +1621,14 @@ extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* a
     return odin_tconv_ring_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, nullptr, nullptr,
                                   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->OH,
                                   d->OW, d->Cin, 2, stream);
+  if (odin_igemm_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0) &&
+      (odin_igemm_tiles(1, d->B, d->H, d->W, d->stride) <= ODIN_MAX_COLSUM_BLOCKS ||
+       (colsum_slab == nullptr && dx != nullptr))) {
+    if (slab_rows_out) *slab_rows_out = odin_igemm_tiles(1, d->B, d->H, d->W, d->stride);
+    if (dx == nullptr) return 0;  // dry run
+    return odin_igemm_launch(1, dy, w, nullptr, aux, aux_act, dx, colsum_slab, d->B, d->OH, d->OW, d->Cout,
+                             d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0, stream);
+  }
   GParams p;
   fill_common(p, d);
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;
@@ -1642,6 +1654,10 @@ extern "C" int odin_deconv2d_fwd(const float* x, const float* w, const float* bi
     return odin_tconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr,
                                   nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->H, d->W,
                                   d->Cout, 1, stream);
+  if (odin_igemm_applicable(1, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
+                            d->center))
+    return odin_igemm_launch(1, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
+                             d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, stream);
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = y;
@@ -1664,6 +1680,14 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
                                  d->pad_t, d->pad_l, 0))
     return odin_fconv_ring_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, d->B, d->OH,
                                   d->OW, d->Cout, d->H, d->W, d->Cin, 2, stream);
+  if (odin_igemm_applicable(0, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0) &&
+      (odin_igemm_tiles(0, d->B, d->H, d->W, d->stride) <= ODIN_MAX_COLSUM_BLOCKS ||
+       (colsum_slab == nullptr && dx != nullptr))) {
+    if (slab_rows_out) *slab_rows_out = odin_igemm_tiles(0, d->B, d->H, d->W, d->stride);
+    if (dx == nullptr) return 0;  // dry run
+    return odin_igemm_launch(0, dy, w, nullptr, aux, aux_act, dx, colsum_slab, d->B, d->OH, d->OW, d->Cout,
+                             d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0, stream);
+  }
   GParams p;
   fill_common(p, d);
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;
@@ -1747,5 +1771,6 @@ extern "C" int odin_debug_set_stamps(void* buf) {
   odin_fconv_ring_set_stamps(buf);
   odin_tconv_ring_set_stamps(buf);
   odin_tconv_planes_set_stamps(buf);
+  odin_igemm_set_stamps(buf);
   return 0;
 }

@@ -1,0 +1,500 @@
+// igemm.hip -- the small-spatial layers of the image stacks (encoder3, decoder1 of
+// odin/networks/image_networks.py:462-505; CelebA's 8x8 layers, :678-703; the 6x5 layers of the speech
+// stack) as implicit GEMMs on the fp32 matrix cores with BOTH operands straight from L2.
+//
+// These layers are 0.07-0.5 GFLOP at batch 256: on the tiled paths (gather_conv.hip / wgrad.hip) they
+// are <= 128 workgroups that first stage a 128 KB weight slice through LDS and then multiply -- 16-28 us
+// per launch for 3 % of the step's FLOPs.  Here nothing is staged: a workgroup owns ONE 32 x 32 output
+// tile, its NW waves split the reduction, and every wave streams its share of both operands from L2 in
+// 8-deep, double-buffered batches of 16-byte loads (the next batch is in flight while the current one
+// feeds v_mfma_f32_32x32x2_f32); the partial tiles meet in LDS in wave order (bit-reproducible).
+//
+//   forward / data gradient (igemm_kernel):  C[m][j] = sum_k A(m, k) * Wt(k, j)
+//     rows m   = output pixels; for the transposed gathers (Conv2DTranspose forward, Conv2D data gradient)
+//                ordered by stride class (oy % S, ox % S) so that a tile's rows share their valid taps and
+//                the reduction runs over those only (4 of the 16 taps of a 4x4/s2 kernel)
+//     k        = (tap, channel): 8 consecutive channels of one tap per k-group, the gather address is one
+//                per-lane base + one wave-uniform tap offset, SAME padding is a per-lane tap bit mask
+//   weight gradient (igemm_wgrad_kernel):    dW[(tap, cu)][cv] = sum_m U(pix(m, tap), cu) * V(m, cv)
+//     U = the fine tensor (Conv2D: input, Conv2DTranspose: output gradient), V = the coarse one; the
+//     reduction over the pixels m is split over gridDim.z workgroups (one slab row each) and their waves
+#include "odin_device.h"
+#include "odin_internal.h"
+#include <cstdlib>
+
+namespace {
+
+#ifdef ODIN_SIM
+#define IG_UNIFORM(x) (x)
+#else
+#define IG_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
+constexpr int IG_U = 8;  // k-groups (8 k-values each) per batch
+
+struct IGParams {
+  const float* in;    // gathered tensor [B, H, W, CI]
+  const float* w;
+  float* out;         // [B, OH, OW, CO]
+  const float* bias;  // forward
+  const float* aux;   // data gradient: multiply by act'(aux), aux shaped like out
+  float* colsum;      // data gradient: slab [gridDim.y][CO] of column sums (may be null)
+  int B, H, W, CI, OH, OW, CO, KH, KW, S, pt, pl;
+  int ci_shift;       // CI = 1 << ci_shift
+  int act, aux_act;
+  int Mc;             // rows per stride class
+  int tpc;            // 32-row tiles per stride class
+  unsigned mg_tpc, mg_img, mg_row;  // ceil(2^32 / d) for d = tpc, (OH/S)(OW/S), OW/S (0: d == 1)
+  unsigned dbg_a, dbg_b;  // diagnostics (ODIN_IG_DBG bit 0 / 1): all A / B loads out of range (no traffic)
+  long long* stamps;      // diagnostics build: clock stamps of workgroup (0, 0), wave 0
+};
+
+#if defined(ODIN_SIM) || !defined(ODIN_DIAG)
+#define IG_STAMP(k) ((void)0)
+#define IG_WSTAMP(k) ((void)0)
+#else
+#define IG_STAMP(k)                                                                        \
+  do {                                                                                     \
+    if (p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)             \
+      p.stamps[k] = (long long)clock64();                                                  \
+  } while (0)
+#define IG_WSTAMP(k)                                                                       \
+  do {                                                                                     \
+    if (p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)             \
+      p.stamps[k] = (long long)wall_clock64();                                             \
+  } while (0)
+#endif
+
+// q / d through the host-computed magic = ceil(2^32 / d): exact for q * d < 2^32 (launcher checks)
+__device__ __forceinline__ int ig_magicdiv(int q, unsigned magic) {
+  return magic == 0u ? q : (int)__umulhi((unsigned)q, magic);
+}
+// t / d for 0 <= t < 64, 1 <= d <= 8 on the scalar unit
+__device__ __forceinline__ int ig_smalldiv(int t, int d) { return (t * (256 / d + 1)) >> 8; }
+
+template <int NW, bool TMODE, bool BKC>
+__global__ __launch_bounds__(NW * 64) void igemm_kernel(IGParams p) {
+  __shared__ float red[NW > 1 ? (NW - 1) * 16 * 64 : 64];
+  __shared__ int rowoff[32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  IG_STAMP(0);
+  IG_WSTAMP(8);
+  const int wave = IG_UNIFORM(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  // ---- this tile's stride class and its taps ----
+  const int cls = TMODE ? ig_magicdiv((int)blockIdx.y, p.mg_tpc) : 0;
+  const int tile = TMODE ? (int)blockIdx.y - cls * p.tpc : (int)blockIdx.y;
+  const int SS = TMODE ? p.S : 1;     // 1 or 2
+  const int ssh = SS >> 1;            // x / SS = x >> ssh,  x % SS = x & (SS - 1)
+  const int cy = cls >> ssh, cx = cls - (cy << ssh);
+  const int kh0 = TMODE ? (cy + p.pt) & (SS - 1) : 0, kw0 = TMODE ? (cx + p.pl) & (SS - 1) : 0;
+  const int nkh = (p.KH - kh0 + SS - 1) >> ssh, nkw = (p.KW - kw0 + SS - 1) >> ssh;
+  const int ntap = nkh * nkw;
+  // ---- this lane's A row: one output pixel ----
+  const int q = tile * 32 + l31;
+  const bool a_ok = q < p.Mc;
+  const int ohs = p.OH >> ssh, ows = p.OW >> ssh;
+  const int b = ig_magicdiv(q, p.mg_img), r = q - b * (ohs * ows);
+  const int ys = ig_magicdiv(r, p.mg_row), xs = r - ys * ows;
+  const int oy = ys * SS + cy, ox = xs * SS + cx;
+  // gathered pixel of tap (a, c): (Y0 + sg a, X0 + sg c)
+  const int sg = TMODE ? -1 : 1;
+  const int Y0 = TMODE ? (oy + p.pt - kh0) >> ssh : oy * p.S - p.pt;
+  const int X0 = TMODE ? (ox + p.pl - kw0) >> ssh : ox * p.S - p.pl;
+  unsigned mask = 0;
+  {
+    int t = 0;
+    for (int a = 0; a < nkh; ++a)
+      for (int c = 0; c < nkw; ++c, ++t) {
+        const unsigned in = ((unsigned)(Y0 + sg * a) < (unsigned)p.H) & ((unsigned)(X0 + sg * c) < (unsigned)p.W);
+        mask |= in << t;
+      }
+  }
+  mask = a_ok ? mask : 0u;
+  const int lanebase = (((b * p.H + Y0) * p.W + X0) << p.ci_shift) + 4 * h;  // floats
+  if (h == 0) rowoff[l31] = a_ok ? ((b * p.OH + oy) * p.OW + ox) : -1;
+  const int j = blockIdx.x * 32 + l31;
+  const bool b_ok = j < p.CO;
+  const unsigned bl = b_ok ? (unsigned)((BKC ? (j << p.ci_shift) + 4 * h : 4 * h * p.CO + j) * 4) : ODIN_OOB_V;
+  const OdinRun RA = odin_run(p.in, (unsigned)((size_t)p.B * p.H * p.W * p.CI * 4));
+  const OdinRun RB = odin_run(p.w, (unsigned)((size_t)p.KH * p.KW * p.CI * p.CO * 4));
+  const int gsh = p.ci_shift - 3;       // k-groups per tap = 1 << gsh
+  const int ngroups = ntap << gsh;
+  f32x16 acc = f32x16_zero();
+  float av0[IG_U][4], bv0[IG_U][4], av1[IG_U][4], bv1[IG_U][4];
+  // the epilogue's operands (bias; store offsets and act'(aux) factors of wave 0's 16 rows) are fetched NOW:
+  // loaded in the epilogue they cost one exposed cold-L2 round trip, and 16 dependent LDS reads inside
+  // exec-mask branches another 2 us (in-kernel stamps: 4.8 k of 24 k cycles)
+  float auxv[16];
+  unsigned ooff[16];  // byte offset of (row, column j) in `out`; out of range for rows / columns beyond the tensor
+  __syncthreads();    // rowoff
+  const float bj = (p.bias != nullptr && b_ok) ? p.bias[j] : 0.f;
+  {
+    const OdinRun RX = odin_run(p.aux != nullptr ? p.aux : p.in,
+                                p.aux != nullptr ? (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4) : 0u);
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int po = rowoff[(rr & 3) + 8 * (rr >> 2) + 4 * h];
+      const unsigned ok = (unsigned)(wave == 0) & (unsigned)b_ok & (((unsigned)po >> 31) ^ 1u);
+      ooff[rr] = (unsigned)((po * p.CO + j) * 4) | (ok - 1u);
+      auxv[rr] = odin_run_load1(RX, ooff[rr]);
+    }
+  }
+
+  auto load_group = [&](int gr, float (&av)[4], float (&bv)[4]) {
+    // branch-free (a wave-uniform `cond ? a : b` becomes a scalar branch that cuts the batch of loads in
+    // two): groups beyond the reduction are clamped to the last one and their lanes read out of range
+    const unsigned live = (unsigned)(gr - ngroups) >> 31;   // 1 / 0   (gr is wave-uniform)
+    const unsigned dead = live - 1u;                          // 0 / 0xFFFFFFFF
+    const int g = gr < ngroups ? gr : ngroups - 1;
+    const int t = g >> gsh;                     // tap index within the stride class
+    const int ci0 = (g - (t << gsh)) << 3;
+    const int a = ig_smalldiv(t, nkw), c = t - a * nkw;
+    const int tapoff = (sg * (a * p.W + c)) << p.ci_shift;
+    const unsigned va = live & (mask >> t) & 1u;
+    const float4 x = odin_run_load4(RA, (unsigned)((lanebase + tapoff + ci0) * 4) | (va - 1u) | p.dbg_a);
+    av[0] = x.x; av[1] = x.y; av[2] = x.z; av[3] = x.w;
+    const int wt = (kh0 + a * SS) * p.KW + kw0 + c * SS;  // weight tap
+    if constexpr (BKC) {
+      const unsigned so = (unsigned)(((wt * p.CO) << p.ci_shift) + ci0) * 4u;
+      const float4 y = odin_run_load4s(RB, bl | dead | p.dbg_b, so);
+      bv[0] = y.x; bv[1] = y.y; bv[2] = y.z; bv[3] = y.w;
+    } else {
+      const unsigned so = (unsigned)(((wt << p.ci_shift) + ci0) * p.CO) * 4u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        bv[e] = odin_run_load1s(RB, bl | dead | p.dbg_b, so + (unsigned)(e * p.CO * 4));
+    }
+  };
+  // the MFMAs of the current batch with the loads of the next one BETWEEN them: a wave issues in order and
+  // its dependent MFMA chain occupies the issue slot for 64 cycles per instruction -- loads placed behind the
+  // chain would only start once it has drained (measured: 4 k cycles per batch instead of 2 k).  The fences
+  // pin the interleaving.
+  auto mul_load = [&](const float (&av)[IG_U][4], const float (&bv)[IG_U][4], int gnext,
+                      float (&nav)[IG_U][4], float (&nbv)[IG_U][4]) {
+#pragma unroll
+    for (int u = 0; u < IG_U; ++u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma32(av[u][e], bv[u][e], acc);
+      ODIN_SCHED_FENCE();
+      load_group(gnext + u, nav[u], nbv[u]);
+      ODIN_SCHED_FENCE();
+    }
+  };
+
+  // ---- this wave's batches: wave, wave + NW, ... ----
+  const int stride = NW * IG_U;
+  int g = wave * IG_U;
+  IG_STAMP(1);
+  if (g < ngroups) {
+#pragma unroll
+    for (int u = 0; u < IG_U; ++u) load_group(g + u, av0[u], bv0[u]);
+    IG_STAMP(2);
+    for (;;) {
+      mul_load(av0, bv0, g + stride, av1, bv1);  // (beyond the reduction: zeros, no memory traffic)
+      g += 2 * stride;
+      if (g - stride >= ngroups) break;
+      mul_load(av1, bv1, g, av0, bv0);
+      if (g >= ngroups) break;
+    }
+  }
+  IG_STAMP(3);
+  // ---- combine the NW partial tiles in wave order ----
+  if (NW > 1) {
+    if (wave > 0) {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) red[((wave - 1) * 16 + rr) * 64 + lane] = acc[rr];
+    }
+  }
+  __syncthreads();
+  IG_STAMP(4);
+  if (wave != 0) return;
+  if (NW > 1) {
+    for (int w = 1; w < NW; ++w) {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) acc[rr] += red[((w - 1) * 16 + rr) * 64 + lane];
+    }
+  }
+  IG_STAMP(5);
+  // ---- epilogue: lane holds column j, rows (rr & 3) + 8 (rr >> 2) + 4 h ----
+  float cs = 0.f;
+  const OdinRun RO = odin_run(p.out, (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4));
+  const bool has_aux = p.aux != nullptr;
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    float v = odin_act(p.act, acc[rr] + bj);
+    if (has_aux) v *= odin_act_grad(p.aux_act, auxv[rr]);
+    odin_run_store1(RO, ooff[rr], v);           // range-checked: nothing is written for masked rows
+    cs += ((int)ooff[rr] >= 0) ? v : 0.f;
+  }
+  if (p.colsum != nullptr) {
+    cs += __shfl_xor(cs, 32);
+    if (h == 0 && b_ok) p.colsum[(size_t)blockIdx.y * p.CO + j] = cs;
+  }
+  IG_STAMP(6);
+  IG_WSTAMP(9);
+}
+
+// --------------------------------------------------------------------------------------------------
+struct IWParams {
+  const float* u;   // fine tensor   [B, FH, FW, CU]
+  const float* v;   // coarse tensor [B, h, w, CV]
+  float* slab;      // [gridDim.z][slab_stride]: (dW [KH*KW*CU][CV] | column sums of V [CV])
+  int slab_stride;
+  int B, FH, FW, CU, h, w, CV, KH, KW, S, pt, pl;
+  int cu_shift;
+  int M;            // B * h * w
+  int chunk;        // pixels per workgroup (multiple of 8, <= IW_CHUNK)
+  int want_bias;
+};
+
+constexpr int IW_CHUNK = 1024;
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(IWParams p) {
+  __shared__ float red[NW > 1 ? (NW - 1) * 16 * 64 : 64];
+  __shared__ int tb_base[IW_CHUNK + 8];   // float offset of the fine pixel (y S - pt, x S - pl) of coarse pixel m
+  __shared__ int tb_yx[IW_CHUNK + 8];     // (y S - pt + 64) << 16 | (x S - pl + 64); -1: beyond this workgroup's pixels
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = IG_UNIFORM(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int I = p.KH * p.KW * p.CU;
+  const int i = blockIdx.y * 32 + l31, j = blockIdx.x * 32 + l31;
+  const bool i_ok = i < I, j_ok = j < p.CV;
+  const int tap = i >> p.cu_shift, cu = i & (p.CU - 1);
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int rowc = ((kh * p.FW + kw) << p.cu_shift) + cu;
+  const int mlo = blockIdx.z * p.chunk;
+  const int mhi = (mlo + p.chunk < p.M) ? mlo + p.chunk : p.M;
+  for (int e = tid; e < IW_CHUNK + 8; e += NW * 64) {
+    const int m = mlo + e;
+    if (m < mhi && e < p.chunk) {
+      const int b = m / (p.h * p.w), r = m - b * (p.h * p.w), y = r / p.w, x = r - y * p.w;
+      const int fy = y * p.S - p.pt, fx = x * p.S - p.pl;
+      tb_base[e] = ((b * p.FH + fy) * p.FW + fx) << p.cu_shift;
+      tb_yx[e] = ((fy + 64) << 16) | (fx + 64);
+    } else {
+      tb_base[e] = 0;
+      tb_yx[e] = -1;
+    }
+  }
+  __syncthreads();
+  const OdinRun RU = odin_run(p.u, (unsigned)((size_t)p.B * p.FH * p.FW * p.CU * 4));
+  const OdinRun RV = odin_run(p.v, (unsigned)((size_t)p.M * p.CV * 4));
+  const int ngroups = (mhi - mlo + 7) >> 3;
+  f32x16 acc = f32x16_zero();
+  float csum = 0.f;
+  float av0[IG_U][4], bv0[IG_U][4], av1[IG_U][4], bv1[IG_U][4];
+
+  auto load_group = [&](int gr, float (&av)[4], float (&bv)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // pixel of this lane's half within the chunk (branch-free: entries [chunk, IW_CHUNK + 8) are -1)
+      const int mr = gr * 8 + 4 * h + e;
+      const int ml = mr < IW_CHUNK ? mr : IW_CHUNK;
+      const int base = tb_base[ml];
+      const int yx = tb_yx[ml];
+      const int fy = (yx >> 16) - 64 + kh, fx = (yx & 0xFFFF) - 64 + kw;
+      const unsigned inb = ((unsigned)yx >> 31) ^ 1u;   // 1: a pixel of this workgroup
+      const unsigned va = (unsigned)i_ok & inb & ((unsigned)fy < (unsigned)p.FH) & ((unsigned)fx < (unsigned)p.FW);
+      av[e] = odin_run_load1(RU, (unsigned)((base + rowc) * 4) | (va - 1u));
+      const unsigned vb = (unsigned)j_ok & inb;
+      bv[e] = odin_run_load1(RV, (unsigned)(((mlo + ml) * p.CV + j) * 4) | (vb - 1u));
+    }
+  };
+  // (MFMAs of the current batch with the loads of the next between them, as in igemm_kernel)
+  auto mul_load = [&](const float (&av)[IG_U][4], const float (&bv)[IG_U][4], int gnext,
+                      float (&nav)[IG_U][4], float (&nbv)[IG_U][4]) {
+#pragma unroll
+    for (int u = 0; u < IG_U; ++u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc = mfma32(av[u][e], bv[u][e], acc);
+        csum += bv[u][e];
+      }
+      ODIN_SCHED_FENCE();
+      load_group(gnext + u, nav[u], nbv[u]);
+      ODIN_SCHED_FENCE();
+    }
+  };
+
+  const int stride = NW * IG_U;
+  int g = wave * IG_U;
+  if (g < ngroups) {
+#pragma unroll
+    for (int u = 0; u < IG_U; ++u) load_group(g + u, av0[u], bv0[u]);
+    for (;;) {
+      mul_load(av0, bv0, g + stride, av1, bv1);
+      g += 2 * stride;
+      if (g - stride >= ngroups) break;
+      mul_load(av1, bv1, g, av0, bv0);
+      if (g >= ngroups) break;
+    }
+  }
+  if (NW > 1) {
+    if (wave > 0) {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) red[((wave - 1) * 16 + rr) * 64 + lane] = acc[rr];
+    }
+  }
+  __syncthreads();
+  if (NW > 1 && wave == 0) {
+    for (int w = 1; w < NW; ++w) {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) acc[rr] += red[((w - 1) * 16 + rr) * 64 + lane];
+    }
+  }
+  float* row = p.slab + (size_t)blockIdx.z * p.slab_stride;
+  if (p.want_bias && blockIdx.y == 0) {
+    // column sums of V over this workgroup's pixels: halves h = 0 / 1 and the NW waves, fixed order
+    __syncthreads();
+    const float t = csum + __shfl_xor(csum, 32);
+    if (h == 0) red[wave * 32 + l31] = t;
+    __syncthreads();
+    if (wave == 0 && h == 0 && j_ok) {
+      float s = 0.f;
+      for (int w = 0; w < NW; ++w) s += red[w * 32 + l31];
+      row[(size_t)I * p.CV + j] = s;
+    }
+  }
+  if (wave != 0 || !j_ok) return;
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int ii = blockIdx.y * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+    if (ii < I) row[(size_t)ii * p.CV + j] = acc[rr];
+  }
+}
+
+int ilog2_exact(int v) {
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return (1 << s) == v ? s : -1;
+}
+
+// (read on every call: the A/B tests of the other paths switch it at run time; graph replays never get here)
+bool igemm_enabled() { return getenv("ODIN_NOIGEMM") == nullptr; }
+
+template <bool TMODE, bool BKC>
+int ig_launch_t(IGParams& p, dim3 grid, int nw, void* stream) {
+  if (nw >= 8) ODIN_LAUNCH((igemm_kernel<8, TMODE, BKC>), grid, dim3(512), 0, stream, p);
+  else if (nw == 4) ODIN_LAUNCH((igemm_kernel<4, TMODE, BKC>), grid, dim3(256), 0, stream, p);
+  else if (nw == 2) ODIN_LAUNCH((igemm_kernel<2, TMODE, BKC>), grid, dim3(128), 0, stream, p);
+  else ODIN_LAUNCH((igemm_kernel<1, TMODE, BKC>), grid, dim3(64), 0, stream, p);
+  return odin_check_launch("igemm");
+}
+
+long long* g_ig_stamps = nullptr;
+
+}  // namespace
+
+void odin_igemm_set_stamps(void* buf) { g_ig_stamps = (long long*)buf; }
+
+// The small-layer regime: a reduction of whole 8-channel groups over a power-of-two channel count, at most
+// 25 taps, strides 1 / 2 (transposed gathers: output extents divisible by the stride), <= 1.2 GFLOP, and
+// tensors below 2^29 elements (32-bit byte offsets).  `tmode`: transposed gather.  (H, W, CI) = gathered
+// tensor, (OH, OW, CO) = produced tensor.
+bool odin_igemm_applicable(int tmode, int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
+                           int S, int center) {
+  if (!igemm_enabled() || center) return false;
+  if (ilog2_exact(CI) < 3 || KH * KW > 25 || KH < 1 || KW < 1 || KH > 8 || KW > 8 || S < 1 || S > 2) return false;
+  if (tmode && (OH % S || OW % S || KH < S || KW < S)) return false;
+  const double flop = 2.0 * B * (tmode ? (double)H * W : (double)OH * OW) * KH * KW * CI * CO;
+  if (flop > 1.2e9) return false;
+  if ((double)B * OH * OW * OH * OW >= 2e9) return false;  // exactness of the magic-number row decoding
+  if ((long)B * H * W * CI >= (1L << 29) || (long)B * OH * OW * CO >= (1L << 29) ||
+      (long)KH * KW * CI * CO >= (1L << 29))
+    return false;
+  return true;
+}
+
+// rows of column sums the data-gradient launch writes (= its 32-row tiles)
+int odin_igemm_tiles(int tmode, int B, int OH, int OW, int S) {
+  const int SS = tmode ? S : 1;
+  const int Mc = B * (OH / SS) * (OW / SS);
+  return SS * SS * ((Mc + 31) / 32);
+}
+
+int odin_igemm_launch(int tmode, const float* in, const float* w, const float* bias, const float* aux,
+                      int aux_act, float* out, float* colsum, int B, int H, int W, int CI, int OH, int OW,
+                      int CO, int KH, int KW, int S, int pt, int pl, int act, void* stream) {
+  IGParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = in; p.w = w; p.out = out; p.bias = bias;
+  p.aux = (aux != nullptr && aux_act != 0) ? aux : nullptr; p.aux_act = aux_act; p.colsum = colsum;
+  p.B = B; p.H = H; p.W = W; p.CI = CI; p.OH = OH; p.OW = OW; p.CO = CO;
+  p.KH = KH; p.KW = KW; p.S = S; p.pt = pt; p.pl = pl; p.ci_shift = ilog2_exact(CI); p.act = act;
+  const int SS = tmode ? S : 1;
+  p.Mc = B * (OH / SS) * (OW / SS);
+  p.tpc = (p.Mc + 31) / 32;
+  auto magic = [](long d) { return d <= 1 ? 0u : (unsigned)(((1L << 32) + d - 1) / d); };
+  p.mg_tpc = magic(p.tpc); p.mg_img = magic((long)(OH / SS) * (OW / SS)); p.mg_row = magic(OW / SS);
+  dim3 grid((CO + 31) / 32, SS * SS * p.tpc, 1);
+  // waves per tile: enough k-groups per wave to amortise the launch, enough waves to fill the chip
+  const int ngroups = (KH / SS) * (KW / SS) * CI / 8;
+  const long tiles = (long)grid.x * grid.y;
+  int nw = 1;
+  // (4 waves at most: the 8-wave variant measured slower on every layer -- the serial 7-tile sum of wave 0)
+  while (nw < 4 && tiles * nw < 4 * 256 && ngroups / (nw * 2) >= IG_U) nw *= 2;
+  if (const char* e = getenv("ODIN_IG_NW")) nw = atoi(e);
+  if (const char* e = getenv("ODIN_IG_DBG")) {
+    const int f = atoi(e);
+    p.dbg_a = (f & 1) ? 0xFFFFFFFFu : 0u;
+    p.dbg_b = (f & 2) ? 0xFFFFFFFFu : 0u;
+  }
+  p.stamps = g_ig_stamps;
+  // Conv2D forward / Conv2DTranspose data gradient: weights [tap][k][j]; the transposed gathers: [tap][j][k]
+  if (tmode) return ig_launch_t<true, true>(p, grid, nw, stream);
+  return ig_launch_t<false, false>(p, grid, nw, stream);
+}
+
+// weight gradient: fine tensor (FH, FW, CU) gathered around the pixels of the coarse one (h, w, CV)
+bool odin_igemm_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, int CV, int KH, int KW, int S,
+                                 int center) {
+  if (!igemm_enabled() || center) return false;
+  if (ilog2_exact(CU) < 3 || KH * KW > 64 || KH < 1 || KW < 1 || S < 1 || S > 4) return false;
+  if (FH > 8192 || FW > 8192 || (long)B * h * w > 65536) return false;
+  const double flop = 2.0 * B * h * w * KH * KW * CU * CV;
+  if (flop > 1.2e9) return false;
+  if ((long)B * FH * FW * CU >= (1L << 29) || (long)B * h * w * CV >= (1L << 29)) return false;
+  return true;
+}
+
+// reduction splits (= slab rows) of the weight-gradient launch
+int odin_igemm_wgrad_rows(int B, int h, int w, int KH, int KW, int CU, int CV) {
+  const int M = B * h * w;
+  const long tiles = (long)((KH * KW * CU + 31) / 32) * ((CV + 31) / 32);
+  int R = (M + IW_CHUNK - 1) / IW_CHUNK;
+  // enough workgroups to fill the chip, at least 64 pixels each
+  while (tiles * R < 512 && M / (R * 2) >= 64 && R * 2 <= ODIN_MAX_SLAB_BLOCKS) R *= 2;
+  if (const char* e = getenv("ODIN_IG_R")) {
+    const int r = atoi(e);
+    if (r >= 1 && r <= ODIN_MAX_SLAB_BLOCKS && (M + r - 1) / r <= IW_CHUNK) R = r;
+  }
+  return R;
+}
+
+int odin_igemm_wgrad_launch(const float* u, const float* v, float* slab, int slab_stride, int B, int FH,
+                            int FW, int CU, int h, int w, int CV, int KH, int KW, int S, int pt, int pl,
+                            int want_bias, void* stream) {
+  IWParams p;
+  memset(&p, 0, sizeof(p));
+  p.u = u; p.v = v; p.slab = slab; p.slab_stride = slab_stride;
+  p.B = B; p.FH = FH; p.FW = FW; p.CU = CU; p.h = h; p.w = w; p.CV = CV;
+  p.KH = KH; p.KW = KW; p.S = S; p.pt = pt; p.pl = pl; p.cu_shift = ilog2_exact(CU);
+  p.M = B * h * w; p.want_bias = want_bias;
+  const int R = odin_igemm_wgrad_rows(B, h, w, KH, KW, CU, CV);
+  p.chunk = (((p.M + R - 1) / R) + 7) & ~7;
+  if (p.chunk > IW_CHUNK) return odin_fail(-2, "igemm wgrad: reduction chunk too long");
+  dim3 grid((CV + 31) / 32, (KH * KW * CU + 31) / 32, R);
+  const int ngroups = p.chunk / 8;
+  const long wgs = (long)grid.x * grid.y * grid.z;
+  // measured (enc3 / dec1 weight gradients): 4 waves beat 1, 2 and 8 even with one batch per wave
+  (void)wgs;
+  int nw = ngroups >= 16 ? 4 : ngroups >= 8 ? 2 : 1;
+  if (const char* e = getenv("ODIN_IG_NW")) nw = atoi(e);
+  if (nw >= 8) ODIN_LAUNCH((igemm_wgrad_kernel<8>), grid, dim3(512), 0, stream, p);
+  else if (nw == 4) ODIN_LAUNCH((igemm_wgrad_kernel<4>), grid, dim3(256), 0, stream, p);
+  else if (nw == 2) ODIN_LAUNCH((igemm_wgrad_kernel<2>), grid, dim3(128), 0, stream, p);
+  else ODIN_LAUNCH((igemm_wgrad_kernel<1>), grid, dim3(64), 0, stream, p);
+  return odin_check_launch("igemm_wgrad");
+}

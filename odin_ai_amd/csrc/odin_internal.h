@@ -85,3 +85,18 @@ bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, i
 int odin_fconv_planes_launch(const float* in, const float* w, const float* bias, const float* aux,
                              float* out, float* colsum, int* rows_out, int B, int OH, int OW, int CO,
                              int epi, void* stream);
+
+// small-spatial layers as implicit GEMMs with both operands straight from L2 (igemm.hip)
+bool odin_igemm_applicable(int tmode, int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
+                           int S, int center);
+void odin_igemm_set_stamps(void* buf);
+int odin_igemm_tiles(int tmode, int B, int OH, int OW, int S);
+int odin_igemm_launch(int tmode, const float* in, const float* w, const float* bias, const float* aux,
+                      int aux_act, float* out, float* colsum, int B, int H, int W, int CI, int OH, int OW,
+                      int CO, int KH, int KW, int S, int pt, int pl, int act, void* stream);
+bool odin_igemm_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, int CV, int KH, int KW, int S,
+                                 int center);
+int odin_igemm_wgrad_rows(int B, int h, int w, int KH, int KW, int CU, int CV);
+int odin_igemm_wgrad_launch(const float* u, const float* v, float* slab, int slab_stride, int B, int FH,
+                            int FW, int CU, int h, int w, int CV, int KH, int KW, int S, int pt, int pl,
+                            int want_bias, void* stream);

@@ -7,19 +7,12 @@
 // step) are read from device memory so that a captured HIP graph can be replayed.
 #include "odin_device.h"
 #include "odin_internal.h"
+#include "odin_latent_math.h"
 #include <cstdlib>
 #include <cstdint>
 
 namespace {
 
-__device__ __forceinline__ float softplus_f(float x) {
-  return fmaxf(x, 0.f) + log1pf(odin_exp(-fabsf(x)));
-}
-__device__ __forceinline__ float sigmoid_f(float x) {
-  float e = odin_exp(-fabsf(x));
-  float s = 1.f / (1.f + e);
-  return x >= 0.f ? s : e * s;
-}
 constexpr float LOG2PI_F = 1.8378770664093453f;
 constexpr float SOFTPLUS_INV1 = 0.5413248546129181f;
 
@@ -491,37 +484,13 @@ __global__ __launch_bounds__(256) void sum_stage2(const float* part, int n, floa
 }
 
 // ------------------------------------------------------------------ RNG -------------
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
-                                              unsigned k0, unsigned k1, unsigned out[4]) {
-  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    unsigned hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    unsigned hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-    unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += W0; k1 += W1;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 __global__ __launch_bounds__(256) void rng_normal_kernel(float* out, size_t n, unsigned k0,
                                                          unsigned k1, const int* step_dev) {
   const unsigned step = step_dev ? (unsigned)step_dev[0] : 0u;
   const size_t n4 = (n + 3) >> 2, stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    unsigned r[4];
-    philox4x32_10((unsigned)i, (unsigned)(i >> 32), step, 0u, k0, k1, r);
-    float u0 = ((float)(r[0] >> 8) + 0.5f) * (1.f / 16777216.f);
-    float u1 = ((float)(r[1] >> 8) + 0.5f) * (1.f / 16777216.f);
-    float u2 = ((float)(r[2] >> 8) + 0.5f) * (1.f / 16777216.f);
-    float u3 = ((float)(r[3] >> 8) + 0.5f) * (1.f / 16777216.f);
-    float ra = sqrtf(-2.f * odin_log(u0)), rb = sqrtf(-2.f * odin_log(u2));
     float v[4];
-    v[0] = ra * cosf(6.2831853071795865f * u1);
-    v[1] = ra * sinf(6.2831853071795865f * u1);
-    v[2] = rb * cosf(6.2831853071795865f * u3);
-    v[3] = rb * sinf(6.2831853071795865f * u3);
+    odin_normal4((unsigned)i, (unsigned)(i >> 32), step, k0, k1, v);
     for (int j = 0; j < 4; ++j)
       if (i * 4 + j < n) out[i * 4 + j] = v[j];
   }

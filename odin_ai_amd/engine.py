@@ -197,11 +197,13 @@ class NetProgram:
     return self.params[r.b_off:r.b_off + r.b_n]
 
   # -- forward --------------------------------------------------------------------------
-  def forward(self, x: torch.Tensor, st, upto: Optional[int] = None):
-    """run layers [0, upto) (all when None); returns the last output (or x)."""
+  def forward(self, x: torch.Tensor, st, upto: Optional[int] = None, start: int = 0):
+    """run layers [start, upto) (to the end when None) on x = the input of layer `start`; returns the last
+    output (or x)."""
     lib, B = self.lib, self.B
     h = x
-    for i, r in enumerate(self.recs[:upto]):
+    for i in range(start, len(self.recs) if upto is None else upto):
+      r = self.recs[i]
       y = self.outs[i]
       if r.kind == 'conv':
         lib.odin_conv2d_fwd(h.data_ptr(), self.w(i).data_ptr(), self.b(i).data_ptr(),
@@ -219,15 +221,16 @@ class NetProgram:
   def backward(self, x: torch.Tensor, gout_last: torch.Tensor, st,
                dx_out: Optional[torch.Tensor] = None, last: Optional[int] = None,
                skip_bias_of_last: bool = False, data_only: bool = False,
-               fork=None, side_jobs: Optional[list] = None) -> List[ReduceJob]:
+               fork=None, side_jobs: Optional[list] = None, first: int = 0) -> List[ReduceJob]:
     """gout_last: dL/d(pre-activation output of the last layer).  If dx_out is given the
-    gradient wrt the network input is written there.  Returns the slab-reduce jobs."""
+    gradient wrt the network input is written there.  `first` > 0 stops above layer `first`: its data
+    gradient still lands in gouts[first - 1], layers below are the caller's.  Returns the slab-reduce jobs."""
     lib, B = self.lib, self.B
     n = len(self.recs) if last is None else last + 1
     jobs: List[ReduceJob] = []
     g = gout_last
     rows = C.c_int(0)
-    for i in range(n - 1, -1, -1):
+    for i in range(n - 1, first - 1, -1):
       r, d = self.recs[i], self.descs[i]
       xin = x if i == 0 else self.outs[i - 1]
       # ---- weight (and bias) gradient: independent of the data-gradient chain, so it is
@@ -404,6 +407,7 @@ class VAEEngine:
         self.tc_p_all = torch.empty(Bg, 2 * D, **f32)
         self.tc_part_all = torch.empty(2, Bg, D, **f32)    # dloc / dscale partials for every i
     self._plan_fused_tail(f32)
+    self._plan_latent_block(f32)
     self.ws = torch.empty(1024, **f32)
     self.gnorm2 = torch.zeros(1, **f32)
     self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -493,6 +497,27 @@ class VAEEngine:
     co, c1 = a.desc['Cout'], b.desc['Cout']
     self.tail_slab = torch.empty(rows.value, co * c1 + c1 + co, **f32)
     self.tail_llk_part = torch.empty(self.B * npart.value, **f32)
+
+  def _plan_latent_block(self, f32):
+    """Training-step fusion of the bottleneck (latent_block.hip): noise + DistributionDense + reparameterise /
+    KL + the decoder's first Dense as one launch, and their five backward launches as one, when the decoder
+    starts with a Dense layer and both weight matrices fit in LDS."""
+    self.lat_block = self._used_block = False
+    recs = self.dec_recs
+    if len(recs) < 2 or recs[0].kind != 'dense' or self.enc_recs[-1].kind == 'deconv':
+      return
+    rows = self.lib.odin_latent_block_rows(self.B, self.hdim, self.D, recs[0].N)
+    if rows <= 0:
+      return
+    self.lat_block, self.lb_rows = True, rows
+    D, N0 = self.D, recs[0].N
+    self.lb_slab0 = torch.empty(rows, D * N0 + N0, **f32)
+    self.lb_slabl = torch.empty(rows, self.hdim * 2 * D + 2 * D, **f32)
+
+  def _bwd_block(self) -> bool:
+    # (two gradient buckets: the decoder's first Dense belongs to the bucket that is already being
+    # all-reduced while the encoder's share runs -- keep the separate launches there)
+    return self.lat_block and self._used_block and not (self.is_dp and self.dp_buckets >= 2)
 
   # ---- helpers -----------------------------------------------------------------------
   def hp(self, idx):  # device address of one hyper scalar
@@ -611,22 +636,37 @@ class VAEEngine:
     st = self.stream() if st is None else st
     assert x.shape == (B,) + self.in_shape and x.is_contiguous()
     self.x = x
-    if eps is None:
-      lib.odin_rng_normal(self.eps.data_ptr(), B * D, self.seed, self.hp(N_HYPER), st)
-    elif eps is not self.eps:
-      self.eps.copy_(eps)
-    h_e = self.enc.forward(x, st)
     lw = self.params[self.lat_w_off:]
     lb = self.params[self.lat_b_off:]
-    lib.odin_dense_fwd(h_e.data_ptr(), lw.data_ptr(), lb.data_ptr(), self.p.data_ptr(), B,
-                       self.hdim, 2 * D, 0, st)
-    lib.odin_latent_fwd(self.p.data_ptr(), self.eps.data_ptr(), self.z.data_ptr(),
-                        self.kl.data_ptr(), self.fbmask.data_ptr(), B, D, int(self.analytic),
-                        self.free_bits, st)
+    self._used_block = self.lat_block and fused
+    if self._used_block:
+      if eps is not None and eps is not self.eps:
+        self.eps.copy_(eps)
+      h_e = self.enc.forward(x, st)
+      r0 = self.dec_recs[0]
+      lib.odin_latent_block_fwd(h_e.data_ptr(), lw.data_ptr(), lb.data_ptr(),
+                                None if eps is None else self.eps.data_ptr(), self.eps.data_ptr(),
+                                self.seed, self.hp(N_HYPER), self.p.data_ptr(), self.z.data_ptr(),
+                                self.kl.data_ptr(), self.fbmask.data_ptr(), self.dec.w(0).data_ptr(),
+                                self.dec.b(0).data_ptr(), self.dec.outs[0].data_ptr(), B, self.hdim, D,
+                                r0.N, ACT[r0.act], int(self.analytic), self.free_bits, st)
+      dec_in, dec_start = self.dec.outs[0], 1
+    else:
+      if eps is None:
+        lib.odin_rng_normal(self.eps.data_ptr(), B * D, self.seed, self.hp(N_HYPER), st)
+      elif eps is not self.eps:
+        self.eps.copy_(eps)
+      h_e = self.enc.forward(x, st)
+      lib.odin_dense_fwd(h_e.data_ptr(), lw.data_ptr(), lb.data_ptr(), self.p.data_ptr(), B,
+                         self.hdim, 2 * D, 0, st)
+      lib.odin_latent_fwd(self.p.data_ptr(), self.eps.data_ptr(), self.z.data_ptr(),
+                          self.kl.data_ptr(), self.fbmask.data_ptr(), B, D, int(self.analytic),
+                          self.free_bits, st)
+      dec_in, dec_start = self.z, 0
     npart = C.c_int(0)
     if self.fused_tail and fused:
       nd = len(self.dec_recs)
-      h = self.dec.forward(self.z, st, upto=nd - 2)
+      h = self.dec.forward(dec_in, st, upto=nd - 2, start=dec_start)
       a, b = self.dec_recs[-2], self.dec_recs[-1]
       rows = C.c_int(0)
       lib.odin_bernoulli_tail_fwd_bwd(
@@ -642,7 +682,7 @@ class VAEEngine:
     else:
       self._used_fused = False
       llk_part = self.llk_part
-      h_d = self.dec.forward(self.z, st)
+      h_d = self.dec.forward(dec_in, st, start=dec_start)
     gl = self.dec.gouts[-1]
     if self._used_fused:
       pass
@@ -780,7 +820,7 @@ class VAEEngine:
       co, c1 = a.desc['Cout'], b.desc['Cout']
       jobs = self.dec.backward(self.z, self.dec.gouts[-2], st, dx_out=self.dz, last=nd - 2,
                                skip_bias_of_last=True, fork=fork,
-                               side_jobs=late_jobs if early else None)
+                               side_jobs=late_jobs if early else None, first=int(self._bwd_block()))
       ts, stride = self.tail_slab, self.tail_slab.shape[1]
       # (dW1 | db1) of the 1x1 conv, then the bias gradient of the fused layer
       jobs.append(ReduceJob(ts.data_ptr(), self.grads[b.w_off:].data_ptr(), co * c1 + c1,
@@ -789,7 +829,7 @@ class VAEEngine:
                             self.tail_rows, stride, 0))
     else:
       jobs = self.dec.backward(self.z, self.dec.gouts[-1], st, dx_out=self.dz, fork=fork,
-                               side_jobs=late_jobs if early else None)
+                               side_jobs=late_jobs if early else None, first=int(self._bwd_block()))
     if early and jobs:
       # the decoder's slabs (most of the slab bytes) are complete: reduce them on a side stream
       # while the encoder's backward pass keeps the matrix cores busy (the reduction is HBM-bound)
@@ -807,27 +847,40 @@ class VAEEngine:
       dzx = self.tc_dz.data_ptr()
     tl = self.tc_dloc.data_ptr() if self.tc_mode == 'betatc' else None
     ts = self.tc_dscale.data_ptr() if self.tc_mode == 'betatc' else None
-    lib.odin_latent_bwd(self.p.data_ptr(), self.eps.data_ptr(), self.z.data_ptr(),
-                        self.dz.data_ptr(), dzx, self.fbmask.data_ptr(), self.hp(H_KLW), tl, ts,
-                        self.dp.data_ptr(), B, D, int(self.analytic), st)
     h_e = self.enc.outs[-1]
-    rows = C.c_int(0)
-    lib.odin_dense_wgrad(h_e.data_ptr(), self.dp.data_ptr(), self.lat_slab.data_ptr(),
-                         C.byref(rows), B, self.hdim, 2 * D, st if fork is None else fork(-1))  # small
-    jobs.append(ReduceJob(self.lat_slab.data_ptr(), self.grads[self.lat_w_off:].data_ptr(),
-                          self.lat_slab.shape[1], rows.value, self.lat_slab.shape[1], 0))
     last = self.enc_recs[-1]
     aux_act = ACT[last.act]
-    auxp = h_e.data_ptr() if aux_act != 0 else None
-    bslab = self.enc.bslabs[-1]
     lw = self.params[self.lat_w_off:]
-    lib.odin_dense_dgrad(self.dp.data_ptr(), lw.data_ptr(), auxp, aux_act,
-                         self.enc.gouts[-1].data_ptr(),
-                         bslab.data_ptr() if bslab is not None else None, C.byref(rows), B,
-                         self.hdim, 2 * D, st)
-    if bslab is not None:
-      jobs.append(ReduceJob(bslab.data_ptr(), self.grads[last.b_off:].data_ptr(), last.b_n,
-                            rows.value, last.b_n, 0))
+    if self._bwd_block():
+      r0 = self.dec_recs[0]
+      lib.odin_latent_block_bwd(self.dec.gouts[0].data_ptr(), self.dec.w(0).data_ptr(), self.z.data_ptr(),
+                                self.p.data_ptr(), self.eps.data_ptr(), self.fbmask.data_ptr(),
+                                self.hp(H_KLW), dzx, tl, ts, lw.data_ptr(), h_e.data_ptr(), aux_act,
+                                self.dz.data_ptr(), self.dp.data_ptr(), self.enc.gouts[-1].data_ptr(),
+                                self.lb_slab0.data_ptr(), self.lb_slabl.data_ptr(), B, self.hdim, D, r0.N,
+                                int(self.analytic), st)
+      jobs.append(ReduceJob(self.lb_slab0.data_ptr(), self.grads[r0.w_off:].data_ptr(),
+                            self.lb_slab0.shape[1], self.lb_rows, self.lb_slab0.shape[1], 0))
+      jobs.append(ReduceJob(self.lb_slabl.data_ptr(), self.grads[self.lat_w_off:].data_ptr(),
+                            self.lb_slabl.shape[1], self.lb_rows, self.lb_slabl.shape[1], 0))
+    else:
+      lib.odin_latent_bwd(self.p.data_ptr(), self.eps.data_ptr(), self.z.data_ptr(),
+                          self.dz.data_ptr(), dzx, self.fbmask.data_ptr(), self.hp(H_KLW), tl, ts,
+                          self.dp.data_ptr(), B, D, int(self.analytic), st)
+      rows = C.c_int(0)
+      lib.odin_dense_wgrad(h_e.data_ptr(), self.dp.data_ptr(), self.lat_slab.data_ptr(),
+                           C.byref(rows), B, self.hdim, 2 * D, st if fork is None else fork(-1))  # small
+      jobs.append(ReduceJob(self.lat_slab.data_ptr(), self.grads[self.lat_w_off:].data_ptr(),
+                            self.lat_slab.shape[1], rows.value, self.lat_slab.shape[1], 0))
+      auxp = h_e.data_ptr() if aux_act != 0 else None
+      bslab = self.enc.bslabs[-1]
+      lib.odin_dense_dgrad(self.dp.data_ptr(), lw.data_ptr(), auxp, aux_act,
+                           self.enc.gouts[-1].data_ptr(),
+                           bslab.data_ptr() if bslab is not None else None, C.byref(rows), B,
+                           self.hdim, 2 * D, st)
+      if bslab is not None:
+        jobs.append(ReduceJob(bslab.data_ptr(), self.grads[last.b_off:].data_ptr(), last.b_n,
+                              rows.value, last.b_n, 0))
     jobs += self.enc.backward(self.x, self.enc.gouts[-1], st, fork=fork)
     jobs += late_jobs
     join()

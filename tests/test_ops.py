@@ -272,6 +272,8 @@ def test_split_bf16_path_matches_fp32(bk, monkeypatch):
   tx, tw = T(rng.standard_normal((B, H, W, Ci))), T(rng.standard_normal((K, K, Co, Ci)) * 0.1)
   tb = T(rng.standard_normal(Co) * 0.1)
   outs = []
+  monkeypatch.setenv('ODIN_NOIGEMM', '1')  # (a layer this small would take the implicit-GEMM path)
+  os.putenv('ODIN_NOIGEMM', '1')
   for flag in ('0', '1', '8'):  # fp32 MFMA / weights in registers / 8-wave, weight planes in LDS
     monkeypatch.setenv('ODIN_SPLIT', flag)
     os.putenv('ODIN_SPLIT', flag)
@@ -279,6 +281,7 @@ def test_split_bf16_path_matches_fp32(bk, monkeypatch):
     L.odin_deconv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
     outs.append(ty.cpu().numpy().copy())
   os.putenv('ODIN_SPLIT', '0')
+  os.unsetenv('ODIN_NOIGEMM')
   assert np.abs(outs[0]).max() > 0.5
   for o in outs[1:]:
     assert np.abs(outs[0] - o).max() <= 2e-6 * np.abs(outs[0]).max()

@@ -340,3 +340,92 @@ def test_elbo_mixture_quantized_logistic(bk, npix, Cc):
   close(dh.cpu().numpy(), dh_ref, 1e-4)
   with pytest.raises(_lib.OdinError):
     L.odin_elbo_mixqlogistic_fwd_bwd(None, None, None, None, None, B, npix, 2, K, C.byref(npart), None)
+
+
+@pytest.mark.parametrize('B,P,D,N0,analytic,fb,act0,hact,draw', [
+    (37, 128, 10, 128, 0, -1.0, 'linear', 'linear', False),   # dSprites bottleneck, ragged last workgroup
+    (16, 256, 6, 256, 1, 0.5, 'linear', 'linear', False),     # Shapes3D, analytic KL + free bits
+    (9, 96, 32, 60, 0, -1.0, 'elu', 'relu', True),            # zdim 32 (speech / MNIST), activations, device noise
+    (5, 40, 3, 17, 2, -1.0, 'relu', 'elu', False),            # reverse KL, odd widths
+])
+def test_latent_block_fwd_bwd(bk, B, P, D, N0, analytic, fb, act0, hact, draw):
+  """odin_latent_block_fwd / _bwd (the bottleneck as one launch per direction) against the oracle's
+  DistributionDense -> reparameterise -> KL -> Dense formulas and their hand-written backward."""
+  from odin_ai_amd._lib import ACT
+  L, T = bk.L, bk.T
+  rows = L.odin_latent_block_rows(B, P, D, N0)
+  assert rows > 0
+  rng = np.random.default_rng(5)
+  h = rng.standard_normal((B, P))
+  if hact == 'relu':
+    h = np.maximum(h, 0)
+  wl, bl = rng.standard_normal((P, 2 * D)) * 0.1, rng.standard_normal(2 * D) * 0.1
+  w0, b0 = rng.standard_normal((D, N0)) * 0.3, rng.standard_normal(N0) * 0.1
+  th, twl, tbl, tw0, tb0 = T(h), T(wl), T(bl), T(w0), T(b0)
+  step = bk.T(np.array([7]), torch.int32)
+  teps = bk.zeros(B, D)
+  if draw:
+    L.odin_rng_normal(teps.data_ptr(), B * D, 1234, step.data_ptr(), None)
+    eps = teps.cpu().numpy().astype(np.float64)
+    eps_out = bk.full((B, D), float('nan'))
+  else:
+    eps = rng.standard_normal((B, D))
+    teps = T(eps)
+    eps_out = teps
+  p, z, kl, m, y0 = bk.zeros(B, 2 * D), bk.zeros(B, D), bk.zeros(B), bk.zeros(B), bk.zeros(B, N0)
+  L.odin_latent_block_fwd(th.data_ptr(), twl.data_ptr(), tbl.data_ptr(), None if draw else teps.data_ptr(),
+                          eps_out.data_ptr(), 1234, step.data_ptr(), p.data_ptr(), z.data_ptr(), kl.data_ptr(),
+                          m.data_ptr(), tw0.data_ptr(), tb0.data_ptr(), y0.data_ptr(), B, P, D, N0, ACT[act0],
+                          analytic, fb, None)
+  if draw:  # the noise is the stream odin_rng_normal writes, bit for bit
+    assert np.array_equal(eps_out.cpu().numpy(), teps.cpu().numpy())
+  p_ref = h @ wl + bl
+  loc, sc = vo.mvn_diag_params(p_ref, D)
+  z_ref = loc + sc * eps
+  if analytic == 2:
+    klr = (np.log(sc) + 0.5 * (1 + loc ** 2) / sc ** 2 - 0.5).sum(-1)
+  else:
+    klr = vo.kl_analytic(loc, sc) if analytic else vo.kl_mc(loc, sc, z_ref)
+  kl_ref, m_ref = vo.free_bits_clamp(klr, None if fb < 0 else fb, D)
+  close(p.cpu().numpy(), p_ref)
+  close(z.cpu().numpy(), z_ref)
+  close(kl.cpu().numpy(), kl_ref)
+  assert (m.cpu().numpy() == m_ref).all()
+  y0_ref = vo._ACT[act0](z_ref @ w0 + b0)
+  close(y0.cpu().numpy(), y0_ref)
+  # ---- backward ----
+  g0 = rng.standard_normal((B, N0))
+  dz_extra = rng.standard_normal((B, D)) * 0.1
+  klw = 4.0 / B
+  dz_ref = g0 @ w0.T
+  w = klw * m_ref[:, None]
+  if analytic == 2:
+    dloc, dsc = w * loc / sc ** 2, w * (1 / sc - (1 + loc ** 2) / sc ** 3)
+  elif analytic:
+    dloc, dsc = w * loc, w * (sc - 1 / sc)
+  else:
+    dloc, dsc = w * z_ref, w * (z_ref * eps - 1 / sc)
+  gz = dz_ref + dz_extra
+  dloc, dsc = dloc + gz, dsc + gz * eps
+  dp_ref = np.concatenate([dloc, dsc * vo.sigmoid(p_ref[:, D:])], -1)
+  hf = h.astype(np.float32).astype(np.float64)
+  hgrad = {'linear': np.ones_like(hf), 'relu': (hf > 0).astype(np.float64),
+           'elu': vo.elu_grad_from_output(hf)}[hact]
+  dh_ref = (dp_ref @ wl.T) * hgrad
+  tg0, tx, tk = T(g0), T(dz_extra), T([klw])
+  dz, dp, dh = bk.zeros(B, D), bk.zeros(B, 2 * D), bk.zeros(B, P)
+  s0 = bk.full((rows, D * N0 + N0), float('nan'))
+  sl = bk.full((rows, P * 2 * D + 2 * D), float('nan'))
+  L.odin_latent_block_bwd(tg0.data_ptr(), tw0.data_ptr(), z.data_ptr(), p.data_ptr(), eps_out.data_ptr(),
+                          m.data_ptr(), tk.data_ptr(), tx.data_ptr(), None, None, twl.data_ptr(), th.data_ptr(),
+                          ACT[hact], dz.data_ptr(), dp.data_ptr(), dh.data_ptr(), s0.data_ptr(), sl.data_ptr(),
+                          B, P, D, N0, analytic, None)
+  close(dz.cpu().numpy(), dz_ref)
+  close(dp.cpu().numpy(), dp_ref)
+  close(dh.cpu().numpy(), dh_ref)
+  g = s0.cpu().numpy().astype(np.float64).sum(0)
+  close(g[:D * N0].reshape(D, N0), z_ref.T @ g0, 1e-4)
+  close(g[D * N0:], g0.sum(0), 1e-4)
+  g = sl.cpu().numpy().astype(np.float64).sum(0)
+  close(g[:P * 2 * D].reshape(P, 2 * D), h.T @ dp_ref, 1e-4)
+  close(g[P * 2 * D:], dp_ref.sum(0), 1e-4)
