@@ -1285,6 +1285,12 @@ extern "C" int odin_dense_wgrad(const float* x, const float* dy, float* slab, in
                                 int B, int K, int N, void* stream) {
   // (also the tiny layers: their forward / data gradient run on the vector ALUs, but the weight gradient
   // through the generic kernel was a 14.5 us launch for 0.001 GFLOP)
+  if (!getenv("ODIN_NODENSEIGEMM") && !odin_tiny_dense_ok(B, K, N) &&
+      odin_igemm_wgrad_applicable(B, 1, 1, K, 1, 1, N, 1, 1, 1, 0)) {
+    if (slab_rows_out) *slab_rows_out = odin_igemm_wgrad_rows(B, 1, 1, 1, 1, K, N);
+    if (slab == nullptr) return 0;  // dry run
+    return odin_igemm_wgrad_launch(x, dy, slab, K * N + N, B, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, 1, stream);
+  }
   if (odin_dense_gemm_ok(B, K, N) && !getenv("ODIN_NOTINYWGRADGEMM")) {
     // small GEMM: the waves of a workgroup split the batch, the result is complete: ONE slab row
     if (slab_rows_out) *slab_rows_out = 1;

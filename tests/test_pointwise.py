@@ -347,6 +347,7 @@ def test_elbo_mixture_quantized_logistic(bk, npix, Cc):
     (16, 256, 6, 256, 1, 0.5, 'linear', 'linear', False),     # Shapes3D, analytic KL + free bits
     (9, 96, 32, 60, 0, -1.0, 'elu', 'relu', True),            # zdim 32 (speech / MNIST), activations, device noise
     (5, 40, 3, 17, 2, -1.0, 'relu', 'elu', False),            # reverse KL, odd widths
+    (4, 512, 16, 512, 0, -1.0, 'relu', 'relu', False),        # dense default nets: 512-wide layers, ~100 KB of LDS
 ])
 def test_latent_block_fwd_bwd(bk, B, P, D, N0, analytic, fb, act0, hact, draw):
   """odin_latent_block_fwd / _bwd (the bottleneck as one launch per direction) against the oracle's

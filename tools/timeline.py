@@ -10,8 +10,11 @@ for f in glob.glob(root + '/**/*kernel_trace.csv', recursive=True):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r.get('Queue_Id', '?'), r.get('Stream_Id', '?'),
                  re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name']), r.get('Grid_Size_X', r.get('Grid_Size', '?'))))
 rows.sort()
-# a step starts at each rng_normal_kernel
+# a step starts at its first kernel: the noise (round 2) or the first-layer convolution (the noise is drawn inside
+# latent_block_fwd since round 3)
 starts = [i for i, r in enumerate(rows) if r[4].startswith('rng_normal_kernel')]
+if len(starts) < 10:
+  starts = [i for i, r in enumerate(rows) if 'smallc_fwd' in r[4]]
 i0, i1 = starts[which], starts[which + 1]
 t0 = rows[i0][0]
 busy_end = t0
