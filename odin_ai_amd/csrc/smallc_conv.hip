@@ -22,6 +22,10 @@ struct SCParams {
   int pix_per_block, slab_stride;
 };
 
+// t / d for 0 <= t < 64, 1 <= d <= 8 (tap decoding: a runtime integer division is ~30 instructions, and the
+// matrix-core kernels decode 24 taps per lane before their first load)
+__device__ __forceinline__ int sc_smalldiv(int t, int d) { return (t * (256 / d + 1)) >> 8; }
+
 // forward: thread = (output pixel, 4 consecutive output channels)
 __global__ __launch_bounds__(256) void smallc_fwd_kernel(SCParams p) {
   ODIN_DYN_SMEM(float, wl);  // [KH*KW*CI][CO] + bias[CO]
@@ -215,9 +219,9 @@ __global__ __launch_bounds__(256) void smallc_fwd_mfma_kernel(SCParams p) {
 #pragma unroll
   for (int u = 0; u < NK2; ++u) {
     const int k = 2 * u + h;
-    const int tap = k / p.CI;
+    const int tap = sc_smalldiv(k, p.CI);
     tc[u] = k - tap * p.CI;
-    tkh[u] = tap / p.KW;
+    tkh[u] = sc_smalldiv(tap, p.KW);
     tkw[u] = tap - tkh[u] * p.KW;
     tok[u] = k < K;
 #pragma unroll
@@ -237,12 +241,15 @@ __global__ __launch_bounds__(256) void smallc_fwd_mfma_kernel(SCParams p) {
   const int cpr = p.OW >> 5;  // 32-pixel column blocks per output row
   const int n_it = p.B * p.OH * cpr;
   const int gw = (blockIdx.x * 256 + tid) >> 6, nw = (gridDim.x * 256) >> 6;
-  for (int it = gw; it < n_it; it += nw) {  // wave-uniform
-    const int r = it / cpr, q0 = (it - r * cpr) << 5;
+  // Persistent waves, the NEXT block's taps requested before the current block's MFMAs: one wave per block
+  // (round 2) paid the weight fetch, the tap decoding and a full L2 round trip per 24 MFMAs -- 37 us for the
+  // 64x64x3 first layer whose matrix time is 6 us.
+  auto gather = [&](int it, float (&b)[NK2]) {
+    const int itc = it < n_it ? it : n_it - 1;          // (beyond the end: a valid block, never used)
+    const int r = itc / cpr, q0 = (itc - r * cpr) << 5;
     const int bb = r / p.OH, oh = r - bb * p.OH;
     const int ow = q0 + l31;
     const int ih0 = oh * p.S - p.pt, iw0 = ow * p.S - p.pl;
-    float b[NK2];
 #pragma unroll
     for (int u = 0; u < NK2; ++u) {
       const int ih = ih0 + tkh[u], iw = iw0 + tkw[u];
@@ -251,7 +258,140 @@ __global__ __launch_bounds__(256) void smallc_fwd_mfma_kernel(SCParams p) {
       if (p.center) v = ok ? 2.f * v - 1.f : 0.f;
       b[u] = v;
     }
+  };
+  auto block = [&](int it, const float (&b)[NK2]) {
+    const int r = it / cpr, q0 = (it - r * cpr) << 5;
+    const int ow = q0 + l31;
     float* outp = p.y + ((size_t)(r * p.OW + ow)) * p.CO + 4 * h;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      f32x16 acc = f32x16_zero();
+#pragma unroll
+      for (int u = 0; u < NK2; ++u) acc = mfma32(a[u][rb], b[u], acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = rb * 32 + 8 * q + 4 * h;
+        if (n + 3 < p.CO)
+          *reinterpret_cast<float4*>(outp + rb * 32 + 8 * q) =
+              make_float4(odin_act(p.act, acc[4 * q] + bias_r[rb][4 * q]),
+                          odin_act(p.act, acc[4 * q + 1] + bias_r[rb][4 * q + 1]),
+                          odin_act(p.act, acc[4 * q + 2] + bias_r[rb][4 * q + 2]),
+                          odin_act(p.act, acc[4 * q + 3] + bias_r[rb][4 * q + 3]));
+      }
+    }
+  };
+  float b0[NK2], b1[NK2];
+  int it = gw;  // wave-uniform
+  if (it < n_it) {
+    gather(it, b0);
+    for (;;) {
+      gather(it + nw, b1);
+      ODIN_SCHED_FENCE();
+      block(it, b0);
+      ODIN_SCHED_FENCE();
+      it += 2 * nw;
+      if (it - nw >= n_it) break;
+      gather(it, b0);
+      ODIN_SCHED_FENCE();
+      block(it - nw, b1);
+      ODIN_SCHED_FENCE();
+      if (it >= n_it) break;
+    }
+  }
+}
+
+// The same forward with the input rows staged in LDS: for RGB images (K = 48) the direct gather is bound by the
+// texture-address path -- 24 four-byte gathers per lane per 32 pixels, each touching ~12 cache lines: 38 us for
+// the 64x64x3 first layer at batch 256 whatever the occupancy or prefetch depth -- while every input element is
+// needed by 4 taps x 2 rows.  A workgroup owns NR consecutive output rows of one image: its S (NR - 1) + KH input
+// rows arrive with coalesced 16-byte loads (CenterAt0 applied here, SAME-padding rows zeroed), the taps are
+// gathered from LDS (4-byte ds_reads, <= 2-way bank conflicts), wave w multiplies rows w, w + 4, ...
+template <int NK2, int RB>
+__global__ __launch_bounds__(256) void smallc_fwd_lds_kernel(SCParams p, int NR) {
+  ODIN_DYN_SMEM(float, xs);  // [S (NR - 1) + KH rows][W * CI]
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef ODIN_SIM
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int l31 = lane & 31, h = lane >> 5;
+  const int K = p.KH * p.KW * p.CI;
+  const int rowf = p.W * p.CI;                 // floats per input row
+  const int nrows = p.S * (NR - 1) + p.KH;
+  const int gpi = p.OH / NR;                   // row groups per image
+  const int bb = blockIdx.x / gpi, oh0 = (blockIdx.x - bb * gpi) * NR;
+  const int ih_first = oh0 * p.S - p.pt;
+  // ---- stage the rows: all loads of a thread before its stores ----
+  {
+    const OdinRun XR = odin_run(p.x, (unsigned)((size_t)p.B * p.H * rowf * 4));
+    const int n4 = (nrows * rowf) >> 2;        // (rowf % 4 == 0: checked on the host)
+    const int r4 = rowf >> 2;
+    for (int e0 = 0; e0 < n4; e0 += 256 * 4) {
+      float4 v[4];
+      bool real[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * 256 + tid;
+        const int r = e / r4, c4 = e - r * r4;
+        const int ih = ih_first + r;
+        real[u] = e < n4 && ih >= 0 && ih < p.H;
+        v[u] = odin_run_load4(XR, real[u] ? (unsigned)((((bb * p.H + ih) * rowf) + 4 * c4) * 4) : ODIN_OOB);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * 256 + tid;
+        if (e < n4) {
+          float4 t = v[u];
+          if (p.center && real[u]) { t.x = 2.f * t.x - 1.f; t.y = 2.f * t.y - 1.f; t.z = 2.f * t.z - 1.f; t.w = 2.f * t.w - 1.f; }
+          reinterpret_cast<float4*>(xs)[e] = t;
+        }
+      }
+    }
+  }
+  // ---- weights / bias / tap tables (in flight while the rows land) ----
+  const OdinRun WR = odin_run(p.w, (unsigned)((size_t)K * p.CO * 4));
+  float a[NK2][RB];
+  int toff[NK2], tkw[NK2];
+  bool tok[NK2];
+#pragma unroll
+  for (int u = 0; u < NK2; ++u) {
+    const int k = 2 * u + h;
+    const int tap = sc_smalldiv(k, p.CI);
+    const int c = k - tap * p.CI;
+    const int kh = sc_smalldiv(tap, p.KW);
+    tkw[u] = tap - kh * p.KW;
+    toff[u] = (kh * p.W + tkw[u]) * p.CI + c;   // relative to the block's first (row, column) tap
+    tok[u] = k < K;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int co = rb * 32 + l31;
+      a[u][rb] = odin_run_load1(WR, (k < K && co < p.CO) ? (unsigned)((k * p.CO + co) * 4) : ODIN_OOB);
+    }
+  }
+  float bias_r[RB][16];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+      bias_r[rb][i] = (p.bias != nullptr && n < p.CO) ? p.bias[n] : 0.f;
+    }
+  __syncthreads();
+  const int cpr = p.OW >> 5;
+  for (int j = wave; j < NR * cpr; j += 4) {  // wave-uniform: (row of the group, 32-pixel column block)
+    const int rr = j / cpr, q0 = (j - rr * cpr) << 5;
+    const int ow = q0 + l31;
+    const int iw0 = ow * p.S - p.pl;
+    const int base = (rr * p.S * p.W + iw0) * p.CI;
+    float b[NK2];
+#pragma unroll
+    for (int u = 0; u < NK2; ++u) {
+      const int iw = iw0 + tkw[u];
+      const bool ok = tok[u] && iw >= 0 && iw < p.W;
+      b[u] = ok ? xs[base + toff[u]] : 0.f;
+    }
+    float* outp = p.y + ((size_t)((bb * p.OH + oh0 + rr) * p.OW + ow)) * p.CO + 4 * h;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       f32x16 acc = f32x16_zero();
@@ -416,8 +556,25 @@ int odin_smallc_fwd(const float* x, const float* w, const float* bias, float* y,
     const int K = d->KH * d->KW * d->Cin;
     const int nk2 = (K + 1) / 2, rb = (d->Cout + 31) / 32;
     const long n_it = (long)d->B * d->OH * (d->OW / 32);
+    // rows staged in LDS (RGB first layers; also the grey ones when the row groups divide evenly)
+    if (!getenv("ODIN_SMALLC_NOLDS") && ((d->W * d->Cin) % 4) == 0 && (K == 16 || K == 48)) {
+      int NR = getenv("ODIN_SMALLC_NR") ? atoi(getenv("ODIN_SMALLC_NR")) : 16;
+      while (NR > 1 && ((d->OH % NR) != 0 ||
+                        (size_t)(d->stride * (NR - 1) + d->KH) * d->W * d->Cin * 4 > 48 * 1024))
+        NR >>= 1;
+      const size_t l3 = (size_t)(d->stride * (NR - 1) + d->KH) * d->W * d->Cin * 4;
+      const long gb = (long)d->B * (d->OH / NR);
+      if (l3 <= 48 * 1024 && gb < (1L << 30)) {
+        if (nk2 == 8 && rb == 1) { ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 1>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); return odin_check_launch("smallc_fwd_lds"); }
+        if (nk2 == 8 && rb == 2) { ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 2>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); return odin_check_launch("smallc_fwd_lds"); }
+        if (nk2 == 24 && rb == 1) { ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 1>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); return odin_check_launch("smallc_fwd_lds"); }
+        if (nk2 == 24 && rb == 2) { ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 2>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); return odin_check_launch("smallc_fwd_lds"); }
+      }
+    }
+    // persistent waves (2 x 4-wave workgroups per CU-pair ... 4 blocks per wave at batch 256)
     long bl = (n_it + 3) / 4;
-    if (bl > 2048) bl = 2048;
+    const long cap = getenv("ODIN_SMALLC_BL") ? atol(getenv("ODIN_SMALLC_BL")) : 4L * odin_num_cus();
+    if (bl > cap) bl = cap;
     if (nk2 == 8 && rb == 1) { ODIN_LAUNCH((smallc_fwd_mfma_kernel<8, 1>), dim3((unsigned)bl), dim3(256), 0, stream, p); return odin_check_launch("smallc_fwd_mfma"); }
     if (nk2 == 8 && rb == 2) { ODIN_LAUNCH((smallc_fwd_mfma_kernel<8, 2>), dim3((unsigned)bl), dim3(256), 0, stream, p); return odin_check_launch("smallc_fwd_mfma"); }
     if (nk2 == 24 && rb == 1) { ODIN_LAUNCH((smallc_fwd_mfma_kernel<24, 1>), dim3((unsigned)bl), dim3(256), 0, stream, p); return odin_check_launch("smallc_fwd_mfma"); }

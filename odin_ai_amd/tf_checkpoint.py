@@ -14,8 +14,10 @@ third-party, restated from their published layouts), so that
   * weights trained here can be read back with `tf.train.load_checkpoint(prefix)`.
 
 Not verified against a TensorFlow installation in this repository's test environment (there is
-none): the tests cover write -> read round trips, the table / record checksums and the published
-known answer of CRC-32C.  Loading through `keras.Model.load_weights` additionally needs the
+none): the tests cover write -> read round trips, the table / record checksums, the published
+known answer of CRC-32C, and a reader test on a fixture assembled INDEPENDENTLY of this module in the
+shape Keras writes (tests/golden/gen_keras_ckpt.py: nested object graph `encoder/layer_with_weights-N/kernel`,
+`save_counter`, optimizer hyper-parameters and slot variables, two data shards, multi-block index).  Loading through `keras.Model.load_weights` additionally needs the
 reference model's exact Python attribute paths and is therefore left to `tf.train.load_checkpoint`
 + assignment on that side.
 """
@@ -184,7 +186,9 @@ def write_table(path: str, items: List[Tuple[bytes, bytes]], block_bytes: int = 
 def _read_block(buf: bytes, off: int, n: int, verify: bool = True, lib=None) -> List[Tuple[bytes, bytes]]:
   contents, trailer = buf[off:off + n], buf[off + n:off + n + 5]
   if trailer[0] != 0:
-    raise ValueError('compressed table blocks are not supported')
+    kind = {1: 'snappy'}.get(trailer[0], f'type {trailer[0]}')
+    raise ValueError(f'{kind}-compressed table block: only uncompressed index files are supported '
+                     '(TensorFlow writes checkpoint indices uncompressed; re-save the checkpoint)')
   if verify and unmask(struct.unpack('<I', trailer[1:])[0]) != crc32c(contents + trailer[:1], lib=lib):
     raise ValueError('table block checksum mismatch')
   nrest = struct.unpack_from('<I', contents, len(contents) - 4)[0]
@@ -252,9 +256,9 @@ def _object_graph(names: List[str]) -> bytes:
 
 
 def checkpoint_key(full_name: str) -> str:
-  """object-based key of a variable hung directly under the root as child `full_name`
-  ('/' inside a name is escaped as '.S', as tf.train.Checkpoint does)."""
-  return full_name.replace('/', '.S') + '/.ATTRIBUTES/VARIABLE_VALUE'
+  """object-based key of a variable hung directly under the root as child `full_name` (local names are
+  escaped as tf.train.Checkpoint does: '.' doubled first, then '/' -> '.S')."""
+  return full_name.replace('.', '..').replace('/', '.S') + '/.ATTRIBUTES/VARIABLE_VALUE'
 
 
 def save_checkpoint(prefix: str, variables: Dict[str, np.ndarray], lib=None):
