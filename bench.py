@@ -199,8 +199,15 @@ def profile_hbm_kernels(eng, reps=48):
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e-3
 
-  def entry(kernel, shape, nbytes, t_hbm, t_hot, nsets):
-    return dict(bound='hbm', kernel=kernel, shape=shape, achieved=round(nbytes / t_hbm * 1e-9, 1),
+  def entry(kernel, shape, nbytes, t_hbm, t_hot, nsets, t_probe=None):
+    extra = {}
+    if t_probe is not None:
+      # a plain elementwise launch with the SAME traffic (2 arrays read, 1 written, same sizes, same rotation):
+      # what a stream of this length reaches on this box from cold HBM -- short launches pay their ramp
+      extra = dict(same_traffic_probe_gbs=round(nbytes / t_probe * 1e-9, 1),
+                   same_traffic_probe='torch.add(a, b, out=c) over the same rotating buffer sets',
+                   frac_of_probe=round(t_probe / t_hbm, 4))
+    return dict(extra, bound='hbm', kernel=kernel, shape=shape, achieved=round(nbytes / t_hbm * 1e-9, 1),
                 peak=PEAK_HBM_GBS, unit='GB/s', frac=round(nbytes / t_hbm * 1e-9 / PEAK_HBM_GBS, 4),
                 us_per_launch=round(t_hbm * 1e6, 2), mbytes_per_launch=round(nbytes * 1e-6, 2),
                 buffer_sets=nsets, footprint_mb=round(nsets * nbytes * 1e-6, 1),
@@ -227,7 +234,10 @@ def profile_hbm_kernels(eng, reps=48):
     mk = lambda lg, x, dl: (lambda: lib.odin_elbo_bernoulli_fwd_bwd(
         lg.data_ptr(), x.data_ptr(), part.data_ptr(), dl.data_ptr(), sc, B, n, C.byref(npart), st))
     fns = [mk(*t) for t in sets]
-    out.append(entry('elbo_bernoulli_fwd_bwd', [B, npix, Cc], 12.0 * B * n, timeit(fns), timeit(fns[:1]), ns))
+    probe = [(lambda a=a, b=b, c=c: torch.add(a, b, out=c)) for (a, b, c) in sets]
+    out.append(entry('elbo_bernoulli_fwd_bwd', [B, npix, Cc], 12.0 * B * n, timeit(fns), timeit(fns[:1]), ns,
+                     timeit(probe)))
+    del probe
     del sets, fns
     ns = nsets_for(20.0 * B * n)
     sets = [(torch.randn(B, npix, 2 * Cc, device=dev), torch.rand(B, n, device=dev),
@@ -601,10 +611,14 @@ def main():
   pmc = {}
   try:
     import json as _json
-    pmc = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                                       'r02_pmc_traffic.json')))
-  except (OSError, ValueError):
-    pass
+    import glob as _glob
+    # the newest round's PMC table (tools/pmc_traffic.py <tag> after tools/pmc.sh <tag>)
+    _cand = sorted(_glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                                           'r*_pmc_traffic.json')))
+    pmc_file = _cand[-1]
+    pmc = _json.load(open(pmc_file))
+  except (OSError, ValueError, IndexError):
+    pmc_file = None
 
   def attach_traffic(obj):
     # HBM traffic from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected inside
@@ -614,7 +628,7 @@ def main():
       obj['traffic'] = ent['traffic_bytes']
       obj['traffic_unit'] = 'bytes'
       obj['algorithmic_bytes'] = ent.get('algorithmic_bytes')
-      obj['traffic_source'] = 'profiles/r02_pmc_traffic.json'
+      obj['traffic_source'] = 'profiles/' + os.path.basename(pmc_file)
 
   attach_traffic(roofline)
   roofline_split = None

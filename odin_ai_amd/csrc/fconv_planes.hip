@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   constexpr int NSU = 4 * TC + 3;        // live input rows (2 TC + 2) + the next tile's (2 TC + 1 at an image seam)
   constexpr int IPU = WU / 8;            // 1 KB load items per input row
   constexpr int RJ = 8 / IPU > 0 ? 8 / IPU : 1;
-  constexpr int RED = 8 * 4 * 64 * 16;   // one reduction buffer: [wave][r4][lane][16 B]
+  constexpr int RED = 8 * 8 * 64 * 8;    // one reduction buffer: [register pair][wave][lane][8 B]
   ODIN_DYN_SMEM(char, smem);
   char* ring = smem;
   char* red = smem + NSU * RBU;
@@ -194,11 +194,14 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 
   // sums the eight partial tiles of registers 2 wave, 2 wave + 1 of tile T - 1 and finishes them
   auto finish = [&](int buf) {
-    const char* q = red + buf * RED + (((wave >> 1) * 64 + lane) << 4) + (wave & 1) * 8;
+    // scratch layout [register pair][source wave][lane][8 B]: this wave reads pair `wave` of all eight sources --
+    // 512 contiguous bytes per read (the round-2 layout [wave][r4][lane][16 B] made these reads 8-byte pieces at
+    // a 16-byte stride: 29 % of the kernel's LDS cycles were bank conflicts, profiles/r03_kpmc_planes_8wave.txt)
+    const char* q = red + buf * RED + ((wave * 8 * 64 + lane) << 3);
     float2 s = *reinterpret_cast<const float2*>(q);
 #pragma unroll
     for (int wv = 1; wv < 8; ++wv) {
-      const float2 t = *reinterpret_cast<const float2*>(q + wv * (4 * 64 * 16));
+      const float2 t = *reinterpret_cast<const float2*>(q + wv * (64 * 8));
       s.x += t.x; s.y += t.y;
     }
     float v[2] = {s.x, s.y};
@@ -248,12 +251,11 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
       if ((m & 3) == 1 && (m >> 2) < FP_MAXU) store_item(stu[m >> 2]);  // rows of tile T + 1
       ODIN_SCHED_FENCE();
     }
-    // this wave's partial tile -> scratch [T & 1][wave][r4][lane]
-    char* d = red + (T & 1) * RED + ((wave * 4 * 64 + lane) << 4);
+    // this wave's partial tile -> scratch [T & 1][register pair][wave][lane]
+    char* d = red + (T & 1) * RED + ((wave * 64 + lane) << 3);
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4)
-      *reinterpret_cast<float4*>(d + r4 * (64 * 16)) =
-          make_float4(acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]);
+    for (int pr = 0; pr < 8; ++pr)
+      *reinterpret_cast<float2*>(d + pr * (8 * 64 * 8)) = make_float2(acc[2 * pr], acc[2 * pr + 1]);
     opixP = opix;
     auxP = auxN;
     su0 += 2 * TC;

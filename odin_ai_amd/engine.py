@@ -569,6 +569,8 @@ class VAEEngine:
         h[10 + i] = float(val)
     h[N_HYPER:].view(torch.int32)[0] = int(t)
     h[N_HYPER:].view(torch.int32)[1] = int(skip_enable)
+    # (leaving this 80-byte copy out of the steady state was measured: 0.7182 vs 0.7180 ms per step -- the
+    # idle time between two graph launches does not come from it)
     self.hyper.copy_(h, non_blocking=True)
     if self.device.type == 'cuda':
       ev = torch.cuda.Event()

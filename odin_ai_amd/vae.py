@@ -685,8 +685,13 @@ class VariationalAutoencoder:
           skip_fitted: Union[bool, int] = False, nan_gradients_policy: str = 'stop',
           logdir=None, allow_none_gradients=False, track_gradients=False, seed: int = 1,
           nan_check_interval: int = 50):
-    """Networks.fit (base_networks.py:642-812).  `train`: array / tensor [N,H,W,C] or an
-    iterable of batches.  compile_graph -> the step is replayed as one HIP graph."""
+    """Networks.fit (base_networks.py:642-812) with Trainer.fit's cadence (training/trainer.py:536-738).
+    `train` / `valid`: array / tensor [N,H,W,C] or an iterable of batches.  compile_graph -> the step is
+    replayed as one HIP graph.  Validation (mean loss / metrics of the training=False step over `valid`,
+    `last_valid_loss`, `last_valid_metrics`, `valid/*` scalars) and the `on_valid_end` callback run at the first
+    iteration, whenever step % valid_freq == 0 and `valid_interval` seconds have passed (`valid_interval` > 0
+    makes valid_freq 1), and once more when training ends; `on_batch_end` after every step; `train/*` scalars
+    at most every `logging_interval` seconds (metrics whose name starts with '_' stay hidden)."""
     if optimizer not in ('adam', None) and not callable(optimizer):
       raise RuntimeError(f'No support for optimizer {optimizer!r} on the HIP path (adam only)')
     if nan_gradients_policy not in ('stop', 'skip', 'raise', 'ignore', 'restore'):
@@ -713,7 +718,66 @@ class VariationalAutoencoder:
             yield _as_tensor(b, self.device)
           ep += 1
 
+    # ---- validation / logging cadence of Trainer.fit (training/trainer.py:607-700): `valid_interval` > 0 takes
+    # precedence over `valid_freq`; validation (and ALWAYS the on_valid_end callback) runs at the first
+    # iteration, then whenever step % valid_freq == 0 and valid_interval seconds have passed, and once more
+    # when training ends; train summaries are written at most every `logging_interval` seconds
+    import time as _time
+    valid_freq = max(1, int(valid_freq))
+    valid_interval = float(valid_interval)
+    if valid_interval > 0:
+      valid_freq = 1
+
+    def valid_batches():
+      if torch.is_tensor(valid) or isinstance(valid, np.ndarray):
+        data = _as_tensor(valid, self.device)
+        N = data.shape[0]
+        bs = min(batch_size, N)
+        for i in range(0, N - bs + 1, bs):
+          yield data[i:i + bs].contiguous()
+      else:
+        for b in valid:
+          yield _as_tensor(b, self.device)
+
+    def run_valid():
+      losses, mets = [], {}
+      for vb in valid_batches():
+        l, m = next(iter(self.train_steps(vb, training=False)))()
+        losses.append(float(l))
+        for k, v in m.items():
+          mets.setdefault(k, []).append(float(v))
+      if not losses:
+        return None, {}
+      return float(np.mean(losses)), {k: float(np.mean(v)) for k, v in mets.items()}
+
+    def events(eng):
+      if getattr(self, '_events', None) is None or self._events_dir != logdir:
+        from .tf_checkpoint import ScalarEventWriter
+        self._events, self._events_dir = ScalarEventWriter(logdir, lib=eng.lib), logdir
+      return self._events
+
+    def validate(eng):
+      if valid is not None:
+        vl, vm = run_valid()
+        self.last_valid_loss, self.last_valid_metrics = vl, vm
+        if vl is not None:
+          self.valid_history.append((self._step, vl))
+          if logdir is not None:
+            ev = events(eng)
+            ev.scalar('valid/loss', vl, self._step)
+            for mk, mv in vm.items():
+              if not mk.startswith('_'):
+                ev.scalar(f'valid/{mk}', mv, self._step)
+            ev.flush()
+      if on_valid_end is not None:  # (the callback is always called, with or without a validation set)
+        on_valid_end()
+
+    self.valid_history = getattr(self, 'valid_history', [])
+    self.last_valid_loss, self.last_valid_metrics = None, {}
+    t_start = _time.monotonic()
+    last_log, last_valid = -float('inf'), t_start
     it = 0
+    eng = None
     for xb in batches():
       if it >= max_iter:
         break
@@ -727,6 +791,10 @@ class VariationalAutoencoder:
                                     use_graph=compile_graph and self.device.type == 'cuda')
       it += 1
       eng = self._engine(xb.shape[0])
+      self.last_train_loss, self.last_train_metrics = loss, metrics
+      if on_batch_end is not None:
+        on_batch_end()
+      now = _time.monotonic()
       # the NaN flag is sticky on device; polling it costs a host sync, so it is read every
       # `nan_check_interval` iterations (and at the end) unless the policy must act at once
       if it % nan_check_interval == 0 or it == max_iter:
@@ -739,19 +807,20 @@ class VariationalAutoencoder:
             self.load_weights(raise_notfound=False)
           eng.flag.zero_()
         history.append((self._step, float(loss)))
-        if logdir is not None:  # Trainer's TensorBoard scalars (training/trainer.py:52-71)
-          if getattr(self, '_events', None) is None or self._events_dir != logdir:
-            from .tf_checkpoint import ScalarEventWriter
-            self._events, self._events_dir = ScalarEventWriter(logdir, lib=eng.lib), logdir
-          self._events.scalar('train/loss', float(loss), self._step)
+        # Trainer's TensorBoard scalars (training/trainer.py:52-71), at most every logging_interval seconds
+        if logdir is not None and now - last_log >= float(logging_interval):
+          ev = events(eng)
+          ev.scalar('train/loss', float(loss), self._step)
           for mk, mv in metrics.items():
-            if not mk.startswith('_grad/'):
-              self._events.scalar(f'train/{mk}', float(mv), self._step)
-          self._events.flush()
-      if on_batch_end is not None:
-        on_batch_end()
-      if valid is not None and on_valid_end is not None and it % valid_freq == 0:
-        on_valid_end()
+            if not mk.startswith('_'):   # (metrics hidden with a leading '_', trainer.py:662)
+              ev.scalar(f'train/{mk}', float(mv), self._step)
+          ev.flush()
+          last_log = now
+      if it == 1 or (self._step % valid_freq == 0 and now - last_valid >= valid_interval):
+        validate(eng)
+        last_valid = _time.monotonic()
+    if eng is not None:
+      validate(eng)  # final callback: training ended (trainer.py:704-709)
     self.history = history
     return self
 

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""profiles/r02_pmc_traffic.json from the separate rocprofv3 --pmc passes (tools/pmc.sh r02):
+"""profiles/<tag>_pmc_traffic.json from the separate rocprofv3 --pmc passes (tools/pmc.sh <tag>; usage:
+tools/pmc_traffic.py <tag>, default r03).  Exits non-zero when a kernel it prices no longer exists in the
+passes -- a kernel was renamed or rerouted and the table must be updated, not silently left stale.
 HBM traffic per launch of the three largest kernels of the dsprites_betavae_b256 step, corrected as
 MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts 128-byte reads at 64 bytes: doubled;
 WRITE_SIZE exact), next to the algorithmic bytes of the launch."""
 import json, re, sys
 B = 256
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 
 
 def read(fn):
@@ -16,7 +19,7 @@ def read(fn):
   return out
 
 
-fetch, write = read('gpurun_out/r02_pmc_FETCH_SIZE.txt'), read('gpurun_out/r02_pmc_WRITE_SIZE.txt')
+fetch, write = read(f'gpurun_out/{TAG}_pmc_FETCH_SIZE.txt'), read(f'gpurun_out/{TAG}_pmc_WRITE_SIZE.txt')
 f4 = 4
 kernels = {
     # bench op name: (kernel-name prefix, grid, description, algorithmic bytes)
@@ -32,6 +35,10 @@ kernels = {
                              'fused decoder tail (tconv_planes, fp32 operands as 3 bf16 planes)',
                              # x [B,32,32,32] + target [B,64,64,1] read; logits + d(pre-activation) [B,64,64,32] written
                              (B * 32 * 32 * 32 + 2 * B * 64 * 64 + B * 64 * 64 * 32) * f4),
+    'enc3:conv:fwd': ('igemm_kernel<4, false, false', '512',
+                      'encoder3 forward (igemm: implicit GEMM, both operands straight from L2, fp32 MFMA)',
+                      # x [B,8,8,64] read + y [B,4,4,64] written + weights 16*64*64
+                      (B * 8 * 8 * 64 + B * 4 * 4 * 64 + 16 * 64 * 64) * f4),
     'dec2:deconv:dgrad': ('fconv_ring_kernel<2, true', '131072',
                           'data gradient of decoder2, second of the two 32-channel passes (fconv_ring, fp32 MFMA)',
                           # dY [B,16,16,64]: 32 of 64 channels read + partial sums read + aux read + dx written, [B,8,8,64] each
@@ -47,17 +54,20 @@ def find(tab, prefix, grid):
 
 
 res = {}
+missing = 0
 for op, (k, key, desc, alg) in kernels.items():
   kn, fk = find(fetch, k, key)
   _, wk = find(write, k, key)
   if fk is None or wk is None:
     print('missing', op, k, key, file=sys.stderr)
+    missing += 1
     continue
   k = kn
   res[op] = dict(kernel=f'{k} ({desc})', FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk,
                  traffic_bytes=int((2 * fk + wk) * 1024), algorithmic_bytes=int(alg),
-                 source='profiles/r02_pmc_FETCH_SIZE.txt + r02_pmc_WRITE_SIZE.txt (separate --pmc passes of '
+                 source=f'profiles/{TAG}_pmc_FETCH_SIZE.txt + {TAG}_pmc_WRITE_SIZE.txt (separate --pmc passes of '
                         '`bench.py --steps 20 --warmup 5`); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 '
                         'reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM section)')
-json.dump(res, open('profiles/r02_pmc_traffic.json', 'w'), indent=1)
+json.dump(res, open(f'profiles/{TAG}_pmc_traffic.json', 'w'), indent=1)
 print(json.dumps(res, indent=1))
+sys.exit(1 if missing else 0)
