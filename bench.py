@@ -665,8 +665,8 @@ def main():
 
   # ---- CPU baseline: the same step as a torch-CPU fp32 port, all host cores --------------
   cpu = None
-  if not args.no_cpu_baseline and world == 1 and kind in (None, 'betatc'):
-    from oracle.torch_ref import TorchTrainer, TorchVAE
+  if not args.no_cpu_baseline and world == 1:
+    from oracle.torch_ref import TorchFactorTrainer, TorchTrainer, TorchVAE
     # torch-CPU scales to ~32 threads on this step (measured 8..128 on the GPU box's host:
     # 32 is the fastest), so the baseline uses min(32, cores) threads and reports that count
     cores = min(32, os.cpu_count() or 1)
@@ -674,15 +674,48 @@ def main():
     model = TorchVAE(enc, dec, in_shape, zdim, observation=nets['observation'].posterior,
                      beta=beta, tc_beta=beta if kind == 'betatc' else None, dtype=torch.float32)
     P = {k: v.detach().cpu().numpy() for k, v in eng.param_views().items()}
-    tr = TorchTrainer(model, P, lr=lr, threads=cores)
-    xc, ec = x.cpu(), torch.randn(B, zdim)
-    tr.step(xc, ec)  # warm-up
+    n_cpu = args.cpu_steps
+    if kind == 'factor':
+      # both optimisers of one FactorVAE iteration (VAE step on 128 images with the discriminator's TC term,
+      # discriminator step on the other 128 + the permuted codes)
+      dp = fv._discriminator(B // 2).disc
+      DP = {k: v.detach().cpu().numpy() for k, v in dp.layout.views(dp.params).items()}
+      dlayers = [('dense', int(s2[1]), 'relu' if i + 1 < len(dp.recs) else 'linear')
+                 for i, (_, s2, _) in enumerate(e for e in dp.layout.entries if e[0][-1] == 'w')]
+      tr = TorchFactorTrainer(model, P, dlayers, DP, lr=lr, tc_coef=fv.tc_coef, threads=cores)
+      xc = x.cpu()
+      e1, e2 = torch.randn(B // 2, zdim), torch.randn(B // 2, zdim)
+      perm = torch.stack([torch.randperm(B // 2) for _ in range(zdim)], 1)
+      one = lambda: tr.step(xc, e1, e2, perm)
+      what = 'FactorVAE iterations (VAE step + discriminator step)'
+    elif kind == 'speech':
+      # the front-end on the host (numpy float64 restatement of odin/preprocessing/signal.py, the reference's
+      # own arithmetic) + the conv-VAE step
+      from oracle import mel_oracle as mo
+      tr = TorchTrainer(model, P, lr=lr, threads=cores)
+      yc = y.cpu().numpy().astype(np.float64)
+      ec = torch.randn(B, zdim)
+      T = in_shape[0]
+
+      def one():
+        # dB relative to the utterance's maximum, top_db = 80 -> [0, 1] (the mode-2 output of odin_stft_mel_db)
+        mel = np.stack([mo.mel_frontend(u)[:T] for u in yc])
+        mel = (mel - mel.max(axis=(1, 2), keepdims=True)) / 80.0 + 1.0
+        return tr.step(torch.tensor(mel.reshape(B, T, in_shape[1], 1), dtype=torch.float32), ec)
+      what = 'speech steps (numpy STFT -> mel -> dB front-end + conv-VAE step)'
+      n_cpu = max(2, args.cpu_steps // 8)
+    else:
+      tr = TorchTrainer(model, P, lr=lr, threads=cores)
+      xc, ec = x.cpu(), torch.randn(B, zdim)
+      one = lambda: tr.step(xc, ec)
+      what = 'training steps'
+    one()  # warm-up
     c0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
-      tr.step(xc, ec)
+    for _ in range(n_cpu):
+      one()
     cdt = time.perf_counter() - c0
-    cpu = dict(value=round(B * args.cpu_steps / cdt, 1), unit='images/sec', cores=cores,
-               kind='port', sample=f'{args.cpu_steps} training steps of the same workload '
+    cpu = dict(value=round(B * n_cpu / cdt, 1), unit='images/sec', cores=cores,
+               kind='port', sample=f'{n_cpu} {what} of the same workload '
                f'(batch {B}), torch-CPU fp32 port of the reference step')
 
   ns3 = None

@@ -53,7 +53,10 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   constexpr int TC = 32 / OW;            // output rows per tile
   constexpr int WU = 2 * OW;             // input row length
   constexpr int SU = OW + 1;             // slots per column-parity plane
-  constexpr int PARB = SU * 64;
+  // one parity plane + one spare slot: the two parity planes then sit 128 bytes apart modulo the 256-byte bank
+  // row, so the 8 pixels of a row-fill item (alternating parity) spread over all banks -- with SU * 64 the pixel
+  // pairs (1, 2), (3, 4), (5, 6) shared their banks (15-19 % of the LDS cycles of fconv_planes / wgrad_planes)
+  constexpr int PARB = (SU + 1) * 64;
   constexpr int PBU = 2 * PARB;
   constexpr int RBU = 3 * PBU;
   constexpr int NSU = 4 * TC + 3;        // live input rows (2 TC + 2) + the next tile's (2 TC + 1 at an image seam)
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 template <int EPI, int OW>
 int fp_launch(const FPParams& p, dim3 grid, void* stream) {
   constexpr int TC = 32 / OW;
-  const size_t lds = (size_t)(4 * TC + 3) * 3 * 2 * (OW + 1) * 64 + 2 * (8 * 4 * 64 * 16);
+  const size_t lds = (size_t)(4 * TC + 3) * 3 * 2 * (OW + 2) * 64 + 2 * (8 * 4 * 64 * 16);
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {

@@ -1525,6 +1525,14 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
       if (epi == 2) return launch_inst<MODE_F, 4, 2, 64, true, 0, 5, 3, 2>(p, tp, grid, lds, stream);
       return launch_inst<MODE_F, 4, 2, 64, true, 0, 5, 3, 0>(p, tp, grid, lds, stream);
     }
+    // wider rows than the image stacks' (the speech stack: 40- and 80-pixel rows; vae_audio.py:84-110): the same
+    // 4x4 / stride-2 instances with longer patch rows per lane -- these shapes used to fall to the generic
+    // instance (30-40 TFLOP/s)
+    if (k4s2 && p.CIC == 32 && p.KI <= 12 && !getenv("ODIN_NOWIDEROWS")) {
+      if (epi == 1) return launch_inst<MODE_F, 4, 2, 32, true, 0, 12, 2, 1>(p, tp, grid, lds, stream);
+      if (epi == 2) return launch_inst<MODE_F, 4, 2, 32, true, 0, 12, 2, 2>(p, tp, grid, lds, stream);
+      return launch_inst<MODE_F, 4, 2, 32, true, 0, 12, 2, 0>(p, tp, grid, lds, stream);
+    }
     if (p.flat && p.vec) return launch_inst<MODE_F, 0, 0, 0, true, 0, 2, 8, 3>(p, tp, grid, lds, stream);
     if (p.flat) return launch_inst<MODE_F, 0, 0, 0, false, 0, 2, 8, 3>(p, tp, grid, lds, stream);
     if (p.vec && p.KI <= 2) return launch_inst<MODE_F, 0, 0, 0, true, 0, 2, 8>(p, tp, grid, lds, stream);
@@ -1551,6 +1559,16 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     if (epi == 1) return launch_inst<MODE_T, 4, 2, 64, true, 0, 5, 2, 1>(p, tp, grid, lds, stream);
     if (epi == 2) return launch_inst<MODE_T, 4, 2, 64, true, 0, 5, 2, 2>(p, tp, grid, lds, stream);
     return launch_inst<MODE_T, 4, 2, 64, true, 0, 5, 2, 0>(p, tp, grid, lds, stream);
+  }
+  if (k4s2 && (p.CIC == 32 || p.CIC == 64) && p.KI <= 8 && !getenv("ODIN_NOWIDEROWS")) {  // (wider rows: see MODE_F)
+    if (p.CIC == 32) {
+      if (epi == 1) return launch_inst<MODE_T, 4, 2, 32, true, 0, 8, 2, 1>(p, tp, grid, lds, stream);
+      if (epi == 2) return launch_inst<MODE_T, 4, 2, 32, true, 0, 8, 2, 2>(p, tp, grid, lds, stream);
+      return launch_inst<MODE_T, 4, 2, 32, true, 0, 8, 2, 0>(p, tp, grid, lds, stream);
+    }
+    if (epi == 1) return launch_inst<MODE_T, 4, 2, 64, true, 0, 8, 2, 1>(p, tp, grid, lds, stream);
+    if (epi == 2) return launch_inst<MODE_T, 4, 2, 64, true, 0, 8, 2, 2>(p, tp, grid, lds, stream);
+    return launch_inst<MODE_T, 4, 2, 64, true, 0, 8, 2, 0>(p, tp, grid, lds, stream);
   }
   if (p.vec && p.KI <= 2) return launch_inst<MODE_T, 0, 0, 0, true, 0, 2, 8>(p, tp, grid, lds, stream);
   if (p.vec) return launch_inst<MODE_T, 0, 0, 0, true, 0, GK, 2>(p, tp, grid, lds, stream);

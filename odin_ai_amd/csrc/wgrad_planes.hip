@@ -83,7 +83,9 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   constexpr int TC = 32 / W;             // coarse rows per tile
   constexpr int WU = 2 * W;              // fine row length
   constexpr int SU = W + 1;              // slots per column-parity plane of a fine row
-  constexpr int PARB = SU * 64;          // one parity plane
+  // one parity plane.  (A spare slot per plane -- fconv_planes.hip -- spreads the row fills' stores over all banks
+  // but moves the parity-1 plane's transposed reads onto shared banks: measured 66.5 -> 70.1 us on decoder4.)
+  constexpr int PARB = SU * 64;
   constexpr int PBU = 2 * PARB;          // one bf16 plane of a fine row
   constexpr int RBU = 3 * PBU;
   constexpr int NSU = 4 * TC + 3;        // live fine rows (2 TC + 2) + the next tile's (2 TC + 1 at an image seam)

@@ -242,3 +242,63 @@ class TorchTrainer:
         self.V[k].mul_(b2).addcmul_(g, g, value=1 - b2)
         p.addcdiv_(self.M[k], self.V[k].sqrt().add_(e), value=-a)
     return float(out['loss'])
+
+
+class TorchFactorTrainer:
+  """fp32 CPU port of ONE FactorVAE iteration (odin/bay/vi/autoencoder/factor_vae.py:239-287, restated in
+  oracle.vae_oracle.factor_vae_iteration): VAE step on the first half of the batch with the discriminator's
+  tc_coef * mean(D(z)) term (D's parameters not updated), Keras-Adam; then the discriminator step on the second
+  half -- z' = encode(x2) with the ALREADY updated encoder, permute_dims, dtc_loss on stopped gradients,
+  Adam(1e-5, 0.5, 0.9).  bench.py's cpu_baseline for the FactorVAE workload."""
+
+  def __init__(self, model: TorchVAE, P: Dict, disc_layers, DP: Dict, lr=1e-3, tc_coef=7.0,
+               threads: Optional[int] = None):
+    self.vae = TorchTrainer(model, P, lr=lr, threads=threads)
+    self.dl = list(disc_layers)
+    self.D = {k: torch.tensor(np.asarray(v), dtype=model.dtype, requires_grad=True) for k, v in DP.items()}
+    self.DM = {k: torch.zeros_like(v) for k, v in self.D.items()}
+    self.DV = {k: torch.zeros_like(v) for k, v in self.D.items()}
+    self.td, self.tc_coef = 0, float(tc_coef)
+
+  def _disc(self, z, params):
+    return t_seq(self.dl, params, z)[:, 0]
+
+  def step(self, x: torch.Tensor, eps1: torch.Tensor, eps2: torch.Tensor, perm: torch.Tensor) -> float:
+    B1 = x.shape[0] // 2
+    x1, x2 = x[:B1], x[B1:]
+    tr, m = self.vae, self.vae.model
+    Dfix = {(k[1], k[2]): v.detach() for k, v in self.D.items()}
+    for v in tr.T.values():
+      v.grad = None
+    out = m.forward(tr.T, x1, eps1, extra_loss_fn=lambda o: self.tc_coef * self._disc(o['z'], Dfix).mean())
+    out['loss'].backward()
+    tr.t += 1
+    b1, b2, e = 0.9, 0.999, 1e-7
+    a = tr.lr * math.sqrt(1 - b2 ** tr.t) / (1 - b1 ** tr.t)
+    with torch.no_grad():
+      for k, p in tr.T.items():
+        g = p.grad
+        tr.M[k].mul_(b1).add_(g, alpha=1 - b1)
+        tr.V[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.addcdiv_(tr.M[k], tr.V[k].sqrt().add_(e), value=-a)
+    # ---- discriminator step ----
+    with torch.no_grad():
+      z1 = out['z'].detach()
+      z2 = m.forward(tr.T, x2, eps2)['z']
+      zp = torch.gather(z2, 0, perm)
+    for v in self.D.values():
+      v.grad = None
+    Dp = {(k[1], k[2]): v for k, v in self.D.items()}
+    l1, l2 = self._disc(z1, Dp), self._disc(zp, Dp)
+    dloss = 0.5 * (F.softplus(-l1).mean() + F.softplus(l2).mean())
+    dloss.backward()
+    self.td += 1
+    b1, b2 = 0.5, 0.9
+    a = 1e-5 * math.sqrt(1 - b2 ** self.td) / (1 - b1 ** self.td)
+    with torch.no_grad():
+      for k, p in self.D.items():
+        g = p.grad
+        self.DM[k].mul_(b1).add_(g, alpha=1 - b1)
+        self.DV[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.addcdiv_(self.DM[k], self.DV[k].sqrt().add_(e), value=-a)
+    return float(out['loss'].detach())

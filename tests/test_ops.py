@@ -60,6 +60,7 @@ CONV_CASES = [
     (3, 16, 16, 32, 64, 4, 2, 'elu', False),   # fconv_ring forward, 8-pixel output rows (a wave spans two rows; encoder2)
     (2, 32, 32, 64, 32, 4, 2, 'elu', False),   # fconv_ring forward over 64 channels: two reduction passes
     (2, 32, 32, 32, 64, 4, 2, 'elu', False),   # data gradient = tconv_planes over 64 reduction channels (two passes)
+    (1, 24, 80, 32, 32, 4, 2, 'elu', False),   # speech stack (80-pixel rows): wide-row instances of the 4x4/s2 gathers
 ]
 
 
@@ -118,6 +119,8 @@ DECONV_CASES = [
     (1, 32, 32, 64, 32, 4, 2, 'elu'),          # tconv_planes forward over 64 channels (two reduction passes), 32-pixel rows
     (2, 8, 8, 8, 64, 4, 1, 'elu'),
     (3, 7, 7, 4, 16, 5, 2, 'elu'),
+    (1, 12, 40, 32, 32, 4, 2, 'elu'),          # speech decoder4 geometry (40 -> 80 pixels per row): wide-row instances
+    (1, 12, 20, 64, 32, 4, 2, 'elu'),          # speech decoder3 geometry, 64 reduction channels
 ]
 
 

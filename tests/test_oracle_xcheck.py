@@ -78,3 +78,34 @@ def test_tc_grad_matches_autograd():
   np.testing.assert_allclose(gz, tz.grad.numpy(), atol=1e-12)
   np.testing.assert_allclose(gl, tl.grad.numpy(), atol=1e-12)
   np.testing.assert_allclose(gs, ts.grad.numpy(), atol=1e-12)
+
+
+def test_torch_factor_iteration_matches_numpy_oracle():
+  """oracle/torch_ref.TorchFactorTrainer (bench.py's cpu_baseline of the FactorVAE workload) against
+  vo.factor_vae_iteration: both optimisers' parameters after one iteration, float64."""
+  import torch
+  from oracle.torch_ref import TorchFactorTrainer, TorchVAE
+  enc = [('flatten',), ('dense', 12, 'relu')]
+  dec = [('dense', 12, 'relu'), ('dense', 16, 'linear'), ('reshape', (4, 4, 1))]
+  in_shape, zdim, B = (4, 4, 1), 3, 8
+  model = vo.OracleVAE(enc, dec, in_shape, zdim, observation='bernoulli', beta=1.0)
+  P = model.init_params(seed=1)
+  dl = [('dense', 6, 'relu'), ('dense', 1, 'linear')]
+  rng = np.random.default_rng(0)
+  DP = {('disc', 0, 'w'): rng.standard_normal((3, 6)) * 0.5, ('disc', 0, 'b'): np.zeros(6),
+        ('disc', 1, 'w'): rng.standard_normal((6, 1)) * 0.5, ('disc', 1, 'b'): np.zeros(1)}
+  x = (rng.random((B, 4, 4, 1)) < 0.4).astype(np.float64)
+  e1, e2 = rng.standard_normal((4, 3)), rng.standard_normal((4, 3))
+  perm = np.stack([rng.permutation(4) for _ in range(3)], 1)
+  M = {k: np.zeros_like(v) for k, v in P.items()}
+  V = {k: np.zeros_like(v) for k, v in P.items()}
+  DPo = {(k[1], k[2]): v for k, v in DP.items()}
+  DM = {k: np.zeros_like(v) for k, v in DPo.items()}
+  DV = {k: np.zeros_like(v) for k, v in DPo.items()}
+  o = vo.factor_vae_iteration(model, P, M, V, 1, dl, DPo, DM, DV, 1, x, e1, e2, perm, 1e-3, tc_coef=7.0)
+  tm = TorchVAE(enc, dec, in_shape, zdim, observation='bernoulli', beta=1.0, dtype=torch.float64)
+  tr = TorchFactorTrainer(tm, P, dl, DP, lr=1e-3, tc_coef=7.0)
+  loss = tr.step(torch.tensor(x), torch.tensor(e1), torch.tensor(e2), torch.tensor(perm))
+  assert abs(loss - o['loss']) < 1e-10
+  assert max(np.abs(tr.vae.T[k].detach().numpy() - o['P'][k]).max() for k in P) < 1e-12
+  assert max(np.abs(tr.D[k].detach().numpy() - o['DP'][(k[1], k[2])]).max() for k in DP) < 1e-12
