@@ -1284,7 +1284,11 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
     long wf = (long)ntaps * cic * p.WP + W_SCRATCH;
     long rowlen = (long)p.PW * ((vec0 && (cic & 3) == 0) ? cic / 4 : cic);
     const bool flat0 = (p.PW == 1 && p.NRI == 1);
-    if (pf + wf <= LDS_BUDGET_FLOATS && (flat0 || rowlen <= 64 * GENERIC_KMAX)) break;
+    // (longest patch row an instance stages: the generic ones KMAX = 9 items per lane, the wide-row 4x4 / stride-2
+    // strided-gather instance over 32 channels 12)
+    const int kmax_row = (mode == MODE_F && p.KH == 4 && p.KW == 4 && S == 2 && p.CI == 32 && cic == 32 &&
+                          !getenv("ODIN_NOWIDEROWS")) ? 12 : GENERIC_KMAX;
+    if (pf + wf <= LDS_BUDGET_FLOATS && (flat0 || rowlen <= 64 * kmax_row)) break;
     if (cic <= gran) return false;
     // next smaller chunk: halve, rounded up to the granularity
     int nc = (CIp + cic - 1) / cic + 1;
