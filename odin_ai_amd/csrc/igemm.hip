@@ -373,6 +373,14 @@ int ilog2_exact(int v) {
 
 // (read on every call: the A/B tests of the other paths switch it at run time; graph replays never get here)
 bool igemm_enabled() { return getenv("ODIN_NOIGEMM") == nullptr; }
+// Largest layer routed here, in FLOP (ODIN_IG_MAXGF overrides, GFLOP).  Measured against the tiled paths
+// (CelebA B=512, speech B=256; profiles/r03_igemm_cap.txt): strided gathers, stride-1 layers and Dense layers win up
+// to ~5 GFLOP (Dense 4096 -> 512: 114 / 66 / 96 -> 32 / 38 / 52 us; Conv2D 64 -> 64 k4 s1 on 8x8: 94 / 99 -> 52 / 66 us),
+// the transposed stride-2 gathers and the convolution weight gradients only while the layer is launch-bound.
+double igemm_max_flop(bool wide) {
+  const char* e = getenv("ODIN_IG_MAXGF");
+  return e ? atof(e) * 1e9 : (wide ? 5.0e9 : 1.2e9);
+}
 
 template <bool TMODE, bool BKC>
 int ig_launch_t(IGParams& p, dim3 grid, int nw, void* stream) {
@@ -399,7 +407,7 @@ bool odin_igemm_applicable(int tmode, int B, int H, int W, int CI, int OH, int O
   if (ilog2_exact(CI) < 3 || KH * KW > 25 || KH < 1 || KW < 1 || KH > 8 || KW > 8 || S < 1 || S > 2) return false;
   if (tmode && (OH % S || OW % S || KH < S || KW < S)) return false;
   const double flop = 2.0 * B * (tmode ? (double)H * W : (double)OH * OW) * KH * KW * CI * CO;
-  if (flop > 1.2e9) return false;
+  if (flop > igemm_max_flop(!tmode || S == 1)) return false;
   if ((double)B * OH * OW * OH * OW >= 2e9) return false;  // exactness of the magic-number row decoding
   if ((long)B * H * W * CI >= (1L << 29) || (long)B * OH * OW * CO >= (1L << 29) ||
       (long)KH * KW * CI * CO >= (1L << 29))
@@ -454,7 +462,7 @@ bool odin_igemm_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, in
   if (ilog2_exact(CU) < 3 || KH * KW > 64 || KH < 1 || KW < 1 || S < 1 || S > 4) return false;
   if (FH > 8192 || FW > 8192 || (long)B * h * w > 65536) return false;
   const double flop = 2.0 * B * h * w * KH * KW * CU * CV;
-  if (flop > 1.2e9) return false;
+  if (flop > igemm_max_flop(h * w == 1 && FH * FW == 1)) return false;
   if ((long)B * FH * FW * CU >= (1L << 29) || (long)B * h * w * CV >= (1L << 29)) return false;
   return true;
 }
