@@ -1719,7 +1719,8 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
                        slab_rows_out);
 }
 
-// Dense layers through the implicit-GEMM kernel (a 1x1 convolution on a 1x1 image; enc4 of the dSprites step:
+// Dense layers whose reduction width is a multiple of 8 through the implicit-GEMM kernel (a 1x1 convolution on a
+// 1x1 image; FactorVAE's 1000-unit discriminator, the 512-unit default nets; enc4 of the dSprites step:
 // 12.6 + 9.2 + 7.7 -> 9.9 + 9.6 + 6.4 us stand-alone, 11 us per step in the graph); ODIN_NODENSEIGEMM: A/B switch
 static bool dense_via_igemm() { return getenv("ODIN_NODENSEIGEMM") == nullptr; }
 

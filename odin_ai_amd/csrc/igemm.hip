@@ -40,7 +40,8 @@ struct IGParams {
   const float* aux;   // data gradient: multiply by act'(aux), aux shaped like out
   float* colsum;      // data gradient: slab [gridDim.y][CO] of column sums (may be null)
   int B, H, W, CI, OH, OW, CO, KH, KW, S, pt, pl;
-  int ci_shift;       // CI = 1 << ci_shift
+  int gpt;            // k-groups per tap = CI / 8
+  unsigned mg_gpt;    // ceil(2^32 / gpt) (0: gpt == 1)
   int act, aux_act;
   int Mc;             // rows per stride class
   int tpc;            // 32-row tiles per stride class
@@ -111,15 +112,15 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IGParams p) {
       }
   }
   mask = a_ok ? mask : 0u;
-  const int lanebase = (((b * p.H + Y0) * p.W + X0) << p.ci_shift) + 4 * h;  // floats
+  const int lanebase = ((b * p.H + Y0) * p.W + X0) * p.CI + 4 * h;  // floats
   if (h == 0) rowoff[l31] = a_ok ? ((b * p.OH + oy) * p.OW + ox) : -1;
   const int j = blockIdx.x * 32 + l31;
   const bool b_ok = j < p.CO;
-  const unsigned bl = b_ok ? (unsigned)((BKC ? (j << p.ci_shift) + 4 * h : 4 * h * p.CO + j) * 4) : ODIN_OOB_V;
+  const unsigned bl = b_ok ? (unsigned)((BKC ? j * p.CI + 4 * h : 4 * h * p.CO + j) * 4) : ODIN_OOB_V;
   const OdinRun RA = odin_run(p.in, (unsigned)((size_t)p.B * p.H * p.W * p.CI * 4));
   const OdinRun RB = odin_run(p.w, (unsigned)((size_t)p.KH * p.KW * p.CI * p.CO * 4));
-  const int gsh = p.ci_shift - 3;       // k-groups per tap = 1 << gsh
-  const int ngroups = ntap << gsh;
+  const int gpt = p.gpt;                // k-groups (8 channels) per tap
+  const int ngroups = ntap * gpt;
   f32x16 acc = f32x16_zero();
   float av0[IG_U][4], bv0[IG_U][4], av1[IG_U][4], bv1[IG_U][4];
   // the epilogue's operands (bias; store offsets and act'(aux) factors of wave 0's 16 rows) are fetched NOW:
@@ -147,20 +148,20 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IGParams p) {
     const unsigned live = (unsigned)(gr - ngroups) >> 31;   // 1 / 0   (gr is wave-uniform)
     const unsigned dead = live - 1u;                          // 0 / 0xFFFFFFFF
     const int g = gr < ngroups ? gr : ngroups - 1;
-    const int t = g >> gsh;                     // tap index within the stride class
-    const int ci0 = (g - (t << gsh)) << 3;
+    const int t = ig_magicdiv(g, p.mg_gpt);     // tap index within the stride class
+    const int ci0 = (g - t * gpt) << 3;
     const int a = ig_smalldiv(t, nkw), c = t - a * nkw;
-    const int tapoff = (sg * (a * p.W + c)) << p.ci_shift;
+    const int tapoff = sg * (a * p.W + c) * p.CI;
     const unsigned va = live & (mask >> t) & 1u;
     const float4 x = odin_run_load4(RA, (unsigned)((lanebase + tapoff + ci0) * 4) | (va - 1u) | p.dbg_a);
     av[0] = x.x; av[1] = x.y; av[2] = x.z; av[3] = x.w;
     const int wt = (kh0 + a * SS) * p.KW + kw0 + c * SS;  // weight tap
     if constexpr (BKC) {
-      const unsigned so = (unsigned)(((wt * p.CO) << p.ci_shift) + ci0) * 4u;
+      const unsigned so = (unsigned)(wt * p.CO * p.CI + ci0) * 4u;
       const float4 y = odin_run_load4s(RB, bl | dead | p.dbg_b, so);
       bv[0] = y.x; bv[1] = y.y; bv[2] = y.z; bv[3] = y.w;
     } else {
-      const unsigned so = (unsigned)(((wt << p.ci_shift) + ci0) * p.CO) * 4u;
+      const unsigned so = (unsigned)((wt * p.CI + ci0) * p.CO) * 4u;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         bv[e] = odin_run_load1s(RB, bl | dead | p.dbg_b, so + (unsigned)(e * p.CO * 4));
@@ -242,7 +243,7 @@ struct IWParams {
   float* slab;      // [gridDim.z][slab_stride]: (dW [KH*KW*CU][CV] | column sums of V [CV])
   int slab_stride;
   int B, FH, FW, CU, h, w, CV, KH, KW, S, pt, pl;
-  int cu_shift;
+  unsigned mg_cu;   // ceil(2^32 / CU)
   int M;            // B * h * w
   int chunk;        // pixels per workgroup (multiple of 8, <= IW_CHUNK)
   int want_bias;
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(IWParams p) {
   const int I = p.KH * p.KW * p.CU;
   const int i = blockIdx.y * 32 + l31, j = blockIdx.x * 32 + l31;
   const bool i_ok = i < I, j_ok = j < p.CV;
-  const int tap = i >> p.cu_shift, cu = i & (p.CU - 1);
+  const int tap = ig_magicdiv(i, p.mg_cu), cu = i - tap * p.CU;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const int rowc = ((kh * p.FW + kw) << p.cu_shift) + cu;
+  const int rowc = (kh * p.FW + kw) * p.CU + cu;
   const int mlo = blockIdx.z * p.chunk;
   const int mhi = (mlo + p.chunk < p.M) ? mlo + p.chunk : p.M;
   for (int e = tid; e < IW_CHUNK + 8; e += NW * 64) {
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(IWParams p) {
     if (m < mhi && e < p.chunk) {
       const int b = m / (p.h * p.w), r = m - b * (p.h * p.w), y = r / p.w, x = r - y * p.w;
       const int fy = y * p.S - p.pt, fx = x * p.S - p.pl;
-      tb_base[e] = ((b * p.FH + fy) * p.FW + fx) << p.cu_shift;
+      tb_base[e] = ((b * p.FH + fy) * p.FW + fx) * p.CU;
       tb_yx[e] = ((fy + 64) << 16) | (fx + 64);
     } else {
       tb_base[e] = 0;
@@ -365,12 +366,6 @@ __global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(IWParams p) {
   }
 }
 
-int ilog2_exact(int v) {
-  int s = 0;
-  while ((1 << s) < v) ++s;
-  return (1 << s) == v ? s : -1;
-}
-
 // (read on every call: the A/B tests of the other paths switch it at run time; graph replays never get here)
 bool igemm_enabled() { return getenv("ODIN_NOIGEMM") == nullptr; }
 // Largest layer routed here, in FLOP (ODIN_IG_MAXGF overrides, GFLOP).  Measured against the tiled paths
@@ -397,14 +392,15 @@ long long* g_ig_stamps = nullptr;
 
 void odin_igemm_set_stamps(void* buf) { g_ig_stamps = (long long*)buf; }
 
-// The small-layer regime: a reduction of whole 8-channel groups over a power-of-two channel count, at most
+// The small-layer regime: a reduction of whole 8-channel groups (channel count divisible by 8), at most
 // 25 taps, strides 1 / 2 (transposed gathers: output extents divisible by the stride), <= 1.2 GFLOP, and
 // tensors below 2^29 elements (32-bit byte offsets).  `tmode`: transposed gather.  (H, W, CI) = gathered
 // tensor, (OH, OW, CO) = produced tensor.
 bool odin_igemm_applicable(int tmode, int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
                            int S, int center) {
   if (!igemm_enabled() || center) return false;
-  if (ilog2_exact(CI) < 3 || KH * KW > 25 || KH < 1 || KW < 1 || KH > 8 || KW > 8 || S < 1 || S > 2) return false;
+  if (CI < 8 || (CI & 7) != 0 || CI > 8192 || KH * KW > 25 || KH < 1 || KW < 1 || KH > 8 || KW > 8 || S < 1 || S > 2)
+    return false;
   if (tmode && (OH % S || OW % S || KH < S || KW < S)) return false;
   const double flop = 2.0 * B * (tmode ? (double)H * W : (double)OH * OW) * KH * KW * CI * CO;
   if (flop > igemm_max_flop(!tmode || S == 1)) return false;
@@ -430,12 +426,13 @@ int odin_igemm_launch(int tmode, const float* in, const float* w, const float* b
   p.in = in; p.w = w; p.out = out; p.bias = bias;
   p.aux = (aux != nullptr && aux_act != 0) ? aux : nullptr; p.aux_act = aux_act; p.colsum = colsum;
   p.B = B; p.H = H; p.W = W; p.CI = CI; p.OH = OH; p.OW = OW; p.CO = CO;
-  p.KH = KH; p.KW = KW; p.S = S; p.pt = pt; p.pl = pl; p.ci_shift = ilog2_exact(CI); p.act = act;
+  p.KH = KH; p.KW = KW; p.S = S; p.pt = pt; p.pl = pl; p.gpt = CI / 8; p.act = act;
   const int SS = tmode ? S : 1;
   p.Mc = B * (OH / SS) * (OW / SS);
   p.tpc = (p.Mc + 31) / 32;
   auto magic = [](long d) { return d <= 1 ? 0u : (unsigned)(((1L << 32) + d - 1) / d); };
   p.mg_tpc = magic(p.tpc); p.mg_img = magic((long)(OH / SS) * (OW / SS)); p.mg_row = magic(OW / SS);
+  p.mg_gpt = magic(p.gpt);
   dim3 grid((CO + 31) / 32, SS * SS * p.tpc, 1);
   // waves per tile: enough k-groups per wave to amortise the launch, enough waves to fill the chip
   const int ngroups = (KH / SS) * (KW / SS) * CI / 8;
@@ -459,8 +456,9 @@ int odin_igemm_launch(int tmode, const float* in, const float* w, const float* b
 bool odin_igemm_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, int CV, int KH, int KW, int S,
                                  int center) {
   if (!igemm_enabled() || center) return false;
-  if (ilog2_exact(CU) < 3 || KH * KW > 64 || KH < 1 || KW < 1 || S < 1 || S > 4) return false;
+  if (CU < 8 || (CU & 7) != 0 || CU > 8192 || KH * KW > 64 || KH < 1 || KW < 1 || S < 1 || S > 4) return false;
   if (FH > 8192 || FW > 8192 || (long)B * h * w > 65536) return false;
+  if ((double)KH * KW * CU * CU >= 4e9) return false;  // exactness of the magic-number row decoding
   const double flop = 2.0 * B * h * w * KH * KW * CU * CV;
   if (flop > igemm_max_flop(h * w == 1 && FH * FW == 1)) return false;
   if ((long)B * FH * FW * CU >= (1L << 29) || (long)B * h * w * CV >= (1L << 29)) return false;
@@ -488,7 +486,8 @@ int odin_igemm_wgrad_launch(const float* u, const float* v, float* slab, int sla
   memset(&p, 0, sizeof(p));
   p.u = u; p.v = v; p.slab = slab; p.slab_stride = slab_stride;
   p.B = B; p.FH = FH; p.FW = FW; p.CU = CU; p.h = h; p.w = w; p.CV = CV;
-  p.KH = KH; p.KW = KW; p.S = S; p.pt = pt; p.pl = pl; p.cu_shift = ilog2_exact(CU);
+  p.KH = KH; p.KW = KW; p.S = S; p.pt = pt; p.pl = pl;
+  p.mg_cu = CU <= 1 ? 0u : (unsigned)(((1L << 32) + CU - 1) / CU);
   p.M = B * h * w; p.want_bias = want_bias;
   const int R = odin_igemm_wgrad_rows(B, h, w, KH, KW, CU, CV);
   p.chunk = (((p.M + R - 1) / R) + 7) & ~7;
