@@ -35,7 +35,7 @@ kernels = {
                              'fused decoder tail (tconv_planes, fp32 operands as 3 bf16 planes)',
                              # x [B,32,32,32] + target [B,64,64,1] read; logits + d(pre-activation) [B,64,64,32] written
                              (B * 32 * 32 * 32 + 2 * B * 64 * 64 + B * 64 * 64 * 32) * f4),
-    'enc3:conv:fwd': ('igemm_kernel<4, false, false', '512',
+    'enc3:conv:fwd': ('igemm_kernel<4, false, false', '65536',
                       'encoder3 forward (igemm: implicit GEMM, both operands straight from L2, fp32 MFMA)',
                       # x [B,8,8,64] read + y [B,4,4,64] written + weights 16*64*64
                       (B * 8 * 8 * 64 + B * 4 * 4 * 64 + 16 * 64 * 64) * f4),
