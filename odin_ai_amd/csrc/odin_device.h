@@ -121,6 +121,24 @@ __device__ __forceinline__ f32x16 mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) {
 #endif
 }
 
+// D(16 x 16) += A(16 x 32) * B(32 x 16), v_mfma_f32_16x16x32_bf16 (8 passes = 16 cycles: the same FLOP per cycle as
+// the 32x32x16 form).  Lane l supplies A[row l & 15][k = 8 (l >> 4) + j] and B[k = 8 (l >> 4) + j][col l & 15] in
+// element j; D: col = l & 15, row = 4 (l >> 4) + r for accumulator register r.
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
+#ifdef ODIN_SIM
+  for (int j = 0; j < 8; ++j) {
+    const float af = odin_bitsf((a[j >> 1] >> (16 * (j & 1))) << 16);
+    const float bf = odin_bitsf((b[j >> 1] >> (16 * (j & 1))) << 16);
+    c = sim::mfma_16x16x4(af, bf, c);
+  }
+  return c;
+#else
+  typedef __bf16 odin_bf16x8b __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(odin_bf16x8b, a),
+                                                 __builtin_bit_cast(odin_bf16x8b, b), c, 0, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ f32x16 f32x16_zero() {
   f32x16 z;
 #pragma unroll
