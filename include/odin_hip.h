@@ -266,6 +266,14 @@ int odin_sumsq_adam_flat(float* theta, const float* g, float* m, float* v, size_
                          const float* hyper, float* workspace, float* gnorm2_out, float clip,
                          int32_t* flag, void* stream);
 
+/* odin_sumsq_adam_flat whose first launch also finalises the step's ELBO (the arguments of odin_elbo_finalize):
+ * one launch less per training step; loss / norm / update bit-identical to the separate calls. */
+int odin_sumsq_adam_finalize_flat(float* theta, const float* g, float* m, float* v, size_t n,
+                                  const float* hyper, float* workspace, float* gnorm2_out, float clip,
+                                  int32_t* flag, const float* llk_part, int n_part, const float* kl,
+                                  const float* elbo_hyper, const float* tc, float* llk, float* out4, int B,
+                                  void* stream);
+
 /* ---- counter-based RNG (the reference uses TF's Philox via tfd.sample; streams are not
  * reproducible across frameworks, so parity tests pass eps explicitly) ------------------ */
 int odin_rng_normal(float* out, size_t n, uint64_t seed, const int32_t* step_dev, void* stream);

@@ -82,6 +82,7 @@ SIGNATURES = {
     'odin_clip_by_norm_segments': [P, P, I, F, P],
     'odin_clip_by_value': [P, C.c_size_t, F, P, F, P],
     'odin_sumsq_adam_flat': [P, P, P, P, C.c_size_t, P, P, P, F, P, P],
+    'odin_sumsq_adam_finalize_flat': [P, P, P, P, C.c_size_t, P, P, P, F, P, P, I, P, P, P, P, P, I, P],
     'odin_rng_normal': [P, C.c_size_t, C.c_uint64, P, P],
     'odin_gather_normalize_u8': [P, P, P, I, I, F, I, P],
     'odin_stft_mel_db': [P, P, P, P, P, P, I, I, I, I, I, I, C.c_double, C.c_double, I, P],

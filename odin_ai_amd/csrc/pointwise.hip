@@ -369,11 +369,9 @@ __device__ __forceinline__ float sum_partials8(const float* __restrict__ q, int 
   return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
 }
 
-__global__ __launch_bounds__(256) void elbo_finalize_kernel(const float* llk_part, int n_part,
-                                                            const float* kl, const float* hyper,
-                                                            const float* tcp, float* llk,
-                                                            float* out4, int B) {
-  __shared__ float red[4];
+__device__ __forceinline__ void elbo_finalize_body(const float* llk_part, int n_part, const float* kl,
+                                                    const float* hyper, const float* tcp, float* llk,
+                                                    float* out4, int B, float* red /* >= 4 floats LDS */) {
   float sl = 0.f, sk = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) {
     float t = 0.f;
@@ -393,6 +391,14 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(const float* llk_par
     out4[2] = mk;
     out4[3] = tc;
   }
+}
+
+__global__ __launch_bounds__(256) void elbo_finalize_kernel(const float* llk_part, int n_part,
+                                                            const float* kl, const float* hyper,
+                                                            const float* tcp, float* llk,
+                                                            float* out4, int B) {
+  __shared__ float red[4];
+  elbo_finalize_body(llk_part, n_part, kl, hyper, tcp, llk, out4, B, red);
 }
 
 // ------------------------------------------------------------------ Adam ------------
@@ -463,6 +469,34 @@ __global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ g,
   __shared__ float red[4];
   float acc = 0.f;
   const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 t = reinterpret_cast<const float4*>(g)[i];
+    acc += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    float t = g[(n4 << 2) + threadIdx.x];
+    acc += t * t;
+  }
+  float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// sumsq_stage1 whose LAST workgroup finalises the step's ELBO instead (elbo_finalize_kernel's work: 4.7 us as a
+// launch of its own, nothing in the backward pass depends on it): one launch less per training step.
+struct FinArgs {
+  const float* llk_part; const float* kl; const float* hyper; const float* tcp;
+  float* llk; float* out4;
+  int n_part, B;
+};
+__global__ __launch_bounds__(256) void sumsq_stage1_fin(const float* __restrict__ g, size_t n,
+                                                        float* __restrict__ part, FinArgs f) {
+  __shared__ float red[4];
+  if (blockIdx.x + 1 == gridDim.x) {
+    elbo_finalize_body(f.llk_part, f.n_part, f.kl, f.hyper, f.tcp, f.llk, f.out4, f.B, red);
+    return;
+  }
+  float acc = 0.f;
+  const size_t n4 = n >> 2, stride = (size_t)(gridDim.x - 1) * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     float4 t = reinterpret_cast<const float4*>(g)[i];
     acc += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
@@ -863,6 +897,23 @@ extern "C" int odin_sumsq_adam_flat(float* theta, const float* g, float* m, floa
   ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper,
               (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out);
   return odin_check_launch("sumsq_adam");
+}
+
+extern "C" int odin_sumsq_adam_finalize_flat(float* theta, const float* g, float* m, float* v, size_t n,
+                                             const float* hyper, float* workspace, float* gnorm2_out,
+                                             float clip, int32_t* flag, const float* llk_part, int n_part,
+                                             const float* kl, const float* elbo_hyper, const float* tc,
+                                             float* llk, float* out4, int B, void* stream) {
+  // (same stage-1 partition as odin_sumsq_adam_flat: the gradient norm is bit-identical)
+  int g1 = grid_for(n / 4 + 1, 256, 1024);
+  FinArgs f;
+  f.llk_part = llk_part; f.kl = kl; f.hyper = elbo_hyper; f.tcp = tc; f.llk = llk; f.out4 = out4;
+  f.n_part = n_part; f.B = B;
+  ODIN_LAUNCH(sumsq_stage1_fin, dim3(g1 + 1), dim3(256), 0, stream, g, n, workspace, f);
+  int grid = grid_for(n / 4 + 1, 256, 2048);
+  ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper,
+              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out);
+  return odin_check_launch("sumsq_adam_finalize");
 }
 
 extern "C" int odin_sumsq_flat(const float* g, size_t n, float* workspace, float* out,

@@ -910,6 +910,12 @@ class VAEEngine:
            clipvalue: Optional[float] = None):
     lib = self.lib
     st = self.stream() if st is None else st
+    fin, self._fin_pending = getattr(self, '_fin_pending', None), None
+    if fin is not None and (clipvalue is not None or not (global_clipnorm is not None or check_nan)):
+      # (an update path without the fused first launch: finalise on its own)
+      lib.odin_elbo_finalize(fin[0], fin[1], self.kl.data_ptr(), self.hp(H_BETA), fin[2], self.llk.data_ptr(),
+                             self.out4.data_ptr(), self.B, st)
+      fin = None
     if clipvalue is not None:
       # reference order: clip_by_global_norm, THEN clip_by_value (base_networks.py:584-596): the
       # norm is taken first, one elementwise launch scales and clamps, Adam runs unscaled (its
@@ -927,6 +933,14 @@ class VAEEngine:
     if global_clipnorm is not None or check_nan:
       # gradient norm (clip scale, NaN guard) + update: stage-1 partial sums, then ONE launch that
       # finishes the norm and applies Adam
+      if fin is not None and clipvalue is None:
+        lib.odin_sumsq_adam_finalize_flat(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
+                                          self.v.data_ptr(), self.params.numel(), self.hp(H_ALPHA),
+                                          self.ws.data_ptr(), self.gnorm2.data_ptr(),
+                                          float(global_clipnorm or 0.0), self.flag.data_ptr(), fin[0], fin[1],
+                                          self.kl.data_ptr(), self.hp(H_BETA), fin[2], self.llk.data_ptr(),
+                                          self.out4.data_ptr(), self.B, st)
+        return
       lib.odin_sumsq_adam_flat(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
                                self.v.data_ptr(), self.params.numel(), self.hp(H_ALPHA),
                                self.ws.data_ptr(), self.gnorm2.data_ptr(),
@@ -956,7 +970,13 @@ class VAEEngine:
       P.append(('c', self._tc_scatter))
       P.append(('k', lambda: self.finalize(self.tc_ws.data_ptr())))
     else:
-      P.append(('k', lambda: self.forward(x, eps)))
+      # the ELBO finalisation (llk[B], loss, mean terms: nothing in the backward pass reads them) rides in the
+      # update's first launch instead of being a launch of its own
+      def fwd():
+        self.forward(x, eps, finalize=False)
+        tcp = self.tc_ws.data_ptr() if self.tc_mode == 'betatc' else None
+        self._fin_pending = (self._llk_part_used.data_ptr(), self.n_part, tcp)
+      P.append(('k', fwd))
     if self.is_dp and self.dp_buckets >= 2:
       cur = lambda: torch.cuda.current_stream(self.device)
       side = self.side_stream  # (None on the CPU: the two buckets reduce one after the other)
