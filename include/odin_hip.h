@@ -193,7 +193,10 @@ int odin_elbo_finalize(const float* llk_part, int n_part, const float* kl, const
 int odin_mean(const float* x, int n, float* out, void* stream);
 
 /* ---- beta-TCVAE total correlation (odin/bay/vi/losses.py:101-157), never materialising
- * the [B,B,D] tensor.  tc_out[0] = TC; grads scaled by coef[0] (DEVICE scalar (beta-1)). */
+ * the [B,B,D] tensor.  tc_out[0] = TC; grads scaled by coef[0] (DEVICE scalar (beta-1)).
+ * tc_out is also the workspace: odin_total_correlation_workspace(B_local, B_global, D) floats
+ * (B_local = B_global = B for the single-device form). */
+int odin_total_correlation_workspace(int B_local, int B_global, int D);
 int odin_total_correlation_fwd_bwd(const float* z, const float* p, float* tc_out, float* dz,
                                    float* dloc, float* dscale, const float* coef, int B, int D,
                                    void* stream);
@@ -202,7 +205,7 @@ int odin_total_correlation_fwd_bwd(const float* z, const float* p, float* tc_out
  * against ALL posteriors i (p_global [B_global, 2D], all-gathered): tc_out[0] = this rank's share
  * sum_j(...) / B_global (sum the shares of the ranks), dz_local [B_local, D] is complete, and
  * dloc_part / dscale_part [B_global, D] hold this rank's partial sums over its j for EVERY
- * posterior i (reduce-scatter them).  Workspace as above with B = B_local. */
+ * posterior i (reduce-scatter them).  tc_out: odin_total_correlation_workspace(B_local, B_global, D) floats. */
 int odin_total_correlation_shard(const float* z_local, const float* p_global, float* tc_out,
                                  float* dz_local, float* dloc_part, float* dscale_part,
                                  const float* coef, int B_local, int B_global, int D, void* stream);

@@ -68,6 +68,7 @@ SIGNATURES = {
     'odin_elbo_mixqlogistic_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
     'odin_elbo_finalize': [P, I, P, P, P, P, P, I, P],
     'odin_mean': [P, I, P, P],
+    'odin_total_correlation_workspace': [I, I, I],
     'odin_total_correlation_fwd_bwd': [P, P, P, P, P, P, P, I, I, P],
     'odin_total_correlation_shard': [P, P, P, P, P, P, P, I, I, I, P],
     'odin_permute_dims': [P, P, P, I, I, P],
@@ -97,7 +98,7 @@ SIGNATURES = {
 
 # entry points whose return value is a result, not an error code
 VALUE_RETURNING = ('odin_version', 'odin_max_slab_rows', 'odin_crc32c', 'odin_debug_last_path',
-                   'odin_latent_block_rows')
+                   'odin_latent_block_rows', 'odin_total_correlation_workspace')
 
 
 class OdinError(RuntimeError):

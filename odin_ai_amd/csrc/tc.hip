@@ -25,26 +25,52 @@ __device__ __forceinline__ float wave_max64(float v) {
   return v;
 }
 
+// ---- round 3: the estimator on precomputed, TRANSPOSED posterior parameters.  Round 2 evaluated
+// softplus(raw), its logarithm and a division for every one of the B x B x D pairs, three times over, from
+// [i][2D]-strided loads: 240 + 163 us at CelebA size (B = 512, D = 45), a fifth of the beta-TCVAE step, for
+// ~36 M exponentials that fit in a few microseconds.  tc_prep_kernel evaluates them once per (i, l) and lays
+// mu / 1/sigma / log sigma + log(2 pi)/2 out as [l][i] (and z, L as [l][j]) so that a wave's lanes read
+// consecutive i (or j).
+__global__ __launch_bounds__(256) void tc_prep_kernel(const float* z, const float* p, float* muT, float* isgT,
+                                                      float* lsgT, float* zT, int Bj, int Bi, int D) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < Bi * D) {
+    const int i = e / D, l = e - i * D;
+    const float sg = softplus_t(p[(size_t)i * 2 * D + D + l]);
+    muT[(size_t)l * Bi + i] = p[(size_t)i * 2 * D + l];
+    isgT[(size_t)l * Bi + i] = 1.f / sg;
+    lsgT[(size_t)l * Bi + i] = odin_log(sg) + 0.5f * LOG2PI_F;
+  }
+  if (e < Bj * D) {
+    const int j = e / D, l = e - j * D;
+    zT[(size_t)l * Bj + j] = z[e];
+  }
+}
+
 // One workgroup per sample j (gridDim.x rows: the LOCAL shard under data parallelism); B = number
-// of posteriors i the log-sum-exps run over (the GLOBAL batch).  LDS: lp[B][D] (log q(z_j | x_i)
-// per latent), S[B].  Outputs: logqz[j], L[j][l] (log-sum-exp over i per latent), tc_part[j],
+// of posteriors i the log-sum-exps run over (the GLOBAL batch).  LDS: lp[D][B] (log q(z_j | x_i)
+// per latent), S[B], wS[B].  Outputs: logqz[j], LT[l][j] (log-sum-exp over i per latent), tc_part[j],
 // dz[j][l].
-__global__ __launch_bounds__(256) void tc_rows_kernel(const float* z, const float* p,
-                                                      float* logqz, float* Lout, float* tc_part,
-                                                      float* dz, const float* coef, int B, int D) {
+__global__ __launch_bounds__(256) void tc_rows_kernel(const float* zT, const float* muT, const float* isgT,
+                                                      const float* lsgT, float* logqz, float* LT,
+                                                      float* tc_part, float* dz, const float* coef, int B,
+                                                      int D, int Bj) {
   ODIN_DYN_SMEM(float, smem);
-  float* lp = smem;                 // [B][D]
+  float* lp = smem;                 // [D][B]
   float* S = smem + (size_t)B * D;  // [B]
-  float* Ll = S + B;                // [D]
-  float* misc = Ll + D;             // [8]
+  float* wS = S + B;                // [B]
+  float* Ll = wS + B;               // [D]
+  float* zj = Ll + D;               // [D]
+  float* misc = zj + D;             // [8]
   const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int l = tid; l < D; l += 256) zj[l] = zT[(size_t)l * Bj + j];
+  __syncthreads();
   for (int i = tid; i < B; i += 256) {
     float s = 0.f;
     for (int l = 0; l < D; ++l) {
-      float mu = p[(size_t)i * 2 * D + l], sg = softplus_t(p[(size_t)i * 2 * D + D + l]);
-      float d = (z[(size_t)j * D + l] - mu) / sg;
-      float v = -0.5f * d * d - odin_log(sg) - 0.5f * LOG2PI_F;
-      lp[(size_t)i * D + l] = v;
+      const float d = (zj[l] - muT[(size_t)l * B + i]) * isgT[(size_t)l * B + i];
+      const float v = -0.5f * d * d - lsgT[(size_t)l * B + i];
+      lp[(size_t)l * B + i] = v;
       s += v;
     }
     S[i] = s;
@@ -52,11 +78,12 @@ __global__ __launch_bounds__(256) void tc_rows_kernel(const float* z, const floa
   __syncthreads();
   // per-latent log-sum-exp over i: wave w handles l = w, w+4, ...; index D = the joint S
   for (int l = wave; l <= D; l += 4) {
+    const float* row = l < D ? lp + (size_t)l * B : S;
     float mx = -3.0e38f;
-    for (int i = lane; i < B; i += 64) mx = fmaxf(mx, l < D ? lp[(size_t)i * D + l] : S[i]);
+    for (int i = lane; i < B; i += 64) mx = fmaxf(mx, row[i]);
     mx = wave_max64(mx);
     float sm = 0.f;
-    for (int i = lane; i < B; i += 64) sm += odin_exp((l < D ? lp[(size_t)i * D + l] : S[i]) - mx);
+    for (int i = lane; i < B; i += 64) sm += odin_exp(row[i] - mx);
     sm = wave_sum64(sm);
     if (lane == 0) {
       float lse = mx + odin_log(sm);
@@ -71,16 +98,18 @@ __global__ __launch_bounds__(256) void tc_rows_kernel(const float* z, const floa
     tc_part[j] = lq - t;
     logqz[j] = lq;
   }
-  for (int l = tid; l < D; l += 256) Lout[(size_t)j * D + l] = Ll[l];
+  for (int l = tid; l < D; l += 256) LT[(size_t)l * Bj + j] = Ll[l];
+  for (int i = tid; i < B; i += 256) wS[i] = odin_exp(S[i] - lq);
+  __syncthreads();
   // dz[j,l] = coef/B * sum_i (wj[i] - wl[i,l]) * (-(z_j - mu_i)/sg_i^2)
   const float cf = coef[0] / (float)B;
   for (int l = wave; l < D; l += 4) {
     float acc = 0.f;
-    const float zz = z[(size_t)j * D + l];
+    const float zz = zj[l], ll = Ll[l];
     for (int i = lane; i < B; i += 64) {
-      float mu = p[(size_t)i * 2 * D + l], sg = softplus_t(p[(size_t)i * 2 * D + D + l]);
-      float g = odin_exp(S[i] - lq) - odin_exp(lp[(size_t)i * D + l] - Ll[l]);
-      acc += g * (-(zz - mu) / (sg * sg));
+      const float is = isgT[(size_t)l * B + i];
+      const float g = wS[i] - odin_exp(lp[(size_t)l * B + i] - ll);
+      acc += g * (-(zz - muT[(size_t)l * B + i]) * is * is);
     }
     acc = wave_sum64(acc);
     if (lane == 0) dz[(size_t)j * D + l] = cf * acc;
@@ -90,52 +119,48 @@ __global__ __launch_bounds__(256) void tc_rows_kernel(const float* z, const floa
 // One workgroup per posterior i (gridDim.x = global batch): sums over the Bj rows j this rank
 // evaluated (all of them on one GPU; the local shard under data parallelism, where the partial
 // sums of the ranks are then reduce-scattered).  Bn = global batch (the estimator's 1/B).
-__global__ __launch_bounds__(256) void tc_cols_kernel(const float* z, const float* p,
-                                                      const float* logqz, const float* Lin,
-                                                      float* dloc, float* dscale,
+// LDS: Sw[Bj] (= w_joint[j, i]), the D parameters of posterior i.
+__global__ __launch_bounds__(256) void tc_cols_kernel(const float* zT, const float* muT, const float* isgT,
+                                                      const float* lsgT, const float* logqz,
+                                                      const float* LT, float* dloc, float* dscale,
                                                       const float* coef, int B, int D, int Bn) {
-  __shared__ float red[8];
-  constexpr int MAXJ = 16;  // B <= 4096
+  ODIN_DYN_SMEM(float, smem);
+  float* Sw = smem;          // [B]
+  float* mu = Sw + B;        // [D]
+  float* is = mu + D;        // [D]
+  float* ls = is + D;        // [D]
   const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float Sj[MAXJ];
-#pragma unroll
-  for (int q = 0; q < MAXJ; ++q) {
-    int j = tid + q * 256;
-    float s = 0.f;
-    if (j < B) {
-      for (int l = 0; l < D; ++l) {
-        float mu = p[(size_t)i * 2 * D + l], sg = softplus_t(p[(size_t)i * 2 * D + D + l]);
-        float d = (z[(size_t)j * D + l] - mu) / sg;
-        s += -0.5f * d * d - odin_log(sg) - 0.5f * LOG2PI_F;
-      }
-      s = odin_exp(s - logqz[j]);
-    }
-    Sj[q] = s;  // = wj[j,i]
+  for (int l = tid; l < D; l += 256) {
+    mu[l] = muT[(size_t)l * Bn + i];
+    is[l] = isgT[(size_t)l * Bn + i];
+    ls[l] = lsgT[(size_t)l * Bn + i];
   }
+  __syncthreads();
+  for (int j = tid; j < B; j += 256) {
+    float s = 0.f;
+    for (int l = 0; l < D; ++l) {
+      const float d = (zT[(size_t)l * B + j] - mu[l]) * is[l];
+      s += -0.5f * d * d - ls[l];
+    }
+    Sw[j] = odin_exp(s - logqz[j]);  // = wj[j, i]
+  }
+  __syncthreads();
   const float cf = coef[0] / (float)Bn;
-  for (int l = 0; l < D; ++l) {
-    float mu = p[(size_t)i * 2 * D + l], sg = softplus_t(p[(size_t)i * 2 * D + D + l]);
-    float lsg = odin_log(sg);
+  for (int l = wave; l < D; l += 4) {
+    const float m = mu[l], s1 = is[l], lsg = ls[l];
     float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < MAXJ; ++q) {
-      int j = tid + q * 256;
-      if (j < B) {
-        float d = (z[(size_t)j * D + l] - mu) / sg;
-        float v = -0.5f * d * d - lsg - 0.5f * LOG2PI_F;
-        float g = Sj[q] - odin_exp(v - Lin[(size_t)j * D + l]);
-        a1 += g * d / sg;
-        a2 += g * (d * d - 1.f) / sg;
-      }
+    for (int j = lane; j < B; j += 64) {
+      const float d = (zT[(size_t)l * B + j] - m) * s1;
+      const float v = -0.5f * d * d - lsg;
+      const float g = Sw[j] - odin_exp(v - LT[(size_t)l * B + j]);
+      a1 += g * d * s1;
+      a2 += g * (d * d - 1.f) * s1;
     }
     a1 = wave_sum64(a1);
     a2 = wave_sum64(a2);
-    __syncthreads();
-    if (lane == 0) { red[wave] = a1; red[4 + wave] = a2; }
-    __syncthreads();
-    if (tid == 0) {
-      dloc[(size_t)i * D + l] = cf * ((red[0] + red[1]) + (red[2] + red[3]));
-      dscale[(size_t)i * D + l] = cf * ((red[4] + red[5]) + (red[6] + red[7]));
+    if (lane == 0) {
+      dloc[(size_t)i * D + l] = cf * a1;
+      dscale[(size_t)i * D + l] = cf * a2;
     }
   }
 }
@@ -213,15 +238,24 @@ __global__ __launch_bounds__(256) void dtc_loss_kernel(const float* lz, const fl
 
 }  // namespace
 
-// workspace layout inside tc_out: [0]=TC, then logqz[Bj], L[Bj*D], tc_part[Bj]  (Bj*(D+2)+1 floats)
+// workspace layout inside tc_out: [0] = TC | logqz [Bj] | LT [D][Bj] | tc_part [Bj] | muT, isgT, lsgT [D][Bi] each |
+// zT [D][Bj]  =  odin_total_correlation_workspace(Bj, Bi, D) floats
+extern "C" int odin_total_correlation_workspace(int B_local, int B_global, int D) {
+  return 1 + B_local * (2 * D + 2) + 3 * B_global * D;
+}
+
 static int tc_launch(const float* z, const float* p, float* tc_out, float* dz, float* dloc,
                      float* dscale, const float* coef, int Bj, int Bi, int D, void* stream) {
-  size_t lds = ((size_t)Bi * D + Bi + D + 8) * 4;
+  size_t lds = ((size_t)Bi * D + 2 * Bi + 2 * D + 8) * 4;
   if (lds > 158 * 1024) return odin_fail(-2, "total_correlation: B*D too large for LDS");
   if (Bj > 4096 || Bi > 4096) return odin_fail(-2, "total_correlation: B > 4096");
   float* logqz = tc_out + 1;
-  float* L = logqz + Bj;
-  float* part = L + (size_t)Bj * D;
+  float* LT = logqz + Bj;
+  float* part = LT + (size_t)Bj * D;
+  float* muT = part + Bj;
+  float* isgT = muT + (size_t)Bi * D;
+  float* lsgT = isgT + (size_t)Bi * D;
+  float* zT = lsgT + (size_t)Bi * D;
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
@@ -230,10 +264,14 @@ static int tc_launch(const float* z, const float* p, float* tc_out, float* dz, f
     attr_done = true;
   }
 #endif
+  const int nmax = (Bi > Bj ? Bi : Bj) * D;
+  ODIN_LAUNCH(tc_prep_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, z, p, muT, isgT, lsgT, zT, Bj, Bi, D);
   // rows: coefficient coef/Bi inside (cf = coef[0] / B with B = Bi)
-  ODIN_LAUNCH(tc_rows_kernel, dim3(Bj), dim3(256), lds, stream, z, p, logqz, L, part, dz, coef, Bi, D);
-  ODIN_LAUNCH(tc_cols_kernel, dim3(Bi), dim3(256), 0, stream, z, p, (const float*)logqz,
-              (const float*)L, dloc, dscale, coef, Bj, D, Bi);
+  ODIN_LAUNCH(tc_rows_kernel, dim3(Bj), dim3(256), lds, stream, (const float*)zT, (const float*)muT,
+              (const float*)isgT, (const float*)lsgT, logqz, LT, part, dz, coef, Bi, D, Bj);
+  ODIN_LAUNCH(tc_cols_kernel, dim3(Bi), dim3(256), (size_t)(Bj + 3 * D) * 4, stream, (const float*)zT,
+              (const float*)muT, (const float*)isgT, (const float*)lsgT, (const float*)logqz, (const float*)LT,
+              dloc, dscale, coef, Bj, D, Bi);
   ODIN_LAUNCH(sum_div_kernel, dim3(1), dim3(256), 0, stream, (const float*)part, Bj, tc_out, (float)Bi);
   return odin_check_launch("total_correlation");
 }

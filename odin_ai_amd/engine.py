@@ -394,7 +394,8 @@ class VAEEngine:
     self.lat_slab = torch.empty(rows.value, self.hdim * 2 * D + 2 * D, **f32)
     self.lat_rows = rows.value
     if tc == 'betatc':
-      self.tc_ws = torch.zeros(B * (D + 2) + 1, **f32)
+      self.tc_ws = torch.zeros(self.lib.odin_total_correlation_workspace(
+          B, B * self.world_size if self.tc_sharded else B, D), **f32)
       self.tc_dz = torch.empty(B, D, **f32)
       self.tc_dloc = torch.empty(B, D, **f32)
       self.tc_dscale = torch.empty(B, D, **f32)

@@ -164,7 +164,7 @@ def test_total_correlation(bk):
   gz, gl, gs = vo.total_correlation_bwd(z, loc, sc)
   coef = 3.0
   tz, tp, tcf = T(z), T(p), T([coef])
-  ws = bk.zeros(B * (D + 2) + 1)
+  ws = bk.zeros(L.odin_total_correlation_workspace(B, B, D))
   dz, dl, ds = bk.zeros(B, D), bk.zeros(B, D), bk.zeros(B, D)
   L.odin_total_correlation_fwd_bwd(tz.data_ptr(), tp.data_ptr(), ws.data_ptr(), dz.data_ptr(),
                                    dl.data_ptr(), ds.data_ptr(), tcf.data_ptr(), B, D, None)
@@ -188,7 +188,7 @@ def test_total_correlation_on_posterior_samples(bk, spread):
   tc_ref = vo.total_correlation(z, loc, sc)
   gz, gl, gs = vo.total_correlation_bwd(z, loc, sc)
   tz, tp, tcf = T(z), T(p), T([3.0])
-  ws = bk.zeros(B * (D + 2) + 1)
+  ws = bk.zeros(L.odin_total_correlation_workspace(B, B, D))
   dz, dl, ds = bk.zeros(B, D), bk.zeros(B, D), bk.zeros(B, D)
   L.odin_total_correlation_fwd_bwd(tz.data_ptr(), tp.data_ptr(), ws.data_ptr(), dz.data_ptr(),
                                    dl.data_ptr(), ds.data_ptr(), tcf.data_ptr(), B, D, None)
