@@ -5,7 +5,7 @@ ODIN_NOIGEMM=1 times the tiled paths instead; ODIN_IG_NW / ODIN_IG_R override th
 import ctypes as C, os, sys, torch
 sys.path.insert(0, '.')
 from odin_ai_amd import _lib
-L = _lib.load()
+L = _lib.load(os.environ.get('ODIN_DIAG_LIB') or None)
 dev = torch.device('cuda:0')
 REPS = int(os.environ.get('KB_REPS', '50'))
 
