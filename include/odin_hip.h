@@ -224,8 +224,8 @@ int odin_dtc_loss_fwd_bwd(const float* logit_z, const float* logit_perm, float* 
  * hyper (DEVICE): {alpha_t = lr*sqrt(1-b2^t)/(1-b1^t), beta1, beta2, eps, grad_scale};
  * gnorm2 (optional DEVICE scalar): if non-NULL and clip>0 the gradient is scaled by
  * clip/max(sqrt(gnorm2),clip) (tf.clip_by_global_norm, base_networks.py:588); if
- * non-finite the update is skipped (nan_gradients_policy, base_networks.py:519-547) and
- * flag[0] is set to 1. */
+ * non-finite AND flag is non-NULL the update is skipped (nan_gradients_policy, base_networks.py:519-547)
+ * and flag[0] is set to 1; with flag == NULL ('ignore') the update is applied whatever the norm holds. */
 int odin_adam_step_flat(float* theta, const float* g, float* m, float* v, size_t n,
                         const float* hyper, const float* gnorm2, float clip, int32_t* flag,
                         void* stream);

@@ -440,8 +440,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta,
   }
   if (gnorm2 != nullptr || parts != nullptr) {
     float n2 = parts != nullptr ? n2_sh : gnorm2[0];
-    if (!(n2 == n2) || n2 > 3.0e38f) {  // NaN / Inf gradients: skip the update
-      if (flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) flag[0] = 1;
+    // NaN / Inf gradients: skip the update and raise the flag -- unless the caller passed no flag
+    // (nan_gradients_policy='ignore', base_networks.py:519-547: the update is applied whatever the gradients hold)
+    if ((!(n2 == n2) || n2 > 3.0e38f) && flag != nullptr) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) flag[0] = 1;
       return;
     }
     if (clip > 0.f) gs *= clip / fmaxf(sqrtf(n2), clip);

@@ -938,14 +938,15 @@ class VAEEngine:
         lib.odin_sumsq_adam_finalize_flat(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
                                           self.v.data_ptr(), self.params.numel(), self.hp(H_ALPHA),
                                           self.ws.data_ptr(), self.gnorm2.data_ptr(),
-                                          float(global_clipnorm or 0.0), self.flag.data_ptr(), fin[0], fin[1],
+                                          float(global_clipnorm or 0.0),
+                                          self.flag.data_ptr() if check_nan else None, fin[0], fin[1],
                                           self.kl.data_ptr(), self.hp(H_BETA), fin[2], self.llk.data_ptr(),
                                           self.out4.data_ptr(), self.B, st)
         return
       lib.odin_sumsq_adam_flat(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
                                self.v.data_ptr(), self.params.numel(), self.hp(H_ALPHA),
                                self.ws.data_ptr(), self.gnorm2.data_ptr(),
-                               float(global_clipnorm or 0.0), self.flag.data_ptr(), st)
+                               float(global_clipnorm or 0.0), self.flag.data_ptr() if check_nan else None, st)
       return
     lib.odin_adam_step_flat(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
                             self.v.data_ptr(), self.params.numel(), self.hp(H_ALPHA), None,

@@ -240,6 +240,27 @@ def test_track_gradients_and_checkpoint_names(L, DEV, tmp_path):
   assert {t for _, t, _ in ev} >= {'train/loss', 'train/llk_image', 'train/kl_latents'}
 
 
+def test_nan_gradients_policy_skip_vs_ignore(L, DEV):
+  """Networks.optimize (base_networks.py:519-547): with a non-finite gradient 'skip' leaves parameters and
+  optimiser state untouched and raises the flag; 'ignore' applies the update whatever the gradients hold -- also
+  when global_clipnorm routes the update through the fused norm + Adam launches."""
+  x = (np.random.default_rng(8).random((4, 8, 8, 1)) < 0.3).astype(np.float32)
+  xbad = x.copy()
+  xbad[1, 2, 3, 0] = float('nan')
+  for gclip in (None, 10.0):
+    vae = VariationalAutoencoder(device=DEV, lib=L, **tiny_nets())
+    P0 = {k: v.clone() for k, v in vae.trainable_variables.items()}
+    vae.optimize(xbad, nan_gradients_policy='skip', global_clipnorm=gclip)
+    eng = vae._engine(4)
+    assert int(eng.flag.item()) == 1
+    for k, v in vae.trainable_variables.items():
+      assert torch.equal(v, P0[k]), k
+    eng.flag.zero_()
+    vae.optimize(xbad, nan_gradients_policy='ignore', global_clipnorm=gclip)
+    assert int(eng.flag.item()) == 0
+    assert any(not torch.isfinite(v).all() for v in vae.trainable_variables.values())
+
+
 def test_fit_validation_cadence_and_callbacks(L, DEV, tmp_path):
   """Trainer.fit (training/trainer.py:607-709): validation at the first iteration, then every `valid_freq`
   steps, and once more when training ends; on_valid_end is called every time (with or without a validation
