@@ -307,6 +307,15 @@ int odin_stft_mel_db(const float* y, const double* window, const double* twiddle
                      const double* fb_vals, const int32_t* fb_band, float* out, int B,
                      int n_samples, int frame_length, int step_length, int n_fft, int n_mels,
                      double preemph, double top_db, int log_output, void* stream);
+/* the same, storing only the first n_out_frames frames of every utterance (out [B, n_out_frames, n_mels]; the
+ * top_db floor is still taken over all frames): the front-end writes the VAE's [B, T, n_mels, 1] input buffer
+ * directly (fuel/audio_data.py:236-260 crops the spectrogram to max_length).  workspace: 8 * B floats or NULL;
+ * with a workspace the frame blocks of an utterance are dealt to up to 8 workgroups (one workgroup per
+ * utterance leaves most of the chip idle at batch 256) and the top_db floor follows in a second launch. */
+int odin_stft_mel_db_frames(const float* y, const double* window, const double* twiddles,
+                            const double* fb_vals, const int32_t* fb_band, float* out, int B, int n_samples,
+                            int frame_length, int step_length, int n_fft, int n_mels, double preemph,
+                            double top_db, int log_output, int n_out_frames, float* workspace, void* stream);
 
 /* ---- data parallel (the reference has no distributed path) --------------------
  * Thin RCCL entry points: one process per GPU, every collective is enqueued on the caller's stream.

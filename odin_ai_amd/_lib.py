@@ -87,6 +87,7 @@ SIGNATURES = {
     'odin_rng_normal': [P, C.c_size_t, C.c_uint64, P, P],
     'odin_gather_normalize_u8': [P, P, P, I, I, F, I, P],
     'odin_stft_mel_db': [P, P, P, P, P, P, I, I, I, I, I, I, C.c_double, C.c_double, I, P],
+    'odin_stft_mel_db_frames': [P, P, P, P, P, P, I, I, I, I, I, I, C.c_double, C.c_double, I, I, P, P],
     'odin_debug_set_stamps': [P],
     'odin_debug_set_wgrad_stamps': [P],
     'odin_graph_begin': [P],

@@ -24,6 +24,7 @@
 // HBM traffic: 4 B/sample read, 4 B/(frame, band) written (+ the same again through L2).
 #include "odin_device.h"
 #include "odin_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
     const float* __restrict__ y, const double* __restrict__ window, const double* __restrict__ tw_g,
     const double* __restrict__ fb_vals, const int* __restrict__ fb_band, float* __restrict__ out,
     int n_samples, int frame_length, int step, int n_fft, int log4, int radix2, int fpb,
-    int n_frames, int n_mels, double preemph, double top_db, int log_output) {
+    int n_frames, int n_mels, double preemph, double top_db, int log_output, int n_out,
+    float* __restrict__ bmax /* [B][gridDim.y] block maxima when the frames are split over gridDim.y > 1 */) {
   ODIN_DYN_SMEM(double, smem);
   const int H = n_fft / 2, nb = H + 1;
   cplx* tw = reinterpret_cast<cplx*>(smem);                 // [H]
@@ -64,10 +66,13 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
   const int b = blockIdx.x;
   const double ref_value = 1.0;
   const float* yb = y + (size_t)b * n_samples;
-  float* ob = out + (size_t)b * n_frames * n_mels;
+  // (only the first n_out frames are stored; the top_db floor is still taken over the whole utterance)
+  float* ob = out + (size_t)b * n_out * n_mels;
   for (int k = tid; k < H; k += 256) tw[k] = {tw_g[2 * k], tw_g[2 * k + 1]};
   float vmax = -3.0e38f;
-  for (int t0 = 0; t0 < n_frames; t0 += fpb) {
+  // (gridDim.y workgroups share an utterance: each takes every gridDim.y-th block of fpb frames; the top_db floor
+  // then needs the maximum over all of them and is applied by mel_floor_kernel)
+  for (int t0 = blockIdx.y * fpb; t0 < n_frames; t0 += gridDim.y * fpb) {
     __syncthreads();  // previous pass is done with Z / pw (and tw is staged)
     // ---- 1. stage: pre-emphasis, window, pack, digit-reverse ----
     for (int e = tid; e < fpb * H; e += 256) {
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
       if (log_output == 3) r = (float)log(acc + 1e-6);  // AudioFeatureLoader(log_mels=True)
       else if (log_output) r = (float)(10.0 * log10(fmax(1e-10, acc) / ref_value));
       else r = (float)acc;
-      ob[(size_t)t * n_mels + m] = r;
+      if (t < n_out) ob[(size_t)t * n_mels + m] = r;
       vmax = fmaxf(vmax, r);
     }
   }
@@ -175,8 +180,12 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
   for (int k = 32; k >= 1; k >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, k));
   if ((tid & 63) == 0) red[tid >> 6] = vmax;
   __syncthreads();  // also orders this workgroup's stores before its re-reads below
+  if (gridDim.y > 1) {
+    if (tid == 0) bmax[(size_t)b * gridDim.y + blockIdx.y] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    return;
+  }
   const float floor_ = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - (float)top_db;
-  const int n = n_frames * n_mels;
+  const int n = n_out * n_mels;
   if (log_output == 2) {
     // unit range: the floored dB values span [max - top_db, max] -> (v - max) / top_db + 1 in [0, 1]
     const float mx = floor_ + (float)top_db, inv = 1.f / (float)top_db;
@@ -189,13 +198,31 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
   }
 }
 
+// the top_db floor (and the unit-range map) of an utterance whose frames were computed by several workgroups
+__global__ __launch_bounds__(256) void mel_floor_kernel(float* __restrict__ out, const float* __restrict__ bmax,
+                                                        int nblk, int n, float top_db, int log_output) {
+  float* ob = out + (size_t)blockIdx.x * n;
+  float mxv = -3.0e38f;
+  for (int k = 0; k < nblk; ++k) mxv = fmaxf(mxv, bmax[(size_t)blockIdx.x * nblk + k]);
+  const float floor_ = mxv - top_db;
+  if (log_output == 2) {
+    const float inv = 1.f / top_db;
+    for (int i = threadIdx.x; i < n; i += 256) ob[i] = (fmaxf(ob[i], floor_) - mxv) * inv + 1.f;
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = ob[i];
+    if (v < floor_) ob[i] = floor_;
+  }
+}
+
 }  // namespace
 
-extern "C" int odin_stft_mel_db(const float* y, const double* window, const double* twiddles,
-                                const double* fb_vals, const int32_t* fb_band, float* out, int B,
-                                int n_samples, int frame_length, int step_length, int n_fft,
-                                int n_mels, double preemph, double top_db, int log_output,
-                                void* stream) {
+extern "C" int odin_stft_mel_db_frames(const float* y, const double* window, const double* twiddles,
+                                       const double* fb_vals, const int32_t* fb_band, float* out, int B,
+                                       int n_samples, int frame_length, int step_length, int n_fft,
+                                       int n_mels, double preemph, double top_db, int log_output,
+                                       int n_out_frames, float* workspace, void* stream) {
   const int Hc = n_fft / 2;
   int log4 = 0, radix2 = 0;
   while ((1 << (2 * log4 + 2)) <= Hc) ++log4;
@@ -208,10 +235,15 @@ extern "C" int odin_stft_mel_db(const float* y, const double* window, const doub
     return odin_fail(-2, "stft_mel_db: the unit-range output (log_output=2) needs top_db > 0");
   if (n_samples < frame_length) return odin_fail(-2, "stft_mel_db: utterance shorter than a frame");
   const int n_frames = 1 + (n_samples - frame_length) / step_length;
+  if (n_out_frames < 1 || n_out_frames > n_frames)
+    return odin_fail(-2, "stft_mel_db: n_out_frames must be in [1, n_frames]");
   const int H = n_fft / 2, nbp = (H + 1) | 1;
-  int fpb = 4096 / H;  // complex points per pass: 64 KB of float64 pairs
+  // frames per pass: 1024 complex points = 28 KB of LDS per workgroup, five workgroups per CU (with 4096 points --
+  // 102 KB, one workgroup of 4 waves per CU -- the launch took 213 us instead of 100 us at batch 256)
+  int fpb = 1024 / H;
   if (fpb > 16) fpb = 16;
   if (fpb < 1) fpb = 1;
+  if (const char* e = getenv("ODIN_MEL_FPB")) { const int v = atoi(e); if (v >= 1 && v <= fpb) fpb = v; }
   const size_t lds = ((size_t)2 * H + (size_t)2 * fpb * H + (size_t)fpb * nbp) * 8;
 #ifndef ODIN_SIM
   static bool attr_done = false;
@@ -224,8 +256,27 @@ extern "C" int odin_stft_mel_db(const float* y, const double* window, const doub
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH(stft_mel_f64_kernel, dim3(B), dim3(256), lds, stream, y, window, twiddles, fb_vals,
+  // one workgroup per utterance leaves most of the chip idle at batch 256 (208 us for 0.4 GFLOP of float64): the
+  // blocks of fpb frames of an utterance are dealt to up to 8 workgroups, the floor follows in a second launch
+  const int nblocks = (n_frames + fpb - 1) / fpb;
+  int gy = 1;
+  if (workspace != nullptr && !getenv("ODIN_MEL_NOSPLIT"))
+    while (gy < 8 && gy * 2 <= nblocks && (long)B * gy < 8L * odin_num_cus()) gy *= 2;
+  ODIN_LAUNCH(stft_mel_f64_kernel, dim3(B, gy), dim3(256), lds, stream, y, window, twiddles, fb_vals,
               (const int*)fb_band, out, n_samples, frame_length, step_length, n_fft, log4, radix2,
-              fpb, n_frames, n_mels, preemph, top_db, log_output);
+              fpb, n_frames, n_mels, preemph, top_db, log_output, n_out_frames, workspace);
+  if (gy > 1 && log_output != 0 && log_output != 3 && top_db >= 0.0)
+    ODIN_LAUNCH(mel_floor_kernel, dim3(B), dim3(256), 0, stream, out, (const float*)workspace, gy,
+                n_out_frames * n_mels, (float)top_db, log_output);
   return odin_check_launch("stft_mel_db");
+}
+
+extern "C" int odin_stft_mel_db(const float* y, const double* window, const double* twiddles,
+                                const double* fb_vals, const int32_t* fb_band, float* out, int B,
+                                int n_samples, int frame_length, int step_length, int n_fft,
+                                int n_mels, double preemph, double top_db, int log_output,
+                                void* stream) {
+  const int n_frames = n_samples >= frame_length ? 1 + (n_samples - frame_length) / step_length : 1;
+  return odin_stft_mel_db_frames(y, window, twiddles, fb_vals, fb_band, out, B, n_samples, frame_length,
+                                 step_length, n_fft, n_mels, preemph, top_db, log_output, n_frames, nullptr, stream);
 }

@@ -108,20 +108,32 @@ class MelsSpecExtractor:
   def n_frames(self, n_samples: int) -> int:
     return 1 + (n_samples - self.frame_length) // self.step_length
 
-  def transform(self, y) -> torch.Tensor:
-    """y [B, n_samples] (or [n_samples]) -> [B, n_frames, n_mels] float32 on the device."""
+  def transform(self, y, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y [B, n_samples] (or [n_samples]) -> [B, n_frames, n_mels] float32 on the device.  With `out` (a
+    contiguous float32 device tensor of B * T * n_mels elements, T <= n_frames, e.g. the VAE's [B, T, n_mels, 1]
+    input buffer) only the first T frames are stored, straight into it (the top_db floor still spans the whole
+    utterance): no intermediate spectrogram, no crop copy."""
     y = torch.as_tensor(y, dtype=torch.float32, device=self.device)
     squeeze = y.ndim == 1
     if squeeze:
       y = y[None]
     y = y.contiguous()
     B, n = y.shape
-    out = torch.empty(B, self.n_frames(n), self.n_mels, dtype=torch.float32, device=self.device)
+    nf = self.n_frames(n)
+    if out is None:
+      out = torch.empty(B, nf, self.n_mels, dtype=torch.float32, device=self.device)
+      T = nf
+    else:
+      assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() % (B * self.n_mels) == 0
+      T = out.numel() // (B * self.n_mels)
     st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == 'cuda' else None
-    self.lib.odin_stft_mel_db(y.data_ptr(), self.window.data_ptr(), self.twiddles.data_ptr(),
-                              self.fb_vals.data_ptr(), self.fb_band.data_ptr(), out.data_ptr(), B,
-                              n, self.frame_length, self.step_length, self.n_fft, self.n_mels,
-                              self.preemph, self.top_db, self.mode, st)
+    ws = getattr(self, '_ws', None)
+    if ws is None or ws.numel() < 8 * B:  # block maxima of the split launch
+      ws = self._ws = torch.empty(8 * B, dtype=torch.float32, device=self.device)
+    self.lib.odin_stft_mel_db_frames(y.data_ptr(), self.window.data_ptr(), self.twiddles.data_ptr(),
+                                     self.fb_vals.data_ptr(), self.fb_band.data_ptr(), out.data_ptr(), B,
+                                     n, self.frame_length, self.step_length, self.n_fft, self.n_mels,
+                                     self.preemph, self.top_db, self.mode, T, ws.data_ptr(), st)
     return out[0] if squeeze else out
 
   __call__ = transform

@@ -53,6 +53,17 @@ def test_unit_range_output_and_tf_variant(bk):
     ref = mo.mel_frontend(y[i])
     want = (ref - ref.max()) / 80.0 + 1.0
     assert np.abs(out[i] - want).max() < 1e-6 and out[i].min() >= 0.0 and out[i].max() == 1.0
+  # the first T frames written straight into a [B, T, n_mels, 1] buffer (the VAE's input): the same values as
+  # cropping the full spectrogram -- the top_db floor still spans all frames
+  import torch
+  buf = torch.full((2, 10, 80, 1), float('nan'), dtype=torch.float32, device=DEV)
+  assert ex(y, out=buf) is buf
+  assert np.array_equal(buf.numpy(force=True)[..., 0], out[:, :10])
+  ex_db = MelsSpecExtractor(device=DEV, lib=L)
+  full = ex_db(y).numpy(force=True)
+  buf2 = torch.empty(2, 7, 80, dtype=torch.float32, device=DEV)
+  ex_db(y, out=buf2)
+  assert np.array_equal(buf2.numpy(force=True), full[:, :7])
   for log_mels in (False, True):
     al = AudioFeatureLoader(device=DEV, lib=L, log_mels=log_mels)
     o = al.melspec(y).numpy(force=True)
