@@ -29,7 +29,18 @@ struct FPParams {
   float* colsum;       // EPI 2: [gridDim.x][CO] partial column sums of out (may be null)
   int B, OH, CO;
   int tiles_per_img, n_tiles, tiles_per_wg;
+  long long* stamps;   // diagnostics build: s_memtime stamps of workgroup 0, [wave][32]
 };
+
+#if defined(ODIN_SIM) || !defined(ODIN_DIAG)  // in-kernel stamps: diagnostics build only (make diag)
+#define FP_STAMP(k) ((void)0)
+#else
+#define FP_STAMP(k)                                                                               \
+  do {                                                                                            \
+    if (p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && stamp_i < 32 && stamp_on) \
+      p.stamps[32 * wave + stamp_i++] = ((long long)(k) << 56) | (long long)(clock64() & 0xFFFFFFFFFFFFFFll); \
+  } while (0)
+#endif
 
 __device__ __forceinline__ void fp_split4(const float4& v, u32x2& h, u32x2& m, u32x2& l) {
   h = odin_u2(odin_pack_bf16(v.x, v.y), odin_pack_bf16(v.z, v.w));
@@ -39,6 +50,10 @@ __device__ __forceinline__ void fp_split4(const float4& v, u32x2& h, u32x2& m, u
   l = odin_u2(odin_pack_bf16(odin_bf16_rest(r0), odin_bf16_rest(r1)),
               odin_pack_bf16(odin_bf16_rest(r2), odin_bf16_rest(r3)));
 }
+
+struct alignas(8) FpEnt {
+  int x, y;
+};
 
 struct FpItem {
   float4 v;
@@ -79,6 +94,10 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   int T1 = T0 + p.tiles_per_wg;
   if (T1 > p.n_tiles) T1 = p.n_tiles;
   if (T0 >= T1) return;
+  int stamp_i = 0;
+  bool stamp_on = false;  // (the third tile of workgroup 0 only)
+  (void)stamp_i;
+  (void)stamp_on;
 
   // ---- SAME-padding slots (parity plane 0 slot 0, parity plane 1 slot OW) of every ring row and plane ----
   for (int e = tid; e < NSU * 24; e += 512) {
@@ -88,55 +107,74 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
         make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
+  for (int e = tid; e < RED / 16; e += 512)
+    *reinterpret_cast<float4*>(red + ((T0 - 1) & 1) * RED + e * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+
   // ---- this wave's weight fragments: taps (kh, kw0), (kh, kw0 + 1); lane = output channel l31, k = 8 half + e ----
   const int kh = wave >> 1, kw0 = 2 * (wave & 1);
   // ---- row fills (as wgrad_planes.hip; the k-pieces of a pixel slot are swizzled by the slot) ----
+  // Which rows a fill moves, where they land in the ring and where each tile starts is pure index arithmetic with
+  // image seams and ring wrap-arounds: ~170 dependent scalar instructions per tile when done between the MFMAs,
+  // 14 of the kernel's 71 us (profiles/r03_fconv_planes_bookkeeping.txt).  It is done ONCE here, by all threads in
+  // parallel, into two small LDS tables; the tile loop reads its entries (wave-uniform addresses) and adds lane
+  // offsets.  Fill f >= 1 brings the rows tile T0 + f needs beyond those of tile T0 + f - 1; fill 0 all of tile T0's.
   const OdinRun RU = odin_run(p.in, (unsigned)((size_t)p.B * HU * WU * 32 * 4));
-  int fu_g, fu_gi, fu_b, fu_slot, need_gu0, ft_t;
+  constexpr int RPF = FP_MAXU * RJ;      // rows a fill can carry (row r = r0w + RJ j of item j)
+  constexpr int DST_NONE = -(1 << 24);   // ring offset of an item without a row: dst stays negative
+  constexpr unsigned OFF_NONE = 0x7FFF0000u;  // global offset of a row that is not read (padding row, no image): out of range
+  const int NF = p.tiles_per_wg + 4;
+  FpEnt* tt = reinterpret_cast<FpEnt*>(red + 2 * RED);  // [NF] tile: (first ring slot, byte offset of its first output)
+  FpEnt* tr = tt + NF;                                 // [NF][RPF] fill row: (ring byte offset, global byte offset)
+  const unsigned u_rowbytes = (unsigned)(WU * 32 * 4);
   {
-    const int b0 = T0 / p.tiles_per_img, t0 = T0 - b0 * p.tiles_per_img;
-    fu_g = HPU * b0 + 2 * TC * t0;
-    fu_gi = 2 * TC * t0;
-    fu_b = b0;
-    fu_slot = fu_g % NSU;
-    need_gu0 = fu_g;
-    ft_t = t0;
+    const int tpi = p.tiles_per_img;
+    for (int e = tid; e < NF; e += 512) {
+      const int T = T0 + e, b = T / tpi, t = T - b * tpi;
+      tt[e] = FpEnt{(HPU * b + 2 * TC * t) % NSU, (int)(((size_t)(b * p.OH + TC * t) * OW) * p.CO * 4)};
+    }
+    for (int e = tid; e < NF * RPF; e += 512) {
+      const int f = e / RPF, r = e - f * RPF;
+      const int T = T0 + f, b1 = T / tpi, t1 = T - b1 * tpi;
+      const int end = HPU * b1 + 2 * TC * t1 + 2 * TC + 2;
+      int start = end - (2 * TC + 2);
+      if (f > 0) {
+        const int b0 = (T - 1) / tpi, t0 = (T - 1) - b0 * tpi;
+        start = HPU * b0 + 2 * TC * t0 + 2 * TC + 2;
+      }
+      const int G = start + r;
+      const bool valid = T < T1 && G < end;
+      const int b = G / HPU, gi = G - b * HPU;
+      const bool real = valid && gi != 0 && b < p.B;  // gi == 0: the zero row between images
+      tr[e] = FpEnt{valid ? (G % NSU) * RBU : DST_NONE,
+                        real ? (int)((unsigned)(G - b - 1) * u_rowbytes) : (int)OFF_NONE};
+    }
   }
   const int ch4 = lane & 7, pxl = lane >> 3;
   const int r0w = wave / IPU, cblk = wave - r0w * IPU;
   const int pcw = 8 * cblk + pxl + 1;  // padded column of this lane's pixel: parity pcw & 1, slot pcw >> 1
   const int u_lds = (pcw & 1) * PARB + (pcw >> 1) * 64 + (((ch4 >> 1) ^ (((pcw >> 1) >> 2) & 3)) << 4) + (ch4 & 1) * 8;
   const unsigned u_g = (unsigned)(((8 * cblk + pxl) * 32 + 4 * ch4) * 4);
-  const unsigned u_rowbytes = (unsigned)(WU * 32 * 4);
-  auto load_fill = [&](FpItem (&iu)[FP_MAXU], bool live) {
-    const int nrows = live ? need_gu0 + 2 * TC + 2 - fu_g : 0;
+  // the table entries of fill f for this wave's items, then the loads themselves
+  auto fill_entries = [&](FpEnt (&en)[FP_MAXU], int f) {
+#pragma unroll
+    for (int j = 0; j < FP_MAXU; ++j) en[j] = tr[f * RPF + r0w + RJ * j];
+  };
+  auto fill_loads = [&](FpItem (&iu)[FP_MAXU], const FpEnt (&en)[FP_MAXU]) {
 #pragma unroll
     for (int j = 0; j < FP_MAXU; ++j) {
-      const int r = r0w + RJ * j;
-      const bool valid = r < nrows;
-      int gi = fu_gi + r, b = fu_b;
-      if (gi >= HPU) { gi -= HPU; ++b; }
-      int slot = fu_slot + r;
-      if (slot >= NSU) slot -= NSU;
-      iu[j].dst = valid ? slot * RBU + u_lds : -1;
-      const bool real = valid && gi != 0 && b < p.B;  // gi == 0: the zero row between images
-      iu[j].v = odin_run_load4(RU, real ? (unsigned)(b * HU + gi - 1) * u_rowbytes + u_g : ODIN_OOB);
-    }
-    if (live) {
-      fu_g += nrows;
-      fu_gi += nrows;
-      if (fu_gi >= HPU) { fu_gi -= HPU; ++fu_b; }
-      fu_slot += nrows;
-      if (fu_slot >= NSU) fu_slot -= NSU;
-      need_gu0 += 2 * TC;
-      if (++ft_t == p.tiles_per_img) { ft_t = 0; need_gu0 += 1; }
+      iu[j].dst = en[j].x + u_lds;  // negative: no row
+      iu[j].v = odin_run_load4(RU, (unsigned)en[j].y + u_g);
     }
   };
+  // An item without a row (dst < 0, wave-uniform) is skipped by ONE scalar branch: the matrix pipe shares its issue
+  // port with the vector ALUs (an MFMA takes ~10 issue cycles, every VALU instruction 4: tools/micro/mfma_bf16_split.hip),
+  // and with ~190 VALU instructions per 24 MFMAs the tile was bound by VALU issue, not by the MFMAs -- the ~35
+  // instructions of a split nobody needs cost more than the branch around them.
   auto store_item = [&](const FpItem& it) {
 #ifdef ODIN_SIM
     if (it.dst < 0) return;
 #else
-    if (__builtin_amdgcn_readfirstlane(it.dst) < 0) return;  // wave-uniform: a scalar branch
+    if (__builtin_amdgcn_readfirstlane(it.dst) < 0) return;
 #endif
     u32x2 h, m, l;
     fp_split4(it.v, h, m, l);
@@ -165,7 +203,10 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   float csum[2] = {0.f, 0.f};
 
   FpItem iuA[FP_MAXU], iuB[FP_MAXU], iuC[FP_MAXU];
-  load_fill(iuA, true);  // (in flight while the weight fragments are fetched and split)
+  FpEnt en[FP_MAXU];
+  __syncthreads();  // the tables
+  fill_entries(en, 0);
+  fill_loads(iuA, en);  // (in flight while the weight fragments are fetched and split)
   u32x4 wf[2][2][3];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -186,27 +227,35 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 
 #pragma unroll
   for (int j = 0; j < FP_MAXU; ++j) store_item(iuA[j]);
-  load_fill(iuA, T0 + 1 < T1);
-  load_fill(iuB, T0 + 2 < T1);
+  fill_entries(en, 1);
+  fill_loads(iuA, en);
+  fill_entries(en, 2);
+  fill_loads(iuB, en);
+  fill_entries(en, 3);
+  FpEnt thN = tt[0];  // (su0, output offset) of the next tile
+  const unsigned o_lane = (unsigned)(((orow * OW + ocol) * p.CO + c0) * 4);
   __syncthreads();
 
-  int b_cur = T0 / p.tiles_per_img, t_cur = T0 - b_cur * p.tiles_per_img;
-  int su0 = (HPU * b_cur + 2 * TC * t_cur) % NSU;
-  size_t opixP = 0;
+  // (the first tile's epilogue pass has no predecessor: it sums a zeroed scratch buffer and its store is out of range)
+  const unsigned out_bytes = (unsigned)((size_t)p.B * p.OH * OW * p.CO * 4);
+  const OdinRun RO = odin_run(p.out, out_bytes);
+  const OdinRun RX = odin_run(EPI == 2 ? p.aux : p.out, out_bytes);
+  unsigned ooffP = ODIN_OOB;
   float2 auxP = make_float2(0.f, 0.f);
 
   // sums the eight partial tiles of registers 2 wave, 2 wave + 1 of tile T - 1 and finishes them
-  auto finish = [&](int buf) {
-    // scratch layout [register pair][source wave][lane][8 B]: this wave reads pair `wave` of all eight sources --
-    // 512 contiguous bytes per read (the round-2 layout [wave][r4][lane][16 B] made these reads 8-byte pieces at
-    // a 16-byte stride: 29 % of the kernel's LDS cycles were bank conflicts, profiles/r03_kpmc_planes_8wave.txt)
+  // scratch layout [register pair][source wave][lane][8 B]: this wave reads pair `wave` of all eight sources --
+  // 512 contiguous bytes per read (the round-2 layout [wave][r4][lane][16 B] made these reads 8-byte pieces at
+  // a 16-byte stride: 29 % of the kernel's LDS cycles were bank conflicts, profiles/r03_kpmc_planes_8wave.txt)
+  auto finish_load = [&](int buf, float2 (&q8)[8]) {
     const char* q = red + buf * RED + ((wave * 8 * 64 + lane) << 3);
-    float2 s = *reinterpret_cast<const float2*>(q);
 #pragma unroll
-    for (int wv = 1; wv < 8; ++wv) {
-      const float2 t = *reinterpret_cast<const float2*>(q + wv * (64 * 8));
-      s.x += t.x; s.y += t.y;
-    }
+    for (int wv = 0; wv < 8; ++wv) q8[wv] = *reinterpret_cast<const float2*>(q + wv * (64 * 8));
+  };
+  auto finish_done = [&](const float2 (&q8)[8]) {
+    float2 s = q8[0];
+#pragma unroll
+    for (int wv = 1; wv < 8; ++wv) { s.x += q8[wv].x; s.y += q8[wv].y; }
     float v[2] = {s.x, s.y};
     if (EPI == 1) {
 #pragma unroll
@@ -220,29 +269,32 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
       csum[0] += v[0];
       csum[1] += v[1];
     }
-    *reinterpret_cast<float2*>(p.out + opixP * p.CO + c0) = make_float2(v[0], v[1]);
+    odin_run_store2(RO, ooffP, make_float2(v[0], v[1]));  // (range-checked: the first tile's pass has no tile T - 1)
   };
 
+  // One tile.  Between its first and last MFMA there is NO branch: the row fills of tile T + 3 (loads), the split
+  // and LDS stores of tile T + 1's rows and the epilogue of tile T - 1 all ride between the MFMAs as straight-line
+  // code with masked addresses -- with one scalar branch per fill item the 24 MFMAs of a wave took 2.1-2.9 k
+  // cycles, without any 0.85 k (in-kernel stamps, profiles/r03_stamps_fconv_planes.txt).
   auto run_tile = [&](int T, FpItem (&ldu)[FP_MAXU], const FpItem (&stu)[FP_MAXU]) {
-    // row slots of this lane's two tap rows... one tap row: kh is the wave's
-    int su = su0 + 2 * orow + kh;
-    if (su >= NSU) su -= NSU;
+    const FpEnt th = thN;
+    int su = th.x + 2 * orow + kh;  // the wave's tap row kh of this lane's output row
+    su -= su >= NSU ? NSU : 0;
     const char* rowp = ring + su * RBU;
     u32x4 fb[2][2][3];
+    stamp_on = T == T0 + 2;
+    FP_STAMP(2);
+    // (the fragments of the first products first)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int pl = 2; pl >= 0; --pl)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fb[t][kk][pl] = *reinterpret_cast<const u32x4*>(rowp + boff[t][kk] + pl * PBU);
+        for (int kk = 0; kk < 2; ++kk) fb[t][kk][pl] = *reinterpret_cast<const u32x4*>(rowp + boff[t][kk] + pl * PBU);
     ODIN_SCHED_FENCE();
-    load_fill(ldu, T + 3 < T1);
-    const int oh = TC * t_cur + orow;
-    const size_t opix = ((size_t)b_cur * p.OH + oh) * OW + ocol;
+    const unsigned ooff = (unsigned)th.y + o_lane;
     float2 auxN = make_float2(0.f, 0.f);
-    if (EPI == 2) auxN = *reinterpret_cast<const float2*>(p.aux + opix * p.CO + c0);
-    if (T > T0) finish((T - 1) & 1);  // tile T - 1: its partials are complete behind the last barrier
-    ODIN_SCHED_FENCE();
+    float2 q8[8];
     f32x16 acc = f32x16_zero();
 #pragma unroll
     for (int m = 0; m < 24; ++m) {
@@ -251,7 +303,19 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
       const int ia = (pp == 0) ? 0 : (pp == 1) ? 2 : (pp == 2) ? 1 : (pp == 3) ? 0 : (pp == 4) ? 1 : 0;
       const int ib = (pp == 0) ? 2 : (pp == 1) ? 0 : (pp == 2) ? 1 : (pp == 3) ? 1 : (pp == 4) ? 0 : 0;
       acc = mfma32_bf16(wf[t][kk][ia], fb[t][kk][ib], acc);
+      FP_STAMP(10 + m);
+      // the matrix pipe starts as soon as the first fragments are there; everything else rides between MFMAs
+      if (m == 0) {
+        fill_loads(ldu, en);  // fill T - T0 + 3: its table entries were read a tile ago
+        if (EPI == 2) auxN = odin_run_load2(RX, ooff);
+      }
+      if (m == 21) {  // (behind every other LDS read of this tile)
+        fill_entries(en, T - T0 + 4);
+        thN = tt[T - T0 + 1];
+      }
       if ((m & 3) == 1 && (m >> 2) < FP_MAXU) store_item(stu[m >> 2]);  // rows of tile T + 1
+      if (m == 17) finish_load((T - 1) & 1, q8);  // tile T - 1: its partials are complete behind the last barrier
+      if (m == 20) finish_done(q8);
       ODIN_SCHED_FENCE();
     }
     // this wave's partial tile -> scratch [T & 1][register pair][wave][lane]
@@ -259,11 +323,9 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 #pragma unroll
     for (int pr = 0; pr < 8; ++pr)
       *reinterpret_cast<float2*>(d + pr * (8 * 64 * 8)) = make_float2(acc[2 * pr], acc[2 * pr + 1]);
-    opixP = opix;
+    FP_STAMP(5);
+    ooffP = ooff;
     auxP = auxN;
-    su0 += 2 * TC;
-    if (++t_cur == p.tiles_per_img) { t_cur = 0; ++b_cur; ++su0; }
-    if (su0 >= NSU) su0 -= NSU;
     __syncthreads();  // partial tiles complete; every wave is past tile T's rows; tile T + 1's rows are stored
   };
 #pragma unroll 1
@@ -272,7 +334,11 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
     if (T + 1 < T1) run_tile(T + 1, iuA, iuB);
     if (T + 2 < T1) run_tile(T + 2, iuB, iuC);
   }
-  finish((T1 - 1) & 1);
+  {
+    float2 q8[8];
+    finish_load((T1 - 1) & 1, q8);
+    finish_done(q8);
+  }
 
   if (EPI == 2 && p.colsum != nullptr) {
     // column sums of this workgroup's outputs: the 32 pixel lanes of each half by shuffles; every
@@ -287,15 +353,33 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   }
 }
 
+// LDS: row ring + two partial-tile buffers + the fill tables ((1 + rows per fill) x 8 bytes per fill, tiles + 4 fills)
+constexpr int FP_LDS_MAX = 160 * 1024;
+int fp_ring_bytes(int OW) { return (4 * (32 / OW) + 3) * 3 * 2 * (OW + 2) * 64 + 2 * (8 * 4 * 64 * 16); }
+int fp_fill_bytes(int OW) {
+  const int ipu = 2 * OW / 8, rj = 8 / ipu > 0 ? 8 / ipu : 1;
+  return 8 * (1 + FP_MAXU * rj);
+}
+// tiles per workgroup: one workgroup per CU when the tables fit, more workgroups otherwise; -1: does not fit
+int fp_tiles_per_wg(int OW, int n_tiles, int gy) {
+  int cap = odin_num_cus() / gy;
+  if (cap < 1) cap = 1;
+  if (cap > ODIN_MAX_COLSUM_BLOCKS) cap = ODIN_MAX_COLSUM_BLOCKS;
+  int tpw = (n_tiles + cap - 1) / cap;
+  const int limit = (FP_LDS_MAX - fp_ring_bytes(OW)) / fp_fill_bytes(OW) - 4;
+  if (tpw > limit) tpw = limit;
+  if ((n_tiles + tpw - 1) / tpw > ODIN_MAX_COLSUM_BLOCKS) return -1;
+  return tpw;
+}
+
 template <int EPI, int OW>
 int fp_launch(const FPParams& p, dim3 grid, void* stream) {
-  constexpr int TC = 32 / OW;
-  const size_t lds = (size_t)(4 * TC + 3) * 3 * 2 * (OW + 2) * 64 + 2 * (8 * 4 * 64 * 16);
+  const size_t lds = (size_t)fp_ring_bytes(OW) + (size_t)(p.tiles_per_wg + 4) * fp_fill_bytes(OW);
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fconv_planes_kernel<EPI, OW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, FP_LDS_MAX) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
@@ -306,13 +390,17 @@ int fp_launch(const FPParams& p, dim3 grid, void* stream) {
 
 }  // namespace
 
+static long long* g_fp_stamps = nullptr;
+void odin_fconv_planes_set_stamps(void* buf) { g_fp_stamps = (long long*)buf; }
+
 bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
                                   int pt, int pl, int center) {
   // (read per call: the A/B tests switch paths inside one process; a captured graph never comes here)
   if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT") || getenv("ODIN_NOFPLANES")) return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && CI == 32 && (CO % 32) == 0 && !center &&
          H == 2 * OH && W == 2 * OW && (OW == 8 || OW == 16 || OW == 32) && (OH % (32 / OW)) == 0 &&
-         (size_t)B * H * W * CI * 4 < (1ull << 31);
+         (size_t)B * H * W * CI * 4 < 0x7FFF0000ull && (size_t)B * OH * OW * CO * 4 < (1ull << 31) &&
+         fp_tiles_per_wg(OW, B * (OH / (32 / OW)), CO / 32) > 0;
 }
 
 // epi 1: Conv2D forward (bias + ELU); epi 2: Conv2DTranspose data gradient (x ELU'(aux), column sums)
@@ -323,14 +411,13 @@ int odin_fconv_planes_launch(const float* in, const float* w, const float* bias,
   memset(&p, 0, sizeof(p));
   p.in = in; p.w = w; p.bias = bias; p.aux = aux; p.out = out; p.colsum = colsum;
   p.B = B; p.OH = OH; p.CO = CO;
+  p.stamps = g_fp_stamps;
   const int TC = 32 / OW;
   p.tiles_per_img = OH / TC;
   p.n_tiles = B * p.tiles_per_img;
   const int gy = CO / 32;
-  int cap = odin_num_cus() / gy;
-  if (cap < 1) cap = 1;
-  if (cap > ODIN_MAX_COLSUM_BLOCKS) cap = ODIN_MAX_COLSUM_BLOCKS;
-  p.tiles_per_wg = (p.n_tiles + cap - 1) / cap;
+  p.tiles_per_wg = fp_tiles_per_wg(OW, p.n_tiles, gy);
+  if (p.tiles_per_wg <= 0) return odin_fail(-2, "fconv_planes: too many tiles for the fill tables");
   const int gx = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
   if (rows_out) *rows_out = gx;
   if (out == nullptr) return 0;  // dry run

@@ -1813,6 +1813,7 @@ extern "C" int odin_debug_set_stamps(void* buf) {
   odin_fconv_ring_set_stamps(buf);
   odin_tconv_ring_set_stamps(buf);
   odin_tconv_planes_set_stamps(buf);
+  odin_fconv_planes_set_stamps(buf);
   odin_igemm_set_stamps(buf);
   return 0;
 }

@@ -250,6 +250,30 @@ __device__ __forceinline__ void odin_run_store1(const OdinRun& R, unsigned off, 
 #endif
 }
 
+// the same for two floats (8-byte aligned offset) and a range-checked two-float load
+__device__ __forceinline__ void odin_run_store2(const OdinRun& R, unsigned off, float2 v) {
+#ifdef ODIN_SIM
+  if ((unsigned long long)off + 8 <= R.bytes)
+    *reinterpret_cast<float2*>(const_cast<char*>(R.base) + off) = v;
+#else
+  typedef unsigned int odin_u32x2 __attribute__((ext_vector_type(2)));
+  odin_u32x2 d;
+  d.x = __float_as_uint(v.x);
+  d.y = __float_as_uint(v.y);
+  __builtin_amdgcn_raw_buffer_store_b64(d, R.r, off, 0, 0);
+#endif
+}
+__device__ __forceinline__ float2 odin_run_load2(const OdinRun& R, unsigned off) {
+#ifdef ODIN_SIM
+  if ((unsigned long long)off + 8 > R.bytes) return make_float2(0.f, 0.f);
+  return *reinterpret_cast<const float2*>(R.base + off);
+#else
+  typedef unsigned int odin_u32x2 __attribute__((ext_vector_type(2)));
+  const odin_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(R.r, off, 0, 0);
+  return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+#endif
+}
+
 // LDS-DMA: every active lane moves 16 bytes from the run straight into LDS at
 // lds_base + lane*16 (lds_base wave-uniform, 16-byte aligned); no VGPR destination, no ds_write.
 // Completion is tracked by the issuing wave's vmcnt.  Never issued with out-of-range offsets

@@ -82,6 +82,7 @@ int odin_wgrad_planes_launch(const float* U, const float* V, float* slab, int* r
 // the same strided gathers through the bf16 matrix pipe, reduction split over the waves (fconv_planes.hip)
 bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
                                   int pt, int pl, int center);
+void odin_fconv_planes_set_stamps(void* buf);
 int odin_fconv_planes_launch(const float* in, const float* w, const float* bias, const float* aux,
                              float* out, float* colsum, int* rows_out, int B, int OH, int OW, int CO,
                              int epi, void* stream);

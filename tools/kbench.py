@@ -26,6 +26,8 @@ d = _lib.conv_desc(B, H, W, 32, 2 * H, 2 * W, 32, 4, 2, 1, 1, 'elu')
 x = torch.randn(B, H, W, 32, device=dev); w = torch.randn(4, 4, 32, 32, device=dev) * 0.1
 b = torch.randn(32, device=dev) * 0.1
 g = torch.randn(B, 2 * H, 2 * W, 32, device=dev)
+if os.environ.get('KB_ZERO'):  # all-zero operands: the same instruction stream at minimal switching power
+  x.zero_(); w.zero_(); g.zero_()
 rows, npart = C.c_int(0), C.c_int(0)
 for C1 in (1, 3):
   if f'tail{C1}' not in WHICH: continue
