@@ -69,6 +69,10 @@ __device__ __forceinline__ u32x2 wp_tr_read(const char* blk, int stride, int l16
 #endif
 }
 
+struct alignas(8) WpEnt {
+  int x, y;
+};
+
 struct WpItem {
   float4 v;
   int dst;  // byte offset of the hi-plane store inside the LDS image; < 0: no item (wave-uniform)
@@ -124,19 +128,6 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   // ---- row fills (wave-uniform walks; a wave moves up to WP_MAXU fine-row items and one coarse-row item) ----
   const OdinRun RU = odin_run(p.U, (unsigned)((size_t)p.B * HU * WU * p.CUt * 4));
   const OdinRun RV = odin_run(p.V, (unsigned)((size_t)p.B * p.h * W * p.CVt * 4));
-  // fine rows: global padded row g = HPU * b + (fine row + 1); gi = g mod HPU (0: the zero row)
-  int fu_g, fu_gi, fu_b, fu_slot, need_gu0, ft_t;
-  int fv_row;  // next coarse row (global index h * b + i) to fill
-  {
-    const int b0 = T0 / p.tiles_per_img, t0 = T0 - b0 * p.tiles_per_img;
-    fu_g = HPU * b0 + 2 * TC * t0;
-    fu_gi = 2 * TC * t0;
-    fu_b = b0;
-    fu_slot = fu_g % NSU;
-    need_gu0 = fu_g;
-    ft_t = t0;
-    fv_row = p.h * b0 + TC * t0;
-  }
   float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);  // column sums of V (channels 4 (lane & 7) ..) for the bias
   // lane-constant parts of an item: pixel inside the 8-pixel item, channel quad, LDS / global offsets
   const int ch4 = lane & 7, pxl = lane >> 3;
@@ -158,41 +149,66 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   const unsigned v_colb = (unsigned)(8 * vc * p.CVt * 4) + v_g_lane;
   const int v_lds_item = NSU * RBU + 8 * vc * 64 + v_lds_lane;
   const int n_vrows = p.B * p.h;
-  auto load_fill = [&](WpItem (&iu)[WP_MAXU], WpItem& iv, bool live) {
-    const int nrows = live ? need_gu0 + 2 * TC + 2 - fu_g : 0;
+  // Which rows a fill moves and where they land (image seams, ring wrap-arounds) is index arithmetic that cost
+  // ~170 dependent scalar instructions per tile inside the MFMA stream (fconv_planes.hip: 14 of 71 us).  It is done
+  // once here, by all threads, into LDS tables; the tile loop reads its entries (wave-uniform addresses) and adds
+  // lane offsets.  Fill f >= 1 brings the fine rows tile T0 + f needs beyond those of tile T0 + f - 1 (fill 0: all of
+  // tile T0's) and the TC coarse rows of tile T0 + f.
+  constexpr int RPF = WP_MAXU * RJ;           // fine rows a fill can carry (row r = r0 + RJ j of item j)
+  constexpr int DST_NONE = -(1 << 24);        // LDS offset of an item without a row: dst stays negative
+  constexpr unsigned OFF_NONE = 0x7FFF0000u;  // global offset of a row that is not read: out of range
+  const int NF = p.tiles_per_wg + 4;
+  WpEnt* tt = reinterpret_cast<WpEnt*>(vring + NSV * RBV);  // [NF] tile: (first fine ring slot, first coarse ring slot)
+  WpEnt* tr = tt + NF;                                      // [NF][RPF] fine row: (LDS byte offset, global byte offset)
+  WpEnt* tv = tr + NF * RPF;                                // [NF][TC] coarse row: the same
+  {
+    const int tpi = p.tiles_per_img;
+    for (int e = tid; e < NF; e += 512) {
+      const int T = T0 + e, b = T / tpi, t = T - b * tpi;
+      tt[e] = WpEnt{(HPU * b + 2 * TC * t) % NSU, (TC * T) % NSV};
+    }
+    for (int e = tid; e < NF * RPF; e += 512) {
+      const int f = e / RPF, r = e - f * RPF;
+      const int T = T0 + f, b1 = T / tpi, t1 = T - b1 * tpi;
+      const int end = HPU * b1 + 2 * TC * t1 + 2 * TC + 2;
+      int start = end - (2 * TC + 2);
+      if (f > 0) {
+        const int b0 = (T - 1) / tpi, t0 = (T - 1) - b0 * tpi;
+        start = HPU * b0 + 2 * TC * t0 + 2 * TC + 2;
+      }
+      const int G = start + r;  // global padded fine row HPU * b + gi; gi == 0: the zero row between images
+      const bool valid = T < T1 && G < end;
+      const int b = G / HPU, gi = G - b * HPU;
+      const bool real = valid && gi != 0 && b < p.B;
+      tr[e] = WpEnt{valid ? (G % NSU) * RBU : DST_NONE, real ? (int)((unsigned)(G - b - 1) * u_rowbytes) : (int)OFF_NONE};
+    }
+    for (int e = tid; e < NF * TC; e += 512) {
+      const int f = e / TC, q = e - f * TC;
+      const int T = T0 + f, grow = TC * T + q;  // global coarse row h * b + i
+      const bool valid = T < T1;
+      tv[e] = WpEnt{valid ? (grow & (NSV - 1)) * RBV : DST_NONE,
+                    valid && grow < n_vrows ? (int)((unsigned)grow * v_rowbytes) : (int)OFF_NONE};
+    }
+  }
+  // waves 4-7 carry no coarse-row item
+  const int v_none_dst = wave < 4 ? 0 : (int)0x80000000;
+  const unsigned v_none_off = wave < 4 ? 0u : OFF_NONE;
+  struct FillEnt { WpEnt u[WP_MAXU]; WpEnt v; };
+  auto fill_entries = [&](FillEnt& en, int f) {
+#pragma unroll
+    for (int j = 0; j < WP_MAXU; ++j) en.u[j] = tr[f * RPF + r0 + RJ * j];
+    en.v = tv[f * TC + vr];
+  };
+  // (the loads are unconditional -- an absent item reads zeros through the range check -- so that the number of
+  // loads in flight is a compile-time constant: the wait before a store is vmcnt(N), not vmcnt(0))
+  auto fill_loads = [&](WpItem (&iu)[WP_MAXU], WpItem& iv, const FillEnt& en) {
 #pragma unroll
     for (int j = 0; j < WP_MAXU; ++j) {
-      // (the load itself is unconditional -- an absent item reads zeros through the range check -- so
-      // that the number of loads in flight is a compile-time constant: the wait before a store is
-      // vmcnt(N), not vmcnt(0))
-      const int r = r0 + RJ * j;
-      const bool valid = r < nrows;
-      int gi = fu_gi + r, b = fu_b;
-      if (gi >= HPU) { gi -= HPU; ++b; }
-      int slot = fu_slot + r;
-      if (slot >= NSU) slot -= NSU;
-      iu[j].dst = valid ? slot * RBU + u_lds_item : -1;
-      const bool real = valid && gi != 0 && b < p.B;   // gi == 0: the zero row between images
-      const unsigned rowb = (unsigned)(b * HU + gi - 1) * u_rowbytes;
-      iu[j].v = odin_run_load4(RU, real ? rowb + u_colb : ODIN_OOB);
+      iu[j].dst = en.u[j].x + u_lds_item;  // negative: no row
+      iu[j].v = odin_run_load4(RU, (unsigned)en.u[j].y + u_colb);
     }
-    {
-      // coarse rows of the tile: TC rows x IPV items = 4 items, waves 0-3
-      const bool valid = live && wave < 4;
-      const int grow = fv_row + vr;
-      iv.dst = valid ? (grow & (NSV - 1)) * RBV + v_lds_item : -1;
-      iv.v = odin_run_load4(RV, (valid && grow < n_vrows) ? (unsigned)grow * v_rowbytes + v_colb : ODIN_OOB);
-    }
-    if (live) {
-      fu_g += nrows;
-      fu_gi += nrows;
-      if (fu_gi >= HPU) { fu_gi -= HPU; ++fu_b; }
-      fu_slot += nrows;
-      if (fu_slot >= NSU) fu_slot -= NSU;
-      need_gu0 += 2 * TC;
-      if (++ft_t == p.tiles_per_img) { ft_t = 0; need_gu0 += 1; }
-      fv_row += TC;
-    }
+    iv.dst = (en.v.x + v_lds_item) | v_none_dst;
+    iv.v = odin_run_load4(RV, ((unsigned)en.v.y + v_colb) | v_none_off);
   };
   auto store_item = [&](const WpItem& it, int plane_bytes) {
 #ifdef ODIN_SIM
@@ -240,15 +256,19 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   WpItem iuA[WP_MAXU], iuB[WP_MAXU], iuC[WP_MAXU], ivA, ivB, ivC;
 
   // ---- prologue: rows of the first tile, then the second tile's into registers ----
-  load_fill(iuA, ivA, true);
+  FillEnt en;
+  __syncthreads();  // the tables
+  fill_entries(en, 0);
+  fill_loads(iuA, ivA, en);
   store_fill(iuA, ivA);
-  load_fill(iuA, ivA, T0 + 1 < T1);
-  load_fill(iuB, ivB, T0 + 2 < T1);
+  fill_entries(en, 1);
+  fill_loads(iuA, ivA, en);
+  fill_entries(en, 2);
+  fill_loads(iuB, ivB, en);
+  fill_entries(en, 3);
+  WpEnt thN = tt[0];  // ring slots of the next tile's first fine / coarse row
   __syncthreads();
-
-  int b_cur = T0 / p.tiles_per_img, t_cur = T0 - b_cur * p.tiles_per_img;
-  int su0 = (HPU * b_cur + 2 * TC * t_cur) % NSU;  // ring slot of the tile's first padded fine row
-  int sv0 = (p.h * b_cur + TC * t_cur) % NSV;
+  int su0 = 0, sv0 = 0;
 
   // fragments of one 16-pixel chunk: V (3 planes) and U for the wave's two taps
   struct Frags { u32x4 fv[3]; u32x4 fu[2][3]; };
@@ -307,18 +327,17 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   // register copies: a copy of a freshly loaded register would wait for the load, vmcnt(0), every tile).
   Frags F0, F1;
   auto run_tile = [&](int T, WpItem (&ldu)[WP_MAXU], WpItem& ldv, const WpItem (&stu)[WP_MAXU], const WpItem& stv) {
+    su0 = thN.x;
+    sv0 = thN.y;
     if (!(DBG & 2) || T == T0) read_chunk(0, F0);   // first thing behind the barrier
     ODIN_SCHED_FENCE();
-    load_fill(ldu, ldv, T + 3 < T1 && !(DBG & 4) && !(DBG & 8));
+    fill_loads(ldu, ldv, en);  // fill T - T0 + 3: its table entries were read a tile ago
     if (!(DBG & 2) || T == T0) read_chunk(1, F1);
     ODIN_SCHED_FENCE();
     mfma_chunk(F0, 0, stu, stv);   // items 0, 1, 2
+    fill_entries(en, T - T0 + 4);
+    thN = tt[T - T0 + 1];
     mfma_chunk(F1, 3, stu, stv);   // items 3, 4
-    su0 += 2 * TC;
-    sv0 += TC;
-    if (++t_cur == p.tiles_per_img) { t_cur = 0; ++b_cur; ++su0; }
-    if (su0 >= NSU) su0 -= NSU;
-    if (sv0 >= NSV) sv0 -= NSV;
     __syncthreads();  // every wave is past tile T's rows; tile T + 1's rows are stored
   };
   // (loads run TWO tiles ahead of their stores: one tile, ~2 us, did not cover the HBM latency under
@@ -362,15 +381,36 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   }
 }
 
+// LDS: fine-row ring + coarse-row ring + the fill tables ((1 + fine rows per fill + TC) x 8 bytes per fill, tiles + 4 fills)
+constexpr int WP_LDS_MAX = 156 * 1024;
+int wp_ring_bytes(int W) {
+  const int TC = 32 / W;
+  return (4 * TC + 3) * 3 * 2 * (W + 1) * 64 + (2 * TC) * 3 * W * 64;
+}
+int wp_fill_bytes(int W) {
+  const int ipu = 2 * W / 8, rj = 8 / ipu > 0 ? 8 / ipu : 1;
+  return 8 * (1 + WP_MAXU * rj + 32 / W);
+}
+// tiles per workgroup: the chip filled once when the tables fit, more workgroups otherwise; -1: does not fit
+int wp_tiles_per_wg(int W, int n_tiles, int gyz) {
+  int cap = odin_num_cus() / gyz;
+  if (cap < 1) cap = 1;
+  if (cap > ODIN_MAX_SLAB_BLOCKS) cap = ODIN_MAX_SLAB_BLOCKS;
+  int tpw = (n_tiles + cap - 1) / cap;
+  const int limit = (WP_LDS_MAX - wp_ring_bytes(W)) / wp_fill_bytes(W) - 4;
+  if (tpw > limit) tpw = limit;
+  if ((n_tiles + tpw - 1) / tpw > ODIN_MAX_SLAB_BLOCKS) return -1;
+  return tpw;
+}
+
 template <int W>
 int wp_launch(const WPParams& p, dim3 grid, void* stream) {
-  constexpr int TC = 32 / W;
-  const size_t lds = (size_t)(4 * TC + 3) * 3 * 2 * (W + 1) * 64 + (size_t)(2 * TC) * 3 * W * 64;
+  const size_t lds = (size_t)wp_ring_bytes(W) + (size_t)(p.tiles_per_wg + 4) * wp_fill_bytes(W);
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<W>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS_MAX) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
@@ -387,7 +427,7 @@ int wp_launch(const WPParams& p, dim3 grid, void* stream) {
                             reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 8 : 0)>),
                             reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 16 : 0)>)};
       for (const void* f : fns)
-        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS_MAX) != hipSuccess)
           (void)hipGetLastError();
       dattr = true;
     }
@@ -412,7 +452,8 @@ bool odin_wgrad_planes_applicable(int B, int H, int W, int CI, int OH, int OW, i
   if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT") || getenv("ODIN_NOWPLANES")) return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && !center && (CI % 32) == 0 && (CO % 32) == 0 &&
          H == 2 * OH && W == 2 * OW && (OW == 8 || OW == 16 || OW == 32) && (OH % (32 / OW)) == 0 &&
-         (size_t)B * H * W * CI * 4 < (1ull << 31) && (size_t)B * OH * OW * CO * 4 < (1ull << 31);
+         (size_t)B * H * W * CI * 4 < 0x7FFF0000ull && (size_t)B * OH * OW * CO * 4 < 0x7FFF0000ull &&
+         wp_tiles_per_wg(OW, B * (OH / (32 / OW)), (CI / 32) * (CO / 32)) > 0;
 }
 
 int odin_wgrad_planes_launch(const float* U, const float* V, float* slab, int* rows_out, int B, int OH,
@@ -426,10 +467,8 @@ int odin_wgrad_planes_launch(const float* U, const float* V, float* slab, int* r
   p.tiles_per_img = OH / TC;
   p.n_tiles = B * p.tiles_per_img;
   const int gy = CI / 32, gz = CO / 32;
-  int cap = odin_num_cus() / (gy * gz);
-  if (cap < 1) cap = 1;
-  if (cap > ODIN_MAX_SLAB_BLOCKS) cap = ODIN_MAX_SLAB_BLOCKS;
-  p.tiles_per_wg = (p.n_tiles + cap - 1) / cap;
+  p.tiles_per_wg = wp_tiles_per_wg(OW, p.n_tiles, gy * gz);
+  if (p.tiles_per_wg <= 0) return odin_fail(-2, "wgrad_planes: too many tiles for the fill tables");
   const int gx = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
   if (rows_out) *rows_out = gx;
   if (slab == nullptr) return 0;  // dry run
