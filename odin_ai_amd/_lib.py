@@ -163,7 +163,8 @@ def load(path: Optional[str] = None) -> Lib:
   if path is not None:
     _lib = Lib(path)
   elif _lib is None:
-    _lib = Lib(DEFAULT_LIB)
+    # ODIN_HIP_LIB: another build of the SAME library (A/B timing of two builds in one gpurun call)
+    _lib = Lib(os.environ.get('ODIN_HIP_LIB') or DEFAULT_LIB)
   return _lib
 
 

@@ -113,6 +113,10 @@ __device__ __forceinline__ void tp_split4(const float4& v, u32x2& h, u32x2& m, u
               odin_pack_bf16(odin_bf16_rest(r2), odin_bf16_rest(r3)));
 }
 
+struct alignas(8) TpEnt {
+  int x, y;
+};
+
 struct TpItem {
   float4 v;
   int dst;  // byte offset of the hi-plane store inside the ring
@@ -172,16 +176,6 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
 
   // ---- row fills: wave-uniform walk over the padded rows; a wave moves up to two 1 KB items ----
   const OdinRun IN = odin_run(p.in, (unsigned)((size_t)p.B * p.H * W * p.CS * 4));
-  int f_gi, f_b, f_slot, f_g, need_g0, ft_t;
-  {
-    const int b0 = T0 / p.tiles_per_img, t0 = T0 - b0 * p.tiles_per_img;
-    f_g = HP * b0 + RP * t0;
-    f_gi = RP * t0;
-    f_b = b0;
-    f_slot = f_g % NSLOT;
-    need_g0 = f_g;
-    ft_t = t0;
-  }
   // loads the rows tile `need` still misses into registers; advances the walk.  The row part of an
   // item is wave-uniform (scalar, 32-bit: the applicability test bounds the tensor to 2 GB), the lane part
   // is computed once.
@@ -191,38 +185,47 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   const int f_lds_lane = f_pc * 64 + ((((f_ch4 >> 1) ^ ((f_pc >> 2) & 3))) << 4) + (f_ch4 & 1) * 8;
   const unsigned f_g_lane = (unsigned)((f_px * p.CS + p.ci_off + 4 * f_ch4) * 4);
   const unsigned f_rowbytes = (unsigned)(W * p.CS * 4);
-  // (branch-free on purpose: selects on wave-uniform integers become s_cselect; the compiler turned the
-  // `if`-form of this walk into ~150 scalar instructions with 8 branches per tile, which both waves of a
-  // SIMD executed at the same time -- the matrix pipe idled behind them)
-  auto load_fill = [&](TpItem (&it)[2], bool live) {
-    const int nrows = live ? need_g0 + RP + 2 - f_g : 0;
+  // Which rows a fill moves and where they land (image seams, ring wrap-arounds) is index arithmetic: ~150 dependent
+  // scalar instructions per tile when done inside the MFMA stream, where both waves of a SIMD executed them at the
+  // same time and the matrix pipe idled behind them (fconv_planes.hip: 14 of 71 us).  It is done once here, by all
+  // threads, into an LDS table; the tile loop reads its entries (wave-uniform addresses) and adds lane offsets.
+  // Fill f >= 1 brings the rows tile T0 + f needs beyond those of tile T0 + f - 1, fill 0 all of tile T0's.
+  constexpr int RPF = 2 * F_RJ;  // rows a fill can carry (row r = f_r0 + F_RJ j of item j)
+  const int NF = p.tiles_per_wg + 3;
+  TpEnt* tr = reinterpret_cast<TpEnt*>(ring + NSLOT * RB);  // [NF][RPF] row: (ring byte offset or -1, global byte offset)
+  {
+    const int tpi = p.tiles_per_img;
+    for (int e = tid; e < NF * RPF; e += 512) {
+      const int f = e / RPF, r = e - f * RPF;
+      const int T = T0 + f, b1 = T / tpi, t1 = T - b1 * tpi;
+      const int end = HP * b1 + RP * t1 + RP + 2;
+      int start = end - (RP + 2);
+      if (f > 0) {
+        const int b0 = (T - 1) / tpi, t0 = (T - 1) - b0 * tpi;
+        start = HP * b0 + RP * t0 + RP + 2;
+      }
+      const int G = start + r;  // global padded row HP * b + gi; gi == 0: the zero row between images
+      const bool valid = T < T1 && G < end;
+      const int b = G / HP, gi = G - b * HP;
+      const bool real = valid && gi != 0 && b < p.B;
+      tr[e] = TpEnt{valid ? (G % NSLOT) * RB : -1, real ? (int)((unsigned)(G - b - 1) * f_rowbytes) : (int)0xFFFF0000u};
+    }
+  }
+  auto fill_entries = [&](TpEnt (&en)[2], int f) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) en[j] = tr[f * RPF + f_r0 + F_RJ * j];
+  };
+  auto fill_loads = [&](TpItem (&it)[2], const TpEnt (&en)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int r = f_r0 + F_RJ * j;
-      const int valid = r < nrows;
-      int gi = f_gi + r;
-      const int wrap = gi >= HP;
-      gi -= wrap ? HP : 0;
-      const int b = f_b + wrap;
-      int slot = f_slot + r;
-      slot -= slot >= NSLOT ? NSLOT : 0;
-      // (no item: the spare slot behind the ring, same lane pattern)
-      it[j].dst = (valid ? slot : NSLOT) * RB + f_lds_lane;
-      it[j].ok = valid;
-      const int real = valid & (gi != 0) & (b < p.B);  // gi == 0: the zero row between images
-      const unsigned row_off = real ? (unsigned)(b * p.H + gi - 1) * f_rowbytes : 0xFFFF0000u;
-      it[j].v = odin_run_load4(IN, row_off + f_g_lane);
+      it[j].dst = en[j].x + f_lds_lane;
+#ifdef ODIN_SIM
+      it[j].ok = en[j].x >= 0;
+#else
+      it[j].ok = __builtin_amdgcn_readfirstlane(en[j].x) >= 0;  // (wave-uniform: a scalar branch around the stores)
+#endif
+      it[j].v = odin_run_load4(IN, (unsigned)en[j].y + f_g_lane);
     }
-    f_g += nrows;
-    f_gi += nrows;
-    const int w2 = f_gi >= HP;
-    f_gi -= w2 ? HP : 0;
-    f_b += w2;
-    f_slot += nrows;
-    f_slot -= f_slot >= NSLOT ? NSLOT : 0;
-    const int seam = live & (ft_t + 1 == p.tiles_per_img);
-    need_g0 += live ? RP + seam : 0;
-    ft_t = live ? (seam ? 0 : ft_t + 1) : ft_t;
   };
   // (a wave-uniform branch: ~30 VALU + 3 LDS stores per item, and half of the 16 item slots of a tile are
   // empty -- the kernel is bound by instruction issue, profiles/r03_kpmc_planes_8wave.txt)
@@ -317,7 +320,10 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
 
   // ---- prologue: rows of the first tile, then the second tile's into registers ----
   TpItem itA[2], itB[2];
-  load_fill(itA, true);  // (in flight while the weights are split)
+  TpEnt en[2];
+  __syncthreads();  // the table
+  fill_entries(en, 0);
+  fill_loads(itA, en);  // (in flight while the weights are split)
   // ---- weights: fp32 [tap][co][32] -> planes [tap][plane][k-piece][co][8 bf16] ----
   {
     float4 wv[8];  // all 8 loads of a thread in flight before the first split
@@ -340,7 +346,8 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     }
   }
   store_fill(itA);
-  load_fill(itA, T0 + 1 < T1);
+  fill_entries(en, 1);
+  fill_loads(itA, en);
   TP_STAMP(2);
   __syncthreads();  // weights, pads and the first tile's rows are in LDS
   TP_STAMP(10);
@@ -617,7 +624,8 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
       constexpr int k = me < 0 ? -1 : (me < 16 ? ((me & 1) ? -1 : me / 2) : me - 8);
       if constexpr (WE && !CL && k >= 0 && k < N_EPI_OPS && !(DBG & 4)) epi_op(k);
       if constexpr (WE && CL && !(DBG & 4)) cl_slot(M);
-      if (m == 32) load_fill(itB, T + 2 < T1);  // global loads of tile T + 2's rows
+      if (m == 20) fill_entries(en, T - T0 + 2);
+      if (m == 32) fill_loads(itB, en);  // global loads of tile T + 2's rows
       if (m == 33) {                            // this tile's epilogue operands (used one tile later)
         if (EPI == 2) {
 #pragma unroll
@@ -755,9 +763,25 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   }
 }
 
+// LDS: weight planes + row ring + the fill table (rows per fill x 8 bytes per fill, tiles + 3 fills); 4.3 KB are static
+constexpr int TP_LDS_MAX = 155 * 1024;
+int tp_ring_bytes(int W) { return TP_WBYTES + (2 * (64 / W) + 3) * 3 * (W + 2) * 64; }
+int tp_fill_bytes(int W) { return 8 * 2 * (W == 32 ? 2 : W == 16 ? 4 : 8); }
+// tiles per workgroup: the chip filled once when the table fits, more workgroups otherwise; -1: does not fit
+int tp_tiles_per_wg(int W, int n_tiles, int gy) {
+  int cap = odin_num_cus() / gy;
+  if (cap < 1) cap = 1;
+  if (cap > ODIN_MAX_COLSUM_BLOCKS) cap = ODIN_MAX_COLSUM_BLOCKS;
+  int tpw = (n_tiles + cap - 1) / cap;
+  const int limit = (TP_LDS_MAX - tp_ring_bytes(W)) / tp_fill_bytes(W) - 3;
+  if (tpw > limit) tpw = limit;
+  if ((n_tiles + tpw - 1) / tpw > ODIN_MAX_COLSUM_BLOCKS) return -1;
+  return tpw;
+}
+
 template <int EPI, int C1, bool ACC>
 int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
-  const size_t lds = (size_t)TP_WBYTES + (size_t)(2 * (64 / W) + 3 + 1) * 3 * (W + 2) * 64;  // ring + spare slot
+  const size_t lds = (size_t)tp_ring_bytes(W) + (size_t)(p.tiles_per_wg + 3) * tp_fill_bytes(W);  // + the fill table
   constexpr int W3 = (EPI == 3 ? 16 : 8);  // (the fused tail has no 8-pixel geometry)
 #ifndef ODIN_SIM
   static bool attr_done = false;
@@ -812,7 +836,7 @@ bool odin_tconv_planes_applicable(int B, int H, int W, int CI, int CO, int KH, i
   if (epi == 3 && (CO != 32 || (C1 != 1 && C1 != 3) || CI != 32 || W == 8)) return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && (CI == 32 || CI == 64) && (CO % 32) == 0 &&
          !center && (W == 8 || W == 16 || W == 32) && (H % (64 / W)) == 0 && (size_t)B * H * W * CI * 4 < (1ull << 31) &&
-         (size_t)B * H * W * 4 * C1 * 4 < (1ull << 31);
+         (size_t)B * H * W * 4 * C1 * 4 < (1ull << 31) && tp_tiles_per_wg(W, B * (H / (64 / W)), CO / 32) > 0;
 }
 
 // epi 1: deconv forward (bias + ELU); 2: conv data gradient (x ELU'(aux), column sums); 3: fused tail.
@@ -835,10 +859,8 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
   p.tiles_per_img = H / RP;
   p.n_tiles = B * p.tiles_per_img;
   const int gy = CO / 32;
-  int cap = odin_num_cus() / gy;
-  if (cap < 1) cap = 1;
-  if (cap > ODIN_MAX_COLSUM_BLOCKS) cap = ODIN_MAX_COLSUM_BLOCKS;
-  p.tiles_per_wg = (p.n_tiles + cap - 1) / cap;
+  p.tiles_per_wg = tp_tiles_per_wg(W, p.n_tiles, gy);
+  if (p.tiles_per_wg <= 0) return odin_fail(-2, "tconv_planes: too many tiles for the fill table");
   const int gx = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
   if (rows_out) *rows_out = gx;
   if (n_part_out) *n_part_out = p.tiles_per_img;
