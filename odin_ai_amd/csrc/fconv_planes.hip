@@ -37,7 +37,7 @@ struct FPParams {
 #else
 #define FP_STAMP(k)                                                                               \
   do {                                                                                            \
-    if (p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && stamp_i < 32 && stamp_on) \
+    if (p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && stamp_i < 32)        \
       p.stamps[32 * wave + stamp_i++] = ((long long)(k) << 56) | (long long)(clock64() & 0xFFFFFFFFFFFFFFll); \
   } while (0)
 #endif
@@ -95,9 +95,8 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   if (T1 > p.n_tiles) T1 = p.n_tiles;
   if (T0 >= T1) return;
   int stamp_i = 0;
-  bool stamp_on = false;  // (the third tile of workgroup 0 only)
   (void)stamp_i;
-  (void)stamp_on;
+  FP_STAMP(1);
 
   // ---- SAME-padding slots (parity plane 0 slot 0, parity plane 1 slot OW) of every ring row and plane ----
   for (int e = tid; e < NSU * 24; e += 512) {
@@ -272,17 +271,16 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
     odin_run_store2(RO, ooffP, make_float2(v[0], v[1]));  // (range-checked: the first tile's pass has no tile T - 1)
   };
 
-  // One tile.  Between its first and last MFMA there is NO branch: the row fills of tile T + 3 (loads), the split
-  // and LDS stores of tile T + 1's rows and the epilogue of tile T - 1 all ride between the MFMAs as straight-line
-  // code with masked addresses -- with one scalar branch per fill item the 24 MFMAs of a wave took 2.1-2.9 k
-  // cycles, without any 0.85 k (in-kernel stamps, profiles/r03_stamps_fconv_planes.txt).
+  // One tile.  The row fills of tile T + 3 (loads), the split and LDS stores of tile T + 1's rows and the epilogue of
+  // tile T - 1 ride between the MFMAs; the only scalar work left in there is one branch per fill item (the index walk
+  // that used to sit here made the 24 MFMAs of a wave take 2.1-2.9 k cycles; a bare MFMA chain takes 0.85 k:
+  // in-kernel stamps and ablations, profiles/r03_fconv_planes_bookkeeping.txt).
   auto run_tile = [&](int T, FpItem (&ldu)[FP_MAXU], const FpItem (&stu)[FP_MAXU]) {
     const FpEnt th = thN;
     int su = th.x + 2 * orow + kh;  // the wave's tap row kh of this lane's output row
     su -= su >= NSU ? NSU : 0;
     const char* rowp = ring + su * RBU;
     u32x4 fb[2][2][3];
-    stamp_on = T == T0 + 2;
     FP_STAMP(2);
     // (the fragments of the first products first)
 #pragma unroll
@@ -303,7 +301,8 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
       const int ia = (pp == 0) ? 0 : (pp == 1) ? 2 : (pp == 2) ? 1 : (pp == 3) ? 0 : (pp == 4) ? 1 : 0;
       const int ib = (pp == 0) ? 2 : (pp == 1) ? 0 : (pp == 2) ? 1 : (pp == 3) ? 1 : (pp == 4) ? 0 : 0;
       acc = mfma32_bf16(wf[t][kk][ia], fb[t][kk][ib], acc);
-      FP_STAMP(10 + m);
+      if (m == 0) FP_STAMP(3);
+      if (m == 23) FP_STAMP(4);
       // the matrix pipe starts as soon as the first fragments are there; everything else rides between MFMAs
       if (m == 0) {
         fill_loads(ldu, en);  // fill T - T0 + 3: its table entries were read a tile ago

@@ -7,8 +7,7 @@ sys.path.insert(0, '.')
 from odin_ai_amd import _lib
 L = _lib.load(os.environ.get('ODIN_DIAG_LIB') or 'tools/diag/libodin_hip_diag.so')
 dev = torch.device('cuda:0')
-names = {1: 'kernel start', 2: 'tile start', 5: 'partials written'}
-names.update({10 + m: f'mfma {m} issued' for m in range(24)})
+names = {1: 'kernel start', 2: 'tile start', 3: 'mfma 0 issued', 4: 'mfma 23 issued', 5: 'partials written'}
 B, H, W = 256, 32, 32
 d = _lib.conv_desc(B, H, W, 32, 2 * H, 2 * W, 32, 4, 2, 1, 1, 'elu')
 w = torch.randn(4, 4, 32, 32, device=dev) * 0.1
@@ -30,7 +29,7 @@ L.odin_debug_set_stamps(None)
 print('path', L.odin_debug_last_path().decode())
 va = st.cpu().numpy().reshape(8, 32)
 t0 = min(int(va[w][0] & ((1 << 56) - 1)) for w in range(8))
-print('third tile of workgroup 0: ticks since its first wave passed the barrier; rows = stamps, columns = waves 0..7')
+print('workgroup 0: shader cycles since its first wave started; rows = stamps, columns = waves 0..7')
 for i in range(32):
   k = int(va[0][i] >> 56)
   if k == 0: break
