@@ -28,6 +28,7 @@ struct FPParams {
   float* out;          // [B, OH, OW, CO]
   float* colsum;       // EPI 2: [gridDim.x][CO] partial column sums of out (may be null)
   int B, OH, CO;
+  int CS, ci_off;      // channels of the input tensor; first of the 32 this pass reduces over
   int tiles_per_img, n_tiles, tiles_per_wg;
   long long* stamps;   // diagnostics build: s_memtime stamps of workgroup 0, [wave][32]
 };
@@ -62,8 +63,10 @@ struct FpItem {
 
 constexpr int FP_MAXU = 4;
 
-// EPI 1: bias + ELU (Conv2D forward); EPI 2: x ELU'(aux), column sums (deconv data gradient)
-template <int EPI, int OW>
+// EPI 1: bias + ELU (Conv2D forward); EPI 2: x ELU'(aux), column sums (deconv data gradient); EPI 0: raw partial sums
+// (first of two reduction passes over 64 input channels); ACC: add the partial sums the previous pass left in `out`
+// before the epilogue.
+template <int EPI, int OW, bool ACC>
 __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   constexpr int TC = 32 / OW;            // output rows per tile
   constexpr int WU = 2 * OW;             // input row length
@@ -117,14 +120,14 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   // 14 of the kernel's 71 us (profiles/r03_fconv_planes_bookkeeping.txt).  It is done ONCE here, by all threads in
   // parallel, into two small LDS tables; the tile loop reads its entries (wave-uniform addresses) and adds lane
   // offsets.  Fill f >= 1 brings the rows tile T0 + f needs beyond those of tile T0 + f - 1; fill 0 all of tile T0's.
-  const OdinRun RU = odin_run(p.in, (unsigned)((size_t)p.B * HU * WU * 32 * 4));
+  const OdinRun RU = odin_run(p.in, (unsigned)((size_t)p.B * HU * WU * p.CS * 4));
   constexpr int RPF = FP_MAXU * RJ;      // rows a fill can carry (row r = r0w + RJ j of item j)
   constexpr int DST_NONE = -(1 << 24);   // ring offset of an item without a row: dst stays negative
   constexpr unsigned OFF_NONE = 0x7FFF0000u;  // global offset of a row that is not read (padding row, no image): out of range
   const int NF = p.tiles_per_wg + 4;
   FpEnt* tt = reinterpret_cast<FpEnt*>(red + 2 * RED);  // [NF] tile: (first ring slot, byte offset of its first output)
   FpEnt* tr = tt + NF;                                 // [NF][RPF] fill row: (ring byte offset, global byte offset)
-  const unsigned u_rowbytes = (unsigned)(WU * 32 * 4);
+  const unsigned u_rowbytes = (unsigned)(WU * p.CS * 4);
   {
     const int tpi = p.tiles_per_img;
     for (int e = tid; e < NF; e += 512) {
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   const int r0w = wave / IPU, cblk = wave - r0w * IPU;
   const int pcw = 8 * cblk + pxl + 1;  // padded column of this lane's pixel: parity pcw & 1, slot pcw >> 1
   const int u_lds = (pcw & 1) * PARB + (pcw >> 1) * 64 + (((ch4 >> 1) ^ (((pcw >> 1) >> 2) & 3)) << 4) + (ch4 & 1) * 8;
-  const unsigned u_g = (unsigned)(((8 * cblk + pxl) * 32 + 4 * ch4) * 4);
+  const unsigned u_g = (unsigned)(((8 * cblk + pxl) * p.CS + p.ci_off + 4 * ch4) * 4);
   // the table entries of fill f for this wave's items, then the loads themselves
   auto fill_entries = [&](FpEnt (&en)[FP_MAXU], int f) {
 #pragma unroll
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        v[e] = p.w[((size_t)(tap * 32 + 16 * kk + 8 * half + e)) * p.CO + n0 + l31];
+        v[e] = p.w[((size_t)(tap * p.CS + p.ci_off + 16 * kk + 8 * half + e)) * p.CO + n0 + l31];
       u32x2 h0, m0, l0, h1, m1, l1;
       fp_split4(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
       fp_split4(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   const OdinRun RO = odin_run(p.out, out_bytes);
   const OdinRun RX = odin_run(EPI == 2 ? p.aux : p.out, out_bytes);
   unsigned ooffP = ODIN_OOB;
-  float2 auxP = make_float2(0.f, 0.f);
+  float2 auxP = make_float2(0.f, 0.f), pvP = make_float2(0.f, 0.f);
 
   // sums the eight partial tiles of registers 2 wave, 2 wave + 1 of tile T - 1 and finishes them
   // scratch layout [register pair][source wave][lane][8 B]: this wave reads pair `wave` of all eight sources --
@@ -256,13 +259,14 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 #pragma unroll
     for (int wv = 1; wv < 8; ++wv) { s.x += q8[wv].x; s.y += q8[wv].y; }
     float v[2] = {s.x, s.y};
+    if (ACC) { v[0] += pvP.x; v[1] += pvP.y; }
     if (EPI == 1) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const float tt = v[k] + bias2[k];
         v[k] = fmaxf(tt, 0.f) + (odin_exp2(fminf(tt, 0.f) * 1.44269504088896341f) - 1.f);
       }
-    } else {
+    } else if (EPI == 2) {
       v[0] = fmaf(v[0], fminf(auxP.x, 0.f), v[0]);  // x ELU'(aux) = 1 + min(aux, 0)
       v[1] = fmaf(v[1], fminf(auxP.y, 0.f), v[1]);
       csum[0] += v[0];
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
         for (int kk = 0; kk < 2; ++kk) fb[t][kk][pl] = *reinterpret_cast<const u32x4*>(rowp + boff[t][kk] + pl * PBU);
     ODIN_SCHED_FENCE();
     const unsigned ooff = (unsigned)th.y + o_lane;
-    float2 auxN = make_float2(0.f, 0.f);
+    float2 auxN = make_float2(0.f, 0.f), pvN = make_float2(0.f, 0.f);
     float2 q8[8];
     f32x16 acc = f32x16_zero();
 #pragma unroll
@@ -307,6 +311,7 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
       if (m == 0) {
         fill_loads(ldu, en);  // fill T - T0 + 3: its table entries were read a tile ago
         if (EPI == 2) auxN = odin_run_load2(RX, ooff);
+        if (ACC) pvN = odin_run_load2(RO, ooff);
       }
       if (m == 21) {  // (behind every other LDS read of this tile)
         fill_entries(en, T - T0 + 4);
@@ -325,6 +330,7 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
     FP_STAMP(5);
     ooffP = ooff;
     auxP = auxN;
+    pvP = pvN;
     __syncthreads();  // partial tiles complete; every wave is past tile T's rows; tile T + 1's rows are stored
   };
 #pragma unroll 1
@@ -371,19 +377,19 @@ int fp_tiles_per_wg(int OW, int n_tiles, int gy) {
   return tpw;
 }
 
-template <int EPI, int OW>
+template <int EPI, int OW, bool ACC>
 int fp_launch(const FPParams& p, dim3 grid, void* stream) {
   const size_t lds = (size_t)fp_ring_bytes(OW) + (size_t)(p.tiles_per_wg + 4) * fp_fill_bytes(OW);
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fconv_planes_kernel<EPI, OW>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fconv_planes_kernel<EPI, OW, ACC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, FP_LDS_MAX) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((fconv_planes_kernel<EPI, OW>), grid, dim3(512), lds, stream, p);
+  ODIN_LAUNCH((fconv_planes_kernel<EPI, OW, ACC>), grid, dim3(512), lds, stream, p);
   return odin_check_launch("fconv_planes(bf16x3)");
 }
 
@@ -396,20 +402,30 @@ bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, i
                                   int pt, int pl, int center) {
   // (read per call: the A/B tests switch paths inside one process; a captured graph never comes here)
   if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT") || getenv("ODIN_NOFPLANES")) return false;
-  return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && CI == 32 && (CO % 32) == 0 && !center &&
+  return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && (CI == 32 || (CI == 64 && !getenv("ODIN_FP_NO64"))) && (CO % 32) == 0 && !center &&
          H == 2 * OH && W == 2 * OW && (OW == 8 || OW == 16 || OW == 32) && (OH % (32 / OW)) == 0 &&
          (size_t)B * H * W * CI * 4 < 0x7FFF0000ull && (size_t)B * OH * OW * CO * 4 < (1ull << 31) &&
          fp_tiles_per_wg(OW, B * (OH / (32 / OW)), CO / 32) > 0;
 }
 
-// epi 1: Conv2D forward (bias + ELU); epi 2: Conv2DTranspose data gradient (x ELU'(aux), column sums)
+template <int EPI, bool ACC>
+int fp_launch_w(const FPParams& p, int OW, dim3 grid, void* stream) {
+  if (OW == 32) return fp_launch<EPI, 32, ACC>(p, grid, stream);
+  if (OW == 16) return fp_launch<EPI, 16, ACC>(p, grid, stream);
+  return fp_launch<EPI, 8, ACC>(p, grid, stream);
+}
+
+// epi 1: Conv2D forward (bias + ELU); epi 2: Conv2DTranspose data gradient (x ELU'(aux), column sums).
+// CI = 64: two reduction passes over 32 channels each (a wave keeps the weight fragments of 32 channels in
+// registers): the first leaves raw partial sums in `out`, the second adds them and runs the epilogue.
 int odin_fconv_planes_launch(const float* in, const float* w, const float* bias, const float* aux,
-                             float* out, float* colsum, int* rows_out, int B, int OH, int OW, int CO,
+                             float* out, float* colsum, int* rows_out, int B, int OH, int OW, int CI, int CO,
                              int epi, void* stream) {
   FPParams p;
   memset(&p, 0, sizeof(p));
   p.in = in; p.w = w; p.bias = bias; p.aux = aux; p.out = out; p.colsum = colsum;
   p.B = B; p.OH = OH; p.CO = CO;
+  p.CS = CI; p.ci_off = 0;
   p.stamps = g_fp_stamps;
   const int TC = 32 / OW;
   p.tiles_per_img = OH / TC;
@@ -421,12 +437,13 @@ int odin_fconv_planes_launch(const float* in, const float* w, const float* bias,
   if (rows_out) *rows_out = gx;
   if (out == nullptr) return 0;  // dry run
   dim3 grid(gx, gy, 1);
-  if (epi == 1) {
-    if (OW == 32) return fp_launch<1, 32>(p, grid, stream);
-    if (OW == 16) return fp_launch<1, 16>(p, grid, stream);
-    return fp_launch<1, 8>(p, grid, stream);
+  if (CI == 64) {
+    FPParams q = p;
+    q.colsum = nullptr;
+    const int rc = fp_launch_w<0, false>(q, OW, grid, stream);
+    if (rc != 0) return rc;
+    p.ci_off = 32;
+    return epi == 1 ? fp_launch_w<1, true>(p, OW, grid, stream) : fp_launch_w<2, true>(p, OW, grid, stream);
   }
-  if (OW == 32) return fp_launch<2, 32>(p, grid, stream);
-  if (OW == 16) return fp_launch<2, 16>(p, grid, stream);
-  return fp_launch<2, 8>(p, grid, stream);
+  return epi == 1 ? fp_launch_w<1, false>(p, OW, grid, stream) : fp_launch_w<2, false>(p, OW, grid, stream);
 }

@@ -1602,8 +1602,8 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
   if (d->act == ODIN_ACT_ELU && bias != nullptr &&
       odin_fconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                                    d->pad_t, d->pad_l, d->center))
-    return odin_fconv_planes_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->OH, d->OW, d->Cout, 1,
-                                    stream);
+    return odin_fconv_planes_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->OH, d->OW, d->Cin, d->Cout,
+                                    1, stream);
   if (d->act == ODIN_ACT_ELU && bias != nullptr &&
       odin_fconv_ring_applicable(d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                                  d->pad_t, d->pad_l, d->center))
@@ -1696,7 +1696,7 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
       odin_fconv_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
                                    d->pad_t, d->pad_l, 0))
     return odin_fconv_planes_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, d->B, d->H, d->W,
-                                    d->Cin, 2, stream);
+                                    d->Cout, d->Cin, 2, stream);
   // (64 reduction channels take two fconv_ring passes: where the implicit-GEMM kernel covers the layer it does the
   // same work in one launch -- decoder2 of the dSprites stack: 30.8 us in two launches vs 30.2 us in one)
   const bool ring_two_pass_vs_igemm =

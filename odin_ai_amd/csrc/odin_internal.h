@@ -84,7 +84,7 @@ bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, i
                                   int pt, int pl, int center);
 void odin_fconv_planes_set_stamps(void* buf);
 int odin_fconv_planes_launch(const float* in, const float* w, const float* bias, const float* aux,
-                             float* out, float* colsum, int* rows_out, int B, int OH, int OW, int CO,
+                             float* out, float* colsum, int* rows_out, int B, int OH, int OW, int CI, int CO,
                              int epi, void* stream);
 
 // small-spatial layers as implicit GEMMs with both operands straight from L2 (igemm.hip)
