@@ -591,6 +591,130 @@ int odin_smallc_fwd(const float* x, const float* w, const float* bias, float* y,
   return odin_check_launch("smallc_fwd");
 }
 
+// The same weight gradient for the first layers of the image stacks (4x4 / stride 2, pads (1, 1), 64-pixel input rows
+// of CI = 1 or 3 channels, <= 32 output channels): the four input rows of an output row are STAGED in LDS by the wave
+// that owns the row -- 1 (CI = 1) or 3 (CI = 3) coalesced 16-byte loads per lane instead of one 4-byte gather per tap
+// row and pixel pair -- with four zero floats either side of each row, so a tap read needs no bounds test: its address
+// is a per-lane constant plus the pixel step.  A row of ones feeds the bias row of the tile, a row of zeros the unused
+// tile rows.  fp32 MFMAs do not run beside VALU work: the ~6 VALU per gather of the kernel above were
+// half of its time.  The next row's loads are in flight while the current row is multiplied.
+template <int RB, int CI>
+__global__ __launch_bounds__(1024) void smallc_wgrad_lds_kernel(SCParams p) {
+  constexpr int NW = 16, U = 4, W = 64, OW = 32;
+  constexpr int K = 16 * CI;
+  constexpr int NCH = W * CI / 4;                 // 16-byte chunks per input row
+  constexpr int NI = (4 * NCH + 63) / 64;         // chunks per lane and output row
+  constexpr int RS = W * CI + 8;                  // floats per staged row
+  constexpr int WS = 6 * RS;                      // per wave: 4 data rows, the ones row, the zero row
+  ODIN_DYN_SMEM(float, smem);  // staging [NW][WS] inside the loop, partial tiles [NW][RB][16][64] behind it
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef ODIN_SIM
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int l31 = lane & 31, h = lane >> 5;
+  float* st = smem + wave * WS;
+  const OdinRun XR = odin_run(p.x, (unsigned)((size_t)p.B * p.H * W * CI * 4));
+  const OdinRun DR = odin_run(p.dy, (unsigned)((size_t)p.B * p.OH * OW * p.CO * 4));
+  // guards, ones row, zero row (the data rows' interiors are rewritten for every output row)
+  for (int e = lane; e < WS; e += 64) st[e] = (e >= 4 * RS && e < 5 * RS) ? 1.f : 0.f;
+  // this lane's tile rows: k = tap * CI + c -> staged row kh, float 4 + (2 ow - 1 + kw) CI + c for pixel ow
+  int abase[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int k = rb * 32 + l31;
+    const int tap = k / CI, c = k - tap * CI, kh = tap >> 2, kw = tap & 3;
+    int idx = kh * RS + 4 + (kw - 1) * CI + c;
+    if (k == K) idx = 4 * RS + 4;   // bias row: ones
+    if (k > K) idx = 5 * RS + 4;    // unused row of the tile: zeros
+    abase[rb] = (wave * WS + idx + h * 2 * CI) * 4;  // bytes; pixel ow = q0 + 2 u + h: + (q0 + 2 u) 2 CI floats
+  }
+  unsigned boff[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) boff[u] = l31 < p.CO ? (unsigned)(((2 * u + h) * p.CO + l31) * 4) : ODIN_OOB_V;
+  // staging chunks of this lane: chunk e = lane + 64 i of the 4 NCH chunks of rows ih0 .. ih0 + 3
+  int cdst[NI];
+  unsigned csrc[NI];
+  bool cj0[NI], cj3[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int e = lane + 64 * i, j = e / NCH, ci = e - j * NCH;
+    const bool in = e < 4 * NCH;
+    cdst[i] = in ? (wave * WS + j * RS + 4 + 4 * ci) * 4 : -1;
+    csrc[i] = in ? (unsigned)(e * 16) : ODIN_OOB;
+    cj0[i] = j == 0;
+    cj3[i] = j == 3;
+  }
+  f32x16 acc[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x16_zero();
+  const int r0 = blockIdx.x * (p.pix_per_block / OW);
+  int r1 = r0 + p.pix_per_block / OW;
+  if (r1 > p.B * p.OH) r1 = p.B * p.OH;
+  float4 nx[NI];
+  auto fetch = [&](int r) {  // rows 2 oh - 1 .. 2 oh + 2 of image bb: contiguous in memory
+    const int bb = r / p.OH, oh = r - bb * p.OH;
+    const unsigned base = (unsigned)(((bb * p.H + 2 * oh - 1) * W * CI) * 4);
+    const bool top = oh == 0, bot = oh == p.OH - 1, live = r < r1;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const bool ok = live && !(cj0[i] && top) && !(cj3[i] && bot);
+      nx[i] = odin_run_load4(XR, ok ? base + csrc[i] : ODIN_OOB);
+      if (p.center && ok) {
+        nx[i].x = 2.f * nx[i].x - 1.f; nx[i].y = 2.f * nx[i].y - 1.f;
+        nx[i].z = 2.f * nx[i].z - 1.f; nx[i].w = 2.f * nx[i].w - 1.f;
+      }
+    }
+  };
+  fetch(r0 + wave);
+  for (int r = r0 + wave; r < r1; r += NW) {  // wave-uniform
+    odin_wave_sync();  // (the wave's reads of the previous row are issued; LDS runs a wave's accesses in order)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (cdst[i] >= 0) *reinterpret_cast<float4*>(reinterpret_cast<char*>(smem) + cdst[i]) = nx[i];
+    odin_wave_sync();
+    fetch(r + NW);
+    const unsigned dyrow = (unsigned)(r * OW * p.CO * 4);
+#pragma unroll 1
+    for (int q0 = 0; q0 < OW; q0 += 2 * U) {
+      float a[U][RB], b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+          a[u][rb] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + abase[rb] +
+                                                     (q0 + 2 * u) * 2 * CI * 4);
+        b[u] = odin_run_load1s(DR, boff[u], dyrow + (unsigned)(q0 * p.CO * 4));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma32(a[u][rb], b[u], acc[rb]);
+    }
+  }
+  // combine the NW waves in a fixed order, then write the slab row [K*CO | CO]
+  __syncthreads();  // (the partial tiles overlay the staging areas)
+  float* mine = smem + wave * (RB * 16 * 64);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[(rb * 16 + r) * 64 + lane] = acc[rb][r];
+  __syncthreads();
+  float* row = p.y + (size_t)blockIdx.x * p.slab_stride;
+  for (int e = tid; e < RB * 16 * 64; e += NW * 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NW; wv += 4)
+      t += (smem[e + wv * RB * 1024] + smem[e + (wv + 1) * RB * 1024]) +
+           (smem[e + (wv + 2) * RB * 1024] + smem[e + (wv + 3) * RB * 1024]);
+    const int ln = e & 63, r = (e >> 6) & 15, rb = e >> 10;
+    const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+    const int co = ln & 31;
+    if (co < p.CO && k <= K) row[(size_t)k * p.CO + co] = t;  // k == K: the bias row
+  }
+}
+
 int odin_smallc_wgrad(const float* x, const float* dy, float* slab, int* rows_out,
                       const odin_conv_desc* d, void* stream) {
   SCParams p;
@@ -613,6 +737,27 @@ int odin_smallc_wgrad(const float* x, const float* dy, float* slab, int* rows_ou
     const int RB = (K + 1 + 31) / 32, CB = (d->Cout + 31) / 32;
     const int NW = (RB * CB == 4) ? 8 : 16;   // NW x RB x CB x 4 KB of LDS for the partial tiles
     const size_t l2 = (size_t)NW * RB * CB * 1024 * 4;
+    // rows staged in LDS: the first layers of the image stacks
+    if ((d->Cin == 1 || d->Cin == 3) && d->W == 64 && d->OW == 32 && d->H == 2 * d->OH && d->KH == 4 && d->KW == 4 &&
+        d->stride == 2 && d->pad_t == 1 && d->pad_l == 1 && d->Cout <= 32 && !getenv("ODIN_SMALLC_NOLDS") &&
+        (size_t)d->B * d->OH * d->OW * d->Cout * 4 < (1ull << 31)) {
+      const size_t stage = (size_t)16 * 6 * (64 * d->Cin + 8) * 4;
+      const size_t l3 = stage > (size_t)16 * RB * 4096 ? stage : (size_t)16 * RB * 4096;
+#ifndef ODIN_SIM
+      static bool attr3 = false;
+      if (!attr3) {
+        const void* fns[2] = {reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<1, 1>),
+                              reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<2, 3>)};
+        for (const void* f : fns)
+          if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        attr3 = true;
+      }
+#endif
+      if (d->Cin == 1) ODIN_LAUNCH((smallc_wgrad_lds_kernel<1, 1>), dim3(rows), dim3(1024), l3, stream, p);
+      else ODIN_LAUNCH((smallc_wgrad_lds_kernel<2, 3>), dim3(rows), dim3(1024), l3, stream, p);
+      return odin_check_launch("smallc_wgrad_lds");
+    }
 #ifndef ODIN_SIM
     static bool attr2 = false;
     if (!attr2) {

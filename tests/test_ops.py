@@ -35,6 +35,8 @@ CONV_CASES = [
     (2, 16, 16, 3, 32, 4, 2, 'elu', True),     # small-Cin VALU kernels, 48 taps
     (1, 64, 64, 1, 32, 4, 2, 'elu', True),     # first-layer matrix-core kernels (32-pixel row blocks)
     (1, 64, 64, 3, 64, 4, 2, 'elu', True),     # first-layer matrix-core kernels, 48 taps, 64 channels
+    (2, 64, 64, 3, 32, 4, 2, 'elu', True),     # RGB first layer: rows staged in LDS (forward and weight gradient), image seam
+    (2, 64, 64, 1, 32, 4, 2, 'elu', False),    # the same with one channel, no centring
     (3, 12, 12, 1, 64, 5, 1, 'elu', False),    # small-Cin VALU kernels, 25 taps, 64 lanes per pixel
     (3, 8, 8, 32, 32, 4, 2, 'elu', False),
     (2, 8, 8, 32, 64, 4, 2, 'elu', False),

@@ -17,6 +17,10 @@ timeout 200 python tools/stamps_ig.py > gpurun_out/r03_final_stamps_igemm.txt 2>
 python tools/igbench.py > gpurun_out/r03_final_igbench.txt 2>&1
 ODIN_NOIGEMM=1 python tools/igbench.py > gpurun_out/r03_final_igbench_tiled.txt 2>&1
 python tools/enc0bench.py > gpurun_out/r03_final_enc0bench.txt 2>&1
+timeout 200 python tools/stamps_fp.py > gpurun_out/r03_final_stamps_fconv_planes.txt 2>&1
+timeout 300 python tools/kclock.py > gpurun_out/r03_final_inkernel_clock.txt 2>&1
+python tools/kbench.py > gpurun_out/r03_final_kbench.txt 2>&1
+python tools/slabstat.py > gpurun_out/r03_final_slabstat.txt 2>&1
 for w in shapes3d_vae_b256 celeba_betatcvae_b512 mnist_dense_b128 factorvae_shapes3d_b256 speech_vae_b256; do
   timeout 600 python bench.py --workload $w --profile-ops --no-cpu-baseline --no-north-star-3ch > gpurun_out/r03_final_$w.json 2> gpurun_out/r03_final_$w.err
 done
