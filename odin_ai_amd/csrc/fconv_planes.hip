@@ -206,7 +206,9 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 
   FpItem iuA[FP_MAXU], iuB[FP_MAXU], iuC[FP_MAXU];
   FpEnt en[FP_MAXU];
+  FP_STAMP(6);
   __syncthreads();  // the tables
+  FP_STAMP(7);
   fill_entries(en, 0);
   fill_loads(iuA, en);  // (in flight while the weight fragments are fetched and split)
   u32x4 wf[2][2][3];
@@ -227,8 +229,10 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
       wf[t][kk][2][0] = l0.x; wf[t][kk][2][1] = l0.y; wf[t][kk][2][2] = l1.x; wf[t][kk][2][3] = l1.y;
     }
 
+  FP_STAMP(8);
 #pragma unroll
   for (int j = 0; j < FP_MAXU; ++j) store_item(iuA[j]);
+  FP_STAMP(9);
   fill_entries(en, 1);
   fill_loads(iuA, en);
   fill_entries(en, 2);
