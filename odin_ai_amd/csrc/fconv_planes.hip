@@ -101,6 +101,49 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   (void)stamp_i;
   FP_STAMP(1);
 
+  // ---- the loads of the prologue go out FIRST: this wave's weight fragments (taps (kh, kw0), (kh, kw0 + 1); lane =
+  // output channel l31, k = 8 half + e) and its items of fill 0 (all rows of tile T0, offsets computed directly) are in
+  // flight while the zero fills and the table arithmetic below run -- a cold L2 answers in ~1 us, and the layers with
+  // 8- and 16-pixel rows run only 1-4 tiles per workgroup ----
+  const int kh = wave >> 1, kw0 = 2 * (wave & 1);
+  float wv[2][2][8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int tap = kh * 4 + kw0 + t;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        wv[t][kk][e] = p.w[((size_t)(tap * p.CS + p.ci_off + 16 * kk + 8 * half + e)) * p.CO + n0 + l31];
+    }
+  const OdinRun RU = odin_run(p.in, (unsigned)((size_t)p.B * HU * WU * p.CS * 4));
+  constexpr int RPF = FP_MAXU * RJ;      // rows a fill can carry (row r = r0w + RJ j of item j)
+  constexpr int DST_NONE = -(1 << 24);   // ring offset of an item without a row: dst stays negative
+  constexpr unsigned OFF_NONE = 0x7FFF0000u;  // global offset of a row that is not read (padding row, no image): out of range
+  const unsigned u_rowbytes = (unsigned)(WU * p.CS * 4);
+  const int ch4 = lane & 7, pxl = lane >> 3;
+  const int r0w = wave / IPU, cblk = wave - r0w * IPU;
+  const int pcw = 8 * cblk + pxl + 1;  // padded column of this lane's pixel: parity pcw & 1, slot pcw >> 1
+  const int u_lds = (pcw & 1) * PARB + (pcw >> 1) * 64 + (((ch4 >> 1) ^ (((pcw >> 1) >> 2) & 3)) << 4) + (ch4 & 1) * 8;
+  const unsigned u_g = (unsigned)(((8 * cblk + pxl) * p.CS + p.ci_off + 4 * ch4) * 4);
+  FpItem iuA[FP_MAXU], iuB[FP_MAXU], iuC[FP_MAXU];
+  {
+    const int tpi = p.tiles_per_img;
+    const int b0 = odin_div_small(T0, tpi), t0 = T0 - b0 * tpi;
+    const int start = HPU * b0 + 2 * TC * t0;
+#pragma unroll
+    for (int j = 0; j < FP_MAXU; ++j) {
+      const int r = r0w + RJ * j, G = start + r;
+      const bool valid = r < 2 * TC + 2;
+      const int b = b0 + (2 * TC * t0 + r >= HPU ? 1 : 0), gi = G - b * HPU;
+      const bool real = valid && gi != 0 && b < p.B;  // gi == 0: the zero row between images
+      const int slot = G - odin_div_small(G, NSU) * NSU;
+      iuA[j].dst = valid ? slot * RBU + u_lds : -1;
+      iuA[j].v = odin_run_load4(RU, real ? (unsigned)(G - b - 1) * u_rowbytes + u_g : ODIN_OOB);
+    }
+  }
+  ODIN_SCHED_FENCE();
+
   // ---- SAME-padding slots (parity plane 0 slot 0, parity plane 1 slot OW) of every ring row and plane ----
   for (int e = tid; e < NSU * 24; e += 512) {
     const int sl = e / 24, rem = e - sl * 24;
@@ -112,50 +155,39 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   for (int e = tid; e < RED / 16; e += 512)
     *reinterpret_cast<float4*>(red + ((T0 - 1) & 1) * RED + e * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // ---- this wave's weight fragments: taps (kh, kw0), (kh, kw0 + 1); lane = output channel l31, k = 8 half + e ----
-  const int kh = wave >> 1, kw0 = 2 * (wave & 1);
   // ---- row fills (as wgrad_planes.hip; the k-pieces of a pixel slot are swizzled by the slot) ----
   // Which rows a fill moves, where they land in the ring and where each tile starts is pure index arithmetic with
   // image seams and ring wrap-arounds: ~170 dependent scalar instructions per tile when done between the MFMAs,
   // 14 of the kernel's 71 us (profiles/r03_fconv_planes_bookkeeping.txt).  It is done ONCE here, by all threads in
   // parallel, into two small LDS tables; the tile loop reads its entries (wave-uniform addresses) and adds lane
   // offsets.  Fill f >= 1 brings the rows tile T0 + f needs beyond those of tile T0 + f - 1; fill 0 all of tile T0's.
-  const OdinRun RU = odin_run(p.in, (unsigned)((size_t)p.B * HU * WU * p.CS * 4));
-  constexpr int RPF = FP_MAXU * RJ;      // rows a fill can carry (row r = r0w + RJ j of item j)
-  constexpr int DST_NONE = -(1 << 24);   // ring offset of an item without a row: dst stays negative
-  constexpr unsigned OFF_NONE = 0x7FFF0000u;  // global offset of a row that is not read (padding row, no image): out of range
   const int NF = p.tiles_per_wg + 4;
   FpEnt* tt = reinterpret_cast<FpEnt*>(red + 2 * RED);  // [NF] tile: (first ring slot, byte offset of its first output)
   FpEnt* tr = tt + NF;                                 // [NF][RPF] fill row: (ring byte offset, global byte offset)
-  const unsigned u_rowbytes = (unsigned)(WU * p.CS * 4);
   {
     const int tpi = p.tiles_per_img;
     for (int e = tid; e < NF; e += 512) {
-      const int T = T0 + e, b = T / tpi, t = T - b * tpi;
-      tt[e] = FpEnt{(HPU * b + 2 * TC * t) % NSU, (int)(((size_t)(b * p.OH + TC * t) * OW) * p.CO * 4)};
+      const int T = T0 + e, b = odin_div_small(T, tpi), t = T - b * tpi;
+      const int g0 = HPU * b + 2 * TC * t;
+      tt[e] = FpEnt{g0 - odin_div_small(g0, NSU) * NSU, (int)(((size_t)(b * p.OH + TC * t) * OW) * p.CO * 4)};
     }
     for (int e = tid; e < NF * RPF; e += 512) {
       const int f = e / RPF, r = e - f * RPF;
-      const int T = T0 + f, b1 = T / tpi, t1 = T - b1 * tpi;
+      const int T = T0 + f, b1 = odin_div_small(T, tpi), t1 = T - b1 * tpi;
       const int end = HPU * b1 + 2 * TC * t1 + 2 * TC + 2;
       int start = end - (2 * TC + 2);
-      if (f > 0) {
-        const int b0 = (T - 1) / tpi, t0 = (T - 1) - b0 * tpi;
+      if (f > 0) {  // (tile T - 1 lies in image b1 or in the one before it)
+        const int b0 = t1 > 0 ? b1 : b1 - 1, t0 = t1 > 0 ? t1 - 1 : tpi - 1;
         start = HPU * b0 + 2 * TC * t0 + 2 * TC + 2;
       }
       const int G = start + r;
       const bool valid = T < T1 && G < end;
-      const int b = G / HPU, gi = G - b * HPU;
+      const int b = odin_div_small(G, HPU), gi = G - b * HPU;
       const bool real = valid && gi != 0 && b < p.B;  // gi == 0: the zero row between images
-      tr[e] = FpEnt{valid ? (G % NSU) * RBU : DST_NONE,
+      tr[e] = FpEnt{valid ? (G - odin_div_small(G, NSU) * NSU) * RBU : DST_NONE,
                         real ? (int)((unsigned)(G - b - 1) * u_rowbytes) : (int)OFF_NONE};
     }
   }
-  const int ch4 = lane & 7, pxl = lane >> 3;
-  const int r0w = wave / IPU, cblk = wave - r0w * IPU;
-  const int pcw = 8 * cblk + pxl + 1;  // padded column of this lane's pixel: parity pcw & 1, slot pcw >> 1
-  const int u_lds = (pcw & 1) * PARB + (pcw >> 1) * 64 + (((ch4 >> 1) ^ (((pcw >> 1) >> 2) & 3)) << 4) + (ch4 & 1) * 8;
-  const unsigned u_g = (unsigned)(((8 * cblk + pxl) * p.CS + p.ci_off + 4 * ch4) * 4);
   // the table entries of fill f for this wave's items, then the loads themselves
   auto fill_entries = [&](FpEnt (&en)[FP_MAXU], int f) {
 #pragma unroll
@@ -204,23 +236,16 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   if (EPI == 1) { bias2[0] = p.bias[c0]; bias2[1] = p.bias[c0 + 1]; }
   float csum[2] = {0.f, 0.f};
 
-  FpItem iuA[FP_MAXU], iuB[FP_MAXU], iuC[FP_MAXU];
   FpEnt en[FP_MAXU];
   FP_STAMP(6);
   __syncthreads();  // the tables
   FP_STAMP(7);
-  fill_entries(en, 0);
-  fill_loads(iuA, en);  // (in flight while the weight fragments are fetched and split)
   u32x4 wf[2][2][3];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const int tap = kh * 4 + kw0 + t;
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        v[e] = p.w[((size_t)(tap * p.CS + p.ci_off + 16 * kk + 8 * half + e)) * p.CO + n0 + l31];
+      const float(&v)[8] = wv[t][kk];
       u32x2 h0, m0, l0, h1, m1, l1;
       fp_split4(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
       fp_split4(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);

@@ -308,6 +308,20 @@ __device__ __forceinline__ float odin_act_grad(int act, float y) {
   return 1.f;
 }
 
+// a / b for 0 <= a < 2^22, 1 <= b < 2^22 through the float reciprocal and one correction step: ~8 instructions
+// against the ~40 of the integer division sequence (kernel prologues that build index tables)
+__device__ __forceinline__ int odin_div_small(int a, int b) {
+#ifdef ODIN_SIM
+  return a / b;
+#else
+  int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+  const int r = a - q * b;
+  q += r >= b ? 1 : 0;
+  q -= r < 0 ? 1 : 0;
+  return q;
+#endif
+}
+
 // rendezvous of the lanes of ONE wave around wave-private LDS traffic.  On the hardware the DS
 // pipe executes a wave's LDS instructions in order, so only the compiler has to be kept from
 // moving accesses across; the simulator runs lanes as fibers and needs a real rendezvous.
