@@ -197,16 +197,16 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     const int tpi = p.tiles_per_img;
     for (int e = tid; e < NF * RPF; e += 512) {
       const int f = e / RPF, r = e - f * RPF;
-      const int T = T0 + f, b1 = T / tpi, t1 = T - b1 * tpi;
+      const int T = T0 + f, b1 = odin_div_small(T, tpi), t1 = T - b1 * tpi;
       const int end = HP * b1 + RP * t1 + RP + 2;
       int start = end - (RP + 2);
       if (f > 0) {
-        const int b0 = (T - 1) / tpi, t0 = (T - 1) - b0 * tpi;
+        const int b0 = t1 > 0 ? b1 : b1 - 1, t0 = t1 > 0 ? t1 - 1 : tpi - 1;  // tile T - 1: this image or the one before
         start = HP * b0 + RP * t0 + RP + 2;
       }
       const int G = start + r;  // global padded row HP * b + gi; gi == 0: the zero row between images
       const bool valid = T < T1 && G < end;
-      const int b = G / HP, gi = G - b * HP;
+      const int b = odin_div_small(G, HP), gi = G - b * HP;
       const bool real = valid && gi != 0 && b < p.B;
       tr[e] = TpEnt{valid ? (G % NSLOT) * RB : -1, real ? (int)((unsigned)(G - b - 1) * f_rowbytes) : (int)0xFFFF0000u};
     }

@@ -164,21 +164,21 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   {
     const int tpi = p.tiles_per_img;
     for (int e = tid; e < NF; e += 512) {
-      const int T = T0 + e, b = T / tpi, t = T - b * tpi;
+      const int T = T0 + e, b = odin_div_small(T, tpi), t = T - b * tpi;
       tt[e] = WpEnt{(HPU * b + 2 * TC * t) % NSU, (TC * T) % NSV};
     }
     for (int e = tid; e < NF * RPF; e += 512) {
       const int f = e / RPF, r = e - f * RPF;
-      const int T = T0 + f, b1 = T / tpi, t1 = T - b1 * tpi;
+      const int T = T0 + f, b1 = odin_div_small(T, tpi), t1 = T - b1 * tpi;
       const int end = HPU * b1 + 2 * TC * t1 + 2 * TC + 2;
       int start = end - (2 * TC + 2);
       if (f > 0) {
-        const int b0 = (T - 1) / tpi, t0 = (T - 1) - b0 * tpi;
+        const int b0 = t1 > 0 ? b1 : b1 - 1, t0 = t1 > 0 ? t1 - 1 : tpi - 1;  // tile T - 1: this image or the one before
         start = HPU * b0 + 2 * TC * t0 + 2 * TC + 2;
       }
       const int G = start + r;  // global padded fine row HPU * b + gi; gi == 0: the zero row between images
       const bool valid = T < T1 && G < end;
-      const int b = G / HPU, gi = G - b * HPU;
+      const int b = odin_div_small(G, HPU), gi = G - b * HPU;
       const bool real = valid && gi != 0 && b < p.B;
       tr[e] = WpEnt{valid ? (G % NSU) * RBU : DST_NONE, real ? (int)((unsigned)(G - b - 1) * u_rowbytes) : (int)OFF_NONE};
     }
