@@ -397,3 +397,35 @@ def test_speech_vae_config5_pipeline(dev, L):
   vae.fit(xb, max_iter=20, batch_size=32, learning_rate=1e-3, global_clipnorm=100.0)
   l1, _ = vae.optimize(xb, training=False)
   assert float(l1) < float(l0)
+
+
+def test_conv_forward_beyond_the_fill_table_bound(dev, L):
+  """A batch whose tiles per workgroup exceed the LDS fill tables of fconv_planes (168 tiles at 32-pixel output rows:
+  more than 1344 images of 64x64x32 on 256 CUs) runs on more workgroups than CUs: the result must be the one of the
+  two half batches, bit for bit (a tile's arithmetic does not depend on the workgroup that owns it)."""
+  from odin_ai_amd import _lib
+  B, H, W, Ci, Co = 1400, 64, 64, 32, 32
+  g = torch.Generator(device='cpu').manual_seed(5)
+  x = torch.randn(B, H, W, Ci, generator=g).to(dev)
+  w = (torch.randn(4, 4, Ci, Co, generator=g) * 0.1).to(dev)
+  b = (torch.randn(Co, generator=g) * 0.1).to(dev)
+
+  def fwd(xs):
+    n = xs.shape[0]
+    d = _lib.conv_desc(n, H, W, Ci, 32, 32, Co, 4, 2, 1, 1, 'elu')
+    y = torch.empty(n, 32, 32, Co, device=dev)
+    L.odin_conv2d_fwd(xs.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), C.byref(d), None)
+    return y, L.odin_debug_last_path().decode()
+
+  y, path = fwd(x)
+  assert path.startswith('fconv_planes'), path
+  y0, _ = fwd(x[:700].contiguous())
+  y1, _ = fwd(x[700:].contiguous())
+  torch.cuda.synchronize()
+  assert torch.equal(y[:700], y0) and torch.equal(y[700:], y1)
+  # and against a float64 reference on a few images across the batch (first, seam of the halves, last)
+  idx = [0, 699, 700, 1399]
+  ref = torch.nn.functional.elu(torch.nn.functional.conv2d(
+      x[idx].double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), b.double(), stride=2, padding=1))
+  err = (y[idx].double() - ref.permute(0, 2, 3, 1)).abs().max().item()
+  assert err < 1e-4 * ref.abs().max().item(), err
