@@ -166,6 +166,41 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   if (T1 > p.n_tiles) T1 = p.n_tiles;
   if (T0 >= T1) return;
 
+  // ---- the loads of the prologue go out FIRST: the 8 weight loads of a thread (fp32 [tap][co][32]) and the wave's
+  // items of fill 0 (all rows of tile T0, offsets computed directly) are in flight while the zero fills and the table
+  // arithmetic run -- the layers with 8- and 16-pixel rows run only 1-4 tiles per workgroup ----
+  float4 wv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int e = tid + 512 * j;
+    const int ci4 = e & 7, co = (e >> 3) & 31, tap = e >> 8;
+    wv[j] = *reinterpret_cast<const float4*>(p.w + ((size_t)(tap * p.CO + n0 + co) * p.CS + p.ci_off + 4 * ci4));
+  }
+  const OdinRun IN = odin_run(p.in, (unsigned)((size_t)p.B * p.H * W * p.CS * 4));
+  const int f_c = wave & (CPR - 1), f_r0 = wave >> CSHIFT;
+  constexpr int F_RJ = 8 >> CSHIFT;  // rows between a wave's two items
+  const int f_px = 8 * f_c + (lane >> 3), f_ch4 = lane & 7, f_pc = f_px + 1;
+  const int f_lds_lane = f_pc * 64 + ((((f_ch4 >> 1) ^ ((f_pc >> 2) & 3))) << 4) + (f_ch4 & 1) * 8;
+  const unsigned f_g_lane = (unsigned)((f_px * p.CS + p.ci_off + 4 * f_ch4) * 4);
+  const unsigned f_rowbytes = (unsigned)(W * p.CS * 4);
+  TpItem itA[2], itB[2];
+  {
+    const int tpi = p.tiles_per_img;
+    const int b0 = odin_div_small(T0, tpi), t0 = T0 - b0 * tpi;
+    const int start = HP * b0 + RP * t0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = f_r0 + F_RJ * j, G = start + r;
+      const bool valid = r < RP + 2;
+      const int b = b0 + (RP * t0 + r >= HP ? 1 : 0), gi = G - b * HP;
+      const bool real = valid && gi != 0 && b < p.B;  // gi == 0: the zero row between images
+      itA[j].dst = (G % NSLOT) * RB + f_lds_lane;
+      itA[j].ok = valid;
+      itA[j].v = odin_run_load4(IN, (real ? (unsigned)(G - b - 1) * f_rowbytes : 0xFFFF0000u) + f_g_lane);
+    }
+  }
+  ODIN_SCHED_FENCE();
+
   // ---- SAME-padding pixels (pc = 0 and pc = W + 1) of every ring row and plane: zero for ever ----
   for (int e = tid; e < NSLOT * 24; e += 512) {
     const int sl = e / 24, rem = e - sl * 24;
@@ -175,16 +210,6 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   }
 
   // ---- row fills: wave-uniform walk over the padded rows; a wave moves up to two 1 KB items ----
-  const OdinRun IN = odin_run(p.in, (unsigned)((size_t)p.B * p.H * W * p.CS * 4));
-  // loads the rows tile `need` still misses into registers; advances the walk.  The row part of an
-  // item is wave-uniform (scalar, 32-bit: the applicability test bounds the tensor to 2 GB), the lane part
-  // is computed once.
-  const int f_c = wave & (CPR - 1), f_r0 = wave >> CSHIFT;
-  constexpr int F_RJ = 8 >> CSHIFT;  // rows between a wave's two items
-  const int f_px = 8 * f_c + (lane >> 3), f_ch4 = lane & 7, f_pc = f_px + 1;
-  const int f_lds_lane = f_pc * 64 + ((((f_ch4 >> 1) ^ ((f_pc >> 2) & 3))) << 4) + (f_ch4 & 1) * 8;
-  const unsigned f_g_lane = (unsigned)((f_px * p.CS + p.ci_off + 4 * f_ch4) * 4);
-  const unsigned f_rowbytes = (unsigned)(W * p.CS * 4);
   // Which rows a fill moves and where they land (image seams, ring wrap-arounds) is index arithmetic: ~150 dependent
   // scalar instructions per tile when done inside the MFMA stream, where both waves of a SIMD executed them at the
   // same time and the matrix pipe idled behind them (fconv_planes.hip: 14 of 71 us).  It is done once here, by all
@@ -318,21 +343,9 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   const OdinRun TG = odin_run(EPI == 3 ? p.target : nullptr, tgt_bytes);
   const OdinRun LG = odin_run(EPI == 3 ? p.logits : nullptr, (EPI == 3 && p.logits != nullptr) ? tgt_bytes : 0u);
 
-  // ---- prologue: rows of the first tile, then the second tile's into registers ----
-  TpItem itA[2], itB[2];
-  TpEnt en[2];
-  __syncthreads();  // the table
-  fill_entries(en, 0);
-  fill_loads(itA, en);  // (in flight while the weights are split)
-  // ---- weights: fp32 [tap][co][32] -> planes [tap][plane][k-piece][co][8 bf16] ----
+  // ---- prologue, second half: the weights -> planes [tap][plane][k-piece][co][8 bf16], the first tile's rows ->
+  // ring (both loaded at the top of the kernel), then ONE barrier publishes them together with the pads and the table
   {
-    float4 wv[8];  // all 8 loads of a thread in flight before the first split
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int e = tid + 512 * j;
-      const int ci4 = e & 7, co = (e >> 3) & 31, tap = e >> 8;
-      wv[j] = *reinterpret_cast<const float4*>(p.w + ((size_t)(tap * p.CO + n0 + co) * p.CS + p.ci_off + 4 * ci4));
-    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int e = tid + 512 * j;
@@ -346,11 +359,12 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     }
   }
   store_fill(itA);
+  TP_STAMP(2);
+  __syncthreads();  // weights, pads, the table and the first tile's rows are in LDS
+  TP_STAMP(10);
+  TpEnt en[2];
   fill_entries(en, 1);
   fill_loads(itA, en);
-  TP_STAMP(2);
-  __syncthreads();  // weights, pads and the first tile's rows are in LDS
-  TP_STAMP(10);
 
   int b_cur = T0 / p.tiles_per_img, t_cur = T0 - b_cur * p.tiles_per_img;
   int sl0 = (HP * b_cur + RP * t_cur) % NSLOT;  // ring slot of the tile's first padded row
