@@ -116,15 +116,6 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   if (T1 > p.n_tiles) T1 = p.n_tiles;
   if (T0 >= T1) return;
 
-  // ---- SAME-padding slots of every fine ring row and plane: parity plane 0 slot 0 (padded column 0)
-  // and parity plane 1 slot W (padded column 2 w + 1): zero for ever ----
-  for (int e = tid; e < NSU * 24; e += 512) {
-    const int sl = e / 24, rem = e - sl * 24;
-    const int pl = rem >> 3, side = (rem >> 2) & 1, piece = rem & 3;
-    *reinterpret_cast<float4*>(uring + sl * RBU + pl * PBU + (side ? PARB + W * 64 : 0) + piece * 16) =
-        make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-
   // ---- row fills (wave-uniform walks; a wave moves up to WP_MAXU fine-row items and one coarse-row item) ----
   const OdinRun RU = odin_run(p.U, (unsigned)((size_t)p.B * HU * WU * p.CUt * 4));
   const OdinRun RV = odin_run(p.V, (unsigned)((size_t)p.B * p.h * W * p.CVt * 4));
@@ -149,6 +140,37 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   const unsigned v_colb = (unsigned)(8 * vc * p.CVt * 4) + v_g_lane;
   const int v_lds_item = NSU * RBU + 8 * vc * 64 + v_lds_lane;
   const int n_vrows = p.B * p.h;
+  // ---- the loads of fill 0 (all rows of tile T0, offsets computed directly) go out FIRST: they are in flight while
+  // the zero fills and the table arithmetic run (the layers with 8- and 16-pixel rows run few tiles per workgroup) ----
+  WpItem iuA[WP_MAXU], iuB[WP_MAXU], iuC[WP_MAXU], ivA, ivB, ivC;
+  {
+    const int tpi = p.tiles_per_img;
+    const int b0 = odin_div_small(T0, tpi), t0 = T0 - b0 * tpi;
+    const int start = HPU * b0 + 2 * TC * t0;
+#pragma unroll
+    for (int j = 0; j < WP_MAXU; ++j) {
+      const int r = r0 + RJ * j, G = start + r;
+      const bool valid = r < 2 * TC + 2;
+      const int b = b0 + (2 * TC * t0 + r >= HPU ? 1 : 0), gi = G - b * HPU;
+      const bool real = valid && gi != 0 && b < p.B;  // gi == 0: the zero row between images
+      iuA[j].dst = valid ? (G % NSU) * RBU + u_lds_item : -1;
+      iuA[j].v = odin_run_load4(RU, real ? (unsigned)(G - b - 1) * u_rowbytes + u_colb : ODIN_OOB);
+    }
+    const int grow = TC * T0 + vr;
+    ivA.dst = wave < 4 ? (grow & (NSV - 1)) * RBV + v_lds_item : -1;
+    ivA.v = odin_run_load4(RV, (wave < 4 && grow < n_vrows) ? (unsigned)grow * v_rowbytes + v_colb : ODIN_OOB);
+  }
+  ODIN_SCHED_FENCE();
+
+  // ---- SAME-padding slots of every fine ring row and plane: parity plane 0 slot 0 (padded column 0)
+  // and parity plane 1 slot W (padded column 2 w + 1): zero for ever ----
+  for (int e = tid; e < NSU * 24; e += 512) {
+    const int sl = e / 24, rem = e - sl * 24;
+    const int pl = rem >> 3, side = (rem >> 2) & 1, piece = rem & 3;
+    *reinterpret_cast<float4*>(uring + sl * RBU + pl * PBU + (side ? PARB + W * 64 : 0) + piece * 16) =
+        make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
   // Which rows a fill moves and where they land (image seams, ring wrap-arounds) is index arithmetic that cost
   // ~170 dependent scalar instructions per tile inside the MFMA stream (fconv_planes.hip: 14 of 71 us).  It is done
   // once here, by all threads, into LDS tables; the tile loop reads its entries (wave-uniform addresses) and adds
@@ -253,21 +275,17 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   }
 
   f32x16 acc[2] = {f32x16_zero(), f32x16_zero()};
-  WpItem iuA[WP_MAXU], iuB[WP_MAXU], iuC[WP_MAXU], ivA, ivB, ivC;
-
-  // ---- prologue: rows of the first tile, then the second tile's into registers ----
+  // ---- prologue: rows of the first tile into LDS; ONE barrier publishes them with the pads and the tables; then
+  // the second and third tile's rows into registers ----
   FillEnt en;
-  __syncthreads();  // the tables
-  fill_entries(en, 0);
-  fill_loads(iuA, ivA, en);
   store_fill(iuA, ivA);
+  __syncthreads();
   fill_entries(en, 1);
   fill_loads(iuA, ivA, en);
   fill_entries(en, 2);
   fill_loads(iuB, ivB, en);
   fill_entries(en, 3);
   WpEnt thN = tt[0];  // ring slots of the next tile's first fine / coarse row
-  __syncthreads();
   int su0 = 0, sv0 = 0;
 
   // fragments of one 16-pixel chunk: V (3 planes) and U for the wave's two taps
