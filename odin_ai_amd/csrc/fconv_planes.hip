@@ -238,8 +238,6 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 
   FpEnt en[FP_MAXU];
   FP_STAMP(6);
-  __syncthreads();  // the tables
-  FP_STAMP(7);
   u32x4 wf[2][2][3];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -258,14 +256,16 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 #pragma unroll
   for (int j = 0; j < FP_MAXU; ++j) store_item(iuA[j]);
   FP_STAMP(9);
-  fill_entries(en, 1);
-  fill_loads(iuA, en);
-  fill_entries(en, 2);
-  fill_loads(iuB, en);
+  __syncthreads();  // ONE barrier: pads, tables and the first tile's rows are in LDS
+  FP_STAMP(7);
+  FpEnt en1[FP_MAXU], en2[FP_MAXU];
+  fill_entries(en1, 1);  // (all table reads of the prologue in one batch: one LDS round trip, not four)
+  fill_entries(en2, 2);
   fill_entries(en, 3);
   FpEnt thN = tt[0];  // (su0, output offset) of the next tile
+  fill_loads(iuA, en1);
+  fill_loads(iuB, en2);
   const unsigned o_lane = (unsigned)(((orow * OW + ocol) * p.CO + c0) * 4);
-  __syncthreads();
 
   // (the first tile's epilogue pass has no predecessor: it sums a zeroed scratch buffer and its store is out of range)
   const unsigned out_bytes = (unsigned)((size_t)p.B * p.OH * OW * p.CO * 4);

@@ -280,12 +280,13 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   FillEnt en;
   store_fill(iuA, ivA);
   __syncthreads();
-  fill_entries(en, 1);
-  fill_loads(iuA, ivA, en);
-  fill_entries(en, 2);
-  fill_loads(iuB, ivB, en);
+  FillEnt en1, en2;
+  fill_entries(en1, 1);  // (all table reads of the prologue in one batch: one LDS round trip, not four)
+  fill_entries(en2, 2);
   fill_entries(en, 3);
   WpEnt thN = tt[0];  // ring slots of the next tile's first fine / coarse row
+  fill_loads(iuA, ivA, en1);
+  fill_loads(iuB, ivB, en2);
   int su0 = 0, sv0 = 0;
 
   // fragments of one 16-pixel chunk: V (3 planes) and U for the wave's two taps

@@ -8,7 +8,7 @@ from odin_ai_amd import _lib
 L = _lib.load(os.environ.get('ODIN_DIAG_LIB') or 'tools/diag/libodin_hip_diag.so')
 dev = torch.device('cuda:0')
 names = {1: 'kernel start', 2: 'tile start', 3: 'mfma 0 issued', 4: 'mfma 23 issued', 5: 'partials written',
-         6: 'zero fills + tables done', 7: 'behind the table barrier', 8: 'weights split', 9: 'first rows stored'}
+         6: 'zero fills + tables done', 7: 'behind the prologue barrier', 8: 'weights split', 9: 'first rows stored'}
 B, H, W = 256, 32, 32
 d = _lib.conv_desc(B, H, W, 32, 2 * H, 2 * W, 32, 4, 2, 1, 1, 'elu')
 w = torch.randn(4, 4, 32, 32, device=dev) * 0.1
