@@ -28,6 +28,9 @@ def same_pads(n, k, s):
 CASES = [  # kind, B, H, W, Ci, Co, K, S
     ('conv', 256, 8, 8, 64, 64, 4, 2), ('deconv', 256, 4, 4, 8, 64, 4, 2), ('deconv', 256, 4, 4, 16, 64, 4, 2),
     ('conv', 256, 12, 10, 64, 64, 4, 2), ('deconv', 256, 6, 5, 8, 64, 4, 2)]
+if os.environ.get('IG_MID'):  # the 8- and 16-pixel layers of the image stacks (plane kernels by default)
+  CASES = [('conv', 256, 16, 16, 32, 64, 4, 2), ('deconv', 256, 8, 8, 64, 64, 4, 2), ('deconv', 256, 16, 16, 64, 32, 4, 2),
+           ('conv', 256, 32, 32, 32, 32, 4, 2)]
 for kind, B, H, W, Ci, Co, K, S in CASES:
   if kind == 'conv':
     OH, pt = same_pads(H, K, S); OW, pl = same_pads(W, K, S)
