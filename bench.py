@@ -429,7 +429,7 @@ def main():
                   help='launcher / rendezvous self-test on CPU (gloo): no kernels, no GPU')
   ap.add_argument('--dp-buckets', type=int, default=0,
                   help='gradient buckets of the data-parallel step (2: the decoder bucket is all-reduced on a '
-                  'side stream beside the encoder backward; default 1 below 4 ranks, 2 from 4 ranks up)')
+                  'side stream beside the encoder backward; default: 2 from 4 ranks up when the bucket is >= 8 MB, else 1)')
   ap.add_argument('--force-dist', action='store_true',
                   help='initialise the RCCL process group even at world size 1, so that the '
                   'data-parallel step (graph A, RCCL all-reduce, graph B) runs on a 1-GPU box')

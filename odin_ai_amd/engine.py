@@ -446,10 +446,13 @@ class VAEEngine:
     self._jobs_keepalive = None
     # data parallel: collectives through `dist.Comm` (RCCL via the C ABI on a GPU); gradient buckets:
     # 2 = the decoder's share of the flat gradient buffer is all-reduced on a side stream while the
-    # encoder's backward pass runs (ring all-reduce over xGMI is latency-bound at these sizes: worth it
-    # from 4 ranks up; ODIN_DP_BUCKETS overrides)
+    # encoder's backward pass runs.  Splitting the step costs by itself (three graph segments, two slab
+    # reductions, no fused bottleneck backward): +84 us on the dSprites step (1.5 MB bucket), +23 us on the CelebA
+    # step (9.6 MB) at world size 1 (profiles/r03_dp_buckets.txt) -- more than the all-reduce of a small bucket
+    # takes.  Default: two buckets only from 4 ranks up AND from 8 MB of gradients; ODIN_DP_BUCKETS overrides.
     self.comm = None
-    self.dp_buckets = int(_os.environ.get('ODIN_DP_BUCKETS', '0')) or (2 if self.world_size >= 4 else 1)
+    big = self.grads.numel() * 4 >= (8 << 20)
+    self.dp_buckets = int(_os.environ.get('ODIN_DP_BUCKETS', '0')) or (2 if (self.world_size >= 4 and big) else 1)
     self.dec_start = min(o for k, _, o in self.layout.entries if k[0] == 'dec')
 
   def _comm(self):
