@@ -265,13 +265,13 @@ def profile_hbm_kernels(eng, reps=48):
 
 def dominant_rooflines(ops):
   """(roofline of the dominant kernel, priced on the pipe it executes on; conv/dense stack summary)."""
-  is_split = lambda o: o.get('path', '').endswith('(bf16x3)')
+  is_split = lambda o: o.get('path', '').endswith('(f16x2)')
   dom = max(ops, key=lambda o: o['us'])
   if is_split(dom):
-    bf16_gflop = 6.0 * dom.get('mfma_gflop', dom['gflop'])
+    bf16_gflop = 3.0 * dom.get('mfma_gflop', dom['gflop'])
     roof = dict(bound='mfma', kernel=f"{dom['layer']}:{dom['op']}", path=dom.get('path'),
                 achieved=round(bf16_gflop / dom['us'] * 1e3, 3), peak=PEAK_MFMA_BF16_TFLOPS,
-                unit='TFLOP/s (bf16 FLOPs executed)',
+                unit='TFLOP/s (f16 FLOPs executed)',
                 frac=round(bf16_gflop / dom['us'] * 1e3 / PEAK_MFMA_BF16_TFLOPS, 4),
                 fp32_equivalent_frac=round(dom['tflops'] / PEAK_MFMA_F32_TFLOPS, 4),
                 us_per_launch=round(dom['us'], 2))
@@ -599,7 +599,7 @@ def main():
   # FLOPs they execute (6 x the fp32 FLOPs of the convolution) in `roofline_split`;
   # `roofline` is the dominant kernel among those that compute in fp32 MFMAs.
   ops = profile_ops(eng)
-  is_split = lambda o: o.get('path', '').endswith('(bf16x3)')
+  is_split = lambda o: o.get('path', '').endswith('(f16x2)')
   fp32_ops = [o for o in ops if not is_split(o)] or ops
   dom = max(fp32_ops, key=lambda o: o['us'])
   roofline = dict(bound='mfma', kernel=f"{dom['layer']}:{dom['op']}", path=dom.get('path'),
@@ -634,16 +634,16 @@ def main():
   split_ops = [o for o in ops if is_split(o)]
   if split_ops:
     so = max(split_ops, key=lambda o: o['us'])
-    bf16_gflop = 6.0 * so.get('mfma_gflop', so['gflop'])
+    bf16_gflop = 3.0 * so.get('mfma_gflop', so['gflop'])
     roofline_split = dict(bound='mfma', kernel=f"{so['layer']}:{so['op']}", path=so.get('path'),
                           achieved=round(bf16_gflop / so['us'] * 1e3, 3), peak=PEAK_MFMA_BF16_TFLOPS,
-                          unit='TFLOP/s (bf16 FLOPs executed)',
+                          unit='TFLOP/s (f16 FLOPs executed)',
                           frac=round(bf16_gflop / so['us'] * 1e3 / PEAK_MFMA_BF16_TFLOPS, 4),
                           fp32_equivalent_tflops=round(so['tflops'], 3),
                           fp32_equivalent_frac=round(so['tflops'] / PEAK_MFMA_F32_TFLOPS, 4), traffic=None,
                           us_per_launch=round(so['us'], 2), gflop_per_launch=round(bf16_gflop, 4),
-                          note='fp32 operands as 3 exact bf16 planes: 6 v_mfma_f32_32x32x16_bf16 per 16 '
-                               'k-values, priced against the dense bf16 MFMA peak')
+                          note='fp32 operands as 2 f16 planes: 3 v_mfma_f32_32x32x16_f16 per 16 '
+                               'k-values, priced against the dense f16 MFMA peak')
     attach_traffic(roofline_split)
   # `roofline` is THE dominant kernel of the step, priced on the pipe it executes on; when that is a
   # bf16-plane kernel the dominant fp32-MFMA kernel is kept beside it as `roofline_fp32`

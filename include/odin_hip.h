@@ -34,12 +34,22 @@ typedef struct odin_conv_desc {
   int pad_t, pad_l;
   int act;            /* fused epilogue activation (forward only) */
   int center;         /* fold CenterAt0 (2x-1) into the input load (image_networks.py:121-126) */
+  /* Backward pass only, both optional (NULL): the dynamic-range side channel of the 4x4/stride-2 layers whose
+   * fp32 operands travel through the f16 matrix pipe as two planes.  Each range word (a block of
+   * ODIN_RANGE_WORDS uint32: 32 sub-words on separate memory lines, the bound is their maximum) holds the fp32
+   * BIT PATTERN of an upper bound of max|t| of a gradient tensor t; the caller zeroes the words once per step
+   * (odin_range_reset), producers fold their outputs in with one atomicMax per workgroup, consumers scale t by an
+   * exact power of two on its way into the planes.  dy_amax: word of dy (this layer's pre-activation gradient) -- read by the data / weight gradient,
+   * written by the fused tail that produces dy.  dx_amax: word of dx -- written by the data gradient.  A consumer
+   * without a word computes the bound itself (odin_absmax: one extra pass over the tensor). */
+  uint32_t* dy_amax;
+  uint32_t* dx_amax;
 } odin_conv_desc;
 
 /* ---- runtime ------------------------------------------------------------------------ */
 int odin_version(void);
-/* diagnostics: kernel family launched last by the calling thread ("...(bf16x3)": fp32 operands through
- * the bf16 matrix pipe as three exact planes); used by bench.py to price kernels against the right peak */
+/* diagnostics: kernel family launched last by the calling thread ("...(f16x2)": fp32 operands through
+ * the f16 matrix pipe as two planes); used by bench.py to price kernels against the right peak */
 const char* odin_debug_last_path(void);
 /* CRC-32C (Castagnoli) of host bytes, continuing from `crc` (0 to start): the checksum of the
  * TensorFlow checkpoint / event-file formats the reference saves (base_networks.py:373-390,
@@ -47,6 +57,14 @@ const char* odin_debug_last_path(void);
 uint32_t odin_crc32c(uint32_t crc, const void* data, size_t n);
 const char* odin_last_error(void);
 int odin_max_slab_rows(void);      /* upper bound of the rows any slab-producing call writes */
+/* Range words (odin_conv_desc.dy_amax / dx_amax; ODIN_RANGE_WORDS uint32 each): zero `n` words at the top of a
+ * step; fold max|t[0..n)| of an fp32 tensor into a word (producers that do not track their outputs themselves, or
+ * external callers). */
+#define ODIN_RANGE_WORDS 2048
+int odin_range_reset(uint32_t* words, int n, void* stream);
+int odin_absmax(const float* t, size_t n, uint32_t* word, void* stream);
+/* diagnostics: how many times a consumer had to bound a gradient tensor itself (no range word given) */
+int odin_debug_absmax_fallbacks(void);
 
 /* ---- Conv2D (keras.layers.Conv2D, odin/networks/image_networks.py:166-169,463-466) --- */
 int odin_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
@@ -118,9 +136,10 @@ int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* stream);
  * log q(z) - log p(z) at the same z; analytic=1 -> closed form KL(q||p); analytic=2 -> closed
  * form KL(p||q) (`reverse=False`, helpers.py:261-262); free_bits<0 = disabled,
  * else max(kl, free_bits*D).   p [B,2D], eps [B,D] -> z [B,D], kl [B] (after free bits),
- * fbmask [B] (1 where the gradient flows). */
+ * fbmask [B] (1 where the gradient flows).  capacity (optional DEVICE scalar C(step)): BetaCapacityVAE
+ * (odin/bay/vi/autoencoder/beta_vae.py:132-177) -- kl <- |kl - C|, fbmask <- fbmask * sign(kl - C). */
 int odin_latent_fwd(const float* p, const float* eps, float* z, float* kl, float* fbmask, int B,
-                    int D, int analytic, float free_bits, void* stream);
+                    int D, int analytic, float free_bits, const float* capacity, void* stream);
 /* dp [B,2D] of  L = sum_b klw[0]*kl_b  given dz (+ dz_extra) = dL/dz from the decoder
  * / regularisers (may be NULL) and optional extra grads (dloc_x, dscale_x: total correlation).  klw is a DEVICE scalar
  * (= beta / B) so that graph replays see schedule updates. */
@@ -146,7 +165,8 @@ int odin_latent_block_rows(int B, int P, int D, int N0);
 int odin_latent_block_fwd(const float* h, const float* wl, const float* bl, const float* eps_in,
                           float* eps_out, uint64_t seed, const int32_t* step_dev, float* p, float* z,
                           float* kl, float* fbmask, const float* w0, const float* b0, float* y0, int B,
-                          int P, int D, int N0, int act0, int analytic, float free_bits, void* stream);
+                          int P, int D, int N0, int act0, int analytic, float free_bits,
+                          const float* capacity, void* stream);
 int odin_latent_block_bwd(const float* g0, const float* w0, const float* z, const float* p,
                           const float* eps, const float* fbmask, const float* klw, const float* dz_extra,
                           const float* dloc_x, const float* dscale_x, const float* wl, const float* h,

@@ -21,7 +21,8 @@ ACT = {'linear': 0, 'elu': 1, 'relu': 2, None: 0}
 class ConvDesc(C.Structure):
   """mirror of ``odin_conv_desc`` (include/odin_hip.h)."""
   _fields_ = [(n, C.c_int) for n in ('B', 'H', 'W', 'Cin', 'OH', 'OW', 'Cout', 'KH', 'KW',
-                                     'stride', 'pad_t', 'pad_l', 'act', 'center')]
+                                     'stride', 'pad_t', 'pad_l', 'act', 'center')] + \
+             [('dy_amax', C.c_void_p), ('dx_amax', C.c_void_p)]  # range words of dy / dx (backward; optional)
 
 
 class ReduceJob(C.Structure):
@@ -41,6 +42,9 @@ SIGNATURES = {
     'odin_debug_last_path': [],
     'odin_crc32c': [C.c_uint32, P, C.c_size_t],
     'odin_max_slab_rows': [],
+    'odin_range_reset': [P, I, P],
+    'odin_absmax': [P, C.c_size_t, P, P],
+    'odin_debug_absmax_fallbacks': [],
     'odin_comm_unique_id': [P],
     'odin_comm_init': [C.POINTER(C.c_void_p), P, I, I],
     'odin_comm_destroy': [P],
@@ -58,10 +62,10 @@ SIGNATURES = {
     'odin_dense_dgrad': [P, P, P, I, P, P, IP, I, I, I, P],
     'odin_dense_wgrad': [P, P, P, IP, I, I, I, P],
     'odin_slab_reduce': [C.POINTER(ReduceJob), I, P],
-    'odin_latent_fwd': [P, P, P, P, P, I, I, I, F, P],
+    'odin_latent_fwd': [P, P, P, P, P, I, I, I, F, P, P],
     'odin_latent_bwd': [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     'odin_latent_block_rows': [I, I, I, I],
-    'odin_latent_block_fwd': [P, P, P, P, P, C.c_uint64, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
+    'odin_latent_block_fwd': [P, P, P, P, P, C.c_uint64, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, P],
     'odin_latent_block_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, I, I, P],
     'odin_elbo_bernoulli_fwd_bwd': [P, P, P, P, P, I, I, IP, P],
     'odin_elbo_gaussian_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
@@ -98,7 +102,7 @@ SIGNATURES = {
 
 
 # entry points whose return value is a result, not an error code
-VALUE_RETURNING = ('odin_version', 'odin_max_slab_rows', 'odin_crc32c', 'odin_debug_last_path',
+VALUE_RETURNING = ('odin_version', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
                    'odin_latent_block_rows', 'odin_total_correlation_workspace')
 
 

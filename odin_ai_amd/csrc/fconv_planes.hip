@@ -1,5 +1,6 @@
 // fconv_planes.hip -- STRIDED gather convolution 4x4 / stride 2 over 32 reduction channels (TF `SAME`,
-// pads (1, 1)) with fp32 operands carried through the bf16 matrix pipe as three exact bf16 planes:
+// pads (1, 1)) with fp32 operands carried through the f16 matrix pipe as two f16 planes (odin_device.h:
+// x = h + 2^-11 l; three v_mfma_f32_32x32x16_f16 per 16 k-values into a main and a cross accumulator):
 //   Conv2D(k4, s2) forward over 32 input channels                    (image_networks.py:462-468)
 //   Conv2DTranspose(k4, s2) DATA GRADIENT over 32 output channels     (tape.gradient of decoder3/4)
 //       out[b, oh, ow, n] = sum over (kh, kw, c < 32) of in[b, 2 oh - 1 + kh, 2 ow - 1 + kw, c] * W[kh, kw, c, n]
@@ -7,8 +8,8 @@
 // The strided gather reads an input area 4x the output area, so the LDS cannot hold the weight
 // planes (96 KB) beside a useful row window.  Instead the REDUCTION is split over the 8 waves of a
 // workgroup: wave v owns the taps (kh = v >> 1, kw = 2 (v & 1) + {0, 1}) and keeps their weight
-// fragments -- 2 taps x 2 k-halves x 3 planes = 48 registers -- for the whole kernel; all waves
-// multiply the same 32-pixel x 32-channel output tile (24 MFMAs each), leave their partial tiles in
+// fragments -- 2 taps x 2 k-halves x 2 planes = 32 registers -- for the whole kernel; all waves
+// multiply the same 32-pixel x 32-channel output tile (12 MFMAs each), leave their partial tiles in
 // LDS and meet at the tile's barrier; behind it wave v sums the eight partials of accumulator
 // registers 2 v, 2 v + 1 and runs their epilogue while the next tile's MFMAs are already going (two
 // scratch buffers).  The row window is the one of wgrad_planes.hip (fine rows as two column-parity
@@ -30,6 +31,8 @@ struct FPParams {
   int B, OH, CO;
   int CS, ci_off;      // channels of the input tensor; first of the 32 this pass reduces over
   int tiles_per_img, n_tiles, tiles_per_wg;
+  const unsigned* in_amax;  // SC instances: the input is a gradient tensor; its range word (odin_device.h)
+  unsigned* out_amax;       // EPI 2: range word of `out` (may be null)
   long long* stamps;   // diagnostics build: s_memtime stamps of workgroup 0, [wave][32]
 };
 
@@ -42,15 +45,6 @@ struct FPParams {
       p.stamps[32 * wave + stamp_i++] = ((long long)(k) << 56) | (long long)(clock64() & 0xFFFFFFFFFFFFFFll); \
   } while (0)
 #endif
-
-__device__ __forceinline__ void fp_split4(const float4& v, u32x2& h, u32x2& m, u32x2& l) {
-  h = odin_u2(odin_pack_bf16(v.x, v.y), odin_pack_bf16(v.z, v.w));
-  const float r0 = odin_bf16_rest(v.x), r1 = odin_bf16_rest(v.y), r2 = odin_bf16_rest(v.z),
-              r3 = odin_bf16_rest(v.w);
-  m = odin_u2(odin_pack_bf16(r0, r1), odin_pack_bf16(r2, r3));
-  l = odin_u2(odin_pack_bf16(odin_bf16_rest(r0), odin_bf16_rest(r1)),
-              odin_pack_bf16(odin_bf16_rest(r2), odin_bf16_rest(r3)));
-}
 
 struct alignas(8) FpEnt {
   int x, y;
@@ -66,8 +60,10 @@ constexpr int FP_MAXU = 4;
 // EPI 1: bias + ELU (Conv2D forward); EPI 2: x ELU'(aux), column sums (deconv data gradient); EPI 0: raw partial sums
 // (first of two reduction passes over 64 input channels); ACC: add the partial sums the previous pass left in `out`
 // before the epilogue.
-template <int EPI, int OW, bool ACC>
+// SC: the input tensor is a gradient (scaled by 2^gexp on its way into the planes, the result scaled back)
+template <int EPI, int OW, bool ACC, bool SC>
 __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
+  constexpr int NPL = 2;                 // f16 planes per operand
   constexpr int TC = 32 / OW;            // output rows per tile
   constexpr int WU = 2 * OW;             // input row length
   constexpr int SU = OW + 1;             // slots per column-parity plane
@@ -76,7 +72,7 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   // pairs (1, 2), (3, 4), (5, 6) shared their banks (15-19 % of the LDS cycles of fconv_planes / wgrad_planes)
   constexpr int PARB = (SU + 1) * 64;
   constexpr int PBU = 2 * PARB;
-  constexpr int RBU = 3 * PBU;
+  constexpr int RBU = NPL * PBU;
   constexpr int NSU = 4 * TC + 3;        // live input rows (2 TC + 2) + the next tile's (2 TC + 1 at an image seam)
   constexpr int IPU = WU / 8;            // 1 KB load items per input row
   constexpr int RJ = 8 / IPU > 0 ? 8 / IPU : 1;
@@ -117,6 +113,16 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
         wv[t][kk][e] = p.w[((size_t)(tap * p.CS + p.ci_off + 16 * kk + 8 * half + e)) * p.CO + n0 + l31];
     }
   const OdinRun RU = odin_run(p.in, (unsigned)((size_t)p.B * HU * WU * p.CS * 4));
+  // a gradient input is carried times 2^gk (its maximum lands in [2^14, 2^15)), the sums are scaled back
+#ifdef ODIN_SIM
+  const int gk = SC ? odin_range_shift(odin_range_load(p.in_amax)) : 0;
+#else
+  const int gk = SC ? odin_range_shift(odin_range_load(p.in_amax)) : 0;
+#endif
+  const float in_s = SC ? odin_pow2(gk) : 1.f;
+  const float in_s2k = SC ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
+  const float out_s = SC ? odin_pow2(-gk) : 1.f;
+  float amx = 0.f;  // running max |out| of this lane (EPI 2)
   constexpr int RPF = FP_MAXU * RJ;      // rows a fill can carry (row r = r0w + RJ j of item j)
   constexpr int DST_NONE = -(1 << 24);   // ring offset of an item without a row: dst stays negative
   constexpr unsigned OFF_NONE = 0x7FFF0000u;  // global offset of a row that is not read (padding row, no image): out of range
@@ -145,8 +151,8 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   ODIN_SCHED_FENCE();
 
   // ---- SAME-padding slots (parity plane 0 slot 0, parity plane 1 slot OW) of every ring row and plane ----
-  for (int e = tid; e < NSU * 24; e += 512) {
-    const int sl = e / 24, rem = e - sl * 24;
+  for (int e = tid; e < NSU * 8 * NPL; e += 512) {
+    const int sl = e / (8 * NPL), rem = e - sl * (8 * NPL);
     const int pl = rem >> 3, side = (rem >> 2) & 1, piece = rem & 3;
     *reinterpret_cast<float4*>(ring + sl * RBU + pl * PBU + (side ? PARB + OW * 64 : 0) + piece * 16) =
         make_float4(0.f, 0.f, 0.f, 0.f);
@@ -210,12 +216,11 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 #else
     if (__builtin_amdgcn_readfirstlane(it.dst) < 0) return;
 #endif
-    u32x2 h, m, l;
-    fp_split4(it.v, h, m, l);
+    u32x2 h, l;
+    odin_split_h4<SC>(it.v, in_s, in_s2k, h, l);
     char* d = ring + it.dst;
     *reinterpret_cast<u32x2*>(d) = h;
-    *reinterpret_cast<u32x2*>(d + PBU) = m;
-    *reinterpret_cast<u32x2*>(d + 2 * PBU) = l;
+    *reinterpret_cast<u32x2*>(d + PBU) = l;
   };
 
   // ---- this lane's output pixel inside the tile and its read offsets ----
@@ -238,18 +243,17 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 
   FpEnt en[FP_MAXU];
   FP_STAMP(6);
-  u32x4 wf[2][2][3];
+  u32x4 wf[2][2][NPL];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const float(&v)[8] = wv[t][kk];
-      u32x2 h0, m0, l0, h1, m1, l1;
-      fp_split4(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
-      fp_split4(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+      u32x2 h0, l0, h1, l1;
+      odin_split_h4<false>(make_float4(v[0], v[1], v[2], v[3]), 1.f, ODIN_LO_SCALE, h0, l0);
+      odin_split_h4<false>(make_float4(v[4], v[5], v[6], v[7]), 1.f, ODIN_LO_SCALE, h1, l1);
       wf[t][kk][0][0] = h0.x; wf[t][kk][0][1] = h0.y; wf[t][kk][0][2] = h1.x; wf[t][kk][0][3] = h1.y;
-      wf[t][kk][1][0] = m0.x; wf[t][kk][1][1] = m0.y; wf[t][kk][1][2] = m1.x; wf[t][kk][1][3] = m1.y;
-      wf[t][kk][2][0] = l0.x; wf[t][kk][2][1] = l0.y; wf[t][kk][2][2] = l1.x; wf[t][kk][2][3] = l1.y;
+      wf[t][kk][1][0] = l0.x; wf[t][kk][1][1] = l0.y; wf[t][kk][1][2] = l1.x; wf[t][kk][1][3] = l1.y;
     }
 
   FP_STAMP(8);
@@ -288,6 +292,7 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 #pragma unroll
     for (int wv = 1; wv < 8; ++wv) { s.x += q8[wv].x; s.y += q8[wv].y; }
     float v[2] = {s.x, s.y};
+    if (SC) { v[0] *= out_s; v[1] *= out_s; }
     if (ACC) { v[0] += pvP.x; v[1] += pvP.y; }
     if (EPI == 1) {
 #pragma unroll
@@ -300,6 +305,8 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
       v[1] = fmaf(v[1], fminf(auxP.y, 0.f), v[1]);
       csum[0] += v[0];
       csum[1] += v[1];
+      // (the first tile's pass has no predecessor and sums zeros: nothing to mask)
+      amx = fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1])));
     }
     odin_run_store2(RO, ooffP, make_float2(v[0], v[1]));  // (range-checked: the first tile's pass has no tile T - 1)
   };
@@ -313,11 +320,11 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
     int su = th.x + 2 * orow + kh;  // the wave's tap row kh of this lane's output row
     su -= su >= NSU ? NSU : 0;
     const char* rowp = ring + su * RBU;
-    u32x4 fb[2][2][3];
+    u32x4 fb[2][2][NPL];
     FP_STAMP(2);
     // (the fragments of the first products first)
 #pragma unroll
-    for (int pl = 2; pl >= 0; --pl)
+    for (int pl = NPL - 1; pl >= 0; --pl)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -326,31 +333,33 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
     const unsigned ooff = (unsigned)th.y + o_lane;
     float2 auxN = make_float2(0.f, 0.f), pvN = make_float2(0.f, 0.f);
     float2 q8[8];
-    f32x16 acc = f32x16_zero();
+    f32x16 acc = f32x16_zero(), acx = f32x16_zero();  // main (h x h) and cross (h x l + l x h, times 2^11) sums
 #pragma unroll
-    for (int m = 0; m < 24; ++m) {
+    for (int m = 0; m < 12; ++m) {
       const int t = (m >> 1) & 1, kk = m & 1, pp = m >> 2;
-      // plane products, smallest first: 0*2, 2*0, 1*1, 0*1, 1*0, 0*0 (weights x pixels)
-      const int ia = (pp == 0) ? 0 : (pp == 1) ? 2 : (pp == 2) ? 1 : (pp == 3) ? 0 : (pp == 4) ? 1 : 0;
-      const int ib = (pp == 0) ? 2 : (pp == 1) ? 0 : (pp == 2) ? 1 : (pp == 3) ? 1 : (pp == 4) ? 0 : 0;
-      acc = mfma32_bf16(wf[t][kk][ia], fb[t][kk][ib], acc);
+      // plane products: weights x pixels h*l, l*h (cross accumulator), h*h (main accumulator)
+      if (pp == 0) acx = mfma32_f16(wf[t][kk][0], fb[t][kk][1], acx);
+      if (pp == 1) acx = mfma32_f16(wf[t][kk][1], fb[t][kk][0], acx);
+      if (pp == 2) acc = mfma32_f16(wf[t][kk][0], fb[t][kk][0], acc);
       if (m == 0) FP_STAMP(3);
-      if (m == 23) FP_STAMP(4);
+      if (m == 11) FP_STAMP(4);
       // the matrix pipe starts as soon as the first fragments are there; everything else rides between MFMAs
       if (m == 0) {
         fill_loads(ldu, en);  // fill T - T0 + 3: its table entries were read a tile ago
         if (EPI == 2) auxN = odin_run_load2(RX, ooff);
         if (ACC) pvN = odin_run_load2(RO, ooff);
       }
-      if (m == 21) {  // (behind every other LDS read of this tile)
+      if (m == 10) {  // (behind every other LDS read of this tile)
         fill_entries(en, T - T0 + 4);
         thN = tt[T - T0 + 1];
       }
-      if ((m & 3) == 1 && (m >> 2) < FP_MAXU) store_item(stu[m >> 2]);  // rows of tile T + 1
-      if (m == 17) finish_load((T - 1) & 1, q8);  // tile T - 1: its partials are complete behind the last barrier
-      if (m == 20) finish_done(q8);
+      if ((m & 1) == 1 && (m >> 1) < FP_MAXU) store_item(stu[m >> 1]);  // rows of tile T + 1
+      if (m == 8) finish_load((T - 1) & 1, q8);  // tile T - 1: its partials are complete behind the last barrier
+      if (m == 9) finish_done(q8);
       ODIN_SCHED_FENCE();
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = fmaf(acx[r], ODIN_LO_UNSCALE, acc[r]);
     // this wave's partial tile -> scratch [T & 1][register pair][wave][lane]
     char* d = red + (T & 1) * RED + ((wave * 64 + lane) << 3);
 #pragma unroll
@@ -374,6 +383,10 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
     finish_done(q8);
   }
 
+  if (EPI == 2) {
+    __syncthreads();  // (the partial-tile scratch is free: every wave is past its last finish pass)
+    odin_amax_commit_wg(p.out_amax, amx, tid, 512, reinterpret_cast<float*>(red), blockIdx.x + gridDim.x * blockIdx.y);
+  }
   if (EPI == 2 && p.colsum != nullptr) {
     // column sums of this workgroup's outputs: the 32 pixel lanes of each half by shuffles; every
     // (wave, half) owns its own two channels
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
 
 // LDS: row ring + two partial-tile buffers + the fill tables ((1 + rows per fill) x 8 bytes per fill, tiles + 4 fills)
 constexpr int FP_LDS_MAX = 160 * 1024;
-int fp_ring_bytes(int OW) { return (4 * (32 / OW) + 3) * 3 * 2 * (OW + 2) * 64 + 2 * (8 * 4 * 64 * 16); }
+int fp_ring_bytes(int OW) { return (4 * (32 / OW) + 3) * 2 * 2 * (OW + 2) * 64 + 2 * (8 * 4 * 64 * 16); }
 int fp_fill_bytes(int OW) {
   const int ipu = 2 * OW / 8, rj = 8 / ipu > 0 ? 8 / ipu : 1;
   return 8 * (1 + FP_MAXU * rj);
@@ -406,20 +419,20 @@ int fp_tiles_per_wg(int OW, int n_tiles, int gy) {
   return tpw;
 }
 
-template <int EPI, int OW, bool ACC>
+template <int EPI, int OW, bool ACC, bool SC>
 int fp_launch(const FPParams& p, dim3 grid, void* stream) {
   const size_t lds = (size_t)fp_ring_bytes(OW) + (size_t)(p.tiles_per_wg + 4) * fp_fill_bytes(OW);
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fconv_planes_kernel<EPI, OW, ACC>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fconv_planes_kernel<EPI, OW, ACC, SC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, FP_LDS_MAX) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((fconv_planes_kernel<EPI, OW, ACC>), grid, dim3(512), lds, stream, p);
-  return odin_check_launch("fconv_planes(bf16x3)");
+  ODIN_LAUNCH((fconv_planes_kernel<EPI, OW, ACC, SC>), grid, dim3(512), lds, stream, p);
+  return odin_check_launch("fconv_planes(f16x2)");
 }
 
 }  // namespace
@@ -437,11 +450,11 @@ bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, i
          fp_tiles_per_wg(OW, B * (OH / (32 / OW)), CO / 32) > 0;
 }
 
-template <int EPI, bool ACC>
+template <int EPI, bool ACC, bool SC>
 int fp_launch_w(const FPParams& p, int OW, dim3 grid, void* stream) {
-  if (OW == 32) return fp_launch<EPI, 32, ACC>(p, grid, stream);
-  if (OW == 16) return fp_launch<EPI, 16, ACC>(p, grid, stream);
-  return fp_launch<EPI, 8, ACC>(p, grid, stream);
+  if (OW == 32) return fp_launch<EPI, 32, ACC, SC>(p, grid, stream);
+  if (OW == 16) return fp_launch<EPI, 16, ACC, SC>(p, grid, stream);
+  return fp_launch<EPI, 8, ACC, SC>(p, grid, stream);
 }
 
 // epi 1: Conv2D forward (bias + ELU); epi 2: Conv2DTranspose data gradient (x ELU'(aux), column sums).
@@ -449,7 +462,7 @@ int fp_launch_w(const FPParams& p, int OW, dim3 grid, void* stream) {
 // registers): the first leaves raw partial sums in `out`, the second adds them and runs the epilogue.
 int odin_fconv_planes_launch(const float* in, const float* w, const float* bias, const float* aux,
                              float* out, float* colsum, int* rows_out, int B, int OH, int OW, int CI, int CO,
-                             int epi, void* stream) {
+                             int epi, const uint32_t* in_amax, uint32_t* out_amax, void* stream) {
   FPParams p;
   memset(&p, 0, sizeof(p));
   p.in = in; p.w = w; p.bias = bias; p.aux = aux; p.out = out; p.colsum = colsum;
@@ -465,14 +478,20 @@ int odin_fconv_planes_launch(const float* in, const float* w, const float* bias,
   const int gx = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
   if (rows_out) *rows_out = gx;
   if (out == nullptr) return 0;  // dry run
+  if (epi == 2) {
+    p.in_amax = odin_range_word_of(in, (size_t)B * 2 * OH * 2 * OW * CI, in_amax, stream);
+    if (p.in_amax == nullptr) return odin_fail(-3, "fconv_planes: no range word for the gradient input");
+    p.out_amax = out_amax;
+  }
   dim3 grid(gx, gy, 1);
   if (CI == 64) {
     FPParams q = p;
     q.colsum = nullptr;
-    const int rc = fp_launch_w<0, false>(q, OW, grid, stream);
+    q.out_amax = nullptr;
+    const int rc = epi == 1 ? fp_launch_w<0, false, false>(q, OW, grid, stream) : fp_launch_w<0, false, true>(q, OW, grid, stream);
     if (rc != 0) return rc;
     p.ci_off = 32;
-    return epi == 1 ? fp_launch_w<1, true>(p, OW, grid, stream) : fp_launch_w<2, true>(p, OW, grid, stream);
+    return epi == 1 ? fp_launch_w<1, true, false>(p, OW, grid, stream) : fp_launch_w<2, true, true>(p, OW, grid, stream);
   }
-  return epi == 1 ? fp_launch_w<1, false>(p, OW, grid, stream) : fp_launch_w<2, false>(p, OW, grid, stream);
+  return epi == 1 ? fp_launch_w<1, false, false>(p, OW, grid, stream) : fp_launch_w<2, false, true>(p, OW, grid, stream);
 }

@@ -1603,7 +1603,7 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
       odin_fconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                                    d->pad_t, d->pad_l, d->center))
     return odin_fconv_planes_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->OH, d->OW, d->Cin, d->Cout,
-                                    1, stream);
+                                    1, nullptr, nullptr, stream);
   if (d->act == ODIN_ACT_ELU && bias != nullptr &&
       odin_fconv_ring_applicable(d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                                  d->pad_t, d->pad_l, d->center))
@@ -1612,7 +1612,7 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
   if (odin_igemm_applicable(0, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                             d->center))
     return odin_igemm_launch(0, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
-                             d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, stream);
+                             d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, nullptr, stream);
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = y;
@@ -1623,11 +1623,17 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
 
 // dx[b,ih,iw,ci] = sum_{kh,kw,co} dy[b,(ih+pt-kh)/S,(iw+pl-kw)/S,co] * W[kh,kw,ci,co];
 // optionally multiplied by act'(aux) (aux = this layer's input = previous layer's output)
+// a data gradient whose kernel family does not keep the range word of dx itself: one pass over dx
+static int track_dx(int rc, const float* dx, const odin_conv_desc* d, void* stream) {
+  if (rc != 0 || dx == nullptr || d->dx_amax == nullptr) return rc;
+  return odin_absmax(dx, (size_t)d->B * d->H * d->W * d->Cin, d->dx_amax, stream);
+}
+
 extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* aux, int aux_act,
                                  float* dx, float* colsum_slab, int* slab_rows_out,
                                  const odin_conv_desc* d, void* stream) {
   if (odin_pw1x1_applicable(d))
-    return odin_pw1x1_dgrad(dy, w, aux, aux_act, dx, colsum_slab, slab_rows_out, d, stream);
+    return track_dx(odin_pw1x1_dgrad(dy, w, aux, aux_act, dx, colsum_slab, slab_rows_out, d, stream), dx, d, stream);
   // data gradient of a Conv2D = transposed gather over dY: input (OH, OW, Cout), output (H, W, Cin)
   if (aux_act == ODIN_ACT_ELU && (aux != nullptr || dx == nullptr) && d->H == 2 * d->OH &&
       d->W == 2 * d->OW &&
@@ -1635,29 +1641,29 @@ extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* a
                                    d->pad_l, 0, 2, 1))
     return odin_tconv_planes_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->OH,
-                                    d->OW, d->Cout, d->Cin, 2, stream);
+                                    d->OW, d->Cout, d->Cin, 2, d->dy_amax, d->dx_amax, stream);
   if (aux_act == ODIN_ACT_ELU && (aux != nullptr || dx == nullptr) && d->H == 2 * d->OH &&
       d->W == 2 * d->OW &&
       odin_tconv_ring_applicable(d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t,
                                  d->pad_l, 0))
-    return odin_tconv_ring_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, nullptr, nullptr,
-                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->OH,
-                                  d->OW, d->Cin, 2, stream);
+    return track_dx(odin_tconv_ring_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, nullptr, nullptr,
+                                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->OH,
+                                           d->OW, d->Cin, 2, stream), dx, d, stream);
   if (odin_igemm_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0) &&
       (odin_igemm_tiles(1, d->B, d->H, d->W, d->stride) <= ODIN_MAX_COLSUM_BLOCKS ||
        (colsum_slab == nullptr && dx != nullptr))) {
     if (slab_rows_out) *slab_rows_out = odin_igemm_tiles(1, d->B, d->H, d->W, d->stride);
     if (dx == nullptr) return 0;  // dry run
     return odin_igemm_launch(1, dy, w, nullptr, aux, aux_act, dx, colsum_slab, d->B, d->OH, d->OW, d->Cout,
-                             d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0, stream);
+                             d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0, d->dx_amax, stream);
   }
   GParams p;
   fill_common(p, d);
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;
   p.H = d->OH; p.W = d->OW; p.CI = d->Cout; p.OH = d->H; p.OW = d->W; p.CO = d->Cin;
   p.wmode = 1;
-  return launch_gather(MODE_T, p, stream, colsum_slab ? -ODIN_MAX_COLSUM_BLOCKS : odin_num_cus(),
-                       slab_rows_out);
+  return track_dx(launch_gather(MODE_T, p, stream, colsum_slab ? -ODIN_MAX_COLSUM_BLOCKS : odin_num_cus(),
+                                slab_rows_out), dx, d, stream);
 }
 
 // ---- Conv2DTranspose (desc: H,W,Cin = input; OH=H*S, OW=W*S, Cout = output; pads = the
@@ -1669,7 +1675,7 @@ extern "C" int odin_deconv2d_fwd(const float* x, const float* w, const float* bi
                                    d->pad_l, d->center, 1, 1))
     return odin_tconv_planes_launch(x, w, bias, nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->H, d->W,
-                                    d->Cin, d->Cout, 1, stream);
+                                    d->Cin, d->Cout, 1, nullptr, nullptr, stream);
   if (d->act == ODIN_ACT_ELU && bias != nullptr && d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_tconv_ring_applicable(d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
                                  d->pad_l, d->center))
@@ -1679,7 +1685,7 @@ extern "C" int odin_deconv2d_fwd(const float* x, const float* w, const float* bi
   if (odin_igemm_applicable(1, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                             d->center))
     return odin_igemm_launch(1, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
-                             d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, stream);
+                             d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, nullptr, stream);
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = y;
@@ -1696,7 +1702,7 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
       odin_fconv_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
                                    d->pad_t, d->pad_l, 0))
     return odin_fconv_planes_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, d->B, d->H, d->W,
-                                    d->Cout, d->Cin, 2, stream);
+                                    d->Cout, d->Cin, 2, d->dy_amax, d->dx_amax, stream);
   // (64 reduction channels take two fconv_ring passes: where the implicit-GEMM kernel covers the layer it does the
   // same work in one launch -- decoder2 of the dSprites stack: 30.8 us in two launches vs 30.2 us in one)
   const bool ring_two_pass_vs_igemm =
@@ -1706,23 +1712,23 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
   if (!ring_two_pass_vs_igemm && aux_act == ODIN_ACT_ELU && (aux != nullptr || dx == nullptr) &&
       odin_fconv_ring_applicable(d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
                                  d->pad_t, d->pad_l, 0))
-    return odin_fconv_ring_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, d->B, d->OH,
-                                  d->OW, d->Cout, d->H, d->W, d->Cin, 2, stream);
+    return track_dx(odin_fconv_ring_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, d->B, d->OH,
+                                           d->OW, d->Cout, d->H, d->W, d->Cin, 2, stream), dx, d, stream);
   if (odin_igemm_applicable(0, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0) &&
       (odin_igemm_tiles(0, d->B, d->H, d->W, d->stride) <= ODIN_MAX_COLSUM_BLOCKS ||
        (colsum_slab == nullptr && dx != nullptr))) {
     if (slab_rows_out) *slab_rows_out = odin_igemm_tiles(0, d->B, d->H, d->W, d->stride);
     if (dx == nullptr) return 0;  // dry run
     return odin_igemm_launch(0, dy, w, nullptr, aux, aux_act, dx, colsum_slab, d->B, d->OH, d->OW, d->Cout,
-                             d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0, stream);
+                             d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0, d->dx_amax, stream);
   }
   GParams p;
   fill_common(p, d);
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;
   p.H = d->OH; p.W = d->OW; p.CI = d->Cout; p.OH = d->H; p.OW = d->W; p.CO = d->Cin;
   p.wmode = 0;
-  return launch_gather(MODE_F, p, stream, colsum_slab ? -ODIN_MAX_COLSUM_BLOCKS : odin_num_cus(),
-                       slab_rows_out);
+  return track_dx(launch_gather(MODE_F, p, stream, colsum_slab ? -ODIN_MAX_COLSUM_BLOCKS : odin_num_cus(),
+                                slab_rows_out), dx, d, stream);
 }
 
 // Dense layers whose reduction width is a multiple of 8 through the implicit-GEMM kernel (a 1x1 convolution on a
@@ -1735,7 +1741,8 @@ extern "C" int odin_dense_fwd(const float* x, const float* w, const float* bias,
                               int K, int N, int act, void* stream) {
   if (odin_tiny_dense_ok(B, K, N)) return odin_tiny_dense_fwd(x, w, bias, y, B, K, N, act, stream);
   if (dense_via_igemm() && odin_igemm_applicable(0, B, 1, 1, K, 1, 1, N, 1, 1, 1, 0))
-    return odin_igemm_launch(0, x, w, bias, nullptr, 0, y, nullptr, B, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, act, stream);
+    return odin_igemm_launch(0, x, w, bias, nullptr, 0, y, nullptr, B, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, act, nullptr,
+                             stream);
   if (odin_dense_gemm_ok(B, K, N)) return odin_dense_gemm_fwd(x, w, bias, y, B, K, N, act, stream);
   GParams p;
   memset(&p, 0, sizeof(p));
@@ -1756,7 +1763,7 @@ extern "C" int odin_dense_dgrad(const float* dy, const float* w, const float* au
     if (slab_rows_out) *slab_rows_out = 0;
     if (dx == nullptr) return 0;
     return odin_igemm_launch(1, dy, w, nullptr, aux, aux_act, dx, nullptr, B, 1, 1, N, 1, 1, K, 1, 1, 1, 0, 0, 0,
-                             stream);
+                             nullptr, stream);
   }
   if (colsum_slab == nullptr && odin_dense_gemm_ok(B, K, N)) {
     if (slab_rows_out) *slab_rows_out = 0;
@@ -1785,14 +1792,19 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
                                    d->pad_l, d->center, 3, C1))
     return odin_tconv_planes_launch(x, w, bias, nullptr, g_out, nullptr, slab_rows_out, w1, b1, target,
                                     logits, llk_part, n_part_out, tail_slab, scale, C1, d->B, d->H, d->W,
-                                    d->Cin, d->Cout, 3, stream);
+                                    d->Cin, d->Cout, 3, nullptr, d->dy_amax, stream);
   if (is_deconv && d->act == ODIN_ACT_ELU && d->Cout == 32 && (C1 == 1 || C1 == 3) &&
       d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_tconv_ring_applicable(d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
                                  d->pad_l, d->center))
-    return odin_tconv_ring_launch(x, w, bias, nullptr, g_out, nullptr, slab_rows_out, w1, b1, target,
-                                  logits, llk_part, n_part_out, tail_slab, scale, C1, d->B, d->H, d->W,
-                                  d->Cout, 3, stream);
+  {
+    int rc = odin_tconv_ring_launch(x, w, bias, nullptr, g_out, nullptr, slab_rows_out, w1, b1, target,
+                                    logits, llk_part, n_part_out, tail_slab, scale, C1, d->B, d->H, d->W,
+                                    d->Cout, 3, stream);
+    if (rc == 0 && g_out != nullptr && d->dy_amax != nullptr)
+      rc = odin_absmax(g_out, (size_t)d->B * d->OH * d->OW * d->Cout, d->dy_amax, stream);
+    return rc;
+  }
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = g_out;
@@ -1804,6 +1816,8 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
   int rc = launch_gather(is_deconv ? MODE_T : MODE_F, p, stream, -ODIN_MAX_COLSUM_BLOCKS,
                          slab_rows_out, &tp);
   if (n_part_out) *n_part_out = p.OH / (p.TR > 0 ? p.TR : 1);  // log-likelihood parts per sample
+  if (rc == 0 && g_out != nullptr && d->dy_amax != nullptr)
+    rc = odin_absmax(g_out, (size_t)d->B * d->OH * d->OW * d->Cout, d->dy_amax, stream);
   return rc;
 }
 

@@ -39,6 +39,7 @@ struct IGParams {
   const float* bias;  // forward
   const float* aux;   // data gradient: multiply by act'(aux), aux shaped like out
   float* colsum;      // data gradient: slab [gridDim.y][CO] of column sums (may be null)
+  unsigned* out_amax; // data gradient: range word of `out` (odin_device.h; may be null)
   int B, H, W, CI, OH, OW, CO, KH, KW, S, pt, pl;
   int gpt;            // k-groups per tap = CI / 8
   unsigned mg_gpt;    // ceil(2^32 / gpt) (0: gpt == 1)
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IGParams p) {
   }
   IG_STAMP(5);
   // ---- epilogue: lane holds column j, rows (rr & 3) + 8 (rr >> 2) + 4 h ----
-  float cs = 0.f;
+  float cs = 0.f, amx = 0.f;
   const OdinRun RO = odin_run(p.out, (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4));
   const bool has_aux = p.aux != nullptr;
 #pragma unroll
@@ -227,7 +228,9 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IGParams p) {
     if (has_aux) v *= odin_act_grad(p.aux_act, auxv[rr]);
     odin_run_store1(RO, ooff[rr], v);           // range-checked: nothing is written for masked rows
     cs += ((int)ooff[rr] >= 0) ? v : 0.f;
+    amx = fmaxf(amx, ((int)ooff[rr] >= 0 && b_ok) ? fabsf(v) : 0.f);
   }
+  odin_amax_commit_wave(p.out_amax, amx, lane, blockIdx.x + gridDim.x * blockIdx.y);  // (wave 0 speaks for the tile)
   if (p.colsum != nullptr) {
     cs += __shfl_xor(cs, 32);
     if (h == 0 && b_ok) p.colsum[(size_t)blockIdx.y * p.CO + j] = cs;
@@ -420,10 +423,10 @@ int odin_igemm_tiles(int tmode, int B, int OH, int OW, int S) {
 
 int odin_igemm_launch(int tmode, const float* in, const float* w, const float* bias, const float* aux,
                       int aux_act, float* out, float* colsum, int B, int H, int W, int CI, int OH, int OW,
-                      int CO, int KH, int KW, int S, int pt, int pl, int act, void* stream) {
+                      int CO, int KH, int KW, int S, int pt, int pl, int act, uint32_t* out_amax, void* stream) {
   IGParams p;
   memset(&p, 0, sizeof(p));
-  p.in = in; p.w = w; p.out = out; p.bias = bias;
+  p.in = in; p.w = w; p.out = out; p.bias = bias; p.out_amax = out_amax;
   p.aux = (aux != nullptr && aux_act != 0) ? aux : nullptr; p.aux_act = aux_act; p.colsum = colsum;
   p.B = B; p.H = H; p.W = W; p.CI = CI; p.OH = OH; p.OW = OW; p.CO = CO;
   p.KH = KH; p.KW = KW; p.S = S; p.pt = pt; p.pl = pl; p.gpt = CI / 8; p.act = act;

@@ -103,6 +103,7 @@ struct LBFwd {
   unsigned k0, k1;
   int B, P, D, N0, act0, analytic, S;
   float free_bits;
+  const float* cap;     // BetaCapacityVAE: device scalar C(step), kl <- |kl - C| (null: off)
 };
 
 // LDS (floats): wl [P * 2D] | w0 [D * N0] | hs [S * P] | bls [2D] | b0s [N0] | es [S * D] | ps [S * 2D] |
@@ -202,6 +203,11 @@ __global__ __launch_bounds__(256) void latent_block_fwd_kernel(LBFwd q) {
     if (q.free_bits >= 0.f) {
       const float thr = q.free_bits * (float)D;
       if (!(acc > thr)) { acc = thr; m = 0.f; }
+    }
+    if (q.cap != nullptr) {  // beta_vae.py:171-177: |kl - C(step)|, gradient sign(kl - C)
+      const float d = acc - q.cap[0];
+      m *= d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      acc = fabsf(d);
     }
     q.kl[b0 + tid] = acc;
     q.fbmask[b0 + tid] = m;
@@ -434,7 +440,7 @@ extern "C" int odin_latent_block_fwd(const float* h, const float* wl, const floa
                                      float* eps_out, uint64_t seed, const int32_t* step_dev, float* p,
                                      float* z, float* kl, float* fbmask, const float* w0, const float* b0,
                                      float* y0, int B, int P, int D, int N0, int act0, int analytic,
-                                     float free_bits, void* stream) {
+                                     float free_bits, const float* capacity, void* stream) {
   const int rows = odin_latent_block_rows(B, P, D, N0);
   if (rows == 0) return odin_fail(-2, "latent_block_fwd: shapes outside the fused regime");
   LBFwd q;
@@ -444,6 +450,7 @@ extern "C" int odin_latent_block_fwd(const float* h, const float* wl, const floa
   q.k0 = (unsigned)seed; q.k1 = (unsigned)(seed >> 32);
   q.B = B; q.P = P; q.D = D; q.N0 = N0; q.act0 = act0; q.analytic = analytic; q.S = lb_samples(B, P, D, N0);
   q.free_bits = free_bits;
+  q.cap = capacity;
   const size_t lds = lb_lds_floats(P, D, N0, q.S) * 4;
   const bool v4 = lb_vec_ok(wl, w0, P, D, N0);
   switch (q.S) {

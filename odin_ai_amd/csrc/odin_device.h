@@ -2,6 +2,7 @@
 // With -DODIN_SIM the same sources compile as host C++ against tests/sim/hipsim.h
 // (a debugging emulator, test infrastructure only); the product build is hipcc/gfx950.
 #pragma once
+#include "../../include/odin_hip.h"
 #ifdef ODIN_SIM
 #include "hipsim.h"
 #define ODIN_DYN_SMEM(T, name) T* name = (T*)sim::S().dyn_smem
@@ -137,6 +138,132 @@ __device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(odin_bf16x8b, a),
                                                  __builtin_bit_cast(odin_bf16x8b, b), c, 0, 0, 0);
 #endif
+}
+
+// ---- fp32 through the f16 matrix pipe: two planes -----------------------------------------------
+// x = h + 2^-11 l with h = RNE_f16(x) and l = RNE_f16(2^11 (x - h)): |x - h| <= 2^-11 |x| and the second
+// rounding leaves <= 2^-22 |x| (the low plane is carried scaled by 2^11 so that it stays a NORMAL f16 down
+// to |x| = 2^-25; below that its absolute error is 2^-36).  A product x w is then
+//   h_x h_w  +  2^-11 (h_x l_w + l_x h_w)   (+ the dropped l_x l_w <= 2^-22 |x w|):
+// three v_mfma_f32_32x32x16_f16 per 16 k-values into TWO fp32 accumulators (main, cross), combined once as
+// main + 2^-11 cross.  Error <= 3 * 2^-22 per product -- below the rounding noise of an fp32 dot product of the
+// layers' reduction lengths (512-1024 terms, 2^-24 per addition) -- at half the matrix work and about half the
+// split work of the three-plane bf16 form.  Range: |x| <= 65504 for activations and weights (larger values become
+// inf and trip the optimiser's NaN policy); gradient operands are carried times a per-tensor power of two
+// (odin_range_shift below) through the split.
+#define ODIN_LO_SCALE 2048.f
+#define ODIN_LO_UNSCALE 4.8828125e-4f  // 2^-11
+// (a, b) -> packed f16 pair, round to nearest even (v_cvt_pk_f16_f32)
+__device__ __forceinline__ unsigned odin_pack_f16(float a, float b) {
+  typedef _Float16 odin_h2 __attribute__((ext_vector_type(2)));
+#ifdef ODIN_SIM
+  odin_h2 h;
+  h.x = (_Float16)a;
+  h.y = (_Float16)b;
+  return __builtin_bit_cast(unsigned, h);
+#else
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#endif
+}
+// m - 2048 * (f16 half `HI` of hp): one v_fma_mix_f32 (the f16 operand is widened inside the instruction)
+template <int HI>
+__device__ __forceinline__ float odin_lo_rest(unsigned hp, float m) {
+#ifdef ODIN_SIM
+  typedef _Float16 odin_h2 __attribute__((ext_vector_type(2)));
+  const odin_h2 h = __builtin_bit_cast(odin_h2, hp);
+  return fmaf((float)(HI ? h.y : h.x), -ODIN_LO_SCALE, m);
+#else
+  float r;
+  if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "s"(-ODIN_LO_SCALE), "v"(m));
+  else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "s"(-ODIN_LO_SCALE), "v"(m));
+  return r;
+#endif
+}
+// four consecutive fp32 values (times s when SC) -> their two f16 planes (4 f16 = 8 bytes each); s2k = 2048 s
+template <bool SC>
+__device__ __forceinline__ void odin_split_h4(const float4& v, float s, float s2k, u32x2& h, u32x2& l) {
+  const float x0 = SC ? v.x * s : v.x, x1 = SC ? v.y * s : v.y, x2 = SC ? v.z * s : v.z, x3 = SC ? v.w * s : v.w;
+  const float k = SC ? s2k : ODIN_LO_SCALE;
+  const unsigned h01 = odin_pack_f16(x0, x1), h23 = odin_pack_f16(x2, x3);
+  const float r0 = odin_lo_rest<0>(h01, v.x * k), r1 = odin_lo_rest<1>(h01, v.y * k);
+  const float r2 = odin_lo_rest<0>(h23, v.z * k), r3 = odin_lo_rest<1>(h23, v.w * k);
+  h = odin_u2(h01, h23);
+  l = odin_u2(odin_pack_f16(r0, r1), odin_pack_f16(r2, r3));
+}
+// D = A(32 x 16) * B(16 x 32) + C on f16 operands (8 f16 per lane and operand; layouts of mfma32_bf16)
+__device__ __forceinline__ f32x16 mfma32_f16(u32x4 a, u32x4 b, f32x16 c) {
+  typedef _Float16 odin_h8 __attribute__((ext_vector_type(8)));
+#ifdef ODIN_SIM
+  const odin_h8 ah = __builtin_bit_cast(odin_h8, a), bh = __builtin_bit_cast(odin_h8, b);
+  for (int j = 0; j < 8; ++j) c = sim::mfma_32x32x2((float)ah[j], (float)bh[j], c);
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(odin_h8, a), __builtin_bit_cast(odin_h8, b), c, 0, 0, 0);
+#endif
+}
+// Dynamic range of gradient operands.  f16 planes hold |x| <= 65504, and gradient tensors range from 1e-8 (a mean
+// over a large batch, deep layers) to 1e5 (reverse KL at random initialisation): every gradient tensor that feeds
+// a plane kernel travels with a device word holding the fp32 bit pattern of (an upper bound of) max |x| -- its
+// producer kernel keeps a running maximum of what it stores and issues one atomicMax per workgroup; a tensor without a
+// tracked producer gets the word from odin_absmax (runtime.hip) -- and the consumer scales the tensor by the power
+// of two that brings that maximum into [2^14, 2^15) on its way into the planes, and its result back.  Exact (powers
+// of two), never overflows, and the planes' absolute error floor sits 2^-50 below the tensor's maximum.
+// k = odin_range_shift(bits): the tensor is carried times 2^k, -113 <= k <= 115
+__device__ __forceinline__ int odin_range_shift(unsigned mb) {
+  int e = (int)((mb >> 23) & 0xFFu);
+  if (e == 255) e = 141;  // an inf / NaN maximum: no scaling, the non-finite values propagate
+  if (e < 26) e = 26;     // a zero (or < 2^-101) tensor
+  return 141 - e;
+}
+__device__ __forceinline__ float odin_pow2(int k) { return odin_bitsf((unsigned)(127 + k) << 23); }  // -126 <= k <= 127
+// max over the 64 lanes (every lane receives it)
+__device__ __forceinline__ float odin_wave_max64(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+// A range "word" is a BLOCK of ODIN_RANGE_SLOTS sub-words, ODIN_RANGE_STRIDE words apart (one per 256-byte
+// line): same-address atomics of a whole launch serialise at the memory side (~8 ns each measured: one atomicMax
+// per wave of a 256-workgroup launch added 16 us to the kernel), so a workgroup reduces its waves through LDS and
+// issues ONE atomicMax into the slot blockIdx selects; the consumer takes the maximum of the slots (scalar loads).
+#define ODIN_RANGE_SLOTS 32
+#define ODIN_RANGE_STRIDE 64
+static_assert(ODIN_RANGE_SLOTS * ODIN_RANGE_STRIDE == ODIN_RANGE_WORDS, "include/odin_hip.h: ODIN_RANGE_WORDS");
+// consumer side: the bound (fp32 bit pattern) of a tensor, wave-uniform
+__device__ __forceinline__ unsigned odin_range_load(const unsigned* block) {
+  unsigned m = 0u;
+#pragma unroll
+  for (int s = 0; s < ODIN_RANGE_SLOTS; ++s) {
+    const unsigned v = block[s * ODIN_RANGE_STRIDE];
+    m = v > m ? v : m;
+  }
+#ifdef ODIN_SIM
+  return m;
+#else
+  return __builtin_amdgcn_readfirstlane(m);
+#endif
+}
+// producer side, one wave speaking for its workgroup (fp32 bit patterns of non-negative values order like
+// unsigned integers)
+__device__ __forceinline__ void odin_amax_commit_wave(unsigned* block, float amx, int lane, unsigned wg) {
+  if (block == nullptr) return;
+  const float m = odin_wave_max64(amx);
+  if (lane == 0) atomicMax(block + (wg & (ODIN_RANGE_SLOTS - 1)) * ODIN_RANGE_STRIDE, odin_fbits(m));
+}
+// producer side, all waves of a workgroup (call from uniform control flow; `red` = LDS scratch of >= 16 floats)
+__device__ __forceinline__ void odin_amax_commit_wg(unsigned* block, float amx, int tid, int nthreads, float* red,
+                                                    unsigned wg) {
+  if (block == nullptr) return;
+  const float m = odin_wave_max64(amx);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    float t = red[0];
+    for (int w = 1; w < (nthreads >> 6); ++w) t = fmaxf(t, red[w]);
+    atomicMax(block + (wg & (ODIN_RANGE_SLOTS - 1)) * ODIN_RANGE_STRIDE, odin_fbits(t));
+  }
 }
 
 __device__ __forceinline__ f32x16 f32x16_zero() {

@@ -10,6 +10,9 @@
 int odin_fail(int code, const char* msg);
 int odin_check_launch(const char* what);
 int odin_num_cus();
+// range word of a gradient tensor (include/odin_hip.h: odin_conv_desc.dy_amax): the caller's word, or a scratch
+// word filled by one pass over the tensor; nullptr on failure
+const uint32_t* odin_range_word_of(const float* t, size_t n, const uint32_t* given, void* stream);
 
 // first-layer (Cin <= 4) convolutions on the vector ALUs (smallc_conv.hip)
 bool odin_smallc_applicable(const odin_conv_desc* d);
@@ -70,14 +73,15 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
                              float* out, float* colsum, int* rows_out, const float* w1, const float* b1,
                              const float* target, float* logits, float* llk_part, int* n_part_out,
                              float* slab, const float* scale, int C1, int B, int H, int W, int CI,
-                             int CO, int epi, void* stream);
+                             int CO, int epi, const uint32_t* in_amax, uint32_t* out_amax, void* stream);
 
 // weight gradients of the 4x4 / stride-2 layers with both operands as bf16 planes, transposing LDS reads
 // (wgrad_planes.hip)
 bool odin_wgrad_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
                                   int S, int pt, int pl, int center);
 int odin_wgrad_planes_launch(const float* U, const float* V, float* slab, int* rows_out, int B, int OH,
-                             int OW, int CI, int CO, int want_bias, void* stream);
+                             int OW, int CI, int CO, int want_bias, int grad_u, const uint32_t* g_amax,
+                             void* stream);
 
 // the same strided gathers through the bf16 matrix pipe, reduction split over the waves (fconv_planes.hip)
 bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
@@ -85,7 +89,7 @@ bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, i
 void odin_fconv_planes_set_stamps(void* buf);
 int odin_fconv_planes_launch(const float* in, const float* w, const float* bias, const float* aux,
                              float* out, float* colsum, int* rows_out, int B, int OH, int OW, int CI, int CO,
-                             int epi, void* stream);
+                             int epi, const uint32_t* in_amax, uint32_t* out_amax, void* stream);
 
 // small-spatial layers as implicit GEMMs with both operands straight from L2 (igemm.hip)
 bool odin_igemm_applicable(int tmode, int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
@@ -94,7 +98,7 @@ void odin_igemm_set_stamps(void* buf);
 int odin_igemm_tiles(int tmode, int B, int OH, int OW, int S);
 int odin_igemm_launch(int tmode, const float* in, const float* w, const float* bias, const float* aux,
                       int aux_act, float* out, float* colsum, int B, int H, int W, int CI, int OH, int OW,
-                      int CO, int KH, int KW, int S, int pt, int pl, int act, void* stream);
+                      int CO, int KH, int KW, int S, int pt, int pl, int act, uint32_t* out_amax, void* stream);
 bool odin_igemm_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, int CV, int KH, int KW, int S,
                                  int center);
 int odin_igemm_wgrad_rows(int B, int h, int w, int KH, int KW, int CU, int CV);

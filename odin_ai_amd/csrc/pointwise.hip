@@ -34,7 +34,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 float
 __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* p, const float* eps,
                                                          float* z, float* kl, float* fbmask,
                                                          int B, int D, int analytic,
-                                                         float free_bits) {
+                                                         float free_bits, const float* cap) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= B) return;
   const float* pb = p + (size_t)b * 2 * D;
@@ -54,6 +54,11 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* p, const f
   if (free_bits >= 0.f) {
     float thr = free_bits * (float)D;
     if (!(acc > thr)) { acc = thr; m = 0.f; }
+  }
+  if (cap != nullptr) {  // BetaCapacityVAE (beta_vae.py:171-177): |kl - C(step)|, gradient sign(kl - C)
+    const float d = acc - cap[0];
+    m *= d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    acc = fabsf(d);
   }
   kl[b] = acc;
   fbmask[b] = m;
@@ -652,9 +657,9 @@ inline int grid_for(size_t work_items, int per_block, int cap) {
 
 extern "C" int odin_latent_fwd(const float* p, const float* eps, float* z, float* kl,
                                float* fbmask, int B, int D, int analytic, float free_bits,
-                               void* stream) {
+                               const float* capacity, void* stream) {
   ODIN_LAUNCH(latent_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, p, eps, z, kl,
-              fbmask, B, D, analytic, free_bits);
+              fbmask, B, D, analytic, free_bits, capacity);
   return odin_check_launch("latent_fwd");
 }
 

@@ -72,7 +72,72 @@ extern "C" uint32_t odin_crc32c(uint32_t crc, const void* data, size_t n) {
   return ~c;
 }
 
-extern "C" int odin_version(void) { return 102; }
+extern "C" int odin_version(void) { return 103; }
+
+// ---- range words of gradient tensors (odin_device.h: odin_range_shift) -----------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ t, size_t n, unsigned* word) {
+  const size_t n4 = n >> 2;
+  const float4* t4 = reinterpret_cast<const float4*>(t);
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = t4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    // (fmaxf drops NaNs: a NaN element propagates through the consumer's arithmetic, not through its scale)
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(t[(n4 << 2) + threadIdx.x]));
+  __shared__ float red[16];
+  odin_amax_commit_wg(word, m, threadIdx.x, 256, red, blockIdx.x);
+}
+constexpr int RANGE_SCRATCH_BLOCKS = 16;
+#ifdef ODIN_SIM
+unsigned g_range_scratch[RANGE_SCRATCH_BLOCKS * ODIN_RANGE_WORDS];
+#else
+__device__ unsigned g_range_scratch[RANGE_SCRATCH_BLOCKS * ODIN_RANGE_WORDS];
+#endif
+}  // namespace
+
+extern "C" int odin_range_reset(uint32_t* words, int n, void* stream) {
+  if (words == nullptr || n <= 0) return 0;
+  if (hipMemsetAsync(words, 0, (size_t)n * ODIN_RANGE_WORDS * 4, (hipStream_t)stream) != hipSuccess)
+    return odin_fail(-3, "odin_range_reset: memset failed");
+  return 0;
+}
+
+extern "C" int odin_absmax(const float* t, size_t n, uint32_t* word, void* stream) {
+  if (t == nullptr || word == nullptr) return odin_fail(-2, "odin_absmax: null argument");
+  if (n == 0) return 0;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  ODIN_LAUNCH(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, n, (unsigned*)word);
+  return odin_check_launch("absmax");
+}
+
+static int g_absmax_fallbacks = 0;
+extern "C" int odin_debug_absmax_fallbacks(void) { return g_absmax_fallbacks; }
+
+// the word a consumer reads: the caller's, or a library scratch word filled by one pass over the tensor (a ring of
+// 16 words: launches on one stream are ordered, and 16 launches later the word's reader has long finished)
+const uint32_t* odin_range_word_of(const float* t, size_t n, const uint32_t* given, void* stream) {
+  if (given != nullptr) return given;
+  static unsigned* base = nullptr;
+  static int next = 0;
+  if (base == nullptr) {
+#ifdef ODIN_SIM
+    base = g_range_scratch;
+#else
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_range_scratch)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    base = (unsigned*)q;
+#endif
+  }
+  unsigned* w = base + (size_t)(next++ % RANGE_SCRATCH_BLOCKS) * ODIN_RANGE_WORDS;
+  ++g_absmax_fallbacks;
+  if (odin_range_reset(w, 1, stream) != 0) return nullptr;
+  if (odin_absmax(t, n, w, stream) != 0) return nullptr;
+  return w;
+}
 
 // diagnostics: name of the kernel family the calling thread launched last; a "(bf16x3)" suffix marks
 // fp32 work carried through the bf16 matrix pipe (priced separately by bench.py's roofline_split)

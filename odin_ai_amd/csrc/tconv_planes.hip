@@ -1,7 +1,8 @@
 // tconv_planes.hip -- TRANSPOSED gather convolution 4x4 / stride 2 over 32 reduction channels with
-// fp32 operands carried through the bf16 matrix pipe as three exact bf16 planes (odin_device.h:
-// x = x0 + x1 + x2 by truncation; the six plane products with i + j <= 2 are accumulated in fp32 by
-// v_mfma_f32_32x32x16_bf16 -- error <= 3 * 2^-24 per product, fp32-class).
+// fp32 operands carried through the f16 matrix pipe as two f16 planes (odin_device.h: x = h + 2^-11 l;
+// the three plane products h*h, h*l, l*h are accumulated in fp32 by v_mfma_f32_32x32x16_f16 into a main
+// and a cross accumulator -- error <= 3 * 2^-22 per product, below the rounding noise of an fp32 dot
+// product of these reduction lengths; round 2-3 carried three bf16 planes and six products).
 //
 // Serves (TF `SAME`, pads (1, 1)):
 //   Conv2DTranspose(k4, s2) forward from 32 channels          (image_networks.py:503-506, decoder4)
@@ -15,17 +16,18 @@
 // mfma_bf16_fillers.hip) v_mfma_f32_*_f32 shares the vector ALU's issue -- every VALU instruction of
 // an epilogue adds its full time to an fp32 MFMA stream, from the same wave or from a partner wave --
 // while bf16 MFMAs run beside the VALU (5 VALU instructions per 32-cycle MFMA are free) at 16x the
-// fp32 MFMA rate.  Six bf16 plane products per 16 k-values take 2.7x less matrix time than the
-// fp32 MFMAs of the same block, and the epilogue hides behind them.  Splitting costs ~6 VALU instructions per element, so every input element is split
-// exactly once per workgroup, on its way from HBM into LDS: global_load -> registers -> three
+// fp32 MFMA rate; f16 MFMAs behave the same (tools/micro/mfma_f16_split.hip).  Three f16 plane products
+// per 16 k-values take 5.3x less matrix time than the fp32 MFMAs of the same block, and the epilogue hides
+// behind them.  Splitting costs ~3 VALU instructions per element, so every input element is split
+// exactly once per workgroup, on its way from HBM into LDS: global_load -> registers -> two
 // ds_write_b64 (no LDS-DMA: DMA cannot convert).  The weights are split once per workgroup too.
 //
-// Structure: 8 waves, all alike.  LDS = weight planes [tap][plane][k-piece][co][8 bf16] (96 KB) +
-// a rolling window of input rows, slot = global padded row mod NSLOT, each [plane][pixel][32 bf16]
+// Structure: 8 waves, all alike.  LDS = weight planes [tap][plane][k-piece][co][8 f16] (64 KB) +
+// a rolling window of input rows, slot = global padded row mod NSLOT, each [plane][pixel][32 f16]
 // with the 16-byte k-pieces XOR-swizzled by (pixel >> 2) so that the 16-lane groups of ds_read_b128
 // (MI355X_MICROARCH.md, LDS) hit 16 distinct slots of the 256-byte bank row.  A tile = RP input
 // rows (RP * W = 64) = 2 RP output rows; a wave owns one (column parity, row parity) class and one
-// 32-pixel group of the tile: 4 taps x 2 k-halves x 6 plane products = 48 MFMAs per tile, with the
+// 32-pixel group of the tile: 4 taps x 2 k-halves x 3 plane products = 24 MFMAs per tile, with the
 // previous tile's epilogue, the split + store of the next tile's rows and the loads of the one after
 // scheduled into the same MFMA stream.  One workgroup barrier per tile.
 #include "odin_device.h"
@@ -53,6 +55,8 @@ struct TPParams {
   int B, H, CO;
   int CS, ci_off;      // channels per input pixel in memory (32 or 64) and the first of this pass's 32
   int tiles_per_img, n_tiles, tiles_per_wg;
+  const unsigned* in_amax;  // SC instances: the input is a gradient tensor; its range word (odin_device.h)
+  unsigned* out_amax;       // EPI 2 / 3: range word of `out`, a gradient tensor (may be null)
   long long* stamps;   // diagnostics: s_memtime stamps of workgroup 0 (wave 0: [0,32), wave 4: [32,64))
 };
 
@@ -90,7 +94,9 @@ __device__ __forceinline__ void tp_static_for(F&& f) {
 struct TpYes { static constexpr bool value = true; };
 struct TpNo { static constexpr bool value = false; };
 
-constexpr int TP_WBYTES = 16 * 3 * 4 * 512;  // weight planes: 96 KB
+constexpr int TP_NPL = 2;                        // f16 planes per operand
+constexpr int TP_TAPB = TP_NPL * 4 * 512;        // one tap of the weight planes: [plane][k-piece][co][8 f16]
+constexpr int TP_WBYTES = 16 * TP_TAPB;          // weight planes: 64 KB
 
 // x + the value of lane ^ 32
 __device__ __forceinline__ float tp_pairsum32(float x) {
@@ -101,16 +107,6 @@ __device__ __forceinline__ float tp_pairsum32(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 #endif
-}
-
-// four consecutive fp32 values -> their three bf16 planes (4 bf16 = 8 bytes each), exact
-__device__ __forceinline__ void tp_split4(const float4& v, u32x2& h, u32x2& m, u32x2& l) {
-  h = odin_u2(odin_pack_bf16(v.x, v.y), odin_pack_bf16(v.z, v.w));
-  const float r0 = odin_bf16_rest(v.x), r1 = odin_bf16_rest(v.y), r2 = odin_bf16_rest(v.z),
-              r3 = odin_bf16_rest(v.w);
-  m = odin_u2(odin_pack_bf16(r0, r1), odin_pack_bf16(r2, r3));
-  l = odin_u2(odin_pack_bf16(odin_bf16_rest(r0), odin_bf16_rest(r1)),
-              odin_pack_bf16(odin_bf16_rest(r2), odin_bf16_rest(r3)));
 }
 
 struct alignas(8) TpEnt {
@@ -128,12 +124,14 @@ struct TpItem {
 // 4 = no epilogue micro-ops
 // EPI 0: raw partial sums (first of two reduction passes over 64 input channels); ACC: add the partial
 // sums the previous pass left in `out` before the epilogue.
-template <int EPI, int C1, int W, int DBG = 0, bool ACC = false>
+// SC: the input tensor is a gradient (scaled by 2^gexp on its way into the planes, the result scaled back)
+template <int EPI, int C1, int W, int DBG = 0, bool ACC = false, bool SC = false>
 __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
+  constexpr int NPL = TP_NPL;
   constexpr int RP = 64 / W;              // input rows per tile
   constexpr int NSLOT = 2 * RP + 3;       // live rows of a tile (RP + 2) + the next tile's (RP + 1 at an image seam)
-  constexpr int PB = (W + 2) * 64;        // one plane of a row: W + 2 pixels x 32 bf16
-  constexpr int RB = 3 * PB;
+  constexpr int PB = (W + 2) * 64;        // one plane of a row: W + 2 pixels x 32 f16
+  constexpr int RB = NPL * PB;
   constexpr int CPR = W / 8;              // 1 KB load items (8 pixels x 32 channels fp32) per row
   constexpr int CSHIFT = (W == 32) ? 2 : (W == 16) ? 1 : 0;
   ODIN_DYN_SMEM(char, smem);
@@ -177,6 +175,17 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     wv[j] = *reinterpret_cast<const float4*>(p.w + ((size_t)(tap * p.CO + n0 + co) * p.CS + p.ci_off + 4 * ci4));
   }
   const OdinRun IN = odin_run(p.in, (unsigned)((size_t)p.B * p.H * W * p.CS * 4));
+  // a gradient input is carried times 2^gk (its maximum lands in [2^14, 2^15)); the two accumulators are scaled back
+#ifdef ODIN_SIM
+  const int gk = SC ? odin_range_shift(odin_range_load(p.in_amax)) : 0;
+#else
+  const int gk = SC ? odin_range_shift(odin_range_load(p.in_amax)) : 0;
+#endif
+  const float in_s = SC ? odin_pow2(gk) : 1.f;
+  const float in_s2k = SC ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
+  const float out_s = SC ? odin_pow2(-gk) : 1.f;
+  const float out_sx = SC ? odin_pow2(-gk - 11) : ODIN_LO_UNSCALE;
+  float amx = 0.f;  // running max |out| of this lane (EPI 2 / 3: `out` is a gradient tensor)
   const int f_c = wave & (CPR - 1), f_r0 = wave >> CSHIFT;
   constexpr int F_RJ = 8 >> CSHIFT;  // rows between a wave's two items
   const int f_px = 8 * f_c + (lane >> 3), f_ch4 = lane & 7, f_pc = f_px + 1;
@@ -202,8 +211,8 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   ODIN_SCHED_FENCE();
 
   // ---- SAME-padding pixels (pc = 0 and pc = W + 1) of every ring row and plane: zero for ever ----
-  for (int e = tid; e < NSLOT * 24; e += 512) {
-    const int sl = e / 24, rem = e - sl * 24;
+  for (int e = tid; e < NSLOT * 8 * NPL; e += 512) {
+    const int sl = e / (8 * NPL), rem = e - sl * (8 * NPL);
     const int pl = rem >> 3, side = (rem >> 2) & 1, piece = rem & 3;
     *reinterpret_cast<float4*>(ring + sl * RB + pl * PB + (side ? (W + 1) * 64 : 0) + piece * 16) =
         make_float4(0.f, 0.f, 0.f, 0.f);
@@ -256,12 +265,11 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   // empty -- the kernel is bound by instruction issue, profiles/r03_kpmc_planes_8wave.txt)
   auto store_fill1 = [&](const TpItem& it) {
     if (it.ok) {
-      u32x2 h, m, l;
-      tp_split4(it.v, h, m, l);
+      u32x2 h, l;
+      odin_split_h4<SC>(it.v, in_s, in_s2k, h, l);
       char* d = ring + it.dst;
       *reinterpret_cast<u32x2*>(d) = h;
-      *reinterpret_cast<u32x2*>(d + PB) = m;
-      *reinterpret_cast<u32x2*>(d + 2 * PB) = l;
+      *reinterpret_cast<u32x2*>(d + PB) = l;
     }
   };
   auto store_fill = [&](const TpItem (&it)[2]) {
@@ -289,8 +297,8 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   }
   const int roff_a = rp + (rpar ? 2 : 1);  // padded row of row tap a relative to the tile's first
   const char* wlane = wl + half * 512 + l31 * 16;
-  const int tap_aa = (kh_a * 4 + kw_a) * 6144, tap_ab = (kh_a * 4 + kw_b) * 6144;
-  const int tap_ba = (kh_b * 4 + kw_a) * 6144, tap_bb = (kh_b * 4 + kw_b) * 6144;
+  const int tap_aa = (kh_a * 4 + kw_a) * TP_TAPB, tap_ab = (kh_a * 4 + kw_b) * TP_TAPB;
+  const int tap_ba = (kh_b * 4 + kw_a) * TP_TAPB, tap_bb = (kh_b * 4 + kw_b) * TP_TAPB;
 
   // ---- epilogue constants: accumulator register r holds channel n0 + (r & 3) + 8 (r >> 2) + 4 half.
   // Plain (unpacked) VALU arithmetic only: v_pk_*_f32 serialises with the bf16 matrix pipe, plain VALU
@@ -343,19 +351,18 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   const OdinRun TG = odin_run(EPI == 3 ? p.target : nullptr, tgt_bytes);
   const OdinRun LG = odin_run(EPI == 3 ? p.logits : nullptr, (EPI == 3 && p.logits != nullptr) ? tgt_bytes : 0u);
 
-  // ---- prologue, second half: the weights -> planes [tap][plane][k-piece][co][8 bf16], the first tile's rows ->
+  // ---- prologue, second half: the weights -> planes [tap][plane][k-piece][co][8 f16], the first tile's rows ->
   // ring (both loaded at the top of the kernel), then ONE barrier publishes them together with the pads and the table
   {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int e = tid + 512 * j;
       const int ci4 = e & 7, co = (e >> 3) & 31, tap = e >> 8;
-      u32x2 h, m, l;
-      tp_split4(wv[j], h, m, l);
-      char* d = wl + tap * 6144 + (ci4 >> 1) * 512 + co * 16 + (ci4 & 1) * 8;
+      u32x2 h, l;
+      odin_split_h4<false>(wv[j], 1.f, ODIN_LO_SCALE, h, l);
+      char* d = wl + tap * TP_TAPB + (ci4 >> 1) * 512 + co * 16 + (ci4 & 1) * 8;
       *reinterpret_cast<u32x2*>(d) = h;
-      *reinterpret_cast<u32x2*>(d + 2048) = m;
-      *reinterpret_cast<u32x2*>(d + 4096) = l;
+      *reinterpret_cast<u32x2*>(d + 2048) = l;
     }
   }
   store_fill(itA);
@@ -394,6 +401,9 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   auto elu_r = [&](int r) { elu_b(r, bias_r[((EPI == 1 || EPI == 3) && !CL) ? r : 0]); };
   auto store_q = [&](int q) __attribute__((always_inline)) {
     if (DBG & 1) return;
+    if (EPI >= 2)
+      amx = fmaxf(fmaxf(amx, fmaxf(fabsf(pa[4 * q]), fabsf(pa[4 * q + 1]))),
+                  fmaxf(fabsf(pa[4 * q + 2]), fabsf(pa[4 * q + 3])));
     odin_run_store4s(OUT, out_lane + 32 * q, tileP_out,
                      make_float4(pa[4 * q], pa[4 * q + 1], pa[4 * q + 2], pa[4 * q + 3]));
   };
@@ -587,18 +597,17 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     if (sb >= NSLOT) sb -= NSLOT;
     const char* row_a = ring + sa * RB;
     const char* row_b = ring + sb * RB;
-    // (one accumulator chain: a second one measured no faster -- 5888 vs 5808 cycles per tile -- and
-    // costs 16 registers + 16 adds)
-    f32x16 acc = f32x16_zero();
-    u32x4 fa[2][3], fb[2][3];
+    // two accumulator chains: main (h x h) and cross (h x l + l x h, carried times 2^11)
+    f32x16 acc = f32x16_zero(), acx = f32x16_zero();
+    u32x4 fa[2][NPL], fb[2][NPL];
     // 8 steps = 4 taps (a/a, a/b, b/a, b/b) x 2 k-halves of 16 channels
-    auto loads = [&](int s, u32x4 (&A)[3], u32x4 (&Bf)[3]) {
+    auto loads = [&](int s, u32x4 (&A)[NPL], u32x4 (&Bf)[NPL]) {
       const int tp = s >> 1, kk = s & 1;
       const bool ra = tp < 2, ca = (tp & 1) == 0;
       const char* bp = (ra ? row_a : row_b) + (ca ? offA[kk] : offB[kk]);
       const char* ap = wlane + (ra ? (ca ? tap_aa : tap_ab) : (ca ? tap_ba : tap_bb)) + kk * 1024;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < NPL; ++pl) {
         A[pl] = *reinterpret_cast<const u32x4*>(ap + pl * 2048);
         Bf[pl] = *reinterpret_cast<const u32x4*>(bp + pl * PB);
       }
@@ -613,31 +622,16 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) axN[q] = pvN[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     ODIN_SCHED_FENCE();
-    tp_static_for<48>([&](auto M) __attribute__((always_inline)) {
-      constexpr int m = decltype(M)::value;
-      constexpr int s = m / 6, u = m % 6, cur = s & 1, nxt = cur ^ 1;
-      if constexpr (u == 0) {
-        // the six reads of step s + 1 go out before the MFMAs of step s (a read issued one MFMA before its
-        // use exposes the LDS latency)
-        if (s + 1 < 8 && !(DBG & 2)) loads(s + 1, fa[nxt], fb[nxt]);
-        if (s + 1 < 8 && (DBG & 2)) {
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) { fa[nxt][pl] = fa[cur][pl]; fb[nxt][pl] = fb[cur][pl]; }
-        }
-      }
-      // plane products, smallest first: 0*2, 2*0, 1*1, 0*1, 1*0, 0*0 (weights x pixels)
-      if (u == 0) acc = mfma32_bf16(fa[cur][0], fb[cur][2], acc);
-      if (u == 1) acc = mfma32_bf16(fa[cur][2], fb[cur][0], acc);
-      if (u == 2) acc = mfma32_bf16(fa[cur][1], fb[cur][1], acc);
-      if (u == 3) acc = mfma32_bf16(fa[cur][0], fb[cur][1], acc);
-      if (u == 4) acc = mfma32_bf16(fa[cur][1], fb[cur][0], acc);
-      if (u == 5) acc = mfma32_bf16(fa[cur][0], fb[cur][0], acc);
-      // MFMA m carries: the 8 activation ops (2 x ~6 VALU + 2 transcendentals each) behind every
-      // other MFMA of the first 16, the remaining ops one per MFMA, the row stores in steps 6 and 7
+    // what rides behind the MFMAs, by SLOT: the slot schedule was laid out for the 48 MFMAs of the three-plane form and
+    // is kept -- MFMA M of the 24 carries slots 2 M and 2 M + 1
+    auto slot = [&](auto MS) __attribute__((always_inline)) {
+      constexpr int m = decltype(MS)::value;
+      // the 8 activation ops (2 x ~6 VALU + 2 transcendentals each) in every other slot of the first 16, the remaining
+      // ops one per slot, the row stores in the last two steps
       constexpr int me = m - ESH;
       constexpr int k = me < 0 ? -1 : (me < 16 ? ((me & 1) ? -1 : me / 2) : me - 8);
       if constexpr (WE && !CL && k >= 0 && k < N_EPI_OPS && !(DBG & 4)) epi_op(k);
-      if constexpr (WE && CL && !(DBG & 4)) cl_slot(M);
+      if constexpr (WE && CL && !(DBG & 4)) cl_slot(MS);
       if (m == 20) fill_entries(en, T - T0 + 2);
       if (m == 32) fill_loads(itB, en);  // global loads of tile T + 2's rows
       if (m == 33) {                            // this tile's epilogue operands (used one tile later)
@@ -660,12 +654,32 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
       if (WE && m == FL && t_cur == 0) flush_llk(T - 1);
       if (m == SF0) store_fill1(itA[0]);
       if (m == SF1) store_fill1(itA[1]);
+    };
+    tp_static_for<24>([&](auto MM) __attribute__((always_inline)) {
+      constexpr int M = decltype(MM)::value;
+      constexpr int s = M / 3, u = M % 3, cur = s & 1, nxt = cur ^ 1;
+      if constexpr (u == 0) {
+        // the four reads of step s + 1 go out before the MFMAs of step s (a read issued one MFMA before its
+        // use exposes the LDS latency)
+        if (s + 1 < 8 && !(DBG & 2)) loads(s + 1, fa[nxt], fb[nxt]);
+        if (s + 1 < 8 && (DBG & 2)) {
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) { fa[nxt][pl] = fa[cur][pl]; fb[nxt][pl] = fb[cur][pl]; }
+        }
+      }
+      // plane products (weights x pixels): h*l and l*h into the cross accumulator, h*h into the main one
+      if (u == 0) acx = mfma32_f16(fa[cur][0], fb[cur][1], acx);
+      if (u == 1) acc = mfma32_f16(fa[cur][0], fb[cur][0], acc);
+      if (u == 2) acx = mfma32_f16(fa[cur][1], fb[cur][0], acx);
+      slot(std::integral_constant<int, 2 * M>{});
+      slot(std::integral_constant<int, 2 * M + 1>{});
       ODIN_SCHED_FENCE();
 #ifdef ODIN_DIAG
-      if (m == 0 || m == 11 || m == 23 || m == 35 || m == 47) TP_STAMP(12 + (m + 1) / 12);
+      if (M == 0 || M == 5 || M == 11 || M == 17 || M == 23) TP_STAMP(12 + (M + 1) / 6);
 #endif
     });
-    pa = acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pa[r] = SC ? fmaf(acx[r], out_sx, acc[r] * out_s) : fmaf(acx[r], out_sx, acc[r]);
     tileP_out = tile_out;
     tileP_tgt = tile_tgt;
 #pragma unroll
@@ -717,6 +731,11 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
     p.stamps[67] = wall_clock64();
   }
 #endif
+  if (EPI >= 2) {
+    __syncthreads();
+    odin_amax_commit_wg(p.out_amax, amx, tid, 512, cred, blockIdx.x + gridDim.x * blockIdx.y);
+    __syncthreads();  // (cred is reused below)
+  }
   // ---- per-workgroup partial sums: 32 pixel lanes by shuffles, then the 8 waves through LDS ----
   if (EPI >= 2) {
 #pragma unroll
@@ -779,7 +798,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
 
 // LDS: weight planes + row ring + the fill table (rows per fill x 8 bytes per fill, tiles + 3 fills); 4.3 KB are static
 constexpr int TP_LDS_MAX = 155 * 1024;
-int tp_ring_bytes(int W) { return TP_WBYTES + (2 * (64 / W) + 3) * 3 * (W + 2) * 64; }
+int tp_ring_bytes(int W) { return TP_WBYTES + (2 * (64 / W) + 3) * TP_NPL * (W + 2) * 64; }
 int tp_fill_bytes(int W) { return 8 * 2 * (W == 32 ? 2 : W == 16 ? 4 : 8); }
 // tiles per workgroup: the chip filled once when the table fits, more workgroups otherwise; -1: does not fit
 int tp_tiles_per_wg(int W, int n_tiles, int gy) {
@@ -793,16 +812,16 @@ int tp_tiles_per_wg(int W, int n_tiles, int gy) {
   return tpw;
 }
 
-template <int EPI, int C1, bool ACC>
+template <int EPI, int C1, bool ACC, bool SC>
 int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
   const size_t lds = (size_t)tp_ring_bytes(W) + (size_t)(p.tiles_per_wg + 3) * tp_fill_bytes(W);  // + the fill table
   constexpr int W3 = (EPI == 3 ? 16 : 8);  // (the fused tail has no 8-pixel geometry)
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    const void* fns[3] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 0, ACC>),
-                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 16, 0, ACC>),
-                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, W3, 0, ACC>)};
+    const void* fns[3] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 0, ACC, SC>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 16, 0, ACC, SC>),
+                          reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, W3, 0, ACC, SC>)};
     for (int i = 0; i < 3; ++i)
       if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
         (void)hipGetLastError();
@@ -815,26 +834,26 @@ int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
     static const int dbg = [] { const char* e = getenv("ODIN_TP_DBG"); return e ? atoi(e) : 0; }();
     static bool dattr = false;
     if (!dattr) {
-      const void* dfn[4] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 1, ACC>),
-                            reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 2, ACC>),
-                            reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 4, ACC>),
-                            reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 7, ACC>)};
+      const void* dfn[4] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 1, ACC, SC>),
+                            reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 2, ACC, SC>),
+                            reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 4, ACC, SC>),
+                            reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 7, ACC, SC>)};
       for (int i = 0; i < 4; ++i)
         if (hipFuncSetAttribute(dfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
           (void)hipGetLastError();
       dattr = true;
     }
-    if (dbg == 1) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 1, ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
-    if (dbg == 2) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 2, ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
-    if (dbg == 4) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 4, ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
-    if (dbg == 7) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 7, ACC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(bf16x3)"); }
+    if (dbg == 1) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 1, ACC, SC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(f16x2)"); }
+    if (dbg == 2) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 2, ACC, SC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(f16x2)"); }
+    if (dbg == 4) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 4, ACC, SC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(f16x2)"); }
+    if (dbg == 7) { ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 7, ACC, SC>), grid, dim3(512), lds, stream, p); return odin_check_launch("tconv_planes(f16x2)"); }
   }
 #endif
 #endif
-  if (W == 32) ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 0, ACC>), grid, dim3(512), lds, stream, p);
-  else if (W == 16) ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 16, 0, ACC>), grid, dim3(512), lds, stream, p);
-  else ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, W3, 0, ACC>), grid, dim3(512), lds, stream, p);
-  return odin_check_launch("tconv_planes(bf16x3)");
+  if (W == 32) ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 32, 0, ACC, SC>), grid, dim3(512), lds, stream, p);
+  else if (W == 16) ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, 16, 0, ACC, SC>), grid, dim3(512), lds, stream, p);
+  else ODIN_LAUNCH((tconv_planes_kernel<EPI, C1, W3, 0, ACC, SC>), grid, dim3(512), lds, stream, p);
+  return odin_check_launch("tconv_planes(f16x2)");
 }
 
 }  // namespace
@@ -860,7 +879,7 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
                              float* out, float* colsum, int* rows_out, const float* w1, const float* b1,
                              const float* target, float* logits, float* llk_part, int* n_part_out,
                              float* slab, const float* scale, int C1, int B, int H, int W, int CI,
-                             int CO, int epi, void* stream) {
+                             int CO, int epi, const uint32_t* in_amax, uint32_t* out_amax, void* stream) {
   TPParams p;
   memset(&p, 0, sizeof(p));
   p.in = in; p.w = w; p.bias = bias; p.aux = aux; p.out = out; p.colsum = colsum;
@@ -879,19 +898,25 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
   if (rows_out) *rows_out = gx;
   if (n_part_out) *n_part_out = p.tiles_per_img;
   if (out == nullptr) return 0;  // dry run
+  if (epi == 2) {
+    p.in_amax = odin_range_word_of(in, (size_t)B * H * W * CI, in_amax, stream);
+    if (p.in_amax == nullptr) return odin_fail(-3, "tconv_planes: no range word for the gradient input");
+  }
+  if (epi >= 2) p.out_amax = out_amax;
   dim3 grid(gx, gy, 1);
   if (CI == 64) {
     if (epi == 3) return odin_fail(-2, "tconv_planes tail: 32 input channels only");
     TPParams q = p;
     q.colsum = nullptr;
-    const int rc = tp_launch_w<0, 1, false>(q, W, grid, stream);
+    q.out_amax = nullptr;
+    const int rc = epi == 1 ? tp_launch_w<0, 1, false, false>(q, W, grid, stream) : tp_launch_w<0, 1, false, true>(q, W, grid, stream);
     if (rc != 0) return rc;
     p.ci_off = 32;
-    return epi == 1 ? tp_launch_w<1, 1, true>(p, W, grid, stream) : tp_launch_w<2, 1, true>(p, W, grid, stream);
+    return epi == 1 ? tp_launch_w<1, 1, true, false>(p, W, grid, stream) : tp_launch_w<2, 1, true, true>(p, W, grid, stream);
   }
-  if (epi == 1) return tp_launch_w<1, 1, false>(p, W, grid, stream);
-  if (epi == 2) return tp_launch_w<2, 1, false>(p, W, grid, stream);
-  if (C1 == 1) return tp_launch_w<3, 1, false>(p, W, grid, stream);
-  if (C1 == 3) return tp_launch_w<3, 3, false>(p, W, grid, stream);
+  if (epi == 1) return tp_launch_w<1, 1, false, false>(p, W, grid, stream);
+  if (epi == 2) return tp_launch_w<2, 1, false, true>(p, W, grid, stream);
+  if (C1 == 1) return tp_launch_w<3, 1, false, false>(p, W, grid, stream);
+  if (C1 == 3) return tp_launch_w<3, 3, false, false>(p, W, grid, stream);
   return odin_fail(-2, "tconv_planes tail: one or three logit maps only");
 }

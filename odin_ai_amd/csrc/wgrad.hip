@@ -46,6 +46,7 @@ struct WParams {
   int flat, n_batches;  // Dense: IN tile is one contiguous [NIMG, CIB] block
   long long* stamps;
   int bias_mode;  // 0 none, 1 extra MFMA tile with A = 1, 2 summed while staging DY
+  const uint32_t* g_amax;  // range word of the gradient operand (wgrad_planes only; may be null)
 };
 
 // ---- staging ------------------------------------------------------------------------
@@ -1036,7 +1037,7 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
   if (odin_wgrad_planes_applicable(p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO, p.KH, p.KW, p.S, p.pt, p.pl,
                                    p.center))
     return odin_wgrad_planes_launch(p.in, p.dy, p.slab, rows_out, p.B, p.OH, p.OW, p.CI, p.CO,
-                                    p.want_bias, stream);
+                                    p.want_bias, p.want_bias ? 0 : 1, p.g_amax, stream);
   if (odin_igemm_wgrad_applicable(p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO, p.KH, p.KW, p.S, p.center)) {
     if (rows_out) *rows_out = odin_igemm_wgrad_rows(p.B, p.OH, p.OW, p.KH, p.KW, p.CI, p.CO);
     if (p.slab == nullptr) return 0;  // dry run
@@ -1266,6 +1267,7 @@ extern "C" int odin_conv2d_wgrad(const float* x, const float* dy, float* slab,
   p.B = d->B; p.H = d->H; p.W = d->W; p.CI = d->Cin; p.OH = d->OH; p.OW = d->OW; p.CO = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.S = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
   p.center = d->center; p.want_bias = 1;
+  p.g_amax = d->dy_amax;
   return launch_wgrad(p, slab_rows_out, stream);
 }
 
@@ -1278,6 +1280,7 @@ extern "C" int odin_deconv2d_wgrad(const float* x, const float* dy, float* slab,
   p.B = d->B; p.H = d->OH; p.W = d->OW; p.CI = d->Cout; p.OH = d->H; p.OW = d->W; p.CO = d->Cin;
   p.KH = d->KH; p.KW = d->KW; p.S = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
   p.center = 0; p.want_bias = 0;
+  p.g_amax = d->dy_amax;
   return launch_wgrad(p, slab_rows_out, stream);
 }
 

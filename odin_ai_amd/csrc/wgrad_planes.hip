@@ -1,7 +1,7 @@
 // wgrad_planes.hip -- WEIGHT GRADIENT of the 4x4 / stride-2 layers (Conv2D and Conv2DTranspose, TF
-// `SAME`, pads (1, 1)) with BOTH fp32 operands carried through the bf16 matrix pipe as three exact bf16
-// planes (odin_device.h: x = x0 + x1 + x2 by truncation; six plane products per 16 k-values,
-// fp32 accumulation, <= 3 * 2^-24 per product).
+// `SAME`, pads (1, 1)) with BOTH fp32 operands carried through the f16 matrix pipe as two f16 planes
+// (odin_device.h: x = h + 2^-11 l; three plane products per 16 k-values into a main and a cross fp32
+// accumulator, <= 3 * 2^-22 per product; the gradient operand is carried times 2^gexp).
 //
 // One formulation serves both layer kinds.  With a FINE tensor U [B, 2h, 2w, CU] and a COARSE tensor
 // V [B, h, w, CV] related by coarse pixel (i, j) <-> fine pixel (2 i - 1 + kh, 2 j - 1 + kw):
@@ -11,9 +11,9 @@
 //   Conv2DTranspose (image_networks.py:499-506): U = dL/d pre-activation,    V = layer input,
 //                                                dW in Keras' (kh, kw, Cout, Cin)
 // (tape.gradient of the step, base_networks.py:549.)  The MFMA reduction index is the PIXEL: a
-// v_mfma_f32_32x32x16_bf16 multiplies A = U^T [32 cu][16 pixels] by B = V [16 pixels][32 cv].  Both
+// v_mfma_f32_32x32x16_f16 multiplies A = U^T [32 cu][16 pixels] by B = V [16 pixels][32 cv].  Both
 // operands are channel-major fragments of pixel-major data: the LDS images stay [pixel][32 channels]
-// (written exactly as in tconv_planes.hip: global_load -> split once -> three ds_write_b64) and the
+// (written exactly as in tconv_planes.hip: global_load -> split once -> two ds_write_b64) and the
 // fragments are fetched with ds_read_b64_tr_b16, the transposing LDS read of gfx950 (a 16-lane group
 // reads 4 pixels x 16 channels and every lane receives one channel's 4 pixels).  A shift by one
 // coarse column (kw >= 2) is a shift by one 64-byte pixel slot: always aligned.
@@ -23,12 +23,14 @@
 // coarse pixels (1, 2 or 4 coarse rows) = 2 chunks of 16: per chunk 6 transposed reads of V (shared by
 // the wave's two taps), 12 of U, 12 MFMAs.  Rolling row windows in LDS (slot = global padded row mod
 // NS), fine rows as two column-parity planes so that the 16 pixels of a chunk are consecutive slots;
+// per chunk 4 transposed reads of V, 8 of U, 6 MFMAs;
 // the split + store of the next tile's rows and the global loads of the one after ride in the MFMA
 // stream; one workgroup barrier per tile.  No epilogue: the accumulators go to this workgroup's slab
 // row once, at the end (odin_slab_reduce sums the rows in fixed order).
 #include "odin_device.h"
 #include "odin_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -41,17 +43,8 @@ struct WPParams {
   int want_bias;
   int slab_stride;
   int tiles_per_img, n_tiles, tiles_per_wg;
+  const unsigned* g_amax;  // range word (odin_device.h) of the gradient operand (GU: U, else V)
 };
-
-// four consecutive fp32 values -> their three bf16 planes (4 bf16 = 8 bytes each), exact
-__device__ __forceinline__ void wp_split4(const float4& v, u32x2& h, u32x2& m, u32x2& l) {
-  h = odin_u2(odin_pack_bf16(v.x, v.y), odin_pack_bf16(v.z, v.w));
-  const float r0 = odin_bf16_rest(v.x), r1 = odin_bf16_rest(v.y), r2 = odin_bf16_rest(v.z),
-              r3 = odin_bf16_rest(v.w);
-  m = odin_u2(odin_pack_bf16(r0, r1), odin_pack_bf16(r2, r3));
-  l = odin_u2(odin_pack_bf16(odin_bf16_rest(r0), odin_bf16_rest(r1)),
-              odin_pack_bf16(odin_bf16_rest(r2), odin_bf16_rest(r3)));
-}
 
 // ds_read_b64_tr_b16: `blk` = byte address of a block of 4 rows (`stride` bytes apart) x 16 bf16 columns;
 // lane l16 of the 16-lane group receives column l16 of the 4 rows (row q in element q).  On the
@@ -82,8 +75,10 @@ constexpr int WP_MAXU = 4;  // 1 KB load items (8 pixels x 32 channels) of fine 
 
 // W = coarse row length (8, 16 or 32); DBG (diagnostics, ODIN_WP_DBG): 1 no MFMAs, 2 no LDS reads in the loop,
 // 4 no row fills after the prologue
-template <int W, int DBG = 0>
+// GU: the gradient operand is U (Conv2DTranspose), else V (Conv2D)
+template <int W, bool GU, int DBG = 0>
 __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
+  constexpr int NPL = 2;                 // f16 planes per operand
   constexpr int TC = 32 / W;             // coarse rows per tile
   constexpr int WU = 2 * W;              // fine row length
   constexpr int SU = W + 1;              // slots per column-parity plane of a fine row
@@ -91,10 +86,10 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   // but moves the parity-1 plane's transposed reads onto shared banks: measured 66.5 -> 70.1 us on decoder4.)
   constexpr int PARB = SU * 64;
   constexpr int PBU = 2 * PARB;          // one bf16 plane of a fine row
-  constexpr int RBU = 3 * PBU;
+  constexpr int RBU = NPL * PBU;
   constexpr int NSU = 4 * TC + 3;        // live fine rows (2 TC + 2) + the next tile's (2 TC + 1 at an image seam)
   constexpr int PBV = W * 64;
-  constexpr int RBV = 3 * PBV;
+  constexpr int RBV = NPL * PBV;
   constexpr int NSV = 2 * TC;
   constexpr int IPU = WU / 8;            // load items per fine row: 8, 4, 2
   constexpr int IPV = W / 8;             // per coarse row: 4, 2, 1
@@ -164,8 +159,8 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
 
   // ---- SAME-padding slots of every fine ring row and plane: parity plane 0 slot 0 (padded column 0)
   // and parity plane 1 slot W (padded column 2 w + 1): zero for ever ----
-  for (int e = tid; e < NSU * 24; e += 512) {
-    const int sl = e / 24, rem = e - sl * 24;
+  for (int e = tid; e < NSU * 8 * NPL; e += 512) {
+    const int sl = e / (8 * NPL), rem = e - sl * (8 * NPL);
     const int pl = rem >> 3, side = (rem >> 2) & 1, piece = rem & 3;
     *reinterpret_cast<float4*>(uring + sl * RBU + pl * PBU + (side ? PARB + W * 64 : 0) + piece * 16) =
         make_float4(0.f, 0.f, 0.f, 0.f);
@@ -232,25 +227,31 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
     iv.dst = (en.v.x + v_lds_item) | v_none_dst;
     iv.v = odin_run_load4(RV, ((unsigned)en.v.y + v_colb) | v_none_off);
   };
-  auto store_item = [&](const WpItem& it, int plane_bytes) {
+  // the gradient operand is carried times 2^gk (its maximum lands in [2^14, 2^15)), the sums are scaled back at the end
+#ifdef ODIN_SIM
+  const int gk = odin_range_shift(odin_range_load(p.g_amax));
+#else
+  const int gk = odin_range_shift(odin_range_load(p.g_amax));
+#endif
+  const float g_s = odin_pow2(gk), g_s2k = odin_pow2(gk + 11);
+  auto store_item = [&](const WpItem& it, int plane_bytes, auto is_grad) {
 #ifdef ODIN_SIM
     if (it.dst < 0) return;
 #else
     if (__builtin_amdgcn_readfirstlane(it.dst) < 0) return;  // wave-uniform: a scalar branch
 #endif
-    u32x2 h, m, l;
-    wp_split4(it.v, h, m, l);
+    u32x2 h, l;
+    odin_split_h4<decltype(is_grad)::value>(it.v, g_s, g_s2k, h, l);
     char* d = smem + it.dst;
     *reinterpret_cast<u32x2*>(d) = h;
-    *reinterpret_cast<u32x2*>(d + plane_bytes) = m;
-    *reinterpret_cast<u32x2*>(d + 2 * plane_bytes) = l;
+    *reinterpret_cast<u32x2*>(d + plane_bytes) = l;
   };
   // item k of a fill: 0 .. WP_MAXU - 1 fine-row items, WP_MAXU: the coarse-row item (+ its bias sums)
   auto store_fill_item = [&](const WpItem (&iu)[WP_MAXU], const WpItem& iv, int k) {
     if (k < WP_MAXU) {
-      store_item(iu[k], PBU);
+      store_item(iu[k], PBU, std::integral_constant<bool, GU>{});
     } else {
-      store_item(iv, PBV);
+      store_item(iv, PBV, std::integral_constant<bool, !GU>{});
       bsum4.x += iv.v.x; bsum4.y += iv.v.y; bsum4.z += iv.v.z; bsum4.w += iv.v.w;  // (absent items hold zeros)
     }
   };
@@ -274,7 +275,8 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
     kcol[blk] = (W >= 16) ? kpix[blk] : (kpix[blk] & 7);
   }
 
-  f32x16 acc[2] = {f32x16_zero(), f32x16_zero()};
+  f32x16 acc[2] = {f32x16_zero(), f32x16_zero()};  // main sums (h x h)
+  f32x16 acx[2] = {f32x16_zero(), f32x16_zero()};  // cross sums (h x l + l x h), times 2^11
   // ---- prologue: rows of the first tile into LDS; ONE barrier publishes them with the pads and the tables; then
   // the second and third tile's rows into registers ----
   FillEnt en;
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   int su0 = 0, sv0 = 0;
 
   // fragments of one 16-pixel chunk: V (3 planes) and U for the wave's two taps
-  struct Frags { u32x4 fv[3]; u32x4 fu[2][3]; };
+  struct Frags { u32x4 fv[NPL]; u32x4 fu[2][NPL]; };
   auto read_chunk = [&](int c, Frags& F) {
     // chunk c: coarse rows row0 (+ krow), columns j0 + kcol
     const int row0 = (W == 32) ? 0 : (W == 16) ? c : 2 * c;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
       const char* vb = vring + sv * RBV + (j0 + kcol[blk] - q) * 64 + colb - (l16 & 3) * 8;
       const char* ub = uring + su * RBU + (j0 + kcol[blk] - q) * 64 + colb - (l16 & 3) * 8;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < NPL; ++pl) {
         const u32x2 tv = wp_tr_read(vb + pl * PBV, 64, l16);
         F.fv[pl][2 * blk] = tv.x; F.fv[pl][2 * blk + 1] = tv.y;
 #pragma unroll
@@ -318,19 +320,22 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
       }
     }
   };
-  // the 12 MFMAs of a chunk (plane products, smallest first: 0*2, 2*0, 1*1, 0*1, 1*0, 0*0; the two taps
-  // alternate so that consecutive MFMAs are independent); behind MFMA m one item of the next tile's
-  // rows is split and stored (bf16 MFMAs run beside plain VALU work)
+  // the 6 MFMAs of a chunk (plane products h*l, l*h into the cross accumulator, h*h into the main one; the two
+  // taps alternate so that consecutive MFMAs are independent); behind every other MFMA one item of the next tile's
+  // rows is split and stored (f16 MFMAs run beside plain VALU work)
   auto mfma_chunk = [&](const Frags& F, int item0, const WpItem (&stu)[WP_MAXU], const WpItem& stv) {
 #pragma unroll
-    for (int m = 0; m < 12; ++m) {
+    for (int m = 0; m < 6; ++m) {
       const int t = m & 1, pp = m >> 1;
-      const int ia = (pp == 0) ? 0 : (pp == 1) ? 2 : (pp == 2) ? 1 : (pp == 3) ? 0 : (pp == 4) ? 1 : 0;
-      const int ib = (pp == 0) ? 2 : (pp == 1) ? 0 : (pp == 2) ? 1 : (pp == 3) ? 1 : (pp == 4) ? 0 : 0;
-      if (!(DBG & 1)) acc[t] = mfma32_bf16(F.fu[t][ia], F.fv[ib], acc[t]);
-      else acc[t][m] += odin_bitsf(F.fu[t][ia][0] ^ F.fv[ib][1]);
-      if ((m & 3) == 1) {
-        const int k = item0 + (m >> 2);
+      if (!(DBG & 1)) {
+        if (pp == 0) acx[t] = mfma32_f16(F.fu[t][0], F.fv[1], acx[t]);
+        if (pp == 1) acx[t] = mfma32_f16(F.fu[t][1], F.fv[0], acx[t]);
+        if (pp == 2) acc[t] = mfma32_f16(F.fu[t][0], F.fv[0], acc[t]);
+      } else {
+        acc[t][m] += odin_bitsf(F.fu[t][pp & 1][0] ^ F.fv[pp & 1][1]);
+      }
+      if ((m & 1) == 1) {
+        const int k = item0 + (m >> 1);
         if (k <= WP_MAXU && !(DBG & 4) && !(DBG & 16)) store_fill_item(stu, stv, k);
         if (k <= WP_MAXU && (DBG & 16)) {  // keep the loads alive without the split / LDS stores
           const float4 t = k < WP_MAXU ? stu[k].v : stv.v;
@@ -370,13 +375,14 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
 
   // ---- this workgroup's slab row: dW[tap][cu0 + cu][cv0 + cv], lane = column cv = l31 ----
   float* row = p.slab + (size_t)blockIdx.x * p.slab_stride;
+  const float o_s = odin_pow2(-gk), o_sx = odin_pow2(-gk - 11);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int tap = kh * 4 + kw0 + t;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cu = (r & 3) + 8 * (r >> 2) + 4 * half;
-      row[((size_t)tap * p.CUt + cu0 + cu) * p.CVt + cv0 + l31] = acc[t][r];
+      row[((size_t)tap * p.CUt + cu0 + cu) * p.CVt + cv0 + l31] = fmaf(acx[t][r], o_sx, acc[t][r] * o_s);
     }
   }
   if (p.want_bias && blockIdx.y == 0) {
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
 constexpr int WP_LDS_MAX = 156 * 1024;
 int wp_ring_bytes(int W) {
   const int TC = 32 / W;
-  return (4 * TC + 3) * 3 * 2 * (W + 1) * 64 + (2 * TC) * 3 * W * 64;
+  return (4 * TC + 3) * 2 * 2 * (W + 1) * 64 + (2 * TC) * 2 * W * 64;
 }
 int wp_fill_bytes(int W) {
   const int ipu = 2 * W / 8, rj = 8 / ipu > 0 ? 8 / ipu : 1;
@@ -422,13 +428,13 @@ int wp_tiles_per_wg(int W, int n_tiles, int gyz) {
   return tpw;
 }
 
-template <int W>
+template <int W, bool GU>
 int wp_launch(const WPParams& p, dim3 grid, void* stream) {
   const size_t lds = (size_t)wp_ring_bytes(W) + (size_t)(p.tiles_per_wg + 4) * wp_fill_bytes(W);
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<W>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<W, GU>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS_MAX) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
@@ -436,30 +442,32 @@ int wp_launch(const WPParams& p, dim3 grid, void* stream) {
 #ifdef ODIN_DIAG
   // diagnostics build only (make diag): instances with parts of the kernel switched off, selected by
   // ODIN_WP_DBG -- they compute WRONG results and are not in the product library
-  if (W == 32) {
+  if (W == 32 && GU) {
     static const int dbg = [] { const char* e = getenv("ODIN_WP_DBG"); return e ? atoi(e) : 0; }();
     static bool dattr = false;
+    constexpr int D1 = (W == 32 && GU) ? 1 : 0, D2 = (W == 32 && GU) ? 2 : 0, D4 = (W == 32 && GU) ? 4 : 0,
+                  D8 = (W == 32 && GU) ? 8 : 0, D16 = (W == 32 && GU) ? 16 : 0;
     if (!dattr) {
-      const void* fns[5] = {reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 1 : 0)>),
-                            reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 2 : 0)>),
-                            reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 4 : 0)>),
-                            reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 8 : 0)>),
-                            reinterpret_cast<const void*>(&wgrad_planes_kernel<W, (W == 32 ? 16 : 0)>)};
+      const void* fns[5] = {reinterpret_cast<const void*>(&wgrad_planes_kernel<W, GU, D1>),
+                            reinterpret_cast<const void*>(&wgrad_planes_kernel<W, GU, D2>),
+                            reinterpret_cast<const void*>(&wgrad_planes_kernel<W, GU, D4>),
+                            reinterpret_cast<const void*>(&wgrad_planes_kernel<W, GU, D8>),
+                            reinterpret_cast<const void*>(&wgrad_planes_kernel<W, GU, D16>)};
       for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS_MAX) != hipSuccess)
           (void)hipGetLastError();
       dattr = true;
     }
-    if (dbg == 1) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 1 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
-    if (dbg == 2) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 2 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
-    if (dbg == 4) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 4 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
-    if (dbg == 8) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 8 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
-    if (dbg == 16) { ODIN_LAUNCH((wgrad_planes_kernel<W, (W == 32 ? 16 : 0)>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(bf16x3)"); }
+    if (dbg == 1) { ODIN_LAUNCH((wgrad_planes_kernel<W, GU, D1>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(f16x2)"); }
+    if (dbg == 2) { ODIN_LAUNCH((wgrad_planes_kernel<W, GU, D2>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(f16x2)"); }
+    if (dbg == 4) { ODIN_LAUNCH((wgrad_planes_kernel<W, GU, D4>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(f16x2)"); }
+    if (dbg == 8) { ODIN_LAUNCH((wgrad_planes_kernel<W, GU, D8>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(f16x2)"); }
+    if (dbg == 16) { ODIN_LAUNCH((wgrad_planes_kernel<W, GU, D16>), grid, dim3(512), lds, stream, p); return odin_check_launch("wgrad_planes(f16x2)"); }
   }
 #endif
 #endif
-  ODIN_LAUNCH((wgrad_planes_kernel<W>), grid, dim3(512), lds, stream, p);
-  return odin_check_launch("wgrad_planes(bf16x3)");
+  ODIN_LAUNCH((wgrad_planes_kernel<W, GU>), grid, dim3(512), lds, stream, p);
+  return odin_check_launch("wgrad_planes(f16x2)");
 }
 
 }  // namespace
@@ -475,8 +483,10 @@ bool odin_wgrad_planes_applicable(int B, int H, int W, int CI, int OH, int OW, i
          wp_tiles_per_wg(OW, B * (OH / (32 / OW)), (CI / 32) * (CO / 32)) > 0;
 }
 
+// grad_u: the gradient operand is U (Conv2DTranspose) rather than V (Conv2D)
 int odin_wgrad_planes_launch(const float* U, const float* V, float* slab, int* rows_out, int B, int OH,
-                             int OW, int CI, int CO, int want_bias, void* stream) {
+                             int OW, int CI, int CO, int want_bias, int grad_u, const uint32_t* g_amax,
+                             void* stream) {
   WPParams p;
   memset(&p, 0, sizeof(p));
   p.U = U; p.V = V; p.slab = slab;
@@ -491,8 +501,16 @@ int odin_wgrad_planes_launch(const float* U, const float* V, float* slab, int* r
   const int gx = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
   if (rows_out) *rows_out = gx;
   if (slab == nullptr) return 0;  // dry run
+  p.g_amax = grad_u ? odin_range_word_of(U, (size_t)B * 2 * OH * 2 * OW * CI, g_amax, stream)
+                    : odin_range_word_of(V, (size_t)B * OH * OW * CO, g_amax, stream);
+  if (p.g_amax == nullptr) return odin_fail(-3, "wgrad_planes: no range word for the gradient operand");
   dim3 grid(gx, gy, gz);
-  if (OW == 32) return wp_launch<32>(p, grid, stream);
-  if (OW == 16) return wp_launch<16>(p, grid, stream);
-  return wp_launch<8>(p, grid, stream);
+  if (grad_u) {
+    if (OW == 32) return wp_launch<32, true>(p, grid, stream);
+    if (OW == 16) return wp_launch<16, true>(p, grid, stream);
+    return wp_launch<8, true>(p, grid, stream);
+  }
+  if (OW == 32) return wp_launch<32, false>(p, grid, stream);
+  if (OW == 16) return wp_launch<16, false>(p, grid, stream);
+  return wp_launch<8, false>(p, grid, stream);
 }

@@ -128,13 +128,21 @@ def build_layers(net: str, layers: Sequence[tuple], in_shape: Tuple[int, ...],
 # --------------------------------------------------------------------------------------
 # one sequential network bound to buffers for a fixed batch size
 # --------------------------------------------------------------------------------------
+RANGE_WORDS = 2048  # include/odin_hip.h: ODIN_RANGE_WORDS (uint32 per range word)
+
+
 class NetProgram:
 
   def __init__(self, lib, recs: List[LayerRec], B: int, device, params: torch.Tensor,
-               grads: torch.Tensor, max_rows: int):
+               grads: torch.Tensor, max_rows: int, range_words: Optional[torch.Tensor] = None):
     self.lib, self.recs, self.B, self.device = lib, recs, B, device
     self.params, self.grads = params, grads
     f32 = dict(dtype=torch.float32, device=device)
+    # one range word per gouts[i] (include/odin_hip.h: odin_conv_desc.dy_amax / dx_amax): max |gradient|, kept by the
+    # kernel that produces the tensor and read by the f16-plane kernels that consume it; zeroed once per step
+    self.range_words = (torch.zeros(len(recs) * RANGE_WORDS, dtype=torch.int32, device=device)
+                        if range_words is None else range_words)
+    assert self.range_words.numel() == len(recs) * RANGE_WORDS and self.range_words.is_contiguous()
     self.outs = [torch.empty((B,) + r.out_shape, **f32) for r in recs]
     # gradient wrt the PRE-activation output of every layer
     self.gouts = [torch.empty((B,) + r.out_shape, **f32) for r in recs]
@@ -142,9 +150,16 @@ class NetProgram:
     for r in recs:
       if r.desc is not None:
         d = r.desc
-        self.descs.append(_lib.conv_desc(B, d['H'], d['W'], d['Cin'], d['OH'], d['OW'], d['Cout'],
-                                         d['K'], d['stride'], d['pad_t'], d['pad_l'], r.act,
-                                         r.center))
+        cd = _lib.conv_desc(B, d['H'], d['W'], d['Cin'], d['OH'], d['OW'], d['Cout'],
+                            d['K'], d['stride'], d['pad_t'], d['pad_l'], r.act, r.center)
+        i = len(self.descs)
+        # gouts[i] has a word when its producer keeps one: the data gradient of a conv / deconv layer i + 1 (or the
+        # fused tail standing in for it); produced by anything else (ELBO kernel, Dense, latent block) the consumer
+        # is told nothing and bounds the tensor itself if it needs to
+        tracked = i + 1 < len(recs) and recs[i + 1].desc is not None
+        cd.dy_amax = (self.range_words.data_ptr() + 4 * RANGE_WORDS * i) if tracked else None
+        cd.dx_amax = (self.range_words.data_ptr() + 4 * RANGE_WORDS * (i - 1)) if i > 0 else None
+        self.descs.append(cd)
       else:
         self.descs.append(None)
     self.wslabs: List[Optional[torch.Tensor]] = [None] * len(recs)
@@ -302,6 +317,7 @@ def observation_maps(observation: str, C: int) -> int:
     return MIXQL_K * (2 * C + C * (C - 1) // 2 + 1)
   return 2 * C
 H_ALPHA, H_B1, H_B2, H_EPS, H_GSCALE, H_INVB, H_KLW, H_BETA, H_TCCOEF, H_TCGRAD = range(10)
+H_CAP = 15  # BetaCapacityVAE: the capacity C(step) (slots 10..14: the second optimiser's Adam block)
 N_HYPER = 16
 
 
@@ -316,10 +332,12 @@ class VAEEngine:
                observation='bernoulli', analytic=False, free_bits=None, tc=None, lib=None,
                params: Optional[torch.Tensor] = None, world_size: int = 1, seed: int = 1,
                optim_state: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-               force_dp: bool = False, reverse: bool = True):
+               force_dp: bool = False, reverse: bool = True, capacity: bool = False):
     self.lib = lib if lib is not None else _lib.load()
     self.device = torch.device(device)
     self.B, self.D = int(batch_size), int(zdim)
+    # BetaCapacityVAE (beta_vae.py:132-177): the KL kernels emit |kl - C(step)| and its sign; `beta` plays gamma
+    self.capacity_on = bool(capacity)
     self.in_shape = tuple(in_shape)
     # KL form handed to the latent kernels: 0 = Monte-Carlo, 1 = closed-form KL(q||p),
     # 2 = closed-form KL(p||q) (`reverse=False`, odin/bay/helpers.py:261-265)
@@ -359,8 +377,12 @@ class VAEEngine:
     # ---- programs / buffers ----
     B, D = self.B, self.D
     mr = self.lib.odin_max_slab_rows()
-    self.enc = NetProgram(self.lib, self.enc_recs, B, self.device, self.params, self.grads, mr)
-    self.dec = NetProgram(self.lib, self.dec_recs, B, self.device, self.params, self.grads, mr)
+    ne = len(self.enc_recs)
+    self.range_words = torch.zeros((ne + len(self.dec_recs)) * RANGE_WORDS, dtype=torch.int32, device=self.device)
+    self.enc = NetProgram(self.lib, self.enc_recs, B, self.device, self.params, self.grads, mr,
+                          range_words=self.range_words[:ne * RANGE_WORDS])
+    self.dec = NetProgram(self.lib, self.dec_recs, B, self.device, self.params, self.grads, mr,
+                          range_words=self.range_words[ne * RANGE_WORDS:])
     self.p = torch.empty(B, 2 * D, **f32)
     self.dp = torch.empty(B, 2 * D, **f32)
     self.eps = torch.zeros(B, D, **f32)
@@ -547,7 +569,8 @@ class VAEEngine:
 
   def set_hyper(self, lr=1e-3, beta=1.0, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0,
                 t: Optional[int] = None, tc_coef: Optional[float] = None,
-                skip_enable: bool = True, extra: Optional[Sequence[float]] = None):
+                skip_enable: bool = True, extra: Optional[Sequence[float]] = None,
+                capacity: Optional[float] = None):
     """Host scalars -> device (one small async H2D copy)."""
     t = self.step_count if t is None else t
     tt = max(int(t), 1)
@@ -571,6 +594,9 @@ class VAEEngine:
     if extra is not None:  # second optimiser's Adam block (FactorVAE discriminator), slots 10..14
       for i, val in enumerate(extra):
         h[10 + i] = float(val)
+    if self.capacity_on:
+      assert capacity is not None, 'this engine was built with capacity=True: pass the capacity C(step)'
+      h[H_CAP] = float(capacity)
     h[N_HYPER:].view(torch.int32)[0] = int(t)
     h[N_HYPER:].view(torch.int32)[1] = int(skip_enable)
     # (leaving this 80-byte copy out of the steady state was measured: 0.7182 vs 0.7180 ms per step -- the
@@ -599,7 +625,7 @@ class VAEEngine:
                        self.hdim, 2 * D, 0, st)
     lib.odin_latent_fwd(self.p.data_ptr(), self.eps.data_ptr(), self.z.data_ptr(),
                         self.kl.data_ptr(), self.fbmask.data_ptr(), B, D, int(self.analytic),
-                        self.free_bits, st)
+                        self.free_bits, self.hp(H_CAP) if self.capacity_on else None, st)
     return self.p, self.z
 
   def run_decoder(self, z: torch.Tensor, st=None):
@@ -642,6 +668,8 @@ class VAEEngine:
     st = self.stream() if st is None else st
     assert x.shape == (B,) + self.in_shape and x.is_contiguous()
     self.x = x
+    # the range words of this step's gradient tensors start from zero (their producers fold in with atomicMax)
+    lib.odin_range_reset(self.range_words.data_ptr(), self.range_words.numel() // RANGE_WORDS, st)
     lw = self.params[self.lat_w_off:]
     lb = self.params[self.lat_b_off:]
     self._used_block = self.lat_block and fused
@@ -655,7 +683,8 @@ class VAEEngine:
                                 self.seed, self.hp(N_HYPER), self.p.data_ptr(), self.z.data_ptr(),
                                 self.kl.data_ptr(), self.fbmask.data_ptr(), self.dec.w(0).data_ptr(),
                                 self.dec.b(0).data_ptr(), self.dec.outs[0].data_ptr(), B, self.hdim, D,
-                                r0.N, ACT[r0.act], int(self.analytic), self.free_bits, st)
+                                r0.N, ACT[r0.act], int(self.analytic), self.free_bits,
+                                self.hp(H_CAP) if self.capacity_on else None, st)
       dec_in, dec_start = self.dec.outs[0], 1
     else:
       if eps is None:
@@ -667,7 +696,7 @@ class VAEEngine:
                          self.hdim, 2 * D, 0, st)
       lib.odin_latent_fwd(self.p.data_ptr(), self.eps.data_ptr(), self.z.data_ptr(),
                           self.kl.data_ptr(), self.fbmask.data_ptr(), B, D, int(self.analytic),
-                          self.free_bits, st)
+                          self.free_bits, self.hp(H_CAP) if self.capacity_on else None, st)
       dec_in, dec_start = self.z, 0
     npart = C.c_int(0)
     if self.fused_tail and fused:
@@ -1013,12 +1042,12 @@ class VAEEngine:
                  global_clipnorm: Optional[float] = None, use_graph: bool = False,
                  clipnorm: Optional[float] = None, clipvalue: Optional[float] = None,
                  skip_update_threshold: Optional[float] = None, when_skip_update: int = 0,
-                 check_nan: bool = True):
+                 check_nan: bool = True, capacity: Optional[float] = None):
     """Networks.optimize for one VAEStep: step += 1, forward, backward, (all-reduce), gradient
     policies, Adam.  Returns the device tensor out4 = [loss, mean llk, mean beta*kl, tc] (no host
     sync)."""
     self.step_count += 1
-    self.set_hyper(lr=lr, beta=beta, skip_enable=self.step_count >= int(when_skip_update))
+    self.set_hyper(lr=lr, beta=beta, skip_enable=self.step_count >= int(when_skip_update), capacity=capacity)
     pol = (global_clipnorm, clipnorm, clipvalue, skip_update_threshold, bool(check_nan))
     if use_graph and self.device.type == 'cuda':
       self._graph_step(x, eps, pol)

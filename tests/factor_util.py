@@ -71,3 +71,75 @@ def check_factor_vae_iteration(fv, nets, units, B1, x, eps1, eps2, perm, lr=1e-3
     assert d.mean() <= 5e-3 * dlr, ('disc-param-mean', k, d.mean())
   rep['unmasked_param_max'] = max(np.abs(pv[k] - ref['P'][k]).max() for k in keys)
   return rep
+
+
+def check_factor_vae_full_size(fv, nets, units, B1, x, eps1, eps2, perm, lr=1e-3, tc_coef=7.0,
+                               start_step=999, tol=1e-4, clip=None, threads=None):
+  """The same iteration at BENCHMARK size (BASELINE config 3: 128 + 128 samples, 5 x 1000 discriminator) against
+  an independent float64 restatement by torch autograd on the host (oracle/torch_ref.py) -- the numpy oracle's
+  hand-written conv loops are too slow there.  Compared: loss, TC estimate, dtc_loss, the gradient that flows
+  through D into z, EVERY VAE gradient tensor and EVERY discriminator gradient tensor (the latter from z' of
+  the already-updated encoder, factor_vae.py:279-287, evaluated in float64 from the engine's own updated
+  parameters)."""
+  import torch.nn.functional as F
+  from oracle.torch_ref import TorchVAE, t_seq
+  if threads:
+    torch.set_num_threads(threads)
+  D = fv.zdim
+  in_shape = tuple(nets['encoder'].input_shape)
+  fv._step = start_step
+  eng, disc = fv._engine(B1), fv._discriminator(B1)
+  P = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in eng.param_views().items()}
+  DP = {(k[1], k[2]): v.detach().cpu().numpy().astype(np.float64)
+        for k, v in disc.layout.views(disc.params).items()}
+  t = start_step + 1
+  beta = vo.interp_linear(t)
+  dl = vo.disc_layers(units)
+  model = TorchVAE(nets['encoder'].layers, nets['decoder'].layers, in_shape, D, beta=beta)
+  f64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+  x1, x2 = f64(x[:B1]), f64(x[B1:])
+  # ---- step 1 (reference): VAE loss + tc_coef * mean(D(z)), discriminator parameters held fixed
+  T = model.tensors(P)
+  Dfix = {k: f64(v) for k, v in DP.items()}
+  keep = {}
+
+  def extra(o):
+    o['z'].retain_grad()
+    keep['z'] = o['z']
+    keep['tc'] = tc_coef * t_seq(dl, Dfix, o['z'])[:, 0].mean()
+    return keep['tc']
+
+  out = model.forward(T, x1, f64(eps1), extra_loss_fn=extra)
+  # the D -> z term alone (disc.dz): d tc / d z
+  extra_dz, = torch.autograd.grad(keep['tc'], keep['z'], retain_graph=True)
+  out['loss'].backward()
+  G = {k: v.grad.detach().numpy() for k, v in T.items()}
+  # ---- the iteration on the device
+  loss, metrics = fv.optimize(x, training=True, learning_rate=lr, eps=eps1, eps2=eps2, perm=perm,
+                              global_clipnorm=clip)
+  rep = {}
+  ref_loss = float(out['loss'].detach())
+  rep['loss'] = abs(float(loss) - ref_loss) / max(1.0, abs(ref_loss))
+  rep['tc'] = abs(float(metrics['elbo/tc']) - float(keep['tc'].detach())) / max(1.0, abs(float(keep['tc'].detach())))
+  rep['extra_dz'] = relerr(disc.dz.cpu().numpy(), extra_dz.numpy())
+  gv = {k: v.cpu().numpy() for k, v in eng.grad_views().items()}
+  for k, g in G.items():
+    rep['grad' + str(k)] = relerr(gv[k], g)
+  # ---- step 2 (reference): z1 stale, z' from the engine's UPDATED parameters, permuted, dtc_loss
+  P2 = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in eng.param_views().items()}
+  with torch.no_grad():
+    z1 = out['z'].detach()
+    z2 = model.forward(model.tensors(P2, requires_grad=False), x2, f64(eps2))['z']
+    zp = torch.gather(z2, 0, torch.tensor(perm.astype(np.int64)))
+  Dt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in DP.items()}
+  l1, l2 = t_seq(dl, Dt, z1)[:, 0], t_seq(dl, Dt, zp)[:, 0]
+  dloss = 0.5 * (F.softplus(-l1).mean() + F.softplus(l2).mean())
+  dloss.backward()
+  rep['dtc_loss'] = abs(float(metrics['disc/dtc_loss']) - float(dloss.detach()))
+  rep['z2'] = np.abs(fv._engine_x2(B1).z.cpu().numpy() - z2.numpy()).max()
+  dgv = {(k[1], k[2]): v.cpu().numpy() for k, v in disc.layout.views(disc.grads).items()}
+  for k, v in Dt.items():
+    rep['dgrad' + str(k)] = relerr(dgv[k], v.grad.numpy())
+  for k, v in rep.items():
+    assert v <= tol, (k, v, rep)
+  return rep

@@ -230,6 +230,7 @@ static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; ret
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline unsigned __brev(unsigned x) {
   unsigned r = 0;

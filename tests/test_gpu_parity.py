@@ -221,6 +221,28 @@ def test_factor_vae_iteration_parity(dev, L, units):
   print('factor_vae', units, {k: f'{v:.2e}' for k, v in rep.items() if 'grad' not in k})
 
 
+def test_factor_vae_full_size_gradients(dev, L):
+  """BASELINE config 3 at its own size (batch 256 = 128 + 128, discriminator 5 x 1000: factor_vae.py:150-176,
+  239-287): the igemm instances of the [128 | 256] x 1000 x 1000 Dense layers and the 128-sample conv stack,
+  every VAE gradient (with the term that flows through D into z) and every discriminator gradient against
+  float64 torch autograd."""
+  import os
+  from odin_ai_amd.networks import get_networks
+  from odin_ai_amd.vae import FactorVAE
+  from tests.factor_util import check_factor_vae_full_size
+  nets = get_networks('shapes3d')
+  B1, D, units = 128, 6, (1000,) * 5
+  fv = FactorVAE(discriminator_units=units, tc_coef=7.0, device=dev, lib=L, **nets)
+  rng = np.random.default_rng(33)
+  x = np.clip(rng.random((2 * B1, 64, 64, 3)), 1e-6, 1 - 1e-6).astype(np.float32)
+  eps, eps2 = (rng.standard_normal((B1, D)).astype(np.float32) for _ in range(2))
+  perm = np.stack([rng.permutation(B1) for _ in range(D)], 1).astype(np.int32)
+  rep = check_factor_vae_full_size(fv, nets, units, B1, x, eps, eps2, perm, lr=1e-3, clip=100.0,
+                                   threads=min(32, os.cpu_count() or 1))
+  worst = max(((k, v) for k, v in rep.items() if 'grad' in k), key=lambda kv: kv[1])
+  print('factor_vae_b256', {k: f'{v:.2e}' for k, v in rep.items() if 'grad' not in k}, 'worst grad', worst)
+
+
 def test_gaussian_raw_scale_parity(dev, L):
   """a11's primary branch (image_networks.py:95-102): Normal(loc, scale) with the scale taken RAW
   from the decoder (no positivity transform).  The scale maps' bias is set positive so that the
@@ -275,6 +297,11 @@ FULL = [
     ('shapes3d_b128', lambda: vo.dsprites_spec(3), 128, dict(beta=1.0), {}),
     ('celeba_b512', lambda: vo.celeba_spec(45, 3), 512, dict(beta=4.0), {}),
     ('celeba_betatc_b512', lambda: vo.celeba_spec(45, 3), 512, dict(beta=4.0, tc_beta=4.0), {}),
+    # BASELINE config 1 at its batch size (dense default nets and the mnist conv stack) and config 5's conv VAE
+    # on [96, 80, 1] mel patches with the Gaussian (softplus1) observation at batch 256
+    ('mnist_dense_b128', lambda: vo.mnist_dense_spec(), 128, dict(beta=1.0), {}),
+    ('mnist_conv_b128', lambda: vo.mnist_conv_spec(), 128, dict(beta=1.0), {}),
+    ('speech_b256', 'speech', 256, dict(beta=1.0, observation='gaussian_softplus1'), {}),
 ]
 
 
@@ -290,7 +317,14 @@ def test_full_batch_gradients_vs_f64_autograd(dev, L, monkeypatch, name, spec, B
   for k, v in env.items():
     monkeypatch.setenv(k, v)
     os.putenv(k, v)
-  enc, dec, in_shape, zdim = spec()
+  if spec == 'speech':
+    from odin_ai_amd.networks import get_networks
+    nets = get_networks('speech', n_frames=96, n_mels=80)
+    enc, dec = nets['encoder'].layers, nets['decoder'].layers
+    in_shape, zdim = nets['encoder'].input_shape, nets['latents'].event_shape[0]
+  else:
+    enc, dec, in_shape, zdim = spec()
+  obs = kw.get('observation', 'bernoulli')
   rng = np.random.default_rng(5)
   x = np.clip(rng.random((B,) + tuple(in_shape)), 1e-6, 1 - 1e-6).astype(np.float32)
   eps = rng.standard_normal((B, zdim)).astype(np.float32)
@@ -301,7 +335,7 @@ def test_full_batch_gradients_vs_f64_autograd(dev, L, monkeypatch, name, spec, B
   torch.set_num_threads(min(32, os.cpu_count() or 1))
   out, G = ref.loss_and_grads(P, x.astype(np.float64), eps.astype(np.float64))
   eng = VAEEngine(enc, dec, in_shape, zdim, B, dev, tc='betatc' if 'tc_beta' in kw else None,
-                  lib=L)
+                  observation=obs, lib=L)
   eng.load_params(P)
   eng.step_count = 1
   eng.set_hyper(lr=1e-3, beta=kw['beta'])

@@ -204,6 +204,59 @@ def test_dense(bk, B, K, N, act):
   close(g[-N:], db_ref, 1e-4)
 
 
+@pytest.fixture(scope='module')
+def hipbk():
+  import torch
+  from tests.conftest import Backend
+  assert torch.cuda.is_available(), 'the hip backend needs an MI355X'
+  return Backend('hip', _lib.load(), 'cuda:0')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,K,N,act,family', [
+    # FactorVAE's discriminator layers at BASELINE config 3's half batches (factor_vae.py:150-153) and the whole
+    # batch of the discriminator step, MNIST's dense stack at batch 128 (variational_autoencoder.py:181-185),
+    # CelebA's encoder head: the instances the benchmarks run, held to the float64 oracle (too large for the
+    # CPU simulator) -- `family` is the kernel family the dispatcher must have picked
+    (128, 1000, 1000, 'relu', 'igemm'), (256, 1000, 1000, 'relu', 'igemm'), (128, 6, 1000, 'relu', None),
+    (128, 1000, 1, 'linear', None), (128, 784, 512, 'relu', 'igemm'), (128, 512, 784, 'linear', 'igemm'),
+    (128, 512, 512, 'relu', 'igemm'), (512, 4096, 512, 'linear', 'igemm'), (256, 1024, 256, 'linear', 'igemm')])
+def test_dense_at_benchmark_sizes(hipbk, B, K, N, act, family):
+  bk = hipbk
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(4)
+  x = rng.standard_normal((B, K))
+  w = rng.standard_normal((K, N)) / np.sqrt(K)
+  b = rng.standard_normal(N) * 0.1
+  y_ref = vo._ACT[act](vo.dense(x, w, b))
+  ty = bk.full((B, N), float('nan'))
+  tx, tw, tb = T(x), T(w), T(b)
+  paths = []
+  L.odin_dense_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), B, K, N, _lib.ACT[act], None)
+  paths.append(L.odin_debug_last_path().decode())
+  close(ty.cpu().numpy(), y_ref)
+  dy = rng.standard_normal((B, N))
+  aux = rng.standard_normal((B, K))
+  tdy, taux = T(dy), T(aux)
+  dx_ref, dw_ref, db_ref = vo.dense_bwd(x, w, dy)
+  tdx = bk.full((B, K), float('nan'))
+  rows = C.c_int(0)
+  L.odin_dense_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), _lib.ACT['relu'], tdx.data_ptr(),
+                     None, None, B, K, N, None)
+  paths.append(L.odin_debug_last_path().decode())
+  close(tdx.cpu().numpy(), dx_ref * (aux.astype(np.float32) > 0))
+  n = K * N + N
+  slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
+  L.odin_dense_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), B, K, N, None)
+  paths.append(L.odin_debug_last_path().decode())
+  g = reduce_slab(bk, slab, rows.value, n)
+  close(g[:-N].reshape(K, N), dw_ref, 1e-4)
+  close(g[-N:], db_ref, 1e-4)
+  print('dense', (B, K, N), paths)
+  if family is not None:
+    assert all(family in q for q in paths), paths
+
+
 @pytest.mark.parametrize('is_deconv,B,H,W,Ci,Co,K,S,C1', [
     (1, 2, 8, 8, 32, 32, 4, 2, 1),     # specialised <T,4,2,32> instance
     (1, 1, 16, 16, 32, 32, 4, 2, 1),   # two-workgroup fused tail instance (also the shape of the opt-in bf16-plane path)

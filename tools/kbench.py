@@ -29,6 +29,10 @@ g = torch.randn(B, 2 * H, 2 * W, 32, device=dev)
 if os.environ.get('KB_ZERO'):  # all-zero operands: the same instruction stream at minimal switching power
   x.zero_(); w.zero_(); g.zero_()
 rows, npart = C.c_int(0), C.c_int(0)
+# range word of the gradient tensor g (include/odin_hip.h: odin_conv_desc.dy_amax), as the engine's step keeps it
+words = torch.zeros(2048, dtype=torch.int32, device=dev)
+L.odin_absmax(g.data_ptr(), g.numel(), words.data_ptr(), None)
+d.dy_amax = words.data_ptr()
 for C1 in (1, 3):
   if f'tail{C1}' not in WHICH: continue
   w1 = torch.randn(32, C1, device=dev) * 0.3; b1 = torch.randn(C1, device=dev)
