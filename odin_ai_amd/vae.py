@@ -348,6 +348,7 @@ class VariationalAutoencoder:
     self._optim_state = None
     self._last_outputs = None
     self._tc_mode = None
+    self._capacity_mode = False
     self.trainer = None
     self.input_shape = tuple(encoder.input_shape) if encoder.input_shape else None
     self.zdim = int(latents.event_size)
@@ -374,7 +375,7 @@ class VariationalAutoencoder:
       eng = VAEEngine(self.encoder.layers, self.decoder.layers, self.input_shape, self.zdim, B,
                       self.device, observation=self.observation.posterior,
                       analytic=self.analytic, reverse=self.reverse, free_bits=self.free_bits,
-                      tc=self._tc_mode,
+                      tc=self._tc_mode, capacity=self._capacity_mode,
                       lib=self._lib, params=self._params, seed=self.seed + self._rank(),
                       optim_state=self._optim_state, world_size=self._world_size(),
                       force_dp=bool(getattr(self, 'force_dp', False)))
@@ -470,6 +471,10 @@ class VariationalAutoencoder:
   def beta(self) -> float:
     return 1.0
 
+  def _hyper_extra(self) -> dict:
+    """per-step scalars beyond (lr, beta) that a subclass hands to the engine (BetaCapacityVAE: the capacity)"""
+    return {}
+
   # ------------------------------------------------------------------ forward API
   def _posterior(self, eng: VAEEngine) -> MVNDiagPosterior:
     return MVNDiagPosterior(eng.p.clone(), eng.z.clone(), eng.D)
@@ -488,7 +493,7 @@ class VariationalAutoencoder:
     """variational_autoencoder.py:288-314"""
     x = _as_tensor(inputs, self.device)
     eng = self._engine(x.shape[0])
-    eng.set_hyper(beta=self.beta, t=self._step)
+    eng.set_hyper(beta=self.beta, t=self._step, **self._hyper_extra())
     eng.run_encoder(x, None if eps is None else _as_tensor(eps, self.device))
     if only_encoding:
       return eng.enc.outs[-1].clone()
@@ -517,7 +522,7 @@ class VariationalAutoencoder:
     x = self._tile(_as_tensor(inputs, self.device))
     n = self.n_samples
     eng = self._engine(x.shape[0])
-    eng.set_hyper(beta=self.beta, t=self._step)
+    eng.set_hyper(beta=self.beta, t=self._step, **self._hyper_extra())
     eng.forward(x, None if eps is None else _as_tensor(eps, self.device).reshape(x.shape[0], -1))
     qz_x = self._posterior(eng)
     px_z = self._observation_dist(eng.dec.outs[-1].clone())
@@ -571,7 +576,7 @@ class VariationalAutoencoder:
       B = x.shape[0]
       eng = self._engine(B)
       lib, st = eng.lib, eng.stream()
-      eng.set_hyper(beta=1.0, t=self._step)
+      eng.set_hyper(beta=1.0, t=self._step, **self._hyper_extra())
       eng.run_encoder(x)  # fills eng.p = (loc | raw scale)
       if eps is None:
         e = torch.empty(n, B, D, **f32)
@@ -587,7 +592,7 @@ class VariationalAutoencoder:
       for k0 in range(0, n, rows):
         r = min(rows, n - k0)
         de = self._engine(r * B)
-        de.set_hyper(beta=1.0, t=self._step)
+        de.set_hyper(beta=1.0, t=self._step, **self._hyper_extra())
         h = de.run_decoder(z[k0:k0 + r].reshape(r * B, D))
         xt = x.repeat((r,) + (1,) * (x.dim() - 1))
         de.observation_llk(h, xt, llk[k0:k0 + r].reshape(r * B))
@@ -637,7 +642,7 @@ class VariationalAutoencoder:
       self._step += 1
     eng.step_count = self._step - 1 if training else self._step
     if not training:
-      eng.set_hyper(beta=self.beta, t=self._step)
+      eng.set_hyper(beta=self.beta, t=self._step, **self._hyper_extra())
       eng.forward(x, eps)
     else:
       eng.train_step(x, eps,
@@ -645,7 +650,7 @@ class VariationalAutoencoder:
                      global_clipnorm=global_clipnorm, use_graph=use_graph, clipnorm=clipnorm,
                      clipvalue=clipvalue, skip_update_threshold=skip_update_threshold,
                      when_skip_update=when_skip_update,
-                     check_nan=nan_gradients_policy != 'ignore')
+                     check_nan=nan_gradients_policy != 'ignore', **self._hyper_extra())
       self._step = eng.step_count
     out = eng.out4.clone()
     metrics = {f'llk_{self.observation.name}': out[1], f'kl_{self.latents.name}': out[2]}
@@ -929,6 +934,33 @@ class BetaVAE(VariationalAutoencoder):
   @beta.setter
   def beta(self, b):
     self._beta = b
+
+
+class BetaCapacityVAE(VariationalAutoencoder):
+  """beta_vae.py:132-177 (Burgess et al. 2018, eq. 8): every KL term becomes gamma * |kl - C(step)| with the
+  capacity C raised from c_min to c_max over n_steps by `interpolation` (backend/interpolation.py); `step` is the
+  training step, incremented before the loss is evaluated (base_networks.py:478-479).  The latent kernels emit
+  |kl - C| and its sign (odin_latent_fwd's `capacity` argument), so gamma takes the place beta has in BetaVAE."""
+
+  def __init__(self, gamma: float = 10.0, c_min: float = 0.01, c_max: float = 25.0, n_steps: int = 10000,
+               interpolation: str = 'linear', name='BetaCapacityVAE', **kwargs):
+    from . import interpolation as interp
+    self.gamma = float(gamma)
+    self.interpolation = getattr(interp, str(interpolation))(vmin=float(c_min), vmax=float(c_max), steps=int(n_steps))
+    super().__init__(name=name, **kwargs)
+    self._capacity_mode = True
+    self._engines.clear()
+
+  @property
+  def beta(self) -> float:  # the weight the engine multiplies the (capacity-shifted) KL by
+    return self.gamma
+
+  @property
+  def capacity(self) -> float:
+    return float(self.interpolation(self._step))
+
+  def _hyper_extra(self) -> dict:
+    return dict(capacity=self.capacity)
 
 
 class AnnealingVAE(BetaVAE):

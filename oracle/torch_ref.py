@@ -138,7 +138,8 @@ class TorchVAE:
 
   def __init__(self, enc_layers, dec_layers, in_shape, zdim, observation='bernoulli',
                analytic=False, free_bits=None, beta=1.0, tc_beta=None,
-               dtype=torch.float64, reverse=True, n_components=10):
+               dtype=torch.float64, reverse=True, n_components=10, capacity=None):
+    self.capacity = capacity  # BetaCapacityVAE (beta_vae.py:132-177): beta * |kl - capacity|
     self.reverse = bool(reverse)
     self.n_components = int(n_components)
     self.enc, self.dec = list(enc_layers), list(dec_layers)
@@ -190,6 +191,8 @@ class TorchVAE:
     kl = kl_raw
     if self.free_bits is not None:
       kl = torch.clamp(kl, min=self.free_bits * D)
+    if self.capacity is not None:
+      kl = torch.abs(kl - self.capacity)
     kl = self.beta * kl
     elbo = llk - kl
     out = dict(h_e=h_e, p=p, loc=loc, scale=scale, z=z, h_d=h_d, recon=recon, llk=llk,

@@ -648,7 +648,10 @@ class OracleVAE:
 
   def __init__(self, enc_layers, dec_layers, in_shape, zdim, observation='bernoulli',
                analytic=False, free_bits=None, beta=1.0, tc_beta: Optional[float] = None,
-               reverse: bool = True, n_components: int = 10):
+               reverse: bool = True, n_components: int = 10, capacity: Optional[float] = None):
+    # capacity: BetaCapacityVAE (odin/bay/vi/autoencoder/beta_vae.py:132-177): every KL term becomes
+    # gamma * |kl - C(step)| -- `beta` plays gamma, `capacity` is the value C(step) of the schedule
+    self.capacity = None if capacity is None else float(capacity)
     self.reverse = bool(reverse)
     self.n_components = int(n_components)  # 'mixqlogistic' (image_networks.py:48, default 10)
     self.enc, self.dec = list(enc_layers), list(dec_layers)
@@ -727,6 +730,9 @@ class OracleVAE:
     else:
       kl_raw = kl_analytic(loc, scale) if self.analytic else kl_mc(loc, scale, z)
     kl_c, fb_mask = free_bits_clamp(kl_raw, self.free_bits, self.D)
+    if self.capacity is not None:  # beta_vae.py:174-176: tf.math.abs(val - c); d|x| = sign(x)
+      fb_mask = fb_mask * np.sign(kl_c - self.capacity)
+      kl_c = np.abs(kl_c - self.capacity)
     kl = self.beta * kl_c
     elbo = llk - kl
     out = dict(h_e=h_e, p=p, loc=loc, raw_scale=p[:, self.D:], scale=scale, z=z, h_d=h_d,

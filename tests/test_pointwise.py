@@ -30,7 +30,7 @@ def test_latent_fwd_bwd(bk, analytic, fb):
   tp, te = T(p), T(eps)
   z, kl, m = bk.zeros(B, D), bk.zeros(B), bk.zeros(B)
   L.odin_latent_fwd(tp.data_ptr(), te.data_ptr(), z.data_ptr(), kl.data_ptr(), m.data_ptr(), B, D,
-                    analytic, fb, None)
+                    analytic, fb, None, None)
   close(z.cpu().numpy(), z_ref)
   close(kl.cpu().numpy(), kl_ref)
   assert (m.cpu().numpy() == m_ref).all()
@@ -377,7 +377,7 @@ def test_latent_block_fwd_bwd(bk, B, P, D, N0, analytic, fb, act0, hact, draw):
   L.odin_latent_block_fwd(th.data_ptr(), twl.data_ptr(), tbl.data_ptr(), None if draw else teps.data_ptr(),
                           eps_out.data_ptr(), 1234, step.data_ptr(), p.data_ptr(), z.data_ptr(), kl.data_ptr(),
                           m.data_ptr(), tw0.data_ptr(), tb0.data_ptr(), y0.data_ptr(), B, P, D, N0, ACT[act0],
-                          analytic, fb, None)
+                          analytic, fb, None, None)
   if draw:  # the noise is the stream odin_rng_normal writes, bit for bit
     assert np.array_equal(eps_out.cpu().numpy(), teps.cpu().numpy())
   p_ref = h @ wl + bl
