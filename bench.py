@@ -286,6 +286,40 @@ def dominant_rooflines(ops):
   return roof, stack
 
 
+def fit_throughput(device, iters=600):
+  """The API north_star names: `BetaVAE(**get_networks('dsprites')).fit(...)` end to end (Python loop, per-step
+  hyper-parameter copy, graph replay, NaN polling, metrics) on (a) the on-device uint8 pipeline
+  `DeviceImageDataset(out=vae.input_buffer(256))` and (b) a plain float32 tensor resident in HBM
+  (odin/networks/base_networks.py:642-812, odin/training/trainer.py:536-738)."""
+  from odin_ai_amd.data import DeviceImageDataset
+  from odin_ai_amd.networks import get_networks
+  from odin_ai_amd.vae import BetaVAE
+  B = 256
+  g = torch.Generator(device='cpu').manual_seed(7)
+  imgs = (torch.rand(8192, 64, 64, 1, generator=g) < 0.05).to(torch.uint8)
+  out = {}
+  for tag in ('device_dataset', 'float_tensor'):
+    vae = BetaVAE(beta=4.0, device=device, seed=3, **get_networks('dsprites'))
+    init_params_(vae._engine(B), seed=3)
+    if tag == 'device_dataset':
+      train = DeviceImageDataset(imgs, batch_size=B, normalize='probs', premul=255.0, device=device,
+                                 out=vae.input_buffer(B))
+    else:
+      train = imgs.to(device).float().clamp_(1e-6, 1 - 1e-6)
+    kw = dict(batch_size=B, learning_rate=1e-3, global_clipnorm=100.0, compile_graph=True)
+    vae.fit(train, max_iter=60, **kw)   # graph capture + warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vae.fit(train, max_iter=iters, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert not vae.nan_flag
+    out[tag] = dict(images_per_sec=round(B * iters / dt, 1), ms_per_step=round(dt / iters * 1e3, 4), iters=iters)
+    del vae, train
+  torch.cuda.empty_cache()
+  return out
+
+
 def north_star_3ch(device, steps=50):
   """The shape north_star states its roofline targets on -- 64x64x3 beta-VAE (beta = 4) at batch 256 =
   the Shapes3D networks (image_networks.py:560-597) -- measured in the SAME process as the headline
@@ -424,6 +458,7 @@ def main():
   ap.add_argument('--no-graph', action='store_true')
   ap.add_argument('--no-north-star-3ch', action='store_true',
                   help='skip the 64x64x3 beta-VAE (Shapes3D networks) measurement added to the default line')
+  ap.add_argument('--no-fit', action='store_true', help='skip the fit()-level throughput measurement')
   ap.add_argument('--profile-ops', action='store_true', help='print a per-kernel timing table')
   ap.add_argument('--dry-run', action='store_true',
                   help='launcher / rendezvous self-test on CPU (gloo): no kernels, no GPU')
@@ -741,6 +776,11 @@ def main():
   ns3 = None
   if world == 1 and args.workload == 'dsprites_betavae_b256' and not args.no_north_star_3ch:
     ns3 = north_star_3ch(device)
+  fit_tp = None
+  if world == 1 and args.workload == 'dsprites_betavae_b256' and not args.no_fit:
+    fit_tp = fit_throughput(device)
+    for v in fit_tp.values():
+      v['frac_of_step_replay'] = round(v['images_per_sec'] / (B * args.steps / dt), 4)
   res = dict(metric='VAE train images/sec', value=round(B * world * args.steps / dt, 1),
              unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
              ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling='weak',
@@ -757,6 +797,9 @@ def main():
              elbo_kernel=hbm[0],
              hbm_kernels=hbm,
              north_star_3ch=ns3)
+  if fit_tp is not None:
+    res['fit_images_per_sec'] = fit_tp['device_dataset']['images_per_sec']
+    res['fit'] = fit_tp
   if mel_kernel is not None:
     res['mel_kernel'] = mel_kernel
   if rccl is not None:

@@ -94,6 +94,21 @@ int odin_deconv2d_dgrad(const float* dy, const float* w, const float* aux, int a
 int odin_deconv2d_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out,
                         const odin_conv_desc* d, void* stream);
 
+/* ---- a layer's whole backward pass in ONE call: weight gradient (wslab as in *_wgrad) + data gradient (dx,
+ * colsum_slab as in *_dgrad; same argument meaning, same results bit for bit).  Where both halves run on the
+ * small-layer implicit-GEMM kernels they share one launch -- each alone is a latency-bound launch of a few hundred
+ * workgroups -- otherwise the call is the two calls above.  Replaces the tape.gradient of one layer
+ * (odin/networks/base_networks.py:514-518). */
+int odin_conv2d_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                    float* colsum_slab, int* colsum_rows_out, float* wslab, int* wslab_rows_out,
+                    const odin_conv_desc* d, void* stream);
+int odin_deconv2d_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                      float* colsum_slab, int* colsum_rows_out, float* wslab, int* wslab_rows_out,
+                      const odin_conv_desc* d, void* stream);
+int odin_dense_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                   float* colsum_slab, int* colsum_rows_out, float* wslab, int* wslab_rows_out, int B, int K,
+                   int N, void* stream);
+
 /* ---- fused decoder tail of the TRAINING step: layer (Conv2DTranspose if is_deconv else
  * Conv2D, activation d->act, Cout<=32) -> Conv2D 1x1 linear with C1<=4 maps (w1 [Cout,C1],
  * b1 [C1]) -> Independent(Bernoulli(logits),3).log_prob(target), forward AND backward:
@@ -309,6 +324,9 @@ int odin_rng_normal(float* out, size_t n, uint64_t seed, const int32_t* step_dev
  * and uses premul = 255 (fuel/image_data/shapes.py:69-72,80).  n_per % 16 == 0. */
 int odin_gather_normalize_u8(const uint8_t* data, const int32_t* idx, float* out, int B, int n_per,
                              float premul, int mode, void* stream);
+/* the same for a float32 dataset that is already normalised: out[b, :] = data[idx[b], :]; n_per % 4 == 0.  The
+ * batch selection of Networks.fit on an in-memory array (odin/networks/base_networks.py:642-812). */
+int odin_gather_rows_f32(const float* data, const int32_t* idx, float* out, int B, int n_per, void* stream);
 
 /* ---- speech front-end: pre-emphasis -> STFT -> |.|^2 -> Slaney mel -> dB
  * (odin/preprocessing/signal.py:955-967,1442-1562,1623-1691,636-680), computed in float64 like

@@ -43,6 +43,9 @@ SIGNATURES = {
     'odin_crc32c': [C.c_uint32, P, C.c_size_t],
     'odin_max_slab_rows': [],
     'odin_range_reset': [P, I, P],
+    'odin_conv2d_bwd': [P, P, P, P, I, P, P, IP, P, IP, DP, P],
+    'odin_deconv2d_bwd': [P, P, P, P, I, P, P, IP, P, IP, DP, P],
+    'odin_dense_bwd': [P, P, P, P, I, P, P, IP, P, IP, I, I, I, P],
     'odin_absmax': [P, C.c_size_t, P, P],
     'odin_debug_absmax_fallbacks': [],
     'odin_comm_unique_id': [P],
@@ -90,6 +93,7 @@ SIGNATURES = {
     'odin_sumsq_adam_finalize_flat': [P, P, P, P, C.c_size_t, P, P, P, F, P, P, I, P, P, P, P, P, I, P],
     'odin_rng_normal': [P, C.c_size_t, C.c_uint64, P, P],
     'odin_gather_normalize_u8': [P, P, P, I, I, F, I, P],
+    'odin_gather_rows_f32': [P, P, P, I, I, P],
     'odin_stft_mel_db': [P, P, P, P, P, P, I, I, I, I, I, I, C.c_double, C.c_double, I, P],
     'odin_stft_mel_db_frames': [P, P, P, P, P, P, I, I, I, I, I, I, C.c_double, C.c_double, I, I, P, P],
     'odin_debug_set_stamps': [P],

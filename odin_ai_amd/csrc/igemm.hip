@@ -74,8 +74,10 @@ __device__ __forceinline__ int ig_magicdiv(int q, unsigned magic) {
 // t / d for 0 <= t < 64, 1 <= d <= 8 on the scalar unit
 __device__ __forceinline__ int ig_smalldiv(int t, int d) { return (t * (256 / d + 1)) >> 8; }
 
+// (bx, by): the tile's block coordinates -- blockIdx of a launch of its own, decoded from a linear index in the
+// paired launch below; gx = blocks along x
 template <int NW, bool TMODE, bool BKC>
-__global__ __launch_bounds__(NW * 64) void igemm_kernel(IGParams p) {
+__device__ __forceinline__ void igemm_body(const IGParams& p, const int bx, const int by, const int gx) {
   __shared__ float red[NW > 1 ? (NW - 1) * 16 * 64 : 64];
   __shared__ int rowoff[32];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -84,8 +86,8 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IGParams p) {
   const int wave = IG_UNIFORM(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   // ---- this tile's stride class and its taps ----
-  const int cls = TMODE ? ig_magicdiv((int)blockIdx.y, p.mg_tpc) : 0;
-  const int tile = TMODE ? (int)blockIdx.y - cls * p.tpc : (int)blockIdx.y;
+  const int cls = TMODE ? ig_magicdiv(by, p.mg_tpc) : 0;
+  const int tile = TMODE ? by - cls * p.tpc : by;
   const int SS = TMODE ? p.S : 1;     // 1 or 2
   const int ssh = SS >> 1;            // x / SS = x >> ssh,  x % SS = x & (SS - 1)
   const int cy = cls >> ssh, cx = cls - (cy << ssh);
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IGParams p) {
   mask = a_ok ? mask : 0u;
   const int lanebase = ((b * p.H + Y0) * p.W + X0) * p.CI + 4 * h;  // floats
   if (h == 0) rowoff[l31] = a_ok ? ((b * p.OH + oy) * p.OW + ox) : -1;
-  const int j = blockIdx.x * 32 + l31;
+  const int j = bx * 32 + l31;
   const bool b_ok = j < p.CO;
   const unsigned bl = b_ok ? (unsigned)((BKC ? j * p.CI + 4 * h : 4 * h * p.CO + j) * 4) : ODIN_OOB_V;
   const OdinRun RA = odin_run(p.in, (unsigned)((size_t)p.B * p.H * p.W * p.CI * 4));
@@ -230,13 +232,18 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IGParams p) {
     cs += ((int)ooff[rr] >= 0) ? v : 0.f;
     amx = fmaxf(amx, ((int)ooff[rr] >= 0 && b_ok) ? fabsf(v) : 0.f);
   }
-  odin_amax_commit_wave(p.out_amax, amx, lane, blockIdx.x + gridDim.x * blockIdx.y);  // (wave 0 speaks for the tile)
+  odin_amax_commit_wave(p.out_amax, amx, lane, (unsigned)(bx + gx * by));  // (wave 0 speaks for the tile)
   if (p.colsum != nullptr) {
     cs += __shfl_xor(cs, 32);
-    if (h == 0 && b_ok) p.colsum[(size_t)blockIdx.y * p.CO + j] = cs;
+    if (h == 0 && b_ok) p.colsum[(size_t)by * p.CO + j] = cs;
   }
   IG_STAMP(6);
   IG_WSTAMP(9);
+}
+
+template <int NW, bool TMODE, bool BKC>
+__global__ __launch_bounds__(NW * 64) void igemm_kernel(IGParams p) {
+  igemm_body<NW, TMODE, BKC>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -255,7 +262,7 @@ struct IWParams {
 constexpr int IW_CHUNK = 1024;
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(IWParams p) {
+__device__ __forceinline__ void igemm_wgrad_body(const IWParams& p, const int bx, const int by, const int bz) {
   __shared__ float red[NW > 1 ? (NW - 1) * 16 * 64 : 64];
   __shared__ int tb_base[IW_CHUNK + 8];   // float offset of the fine pixel (y S - pt, x S - pl) of coarse pixel m
   __shared__ int tb_yx[IW_CHUNK + 8];     // (y S - pt + 64) << 16 | (x S - pl + 64); -1: beyond this workgroup's pixels
@@ -263,12 +270,12 @@ __global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(IWParams p) {
   const int wave = IG_UNIFORM(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int I = p.KH * p.KW * p.CU;
-  const int i = blockIdx.y * 32 + l31, j = blockIdx.x * 32 + l31;
+  const int i = by * 32 + l31, j = bx * 32 + l31;
   const bool i_ok = i < I, j_ok = j < p.CV;
   const int tap = ig_magicdiv(i, p.mg_cu), cu = i - tap * p.CU;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const int rowc = (kh * p.FW + kw) * p.CU + cu;
-  const int mlo = blockIdx.z * p.chunk;
+  const int mlo = bz * p.chunk;
   const int mhi = (mlo + p.chunk < p.M) ? mlo + p.chunk : p.M;
   for (int e = tid; e < IW_CHUNK + 8; e += NW * 64) {
     const int m = mlo + e;
@@ -348,8 +355,8 @@ __global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(IWParams p) {
       for (int rr = 0; rr < 16; ++rr) acc[rr] += red[((w - 1) * 16 + rr) * 64 + lane];
     }
   }
-  float* row = p.slab + (size_t)blockIdx.z * p.slab_stride;
-  if (p.want_bias && blockIdx.y == 0) {
+  float* row = p.slab + (size_t)bz * p.slab_stride;
+  if (p.want_bias && by == 0) {
     // column sums of V over this workgroup's pixels: halves h = 0 / 1 and the NW waves, fixed order
     __syncthreads();
     const float t = csum + __shfl_xor(csum, 32);
@@ -364,8 +371,32 @@ __global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(IWParams p) {
   if (wave != 0 || !j_ok) return;
 #pragma unroll
   for (int rr = 0; rr < 16; ++rr) {
-    const int ii = blockIdx.y * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+    const int ii = by * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
     if (ii < I) row[(size_t)ii * p.CV + j] = acc[rr];
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(IWParams p) {
+  igemm_wgrad_body<NW>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// A layer's data gradient and weight gradient in ONE launch: both read dy, neither reads the other's result, and each
+// alone is a latency-bound launch of a few hundred single- to four-wave workgroups (12-18 us for 0.07-0.5 GFLOP:
+// DESIGN 3.8).  Workgroups [0, na) run the data gradient, the rest the weight gradient; waves beyond a role's count
+// leave at once (a finished wave does not take part in s_barrier).
+template <int NWA, bool TMODE, bool BKC, int NWB>
+__global__ __launch_bounds__((NWA > NWB ? NWA : NWB) * 64) void igemm_pair_kernel(IGParams a, IWParams b, int na,
+                                                                                 int gax, int gbx, int gby) {
+  const int id = (int)blockIdx.x;
+  if (id < na) {
+    if (NWA < NWB && (int)threadIdx.x >= NWA * 64) return;
+    const int by = id / gax;
+    igemm_body<NWA, TMODE, BKC>(a, id - by * gax, by, gax);
+  } else {
+    if (NWB < NWA && (int)threadIdx.x >= NWB * 64) return;
+    const int r = id - na, bz = r / (gbx * gby), q = r - bz * (gbx * gby), by = q / gbx;
+    igemm_wgrad_body<NWB>(b, q - by * gbx, by, bz);
   }
 }
 
@@ -380,8 +411,45 @@ double igemm_max_flop(bool wide) {
   return e ? atof(e) * 1e9 : (wide ? 5.0e9 : 1.2e9);
 }
 
+// ---- deferred weight-gradient launch (odin_igemm_pair_begin / _end): the *_bwd entry points issue the weight
+// gradient first; when it lands here it waits for the data gradient of the same layer and shares its launch ----
+struct PendingW {
+  bool defer = false, pending = false;
+  IWParams p;
+  dim3 grid;
+  int nw = 0;
+  void* stream = nullptr;
+};
+thread_local PendingW g_pw;
+
+int iw_launch_now(const IWParams& p, dim3 grid, int nw, void* stream) {
+  if (nw >= 8) ODIN_LAUNCH((igemm_wgrad_kernel<8>), grid, dim3(512), 0, stream, p);
+  else if (nw == 4) ODIN_LAUNCH((igemm_wgrad_kernel<4>), grid, dim3(256), 0, stream, p);
+  else if (nw == 2) ODIN_LAUNCH((igemm_wgrad_kernel<2>), grid, dim3(128), 0, stream, p);
+  else ODIN_LAUNCH((igemm_wgrad_kernel<1>), grid, dim3(64), 0, stream, p);
+  return odin_check_launch("igemm_wgrad");
+}
+
+template <int NWA, bool TMODE, bool BKC>
+int ig_pair_b(const IGParams& a, dim3 ga, const IWParams& b, dim3 gb, int nwb, void* stream) {
+  const int na = (int)(ga.x * ga.y), nb = (int)(gb.x * gb.y * gb.z);
+  const dim3 grid((unsigned)(na + nb));
+  if (nwb == 4) ODIN_LAUNCH((igemm_pair_kernel<NWA, TMODE, BKC, 4>), grid, dim3((NWA > 4 ? NWA : 4) * 64), 0, stream, a, b, na, (int)ga.x, (int)gb.x, (int)gb.y);
+  else if (nwb == 2) ODIN_LAUNCH((igemm_pair_kernel<NWA, TMODE, BKC, 2>), grid, dim3((NWA > 2 ? NWA : 2) * 64), 0, stream, a, b, na, (int)ga.x, (int)gb.x, (int)gb.y);
+  else ODIN_LAUNCH((igemm_pair_kernel<NWA, TMODE, BKC, 1>), grid, dim3(NWA * 64), 0, stream, a, b, na, (int)ga.x, (int)gb.x, (int)gb.y);
+  return odin_check_launch("igemm+igemm_wgrad");
+}
+
 template <bool TMODE, bool BKC>
 int ig_launch_t(IGParams& p, dim3 grid, int nw, void* stream) {
+#ifndef ODIN_SIM  // (the simulator's barrier counts every thread of the block: the roles keep their own launches there)
+  if (g_pw.pending && g_pw.stream == stream && nw <= 4 && g_pw.nw <= 4 && p.stamps == nullptr) {
+    g_pw.pending = false;
+    if (nw == 4) return ig_pair_b<4, TMODE, BKC>(p, grid, g_pw.p, g_pw.grid, g_pw.nw, stream);
+    if (nw == 2) return ig_pair_b<2, TMODE, BKC>(p, grid, g_pw.p, g_pw.grid, g_pw.nw, stream);
+    return ig_pair_b<1, TMODE, BKC>(p, grid, g_pw.p, g_pw.grid, g_pw.nw, stream);
+  }
+#endif
   if (nw >= 8) ODIN_LAUNCH((igemm_kernel<8, TMODE, BKC>), grid, dim3(512), 0, stream, p);
   else if (nw == 4) ODIN_LAUNCH((igemm_kernel<4, TMODE, BKC>), grid, dim3(256), 0, stream, p);
   else if (nw == 2) ODIN_LAUNCH((igemm_kernel<2, TMODE, BKC>), grid, dim3(128), 0, stream, p);
@@ -502,9 +570,18 @@ int odin_igemm_wgrad_launch(const float* u, const float* v, float* slab, int sla
   (void)wgs;
   int nw = ngroups >= 16 ? 4 : ngroups >= 8 ? 2 : 1;
   if (const char* e = getenv("ODIN_IG_NW")) nw = atoi(e);
-  if (nw >= 8) ODIN_LAUNCH((igemm_wgrad_kernel<8>), grid, dim3(512), 0, stream, p);
-  else if (nw == 4) ODIN_LAUNCH((igemm_wgrad_kernel<4>), grid, dim3(256), 0, stream, p);
-  else if (nw == 2) ODIN_LAUNCH((igemm_wgrad_kernel<2>), grid, dim3(128), 0, stream, p);
-  else ODIN_LAUNCH((igemm_wgrad_kernel<1>), grid, dim3(64), 0, stream, p);
-  return odin_check_launch("igemm_wgrad");
+  if (g_pw.defer && !g_pw.pending) {  // wait for the data gradient of the same layer (odin_igemm_pair_end flushes)
+    g_pw.pending = true;
+    g_pw.p = p; g_pw.grid = grid; g_pw.nw = nw; g_pw.stream = stream;
+    return 0;
+  }
+  return iw_launch_now(p, grid, nw, stream);
+}
+
+void odin_igemm_pair_begin() { g_pw.defer = true; g_pw.pending = false; }
+int odin_igemm_pair_end() {
+  g_pw.defer = false;
+  if (!g_pw.pending) return 0;
+  g_pw.pending = false;
+  return iw_launch_now(g_pw.p, g_pw.grid, g_pw.nw, g_pw.stream);
 }

@@ -99,6 +99,10 @@ int odin_igemm_tiles(int tmode, int B, int OH, int OW, int S);
 int odin_igemm_launch(int tmode, const float* in, const float* w, const float* bias, const float* aux,
                       int aux_act, float* out, float* colsum, int B, int H, int W, int CI, int OH, int OW,
                       int CO, int KH, int KW, int S, int pt, int pl, int act, uint32_t* out_amax, void* stream);
+// between begin and end an igemm weight-gradient launch waits for the next igemm data-gradient launch on the same
+// stream and shares its launch (igemm_pair_kernel); end flushes a weight gradient that found no partner
+void odin_igemm_pair_begin();
+int odin_igemm_pair_end();
 bool odin_igemm_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, int CV, int KH, int KW, int S,
                                  int center);
 int odin_igemm_wgrad_rows(int B, int h, int w, int KH, int KW, int CU, int CV);

@@ -1080,6 +1080,28 @@ extern "C" int odin_gather_normalize_u8(const uint8_t* data, const int32_t* idx,
   return odin_check_launch("gather_normalize_u8");
 }
 
+// batch gather from an HBM-resident float32 dataset that is already normalised (fit() on a tensor:
+// odin/networks/base_networks.py:642-812 feeds `train` batch by batch): out[b] = data[idx[b]], 16 bytes per thread
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ data,
+                                                              const int* __restrict__ idx, float* __restrict__ out,
+                                                              int B, int n_per) {
+  const int per4 = n_per >> 2;
+  const long total = (long)B * per4;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int b = (int)(t / per4), q = (int)(t - (long)b * per4);
+    reinterpret_cast<float4*>(out + (size_t)b * n_per)[q] =
+        reinterpret_cast<const float4*>(data + (size_t)idx[b] * n_per)[q];
+  }
+}
+
+extern "C" int odin_gather_rows_f32(const float* data, const int32_t* idx, float* out, int B, int n_per,
+                                    void* stream) {
+  if (n_per % 4 != 0) return odin_fail(-2, "gather_rows_f32: floats per row must be a multiple of 4");
+  int grid = grid_for((size_t)B * (n_per / 4), 256, 4096);
+  ODIN_LAUNCH(gather_rows_f32_kernel, dim3(grid), dim3(256), 0, stream, data, (const int*)idx, out, B, n_per);
+  return odin_check_launch("gather_rows_f32");
+}
+
 extern "C" int odin_rng_normal(float* out, size_t n, uint64_t seed, const int32_t* step_dev,
                                void* stream) {
   int grid = grid_for((n + 3) / 4, 256, 2048);

@@ -1308,6 +1308,38 @@ extern "C" int odin_dense_wgrad(const float* x, const float* dy, float* slab, in
   return launch_wgrad(p, slab_rows_out, stream);
 }
 
+// ---- a layer's whole backward pass in one call: weight gradient + data gradient.  Where both run on the
+// implicit-GEMM kernels (igemm.hip) they share ONE launch; otherwise exactly the two calls above. ----
+extern "C" int odin_conv2d_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act,
+                               float* dx, float* colsum_slab, int* colsum_rows_out, float* wslab,
+                               int* wslab_rows_out, const odin_conv_desc* d, void* stream) {
+  odin_igemm_pair_begin();
+  int rc = odin_conv2d_wgrad(x, dy, wslab, wslab_rows_out, d, stream);
+  if (rc == 0) rc = odin_conv2d_dgrad(dy, w, aux, aux_act, dx, colsum_slab, colsum_rows_out, d, stream);
+  const int rc2 = odin_igemm_pair_end();
+  return rc != 0 ? rc : rc2;
+}
+
+extern "C" int odin_deconv2d_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act,
+                                 float* dx, float* colsum_slab, int* colsum_rows_out, float* wslab,
+                                 int* wslab_rows_out, const odin_conv_desc* d, void* stream) {
+  odin_igemm_pair_begin();
+  int rc = odin_deconv2d_wgrad(x, dy, wslab, wslab_rows_out, d, stream);
+  if (rc == 0) rc = odin_deconv2d_dgrad(dy, w, aux, aux_act, dx, colsum_slab, colsum_rows_out, d, stream);
+  const int rc2 = odin_igemm_pair_end();
+  return rc != 0 ? rc : rc2;
+}
+
+extern "C" int odin_dense_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act,
+                              float* dx, float* colsum_slab, int* colsum_rows_out, float* wslab,
+                              int* wslab_rows_out, int B, int K, int N, void* stream) {
+  odin_igemm_pair_begin();
+  int rc = odin_dense_wgrad(x, dy, wslab, wslab_rows_out, B, K, N, stream);
+  if (rc == 0) rc = odin_dense_dgrad(dy, w, aux, aux_act, dx, colsum_slab, colsum_rows_out, B, K, N, stream);
+  const int rc2 = odin_igemm_pair_end();
+  return rc != 0 ? rc : rc2;
+}
+
 extern "C" int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* stream) {
   if (n_jobs <= 0) return 0;
   for (int j0 = 0; j0 < n_jobs; j0 += MAX_JOBS) {

@@ -252,27 +252,6 @@ class NetProgram:
       # issued on the side stream (fork) and overlaps the next layers' data-gradients ----
       slab = self.wslabs[i]
       wst = st if (fork is None or not fork.wants(self.small_wgrad[i])) else fork(i)
-      if data_only:
-        pass
-      elif r.kind == 'conv':
-        lib.odin_conv2d_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows),
-                              C.byref(d), wst)
-      elif r.kind == 'deconv':
-        lib.odin_deconv2d_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows),
-                                C.byref(d), wst)
-      else:
-        lib.odin_dense_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(rows), B,
-                             r.K, r.N, wst)
-      if not data_only:
-        assert rows.value == self.wrows[i]
-        n_red = slab.shape[1]
-        if skip_bias_of_last and i == n - 1 and r.kind != 'deconv':
-          n_red = r.w_n  # the fused tail already delivers this layer's bias gradient
-        # (jobs whose slab was written on a side stream are kept apart: only the final reduction,
-        # after the join, may read them)
-        tgt = side_jobs if (side_jobs is not None and wst is not st) else jobs
-        tgt.append(ReduceJob(slab.data_ptr(), self.grads[r.w_off:].data_ptr(), n_red, rows.value,
-                             slab.shape[1], 0))
       # ---- data gradient -> pre-activation gradient of the previous layer ----
       if i > 0:
         prev = self.recs[i - 1]
@@ -281,18 +260,56 @@ class NetProgram:
       elif dx_out is not None:
         dst, aux, aux_act, bslab = dx_out, None, 0, None
       else:
-        break
-      auxp = aux.data_ptr() if (aux is not None and aux_act != 0) else None
-      bsp = bslab.data_ptr() if bslab is not None else None
-      if r.kind == 'conv':
-        lib.odin_conv2d_dgrad(g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
-                              bsp, C.byref(rows), C.byref(d), st)
+        dst = None
+      auxp = aux.data_ptr() if (dst is not None and aux is not None and aux_act != 0) else None
+      bsp = bslab.data_ptr() if (dst is not None and bslab is not None) else None
+      # both halves on one stream: ONE call -- where both run on the small-layer implicit-GEMM kernels they share
+      # a launch (include/odin_hip.h: odin_conv2d_bwd)
+      both = (not data_only) and dst is not None and wst is st
+      wrows = C.c_int(0)
+      if both:
+        if r.kind == 'conv':
+          lib.odin_conv2d_bwd(xin.data_ptr(), g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
+                              bsp, C.byref(rows), slab.data_ptr(), C.byref(wrows), C.byref(d), st)
+        elif r.kind == 'deconv':
+          lib.odin_deconv2d_bwd(xin.data_ptr(), g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
+                                bsp, C.byref(rows), slab.data_ptr(), C.byref(wrows), C.byref(d), st)
+        else:
+          lib.odin_dense_bwd(xin.data_ptr(), g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
+                             bsp, C.byref(rows), slab.data_ptr(), C.byref(wrows), B, r.K, r.N, st)
+      elif data_only:
+        pass
+      elif r.kind == 'conv':
+        lib.odin_conv2d_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(wrows),
+                              C.byref(d), wst)
       elif r.kind == 'deconv':
-        lib.odin_deconv2d_dgrad(g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act,
-                                dst.data_ptr(), bsp, C.byref(rows), C.byref(d), st)
+        lib.odin_deconv2d_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(wrows),
+                                C.byref(d), wst)
       else:
-        lib.odin_dense_dgrad(g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
-                             bsp, C.byref(rows), B, r.K, r.N, st)
+        lib.odin_dense_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(wrows), B,
+                             r.K, r.N, wst)
+      if not data_only:
+        assert wrows.value == self.wrows[i]
+        n_red = slab.shape[1]
+        if skip_bias_of_last and i == n - 1 and r.kind != 'deconv':
+          n_red = r.w_n  # the fused tail already delivers this layer's bias gradient
+        # (jobs whose slab was written on a side stream are kept apart: only the final reduction,
+        # after the join, may read them)
+        tgt = side_jobs if (side_jobs is not None and wst is not st) else jobs
+        tgt.append(ReduceJob(slab.data_ptr(), self.grads[r.w_off:].data_ptr(), n_red, wrows.value,
+                             slab.shape[1], 0))
+      if dst is None:
+        break
+      if not both:
+        if r.kind == 'conv':
+          lib.odin_conv2d_dgrad(g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
+                                bsp, C.byref(rows), C.byref(d), st)
+        elif r.kind == 'deconv':
+          lib.odin_deconv2d_dgrad(g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act,
+                                  dst.data_ptr(), bsp, C.byref(rows), C.byref(d), st)
+        else:
+          lib.odin_dense_dgrad(g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
+                               bsp, C.byref(rows), B, r.K, r.N, st)
       if bslab is not None and not data_only:
         pr = self.recs[i - 1]
         jobs.append(ReduceJob(bslab.data_ptr(), self.grads[pr.b_off:].data_ptr(), pr.b_n,
@@ -668,8 +685,6 @@ class VAEEngine:
     st = self.stream() if st is None else st
     assert x.shape == (B,) + self.in_shape and x.is_contiguous()
     self.x = x
-    # the range words of this step's gradient tensors start from zero (their producers fold in with atomicMax)
-    lib.odin_range_reset(self.range_words.data_ptr(), self.range_words.numel() // RANGE_WORDS, st)
     lw = self.params[self.lat_w_off:]
     lb = self.params[self.lat_b_off:]
     self._used_block = self.lat_block and fused
@@ -918,6 +933,11 @@ class VAEEngine:
                               rows.value, last.b_n, 0))
     jobs += self.enc.backward(self.x, self.enc.gouts[-1], st, fork=fork)
     jobs += late_jobs
+    # the range words of the gradient tensors (their producers fold in with atomicMax, so every step starts from
+    # zero): cleared by the step's LAST backward launch -- a reduction over zero slab rows writes zeros -- instead
+    # of a memset node of its own at the top of the step (4.3 us in the step timeline)
+    rw = self.range_words
+    jobs.append(ReduceJob(rw.data_ptr(), rw.data_ptr(), rw.numel(), 0, rw.numel(), 0))
     join()
     arr = (ReduceJob * len(jobs))(*jobs)
     self._jobs_keepalive = arr

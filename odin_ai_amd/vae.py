@@ -707,14 +707,27 @@ class VariationalAutoencoder:
 
     def batches():
       if torch.is_tensor(train) or isinstance(train, np.ndarray):
-        data = _as_tensor(train, self.device)
+        data = _as_tensor(train, self.device).contiguous()
         N = data.shape[0]
         g = torch.Generator(device='cpu').manual_seed(seed)
         ep = 0
+        n_per = int(np.prod(data.shape[1:]))
+        # the shuffled batch is gathered by ONE launch straight into the tensor the step graph reads (no torch
+        # advanced-indexing kernel, no per-step copy into the static buffer)
+        direct = (data.dtype == torch.float32 and n_per % 4 == 0 and tuple(data.shape[1:]) == tuple(self.input_shape)
+                  and N >= batch_size)
+        if direct:
+          eng0 = self._engine(int(batch_size))
+          xb0 = eng0.input_buffer()
         while epochs < 0 or ep < epochs:
-          perm = torch.randperm(N, generator=g).to(self.device)
+          perm = torch.randperm(N, generator=g).to(device=self.device, dtype=torch.int32)
           for i in range(0, N - batch_size + 1, batch_size):
-            yield data[perm[i:i + batch_size]].contiguous()
+            if direct:
+              eng0.lib.odin_gather_rows_f32(data.data_ptr(), perm.data_ptr() + 4 * i, xb0.data_ptr(),
+                                            int(batch_size), n_per, eng0.stream())
+              yield xb0
+            else:
+              yield data[perm[i:i + batch_size].long()].contiguous()
           ep += 1
       else:
         ep = 0

@@ -204,6 +204,57 @@ def test_dense(bk, B, K, N, act):
   close(g[-N:], db_ref, 1e-4)
 
 
+@pytest.mark.parametrize('kind,shape', [
+    ('conv', (5, 8, 8, 64, 64, 4, 2)), ('conv', (16, 8, 8, 32, 64, 4, 2)), ('deconv', (6, 4, 4, 8, 64, 4, 2)),
+    ('dense', (100, 256, 40)), ('dense', (64, 1024, 128)), ('conv', (3, 16, 16, 32, 32, 4, 2))])
+def test_layer_bwd_in_one_call(bk, kind, shape):
+  """odin_conv2d_bwd / odin_deconv2d_bwd / odin_dense_bwd = the weight gradient + the data gradient of a layer in
+  one call (small layers: ONE launch shared by the two implicit-GEMM kernels): results identical, bit for bit, to
+  the two separate calls -- the same workgroups run the same arithmetic."""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(9)
+  rows, rows2 = C.c_int(0), C.c_int(0)
+  if kind == 'dense':
+    B, K, N = shape
+    x, w, dy, aux = (rng.standard_normal(s_) for s_ in ((B, K), (K, N), (B, N), (B, K)))
+    tx, tw, tdy, taux = T(x), T(w / np.sqrt(K)), T(dy), T(aux)
+    n = K * N + N
+    dx1, dx2 = bk.full((B, K), float('nan')), bk.full((B, K), float('nan'))
+    s1, s2 = bk.full((L.odin_max_slab_rows(), n), float('nan')), bk.full((L.odin_max_slab_rows(), n), float('nan'))
+    L.odin_dense_wgrad(tx.data_ptr(), tdy.data_ptr(), s1.data_ptr(), C.byref(rows), B, K, N, None)
+    L.odin_dense_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx1.data_ptr(), None, None, B, K, N, None)
+    L.odin_dense_bwd(tx.data_ptr(), tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx2.data_ptr(), None, None,
+                     s2.data_ptr(), C.byref(rows2), B, K, N, None)
+  else:
+    B, H, W, Ci, Co, K, S = shape
+    if kind == 'conv':
+      OH, pt, _ = vo.same_pads(H, K, S)
+      OW, pl, _ = vo.same_pads(W, K, S)
+      wshape = (K, K, Ci, Co)
+    else:
+      OH, OW = H * S, W * S
+      _, pt, _ = vo.same_pads(OH, K, S)
+      _, pl, _ = vo.same_pads(OW, K, S)
+      wshape = (K, K, Co, Ci)
+    d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, 'elu')
+    x, w, dy, aux = (rng.standard_normal(s_) for s_ in ((B, H, W, Ci), wshape, (B, OH, OW, Co), (B, H, W, Ci)))
+    tx, tw, tdy, taux = T(x), T(w * 0.1), T(dy), T(aux)
+    n = K * K * Ci * Co + (Co if kind == 'conv' else 0)
+    dx1, dx2 = bk.full((B, H, W, Ci), float('nan')), bk.full((B, H, W, Ci), float('nan'))
+    s1, s2 = bk.full((L.odin_max_slab_rows(), n), float('nan')), bk.full((L.odin_max_slab_rows(), n), float('nan'))
+    wg, dg, bw = ((L.odin_conv2d_wgrad, L.odin_conv2d_dgrad, L.odin_conv2d_bwd) if kind == 'conv' else
+                  (L.odin_deconv2d_wgrad, L.odin_deconv2d_dgrad, L.odin_deconv2d_bwd))
+    wg(tx.data_ptr(), tdy.data_ptr(), s1.data_ptr(), C.byref(rows), C.byref(d), None)
+    dg(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx1.data_ptr(), None, None, C.byref(d), None)
+    bw(tx.data_ptr(), tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx2.data_ptr(), None, None,
+       s2.data_ptr(), C.byref(rows2), C.byref(d), None)
+  path = L.odin_debug_last_path().decode()
+  print(kind, shape, path)
+  assert rows.value == rows2.value and rows.value > 0
+  assert torch.equal(dx1, dx2)
+  assert torch.equal(s1[:rows.value], s2[:rows.value])
+
+
 @pytest.fixture(scope='module')
 def hipbk():
   import torch

@@ -7,7 +7,7 @@ sys.path.insert(0, '.')
 from odin_ai_amd import _lib
 L = _lib.load(os.environ.get('ODIN_DIAG_LIB') or 'tools/diag/libodin_hip_diag.so')
 dev = torch.device('cuda:0')
-names = {1: 'kernel start', 2: 'tile start', 3: 'mfma 0 issued', 4: 'mfma 23 issued', 5: 'partials written',
+names = {1: 'kernel start', 2: 'tile start', 3: 'mfma 0 issued', 4: 'mfma 11 issued', 5: 'partials written',
          6: 'zero fills + tables done', 7: 'behind the prologue barrier', 8: 'weights split', 9: 'first rows stored'}
 B, H, W = 256, 32, 32
 d = _lib.conv_desc(B, H, W, 32, 2 * H, 2 * W, 32, 4, 2, 1, 1, 'elu')
@@ -16,6 +16,9 @@ g = torch.randn(B, 2 * H, 2 * W, 32, device=dev)
 dx = torch.empty(B, H, W, 32, device=dev); aux = torch.randn(B, H, W, 32, device=dev)
 bs = torch.empty(L.odin_max_slab_rows(), 32, device=dev)
 rows = C.c_int(0)
+words = torch.zeros(2048, dtype=torch.int32, device=dev)   # range word of g (odin_conv_desc.dy_amax)
+L.odin_absmax(g.data_ptr(), g.numel(), words.data_ptr(), None)
+d.dy_amax = words.data_ptr()
 fn = lambda: L.odin_deconv2d_dgrad(g.data_ptr(), w.data_ptr(), aux.data_ptr(), 1, dx.data_ptr(), bs.data_ptr(),
                                    C.byref(rows), C.byref(d), None)
 for _ in range(5): fn()
