@@ -199,12 +199,19 @@ def profile_hbm_kernels(eng, reps=48):
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e-3
 
-  def entry(kernel, shape, nbytes, t_hbm, t_hot, nsets, t_probe=None):
+  def entry(kernel, shape, nbytes, t_hbm, t_hot, nsets, t_probe=None, t_own=None):
     extra = {}
+    if t_own is not None:
+      # the ceiling of THIS part for a stream of this length and shape: a hand-written kernel with the same traffic
+      # (two arrays read, one written) and no arithmetic, persistent grid, streaming stores -- the fastest of the launch
+      # shapes swept by tools/elbo_ceiling.py (odin_debug_stream_probe, profiles/r04_elbo_stream_sweep.txt)
+      extra.update(own_stream_gbs=round(nbytes / t_own * 1e-9, 1), own_stream_frac_of_hbm_peak=round(nbytes / t_own * 1e-9 / PEAK_HBM_GBS, 4),
+                   frac_of_own_stream=round(t_own / t_hbm, 4),
+                   own_stream='odin_debug_stream_probe variant 8 (out = a + b, 512 workgroups grid-stride, non-temporal stores)')
     if t_probe is not None:
       # a plain elementwise launch with the SAME traffic (2 arrays read, 1 written, same sizes, same rotation):
       # what a stream of this length reaches on this box from cold HBM -- short launches pay their ramp
-      extra = dict(same_traffic_probe_gbs=round(nbytes / t_probe * 1e-9, 1),
+      extra.update(same_traffic_probe_gbs=round(nbytes / t_probe * 1e-9, 1),
                    same_traffic_probe='torch.add(a, b, out=c) over the same rotating buffer sets',
                    frac_of_probe=round(t_probe / t_hbm, 4))
     return dict(extra, bound='hbm', kernel=kernel, shape=shape, achieved=round(nbytes / t_hbm * 1e-9, 1),
@@ -235,9 +242,11 @@ def profile_hbm_kernels(eng, reps=48):
         lg.data_ptr(), x.data_ptr(), part.data_ptr(), dl.data_ptr(), sc, B, n, C.byref(npart), st))
     fns = [mk(*t) for t in sets]
     probe = [(lambda a=a, b=b, c=c: torch.add(a, b, out=c)) for (a, b, c) in sets]
+    own = [(lambda a=a, b=b, c=c: lib.odin_debug_stream_probe(a.data_ptr(), b.data_ptr(), c.data_ptr(), B * n, 8, 512, st))
+           for (a, b, c) in sets] if (B * n) % 4 == 0 else None
     out.append(entry('elbo_bernoulli_fwd_bwd', [B, npix, Cc], 12.0 * B * n, timeit(fns), timeit(fns[:1]), ns,
-                     timeit(probe)))
-    del probe
+                     timeit(probe), timeit(own) if own else None))
+    del probe, own
     del sets, fns
     ns = nsets_for(20.0 * B * n)
     sets = [(torch.randn(B, npix, 2 * Cc, device=dev), torch.rand(B, n, device=dev),

@@ -63,6 +63,10 @@ int odin_max_slab_rows(void);      /* upper bound of the rows any slab-producing
 #define ODIN_RANGE_WORDS 2048
 int odin_range_reset(uint32_t* words, int n, void* stream);
 int odin_absmax(const float* t, size_t n, uint32_t* word, void* stream);
+/* diagnostics: a stream with the traffic of the fused Bernoulli ELBO kernel (out = a + b over n floats; 12 bytes per
+ * element) in several launch shapes -- the ceiling bench.py prices that kernel against beside the 8 TB/s peak */
+int odin_debug_stream_probe(const float* a, const float* b, float* out, size_t n, int variant, int blocks,
+                            void* stream);
 /* diagnostics: how many times a consumer had to bound a gradient tensor itself (no range word given) */
 int odin_debug_absmax_fallbacks(void);
 

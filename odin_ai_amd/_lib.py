@@ -48,6 +48,7 @@ SIGNATURES = {
     'odin_dense_bwd': [P, P, P, P, I, P, P, IP, P, IP, I, I, I, P],
     'odin_absmax': [P, C.c_size_t, P, P],
     'odin_debug_absmax_fallbacks': [],
+    'odin_debug_stream_probe': [P, P, P, C.c_size_t, I, I, P],
     'odin_comm_unique_id': [P],
     'odin_comm_init': [C.POINTER(C.c_void_p), P, I, I],
     'odin_comm_destroy': [P],

@@ -421,6 +421,17 @@ __device__ __forceinline__ void odin_wait_vmem() {
 #endif
 }
 
+// 16-byte store with the streaming (non-temporal) hint: for outputs of HBM-bound kernels
+__device__ __forceinline__ void odin_store4_stream(float4* p, const float4& v) {
+#ifdef ODIN_SIM
+  *p = v;
+#else
+  f32x4 r;
+  r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+  __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(p));
+#endif
+}
+
 enum { ODIN_ACT_LINEAR = 0, ODIN_ACT_ELU = 1, ODIN_ACT_RELU = 2 };
 
 __device__ __forceinline__ float odin_act(int act, float v) {

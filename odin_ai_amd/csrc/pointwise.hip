@@ -226,10 +226,52 @@ __global__ __launch_bounds__(256) void elbo_bernoulli_stream_kernel(
     bern1(l[u].y, t[u].y, sc, acc, g.y);
     bern1(l[u].z, t[u].z, sc, acc, g.z);
     bern1(l[u].w, t[u].w, sc, acc, g.w);
-    dlogits[base + 64 * u] = g;
+    // non-temporal store: measured on the same traffic (tools/elbo_ceiling.py, odin_debug_stream_probe) a 38 MB cold
+    // stream reaches 4.4 TB/s with plain stores and 5.7 TB/s with streaming ones -- the written lines do not wait in
+    // the caches behind the reads
+    odin_store4_stream(dlogits + base + 64 * u, g);
   }
   acc = wave_sum64(acc);
   if (lane == 0) llk_part[w] = acc;
+}
+
+// The same as a persistent grid: 512 workgroups walk the 256-element chunks (64 lanes x float4; a chunk lies inside
+// one sample) grid-stride with U chunks of loads in flight per lane and streaming stores; one partial per chunk.
+// On the stream probes (tools/elbo_ceiling.py) this launch shape with non-temporal stores is the fastest
+// 2-in / 1-out stream of this length on the part (5.6-5.7 TB/s cold against 4.4 for the chunk-per-wave shape).
+template <int U>
+__global__ __launch_bounds__(256) void elbo_bernoulli_gs_kernel(
+    const float4* __restrict__ logits, const float4* __restrict__ x, float* __restrict__ llk_part,
+    float4* __restrict__ dlogits, const float* __restrict__ scale, size_t n_chunks) {
+  const size_t nw = (size_t)gridDim.x * 4;
+  const int lane = threadIdx.x & 63;
+  const float sc = scale[0];
+  for (size_t c0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); c0 < n_chunks; c0 += nw * U) {
+    float4 l[U], t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t c = c0 + u * nw;  // (wave-uniform)
+      if (c < n_chunks) {
+        l[u] = logits[c * 64 + lane];
+        t[u] = x[c * 64 + lane];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t c = c0 + u * nw;
+      if (c < n_chunks) {
+        float4 g;
+        float acc = 0.f;
+        bern1(l[u].x, t[u].x, sc, acc, g.x);
+        bern1(l[u].y, t[u].y, sc, acc, g.y);
+        bern1(l[u].z, t[u].z, sc, acc, g.z);
+        bern1(l[u].w, t[u].w, sc, acc, g.w);
+        odin_store4_stream(dlogits + c * 64 + lane, g);
+        acc = odin_wave_sum64_valu(acc);
+        if (lane == 0) llk_part[c] = acc;
+      }
+    }
+  }
 }
 
 // h [B, n_pix, 2C] (loc | raw scale), x [B, n_pix, C]; N = n_pix*C elements per sample
@@ -361,7 +403,7 @@ __global__ __launch_bounds__(256) void elbo_gaussian_stream_kernel(
     for (int j = 0; j < 2 * C; ++j) hs[(q * 64 + lane) * 2 * C + j] = o[q * 2 * C + j];
   odin_wave_sync();
 #pragma unroll
-  for (int j = 0; j < NH; ++j) dh[bh + j * 64 + lane] = hs[j * 64 + lane];
+  for (int j = 0; j < NH; ++j) odin_store4_stream(dh + bh + j * 64 + lane, hs[j * 64 + lane]);
   acc = wave_sum64(acc);
   if (lane == 0) llk_part[w] = acc;
 }
@@ -688,6 +730,26 @@ static int elbo_stream_unroll(int n_per_sample) {
 extern "C" int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, float* llk_part,
                                            float* dlogits, const float* scale, int B,
                                            int n_per_sample, int* n_part_out, void* stream) {
+  // large tensors: the persistent form (one partial per 256-element chunk)
+  if (n_per_sample % 256 == 0 && (size_t)B * n_per_sample >= (1u << 20) && !getenv("ODIN_ELBO_U") &&
+      (((uintptr_t)logits | (uintptr_t)x | (uintptr_t)dlogits) & 15) == 0) {
+    const int n_part = n_per_sample / 256;
+    if (n_part_out) *n_part_out = n_part;
+    if (logits == nullptr) return 0;  // dry run: reports the partial count
+    const size_t n_chunks = (size_t)B * n_part;
+    int blocks = 2048, U = 2;  // (sweep of blocks x U on the 64x64x3, batch-256 shape: profiles/r04_elbo_stream_sweep.txt)
+    if (const char* e = getenv("ODIN_ELBO_GS")) sscanf(e, "%d,%d", &blocks, &U);  // diagnostics sweep
+#define ODIN_ELBO_GS_LAUNCH(UU)                                                                              \
+  ODIN_LAUNCH((elbo_bernoulli_gs_kernel<UU>), dim3(blocks), dim3(256), 0, stream, (const float4*)logits,    \
+              (const float4*)x, llk_part, (float4*)dlogits, scale, n_chunks)
+    if (U == 2) ODIN_ELBO_GS_LAUNCH(2);
+    else if (U == 3) ODIN_ELBO_GS_LAUNCH(3);
+    else if (U == 6) ODIN_ELBO_GS_LAUNCH(6);
+    else if (U == 8) ODIN_ELBO_GS_LAUNCH(8);
+    else ODIN_ELBO_GS_LAUNCH(4);
+#undef ODIN_ELBO_GS_LAUNCH
+    return odin_check_launch("elbo_bernoulli");
+  }
   const int U = elbo_stream_unroll(n_per_sample);
   if (U > 0 && (((uintptr_t)logits | (uintptr_t)x | (uintptr_t)dlogits) & 15) == 0) {
     const int n_part = n_per_sample / (256 * U);
@@ -1078,6 +1140,89 @@ extern "C" int odin_gather_normalize_u8(const uint8_t* data, const int32_t* idx,
   ODIN_LAUNCH(gather_normalize_u8_kernel, dim3(grid), dim3(256), 0, stream, data, (const int*)idx, out,
               B, n_per, premul, mode);
   return odin_check_launch("gather_normalize_u8");
+}
+
+// ---- diagnostics: hand-written streams with the traffic of the fused Bernoulli ELBO kernel (two arrays read, one
+// written, 12 bytes per element) and NO arithmetic to speak of -- the ceiling a launch of that length can reach on
+// this part (bench.py: elbo_kernel.frac_of_own_stream).  variant 0: the ELBO kernel's own shape (one wave = 64 x U
+// float4 per array, all loads first); 1: persistent grid, grid-stride, 4 float4 pairs in flight per lane; 2: the same
+// with non-temporal loads and stores; 3: 8 pairs in flight ----
+// NT bits: 1 = non-temporal loads of a, 2 = of b, 4 = non-temporal stores
+template <int U, int NT>
+__global__ __launch_bounds__(256) void stream_probe_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b,
+                                                           f32x4* __restrict__ out, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += stride * U) {
+    f32x4 x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i < n4) {
+        x[u] = (NT & 1) ? __builtin_nontemporal_load(a + i) : a[i];
+        y[u] = (NT & 2) ? __builtin_nontemporal_load(b + i) : b[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i < n4) {
+        const f32x4 r = x[u] + y[u];
+        if (NT & 4) __builtin_nontemporal_store(r, out + i); else out[i] = r;
+      }
+    }
+  }
+}
+template <int U>
+__global__ __launch_bounds__(256) void stream_probe_wave_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                                float4* __restrict__ out, size_t n_waves) {
+  const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_waves) return;
+  const size_t base = w * (size_t)(64 * U) + (threadIdx.x & 63);
+  float4 x[U], y[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) x[u] = a[base + 64 * u];
+#pragma unroll
+  for (int u = 0; u < U; ++u) y[u] = b[base + 64 * u];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    out[base + 64 * u] = make_float4(x[u].x + y[u].x, x[u].y + y[u].y, x[u].z + y[u].z, x[u].w + y[u].w);
+}
+
+extern "C" int odin_debug_stream_probe(const float* a, const float* b, float* out, size_t n, int variant, int blocks,
+                                       void* stream) {
+  if ((n & 3) != 0 || n == 0) return odin_fail(-2, "stream_probe: n must be a positive multiple of 4");
+  const size_t n4 = n >> 2;
+  const float4 *a4 = (const float4*)a, *b4 = (const float4*)b;
+  float4* o4 = (float4*)out;
+  const f32x4 *av = (const f32x4*)a, *bv = (const f32x4*)b;
+  f32x4* ov = (f32x4*)out;
+  if (blocks <= 0) blocks = odin_num_cus() * 8;
+  if (variant == 0) {
+    if (n4 % (64 * 3) != 0) return odin_fail(-2, "stream_probe 0: n must be a multiple of 768");
+    const size_t nw = n4 / (64 * 3);
+    ODIN_LAUNCH((stream_probe_wave_kernel<3>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, stream, a4, b4, o4, nw);
+  } else if (variant == 1) {
+    ODIN_LAUNCH((stream_probe_kernel<4, 0>), dim3(blocks), dim3(256), 0, stream, av, bv, ov, n4);
+  } else if (variant == 2) {
+    ODIN_LAUNCH((stream_probe_kernel<4, 7>), dim3(blocks), dim3(256), 0, stream, av, bv, ov, n4);
+  } else if (variant == 3) {
+    ODIN_LAUNCH((stream_probe_kernel<8, 0>), dim3(blocks), dim3(256), 0, stream, av, bv, ov, n4);
+  } else if (variant == 4) {
+    ODIN_LAUNCH((stream_probe_kernel<8, 7>), dim3(blocks), dim3(256), 0, stream, av, bv, ov, n4);
+  } else if (variant == 5) {
+    ODIN_LAUNCH((stream_probe_kernel<2, 0>), dim3(blocks), dim3(256), 0, stream, av, bv, ov, n4);
+  } else if (variant == 6) {
+    ODIN_LAUNCH((stream_probe_kernel<4, 2>), dim3(blocks), dim3(256), 0, stream, av, bv, ov, n4);
+  } else if (variant == 7) {
+    ODIN_LAUNCH((stream_probe_kernel<4, 3>), dim3(blocks), dim3(256), 0, stream, av, bv, ov, n4);
+  } else if (variant == 8) {
+    ODIN_LAUNCH((stream_probe_kernel<4, 4>), dim3(blocks), dim3(256), 0, stream, av, bv, ov, n4);
+  } else if (variant == 9) {
+    ODIN_LAUNCH((stream_probe_kernel<4, 6>), dim3(blocks), dim3(256), 0, stream, av, bv, ov, n4);
+  } else {
+    return odin_fail(-2, "stream_probe: variant 0..9");
+  }
+  return odin_check_launch("stream_probe");
 }
 
 // batch gather from an HBM-resident float32 dataset that is already normalised (fit() on a tensor:

@@ -50,8 +50,12 @@ def test_latent_fwd_bwd(bk, analytic, fb):
 
 
 @pytest.mark.parametrize('shape', [(3, 8, 8, 1), (2, 64, 64, 3), (5, 7, 3, 1), (3, 64, 64, 1),
-                                   (2, 32, 32, 1), (3, 16, 16, 2)])
+                                   (2, 32, 32, 1), (3, 16, 16, 2),
+                                   # >= 2^20 elements: the persistent grid-stride form (one partial per 256 elements)
+                                   (86, 64, 64, 3), (300, 64, 64, 1)])
 def test_elbo_bernoulli_and_finalize(bk, shape):
+  if bk.name == 'sim' and int(np.prod(shape)) > 200000:
+    pytest.skip('large shapes run on the GPU backend only (fiber simulator: minutes)')
   L, T = bk.L, bk.T
   rng = np.random.default_rng(1)
   B = shape[0]
