@@ -625,6 +625,7 @@ def main():
     rccl['transport'] = ('RCCL through the C ABI (odin_allreduce_flat, own communicator)'
                          if eng._comm().native else 'torch.distributed ' + dist.get_backend())
     rccl['dp_buckets'] = eng.dp_buckets
+    rccl['library'] = eng.lib.odin_comm_library().decode() if eng._comm().native else 'torch.distributed'
     sgs = list(getattr(eng, '_graphs', {}).values()) + [v[0] for v in getattr(fv, '_fgraphs', {}).values()] \
         if use_graph else []
     if sgs:
@@ -672,6 +673,7 @@ def main():
       obj['traffic_unit'] = 'bytes'
       obj['algorithmic_bytes'] = ent.get('algorithmic_bytes')
       obj['traffic_source'] = 'profiles/' + os.path.basename(pmc_file)
+      obj['traffic_measured_in_this_run'] = False  # (PMC counters cannot be collected inside this process)
 
   attach_traffic(roofline)
   roofline_split = None

@@ -375,6 +375,9 @@ int odin_stft_mel_db_frames(const float* y, const double* window, const double* 
 int odin_comm_unique_id(void* id128);
 int odin_comm_init(void** comm_out, const void* id128, int rank, int world_size);
 int odin_comm_destroy(void* comm);
+/* the RCCL library bound by this process: ODIN_RCCL_LIB, else the librccl the process has already mapped (the one
+ * PyTorch bundles -- never a second copy), else the system one; "" before the first odin_comm_* call */
+const char* odin_comm_library(void);
 int odin_allreduce_flat(void* comm, float* buf, size_t n, void* stream);
 int odin_allgather_flat(void* comm, const float* send, float* recv, size_t n_per_rank, void* stream);
 int odin_reduce_scatter_flat(void* comm, const float* send, float* recv, size_t n_per_rank, void* stream);

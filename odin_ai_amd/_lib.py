@@ -52,6 +52,7 @@ SIGNATURES = {
     'odin_comm_unique_id': [P],
     'odin_comm_init': [C.POINTER(C.c_void_p), P, I, I],
     'odin_comm_destroy': [P],
+    'odin_comm_library': [],
     'odin_allreduce_flat': [P, P, C.c_size_t, P],
     'odin_allgather_flat': [P, P, P, C.c_size_t, P],
     'odin_reduce_scatter_flat': [P, P, P, C.c_size_t, P],
@@ -107,7 +108,7 @@ SIGNATURES = {
 
 
 # entry points whose return value is a result, not an error code
-VALUE_RETURNING = ('odin_version', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
+VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
                    'odin_latent_block_rows', 'odin_total_correlation_workspace')
 
 
@@ -130,7 +131,7 @@ class Lib:
     for name, args in SIGNATURES.items():
       fn = getattr(self.c, name)  # AttributeError if the symbol is missing: fail loudly
       fn.argtypes = args
-      fn.restype = (C.c_char_p if name == 'odin_debug_last_path' else
+      fn.restype = (C.c_char_p if name in ('odin_debug_last_path', 'odin_comm_library') else
                     C.c_uint32 if name in VALUE_RETURNING else C.c_int)
 
   def check(self, rc: int, what: str = ''):

@@ -27,6 +27,7 @@ struct Rccl {
   int (*AllGather)(const void*, void*, size_t, int, OdinNcclComm, void*) = nullptr;
   int (*ReduceScatter)(const void*, void*, size_t, int, int, OdinNcclComm, void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  char origin[256] = "";  // which library was bound (odin_comm_library)
 };
 Rccl g_rccl;
 
@@ -35,12 +36,24 @@ int rccl_bind() {
   return odin_fail(-3, "RCCL is unavailable in the simulator build");
 #else
   if (g_rccl.h != nullptr) return 0;
-  const char* names[] = {getenv("ODIN_RCCL_LIB"), "librccl.so.1", "librccl.so"};
+  // 1. an explicit ODIN_RCCL_LIB; 2. the RCCL the process has ALREADY mapped (PyTorch bundles its own librccl and
+  // loads it with torch.distributed: RTLD_NOLOAD returns that handle instead of mapping a second copy of the library
+  // -- two RCCLs in one process each run their own bootstrap and proxy threads); 3. the system library
+  const char* explicit_lib = getenv("ODIN_RCCL_LIB");
+  const char* names[] = {"librccl.so.1", "librccl.so"};
   void* h = nullptr;
-  for (const char* n : names) {
-    if (n == nullptr || *n == 0) continue;
-    h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (h != nullptr) break;
+  if (explicit_lib != nullptr && *explicit_lib != 0) {
+    h = dlopen(explicit_lib, RTLD_NOW | RTLD_LOCAL);
+    if (h != nullptr) snprintf(g_rccl.origin, sizeof(g_rccl.origin), "ODIN_RCCL_LIB=%s", explicit_lib);
+  }
+  for (int pass = 0; h == nullptr && pass < 2; ++pass) {
+    for (const char* n : names) {
+      h = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+      if (h != nullptr) {
+        snprintf(g_rccl.origin, sizeof(g_rccl.origin), "%s (%s)", n, pass == 0 ? "already loaded by the process" : "dlopen");
+        break;
+      }
+    }
   }
   if (h == nullptr) return odin_fail(-4, "cannot load librccl (set ODIN_RCCL_LIB to its path)");
 #define ODIN_SYM(field, name)                                      \
@@ -82,6 +95,9 @@ extern "C" int odin_comm_init(void** comm_out, const void* id128, int rank, int 
   *comm_out = c;
   return 0;
 }
+
+// which RCCL the communicators of this process run on ("" before the first odin_comm_* call)
+extern "C" const char* odin_comm_library(void) { return g_rccl.origin; }
 
 extern "C" int odin_comm_destroy(void* comm) {
   if (comm == nullptr || g_rccl.h == nullptr) return 0;

@@ -169,7 +169,7 @@ int dg_launch(DGParams& p, void* stream) {
 // layer alone fills the chip for long enough to amortise its LDS staging).
 bool odin_dense_gemm_ok(int B, int K, int N) {
   static int off = -1;
-  if (off < 0) off = getenv("ODIN_NODENSEGEMM") ? 1 : 0;
+  if (off < 0) off = ODIN_DIAG_ENV("ODIN_NODENSEGEMM") ? 1 : 0;
   if (off) return false;
   const double flop = 2.0 * B * K * N;
   return B >= 1 && B <= 4096 && K >= 1 && N >= 1 && flop <= 1.2e9 && (long)K * N < (1L << 28) &&

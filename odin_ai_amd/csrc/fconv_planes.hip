@@ -443,8 +443,8 @@ void odin_fconv_planes_set_stamps(void* buf) { g_fp_stamps = (long long*)buf; }
 bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
                                   int pt, int pl, int center) {
   // (read per call: the A/B tests switch paths inside one process; a captured graph never comes here)
-  if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT") || getenv("ODIN_NOFPLANES")) return false;
-  return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && (CI == 32 || (CI == 64 && !getenv("ODIN_FP_NO64"))) && (CO % 32) == 0 && !center &&
+  if (odin_exact_fp32() || ODIN_DIAG_ENV("ODIN_NOPLANES") || ODIN_DIAG_ENV("ODIN_SPLIT") || ODIN_DIAG_ENV("ODIN_NOFPLANES")) return false;
+  return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && (CI == 32 || (CI == 64 && !ODIN_DIAG_ENV("ODIN_FP_NO64"))) && (CO % 32) == 0 && !center &&
          H == 2 * OH && W == 2 * OW && (OW == 8 || OW == 16 || OW == 32) && (OH % (32 / OW)) == 0 &&
          (size_t)B * H * W * CI * 4 < 0x7FFF0000ull && (size_t)B * OH * OW * CO * 4 < (1ull << 31) &&
          fp_tiles_per_wg(OW, B * (OH / (32 / OW)), CO / 32) > 0;

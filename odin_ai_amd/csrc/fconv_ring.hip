@@ -419,7 +419,7 @@ int odin_fconv_ring_launch(const float* in, const float* w, const float* bias, c
 bool odin_fconv_ring_applicable(int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
                                 int pt, int pl, int center) {
   static int off = -1;
-  if (off < 0) off = getenv("ODIN_NOFRING") ? 1 : 0;
+  if (off < 0) off = ODIN_DIAG_ENV("ODIN_NOFRING") ? 1 : 0;
   return !off && KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && (CI == 32 || CI == 64) &&
          (CO % 32) == 0 && !center && H == 2 * OH && W == 2 * OW && (OW == 8 || OW == 16 || OW == 32) &&
          (OH % (64 / OW)) == 0;

@@ -1287,7 +1287,7 @@ bool plan_gather(GParams& p, int mode, int max_blocks, int* grid_x, size_t* lds_
     // (longest patch row an instance stages: the generic ones KMAX = 9 items per lane, the wide-row 4x4 / stride-2
     // strided-gather instance over 32 channels 12)
     const int kmax_row = (mode == MODE_F && p.KH == 4 && p.KW == 4 && S == 2 && p.CI == 32 && cic == 32 &&
-                          !getenv("ODIN_NOWIDEROWS")) ? 12 : GENERIC_KMAX;
+                          !ODIN_DIAG_ENV("ODIN_NOWIDEROWS")) ? 12 : GENERIC_KMAX;
     if (pf + wf <= LDS_BUDGET_FLOATS && (flat0 || rowlen <= 64 * kmax_row)) break;
     if (cic <= gran) return false;
     // next smaller chunk: halve, rounded up to the granularity
@@ -1370,7 +1370,7 @@ int launch_inst(GParams& p, const TailParams& tp, dim3 grid, size_t lds, void* s
 // (144.6 vs 121.8 us).  The default is the 8-wave form with the weight planes in LDS (split8 in
 // launch_gather: fused tail 116.7 -> 89.4 us).
 bool split_ok(const GParams& p) {
-  const char* e = getenv("ODIN_SPLIT");
+  const char* e = ODIN_DIAG_ENV("ODIN_SPLIT");
   return e != nullptr && e[0] == '1' && p.CI == 32 && !p.center && p.MT <= NW_G && p.w_resident;
 }
 size_t split_lds(GParams& p) {
@@ -1387,7 +1387,7 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
   if (!plan_gather(p, mode, max_blocks, &gx, &lds)) return odin_fail(-2, "gather_conv: no tiling plan");
   // small-M layers: with 128-pixel tiles only a few workgroups exist while each carries a long
   // reduction -> use 32- (or 64-) pixel tiles and let 4 (2) waves split the channels
-  if (mode == MODE_F && tail == nullptr && !getenv("ODIN_NOKSPLIT")) {
+  if (mode == MODE_F && tail == nullptr && !ODIN_DIAG_ENV("ODIN_NOKSPLIT")) {
     const int blocks = p.n_tiles * ((p.CO + 31) / 32);
     const long kdepth = (long)p.KH * p.KW * p.CI;
     if (blocks * 2 <= odin_num_cus() && kdepth >= 256) {
@@ -1406,13 +1406,13 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     }
   }
   p.wdma = (p.wmode == 0 && p.w_resident && (p.CO % 32) == 0 && p.CI == p.CIC && (p.CIC % 8) == 0 &&
-            !getenv("ODIN_NOWDMA")) ? 1 : 0;
+            !ODIN_DIAG_ENV("ODIN_NOWDMA")) ? 1 : 0;
   // opt-in ODIN_SPLIT=8: 8-wave workgroups (two waves per SIMD) on 256-pixel tiles, fp32 through
   // the bf16 pipe with the three weight planes shared in LDS
   int split8 = 0;  // 1: EPI 1, 2: EPI 2, 3: fused tail (EPI 1, one logit map)
   {
-    const char* e = getenv("ODIN_SPLIT");
-    const bool on8 = e == nullptr || e[0] == '8';  // default; ODIN_SPLIT=0: fp32 MFMA instances
+    const char* e = ODIN_DIAG_ENV("ODIN_SPLIT");
+    const bool on8 = (e == nullptr || e[0] == '8') && !odin_exact_fp32();  // default; ODIN_EXACT_FP32: fp32 MFMA instances
     const bool elu_fwd = p.act == ODIN_ACT_ELU && p.aux == nullptr;
     const bool lin_bwd = p.act == ODIN_ACT_LINEAR && p.aux != nullptr && p.aux_act == ODIN_ACT_ELU;
     if (on8 && mode == MODE_T && p.KH == 4 && p.KW == 4 && p.S == 2 &&
@@ -1441,7 +1441,7 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
   // staging and barrier waits (what two workgroups per CU do for the 32-channel instances)
   int wave8 = 0;  // 1: forward (ELU epilogue)
   if (split8 == 0 && tail == nullptr && mode == MODE_T && p.KH == 4 && p.KW == 4 && p.S == 2 &&
-      p.CI == 64 && (p.CO % 32) == 0 && !p.center && !getenv("ODIN_NOWAVE8")) {
+      p.CI == 64 && (p.CO % 32) == 0 && !p.center && !ODIN_DIAG_ENV("ODIN_NOWAVE8")) {
     const bool elu_fwd = p.act == ODIN_ACT_ELU && p.aux == nullptr;
     GParams q = p;
     int gx2;
@@ -1465,7 +1465,7 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
   if (p.out == nullptr) return 0;  // dry run: planning only
   {
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("ODIN_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) { const char* e = ODIN_DIAG_ENV("ODIN_DBG"); dbg = e ? atoi(e) : 0; }
     p.dbg = dbg;
     p.stamps = g_stamps;
   }
@@ -1476,7 +1476,7 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
   const int rpw = (p.NIMG * p.NRI + NW_G - 1) / NW_G;
   constexpr int GK = GENERIC_KMAX;
   static int noepi = -1;
-  if (noepi < 0) { const char* e = getenv("ODIN_NOEPI"); noepi = e ? atoi(e) : 0; }
+  if (noepi < 0) { const char* e = ODIN_DIAG_ENV("ODIN_NOEPI"); noepi = e ? atoi(e) : 0; }
   const bool fulln = (p.CO % 32) == 0 && !noepi;
   const int epi = !fulln ? 0
                   : (p.act == ODIN_ACT_ELU && p.aux == nullptr) ? 1
@@ -1494,7 +1494,7 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     if (p.CO > 32 || tp.C1 > MAXC1 || p.NIMG != 1 || !p.vec)
       return odin_fail(-2, "bernoulli tail: needs Cout<=32, C1<=4, Cin%4==0 and one image per tile");
     if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 1 && tp.C1 == 1 &&
-        !getenv("ODIN_NOTAIL2WG"))  // two workgroups per CU
+        !ODIN_DIAG_ENV("ODIN_NOTAIL2WG"))  // two workgroups per CU
     {
       if (split_ok(p))
         return launch_inst2<MODE_T, 4, 2, 32, true, 1, 5, 1, 1, 1, true>(p, tp, grid, split_lds(p), stream);
@@ -1532,7 +1532,7 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     // wider rows than the image stacks' (the speech stack: 40- and 80-pixel rows; vae_audio.py:84-110): the same
     // 4x4 / stride-2 instances with longer patch rows per lane -- these shapes used to fall to the generic
     // instance (30-40 TFLOP/s)
-    if (k4s2 && p.CIC == 32 && p.KI <= 12 && !getenv("ODIN_NOWIDEROWS")) {
+    if (k4s2 && p.CIC == 32 && p.KI <= 12 && !ODIN_DIAG_ENV("ODIN_NOWIDEROWS")) {
       if (epi == 1) return launch_inst<MODE_F, 4, 2, 32, true, 0, 12, 2, 1>(p, tp, grid, lds, stream);
       if (epi == 2) return launch_inst<MODE_F, 4, 2, 32, true, 0, 12, 2, 2>(p, tp, grid, lds, stream);
       return launch_inst<MODE_F, 4, 2, 32, true, 0, 12, 2, 0>(p, tp, grid, lds, stream);
@@ -1544,12 +1544,12 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     if (p.KI <= 2) return launch_inst<MODE_F, 0, 0, 0, false, 0, 2, 8>(p, tp, grid, lds, stream);
     return launch_inst<MODE_F, 0, 0, 0, false, 0, GK, 2>(p, tp, grid, lds, stream);
   }
-  if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 1 && !getenv("ODIN_NO2WG")) {
+  if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 1 && !ODIN_DIAG_ENV("ODIN_NO2WG")) {
     if (split_ok(p))
       return launch_inst2<MODE_T, 4, 2, 32, true, 0, 5, 1, 1, 1, true>(p, tp, grid, split_lds(p), stream);
     return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 1, 1>(p, tp, grid, lds, stream);
   }
-  if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 2 && !getenv("ODIN_NO2WG")) {
+  if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 2 && !ODIN_DIAG_ENV("ODIN_NO2WG")) {
     if (split_ok(p))
       return launch_inst2<MODE_T, 4, 2, 32, true, 0, 5, 1, 2, 1, true>(p, tp, grid, split_lds(p), stream);
     return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 1, 2>(p, tp, grid, lds, stream);
@@ -1564,7 +1564,7 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     if (epi == 2) return launch_inst<MODE_T, 4, 2, 64, true, 0, 5, 2, 2>(p, tp, grid, lds, stream);
     return launch_inst<MODE_T, 4, 2, 64, true, 0, 5, 2, 0>(p, tp, grid, lds, stream);
   }
-  if (k4s2 && (p.CIC == 32 || p.CIC == 64) && p.KI <= 8 && !getenv("ODIN_NOWIDEROWS")) {  // (wider rows: see MODE_F)
+  if (k4s2 && (p.CIC == 32 || p.CIC == 64) && p.KI <= 8 && !ODIN_DIAG_ENV("ODIN_NOWIDEROWS")) {  // (wider rows: see MODE_F)
     if (p.CIC == 32) {
       if (epi == 1) return launch_inst<MODE_T, 4, 2, 32, true, 0, 8, 2, 1>(p, tp, grid, lds, stream);
       if (epi == 2) return launch_inst<MODE_T, 4, 2, 32, true, 0, 8, 2, 2>(p, tp, grid, lds, stream);
@@ -1734,7 +1734,7 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
 // Dense layers whose reduction width is a multiple of 8 through the implicit-GEMM kernel (a 1x1 convolution on a
 // 1x1 image; FactorVAE's 1000-unit discriminator, the 512-unit default nets; enc4 of the dSprites step:
 // 12.6 + 9.2 + 7.7 -> 9.9 + 9.6 + 6.4 us stand-alone, 11 us per step in the graph); ODIN_NODENSEIGEMM: A/B switch
-static bool dense_via_igemm() { return getenv("ODIN_NODENSEIGEMM") == nullptr; }
+static bool dense_via_igemm() { return ODIN_DIAG_ENV("ODIN_NODENSEIGEMM") == nullptr; }
 
 // ---- Dense: y[B,N] = act(x[B,K] @ w[K,N] + b) ----------------------------------------
 extern "C" int odin_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B,

@@ -401,13 +401,13 @@ __global__ __launch_bounds__((NWA > NWB ? NWA : NWB) * 64) void igemm_pair_kerne
 }
 
 // (read on every call: the A/B tests of the other paths switch it at run time; graph replays never get here)
-bool igemm_enabled() { return getenv("ODIN_NOIGEMM") == nullptr; }
+bool igemm_enabled() { return ODIN_DIAG_ENV("ODIN_NOIGEMM") == nullptr; }
 // Largest layer routed here, in FLOP (ODIN_IG_MAXGF overrides, GFLOP).  Measured against the tiled paths
 // (CelebA B=512, speech B=256; profiles/r03_igemm_cap.txt): strided gathers, stride-1 layers and Dense layers win up
 // to ~5 GFLOP (Dense 4096 -> 512: 114 / 66 / 96 -> 32 / 38 / 52 us; Conv2D 64 -> 64 k4 s1 on 8x8: 94 / 99 -> 52 / 66 us),
 // the transposed stride-2 gathers and the convolution weight gradients only while the layer is launch-bound.
 double igemm_max_flop(bool wide) {
-  const char* e = getenv("ODIN_IG_MAXGF");
+  const char* e = ODIN_DIAG_ENV("ODIN_IG_MAXGF");
   return e ? atof(e) * 1e9 : (wide ? 5.0e9 : 1.2e9);
 }
 
@@ -511,8 +511,8 @@ int odin_igemm_launch(int tmode, const float* in, const float* w, const float* b
   int nw = 1;
   // (4 waves at most: the 8-wave variant measured slower on every layer -- the serial 7-tile sum of wave 0)
   while (nw < 4 && tiles * nw < 4 * 256 && ngroups / (nw * 2) >= IG_U) nw *= 2;
-  if (const char* e = getenv("ODIN_IG_NW")) nw = atoi(e);
-  if (const char* e = getenv("ODIN_IG_DBG")) {
+  if (const char* e = ODIN_DIAG_ENV("ODIN_IG_NW")) nw = atoi(e);
+  if (const char* e = ODIN_DIAG_ENV("ODIN_IG_DBG")) {
     const int f = atoi(e);
     p.dbg_a = (f & 1) ? 0xFFFFFFFFu : 0u;
     p.dbg_b = (f & 2) ? 0xFFFFFFFFu : 0u;
@@ -543,7 +543,7 @@ int odin_igemm_wgrad_rows(int B, int h, int w, int KH, int KW, int CU, int CV) {
   int R = (M + IW_CHUNK - 1) / IW_CHUNK;
   // enough workgroups to fill the chip, at least 64 pixels each
   while (tiles * R < 512 && M / (R * 2) >= 64 && R * 2 <= ODIN_MAX_SLAB_BLOCKS) R *= 2;
-  if (const char* e = getenv("ODIN_IG_R")) {
+  if (const char* e = ODIN_DIAG_ENV("ODIN_IG_R")) {
     const int r = atoi(e);
     if (r >= 1 && r <= ODIN_MAX_SLAB_BLOCKS && (M + r - 1) / r <= IW_CHUNK) R = r;
   }
@@ -569,7 +569,7 @@ int odin_igemm_wgrad_launch(const float* u, const float* v, float* slab, int sla
   // measured (enc3 / dec1 weight gradients): 4 waves beat 1, 2 and 8 even with one batch per wave
   (void)wgs;
   int nw = ngroups >= 16 ? 4 : ngroups >= 8 ? 2 : 1;
-  if (const char* e = getenv("ODIN_IG_NW")) nw = atoi(e);
+  if (const char* e = ODIN_DIAG_ENV("ODIN_IG_NW")) nw = atoi(e);
   if (g_pw.defer && !g_pw.pending) {  // wait for the data gradient of the same layer (odin_igemm_pair_end flushes)
     g_pw.pending = true;
     g_pw.p = p; g_pw.grid = grid; g_pw.nw = nw; g_pw.stream = stream;

@@ -428,7 +428,7 @@ int lb_launch_bwd(const LBBwd& q, int rows, size_t lds, void* stream) {
 // Number of workgroups (= slab rows of the backward launch); 0 when the shapes are outside the fused regime
 // (both weight matrices + S rows must fit in LDS).
 extern "C" int odin_latent_block_rows(int B, int P, int D, int N0) {
-  if (getenv("ODIN_NOLATBLOCK")) return 0;
+  if (ODIN_DIAG_ENV("ODIN_NOLATBLOCK")) return 0;
   if (B < 1 || P < 1 || D < 1 || N0 < 1 || 2 * D > 128 || P > 2048 || N0 > 2048) return 0;
   const int S = lb_samples(B, P, D, N0);
   if (lb_lds_floats(P, D, N0, S) * 4 > 120 * 1024) return 0;

@@ -243,7 +243,7 @@ extern "C" int odin_stft_mel_db_frames(const float* y, const double* window, con
   int fpb = 1024 / H;
   if (fpb > 16) fpb = 16;
   if (fpb < 1) fpb = 1;
-  if (const char* e = getenv("ODIN_MEL_FPB")) { const int v = atoi(e); if (v >= 1 && v <= fpb) fpb = v; }
+  if (const char* e = ODIN_DIAG_ENV("ODIN_MEL_FPB")) { const int v = atoi(e); if (v >= 1 && v <= fpb) fpb = v; }
   const size_t lds = ((size_t)2 * H + (size_t)2 * fpb * H + (size_t)fpb * nbp) * 8;
 #ifndef ODIN_SIM
   static bool attr_done = false;
@@ -260,7 +260,7 @@ extern "C" int odin_stft_mel_db_frames(const float* y, const double* window, con
   // blocks of fpb frames of an utterance are dealt to up to 8 workgroups, the floor follows in a second launch
   const int nblocks = (n_frames + fpb - 1) / fpb;
   int gy = 1;
-  if (workspace != nullptr && !getenv("ODIN_MEL_NOSPLIT"))
+  if (workspace != nullptr && !ODIN_DIAG_ENV("ODIN_MEL_NOSPLIT"))
     while (gy < 8 && gy * 2 <= nblocks && (long)B * gy < 8L * odin_num_cus()) gy *= 2;
   ODIN_LAUNCH(stft_mel_f64_kernel, dim3(B, gy), dim3(256), lds, stream, y, window, twiddles, fb_vals,
               (const int*)fb_band, out, n_samples, frame_length, step_length, n_fft, log4, radix2,

@@ -7,6 +7,18 @@
 #define ODIN_MAX_SLAB_BLOCKS 256     // weight-gradient slabs: rows per (ci, co) block set
 #define ODIN_MAX_COLSUM_BLOCKS 512   // column-sum / fused-tail slabs (two workgroups per CU)
 
+// Environment switches.  The product library reads TWO: ODIN_EXACT_FP32 (any value: every convolution on the exact
+// fp32 matrix-core kernels -- no f16 / bf16 plane kernels) and ODIN_RCCL_LIB (comm.hip).  Everything else is an A/B
+// switch of the diagnostics build (`make diag`, -DODIN_DIAG) and compiles to "not set" here.
+#include <cstdlib>
+#ifdef ODIN_DIAG
+#define ODIN_DIAG_ENV(name) getenv(name)
+#else
+#define ODIN_DIAG_ENV(name) ((const char*)nullptr)
+#endif
+// (read per call: the tests switch it inside one process; a captured graph never comes here)
+static inline bool odin_exact_fp32() { return getenv("ODIN_EXACT_FP32") != nullptr; }
+
 int odin_fail(int code, const char* msg);
 int odin_check_launch(const char* what);
 int odin_num_cus();

@@ -718,7 +718,7 @@ extern "C" int odin_latent_bwd(const float* p, const float* eps, const float* z,
 static int elbo_stream_unroll(int n_per_sample) {
   // elements per wave = 256 * U must divide the sample; prefer >= 6 loads in flight per lane
   static const int cand[] = {3, 4, 2, 1};
-  if (const char* e = getenv("ODIN_ELBO_U")) {  // diagnostics: A/B the loads in flight per lane
+  if (const char* e = ODIN_DIAG_ENV("ODIN_ELBO_U")) {  // diagnostics: A/B the loads in flight per lane
     const int u = atoi(e);
     return (u >= 1 && u <= 4 && n_per_sample % (256 * u) == 0) ? u : 0;
   }
@@ -731,14 +731,14 @@ extern "C" int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, 
                                            float* dlogits, const float* scale, int B,
                                            int n_per_sample, int* n_part_out, void* stream) {
   // large tensors: the persistent form (one partial per 256-element chunk)
-  if (n_per_sample % 256 == 0 && (size_t)B * n_per_sample >= (1u << 20) && !getenv("ODIN_ELBO_U") &&
+  if (n_per_sample % 256 == 0 && (size_t)B * n_per_sample >= (1u << 20) && !ODIN_DIAG_ENV("ODIN_ELBO_U") &&
       (((uintptr_t)logits | (uintptr_t)x | (uintptr_t)dlogits) & 15) == 0) {
     const int n_part = n_per_sample / 256;
     if (n_part_out) *n_part_out = n_part;
     if (logits == nullptr) return 0;  // dry run: reports the partial count
     const size_t n_chunks = (size_t)B * n_part;
     int blocks = 2048, U = 2;  // (sweep of blocks x U on the 64x64x3, batch-256 shape: profiles/r04_elbo_stream_sweep.txt)
-    if (const char* e = getenv("ODIN_ELBO_GS")) sscanf(e, "%d,%d", &blocks, &U);  // diagnostics sweep
+    if (const char* e = ODIN_DIAG_ENV("ODIN_ELBO_GS")) sscanf(e, "%d,%d", &blocks, &U);  // diagnostics sweep
 #define ODIN_ELBO_GS_LAUNCH(UU)                                                                              \
   ODIN_LAUNCH((elbo_bernoulli_gs_kernel<UU>), dim3(blocks), dim3(256), 0, stream, (const float4*)logits,    \
               (const float4*)x, llk_part, (float4*)dlogits, scale, n_chunks)
@@ -1071,7 +1071,7 @@ static void tiny_dense_geom(int NO, int NR, int B, int* nop, int* sb, int* block
 }
 
 bool odin_tiny_dense_ok(int B, int K, int N) {
-  return (long)K * N <= 4096 && K <= 256 && N <= 256 && B >= 1 && B <= 1024 && !getenv("ODIN_NOTINYDENSE");
+  return (long)K * N <= 4096 && K <= 256 && N <= 256 && B >= 1 && B <= 1024 && !ODIN_DIAG_ENV("ODIN_NOTINYDENSE");
 }
 
 int odin_tiny_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K,

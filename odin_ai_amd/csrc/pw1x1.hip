@@ -220,7 +220,7 @@ bool odin_pw1x1_applicable(const odin_conv_desc* d) {
   const int ci = d->Cin;
   return d->KH == 1 && d->KW == 1 && d->stride == 1 && d->Cout >= 1 && d->Cout <= PW_MAXCO &&
          (ci == 8 || ci == 16 || ci == 32 || ci == 64) && !d->center && d->H == d->OH &&
-         d->W == d->OW && !getenv("ODIN_NOPW1X1");
+         d->W == d->OW && !ODIN_DIAG_ENV("ODIN_NOPW1X1");
 }
 
 #define ODIN_PW_SWITCH(CALL)                                                         \

@@ -552,14 +552,14 @@ int odin_smallc_fwd(const float* x, const float* w, const float* bias, float* y,
   if (blocks > 16384) blocks = 16384;
   size_t lds = (size_t)(d->KH * d->KW * d->Cin + 1) * d->Cout * 4;
   const bool small_x = (size_t)d->B * d->H * d->W * d->Cin * 4 < 0x7FFFFFF0u;
-  if (small_x && (d->OW % 32) == 0 && !getenv("ODIN_SMALLC_VALU")) {
+  if (small_x && (d->OW % 32) == 0 && !ODIN_DIAG_ENV("ODIN_SMALLC_VALU")) {
     const int K = d->KH * d->KW * d->Cin;
     const int nk2 = (K + 1) / 2, rb = (d->Cout + 31) / 32;
     const long n_it = (long)d->B * d->OH * (d->OW / 32);
     // rows staged in LDS (RGB first layers; also the grey ones when the row groups divide evenly)
-    if (!getenv("ODIN_SMALLC_NOLDS") && ((d->W * d->Cin) % 4) == 0 && (K == 16 || K == 48)) {
+    if (!ODIN_DIAG_ENV("ODIN_SMALLC_NOLDS") && ((d->W * d->Cin) % 4) == 0 && (K == 16 || K == 48)) {
       // (rows per workgroup: 16 for RGB, 8 for one channel -- 14.2 vs 14.9 us on 64x64x1, profiles/r03_enc0bench.txt)
-      int NR = getenv("ODIN_SMALLC_NR") ? atoi(getenv("ODIN_SMALLC_NR")) : (d->Cin == 1 ? 8 : 16);
+      int NR = ODIN_DIAG_ENV("ODIN_SMALLC_NR") ? atoi(ODIN_DIAG_ENV("ODIN_SMALLC_NR")) : (d->Cin == 1 ? 8 : 16);
       while (NR > 1 && ((d->OH % NR) != 0 ||
                         (size_t)(d->stride * (NR - 1) + d->KH) * d->W * d->Cin * 4 > 48 * 1024))
         NR >>= 1;
@@ -574,7 +574,7 @@ int odin_smallc_fwd(const float* x, const float* w, const float* bias, float* y,
     }
     // persistent waves (2 x 4-wave workgroups per CU-pair ... 4 blocks per wave at batch 256)
     long bl = (n_it + 3) / 4;
-    const long cap = getenv("ODIN_SMALLC_BL") ? atol(getenv("ODIN_SMALLC_BL")) : 4L * odin_num_cus();
+    const long cap = ODIN_DIAG_ENV("ODIN_SMALLC_BL") ? atol(ODIN_DIAG_ENV("ODIN_SMALLC_BL")) : 4L * odin_num_cus();
     if (bl > cap) bl = cap;
     if (nk2 == 8 && rb == 1) { ODIN_LAUNCH((smallc_fwd_mfma_kernel<8, 1>), dim3((unsigned)bl), dim3(256), 0, stream, p); return odin_check_launch("smallc_fwd_mfma"); }
     if (nk2 == 8 && rb == 2) { ODIN_LAUNCH((smallc_fwd_mfma_kernel<8, 2>), dim3((unsigned)bl), dim3(256), 0, stream, p); return odin_check_launch("smallc_fwd_mfma"); }
@@ -725,7 +725,7 @@ int odin_smallc_wgrad(const float* x, const float* dy, float* slab, int* rows_ou
   int rows = ODIN_MAX_SLAB_BLOCKS;
   if (total < rows * 64L) rows = (int)((total + 63) / 64);
   p.pix_per_block = (int)((total + rows - 1) / rows);
-  const bool use_mfma = !getenv("ODIN_SMALLC_VALU") && (d->OW % 2) == 0;
+  const bool use_mfma = !ODIN_DIAG_ENV("ODIN_SMALLC_VALU") && (d->OW % 2) == 0;
   if (use_mfma)  // whole output rows per block
     p.pix_per_block = (p.pix_per_block + d->OW - 1) / d->OW * d->OW;
   rows = (int)((total + p.pix_per_block - 1) / p.pix_per_block);
@@ -740,7 +740,7 @@ int odin_smallc_wgrad(const float* x, const float* dy, float* slab, int* rows_ou
     const size_t l2 = (size_t)NW * RB * CB * 1024 * 4;
     // rows staged in LDS: the first layers of the image stacks
     if ((d->Cin == 1 || d->Cin == 3) && d->W == 64 && d->OW == 32 && d->H == 2 * d->OH && d->KH == 4 && d->KW == 4 &&
-        d->stride == 2 && d->pad_t == 1 && d->pad_l == 1 && d->Cout <= 32 && !getenv("ODIN_SMALLC_NOLDS") &&
+        d->stride == 2 && d->pad_t == 1 && d->pad_l == 1 && d->Cout <= 32 && !ODIN_DIAG_ENV("ODIN_SMALLC_NOLDS") &&
         (size_t)d->B * d->OH * d->OW * d->Cout * 4 < (1ull << 31)) {
       const size_t stage = (size_t)16 * 6 * (64 * d->Cin + 8) * 4;
       const size_t l3 = stage > (size_t)16 * RB * 4096 ? stage : (size_t)16 * RB * 4096;

@@ -831,7 +831,7 @@ int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
   // diagnostics build only (make FLAGS_tconv_planes+=-DODIN_DIAG): instances with parts of the kernel
   // switched off, selected by ODIN_TP_DBG -- they compute WRONG results and are not in the product library
   if (W == 32 && EPI == 3 && C1 == 1) {
-    static const int dbg = [] { const char* e = getenv("ODIN_TP_DBG"); return e ? atoi(e) : 0; }();
+    static const int dbg = [] { const char* e = ODIN_DIAG_ENV("ODIN_TP_DBG"); return e ? atoi(e) : 0; }();
     static bool dattr = false;
     if (!dattr) {
       const void* dfn[4] = {reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 1, ACC, SC>),
@@ -865,7 +865,7 @@ void odin_tconv_planes_set_stamps(void* buf) { g_tp_stamps = (long long*)buf; }
 bool odin_tconv_planes_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt,
                                   int pl, int center, int epi, int C1) {
   // (read per call: the A/B tests switch paths inside one process; a captured graph never comes here)
-  if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT")) return false;
+  if (odin_exact_fp32() || ODIN_DIAG_ENV("ODIN_NOPLANES") || ODIN_DIAG_ENV("ODIN_SPLIT")) return false;
   if (epi == 3 && (CO != 32 || (C1 != 1 && C1 != 3) || CI != 32 || W == 8)) return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && (CI == 32 || CI == 64) && (CO % 32) == 0 &&
          !center && (W == 8 || W == 16 || W == 32) && (H % (64 / W)) == 0 && (size_t)B * H * W * CI * 4 < (1ull << 31) &&

@@ -23,6 +23,18 @@
 #include "odin_internal.h"
 #include <cstdlib>
 
+// Since round 3 this all-fp32 kernel is the A/B reference of tconv_planes.hip only (ODIN_TRING=1): it is compiled in
+// the diagnostics build (`make diag`) and absent from the product library.
+#ifndef ODIN_DIAG
+void odin_tconv_ring_set_stamps(void*) {}
+bool odin_tconv_ring_applicable(int, int, int, int, int, int, int, int, int, int) { return false; }
+int odin_tconv_ring_launch(const float*, const float*, const float*, const float*, float*, float*, int*, const float*,
+                           const float*, const float*, float*, float*, int*, float*, const float*, int, int, int, int,
+                           int, int, void*) {
+  return odin_fail(-2, "tconv_ring: diagnostics build only");
+}
+#else
+
 __device__ float odin_tr_zero_row[1024];  // 4 KB of zeros: DMA source of the SAME-padding rows
 
 namespace {
@@ -526,7 +538,7 @@ bool odin_tconv_ring_applicable(int H, int W, int CI, int CO, int KH, int KW, in
   // instances of gather_conv.hip (fused tail 105 vs 90 us, encoder1 data gradient 25.7 vs 25.5 us):
   // v_mfma_f32_*_f32 shares the vector ALU's issue with every other VALU instruction (nothing of an
   // epilogue hides behind it -- tools/micro/mfma_fillers.hip), while bf16 MFMAs run beside the VALU.
-  const char* e = getenv("ODIN_TRING");
+  const char* e = ODIN_DIAG_ENV("ODIN_TRING");
   if (e == nullptr || e[0] != '1') return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && CI == 32 && (CO % 32) == 0 &&
          !center && (W == 16 || W == 32) && (H % (64 / W)) == 0;
@@ -582,3 +594,4 @@ int odin_tconv_ring_launch(const float* in, const float* w, const float* bias, c
   else ODIN_LAUNCH((tconv_ring_kernel<3, 3>), grid, dim3(TR_THREADS), lds, stream, p);
   return odin_check_launch("tconv_ring");
 }
+#endif  // ODIN_DIAG

@@ -940,7 +940,7 @@ int launch_winst2(WParams& p, dim3 grid, size_t lds, void* stream) {
     if constexpr (PVEC && DCONT && !FLAT) {
       // row-chunk loop: whole chunks of 4 pixel pairs per output row, no pad slots
       static int norow = -1;
-      if (norow < 0) norow = getenv("ODIN_NOROWCHUNK") ? 1 : 0;
+      if (norow < 0) norow = ODIN_DIAG_ENV("ODIN_NOROWCHUNK") ? 1 : 0;
       if (!norow && (p.OW % 8) == 0 && p.TR * p.OW == p.slots && p.COB == 32 && p.DP == 32) {
         const int sp = p.S * p.P;
         if (sp == 32) return launch_winst3<TNACC, KMAX, RPWMAX, DMAX, FLAT, true, true, true, 32>(p, grid, lds, stream);
@@ -988,7 +988,7 @@ int launch_ws_inst(WParams& p, dim3 grid, size_t lds, void* stream) {
 // shape does not qualify (caller falls back to the single-role kernel).
 int try_launch_ws(const WParams& p0, int* rows_out, void* stream) {
   static int nows = -1;
-  if (nows < 0) nows = getenv("ODIN_NOWS") ? 1 : 0;
+  if (nows < 0) nows = ODIN_DIAG_ENV("ODIN_NOWS") ? 1 : 0;
   if (nows) return 1;
   WParams p = p0;
   int gx, gy, gz;
@@ -1051,7 +1051,7 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
   if (!plan_wgrad(p, &gx, &gy, &gz, &lds)) return odin_fail(-2, "wgrad: no tiling plan");
   // bottleneck layers: 128-pixel tiles give only a few dozen workgroups, each with a long serial
   // reduction.  Smaller pixel tiles split the reduction over more slab rows.
-  if (gx * gy * gz < 128 && !getenv("ODIN_NOWSPLIT")) {
+  if (gx * gy * gz < 128 && !ODIN_DIAG_ENV("ODIN_NOWSPLIT")) {
     for (int tgt = 64; tgt >= 32; tgt >>= 1) {
       WParams q = p;
       int gx2, gy2, gz2;
@@ -1066,7 +1066,7 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
   // short rows, and staging them RPWMAX rows per wave at a time costs one HBM round trip per
   // batch (enc3 / dec1 weight gradients: 10 batches, ~40 us for 0.07-0.5 GFLOP).  Pick the tile
   // whose rows fit ONE batch of the 12-rows-per-wave instance, so that the staging pipelines.
-  if (!p.flat && p.KI <= 2 && (p.NIMG * p.NRI + NW_W - 1) / NW_W > 12 && !getenv("ODIN_NOWSPLIT")) {
+  if (!p.flat && p.KI <= 2 && (p.NIMG * p.NRI + NW_W - 1) / NW_W > 12 && !ODIN_DIAG_ENV("ODIN_NOWSPLIT")) {
     for (int tgt = 64; tgt >= 16; tgt >>= 1) {
       WParams q = p;
       int gx2, gy2, gz2;
@@ -1288,13 +1288,13 @@ extern "C" int odin_dense_wgrad(const float* x, const float* dy, float* slab, in
                                 int B, int K, int N, void* stream) {
   // (also the tiny layers: their forward / data gradient run on the vector ALUs, but the weight gradient
   // through the generic kernel was a 14.5 us launch for 0.001 GFLOP)
-  if (!getenv("ODIN_NODENSEIGEMM") && !odin_tiny_dense_ok(B, K, N) &&
+  if (!ODIN_DIAG_ENV("ODIN_NODENSEIGEMM") && !odin_tiny_dense_ok(B, K, N) &&
       odin_igemm_wgrad_applicable(B, 1, 1, K, 1, 1, N, 1, 1, 1, 0)) {
     if (slab_rows_out) *slab_rows_out = odin_igemm_wgrad_rows(B, 1, 1, 1, 1, K, N);
     if (slab == nullptr) return 0;  // dry run
     return odin_igemm_wgrad_launch(x, dy, slab, K * N + N, B, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, 1, stream);
   }
-  if (odin_dense_gemm_ok(B, K, N) && !getenv("ODIN_NOTINYWGRADGEMM")) {
+  if (odin_dense_gemm_ok(B, K, N) && !ODIN_DIAG_ENV("ODIN_NOTINYWGRADGEMM")) {
     // small GEMM: the waves of a workgroup split the batch, the result is complete: ONE slab row
     if (slab_rows_out) *slab_rows_out = 1;
     if (slab == nullptr) return 0;  // dry run

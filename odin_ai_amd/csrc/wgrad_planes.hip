@@ -443,7 +443,7 @@ int wp_launch(const WPParams& p, dim3 grid, void* stream) {
   // diagnostics build only (make diag): instances with parts of the kernel switched off, selected by
   // ODIN_WP_DBG -- they compute WRONG results and are not in the product library
   if (W == 32 && GU) {
-    static const int dbg = [] { const char* e = getenv("ODIN_WP_DBG"); return e ? atoi(e) : 0; }();
+    static const int dbg = [] { const char* e = ODIN_DIAG_ENV("ODIN_WP_DBG"); return e ? atoi(e) : 0; }();
     static bool dattr = false;
     constexpr int D1 = (W == 32 && GU) ? 1 : 0, D2 = (W == 32 && GU) ? 2 : 0, D4 = (W == 32 && GU) ? 4 : 0,
                   D8 = (W == 32 && GU) ? 8 : 0, D16 = (W == 32 && GU) ? 16 : 0;
@@ -476,7 +476,7 @@ int wp_launch(const WPParams& p, dim3 grid, void* stream) {
 bool odin_wgrad_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
                                   int S, int pt, int pl, int center) {
   // (read per call: the A/B tests switch paths inside one process; a captured graph never comes here)
-  if (getenv("ODIN_NOPLANES") || getenv("ODIN_SPLIT") || getenv("ODIN_NOWPLANES")) return false;
+  if (odin_exact_fp32() || ODIN_DIAG_ENV("ODIN_NOPLANES") || ODIN_DIAG_ENV("ODIN_SPLIT") || ODIN_DIAG_ENV("ODIN_NOWPLANES")) return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && !center && (CI % 32) == 0 && (CO % 32) == 0 &&
          H == 2 * OH && W == 2 * OW && (OW == 8 || OW == 16 || OW == 32) && (OH % (32 / OW)) == 0 &&
          (size_t)B * H * W * CI * 4 < 0x7FFF0000ull && (size_t)B * OH * OW * CO * 4 < 0x7FFF0000ull &&

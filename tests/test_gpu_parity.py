@@ -291,7 +291,7 @@ FULL = [
     # name, spec, B, kwargs, env
     ('dsprites_b256_default', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0), {}),
     ('dsprites_b256_fp32_mfma_only', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0),
-     {'ODIN_SPLIT': '0'}),
+     {'ODIN_EXACT_FP32': '1'}),
     ('dsprites_b256_no_overlap', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0),
      {'ODIN_OVERLAP_WGRAD': '0', 'ODIN_EARLY_REDUCE': '0'}),
     ('shapes3d_b128', lambda: vo.dsprites_spec(3), 128, dict(beta=1.0), {}),

@@ -366,57 +366,38 @@ def test_bernoulli_tail(bk, is_deconv, B, H, W, Ci, Co, K, S, C1):
   close(red[Co * C1 + C1:], g_ref.sum((0, 1, 2)), 1e-4)
 
 
-def test_split_bf16_path_matches_fp32(bk, monkeypatch):
-  L, T = bk.L, bk.T
-  """ODIN_SPLIT=1 routes the transposed 4x4/s2 32-channel instances through the bf16-plane path
-  (fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per 16 k-values): results must
-  agree with the fp32 MFMA path to fp32-class accuracy (<= 2e-6 of the tensor maximum)."""
+def test_exact_fp32_switch_matches_the_plane_kernels(bk, monkeypatch):
+  """ODIN_EXACT_FP32 (the one arithmetic switch of the product library, odin_internal.h) routes every convolution
+  through the exact fp32 matrix-core kernels; the default carries the 4x4/s2 32-channel layers through the f16 matrix
+  pipe as two planes (3 MFMAs per 16 k-values, <= 3 * 2^-22 per product): results must agree to fp32-class accuracy
+  (<= 4e-6 of the tensor maximum) and differ in their rounding (the plane path really ran)."""
   import os
+  L, T = bk.L, bk.T
   rng = np.random.default_rng(11)
-  B, H, W, Ci, Co, K, S = 1, 16, 16, 32, 32, 4, 2
+  B, H, W, Ci, Co, K, S = 4, 16, 16, 32, 32, 4, 2
   OH, OW = H * S, W * S
   _, pt, _ = vo.same_pads(OH, K, S)
   _, pl, _ = vo.same_pads(OW, K, S)
   d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, 'elu')
   tx, tw = T(rng.standard_normal((B, H, W, Ci))), T(rng.standard_normal((K, K, Co, Ci)) * 0.1)
   tb = T(rng.standard_normal(Co) * 0.1)
-  outs = []
-  monkeypatch.setenv('ODIN_NOIGEMM', '1')  # (a layer this small would take the implicit-GEMM path)
-  os.putenv('ODIN_NOIGEMM', '1')
-  for flag in ('0', '1', '8'):  # fp32 MFMA / weights in registers / 8-wave, weight planes in LDS
-    monkeypatch.setenv('ODIN_SPLIT', flag)
-    os.putenv('ODIN_SPLIT', flag)
+  outs, paths = [], []
+  for flag in (None, '1'):
+    if flag is None:
+      monkeypatch.delenv('ODIN_EXACT_FP32', raising=False)
+      os.unsetenv('ODIN_EXACT_FP32')
+    else:
+      monkeypatch.setenv('ODIN_EXACT_FP32', flag)
+      os.putenv('ODIN_EXACT_FP32', flag)
     ty = bk.zeros(B, OH, OW, Co)
     L.odin_deconv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
     outs.append(ty.cpu().numpy().copy())
-  os.putenv('ODIN_SPLIT', '0')
-  os.unsetenv('ODIN_NOIGEMM')
+    paths.append(L.odin_debug_last_path().decode())
+  os.unsetenv('ODIN_EXACT_FP32')
+  assert paths[0].endswith('(f16x2)') and not paths[1].endswith('(f16x2)'), paths
   assert np.abs(outs[0]).max() > 0.5
-  for o in outs[1:]:
-    assert np.abs(outs[0] - o).max() <= 2e-6 * np.abs(outs[0]).max()
-    assert not np.array_equal(outs[0], o)  # the split path really ran (different rounding)
-
-
-@pytest.mark.parametrize('kind,args', [
-    ('tail', (1, 3, 16, 16, 32, 32, 4, 2, 3)),
-    ('deconv', (2, 16, 16, 32, 64, 4, 2, 'elu')),
-    ('conv', (3, 32, 32, 32, 32, 4, 2, 'elu', False)),
-])
-def test_tconv_ring_fp32_opt_in(bk, kind, args):
-  """ODIN_TRING=1: the all-fp32 rolling-window kernel for transposed 4x4/s2 gathers over 32 channels
-  (tconv_ring.hip: LDS-DMA row ring, 8 consumer + 4 producer waves meeting through LDS counters)
-  -- deconv forward, Conv2D data gradient and the fused Bernoulli tail with 1 / 3 logit maps."""
-  import os
-  os.putenv('ODIN_TRING', '1')
-  try:
-    if kind == 'tail':
-      test_bernoulli_tail(bk, *args)
-    elif kind == 'deconv':
-      test_deconv2d_fwd_dgrad_wgrad(bk, *args)
-    else:
-      test_conv2d_fwd_dgrad_wgrad(bk, *args)
-  finally:
-    os.unsetenv('ODIN_TRING')
+  assert np.abs(outs[0] - outs[1]).max() <= 4e-6 * np.abs(outs[0]).max()
+  assert not np.array_equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize('B,H,W,Ci,Co', [(2, 16, 16, 32, 48), (1, 32, 32, 32, 80), (3, 16, 16, 32, 32),
