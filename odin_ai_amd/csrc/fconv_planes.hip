@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
       csum[0] += v[0];
       csum[1] += v[1];
       // (the first tile's pass has no predecessor and sums zeros: nothing to mask)
-      amx = fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1])));
+      amx = odin_amax3(amx, v[0], v[1]);
     }
     odin_run_store2(RO, ooffP, make_float2(v[0], v[1]));  // (range-checked: the first tile's pass has no tile T - 1)
   };

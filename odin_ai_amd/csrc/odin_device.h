@@ -245,6 +245,17 @@ __device__ __forceinline__ unsigned odin_range_load(const unsigned* block) {
   return __builtin_amdgcn_readfirstlane(m);
 #endif
 }
+// running maximum of |values|: max(m, |a|, |b|) as ONE v_max3_f32 with source modifiers (the generic fmaxf / fabsf form
+// compiles to four instructions per pair: IEEE canonicalisation of each |x|)
+__device__ __forceinline__ float odin_amax3(float m, float a, float b) {
+#ifdef ODIN_SIM
+  return fmaxf(m, fmaxf(fabsf(a), fabsf(b)));
+#else
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
+  return r;
+#endif
+}
 // producer side, one wave speaking for its workgroup (fp32 bit patterns of non-negative values order like
 // unsigned integers)
 __device__ __forceinline__ void odin_amax_commit_wave(unsigned* block, float amx, int lane, unsigned wg) {

@@ -401,9 +401,7 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   auto elu_r = [&](int r) { elu_b(r, bias_r[((EPI == 1 || EPI == 3) && !CL) ? r : 0]); };
   auto store_q = [&](int q) __attribute__((always_inline)) {
     if (DBG & 1) return;
-    if (EPI >= 2)
-      amx = fmaxf(fmaxf(amx, fmaxf(fabsf(pa[4 * q]), fabsf(pa[4 * q + 1]))),
-                  fmaxf(fabsf(pa[4 * q + 2]), fabsf(pa[4 * q + 3])));
+    if (EPI >= 2) amx = odin_amax3(odin_amax3(amx, pa[4 * q], pa[4 * q + 1]), pa[4 * q + 2], pa[4 * q + 3]);
     odin_run_store4s(OUT, out_lane + 32 * q, tileP_out,
                      make_float4(pa[4 * q], pa[4 * q + 1], pa[4 * q + 2], pa[4 * q + 3]));
   };
