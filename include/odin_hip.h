@@ -40,8 +40,9 @@ typedef struct odin_conv_desc {
    * BIT PATTERN of an upper bound of max|t| of a gradient tensor t; the caller zeroes the words once per step
    * (odin_range_reset), producers fold their outputs in with one atomicMax per workgroup, consumers scale t by an
    * exact power of two on its way into the planes.  dy_amax: word of dy (this layer's pre-activation gradient) -- read by the data / weight gradient,
-   * written by the fused tail that produces dy.  dx_amax: word of dx -- written by the data gradient.  A consumer
-   * without a word computes the bound itself (odin_absmax: one extra pass over the tensor). */
+   * written by the fused tail that produces dy.  dx_amax: word of dx -- written by the data gradient when its kernel
+   * family keeps one (odin_*_dgrad_keeps_range), untouched otherwise.  A consumer without a word computes the bound
+   * itself (odin_absmax: one extra pass over the tensor), and only if it is a plane kernel. */
   uint32_t* dy_amax;
   uint32_t* dx_amax;
 } odin_conv_desc;
@@ -57,6 +58,12 @@ const char* odin_debug_last_path(void);
 uint32_t odin_crc32c(uint32_t crc, const void* data, size_t n);
 const char* odin_last_error(void);
 int odin_max_slab_rows(void);      /* upper bound of the rows any slab-producing call writes */
+/* Which producers keep a range word: 1 when the data gradient of layer `d` (dispatched for aux_act, aux present) /
+ * the fused tail folds max|dx| / max|g_out| into d->dx_amax / d->dy_amax itself.  A caller hands a word to the
+ * CONSUMERS of a tensor (their d->dy_amax) only when its producer keeps it; otherwise it passes NULL there. */
+int odin_conv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_act);
+int odin_deconv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_act);
+int odin_bernoulli_tail_keeps_range(int is_deconv, const odin_conv_desc* d, int C1);
 /* Range words (odin_conv_desc.dy_amax / dx_amax; ODIN_RANGE_WORDS uint32 each): zero `n` words at the top of a
  * step; fold max|t[0..n)| of an fp32 tensor into a word (producers that do not track their outputs themselves, or
  * external callers). */

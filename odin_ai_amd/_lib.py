@@ -43,6 +43,9 @@ SIGNATURES = {
     'odin_crc32c': [C.c_uint32, P, C.c_size_t],
     'odin_max_slab_rows': [],
     'odin_range_reset': [P, I, P],
+    'odin_conv2d_dgrad_keeps_range': [DP, I],
+    'odin_deconv2d_dgrad_keeps_range': [DP, I],
+    'odin_bernoulli_tail_keeps_range': [I, DP, I],
     'odin_conv2d_bwd': [P, P, P, P, I, P, P, IP, P, IP, DP, P],
     'odin_deconv2d_bwd': [P, P, P, P, I, P, P, IP, P, IP, DP, P],
     'odin_dense_bwd': [P, P, P, P, I, P, P, IP, P, IP, I, I, I, P],
@@ -108,7 +111,8 @@ SIGNATURES = {
 
 
 # entry points whose return value is a result, not an error code
-VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
+VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_conv2d_dgrad_keeps_range',
+                   'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
                    'odin_latent_block_rows', 'odin_total_correlation_workspace')
 
 

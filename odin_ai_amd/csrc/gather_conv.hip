@@ -1623,10 +1623,44 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
 
 // dx[b,ih,iw,ci] = sum_{kh,kw,co} dy[b,(ih+pt-kh)/S,(iw+pl-kw)/S,co] * W[kh,kw,ci,co];
 // optionally multiplied by act'(aux) (aux = this layer's input = previous layer's output)
-// a data gradient whose kernel family does not keep the range word of dx itself: one pass over dx
-static int track_dx(int rc, const float* dx, const odin_conv_desc* d, void* stream) {
-  if (rc != 0 || dx == nullptr || d->dx_amax == nullptr) return rc;
-  return odin_absmax(dx, (size_t)d->B * d->H * d->W * d->Cin, d->dx_amax, stream);
+// Kernel families that do not keep the range word of dx leave it untouched: the caller learns which layers do
+// from odin_conv2d_dgrad_keeps_range / odin_deconv2d_dgrad_keeps_range below and hands a word to the consumers of dx
+// only then (a consumer without a word bounds the tensor itself, and only if it is a plane kernel).
+static int track_dx(int rc, const float*, const odin_conv_desc*, void*) { return rc; }
+
+// 1: the data gradient of this layer (as dispatched for `aux_act`, with the aux tensor present) folds max|dx| into
+// d->dx_amax itself
+extern "C" int odin_conv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_act) {
+  if (odin_pw1x1_applicable(d)) return 0;
+  if (aux_act == ODIN_ACT_ELU && d->H == 2 * d->OH && d->W == 2 * d->OW &&
+      odin_tconv_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t,
+                                   d->pad_l, 0, 2, 1))
+    return 1;
+  if (aux_act == ODIN_ACT_ELU && d->H == 2 * d->OH && d->W == 2 * d->OW &&
+      odin_tconv_ring_applicable(d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0))
+    return 0;
+  return odin_igemm_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0) ? 1 : 0;
+}
+extern "C" int odin_deconv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_act) {
+  if (aux_act == ODIN_ACT_ELU &&
+      odin_fconv_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
+                                   d->pad_t, d->pad_l, 0))
+    return 1;
+  const bool ring_two_pass_vs_igemm =
+      d->Cout == 64 && odin_igemm_applicable(0, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW,
+                                             d->stride, 0) &&
+      odin_igemm_tiles(0, d->B, d->H, d->W, d->stride) <= ODIN_MAX_COLSUM_BLOCKS;
+  if (!ring_two_pass_vs_igemm && aux_act == ODIN_ACT_ELU &&
+      odin_fconv_ring_applicable(d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t,
+                                 d->pad_l, 0))
+    return 0;
+  return odin_igemm_applicable(0, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0) ? 1 : 0;
+}
+// 1: the fused tail folds max|g_out| into d->dy_amax itself
+extern "C" int odin_bernoulli_tail_keeps_range(int is_deconv, const odin_conv_desc* d, int C1) {
+  return (is_deconv && d->act == ODIN_ACT_ELU && d->OH == 2 * d->H && d->OW == 2 * d->W &&
+          odin_tconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
+                                       d->pad_l, d->center, 3, C1)) ? 1 : 0;
 }
 
 extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* aux, int aux_act,
@@ -1797,14 +1831,9 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
       d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_tconv_ring_applicable(d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
                                  d->pad_l, d->center))
-  {
-    int rc = odin_tconv_ring_launch(x, w, bias, nullptr, g_out, nullptr, slab_rows_out, w1, b1, target,
-                                    logits, llk_part, n_part_out, tail_slab, scale, C1, d->B, d->H, d->W,
-                                    d->Cout, 3, stream);
-    if (rc == 0 && g_out != nullptr && d->dy_amax != nullptr)
-      rc = odin_absmax(g_out, (size_t)d->B * d->OH * d->OW * d->Cout, d->dy_amax, stream);
-    return rc;
-  }
+    return odin_tconv_ring_launch(x, w, bias, nullptr, g_out, nullptr, slab_rows_out, w1, b1, target,
+                                  logits, llk_part, n_part_out, tail_slab, scale, C1, d->B, d->H, d->W,
+                                  d->Cout, 3, stream);
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = g_out;
@@ -1816,8 +1845,6 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
   int rc = launch_gather(is_deconv ? MODE_T : MODE_F, p, stream, -ODIN_MAX_COLSUM_BLOCKS,
                          slab_rows_out, &tp);
   if (n_part_out) *n_part_out = p.OH / (p.TR > 0 ? p.TR : 1);  // log-likelihood parts per sample
-  if (rc == 0 && g_out != nullptr && d->dy_amax != nullptr)
-    rc = odin_absmax(g_out, (size_t)d->B * d->OH * d->OW * d->Cout, d->dy_amax, stream);
   return rc;
 }
 

@@ -153,15 +153,18 @@ class NetProgram:
         cd = _lib.conv_desc(B, d['H'], d['W'], d['Cin'], d['OH'], d['OW'], d['Cout'],
                             d['K'], d['stride'], d['pad_t'], d['pad_l'], r.act, r.center)
         i = len(self.descs)
-        # gouts[i] has a word when its producer keeps one: the data gradient of a conv / deconv layer i + 1 (or the
-        # fused tail standing in for it); produced by anything else (ELBO kernel, Dense, latent block) the consumer
-        # is told nothing and bounds the tensor itself if it needs to
-        tracked = i + 1 < len(recs) and recs[i + 1].desc is not None
-        cd.dy_amax = (self.range_words.data_ptr() + 4 * RANGE_WORDS * i) if tracked else None
         cd.dx_amax = (self.range_words.data_ptr() + 4 * RANGE_WORDS * (i - 1)) if i > 0 else None
         self.descs.append(cd)
       else:
         self.descs.append(None)
+    # gouts[i] travels with a word only when its producer keeps one -- the data gradient of layer i + 1 on a kernel
+    # family that tracks its output (include/odin_hip.h: odin_*_dgrad_keeps_range); produced by anything else (ELBO
+    # kernel, Dense, latent block, generic kernels) the consumers are told nothing: a plane kernel then bounds the
+    # tensor itself, the others never look
+    for i, cd in enumerate(self.descs):
+      if cd is None:
+        continue
+      cd.dy_amax = self.word(i) if self.dgrad_keeps_range(i + 1) else None
     self.wslabs: List[Optional[torch.Tensor]] = [None] * len(recs)
     self.wrows = [0] * len(recs)
     self.bslabs: List[Optional[torch.Tensor]] = [None] * len(recs)  # deconv bias (colsum)
@@ -178,6 +181,18 @@ class NetProgram:
         mac = B * r.K * r.N
       self.small_wgrad.append(2 * mac < float(__import__('os').environ.get('ODIN_SMALL_WGRAD_GF', '0.8')) * 1e9)
     self._plan_slabs()
+
+  def word(self, i: int) -> int:
+    """device address of the range word of gouts[i]"""
+    return self.range_words.data_ptr() + 4 * RANGE_WORDS * i
+
+  def dgrad_keeps_range(self, j: int) -> bool:
+    """does the data gradient of layer j fold max |gouts[j - 1]| into its range word itself?"""
+    if j <= 0 or j >= len(self.recs) or self.descs[j] is None:
+      return False
+    fn = (self.lib.odin_conv2d_dgrad_keeps_range if self.recs[j].kind == 'conv'
+          else self.lib.odin_deconv2d_dgrad_keeps_range)
+    return bool(fn(C.byref(self.descs[j]), ACT[self.recs[j - 1].act]))
 
   # -- planning (dry runs report how many slab rows each call will write) --------------
   def _plan_slabs(self):
@@ -536,6 +551,8 @@ class VAEEngine:
     if a.desc['OH'] * a.desc['OW'] <= 128:
       return
     self.fused_tail = True
+    self.tail_keeps_range = bool(self.lib.odin_bernoulli_tail_keeps_range(
+        int(a.kind == 'deconv'), C.byref(self.dec.descs[-2]), b.desc['Cout']))
     self.tail_rows, self.tail_npart = rows.value, npart.value
     co, c1 = a.desc['Cout'], b.desc['Cout']
     self.tail_slab = torch.empty(rows.value, co * c1 + c1 + co, **f32)
@@ -714,6 +731,12 @@ class VAEEngine:
                           self.free_bits, self.hp(H_CAP) if self.capacity_on else None, st)
       dec_in, dec_start = self.z, 0
     npart = C.c_int(0)
+    if self.fused_tail:
+      # gouts[-2] comes from the fused tail (which keeps the range word on the plane kernel) or, unfused, from the
+      # 1x1 head's data gradient
+      nd2 = len(self.dec_recs) - 2
+      keeps = self.tail_keeps_range if fused else self.dec.dgrad_keeps_range(nd2 + 1)
+      self.dec.descs[nd2].dy_amax = self.dec.word(nd2) if keeps else None
     if self.fused_tail and fused:
       nd = len(self.dec_recs)
       h = self.dec.forward(dec_in, st, upto=nd - 2, start=dec_start)
