@@ -679,18 +679,35 @@ def main():
   roofline_split = None
   split_ops = [o for o in ops if is_split(o)]
   if split_ops:
+    # A plane kernel executes 3 f16 MFMAs per 16 k-values (fp32 operands as two f16 planes): its matrix-pipe floor
+    # is executed FLOPs / the dense f16 peak, its memory floor algorithmic bytes / 8 TB/s.  Since the two-plane form
+    # the MEMORY floor is the higher one for the big layers (arithmetic intensity ~146 executed FLOP per byte against
+    # a machine balance of 314): the kernel is priced against the roof that binds it, the other leg is kept beside.
     so = max(split_ops, key=lambda o: o['us'])
-    bf16_gflop = 3.0 * so.get('mfma_gflop', so['gflop'])
-    roofline_split = dict(bound='mfma', kernel=f"{so['layer']}:{so['op']}", path=so.get('path'),
-                          achieved=round(bf16_gflop / so['us'] * 1e3, 3), peak=PEAK_MFMA_BF16_TFLOPS,
-                          unit='TFLOP/s (f16 FLOPs executed)',
-                          frac=round(bf16_gflop / so['us'] * 1e3 / PEAK_MFMA_BF16_TFLOPS, 4),
-                          fp32_equivalent_tflops=round(so['tflops'], 3),
-                          fp32_equivalent_frac=round(so['tflops'] / PEAK_MFMA_F32_TFLOPS, 4), traffic=None,
-                          us_per_launch=round(so['us'], 2), gflop_per_launch=round(bf16_gflop, 4),
+    f16_gflop = 3.0 * so.get('mfma_gflop', so['gflop'])
+    mfma_leg = dict(achieved=round(f16_gflop / so['us'] * 1e3, 3), peak=PEAK_MFMA_BF16_TFLOPS,
+                    unit='TFLOP/s (f16 FLOPs executed)', frac=round(f16_gflop / so['us'] * 1e3 / PEAK_MFMA_BF16_TFLOPS, 4),
+                    gflop_per_launch=round(f16_gflop, 4),
+                    fp32_equivalent_tflops=round(so['tflops'], 3),
+                    fp32_equivalent_frac_of_fp32_mfma_peak=round(so['tflops'] / PEAK_MFMA_F32_TFLOPS, 4))
+    roofline_split = dict(bound='mfma', kernel=f"{so['layer']}:{so['op']}", path=so.get('path'), traffic=None,
+                          us_per_launch=round(so['us'], 2), **mfma_leg,
                           note='fp32 operands as 2 f16 planes: 3 v_mfma_f32_32x32x16_f16 per 16 '
                                'k-values, priced against the dense f16 MFMA peak')
     attach_traffic(roofline_split)
+    alg = roofline_split.get('algorithmic_bytes')
+    if alg:
+      t_hbm, t_mfma = alg / (PEAK_HBM_GBS * 1e9), f16_gflop * 1e9 / (PEAK_MFMA_BF16_TFLOPS * 1e12)
+      hbm_leg = dict(achieved=round(alg / (so['us'] * 1e-6) * 1e-9, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                     frac=round(alg / (so['us'] * 1e-6) * 1e-9 / PEAK_HBM_GBS, 4))
+      roofline_split['floors_us'] = dict(hbm=round(t_hbm * 1e6, 2), mfma=round(t_mfma * 1e6, 2))
+      if t_hbm >= t_mfma:
+        roofline_split.update(bound='hbm', mfma_leg=mfma_leg, **hbm_leg)
+        roofline_split['note'] = ('memory-bound by the roofline model: algorithmic bytes / 8 TB/s exceeds executed f16 '
+                                  'FLOPs / dense f16 peak (fp32 operands as 2 f16 planes, 3 MFMAs per 16 k-values); '
+                                  'the matrix-pipe leg is in mfma_leg')
+      else:
+        roofline_split['hbm_leg'] = hbm_leg
   # `roofline` is THE dominant kernel of the step, priced on the pipe it executes on; when that is a
   # bf16-plane kernel the dominant fp32-MFMA kernel is kept beside it as `roofline_fp32`
   roofline_fp32 = None
@@ -798,9 +815,10 @@ def main():
              vs_baseline=None, dtype='f32', data='synthetic',
              config=dict(workload=args.workload, global_batch=B * world, per_gpu_batch=B,
                          beta=beta, parallelism=f'dp{world}', graph=bool(use_graph),
-                         arithmetic='fp32 results; the 4x4/s2 32-channel layers carry their fp32 operands through '
-                                    'the bf16 matrix pipe as 3 exact bf16 planes (6 MFMAs per 16 k-values, fp32 '
-                                    'accumulation, <= 3*2^-24 per product), fp32 MFMA / VALU elsewhere',
+                         arithmetic='fp32 results; the 4x4/s2 32-/64-channel layers carry their fp32 operands through '
+                                    'the f16 matrix pipe as 2 planes (x = h + 2^-11 l; 3 MFMAs per 16 k-values, fp32 '
+                                    'accumulation, <= 3*2^-22 per product, gradient tensors scaled per tensor by an '
+                                    'exact power of two), fp32 MFMA / VALU elsewhere (ODIN_EXACT_FP32=1: everywhere)',
                          final_loss=round(loss, 4)),
              roofline=roofline, roofline_split=roofline_split, roofline_fp32=roofline_fp32, cpu_baseline=cpu,
              conv_stack=stack,

@@ -62,7 +62,7 @@ constexpr int FP_MAXU = 4;
 // before the epilogue.
 // SC: the input tensor is a gradient (scaled by 2^gexp on its way into the planes, the result scaled back)
 template <int EPI, int OW, bool ACC, bool SC>
-__global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
+__device__ __forceinline__ void fp_body(const FPParams& p) {
   constexpr int NPL = 2;                 // f16 planes per operand
   constexpr int TC = 32 / OW;            // output rows per tile
   constexpr int WU = 2 * OW;             // input row length
@@ -400,6 +400,34 @@ __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
   }
 }
 
+template <int EPI, int OW, bool ACC, bool SC>
+__global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
+  fp_body<EPI, OW, ACC, SC>(p);
+}
+
+// 64 reduction channels in ONE launch: both 32-channel passes inside the kernel (tconv_planes.hip: tconv_planes2_kernel);
+// the partial sums a thread leaves in `out` are read back by the same thread (same wave / register-pair ownership)
+template <int EPI, int OW, bool SC>
+__global__ __launch_bounds__(512) void fconv_planes2_kernel(FPParams p) {
+  {
+    FPParams q = p;
+    q.colsum = nullptr;
+    q.out_amax = nullptr;
+    q.ci_off = 0;
+    fp_body<0, OW, false, SC>(q);
+  }
+  // (the same thread reads back what it wrote, through the same CU's write-through L1 and its XCD's L2: a
+  // workgroup-scope fence orders it; a device-scope __threadfence() writes back and invalidates the whole L2 of the
+  // XCD and cost 50 us per launch)
+  odin_wait_vmem();
+#ifndef ODIN_SIM
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
+  __syncthreads();
+  p.ci_off = 32;
+  fp_body<EPI, OW, true, SC>(p);
+}
+
 // LDS: row ring + two partial-tile buffers + the fill tables ((1 + rows per fill) x 8 bytes per fill, tiles + 4 fills)
 constexpr int FP_LDS_MAX = 160 * 1024;
 int fp_ring_bytes(int OW) { return (4 * (32 / OW) + 3) * 2 * 2 * (OW + 2) * 64 + 2 * (8 * 4 * 64 * 16); }
@@ -432,6 +460,27 @@ int fp_launch(const FPParams& p, dim3 grid, void* stream) {
   }
 #endif
   ODIN_LAUNCH((fconv_planes_kernel<EPI, OW, ACC, SC>), grid, dim3(512), lds, stream, p);
+  return odin_check_launch("fconv_planes(f16x2)");
+}
+
+template <int EPI, bool SC>
+int fp_launch2_w(const FPParams& p, int OW, dim3 grid, void* stream) {
+  const size_t lds = (size_t)fp_ring_bytes(OW) + (size_t)(p.tiles_per_wg + 4) * fp_fill_bytes(OW);
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    const void* fns[3] = {reinterpret_cast<const void*>(&fconv_planes2_kernel<EPI, 32, SC>),
+                          reinterpret_cast<const void*>(&fconv_planes2_kernel<EPI, 16, SC>),
+                          reinterpret_cast<const void*>(&fconv_planes2_kernel<EPI, 8, SC>)};
+    for (int i = 0; i < 3; ++i)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, FP_LDS_MAX) != hipSuccess)
+        (void)hipGetLastError();
+    attr_done = true;
+  }
+#endif
+  if (OW == 32) ODIN_LAUNCH((fconv_planes2_kernel<EPI, 32, SC>), grid, dim3(512), lds, stream, p);
+  else if (OW == 16) ODIN_LAUNCH((fconv_planes2_kernel<EPI, 16, SC>), grid, dim3(512), lds, stream, p);
+  else ODIN_LAUNCH((fconv_planes2_kernel<EPI, 8, SC>), grid, dim3(512), lds, stream, p);
   return odin_check_launch("fconv_planes(f16x2)");
 }
 
@@ -485,13 +534,18 @@ int odin_fconv_planes_launch(const float* in, const float* w, const float* bias,
   }
   dim3 grid(gx, gy, 1);
   if (CI == 64) {
-    FPParams q = p;
-    q.colsum = nullptr;
-    q.out_amax = nullptr;
-    const int rc = epi == 1 ? fp_launch_w<0, false, false>(q, OW, grid, stream) : fp_launch_w<0, false, true>(q, OW, grid, stream);
-    if (rc != 0) return rc;
-    p.ci_off = 32;
-    return epi == 1 ? fp_launch_w<1, true, false>(p, OW, grid, stream) : fp_launch_w<2, true, true>(p, OW, grid, stream);
+#ifdef ODIN_DIAG  // diagnostics build: A/B against the two-launch form of round 3
+    if (ODIN_DIAG_ENV("ODIN_FP_2LAUNCH")) {
+      FPParams q = p;
+      q.colsum = nullptr;
+      q.out_amax = nullptr;
+      const int rc = epi == 1 ? fp_launch_w<0, false, false>(q, OW, grid, stream) : fp_launch_w<0, false, true>(q, OW, grid, stream);
+      if (rc != 0) return rc;
+      p.ci_off = 32;
+      return epi == 1 ? fp_launch_w<1, true, false>(p, OW, grid, stream) : fp_launch_w<2, true, true>(p, OW, grid, stream);
+    }
+#endif
+    return epi == 1 ? fp_launch2_w<1, false>(p, OW, grid, stream) : fp_launch2_w<2, true>(p, OW, grid, stream);
   }
   return epi == 1 ? fp_launch_w<1, false, false>(p, OW, grid, stream) : fp_launch_w<2, false, true>(p, OW, grid, stream);
 }

@@ -1496,8 +1496,10 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 1 && tp.C1 == 1 &&
         !ODIN_DIAG_ENV("ODIN_NOTAIL2WG"))  // two workgroups per CU
     {
+#ifdef ODIN_DIAG  // (4-wave split form: A/B reference of the diagnostics build)
       if (split_ok(p))
         return launch_inst2<MODE_T, 4, 2, 32, true, 1, 5, 1, 1, 1, true>(p, tp, grid, split_lds(p), stream);
+#endif
       return launch_inst<MODE_T, 4, 2, 32, true, 1, 5, 1, 1>(p, tp, grid, lds, stream);
     }
     if (mode == MODE_T && k4s2 && p.CIC == 32 && p.KI <= 5 && epi == 1 && tp.C1 == 1)
@@ -1545,13 +1547,17 @@ int launch_gather(int mode, GParams& p, void* stream, int max_blocks, int* rows_
     return launch_inst<MODE_F, 0, 0, 0, false, 0, GK, 2>(p, tp, grid, lds, stream);
   }
   if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 1 && !ODIN_DIAG_ENV("ODIN_NO2WG")) {
+#ifdef ODIN_DIAG  // (4-wave split form: A/B reference of the diagnostics build)
     if (split_ok(p))
       return launch_inst2<MODE_T, 4, 2, 32, true, 0, 5, 1, 1, 1, true>(p, tp, grid, split_lds(p), stream);
+#endif
     return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 1, 1>(p, tp, grid, lds, stream);
   }
   if (k4s2 && p.CIC == 32 && p.KI <= 5 && rpw <= 1 && epi == 2 && !ODIN_DIAG_ENV("ODIN_NO2WG")) {
+#ifdef ODIN_DIAG  // (4-wave split form: A/B reference of the diagnostics build)
     if (split_ok(p))
       return launch_inst2<MODE_T, 4, 2, 32, true, 0, 5, 1, 2, 1, true>(p, tp, grid, split_lds(p), stream);
+#endif
     return launch_inst<MODE_T, 4, 2, 32, true, 0, 5, 1, 2>(p, tp, grid, lds, stream);
   }
   if (k4s2 && p.CIC == 32 && p.KI <= 5) {

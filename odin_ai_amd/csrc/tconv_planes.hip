@@ -126,7 +126,7 @@ struct TpItem {
 // sums the previous pass left in `out` before the epilogue.
 // SC: the input tensor is a gradient (scaled by 2^gexp on its way into the planes, the result scaled back)
 template <int EPI, int C1, int W, int DBG = 0, bool ACC = false, bool SC = false>
-__global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
+__device__ __forceinline__ void tp_body(const TPParams& p) {
   constexpr int NPL = TP_NPL;
   constexpr int RP = 64 / W;              // input rows per tile
   constexpr int NSLOT = 2 * RP + 3;       // live rows of a tile (RP + 2) + the next tile's (RP + 1 at an image seam)
@@ -794,6 +794,37 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
   }
 }
 
+template <int EPI, int C1, int W, int DBG = 0, bool ACC = false, bool SC = false>
+__global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
+  tp_body<EPI, C1, W, DBG, ACC, SC>(p);
+}
+
+// 64 reduction channels in ONE launch: both 32-channel passes inside the kernel (round 3 launched them separately: a
+// second launch + prologue drain per 64-channel layer, 4 layers per dSprites step).  A tile's raw partial sums of the
+// first pass are written to `out` and read back in the second pass by the SAME thread (same wave roles, same tile
+// walk); the fence + barrier between the passes also keeps the second prologue's LDS writes behind the first pass's
+// last LDS reads.
+template <int EPI, int W, bool SC>
+__global__ __launch_bounds__(512) void tconv_planes2_kernel(TPParams p) {
+  {
+    TPParams q = p;
+    q.colsum = nullptr;
+    q.out_amax = nullptr;
+    q.ci_off = 0;
+    tp_body<0, 1, W, 0, false, SC>(q);
+  }
+  // (the same thread reads back what it wrote, through the same CU's write-through L1 and its XCD's L2: a
+  // workgroup-scope fence orders it; a device-scope __threadfence() writes back and invalidates the whole L2 of the
+  // XCD and cost 50 us per launch)
+  odin_wait_vmem();
+#ifndef ODIN_SIM
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
+  __syncthreads();
+  p.ci_off = 32;
+  tp_body<EPI, 1, W, 0, true, SC>(p);
+}
+
 // LDS: weight planes + row ring + the fill table (rows per fill x 8 bytes per fill, tiles + 3 fills); 4.3 KB are static
 constexpr int TP_LDS_MAX = 155 * 1024;
 int tp_ring_bytes(int W) { return TP_WBYTES + (2 * (64 / W) + 3) * TP_NPL * (W + 2) * 64; }
@@ -854,6 +885,27 @@ int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
   return odin_check_launch("tconv_planes(f16x2)");
 }
 
+template <int EPI, bool SC>
+int tp_launch2_w(const TPParams& p, int W, dim3 grid, void* stream) {
+  const size_t lds = (size_t)tp_ring_bytes(W) + (size_t)(p.tiles_per_wg + 3) * tp_fill_bytes(W);
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    const void* fns[3] = {reinterpret_cast<const void*>(&tconv_planes2_kernel<EPI, 32, SC>),
+                          reinterpret_cast<const void*>(&tconv_planes2_kernel<EPI, 16, SC>),
+                          reinterpret_cast<const void*>(&tconv_planes2_kernel<EPI, 8, SC>)};
+    for (int i = 0; i < 3; ++i)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+        (void)hipGetLastError();
+    attr_done = true;
+  }
+#endif
+  if (W == 32) ODIN_LAUNCH((tconv_planes2_kernel<EPI, 32, SC>), grid, dim3(512), lds, stream, p);
+  else if (W == 16) ODIN_LAUNCH((tconv_planes2_kernel<EPI, 16, SC>), grid, dim3(512), lds, stream, p);
+  else ODIN_LAUNCH((tconv_planes2_kernel<EPI, 8, SC>), grid, dim3(512), lds, stream, p);
+  return odin_check_launch("tconv_planes(f16x2)");
+}
+
 }  // namespace
 
 static long long* g_tp_stamps = nullptr;
@@ -904,13 +956,18 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
   dim3 grid(gx, gy, 1);
   if (CI == 64) {
     if (epi == 3) return odin_fail(-2, "tconv_planes tail: 32 input channels only");
-    TPParams q = p;
-    q.colsum = nullptr;
-    q.out_amax = nullptr;
-    const int rc = epi == 1 ? tp_launch_w<0, 1, false, false>(q, W, grid, stream) : tp_launch_w<0, 1, false, true>(q, W, grid, stream);
-    if (rc != 0) return rc;
-    p.ci_off = 32;
-    return epi == 1 ? tp_launch_w<1, 1, true, false>(p, W, grid, stream) : tp_launch_w<2, 1, true, true>(p, W, grid, stream);
+#ifdef ODIN_DIAG  // diagnostics build: A/B against the two-launch form of round 3
+    if (ODIN_DIAG_ENV("ODIN_TP_2LAUNCH")) {
+      TPParams q = p;
+      q.colsum = nullptr;
+      q.out_amax = nullptr;
+      const int rc = epi == 1 ? tp_launch_w<0, 1, false, false>(q, W, grid, stream) : tp_launch_w<0, 1, false, true>(q, W, grid, stream);
+      if (rc != 0) return rc;
+      p.ci_off = 32;
+      return epi == 1 ? tp_launch_w<1, 1, true, false>(p, W, grid, stream) : tp_launch_w<2, 1, true, true>(p, W, grid, stream);
+    }
+#endif
+    return epi == 1 ? tp_launch2_w<1, false>(p, W, grid, stream) : tp_launch2_w<2, true>(p, W, grid, stream);
   }
   if (epi == 1) return tp_launch_w<1, 1, false, false>(p, W, grid, stream);
   if (epi == 2) return tp_launch_w<2, 1, false, true>(p, W, grid, stream);

@@ -232,6 +232,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p 
 static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline float __fdividef(float a, float b) { return a / b; }
+static inline void __threadfence() {}
 static inline unsigned __brev(unsigned x) {
   unsigned r = 0;
   for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i);

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """profiles/<tag>_pmc_traffic.json from the separate rocprofv3 --pmc passes (tools/pmc.sh <tag>; usage:
-tools/pmc_traffic.py <tag>, default r03).  Exits non-zero when a kernel it prices no longer exists in the
+tools/pmc_traffic.py <tag>, default r04).  Exits non-zero when a kernel it prices no longer exists in the
 passes -- a kernel was renamed or rerouted and the table must be updated, not silently left stale.
 HBM traffic per launch of the three largest kernels of the dsprites_betavae_b256 step, corrected as
 MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts 128-byte reads at 64 bytes: doubled;
 WRITE_SIZE exact), next to the algorithmic bytes of the launch."""
 import json, re, sys
 B = 256
-TAG = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 
 
 def read(fn):
@@ -23,24 +23,24 @@ fetch, write = read(f'gpurun_out/{TAG}_pmc_FETCH_SIZE.txt'), read(f'gpurun_out/{
 f4 = 4
 kernels = {
     # bench op name: (kernel-name prefix, grid, description, algorithmic bytes)
-    'dec4:deconv:wgrad': ('wgrad_planes_kernel<32', '131072',
-                          'weight gradient of the last Conv2DTranspose (wgrad_planes, both operands as 3 bf16 planes), dSprites B=256',
+    'dec4:deconv:wgrad': ('wgrad_planes_kernel<32, true', '131072',
+                          'weight gradient of the last Conv2DTranspose (wgrad_planes, both operands as 2 f16 planes), dSprites B=256',
                           # x [B,32,32,32] + dY [B,64,64,32] read once, slabs [256 rows][16*32*32] written
                           (B * 32 * 32 * 32 + B * 64 * 64 * 32) * f4 + 256 * 16 * 32 * 32 * f4),
-    'dec4:deconv:dgrad': ('fconv_planes_kernel<2, 32', '131072',
-                          'data gradient of the last Conv2DTranspose (fconv_planes, fp32 operands as 3 bf16 planes)',
+    'dec4:deconv:dgrad': ('fconv_planes_kernel<2, 32, false, true', '131072',
+                          'data gradient of the last Conv2DTranspose (fconv_planes, fp32 operands as 2 f16 planes)',
                           # dY [B,64,64,32] + aux [B,32,32,32] read, dx [B,32,32,32] written
                           (B * 64 * 64 * 32 + 2 * B * 32 * 32 * 32) * f4),
-    'dec4+5:tail:fwd+elbo': ('tconv_planes_kernel<3, 1, 32, 0', '131072',
-                             'fused decoder tail (tconv_planes, fp32 operands as 3 bf16 planes)',
+    'dec4+5:tail:fwd+elbo': ('tconv_planes_kernel<3, 1, 32, 0, false, false', '131072',
+                             'fused decoder tail (tconv_planes, fp32 operands as 2 f16 planes)',
                              # x [B,32,32,32] + target [B,64,64,1] read; logits + d(pre-activation) [B,64,64,32] written
                              (B * 32 * 32 * 32 + 2 * B * 64 * 64 + B * 64 * 64 * 32) * f4),
     'enc3:conv:fwd': ('igemm_kernel<4, false, false', '65536',
                       'encoder3 forward (igemm: implicit GEMM, both operands straight from L2, fp32 MFMA)',
                       # x [B,8,8,64] read + y [B,4,4,64] written + weights 16*64*64
                       (B * 8 * 8 * 64 + B * 4 * 4 * 64 + 16 * 64 * 64) * f4),
-    'dec2:deconv:dgrad': ('fconv_planes_kernel<2, 8, true', '131072',
-                          'data gradient of decoder2, second of the two 32-channel passes (fconv_planes, fp32 operands as 3 bf16 planes)',
+    'dec2:deconv:dgrad': ('fconv_planes_kernel<2, 8, true, true', '65536',
+                          'data gradient of decoder2, second of the two 32-channel passes (fconv_planes, fp32 operands as 2 f16 planes)',
                           # dY [B,16,16,64]: 32 of 64 channels read + partial sums read + aux read + dx written, [B,8,8,64] each
                           (B * 16 * 16 * 32 + 3 * B * 8 * 8 * 64) * f4),
 }

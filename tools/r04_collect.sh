@@ -1,0 +1,25 @@
+#!/bin/bash
+# copies the outputs of tools/r04_final.sh (gpurun_out/, scratch) to their committed names under profiles/
+cd "$(dirname "$0")/.."
+g=gpurun_out; p=profiles
+cp $g/r04_final_bench.json $p/r04_bench_default.json
+cp $g/r04_final_bench2.json $p/r04_bench_default_fresh_traffic.json
+cp $g/r04_final_per_op.txt $p/r04_bench_per_op.txt
+cp $g/r04_final_gpu_tests.txt $p/r04_gpu_tests.txt
+cp $g/r04_final_prof_kernel_stats.csv $p/r04_kernel_stats.csv
+cp $g/r04_final_prof_summary.txt $p/r04_kernel_stats_summary.txt
+cp $g/r04_final_prof_timeline.txt $p/r04_step_timeline.txt
+for c in FETCH_SIZE WRITE_SIZE SQ_WAVES; do cp $g/r04_pmc_$c.txt $p/r04_pmc_$c.txt; done
+cat $g/r04f_kpmc_1.txt $g/r04f_kpmc_2.txt $g/r04f_kpmc_3.txt $g/r04f_kpmc_4.txt > $p/r04_kpmc_planes_final.txt
+cp $g/r04_final_stamps_fconv_planes.txt $p/r04_stamps_fconv_planes.txt
+cp $g/r04_final_kbench.txt $p/r04_kbench.txt
+cp $g/r04_final_stamps_tail.txt $p/r04_stamps_tail.txt
+cp $g/r04_final_elbo_stream_sweep.txt $p/r04_elbo_stream_sweep.txt
+cp $g/r04_final_range_fallbacks.txt $p/r04_range_fallbacks.txt
+cp $g/r04_final_slabstat.txt $p/r04_slabstat.txt
+for w in shapes3d_vae_b256 celeba_betatcvae_b512 mnist_dense_b128 factorvae_shapes3d_b256 speech_vae_b256; do
+  cp $g/r04_final_$w.json $p/r04_bench_$w.json
+  grep "^#" $g/r04_final_$w.err > $p/r04_bench_${w}_per_op.txt
+done
+cp $g/r04_final_forcedist.json $p/r04_bench_force_dist_rccl.json
+cp $g/r04_pmc_traffic.json $p/r04_pmc_traffic.json
