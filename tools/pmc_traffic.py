@@ -39,10 +39,10 @@ kernels = {
                       'encoder3 forward (igemm: implicit GEMM, both operands straight from L2, fp32 MFMA)',
                       # x [B,8,8,64] read + y [B,4,4,64] written + weights 16*64*64
                       (B * 8 * 8 * 64 + B * 4 * 4 * 64 + 16 * 64 * 64) * f4),
-    'dec2:deconv:dgrad': ('fconv_planes_kernel<2, 8, true, true', '65536',
-                          'data gradient of decoder2, second of the two 32-channel passes (fconv_planes, fp32 operands as 2 f16 planes)',
-                          # dY [B,16,16,64]: 32 of 64 channels read + partial sums read + aux read + dx written, [B,8,8,64] each
-                          (B * 16 * 16 * 32 + 3 * B * 8 * 8 * 64) * f4),
+    'dec2:deconv:dgrad': ('fconv_planes2_kernel<2, 8, true', '131072',
+                          'data gradient of decoder2: both 32-channel reduction passes in one launch (fconv_planes, fp32 operands as 2 f16 planes)',
+                          # dY [B,16,16,64] read; partial sums written and read back, aux read, dx written: [B,8,8,64] each
+                          (B * 16 * 16 * 64 + 4 * B * 8 * 8 * 64) * f4),
 }
 
 
