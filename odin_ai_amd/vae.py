@@ -1403,7 +1403,7 @@ class FactorVAE(AnnealingVAE):
 def get_vae(name: str):
   """odin/bay/vi/autoencoder/__init__.py:28"""
   table = {c.__name__.lower(): c for c in (VariationalAutoencoder, BetaVAE, AnnealingVAE,
-                                           BetaTCVAE, FactorVAE)}
+                                           BetaTCVAE, FactorVAE, BetaCapacityVAE)}
   table['vae'] = VariationalAutoencoder
   key = str(name).lower().replace('_', '')
   if key not in table:
