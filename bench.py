@@ -84,6 +84,17 @@ def synthetic_batch(name, B, in_shape, device, seed):
   return x.clamp_(1e-6, 1 - 1e-6).to(device)
 
 
+def describe_nonfinite(eng):
+  """stderr: which gradient tensors of the LAST step hold non-finite values (diagnostics of a failed run)"""
+  for name, prog in (('enc', eng.enc), ('dec', eng.dec)):
+    for i, g in enumerate(prog.gouts):
+      print(f'  {name}[{i}] {prog.recs[i].kind}: |dL/dy| max {float(g.abs().max()):.4g} finite '
+            f'{bool(torch.isfinite(g).all())}, |y| max {float(prog.outs[i].abs().max()):.4g}', file=sys.stderr)
+  for k, v in eng.grad_views().items():
+    if not torch.isfinite(v).all():
+      print(f'  non-finite gradient {k}: {int((~torch.isfinite(v)).sum())} of {v.numel()}', file=sys.stderr)
+
+
 def conv_flops(rec, B):
   d = rec.desc
   if rec.kind == 'conv':
@@ -593,10 +604,17 @@ def main():
     torch.cuda.synchronize()
   else:
     t_pw = time.perf_counter()
+    blocks = 0
     while time.perf_counter() - t_pw < 0.6:
       for _ in range(20):
         step()
       torch.cuda.synchronize()
+      blocks += 1
+      if os.environ.get('ODIN_BENCH_TRACE_FLAG') and eng.flag.item() != 0:
+        print(f'bench.py: non-finite gradients first seen in conditioning block {blocks} (20 steps each)',
+              file=sys.stderr)
+        describe_nonfinite(eng)
+        break
   for _ in range(args.warmup):
     step()
   torch.cuda.synchronize()
@@ -632,6 +650,8 @@ def main():
       rccl['step_segments'] = ''.join('G' if k == 'k' else 'c' for k, _ in sgs[-1].segs)  # G = HIP graph, c = collective
   loss = out[0].item()
   assert math.isfinite(loss), 'training diverged'
+  if eng.flag.item() != 0:
+    describe_nonfinite(eng)
   assert eng.flag.item() == 0, 'non-finite gradients were skipped during the timed region'
 
   if rank != 0:

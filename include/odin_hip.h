@@ -116,9 +116,13 @@ int odin_conv2d_bwd(const float* x, const float* dy, const float* w, const float
 int odin_deconv2d_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
                       float* colsum_slab, int* colsum_rows_out, float* wslab, int* wslab_rows_out,
                       const odin_conv_desc* d, void* stream);
+/* Dense: either half may be left out (want_wgrad / want_dgrad); dy_amax / dx_amax are the optional range words of dy
+ * (read) and dx (written when odin_dense_dgrad_keeps_range(B, K, N) = 1) -- layers with both widths >= 256 run on the
+ * f16 matrix pipe as two planes (dense_h.hip) like the 4x4/s2 convolutions. */
 int odin_dense_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
                    float* colsum_slab, int* colsum_rows_out, float* wslab, int* wslab_rows_out, int B, int K,
-                   int N, void* stream);
+                   int N, int want_wgrad, int want_dgrad, const uint32_t* dy_amax, uint32_t* dx_amax, void* stream);
+int odin_dense_dgrad_keeps_range(int B, int K, int N);
 
 /* ---- fused decoder tail of the TRAINING step: layer (Conv2DTranspose if is_deconv else
  * Conv2D, activation d->act, Cout<=32) -> Conv2D 1x1 linear with C1<=4 maps (w1 [Cout,C1],
@@ -186,7 +190,8 @@ int odin_latent_bwd(const float* p, const float* eps, const float* z, const floa
  * kl [B], fbmask [B] exactly like odin_latent_fwd and y0 = act0(z w0 + b0) [B,N0].
  * backward: g0 [B,N0] = dL/d(pre-activation of that Dense); klw / dz_extra / dloc_x / dscale_x as in
  * odin_latent_bwd; writes dz [B,D], dp [B,2D], dh = (dp wl^T) * act'(h) [B,P] and one partial row per
- * workgroup of slab0 [rows][D*N0 + N0] = (dW0 | db0) and slabl [rows][P*2D + 2D] = (dWl | dbl). */
+ * workgroup of slab0 [rows][D*N0 + N0] = (dW0 | db0) and slabl [rows][P*2D + 2D] = (dWl | dbl);
+ * dh_amax (optional): the range word of dh (ODIN_RANGE_WORDS, below), max |dh| folded in. */
 int odin_latent_block_rows(int B, int P, int D, int N0);
 int odin_latent_block_fwd(const float* h, const float* wl, const float* bl, const float* eps_in,
                           float* eps_out, uint64_t seed, const int32_t* step_dev, float* p, float* z,
@@ -197,7 +202,7 @@ int odin_latent_block_bwd(const float* g0, const float* w0, const float* z, cons
                           const float* eps, const float* fbmask, const float* klw, const float* dz_extra,
                           const float* dloc_x, const float* dscale_x, const float* wl, const float* h,
                           int h_act, float* dz, float* dp, float* dh, float* slab0, float* slabl, int B,
-                          int P, int D, int N0, int analytic, void* stream);
+                          int P, int D, int N0, int analytic, uint32_t* dh_amax, void* stream);
 
 /* ---- observation log-likelihood fused forward+backward
  * Independent(Bernoulli(logits),3).log_prob(x) (image_networks.py:87-93;

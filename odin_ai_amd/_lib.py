@@ -48,7 +48,8 @@ SIGNATURES = {
     'odin_bernoulli_tail_keeps_range': [I, DP, I],
     'odin_conv2d_bwd': [P, P, P, P, I, P, P, IP, P, IP, DP, P],
     'odin_deconv2d_bwd': [P, P, P, P, I, P, P, IP, P, IP, DP, P],
-    'odin_dense_bwd': [P, P, P, P, I, P, P, IP, P, IP, I, I, I, P],
+    'odin_dense_bwd': [P, P, P, P, I, P, P, IP, P, IP, I, I, I, I, I, P, P, P],
+    'odin_dense_dgrad_keeps_range': [I, I, I],
     'odin_absmax': [P, C.c_size_t, P, P],
     'odin_debug_absmax_fallbacks': [],
     'odin_debug_stream_probe': [P, P, P, C.c_size_t, I, I, P],
@@ -74,7 +75,7 @@ SIGNATURES = {
     'odin_latent_bwd': [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     'odin_latent_block_rows': [I, I, I, I],
     'odin_latent_block_fwd': [P, P, P, P, P, C.c_uint64, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, P],
-    'odin_latent_block_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, I, I, P],
+    'odin_latent_block_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, I, I, P, P],
     'odin_elbo_bernoulli_fwd_bwd': [P, P, P, P, P, I, I, IP, P],
     'odin_elbo_gaussian_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
     'odin_elbo_mixqlogistic_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
@@ -112,7 +113,7 @@ SIGNATURES = {
 
 # entry points whose return value is a result, not an error code
 VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_conv2d_dgrad_keeps_range',
-                   'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
+                   'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_dense_dgrad_keeps_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
                    'odin_latent_block_rows', 'odin_total_correlation_workspace')
 
 

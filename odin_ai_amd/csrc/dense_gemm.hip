@@ -37,6 +37,7 @@ struct DGParams {
   int lda, ldb, ldc;
   int a_kc, b_kc;      // 1: operand's k index is the contiguous one
   int act, aux_act;
+  unsigned* out_amax;  // dgrad: range word of C (max |C| folded in by every tile), may be null
 };
 
 constexpr int DG_U = 8;  // k-groups (of 8 k-values) in flight per wave
@@ -121,17 +122,19 @@ __global__ __launch_bounds__(NW * 64) void dense_gemm_kernel(DGParams p) {
   }
   if (wave != 0) return;
   // ---- epilogue: lane holds column j = jb, rows i0 + (r & 3) + 8 (r >> 2) + 4 h ----
-  if (!b_ok) return;
-  const float bj = p.bias != nullptr ? p.bias[jb] : 0.f;
+  const float bj = (b_ok && p.bias != nullptr) ? p.bias[jb] : 0.f;
+  float amx = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (i < p.M) {
+    if (b_ok && i < p.M) {
       float v = odin_act(p.act, acc[r] + bj);
       if (p.aux != nullptr) v *= odin_act_grad(p.aux_act, p.aux[(size_t)i * p.ldc + jb]);
       p.C[(size_t)i * p.ldc + jb] = v;
+      amx = fmaxf(amx, fabsf(v));
     }
   }
+  odin_amax_commit_wave(p.out_amax, amx, lane, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 template <bool A_KC, bool B_KC, bool VEC>
@@ -187,13 +190,14 @@ int odin_dense_gemm_fwd(const float* x, const float* w, const float* bias, float
 }
 
 int odin_dense_gemm_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
-                          int B, int K, int N, void* stream) {
+                          int B, int K, int N, uint32_t* dx_amax, void* stream) {
   DGParams p;
   memset(&p, 0, sizeof(p));
   p.A = dy; p.B = w; p.C = dx;
   p.aux = (aux != nullptr && aux_act != 0) ? aux : nullptr; p.aux_act = aux_act;
   p.M = B; p.N = K; p.K = N; p.lda = N; p.ldb = N; p.ldc = K;
   p.a_kc = 1; p.b_kc = 1;
+  p.out_amax = dx_amax;
   return dg_launch(p, stream);
 }
 

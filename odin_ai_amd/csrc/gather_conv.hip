@@ -1780,6 +1780,7 @@ static bool dense_via_igemm() { return ODIN_DIAG_ENV("ODIN_NODENSEIGEMM") == nul
 extern "C" int odin_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B,
                               int K, int N, int act, void* stream) {
   if (odin_tiny_dense_ok(B, K, N)) return odin_tiny_dense_fwd(x, w, bias, y, B, K, N, act, stream);
+  if (odin_dense_h_ok(B, K, N)) return odin_dense_h_fwd(x, w, bias, y, B, K, N, act, stream);
   if (dense_via_igemm() && odin_igemm_applicable(0, B, 1, 1, K, 1, 1, N, 1, 1, 1, 0))
     return odin_igemm_launch(0, x, w, bias, nullptr, 0, y, nullptr, B, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, act, nullptr,
                              stream);
@@ -1796,19 +1797,39 @@ extern "C" int odin_dense_fwd(const float* x, const float* w, const float* bias,
 extern "C" int odin_dense_dgrad(const float* dy, const float* w, const float* aux, int aux_act,
                                 float* dx, float* colsum_slab, int* slab_rows_out, int B, int K,
                                 int N, void* stream) {
+  // (no range words through this entry: a plane GEMM bounds dy itself)
+  return odin_dense_dgrad_ranged(dy, w, aux, aux_act, dx, colsum_slab, slab_rows_out, B, K, N, nullptr, nullptr,
+                                 stream);
+}
+
+// the kernel families below (without a column-sum slab) that fold max|dx| into dx_amax
+bool odin_dense_dgrad_tracks(int B, int K, int N) {
+  if (odin_tiny_dense_ok(B, K, N)) return false;
+  return odin_dense_h_ok(B, K, N) || (dense_via_igemm() && odin_igemm_applicable(1, B, 1, 1, N, 1, 1, K, 1, 1, 1, 0)) ||
+         odin_dense_gemm_ok(B, K, N);
+}
+
+int odin_dense_dgrad_ranged(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                            float* colsum_slab, int* slab_rows_out, int B, int K, int N, const uint32_t* dy_amax,
+                            uint32_t* dx_amax, void* stream) {
   if (odin_tiny_dense_ok(B, K, N))
     return odin_tiny_dense_dgrad(dy, w, aux, aux_act, dx, colsum_slab, slab_rows_out, B, K, N, stream);
+  if (colsum_slab == nullptr && odin_dense_h_ok(B, K, N)) {
+    if (slab_rows_out) *slab_rows_out = 0;
+    if (dx == nullptr) return 0;
+    return odin_dense_h_dgrad(dy, w, aux, aux_act, dx, B, K, N, dy_amax, dx_amax, stream);
+  }
   // (as a transposed 1x1 gather: reduction over the N outputs, weights [k_in][n] with n contiguous)
   if (colsum_slab == nullptr && dense_via_igemm() && odin_igemm_applicable(1, B, 1, 1, N, 1, 1, K, 1, 1, 1, 0)) {
     if (slab_rows_out) *slab_rows_out = 0;
     if (dx == nullptr) return 0;
     return odin_igemm_launch(1, dy, w, nullptr, aux, aux_act, dx, nullptr, B, 1, 1, N, 1, 1, K, 1, 1, 1, 0, 0, 0,
-                             nullptr, stream);
+                             dx_amax, stream);
   }
   if (colsum_slab == nullptr && odin_dense_gemm_ok(B, K, N)) {
     if (slab_rows_out) *slab_rows_out = 0;
     if (dx == nullptr) return 0;
-    return odin_dense_gemm_dgrad(dy, w, aux, aux_act, dx, B, K, N, stream);
+    return odin_dense_gemm_dgrad(dy, w, aux, aux_act, dx, B, K, N, dx_amax, stream);
   }
   GParams p;
   memset(&p, 0, sizeof(p));

@@ -233,6 +233,7 @@ struct LBBwd {
   float* slab0;          // [gridDim.x][D * N0 + N0]
   float* slabl;          // [gridDim.x][P * 2D + 2D]
   int B, P, D, N0, h_act, analytic, S;
+  unsigned* dh_amax;     // range word of dh (max |dh| folded in by every workgroup), may be null
 };
 
 // LDS (floats): wl [P * 2D] | w0 [D * N0] | hs [S * P] | gs [S * N0] | zs [S * D] | pls [S * 2D] | es [S * D] |
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(256) void latent_block_bwd_kernel(LBBwd q) {
     __syncthreads();
   }
   // ---- dh[s][k] = (sum_j dp[s][j] wl[k][j]) act'(h[s][k]) ----
+  float amx = 0.f;
   for (int o = tid; o < ns * P; o += 256) {
     const int s = o / P, k = o - s * P;
     float c0 = 0.f, c1 = 0.f;
@@ -340,8 +342,11 @@ __global__ __launch_bounds__(256) void latent_block_bwd_kernel(LBBwd q) {
       c0 = fmaf(dps[s * J + j], wl[k * J + j], c0);
       c1 = fmaf(dps[s * J + j + 1], wl[k * J + j + 1], c1);
     }
-    q.dh[(size_t)(b0 + s) * P + k] = (c0 + c1) * odin_act_grad(q.h_act, hs[o]);
+    const float v = (c0 + c1) * odin_act_grad(q.h_act, hs[o]);
+    q.dh[(size_t)(b0 + s) * P + k] = v;
+    amx = fmaxf(amx, fabsf(v));
   }
+  odin_amax_commit_wg(q.dh_amax, amx, tid, 256, red, blockIdx.x);  // (red: free since the dz reduction)
   // ---- this workgroup's partial weight gradients: sums over its S samples, s ascending ----
   {
     float* row = q.slab0 + (size_t)blockIdx.x * (D * N0 + N0);
@@ -466,7 +471,7 @@ extern "C" int odin_latent_block_bwd(const float* g0, const float* w0, const flo
                                      const float* dz_extra, const float* dloc_x, const float* dscale_x,
                                      const float* wl, const float* h, int h_act, float* dz, float* dp,
                                      float* dh, float* slab0, float* slabl, int B, int P, int D, int N0,
-                                     int analytic, void* stream) {
+                                     int analytic, uint32_t* dh_amax, void* stream) {
   const int rows = odin_latent_block_rows(B, P, D, N0);
   if (rows == 0) return odin_fail(-2, "latent_block_bwd: shapes outside the fused regime");
   LBBwd q;
@@ -475,6 +480,7 @@ extern "C" int odin_latent_block_bwd(const float* g0, const float* w0, const flo
   q.dz2 = dz_extra; q.dloc_x = dloc_x; q.dscale_x = dscale_x; q.wl = wl; q.h = h; q.h_act = h_act;
   q.dz = dz; q.dp = dp; q.dh = dh; q.slab0 = slab0; q.slabl = slabl;
   q.B = B; q.P = P; q.D = D; q.N0 = N0; q.analytic = analytic; q.S = lb_samples(B, P, D, N0);
+  q.dh_amax = dh_amax;
   const size_t lds = lb_lds_floats(P, D, N0, q.S) * 4;
   const bool v4 = lb_vec_ok(wl, w0, P, D, N0);
   switch (q.S) {

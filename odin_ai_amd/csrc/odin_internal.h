@@ -54,9 +54,24 @@ bool odin_dense_gemm_ok(int B, int K, int N);
 int odin_dense_gemm_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K,
                         int N, int act, void* stream);
 int odin_dense_gemm_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
-                          int B, int K, int N, void* stream);
+                          int B, int K, int N, uint32_t* dx_amax, void* stream);
+// odin_dense_dgrad with the range words of dy (read by the plane GEMM) and dx (written when odin_dense_dgrad_tracks)
+int odin_dense_dgrad_ranged(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                            float* colsum_slab, int* slab_rows_out, int B, int K, int N, const uint32_t* dy_amax,
+                            uint32_t* dx_amax, void* stream);
+bool odin_dense_dgrad_tracks(int B, int K, int N);
+int odin_zero_u32(uint32_t* p, size_t n, void* stream);  // zero n words with a kernel (runtime.hip: why not a memset)
 int odin_dense_gemm_wgrad(const float* x, const float* dy, float* slab, int B, int K, int N,
                           void* stream);
+
+// Dense layers with both widths >= 256 on the f16 matrix pipe as two planes (dense_h.hip)
+bool odin_dense_h_ok(int B, int K, int N);
+int odin_dense_h_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, int act,
+                     void* stream);
+int odin_dense_h_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx, int B, int K, int N,
+                       const uint32_t* dy_amax, uint32_t* dx_amax, void* stream);
+int odin_dense_h_wgrad(const float* x, const float* dy, float* slab, int B, int K, int N, const uint32_t* dy_amax,
+                       void* stream);
 
 // 4x4 / stride-2 gather convolution over 32 channels with a rolling LDS row window (fconv_ring.hip)
 bool odin_fconv_ring_applicable(int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,

@@ -936,8 +936,7 @@ extern "C" int odin_logmeanexp_rows(const float* in, float* out, int n, int B, v
 
 extern "C" int odin_grad_skip_threshold(float* g, size_t n, float threshold, const int32_t* enable,
                                         int32_t* hit, int32_t* skipped_count, void* stream) {
-  if (hipMemsetAsync(hit, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
-    return odin_fail(-3, "grad_skip_threshold: memset failed");
+  if (int rc = odin_zero_u32((uint32_t*)hit, 1, stream)) return rc;  // (a kernel, not a memset node: runtime.hip)
   int grid = grid_for(n, 256 * 4, 2048);
   ODIN_LAUNCH(grad_any_ge_kernel, dim3(grid), dim3(256), 0, stream, (const float*)g, n, threshold,
               (int*)hit);

@@ -89,6 +89,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ t
   __shared__ float red[16];
   odin_amax_commit_wg(word, m, threadIdx.x, 256, red, blockIdx.x);
 }
+// Zeroing is done by KERNELS, never by hipMemsetAsync: a memset node captured into the step graph was not ordered
+// against its neighbours on replay (ROCm 7.2: the scratch word of a fallback was cleared AFTER absmax_kernel had
+// filled it in about one process out of two -- the consumer then scaled by 2^115 and every product overflowed)
+__global__ void range_zero_kernel(unsigned* word) { word[threadIdx.x * ODIN_RANGE_STRIDE] = 0u; }
+__global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
 constexpr int RANGE_SCRATCH_BLOCKS = 16;
 #ifdef ODIN_SIM
 unsigned g_range_scratch[RANGE_SCRATCH_BLOCKS * ODIN_RANGE_WORDS];
@@ -99,9 +106,15 @@ __device__ unsigned g_range_scratch[RANGE_SCRATCH_BLOCKS * ODIN_RANGE_WORDS];
 
 extern "C" int odin_range_reset(uint32_t* words, int n, void* stream) {
   if (words == nullptr || n <= 0) return 0;
-  if (hipMemsetAsync(words, 0, (size_t)n * ODIN_RANGE_WORDS * 4, (hipStream_t)stream) != hipSuccess)
-    return odin_fail(-3, "odin_range_reset: memset failed");
-  return 0;
+  return odin_zero_u32(words, (size_t)n * ODIN_RANGE_WORDS, stream);
+}
+
+int odin_zero_u32(uint32_t* p, size_t n, void* stream) {
+  if (n == 0) return 0;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  ODIN_LAUNCH(zero_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned*)p, n);
+  return odin_check_launch("zero_u32");
 }
 
 extern "C" int odin_absmax(const float* t, size_t n, uint32_t* word, void* stream) {
@@ -134,7 +147,7 @@ const uint32_t* odin_range_word_of(const float* t, size_t n, const uint32_t* giv
   }
   unsigned* w = base + (size_t)(next++ % RANGE_SCRATCH_BLOCKS) * ODIN_RANGE_WORDS;
   ++g_absmax_fallbacks;
-  if (odin_range_reset(w, 1, stream) != 0) return nullptr;
+  ODIN_LAUNCH(range_zero_kernel, dim3(1), dim3(ODIN_RANGE_SLOTS), 0, stream, w);
   if (odin_absmax(t, n, w, stream) != 0) return nullptr;
   return w;
 }

@@ -1286,6 +1286,11 @@ extern "C" int odin_deconv2d_wgrad(const float* x, const float* dy, float* slab,
 
 extern "C" int odin_dense_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out,
                                 int B, int K, int N, void* stream) {
+  if (odin_dense_h_ok(B, K, N)) {  // both widths >= 256: the two-plane GEMM, ONE complete slab row
+    if (slab_rows_out) *slab_rows_out = 1;
+    if (slab == nullptr) return 0;  // dry run
+    return odin_dense_h_wgrad(x, dy, slab, B, K, N, nullptr, stream);
+  }
   // (also the tiny layers: their forward / data gradient run on the vector ALUs, but the weight gradient
   // through the generic kernel was a 14.5 us launch for 0.001 GFLOP)
   if (!ODIN_DIAG_ENV("ODIN_NODENSEIGEMM") && !odin_tiny_dense_ok(B, K, N) &&
@@ -1330,15 +1335,42 @@ extern "C" int odin_deconv2d_bwd(const float* x, const float* dy, const float* w
   return rc != 0 ? rc : rc2;
 }
 
+// want_wgrad / want_dgrad: either half may be left out (FactorVAE's TC term back-propagates through the discriminator
+// without touching its weights).  dy_amax / dx_amax: the range words of dy (read) and dx (written when
+// odin_dense_dgrad_keeps_range says so), both optional.
 extern "C" int odin_dense_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act,
                               float* dx, float* colsum_slab, int* colsum_rows_out, float* wslab,
-                              int* wslab_rows_out, int B, int K, int N, void* stream) {
+                              int* wslab_rows_out, int B, int K, int N, int want_wgrad, int want_dgrad,
+                              const uint32_t* dy_amax, uint32_t* dx_amax, void* stream) {
+  if (odin_dense_h_ok(B, K, N) && colsum_slab == nullptr) {
+    int rc = 0;
+    // (a dy without a word is bounded ONCE for both halves)
+    if (dy_amax == nullptr && ((want_wgrad && wslab != nullptr) || (want_dgrad && dx != nullptr))) {
+      dy_amax = odin_range_word_of(dy, (size_t)B * N, nullptr, stream);
+      if (dy_amax == nullptr) return odin_fail(-3, "dense_bwd: no range word for dy");
+    }
+    if (want_wgrad) {
+      if (wslab_rows_out) *wslab_rows_out = 1;
+      if (wslab != nullptr) rc = odin_dense_h_wgrad(x, dy, wslab, B, K, N, dy_amax, stream);
+    }
+    if (rc == 0 && want_dgrad) {
+      if (colsum_rows_out) *colsum_rows_out = 0;
+      if (dx != nullptr) rc = odin_dense_h_dgrad(dy, w, aux, aux_act, dx, B, K, N, dy_amax, dx_amax, stream);
+    }
+    return rc;
+  }
   odin_igemm_pair_begin();
-  int rc = odin_dense_wgrad(x, dy, wslab, wslab_rows_out, B, K, N, stream);
-  if (rc == 0) rc = odin_dense_dgrad(dy, w, aux, aux_act, dx, colsum_slab, colsum_rows_out, B, K, N, stream);
+  int rc = 0;
+  if (want_wgrad) rc = odin_dense_wgrad(x, dy, wslab, wslab_rows_out, B, K, N, stream);
+  if (rc == 0 && want_dgrad)
+    rc = odin_dense_dgrad_ranged(dy, w, aux, aux_act, dx, colsum_slab, colsum_rows_out, B, K, N, dy_amax, dx_amax,
+                                 stream);
   const int rc2 = odin_igemm_pair_end();
   return rc != 0 ? rc : rc2;
 }
+
+// 1: the data gradient of this Dense layer (without a column-sum slab) folds max|dx| into dx_amax itself
+extern "C" int odin_dense_dgrad_keeps_range(int B, int K, int N) { return odin_dense_dgrad_tracks(B, K, N) ? 1 : 0; }
 
 extern "C" int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* stream) {
   if (n_jobs <= 0) return 0;

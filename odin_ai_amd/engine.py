@@ -161,10 +161,11 @@ class NetProgram:
     # family that tracks its output (include/odin_hip.h: odin_*_dgrad_keeps_range); produced by anything else (ELBO
     # kernel, Dense, latent block, generic kernels) the consumers are told nothing: a plane kernel then bounds the
     # tensor itself, the others never look
+    self.dy_word = [self.word(i) if self.dgrad_keeps_range(i + 1) else None for i in range(len(recs))]
+    self.dx_word = [self.word(i - 1) if i > 0 else None for i in range(len(recs))]   # (Dense layers: odin_dense_bwd)
     for i, cd in enumerate(self.descs):
-      if cd is None:
-        continue
-      cd.dy_amax = self.word(i) if self.dgrad_keeps_range(i + 1) else None
+      if cd is not None:
+        cd.dy_amax = self.dy_word[i]
     self.wslabs: List[Optional[torch.Tensor]] = [None] * len(recs)
     self.wrows = [0] * len(recs)
     self.bslabs: List[Optional[torch.Tensor]] = [None] * len(recs)  # deconv bias (colsum)
@@ -186,13 +187,28 @@ class NetProgram:
     """device address of the range word of gouts[i]"""
     return self.range_words.data_ptr() + 4 * RANGE_WORDS * i
 
+  def set_top_word(self, kept: bool) -> Optional[int]:
+    """the producer of gouts[-1] (outside this program) says whether it keeps the tensor's range word; -> the word"""
+    n = len(self.recs) - 1
+    self.dy_word[n] = self.word(n) if kept else None
+    if self.descs[n] is not None:
+      self.descs[n].dy_amax = self.dy_word[n]
+    return self.dy_word[n]
+
   def dgrad_keeps_range(self, j: int) -> bool:
     """does the data gradient of layer j fold max |gouts[j - 1]| into its range word itself?"""
-    if j <= 0 or j >= len(self.recs) or self.descs[j] is None:
+    if j <= 0 or j >= len(self.recs):
       return False
+    if self.descs[j] is None:  # Dense (its column-sum slab, if the previous layer wants one, rules the plane GEMM out)
+      return self.bslabs_wanted(j - 1) is False and bool(
+          self.lib.odin_dense_dgrad_keeps_range(self.B, self.recs[j].K, self.recs[j].N))
     fn = (self.lib.odin_conv2d_dgrad_keeps_range if self.recs[j].kind == 'conv'
           else self.lib.odin_deconv2d_dgrad_keeps_range)
     return bool(fn(C.byref(self.descs[j]), ACT[self.recs[j - 1].act]))
+
+  def bslabs_wanted(self, i: int) -> bool:
+    """does layer i take its bias gradient from the column sums of its successor's data gradient?"""
+    return self.recs[i].kind == 'deconv'
 
   # -- planning (dry runs report how many slab rows each call will write) --------------
   def _plan_slabs(self):
@@ -291,7 +307,8 @@ class NetProgram:
                                 bsp, C.byref(rows), slab.data_ptr(), C.byref(wrows), C.byref(d), st)
         else:
           lib.odin_dense_bwd(xin.data_ptr(), g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
-                             bsp, C.byref(rows), slab.data_ptr(), C.byref(wrows), B, r.K, r.N, st)
+                             bsp, C.byref(rows), slab.data_ptr(), C.byref(wrows), B, r.K, r.N, 1, 1,
+                             self.dy_word[i], self.dx_word[i], st)
       elif data_only:
         pass
       elif r.kind == 'conv':
@@ -301,8 +318,8 @@ class NetProgram:
         lib.odin_deconv2d_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(wrows),
                                 C.byref(d), wst)
       else:
-        lib.odin_dense_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(wrows), B,
-                             r.K, r.N, wst)
+        lib.odin_dense_bwd(xin.data_ptr(), g.data_ptr(), None, None, 0, None, None, None, slab.data_ptr(),
+                           C.byref(wrows), B, r.K, r.N, 1, 0, self.dy_word[i], None, wst)
       if not data_only:
         assert wrows.value == self.wrows[i]
         n_red = slab.shape[1]
@@ -323,8 +340,8 @@ class NetProgram:
           lib.odin_deconv2d_dgrad(g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act,
                                   dst.data_ptr(), bsp, C.byref(rows), C.byref(d), st)
         else:
-          lib.odin_dense_dgrad(g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
-                               bsp, C.byref(rows), B, r.K, r.N, st)
+          lib.odin_dense_bwd(None, g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(), bsp,
+                             C.byref(rows), None, None, B, r.K, r.N, 0, 1, self.dy_word[i], self.dx_word[i], st)
       if bslab is not None and not data_only:
         pr = self.recs[i - 1]
         jobs.append(ReduceJob(bslab.data_ptr(), self.grads[pr.b_off:].data_ptr(), pr.b_n,
@@ -931,7 +948,7 @@ class VAEEngine:
                                 self.hp(H_KLW), dzx, tl, ts, lw.data_ptr(), h_e.data_ptr(), aux_act,
                                 self.dz.data_ptr(), self.dp.data_ptr(), self.enc.gouts[-1].data_ptr(),
                                 self.lb_slab0.data_ptr(), self.lb_slabl.data_ptr(), B, self.hdim, D, r0.N,
-                                int(self.analytic), st)
+                                int(self.analytic), self.enc.set_top_word(True), st)
       jobs.append(ReduceJob(self.lb_slab0.data_ptr(), self.grads[r0.w_off:].data_ptr(),
                             self.lb_slab0.shape[1], self.lb_rows, self.lb_slab0.shape[1], 0))
       jobs.append(ReduceJob(self.lb_slabl.data_ptr(), self.grads[self.lat_w_off:].data_ptr(),

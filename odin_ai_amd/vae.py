@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .engine import (ACT, H_ALPHA, N_HYPER, NetProgram, ParamLayout, ReduceJob, VAEEngine,
+from .engine import (ACT, H_ALPHA, N_HYPER, RANGE_WORDS, NetProgram, ParamLayout, ReduceJob, VAEEngine,
                      build_layers)
 from .interpolation import Interpolation, linear
 from .networks import RVconf, SequentialNetwork, get_networks, layer_names
@@ -1043,8 +1043,13 @@ class DiscPrograms:
     self.disc, self.B1 = disc, B1
     self.params, self.grads, self.layout = disc.params, disc.grads, disc.layout
     mr = lib.odin_max_slab_rows()
-    self.prog1 = NetProgram(lib, disc.recs, B1, device, disc.params, disc.grads, mr)
-    self.prog2 = NetProgram(lib, disc.recs, 2 * B1, device, disc.params, disc.grads, mr)
+    # (the range words of both programs' gradient tensors in one buffer: cleared once per iteration, reset_ranges)
+    nw = len(disc.recs) * RANGE_WORDS
+    self.range_words = torch.zeros(2 * nw, dtype=torch.int32, device=device)
+    self.prog1 = NetProgram(lib, disc.recs, B1, device, disc.params, disc.grads, mr,
+                            range_words=self.range_words[:nw])
+    self.prog2 = NetProgram(lib, disc.recs, 2 * B1, device, disc.params, disc.grads, mr,
+                            range_words=self.range_words[nw:])
     self.tc = torch.zeros(1, **f32)
     self.dlogit1 = torch.zeros(B1, 1, **f32)
     self.dlogit1_value = None
@@ -1068,6 +1073,12 @@ class DiscPrograms:
 
   m = property(lambda self: self.disc.m)
   v = property(lambda self: self.disc.v)
+
+  def reset_job(self) -> ReduceJob:
+    """zero the range words (their producers fold in with atomicMax): a reduction over zero slab rows, riding on
+    the iteration's last slab reduction (engine.py: VAEEngine.backward does the same for its own words)"""
+    rw = self.range_words
+    return ReduceJob(rw.data_ptr(), rw.data_ptr(), rw.numel(), 0, rw.numel(), 0)
 
 
 H_DALPHA = 10  # discriminator Adam block {alpha_t, beta1, beta2, eps, grad_scale} in the hyper buffer
@@ -1206,6 +1217,8 @@ class FactorVAE(AnnealingVAE):
         eng.finalize(tc_ptr=disc.tc.data_ptr())
         disc.prog1.backward(eng.z, disc.dlogit1, st, dx_out=disc.dz, data_only=True)
         extra = disc.dz
+        if not training or self._is_pretraining:  # (no discriminator step behind this one to clear the words)
+          lib.odin_range_reset(disc.range_words.data_ptr(), disc.range_words.numel() // RANGE_WORDS, st)
       else:
         eng.finalize()
       if training:
@@ -1242,6 +1255,7 @@ class FactorVAE(AnnealingVAE):
                                   disc.dlogit2.data_ptr(), disc.dlogit2[B1:].data_ptr(), B1, st)
         if training:
           jobs = disc.prog2.backward(disc.zcat, disc.dlogit2, st)
+          jobs.append(disc.reset_job())
           arr = (ReduceJob * len(jobs))(*jobs)
           disc._keep = arr
           lib.odin_slab_reduce(arr, len(jobs), st)

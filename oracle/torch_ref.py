@@ -58,9 +58,22 @@ def t_deconv2d(x, w, b, s):
   return y.permute(0, 2, 3, 1)
 
 
-def t_seq(layers, params, x):
+def t_seq(layers, params, x, relu_ties=None, tie_tol=1e-5):
+  """relu_ties: {layer index: the checked implementation's OUTPUT of that relu Dense layer}.  relu'(0) is a tie that
+  rounding decides: where the two sides disagree on the sign of a pre-activation that is zero to within tie_tol
+  (relative to the layer's largest), the reference takes the other side's branch -- one flipped unit otherwise
+  shows up as an O(1e-3) error of the gradients below it.  A disagreement anywhere else is an error."""
   h = x
   for li, L in enumerate(layers):
+    if relu_ties is not None and li in relu_ties and L[0] == 'dense' and L[2] == 'relu':
+      pre = h @ params[(li, 'w')] + params[(li, 'b')]
+      mine, theirs = pre.detach() > 0, relu_ties[li] > 0
+      diff = mine != theirs
+      if bool(diff.any()):
+        worst = float(pre.detach()[diff].abs().max() / pre.detach().abs().max())
+        assert worst <= tie_tol, ('relu masks disagree away from zero', li, int(diff.sum()), worst)
+      h = pre * theirs.to(pre.dtype)
+      continue
     k = L[0]
     if k == 'center':
       h = 2.0 * h - 1.0

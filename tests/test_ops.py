@@ -175,7 +175,9 @@ def test_deconv2d_fwd_dgrad_wgrad(bk, B, H, W, Ci, Co, K, S, act):
                                        # small matrix-core GEMMs straight from L2 (dense_gemm.hip): ragged
                                        # M / N / K, 1..16 waves per tile
                                        (256, 1024, 128, 'linear'), (37, 1000, 75, 'relu'),
-                                       (128, 70, 1000, 'relu'), (64, 784, 512, 'relu'), (9, 2052, 33, 'linear')])
+                                       (128, 70, 1000, 'relu'), (64, 784, 512, 'relu'), (9, 2052, 33, 'linear'),
+                                       # both widths >= 256, batch a multiple of 8: the two-plane GEMM (dense_h.hip), ragged N
+                                       (40, 264, 296, 'relu'), (32, 512, 256, 'linear')])
 def test_dense(bk, B, K, N, act):
   L, T = bk.L, bk.T
   rng = np.random.default_rng(2)
@@ -206,7 +208,8 @@ def test_dense(bk, B, K, N, act):
 
 @pytest.mark.parametrize('kind,shape', [
     ('conv', (5, 8, 8, 64, 64, 4, 2)), ('conv', (16, 8, 8, 32, 64, 4, 2)), ('deconv', (6, 4, 4, 8, 64, 4, 2)),
-    ('dense', (100, 256, 40)), ('dense', (64, 1024, 128)), ('conv', (3, 16, 16, 32, 32, 4, 2))])
+    ('dense', (100, 256, 40)), ('dense', (64, 1024, 128)), ('conv', (3, 16, 16, 32, 32, 4, 2)),
+    ('dense', (48, 256, 320)), ('dense', (128, 1000, 2)), ('dense', (64, 6, 1000))])
 def test_layer_bwd_in_one_call(bk, kind, shape):
   """odin_conv2d_bwd / odin_deconv2d_bwd / odin_dense_bwd = the weight gradient + the data gradient of a layer in
   one call (small layers: ONE launch shared by the two implicit-GEMM kernels): results identical, bit for bit, to
@@ -224,7 +227,14 @@ def test_layer_bwd_in_one_call(bk, kind, shape):
     L.odin_dense_wgrad(tx.data_ptr(), tdy.data_ptr(), s1.data_ptr(), C.byref(rows), B, K, N, None)
     L.odin_dense_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx1.data_ptr(), None, None, B, K, N, None)
     L.odin_dense_bwd(tx.data_ptr(), tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx2.data_ptr(), None, None,
-                     s2.data_ptr(), C.byref(rows2), B, K, N, None)
+                     s2.data_ptr(), C.byref(rows2), B, K, N, 1, 1, None, None, None)
+    # the range word of dx: kept by the families odin_dense_dgrad_keeps_range names, untouched by the others
+    word, dx3 = bk.zeros(2048, dtype=torch.int32), bk.full((B, K), float('nan'))
+    L.odin_dense_bwd(tx.data_ptr(), tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx3.data_ptr(), None, None,
+                     None, None, B, K, N, 0, 1, None, word.data_ptr(), None)
+    assert torch.equal(dx3, dx2)
+    kept = float(word.view(torch.float32).max())
+    assert kept == (float(dx2.abs().max()) if L.odin_dense_dgrad_keeps_range(B, K, N) else 0.0)
   else:
     B, H, W, Ci, Co, K, S = shape
     if kind == 'conv':
@@ -268,10 +278,12 @@ def hipbk():
     # FactorVAE's discriminator layers at BASELINE config 3's half batches (factor_vae.py:150-153) and the whole
     # batch of the discriminator step, MNIST's dense stack at batch 128 (variational_autoencoder.py:181-185),
     # CelebA's encoder head: the instances the benchmarks run, held to the float64 oracle (too large for the
-    # CPU simulator) -- `family` is the kernel family the dispatcher must have picked
-    (128, 1000, 1000, 'relu', 'igemm'), (256, 1000, 1000, 'relu', 'igemm'), (128, 6, 1000, 'relu', None),
-    (128, 1000, 1, 'linear', None), (128, 784, 512, 'relu', 'igemm'), (128, 512, 784, 'linear', 'igemm'),
-    (128, 512, 512, 'relu', 'igemm'), (512, 4096, 512, 'linear', 'igemm'), (256, 1024, 256, 'linear', 'igemm')])
+    # CPU simulator) -- `family` is the kernel family the dispatcher must have picked (both widths >= 256: the
+    # two-plane GEMM of dense_h.hip; narrower layers: the fp32 implicit GEMM)
+    (128, 1000, 1000, 'relu', 'dense_h'), (256, 1000, 1000, 'relu', 'dense_h'), (128, 6, 1000, 'relu', None),
+    (128, 1000, 1, 'linear', None), (128, 784, 512, 'relu', 'dense_h'), (128, 512, 784, 'linear', 'dense_h'),
+    (128, 512, 512, 'relu', 'dense_h'), (512, 4096, 512, 'linear', 'dense_h'), (256, 1024, 256, 'linear', 'dense_h'),
+    (256, 1024, 128, 'linear', 'igemm')])
 def test_dense_at_benchmark_sizes(hipbk, B, K, N, act, family):
   bk = hipbk
   L, T = bk.L, bk.T

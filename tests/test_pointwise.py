@@ -421,10 +421,12 @@ def test_latent_block_fwd_bwd(bk, B, P, D, N0, analytic, fb, act0, hact, draw):
   dz, dp, dh = bk.zeros(B, D), bk.zeros(B, 2 * D), bk.zeros(B, P)
   s0 = bk.full((rows, D * N0 + N0), float('nan'))
   sl = bk.full((rows, P * 2 * D + 2 * D), float('nan'))
+  word = bk.zeros(2048, dtype=torch.int32)
   L.odin_latent_block_bwd(tg0.data_ptr(), tw0.data_ptr(), z.data_ptr(), p.data_ptr(), eps_out.data_ptr(),
                           m.data_ptr(), tk.data_ptr(), tx.data_ptr(), None, None, twl.data_ptr(), th.data_ptr(),
                           ACT[hact], dz.data_ptr(), dp.data_ptr(), dh.data_ptr(), s0.data_ptr(), sl.data_ptr(),
-                          B, P, D, N0, analytic, None)
+                          B, P, D, N0, analytic, word.data_ptr(), None)
+  assert float(word.view(torch.float32).max()) == float(dh.abs().max())  # (the range word of dh)
   close(dz.cpu().numpy(), dz_ref)
   close(dp.cpu().numpy(), dp_ref)
   close(dh.cpu().numpy(), dh_ref)
