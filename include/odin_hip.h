@@ -223,6 +223,21 @@ int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, float* llk_
 int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float* llk_part, float* dh,
                                const float* scale, int B, int n_pix, int C, int softplus1,
                                int* n_part_out, void* stream);
+/* The Gaussian head in one pass: Conv2D 1x1 (Cin -> 2C maps, linear; image_networks.py:505-511) ->
+ * Independent(Normal(loc, scale)).log_prob(target) (:95-102; softplus1 as above, 0 or 1) forward + backward
+ * (examples/vae/vae_audio.py:84-110: the audio VAE's decoder).  h [B*n_pix, Cin] = the activation below the head
+ * (activation h_act already applied), w1 [Cin, 2C], b1 [2C], target [B, n_pix, C].  Writes logits [B, n_pix, 2C],
+ * dlogits (optional) = -scale * d llk / d logits, dh [B*n_pix, Cin] = (dlogits w1^T) * act'(h), llk_part
+ * [B][n_part] (the layout odin_elbo_finalize sums), one row (dW1 | db1) per workgroup of wslab and (optional) one
+ * row of Cin column sums of dh per workgroup of colsum_slab (the bias gradient of a Conv2DTranspose below);
+ * dh_amax (optional): the range word of dh.  Replaces odin_conv2d_fwd + odin_elbo_gaussian_fwd_bwd +
+ * odin_conv2d_wgrad + odin_conv2d_dgrad of that layer (three passes over h) with one.  Cin in {8, 16, 32},
+ * C in {1, 3}; a NULL h is a dry run that reports n_part / rows; -2: shapes outside the kernel. */
+int odin_gaussian_head_fwd_bwd(const float* h, const float* w1, const float* b1, const float* target,
+                               float* logits, float* dlogits, float* dh, float* llk_part, int* n_part_out,
+                               float* wslab, int* rows_out, float* colsum_slab, const float* scale, int B,
+                               int n_pix, int Cin, int C, int softplus1, int h_act, uint32_t* dh_amax,
+                               void* stream);
 /* MixtureQuantizedLogistic(params, n_components=K, n_channels=C, low=0, high=255,
  * inputs_domain='sigmoid') (odin/bay/distributions/quantized.py:206-349; built by
  * _parse_distribution 'mixqlogistic', image_networks.py:72-85): h [B, n_pix, K*n_out] with

@@ -78,6 +78,7 @@ SIGNATURES = {
     'odin_latent_block_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, I, I, P, P],
     'odin_elbo_bernoulli_fwd_bwd': [P, P, P, P, P, I, I, IP, P],
     'odin_elbo_gaussian_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
+    'odin_gaussian_head_fwd_bwd': [P, P, P, P, P, P, P, P, IP, P, IP, P, P, I, I, I, I, I, I, P, P],
     'odin_elbo_mixqlogistic_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
     'odin_elbo_finalize': [P, I, P, P, P, P, P, I, P],
     'odin_mean': [P, I, P, P],

@@ -776,6 +776,222 @@ extern "C" int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, 
   return odin_check_launch("elbo_bernoulli");
 }
 
+// ---- Gaussian head: Conv2D 1x1 (Cin -> 2C maps, linear) -> Independent(Normal(loc, scale)).log_prob(target) forward +
+// backward in ONE pass over the [pixels, Cin] activation (image_networks.py:505-511 + :95-102; the audio VAE's
+// decoder, examples/vae/vae_audio.py:84-110).  Unfused this is four launches -- pw1x1 forward, the ELBO kernel, pw1x1
+// weight gradient, pw1x1 data gradient -- and three passes over the activation (252 MB at [256, 96, 80, 32]); here
+// every 16 bytes of it are read once and the gradient wrt it is written once.
+// Lane <-> (pixel, channel quad) as in pw1x1.hip: the Q = Cin/4 lanes of a pixel butterfly their partial dots into
+// the 2C logits (every lane of the pixel then holds them), evaluate the C elements of the pixel, and turn
+// d(-llk)/d(logits) straight into this lane's four channels of dh = (dl w1^T) * act'(h), its share of dW1 / db1 and of
+// the column sums of dh (the bias gradient of a Conv2DTranspose below).  A workgroup walks units of 256 pixels of
+// one sample grid-stride (unit u = sample * n_units_per_sample + j; its 8 waves write llk_part[8 u + wave]: per sample
+// n_part = 8 * units contiguous partials, the layout odin_elbo_finalize sums).
+// Fixed-order reductions throughout: bit-reproducible.
+constexpr int GH_NT = 512;   // threads per workgroup
+constexpr int GH_U = 4;      // pixel groups in flight per lane
+template <int C, int SP1>
+__global__ __launch_bounds__(GH_NT) void gauss_head_kernel(
+    const float4* __restrict__ h, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ target, float* __restrict__ logits, float* __restrict__ dlogits,
+    float4* __restrict__ dh, float* __restrict__ llk_part, float* __restrict__ wslab, float* __restrict__ colsum,
+    const float* __restrict__ scale, unsigned* dh_amax, int n_units, int n_part, int n_pix, int Q, int h_act) {
+  constexpr int CO = 2 * C, NWV = GH_NT / 64;
+  __shared__ float wl[64 * CO];
+  __shared__ float red[NWV * 8 * (5 * CO + 4) + 16];
+  const int CI = 4 * Q;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < CI * CO; e += GH_NT) wl[e] = w1[e];
+  __syncthreads();
+  const int q = tid % Q;
+  float wr[4][CO], br[CO];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int o = 0; o < CO; ++o) wr[k][o] = wl[(4 * q + k) * CO + o];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) br[o] = b1[o];
+  const float sc = scale[0];
+  const int ppg = GH_NT / Q;           // pixels per group
+  const int ppu = ppg * GH_U;          // pixels per unit
+  float acc[4][CO], db[CO];
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  float amx = 0.f;
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    db[o] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k][o] = 0.f;
+  }
+  for (int u0 = blockIdx.x; u0 < n_units; u0 += gridDim.x) {
+    const int b = u0 / n_part, part = u0 - b * n_part;
+    const int pin = part * ppu + tid / Q;          // pixel inside the sample (of group 0)
+    const size_t pbase = (size_t)b * n_pix;
+    float4 v[GH_U];
+    float t[GH_U][C];
+#pragma unroll
+    for (int u = 0; u < GH_U; ++u) {
+      const int pi = pin + u * ppg;
+      const bool ok = pi < n_pix;
+      const size_t p = pbase + pi;
+      v[u] = ok ? h[p * Q + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < C; ++c) t[u][c] = ok ? target[p * C + c] : 0.f;
+    }
+    float llk = 0.f;
+#pragma unroll
+    for (int u = 0; u < GH_U; ++u) {
+      const int pi = pin + u * ppg;
+      const bool ok = pi < n_pix;            // (uniform over the Q lanes of the pixel)
+      const size_t p = pbase + pi;
+      float lg[CO];
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+        float a = v[u].x * wr[0][o];
+        a = fmaf(v[u].y, wr[1][o], a);
+        a = fmaf(v[u].z, wr[2][o], a);
+        a = fmaf(v[u].w, wr[3][o], a);
+        for (int m = 1; m < Q; m <<= 1) a += __shfl_xor(a, m);  // fixed-order butterfly (wave-uniform trip count)
+        lg[o] = a + br[o];
+      }
+      float dl[CO];
+      float l1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float loc = lg[c], raw = lg[C + c];
+        float sd, dsd;
+        if (SP1 == 1) {  // softplus1(raw) = softplus(raw + softplus^-1(1)); its derivative = sigmoid(same)
+          const float a = raw + SOFTPLUS_INV1;
+          const float e = odin_exp2(-1.4426950408889634f * fabsf(a));
+          const float r = odin_rcp(1.f + e);
+          sd = fmaxf(a, 0.f) + 0.6931471805599453f * odin_log2(1.f + e);
+          dsd = a >= 0.f ? r : e * r;
+        } else {
+          sd = raw;
+          dsd = 1.f;
+        }
+        const float inv = 1.f / sd;
+        const float d = (t[u][c] - loc) * inv;
+        l1 += -0.5f * d * d - 0.6931471805599453f * odin_log2(sd) - 0.5f * LOG2PI_F;
+        dl[c] = -(d * inv) * sc;
+        dl[C + c] = -((d * d - 1.f) * inv) * dsd * sc;
+      }
+      if (!ok) {
+#pragma unroll
+        for (int o = 0; o < CO; ++o) dl[o] = 0.f;
+        l1 = 0.f;
+      }
+      if (q == 0) llk += l1;
+      if (ok && q == 0) {
+#pragma unroll
+        for (int o = 0; o < CO; ++o) logits[p * CO + o] = lg[o];
+        if (dlogits != nullptr) {
+#pragma unroll
+          for (int o = 0; o < CO; ++o) dlogits[p * CO + o] = dl[o];
+        }
+      }
+      float r[4];
+      const float hv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+          s = fmaf(dl[o], wr[k][o], s);
+          acc[k][o] = fmaf(hv[k], dl[o], acc[k][o]);
+        }
+        r[k] = s * odin_act_grad(h_act, hv[k]);
+        amx = fmaxf(amx, fabsf(r[k]));
+      }
+#pragma unroll
+      for (int o = 0; o < CO; ++o) db[o] += dl[o];
+      cs.x += r[0]; cs.y += r[1]; cs.z += r[2]; cs.w += r[3];
+      if (ok) odin_store4_stream(dh + p * Q + q, make_float4(r[0], r[1], r[2], r[3]));  // (252 MB: read next from HBM anyway)
+    }
+    // one log-likelihood partial per (unit, wave): no workgroup barrier inside the loop, the waves run free and the
+    // next unit's loads overlap this one's arithmetic
+    llk = wave_sum64(llk);
+    if (lane == 0) llk_part[(size_t)u0 * NWV + wave] = llk;
+  }
+  // ---- this workgroup's slab rows: lanes of equal q inside a wave (xor butterfly over the masks >= Q), then the
+  // waves in order ----
+  constexpr int RW = 5 * CO + 4;
+  float mine[RW];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int o = 0; o < CO; ++o) mine[k * CO + o] = acc[k][o];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) mine[4 * CO + o] = db[o];
+  mine[5 * CO] = cs.x; mine[5 * CO + 1] = cs.y; mine[5 * CO + 2] = cs.z; mine[5 * CO + 3] = cs.w;
+#pragma unroll
+  for (int e = 0; e < RW; ++e) {
+    float a = mine[e];
+    for (int m = Q; m < 64; m <<= 1) a += __shfl_xor(a, m);
+    mine[e] = a;
+  }
+  __syncthreads();
+  if (lane < Q) {
+#pragma unroll
+    for (int e = 0; e < RW; ++e) red[(wave * 8 + lane) * RW + e] = mine[e];
+  }
+  __syncthreads();
+  float* row = wslab + (size_t)blockIdx.x * (CI * CO + CO);
+  for (int e = tid; e < CI * CO + CO; e += GH_NT) {
+    float s = 0.f;
+    if (e < CI * CO) {
+      const int c = e / CO, o = e - c * CO;
+      for (int w = 0; w < NWV; ++w) s += red[(w * 8 + (c >> 2)) * RW + (c & 3) * CO + o];
+    } else {
+      for (int w = 0; w < NWV; ++w) s += red[(w * 8) * RW + 4 * CO + (e - CI * CO)];
+    }
+    row[e] = s;
+  }
+  if (colsum != nullptr && tid < CI) {
+    float s = 0.f;
+    for (int w = 0; w < NWV; ++w) s += red[(w * 8 + (tid >> 2)) * RW + 5 * CO + (tid & 3)];
+    colsum[(size_t)blockIdx.x * CI + tid] = s;
+  }
+  if (dh_amax != nullptr) {
+    __syncthreads();
+    odin_amax_commit_wg(dh_amax, amx, tid, GH_NT, red, blockIdx.x);
+  }
+}
+
+// h [B * n_pix, Cin] = the decoder's activation below the 1x1 head (act h_act already applied), w1 [Cin, 2C], b1 [2C],
+// target [B, n_pix, C].  Writes logits [B, n_pix, 2C], dlogits (optional) = -scale * d llk / d logits, dh [B * n_pix,
+// Cin], llk_part [B][n_part], one row (dW1 | db1) per workgroup of wslab and (optional) one row of Cin column sums of
+// dh per workgroup of colsum_slab.  NULL h: dry run that reports n_part / rows.  -2: shapes outside this kernel.
+extern "C" int odin_gaussian_head_fwd_bwd(const float* h, const float* w1, const float* b1, const float* target,
+                                          float* logits, float* dlogits, float* dh, float* llk_part,
+                                          int* n_part_out, float* wslab, int* rows_out, float* colsum_slab,
+                                          const float* scale, int B, int n_pix, int Cin, int C, int softplus1,
+                                          int h_act, uint32_t* dh_amax, void* stream) {
+  if (!(Cin == 8 || Cin == 16 || Cin == 32) || (C != 1 && C != 3) || (softplus1 != 0 && softplus1 != 1) || B < 1 ||
+      n_pix < 1 || (size_t)B * n_pix * Cin * 4 >= (1ull << 40))
+    return odin_fail(-2, "gaussian_head: shapes outside the fused kernel");
+  const int Q = Cin / 4;
+  const int ppu = GH_NT / Q * GH_U;
+  const int n_part = (n_pix + ppu - 1) / ppu;
+  const long n_units = (long)B * n_part;
+  if (n_units > (1L << 30)) return odin_fail(-2, "gaussian_head: too many units");
+  const int grid = (int)(n_units < ODIN_MAX_COLSUM_BLOCKS ? n_units : ODIN_MAX_COLSUM_BLOCKS);
+  if (n_part_out) *n_part_out = n_part * (GH_NT / 64);  // (one partial per unit and wave)
+  if (rows_out) *rows_out = grid;
+  if (h == nullptr) return 0;  // dry run
+  if ((((uintptr_t)h | (uintptr_t)dh) & 15) != 0) return odin_fail(-2, "gaussian_head: unaligned activation");
+#define ODIN_GH(CC, SP)                                                                                          \
+  ODIN_LAUNCH((gauss_head_kernel<CC, SP>), dim3(grid), dim3(GH_NT), 0, stream, (const float4*)h, w1, b1, target, \
+              logits, dlogits, (float4*)dh, llk_part, wslab, colsum_slab, scale, (unsigned*)dh_amax,             \
+              (int)n_units, n_part, n_pix, Q, h_act)
+  if (C == 1 && softplus1 == 1) ODIN_GH(1, 1);
+  else if (C == 1) ODIN_GH(1, 0);
+  else if (softplus1 == 1) ODIN_GH(3, 1);
+  else ODIN_GH(3, 0);
+#undef ODIN_GH
+  return odin_check_launch("gaussian_head");
+}
+
 extern "C" int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float* llk_part,
                                           float* dh, const float* scale, int B, int n_pix, int C,
                                           int softplus1, int* n_part_out, void* stream) {

@@ -187,9 +187,10 @@ class NetProgram:
     """device address of the range word of gouts[i]"""
     return self.range_words.data_ptr() + 4 * RANGE_WORDS * i
 
-  def set_top_word(self, kept: bool) -> Optional[int]:
-    """the producer of gouts[-1] (outside this program) says whether it keeps the tensor's range word; -> the word"""
-    n = len(self.recs) - 1
+  def set_top_word(self, kept: bool, n: Optional[int] = None) -> Optional[int]:
+    """the producer of gouts[n] (outside this program; n = the last layer by default) says whether it keeps the
+    tensor's range word; -> the word"""
+    n = len(self.recs) - 1 if n is None else n
     self.dy_word[n] = self.word(n) if kept else None
     if self.descs[n] is not None:
       self.descs[n].dy_amax = self.dy_word[n]
@@ -479,6 +480,7 @@ class VAEEngine:
         self.tc_p_all = torch.empty(Bg, 2 * D, **f32)
         self.tc_part_all = torch.empty(2, Bg, D, **f32)    # dloc / dscale partials for every i
     self._plan_fused_tail(f32)
+    self._plan_gauss_head(f32)
     self._plan_latent_block(f32)
     self.ws = torch.empty(1024, **f32)
     self.gnorm2 = torch.zeros(1, **f32)
@@ -574,6 +576,33 @@ class VAEEngine:
     co, c1 = a.desc['Cout'], b.desc['Cout']
     self.tail_slab = torch.empty(rows.value, co * c1 + c1 + co, **f32)
     self.tail_llk_part = torch.empty(self.B * npart.value, **f32)
+
+  def _plan_gauss_head(self, f32):
+    """Training-step fusion Conv2D 1x1 -> Normal log-prob + backward (odin_gaussian_head_fwd_bwd) when the decoder
+    ends in the 1x1 head of a Gaussian observation (the audio VAE, examples/vae/vae_audio.py:84-110): one pass over
+    the activation below the head instead of three."""
+    self.gauss_head = self._used_head = False
+    recs = self.dec_recs
+    if self.observation not in ('gaussian', 'gaussian_softplus1') or len(recs) < 2:
+      return
+    a, b = recs[-2], recs[-1]
+    Cc = self.in_shape[-1]
+    if not (b.kind == 'conv' and b.desc['K'] == 1 and b.desc['stride'] == 1 and b.act == 'linear'
+            and b.desc['Cout'] == 2 * Cc and a.kind in ('conv', 'deconv')):
+      return
+    rows, npart = C.c_int(0), C.c_int(0)
+    try:
+      self.lib.odin_gaussian_head_fwd_bwd(None, None, None, None, None, None, None, None, C.byref(npart), None,
+                                          C.byref(rows), None, None, self.B, self.n_per // Cc, b.desc['Cin'], Cc,
+                                          OBS_MODE[self.observation], ACT[a.act], None, None)
+    except _lib.OdinError:
+      return
+    self.gauss_head = True
+    self.head_rows, self.head_npart = rows.value, npart.value
+    cin, co = b.desc['Cin'], 2 * Cc
+    self.head_slab = torch.empty(rows.value, cin * co + co, **f32)
+    self.head_colsum = torch.empty(rows.value, cin, **f32) if a.kind == 'deconv' else None
+    self.head_llk_part = torch.empty(self.B * npart.value, **f32)
 
   def _plan_latent_block(self, f32):
     """Training-step fusion of the bottleneck (latent_block.hip): noise + DistributionDense + reparameterise /
@@ -754,7 +783,28 @@ class VAEEngine:
       nd2 = len(self.dec_recs) - 2
       keeps = self.tail_keeps_range if fused else self.dec.dgrad_keeps_range(nd2 + 1)
       self.dec.descs[nd2].dy_amax = self.dec.word(nd2) if keeps else None
-    if self.fused_tail and fused:
+    self._used_head = False
+    if self.gauss_head:
+      # gouts[-2] comes from the fused head (which keeps its range word) or from the 1x1 head's data gradient
+      nd2 = len(self.dec_recs) - 2
+      self.dec.set_top_word(True if fused else self.dec.dgrad_keeps_range(nd2 + 1), nd2)
+    if self.gauss_head and fused:
+      nd = len(self.dec_recs)
+      hm = self.dec.forward(dec_in, st, upto=nd - 1, start=dec_start)
+      a, b = self.dec_recs[-2], self.dec_recs[-1]
+      Cc = self.in_shape[-1]
+      rows = C.c_int(0)
+      lib.odin_gaussian_head_fwd_bwd(
+          hm.data_ptr(), self.dec.w(nd - 1).data_ptr(), self.dec.b(nd - 1).data_ptr(), x.data_ptr(),
+          self.dec.outs[-1].data_ptr(), None, self.dec.gouts[-2].data_ptr(), self.head_llk_part.data_ptr(),
+          C.byref(npart), self.head_slab.data_ptr(), C.byref(rows),
+          self.head_colsum.data_ptr() if self.head_colsum is not None else None, self.hp(H_INVB), B,
+          self.n_per // Cc, b.desc['Cin'], Cc, OBS_MODE[self.observation], ACT[a.act], self.dec.word(nd - 2), st)
+      assert rows.value == self.head_rows and npart.value == self.head_npart
+      self._used_fused, self._used_head = False, True
+      llk_part = self.head_llk_part
+      h_d = self.dec.outs[-1]
+    elif self.fused_tail and fused:
       nd = len(self.dec_recs)
       h = self.dec.forward(dec_in, st, upto=nd - 2, start=dec_start)
       a, b = self.dec_recs[-2], self.dec_recs[-1]
@@ -774,7 +824,7 @@ class VAEEngine:
       llk_part = self.llk_part
       h_d = self.dec.forward(dec_in, st, start=dec_start)
     gl = self.dec.gouts[-1]
-    if self._used_fused:
+    if self._used_fused or self._used_head:
       pass
     elif self.observation == 'bernoulli':
       lib.odin_elbo_bernoulli_fwd_bwd(h_d.data_ptr(), x.data_ptr(), self.llk_part.data_ptr(),
@@ -917,6 +967,17 @@ class VAEEngine:
                             self.tail_rows, stride, 0))
       jobs.append(ReduceJob(ts[:, co * c1 + c1:].data_ptr(), self.grads[a.b_off:].data_ptr(), co,
                             self.tail_rows, stride, 0))
+    elif self._used_head:
+      nd = len(self.dec_recs)
+      a, b = self.dec_recs[-2], self.dec_recs[-1]
+      jobs = self.dec.backward(self.z, self.dec.gouts[-2], st, dx_out=self.dz, last=nd - 2, fork=fork,
+                               side_jobs=late_jobs if early else None, first=int(self._bwd_block()))
+      hs = self.head_slab
+      jobs.append(ReduceJob(hs.data_ptr(), self.grads[b.w_off:].data_ptr(), hs.shape[1], self.head_rows,
+                            hs.shape[1], 0))  # (dW1 | db1) of the 1x1 head
+      if self.head_colsum is not None:  # bias gradient of the Conv2DTranspose below = column sums of gouts[-2]
+        hc = self.head_colsum
+        jobs.append(ReduceJob(hc.data_ptr(), self.grads[a.b_off:].data_ptr(), a.b_n, self.head_rows, hc.shape[1], 0))
     else:
       jobs = self.dec.backward(self.z, self.dec.gouts[-1], st, dx_out=self.dz, fork=fork,
                                side_jobs=late_jobs if early else None, first=int(self._bwd_block()))

@@ -108,6 +108,69 @@ def test_elbo_gaussian(bk, sp1, npix, Cc):
   close(dh.cpu().numpy(), dh_ref)
 
 
+@pytest.mark.parametrize('B,npix,Cin,Cc,sp1,hact', [(3, 300, 32, 1, 1, 'elu'), (2, 1000, 32, 3, 0, 'elu'),
+                                                     (5, 64, 16, 1, 0, 'relu'), (2, 530, 8, 3, 1, 'linear'),
+                                                     (7, 7680, 32, 1, 1, 'elu')])
+def test_gaussian_head(bk, B, npix, Cin, Cc, sp1, hact):
+  """odin_gaussian_head_fwd_bwd = Conv2D 1x1 -> Normal log-prob -> its backward pass in one launch, against the
+  separate formulas in float64: logits, llk, dlogits, dh = (dlogits w1^T) act'(h), (dW1 | db1), column sums of
+  dh, the range word of dh."""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(12)
+  CO = 2 * Cc
+  pre = rng.standard_normal((B, npix, Cin))
+  h = {'elu': vo.elu, 'relu': lambda a: np.maximum(a, 0.0), 'linear': lambda a: a}[hact](pre)
+  h = h.astype(np.float32).astype(np.float64)
+  w1 = rng.standard_normal((Cin, CO)) * 0.2
+  b1 = rng.standard_normal(CO) * 0.1
+  if not sp1:
+    b1[Cc:] += 3.0  # raw scales must be positive
+  w1[:, Cc:] *= 0.2
+  x = rng.random((B, npix, Cc))
+  lg = h @ w1 + b1
+  loc, raw = lg[..., :Cc], lg[..., Cc:]
+  sd = vo.softplus1(raw) if sp1 else raw
+  assert sd.min() > 0.05
+  llk_ref = vo.gaussian_log_prob(loc, sd, x)
+  d = (x - loc) / sd
+  dsd = vo.sigmoid(raw + vo.SOFTPLUS_INV_1) if sp1 else 1.0
+  dl_ref = -np.concatenate([d / sd, (d * d - 1) / sd * dsd], -1) / B
+  hgrad = {'linear': np.ones_like(h), 'relu': (h > 0).astype(np.float64), 'elu': vo.elu_grad_from_output(h)}[hact]
+  dh_ref = (dl_ref @ w1.T) * hgrad
+  dW_ref = np.einsum('bpc,bpo->co', h, dl_ref)
+  db_ref = dl_ref.sum((0, 1))
+  th, tw, tb, tx, sc = T(h), T(w1), T(b1), T(x), T([1.0 / B])
+  npart, rows = C.c_int(0), C.c_int(0)
+  L.odin_gaussian_head_fwd_bwd(None, None, None, None, None, None, None, None, C.byref(npart), None, C.byref(rows),
+                               None, None, B, npix, Cin, Cc, sp1, 0, None, None)
+  assert npart.value >= 1 and 1 <= rows.value <= 512
+  logits, dl, dh = bk.zeros(B, npix, CO), bk.zeros(B, npix, CO), bk.full((B, npix, Cin), float('nan'))
+  part = bk.full((B * npart.value,), float('nan'))
+  slab = bk.full((rows.value, Cin * CO + CO), float('nan'))
+  cs = bk.full((rows.value, Cin), float('nan'))
+  word = bk.zeros(2048, dtype=torch.int32)
+  act = _lib.ACT[hact]
+  L.odin_gaussian_head_fwd_bwd(th.data_ptr(), tw.data_ptr(), tb.data_ptr(), tx.data_ptr(), logits.data_ptr(),
+                               dl.data_ptr(), dh.data_ptr(), part.data_ptr(), C.byref(npart), slab.data_ptr(),
+                               C.byref(rows), cs.data_ptr(), sc.data_ptr(), B, npix, Cin, Cc, sp1, act,
+                               word.data_ptr(), None)
+  close(logits.cpu().numpy(), lg)
+  close(part.reshape(B, -1).sum(1).cpu().numpy(), llk_ref, 1e-5)
+  close(dl.cpu().numpy(), dl_ref)
+  close(dh.cpu().numpy(), dh_ref)
+  g = slab.cpu().numpy().astype(np.float64).sum(0)
+  close(g[:Cin * CO].reshape(Cin, CO), dW_ref, 1e-4)
+  close(g[Cin * CO:], db_ref, 1e-4)
+  close(cs.cpu().numpy().astype(np.float64).sum(0), dh_ref.sum((0, 1)), 1e-4)
+  assert float(word.view(torch.float32).max()) == float(dh.abs().max())
+  # without the optional outputs
+  dh2 = bk.full((B, npix, Cin), float('nan'))
+  L.odin_gaussian_head_fwd_bwd(th.data_ptr(), tw.data_ptr(), tb.data_ptr(), tx.data_ptr(), logits.data_ptr(), None,
+                               dh2.data_ptr(), part.data_ptr(), C.byref(npart), slab.data_ptr(), C.byref(rows),
+                               None, sc.data_ptr(), B, npix, Cin, Cc, sp1, act, None, None)
+  assert torch.equal(dh2, dh)
+
+
 def test_adam_and_sumsq(bk):
   L, T = bk.L, bk.T
   rng = np.random.default_rng(3)

@@ -37,6 +37,7 @@ CASES = [
     ('tiny', dict(beta=1.0, analytic=True, free_bits=0.3), 'bernoulli', 3),
     ('tiny_tc', dict(beta=3.0, tc_beta=3.0), 'bernoulli', 3),
     ('tiny_gauss', dict(beta=2.0), 'gaussian_softplus1', 3),
+    ('tiny_gauss', dict(beta=1.0), 'gaussian_softplus1', 1),
     ('tiny_gauss', dict(beta=2.0), 'qlogistic', 3),
     ('tiny', dict(beta=2.0, analytic=True, reverse=False), 'bernoulli', 1),
     ('tiny_mixql', dict(beta=2.0), 'mixqlogistic', 1),
@@ -72,4 +73,5 @@ def test_engine_step_matches_oracle(L, name, kw, obs, C):
                   analytic=kw.get('analytic', False), free_bits=kw.get('free_bits'),
                   tc='betatc' if 'tc_beta' in kw else None, lib=L, reverse=kw.get('reverse', True))
   assert eng.fused_tail == name.startswith('tiny16')
+  assert eng.gauss_head == (obs == 'gaussian_softplus1')  # (one pass over the activation below the 1x1 head)
   check_engine_vs_oracle(eng, model, P, x, eps, beta=kw.get('beta', 1.0), steps=2, clip=100.0)
