@@ -233,6 +233,10 @@ int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float* llk_part, 
  * dh_amax (optional): the range word of dh.  Replaces odin_conv2d_fwd + odin_elbo_gaussian_fwd_bwd +
  * odin_conv2d_wgrad + odin_conv2d_dgrad of that layer (three passes over h) with one.  Cin in {8, 16, 32},
  * C in {1, 3}; a NULL h is a dry run that reports n_part / rows; -2: shapes outside the kernel. */
+/* tests / diagnostics: the launch size (FLOP) from which the convolutions that fit no plane kernel run on the
+ * two-plane implicit GEMM (igemm_h.hip) rather than the fp32 one; 0 = every applicable shape, < 0 = only report.
+ * Returns the previous value. */
+double odin_debug_igemm_h_min_flop(double flop);
 int odin_gaussian_head_fwd_bwd(const float* h, const float* w1, const float* b1, const float* target,
                                float* logits, float* dlogits, float* dh, float* llk_part, int* n_part_out,
                                float* wslab, int* rows_out, float* colsum_slab, const float* scale, int B,

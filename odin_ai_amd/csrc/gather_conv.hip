@@ -1615,6 +1615,10 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
                                  d->pad_t, d->pad_l, d->center))
     return odin_fconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->Cin,
                                   d->OH, d->OW, d->Cout, 1, stream);
+  if (odin_igemm_h_applicable(0, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->center))
+    return odin_igemm_h_launch(0, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
+                               d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, nullptr, 0, nullptr,
+                               stream);
   if (odin_igemm_applicable(0, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                             d->center))
     return odin_igemm_launch(0, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
@@ -1645,6 +1649,7 @@ extern "C" int odin_conv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_ac
   if (aux_act == ODIN_ACT_ELU && d->H == 2 * d->OH && d->W == 2 * d->OW &&
       odin_tconv_ring_applicable(d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0))
     return 0;
+  if (odin_igemm_h_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0)) return 1;
   return odin_igemm_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0) ? 1 : 0;
 }
 extern "C" int odin_deconv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_act) {
@@ -1652,6 +1657,7 @@ extern "C" int odin_deconv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_
       odin_fconv_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
                                    d->pad_t, d->pad_l, 0))
     return 1;
+  if (odin_igemm_h_applicable(0, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0)) return 1;
   const bool ring_two_pass_vs_igemm =
       d->Cout == 64 && odin_igemm_applicable(0, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW,
                                              d->stride, 0) &&
@@ -1689,6 +1695,13 @@ extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* a
     return track_dx(odin_tconv_ring_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, nullptr, nullptr,
                                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->OH,
                                            d->OW, d->Cin, 2, stream), dx, d, stream);
+  if (odin_igemm_h_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0)) {
+    if (slab_rows_out) *slab_rows_out = odin_igemm_h_rows(1, d->B, d->H, d->W, d->stride);
+    if (dx == nullptr) return 0;  // dry run
+    return odin_igemm_h_launch(1, dy, w, nullptr, aux, aux_act, dx, colsum_slab, d->B, d->OH, d->OW, d->Cout, d->H,
+                               d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0, d->dy_amax, 1,
+                               d->dx_amax, stream);
+  }
   if (odin_igemm_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0) &&
       (odin_igemm_tiles(1, d->B, d->H, d->W, d->stride) <= ODIN_MAX_COLSUM_BLOCKS ||
        (colsum_slab == nullptr && dx != nullptr))) {
@@ -1722,6 +1735,10 @@ extern "C" int odin_deconv2d_fwd(const float* x, const float* w, const float* bi
     return odin_tconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr,
                                   nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->H, d->W,
                                   d->Cout, 1, stream);
+  if (odin_igemm_h_applicable(1, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->center))
+    return odin_igemm_h_launch(1, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
+                               d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, nullptr, 0, nullptr,
+                               stream);
   if (odin_igemm_applicable(1, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                             d->center))
     return odin_igemm_launch(1, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
@@ -1743,6 +1760,13 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
                                    d->pad_t, d->pad_l, 0))
     return odin_fconv_planes_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, d->B, d->H, d->W,
                                     d->Cout, d->Cin, 2, d->dy_amax, d->dx_amax, stream);
+  if (odin_igemm_h_applicable(0, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0)) {
+    if (slab_rows_out) *slab_rows_out = odin_igemm_h_rows(0, d->B, d->H, d->W, d->stride);
+    if (dx == nullptr) return 0;  // dry run
+    return odin_igemm_h_launch(0, dy, w, nullptr, aux, aux_act, dx, colsum_slab, d->B, d->OH, d->OW, d->Cout, d->H,
+                               d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0, d->dy_amax, 1,
+                               d->dx_amax, stream);
+  }
   // (64 reduction channels take two fconv_ring passes: where the implicit-GEMM kernel covers the layer it does the
   // same work in one launch -- decoder2 of the dSprites stack: 30.8 us in two launches vs 30.2 us in one)
   const bool ring_two_pass_vs_igemm =

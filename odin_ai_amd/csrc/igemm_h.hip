@@ -1,0 +1,680 @@
+// igemm_h.hip -- convolutions of ANY spatial size as implicit GEMMs on the f16 matrix pipe with fp32 operands carried
+// as two planes (odin_device.h: x = h + 2^-11 l, three v_mfma_f32_32x32x16_f16 per 16 k-values into a main and a
+// cross accumulator, <= 3 * 2^-22 per product), both operands straight from L2 -- the plane arithmetic of
+// fconv_planes / tconv_planes / wgrad_planes without their whole-row tiles of 8 / 16 / 32 pixels.  Those kernels stage
+// row windows through LDS and need row widths that are powers of two; the audio VAE's spectrogram stack
+// (examples/vae/vae_audio.py:84-110 on the image stack of image_networks.py:460-513: 96 x 80 -> 48 x 40 -> 24 x 20
+// -> 12 x 10 -> 6 x 5) fits none of them and ran on the fp32 gather kernels (0.31 of the fp32 MFMA peak).  The
+// small-spatial layers of every stack (encoder3 / decoder2: 8 x 8 and 4 x 4 images) come here too: a third of the
+// matrix time of igemm.hip's v_mfma_f32_32x32x2_f32 chains.
+//
+//   forward / data gradient (igemm_h_kernel):  C[m][j] = sum_k A(m, k) * Wt(k, j)
+//     rows m = output pixels (for the transposed gathers ordered by stride class, so that a tile's rows share their
+//     valid taps: 4 of the 16 taps of a 4x4/s2 kernel); k = (tap, channel), 16 consecutive channels of one tap per
+//     MFMA step: lane (row l31, half h) loads the 8 channels 8 h .. 8 h + 7 of its gathered pixel (32 bytes) and of
+//     its weight column, splits both into planes and issues the three MFMAs.
+//     ONE WAVE OWNS ONE 32 x 32 TILE and walks tiles grid-stride: no partial tiles, no workgroup barrier in the loop
+//     (the row table of a tile is wave-private LDS); the column sums of a data gradient (the bias gradient of a
+//     Conv2DTranspose below) are kept per lane across the tiles of a wave and meet once at the end.
+//   weight gradient (igemm_h_wgrad_kernel):    dW[(tap, cu)][cv] = sum_m U(pix(m, tap), cu) * V(m, cv)
+//     the reduction over the pixels m runs 16 per MFMA step; split over gridDim.z workgroups (one slab row each) and
+//     their waves, partial tiles meet in LDS in wave order.
+// A gradient operand is scaled by the power of two of its range word on its way into the planes (odin_range_shift),
+// the data gradient keeps the range word of its output.
+#include "odin_device.h"
+#include "odin_internal.h"
+#include <cstdlib>
+
+namespace {
+
+#ifdef ODIN_SIM
+#define IH_UNIFORM(x) (x)
+#else
+#define IH_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
+constexpr int IH_NW = 4;  // waves (= tiles in flight) per workgroup
+
+struct IHParams {
+  const float* in;    // gathered tensor [B, H, W, CI]
+  const float* w;
+  float* out;         // [B, OH, OW, CO]
+  const float* bias;  // forward
+  const float* aux;   // data gradient: multiply by act'(aux), aux shaped like out
+  float* colsum;      // data gradient: slab [gridDim.y][CO] of column sums (may be null)
+  const unsigned* in_amax;  // SC: range word of `in` (a gradient tensor)
+  unsigned* out_amax;       // data gradient: range word of `out` (may be null)
+  int B, H, W, CI, OH, OW, CO, KH, KW, S, pt, pl;
+  int gpt;            // 16-channel groups per tap = CI / 16
+  int act, aux_act;
+  int Mc;             // rows per stride class
+  int tpc;            // 32-row tiles per stride class
+  int ntile;          // row tiles in all = classes * tpc
+};
+
+template <bool SC>
+__device__ __forceinline__ void ih_split8(const float (&v)[8], float s, float s2k, u32x4& hi, u32x4& lo) {
+  u32x2 h0, l0, h1, l1;
+  odin_split_h4<SC>(make_float4(v[0], v[1], v[2], v[3]), s, s2k, h0, l0);
+  odin_split_h4<SC>(make_float4(v[4], v[5], v[6], v[7]), s, s2k, h1, l1);
+  hi[0] = h0.x; hi[1] = h0.y; hi[2] = h1.x; hi[3] = h1.y;
+  lo[0] = l0.x; lo[1] = l0.y; lo[2] = l1.x; lo[3] = l1.y;
+}
+
+// position of a wave inside the reduction of its tile: tap (a, c) of the stride class, channel group cg
+struct IHCursor {
+  int t, cg, a, c;
+};
+
+template <bool TMODE, bool BKC, bool SC>
+__global__ __launch_bounds__(IH_NW * 64) void igemm_h_kernel(IHParams p) {
+  __shared__ int rowoff[IH_NW][32];
+  __shared__ float cred[IH_NW * 32 + 16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = IH_UNIFORM(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int j = blockIdx.x * 32 + l31;
+  const bool b_ok = j < p.CO;
+  const float bj = (p.bias != nullptr && b_ok) ? p.bias[j] : 0.f;
+  const OdinRun RA = odin_run(p.in, (unsigned)((size_t)p.B * p.H * p.W * p.CI * 4));
+  const OdinRun RB = odin_run(p.w, (unsigned)((size_t)p.KH * p.KW * p.CI * p.CO * 4));
+  const OdinRun RO = odin_run(p.out, (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4));
+  const bool has_aux = p.aux != nullptr;
+  const OdinRun RX = odin_run(has_aux ? p.aux : p.in, has_aux ? (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4) : 0u);
+  // a gradient input is carried times 2^gk (its maximum lands in [2^14, 2^15)), the sums are scaled back
+  const int gk = SC ? odin_range_shift(odin_range_load(p.in_amax)) : 0;
+  const float in_s = SC ? odin_pow2(gk) : 1.f, in_s2k = SC ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
+  const float o_s = SC ? odin_pow2(-gk) : 1.f, o_sx = SC ? odin_pow2(-gk - 11) : ODIN_LO_UNSCALE;
+  const int SS = TMODE ? p.S : 1;     // 1 or 2
+  const int ssh = SS >> 1;            // x / SS = x >> ssh,  x % SS = x & (SS - 1)
+  const int ohs = p.OH >> ssh, ows = p.OW >> ssh;
+  const unsigned img = (unsigned)(ohs * ows);
+  const int sg = TMODE ? -1 : 1;
+  const int gpt = p.gpt;
+  const unsigned bl = b_ok ? (unsigned)((BKC ? j * p.CI + 8 * h : 8 * h * p.CO + j) * 4) : ODIN_OOB_V;
+  float csum = 0.f, amx = 0.f;
+  for (int ty = IH_UNIFORM((int)blockIdx.y * IH_NW + wave); ty < p.ntile; ty += (int)gridDim.y * IH_NW) {
+    // ---- this tile's stride class and its taps (wave-uniform) ----
+    const int cls = TMODE ? ty / p.tpc : 0;
+    const int tile = TMODE ? ty - cls * p.tpc : ty;
+    const int cy = cls >> ssh, cx = cls - (cy << ssh);
+    const int kh0 = TMODE ? (cy + p.pt) & (SS - 1) : 0, kw0 = TMODE ? (cx + p.pl) & (SS - 1) : 0;
+    const int nkh = (p.KH - kh0 + SS - 1) >> ssh, nkw = (p.KW - kw0 + SS - 1) >> ssh;
+    const int ntap = nkh * nkw;
+    // ---- this lane's A row: one output pixel ----
+    const unsigned q = (unsigned)(tile * 32 + l31);
+    const bool a_ok = q < (unsigned)p.Mc;
+    const unsigned b = q / img, r = q - b * img;
+    const unsigned ys = r / (unsigned)ows, xs = r - ys * (unsigned)ows;
+    const int oy = (int)ys * SS + cy, ox = (int)xs * SS + cx;
+    // gathered pixel of tap (a, c): (Y0 + sg a, X0 + sg c)
+    const int Y0 = TMODE ? (oy + p.pt - kh0) >> ssh : oy * p.S - p.pt;
+    const int X0 = TMODE ? (ox + p.pl - kw0) >> ssh : ox * p.S - p.pl;
+    unsigned mask = 0;
+    {
+      int t = 0;
+      for (int a = 0; a < nkh; ++a)
+        for (int c = 0; c < nkw; ++c, ++t) {
+          const unsigned in = ((unsigned)(Y0 + sg * a) < (unsigned)p.H) & ((unsigned)(X0 + sg * c) < (unsigned)p.W);
+          mask |= in << t;
+        }
+    }
+    mask = a_ok ? mask : 0u;
+    const int lanebase = (((int)b * p.H + Y0) * p.W + X0) * p.CI + 8 * h;  // floats
+    odin_wave_sync();  // (the previous tile's epilogue has read the table)
+    if (h == 0) rowoff[wave][l31] = a_ok ? (((int)b * p.OH + oy) * p.OW + ox) : -1;
+    odin_wave_sync();
+    // the epilogue's operands (store offsets, act'(aux) factors) are fetched NOW: loaded in the epilogue they
+    // cost one exposed round trip per tile
+    unsigned ooff[16];
+    float auxv[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int po = rowoff[wave][(rr & 3) + 8 * (rr >> 2) + 4 * h];
+      const unsigned ok = (unsigned)b_ok & (((unsigned)po >> 31) ^ 1u);
+      ooff[rr] = (unsigned)((po * p.CO + j) * 4) | (ok - 1u);
+      auxv[rr] = has_aux ? odin_run_load1(RX, ooff[rr]) : 0.f;
+    }
+    f32x16 acc = f32x16_zero(), acx = f32x16_zero();
+    float a0[8], b0[8], a1[8], b1[8];
+    IHCursor cur = {0, 0, 0, 0};
+    auto load_group = [&](float (&av)[8], float (&bv)[8]) {
+      // branch-free: a group beyond the reduction reads out of range (zeros, no traffic)
+      const unsigned live = (unsigned)(cur.t - ntap) >> 31;   // 1 / 0 (wave-uniform)
+      const unsigned dead = live - 1u;
+      const int tapoff = sg * (cur.a * p.W + cur.c) * p.CI;
+      const unsigned va = live & (mask >> (cur.t & 31)) & 1u;
+      const unsigned ao = (unsigned)((lanebase + tapoff + 16 * cur.cg) * 4);
+      const float4 x0 = odin_run_load4(RA, ao | (va - 1u)), x1 = odin_run_load4(RA, (ao + 16u) | (va - 1u));
+      av[0] = x0.x; av[1] = x0.y; av[2] = x0.z; av[3] = x0.w; av[4] = x1.x; av[5] = x1.y; av[6] = x1.z; av[7] = x1.w;
+      const int wt = (kh0 + cur.a * SS) * p.KW + kw0 + cur.c * SS;  // weight tap
+      if constexpr (BKC) {
+        const unsigned so = (unsigned)(wt * p.CO * p.CI + 16 * cur.cg) * 4u;
+        const float4 y0 = odin_run_load4s(RB, bl | dead, so), y1 = odin_run_load4s(RB, bl | dead, so + 16u);
+        bv[0] = y0.x; bv[1] = y0.y; bv[2] = y0.z; bv[3] = y0.w; bv[4] = y1.x; bv[5] = y1.y; bv[6] = y1.z; bv[7] = y1.w;
+      } else {
+        const unsigned so = (unsigned)((wt * p.CI + 16 * cur.cg) * p.CO) * 4u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = odin_run_load1s(RB, bl | dead, so + (unsigned)(e * p.CO * 4));
+      }
+      // advance (wave-uniform)
+      cur.cg += 1;
+      if (cur.cg == gpt) {
+        cur.cg = 0; cur.t += 1; cur.c += 1;
+        if (cur.c == nkw) { cur.c = 0; cur.a += 1; }
+      }
+    };
+    auto mul = [&](const float (&av)[8], const float (&bv)[8]) {
+      u32x4 ah, al, bh, bl2;
+      ih_split8<SC>(av, in_s, in_s2k, ah, al);
+      ih_split8<false>(bv, 1.f, ODIN_LO_SCALE, bh, bl2);
+      acx = mfma32_f16(ah, bl2, acx);
+      acc = mfma32_f16(ah, bh, acc);
+      acx = mfma32_f16(al, bh, acx);
+    };
+    const int ngroups = ntap * gpt;
+    load_group(a0, b0);
+    for (int g = 0;;) {
+      load_group(a1, b1);
+      ODIN_SCHED_FENCE();
+      mul(a0, b0);
+      ODIN_SCHED_FENCE();
+      g += 2;
+      if (g - 1 >= ngroups) break;
+      load_group(a0, b0);
+      ODIN_SCHED_FENCE();
+      mul(a1, b1);
+      ODIN_SCHED_FENCE();
+      if (g >= ngroups) break;
+    }
+    // ---- epilogue: lane holds column j, rows (rr & 3) + 8 (rr >> 2) + 4 h ----
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      float v = odin_act(p.act, fmaf(acx[rr], o_sx, acc[rr] * o_s) + bj);
+      if (has_aux) v *= odin_act_grad(p.aux_act, auxv[rr]);
+      odin_run_store1(RO, ooff[rr], v);           // range-checked: nothing is written for masked rows
+      const float vv = ((int)ooff[rr] >= 0) ? v : 0.f;
+      csum += vv;
+      amx = fmaxf(amx, fabsf(vv));
+    }
+  }
+  if (p.colsum != nullptr) {
+    csum += __shfl_xor(csum, 32);
+    if (h == 0) cred[wave * 32 + l31] = csum;
+    __syncthreads();
+    if (wave == 0 && h == 0 && b_ok) {
+      float t = 0.f;
+      for (int w = 0; w < IH_NW; ++w) t += cred[w * 32 + l31];
+      p.colsum[(size_t)blockIdx.y * p.CO + j] = t;
+    }
+  }
+  if (p.out_amax != nullptr) {
+    __syncthreads();
+    odin_amax_commit_wg(p.out_amax, amx, tid, IH_NW * 64, cred, blockIdx.x + gridDim.x * blockIdx.y);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same with the WEIGHT PLANES IN LDS.  A workgroup serves one stride class and one 32-column block: it splits that
+// slice of the weights ONCE (<= 32 steps of 16 k-values: 2 KB per step, both planes, already in the MFMA B layout:
+// [step][plane][half][column] x 16 bytes) and its waves then walk the tiles of the class reading B with two
+// ds_read_b128 per step -- on the global-memory variant every tile re-fetched and re-split its 4-32 KB of weights
+// through the vector memory pipe, which the A gathers need (audio decoder4: 270 -> see DESIGN 3.8c).
+template <bool TMODE, bool BKC, bool SC>
+__global__ __launch_bounds__(IH_NW * 64) void igemm_hw_kernel(IHParams p) {
+  ODIN_DYN_SMEM(char, wlds);   // [nsteps][2][2][32] x 16 B
+  __shared__ int rowoff[IH_NW][32];
+  __shared__ float cred[IH_NW * 32 + 16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = IH_UNIFORM(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int j = blockIdx.x * 32 + l31;
+  const bool b_ok = j < p.CO;
+  const float bj = (p.bias != nullptr && b_ok) ? p.bias[j] : 0.f;
+  const OdinRun RA = odin_run(p.in, (unsigned)((size_t)p.B * p.H * p.W * p.CI * 4));
+  const OdinRun RB = odin_run(p.w, (unsigned)((size_t)p.KH * p.KW * p.CI * p.CO * 4));
+  const OdinRun RO = odin_run(p.out, (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4));
+  const bool has_aux = p.aux != nullptr;
+  const OdinRun RX = odin_run(has_aux ? p.aux : p.in, has_aux ? (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4) : 0u);
+  const int gk = SC ? odin_range_shift(odin_range_load(p.in_amax)) : 0;
+  const float in_s = SC ? odin_pow2(gk) : 1.f, in_s2k = SC ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
+  const float o_s = SC ? odin_pow2(-gk) : 1.f, o_sx = SC ? odin_pow2(-gk - 11) : ODIN_LO_UNSCALE;
+  const int SS = TMODE ? p.S : 1;     // 1 or 2
+  const int ssh = SS >> 1;
+  const int ncls = SS * SS;
+  const int ohs = p.OH >> ssh, ows = p.OW >> ssh;
+  const unsigned img = (unsigned)(ohs * ows);
+  const int sg = TMODE ? -1 : 1;
+  const int gpt = p.gpt;
+  // ---- this workgroup's stride class and its taps ----
+  const int cls = (int)blockIdx.y % ncls, slot = (int)blockIdx.y / ncls, nslot = (int)gridDim.y / ncls;
+  const int cy = cls >> ssh, cx = cls - (cy << ssh);
+  const int kh0 = TMODE ? (cy + p.pt) & (SS - 1) : 0, kw0 = TMODE ? (cx + p.pl) & (SS - 1) : 0;
+  const int nkh = (p.KH - kh0 + SS - 1) >> ssh, nkw = (p.KW - kw0 + SS - 1) >> ssh;
+  const int ntap = nkh * nkw;
+  const int ngroups = ntap * gpt;
+  // ---- the weight planes of (class, column block): entry (step s, half hh, column jl) <- 8 weights ----
+  for (int e = tid; e < ngroups * 64; e += IH_NW * 64) {
+    const int s = e >> 6, hh = (e >> 5) & 1, jl = e & 31;
+    const int t = s / gpt, cg = s - t * gpt;
+    const int a = t / nkw, c = t - a * nkw;
+    const int wt = (kh0 + a * SS) * p.KW + kw0 + c * SS;
+    const int jj = blockIdx.x * 32 + jl;
+    float wv[8];
+    if (BKC) {
+      const unsigned off = jj < p.CO ? (unsigned)(((wt * p.CO + jj) * p.CI + 16 * cg + 8 * hh) * 4) : ODIN_OOB;
+      const float4 y0 = odin_run_load4(RB, off), y1 = odin_run_load4(RB, off == ODIN_OOB ? ODIN_OOB : off + 16u);
+      wv[0] = y0.x; wv[1] = y0.y; wv[2] = y0.z; wv[3] = y0.w; wv[4] = y1.x; wv[5] = y1.y; wv[6] = y1.z; wv[7] = y1.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        wv[q] = odin_run_load1(RB, jj < p.CO ? (unsigned)((((wt * p.CI + 16 * cg + 8 * hh + q) * p.CO) + jj) * 4) : ODIN_OOB);
+    }
+    u32x4 wh, wl;
+    ih_split8<false>(wv, 1.f, ODIN_LO_SCALE, wh, wl);
+    *reinterpret_cast<u32x4*>(wlds + ((((s * 2 + 0) * 2 + hh) * 32 + jl) << 4)) = wh;
+    *reinterpret_cast<u32x4*>(wlds + ((((s * 2 + 1) * 2 + hh) * 32 + jl) << 4)) = wl;
+  }
+  __syncthreads();
+  const char* wme = wlds + ((h * 32 + l31) << 4);   // this lane's entry of step 0, plane 0; + 2048 per step, + 1024 lo plane
+  float csum = 0.f, amx = 0.f;
+  for (int tile = IH_UNIFORM(slot * IH_NW + wave); tile < p.tpc; tile += nslot * IH_NW) {
+    // ---- this lane's A row: one output pixel ----
+    const unsigned q = (unsigned)(tile * 32 + l31);
+    const bool a_ok = q < (unsigned)p.Mc;
+    const unsigned b = q / img, r = q - b * img;
+    const unsigned ys = r / (unsigned)ows, xs = r - ys * (unsigned)ows;
+    const int oy = (int)ys * SS + cy, ox = (int)xs * SS + cx;
+    const int Y0 = TMODE ? (oy + p.pt - kh0) >> ssh : oy * p.S - p.pt;
+    const int X0 = TMODE ? (ox + p.pl - kw0) >> ssh : ox * p.S - p.pl;
+    unsigned mask = 0;
+    {
+      int t = 0;
+      for (int a = 0; a < nkh; ++a)
+        for (int c = 0; c < nkw; ++c, ++t) {
+          const unsigned in = ((unsigned)(Y0 + sg * a) < (unsigned)p.H) & ((unsigned)(X0 + sg * c) < (unsigned)p.W);
+          mask |= in << t;
+        }
+    }
+    mask = a_ok ? mask : 0u;
+    const int lanebase = (((int)b * p.H + Y0) * p.W + X0) * p.CI + 8 * h;  // floats
+    odin_wave_sync();  // (the previous tile's epilogue has read the table)
+    if (h == 0) rowoff[wave][l31] = a_ok ? (((int)b * p.OH + oy) * p.OW + ox) : -1;
+    odin_wave_sync();
+    unsigned ooff[16];
+    float auxv[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int po = rowoff[wave][(rr & 3) + 8 * (rr >> 2) + 4 * h];
+      const unsigned ok = (unsigned)b_ok & (((unsigned)po >> 31) ^ 1u);
+      ooff[rr] = (unsigned)((po * p.CO + j) * 4) | (ok - 1u);
+      auxv[rr] = has_aux ? odin_run_load1(RX, ooff[rr]) : 0.f;
+    }
+    f32x16 acc = f32x16_zero(), acx = f32x16_zero();
+    float a0[8], a1[8];
+    IHCursor cur = {0, 0, 0, 0};
+    auto load_a = [&](float (&av)[8]) {
+      const unsigned live = (unsigned)(cur.t - ntap) >> 31;   // 1 / 0 (wave-uniform)
+      const int tapoff = sg * (cur.a * p.W + cur.c) * p.CI;
+      const unsigned va = live & (mask >> (cur.t & 31)) & 1u;
+      const unsigned ao = (unsigned)((lanebase + tapoff + 16 * cur.cg) * 4);
+      const float4 x0 = odin_run_load4(RA, ao | (va - 1u)), x1 = odin_run_load4(RA, (ao + 16u) | (va - 1u));
+      av[0] = x0.x; av[1] = x0.y; av[2] = x0.z; av[3] = x0.w; av[4] = x1.x; av[5] = x1.y; av[6] = x1.z; av[7] = x1.w;
+      cur.cg += 1;
+      if (cur.cg == gpt) {
+        cur.cg = 0; cur.t += 1; cur.c += 1;
+        if (cur.c == nkw) { cur.c = 0; cur.a += 1; }
+      }
+    };
+    auto mul = [&](const float (&av)[8], int s) {
+      u32x4 ah, al;
+      ih_split8<SC>(av, in_s, in_s2k, ah, al);
+      const u32x4 bh = *reinterpret_cast<const u32x4*>(wme + (s << 11));
+      const u32x4 bl2 = *reinterpret_cast<const u32x4*>(wme + (s << 11) + 1024);
+      acx = mfma32_f16(ah, bl2, acx);
+      acc = mfma32_f16(ah, bh, acc);
+      acx = mfma32_f16(al, bh, acx);
+    };
+    load_a(a0);
+    for (int g = 0;;) {
+      load_a(a1);
+      ODIN_SCHED_FENCE();
+      mul(a0, g);
+      ODIN_SCHED_FENCE();
+      g += 2;
+      if (g - 1 >= ngroups) break;
+      load_a(a0);
+      ODIN_SCHED_FENCE();
+      mul(a1, g - 1);
+      ODIN_SCHED_FENCE();
+      if (g >= ngroups) break;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      float v = odin_act(p.act, fmaf(acx[rr], o_sx, acc[rr] * o_s) + bj);
+      if (has_aux) v *= odin_act_grad(p.aux_act, auxv[rr]);
+      odin_run_store1(RO, ooff[rr], v);
+      const float vv = ((int)ooff[rr] >= 0) ? v : 0.f;
+      csum += vv;
+      amx = fmaxf(amx, fabsf(vv));
+    }
+  }
+  if (p.colsum != nullptr) {
+    csum += __shfl_xor(csum, 32);
+    if (h == 0) cred[wave * 32 + l31] = csum;
+    __syncthreads();
+    if (wave == 0 && h == 0 && b_ok) {
+      float t = 0.f;
+      for (int w = 0; w < IH_NW; ++w) t += cred[w * 32 + l31];
+      p.colsum[(size_t)blockIdx.y * p.CO + j] = t;
+    }
+  }
+  if (p.out_amax != nullptr) {
+    __syncthreads();
+    odin_amax_commit_wg(p.out_amax, amx, tid, IH_NW * 64, cred, blockIdx.x + gridDim.x * blockIdx.y);
+  }
+}
+
+template <typename K>
+int ih_set_lds(K kern, size_t bytes) {
+#ifndef ODIN_SIM
+  if (bytes > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)bytes) != hipSuccess)
+    return odin_fail(-4, "igemm_h: cannot raise the dynamic LDS limit");
+#else
+  (void)kern; (void)bytes;
+#endif
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct IHWParams {
+  const float* u;   // fine tensor   [B, FH, FW, CU]
+  const float* v;   // coarse tensor [B, h, w, CV]
+  float* slab;      // [gridDim.z][slab_stride]: (dW [KH*KW*CU][CV] | column sums of V [CV])
+  const unsigned* g_amax;  // range word of the gradient operand (SCU: u, SCV: v)
+  int slab_stride;
+  int B, FH, FW, CU, h, w, CV, KH, KW, S, pt, pl;
+  int M;            // B * h * w
+  int chunk;        // pixels per workgroup (multiple of 16, <= IHW_CHUNK)
+  int want_bias;
+};
+
+constexpr int IHW_CHUNK = 2048;
+
+// NW waves split the 16-pixel steps of a workgroup's chunk; SCU / SCV: that operand is a gradient
+template <int NW, bool SCU, bool SCV>
+__global__ __launch_bounds__(NW * 64) void igemm_h_wgrad_kernel(IHWParams p) {
+  __shared__ float red[NW > 1 ? (NW - 1) * 16 * 64 : 64];
+  __shared__ int tb_base[IHW_CHUNK + 16];   // float offset of the fine pixel (y S - pt, x S - pl) of coarse pixel m
+  __shared__ int tb_yx[IHW_CHUNK + 16];     // (y S - pt + 64) << 16 | (x S - pl + 64); -1: beyond this workgroup's pixels
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = IH_UNIFORM(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int I = p.KH * p.KW * p.CU;
+  const int i = blockIdx.y * 32 + l31, j = blockIdx.x * 32 + l31;
+  const bool i_ok = i < I, j_ok = j < p.CV;
+  const int tap = i / p.CU, cu = i - tap * p.CU;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int rowc = (kh * p.FW + kw) * p.CU + cu;
+  const int mlo = blockIdx.z * p.chunk;
+  const int mhi = (mlo + p.chunk < p.M) ? mlo + p.chunk : p.M;
+  for (int e = tid; e < IHW_CHUNK + 16; e += NW * 64) {
+    const int m = mlo + e;
+    if (m < mhi && e < p.chunk) {
+      const int b = m / (p.h * p.w), r = m - b * (p.h * p.w), y = r / p.w, x = r - y * p.w;
+      const int fy = y * p.S - p.pt, fx = x * p.S - p.pl;
+      tb_base[e] = ((b * p.FH + fy) * p.FW + fx) * p.CU;
+      tb_yx[e] = ((fy + 64) << 16) | (fx + 64);
+    } else {
+      tb_base[e] = 0;
+      tb_yx[e] = -1;
+    }
+  }
+  __syncthreads();
+  const OdinRun RU = odin_run(p.u, (unsigned)((size_t)p.B * p.FH * p.FW * p.CU * 4));
+  const OdinRun RV = odin_run(p.v, (unsigned)((size_t)p.M * p.CV * 4));
+  const int gk = (SCU || SCV) ? odin_range_shift(odin_range_load(p.g_amax)) : 0;
+  const float g_s = (SCU || SCV) ? odin_pow2(gk) : 1.f, g_s2k = (SCU || SCV) ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
+  const int nsteps = (mhi - mlo + 15) >> 4;
+  f32x16 acc = f32x16_zero(), acx = f32x16_zero();
+  float csum = 0.f;
+  float a0[8], b0[8], a1[8], b1[8];
+  auto load_step = [&](int s, float (&av)[8], float (&bv)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      // pixel of this lane's half within the chunk (branch-free: entries [chunk, IHW_CHUNK + 16) are -1)
+      const int mr = s * 16 + 8 * h + e;
+      const int ml = mr < IHW_CHUNK + 8 ? mr : IHW_CHUNK + 8;
+      const int base = tb_base[ml];
+      const int yx = tb_yx[ml];
+      const int fy = (yx >> 16) - 64 + kh, fx = (yx & 0xFFFF) - 64 + kw;
+      const unsigned inb = ((unsigned)yx >> 31) ^ 1u;   // 1: a pixel of this workgroup
+      const unsigned va = (unsigned)i_ok & inb & ((unsigned)fy < (unsigned)p.FH) & ((unsigned)fx < (unsigned)p.FW);
+      av[e] = odin_run_load1(RU, (unsigned)((base + rowc) * 4) | (va - 1u));
+      const unsigned vb = (unsigned)j_ok & inb;
+      bv[e] = odin_run_load1(RV, (unsigned)(((mlo + ml) * p.CV + j) * 4) | (vb - 1u));
+    }
+  };
+  auto mul = [&](const float (&av)[8], const float (&bv)[8]) {
+    u32x4 ah, al, bh, bl;
+    ih_split8<SCU>(av, g_s, g_s2k, ah, al);
+    ih_split8<SCV>(bv, g_s, g_s2k, bh, bl);
+    acx = mfma32_f16(ah, bl, acx);
+    acc = mfma32_f16(ah, bh, acc);
+    acx = mfma32_f16(al, bh, acx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum += bv[e];
+  };
+  int s = wave;
+  if (s < nsteps) {
+    load_step(s, a0, b0);
+    for (;;) {
+      load_step(s + NW, a1, b1);   // (beyond the chunk: table entries -1, zeros, no traffic)
+      ODIN_SCHED_FENCE();
+      mul(a0, b0);
+      ODIN_SCHED_FENCE();
+      s += 2 * NW;
+      if (s - NW >= nsteps) break;
+      load_step(s, a0, b0);
+      ODIN_SCHED_FENCE();
+      mul(a1, b1);
+      ODIN_SCHED_FENCE();
+      if (s >= nsteps) break;
+    }
+  }
+  // ---- combine the NW partial tiles in wave order (main + 2^-11 cross, scaled back) ----
+  const float o_s = (SCU || SCV) ? odin_pow2(-gk) : 1.f, o_sx = (SCU || SCV) ? odin_pow2(-gk - 11) : ODIN_LO_UNSCALE;
+  f32x16 tot;
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) tot[rr] = fmaf(acx[rr], o_sx, acc[rr] * o_s);
+  if (NW > 1) {
+    if (wave > 0) {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) red[((wave - 1) * 16 + rr) * 64 + lane] = tot[rr];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      for (int w = 1; w < NW; ++w) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) tot[rr] += red[((w - 1) * 16 + rr) * 64 + lane];
+      }
+    }
+  }
+  float* row = p.slab + (size_t)blockIdx.z * p.slab_stride;
+  if (p.want_bias && blockIdx.y == 0) {
+    // column sums of V over this workgroup's pixels: halves h = 0 / 1 and the NW waves (raw fp32 values)
+    __syncthreads();
+    const float t = csum + __shfl_xor(csum, 32);
+    if (h == 0) red[wave * 32 + l31] = t;
+    __syncthreads();
+    if (wave == 0 && h == 0 && j_ok) {
+      float sm = 0.f;
+      for (int w = 0; w < NW; ++w) sm += red[w * 32 + l31];
+      row[(size_t)I * p.CV + j] = sm;
+    }
+  }
+  if (wave != 0 || !j_ok) return;
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int ii = blockIdx.y * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+    if (ii < I) row[(size_t)ii * p.CV + j] = tot[rr];
+  }
+}
+
+bool ih_enabled() { return !odin_exact_fp32() && ODIN_DIAG_ENV("ODIN_NOIGEMMH") == nullptr; }
+
+// Below ~1.5 GFLOP per launch the fp32 implicit GEMM (igemm.hip) wins: its workgroups split the reduction of a tile over
+// their waves and the weight and data gradient of a layer share one launch (same-box A/B over the six workloads: the
+// dSprites step 0.544 ms with the small layers there, 0.595 ms with them here; the audio stack's layers of 2-16 GFLOP
+// are 10-60 % faster here)
+double g_ih_min_flop = 1.5e9;
+
+}  // namespace
+
+// tests: the launch size from which convolutions come here (0: every applicable shape); returns the previous value
+extern "C" double odin_debug_igemm_h_min_flop(double flop) {
+  const double old = g_ih_min_flop;
+  if (flop >= 0.0) g_ih_min_flop = flop;
+  return old;
+}
+
+// forward / data gradient: 16-channel steps, at least 128 tiles (fewer: the fp32 kernel splits the reduction of a tile
+// over the waves of a workgroup, igemm.hip)
+bool odin_igemm_h_applicable(int tmode, int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
+                             int center) {
+  if (!ih_enabled() || center) return false;
+  if (CI < 16 || (CI & 15) != 0 || CI > 8192 || KH * KW > 25 || KH < 1 || KW < 1 || KH > 8 || KW > 8 || S < 1 || S > 2)
+    return false;
+  if (tmode && (OH % S || OW % S || KH < S || KW < S)) return false;
+  const int SS = tmode ? S : 1;
+  const long Mc = (long)B * (OH / SS) * (OW / SS);
+  const long tiles = (long)SS * SS * ((Mc + 31) / 32) * ((CO + 31) / 32);
+  if (tiles < 128) return false;
+  if (2.0 * B * (tmode ? (double)H * W : (double)OH * OW) * KH * KW * CI * CO < g_ih_min_flop) return false;
+  if ((long)B * H * W * CI >= (1L << 29) || (long)B * OH * OW * CO >= (1L << 29) || (long)KH * KW * CI * CO >= (1L << 29))
+    return false;
+  return true;
+}
+
+// rows of column sums the data-gradient launch writes (= its gridDim.y)
+int odin_igemm_h_rows(int tmode, int B, int OH, int OW, int S) {
+  const int SS = tmode ? S : 1;
+  const long Mc = (long)B * (OH / SS) * (OW / SS);
+  const long ntile = (long)SS * SS * ((Mc + 31) / 32);
+  long gy = (ntile + IH_NW - 1) / IH_NW;
+  if (gy > ODIN_MAX_COLSUM_BLOCKS) gy = ODIN_MAX_COLSUM_BLOCKS;
+  gy = (gy + SS * SS - 1) / (SS * SS) * (SS * SS);   // (whole stride classes: igemm_hw_kernel)
+  if (gy > ODIN_MAX_COLSUM_BLOCKS) gy -= SS * SS;
+  return (int)gy;
+}
+
+int odin_igemm_h_launch(int tmode, const float* in, const float* w, const float* bias, const float* aux, int aux_act,
+                        float* out, float* colsum, int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
+                        int S, int pt, int pl, int act, const uint32_t* in_amax, int in_is_grad, uint32_t* out_amax,
+                        void* stream) {
+  IHParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = in; p.w = w; p.out = out; p.bias = bias; p.out_amax = out_amax;
+  p.aux = (aux != nullptr && aux_act != 0) ? aux : nullptr; p.aux_act = aux_act; p.colsum = colsum;
+  p.B = B; p.H = H; p.W = W; p.CI = CI; p.OH = OH; p.OW = OW; p.CO = CO;
+  p.KH = KH; p.KW = KW; p.S = S; p.pt = pt; p.pl = pl; p.gpt = CI / 16; p.act = act;
+  const int SS = tmode ? S : 1;
+  p.Mc = B * (OH / SS) * (OW / SS);
+  p.tpc = (p.Mc + 31) / 32;
+  p.ntile = SS * SS * p.tpc;
+  if (in_is_grad) {
+    p.in_amax = odin_range_word_of(in, (size_t)B * H * W * CI, in_amax, stream);
+    if (p.in_amax == nullptr) return odin_fail(-3, "igemm_h: no range word for the gradient input");
+  }
+  // every wave walks tiles grid-stride: the whole chip in one wave of workgroups for the big layers (and the column
+  // sums stay within ODIN_MAX_COLSUM_BLOCKS rows)
+  int gy = (p.ntile + IH_NW - 1) / IH_NW;
+  const int gx = (CO + 31) / 32;
+  int cap = ODIN_MAX_COLSUM_BLOCKS;
+  if (colsum == nullptr) {
+    cap = (8 * odin_num_cus() + gx - 1) / gx;   // ~8 workgroups (32 waves) per CU
+    if (cap < 1) cap = 1;
+  }
+  if (gy > cap) gy = cap;
+  const int ncls = SS * SS;
+  gy = (gy + ncls - 1) / ncls * ncls;             // whole stride classes
+  if (gy > cap && gy > ncls) gy -= ncls;
+  dim3 grid(gx, gy, 1);
+  // weight planes of one (class, column block) in LDS when they fit in 64 KB (2 KB per 16-value step)
+  const int max_steps = ((KH + SS - 1) / SS) * ((KW + SS - 1) / SS) * p.gpt;
+  if (max_steps <= 32 && !ODIN_DIAG_ENV("ODIN_IH_NOLDSW")) {
+    const size_t lds = (size_t)max_steps * 2048;
+#define ODIN_IHW_L(T_, K_, S_)                                                                    \
+  do {                                                                                            \
+    if (int rc = ih_set_lds(&igemm_hw_kernel<T_, K_, S_>, lds)) return rc;                        \
+    ODIN_LAUNCH((igemm_hw_kernel<T_, K_, S_>), grid, dim3(IH_NW * 64), lds, stream, p);           \
+  } while (0)
+    if (tmode) { if (in_is_grad) ODIN_IHW_L(true, true, true); else ODIN_IHW_L(true, true, false); }
+    else { if (in_is_grad) ODIN_IHW_L(false, false, true); else ODIN_IHW_L(false, false, false); }
+#undef ODIN_IHW_L
+    return odin_check_launch("igemm_h(f16x2)");
+  }
+#define ODIN_IH(T_, K_, S_) ODIN_LAUNCH((igemm_h_kernel<T_, K_, S_>), grid, dim3(IH_NW * 64), 0, stream, p)
+  // Conv2D forward / Conv2DTranspose data gradient: weights [tap][k][j]; the transposed gathers: [tap][j][k]
+  if (tmode) { if (in_is_grad) ODIN_IH(true, true, true); else ODIN_IH(true, true, false); }
+  else { if (in_is_grad) ODIN_IH(false, false, true); else ODIN_IH(false, false, false); }
+#undef ODIN_IH
+  return odin_check_launch("igemm_h(f16x2)");
+}
+
+// weight gradient: fine tensor (FH, FW, CU) gathered around the pixels of the coarse one (h, w, CV)
+bool odin_igemm_h_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, int CV, int KH, int KW, int S,
+                                   int center) {
+  if (!ih_enabled() || center) return false;
+  if (CU < 8 || (CU & 7) != 0 || CU > 8192 || KH * KW > 64 || KH < 1 || KW < 1 || S < 1 || S > 4) return false;
+  if (FH > 8192 || FW > 8192) return false;
+  const long M = (long)B * h * w;
+  if (M < 512 || (M + ODIN_MAX_SLAB_BLOCKS - 1) / ODIN_MAX_SLAB_BLOCKS > IHW_CHUNK - 16) return false;
+  if (2.0 * M * KH * KW * CU * CV < g_ih_min_flop) return false;
+  if ((long)B * FH * FW * CU >= (1L << 29) || M * CV >= (1L << 29)) return false;
+  return true;
+}
+
+// reduction splits (= slab rows) of the weight-gradient launch
+int odin_igemm_h_wgrad_rows(int B, int h, int w, int KH, int KW, int CU, int CV) {
+  const int M = B * h * w;
+  const long tiles = (long)((KH * KW * CU + 31) / 32) * ((CV + 31) / 32);
+  int R = (M + IHW_CHUNK - 17) / (IHW_CHUNK - 16);
+  // enough workgroups to fill the chip twice, at least 128 pixels each
+  while (tiles * R < 2048 && M / (R * 2) >= 128 && R * 2 <= ODIN_MAX_SLAB_BLOCKS) R *= 2;
+  return R;
+}
+
+int odin_igemm_h_wgrad_launch(const float* u, const float* v, float* slab, int slab_stride, int B, int FH, int FW,
+                              int CU, int h, int w, int CV, int KH, int KW, int S, int pt, int pl, int want_bias,
+                              int grad_u, const uint32_t* g_amax, void* stream) {
+  IHWParams p;
+  memset(&p, 0, sizeof(p));
+  p.u = u; p.v = v; p.slab = slab; p.slab_stride = slab_stride;
+  p.B = B; p.FH = FH; p.FW = FW; p.CU = CU; p.h = h; p.w = w; p.CV = CV;
+  p.KH = KH; p.KW = KW; p.S = S; p.pt = pt; p.pl = pl; p.want_bias = want_bias;
+  p.M = B * h * w;
+  const int R = odin_igemm_h_wgrad_rows(B, h, w, KH, KW, CU, CV);
+  p.chunk = (((p.M + R - 1) / R) + 15) & ~15;
+  if (p.chunk > IHW_CHUNK) return odin_fail(-2, "igemm_h wgrad: chunk beyond the pixel table");
+  const float* g = grad_u ? u : v;
+  p.g_amax = odin_range_word_of(g, grad_u ? (size_t)B * FH * FW * CU : (size_t)p.M * CV, g_amax, stream);
+  if (p.g_amax == nullptr) return odin_fail(-3, "igemm_h wgrad: no range word for the gradient operand");
+  dim3 grid((CV + 31) / 32, (KH * KW * CU + 31) / 32, R);
+  const int nsteps = (p.chunk + 15) / 16;
+  const long wgs = (long)grid.x * grid.y * grid.z;
+  int nw = 1;
+  while (nw < 4 && wgs * nw < 2048 && nsteps / (nw * 2) >= 4) nw *= 2;
+#define ODIN_IHW(N_)                                                                                        \
+  do {                                                                                                      \
+    if (grad_u) ODIN_LAUNCH((igemm_h_wgrad_kernel<N_, true, false>), grid, dim3(N_ * 64), 0, stream, p);   \
+    else ODIN_LAUNCH((igemm_h_wgrad_kernel<N_, false, true>), grid, dim3(N_ * 64), 0, stream, p);          \
+  } while (0)
+  if (nw >= 4) ODIN_IHW(4);
+  else if (nw == 2) ODIN_IHW(2);
+  else ODIN_IHW(1);
+#undef ODIN_IHW
+  return odin_check_launch("igemm_h_wgrad(f16x2)");
+}

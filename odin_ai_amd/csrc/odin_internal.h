@@ -130,6 +130,20 @@ int odin_igemm_launch(int tmode, const float* in, const float* w, const float* b
 // stream and shares its launch (igemm_pair_kernel); end flushes a weight gradient that found no partner
 void odin_igemm_pair_begin();
 int odin_igemm_pair_end();
+// igemm_h.hip: the same implicit GEMMs on the f16 matrix pipe (two planes per operand), any spatial size
+bool odin_igemm_h_applicable(int tmode, int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
+                             int center);
+int odin_igemm_h_rows(int tmode, int B, int OH, int OW, int S);
+int odin_igemm_h_launch(int tmode, const float* in, const float* w, const float* bias, const float* aux, int aux_act,
+                        float* out, float* colsum, int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
+                        int S, int pt, int pl, int act, const uint32_t* in_amax, int in_is_grad, uint32_t* out_amax,
+                        void* stream);
+bool odin_igemm_h_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, int CV, int KH, int KW, int S,
+                                   int center);
+int odin_igemm_h_wgrad_rows(int B, int h, int w, int KH, int KW, int CU, int CV);
+int odin_igemm_h_wgrad_launch(const float* u, const float* v, float* slab, int slab_stride, int B, int FH, int FW,
+                              int CU, int h, int w, int CV, int KH, int KW, int S, int pt, int pl, int want_bias,
+                              int grad_u, const uint32_t* g_amax, void* stream);
 bool odin_igemm_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, int CV, int KH, int KW, int S,
                                  int center);
 int odin_igemm_wgrad_rows(int B, int h, int w, int KH, int KW, int CU, int CV);

@@ -1038,6 +1038,12 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
                                    p.center))
     return odin_wgrad_planes_launch(p.in, p.dy, p.slab, rows_out, p.B, p.OH, p.OW, p.CI, p.CO,
                                     p.want_bias, p.want_bias ? 0 : 1, p.g_amax, stream);
+  if (odin_igemm_h_wgrad_applicable(p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO, p.KH, p.KW, p.S, p.center)) {
+    if (rows_out) *rows_out = odin_igemm_h_wgrad_rows(p.B, p.OH, p.OW, p.KH, p.KW, p.CI, p.CO);
+    if (p.slab == nullptr) return 0;  // dry run
+    return odin_igemm_h_wgrad_launch(p.in, p.dy, p.slab, p.slab_stride, p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO,
+                                     p.KH, p.KW, p.S, p.pt, p.pl, p.want_bias, p.want_bias ? 0 : 1, p.g_amax, stream);
+  }
   if (odin_igemm_wgrad_applicable(p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO, p.KH, p.KW, p.S, p.center)) {
     if (rows_out) *rows_out = odin_igemm_wgrad_rows(p.B, p.OH, p.OW, p.KH, p.KW, p.CI, p.CO);
     if (p.slab == nullptr) return 0;  // dry run

@@ -63,11 +63,17 @@ CONV_CASES = [
     (2, 32, 32, 64, 32, 4, 2, 'elu', False),   # fconv_ring forward over 64 channels: two reduction passes
     (2, 32, 32, 32, 64, 4, 2, 'elu', False),   # data gradient = tconv_planes over 64 reduction channels (two passes)
     (1, 24, 80, 32, 32, 4, 2, 'elu', False),   # speech stack (80-pixel rows): wide-row instances of the 4x4/s2 gathers
+    # row widths that are not powers of two at >= 128 tiles: the two-plane implicit GEMM (igemm_h.hip), all three roles
+    (20, 24, 20, 32, 64, 4, 2, 'elu', False),  # speech encoder3 geometry
+    (37, 12, 40, 32, 32, 4, 2, 'elu', False),  # ragged last tile, 16-channel steps over 32 channels
+    (130, 8, 8, 64, 64, 4, 2, 'elu', False),   # encoder3 of the image stacks (8 x 8 -> 4 x 4)
+    (20, 10, 12, 48, 48, 3, 1, 'relu', False), # stride 1, 3 x 3, ragged channel tile
 ]
+IGEMM_H_CONV = {(20, 24, 20, 32, 64), (37, 12, 40, 32, 32), (130, 8, 8, 64, 64), (20, 10, 12, 48, 48)}
 
 
 @pytest.mark.parametrize('B,H,W,Ci,Co,K,S,act,center', CONV_CASES)
-def test_conv2d_fwd_dgrad_wgrad(bk, B, H, W, Ci, Co, K, S, act, center):
+def test_conv2d_fwd_dgrad_wgrad(bk, request, B, H, W, Ci, Co, K, S, act, center):
   L, T = bk.L, bk.T
   rng = np.random.default_rng(0)
   x = rng.random((B, H, W, Ci))
@@ -80,8 +86,14 @@ def test_conv2d_fwd_dgrad_wgrad(bk, B, H, W, Ci, Co, K, S, act, center):
   y_ref = vo._ACT[act](vo.conv2d(xin, w, b, S))
   tx, tw, tb = T(x), T(w), T(b)
   ty = bk.full((B, OH, OW, Co), float('nan'))
+  if (B, H, W, Ci, Co) in IGEMM_H_CONV:  # (test sizes are far below the launch size the product sends there)
+    request.addfinalizer(lambda old=L.odin_debug_igemm_h_min_flop(0.0): L.odin_debug_igemm_h_min_flop(old))
   L.odin_conv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
   close(ty.cpu().numpy(), y_ref)
+  want_h = (B, H, W, Ci, Co) in IGEMM_H_CONV
+  print('conv', (B, H, W, Ci, Co), L.odin_debug_last_path().decode())
+  if want_h:
+    assert L.odin_debug_last_path().decode() == 'igemm_h(f16x2)'
   # backward
   dy = rng.standard_normal((B, OH, OW, Co))
   tdy = T(dy)
@@ -94,17 +106,23 @@ def test_conv2d_fwd_dgrad_wgrad(bk, B, H, W, Ci, Co, K, S, act, center):
     slab = bk.full((L.odin_max_slab_rows(), Ci), float('nan'))
     L.odin_conv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, tdx.data_ptr(),
                         slab.data_ptr(), C.byref(rows), C.byref(d), None)
+    path = L.odin_debug_last_path().decode()
     g_ref = dx_ref * vo.elu_grad_from_output(aux.astype(np.float32).astype(np.float64))
     close(tdx.cpu().numpy(), g_ref)
     close(reduce_slab(bk, slab, rows.value, Ci), g_ref.sum((0, 1, 2)), 1e-4)
+    if want_h:
+      assert path == 'igemm_h(f16x2)', path
   rows = C.c_int(0)
   n = K * K * Ci * Co + Co
   slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
   L.odin_conv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d),
                       None)
+  path = L.odin_debug_last_path().decode()
   g = reduce_slab(bk, slab, rows.value, n)
   close(g[:-Co].reshape(K, K, Ci, Co), dw_ref, 1e-4)
   close(g[-Co:], db_ref, 1e-4)
+  if want_h:
+    assert path == 'igemm_h_wgrad(f16x2)', path
 
 
 DECONV_CASES = [
@@ -123,11 +141,16 @@ DECONV_CASES = [
     (3, 7, 7, 4, 16, 5, 2, 'elu'),
     (1, 12, 40, 32, 32, 4, 2, 'elu'),          # speech decoder4 geometry (40 -> 80 pixels per row): wide-row instances
     (1, 12, 20, 64, 32, 4, 2, 'elu'),          # speech decoder3 geometry, 64 reduction channels
+    # the two-plane implicit GEMM (igemm_h.hip) on row widths that are not powers of two, >= 128 tiles
+    (9, 12, 20, 64, 32, 4, 2, 'elu'),          # speech decoder3
+    (5, 24, 40, 32, 32, 4, 2, 'elu'),          # speech decoder4 (40 -> 80 pixels per row)
+    (130, 4, 4, 64, 64, 4, 2, 'elu'),          # 4 x 4 -> 8 x 8 over 64 channels
 ]
+IGEMM_H_DECONV = {(9, 12, 20, 64, 32), (5, 24, 40, 32, 32), (130, 4, 4, 64, 64)}
 
 
 @pytest.mark.parametrize('B,H,W,Ci,Co,K,S,act', DECONV_CASES)
-def test_deconv2d_fwd_dgrad_wgrad(bk, B, H, W, Ci, Co, K, S, act):
+def test_deconv2d_fwd_dgrad_wgrad(bk, request, B, H, W, Ci, Co, K, S, act):
   L, T = bk.L, bk.T
   rng = np.random.default_rng(1)
   x = rng.standard_normal((B, H, W, Ci))
@@ -140,8 +163,14 @@ def test_deconv2d_fwd_dgrad_wgrad(bk, B, H, W, Ci, Co, K, S, act):
   y_ref = vo._ACT[act](vo.conv2d_transpose(x, w, b, S))
   tx, tw, tb = T(x), T(w), T(b)
   ty = bk.full((B, OH, OW, Co), float('nan'))
+  if (B, H, W, Ci, Co) in IGEMM_H_DECONV:  # (test sizes are far below the launch size the product sends there)
+    request.addfinalizer(lambda old=L.odin_debug_igemm_h_min_flop(0.0): L.odin_debug_igemm_h_min_flop(old))
   L.odin_deconv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
   close(ty.cpu().numpy(), y_ref)
+  want_h = (B, H, W, Ci, Co) in IGEMM_H_DECONV
+  print('deconv', (B, H, W, Ci, Co), L.odin_debug_last_path().decode())
+  if want_h:
+    assert L.odin_debug_last_path().decode() == 'igemm_h(f16x2)'
   dy = rng.standard_normal((B, OH, OW, Co))
   tdy = T(dy)
   dx_ref, dw_ref, db_ref = vo.conv2d_transpose_bwd(x, w, dy, S)
@@ -152,14 +181,20 @@ def test_deconv2d_fwd_dgrad_wgrad(bk, B, H, W, Ci, Co, K, S, act):
   slab = bk.full((L.odin_max_slab_rows(), Ci), float('nan'))
   L.odin_deconv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, tdx.data_ptr(),
                         slab.data_ptr(), C.byref(rows), C.byref(d), None)
+  path = L.odin_debug_last_path().decode()
   g_ref = dx_ref * vo.elu_grad_from_output(aux.astype(np.float32).astype(np.float64))
   close(tdx.cpu().numpy(), g_ref)
   close(reduce_slab(bk, slab, rows.value, Ci), g_ref.sum((0, 1, 2)), 1e-4)
+  if want_h:
+    assert path == 'igemm_h(f16x2)', path
   n = K * K * Co * Ci
   slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
   L.odin_deconv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows),
                         C.byref(d), None)
+  path = L.odin_debug_last_path().decode()
   close(reduce_slab(bk, slab, rows.value, n).reshape(K, K, Co, Ci), dw_ref, 1e-4)
+  if want_h:
+    assert path == 'igemm_h_wgrad(f16x2)', path
 
 
 @pytest.mark.parametrize('B,K,N,act', [(5, 1024, 128, 'linear'), (130, 10, 128, 'linear'),
