@@ -407,8 +407,12 @@ constexpr int IHW_CHUNK = 2048;
 template <int NW, bool SCU, bool SCV>
 __global__ __launch_bounds__(NW * 64) void igemm_h_wgrad_kernel(IHWParams p) {
   __shared__ float red[NW > 1 ? (NW - 1) * 16 * 64 : 64];
-  __shared__ int tb_base[IHW_CHUNK + 16];   // float offset of the fine pixel (y S - pt, x S - pl) of coarse pixel m
-  __shared__ int tb_yx[IHW_CHUNK + 16];     // (y S - pt + 64) << 16 | (x S - pl + 64); -1: beyond this workgroup's pixels
+  // per coarse pixel m of this workgroup: byte offset of the fine pixel (y S - pt, x S - pl), and the bit mask of the
+  // taps (kh KW + kw) whose fine pixel lies inside the image (0 beyond the workgroup's pixels) -- a lane's validity
+  // test is one bit extract, eight consecutive entries arrive with two ds_read_b128
+  constexpr int TBN = IHW_CHUNK + 16 * (2 * NW + 1);
+  __shared__ __attribute__((aligned(16))) int tb_off[TBN];
+  __shared__ __attribute__((aligned(16))) unsigned tb_msk[TBN];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = IH_UNIFORM(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
@@ -417,44 +421,52 @@ __global__ __launch_bounds__(NW * 64) void igemm_h_wgrad_kernel(IHWParams p) {
   const bool i_ok = i < I, j_ok = j < p.CV;
   const int tap = i / p.CU, cu = i - tap * p.CU;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const int rowc = (kh * p.FW + kw) * p.CU + cu;
+  const int rowc4 = ((kh * p.FW + kw) * p.CU + cu) * 4;
+  const unsigned tapbit = i_ok ? (unsigned)tap : 31u;   // (bit 31 of a mask is never set)
   const int mlo = blockIdx.z * p.chunk;
   const int mhi = (mlo + p.chunk < p.M) ? mlo + p.chunk : p.M;
-  for (int e = tid; e < IHW_CHUNK + 16; e += NW * 64) {
+  for (int e = tid; e < TBN; e += NW * 64) {
     const int m = mlo + e;
+    int off = 0;
+    unsigned msk = 0u;
     if (m < mhi && e < p.chunk) {
       const int b = m / (p.h * p.w), r = m - b * (p.h * p.w), y = r / p.w, x = r - y * p.w;
       const int fy = y * p.S - p.pt, fx = x * p.S - p.pl;
-      tb_base[e] = ((b * p.FH + fy) * p.FW + fx) * p.CU;
-      tb_yx[e] = ((fy + 64) << 16) | (fx + 64);
-    } else {
-      tb_base[e] = 0;
-      tb_yx[e] = -1;
+      off = ((b * p.FH + fy) * p.FW + fx) * p.CU * 4;
+      // taps kw with 0 <= fx + kw < FW as a bit run, repeated for the rows kh with 0 <= fy + kh < FH
+      const int wlo = fx < 0 ? -fx : 0, whi = (p.FW - fx < p.KW) ? p.FW - fx : p.KW;
+      const unsigned run = whi > wlo ? ((1u << whi) - 1u) & ~((1u << wlo) - 1u) : 0u;
+      for (int a = 0; a < p.KH; ++a)
+        if ((unsigned)(fy + a) < (unsigned)p.FH) msk |= run << (a * p.KW);
     }
+    tb_off[e] = off;
+    tb_msk[e] = msk;
   }
   __syncthreads();
   const OdinRun RU = odin_run(p.u, (unsigned)((size_t)p.B * p.FH * p.FW * p.CU * 4));
-  const OdinRun RV = odin_run(p.v, (unsigned)((size_t)p.M * p.CV * 4));
+  const OdinRun RV = odin_run(p.v, (unsigned)((size_t)mhi * p.CV * 4));   // (rows beyond this workgroup's pixels read zeros)
   const int gk = (SCU || SCV) ? odin_range_shift(odin_range_load(p.g_amax)) : 0;
   const float g_s = (SCU || SCV) ? odin_pow2(gk) : 1.f, g_s2k = (SCU || SCV) ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
   const int nsteps = (mhi - mlo + 15) >> 4;
   f32x16 acc = f32x16_zero(), acx = f32x16_zero();
   float csum = 0.f;
   float a0[8], b0[8], a1[8], b1[8];
+  const unsigned vb0 = j_ok ? (unsigned)(((mlo + 8 * h) * p.CV + j) * 4) : ODIN_OOB;
+  const unsigned vstep = (unsigned)(16 * p.CV * 4), vrow = (unsigned)(p.CV * 4);
+  const bool do_bias = p.want_bias && blockIdx.y == 0;
   auto load_step = [&](int s, float (&av)[8], float (&bv)[8]) {
+    // the 8 pixels 16 s + 8 h .. + 7 of this lane's half (steps beyond the chunk: mask 0 / rows beyond mhi)
+    const int4 o0 = *reinterpret_cast<const int4*>(&tb_off[16 * s + 8 * h]);
+    const int4 o1 = *reinterpret_cast<const int4*>(&tb_off[16 * s + 8 * h + 4]);
+    const uint4 m0 = *reinterpret_cast<const uint4*>(&tb_msk[16 * s + 8 * h]);
+    const uint4 m1 = *reinterpret_cast<const uint4*>(&tb_msk[16 * s + 8 * h + 4]);
+    const int o[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+    const unsigned mk[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    const unsigned vb = vb0 + (unsigned)s * vstep;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      // pixel of this lane's half within the chunk (branch-free: entries [chunk, IHW_CHUNK + 16) are -1)
-      const int mr = s * 16 + 8 * h + e;
-      const int ml = mr < IHW_CHUNK + 8 ? mr : IHW_CHUNK + 8;
-      const int base = tb_base[ml];
-      const int yx = tb_yx[ml];
-      const int fy = (yx >> 16) - 64 + kh, fx = (yx & 0xFFFF) - 64 + kw;
-      const unsigned inb = ((unsigned)yx >> 31) ^ 1u;   // 1: a pixel of this workgroup
-      const unsigned va = (unsigned)i_ok & inb & ((unsigned)fy < (unsigned)p.FH) & ((unsigned)fx < (unsigned)p.FW);
-      av[e] = odin_run_load1(RU, (unsigned)((base + rowc) * 4) | (va - 1u));
-      const unsigned vb = (unsigned)j_ok & inb;
-      bv[e] = odin_run_load1(RV, (unsigned)(((mlo + ml) * p.CV + j) * 4) | (vb - 1u));
+      av[e] = odin_run_load1(RU, ((mk[e] >> tapbit) & 1u) ? (unsigned)(o[e] + rowc4) : ODIN_OOB);
+      bv[e] = odin_run_load1(RV, vb + (unsigned)e * vrow);
     }
   };
   auto mul = [&](const float (&av)[8], const float (&bv)[8]) {
@@ -464,14 +476,16 @@ __global__ __launch_bounds__(NW * 64) void igemm_h_wgrad_kernel(IHWParams p) {
     acx = mfma32_f16(ah, bl, acx);
     acc = mfma32_f16(ah, bh, acc);
     acx = mfma32_f16(al, bh, acx);
+    if (do_bias) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) csum += bv[e];
+      for (int e = 0; e < 8; ++e) csum += bv[e];
+    }
   };
   int s = wave;
   if (s < nsteps) {
     load_step(s, a0, b0);
     for (;;) {
-      load_step(s + NW, a1, b1);   // (beyond the chunk: table entries -1, zeros, no traffic)
+      load_step(s + NW, a1, b1);   // (beyond the chunk: mask 0 / rows beyond mhi: zeros, no traffic)
       ODIN_SCHED_FENCE();
       mul(a0, b0);
       ODIN_SCHED_FENCE();
@@ -628,7 +642,7 @@ int odin_igemm_h_launch(int tmode, const float* in, const float* w, const float*
 bool odin_igemm_h_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, int CV, int KH, int KW, int S,
                                    int center) {
   if (!ih_enabled() || center) return false;
-  if (CU < 8 || (CU & 7) != 0 || CU > 8192 || KH * KW > 64 || KH < 1 || KW < 1 || S < 1 || S > 4) return false;
+  if (CU < 8 || (CU & 7) != 0 || CU > 8192 || KH * KW > 30 || KH < 1 || KW < 1 || KW > 8 || S < 1 || S > 4) return false;
   if (FH > 8192 || FW > 8192) return false;
   const long M = (long)B * h * w;
   if (M < 512 || (M + ODIN_MAX_SLAB_BLOCKS - 1) / ODIN_MAX_SLAB_BLOCKS > IHW_CHUNK - 16) return false;
@@ -664,9 +678,11 @@ int odin_igemm_h_wgrad_launch(const float* u, const float* v, float* slab, int s
   if (p.g_amax == nullptr) return odin_fail(-3, "igemm_h wgrad: no range word for the gradient operand");
   dim3 grid((CV + 31) / 32, (KH * KW * CU + 31) / 32, R);
   const int nsteps = (p.chunk + 15) / 16;
-  const long wgs = (long)grid.x * grid.y * grid.z;
+  // four waves share a workgroup's pixel table (its fill is ~100 VALU per entry) and split its steps: measured on the
+  // audio stack's five weight gradients 210 / 105 / 57 / 33 / 68 us with one wave, 162 / 81 / 42 / 28 / 50 with four
   int nw = 1;
-  while (nw < 4 && wgs * nw < 2048 && nsteps / (nw * 2) >= 4) nw *= 2;
+  while (nw < 4 && nsteps / (nw * 2) >= 4) nw *= 2;
+  if (const char* e = ODIN_DIAG_ENV("ODIN_IHW_NW")) nw = atoi(e);
 #define ODIN_IHW(N_)                                                                                        \
   do {                                                                                                      \
     if (grad_u) ODIN_LAUNCH((igemm_h_wgrad_kernel<N_, true, false>), grid, dim3(N_ * 64), 0, stream, p);   \

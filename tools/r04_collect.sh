@@ -21,5 +21,8 @@ for w in shapes3d_vae_b256 celeba_betatcvae_b512 mnist_dense_b128 factorvae_shap
   cp $g/r04_final_$w.json $p/r04_bench_$w.json
   grep "^#" $g/r04_final_$w.err > $p/r04_bench_${w}_per_op.txt
 done
+for w in speech_vae_b256 factorvae_shapes3d_b256 celeba_betatcvae_b512; do
+  cp $g/r04_final_tl_${w}_timeline.txt $p/r04_step_timeline_$w.txt
+done
 cp $g/r04_final_forcedist.json $p/r04_bench_force_dist_rccl.json
 cp $g/r04_pmc_traffic.json $p/r04_pmc_traffic.json

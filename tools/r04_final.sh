@@ -25,5 +25,8 @@ python tools/slabstat.py > gpurun_out/r04_final_slabstat.txt 2>&1
 for w in shapes3d_vae_b256 celeba_betatcvae_b512 mnist_dense_b128 factorvae_shapes3d_b256 speech_vae_b256; do
   timeout 600 python bench.py --workload $w --profile-ops --no-cpu-baseline --no-north-star-3ch > gpurun_out/r04_final_$w.json 2> gpurun_out/r04_final_$w.err
 done
+for w in speech_vae_b256 factorvae_shapes3d_b256 celeba_betatcvae_b512; do
+  ./tools/profile.sh r04_final_tl_$w --workload $w --no-north-star-3ch --no-fit > /dev/null 2>&1
+done
 timeout 300 python bench.py --gpus 1 --force-dist --no-cpu-baseline --no-north-star-3ch --no-fit > gpurun_out/r04_final_forcedist.json 2>/dev/null
 ls -la gpurun_out | tail -5
