@@ -565,7 +565,7 @@ bool odin_igemm_h_applicable(int tmode, int B, int H, int W, int CI, int OH, int
   const int SS = tmode ? S : 1;
   const long Mc = (long)B * (OH / SS) * (OW / SS);
   const long tiles = (long)SS * SS * ((Mc + 31) / 32) * ((CO + 31) / 32);
-  if (tiles < 128) return false;
+  if (tiles < 128 && g_ih_min_flop > 0.0) return false;   // (tests force small shapes here: min flop 0)
   if (2.0 * B * (tmode ? (double)H * W : (double)OH * OW) * KH * KW * CI * CO < g_ih_min_flop) return false;
   if ((long)B * H * W * CI >= (1L << 29) || (long)B * OH * OW * CO >= (1L << 29) || (long)KH * KW * CI * CO >= (1L << 29))
     return false;
@@ -645,7 +645,8 @@ bool odin_igemm_h_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, 
   if (CU < 8 || (CU & 7) != 0 || CU > 8192 || KH * KW > 30 || KH < 1 || KW < 1 || KW > 8 || S < 1 || S > 4) return false;
   if (FH > 8192 || FW > 8192) return false;
   const long M = (long)B * h * w;
-  if (M < 512 || (M + ODIN_MAX_SLAB_BLOCKS - 1) / ODIN_MAX_SLAB_BLOCKS > IHW_CHUNK - 16) return false;
+  if ((M < 512 && g_ih_min_flop > 0.0) || M < 16 || (M + ODIN_MAX_SLAB_BLOCKS - 1) / ODIN_MAX_SLAB_BLOCKS > IHW_CHUNK - 16)
+    return false;
   if (2.0 * M * KH * KW * CU * CV < g_ih_min_flop) return false;
   if ((long)B * FH * FW * CU >= (1L << 29) || M * CV >= (1L << 29)) return false;
   return true;

@@ -63,13 +63,13 @@ CONV_CASES = [
     (2, 32, 32, 64, 32, 4, 2, 'elu', False),   # fconv_ring forward over 64 channels: two reduction passes
     (2, 32, 32, 32, 64, 4, 2, 'elu', False),   # data gradient = tconv_planes over 64 reduction channels (two passes)
     (1, 24, 80, 32, 32, 4, 2, 'elu', False),   # speech stack (80-pixel rows): wide-row instances of the 4x4/s2 gathers
-    # row widths that are not powers of two at >= 128 tiles: the two-plane implicit GEMM (igemm_h.hip), all three roles
-    (20, 24, 20, 32, 64, 4, 2, 'elu', False),  # speech encoder3 geometry
-    (37, 12, 40, 32, 32, 4, 2, 'elu', False),  # ragged last tile, 16-channel steps over 32 channels
-    (130, 8, 8, 64, 64, 4, 2, 'elu', False),   # encoder3 of the image stacks (8 x 8 -> 4 x 4)
-    (20, 10, 12, 48, 48, 3, 1, 'relu', False), # stride 1, 3 x 3, ragged channel tile
+    # row widths that are not powers of two: the two-plane implicit GEMM (igemm_h.hip), all three roles
+    (3, 24, 20, 32, 64, 4, 2, 'elu', False),   # speech encoder3 geometry
+    (5, 12, 40, 32, 32, 4, 2, 'elu', False),   # ragged last tile, 16-channel steps over 32 channels
+    (7, 8, 8, 64, 64, 4, 2, 'elu', False),     # encoder3 of the image stacks (8 x 8 -> 4 x 4)
+    (3, 10, 12, 48, 48, 3, 1, 'relu', False),  # stride 1, 3 x 3, ragged channel tile
 ]
-IGEMM_H_CONV = {(20, 24, 20, 32, 64), (37, 12, 40, 32, 32), (130, 8, 8, 64, 64), (20, 10, 12, 48, 48)}
+IGEMM_H_CONV = {(3, 24, 20, 32, 64), (5, 12, 40, 32, 32), (7, 8, 8, 64, 64), (3, 10, 12, 48, 48)}
 
 
 @pytest.mark.parametrize('B,H,W,Ci,Co,K,S,act,center', CONV_CASES)
@@ -141,12 +141,12 @@ DECONV_CASES = [
     (3, 7, 7, 4, 16, 5, 2, 'elu'),
     (1, 12, 40, 32, 32, 4, 2, 'elu'),          # speech decoder4 geometry (40 -> 80 pixels per row): wide-row instances
     (1, 12, 20, 64, 32, 4, 2, 'elu'),          # speech decoder3 geometry, 64 reduction channels
-    # the two-plane implicit GEMM (igemm_h.hip) on row widths that are not powers of two, >= 128 tiles
-    (9, 12, 20, 64, 32, 4, 2, 'elu'),          # speech decoder3
-    (5, 24, 40, 32, 32, 4, 2, 'elu'),          # speech decoder4 (40 -> 80 pixels per row)
-    (130, 4, 4, 64, 64, 4, 2, 'elu'),          # 4 x 4 -> 8 x 8 over 64 channels
+    # the two-plane implicit GEMM (igemm_h.hip) on row widths that are not powers of two
+    (2, 12, 20, 64, 32, 4, 2, 'elu'),          # speech decoder3
+    (2, 24, 40, 32, 32, 4, 2, 'elu'),          # speech decoder4 (40 -> 80 pixels per row)
+    (7, 4, 4, 64, 64, 4, 2, 'elu'),            # 4 x 4 -> 8 x 8 over 64 channels
 ]
-IGEMM_H_DECONV = {(9, 12, 20, 64, 32), (5, 24, 40, 32, 32), (130, 4, 4, 64, 64)}
+IGEMM_H_DECONV = {(2, 12, 20, 64, 32), (2, 24, 40, 32, 32), (7, 4, 4, 64, 64)}
 
 
 @pytest.mark.parametrize('B,H,W,Ci,Co,K,S,act', DECONV_CASES)
