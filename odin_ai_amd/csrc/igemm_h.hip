@@ -24,6 +24,7 @@
 #include "odin_device.h"
 #include "odin_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -34,6 +35,7 @@ namespace {
 #endif
 
 constexpr int IH_NW = 4;  // waves (= tiles in flight) per workgroup
+constexpr int IH_U = 4;   // steps per batch of gathers (igemm_hw_kernel)
 
 struct IHParams {
   const float* in;    // gathered tensor [B, H, W, CI]
@@ -50,6 +52,7 @@ struct IHParams {
   int Mc;             // rows per stride class
   int tpc;            // 32-row tiles per stride class
   int ntile;          // row tiles in all = classes * tpc
+  unsigned dbg;       // diagnostics build (ODIN_IH_DBG): bit 0 = gathers read nothing, bit 1 = nothing is stored
 };
 
 template <bool SC>
@@ -133,7 +136,10 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_h_kernel(IHParams p) {
       const int po = rowoff[wave][(rr & 3) + 8 * (rr >> 2) + 4 * h];
       const unsigned ok = (unsigned)b_ok & (((unsigned)po >> 31) ^ 1u);
       ooff[rr] = (unsigned)((po * p.CO + j) * 4) | (ok - 1u);
-      auxv[rr] = has_aux ? odin_run_load1(RX, ooff[rr]) : 0.f;
+    }
+    if (has_aux) {   // (one uniform branch around the 16 loads, not one per load)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) auxv[rr] = odin_run_load1(RX, ooff[rr]);
     }
     f32x16 acc = f32x16_zero(), acx = f32x16_zero();
     float a0[8], b0[8], a1[8], b1[8];
@@ -188,15 +194,28 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_h_kernel(IHParams p) {
       if (g >= ngroups) break;
     }
     // ---- epilogue: lane holds column j, rows (rr & 3) + 8 (rr >> 2) + 4 h ----
+    // (the activation codes are wave-uniform: one switch around the 16-element loop instead of branches inside it)
+    auto epilogue = [&](auto ACT_, auto AUX_) {
+      constexpr int A_ = decltype(ACT_)::value, X_ = decltype(AUX_)::value;
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      float v = odin_act(p.act, fmaf(acx[rr], o_sx, acc[rr] * o_s) + bj);
-      if (has_aux) v *= odin_act_grad(p.aux_act, auxv[rr]);
-      odin_run_store1(RO, ooff[rr], v);           // range-checked: nothing is written for masked rows
-      const float vv = ((int)ooff[rr] >= 0) ? v : 0.f;
-      csum += vv;
-      amx = fmaxf(amx, fabsf(vv));
-    }
+      for (int rr = 0; rr < 16; ++rr) {
+        float v = odin_act(A_, fmaf(acx[rr], o_sx, acc[rr] * o_s) + bj);
+        if (X_ != 0) v *= odin_act_grad(X_, auxv[rr]);
+        odin_run_store1(RO, ooff[rr], v);           // range-checked: nothing is written for masked rows
+        const float vv = ((int)ooff[rr] >= 0) ? v : 0.f;
+        csum += vv;
+        amx = fmaxf(amx, fabsf(vv));
+      }
+    };
+    using IH_I0 = std::integral_constant<int, 0>;
+    using IH_I1 = std::integral_constant<int, ODIN_ACT_ELU>;
+    using IH_I2 = std::integral_constant<int, ODIN_ACT_RELU>;
+    if (has_aux) {   // data gradient: linear output, act'(aux)
+      if (p.aux_act == ODIN_ACT_ELU) epilogue(IH_I0{}, IH_I1{});
+      else epilogue(IH_I0{}, IH_I2{});
+    } else if (p.act == ODIN_ACT_ELU) epilogue(IH_I1{}, IH_I0{});
+    else if (p.act == ODIN_ACT_RELU) epilogue(IH_I2{}, IH_I0{});
+    else epilogue(IH_I0{}, IH_I0{});
   }
   if (p.colsum != nullptr) {
     csum += __shfl_xor(csum, 32);
@@ -220,7 +239,11 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_h_kernel(IHParams p) {
 // [step][plane][half][column] x 16 bytes) and its waves then walk the tiles of the class reading B with two
 // ds_read_b128 per step -- on the global-memory variant every tile re-fetched and re-split its 4-32 KB of weights
 // through the vector memory pipe, which the A gathers need (audio decoder4: 270 -> see DESIGN 3.8c).
-template <bool TMODE, bool BKC, bool SC>
+// ALLC (transposed gathers whose four stride classes fit in LDS together): a wave runs ALL classes of its 32 coarse
+// pixels back to back -- their 16 gathers fall on the same 3 x 3 input neighbourhood, so the input is read from HBM
+// once; with one class per workgroup the classes of a pixel ran on different XCDs at different times and the audio
+// decoder4's 63 MB input crossed the fabric ~16 times (196 us = 1 GB at ~5 TB/s).
+template <bool TMODE, bool BKC, bool SC, bool ALLC>
 __global__ __launch_bounds__(IH_NW * 64) void igemm_hw_kernel(IHParams p) {
   ODIN_DYN_SMEM(char, wlds);   // [nsteps][2][2][32] x 16 B
   __shared__ int rowoff[IH_NW][32];
@@ -246,17 +269,34 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_hw_kernel(IHParams p) {
   const unsigned img = (unsigned)(ohs * ows);
   const int sg = TMODE ? -1 : 1;
   const int gpt = p.gpt;
-  // ---- this workgroup's stride class and its taps ----
-  const int cls = (int)blockIdx.y % ncls, slot = (int)blockIdx.y / ncls, nslot = (int)gridDim.y / ncls;
-  const int cy = cls >> ssh, cx = cls - (cy << ssh);
-  const int kh0 = TMODE ? (cy + p.pt) & (SS - 1) : 0, kw0 = TMODE ? (cx + p.pl) & (SS - 1) : 0;
-  const int nkh = (p.KH - kh0 + SS - 1) >> ssh, nkw = (p.KW - kw0 + SS - 1) >> ssh;
-  const int ntap = nkh * nkw;
-  const int ngroups = ntap * gpt;
+  // ---- this workgroup's stride class(es) and their taps ----
+  const int cls_lo = ALLC ? 0 : (int)blockIdx.y % ncls, cls_hi = ALLC ? ncls : cls_lo + 1;
+  const int slot = ALLC ? (int)blockIdx.y : (int)blockIdx.y / ncls;
+  const int nslot = ALLC ? (int)gridDim.y : (int)gridDim.y / ncls;
+  auto class_taps = [&](int cls, int& kh0, int& kw0, int& nkh, int& nkw) {
+    const int cy = cls >> ssh, cx = cls - (cy << ssh);
+    kh0 = TMODE ? (cy + p.pt) & (SS - 1) : 0;
+    kw0 = TMODE ? (cx + p.pl) & (SS - 1) : 0;
+    nkh = (p.KH - kh0 + SS - 1) >> ssh;
+    nkw = (p.KW - kw0 + SS - 1) >> ssh;
+  };
+  // first step of class c in LDS (prefix sums of taps x channel groups)
+  int sbase[5];
+  sbase[cls_lo] = 0;
+  for (int c = cls_lo; c < cls_hi; ++c) {
+    int kh0, kw0, nkh, nkw;
+    class_taps(c, kh0, kw0, nkh, nkw);
+    sbase[c + 1] = sbase[c] + nkh * nkw * gpt;
+  }
   // ---- the weight planes of (class, column block): entry (step s, half hh, column jl) <- 8 weights ----
-  for (int e = tid; e < ngroups * 64; e += IH_NW * 64) {
+  for (int e = tid; e < sbase[cls_hi] * 64; e += IH_NW * 64) {
     const int s = e >> 6, hh = (e >> 5) & 1, jl = e & 31;
-    const int t = s / gpt, cg = s - t * gpt;
+    int wc = cls_lo;
+    while (wc + 1 < cls_hi && s >= sbase[wc + 1]) ++wc;
+    int kh0, kw0, nkh, nkw;
+    class_taps(wc, kh0, kw0, nkh, nkw);
+    const int sl = s - sbase[wc];
+    const int t = sl / gpt, cg = sl - t * gpt;
     const int a = t / nkw, c = t - a * nkw;
     const int wt = (kh0 + a * SS) * p.KW + kw0 + c * SS;
     const int jj = blockIdx.x * 32 + jl;
@@ -276,14 +316,22 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_hw_kernel(IHParams p) {
     *reinterpret_cast<u32x4*>(wlds + ((((s * 2 + 1) * 2 + hh) * 32 + jl) << 4)) = wl;
   }
   __syncthreads();
-  const char* wme = wlds + ((h * 32 + l31) << 4);   // this lane's entry of step 0, plane 0; + 2048 per step, + 1024 lo plane
+  const unsigned dbg_a = (p.dbg & 1u) ? 0xFFFFFFFFu : 0u, dbg_s = (p.dbg & 2u) ? 0xFFFFFFFFu : 0u;
+  const char* wme0 = wlds + ((h * 32 + l31) << 4);   // this lane's entry of step 0, plane 0; + 2048 per step, + 1024 lo plane
   float csum = 0.f, amx = 0.f;
   for (int tile = IH_UNIFORM(slot * IH_NW + wave); tile < p.tpc; tile += nslot * IH_NW) {
-    // ---- this lane's A row: one output pixel ----
+    // ---- this lane's A row: one (coarse) output pixel ----
     const unsigned q = (unsigned)(tile * 32 + l31);
     const bool a_ok = q < (unsigned)p.Mc;
     const unsigned b = q / img, r = q - b * img;
     const unsigned ys = r / (unsigned)ows, xs = r - ys * (unsigned)ows;
+   for (int cls = cls_lo; cls < cls_hi; ++cls) {
+    const int cy = cls >> ssh, cx = cls - (cy << ssh);
+    int kh0, kw0, nkh, nkw;
+    class_taps(cls, kh0, kw0, nkh, nkw);
+    const int ntap = nkh * nkw;
+    const int ngroups = ntap * gpt;
+    const char* wme = wme0 + (sbase[cls] << 11);
     const int oy = (int)ys * SS + cy, ox = (int)xs * SS + cx;
     const int Y0 = TMODE ? (oy + p.pt - kh0) >> ssh : oy * p.S - p.pt;
     const int X0 = TMODE ? (ox + p.pl - kw0) >> ssh : ox * p.S - p.pl;
@@ -308,17 +356,22 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_hw_kernel(IHParams p) {
       const int po = rowoff[wave][(rr & 3) + 8 * (rr >> 2) + 4 * h];
       const unsigned ok = (unsigned)b_ok & (((unsigned)po >> 31) ^ 1u);
       ooff[rr] = (unsigned)((po * p.CO + j) * 4) | (ok - 1u);
-      auxv[rr] = has_aux ? odin_run_load1(RX, ooff[rr]) : 0.f;
+    }
+    if (has_aux) {   // (one uniform branch around the 16 loads, not one per load)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) auxv[rr] = odin_run_load1(RX, ooff[rr]);
     }
     f32x16 acc = f32x16_zero(), acx = f32x16_zero();
-    float a0[8], a1[8];
+    // batches of IH_U steps, double-buffered: the gathers of the next four steps are in flight while the current four
+    // multiply (one step ahead left an L2 round trip exposed at every step: two waves per SIMD cannot cover it)
+    float a0[IH_U][8], a1[IH_U][8];
     IHCursor cur = {0, 0, 0, 0};
     auto load_a = [&](float (&av)[8]) {
       const unsigned live = (unsigned)(cur.t - ntap) >> 31;   // 1 / 0 (wave-uniform)
       const int tapoff = sg * (cur.a * p.W + cur.c) * p.CI;
       const unsigned va = live & (mask >> (cur.t & 31)) & 1u;
       const unsigned ao = (unsigned)((lanebase + tapoff + 16 * cur.cg) * 4);
-      const float4 x0 = odin_run_load4(RA, ao | (va - 1u)), x1 = odin_run_load4(RA, (ao + 16u) | (va - 1u));
+      const float4 x0 = odin_run_load4(RA, ao | (va - 1u) | dbg_a), x1 = odin_run_load4(RA, (ao + 16u) | (va - 1u) | dbg_a);
       av[0] = x0.x; av[1] = x0.y; av[2] = x0.z; av[3] = x0.w; av[4] = x1.x; av[5] = x1.y; av[6] = x1.z; av[7] = x1.w;
       cur.cg += 1;
       if (cur.cg == gpt) {
@@ -327,37 +380,58 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_hw_kernel(IHParams p) {
       }
     };
     auto mul = [&](const float (&av)[8], int s) {
+      // (a step beyond the reduction carries zeros in A: any valid weight step will do)
+      const int sc = s < ngroups ? s : ngroups - 1;
       u32x4 ah, al;
       ih_split8<SC>(av, in_s, in_s2k, ah, al);
-      const u32x4 bh = *reinterpret_cast<const u32x4*>(wme + (s << 11));
-      const u32x4 bl2 = *reinterpret_cast<const u32x4*>(wme + (s << 11) + 1024);
+      const u32x4 bh = *reinterpret_cast<const u32x4*>(wme + (sc << 11));
+      const u32x4 bl2 = *reinterpret_cast<const u32x4*>(wme + (sc << 11) + 1024);
       acx = mfma32_f16(ah, bl2, acx);
       acc = mfma32_f16(ah, bh, acc);
       acx = mfma32_f16(al, bh, acx);
     };
-    load_a(a0);
+    auto mul_load = [&](const float (&av)[IH_U][8], int g, float (&nav)[IH_U][8]) {
+#pragma unroll
+      for (int u = 0; u < IH_U; ++u) {
+        mul(av[u], g + u);
+        ODIN_SCHED_FENCE();
+        load_a(nav[u]);
+        ODIN_SCHED_FENCE();
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < IH_U; ++u) load_a(a0[u]);
     for (int g = 0;;) {
-      load_a(a1);
-      ODIN_SCHED_FENCE();
-      mul(a0, g);
-      ODIN_SCHED_FENCE();
-      g += 2;
-      if (g - 1 >= ngroups) break;
-      load_a(a0);
-      ODIN_SCHED_FENCE();
-      mul(a1, g - 1);
-      ODIN_SCHED_FENCE();
+      mul_load(a0, g, a1);
+      g += IH_U;
+      if (g >= ngroups) break;
+      mul_load(a1, g, a0);
+      g += IH_U;
       if (g >= ngroups) break;
     }
+    // (the activation codes are wave-uniform: one switch around the 16-element loop instead of branches inside it)
+    auto epilogue = [&](auto ACT_, auto AUX_) {
+      constexpr int A_ = decltype(ACT_)::value, X_ = decltype(AUX_)::value;
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      float v = odin_act(p.act, fmaf(acx[rr], o_sx, acc[rr] * o_s) + bj);
-      if (has_aux) v *= odin_act_grad(p.aux_act, auxv[rr]);
-      odin_run_store1(RO, ooff[rr], v);
-      const float vv = ((int)ooff[rr] >= 0) ? v : 0.f;
-      csum += vv;
-      amx = fmaxf(amx, fabsf(vv));
-    }
+      for (int rr = 0; rr < 16; ++rr) {
+        float v = odin_act(A_, fmaf(acx[rr], o_sx, acc[rr] * o_s) + bj);
+        if (X_ != 0) v *= odin_act_grad(X_, auxv[rr]);
+        odin_run_store1(RO, ooff[rr] | dbg_s, v);
+        const float vv = ((int)ooff[rr] >= 0) ? v : 0.f;
+        csum += vv;
+        amx = fmaxf(amx, fabsf(vv));
+      }
+    };
+    using IH_I0 = std::integral_constant<int, 0>;
+    using IH_I1 = std::integral_constant<int, ODIN_ACT_ELU>;
+    using IH_I2 = std::integral_constant<int, ODIN_ACT_RELU>;
+    if (has_aux) {   // data gradient: linear output, act'(aux)
+      if (p.aux_act == ODIN_ACT_ELU) epilogue(IH_I0{}, IH_I1{});
+      else epilogue(IH_I0{}, IH_I2{});
+    } else if (p.act == ODIN_ACT_ELU) epilogue(IH_I1{}, IH_I0{});
+    else if (p.act == ODIN_ACT_RELU) epilogue(IH_I2{}, IH_I0{});
+    else epilogue(IH_I0{}, IH_I0{});
+   }  // classes
   }
   if (p.colsum != nullptr) {
     csum += __shfl_xor(csum, 32);
@@ -598,6 +672,7 @@ int odin_igemm_h_launch(int tmode, const float* in, const float* w, const float*
   p.Mc = B * (OH / SS) * (OW / SS);
   p.tpc = (p.Mc + 31) / 32;
   p.ntile = SS * SS * p.tpc;
+  if (const char* e = ODIN_DIAG_ENV("ODIN_IH_DBG")) p.dbg = (unsigned)atoi(e);
   if (in_is_grad) {
     p.in_amax = odin_range_word_of(in, (size_t)B * H * W * CI, in_amax, stream);
     if (p.in_amax == nullptr) return odin_fail(-3, "igemm_h: no range word for the gradient input");
@@ -620,13 +695,28 @@ int odin_igemm_h_launch(int tmode, const float* in, const float* w, const float*
   const int max_steps = ((KH + SS - 1) / SS) * ((KW + SS - 1) / SS) * p.gpt;
   if (max_steps <= 32 && !ODIN_DIAG_ENV("ODIN_IH_NOLDSW")) {
     const size_t lds = (size_t)max_steps * 2048;
-#define ODIN_IHW_L(T_, K_, S_)                                                                    \
+#define ODIN_IHW_L(T_, K_, S_, A_, LDS_)                                                          \
   do {                                                                                            \
-    if (int rc = ih_set_lds(&igemm_hw_kernel<T_, K_, S_>, lds)) return rc;                        \
-    ODIN_LAUNCH((igemm_hw_kernel<T_, K_, S_>), grid, dim3(IH_NW * 64), lds, stream, p);           \
+    if (int rc = ih_set_lds(&igemm_hw_kernel<T_, K_, S_, A_>, LDS_)) return rc;                   \
+    ODIN_LAUNCH((igemm_hw_kernel<T_, K_, S_, A_>), grid, dim3(IH_NW * 64), LDS_, stream, p);      \
   } while (0)
-    if (tmode) { if (in_is_grad) ODIN_IHW_L(true, true, true); else ODIN_IHW_L(true, true, false); }
-    else { if (in_is_grad) ODIN_IHW_L(false, false, true); else ODIN_IHW_L(false, false, false); }
+    // all stride classes of a transposed gather in one workgroup when their weights fit together (KH KW / S^2 taps
+    // per class on average: KH * KW * gpt steps in all)
+    // (measured on the audio stack: decoder4 forward 196 -> 212 us, encoder2 data gradient 70 -> 86 -- the kernel is
+    // bound by instruction issue, not by the re-read of its input (no gathers and no stores at all: 139 us); the
+    // instances exist in the diagnostics build only)
+#ifdef ODIN_DIAG
+    const int all_steps = KH * KW * p.gpt;
+    if (tmode && SS > 1 && all_steps <= 32 && ODIN_DIAG_ENV("ODIN_IH_ALLC")) {
+      const size_t lds_all = (size_t)all_steps * 2048;
+      if (in_is_grad) ODIN_IHW_L(true, true, true, true, lds_all); else ODIN_IHW_L(true, true, false, true, lds_all);
+    } else
+#endif
+    if (tmode) {
+      if (in_is_grad) ODIN_IHW_L(true, true, true, false, lds); else ODIN_IHW_L(true, true, false, false, lds);
+    } else {
+      if (in_is_grad) ODIN_IHW_L(false, false, true, false, lds); else ODIN_IHW_L(false, false, false, false, lds);
+    }
 #undef ODIN_IHW_L
     return odin_check_launch("igemm_h(f16x2)");
   }

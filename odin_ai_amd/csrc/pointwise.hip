@@ -789,7 +789,7 @@ extern "C" int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, 
 // n_part = 8 * units contiguous partials, the layout odin_elbo_finalize sums).
 // Fixed-order reductions throughout: bit-reproducible.
 constexpr int GH_NT = 512;   // threads per workgroup
-constexpr int GH_U = 4;      // pixel groups in flight per lane
+constexpr int GH_U = 4;      // pixel groups in flight per lane (8: 116 -> 187 us, register pressure)
 template <int C, int SP1>
 __global__ __launch_bounds__(GH_NT) void gauss_head_kernel(
     const float4* __restrict__ h, const float* __restrict__ w1, const float* __restrict__ b1,
