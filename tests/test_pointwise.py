@@ -82,6 +82,22 @@ def test_elbo_bernoulli_and_finalize(bk, shape):
   close(out.cpu().numpy(), [loss, llk_ref.mean(), 4.0 * kl.mean(), 0.25], 1e-5)
 
 
+@pytest.mark.parametrize('B,n_part', [(5, 1), (70, 33), (256, 240), (9, 100)])
+def test_elbo_finalize_partial_counts(bk, B, n_part):
+  """odin_elbo_finalize over few (one thread per sample) and many (> 32: one wave per sample) partials per sample"""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(21)
+  part = rng.standard_normal((B, n_part)) * 30
+  kl = rng.random(B) * 5
+  tp, tkl, hyper = T(part), T(kl), T([2.0, 0.0])
+  llk, out = bk.zeros(B), bk.zeros(4)
+  L.odin_elbo_finalize(tp.data_ptr(), n_part, tkl.data_ptr(), hyper.data_ptr(), None, llk.data_ptr(), out.data_ptr(),
+                       B, None)
+  ref = part.astype(np.float32).astype(np.float64).sum(1)
+  close(llk.cpu().numpy(), ref, 1e-5)
+  close(out.cpu().numpy(), [-(ref.mean() - 2.0 * kl.mean()), ref.mean(), 2.0 * kl.mean(), 0.0], 1e-5)
+
+
 @pytest.mark.parametrize('npix,Cc', [(50, 3), (1024, 3), (512, 1), (256, 2)])
 @pytest.mark.parametrize('sp1', [0, 1])
 def test_elbo_gaussian(bk, sp1, npix, Cc):
