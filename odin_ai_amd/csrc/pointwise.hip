@@ -425,29 +425,14 @@ __device__ __forceinline__ void elbo_finalize_body(const float* llk_part, int n_
                                                     const float* hyper, const float* tcp, float* llk,
                                                     float* out4, int B, float* red /* >= 4 floats LDS */) {
   float sl = 0.f, sk = 0.f;
-  if (n_part > 32) {
-    // many partials per sample (the Gaussian head writes one per 32 pixels: 240 at 96 x 80): a WAVE sums a sample's
-    // partials with coalesced loads and a fixed-order butterfly (one thread per sample walked 240 strided loads:
-    // 18.8 us for 256 samples)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b = wave; b < B; b += 4) {
-      float t = 0.f;
-      for (int i = lane; i < n_part; i += 64) t += llk_part[(size_t)b * n_part + i];
-      t = wave_sum64(t);
-      if (lane == 0) {
-        llk[b] = t;
-        sl += t;
-        sk += kl[b];
-      }
-    }
-  } else {
-    for (int b = threadIdx.x; b < B; b += 256) {
-      float t = 0.f;
-      t = sum_partials8(llk_part + (size_t)b * n_part, n_part);
-      llk[b] = t;
-      sl += t;
-      sk += kl[b];
-    }
+  // (one thread per sample: 8 independent loads in flight per thread.  A wave per sample with coalesced loads was
+  // tried for the Gaussian head's 240 partials per sample: 64 dependent rounds per wave, 18.8 -> 135 us)
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float t = 0.f;
+    t = sum_partials8(llk_part + (size_t)b * n_part, n_part);
+    llk[b] = t;
+    sl += t;
+    sk += kl[b];
   }
   float tl = block_sum_256(sl, red);
   __syncthreads();
@@ -812,7 +797,8 @@ __global__ __launch_bounds__(GH_NT) void gauss_head_kernel(
     const float4* __restrict__ h, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ target, float* __restrict__ logits, float* __restrict__ dlogits,
     float4* __restrict__ dh, float* __restrict__ llk_part, float* __restrict__ wslab, float* __restrict__ colsum,
-    const float* __restrict__ scale, unsigned* dh_amax, int n_units, int n_part, int n_pix, int Q, int h_act) {
+    const float* __restrict__ scale, unsigned* dh_amax, int n_units, int n_part, int n_pix, int Q, int h_act,
+    int upw) {
   constexpr int CO = 2 * C, NWV = GH_NT / 64;
   __shared__ float wl[64 * CO];
   __shared__ float red[NWV * 8 * (5 * CO + 4) + 16];
@@ -840,7 +826,14 @@ __global__ __launch_bounds__(GH_NT) void gauss_head_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k][o] = 0.f;
   }
-  for (int u0 = blockIdx.x; u0 < n_units; u0 += gridDim.x) {
+  // upw > 0: this workgroup owns the `upw` consecutive units [blockIdx.x upw, ...) -- all inside one sample (the launcher
+  // picks a divisor of the units per sample) -- and a wave keeps ONE log-likelihood partial for all of them; upw == 0:
+  // units grid-stride, one partial per (unit, wave)
+  float llk_run = 0.f;
+  const int u_first = upw > 0 ? (int)blockIdx.x * upw : (int)blockIdx.x;
+  const int u_step = upw > 0 ? 1 : (int)gridDim.x;
+  const int u_end = upw > 0 ? u_first + upw : n_units;
+  for (int u0 = u_first; u0 < u_end; u0 += u_step) {
     const int b = u0 / n_part, part = u0 - b * n_part;
     const int pin = part * ppu + tid / Q;          // pixel inside the sample (of group 0)
     const size_t pbase = (size_t)b * n_pix;
@@ -927,8 +920,16 @@ __global__ __launch_bounds__(GH_NT) void gauss_head_kernel(
     }
     // one log-likelihood partial per (unit, wave): no workgroup barrier inside the loop, the waves run free and the
     // next unit's loads overlap this one's arithmetic
-    llk = wave_sum64(llk);
-    if (lane == 0) llk_part[(size_t)u0 * NWV + wave] = llk;
+    if (upw > 0) {
+      llk_run += llk;
+    } else {
+      llk = wave_sum64(llk);
+      if (lane == 0) llk_part[(size_t)u0 * NWV + wave] = llk;
+    }
+  }
+  if (upw > 0) {
+    llk_run = wave_sum64(llk_run);
+    if (lane == 0) llk_part[(size_t)blockIdx.x * NWV + wave] = llk_run;
   }
   // ---- this workgroup's slab rows: lanes of equal q inside a wave (xor butterfly over the masks >= Q), then the
   // waves in order ----
@@ -992,15 +993,26 @@ extern "C" int odin_gaussian_head_fwd_bwd(const float* h, const float* w1, const
   const int n_part = (n_pix + ppu - 1) / ppu;
   const long n_units = (long)B * n_part;
   if (n_units > (1L << 30)) return odin_fail(-2, "gaussian_head: too many units");
-  const int grid = (int)(n_units < ODIN_MAX_COLSUM_BLOCKS ? n_units : ODIN_MAX_COLSUM_BLOCKS);
-  if (n_part_out) *n_part_out = n_part * (GH_NT / 64);  // (one partial per unit and wave)
+  int grid = (int)(n_units < ODIN_MAX_COLSUM_BLOCKS ? n_units : ODIN_MAX_COLSUM_BLOCKS);
+  int parts = n_part * (GH_NT / 64);  // one partial per unit and wave ...
+  // ... unless a divisor d of the units per sample gives a grid of B * n_part / d <= 512 workgroups with d consecutive
+  // units each: then a wave keeps one partial for its d units (96 x 80 pixels: 30 units, d = 15, 16 partials per
+  // sample instead of 240 -- odin_elbo_finalize sums them with one thread per sample)
+  int upw = 0;
+  for (int d = 1; d <= n_part; ++d)
+    if (n_part % d == 0 && n_units / d <= ODIN_MAX_COLSUM_BLOCKS) { upw = d; break; }
+  if (upw > 0) {
+    grid = (int)(n_units / upw);
+    parts = (n_part / upw) * (GH_NT / 64);
+  }
+  if (n_part_out) *n_part_out = parts;
   if (rows_out) *rows_out = grid;
   if (h == nullptr) return 0;  // dry run
   if ((((uintptr_t)h | (uintptr_t)dh) & 15) != 0) return odin_fail(-2, "gaussian_head: unaligned activation");
 #define ODIN_GH(CC, SP)                                                                                          \
   ODIN_LAUNCH((gauss_head_kernel<CC, SP>), dim3(grid), dim3(GH_NT), 0, stream, (const float4*)h, w1, b1, target, \
               logits, dlogits, (float4*)dh, llk_part, wslab, colsum_slab, scale, (unsigned*)dh_amax,             \
-              (int)n_units, n_part, n_pix, Q, h_act)
+              (int)n_units, n_part, n_pix, Q, h_act, upw)
   if (C == 1 && softplus1 == 1) ODIN_GH(1, 1);
   else if (C == 1) ODIN_GH(1, 0);
   else if (softplus1 == 1) ODIN_GH(3, 1);
