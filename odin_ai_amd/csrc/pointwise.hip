@@ -826,13 +826,14 @@ __global__ __launch_bounds__(GH_NT) void gauss_head_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k][o] = 0.f;
   }
-  // upw > 0: this workgroup owns the `upw` consecutive units [blockIdx.x upw, ...) -- all inside one sample (the launcher
-  // picks a divisor of the units per sample) -- and a wave keeps ONE log-likelihood partial for all of them; upw == 0:
-  // units grid-stride, one partial per (unit, wave)
+  // upw > 0: the n_part / upw workgroups of a sample deal its units round-robin (upw each: the launcher picks a divisor
+  // of the units per sample), so neighbouring workgroups stream neighbouring 32 KB chunks at the same time, and a wave
+  // keeps ONE log-likelihood partial for all of its units; upw == 0: units grid-stride, one partial per (unit, wave)
   float llk_run = 0.f;
-  const int u_first = upw > 0 ? (int)blockIdx.x * upw : (int)blockIdx.x;
-  const int u_step = upw > 0 ? 1 : (int)gridDim.x;
-  const int u_end = upw > 0 ? u_first + upw : n_units;
+  const int npw = upw > 0 ? n_part / upw : 1;
+  const int u_first = upw > 0 ? ((int)blockIdx.x / npw) * n_part + (int)blockIdx.x % npw : (int)blockIdx.x;
+  const int u_step = upw > 0 ? npw : (int)gridDim.x;
+  const int u_end = upw > 0 ? ((int)blockIdx.x / npw + 1) * n_part : n_units;
   for (int u0 = u_first; u0 < u_end; u0 += u_step) {
     const int b = u0 / n_part, part = u0 - b * n_part;
     const int pin = part * ppu + tid / Q;          // pixel inside the sample (of group 0)
