@@ -1025,10 +1025,11 @@ class VAEEngine:
                             self.lat_slab.shape[1], rows.value, self.lat_slab.shape[1], 0))
       auxp = h_e.data_ptr() if aux_act != 0 else None
       bslab = self.enc.bslabs[-1]
-      lib.odin_dense_dgrad(self.dp.data_ptr(), lw.data_ptr(), auxp, aux_act,
-                           self.enc.gouts[-1].data_ptr(),
-                           bslab.data_ptr() if bslab is not None else None, C.byref(rows), B,
-                           self.hdim, 2 * D, st)
+      # (the projection's data gradient keeps the range word of the encoder's top gradient where its kernel family does)
+      top = self.enc.set_top_word(bslab is None and bool(lib.odin_dense_dgrad_keeps_range(B, self.hdim, 2 * D)))
+      lib.odin_dense_bwd(None, self.dp.data_ptr(), lw.data_ptr(), auxp, aux_act, self.enc.gouts[-1].data_ptr(),
+                         bslab.data_ptr() if bslab is not None else None, C.byref(rows), None, None, B,
+                         self.hdim, 2 * D, 0, 1, None, top, st)
       if bslab is not None:
         jobs.append(ReduceJob(bslab.data_ptr(), self.grads[last.b_off:].data_ptr(), last.b_n,
                               rows.value, last.b_n, 0))
