@@ -126,6 +126,7 @@ def profile_ops(eng, reps=20):
 
   nd = len(eng.dec.recs)
   fused = getattr(eng, 'fused_tail', False)
+  head = getattr(eng, 'gauss_head', False)   # the Gaussian 1x1 head runs as ONE launch inside the step
   for net, prog, x0 in (('enc', eng.enc, eng.x), ('dec', eng.dec, eng.z)):
     for i, r in enumerate(prog.recs):
       xin = x0 if i == 0 else prog.outs[i - 1]
@@ -158,6 +159,8 @@ def profile_ops(eng, reps=20):
       if in_tail:
         # inside the training step these launches are replaced by the fused tail kernel
         ops = [] if i == nd - 1 else [('wgrad', f_wg), ('dgrad', f_dg)]
+      if head and net == 'dec' and i == nd - 1:
+        ops = []  # (replaced by odin_gaussian_head_fwd_bwd, timed below)
       for tag, fn in ops:
         if fn is None:
           continue
@@ -179,6 +182,21 @@ def profile_ops(eng, reps=20):
     out.append(dict(layer=f'dec{nd - 2}+{nd - 1}:tail', op='fwd+elbo', us=t * 1e6,
                     gflop=fl * 1e-9, tflops=fl / t * 1e-12, path=lib.odin_debug_last_path().decode(),
                     mfma_gflop=conv_flops(a, B) * 1e-9))
+  if head:
+    from odin_ai_amd.engine import OBS_MODE
+    a, bb = eng.dec.recs[-2], eng.dec.recs[-1]
+    Cc = eng.in_shape[-1]
+    npart = C.c_int(0)
+    fn = lambda: lib.odin_gaussian_head_fwd_bwd(
+        eng.dec.outs[-2].data_ptr(), eng.dec.w(nd - 1).data_ptr(), eng.dec.b(nd - 1).data_ptr(), eng.x.data_ptr(),
+        eng.dec.outs[-1].data_ptr(), None, eng.dec.gouts[-2].data_ptr(), eng.head_llk_part.data_ptr(),
+        C.byref(npart), eng.head_slab.data_ptr(), C.byref(rows),
+        eng.head_colsum.data_ptr() if eng.head_colsum is not None else None, eng.hp(5), B, eng.n_per // Cc,
+        bb.desc['Cin'], Cc, OBS_MODE[eng.observation], ACT[a.act], None, st)
+    t = timeit(fn)
+    fl = 3 * conv_flops(bb, B)
+    out.append(dict(layer=f'dec{nd - 1}:head', op='fwd+elbo+bwd', us=t * 1e6, gflop=fl * 1e-9,
+                    tflops=fl / t * 1e-12, path='gaussian_head'))
   return out
 
 
