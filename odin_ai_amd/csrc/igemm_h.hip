@@ -34,8 +34,14 @@ namespace {
 #define IH_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
+// four waves per SIMD: a tile is 8-32 steps behind a row decode and a first batch of gathers whose latency only other
+// waves can cover (two waves per SIMD left ~3 k cycles exposed per tile)
+#ifdef ODIN_SIM
+#define IH_WAVES_ATTR
+#else
+#define IH_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 constexpr int IH_NW = 4;  // waves (= tiles in flight) per workgroup
-constexpr int IH_U = 4;   // steps per batch of gathers (igemm_hw_kernel)
 
 struct IHParams {
   const float* in;    // gathered tensor [B, H, W, CI]
@@ -243,8 +249,8 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_h_kernel(IHParams p) {
 // pixels back to back -- their 16 gathers fall on the same 3 x 3 input neighbourhood, so the input is read from HBM
 // once; with one class per workgroup the classes of a pixel ran on different XCDs at different times and the audio
 // decoder4's 63 MB input crossed the fabric ~16 times (196 us = 1 GB at ~5 TB/s).
-template <bool TMODE, bool BKC, bool SC, bool ALLC>
-__global__ __launch_bounds__(IH_NW * 64) void igemm_hw_kernel(IHParams p) {
+template <bool TMODE, bool BKC, bool SC, bool ALLC, int IH_U>
+__device__ __forceinline__ void igemm_hw_body(const IHParams& p) {
   ODIN_DYN_SMEM(char, wlds);   // [nsteps][2][2][32] x 16 B
   __shared__ int rowoff[IH_NW][32];
   __shared__ float cred[IH_NW * 32 + 16];
@@ -447,6 +453,25 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_hw_kernel(IHParams p) {
     __syncthreads();
     odin_amax_commit_wg(p.out_amax, amx, tid, IH_NW * 64, cred, blockIdx.x + gridDim.x * blockIdx.y);
   }
+}
+
+// The transposed gathers keep 16-32 KB of weight planes per workgroup: four waves per SIMD fit, and a tile there is only
+// 8-16 steps behind a row decode and a first batch of gathers whose latency only other waves can cover (forced to 128
+// registers: audio decoder4 forward 168 -> 152 us, decoder3 79 -> 74).  The strided gathers (16 taps: 64 KB of planes,
+// two workgroups per CU whatever the register count) keep their 4-step batches and two waves per SIMD (forced to 128
+// registers they spill: decoder4 data gradient 152 -> 197 us).
+template <bool ALLC>
+__global__ __launch_bounds__(IH_NW * 64) IH_WAVES_ATTR void igemm_hw_t_kernel(IHParams p) {
+  igemm_hw_body<true, true, false, ALLC, 2>(p);
+}
+// (a gradient input adds the scale multiplies: at 128 registers it spills -- conv data gradients 58 -> 69 us)
+template <bool ALLC>
+__global__ __launch_bounds__(IH_NW * 64) void igemm_hw_tg_kernel(IHParams p) {
+  igemm_hw_body<true, true, true, ALLC, 4>(p);
+}
+template <bool SC>
+__global__ __launch_bounds__(IH_NW * 64) void igemm_hw_f_kernel(IHParams p) {
+  igemm_hw_body<false, false, SC, false, 4>(p);
 }
 
 template <typename K>
@@ -695,13 +720,21 @@ int odin_igemm_h_launch(int tmode, const float* in, const float* w, const float*
   const int max_steps = ((KH + SS - 1) / SS) * ((KW + SS - 1) / SS) * p.gpt;
   if (max_steps <= 32 && !ODIN_DIAG_ENV("ODIN_IH_NOLDSW")) {
     const size_t lds = (size_t)max_steps * 2048;
-#define ODIN_IHW_L(T_, K_, S_, A_, LDS_)                                                          \
+#define ODIN_IHW_T(S_, A_, LDS_)                                                                  \
   do {                                                                                            \
-    if (int rc = ih_set_lds(&igemm_hw_kernel<T_, K_, S_, A_>, LDS_)) return rc;                   \
-    ODIN_LAUNCH((igemm_hw_kernel<T_, K_, S_, A_>), grid, dim3(IH_NW * 64), LDS_, stream, p);      \
+    if (S_) {                                                                                     \
+      if (int rc = ih_set_lds(&igemm_hw_tg_kernel<A_>, LDS_)) return rc;                          \
+      ODIN_LAUNCH((igemm_hw_tg_kernel<A_>), grid, dim3(IH_NW * 64), LDS_, stream, p);             \
+    } else {                                                                                      \
+      if (int rc = ih_set_lds(&igemm_hw_t_kernel<A_>, LDS_)) return rc;                           \
+      ODIN_LAUNCH((igemm_hw_t_kernel<A_>), grid, dim3(IH_NW * 64), LDS_, stream, p);              \
+    }                                                                                             \
   } while (0)
-    // all stride classes of a transposed gather in one workgroup when their weights fit together (KH KW / S^2 taps
-    // per class on average: KH * KW * gpt steps in all)
+#define ODIN_IHW_F(S_, LDS_)                                                                      \
+  do {                                                                                            \
+    if (int rc = ih_set_lds(&igemm_hw_f_kernel<S_>, LDS_)) return rc;                             \
+    ODIN_LAUNCH((igemm_hw_f_kernel<S_>), grid, dim3(IH_NW * 64), LDS_, stream, p);                \
+  } while (0)
     // (measured on the audio stack: decoder4 forward 196 -> 212 us, encoder2 data gradient 70 -> 86 -- the kernel is
     // bound by instruction issue, not by the re-read of its input (no gathers and no stores at all: 139 us); the
     // instances exist in the diagnostics build only)
@@ -709,15 +742,16 @@ int odin_igemm_h_launch(int tmode, const float* in, const float* w, const float*
     const int all_steps = KH * KW * p.gpt;
     if (tmode && SS > 1 && all_steps <= 32 && ODIN_DIAG_ENV("ODIN_IH_ALLC")) {
       const size_t lds_all = (size_t)all_steps * 2048;
-      if (in_is_grad) ODIN_IHW_L(true, true, true, true, lds_all); else ODIN_IHW_L(true, true, false, true, lds_all);
+      if (in_is_grad) ODIN_IHW_T(true, true, lds_all); else ODIN_IHW_T(false, true, lds_all);
     } else
 #endif
     if (tmode) {
-      if (in_is_grad) ODIN_IHW_L(true, true, true, false, lds); else ODIN_IHW_L(true, true, false, false, lds);
+      if (in_is_grad) ODIN_IHW_T(true, false, lds); else ODIN_IHW_T(false, false, lds);
     } else {
-      if (in_is_grad) ODIN_IHW_L(false, false, true, false, lds); else ODIN_IHW_L(false, false, false, false, lds);
+      if (in_is_grad) ODIN_IHW_F(true, lds); else ODIN_IHW_F(false, lds);
     }
-#undef ODIN_IHW_L
+#undef ODIN_IHW_T
+#undef ODIN_IHW_F
     return odin_check_launch("igemm_h(f16x2)");
   }
 #define ODIN_IH(T_, K_, S_) ODIN_LAUNCH((igemm_h_kernel<T_, K_, S_>), grid, dim3(IH_NW * 64), 0, stream, p)
