@@ -249,11 +249,11 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_h_kernel(IHParams p) {
 // pixels back to back -- their 16 gathers fall on the same 3 x 3 input neighbourhood, so the input is read from HBM
 // once; with one class per workgroup the classes of a pixel ran on different XCDs at different times and the audio
 // decoder4's 63 MB input crossed the fabric ~16 times (196 us = 1 GB at ~5 TB/s).
-template <bool TMODE, bool BKC, bool SC, bool ALLC, int IH_U>
+template <bool TMODE, bool BKC, bool SC, bool ALLC, int IH_U, int NW>
 __device__ __forceinline__ void igemm_hw_body(const IHParams& p) {
   ODIN_DYN_SMEM(char, wlds);   // [nsteps][2][2][32] x 16 B
-  __shared__ int rowoff[IH_NW][32];
-  __shared__ float cred[IH_NW * 32 + 16];
+  __shared__ int rowoff[NW][32];
+  __shared__ float cred[NW * 32 + 16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = IH_UNIFORM(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
@@ -295,7 +295,7 @@ __device__ __forceinline__ void igemm_hw_body(const IHParams& p) {
     sbase[c + 1] = sbase[c] + nkh * nkw * gpt;
   }
   // ---- the weight planes of (class, column block): entry (step s, half hh, column jl) <- 8 weights ----
-  for (int e = tid; e < sbase[cls_hi] * 64; e += IH_NW * 64) {
+  for (int e = tid; e < sbase[cls_hi] * 64; e += NW * 64) {
     const int s = e >> 6, hh = (e >> 5) & 1, jl = e & 31;
     int wc = cls_lo;
     while (wc + 1 < cls_hi && s >= sbase[wc + 1]) ++wc;
@@ -325,7 +325,7 @@ __device__ __forceinline__ void igemm_hw_body(const IHParams& p) {
   const unsigned dbg_a = (p.dbg & 1u) ? 0xFFFFFFFFu : 0u, dbg_s = (p.dbg & 2u) ? 0xFFFFFFFFu : 0u;
   const char* wme0 = wlds + ((h * 32 + l31) << 4);   // this lane's entry of step 0, plane 0; + 2048 per step, + 1024 lo plane
   float csum = 0.f, amx = 0.f;
-  for (int tile = IH_UNIFORM(slot * IH_NW + wave); tile < p.tpc; tile += nslot * IH_NW) {
+  for (int tile = IH_UNIFORM(slot * NW + wave); tile < p.tpc; tile += nslot * NW) {
     // ---- this lane's A row: one (coarse) output pixel ----
     const unsigned q = (unsigned)(tile * 32 + l31);
     const bool a_ok = q < (unsigned)p.Mc;
@@ -355,18 +355,6 @@ __device__ __forceinline__ void igemm_hw_body(const IHParams& p) {
     odin_wave_sync();  // (the previous tile's epilogue has read the table)
     if (h == 0) rowoff[wave][l31] = a_ok ? (((int)b * p.OH + oy) * p.OW + ox) : -1;
     odin_wave_sync();
-    unsigned ooff[16];
-    float auxv[16];
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int po = rowoff[wave][(rr & 3) + 8 * (rr >> 2) + 4 * h];
-      const unsigned ok = (unsigned)b_ok & (((unsigned)po >> 31) ^ 1u);
-      ooff[rr] = (unsigned)((po * p.CO + j) * 4) | (ok - 1u);
-    }
-    if (has_aux) {   // (one uniform branch around the 16 loads, not one per load)
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) auxv[rr] = odin_run_load1(RX, ooff[rr]);
-    }
     f32x16 acc = f32x16_zero(), acx = f32x16_zero();
     // batches of IH_U steps, double-buffered: the gathers of the next four steps are in flight while the current four
     // multiply (one step ahead left an L2 round trip exposed at every step: two waves per SIMD cannot cover it)
@@ -415,6 +403,21 @@ __device__ __forceinline__ void igemm_hw_body(const IHParams& p) {
       g += IH_U;
       if (g >= ngroups) break;
     }
+    // the epilogue's store offsets and act'(aux) factors: fetched HERE, when the gather batches are dead (their registers
+    // are reused) -- before the main loop they cost 32 live registers through it, and the round trip they hid is
+    // covered by the other waves of the SIMD
+    unsigned ooff[16];
+    float auxv[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int po = rowoff[wave][(rr & 3) + 8 * (rr >> 2) + 4 * h];
+      const unsigned ok = (unsigned)b_ok & (((unsigned)po >> 31) ^ 1u);
+      ooff[rr] = (unsigned)((po * p.CO + j) * 4) | (ok - 1u);
+    }
+    if (has_aux) {   // (one uniform branch around the 16 loads, not one per load)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) auxv[rr] = odin_run_load1(RX, ooff[rr]);
+    }
     // (the activation codes are wave-uniform: one switch around the 16-element loop instead of branches inside it)
     auto epilogue = [&](auto ACT_, auto AUX_) {
       constexpr int A_ = decltype(ACT_)::value, X_ = decltype(AUX_)::value;
@@ -445,13 +448,13 @@ __device__ __forceinline__ void igemm_hw_body(const IHParams& p) {
     __syncthreads();
     if (wave == 0 && h == 0 && b_ok) {
       float t = 0.f;
-      for (int w = 0; w < IH_NW; ++w) t += cred[w * 32 + l31];
+      for (int w = 0; w < NW; ++w) t += cred[w * 32 + l31];
       p.colsum[(size_t)blockIdx.y * p.CO + j] = t;
     }
   }
   if (p.out_amax != nullptr) {
     __syncthreads();
-    odin_amax_commit_wg(p.out_amax, amx, tid, IH_NW * 64, cred, blockIdx.x + gridDim.x * blockIdx.y);
+    odin_amax_commit_wg(p.out_amax, amx, tid, NW * 64, cred, blockIdx.x + gridDim.x * blockIdx.y);
   }
 }
 
@@ -462,16 +465,22 @@ __device__ __forceinline__ void igemm_hw_body(const IHParams& p) {
 // registers they spill: decoder4 data gradient 152 -> 197 us).
 template <bool ALLC>
 __global__ __launch_bounds__(IH_NW * 64) IH_WAVES_ATTR void igemm_hw_t_kernel(IHParams p) {
-  igemm_hw_body<true, true, false, ALLC, 2>(p);
+  igemm_hw_body<true, true, false, ALLC, 2, IH_NW>(p);
 }
 // (a gradient input adds the scale multiplies: at 128 registers it spills -- conv data gradients 58 -> 69 us)
 template <bool ALLC>
 __global__ __launch_bounds__(IH_NW * 64) void igemm_hw_tg_kernel(IHParams p) {
-  igemm_hw_body<true, true, true, ALLC, 4>(p);
+  igemm_hw_body<true, true, true, ALLC, 4, IH_NW>(p);
 }
-template <bool SC>
-__global__ __launch_bounds__(IH_NW * 64) void igemm_hw_f_kernel(IHParams p) {
-  igemm_hw_body<false, false, SC, false, 4>(p);
+// (forward: eight waves share the 64 KB of planes of the strided gathers -- two workgroups per CU = four waves per
+// SIMD: audio encoder1 / 2 forward 42.5 / 22.8 -> 37.7 / 21.7 us; the data gradients of the transposed layers were
+// slower that way, 155 -> 172 us, and keep four waves per workgroup)
+constexpr int IH_NWF = 8;
+__global__ __launch_bounds__(IH_NWF * 64) void igemm_hw_f_kernel(IHParams p) {
+  igemm_hw_body<false, false, false, false, 4, IH_NWF>(p);
+}
+__global__ __launch_bounds__(IH_NW * 64) void igemm_hw_fg_kernel(IHParams p) {
+  igemm_hw_body<false, false, true, false, 4, IH_NW>(p);
 }
 
 template <typename K>
@@ -720,6 +729,10 @@ int odin_igemm_h_launch(int tmode, const float* in, const float* w, const float*
   const int max_steps = ((KH + SS - 1) / SS) * ((KW + SS - 1) / SS) * p.gpt;
   if (max_steps <= 32 && !ODIN_DIAG_ENV("ODIN_IH_NOLDSW")) {
     const size_t lds = (size_t)max_steps * 2048;
+    // (eight tiles per workgroup there: half the rows when no column sums are asked for; with column sums the row
+    // count odin_igemm_h_rows promised stays -- surplus workgroups write zero rows)
+    dim3 gridf = grid;
+    if (colsum == nullptr && gridf.y > 1) gridf.y = (gridf.y + 1) / 2;
 #define ODIN_IHW_T(S_, A_, LDS_)                                                                  \
   do {                                                                                            \
     if (S_) {                                                                                     \
@@ -732,8 +745,13 @@ int odin_igemm_h_launch(int tmode, const float* in, const float* w, const float*
   } while (0)
 #define ODIN_IHW_F(S_, LDS_)                                                                      \
   do {                                                                                            \
-    if (int rc = ih_set_lds(&igemm_hw_f_kernel<S_>, LDS_)) return rc;                             \
-    ODIN_LAUNCH((igemm_hw_f_kernel<S_>), grid, dim3(IH_NW * 64), LDS_, stream, p);                \
+    if (S_) {                                                                                     \
+      if (int rc = ih_set_lds(&igemm_hw_fg_kernel, LDS_)) return rc;                              \
+      ODIN_LAUNCH(igemm_hw_fg_kernel, grid, dim3(IH_NW * 64), LDS_, stream, p);                   \
+    } else {                                                                                      \
+      if (int rc = ih_set_lds(&igemm_hw_f_kernel, LDS_)) return rc;                               \
+      ODIN_LAUNCH(igemm_hw_f_kernel, gridf, dim3(IH_NWF * 64), LDS_, stream, p);                  \
+    }                                                                                             \
   } while (0)
     // (measured on the audio stack: decoder4 forward 196 -> 212 us, encoder2 data gradient 70 -> 86 -- the kernel is
     // bound by instruction issue, not by the re-read of its input (no gathers and no stores at all: 139 us); the
