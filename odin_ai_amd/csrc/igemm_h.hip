@@ -4,9 +4,11 @@
 // fconv_planes / tconv_planes / wgrad_planes without their whole-row tiles of 8 / 16 / 32 pixels.  Those kernels stage
 // row windows through LDS and need row widths that are powers of two; the audio VAE's spectrogram stack
 // (examples/vae/vae_audio.py:84-110 on the image stack of image_networks.py:460-513: 96 x 80 -> 48 x 40 -> 24 x 20
-// -> 12 x 10 -> 6 x 5) fits none of them and ran on the fp32 gather kernels (0.31 of the fp32 MFMA peak).  The
-// small-spatial layers of every stack (encoder3 / decoder2: 8 x 8 and 4 x 4 images) come here too: a third of the
-// matrix time of igemm.hip's v_mfma_f32_32x32x2_f32 chains.
+// -> 12 x 10 -> 6 x 5) fits none of them and ran on the fp32 gather kernels (0.31 of the fp32 MFMA peak).  Layers
+// from ~1.5 GFLOP per launch come here (odin_igemm_h_applicable); the small-spatial layers of the image stacks
+// (encoder3 / decoder2: 8 x 8 and 4 x 4 images, 0.5 GFLOP) stay on igemm.hip, whose workgroups split a tile's
+// reduction over their waves and pair a layer's weight and data gradient in one launch (same-box A/B: the dSprites
+// step 0.544 ms there, 0.595 ms here).
 //
 //   forward / data gradient (igemm_h_kernel):  C[m][j] = sum_k A(m, k) * Wt(k, j)
 //     rows m = output pixels (for the transposed gathers ordered by stride class, so that a tile's rows share their
@@ -15,7 +17,9 @@
 //     its weight column, splits both into planes and issues the three MFMAs.
 //     ONE WAVE OWNS ONE 32 x 32 TILE and walks tiles grid-stride: no partial tiles, no workgroup barrier in the loop
 //     (the row table of a tile is wave-private LDS); the column sums of a data gradient (the bias gradient of a
-//     Conv2DTranspose below) are kept per lane across the tiles of a wave and meet once at the end.
+//     Conv2DTranspose below) are kept per lane across the tiles of a wave and meet once at the end.  Where the weight
+//     planes of one stride class and 32 output columns fit in 64 KB of LDS (igemm_hw_*: all the audio stack's layers
+//     but the 64-channel 16-tap ones) a workgroup splits them once and B comes from LDS.
 //   weight gradient (igemm_h_wgrad_kernel):    dW[(tap, cu)][cv] = sum_m U(pix(m, tap), cu) * V(m, cv)
 //     the reduction over the pixels m runs 16 per MFMA step; split over gridDim.z workgroups (one slab row each) and
 //     their waves, partial tiles meet in LDS in wave order.
