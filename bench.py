@@ -40,6 +40,8 @@ WORKLOADS = {
     'shapes3d_vae_b256': ('shapes3d', {}, 256, 1.0, None),
     'celeba_betatcvae_b512': ('celeba', {}, 512, 4.0, 'betatc'),
     'mnist_dense_b128': ('dense', {}, 128, 1.0, None),
+    # BASELINE config 1, the convolutional variant (mnist_networks, image_networks.py:244-271: 5x5 kernels on 28 x 28)
+    'mnist_conv_b128': ('mnist', {}, 128, 1.0, None),
     # BASELINE config 3: both optimisers, batch split 128 + 128, whole iteration as one graph
     'factorvae_shapes3d_b256': ('shapes3d', {}, 256, None, 'factor'),
     # BASELINE config 5: audio [256, 8000] -> log-mel front-end -> conv VAE, front-end INSIDE the step

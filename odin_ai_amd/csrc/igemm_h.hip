@@ -651,11 +651,13 @@ __global__ __launch_bounds__(NW * 64) void igemm_h_wgrad_kernel(IHWParams p) {
 
 bool ih_enabled() { return !odin_exact_fp32() && ODIN_DIAG_ENV("ODIN_NOIGEMMH") == nullptr; }
 
-// Below ~1.5 GFLOP per launch the fp32 implicit GEMM (igemm.hip) wins: its workgroups split the reduction of a tile over
+// Below ~1.2 GFLOP per launch the fp32 implicit GEMM (igemm.hip) wins: its workgroups split the reduction of a tile over
 // their waves and the weight and data gradient of a layer share one launch (same-box A/B over the six workloads: the
-// dSprites step 0.544 ms with the small layers there, 0.595 ms with them here; the audio stack's layers of 2-16 GFLOP
-// are 10-60 % faster here)
-double g_ih_min_flop = 1.5e9;
+// dSprites step 0.544 ms with the small layers (0.5 GFLOP) there, 0.595 ms with them here; the audio stack's layers of
+// 2-16 GFLOP are 10-60 % faster here).  1.2 GFLOP is also where igemm.hip stops taking the transposed gathers: between
+// the two limits the 5x5/s2 layers of the MNIST stack (1.29 GFLOP at batch 128) fell to the generic fp32 kernels
+// (encoder3's data gradient: 226 us).
+double g_ih_min_flop = 1.2e9;
 
 }  // namespace
 
@@ -678,7 +680,12 @@ bool odin_igemm_h_applicable(int tmode, int B, int H, int W, int CI, int OH, int
   const long Mc = (long)B * (OH / SS) * (OW / SS);
   const long tiles = (long)SS * SS * ((Mc + 31) / 32) * ((CO + 31) / 32);
   if (tiles < 128 && g_ih_min_flop > 0.0) return false;   // (tests force small shapes here: min flop 0)
-  if (2.0 * B * (tmode ? (double)H * W : (double)OH * OW) * KH * KW * CI * CO < g_ih_min_flop) return false;
+  const double flop = 2.0 * B * (tmode ? (double)H * W : (double)OH * OW) * KH * KW * CI * CO;
+  if (flop < g_ih_min_flop) return false;
+  // strided gathers whose weight planes do not fit in LDS (> 32 steps: 5x5 kernels, 64 channels x 16 taps) run with both
+  // operands from L2: below 2 GFLOP the fp32 kernel, which takes strided gathers up to 5 GFLOP, is faster (MNIST
+  // encoder3 forward, 1.29 GFLOP: 22.6 us there, 34.7 us here)
+  if (!tmode && KH * KW * (CI / 16) > 32 && flop < 2.0e9 && g_ih_min_flop > 0.0) return false;
   if ((long)B * H * W * CI >= (1L << 29) || (long)B * OH * OW * CO >= (1L << 29) || (long)KH * KW * CI * CO >= (1L << 29))
     return false;
   return true;
