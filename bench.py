@@ -185,7 +185,6 @@ def profile_ops(eng, reps=20):
                     gflop=fl * 1e-9, tflops=fl / t * 1e-12, path=lib.odin_debug_last_path().decode(),
                     mfma_gflop=conv_flops(a, B) * 1e-9))
   if head:
-    from odin_ai_amd.engine import OBS_MODE
     a, bb = eng.dec.recs[-2], eng.dec.recs[-1]
     Cc = eng.in_shape[-1]
     npart = C.c_int(0)
@@ -194,7 +193,7 @@ def profile_ops(eng, reps=20):
         eng.dec.outs[-1].data_ptr(), None, eng.dec.gouts[-2].data_ptr(), eng.head_llk_part.data_ptr(),
         C.byref(npart), eng.head_slab.data_ptr(), C.byref(rows),
         eng.head_colsum.data_ptr() if eng.head_colsum is not None else None, eng.hp(5), B, eng.n_per // Cc,
-        bb.desc['Cin'], Cc, OBS_MODE[eng.observation], ACT[a.act], None, st)
+        bb.desc['Cin'], Cc, eng.head_mode, ACT[a.act], None, st)
     t = timeit(fn)
     fl = 3 * conv_flops(bb, B)
     out.append(dict(layer=f'dec{nd - 1}:head', op='fwd+elbo+bwd', us=t * 1e6, gflop=fl * 1e-9,

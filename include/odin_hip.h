@@ -232,7 +232,10 @@ int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float* llk_part, 
  * row of Cin column sums of dh per workgroup of colsum_slab (the bias gradient of a Conv2DTranspose below);
  * dh_amax (optional): the range word of dh.  Replaces odin_conv2d_fwd + odin_elbo_gaussian_fwd_bwd +
  * odin_conv2d_wgrad + odin_conv2d_dgrad of that layer (three passes over h) with one.  Cin in {8, 16, 32},
- * C in {1, 3}; a NULL h is a dry run that reports n_part / rows; -2: shapes outside the kernel. */
+ * C in {1, 3}; a NULL h is a dry run that reports n_part / rows; -2: shapes outside the kernel.
+ * softplus1 = 3: the Bernoulli observation instead (image_networks.py:87-93): w1 [Cin, C], logits [B, n_pix, C],
+ * llk = Independent(Bernoulli(logits)).log_prob(target) -- a Bernoulli decoder whose last two layers do not fit
+ * odin_bernoulli_tail_fwd_bwd's plane kernel (5x5 kernels, rows that are not 8 / 16 / 32 pixels wide). */
 /* tests / diagnostics: the launch size (FLOP) from which the convolutions that fit no plane kernel run on the
  * two-plane implicit GEMM (igemm_h.hip) rather than the fp32 one; 0 = every applicable shape, < 0 = only report.
  * Returns the previous value. */

@@ -792,6 +792,8 @@ extern "C" int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, 
 // Fixed-order reductions throughout: bit-reproducible.
 constexpr int GH_NT = 512;   // threads per workgroup
 constexpr int GH_U = 4;      // pixel groups in flight per lane (8: 116 -> 187 us, register pressure)
+// SP1 = 0 / 1: Normal(loc, raw | softplus1(raw)) over 2C maps; SP1 = 3: Bernoulli(logits) over C maps
+// (image_networks.py:87-93)
 template <int C, int SP1>
 __global__ __launch_bounds__(GH_NT) void gauss_head_kernel(
     const float4* __restrict__ h, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -799,7 +801,7 @@ __global__ __launch_bounds__(GH_NT) void gauss_head_kernel(
     float4* __restrict__ dh, float* __restrict__ llk_part, float* __restrict__ wslab, float* __restrict__ colsum,
     const float* __restrict__ scale, unsigned* dh_amax, int n_units, int n_part, int n_pix, int Q, int h_act,
     int upw) {
-  constexpr int CO = 2 * C, NWV = GH_NT / 64;
+  constexpr int CO = SP1 == 3 ? C : 2 * C, NWV = GH_NT / 64;
   __shared__ float wl[64 * CO];
   __shared__ float red[NWV * 8 * (5 * CO + 4) + 16];
   const int CI = 4 * Q;
@@ -869,7 +871,11 @@ __global__ __launch_bounds__(GH_NT) void gauss_head_kernel(
       float l1 = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        const float loc = lg[c], raw = lg[C + c];
+        if constexpr (SP1 == 3) {
+          bern1(lg[c], t[u][c], sc, l1, dl[c]);
+          continue;
+        }
+        const float loc = lg[c], raw = lg[SP1 == 3 ? c : C + c];
         float sd, dsd;
         if (SP1 == 1) {  // softplus1(raw) = softplus(raw + softplus^-1(1)); its derivative = sigmoid(same)
           const float a = raw + SOFTPLUS_INV1;
@@ -885,7 +891,7 @@ __global__ __launch_bounds__(GH_NT) void gauss_head_kernel(
         const float d = (t[u][c] - loc) * inv;
         l1 += -0.5f * d * d - 0.6931471805599453f * odin_log2(sd) - 0.5f * LOG2PI_F;
         dl[c] = -(d * inv) * sc;
-        dl[C + c] = -((d * d - 1.f) * inv) * dsd * sc;
+        dl[SP1 == 3 ? c : C + c] = -((d * d - 1.f) * inv) * dsd * sc;
       }
       if (!ok) {
 #pragma unroll
@@ -986,7 +992,8 @@ extern "C" int odin_gaussian_head_fwd_bwd(const float* h, const float* w1, const
                                           int* n_part_out, float* wslab, int* rows_out, float* colsum_slab,
                                           const float* scale, int B, int n_pix, int Cin, int C, int softplus1,
                                           int h_act, uint32_t* dh_amax, void* stream) {
-  if (!(Cin == 8 || Cin == 16 || Cin == 32) || (C != 1 && C != 3) || (softplus1 != 0 && softplus1 != 1) || B < 1 ||
+  if (!(Cin == 8 || Cin == 16 || Cin == 32) || (C != 1 && C != 3) ||
+      (softplus1 != 0 && softplus1 != 1 && softplus1 != 3) || B < 1 ||
       n_pix < 1 || (size_t)B * n_pix * Cin * 4 >= (1ull << 40))
     return odin_fail(-2, "gaussian_head: shapes outside the fused kernel");
   const int Q = Cin / 4;
@@ -1014,7 +1021,8 @@ extern "C" int odin_gaussian_head_fwd_bwd(const float* h, const float* w1, const
   ODIN_LAUNCH((gauss_head_kernel<CC, SP>), dim3(grid), dim3(GH_NT), 0, stream, (const float4*)h, w1, b1, target, \
               logits, dlogits, (float4*)dh, llk_part, wslab, colsum_slab, scale, (unsigned*)dh_amax,             \
               (int)n_units, n_part, n_pix, Q, h_act, upw)
-  if (C == 1 && softplus1 == 1) ODIN_GH(1, 1);
+  if (softplus1 == 3) { if (C == 1) ODIN_GH(1, 3); else ODIN_GH(3, 3); }
+  else if (C == 1 && softplus1 == 1) ODIN_GH(1, 1);
   else if (C == 1) ODIN_GH(1, 0);
   else if (softplus1 == 1) ODIN_GH(3, 1);
   else ODIN_GH(3, 0);

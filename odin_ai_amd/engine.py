@@ -583,23 +583,35 @@ class VAEEngine:
     the activation below the head instead of three."""
     self.gauss_head = self._used_head = False
     recs = self.dec_recs
-    if self.observation not in ('gaussian', 'gaussian_softplus1') or len(recs) < 2:
+    if self.observation not in ('gaussian', 'gaussian_softplus1', 'bernoulli') or len(recs) < 2:
       return
     a, b = recs[-2], recs[-1]
     Cc = self.in_shape[-1]
+    bern = self.observation == 'bernoulli'
     if not (b.kind == 'conv' and b.desc['K'] == 1 and b.desc['stride'] == 1 and b.act == 'linear'
-            and b.desc['Cout'] == 2 * Cc and a.kind in ('conv', 'deconv')):
+            and b.desc['Cout'] == (Cc if bern else 2 * Cc) and a.kind in ('conv', 'deconv')):
       return
+    if bern and self.fused_tail:
+      # the Bernoulli decoders whose last two layers run as ONE plane-kernel launch keep it (dSprites, Shapes3D, CelebA);
+      # the generic fused tail (fp32 gather kernel) gives way to layer + head where the layer is big enough for the
+      # two-plane implicit GEMM (MNIST's 5x5 stack at batch 128: 141 us -> 58 + 10)
+      d = a.desc
+      mac = self.B * (d['OH'] * d['OW'] if a.kind == 'conv' else d['H'] * d['W']) * d['K'] ** 2 * d['Cin'] * d['Cout']
+      if self.tail_keeps_range or 2.0 * mac < 1.2e9:
+        return
+    # (mode of odin_gaussian_head_fwd_bwd: 0 / 1 = Normal with a raw / softplus1 scale, 3 = Bernoulli)
+    self.head_mode = 3 if bern else OBS_MODE[self.observation]
     rows, npart = C.c_int(0), C.c_int(0)
     try:
       self.lib.odin_gaussian_head_fwd_bwd(None, None, None, None, None, None, None, None, C.byref(npart), None,
                                           C.byref(rows), None, None, self.B, self.n_per // Cc, b.desc['Cin'], Cc,
-                                          OBS_MODE[self.observation], ACT[a.act], None, None)
+                                          self.head_mode, ACT[a.act], None, None)
     except _lib.OdinError:
       return
     self.gauss_head = True
+    self.fused_tail = False
     self.head_rows, self.head_npart = rows.value, npart.value
-    cin, co = b.desc['Cin'], 2 * Cc
+    cin, co = b.desc['Cin'], b.desc['Cout']
     self.head_slab = torch.empty(rows.value, cin * co + co, **f32)
     self.head_colsum = torch.empty(rows.value, cin, **f32) if a.kind == 'deconv' else None
     self.head_llk_part = torch.empty(self.B * npart.value, **f32)
@@ -799,7 +811,7 @@ class VAEEngine:
           self.dec.outs[-1].data_ptr(), None, self.dec.gouts[-2].data_ptr(), self.head_llk_part.data_ptr(),
           C.byref(npart), self.head_slab.data_ptr(), C.byref(rows),
           self.head_colsum.data_ptr() if self.head_colsum is not None else None, self.hp(H_INVB), B,
-          self.n_per // Cc, b.desc['Cin'], Cc, OBS_MODE[self.observation], ACT[a.act], self.dec.word(nd - 2), st)
+          self.n_per // Cc, b.desc['Cin'], Cc, self.head_mode, ACT[a.act], self.dec.word(nd - 2), st)
       assert rows.value == self.head_rows and npart.value == self.head_npart
       self._used_fused, self._used_head = False, True
       llk_part = self.head_llk_part

@@ -187,6 +187,43 @@ def test_gaussian_head(bk, B, npix, Cin, Cc, sp1, hact):
   assert torch.equal(dh2, dh)
 
 
+@pytest.mark.parametrize('B,npix,Cin,Cc,hact', [(3, 300, 32, 1, 'elu'), (2, 784, 32, 1, 'relu'), (2, 530, 16, 3, 'elu')])
+def test_bernoulli_head(bk, B, npix, Cin, Cc, hact):
+  """odin_gaussian_head_fwd_bwd with softplus1 = 3: Conv2D 1x1 -> Bernoulli(logits) log-prob -> backward, one launch"""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(14)
+  pre = rng.standard_normal((B, npix, Cin))
+  h = {'elu': vo.elu, 'relu': lambda a: np.maximum(a, 0.0)}[hact](pre).astype(np.float32).astype(np.float64)
+  w1 = rng.standard_normal((Cin, Cc)) * 0.3
+  b1 = rng.standard_normal(Cc) * 0.1
+  x = (rng.random((B, npix, Cc)) < 0.3).astype(np.float64).clip(1e-6, 1 - 1e-6)
+  lg = h @ w1 + b1
+  llk_ref = vo.bernoulli_log_prob(lg.reshape(B, -1), x.reshape(B, -1))
+  dl_ref = -vo.bernoulli_log_prob_grad(lg, x) / B
+  hgrad = {'relu': (h > 0).astype(np.float64), 'elu': vo.elu_grad_from_output(h)}[hact]
+  dh_ref = (dl_ref @ w1.T) * hgrad
+  th, tw, tb, tx, sc = T(h), T(w1), T(b1), T(x), T([1.0 / B])
+  npart, rows = C.c_int(0), C.c_int(0)
+  L.odin_gaussian_head_fwd_bwd(None, None, None, None, None, None, None, None, C.byref(npart), None, C.byref(rows),
+                               None, None, B, npix, Cin, Cc, 3, 0, None, None)
+  logits, dl, dh = bk.zeros(B, npix, Cc), bk.zeros(B, npix, Cc), bk.full((B, npix, Cin), float('nan'))
+  part = bk.full((B * npart.value,), float('nan'))
+  slab = bk.full((rows.value, Cin * Cc + Cc), float('nan'))
+  cs = bk.full((rows.value, Cin), float('nan'))
+  L.odin_gaussian_head_fwd_bwd(th.data_ptr(), tw.data_ptr(), tb.data_ptr(), tx.data_ptr(), logits.data_ptr(),
+                               dl.data_ptr(), dh.data_ptr(), part.data_ptr(), C.byref(npart), slab.data_ptr(),
+                               C.byref(rows), cs.data_ptr(), sc.data_ptr(), B, npix, Cin, Cc, 3, _lib.ACT[hact],
+                               None, None)
+  close(logits.cpu().numpy(), lg)
+  close(part.reshape(B, -1).sum(1).cpu().numpy(), llk_ref, 1e-5)
+  close(dl.cpu().numpy(), dl_ref)
+  close(dh.cpu().numpy(), dh_ref)
+  g = slab.cpu().numpy().astype(np.float64).sum(0)
+  close(g[:Cin * Cc].reshape(Cin, Cc), np.einsum('bpc,bpo->co', h, dl_ref), 1e-4)
+  close(g[Cin * Cc:], dl_ref.sum((0, 1)), 1e-4)
+  close(cs.cpu().numpy().astype(np.float64).sum(0), dh_ref.sum((0, 1)), 1e-4)
+
+
 def test_adam_and_sumsq(bk):
   L, T = bk.L, bk.T
   rng = np.random.default_rng(3)

@@ -73,5 +73,7 @@ def test_engine_step_matches_oracle(L, name, kw, obs, C):
                   analytic=kw.get('analytic', False), free_bits=kw.get('free_bits'),
                   tc='betatc' if 'tc_beta' in kw else None, lib=L, reverse=kw.get('reverse', True))
   assert eng.fused_tail == name.startswith('tiny16')
-  assert eng.gauss_head == (obs == 'gaussian_softplus1')  # (one pass over the activation below the 1x1 head)
+  # one pass over the activation below the 1x1 head: Gaussian observations, and Bernoulli ones without a fused tail
+  conv_dec = any(l[0] in ('conv', 'deconv') for l in dec)
+  assert eng.gauss_head == (conv_dec and (obs == 'gaussian_softplus1' or (obs == 'bernoulli' and not eng.fused_tail)))
   check_engine_vs_oracle(eng, model, P, x, eps, beta=kw.get('beta', 1.0), steps=2, clip=100.0)

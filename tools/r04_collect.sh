@@ -17,7 +17,7 @@ cp $g/r04_final_stamps_tail.txt $p/r04_stamps_tail.txt
 cp $g/r04_final_elbo_stream_sweep.txt $p/r04_elbo_stream_sweep.txt
 cp $g/r04_final_range_fallbacks.txt $p/r04_range_fallbacks.txt
 cp $g/r04_final_slabstat.txt $p/r04_slabstat.txt
-for w in shapes3d_vae_b256 celeba_betatcvae_b512 mnist_dense_b128 factorvae_shapes3d_b256 speech_vae_b256; do
+for w in shapes3d_vae_b256 celeba_betatcvae_b512 mnist_dense_b128 mnist_conv_b128 factorvae_shapes3d_b256 speech_vae_b256; do
   cp $g/r04_final_$w.json $p/r04_bench_$w.json
   grep "^#" $g/r04_final_$w.err > $p/r04_bench_${w}_per_op.txt
 done

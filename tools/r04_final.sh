@@ -22,7 +22,7 @@ python tools/kbench.py > gpurun_out/r04_final_kbench.txt 2>&1
 python tools/elbo_ceiling.py > gpurun_out/r04_final_elbo_stream_sweep.txt 2>&1
 python tools/range_fallbacks.py > gpurun_out/r04_final_range_fallbacks.txt 2>&1
 python tools/slabstat.py > gpurun_out/r04_final_slabstat.txt 2>&1
-for w in shapes3d_vae_b256 celeba_betatcvae_b512 mnist_dense_b128 factorvae_shapes3d_b256 speech_vae_b256; do
+for w in shapes3d_vae_b256 celeba_betatcvae_b512 mnist_dense_b128 mnist_conv_b128 factorvae_shapes3d_b256 speech_vae_b256; do
   timeout 600 python bench.py --workload $w --profile-ops --no-cpu-baseline --no-north-star-3ch > gpurun_out/r04_final_$w.json 2> gpurun_out/r04_final_$w.err
 done
 for w in speech_vae_b256 factorvae_shapes3d_b256 celeba_betatcvae_b512; do
