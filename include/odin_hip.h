@@ -236,6 +236,14 @@ int odin_elbo_gaussian_fwd_bwd(const float* h, const float* x, float* llk_part, 
  * softplus1 = 3: the Bernoulli observation instead (image_networks.py:87-93): w1 [Cin, C], logits [B, n_pix, C],
  * llk = Independent(Bernoulli(logits)).log_prob(target) -- a Bernoulli decoder whose last two layers do not fit
  * odin_bernoulli_tail_fwd_bwd's plane kernel (5x5 kernels, rows that are not 8 / 16 / 32 pixels wide). */
+/* Between _begin and _end the calling thread's weight gradients of the 4x4 / stride-2 plane layers are collected
+ * instead of launched, and _end issues them as ONE multi-layer launch on the stream they were given (they depend on
+ * nothing but their own layer's tensors; a backward pass has five of them: -4 launches).  odin_slab_reduce issues
+ * whatever is still pending first, so a caller that never calls _end stays correct.  Results are bit-identical to
+ * the separate launches.  (Measured on the VAE step: slower than launching each weight gradient right behind the data
+ * gradient that produced its dy, which then still sits in the Infinity Cache -- odin_ai_amd/engine.py keeps it off.) */
+void odin_wgrad_planes_defer_begin(void);
+int odin_wgrad_planes_defer_end(void* stream);
 /* tests / diagnostics: the launch size (FLOP) from which the convolutions that fit no plane kernel run on the
  * two-plane implicit GEMM (igemm_h.hip) rather than the fp32 one; 0 = every applicable shape, < 0 = only report.
  * Returns the previous value. */

@@ -80,6 +80,8 @@ SIGNATURES = {
     'odin_elbo_gaussian_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
     'odin_gaussian_head_fwd_bwd': [P, P, P, P, P, P, P, P, IP, P, IP, P, P, I, I, I, I, I, I, P, P],
     'odin_debug_igemm_h_min_flop': [C.c_double],
+    'odin_wgrad_planes_defer_begin': [],
+    'odin_wgrad_planes_defer_end': [P],
     'odin_elbo_mixqlogistic_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
     'odin_elbo_finalize': [P, I, P, P, P, P, P, I, P],
     'odin_mean': [P, I, P, P],
@@ -116,7 +118,8 @@ SIGNATURES = {
 # entry points whose return value is a result, not an error code
 VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_conv2d_dgrad_keeps_range',
                    'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_dense_dgrad_keeps_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
-                   'odin_latent_block_rows', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop')
+                   'odin_latent_block_rows', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop',
+                   'odin_wgrad_planes_defer_begin')
 
 
 class OdinError(RuntimeError):

@@ -21,6 +21,7 @@ static inline bool odin_exact_fp32() { return getenv("ODIN_EXACT_FP32") != nullp
 
 int odin_fail(int code, const char* msg);
 int odin_check_launch(const char* what);
+int odin_wgrad_planes_flush(void* stream);  // issue the calling thread's deferred plane weight gradients (wgrad_planes.hip)
 int odin_num_cus();
 // range word of a gradient tensor (include/odin_hip.h: odin_conv_desc.dy_amax): the caller's word, or a scratch
 // word filled by one pass over the tensor; nullptr on failure

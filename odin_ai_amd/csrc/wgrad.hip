@@ -1379,6 +1379,7 @@ extern "C" int odin_dense_bwd(const float* x, const float* dy, const float* w, c
 extern "C" int odin_dense_dgrad_keeps_range(int B, int K, int N) { return odin_dense_dgrad_tracks(B, K, N) ? 1 : 0; }
 
 extern "C" int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* stream) {
+  if (int rc = odin_wgrad_planes_flush(stream)) return rc;  // (deferred weight gradients write the slabs read here)
   if (n_jobs <= 0) return 0;
   for (int j0 = 0; j0 < n_jobs; j0 += MAX_JOBS) {
     ReduceJobs rj;

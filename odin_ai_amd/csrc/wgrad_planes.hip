@@ -46,6 +46,20 @@ struct WPParams {
   const unsigned* g_amax;  // range word (odin_device.h) of the gradient operand (GU: U, else V)
 };
 
+struct WPQueue {
+  struct Job {
+    WPParams p;
+    dim3 grid;
+    size_t lds;
+    int kind;
+  };
+  bool defer = false;
+  int n = 0;
+  void* stream = nullptr;
+  Job job[8];
+};
+thread_local WPQueue g_wpq;
+
 // ds_read_b64_tr_b16: `blk` = byte address of a block of 4 rows (`stride` bytes apart) x 16 bf16 columns;
 // lane l16 of the 16-lane group receives column l16 of the 4 rows (row q in element q).  On the
 // hardware lane 4 q + p supplies the address of row q, columns 4 p .. 4 p + 3.
@@ -76,8 +90,10 @@ constexpr int WP_MAXU = 4;  // 1 KB load items (8 pixels x 32 channels) of fine 
 // W = coarse row length (8, 16 or 32); DBG (diagnostics, ODIN_WP_DBG): 1 no MFMAs, 2 no LDS reads in the loop,
 // 4 no row fills after the prologue
 // GU: the gradient operand is U (Conv2DTranspose), else V (Conv2D)
+// (bx, by, bz): the workgroup's block coordinates -- blockIdx of a launch of its own, decoded from a linear index in
+// the multi-layer launch below
 template <int W, bool GU, int DBG = 0>
-__global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
+__device__ __forceinline__ void wp_body(const WPParams& p, const int bx, const int by, const int bz) {
   constexpr int NPL = 2;                 // f16 planes per operand
   constexpr int TC = 32 / W;             // coarse rows per tile
   constexpr int WU = 2 * W;              // fine row length
@@ -104,9 +120,9 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
   const int l31 = lane & 31, half = lane >> 5, l16 = lane & 15;
-  const int cu0 = blockIdx.y * 32, cv0 = blockIdx.z * 32;
+  const int cu0 = by * 32, cv0 = bz * 32;
   const int HU = 2 * p.h, HPU = HU + 1;
-  const int T0 = blockIdx.x * p.tiles_per_wg;
+  const int T0 = bx * p.tiles_per_wg;
   int T1 = T0 + p.tiles_per_wg;
   if (T1 > p.n_tiles) T1 = p.n_tiles;
   if (T0 >= T1) return;
@@ -374,7 +390,7 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
   }
 
   // ---- this workgroup's slab row: dW[tap][cu0 + cu][cv0 + cv], lane = column cv = l31 ----
-  float* row = p.slab + (size_t)blockIdx.x * p.slab_stride;
+  float* row = p.slab + (size_t)bx * p.slab_stride;
   const float o_s = odin_pow2(-gk), o_sx = odin_pow2(-gk - 11);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
       row[((size_t)tap * p.CUt + cu0 + cu) * p.CVt + cv0 + l31] = fmaf(acx[t][r], o_sx, acc[t][r] * o_s);
     }
   }
-  if (p.want_bias && blockIdx.y == 0) {
+  if (p.want_bias && by == 0) {
     // column sums of V: lanes with the same channel quad (lane & 7), then the 8 waves through LDS
     float s[4] = {bsum4.x, bsum4.y, bsum4.z, bsum4.w};
 #pragma unroll
@@ -403,6 +419,39 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
       for (int wv = 0; wv < 8; ++wv) t += bred[wv * 32 + tid];
       row[(size_t)16 * p.CUt * p.CVt + cv0 + tid] = t;
     }
+  }
+}
+
+template <int W, bool GU, int DBG = 0>
+__global__ __launch_bounds__(512) void wgrad_planes_kernel(WPParams p) {
+  wp_body<W, GU, DBG>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// Several layers' weight gradients in ONE launch.  They depend on nothing but their own layer's tensors, so the
+// backward pass defers them (odin_wgrad_planes_defer_begin / _end) and issues them together at its end: a launch costs
+// ~4.6 us of floor plus a tail in which most CUs wait for the last workgroup, and a step has five of them (dSprites:
+// 37.8 + 23.8 + 16.8 + 13.0 + 17.1 us).  Jobs are laid out largest first; a workgroup finds its job by its linear index.
+constexpr int WP_MAXJOBS = 8;
+struct WPMulti {
+  WPParams p[WP_MAXJOBS];
+  int start[WP_MAXJOBS + 1];   // first linear workgroup index of job j
+  int gx[WP_MAXJOBS], gy[WP_MAXJOBS];
+  int kind[WP_MAXJOBS];        // (W == 8 ? 0 : W == 16 ? 1 : 2) * 2 + GU
+  int n;
+};
+__global__ __launch_bounds__(512) void wgrad_planes_multi_kernel(WPMulti m) {
+  int j = 0;
+  while (j + 1 < m.n && (int)blockIdx.x >= m.start[j + 1]) ++j;
+  const int l = (int)blockIdx.x - m.start[j];
+  const int bx = l % m.gx[j], r = l / m.gx[j];
+  const int by = r % m.gy[j], bz = r / m.gy[j];
+  switch (m.kind[j]) {
+    case 0: wp_body<8, false>(m.p[j], bx, by, bz); break;
+    case 1: wp_body<8, true>(m.p[j], bx, by, bz); break;
+    case 2: wp_body<16, false>(m.p[j], bx, by, bz); break;
+    case 3: wp_body<16, true>(m.p[j], bx, by, bz); break;
+    case 4: wp_body<32, false>(m.p[j], bx, by, bz); break;
+    default: wp_body<32, true>(m.p[j], bx, by, bz); break;
   }
 }
 
@@ -429,7 +478,7 @@ int wp_tiles_per_wg(int W, int n_tiles, int gyz) {
 }
 
 template <int W, bool GU>
-int wp_launch(const WPParams& p, dim3 grid, void* stream) {
+int wp_launch(const WPParams& p, dim3 grid, void* stream, bool may_defer) {
   const size_t lds = (size_t)wp_ring_bytes(W) + (size_t)(p.tiles_per_wg + 4) * wp_fill_bytes(W);
 #ifndef ODIN_SIM
   static bool attr_done = false;
@@ -466,11 +515,92 @@ int wp_launch(const WPParams& p, dim3 grid, void* stream) {
   }
 #endif
 #endif
+  // (a job whose range word is a library scratch word -- one of a ring of 16 -- is launched at once: the word would
+  // not outlive the deferral)
+  if (may_defer && g_wpq.defer && g_wpq.n < WP_MAXJOBS && (g_wpq.n == 0 || g_wpq.stream == stream)) {
+    WPQueue::Job& jb = g_wpq.job[g_wpq.n++];
+    jb.p = p; jb.grid = grid; jb.lds = lds; jb.kind = (W == 8 ? 0 : W == 16 ? 1 : 2) * 2 + (GU ? 1 : 0);
+    g_wpq.stream = stream;
+    return odin_check_launch("wgrad_planes(f16x2)");  // (names the family; nothing was launched yet)
+  }
   ODIN_LAUNCH((wgrad_planes_kernel<W, GU>), grid, dim3(512), lds, stream, p);
   return odin_check_launch("wgrad_planes(f16x2)");
 }
 
+int wp_launch_one(const WPQueue::Job& jb, void* stream) {
+  const WPParams& p = jb.p;
+  switch (jb.kind) {
+    case 0: ODIN_LAUNCH((wgrad_planes_kernel<8, false>), jb.grid, dim3(512), jb.lds, stream, p); break;
+    case 1: ODIN_LAUNCH((wgrad_planes_kernel<8, true>), jb.grid, dim3(512), jb.lds, stream, p); break;
+    case 2: ODIN_LAUNCH((wgrad_planes_kernel<16, false>), jb.grid, dim3(512), jb.lds, stream, p); break;
+    case 3: ODIN_LAUNCH((wgrad_planes_kernel<16, true>), jb.grid, dim3(512), jb.lds, stream, p); break;
+    case 4: ODIN_LAUNCH((wgrad_planes_kernel<32, false>), jb.grid, dim3(512), jb.lds, stream, p); break;
+    default: ODIN_LAUNCH((wgrad_planes_kernel<32, true>), jb.grid, dim3(512), jb.lds, stream, p); break;
+  }
+  return odin_check_launch("wgrad_planes(f16x2)");
+}
+
 }  // namespace
+
+// ---- deferred weight gradients: between _begin and _end (or the next odin_slab_reduce, which flushes) the plane
+// weight-gradient launches of the calling thread are collected and issued as one multi-layer launch ----
+extern "C" void odin_wgrad_planes_defer_begin(void) {
+  g_wpq.defer = true;
+  g_wpq.n = 0;
+}
+
+extern "C" int odin_wgrad_planes_defer_end(void* stream) {
+  g_wpq.defer = false;
+  const int n = g_wpq.n;
+  g_wpq.n = 0;
+  if (n == 0) return 0;
+  void* st = g_wpq.stream;
+  (void)stream;
+  if (n == 1) return wp_launch_one(g_wpq.job[0], st);
+  // largest first: the tail of the launch is then made of the small layers' short workgroups
+  int order[WP_MAXJOBS];
+  for (int i = 0; i < n; ++i) order[i] = i;
+  auto work = [&](int i) {
+    const WPQueue::Job& jb = g_wpq.job[i];
+    return (long)jb.p.tiles_per_wg * (jb.kind >= 4 ? 4 : jb.kind >= 2 ? 2 : 1);
+  };
+  for (int a = 0; a < n; ++a)
+    for (int b = a + 1; b < n; ++b)
+      if (work(order[b]) > work(order[a])) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+  WPMulti m;
+  memset(&m, 0, sizeof(m));
+  m.n = n;
+  size_t lds = 0;
+  int total = 0;
+  for (int k = 0; k < n; ++k) {
+    const WPQueue::Job& jb = g_wpq.job[order[k]];
+    m.p[k] = jb.p; m.kind[k] = jb.kind; m.gx[k] = (int)jb.grid.x; m.gy[k] = (int)jb.grid.y;
+    m.start[k] = total;
+    total += (int)(jb.grid.x * jb.grid.y * jb.grid.z);
+    if (jb.lds > lds) lds = jb.lds;
+  }
+  m.start[n] = total;
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_multi_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS_MAX) != hipSuccess)
+      (void)hipGetLastError();
+    attr_done = true;
+  }
+#endif
+  ODIN_LAUNCH(wgrad_planes_multi_kernel, dim3(total), dim3(512), lds, st, m);
+  return odin_check_launch("wgrad_planes_multi(f16x2)");
+}
+
+// (odin_slab_reduce reads the slabs: anything still deferred on this thread is issued first)
+int odin_wgrad_planes_flush(void* stream) {
+  if (g_wpq.n == 0) return 0;
+  const bool was = g_wpq.defer;
+  const int rc = odin_wgrad_planes_defer_end(stream);
+  g_wpq.defer = was;
+  return rc;
+}
 
 // fine tensor U [B, H, W, CI], coarse tensor V [B, OH, OW, CO] (the argument order of wgrad.hip's WParams)
 bool odin_wgrad_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
@@ -505,12 +635,13 @@ int odin_wgrad_planes_launch(const float* U, const float* V, float* slab, int* r
                     : odin_range_word_of(V, (size_t)B * OH * OW * CO, g_amax, stream);
   if (p.g_amax == nullptr) return odin_fail(-3, "wgrad_planes: no range word for the gradient operand");
   dim3 grid(gx, gy, gz);
+  const bool md = g_amax != nullptr;
   if (grad_u) {
-    if (OW == 32) return wp_launch<32, true>(p, grid, stream);
-    if (OW == 16) return wp_launch<16, true>(p, grid, stream);
-    return wp_launch<8, true>(p, grid, stream);
+    if (OW == 32) return wp_launch<32, true>(p, grid, stream, md);
+    if (OW == 16) return wp_launch<16, true>(p, grid, stream, md);
+    return wp_launch<8, true>(p, grid, stream, md);
   }
-  if (OW == 32) return wp_launch<32, false>(p, grid, stream);
-  if (OW == 16) return wp_launch<16, false>(p, grid, stream);
-  return wp_launch<8, false>(p, grid, stream);
+  if (OW == 32) return wp_launch<32, false>(p, grid, stream, md);
+  if (OW == 16) return wp_launch<16, false>(p, grid, stream, md);
+  return wp_launch<8, false>(p, grid, stream, md);
 }

@@ -513,6 +513,12 @@ class VAEEngine:
     # (profiles/r02_step_timeline.txt) and with the round-2 kernels the same A/B reads
     # 0.819 ms (both on) / 0.808 (no side-stream wgrads) / 0.815 (no early slab reduce) / 0.804 (both off)
     self.early_reduce = _os.environ.get('ODIN_EARLY_REDUCE', '0') == '1'
+    # the five plane weight gradients of a step as ONE multi-layer launch at the end of the backward pass
+    # (odin_wgrad_planes_defer_begin / _end): OFF -- same-box A/B, two rounds each: dSprites 0.582 ms with it, 0.564
+    # without; Shapes3D 0.631 / 0.614; CelebA 1.426 / 1.425.  Four launch floors are saved, but issued right behind
+    # the data gradient that produced its dy a weight gradient still finds that tensor in the Infinity Cache; at the
+    # end of the pass it comes from HBM
+    self.defer_wgrad = _os.environ.get('ODIN_DEFER_WGRAD', '0') == '1'
     self.overlap_wgrad = {'0': None, '1': 'all', 'all': 'all', 'small': 'small'}.get(
         _os.environ.get('ODIN_OVERLAP_WGRAD', '0'), None)
     self.graph = None
@@ -949,6 +955,10 @@ class VAEEngine:
     lib, B, D = self.lib, self.B, self.D
     st = self.stream() if st is None else st
     fork, join = self._fork() if phase is None else (None, (lambda: None))
+    if phase is None and fork is None and self.defer_wgrad:
+      # the plane layers' weight gradients depend on nothing but their own layer's tensors: collected here and issued
+      # as ONE launch just before the slab reduction (include/odin_hip.h: odin_wgrad_planes_defer_begin)
+      lib.odin_wgrad_planes_defer_begin()
     if phase == 'enc':
       jobs = []
       late_jobs = []
@@ -1055,6 +1065,7 @@ class VAEEngine:
     join()
     arr = (ReduceJob * len(jobs))(*jobs)
     self._jobs_keepalive = arr
+    lib.odin_wgrad_planes_defer_end(st)   # (no-op unless backward() opened a collection)
     lib.odin_slab_reduce(arr, len(jobs), st)
 
   # ---- optimiser ---------------------------------------------------------------------

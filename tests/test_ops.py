@@ -300,6 +300,65 @@ def test_layer_bwd_in_one_call(bk, kind, shape):
   assert torch.equal(s1[:rows.value], s2[:rows.value])
 
 
+def test_deferred_plane_weight_gradients(bk):
+  """odin_wgrad_planes_defer_begin / _end: the plane weight gradients of several layers as ONE launch, bit-identical
+  to the separate launches; odin_slab_reduce flushes what is still pending."""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(31)
+  cases = [('conv', (2, 64, 64, 32, 32)), ('conv', (3, 32, 32, 32, 64)), ('deconv', (3, 8, 8, 64, 32)),
+           ('deconv', (2, 16, 16, 32, 32)), ('conv', (3, 16, 16, 64, 64))]
+  jobs, words = [], []
+  for kind, (B, H, W, Ci, Co) in cases:
+    K, S = 4, 2
+    if kind == 'conv':
+      OH, pt, _ = vo.same_pads(H, K, S)
+      OW, pl, _ = vo.same_pads(W, K, S)
+      n = K * K * Ci * Co + Co
+    else:
+      OH, OW = H * S, W * S
+      _, pt, _ = vo.same_pads(OH, K, S)
+      _, pl, _ = vo.same_pads(OW, K, S)
+      n = K * K * Ci * Co
+    d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, 'elu')
+    x, dy = T(rng.standard_normal((B, H, W, Ci))), T(rng.standard_normal((B, OH, OW, Co)) * 1e-3)
+    # (the caller's own range word of dy: a job that would need a library scratch word is never deferred)
+    word = bk.zeros(2048, dtype=torch.int32)
+    L.odin_absmax(dy.data_ptr(), dy.numel(), word.data_ptr(), None)
+    d.dy_amax = word.data_ptr()
+    words.append(word)
+    fn = L.odin_conv2d_wgrad if kind == 'conv' else L.odin_deconv2d_wgrad
+    s1 = bk.full((L.odin_max_slab_rows(), n), float('nan'))
+    s2 = bk.full((L.odin_max_slab_rows(), n), float('nan'))
+    jobs.append((fn, x, dy, d, s1, s2, n))
+  rows1, rows2 = [], []
+  for fn, x, dy, d, s1, s2, n in jobs:
+    r = C.c_int(0)
+    fn(x.data_ptr(), dy.data_ptr(), s1.data_ptr(), C.byref(r), C.byref(d), None)
+    assert L.odin_debug_last_path().decode() == 'wgrad_planes(f16x2)'
+    rows1.append(r.value)
+  L.odin_wgrad_planes_defer_begin()
+  for fn, x, dy, d, s1, s2, n in jobs:
+    r = C.c_int(0)
+    fn(x.data_ptr(), dy.data_ptr(), s2.data_ptr(), C.byref(r), C.byref(d), None)
+    rows2.append(r.value)
+  assert all(bool(torch.isnan(j[5][0, 0])) for j in jobs)   # nothing has run yet
+  L.odin_wgrad_planes_defer_end(None)
+  assert L.odin_debug_last_path().decode() == 'wgrad_planes_multi(f16x2)'
+  assert rows1 == rows2
+  for (fn, x, dy, d, s1, s2, n), r in zip(jobs, rows1):
+    assert torch.equal(s1[:r], s2[:r])
+  # a pending job is flushed by the slab reduction that reads it
+  fn, x, dy, d, s1, s2, n = jobs[0]
+  s3, out = bk.full((L.odin_max_slab_rows(), n), float('nan')), bk.zeros(n)
+  r = C.c_int(0)
+  L.odin_wgrad_planes_defer_begin()
+  fn(x.data_ptr(), dy.data_ptr(), s3.data_ptr(), C.byref(r), C.byref(d), None)
+  job = (_lib.ReduceJob * 1)(_lib.ReduceJob(s3.data_ptr(), out.data_ptr(), n, r.value, n, 0))
+  L.odin_slab_reduce(job, 1, None)
+  L.odin_wgrad_planes_defer_end(None)
+  assert torch.equal(s3[:r.value], s1[:r.value]) and bool(torch.isfinite(out).all())
+
+
 @pytest.fixture(scope='module')
 def hipbk():
   import torch
