@@ -137,20 +137,6 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_h_kernel(IHParams p) {
     odin_wave_sync();  // (the previous tile's epilogue has read the table)
     if (h == 0) rowoff[wave][l31] = a_ok ? (((int)b * p.OH + oy) * p.OW + ox) : -1;
     odin_wave_sync();
-    // the epilogue's operands (store offsets, act'(aux) factors) are fetched NOW: loaded in the epilogue they
-    // cost one exposed round trip per tile
-    unsigned ooff[16];
-    float auxv[16];
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int po = rowoff[wave][(rr & 3) + 8 * (rr >> 2) + 4 * h];
-      const unsigned ok = (unsigned)b_ok & (((unsigned)po >> 31) ^ 1u);
-      ooff[rr] = (unsigned)((po * p.CO + j) * 4) | (ok - 1u);
-    }
-    if (has_aux) {   // (one uniform branch around the 16 loads, not one per load)
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) auxv[rr] = odin_run_load1(RX, ooff[rr]);
-    }
     f32x16 acc = f32x16_zero(), acx = f32x16_zero();
     float a0[8], b0[8], a1[8], b1[8];
     IHCursor cur = {0, 0, 0, 0};
@@ -202,6 +188,20 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_h_kernel(IHParams p) {
       mul(a1, b1);
       ODIN_SCHED_FENCE();
       if (g >= ngroups) break;
+    }
+    // the epilogue's store offsets and act'(aux) factors: fetched here, when the operand batches are dead (32 registers
+    // less through the main loop; the round trip is covered by the other waves of the SIMD)
+    unsigned ooff[16];
+    float auxv[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int po = rowoff[wave][(rr & 3) + 8 * (rr >> 2) + 4 * h];
+      const unsigned ok = (unsigned)b_ok & (((unsigned)po >> 31) ^ 1u);
+      ooff[rr] = (unsigned)((po * p.CO + j) * 4) | (ok - 1u);
+    }
+    if (has_aux) {   // (one uniform branch around the 16 loads, not one per load)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) auxv[rr] = odin_run_load1(RX, ooff[rr]);
     }
     // ---- epilogue: lane holds column j, rows (rr & 3) + 8 (rr >> 2) + 4 h ----
     // (the activation codes are wave-uniform: one switch around the 16-element loop instead of branches inside it)
