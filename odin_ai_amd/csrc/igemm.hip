@@ -6,7 +6,7 @@
 // are <= 128 workgroups that first stage a 128 KB weight slice through LDS and then multiply -- 16-28 us
 // per launch for 3 % of the step's FLOPs.  Here nothing is staged: a workgroup owns ONE 32 x 32 output
 // tile, its NW waves split the reduction, and every wave streams its share of both operands from L2 in
-// 8-deep, double-buffered batches of 16-byte loads (the next batch is in flight while the current one
+// 4-deep, double-buffered batches of 16-byte loads (the next batch is in flight while the current one
 // feeds v_mfma_f32_32x32x2_f32); the partial tiles meet in LDS in wave order (bit-reproducible).
 //
 //   forward / data gradient (igemm_kernel):  C[m][j] = sum_k A(m, k) * Wt(k, j)
@@ -30,7 +30,15 @@ namespace {
 #define IG_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
-constexpr int IG_U = 8;  // k-groups (8 k-values each) per batch
+// k-groups (8 k-values each) per batch.  8 until round 4: two double-buffered batches of 8 groups are 128 operand
+// registers (164-168 in all: three waves per SIMD); with 4 the kernels fit five and the launches of 1000-1500
+// workgroups hide their L2 round trips behind other waves instead -- same-box A/B (two rounds, -DODIN_IG_U builds):
+// dSprites step 0.528 -> 0.522 ms, speech 1.550 -> 1.520, FactorVAE 0.860 -> 0.851, Shapes3D 0.574 -> 0.572; 2 groups:
+// speech / FactorVAE slower again (1.537 / 0.857), CelebA slightly faster (1.311 vs 1.324)
+#ifndef ODIN_IG_U
+#define ODIN_IG_U 4
+#endif
+constexpr int IG_U = ODIN_IG_U;
 
 struct IGParams {
   const float* in;    // gathered tensor [B, H, W, CI]
@@ -126,24 +134,11 @@ __device__ __forceinline__ void igemm_body(const IGParams& p, const int bx, cons
   const int ngroups = ntap * gpt;
   f32x16 acc = f32x16_zero();
   float av0[IG_U][4], bv0[IG_U][4], av1[IG_U][4], bv1[IG_U][4];
-  // the epilogue's operands (bias; store offsets and act'(aux) factors of wave 0's 16 rows) are fetched NOW:
-  // loaded in the epilogue they cost one exposed cold-L2 round trip, and 16 dependent LDS reads inside
-  // exec-mask branches another 2 us (in-kernel stamps: 4.8 k of 24 k cycles)
+  // (the epilogue's bias is fetched now; its store offsets and act'(aux) factors after the main loop, see there)
   float auxv[16];
   unsigned ooff[16];  // byte offset of (row, column j) in `out`; out of range for rows / columns beyond the tensor
   __syncthreads();    // rowoff
   const float bj = (p.bias != nullptr && b_ok) ? p.bias[j] : 0.f;
-  {
-    const OdinRun RX = odin_run(p.aux != nullptr ? p.aux : p.in,
-                                p.aux != nullptr ? (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4) : 0u);
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int po = rowoff[(rr & 3) + 8 * (rr >> 2) + 4 * h];
-      const unsigned ok = (unsigned)(wave == 0) & (unsigned)b_ok & (((unsigned)po >> 31) ^ 1u);
-      ooff[rr] = (unsigned)((po * p.CO + j) * 4) | (ok - 1u);
-      auxv[rr] = odin_run_load1(RX, ooff[rr]);
-    }
-  }
 
   auto load_group = [&](int gr, float (&av)[4], float (&bv)[4]) {
     // branch-free (a wave-uniform `cond ? a : b` becomes a scalar branch that cuts the batch of loads in
@@ -213,6 +208,22 @@ __device__ __forceinline__ void igemm_body(const IGParams& p, const int bx, cons
   __syncthreads();
   IG_STAMP(4);
   if (wave != 0) return;
+  // the epilogue's operands (store offsets, act'(aux) factors): fetched HERE by wave 0.  Until round 4 every wave
+  // fetched them before the main loop (one exposed cold-L2 round trip less in a workgroup's life, measured then as
+  // 2 us per launch) -- at the price of 32 registers through the loop; with the 4-group batches above the kernels are
+  // at 76 + 32 registers = four waves per SIMD without them, and other workgroups cover the round trip: same-box A/B
+  // dSprites 0.525 -> 0.517 ms, Shapes3D 0.574 -> 0.567
+  {
+    const OdinRun RX = odin_run(p.aux != nullptr ? p.aux : p.in,
+                                p.aux != nullptr ? (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4) : 0u);
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int po = rowoff[(rr & 3) + 8 * (rr >> 2) + 4 * h];
+      const unsigned ok = (unsigned)b_ok & (((unsigned)po >> 31) ^ 1u);
+      ooff[rr] = (unsigned)((po * p.CO + j) * 4) | (ok - 1u);
+      auxv[rr] = odin_run_load1(RX, ooff[rr]);
+    }
+  }
   if (NW > 1) {
     for (int w = 1; w < NW; ++w) {
 #pragma unroll
