@@ -836,20 +836,42 @@ __global__ __launch_bounds__(GH_NT) void gauss_head_kernel(
   const int u_first = upw > 0 ? ((int)blockIdx.x / npw) * n_part + (int)blockIdx.x % npw : (int)blockIdx.x;
   const int u_step = upw > 0 ? npw : (int)gridDim.x;
   const int u_end = upw > 0 ? ((int)blockIdx.x / npw + 1) * n_part : n_units;
+  // the loads of the NEXT unit are issued before the current one is evaluated (C = 1: +20 registers, still four waves
+  // per SIMD); with more channels the registers are not there and a unit is loaded when it is due
+  constexpr bool PREF = (C == 1);
+  float4 vn[GH_U];
+  float tn[GH_U][C];
+  auto load_unit = [&](int uu, float4 (&vv)[GH_U], float (&tt)[GH_U][C]) {
+    const int b = uu / n_part, part = uu - b * n_part;
+    const int pin = part * ppu + tid / Q;
+    const size_t pbase = (size_t)b * n_pix;
+#pragma unroll
+    for (int u = 0; u < GH_U; ++u) {
+      const int pi = pin + u * ppg;
+      const bool ok = pi < n_pix && uu < u_end;
+      const size_t p = pbase + pi;
+      vv[u] = ok ? h[p * Q + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < C; ++c) tt[u][c] = ok ? target[p * C + c] : 0.f;
+    }
+  };
+  if (PREF && u_first < u_end) load_unit(u_first, vn, tn);
   for (int u0 = u_first; u0 < u_end; u0 += u_step) {
     const int b = u0 / n_part, part = u0 - b * n_part;
     const int pin = part * ppu + tid / Q;          // pixel inside the sample (of group 0)
     const size_t pbase = (size_t)b * n_pix;
     float4 v[GH_U];
     float t[GH_U][C];
+    if (PREF) {
 #pragma unroll
-    for (int u = 0; u < GH_U; ++u) {
-      const int pi = pin + u * ppg;
-      const bool ok = pi < n_pix;
-      const size_t p = pbase + pi;
-      v[u] = ok ? h[p * Q + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < GH_U; ++u) {
+        v[u] = vn[u];
 #pragma unroll
-      for (int c = 0; c < C; ++c) t[u][c] = ok ? target[p * C + c] : 0.f;
+        for (int c = 0; c < C; ++c) t[u][c] = tn[u][c];
+      }
+      load_unit(u0 + u_step, vn, tn);
+    } else {
+      load_unit(u0, v, t);
     }
     float llk = 0.f;
 #pragma unroll
