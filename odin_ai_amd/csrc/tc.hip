@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void tc_prep_kernel(const float* z, const floa
 // of posteriors i the log-sum-exps run over (the GLOBAL batch).  LDS: lp[D][B] (log q(z_j | x_i)
 // per latent), S[B], wS[B].  Outputs: logqz[j], LT[l][j] (log-sum-exp over i per latent), tc_part[j],
 // dz[j][l].
-__global__ __launch_bounds__(256) void tc_rows_kernel(const float* zT, const float* muT, const float* isgT,
+// (1024 threads at B >= 512: the [D][B] row block in LDS -- 92 KB at CelebA size -- allows one workgroup per CU, so
+// the waves that cover its latencies must come from inside it: 256 threads = one wave per SIMD took 79 us, 1024 take ~35)
+__global__ __launch_bounds__(1024) void tc_rows_kernel(const float* zT, const float* muT, const float* isgT,
                                                       const float* lsgT, float* logqz, float* LT,
                                                       float* tc_part, float* dz, const float* coef, int B,
                                                       int D, int Bj) {
@@ -63,9 +65,10 @@ __global__ __launch_bounds__(256) void tc_rows_kernel(const float* zT, const flo
   float* zj = Ll + D;               // [D]
   float* misc = zj + D;             // [8]
   const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int l = tid; l < D; l += 256) zj[l] = zT[(size_t)l * Bj + j];
+  const int NT = (int)blockDim.x, NWV = NT >> 6;
+  for (int l = tid; l < D; l += NT) zj[l] = zT[(size_t)l * Bj + j];
   __syncthreads();
-  for (int i = tid; i < B; i += 256) {
+  for (int i = tid; i < B; i += NT) {
     float s = 0.f;
     for (int l = 0; l < D; ++l) {
       const float d = (zj[l] - muT[(size_t)l * B + i]) * isgT[(size_t)l * B + i];
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void tc_rows_kernel(const float* zT, const flo
   }
   __syncthreads();
   // per-latent log-sum-exp over i: wave w handles l = w, w+4, ...; index D = the joint S
-  for (int l = wave; l <= D; l += 4) {
+  for (int l = wave; l <= D; l += NWV) {
     const float* row = l < D ? lp + (size_t)l * B : S;
     float mx = -3.0e38f;
     for (int i = lane; i < B; i += 64) mx = fmaxf(mx, row[i]);
@@ -98,12 +101,12 @@ __global__ __launch_bounds__(256) void tc_rows_kernel(const float* zT, const flo
     tc_part[j] = lq - t;
     logqz[j] = lq;
   }
-  for (int l = tid; l < D; l += 256) LT[(size_t)l * Bj + j] = Ll[l];
-  for (int i = tid; i < B; i += 256) wS[i] = odin_exp(S[i] - lq);
+  for (int l = tid; l < D; l += NT) LT[(size_t)l * Bj + j] = Ll[l];
+  for (int i = tid; i < B; i += NT) wS[i] = odin_exp(S[i] - lq);
   __syncthreads();
   // dz[j,l] = coef/B * sum_i (wj[i] - wl[i,l]) * (-(z_j - mu_i)/sg_i^2)
   const float cf = coef[0] / (float)B;
-  for (int l = wave; l < D; l += 4) {
+  for (int l = wave; l < D; l += NWV) {
     float acc = 0.f;
     const float zz = zj[l], ll = Ll[l];
     for (int i = lane; i < B; i += 64) {
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void tc_rows_kernel(const float* zT, const flo
 // evaluated (all of them on one GPU; the local shard under data parallelism, where the partial
 // sums of the ranks are then reduce-scattered).  Bn = global batch (the estimator's 1/B).
 // LDS: Sw[Bj] (= w_joint[j, i]), the D parameters of posterior i.
-__global__ __launch_bounds__(256) void tc_cols_kernel(const float* zT, const float* muT, const float* isgT,
+__global__ __launch_bounds__(1024) void tc_cols_kernel(const float* zT, const float* muT, const float* isgT,
                                                       const float* lsgT, const float* logqz,
                                                       const float* LT, float* dloc, float* dscale,
                                                       const float* coef, int B, int D, int Bn) {
@@ -130,13 +133,14 @@ __global__ __launch_bounds__(256) void tc_cols_kernel(const float* zT, const flo
   float* is = mu + D;        // [D]
   float* ls = is + D;        // [D]
   const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int l = tid; l < D; l += 256) {
+  const int NT = (int)blockDim.x, NWV = NT >> 6;
+  for (int l = tid; l < D; l += NT) {
     mu[l] = muT[(size_t)l * Bn + i];
     is[l] = isgT[(size_t)l * Bn + i];
     ls[l] = lsgT[(size_t)l * Bn + i];
   }
   __syncthreads();
-  for (int j = tid; j < B; j += 256) {
+  for (int j = tid; j < B; j += NT) {
     float s = 0.f;
     for (int l = 0; l < D; ++l) {
       const float d = (zT[(size_t)l * B + j] - mu[l]) * is[l];
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void tc_cols_kernel(const float* zT, const flo
   }
   __syncthreads();
   const float cf = coef[0] / (float)Bn;
-  for (int l = wave; l < D; l += 4) {
+  for (int l = wave; l < D; l += NWV) {
     const float m = mu[l], s1 = is[l], lsg = ls[l];
     float a1 = 0.f, a2 = 0.f;
     for (int j = lane; j < B; j += 64) {
@@ -267,9 +271,11 @@ static int tc_launch(const float* z, const float* p, float* tc_out, float* dz, f
   const int nmax = (Bi > Bj ? Bi : Bj) * D;
   ODIN_LAUNCH(tc_prep_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, z, p, muT, isgT, lsgT, zT, Bj, Bi, D);
   // rows: coefficient coef/Bi inside (cf = coef[0] / B with B = Bi)
-  ODIN_LAUNCH(tc_rows_kernel, dim3(Bj), dim3(256), lds, stream, (const float*)zT, (const float*)muT,
+  const int nt_rows = Bi >= 512 ? 1024 : Bi >= 256 ? 512 : 256;   // threads ~ posteriors per row, <= 1024
+  const int nt_cols = Bj >= 512 ? 1024 : Bj >= 256 ? 512 : 256;
+  ODIN_LAUNCH(tc_rows_kernel, dim3(Bj), dim3(nt_rows), lds, stream, (const float*)zT, (const float*)muT,
               (const float*)isgT, (const float*)lsgT, logqz, LT, part, dz, coef, Bi, D, Bj);
-  ODIN_LAUNCH(tc_cols_kernel, dim3(Bi), dim3(256), (size_t)(Bj + 3 * D) * 4, stream, (const float*)zT,
+  ODIN_LAUNCH(tc_cols_kernel, dim3(Bi), dim3(nt_cols), (size_t)(Bj + 3 * D) * 4, stream, (const float*)zT,
               (const float*)muT, (const float*)isgT, (const float*)lsgT, (const float*)logqz, (const float*)LT,
               dloc, dscale, coef, Bj, D, Bi);
   ODIN_LAUNCH(sum_div_kernel, dim3(1), dim3(256), 0, stream, (const float*)part, Bj, tc_out, (float)Bi);
