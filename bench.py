@@ -393,6 +393,49 @@ def north_star_3ch(device, steps=50):
   return res
 
 
+def exact_fp32_step(device, workload='dsprites_betavae_b256', steps=50):
+  """The same step with EVERY layer on the exact fp32 matrix-core kernels (ODIN_EXACT_FP32=1: no f16-plane kernel; the
+  arithmetic of the reference's fp32 Keras layers, image_networks.py:460-513), timed in the same process: what the
+  two-plane substitution of the headline line is worth.  The switch is read when a launch is issued, so it is set
+  while this engine is built, captured and replayed, and removed afterwards."""
+  from odin_ai_amd.engine import VAEEngine
+  from odin_ai_amd.networks import get_networks
+  ds, kw, B, beta, kind = WORKLOADS[workload]
+  nets = get_networks(ds, **kw)
+  enc, dec = nets['encoder'].layers, nets['decoder'].layers
+  in_shape, zdim = nets['encoder'].input_shape, nets['latents'].event_shape[0]
+  had = os.environ.get('ODIN_EXACT_FP32')
+  os.environ['ODIN_EXACT_FP32'] = '1'
+  try:
+    eng = VAEEngine(enc, dec, in_shape, zdim, B, device, observation=nets['observation'].posterior, seed=5)
+    init_params_(eng, seed=5)
+    xb = eng.input_buffer()
+    xb.copy_(synthetic_batch(workload, B, in_shape, device, seed=105))
+    step = lambda: eng.train_step(xb, None, lr=1e-3, beta=beta, global_clipnorm=100.0, use_graph=True)
+    for _ in range(30):
+      step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert math.isfinite(out[0].item()) and eng.flag.item() == 0
+    paths = sorted({o.get('path', '') for o in profile_ops(eng)})
+    assert not any(p.endswith('(f16x2)') for p in paths), paths
+  finally:
+    if had is None:
+      del os.environ['ODIN_EXACT_FP32']
+    else:
+      os.environ['ODIN_EXACT_FP32'] = had
+  res = dict(workload=workload, ms_per_step=round(dt / steps * 1e3, 4), images_per_sec=round(B * steps / dt, 1),
+             steps=steps, kernel_families=paths,
+             note='ODIN_EXACT_FP32=1: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 everywhere (IEEE fp32 products)')
+  del eng
+  torch.cuda.empty_cache()
+  return res
+
+
 def _free_port():
   import socket
   s = socket.socket()
@@ -498,6 +541,8 @@ def main():
   ap.add_argument('--no-north-star-3ch', action='store_true',
                   help='skip the 64x64x3 beta-VAE (Shapes3D networks) measurement added to the default line')
   ap.add_argument('--no-fit', action='store_true', help='skip the fit()-level throughput measurement')
+  ap.add_argument('--no-exact-fp32', action='store_true',
+                  help='skip the second engine that times the step on the exact fp32 kernels (ODIN_EXACT_FP32=1)')
   ap.add_argument('--profile-ops', action='store_true', help='print a per-kernel timing table')
   ap.add_argument('--dry-run', action='store_true',
                   help='launcher / rendezvous self-test on CPU (gloo): no kernels, no GPU')
@@ -848,6 +893,19 @@ def main():
     fit_tp = fit_throughput(device)
     for v in fit_tp.values():
       v['frac_of_step_replay'] = round(v['images_per_sec'] / (B * args.steps / dt), 4)
+  exact = None
+  if world == 1 and args.workload == 'dsprites_betavae_b256' and not args.no_exact_fp32 and use_graph:
+    exact = exact_fp32_step(device)
+  # step-level HBM roofline: bytes of ALL launches of one step (PMC passes, committed table) / step time / 8 TB/s
+  hbm_step = None
+  ent = pmc.get('step')
+  if ent is not None and args.workload == 'dsprites_betavae_b256' and world == 1:
+    bps = ent['traffic_bytes']
+    hbm_step = dict(bytes_per_step=bps, launches=ent.get('launches'),
+                    achieved=round(bps / (dt / args.steps) * 1e-9, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                    frac=round(bps / (dt / args.steps) * 1e-9 / PEAK_HBM_GBS, 4),
+                    floor_ms=round(bps / (PEAK_HBM_GBS * 1e9) * 1e3, 4),
+                    source='profiles/' + os.path.basename(pmc_file), measured_in_this_run=False)
   res = dict(metric='VAE train images/sec', value=round(B * world * args.steps / dt, 1),
              unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
              ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling='weak',
@@ -865,6 +923,11 @@ def main():
              elbo_kernel=hbm[0],
              hbm_kernels=hbm,
              north_star_3ch=ns3)
+  if exact is not None:
+    exact['headline_over_exact'] = round(exact['ms_per_step'] / (dt / args.steps * 1e3), 3)
+    res['exact_fp32'] = exact
+  if hbm_step is not None:
+    res['hbm'] = hbm_step
   if fit_tp is not None:
     res['fit_images_per_sec'] = fit_tp['device_dataset']['images_per_sec']
     res['fit'] = fit_tp

@@ -40,9 +40,11 @@ typedef struct odin_conv_desc {
    * BIT PATTERN of an upper bound of max|t| of a gradient tensor t; the caller zeroes the words once per step
    * (odin_range_reset), producers fold their outputs in with one atomicMax per workgroup, consumers scale t by an
    * exact power of two on its way into the planes.  dy_amax: word of dy (this layer's pre-activation gradient) -- read by the data / weight gradient,
-   * written by the fused tail that produces dy.  dx_amax: word of dx -- written by the data gradient when its kernel
-   * family keeps one (odin_*_dgrad_keeps_range), untouched otherwise.  A consumer without a word computes the bound
-   * itself (odin_absmax: one extra pass over the tensor), and only if it is a plane kernel. */
+   * written by the fused tail that produces dy.  dx_amax: word of dx -- CONTRACT (round 5): a data gradient (and the
+   * fused tail for dy_amax) that is handed a word leaves a valid bound in it whatever kernel family ran: folded in from
+   * the kernel's epilogue where the family tracks its outputs (odin_*_dgrad_keeps_range = 1: free), by one extra pass
+   * over the tensor otherwise.  A consumer without a word computes the bound itself (odin_absmax: one extra pass over
+   * the tensor), and only if it is a plane kernel. */
   uint32_t* dy_amax;
   uint32_t* dx_amax;
 } odin_conv_desc;
@@ -58,9 +60,9 @@ const char* odin_debug_last_path(void);
 uint32_t odin_crc32c(uint32_t crc, const void* data, size_t n);
 const char* odin_last_error(void);
 int odin_max_slab_rows(void);      /* upper bound of the rows any slab-producing call writes */
-/* Which producers keep a range word: 1 when the data gradient of layer `d` (dispatched for aux_act, aux present) /
- * the fused tail folds max|dx| / max|g_out| into d->dx_amax / d->dy_amax itself.  A caller hands a word to the
- * CONSUMERS of a tensor (their d->dy_amax) only when its producer keeps it; otherwise it passes NULL there. */
+/* Which producers keep a range word WITHOUT an extra pass: 1 when the data gradient of layer `d` (dispatched for
+ * aux_act, aux present, no oversized column-sum slab) / the fused tail folds max|dx| / max|g_out| into d->dx_amax /
+ * d->dy_amax from its own epilogue.  Informational since round 5 (cost model, tests): the word is valid either way. */
 int odin_conv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_act);
 int odin_deconv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_act);
 int odin_bernoulli_tail_keeps_range(int is_deconv, const odin_conv_desc* d, int C1);
@@ -117,7 +119,8 @@ int odin_deconv2d_bwd(const float* x, const float* dy, const float* w, const flo
                       float* colsum_slab, int* colsum_rows_out, float* wslab, int* wslab_rows_out,
                       const odin_conv_desc* d, void* stream);
 /* Dense: either half may be left out (want_wgrad / want_dgrad); dy_amax / dx_amax are the optional range words of dy
- * (read) and dx (written when odin_dense_dgrad_keeps_range(B, K, N) = 1) -- layers with both widths >= 256 run on the
+ * (read) and dx (written: from the epilogue when odin_dense_dgrad_keeps_range(B, K, N) = 1, by one extra pass
+ * otherwise) -- layers with both widths >= 256 run on the
  * f16 matrix pipe as two planes (dense_h.hip) like the 4x4/s2 convolutions. */
 int odin_dense_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
                    float* colsum_slab, int* colsum_rows_out, float* wslab, int* wslab_rows_out, int B, int K,

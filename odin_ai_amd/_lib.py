@@ -118,8 +118,9 @@ SIGNATURES = {
 # entry points whose return value is a result, not an error code
 VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_conv2d_dgrad_keeps_range',
                    'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_dense_dgrad_keeps_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
-                   'odin_latent_block_rows', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop',
-                   'odin_wgrad_planes_defer_begin')
+                   'odin_latent_block_rows', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop')
+# entry points declared `void` in include/odin_hip.h
+VOID_RETURNING = ('odin_wgrad_planes_defer_begin',)
 
 
 class OdinError(RuntimeError):
@@ -143,6 +144,7 @@ class Lib:
       fn.argtypes = args
       fn.restype = (C.c_char_p if name in ('odin_debug_last_path', 'odin_comm_library') else
                     C.c_double if name == 'odin_debug_igemm_h_min_flop' else
+                    None if name in VOID_RETURNING else
                     C.c_uint32 if name in VALUE_RETURNING else C.c_int)
 
   def check(self, rc: int, what: str = ''):
@@ -166,6 +168,8 @@ class Lib:
           import torch
           if torch.cuda.is_available():
             torch.cuda.synchronize()
+        if name in VOID_RETURNING:
+          return None
         if rc != 0 and name not in VALUE_RETURNING:
           raise OdinError(f"{name} failed: {self.c.odin_last_error().decode()} (rc={rc})")
         return rc

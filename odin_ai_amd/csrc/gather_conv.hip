@@ -1633,13 +1633,19 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
 
 // dx[b,ih,iw,ci] = sum_{kh,kw,co} dy[b,(ih+pt-kh)/S,(iw+pl-kw)/S,co] * W[kh,kw,ci,co];
 // optionally multiplied by act'(aux) (aux = this layer's input = previous layer's output)
-// Kernel families that do not keep the range word of dx leave it untouched: the caller learns which layers do
-// from odin_conv2d_dgrad_keeps_range / odin_deconv2d_dgrad_keeps_range below and hands a word to the consumers of dx
-// only then (a consumer without a word bounds the tensor itself, and only if it is a plane kernel).
-static int track_dx(int rc, const float*, const odin_conv_desc*, void*) { return rc; }
+// THE CONTRACT: a data gradient that is handed a word (d->dx_amax) leaves a valid bound of dx in it, whatever kernel
+// family ran.  The plane / implicit-GEMM families fold max|dx| in from their epilogues (free); every other family
+// (generic gather, 1x1 stream kernel, the fp32 ring kernels) is followed by ONE absmax pass over dx here.  Round 4
+// left those words untouched and told the caller through the *_keeps_range predicates below -- a predicate that
+// disagreed with the dispatch (a column-sum slab sends a layer of > 16384 tiles to the generic kernel) handed the
+// consumers a ZERO word: they scaled by 2^115 and overflowed.  The predicates remain as "kept without an extra pass".
+static int track_dx(int rc, const float* dx, const odin_conv_desc* d, void* stream) {
+  if (rc != 0 || dx == nullptr || d->dx_amax == nullptr) return rc;
+  return odin_absmax_fold(dx, (size_t)d->B * d->H * d->W * d->Cin, d->dx_amax, stream);
+}
 
-// 1: the data gradient of this layer (as dispatched for `aux_act`, with the aux tensor present) folds max|dx| into
-// d->dx_amax itself
+// 1: the data gradient of this layer (as dispatched for `aux_act`, with the aux tensor present and NO column-sum slab
+// beyond ODIN_MAX_COLSUM_BLOCKS tiles) folds max|dx| into d->dx_amax in its own epilogue; 0: by a pass of its own
 extern "C" int odin_conv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_act) {
   if (odin_pw1x1_applicable(d)) return 0;
   if (aux_act == ODIN_ACT_ELU && d->H == 2 * d->OH && d->W == 2 * d->OW &&
@@ -1836,8 +1842,13 @@ bool odin_dense_dgrad_tracks(int B, int K, int N) {
 int odin_dense_dgrad_ranged(const float* dy, const float* w, const float* aux, int aux_act, float* dx,
                             float* colsum_slab, int* slab_rows_out, int B, int K, int N, const uint32_t* dy_amax,
                             uint32_t* dx_amax, void* stream) {
+  // (the same contract as the convolutions' track_dx: a word that is handed in is valid on return)
+  auto fold = [&](int rc) {
+    if (rc != 0 || dx == nullptr || dx_amax == nullptr) return rc;
+    return odin_absmax_fold(dx, (size_t)B * K, dx_amax, stream);
+  };
   if (odin_tiny_dense_ok(B, K, N))
-    return odin_tiny_dense_dgrad(dy, w, aux, aux_act, dx, colsum_slab, slab_rows_out, B, K, N, stream);
+    return fold(odin_tiny_dense_dgrad(dy, w, aux, aux_act, dx, colsum_slab, slab_rows_out, B, K, N, stream));
   if (colsum_slab == nullptr && odin_dense_h_ok(B, K, N)) {
     if (slab_rows_out) *slab_rows_out = 0;
     if (dx == nullptr) return 0;
@@ -1860,8 +1871,8 @@ int odin_dense_dgrad_ranged(const float* dy, const float* w, const float* aux, i
   p.in = dy; p.w = w; p.out = dx; p.aux = aux; p.aux_act = aux_act; p.colsum_slab = colsum_slab;
   p.B = B; p.H = 1; p.W = 1; p.CI = N; p.OH = 1; p.OW = 1; p.CO = K;
   p.KH = p.KW = 1; p.S = 1; p.wmode = 1;
-  return launch_gather(MODE_F, p, stream, colsum_slab ? -ODIN_MAX_COLSUM_BLOCKS : odin_num_cus(),
-                       slab_rows_out);
+  return fold(launch_gather(MODE_F, p, stream, colsum_slab ? -ODIN_MAX_COLSUM_BLOCKS : odin_num_cus(),
+                            slab_rows_out));
 }
 
 // ---- fused decoder tail: (Conv2DTranspose | Conv2D)(act) -> Conv2D 1x1 linear (C1<=4 maps)
@@ -1872,6 +1883,12 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
                                            float* llk_part, int* n_part_out, float* tail_slab,
                                            int* slab_rows_out, const float* scale,
                                            const odin_conv_desc* d, int C1, void* stream) {
+  // (the range contract: a word handed in as d->dy_amax bounds g_out on return -- the plane kernel folds it in from
+  // its epilogue, the other families are followed by one pass)
+  auto tail_fold = [&](int rc) {
+    if (rc != 0 || g_out == nullptr || d->dy_amax == nullptr) return rc;
+    return odin_absmax_fold(g_out, (size_t)d->B * d->OH * d->OW * d->Cout, d->dy_amax, stream);
+  };
   if (is_deconv && d->act == ODIN_ACT_ELU && d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_tconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
                                    d->pad_l, d->center, 3, C1))
@@ -1882,9 +1899,9 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
       d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_tconv_ring_applicable(d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
                                  d->pad_l, d->center))
-    return odin_tconv_ring_launch(x, w, bias, nullptr, g_out, nullptr, slab_rows_out, w1, b1, target,
-                                  logits, llk_part, n_part_out, tail_slab, scale, C1, d->B, d->H, d->W,
-                                  d->Cout, 3, stream);
+    return tail_fold(odin_tconv_ring_launch(x, w, bias, nullptr, g_out, nullptr, slab_rows_out, w1, b1, target,
+                                            logits, llk_part, n_part_out, tail_slab, scale, C1, d->B, d->H, d->W,
+                                            d->Cout, 3, stream));
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = g_out;
@@ -1896,7 +1913,7 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
   int rc = launch_gather(is_deconv ? MODE_T : MODE_F, p, stream, -ODIN_MAX_COLSUM_BLOCKS,
                          slab_rows_out, &tp);
   if (n_part_out) *n_part_out = p.OH / (p.TR > 0 ? p.TR : 1);  // log-likelihood parts per sample
-  return rc;
+  return tail_fold(rc);
 }
 
 // diagnostics: device buffer (>= 64 int64) receiving s_memtime stamps of workgroup 0

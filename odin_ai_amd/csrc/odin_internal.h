@@ -26,6 +26,9 @@ int odin_num_cus();
 // range word of a gradient tensor (include/odin_hip.h: odin_conv_desc.dy_amax): the caller's word, or a scratch
 // word filled by one pass over the tensor; nullptr on failure
 const uint32_t* odin_range_word_of(const float* t, size_t n, const uint32_t* given, void* stream);
+// fold max|t| into `word` with one pass (a producer whose kernel family does not track its outputs); counted by
+// odin_debug_absmax_fallbacks
+int odin_absmax_fold(const float* t, size_t n, uint32_t* word, void* stream);
 
 // first-layer (Cin <= 4) convolutions on the vector ALUs (smallc_conv.hip)
 bool odin_smallc_applicable(const odin_conv_desc* d);

@@ -77,15 +77,23 @@ extern "C" int odin_version(void) { return 103; }
 // ---- range words of gradient tensors (odin_device.h: odin_range_shift) -----------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ t, size_t n, unsigned* word) {
-  const size_t n4 = n >> 2;
-  const float4* t4 = reinterpret_cast<const float4*>(t);
+  // (a tensor that does not start on a 16-byte boundary -- a view into a flat buffer -- is walked from its first
+  // aligned element; workgroup 0 takes the unaligned head and the tail)
+  const size_t head = (size_t)((4u - (unsigned)(((uintptr_t)t >> 2) & 3u)) & 3u) < n
+                          ? (size_t)((4u - (unsigned)(((uintptr_t)t >> 2) & 3u)) & 3u) : n;
+  const size_t n4 = (n - head) >> 2;
+  const float4* t4 = reinterpret_cast<const float4*>(t + head);
   float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const float4 v = t4[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     // (fmaxf drops NaNs: a NaN element propagates through the consumer's arithmetic, not through its scale)
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(t[(n4 << 2) + threadIdx.x]));
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < head) m = fmaxf(m, fabsf(t[threadIdx.x]));
+    const size_t done = head + (n4 << 2);
+    if (threadIdx.x < n - done) m = fmaxf(m, fabsf(t[done + threadIdx.x]));
+  }
   __shared__ float red[16];
   odin_amax_commit_wg(word, m, threadIdx.x, 256, red, blockIdx.x);
 }
@@ -96,7 +104,7 @@ __global__ void range_zero_kernel(unsigned* word) { word[threadIdx.x * ODIN_RANG
 __global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
 }
-constexpr int RANGE_SCRATCH_BLOCKS = 16;
+constexpr int RANGE_SCRATCH_BLOCKS = 64;
 #ifdef ODIN_SIM
 unsigned g_range_scratch[RANGE_SCRATCH_BLOCKS * ODIN_RANGE_WORDS];
 #else
@@ -127,15 +135,32 @@ extern "C" int odin_absmax(const float* t, size_t n, uint32_t* word, void* strea
   return odin_check_launch("absmax");
 }
 
-static int g_absmax_fallbacks = 0;
-extern "C" int odin_debug_absmax_fallbacks(void) { return g_absmax_fallbacks; }
+#include <atomic>
+static std::atomic<int> g_absmax_fallbacks{0};
+extern "C" int odin_debug_absmax_fallbacks(void) { return g_absmax_fallbacks.load(); }
 
-// the word a consumer reads: the caller's, or a library scratch word filled by one pass over the tensor (a ring of
-// 16 words: launches on one stream are ordered, and 16 launches later the word's reader has long finished)
+// producer side of the range contract (gather_conv.hip: track_dx): a kernel family that does not track its outputs
+// is followed by one pass that folds max|t| into the caller's word (atomicMax: the word keeps what it already holds)
+int odin_absmax_fold(const float* t, size_t n, uint32_t* word, void* stream) {
+  ++g_absmax_fallbacks;
+  return odin_absmax(t, n, word, stream);
+}
+
+// the word a consumer reads: the caller's, or a library scratch word filled by one pass over the tensor.  The
+// scratch words are a ring of 64 per device (a __device__ array has one address PER DEVICE: resolved for the current
+// device, not cached from the first), its position one process-wide atomic counter: launches on one stream are
+// ordered, and 64 fallbacks later the word's reader has long finished.  Callers that spread consumers over several
+// streams hand their own words (the engine always does).
 const uint32_t* odin_range_word_of(const float* t, size_t n, const uint32_t* given, void* stream) {
   if (given != nullptr) return given;
-  static unsigned* base = nullptr;
-  static int next = 0;
+  constexpr int MAX_DEV = 16;
+  static std::atomic<unsigned*> bases[MAX_DEV] = {};
+  static std::atomic<unsigned> next{0};
+  int dev = 0;
+#ifndef ODIN_SIM
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) { (void)hipGetLastError(); return nullptr; }
+#endif
+  unsigned* base = bases[dev].load();
   if (base == nullptr) {
 #ifdef ODIN_SIM
     base = g_range_scratch;
@@ -144,8 +169,9 @@ const uint32_t* odin_range_word_of(const float* t, size_t n, const uint32_t* giv
     if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_range_scratch)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     base = (unsigned*)q;
 #endif
+    bases[dev].store(base);
   }
-  unsigned* w = base + (size_t)(next++ % RANGE_SCRATCH_BLOCKS) * ODIN_RANGE_WORDS;
+  unsigned* w = base + (size_t)(next.fetch_add(1u) % RANGE_SCRATCH_BLOCKS) * ODIN_RANGE_WORDS;
   ++g_absmax_fallbacks;
   ODIN_LAUNCH(range_zero_kernel, dim3(1), dim3(ODIN_RANGE_SLOTS), 0, stream, w);
   if (odin_absmax(t, n, w, stream) != 0) return nullptr;

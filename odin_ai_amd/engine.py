@@ -157,11 +157,12 @@ class NetProgram:
         self.descs.append(cd)
       else:
         self.descs.append(None)
-    # gouts[i] travels with a word only when its producer keeps one -- the data gradient of layer i + 1 on a kernel
-    # family that tracks its output (include/odin_hip.h: odin_*_dgrad_keeps_range); produced by anything else (ELBO
-    # kernel, Dense, latent block, generic kernels) the consumers are told nothing: a plane kernel then bounds the
-    # tensor itself, the others never look
-    self.dy_word = [self.word(i) if self.dgrad_keeps_range(i + 1) else None for i in range(len(recs))]
+    # gouts[i] travels with its word whenever a library data gradient produced it: the data gradient of layer i + 1 is
+    # handed word(i) as dx_amax and leaves a valid bound there whatever kernel family ran (include/odin_hip.h: the
+    # range contract of round 5; round 4 relied on the *_keeps_range predicates agreeing with the dispatch -- they
+    # did not for a column-sum slab on a large layer, and a zero word overflowed the consumers).  The top gradient
+    # (ELBO kernel / fused tail / head / latent block) is the caller's: set_top_word
+    self.dy_word = [self.word(i) if i + 1 < len(recs) else None for i in range(len(recs))]
     self.dx_word = [self.word(i - 1) if i > 0 else None for i in range(len(recs))]   # (Dense layers: odin_dense_bwd)
     for i, cd in enumerate(self.descs):
       if cd is not None:
@@ -195,6 +196,19 @@ class NetProgram:
     if self.descs[n] is not None:
       self.descs[n].dy_amax = self.dy_word[n]
     return self.dy_word[n]
+
+  def check_range_words(self, upto: Optional[int] = None) -> None:
+    """Debug / tests (synchronises): every word handed to a consumer bounds its tensor -- call between backward() and
+    the slab reduction that clears the words (NetProgram.backward alone does not clear them)."""
+    n = len(self.recs) if upto is None else upto
+    for i in range(n):
+      if self.dy_word[i] is None:
+        continue
+      blk = self.range_words[RANGE_WORDS * i:RANGE_WORDS * (i + 1)]
+      bound = float(blk.view(torch.float32).max().item())
+      t = self.gouts[i]
+      m = float(torch.nan_to_num(t, nan=0.0, posinf=0.0, neginf=0.0).abs().max().item())
+      assert bound >= m, f'range word of gouts[{i}] ({self.recs[i].kind}): {bound} < max|t| = {m}'
 
   def dgrad_keeps_range(self, j: int) -> bool:
     """does the data gradient of layer j fold max |gouts[j - 1]| into its range word itself?"""
@@ -499,6 +513,7 @@ class VAEEngine:
       self._ring = [t.pin_memory() for t in self._ring]
     self._ring_i = 0
     self.hyper = torch.zeros(N_HYPER + 4, **f32)
+    self._skip_hyper_copy = __import__('os').environ.get('ODIN_SKIP_HYPER_COPY', '0') == '1'
     self.step_count = 0
     self.side_stream = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
     n_side = int(__import__('os').environ.get('ODIN_SIDE_STREAMS', '2'))
@@ -522,6 +537,9 @@ class VAEEngine:
     self.overlap_wgrad = {'0': None, '1': 'all', 'all': 'all', 'small': 'small'}.get(
         _os.environ.get('ODIN_OVERLAP_WGRAD', '0'), None)
     self.graph = None
+    # tests / debugging: verify every range word against its tensor before the slab reduction clears the words
+    # (synchronises; NetProgram.check_range_words)
+    self.debug_check_ranges = False
     self._jobs_keepalive = None
     # data parallel: collectives through `dist.Comm` (RCCL via the C ABI on a GPU); gradient buckets:
     # 2 = the decoder's share of the flat gradient buffer is all-reduced on a side stream while the
@@ -699,6 +717,8 @@ class VAEEngine:
     h[N_HYPER:].view(torch.int32)[1] = int(skip_enable)
     # (leaving this 80-byte copy out of the steady state was measured: 0.7182 vs 0.7180 ms per step -- the
     # idle time between two graph launches does not come from it)
+    if self._skip_hyper_copy and self.step_count > 60:
+      return  # (diagnostics, ODIN_SKIP_HYPER_COPY=1: what the 80-byte copy costs between two step graphs)
     self.hyper.copy_(h, non_blocking=True)
     if self.device.type == 'cuda':
       ev = torch.cuda.Event()
@@ -799,13 +819,13 @@ class VAEEngine:
       # gouts[-2] comes from the fused tail (which keeps the range word on the plane kernel) or, unfused, from the
       # 1x1 head's data gradient
       nd2 = len(self.dec_recs) - 2
-      keeps = self.tail_keeps_range if fused else self.dec.dgrad_keeps_range(nd2 + 1)
-      self.dec.descs[nd2].dy_amax = self.dec.word(nd2) if keeps else None
+      # (always kept: by the fused tail for its g_out, by the 1x1 head's data gradient otherwise -- the range contract)
+      self.dec.descs[nd2].dy_amax = self.dec.word(nd2)
     self._used_head = False
     if self.gauss_head:
       # gouts[-2] comes from the fused head (which keeps its range word) or from the 1x1 head's data gradient
       nd2 = len(self.dec_recs) - 2
-      self.dec.set_top_word(True if fused else self.dec.dgrad_keeps_range(nd2 + 1), nd2)
+      self.dec.set_top_word(True, nd2)
     if self.gauss_head and fused:
       nd = len(self.dec_recs)
       hm = self.dec.forward(dec_in, st, upto=nd - 1, start=dec_start)
@@ -1048,7 +1068,7 @@ class VAEEngine:
       auxp = h_e.data_ptr() if aux_act != 0 else None
       bslab = self.enc.bslabs[-1]
       # (the projection's data gradient keeps the range word of the encoder's top gradient where its kernel family does)
-      top = self.enc.set_top_word(bslab is None and bool(lib.odin_dense_dgrad_keeps_range(B, self.hdim, 2 * D)))
+      top = self.enc.set_top_word(True)
       lib.odin_dense_bwd(None, self.dp.data_ptr(), lw.data_ptr(), auxp, aux_act, self.enc.gouts[-1].data_ptr(),
                          bslab.data_ptr() if bslab is not None else None, C.byref(rows), None, None, B,
                          self.hdim, 2 * D, 0, 1, None, top, st)
@@ -1066,6 +1086,9 @@ class VAEEngine:
     arr = (ReduceJob * len(jobs))(*jobs)
     self._jobs_keepalive = arr
     lib.odin_wgrad_planes_defer_end(st)   # (no-op unless backward() opened a collection)
+    if self.debug_check_ranges:
+      self.dec.check_range_words()
+      self.enc.check_range_words()
     lib.odin_slab_reduce(arr, len(jobs), st)
 
   # ---- optimiser ---------------------------------------------------------------------

@@ -118,3 +118,18 @@ sineOut = _make('sineOut')
 circle = _make('circle')
 circleIn = _make('circleIn')
 circleOut = _make('circleOut')
+
+
+_KINDS = ('const', 'linear', 'smooth', 'smooth2', 'fade', 'smoother', 'power', 'powerIn', 'powerOut', 'sine', 'sineIn',
+          'sineOut', 'circle', 'circleIn', 'circleOut')
+
+
+def get(name=None):
+  """odin.backend.interpolation.get (interpolation.py:420-428): the constructor registered under `name`, or all of
+  them (sorted by name) for None; an unknown name raises (the reference: KeyError from its dictionary)."""
+  table = {k: globals()[k] for k in _KINDS if k in globals()}
+  if name is None:
+    return [v for _, v in sorted(table.items())]
+  if name not in table:
+    raise KeyError(f"unknown interpolation {name!r} (known: {', '.join(sorted(table))})")
+  return table[name]

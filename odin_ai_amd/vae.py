@@ -959,7 +959,7 @@ class BetaCapacityVAE(VariationalAutoencoder):
                interpolation: str = 'linear', name='BetaCapacityVAE', **kwargs):
     from . import interpolation as interp
     self.gamma = float(gamma)
-    self.interpolation = getattr(interp, str(interpolation))(vmin=float(c_min), vmax=float(c_max), steps=int(n_steps))
+    self.interpolation = interp.get(str(interpolation))(vmin=float(c_min), vmax=float(c_max), steps=int(n_steps))
     super().__init__(name=name, **kwargs)
     self._capacity_mode = True
     self._engines.clear()

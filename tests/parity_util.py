@@ -94,10 +94,12 @@ def check_engine_vs_oracle(eng, model: vo.OracleVAE, P, x, eps, beta, lr=1e-3, t
       good = np.abs(G[k]) > 1e-3 * np.abs(G[k]).max()
       assert d[good].max() <= tol, (t, 'param', k, d[good].max())
       assert d.mean() <= 5e-3 * lr, (t, 'param-mean', k, d.mean())
-      # reported next to the masked check: the UNMASKED maximum; bounded by ~2*lr
-      # (an ill-conditioned element can at worst flip the sign of its normalised update)
+      # reported next to the masked check: the UNMASKED maximum; bounded by 2*lr per step
+      # (an ill-conditioned element can at worst flip the sign of its normalised update).  This bound is the
+      # weakest of the three -- the sharp test of the update is the 2e-6 Adam-kernel check above, on identical
+      # gradients; the masked 1e-4 check is the north-star comparison against the float64 trajectory
       unmasked = max(unmasked, float(d.max()))
-      assert d.max() <= 2.5 * lr * t, (t, 'param-unmasked', k, d.max())
+      assert d.max() <= 2.0 * lr * t + 1e-6, (t, 'param-unmasked', k, d.max())
     report_unmasked = unmasked
     # continue from the oracle's parameters so that errors do not compound in the check
   report['param_unmasked_max'] = report_unmasked

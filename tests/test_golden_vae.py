@@ -73,12 +73,34 @@ def test_hip_engine_matches_frozen_vectors(name):
   gtol = 1e-3 if 'tc_beta' in kw else 1e-4   # (TC conditioning: tests/test_gpu_parity.py)
   for k, v in eng.grad_views().items():
     _digest_close(v.cpu().numpy(), g['grad/' + '/'.join(map(str, k))], gtol)
+  # The optimiser, in three checks of decreasing sharpness:
+  #  (1) THE test of the Adam kernel: Keras-Adam in float64 on the ENGINE's own gradients must reproduce the
+  #      engine's parameters to 2e-6 -- a sign error or a wrong epsilon placement cannot pass this;
+  #  (2) against the frozen float64 trajectory, elements whose gradient is well conditioned
+  #      (|g| > 1e-3 max|g|: Adam normalises every update to ~lr, so a tiny gradient amplifies fp32 rounding to a
+  #      whole step) must agree to 1e-4, the north-star tolerance;
+  #  (3) the rest is bounded by the worst case of (2)'s exclusion -- a flipped normalised update, 2 lr -- and the
+  #      mean error over the samples by 0.5 % of lr.
+  lr = 1e-3
+  gv = {k: v.cpu().numpy().astype(np.float64) for k, v in eng.grad_views().items()}
+  p0 = {k: v.cpu().numpy().astype(np.float64) for k, v in eng.param_views().items()}
+  keys = list(p0)
+  gn = vo.global_norm([gv[k] for k in keys])
+  gs = 100.0 / max(gn, 100.0)
   eng.adam(global_clipnorm=100.0)
   for k, v in eng.param_views().items():
+    pk, _, _ = vo.adam_keras(p0[k], gv[k] * gs, np.zeros_like(p0[k]), np.zeros_like(p0[k]), 1, lr)
+    assert np.abs(v.cpu().numpy() - pk).max() <= 2e-6 * max(1.0, np.abs(pk).max()), ('adam-kernel', k)
     want = g['param/' + '/'.join(map(str, k))]
+    gwant = g['grad/' + '/'.join(map(str, k))]
     got = gen.digest(v.cpu().numpy())
-    assert np.abs(got[3:] - want[3:]).max() <= 2.5e-3  # Adam step = lr = 1e-3 per element at t = 1
-    assert np.abs(got[3:] - want[3:]).mean() <= 1e-4
+    err = np.abs(got[3:] - want[3:])
+    good = np.abs(gwant[3:]) > 1e-3 * gwant[2]
+    tol = 1e-3 if 'tc_beta' in kw else 1e-4
+    if good.any():
+      assert err[good].max() <= tol, (k, err[good].max())
+    assert err.max() <= 2.0 * lr + 1e-6, (k, err.max())
+    assert err.mean() <= (5e-5 if 'tc_beta' in kw else 5e-6), (k, err.mean())
 
 
 @pytest.mark.gpu

@@ -292,8 +292,13 @@ FULL = [
     ('dsprites_b256_default', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0), {}),
     ('dsprites_b256_fp32_mfma_only', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0),
      {'ODIN_EXACT_FP32': '1'}),
-    ('dsprites_b256_no_overlap', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0),
-     {'ODIN_OVERLAP_WGRAD': '0', 'ODIN_EARLY_REDUCE': '0'}),
+    # the engine's opt-in launch orders (all OFF by default, engine.py): weight gradients of the small layers on side
+    # streams + the decoder's slabs reduced early; every weight gradient on side streams; the plane weight
+    # gradients of the step as one deferred launch -- same arithmetic, other launch order
+    ('dsprites_b256_overlap_small_early_reduce', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0),
+     {'ODIN_OVERLAP_WGRAD': 'small', 'ODIN_EARLY_REDUCE': '1'}),
+    ('dsprites_b256_overlap_all', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0), {'ODIN_OVERLAP_WGRAD': 'all'}),
+    ('dsprites_b256_defer_wgrad', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0), {'ODIN_DEFER_WGRAD': '1'}),
     ('shapes3d_b128', lambda: vo.dsprites_spec(3), 128, dict(beta=1.0), {}),
     ('celeba_b512', lambda: vo.celeba_spec(45, 3), 512, dict(beta=4.0), {}),
     ('celeba_betatc_b512', lambda: vo.celeba_spec(45, 3), 512, dict(beta=4.0, tc_beta=4.0), {}),

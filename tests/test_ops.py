@@ -263,13 +263,17 @@ def test_layer_bwd_in_one_call(bk, kind, shape):
     L.odin_dense_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx1.data_ptr(), None, None, B, K, N, None)
     L.odin_dense_bwd(tx.data_ptr(), tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx2.data_ptr(), None, None,
                      s2.data_ptr(), C.byref(rows2), B, K, N, 1, 1, None, None, None)
-    # the range word of dx: kept by the families odin_dense_dgrad_keeps_range names, untouched by the others
+    # the range word of dx: valid whatever family ran (the range contract, include/odin_hip.h) -- from the epilogue
+    # where odin_dense_dgrad_keeps_range says so, by one counted extra pass otherwise
     word, dx3 = bk.zeros(2048, dtype=torch.int32), bk.full((B, K), float('nan'))
+    f0 = L.odin_debug_absmax_fallbacks()
     L.odin_dense_bwd(tx.data_ptr(), tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx3.data_ptr(), None, None,
                      None, None, B, K, N, 0, 1, None, word.data_ptr(), None)
     assert torch.equal(dx3, dx2)
     kept = float(word.view(torch.float32).max())
-    assert kept == (float(dx2.abs().max()) if L.odin_dense_dgrad_keeps_range(B, K, N) else 0.0)
+    assert kept == float(dx2.abs().max())
+    if L.odin_dense_dgrad_keeps_range(B, K, N):
+      assert L.odin_debug_absmax_fallbacks() - f0 <= 1   # (at most the bound of a dy that came without a word)
   else:
     B, H, W, Ci, Co, K, S = shape
     if kind == 'conv':
@@ -298,6 +302,64 @@ def test_layer_bwd_in_one_call(bk, kind, shape):
   assert rows.value == rows2.value and rows.value > 0
   assert torch.equal(dx1, dx2)
   assert torch.equal(s1[:rows.value], s2[:rows.value])
+
+
+@pytest.mark.parametrize('kind,shape,colsum', [
+    # the advisor's round-4 repro: Conv2D 4x4 s1 32->32 on 32x32 at B=32 below a Conv2DTranspose (column-sum slab):
+    # 32768 tiles > ODIN_MAX_COLSUM_BLOCKS sends the data gradient to the generic gather kernel
+    ('conv', (32, 32, 32, 32, 32, 4, 1), True),
+    ('conv', (32, 32, 32, 32, 32, 4, 1), False),
+    ('conv', (4, 16, 16, 32, 64, 4, 2), False),      # tconv_planes
+    ('conv', (3, 14, 14, 32, 64, 5, 2), True),       # MNIST's 5x5 stack
+    ('conv', (2, 28, 28, 32, 32, 5, 1), True),
+    ('conv', (6, 8, 8, 64, 64, 4, 2), False),        # igemm
+    ('conv', (2, 64, 64, 32, 3, 1, 1), True),        # 1x1 head: pw1x1
+    ('deconv', (4, 16, 16, 32, 32, 4, 2), True),     # fconv_planes
+    ('deconv', (5, 7, 7, 64, 32, 5, 2), True),
+    ('deconv', (3, 8, 8, 16, 24, 3, 1), False),      # generic
+    ('deconv', (2, 4, 4, 8, 64, 4, 2), False)])
+def test_data_gradient_range_contract(bk, kind, shape, colsum):
+  """The range contract (include/odin_hip.h, round 5): a data gradient that is handed a dx_amax word leaves a bound
+  >= max|dx| in it whatever kernel family the dispatch picked -- with and without a column-sum slab (the
+  predicate said 'kept' where a slab sent the layer to a family that did not track, and the zero word overflowed the
+  plane kernels below).  Where the predicate says 'kept without an extra pass' no absmax pass may run."""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(77)
+  B, H, W, Ci, Co, K, S = shape
+  if kind == 'conv':
+    OH, pt, _ = vo.same_pads(H, K, S)
+    OW, pl, _ = vo.same_pads(W, K, S)
+    wshape = (K, K, Ci, Co)
+  else:
+    OH, OW = H * S, W * S
+    _, pt, _ = vo.same_pads(OH, K, S)
+    _, pl, _ = vo.same_pads(OW, K, S)
+    wshape = (K, K, Co, Ci)
+  d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, 'elu')
+  w, dy, aux = (rng.standard_normal(s_) for s_ in (wshape, (B, OH, OW, Co), (B, H, W, Ci)))
+  tw, tdy, taux = T(w * 0.1), T(dy * 3e-4), T(aux)
+  dyw, dxw = bk.zeros(2048, dtype=torch.int32), bk.zeros(2048, dtype=torch.int32)
+  L.odin_absmax(tdy.data_ptr(), tdy.numel(), dyw.data_ptr(), None)
+  d.dy_amax, d.dx_amax = dyw.data_ptr(), dxw.data_ptr()
+  dx = bk.full((B, H, W, Ci), float('nan'))
+  slab = bk.full((L.odin_max_slab_rows(), Ci), float('nan')) if colsum else None
+  rows = C.c_int(0)
+  dg = L.odin_conv2d_dgrad if kind == 'conv' else L.odin_deconv2d_dgrad
+  keeps = (L.odin_conv2d_dgrad_keeps_range if kind == 'conv' else L.odin_deconv2d_dgrad_keeps_range)(C.byref(d), 1)
+  f0 = L.odin_debug_absmax_fallbacks()
+  dg(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx.data_ptr(), slab.data_ptr() if colsum else None,
+     C.byref(rows), C.byref(d), None)
+  path = L.odin_debug_last_path().decode()
+  passes = L.odin_debug_absmax_fallbacks() - f0
+  bound = float(dxw.view(torch.float32).max())
+  m = float(dx.abs().max())
+  print(kind, shape, colsum, path, 'keeps', keeps, 'passes', passes, bound, m)
+  assert np.isfinite(m) and m > 0
+  assert bound >= m and bound <= 1.0001 * m, (bound, m)
+  if passes == 0:
+    assert path != 'absmax'
+  if colsum:
+    assert 0 < rows.value <= L.odin_max_slab_rows()
 
 
 def test_deferred_plane_weight_gradients(bk):

@@ -77,3 +77,43 @@ def test_engine_step_matches_oracle(L, name, kw, obs, C):
   conv_dec = any(l[0] in ('conv', 'deconv') for l in dec)
   assert eng.gauss_head == (conv_dec and (obs == 'gaussian_softplus1' or (obs == 'bernoulli' and not eng.fused_tail)))
   check_engine_vs_oracle(eng, model, P, x, eps, beta=kw.get('beta', 1.0), steps=2, clip=100.0)
+
+
+# decoders outside the benchmark shapes: the predicate-vs-dispatch class of bug (a Conv2D k x k below a
+# Conv2DTranspose wants a column-sum slab; with more than 16384 pixels per batch its data gradient leaves the implicit
+# GEMM for the generic kernel, which did not keep the range word it was assumed to keep -> a zero word, 2^115, inf)
+CUSTOM = [
+    # (name, encoder, decoder, input shape, B)
+    ('deconv_conv4_slab',
+     [('center',), ('conv', 8, 4, 2, 'elu'), ('conv', 16, 4, 2, 'elu'), ('flatten',), ('dense', 24, 'linear')],
+     [('dense', 16 * 16 * 8, 'linear'), ('reshape', (16, 16, 8)), ('deconv', 8, 4, 2, 'elu'),
+      ('conv', 8, 4, 1, 'elu'), ('conv', 1, 1, 1, 'linear')], (32, 32, 1), 18),
+    ('deconv_conv4_small',
+     [('center',), ('conv', 8, 4, 2, 'elu'), ('conv', 16, 4, 2, 'elu'), ('flatten',), ('dense', 24, 'linear')],
+     [('dense', 8 * 8 * 8, 'linear'), ('reshape', (8, 8, 8)), ('deconv', 8, 4, 2, 'elu'),
+      ('conv', 8, 4, 1, 'elu'), ('conv', 1, 1, 1, 'linear')], (16, 16, 1), 5),
+    ('five_by_five',
+     [('center',), ('conv', 8, 5, 1, 'elu'), ('conv', 8, 5, 2, 'elu'), ('flatten',), ('dense', 20, 'linear')],
+     [('dense', 7 * 7 * 4, 'linear'), ('reshape', (7, 7, 4)), ('deconv', 8, 5, 2, 'elu'), ('conv', 8, 5, 1, 'elu'),
+      ('conv', 1, 1, 1, 'linear')], (14, 14, 1), 3),
+    ('five_by_five',
+     [('center',), ('conv', 8, 5, 1, 'elu'), ('conv', 8, 5, 2, 'elu'), ('flatten',), ('dense', 20, 'linear')],
+     [('dense', 7 * 7 * 4, 'linear'), ('reshape', (7, 7, 4)), ('deconv', 8, 5, 2, 'elu'), ('conv', 8, 5, 1, 'elu'),
+      ('conv', 1, 1, 1, 'linear')], (14, 14, 1), 11),
+]
+
+
+@pytest.mark.parametrize('name,enc,dec,in_shape,B', CUSTOM)
+def test_custom_decoders_keep_valid_range_words(L, name, enc, dec, in_shape, B):
+  """every range word the engine hands to a consumer bounds its tensor (checked before the words are cleared), the
+  gradients are finite and match the oracle"""
+  spec = (enc, dec, in_shape, 4)
+  enc, dec, in_shape, zdim, x, eps = make_case(spec, 'bernoulli', B)
+  model = vo.OracleVAE(enc, dec, in_shape, zdim, observation='bernoulli', beta=2.0)
+  P = model.init_params(seed=3)
+  eng = VAEEngine(enc, dec, in_shape, zdim, B, 'cpu', observation='bernoulli', lib=L)
+  eng.debug_check_ranges = True
+  rep = check_engine_vs_oracle(eng, model, P, x, eps, beta=2.0, steps=1, clip=100.0)
+  for k, v in eng.grad_views().items():
+    assert torch.isfinite(v).all(), k
+  assert all(np.isfinite(v) for v in rep.values())

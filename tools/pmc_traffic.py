@@ -7,15 +7,20 @@ MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts 128-byte reads at 64 by
 WRITE_SIZE exact), next to the algorithmic bytes of the launch."""
 import json, re, sys
 B = 256
-TAG = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+
+
+COUNTS = {}  # file -> {(kernel, grid): dispatches in that pass} (the passes run different numbers of steps)
 
 
 def read(fn):
   out = {}
+  cnt = COUNTS.setdefault(fn, {})
   for ln in open(fn):
     f = [x.strip() for x in ln.split('|')]
     if len(f) >= 4 and f[0] != 'kernel':
       out[(f[0].replace('void ', ''), f[1])] = float(f[3])
+      cnt[(f[0].replace('void ', ''), f[1])] = int(f[2])
   return out
 
 
@@ -68,6 +73,55 @@ for op, (k, key, desc, alg) in kernels.items():
                  source=f'profiles/{TAG}_pmc_FETCH_SIZE.txt + {TAG}_pmc_WRITE_SIZE.txt (separate --pmc passes of '
                         '`bench.py --steps 20 --warmup 5`); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 '
                         'reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM section)')
+# the whole step: every kernel of the pass that ran once (or k times) per step -- the first-layer convolution runs
+# exactly once per step and gives the step count of the pass; stand-alone probes and torch kernels have other counts
+def step_launches(fn):
+  """[(kernel name, grid)] of one step from the rocprofv3 timeline tools/profile.sh wrote (tools/timeline.py)"""
+  out = []
+  for ln in open(fn):
+    m = re.match(r'\s*[\d.]+\s+[\d.]+\s+\S+\s+(.*) g=(\d+)', ln)
+    if m and not m.group(1).startswith('__amd_rocclr'):
+      out.append((m.group(1).strip(), m.group(2)))
+  return out
+
+
+def lookup(tab, name, grid):
+  for (k, key), v in tab.items():
+    if key.split('/')[0] == grid and k[:60] == name[:60]:
+      return v
+  # (timelines written before round 5 name the x extent of the grid only)
+  hits = [v for (k, key), v in tab.items() if k[:60] == name[:60] and int(key.split('/')[0]) % int(grid) == 0]
+  return hits[0] if len(hits) == 1 else None
+
+
+TL = sys.argv[2] if len(sys.argv) > 2 else f'gpurun_out/{TAG}_final_prof_timeline.txt'
+try:
+  launches = step_launches(TL)
+except OSError:
+  launches = []
+n_step = len(launches)
+if n_step:
+  tot_f = tot_w = 0.0
+  per = []
+  for name, grid in launches:
+    fk, wk = lookup(fetch, name, grid), lookup(write, name, grid)
+    if fk is None or wk is None:
+      print('step: no counters for', name, grid, file=sys.stderr)
+      missing += 1
+      continue
+    tot_f += fk
+    tot_w += wk
+    per.append((int((2 * fk + wk) * 1024), 1, name[:60], grid))
+  per.sort(reverse=True)
+  res['step'] = dict(kernel='every launch of one dsprites_betavae_b256 step',
+                     FETCH_SIZE_KB=round(tot_f, 1), WRITE_SIZE_KB=round(tot_w, 1),
+                     traffic_bytes=int((2 * tot_f + tot_w) * 1024), launches=sum(m for _, m, _, _ in per),
+                     largest=[dict(bytes=b, launches=m, kernel=k, grid=g) for b, m, k, g in per[:8]],
+                     source=f'sum of the mean per-launch counters (profiles/{TAG}_pmc_FETCH_SIZE.txt / _WRITE_SIZE.txt) over the launches of '
+                            f'one step as the rocprofv3 kernel trace lists them (profiles/{TAG}_step_timeline.txt)')
+else:
+  print('no step timeline:', TL, file=sys.stderr)
+  missing += 1
 json.dump(res, open(f'profiles/{TAG}_pmc_traffic.json', 'w'), indent=1)
 print(json.dumps(res, indent=1))
 sys.exit(1 if missing else 0)

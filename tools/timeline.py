@@ -5,10 +5,19 @@ import csv, glob, re, sys
 root = sys.argv[1]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 rows = []
+
+
+def grid_of(r):
+  """total work-items of the dispatch (x * y * z), as the --pmc tables name a grid"""
+  if 'Grid_Size_X' in r:
+    return str(int(r['Grid_Size_X']) * int(r.get('Grid_Size_Y', 1) or 1) * int(r.get('Grid_Size_Z', 1) or 1))
+  return r.get('Grid_Size', '?')
+
+
 for f in glob.glob(root + '/**/*kernel_trace.csv', recursive=True):
   for r in csv.DictReader(open(f)):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r.get('Queue_Id', '?'), r.get('Stream_Id', '?'),
-                 re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name']), r.get('Grid_Size_X', r.get('Grid_Size', '?'))))
+                 re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name']), grid_of(r)))
 rows.sort()
 # a step starts at its first kernel: the noise (round 2) or the first-layer convolution (the noise is drawn inside
 # latent_block_fwd since round 3)
