@@ -207,27 +207,6 @@ int odin_latent_block_bwd(const float* g0, const float* w0, const float* z, cons
                           int h_act, float* dz, float* dp, float* dh, float* slab0, float* slabl, int B,
                           int P, int D, int N0, int analytic, uint32_t* dh_amax, void* stream);
 
-/* The same launches with the decoder's first Conv2DTranspose inside (round 5): Dense(D -> N0) -> Reshape(hh, ww, C0)
- * -> Conv2DTranspose(C1 = 64, 4x4, stride 2, 'same', act1) (image_networks.py:494-500, the dSprites / Shapes3D /
- * audio decoders) -- forward additionally takes w1 [4,4,C1,C0] (Keras layout), b1 [C1] and writes
- * y1 = act1(conv_transpose(y0)) [B,2hh,2ww,C1]; backward takes g1 [B,2hh,2ww,C1] = dL/d(pre-activation of the
- * Conv2DTranspose) and y0 instead of g0, applies act0' itself and also writes one partial row per workgroup of
- * slab1 [rows][16*C1*C0] = dW1 (the layer's bias gradient is the column sum of g1, written by the data gradient of
- * the layer above as for every Conv2DTranspose).  odin_latent_block2_rows: workgroups (= slab rows), 0 outside the
- * regime (C1 = 64, C0 in {8, 16}, N0 = hh*ww*C0, hh*ww <= 64, B <= 1024). */
-int odin_latent_block2_rows(int B, int P, int D, int N0, int hh, int ww, int C0, int C1);
-int odin_latent_block2_fwd(const float* h, const float* wl, const float* bl, const float* eps_in, float* eps_out,
-                           uint64_t seed, const int32_t* step_dev, float* p, float* z, float* kl, float* fbmask,
-                           const float* w0, const float* b0, float* y0, const float* w1, const float* b1, float* y1,
-                           int B, int P, int D, int N0, int hh, int ww, int C0, int C1, int act0, int act1,
-                           int analytic, float free_bits, const float* capacity, void* stream);
-int odin_latent_block2_bwd(const float* g1, const float* y0, const float* w1, const float* w0, const float* z,
-                           const float* p, const float* eps, const float* fbmask, const float* klw,
-                           const float* dz_extra, const float* dloc_x, const float* dscale_x, const float* wl,
-                           const float* h, int h_act, float* dz, float* dp, float* dh, float* slab1, float* slab0,
-                           float* slabl, int B, int P, int D, int N0, int hh, int ww, int C0, int C1, int act0,
-                           int analytic, uint32_t* dh_amax, void* stream);
-
 /* ---- observation log-likelihood fused forward+backward
  * Independent(Bernoulli(logits),3).log_prob(x) (image_networks.py:87-93;
  * variational_autoencoder.py:528-530): llk_part[b][part] partial sums (n_part per

@@ -76,11 +76,6 @@ SIGNATURES = {
     'odin_latent_block_rows': [I, I, I, I],
     'odin_latent_block_fwd': [P, P, P, P, P, C.c_uint64, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, P],
     'odin_latent_block_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, I, I, P, P],
-    'odin_latent_block2_rows': [I, I, I, I, I, I, I, I],
-    'odin_latent_block2_fwd': [P, P, P, P, P, C.c_uint64, P, P, P, P, P, P, P, P, P, P, P,
-                               I, I, I, I, I, I, I, I, I, I, I, F, P, P],
-    'odin_latent_block2_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, P,
-                               I, I, I, I, I, I, I, I, I, I, P, P],
     'odin_elbo_bernoulli_fwd_bwd': [P, P, P, P, P, I, I, IP, P],
     'odin_elbo_gaussian_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
     'odin_gaussian_head_fwd_bwd': [P, P, P, P, P, P, P, P, IP, P, IP, P, P, I, I, I, I, I, I, P, P],
@@ -123,7 +118,7 @@ SIGNATURES = {
 # entry points whose return value is a result, not an error code
 VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_conv2d_dgrad_keeps_range',
                    'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_dense_dgrad_keeps_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
-                   'odin_latent_block_rows', 'odin_latent_block2_rows', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop')
+                   'odin_latent_block_rows', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop')
 # entry points declared `void` in include/odin_hip.h
 VOID_RETURNING = ('odin_wgrad_planes_defer_begin',)
 

@@ -104,56 +104,21 @@ struct LBFwd {
   int B, P, D, N0, act0, analytic, S;
   float free_bits;
   const float* cap;     // BetaCapacityVAE: device scalar C(step), kl <- |kl - C| (null: off)
-  // C0 > 0 instances: the decoder's first Conv2DTranspose(64, 4x4, stride 2, SAME) on y0 viewed as [hh, ww, C0]
-  const float* w1;      // [4, 4, 64, C0] (Keras Conv2DTranspose layout: kh, kw, out, in)
-  const float* b1;      // [64]
-  float* y1;            // [B, 2 hh, 2 ww, 64]
-  int hh, ww, act1;
 };
-
-constexpr int LB_C1 = 64;   // output channels of the fused Conv2DTranspose: one lane per channel, one wave per parity class
-constexpr int LB_GP = 68;   // pixel pitch (floats) of the staged gradient image: 16-byte reads of lanes on different pixels
-                            // fall on different bank groups (68 mod 64 = 4)
 
 // LDS (floats): wl [P * 2D] | w0 [D * N0] | hs [S * P] | bls [2D] | b0s [N0] | es [S * D] | ps [S * 2D] |
 //               zs [S * D] | red [256]
-// C0 > 0: + the decoder's first Conv2DTranspose (image_networks.py:498-500: 4x4 / stride 2 / SAME from the [hh, ww, C0]
-// view of y0 to 64 channels) -- y0 stays in LDS as a zero-bordered image, thread (channel, output parity class)
-// keeps its 4 taps x C0 weights in registers and walks the hh x ww outputs of its class (round 5: the launch of its
-// own this layer was -- 7 us on the implicit-GEMM kernel for 67 MFLOP -- becomes ~1.5 us of vector-ALU work here).
-template <int S, bool V4, int C0 = 0>
+template <int S, bool V4>
 __global__ __launch_bounds__(256) void latent_block_fwd_kernel(LBFwd q) {
   ODIN_DYN_SMEM(float, sm);
   const int P = q.P, D = q.D, J = 2 * q.D, N0 = q.N0;
   const int o_wl = 0, o_w0 = o_wl + P * J, o_hs = o_w0 + D * N0, o_bl = o_hs + S * P, o_b0 = o_bl + J;
   const int o_es = o_b0 + N0, o_ps = o_es + S * D, o_zs = o_ps + S * J, o_red = o_zs + S * D;
-  const int o_y0p = (o_red + 256 + 3) & ~3;   // C0 > 0: [S][hh + 2][ww + 2][C0], zero border
   float *wl = sm + o_wl, *w0 = sm + o_w0, *hs = sm + o_hs, *bls = sm + o_bl, *b0s = sm + o_b0;
   float *es = sm + o_es, *ps = sm + o_ps, *zs = sm + o_zs, *red = sm + o_red;
-  float* y0p = sm + o_y0p;
   const int tid = threadIdx.x, b0 = blockIdx.x * S;
   const int ns = (q.B - b0 < S) ? q.B - b0 : S;
   const unsigned step = q.step_dev ? (unsigned)q.step_dev[0] : 0u;
-  // this thread's Conv2DTranspose role: output channel co, output parity class (r, c); its taps are
-  // kh in {1 - r, 3 - r}, kw in {1 - c, 3 - c} (TF SAME, pads (1, 1): oh = 2 ih - 1 + kh)
-  const int co = tid & 63, cr = (tid >> 7) & 1, cc = (tid >> 6) & 1;
-  float wr[C0 > 0 ? 4 : 1][C0 > 0 ? C0 : 1];
-  float b1v = 0.f;
-  if constexpr (C0 > 0) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int kh = (t >> 1) ? 3 - cr : 1 - cr, kw = (t & 1) ? 3 - cc : 1 - cc;
-      const float4* src = reinterpret_cast<const float4*>(q.w1 + ((size_t)((kh * 4 + kw) * LB_C1 + co)) * C0);
-#pragma unroll
-      for (int v = 0; v < C0 / 4; ++v) {
-        const float4 x = src[v];
-        wr[t][4 * v] = x.x; wr[t][4 * v + 1] = x.y; wr[t][4 * v + 2] = x.z; wr[t][4 * v + 3] = x.w;
-      }
-    }
-    b1v = q.b1[co];
-    const int npad = S * (q.hh + 2) * (q.ww + 2) * C0 + 8 * C0;   // (+ the pixels a 4-output batch reads past the end)
-    for (int e = tid; e < npad; e += 256) y0p[e] = 0.f;
-  }
   {
     LBBig<V4> rwl, rw0;
     LBSmall<8> rh, rb0;   // (N0 <= 2048)
@@ -253,60 +218,7 @@ __global__ __launch_bounds__(256) void latent_block_fwd_kernel(LBFwd q) {
     float acc = 0.f;
 #pragma unroll 4
     for (int d = 0; d < D; ++d) acc = fmaf(zs[s * D + d], w0[d * N0 + n], acc);
-    const float y = odin_act(q.act0, acc + b0s[n]);
-    q.y0[(size_t)(b0 + s) * N0 + n] = y;
-    if constexpr (C0 > 0) {
-      const int pix = n / C0, ci = n - pix * C0;
-      const int ih = pix / q.ww, iw = pix - ih * q.ww;
-      y0p[((s * (q.hh + 2) + ih + 1) * (q.ww + 2) + iw + 1) * C0 + ci] = y;
-    }
-  }
-  if constexpr (C0 > 0) {
-    __syncthreads();
-    // Four outputs of a row per batch: the 2 x 5 input pixels they read (per 4 channels) are fetched in one go --
-    // 10 broadcast reads for 64 FMAs on four independent chains.  (One output at a time the stage was a chain of LDS
-    // round trips: 5.8 us instead of 1.5 at one wave per SIMD.)  Pixels beyond the row's end are read (the buffer is
-    // padded), their outputs not stored.
-    const int HH = q.hh, WW = q.ww, W2 = WW + 2;
-    for (int s = 0; s < ns; ++s) {
-      const float* img = y0p + s * (HH + 2) * W2 * C0;
-      float* out = q.y1 + (size_t)(b0 + s) * (4 * HH * WW) * LB_C1 + co;
-      for (int i = 0; i < HH; ++i) {
-        // padded input rows of the two row taps: kh = 1 - r reads row i + r, kh = 3 - r reads row i - 1 + r
-        const float* ra = img + ((i + 1 + cr) * W2 + cc) * C0;
-        const float* rb = img + ((i + cr) * W2 + cc) * C0;
-        for (int j0 = 0; j0 < WW; j0 += 4) {
-          float acc[4] = {b1v, b1v, b1v, b1v};
-#pragma unroll
-          for (int v = 0; v < C0 / 4; ++v) {
-            float4 xa[5], xb[5];
-#pragma unroll
-            for (int jj = 0; jj < 5; ++jj) {
-              xa[jj] = *reinterpret_cast<const float4*>(ra + (j0 + jj) * C0 + 4 * v);  // (same address in all lanes)
-              xb[jj] = *reinterpret_cast<const float4*>(rb + (j0 + jj) * C0 + 4 * v);
-            }
-#pragma unroll
-            for (int jq = 0; jq < 4; ++jq) {
-              // taps (kh_a, kw_a) / (kh_a, kw_b) / (kh_b, kw_a) / (kh_b, kw_b): column tap a reads pixel j + 1 + c, b pixel j + c
-              float t = acc[jq];
-              t = fmaf(xa[jq + 1].x, wr[0][4 * v], t); t = fmaf(xa[jq + 1].y, wr[0][4 * v + 1], t);
-              t = fmaf(xa[jq + 1].z, wr[0][4 * v + 2], t); t = fmaf(xa[jq + 1].w, wr[0][4 * v + 3], t);
-              t = fmaf(xa[jq].x, wr[1][4 * v], t); t = fmaf(xa[jq].y, wr[1][4 * v + 1], t);
-              t = fmaf(xa[jq].z, wr[1][4 * v + 2], t); t = fmaf(xa[jq].w, wr[1][4 * v + 3], t);
-              t = fmaf(xb[jq + 1].x, wr[2][4 * v], t); t = fmaf(xb[jq + 1].y, wr[2][4 * v + 1], t);
-              t = fmaf(xb[jq + 1].z, wr[2][4 * v + 2], t); t = fmaf(xb[jq + 1].w, wr[2][4 * v + 3], t);
-              t = fmaf(xb[jq].x, wr[3][4 * v], t); t = fmaf(xb[jq].y, wr[3][4 * v + 1], t);
-              t = fmaf(xb[jq].z, wr[3][4 * v + 2], t); t = fmaf(xb[jq].w, wr[3][4 * v + 3], t);
-              acc[jq] = t;
-            }
-          }
-#pragma unroll
-          for (int jq = 0; jq < 4; ++jq)
-            if (j0 + jq < WW)
-              out[(size_t)((2 * i + cr) * (2 * WW) + 2 * (j0 + jq) + cc) * LB_C1] = odin_act(q.act1, acc[jq]);
-        }
-      }
-    }
+    q.y0[(size_t)(b0 + s) * N0 + n] = odin_act(q.act0, acc + b0s[n]);
   }
 }
 
@@ -322,32 +234,20 @@ struct LBBwd {
   float* slabl;          // [gridDim.x][P * 2D + 2D]
   int B, P, D, N0, h_act, analytic, S;
   unsigned* dh_amax;     // range word of dh (max |dh| folded in by every workgroup), may be null
-  // C0 > 0 instances: the backward pass of the fused Conv2DTranspose -- g0 is computed here from g1
-  const float* g1;       // [B, 2 hh, 2 ww, 64] dL/d(pre-activation of the Conv2DTranspose)
-  const float* y0;       // [B, N0] output of the decoder's first Dense (= input image [hh, ww, C0])
-  const float* w1;       // [4, 4, 64, C0]
-  float* slab1;          // [gridDim.x][16 * 64 * C0] partial dW1 (the layer's bias gradient comes from the
-                         // column sums the data gradient of the layer above writes)
-  int hh, ww, act0;
 };
 
 // LDS (floats): wl [P * 2D] | w0 [D * N0] | hs [S * P] | gs [S * N0] | zs [S * D] | pls [S * 2D] | es [S * D] |
 //               x2 [S * D] | xl [S * D] | xs [S * D] | fb [S] | dps [S * 2D] | red [256]
-template <int S, bool V4, int C0 = 0>
+template <int S, bool V4>
 __global__ __launch_bounds__(256) void latent_block_bwd_kernel(LBBwd q) {
   ODIN_DYN_SMEM(float, sm);
   const int P = q.P, D = q.D, J = 2 * q.D, N0 = q.N0;
   const int o_wl = 0, o_w0 = o_wl + P * J, o_hs = o_w0 + D * N0, o_gs = o_hs + S * P, o_zs = o_gs + S * N0;
   const int o_pl = o_zs + S * D, o_es = o_pl + S * J, o_x2 = o_es + S * D, o_xl = o_x2 + S * D;
   const int o_xs = o_xl + S * D, o_fb = o_xs + S * D, o_dp = o_fb + S, o_red = o_dp + S * J;
-  // C0 > 0: y0p [S][hh + 2][ww + 2][C0] (zero border) | w1d [16 taps][C0 (k)][64 (cs * C0 + ci)] | g1s [S][4 hh ww][LB_GP]
-  const int o_y0p = (o_red + 256 + 3) & ~3;
-  const int o_w1d = o_y0p + (((C0 > 0 ? S * (q.hh + 2) * (q.ww + 2) * C0 + 8 * C0 : 0) + 3) & ~3);
-  const int o_g1s = o_w1d + (C0 > 0 ? 16 * LB_C1 * C0 : 0);
   float *wl = sm + o_wl, *w0 = sm + o_w0, *hs = sm + o_hs, *gs = sm + o_gs, *zs = sm + o_zs;
   float *pls = sm + o_pl, *es = sm + o_es, *x2 = sm + o_x2, *xl = sm + o_xl, *xs = sm + o_xs;
   float *fb = sm + o_fb, *dps = sm + o_dp, *red = sm + o_red;
-  float *y0p = sm + o_y0p, *w1d = sm + o_w1d, *g1s = sm + o_g1s;
   const int tid = threadIdx.x, b0 = blockIdx.x * S;
   const int ns = (q.B - b0 < S) ? q.B - b0 : S;
   const float klw = q.klw[0];
@@ -360,7 +260,7 @@ __global__ __launch_bounds__(256) void latent_block_bwd_kernel(LBBwd q) {
     rwl.issue(q.wl, P * J, 0, tid);
     rw0.issue(q.w0, D * N0, 0, tid);
     rh.issue(q.h + (size_t)b0 * P, ns * P, tid);
-    if constexpr (C0 == 0) rg.issue(q.g0 + (size_t)b0 * N0, ns * N0, tid);
+    rg.issue(q.g0 + (size_t)b0 * N0, ns * N0, tid);
     rz.issue(q.z + bd, ns * D, tid);
     rp.issue(q.p + (size_t)b0 * J, ns * J, tid);
     re.issue(q.eps + bd, ns * D, tid);
@@ -368,198 +268,8 @@ __global__ __launch_bounds__(256) void latent_block_bwd_kernel(LBBwd q) {
     rl.issue(hl ? q.dloc_x + bd : q.wl, hl ? ns * D : 0, tid);
     rs.issue(hs_ ? q.dscale_x + bd : q.wl, hs_ ? ns * D : 0, tid);
     rf.issue(q.fbmask + b0, ns, tid);
-    if constexpr (C0 > 0) {
-      // ---- the Conv2DTranspose's operands: its output gradient as a zero-bordered image [2 hh + 2][2 ww + 2] of
-      // LB_GP-float pixels (every tap of every pixel reads inside it: no bounds tests in the loops below), its input
-      // image with a zero border, its weights rearranged for the data gradient ----
-      const int HH = q.hh, WW = q.ww, npix = 4 * HH * WW, PH = 2 * HH + 2, PW = 2 * WW + 2;
-      {
-        const int npad = S * (HH + 2) * (WW + 2) * C0 + 8 * C0;
-        for (int e = tid; e < npad; e += 256) y0p[e] = 0.f;
-      }
-      // (batches of 8 x 16-byte loads per thread in flight, stored after the whole batch has been issued; border
-      // slots and the samples beyond the batch load element 0 and store zeros)
-      {
-        const float4* src = reinterpret_cast<const float4*>(q.g1 + (size_t)b0 * npix * LB_C1);
-        const int units = S * PH * PW * (LB_C1 / 4);
-        for (int e0 = 0; e0 < units; e0 += 256 * LB_DEPTH) {
-          float4 r[LB_DEPTH];
-          bool in[LB_DEPTH];
-#pragma unroll
-          for (int u = 0; u < LB_DEPTH; ++u) {
-            const int e = e0 + u * 256 + tid;
-            const int pp = e >> 4, c4 = e & 15;
-            const int sI = pp / (PH * PW), rem = pp - sI * (PH * PW);
-            const int pr = rem / PW, pc = rem - pr * PW;
-            in[u] = e < units && sI < ns && pr >= 1 && pr <= 2 * HH && pc >= 1 && pc <= 2 * WW;
-            r[u] = src[in[u] ? ((sI * npix + (pr - 1) * (2 * WW) + pc - 1) << 4) + c4 : 0];
-          }
-#pragma unroll
-          for (int u = 0; u < LB_DEPTH; ++u) {
-            const int e = e0 + u * 256 + tid;
-            if (e < units)
-              *reinterpret_cast<float4*>(g1s + (e >> 4) * LB_GP + 4 * (e & 15)) =
-                  in[u] ? r[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-        }
-      }
-      // w1 [tap][co][ci] -> w1d [tap][k][cs][ci] with co = cs * C0 + k: in the data gradient a lane (cs, ci) reads its
-      // C0 weights of a tap at stride 64 floats, the 64 lanes of a wave consecutive floats
-      {
-        const float4* src = reinterpret_cast<const float4*>(q.w1);
-        constexpr int units = 16 * LB_C1 * C0 / 4;
-        for (int e0 = 0; e0 < units; e0 += 256 * LB_DEPTH) {
-          float4 r[LB_DEPTH];
-#pragma unroll
-          for (int u = 0; u < LB_DEPTH; ++u) {
-            const int e = e0 + u * 256 + tid;
-            r[u] = src[e < units ? e : 0];
-          }
-#pragma unroll
-          for (int u = 0; u < LB_DEPTH; ++u) {
-            const int e = e0 + u * 256 + tid;
-            if (e < units) {
-              const int ci4 = e % (C0 / 4), tc = e / (C0 / 4), co = tc & 63, tap = tc >> 6;
-              const int cs = co / C0, k = co - cs * C0;
-              *reinterpret_cast<float4*>(w1d + ((tap * C0 + k) * (LB_C1 / C0) + cs) * C0 + 4 * ci4) = r[u];
-            }
-          }
-        }
-      }
-      __syncthreads();   // (the zero border of y0p is complete before its interior is written)
-      for (int e = tid; e < ns * N0; e += 256) {
-        const int sI = e / N0, n = e - sI * N0;
-        const int pix = n / C0, ci = n - pix * C0;
-        const int ih = pix / WW, iw = pix - ih * WW;
-        y0p[((sI * (HH + 2) + ih + 1) * (WW + 2) + iw + 1) * C0 + ci] = q.y0[(size_t)b0 * N0 + e];
-      }
-      __syncthreads();
-      // ---- weight gradient: thread (channel co, parity class (r, c)) owns dW1[kh][kw][co][0..C0) of its 4 taps; sums
-      // run over the samples, then the hh x ww output pixels of its class in order, four pixels of a row per batch
-      // (their 2 x 5 input pixels and 4 gradient values fetched in one go) ----
-      {
-        const int co = tid & 63, cr = (tid >> 7) & 1, cc = (tid >> 6) & 1, W2 = WW + 2;
-        float acc[4][C0];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int c = 0; c < C0; ++c) acc[t][c] = 0.f;
-        for (int sI = 0; sI < ns; ++sI) {
-          const float* img = y0p + sI * (HH + 2) * W2 * C0;
-          const float* gimg = g1s + (size_t)sI * PH * PW * LB_GP + co;
-          for (int i = 0; i < HH; ++i) {
-            const float* ra = img + ((i + 1 + cr) * W2 + cc) * C0;
-            const float* rb = img + ((i + cr) * W2 + cc) * C0;
-            const float* grow = gimg + ((2 * i + cr + 1) * PW + cc + 1) * LB_GP;
-            for (int j0 = 0; j0 < WW; j0 += 4) {
-              float g[4];
-#pragma unroll
-              for (int jq = 0; jq < 4; ++jq) {
-                const int j = j0 + jq < WW ? j0 + jq : WW - 1;
-                const float gv = grow[2 * j * LB_GP];
-                g[jq] = j0 + jq < WW ? gv : 0.f;   // (the input pixels of a masked output are finite: zero pad)
-              }
-#pragma unroll
-              for (int v = 0; v < C0 / 4; ++v) {
-                float4 xa[5], xb[5];
-#pragma unroll
-                for (int jj = 0; jj < 5; ++jj) {
-                  xa[jj] = *reinterpret_cast<const float4*>(ra + (j0 + jj) * C0 + 4 * v);
-                  xb[jj] = *reinterpret_cast<const float4*>(rb + (j0 + jj) * C0 + 4 * v);
-                }
-#pragma unroll
-                for (int jq = 0; jq < 4; ++jq) {
-                  acc[0][4 * v] = fmaf(xa[jq + 1].x, g[jq], acc[0][4 * v]);
-                  acc[0][4 * v + 1] = fmaf(xa[jq + 1].y, g[jq], acc[0][4 * v + 1]);
-                  acc[0][4 * v + 2] = fmaf(xa[jq + 1].z, g[jq], acc[0][4 * v + 2]);
-                  acc[0][4 * v + 3] = fmaf(xa[jq + 1].w, g[jq], acc[0][4 * v + 3]);
-                  acc[1][4 * v] = fmaf(xa[jq].x, g[jq], acc[1][4 * v]);
-                  acc[1][4 * v + 1] = fmaf(xa[jq].y, g[jq], acc[1][4 * v + 1]);
-                  acc[1][4 * v + 2] = fmaf(xa[jq].z, g[jq], acc[1][4 * v + 2]);
-                  acc[1][4 * v + 3] = fmaf(xa[jq].w, g[jq], acc[1][4 * v + 3]);
-                  acc[2][4 * v] = fmaf(xb[jq + 1].x, g[jq], acc[2][4 * v]);
-                  acc[2][4 * v + 1] = fmaf(xb[jq + 1].y, g[jq], acc[2][4 * v + 1]);
-                  acc[2][4 * v + 2] = fmaf(xb[jq + 1].z, g[jq], acc[2][4 * v + 2]);
-                  acc[2][4 * v + 3] = fmaf(xb[jq + 1].w, g[jq], acc[2][4 * v + 3]);
-                  acc[3][4 * v] = fmaf(xb[jq].x, g[jq], acc[3][4 * v]);
-                  acc[3][4 * v + 1] = fmaf(xb[jq].y, g[jq], acc[3][4 * v + 1]);
-                  acc[3][4 * v + 2] = fmaf(xb[jq].z, g[jq], acc[3][4 * v + 2]);
-                  acc[3][4 * v + 3] = fmaf(xb[jq].w, g[jq], acc[3][4 * v + 3]);
-                }
-              }
-            }
-          }
-        }
-        float* row = q.slab1 + (size_t)blockIdx.x * (16 * LB_C1 * C0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int kh = (t >> 1) ? 3 - cr : 1 - cr, kw = (t & 1) ? 3 - cc : 1 - cc;
-          float4* dst = reinterpret_cast<float4*>(row + (size_t)((kh * 4 + kw) * LB_C1 + co) * C0);
-#pragma unroll
-          for (int v = 0; v < C0 / 4; ++v)
-            dst[v] = make_float4(acc[t][4 * v], acc[t][4 * v + 1], acc[t][4 * v + 2], acc[t][4 * v + 3]);
-        }
-      }
-      // ---- data gradient: g0[s][ih][iw][ci] = act0'(y0) * sum over (kh, kw, co) of g1[2 ih - 1 + kh][2 iw - 1 + kw][co]
-      // * W1[kh][kw][co][ci].  A wave takes four consecutive input pixels at a time; lane (cs, ci) sums its C0
-      // channels co = cs C0 + k of all 16 taps -- a tap's C0 weights are read once for the four pixels, its gradient
-      // pixels lie inside the zero-bordered image -- and the 64 / C0 lanes of a ci meet by shuffles (fixed order) ----
-      {
-        const int lane = tid & 63, wave = tid >> 6, cs = lane / C0, ci = lane - cs * C0;
-        const int HW = HH * WW;
-        for (int sI = 0; sI < ns; ++sI) {
-          const float* gimg = g1s + (size_t)sI * PH * PW * LB_GP + cs * C0;
-          for (int p0 = 4 * wave; p0 < HW; p0 += 16) {
-            int gofs[4];
-#pragma unroll
-            for (int pq = 0; pq < 4; ++pq) {
-              const int pix = p0 + pq < HW ? p0 + pq : HW - 1;
-              const int i = pix / WW, j = pix - i * WW;
-              gofs[pq] = (2 * i * PW + 2 * j) * LB_GP;   // padded pixel (2 i + kh, 2 j + kw) is tap (kh, kw)'s
-            }
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int kh = 0; kh < 4; ++kh) {
-#pragma unroll
-              for (int kw = 0; kw < 4; ++kw) {
-                const int tofs = (kh * PW + kw) * LB_GP;
-                const float* wp = w1d + ((kh * 4 + kw) * C0) * LB_C1 + lane;
-                float w[C0];
-#pragma unroll
-                for (int k = 0; k < C0; ++k) w[k] = wp[k * LB_C1];
-#pragma unroll
-                for (int pq = 0; pq < 4; ++pq) {
-                  const float* gp = gimg + gofs[pq] + tofs;
-                  float t = acc[pq];
-#pragma unroll
-                  for (int v = 0; v < C0 / 4; ++v) {
-                    const float4 g = *reinterpret_cast<const float4*>(gp + 4 * v);
-                    t = fmaf(g.x, w[4 * v], t);
-                    t = fmaf(g.y, w[4 * v + 1], t);
-                    t = fmaf(g.z, w[4 * v + 2], t);
-                    t = fmaf(g.w, w[4 * v + 3], t);
-                  }
-                  acc[pq] = t;
-                }
-              }
-            }
-#pragma unroll
-            for (int pq = 0; pq < 4; ++pq) {
-              float t = acc[pq];
-#pragma unroll
-              for (int m = C0; m < 64; m <<= 1) t += __shfl_xor(t, m);
-              if (cs == 0 && p0 + pq < HW) {
-                const int pix = p0 + pq, i = pix / WW, j = pix - i * WW;
-                const float y = y0p[((sI * (HH + 2) + i + 1) * (WW + 2) + j + 1) * C0 + ci];
-                gs[sI * N0 + pix * C0 + ci] = t * odin_act_grad(q.act0, y);
-              }
-            }
-          }
-        }
-        for (int e = tid + ns * N0; e < S * N0; e += 256) gs[e] = 0.f;   // (rows beyond the batch)
-      }
-    }
     rh.commit(hs, ns * P, S * P, tid);
-    if constexpr (C0 == 0) rg.commit(gs, ns * N0, S * N0, tid);
+    rg.commit(gs, ns * N0, S * N0, tid);
     rz.commit(zs, ns * D, S * D, tid);
     rp.commit(pls, ns * J, S * J, tid);
     re.commit(es, ns * D, S * D, tid);
@@ -680,22 +390,11 @@ int lb_samples(int B, int P, int D, int N0) {
   while (S > 1 && (S * 2 * D > 256 || B / S < 128 || S * P > 2048 || S * N0 > 2048)) S >>= 1;
   return S;
 }
-// with the Conv2DTranspose stage a workgroup's chain is ~4x longer per sample: one sample per workgroup up to 512
-// (every CU busy at batch 256), as few as keep the slab rows within ODIN_MAX_COLSUM_BLOCKS beyond
-int lb2_samples(int B, int P, int D, int N0) {
-  const int S = B <= ODIN_MAX_COLSUM_BLOCKS ? 1 : 2;
-  if ((B + S - 1) / S > ODIN_MAX_COLSUM_BLOCKS || S * 2 * D > 256 || S * P > 2048 || S * N0 > 2048) return 0;
-  return S;
-}
 
 // (the larger of the two kernels' layouts: the backward one)
 size_t lb_lds_floats(int P, int D, int N0, int S) {
   return (size_t)P * 2 * D + (size_t)D * N0 + (size_t)S * P + (size_t)S * N0 + (size_t)S * (9 * D + 1) +
          (size_t)2 * D + N0 + 256 + 8;
-}
-size_t lb2_lds_floats(int P, int D, int N0, int S, int hh, int ww, int C0) {
-  return lb_lds_floats(P, D, N0, S) + 8 + (size_t)S * (hh + 2) * (ww + 2) * C0 + 8 * C0 + 4 + (size_t)16 * LB_C1 * C0 +
-         (size_t)S * (2 * hh + 2) * (2 * ww + 2) * LB_GP;
 }
 
 template <typename K>
@@ -716,17 +415,17 @@ bool lb_vec_ok(const float* wl, const float* w0, int P, int D, int N0) {
   return (((size_t)wl | (size_t)w0) & 15) == 0 && ((P * 2 * D) & 3) == 0 && ((D * N0) & 3) == 0;
 }
 
-template <int S, bool V4, int C0 = 0>
+template <int S, bool V4>
 int lb_launch_fwd(const LBFwd& q, int rows, size_t lds, void* stream) {
-  if (int rc = lb_set_lds(&latent_block_fwd_kernel<S, V4, C0>, lds)) return rc;
-  ODIN_LAUNCH((latent_block_fwd_kernel<S, V4, C0>), dim3(rows), dim3(256), lds, stream, q);
-  return odin_check_launch(C0 > 0 ? "latent_block2_fwd" : "latent_block_fwd");
+  if (int rc = lb_set_lds(&latent_block_fwd_kernel<S, V4>, lds)) return rc;
+  ODIN_LAUNCH((latent_block_fwd_kernel<S, V4>), dim3(rows), dim3(256), lds, stream, q);
+  return odin_check_launch("latent_block_fwd");
 }
-template <int S, bool V4, int C0 = 0>
+template <int S, bool V4>
 int lb_launch_bwd(const LBBwd& q, int rows, size_t lds, void* stream) {
-  if (int rc = lb_set_lds(&latent_block_bwd_kernel<S, V4, C0>, lds)) return rc;
-  ODIN_LAUNCH((latent_block_bwd_kernel<S, V4, C0>), dim3(rows), dim3(256), lds, stream, q);
-  return odin_check_launch(C0 > 0 ? "latent_block2_bwd" : "latent_block_bwd");
+  if (int rc = lb_set_lds(&latent_block_bwd_kernel<S, V4>, lds)) return rc;
+  ODIN_LAUNCH((latent_block_bwd_kernel<S, V4>), dim3(rows), dim3(256), lds, stream, q);
+  return odin_check_launch("latent_block_bwd");
 }
 
 }  // namespace
@@ -742,73 +441,6 @@ extern "C" int odin_latent_block_rows(int B, int P, int D, int N0) {
   return rows <= ODIN_MAX_COLSUM_BLOCKS ? rows : 0;
 }
 
-// The same with the decoder's first Conv2DTranspose inside the launch: y0 viewed as [hh, ww, C0] ->
-// Conv2DTranspose(C1 = 64, 4x4, stride 2, SAME).  0 when outside the regime (C1 = 64, C0 in {8, 16}, N0 = hh ww C0,
-// at most 64 input pixels, everything within 150 KB of LDS).
-extern "C" int odin_latent_block2_rows(int B, int P, int D, int N0, int hh, int ww, int C0, int C1) {
-  if (ODIN_DIAG_ENV("ODIN_NOLATBLOCK2")) return 0;
-  if (odin_latent_block_rows(B, P, D, N0) == 0) return 0;
-  if (C1 != LB_C1 || (C0 != 8 && C0 != 16) || hh < 1 || ww < 1 || hh * ww > 64 || N0 != hh * ww * C0) return 0;
-  const int S = lb2_samples(B, P, D, N0);
-  if (S == 0 || lb2_lds_floats(P, D, N0, S, hh, ww, C0) * 4 > 150 * 1024) return 0;
-  if ((size_t)B * 4 * hh * ww * LB_C1 >= (1u << 29)) return 0;
-  return (B + S - 1) / S;
-}
-
-namespace {
-template <bool V4, int C0>
-int lb_dispatch_fwd(const LBFwd& q, int rows, size_t lds, void* stream) {
-  if constexpr (C0 > 0)   // (lb2_samples: one or two samples per workgroup)
-    return q.S == 2 ? lb_launch_fwd<2, V4, C0>(q, rows, lds, stream) : lb_launch_fwd<1, V4, C0>(q, rows, lds, stream);
-  switch (q.S) {
-    case 8: return lb_launch_fwd<8, V4, C0>(q, rows, lds, stream);
-    case 4: return lb_launch_fwd<4, V4, C0>(q, rows, lds, stream);
-    case 2: return lb_launch_fwd<2, V4, C0>(q, rows, lds, stream);
-    default: return lb_launch_fwd<1, V4, C0>(q, rows, lds, stream);
-  }
-}
-template <bool V4, int C0>
-int lb_dispatch_bwd(const LBBwd& q, int rows, size_t lds, void* stream) {
-  if constexpr (C0 > 0)
-    return q.S == 2 ? lb_launch_bwd<2, V4, C0>(q, rows, lds, stream) : lb_launch_bwd<1, V4, C0>(q, rows, lds, stream);
-  switch (q.S) {
-    case 8: return lb_launch_bwd<8, V4, C0>(q, rows, lds, stream);
-    case 4: return lb_launch_bwd<4, V4, C0>(q, rows, lds, stream);
-    case 2: return lb_launch_bwd<2, V4, C0>(q, rows, lds, stream);
-    default: return lb_launch_bwd<1, V4, C0>(q, rows, lds, stream);
-  }
-}
-
-LBFwd lb_fwd_params(const float* h, const float* wl, const float* bl, const float* eps_in, float* eps_out,
-                    uint64_t seed, const int32_t* step_dev, float* p, float* z, float* kl, float* fbmask,
-                    const float* w0, const float* b0, float* y0, int B, int P, int D, int N0, int act0,
-                    int analytic, float free_bits, const float* capacity) {
-  LBFwd q;
-  memset(&q, 0, sizeof(q));
-  q.h = h; q.wl = wl; q.bl = bl; q.eps_in = eps_in; q.eps = eps_out; q.p = p; q.z = z; q.kl = kl;
-  q.fbmask = fbmask; q.w0 = w0; q.b0 = b0; q.y0 = y0; q.step_dev = (const int*)step_dev;
-  q.k0 = (unsigned)seed; q.k1 = (unsigned)(seed >> 32);
-  q.B = B; q.P = P; q.D = D; q.N0 = N0; q.act0 = act0; q.analytic = analytic;
-  q.free_bits = free_bits;
-  q.cap = capacity;
-  return q;
-}
-LBBwd lb_bwd_params(const float* g0, const float* w0, const float* z, const float* p, const float* eps,
-                    const float* fbmask, const float* klw, const float* dz_extra, const float* dloc_x,
-                    const float* dscale_x, const float* wl, const float* h, int h_act, float* dz, float* dp,
-                    float* dh, float* slab0, float* slabl, int B, int P, int D, int N0, int analytic,
-                    uint32_t* dh_amax) {
-  LBBwd q;
-  memset(&q, 0, sizeof(q));
-  q.g0 = g0; q.w0 = w0; q.z = z; q.p = p; q.eps = eps; q.fbmask = fbmask; q.klw = klw;
-  q.dz2 = dz_extra; q.dloc_x = dloc_x; q.dscale_x = dscale_x; q.wl = wl; q.h = h; q.h_act = h_act;
-  q.dz = dz; q.dp = dp; q.dh = dh; q.slab0 = slab0; q.slabl = slabl;
-  q.B = B; q.P = P; q.D = D; q.N0 = N0; q.analytic = analytic;
-  q.dh_amax = dh_amax;
-  return q;
-}
-}  // namespace
-
 extern "C" int odin_latent_block_fwd(const float* h, const float* wl, const float* bl, const float* eps_in,
                                      float* eps_out, uint64_t seed, const int32_t* step_dev, float* p,
                                      float* z, float* kl, float* fbmask, const float* w0, const float* b0,
@@ -816,12 +448,22 @@ extern "C" int odin_latent_block_fwd(const float* h, const float* wl, const floa
                                      float free_bits, const float* capacity, void* stream) {
   const int rows = odin_latent_block_rows(B, P, D, N0);
   if (rows == 0) return odin_fail(-2, "latent_block_fwd: shapes outside the fused regime");
-  LBFwd q = lb_fwd_params(h, wl, bl, eps_in, eps_out, seed, step_dev, p, z, kl, fbmask, w0, b0, y0, B, P, D, N0, act0,
-                          analytic, free_bits, capacity);
-  q.S = lb_samples(B, P, D, N0);
+  LBFwd q;
+  memset(&q, 0, sizeof(q));
+  q.h = h; q.wl = wl; q.bl = bl; q.eps_in = eps_in; q.eps = eps_out; q.p = p; q.z = z; q.kl = kl;
+  q.fbmask = fbmask; q.w0 = w0; q.b0 = b0; q.y0 = y0; q.step_dev = (const int*)step_dev;
+  q.k0 = (unsigned)seed; q.k1 = (unsigned)(seed >> 32);
+  q.B = B; q.P = P; q.D = D; q.N0 = N0; q.act0 = act0; q.analytic = analytic; q.S = lb_samples(B, P, D, N0);
+  q.free_bits = free_bits;
+  q.cap = capacity;
   const size_t lds = lb_lds_floats(P, D, N0, q.S) * 4;
-  return lb_vec_ok(wl, w0, P, D, N0) ? lb_dispatch_fwd<true, 0>(q, rows, lds, stream)
-                                     : lb_dispatch_fwd<false, 0>(q, rows, lds, stream);
+  const bool v4 = lb_vec_ok(wl, w0, P, D, N0);
+  switch (q.S) {
+    case 8: return v4 ? lb_launch_fwd<8, true>(q, rows, lds, stream) : lb_launch_fwd<8, false>(q, rows, lds, stream);
+    case 4: return v4 ? lb_launch_fwd<4, true>(q, rows, lds, stream) : lb_launch_fwd<4, false>(q, rows, lds, stream);
+    case 2: return v4 ? lb_launch_fwd<2, true>(q, rows, lds, stream) : lb_launch_fwd<2, false>(q, rows, lds, stream);
+    default: return v4 ? lb_launch_fwd<1, true>(q, rows, lds, stream) : lb_launch_fwd<1, false>(q, rows, lds, stream);
+  }
 }
 
 extern "C" int odin_latent_block_bwd(const float* g0, const float* w0, const float* z, const float* p,
@@ -832,51 +474,19 @@ extern "C" int odin_latent_block_bwd(const float* g0, const float* w0, const flo
                                      int analytic, uint32_t* dh_amax, void* stream) {
   const int rows = odin_latent_block_rows(B, P, D, N0);
   if (rows == 0) return odin_fail(-2, "latent_block_bwd: shapes outside the fused regime");
-  LBBwd q = lb_bwd_params(g0, w0, z, p, eps, fbmask, klw, dz_extra, dloc_x, dscale_x, wl, h, h_act, dz, dp, dh, slab0,
-                          slabl, B, P, D, N0, analytic, dh_amax);
-  q.S = lb_samples(B, P, D, N0);
+  LBBwd q;
+  memset(&q, 0, sizeof(q));
+  q.g0 = g0; q.w0 = w0; q.z = z; q.p = p; q.eps = eps; q.fbmask = fbmask; q.klw = klw;
+  q.dz2 = dz_extra; q.dloc_x = dloc_x; q.dscale_x = dscale_x; q.wl = wl; q.h = h; q.h_act = h_act;
+  q.dz = dz; q.dp = dp; q.dh = dh; q.slab0 = slab0; q.slabl = slabl;
+  q.B = B; q.P = P; q.D = D; q.N0 = N0; q.analytic = analytic; q.S = lb_samples(B, P, D, N0);
+  q.dh_amax = dh_amax;
   const size_t lds = lb_lds_floats(P, D, N0, q.S) * 4;
-  return lb_vec_ok(wl, w0, P, D, N0) ? lb_dispatch_bwd<true, 0>(q, rows, lds, stream)
-                                     : lb_dispatch_bwd<false, 0>(q, rows, lds, stream);
-}
-
-// ---- the same with the decoder's first Conv2DTranspose (image_networks.py:494-500: Dense -> Reshape(hh, ww, C0) ->
-// Conv2DTranspose(64, 4, 2, 'same', activation)) inside the launch ----
-extern "C" int odin_latent_block2_fwd(const float* h, const float* wl, const float* bl, const float* eps_in,
-                                      float* eps_out, uint64_t seed, const int32_t* step_dev, float* p,
-                                      float* z, float* kl, float* fbmask, const float* w0, const float* b0,
-                                      float* y0, const float* w1, const float* b1, float* y1, int B, int P, int D,
-                                      int N0, int hh, int ww, int C0, int C1, int act0, int act1, int analytic,
-                                      float free_bits, const float* capacity, void* stream) {
-  const int rows = odin_latent_block2_rows(B, P, D, N0, hh, ww, C0, C1);
-  if (rows == 0) return odin_fail(-2, "latent_block2_fwd: shapes outside the fused regime");
-  if (((size_t)w1 & 15) != 0) return odin_fail(-2, "latent_block2_fwd: w1 must be 16-byte aligned");
-  LBFwd q = lb_fwd_params(h, wl, bl, eps_in, eps_out, seed, step_dev, p, z, kl, fbmask, w0, b0, y0, B, P, D, N0, act0,
-                          analytic, free_bits, capacity);
-  q.S = lb2_samples(B, P, D, N0);
-  q.w1 = w1; q.b1 = b1; q.y1 = y1; q.hh = hh; q.ww = ww; q.act1 = act1;
-  const size_t lds = lb2_lds_floats(P, D, N0, q.S, hh, ww, C0) * 4;
   const bool v4 = lb_vec_ok(wl, w0, P, D, N0);
-  if (C0 == 8) return v4 ? lb_dispatch_fwd<true, 8>(q, rows, lds, stream) : lb_dispatch_fwd<false, 8>(q, rows, lds, stream);
-  return v4 ? lb_dispatch_fwd<true, 16>(q, rows, lds, stream) : lb_dispatch_fwd<false, 16>(q, rows, lds, stream);
-}
-
-extern "C" int odin_latent_block2_bwd(const float* g1, const float* y0, const float* w1, const float* w0,
-                                      const float* z, const float* p, const float* eps, const float* fbmask,
-                                      const float* klw, const float* dz_extra, const float* dloc_x,
-                                      const float* dscale_x, const float* wl, const float* h, int h_act, float* dz,
-                                      float* dp, float* dh, float* slab1, float* slab0, float* slabl, int B, int P,
-                                      int D, int N0, int hh, int ww, int C0, int C1, int act0, int analytic,
-                                      uint32_t* dh_amax, void* stream) {
-  const int rows = odin_latent_block2_rows(B, P, D, N0, hh, ww, C0, C1);
-  if (rows == 0) return odin_fail(-2, "latent_block2_bwd: shapes outside the fused regime");
-  if ((((size_t)w1 | (size_t)g1) & 15) != 0) return odin_fail(-2, "latent_block2_bwd: w1 / g1 must be 16-byte aligned");
-  LBBwd q = lb_bwd_params(nullptr, w0, z, p, eps, fbmask, klw, dz_extra, dloc_x, dscale_x, wl, h, h_act, dz, dp, dh,
-                          slab0, slabl, B, P, D, N0, analytic, dh_amax);
-  q.S = lb2_samples(B, P, D, N0);
-  q.g1 = g1; q.y0 = y0; q.w1 = w1; q.slab1 = slab1; q.hh = hh; q.ww = ww; q.act0 = act0;
-  const size_t lds = lb2_lds_floats(P, D, N0, q.S, hh, ww, C0) * 4;
-  const bool v4 = lb_vec_ok(wl, w0, P, D, N0);
-  if (C0 == 8) return v4 ? lb_dispatch_bwd<true, 8>(q, rows, lds, stream) : lb_dispatch_bwd<false, 8>(q, rows, lds, stream);
-  return v4 ? lb_dispatch_bwd<true, 16>(q, rows, lds, stream) : lb_dispatch_bwd<false, 16>(q, rows, lds, stream);
+  switch (q.S) {
+    case 8: return v4 ? lb_launch_bwd<8, true>(q, rows, lds, stream) : lb_launch_bwd<8, false>(q, rows, lds, stream);
+    case 4: return v4 ? lb_launch_bwd<4, true>(q, rows, lds, stream) : lb_launch_bwd<4, false>(q, rows, lds, stream);
+    case 2: return v4 ? lb_launch_bwd<2, true>(q, rows, lds, stream) : lb_launch_bwd<2, false>(q, rows, lds, stream);
+    default: return v4 ? lb_launch_bwd<1, true>(q, rows, lds, stream) : lb_launch_bwd<1, false>(q, rows, lds, stream);
+  }
 }

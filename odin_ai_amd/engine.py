@@ -197,11 +197,11 @@ class NetProgram:
       self.descs[n].dy_amax = self.dy_word[n]
     return self.dy_word[n]
 
-  def check_range_words(self, upto: Optional[int] = None, start: int = 0) -> None:
+  def check_range_words(self, upto: Optional[int] = None) -> None:
     """Debug / tests (synchronises): every word handed to a consumer bounds its tensor -- call between backward() and
     the slab reduction that clears the words (NetProgram.backward alone does not clear them)."""
     n = len(self.recs) if upto is None else upto
-    for i in range(max(start - 1, 0), n):
+    for i in range(n):
       if self.dy_word[i] is None:
         continue
       blk = self.range_words[RANGE_WORDS * i:RANGE_WORDS * (i + 1)]
@@ -644,7 +644,7 @@ class VAEEngine:
     """Training-step fusion of the bottleneck (latent_block.hip): noise + DistributionDense + reparameterise /
     KL + the decoder's first Dense as one launch, and their five backward launches as one, when the decoder
     starts with a Dense layer and both weight matrices fit in LDS."""
-    self.lat_block = self._used_block = self.lat_block2 = self._used_block2 = False
+    self.lat_block = self._used_block = False
     recs = self.dec_recs
     if len(recs) < 2 or recs[0].kind != 'dense' or self.enc_recs[-1].kind == 'deconv':
       return
@@ -653,27 +653,8 @@ class VAEEngine:
       return
     self.lat_block, self.lb_rows = True, rows
     D, N0 = self.D, recs[0].N
-    # round 5: + the decoder's first Conv2DTranspose(64, 4, 2) inside the same two launches (latent_block.hip,
-    # odin_latent_block2_*: image_networks.py:494-500 -- the dSprites / Shapes3D decoders) where the shapes allow
-    self.lat_block2 = False
-    if (len(recs) >= 3 and recs[1].kind == 'deconv' and len(recs[1].in_shape) == 3 and
-        __import__('os').environ.get('ODIN_LATBLOCK2', '1') != '0'):   # (engine-side A/B switch)
-      d1 = recs[1].desc
-      hh, ww, c0 = recs[1].in_shape
-      if d1['K'] == 4 and d1['stride'] == 2:
-        rows2 = self.lib.odin_latent_block2_rows(self.B, self.hdim, D, N0, hh, ww, c0, d1['Cout'])
-        if rows2 > 0:
-          self.lat_block2, self.lb_rows, rows = True, rows2, rows2
-          self.lb2_geom = (hh, ww, c0, d1['Cout'])
-          self.lb_slab1 = torch.empty(rows, recs[1].w_n, **f32)
     self.lb_slab0 = torch.empty(rows, D * N0 + N0, **f32)
     self.lb_slabl = torch.empty(rows, self.hdim * 2 * D + 2 * D, **f32)
-
-  def _bwd_first(self) -> int:
-    """decoder layers [0, first) have their backward pass inside the bottleneck launch"""
-    if not self._bwd_block():
-      return 0
-    return 2 if self._used_block2 else 1
 
   def _bwd_block(self) -> bool:
     # (two gradient buckets: the decoder's first Dense belongs to the bucket that is already being
@@ -808,23 +789,7 @@ class VAEEngine:
     lw = self.params[self.lat_w_off:]
     lb = self.params[self.lat_b_off:]
     self._used_block = self.lat_block and fused
-    self._used_block2 = self._used_block and self.lat_block2
-    if self._used_block2:
-      if eps is not None and eps is not self.eps:
-        self.eps.copy_(eps)
-      h_e = self.enc.forward(x, st)
-      r0, r1 = self.dec_recs[0], self.dec_recs[1]
-      hh, ww, c0, c1 = self.lb2_geom
-      lib.odin_latent_block2_fwd(h_e.data_ptr(), lw.data_ptr(), lb.data_ptr(),
-                                 None if eps is None else self.eps.data_ptr(), self.eps.data_ptr(),
-                                 self.seed, self.hp(N_HYPER), self.p.data_ptr(), self.z.data_ptr(),
-                                 self.kl.data_ptr(), self.fbmask.data_ptr(), self.dec.w(0).data_ptr(),
-                                 self.dec.b(0).data_ptr(), self.dec.outs[0].data_ptr(), self.dec.w(1).data_ptr(),
-                                 self.dec.b(1).data_ptr(), self.dec.outs[1].data_ptr(), B, self.hdim, D, r0.N,
-                                 hh, ww, c0, c1, ACT[r0.act], ACT[r1.act], int(self.analytic), self.free_bits,
-                                 self.hp(H_CAP) if self.capacity_on else None, st)
-      dec_in, dec_start = self.dec.outs[1], 2
-    elif self._used_block:
+    if self._used_block:
       if eps is not None and eps is not self.eps:
         self.eps.copy_(eps)
       h_e = self.enc.forward(x, st)
@@ -1037,7 +1002,7 @@ class VAEEngine:
       co, c1 = a.desc['Cout'], b.desc['Cout']
       jobs = self.dec.backward(self.z, self.dec.gouts[-2], st, dx_out=self.dz, last=nd - 2,
                                skip_bias_of_last=True, fork=fork,
-                               side_jobs=late_jobs if early else None, first=self._bwd_first())
+                               side_jobs=late_jobs if early else None, first=int(self._bwd_block()))
       ts, stride = self.tail_slab, self.tail_slab.shape[1]
       # (dW1 | db1) of the 1x1 conv, then the bias gradient of the fused layer
       jobs.append(ReduceJob(ts.data_ptr(), self.grads[b.w_off:].data_ptr(), co * c1 + c1,
@@ -1048,7 +1013,7 @@ class VAEEngine:
       nd = len(self.dec_recs)
       a, b = self.dec_recs[-2], self.dec_recs[-1]
       jobs = self.dec.backward(self.z, self.dec.gouts[-2], st, dx_out=self.dz, last=nd - 2, fork=fork,
-                               side_jobs=late_jobs if early else None, first=self._bwd_first())
+                               side_jobs=late_jobs if early else None, first=int(self._bwd_block()))
       hs = self.head_slab
       jobs.append(ReduceJob(hs.data_ptr(), self.grads[b.w_off:].data_ptr(), hs.shape[1], self.head_rows,
                             hs.shape[1], 0))  # (dW1 | db1) of the 1x1 head
@@ -1057,7 +1022,7 @@ class VAEEngine:
         jobs.append(ReduceJob(hc.data_ptr(), self.grads[a.b_off:].data_ptr(), a.b_n, self.head_rows, hc.shape[1], 0))
     else:
       jobs = self.dec.backward(self.z, self.dec.gouts[-1], st, dx_out=self.dz, fork=fork,
-                               side_jobs=late_jobs if early else None, first=self._bwd_first())
+                               side_jobs=late_jobs if early else None, first=int(self._bwd_block()))
     if early and jobs:
       # the decoder's slabs (most of the slab bytes) are complete: reduce them on a side stream
       # while the encoder's backward pass keeps the matrix cores busy (the reduction is HBM-bound)
@@ -1079,23 +1044,7 @@ class VAEEngine:
     last = self.enc_recs[-1]
     aux_act = ACT[last.act]
     lw = self.params[self.lat_w_off:]
-    if self._bwd_block() and self._used_block2:
-      r0, r1 = self.dec_recs[0], self.dec_recs[1]
-      hh, ww, c0, c1 = self.lb2_geom
-      lib.odin_latent_block2_bwd(self.dec.gouts[1].data_ptr(), self.dec.outs[0].data_ptr(), self.dec.w(1).data_ptr(),
-                                 self.dec.w(0).data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.eps.data_ptr(),
-                                 self.fbmask.data_ptr(), self.hp(H_KLW), dzx, tl, ts, lw.data_ptr(), h_e.data_ptr(),
-                                 aux_act, self.dz.data_ptr(), self.dp.data_ptr(), self.enc.gouts[-1].data_ptr(),
-                                 self.lb_slab1.data_ptr(), self.lb_slab0.data_ptr(), self.lb_slabl.data_ptr(), B,
-                                 self.hdim, D, r0.N, hh, ww, c0, c1, ACT[r0.act], int(self.analytic),
-                                 self.enc.set_top_word(True), st)
-      jobs.append(ReduceJob(self.lb_slab1.data_ptr(), self.grads[r1.w_off:].data_ptr(), r1.w_n, self.lb_rows,
-                            self.lb_slab1.shape[1], 0))
-      jobs.append(ReduceJob(self.lb_slab0.data_ptr(), self.grads[r0.w_off:].data_ptr(),
-                            self.lb_slab0.shape[1], self.lb_rows, self.lb_slab0.shape[1], 0))
-      jobs.append(ReduceJob(self.lb_slabl.data_ptr(), self.grads[self.lat_w_off:].data_ptr(),
-                            self.lb_slabl.shape[1], self.lb_rows, self.lb_slabl.shape[1], 0))
-    elif self._bwd_block():
+    if self._bwd_block():
       r0 = self.dec_recs[0]
       lib.odin_latent_block_bwd(self.dec.gouts[0].data_ptr(), self.dec.w(0).data_ptr(), self.z.data_ptr(),
                                 self.p.data_ptr(), self.eps.data_ptr(), self.fbmask.data_ptr(),
@@ -1138,7 +1087,7 @@ class VAEEngine:
     self._jobs_keepalive = arr
     lib.odin_wgrad_planes_defer_end(st)   # (no-op unless backward() opened a collection)
     if self.debug_check_ranges:
-      self.dec.check_range_words(start=self._bwd_first())   # (gouts below `first` never leave the bottleneck launch)
+      self.dec.check_range_words()
       self.enc.check_range_words()
     lib.odin_slab_reduce(arr, len(jobs), st)
 

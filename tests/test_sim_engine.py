@@ -117,20 +117,3 @@ def test_custom_decoders_keep_valid_range_words(L, name, enc, dec, in_shape, B):
   for k, v in eng.grad_views().items():
     assert torch.isfinite(v).all(), k
   assert all(np.isfinite(v) for v in rep.values())
-
-
-def test_bottleneck_with_first_deconv_in_one_launch(L):
-  """decoder Dense -> Reshape(h, w, 8) -> Conv2DTranspose(64, 4, 2): the bottleneck launches take the deconvolution in
-  (engine.lat_block2, odin_latent_block2_*); the step still matches the oracle, range words valid"""
-  enc = [('center',), ('conv', 8, 4, 2, 'elu'), ('conv', 16, 4, 2, 'elu'), ('flatten',), ('dense', 24, 'linear')]
-  dec = [('dense', 2 * 2 * 8, 'linear'), ('reshape', (2, 2, 8)), ('deconv', 64, 4, 2, 'elu'),
-         ('deconv', 8, 4, 2, 'elu'), ('conv', 1, 1, 1, 'linear')]
-  B = 5
-  enc, dec, in_shape, zdim, x, eps = make_case((enc, dec, (8, 8, 1), 4), 'bernoulli', B)
-  model = vo.OracleVAE(enc, dec, in_shape, zdim, observation='bernoulli', beta=3.0)
-  P = model.init_params(seed=21)
-  eng = VAEEngine(enc, dec, in_shape, zdim, B, 'cpu', observation='bernoulli', lib=L)
-  assert eng.lat_block and eng.lat_block2
-  eng.debug_check_ranges = True
-  check_engine_vs_oracle(eng, model, P, x, eps, beta=3.0, steps=2, clip=100.0)
-  assert eng._used_block2 and eng._bwd_first() == 2
