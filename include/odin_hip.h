@@ -353,6 +353,19 @@ int odin_sumsq_adam_flat(float* theta, const float* g, float* m, float* v, size_
                          const float* hyper, float* workspace, float* gnorm2_out, float clip,
                          int32_t* flag, void* stream);
 
+/* The same two launches as the LAST launches of a step whose per-step scalars live in a device ring (round 5: no
+ * per-step host copy): `ring` [rows][row_floats] holds the rows of the coming steps (row of step s at s mod rows, rows a
+ * power of two), `cur` is the row the step's kernels read (`hyper` and `elbo_hyper` point into it), t = the int32 at
+ * cur[t_word].  The stage-1 launch copies hyper[0..4] to `staged` (>= 8 floats), the Adam launch reads them from there
+ * and loads ring row (t + 1) mod rows into `cur` for the next step.  llk_part != NULL: the ELBO finalisation rides in
+ * the first launch as in odin_sumsq_adam_finalize_flat.  Replaces the reference's per-step evaluation of the optimiser's
+ * learning-rate schedule / beta annealing inside Networks.optimize (base_networks.py:549-596, beta_vae.py:97-126). */
+int odin_sumsq_adam_ring(float* theta, const float* g, float* m, float* v, size_t n, const float* hyper,
+                         float* workspace, float* gnorm2_out, float clip, int32_t* flag, const float* llk_part,
+                         int n_part, const float* kl, const float* elbo_hyper, const float* tc, float* llk,
+                         float* out4, int B, const float* ring, float* cur, float* staged, int rows, int row_floats,
+                         int t_word, void* stream);
+
 /* odin_sumsq_adam_flat whose first launch also finalises the step's ELBO (the arguments of odin_elbo_finalize):
  * one launch less per training step; loss / norm / update bit-identical to the separate calls. */
 int odin_sumsq_adam_finalize_flat(float* theta, const float* g, float* m, float* v, size_t n,

@@ -101,6 +101,7 @@ SIGNATURES = {
     'odin_clip_by_value': [P, C.c_size_t, F, P, F, P],
     'odin_sumsq_adam_flat': [P, P, P, P, C.c_size_t, P, P, P, F, P, P],
     'odin_sumsq_adam_finalize_flat': [P, P, P, P, C.c_size_t, P, P, P, F, P, P, I, P, P, P, P, P, I, P],
+    'odin_sumsq_adam_ring': [P, P, P, P, C.c_size_t, P, P, P, F, P, P, I, P, P, P, P, P, I, P, P, P, I, I, I, P],
     'odin_rng_normal': [P, C.c_size_t, C.c_uint64, P, P],
     'odin_gather_normalize_u8': [P, P, P, I, I, F, I, P],
     'odin_gather_rows_f32': [P, P, P, I, I, P],

@@ -464,15 +464,39 @@ __device__ __forceinline__ float adam1(float& th, float g, float& m, float& v, f
   return th;
 }
 
+// Per-step scalars without a per-step host copy (round 5).  The step's kernels read their hyper-parameters from one
+// small device row `cur`; the host used to refresh it with an 80-byte H2D copy before every step graph, which cost
+// 7-8 us of idle time per step (copy node + the gaps around it; same-box A/B in profiles/r05_hyper_ring.txt).  Now the
+// rows of the coming steps sit in a device ring (filled by the host half a ring at a time, stream-ordered) and the
+// step's LAST kernel -- this one -- loads the next step's row into `cur`.  Race-free: the stage-1 launch in front
+// of this one copies Adam's own five scalars to `staged` (workgroup 0), so no workgroup of this kernel reads `cur`
+// while workgroup 0 rewrites it; every other reader of `cur` runs in an earlier launch of the step.
+struct HyperRing {
+  const float* ring;   // [rows][row_floats]
+  float* cur;          // [row_floats]; word `t_word` holds the step number t as int32
+  int rows, row_floats, t_word;
+};
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta,
                                                    const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    size_t n, const float* __restrict__ hyper,
                                                    const float* __restrict__ gnorm2, float clip,
                                                    int* flag, const float* __restrict__ parts,
-                                                   int n_parts, float* __restrict__ gnorm2_out) {
+                                                   int n_parts, float* __restrict__ gnorm2_out,
+                                                   HyperRing hr) {
+  // (hr.ring != null: `hyper` is the staged copy of the five scalars)
   const float a = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   float gs = hyper[4];
+  if (hr.ring != nullptr) {   // (a kernel argument: uniform over the grid)
+    int t = 0;
+    if (blockIdx.x == 0) t = reinterpret_cast<const int*>(hr.cur)[hr.t_word];
+    __syncthreads();           // every thread has read t before its word is rewritten
+    if (blockIdx.x == 0 && threadIdx.x < hr.row_floats) {
+      const int slot = (t + 1) & (hr.rows - 1);
+      hr.cur[threadIdx.x] = hr.ring[(size_t)slot * hr.row_floats + threadIdx.x];
+    }
+  }
   __shared__ float red[4];
   __shared__ float n2_sh;
   if (parts != nullptr) {
@@ -521,8 +545,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta,
 }
 
 __global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ g, size_t n,
-                                                    float* __restrict__ part) {
+                                                    float* __restrict__ part, const float* __restrict__ adam_hyper,
+                                                    float* __restrict__ staged) {
   __shared__ float red[4];
+  if (staged != nullptr && blockIdx.x == 0 && threadIdx.x < 5) staged[threadIdx.x] = adam_hyper[threadIdx.x];
   float acc = 0.f;
   const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -545,8 +571,11 @@ struct FinArgs {
   int n_part, B;
 };
 __global__ __launch_bounds__(256) void sumsq_stage1_fin(const float* __restrict__ g, size_t n,
-                                                        float* __restrict__ part, FinArgs f) {
+                                                        float* __restrict__ part, FinArgs f,
+                                                        const float* __restrict__ adam_hyper,
+                                                        float* __restrict__ staged) {
   __shared__ float red[4];
+  if (staged != nullptr && blockIdx.x == 0 && threadIdx.x < 5) staged[threadIdx.x] = adam_hyper[threadIdx.x];
   if (blockIdx.x + 1 == gridDim.x) {
     elbo_finalize_body(f.llk_part, f.n_part, f.kl, f.hyper, f.tcp, f.llk, f.out4, f.B, red);
     return;
@@ -1187,7 +1216,7 @@ extern "C" int odin_adam_step_flat(float* theta, const float* g, float* m, float
                                    int32_t* flag, void* stream) {
   int grid = grid_for(n / 4 + 1, 256, 2048);
   ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper, gnorm2,
-              clip, (int*)flag, (const float*)nullptr, 0, (float*)nullptr);
+              clip, (int*)flag, (const float*)nullptr, 0, (float*)nullptr, HyperRing{});
   return odin_check_launch("adam");
 }
 
@@ -1237,15 +1266,55 @@ extern "C" int odin_clip_by_value(float* g, size_t n, float clipvalue, const flo
   return odin_check_launch("clip_by_value");
 }
 
+namespace {
+// ring == null: no ring.  Otherwise `cur` = the device row the step's kernels read (the row that holds `hyper`),
+// `staged` >= 8 floats of scratch, `rows` a power of two.
+bool hyper_ring_args(const float* ring, float* cur, float* staged, int rows, int row_floats, int t_word, HyperRing& hr) {
+  memset(&hr, 0, sizeof(hr));
+  if (ring == nullptr) return true;
+  if (cur == nullptr || staged == nullptr || rows < 2 || (rows & (rows - 1)) != 0 || row_floats < 1 ||
+      row_floats > 64 || t_word < 0 || t_word >= row_floats)
+    return false;
+  hr.ring = ring; hr.cur = cur; hr.rows = rows; hr.row_floats = row_floats; hr.t_word = t_word;
+  return true;
+}
+}  // namespace
+
 extern "C" int odin_sumsq_adam_flat(float* theta, const float* g, float* m, float* v, size_t n,
                                     const float* hyper, float* workspace, float* gnorm2_out,
                                     float clip, int32_t* flag, void* stream) {
   int g1 = grid_for(n / 4 + 1, 256, 1024);
-  ODIN_LAUNCH(sumsq_stage1, dim3(g1), dim3(256), 0, stream, g, n, workspace);
+  ODIN_LAUNCH(sumsq_stage1, dim3(g1), dim3(256), 0, stream, g, n, workspace, (const float*)nullptr, (float*)nullptr);
   int grid = grid_for(n / 4 + 1, 256, 2048);
   ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper,
-              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out);
+              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out, HyperRing{});
   return odin_check_launch("sumsq_adam");
+}
+
+// odin_sumsq_adam_flat / odin_sumsq_adam_finalize_flat (llk_part != NULL) as the LAST launches of a step whose
+// per-step scalars live in a device ring: the stage-1 launch stages Adam's five scalars (hyper[0..4]), the Adam
+// launch loads ring row (t + 1) mod rows into `cur`, t = the int32 at cur[t_word].
+extern "C" int odin_sumsq_adam_ring(float* theta, const float* g, float* m, float* v, size_t n, const float* hyper,
+                                    float* workspace, float* gnorm2_out, float clip, int32_t* flag,
+                                    const float* llk_part, int n_part, const float* kl, const float* elbo_hyper,
+                                    const float* tc, float* llk, float* out4, int B, const float* ring, float* cur,
+                                    float* staged, int rows, int row_floats, int t_word, void* stream) {
+  HyperRing hr;
+  if (ring == nullptr || !hyper_ring_args(ring, cur, staged, rows, row_floats, t_word, hr))
+    return odin_fail(-2, "odin_sumsq_adam_ring: bad ring arguments (rows must be a power of two)");
+  int g1 = grid_for(n / 4 + 1, 256, 1024);
+  if (llk_part != nullptr) {
+    FinArgs f;
+    f.llk_part = llk_part; f.kl = kl; f.hyper = elbo_hyper; f.tcp = tc; f.llk = llk; f.out4 = out4;
+    f.n_part = n_part; f.B = B;
+    ODIN_LAUNCH(sumsq_stage1_fin, dim3(g1 + 1), dim3(256), 0, stream, g, n, workspace, f, hyper, staged);
+  } else {
+    ODIN_LAUNCH(sumsq_stage1, dim3(g1), dim3(256), 0, stream, g, n, workspace, hyper, staged);
+  }
+  int grid = grid_for(n / 4 + 1, 256, 2048);
+  ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, (const float*)staged,
+              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out, hr);
+  return odin_check_launch("sumsq_adam_ring");
 }
 
 extern "C" int odin_sumsq_adam_finalize_flat(float* theta, const float* g, float* m, float* v, size_t n,
@@ -1258,17 +1327,18 @@ extern "C" int odin_sumsq_adam_finalize_flat(float* theta, const float* g, float
   FinArgs f;
   f.llk_part = llk_part; f.kl = kl; f.hyper = elbo_hyper; f.tcp = tc; f.llk = llk; f.out4 = out4;
   f.n_part = n_part; f.B = B;
-  ODIN_LAUNCH(sumsq_stage1_fin, dim3(g1 + 1), dim3(256), 0, stream, g, n, workspace, f);
+  ODIN_LAUNCH(sumsq_stage1_fin, dim3(g1 + 1), dim3(256), 0, stream, g, n, workspace, f, (const float*)nullptr,
+              (float*)nullptr);
   int grid = grid_for(n / 4 + 1, 256, 2048);
   ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper,
-              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out);
+              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out, HyperRing{});
   return odin_check_launch("sumsq_adam_finalize");
 }
 
 extern "C" int odin_sumsq_flat(const float* g, size_t n, float* workspace, float* out,
                                void* stream) {
   int grid = grid_for(n / 4 + 1, 256, 1024);
-  ODIN_LAUNCH(sumsq_stage1, dim3(grid), dim3(256), 0, stream, g, n, workspace);
+  ODIN_LAUNCH(sumsq_stage1, dim3(grid), dim3(256), 0, stream, g, n, workspace, (const float*)nullptr, (float*)nullptr);
   ODIN_LAUNCH(sum_stage2, dim3(1), dim3(256), 0, stream, (const float*)workspace, grid, out);
   return odin_check_launch("sumsq");
 }

@@ -514,6 +514,22 @@ class VAEEngine:
     self._ring_i = 0
     self.hyper = torch.zeros(N_HYPER + 4, **f32)
     self._skip_hyper_copy = __import__('os').environ.get('ODIN_SKIP_HYPER_COPY', '0') == '1'
+    # Device-resident schedule (round 5): the rows of the coming steps in a device ring, loaded into `hyper` by the
+    # step's last kernel (include/odin_hip.h: odin_sumsq_adam_ring) -- no per-step host copy while the caller's
+    # (lr, beta, ...) follow the prediction (constant values, or the `schedule` callable of train_step); any other
+    # call falls back to the explicit 80-byte copy of round 4 for that step.  ODIN_HYPER_RING=0 switches it off.
+    self.ring_rows = int(__import__('os').environ.get('ODIN_HYPER_RING_ROWS', '128'))   # (a power of two; tests: 16)
+    assert self.ring_rows >= 8 and self.ring_rows & (self.ring_rows - 1) == 0
+    self.hyper_ring = torch.zeros(self.ring_rows, N_HYPER + 4, **f32)
+    self.hyper_staged = torch.zeros(8, **f32)
+    self._ring_host = torch.zeros(self.ring_rows, N_HYPER + 4, dtype=torch.float32)   # host mirror of the ring
+    if self.device.type == 'cuda':
+      self._ring_host = self._ring_host.pin_memory()
+    self._ring_filled_to = -1      # rows of steps <= this are in the device ring (as predicted)
+    self._ring_live = False        # `hyper` on the device holds (or will hold, by the previous step's Adam) this step's row
+    self._ring_args = None         # the caller's arguments the prediction was made from
+    self._ring_copy_ev = [None, None]   # events of the last two refill copies (the pinned mirror is reused)
+    self.use_hyper_ring = __import__('os').environ.get('ODIN_HYPER_RING', '1') != '0'
     self.step_count = 0
     self.side_stream = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
     n_side = int(__import__('os').environ.get('ODIN_SIDE_STREAMS', '2'))
@@ -689,11 +705,27 @@ class VAEEngine:
                 capacity: Optional[float] = None):
     """Host scalars -> device (one small async H2D copy)."""
     t = self.step_count if t is None else t
-    tt = max(int(t), 1)
+    self._ring_live = False   # (an explicit copy: whatever the ring predicted for this step no longer counts)
     self._ring_i = (self._ring_i + 1) % len(self._ring)
     h = self._ring[self._ring_i]
     if self._ring_ev[self._ring_i] is not None:
       self._ring_ev[self._ring_i].synchronize()
+    self._fill_row(h, t, lr=lr, beta=beta, b1=b1, b2=b2, eps=eps, grad_scale=grad_scale, tc_coef=tc_coef,
+                   skip_enable=skip_enable, extra=extra, capacity=capacity)
+    # (leaving this 80-byte copy out of the steady state was measured in round 4 at 0.72 ms per step: no difference;
+    # at 0.52 ms it is worth 7-8 us -- profiles/r05_hyper_ring.txt -- hence the device ring of train_step)
+    if self._skip_hyper_copy and self.step_count > 60:
+      return  # (diagnostics, ODIN_SKIP_HYPER_COPY=1: what the 80-byte copy costs between two step graphs)
+    self.hyper.copy_(h, non_blocking=True)
+    if self.device.type == 'cuda':
+      ev = torch.cuda.Event()
+      ev.record(torch.cuda.current_stream(self.device))
+      self._ring_ev[self._ring_i] = ev
+
+  def _fill_row(self, h, t, lr=1e-3, beta=1.0, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0, tc_coef=None,
+                skip_enable=True, extra=None, capacity=None):
+    """the hyper-parameter row of step t into the host tensor h (N_HYPER + 4 floats)"""
+    tt = max(int(t), 1)
     Bg = self.B * self.world_size
     h[H_ALPHA] = lr * math.sqrt(1.0 - b2 ** tt) / (1.0 - b1 ** tt)
     h[H_B1], h[H_B2], h[H_EPS], h[H_GSCALE] = b1, b2, eps, grad_scale
@@ -715,15 +747,57 @@ class VAEEngine:
       h[H_CAP] = float(capacity)
     h[N_HYPER:].view(torch.int32)[0] = int(t)
     h[N_HYPER:].view(torch.int32)[1] = int(skip_enable)
-    # (leaving this 80-byte copy out of the steady state was measured: 0.7182 vs 0.7180 ms per step -- the
-    # idle time between two graph launches does not come from it)
-    if self._skip_hyper_copy and self.step_count > 60:
-      return  # (diagnostics, ODIN_SKIP_HYPER_COPY=1: what the 80-byte copy costs between two step graphs)
-    self.hyper.copy_(h, non_blocking=True)
-    if self.device.type == 'cuda':
-      ev = torch.cuda.Event()
-      ev.record(torch.cuda.current_stream(self.device))
-      self._ring_ev[self._ring_i] = ev
+
+  def _ring_step(self, t: int, args: dict, schedule=None) -> None:
+    """Make sure the device row `hyper` holds step t's scalars when the step runs -- without a copy when the ring
+    already predicted exactly this row.  `args`: set_hyper's keyword arguments of this step; `schedule(step) -> dict`
+    (optional) overrides them for FUTURE steps (a learning-rate / beta / capacity schedule known in advance)."""
+    R = self.ring_rows
+    row = self._ring_host[t % R]
+    want = torch.zeros(N_HYPER + 4, dtype=torch.float32)
+    wa = dict(args)
+    if 'when_skip_update' in wa:
+      wa['skip_enable'] = t >= int(wa.pop('when_skip_update'))
+    self._fill_row(want, t, **wa)
+    hit = self._ring_live and self._ring_filled_to >= t and torch.equal(want.view(torch.int32), row.view(torch.int32))
+    key = tuple(sorted((k, v if not isinstance(v, (list, tuple)) else tuple(v)) for k, v in args.items()))
+    stable = schedule is not None or self._ring_args is None or key == self._ring_args
+    self._ring_args = key
+    if not hit:
+      # the explicit copy of round 4 for this step; the ring is refilled from t + 1 with what is known now -- unless
+      # the caller's values change from call to call without a schedule (then every step takes this path and a refill
+      # per step would only add a second copy: behave exactly as round 4 until two consecutive calls agree)
+      self.set_hyper(t=t, **wa)
+      if not stable:
+        return
+      self._ring_filled_to = t
+    # refill: whenever fewer than R / 4 predicted rows are left (or after a miss), rows up to t + R / 2 are written --
+    # stream-ordered behind the previous step, whose Adam has consumed every slot that is overwritten
+    if self._ring_filled_to - t < R // 4:
+      lo, hi = self._ring_filled_to + 1, t + R // 2
+      # the pinned mirror rows written below were last read by a copy enqueued two refills ago at the latest
+      self._ring_copy_ev.append(None)
+      old = self._ring_copy_ev.pop(0)
+      if old is not None:
+        old.synchronize()
+      for u in range(lo, hi + 1):
+        a = dict(args)
+        if schedule is not None:
+          a.update(schedule(u))
+        if 'when_skip_update' in a:
+          a['skip_enable'] = u >= int(a.pop('when_skip_update'))
+        self._fill_row(self._ring_host[u % R], u, **a)
+      # (a contiguous span of the mirror, or two when it wraps)
+      a0, a1 = lo % R, hi % R
+      spans = [(a0, a1 + 1)] if a0 <= a1 else [(a0, R), (0, a1 + 1)]
+      for x0, x1 in spans:
+        self.hyper_ring[x0:x1].copy_(self._ring_host[x0:x1], non_blocking=True)
+      if self.device.type == 'cuda':
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._ring_copy_ev[-1] = ev
+      self._ring_filled_to = hi
+    self._ring_live = True
 
   # ---- partial passes used by the model API (encode / decode) ---------------------------
   def run_encoder(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, st=None):
@@ -1108,10 +1182,23 @@ class VAEEngine:
                                      self.seg_offsets.numel() - 1, float(clipnorm), st)
 
   def adam(self, st=None, global_clipnorm: Optional[float] = None, check_nan: bool = True,
-           clipvalue: Optional[float] = None):
+           clipvalue: Optional[float] = None, ring: bool = False):
+    """`ring`: this is the LAST launch of a train_step whose hyper-parameter rows live in the device ring: the Adam
+    launch also loads the next step's row into `hyper` (odin_sumsq_adam_ring)."""
     lib = self.lib
     st = self.stream() if st is None else st
     fin, self._fin_pending = getattr(self, '_fin_pending', None), None
+    if ring:
+      assert clipvalue is None and (global_clipnorm is not None or check_nan)
+      lib.odin_sumsq_adam_ring(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                               self.params.numel(), self.hp(H_ALPHA), self.ws.data_ptr(), self.gnorm2.data_ptr(),
+                               float(global_clipnorm or 0.0), self.flag.data_ptr() if check_nan else None,
+                               fin[0] if fin is not None else None, fin[1] if fin is not None else 0,
+                               self.kl.data_ptr(), self.hp(H_BETA), fin[2] if fin is not None else None,
+                               self.llk.data_ptr(), self.out4.data_ptr(), self.B, self.hyper_ring.data_ptr(),
+                               self.hyper.data_ptr(), self.hyper_staged.data_ptr(), self.ring_rows, N_HYPER + 4,
+                               N_HYPER, st)
+      return
     if fin is not None and (clipvalue is not None or not (global_clipnorm is not None or check_nan)):
       # (an update path without the fused first launch: finalise on its own)
       lib.odin_elbo_finalize(fin[0], fin[1], self.kl.data_ptr(), self.hp(H_BETA), fin[2], self.llk.data_ptr(),
@@ -1210,13 +1297,19 @@ class VAEEngine:
                  global_clipnorm: Optional[float] = None, use_graph: bool = False,
                  clipnorm: Optional[float] = None, clipvalue: Optional[float] = None,
                  skip_update_threshold: Optional[float] = None, when_skip_update: int = 0,
-                 check_nan: bool = True, capacity: Optional[float] = None):
+                 check_nan: bool = True, capacity: Optional[float] = None, schedule=None):
     """Networks.optimize for one VAEStep: step += 1, forward, backward, (all-reduce), gradient
     policies, Adam.  Returns the device tensor out4 = [loss, mean llk, mean beta*kl, tc] (no host
     sync)."""
     self.step_count += 1
-    self.set_hyper(lr=lr, beta=beta, skip_enable=self.step_count >= int(when_skip_update), capacity=capacity)
-    pol = (global_clipnorm, clipnorm, clipvalue, skip_update_threshold, bool(check_nan))
+    # the device ring serves the update path whose last two launches are odin_sumsq_adam_ring (norm + Adam)
+    ring = bool(self.use_hyper_ring and clipvalue is None and (global_clipnorm is not None or check_nan))
+    if ring:
+      self._ring_step(self.step_count, dict(lr=lr, beta=beta, when_skip_update=int(when_skip_update),
+                                            capacity=capacity), schedule)
+    else:
+      self.set_hyper(lr=lr, beta=beta, skip_enable=self.step_count >= int(when_skip_update), capacity=capacity)
+    pol = (global_clipnorm, clipnorm, clipvalue, skip_update_threshold, bool(check_nan), ring)
     if use_graph and self.device.type == 'cuda':
       self._graph_step(x, eps, pol)
     else:
@@ -1225,9 +1318,9 @@ class VAEEngine:
     return self.out4
 
   def _update(self, pol):
-    gclip, clipnorm, clipvalue, skip_thr, check_nan = pol
+    gclip, clipnorm, clipvalue, skip_thr, check_nan = pol[:5]
     self.grad_policies(clipnorm=clipnorm, skip_update_threshold=skip_thr)
-    self.adam(global_clipnorm=gclip, clipvalue=clipvalue, check_nan=check_nan)
+    self.adam(global_clipnorm=gclip, clipvalue=clipvalue, check_nan=check_nan, ring=len(pol) > 5 and pol[5])
 
   def input_buffer(self) -> torch.Tensor:
     """The static [B, H, W, C] input tensor the captured step graph reads.  A data pipeline that
@@ -1262,12 +1355,13 @@ class VAEEngine:
       cap = torch.cuda.Stream(self.device)
       cap.wait_stream(torch.cuda.current_stream(self.device))
       saved = (self.params.clone(), self.m.clone(), self.v.clone(), self.flag.clone(),
-               self.skipped_update.clone())
+               self.skipped_update.clone(), self.hyper.clone())
       with torch.cuda.stream(cap):
         sg.run_eager()
-        # the warm-up step must not count: restore the optimiser state it touched
+        # the warm-up step must not count: restore the optimiser state it touched (and the hyper-parameter row: with
+        # the device ring the warm-up's Adam has already loaded the NEXT step's row)
         self.params.copy_(saved[0]); self.m.copy_(saved[1]); self.v.copy_(saved[2])
-        self.flag.copy_(saved[3]); self.skipped_update.copy_(saved[4])
+        self.flag.copy_(saved[3]); self.skipped_update.copy_(saved[4]); self.hyper.copy_(saved[5])
       torch.cuda.current_stream(self.device).wait_stream(cap)
       if self.side_stream is not None:
         torch.cuda.current_stream(self.device).wait_stream(self.side_stream)

@@ -117,3 +117,53 @@ def test_custom_decoders_keep_valid_range_words(L, name, enc, dec, in_shape, B):
   for k, v in eng.grad_views().items():
     assert torch.isfinite(v).all(), k
   assert all(np.isfinite(v) for v in rep.values())
+
+
+def _run_steps(L, ring, lrs, betas, monkeypatch, schedule=None, n=None):
+  import os
+  monkeypatch.setenv('ODIN_HYPER_RING', '1' if ring else '0')
+  enc, dec, in_shape, zdim = tiny_conv_spec(1)
+  B = 4
+  eng = VAEEngine(enc, dec, in_shape, zdim, B, 'cpu', lib=L)
+  assert eng.use_hyper_ring == ring
+  g = torch.Generator().manual_seed(3)
+  eng.params.copy_(torch.randn(eng.params.numel(), generator=g) * 0.05)
+  x = torch.rand(B, *in_shape, generator=g).clamp_(1e-6, 1 - 1e-6)
+  copies = 0
+  orig = eng.set_hyper
+  def counting(*a, **k):
+    nonlocal copies
+    copies += 1
+    return orig(*a, **k)
+  eng.set_hyper = counting
+  outs = []
+  for i in range(n or len(lrs)):
+    out = eng.train_step(x, None, lr=lrs[i % len(lrs)], beta=betas[i % len(betas)], global_clipnorm=100.0,
+                         schedule=schedule)
+    outs.append(out.clone())
+  return eng.params.clone(), torch.stack(outs), copies, eng
+
+
+def test_hyper_ring_matches_per_step_copies(L, monkeypatch):
+  """The device-resident schedule (engine._ring_step, odin_sumsq_adam_ring): same parameters and losses, bit for bit,
+  as the per-step host copy -- with constant hyper-parameters (no copy after the first step), across several ring
+  refills, with a learning rate that changes in the middle (one more copy), with values that change every step (a copy
+  per step, as before) and with a schedule known in advance (no copy after the first step)."""
+  monkeypatch.setenv('ODIN_HYPER_RING_ROWS', '16')   # (refilled 4-8 rows at a time: 26 steps wrap it)
+  n = 26
+  p0, o0, c0, _ = _run_steps(L, False, [1e-3], [4.0], monkeypatch, n=n)
+  p1, o1, c1, eng = _run_steps(L, True, [1e-3], [4.0], monkeypatch, n=n)
+  assert torch.equal(p0, p1) and torch.equal(o0, o1)
+  assert c0 == n and c1 == 1
+  assert int(eng.hyper[16:17].view(torch.int32)) == n + 1   # the last Adam loaded the row of the next step
+  lrs = [1e-3] * 5 + [5e-4] * 9
+  p0, o0, c0, _ = _run_steps(L, False, lrs, [2.0], monkeypatch)
+  p1, o1, c1, _ = _run_steps(L, True, lrs, [2.0], monkeypatch)
+  assert torch.equal(p0, p1) and torch.equal(o0, o1) and c1 == 3   # first step, the change, the step that confirms it
+  betas = [1.0 + 0.01 * i for i in range(8)]
+  p0, o0, c0, _ = _run_steps(L, False, [1e-3], betas, monkeypatch, n=8)
+  p1, o1, c1, _ = _run_steps(L, True, [1e-3], betas, monkeypatch, n=8)
+  assert torch.equal(p0, p1) and torch.equal(o0, o1) and c1 == 8
+  sched = lambda u: dict(beta=1.0 + 0.01 * (u - 1))
+  p2, o2, c2, _ = _run_steps(L, True, [1e-3], betas, monkeypatch, schedule=sched, n=8)
+  assert torch.equal(p0, p2) and torch.equal(o0, o2) and c2 == 1
