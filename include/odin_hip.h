@@ -47,6 +47,14 @@ typedef struct odin_conv_desc {
    * the tensor), and only if it is a plane kernel. */
   uint32_t* dy_amax;
   uint32_t* dx_amax;
+  /* Forward pass only, both optional (NULL), round 5: the same side channel for ACTIVATIONS.  x_amax: range word of the
+   * layer input x (read: a plane kernel whose input bound lies outside [2^-8, 2^15) carries x times the exact power of
+   * two that brings it to [2^14, 2^15) -- f16 planes hold |x| <= 65504 and lose relative precision below 2^-25; inside
+   * the window, and without a word, x is carried unscaled as in round 4: then the caller guarantees |x| <= 65504).
+   * y_amax: range word of the layer output y (written, same contract as dx_amax: valid on return whatever family ran).
+   * Weights are always carried unscaled: |w| <= 65504. */
+  const uint32_t* x_amax;
+  uint32_t* y_amax;
 } odin_conv_desc;
 
 /* ---- runtime ------------------------------------------------------------------------ */
@@ -125,6 +133,20 @@ int odin_deconv2d_bwd(const float* x, const float* dy, const float* w, const flo
 int odin_dense_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
                    float* colsum_slab, int* colsum_rows_out, float* wslab, int* wslab_rows_out, int B, int K,
                    int N, int want_wgrad, int want_dgrad, const uint32_t* dy_amax, uint32_t* dx_amax, void* stream);
+/* The Dense entry points with the ACTIVATION range words of round 5 (odin_conv_desc.x_amax / y_amax: same contract):
+ * x_amax (optional) is read by the two-plane GEMM (forward, and the weight gradient's x operand), y_amax (optional) is
+ * valid on return whatever family ran. */
+/* 1: a launch of this layer (forward or weight gradient, as dispatched now) reads the range word of the layer input:
+ * the caller asks the layer below to keep that word only then (a wrong 0 is harmless: no word = unscaled = round 4). */
+int odin_conv2d_reads_x_range(const odin_conv_desc* d);
+int odin_deconv2d_reads_x_range(const odin_conv_desc* d);
+int odin_dense_reads_x_range(int B, int K, int N);
+int odin_dense_fwd_ranged(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, int act,
+                          const uint32_t* x_amax, uint32_t* y_amax, void* stream);
+int odin_dense_bwd_ranged(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                          float* colsum_slab, int* colsum_rows_out, float* wslab, int* wslab_rows_out, int B, int K,
+                          int N, int want_wgrad, int want_dgrad, const uint32_t* dy_amax, uint32_t* dx_amax,
+                          const uint32_t* x_amax, void* stream);
 int odin_dense_dgrad_keeps_range(int B, int K, int N);
 
 /* ---- fused decoder tail of the TRAINING step: layer (Conv2DTranspose if is_deconv else

@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
   """mirror of ``odin_conv_desc`` (include/odin_hip.h)."""
   _fields_ = [(n, C.c_int) for n in ('B', 'H', 'W', 'Cin', 'OH', 'OW', 'Cout', 'KH', 'KW',
                                      'stride', 'pad_t', 'pad_l', 'act', 'center')] + \
-             [('dy_amax', C.c_void_p), ('dx_amax', C.c_void_p)]  # range words of dy / dx (backward; optional)
+             [('dy_amax', C.c_void_p), ('dx_amax', C.c_void_p),  # range words of dy / dx (backward; optional)
+              ('x_amax', C.c_void_p), ('y_amax', C.c_void_p)]    # range words of x / y (forward; optional)
 
 
 class ReduceJob(C.Structure):
@@ -49,7 +50,11 @@ SIGNATURES = {
     'odin_conv2d_bwd': [P, P, P, P, I, P, P, IP, P, IP, DP, P],
     'odin_deconv2d_bwd': [P, P, P, P, I, P, P, IP, P, IP, DP, P],
     'odin_dense_bwd': [P, P, P, P, I, P, P, IP, P, IP, I, I, I, I, I, P, P, P],
+    'odin_dense_bwd_ranged': [P, P, P, P, I, P, P, IP, P, IP, I, I, I, I, I, P, P, P, P],
     'odin_dense_dgrad_keeps_range': [I, I, I],
+    'odin_conv2d_reads_x_range': [DP],
+    'odin_deconv2d_reads_x_range': [DP],
+    'odin_dense_reads_x_range': [I, I, I],
     'odin_absmax': [P, C.c_size_t, P, P],
     'odin_debug_absmax_fallbacks': [],
     'odin_debug_stream_probe': [P, P, P, C.c_size_t, I, I, P],
@@ -68,6 +73,7 @@ SIGNATURES = {
     'odin_deconv2d_wgrad': [P, P, P, IP, DP, P],
     'odin_bernoulli_tail_fwd_bwd': [I, P, P, P, P, P, P, P, P, P, IP, P, IP, P, DP, I, P],
     'odin_dense_fwd': [P, P, P, P, I, I, I, I, P],
+    'odin_dense_fwd_ranged': [P, P, P, P, I, I, I, I, P, P, P],
     'odin_dense_dgrad': [P, P, P, I, P, P, IP, I, I, I, P],
     'odin_dense_wgrad': [P, P, P, IP, I, I, I, P],
     'odin_slab_reduce': [C.POINTER(ReduceJob), I, P],
@@ -118,7 +124,8 @@ SIGNATURES = {
 
 # entry points whose return value is a result, not an error code
 VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_conv2d_dgrad_keeps_range',
-                   'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_dense_dgrad_keeps_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
+                   'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_dense_dgrad_keeps_range', 'odin_conv2d_reads_x_range',
+                   'odin_deconv2d_reads_x_range', 'odin_dense_reads_x_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
                    'odin_latent_block_rows', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop')
 # entry points declared `void` in include/odin_hip.h
 VOID_RETURNING = ('odin_wgrad_planes_defer_begin',)

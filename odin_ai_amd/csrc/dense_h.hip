@@ -30,7 +30,9 @@ struct DHParams {
   const float* aux;         // dgrad: act'(aux) multiplier, same shape as C
   float* colsum;            // wgrad: db[j] = sum_k B(k, j), written by tile row 0 (may be null)
   const unsigned* g_amax;   // range word of the gradient operand (SCA: A, SCB: B)
-  unsigned* out_amax;       // dgrad: range word of C (may be null)
+  unsigned* out_amax;       // forward / dgrad: range word of C (may be null)
+  const unsigned* a_amax;   // AS instances (weight gradient): range word of the activation operand A = x
+  int g_cond;               // the g_amax operand is an ACTIVATION (forward): scaled only outside the safe window
   int M, N, K;              // C is [M, N]; reduction length K (multiple of 8)
   int lda, ldb, ldc;
   int act, aux_act;
@@ -60,7 +62,8 @@ __device__ __forceinline__ void dh_split8(const float (&v)[8], float s, float s2
 }
 
 // NW waves split the k-steps of one 32 x 32 tile (step s -> wave s % NW); SCA / SCB: that operand is a gradient
-template <int NW, bool A_KC, bool B_KC, bool SCA, bool SCB>
+// AS (weight gradient only): the activation operand A comes with its own range word and power of two
+template <int NW, bool A_KC, bool B_KC, bool SCA, bool SCB, bool AS = false>
 __global__ __launch_bounds__(NW * 64) void dense_h_kernel(DHParams p) {
   __shared__ float red[NW * 16 * 64];
   __shared__ float cred[NW * 32 + 16];
@@ -77,16 +80,40 @@ __global__ __launch_bounds__(NW * 64) void dense_h_kernel(DHParams p) {
   const int nsteps = (p.K + 15) >> 4;
   const OdinRun RA = odin_run(p.A, (unsigned)((size_t)(A_KC ? p.M * p.lda : p.K * p.lda) * 4));
   const OdinRun RB = odin_run(p.B, (unsigned)((size_t)(B_KC ? p.N * p.ldb : p.K * p.ldb) * 4));
-  // the gradient operand is carried times 2^gk (its maximum lands in [2^14, 2^15)), the sums are scaled back
-  const int gk = (SCA || SCB) ? odin_range_shift(odin_range_load(p.g_amax)) : 0;
-  const float g_s = (SCA || SCB) ? odin_pow2(gk) : 1.f, g_s2k = (SCA || SCB) ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
+  // the gradient operand is carried times 2^gk (its maximum lands in [2^14, 2^15)), the sums are scaled back.  The
+  // range words are read BEHIND the first operand loads (round 5): their scalar loads then answer beside the vector
+  // loads instead of in front of them -- these launches last 8 us, a serial L2 round trip is 1 us of that
+  int gk = 0, ak = 0;
+  float g_s = 1.f, g_s2k = ODIN_LO_SCALE, a_s = 1.f, a_s2k = ODIN_LO_SCALE;
+  // (activation operands are scaled only when their bound leaves [2^-8, 2^15): wave-uniform flags, one scalar branch
+  // around the split -- the unscaled split is 4 VALU instructions per 4 values cheaper)
+  bool g_on = SCA || SCB, a_on = AS;
+  const OdinRangeReq g_rq = odin_range_issue((SCA || SCB) ? p.g_amax : nullptr, lane);
+  const OdinRangeReq a_rq = odin_range_issue(AS ? p.a_amax : nullptr, lane);
+  auto read_words = [&]() {
+    if (SCA || SCB) {
+      const unsigned mb = odin_range_finish(g_rq);
+      g_on = !p.g_cond || odin_act_needs_scale(mb);
+      gk = g_on ? odin_range_shift(mb) : 0;
+      g_s = odin_pow2(gk); g_s2k = odin_pow2(gk + 11);
+    }
+    if (AS) {
+      const unsigned mb = odin_range_finish(a_rq);
+      a_on = odin_act_needs_scale(mb);
+      ak = a_on ? odin_range_shift(mb) : 0;
+      a_s = odin_pow2(ak); a_s2k = odin_pow2(ak + 11);
+    }
+  };
   f32x16 acc = f32x16_zero(), acx = f32x16_zero();
   float csum = 0.f;  // wgrad bias: column sum of B over this wave's k-steps (lane j = l31, half h)
   float a0[8], b0[8], a1[8], b1[8];
   auto mul = [&](const float (&av)[8], const float (&bv)[8]) {
     u32x4 ah, al, bh, bl;
-    dh_split8<SCA>(av, g_s, g_s2k, ah, al);
-    dh_split8<SCB>(bv, g_s, g_s2k, bh, bl);
+    if (SCA && g_on) dh_split8<true>(av, g_s, g_s2k, ah, al);
+    else if (AS && a_on) dh_split8<true>(av, a_s, a_s2k, ah, al);
+    else dh_split8<false>(av, 1.f, ODIN_LO_SCALE, ah, al);
+    if (SCB && g_on) dh_split8<true>(bv, g_s, g_s2k, bh, bl);
+    else dh_split8<false>(bv, 1.f, ODIN_LO_SCALE, bh, bl);
     acx = mfma32_f16(ah, bl, acx);
     acc = mfma32_f16(ah, bh, acc);
     acx = mfma32_f16(al, bh, acx);
@@ -99,10 +126,12 @@ __global__ __launch_bounds__(NW * 64) void dense_h_kernel(DHParams p) {
   if (s < nsteps) {
     dh_load8<A_KC>(RA, a_ok, ia, p.lda, 16 * s + 8 * h, p.K, a0);
     dh_load8<B_KC>(RB, b_ok, jb, p.ldb, 16 * s + 8 * h, p.K, b0);
+    // (loads beyond the reduction read zeros through the range check: no branch around them)
+    dh_load8<A_KC>(RA, a_ok, ia, p.lda, 16 * (s + NW) + 8 * h, p.K, a1);
+    dh_load8<B_KC>(RB, b_ok, jb, p.ldb, 16 * (s + NW) + 8 * h, p.K, b1);
+    ODIN_SCHED_FENCE();
+    read_words();   // (two batches of operand loads are in flight)
     for (;;) {
-      // (loads beyond the reduction read zeros through the range check: no branch around them)
-      dh_load8<A_KC>(RA, a_ok, ia, p.lda, 16 * (s + NW) + 8 * h, p.K, a1);
-      dh_load8<B_KC>(RB, b_ok, jb, p.ldb, 16 * (s + NW) + 8 * h, p.K, b1);
       ODIN_SCHED_FENCE();
       mul(a0, b0);
       ODIN_SCHED_FENCE();
@@ -114,13 +143,19 @@ __global__ __launch_bounds__(NW * 64) void dense_h_kernel(DHParams p) {
       mul(a1, b1);
       ODIN_SCHED_FENCE();
       if (s >= nsteps) break;
+      dh_load8<A_KC>(RA, a_ok, ia, p.lda, 16 * (s + NW) + 8 * h, p.K, a1);
+      dh_load8<B_KC>(RB, b_ok, jb, p.ldb, 16 * (s + NW) + 8 * h, p.K, b1);
     }
   }
   // ---- the NW partial tiles meet in LDS (main + 2^-11 cross, scaled back); wave w finishes registers
   // [w * 16 / NW, (w + 1) * 16 / NW) in wave order: fixed summation order, bit reproducible ----
+  if (s == wave) read_words();   // (a wave without a k-step: its partial tile is zero, its scales still the tile's)
   const float o_s = (SCA || SCB) ? odin_pow2(-gk) : 1.f, o_sx = (SCA || SCB) ? odin_pow2(-gk - 11) : ODIN_LO_UNSCALE;
 #pragma unroll
-  for (int rr = 0; rr < 16; ++rr) red[(wave * 16 + rr) * 64 + lane] = fmaf(acx[rr], o_sx, acc[rr] * o_s);
+  for (int rr = 0; rr < 16; ++rr) {
+    const float t = fmaf(acx[rr], o_sx, acc[rr] * o_s);
+    red[(wave * 16 + rr) * 64 + lane] = AS ? t * odin_pow2(-ak) : t;   // (the two scales one after the other)
+  }
   if (!A_KC && !B_KC && p.colsum != nullptr) {
     const float t = csum + __shfl_xor(csum, 32);
     if (h == 0) cred[wave * 32 + l31] = t;
@@ -156,13 +191,13 @@ __global__ __launch_bounds__(NW * 64) void dense_h_kernel(DHParams p) {
   }
 }
 
-template <bool A_KC, bool B_KC, bool SCA, bool SCB>
+template <bool A_KC, bool B_KC, bool SCA, bool SCB, bool AS = false>
 int dh_launch(const DHParams& p, int nw, void* stream) {
   dim3 grid((p.N + 31) / 32, (p.M + 31) / 32, 1);
-  if (nw >= 8) ODIN_LAUNCH((dense_h_kernel<8, A_KC, B_KC, SCA, SCB>), grid, dim3(512), 0, stream, p);
-  else if (nw == 4) ODIN_LAUNCH((dense_h_kernel<4, A_KC, B_KC, SCA, SCB>), grid, dim3(256), 0, stream, p);
-  else if (nw == 2) ODIN_LAUNCH((dense_h_kernel<2, A_KC, B_KC, SCA, SCB>), grid, dim3(128), 0, stream, p);
-  else ODIN_LAUNCH((dense_h_kernel<1, A_KC, B_KC, SCA, SCB>), grid, dim3(64), 0, stream, p);
+  if (nw >= 8) ODIN_LAUNCH((dense_h_kernel<8, A_KC, B_KC, SCA, SCB, AS>), grid, dim3(512), 0, stream, p);
+  else if (nw == 4) ODIN_LAUNCH((dense_h_kernel<4, A_KC, B_KC, SCA, SCB, AS>), grid, dim3(256), 0, stream, p);
+  else if (nw == 2) ODIN_LAUNCH((dense_h_kernel<2, A_KC, B_KC, SCA, SCB, AS>), grid, dim3(128), 0, stream, p);
+  else ODIN_LAUNCH((dense_h_kernel<1, A_KC, B_KC, SCA, SCB, AS>), grid, dim3(64), 0, stream, p);
   return odin_check_launch("dense_h(f16x2)");
 }
 
@@ -186,12 +221,21 @@ bool odin_dense_h_ok(int B, int K, int N) {
          (long)B * K < (1L << 29) && (long)B * N < (1L << 29) && (long)K * N < (1L << 29);
 }
 
+// x_amax (optional): the range word of the activation x -- with it x is carried times its own power of two like a
+// gradient operand (any magnitude keeps its 22 bits), without it unscaled (|x| <= 65504); y_amax (optional): the
+// range word of y, folded in from the epilogue
 int odin_dense_h_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, int act,
-                     void* stream) {
+                     const uint32_t* x_amax, uint32_t* y_amax, void* stream) {
   DHParams p;
   memset(&p, 0, sizeof(p));
   p.A = x; p.B = w; p.C = y; p.bias = bias;
   p.M = B; p.N = N; p.K = K; p.lda = K; p.ldb = N; p.ldc = N; p.act = act;
+  p.out_amax = y_amax;
+  if (x_amax != nullptr) {
+    p.g_amax = x_amax;
+    p.g_cond = 1;
+    return dh_launch<true, false, true, false>(p, dh_waves(B, N, K), stream);
+  }
   return dh_launch<true, false, false, false>(p, dh_waves(B, N, K), stream);
 }
 
@@ -210,12 +254,16 @@ int odin_dense_h_dgrad(const float* dy, const float* w, const float* aux, int au
 
 // slab row 0: dW[K, N] = x^T dy, then db[N] = column sums of dy: reduction over the batch; ONE complete row
 int odin_dense_h_wgrad(const float* x, const float* dy, float* slab, int B, int K, int N, const uint32_t* dy_amax,
-                       void* stream) {
+                       const uint32_t* x_amax, void* stream) {
   DHParams p;
   memset(&p, 0, sizeof(p));
   p.A = x; p.B = dy; p.C = slab; p.colsum = slab + (size_t)K * N;
   p.M = K; p.N = N; p.K = B; p.lda = K; p.ldb = N; p.ldc = N;
   p.g_amax = odin_range_word_of(dy, (size_t)B * N, dy_amax, stream);
   if (p.g_amax == nullptr) return odin_fail(-3, "dense_h wgrad: no range word for dy");
+  if (x_amax != nullptr) {
+    p.a_amax = x_amax;
+    return dh_launch<false, false, false, true, true>(p, dh_waves(K, N, B, 2), stream);
+  }
   return dh_launch<false, false, false, true>(p, dh_waves(K, N, B, 2), stream);
 }

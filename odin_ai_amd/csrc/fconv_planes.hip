@@ -60,8 +60,10 @@ constexpr int FP_MAXU = 4;
 // EPI 1: bias + ELU (Conv2D forward); EPI 2: x ELU'(aux), column sums (deconv data gradient); EPI 0: raw partial sums
 // (first of two reduction passes over 64 input channels); ACC: add the partial sums the previous pass left in `out`
 // before the epilogue.
-// SC: the input tensor is a gradient (scaled by 2^gexp on its way into the planes, the result scaled back)
-template <int EPI, int OW, bool ACC, bool SC>
+// SCM 1: the input tensor is a gradient (scaled by 2^gk on its way into the planes, the result scaled back); SCM 2: an
+// ACTIVATION with its range word: scaled the same way only when its bound leaves [2^-8, 2^15) -- a wave-uniform flag,
+// one scalar branch around each split and each scale-back (tconv_planes.hip: why not two bodies behind one branch)
+template <int EPI, int OW, bool ACC, int SCM>
 __device__ __forceinline__ void fp_body(const FPParams& p) {
   constexpr int NPL = 2;                 // f16 planes per operand
   constexpr int TC = 32 / OW;            // output rows per tile
@@ -97,6 +99,7 @@ __device__ __forceinline__ void fp_body(const FPParams& p) {
   (void)stamp_i;
   FP_STAMP(1);
 
+  const OdinRangeReq in_rq = odin_range_issue(SCM != 0 ? p.in_amax : nullptr, lane);   // (finished behind the prologue's loads)
   // ---- the loads of the prologue go out FIRST: this wave's weight fragments (taps (kh, kw0), (kh, kw0 + 1); lane =
   // output channel l31, k = 8 half + e) and its items of fill 0 (all rows of tile T0, offsets computed directly) are in
   // flight while the zero fills and the table arithmetic below run -- a cold L2 answers in ~1 us, and the layers with
@@ -113,16 +116,7 @@ __device__ __forceinline__ void fp_body(const FPParams& p) {
         wv[t][kk][e] = p.w[((size_t)(tap * p.CS + p.ci_off + 16 * kk + 8 * half + e)) * p.CO + n0 + l31];
     }
   const OdinRun RU = odin_run(p.in, (unsigned)((size_t)p.B * HU * WU * p.CS * 4));
-  // a gradient input is carried times 2^gk (its maximum lands in [2^14, 2^15)), the sums are scaled back
-#ifdef ODIN_SIM
-  const int gk = SC ? odin_range_shift(odin_range_load(p.in_amax)) : 0;
-#else
-  const int gk = SC ? odin_range_shift(odin_range_load(p.in_amax)) : 0;
-#endif
-  const float in_s = SC ? odin_pow2(gk) : 1.f;
-  const float in_s2k = SC ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
-  const float out_s = SC ? odin_pow2(-gk) : 1.f;
-  float amx = 0.f;  // running max |out| of this lane (EPI 2)
+  float amx = 0.f;  // running max |out| of this lane (EPI 1 / 2: the range word of `out`)
   constexpr int RPF = FP_MAXU * RJ;      // rows a fill can carry (row r = r0w + RJ j of item j)
   constexpr int DST_NONE = -(1 << 24);   // ring offset of an item without a row: dst stays negative
   constexpr unsigned OFF_NONE = 0x7FFF0000u;  // global offset of a row that is not read (padding row, no image): out of range
@@ -149,6 +143,10 @@ __device__ __forceinline__ void fp_body(const FPParams& p) {
     }
   }
   ODIN_SCHED_FENCE();
+  // (the range word of the input: requested at the top, finished in front of the first split below.  A scaled input
+  // is carried times 2^gk -- its maximum lands in [2^14, 2^15) -- and the sums are scaled back)
+  bool sc = SCM == 1;
+  float in_s = 1.f, in_s2k = ODIN_LO_SCALE, out_s = 1.f;   // (set where the word is finished: in front of the first split)
 
   // ---- SAME-padding slots (parity plane 0 slot 0, parity plane 1 slot OW) of every ring row and plane ----
   for (int e = tid; e < NSU * 8 * NPL; e += 512) {
@@ -217,7 +215,8 @@ __device__ __forceinline__ void fp_body(const FPParams& p) {
     if (__builtin_amdgcn_readfirstlane(it.dst) < 0) return;
 #endif
     u32x2 h, l;
-    odin_split_h4<SC>(it.v, in_s, in_s2k, h, l);
+    if (SCM == 1 || (SCM == 2 && sc)) odin_split_h4<true>(it.v, in_s, in_s2k, h, l);
+    else odin_split_h4<false>(it.v, 1.f, ODIN_LO_SCALE, h, l);
     char* d = ring + it.dst;
     *reinterpret_cast<u32x2*>(d) = h;
     *reinterpret_cast<u32x2*>(d + PBU) = l;
@@ -256,6 +255,13 @@ __device__ __forceinline__ void fp_body(const FPParams& p) {
       wf[t][kk][1][0] = l0.x; wf[t][kk][1][1] = l0.y; wf[t][kk][1][2] = l1.x; wf[t][kk][1][3] = l1.y;
     }
 
+  if (SCM != 0) {
+    // the input's range word (requested first thing in the kernel): the bound, the scale flag, the powers of two
+    const unsigned in_mb = odin_range_finish(in_rq);
+    sc = SCM == 1 || odin_act_needs_scale(in_mb);
+    const int gk = sc ? odin_range_shift(in_mb) : 0;
+    in_s = odin_pow2(gk); in_s2k = odin_pow2(gk + 11); out_s = odin_pow2(-gk);
+  }
   FP_STAMP(8);
 #pragma unroll
   for (int j = 0; j < FP_MAXU; ++j) store_item(iuA[j]);
@@ -292,7 +298,7 @@ __device__ __forceinline__ void fp_body(const FPParams& p) {
 #pragma unroll
     for (int wv = 1; wv < 8; ++wv) { s.x += q8[wv].x; s.y += q8[wv].y; }
     float v[2] = {s.x, s.y};
-    if (SC) { v[0] *= out_s; v[1] *= out_s; }
+    if (SCM == 1 || (SCM == 2 && sc)) { v[0] *= out_s; v[1] *= out_s; }
     if (ACC) { v[0] += pvP.x; v[1] += pvP.y; }
     if (EPI == 1) {
 #pragma unroll
@@ -300,6 +306,7 @@ __device__ __forceinline__ void fp_body(const FPParams& p) {
         const float tt = v[k] + bias2[k];
         v[k] = fmaxf(tt, 0.f) + (odin_exp2(fminf(tt, 0.f) * 1.44269504088896341f) - 1.f);
       }
+      amx = odin_amax3(amx, v[0], v[1]);   // (the range word of the activation: odin_conv_desc.y_amax)
     } else if (EPI == 2) {
       v[0] = fmaf(v[0], fminf(auxP.x, 0.f), v[0]);  // x ELU'(aux) = 1 + min(aux, 0)
       v[1] = fmaf(v[1], fminf(auxP.y, 0.f), v[1]);
@@ -383,7 +390,7 @@ __device__ __forceinline__ void fp_body(const FPParams& p) {
     finish_done(q8);
   }
 
-  if (EPI == 2) {
+  if (EPI == 2 || EPI == 1) {
     __syncthreads();  // (the partial-tile scratch is free: every wave is past its last finish pass)
     odin_amax_commit_wg(p.out_amax, amx, tid, 512, reinterpret_cast<float*>(red), blockIdx.x + gridDim.x * blockIdx.y);
   }
@@ -400,21 +407,21 @@ __device__ __forceinline__ void fp_body(const FPParams& p) {
   }
 }
 
-template <int EPI, int OW, bool ACC, bool SC>
+template <int EPI, int OW, bool ACC, int SCM>
 __global__ __launch_bounds__(512) void fconv_planes_kernel(FPParams p) {
-  fp_body<EPI, OW, ACC, SC>(p);
+  fp_body<EPI, OW, ACC, SCM>(p);
 }
 
 // 64 reduction channels in ONE launch: both 32-channel passes inside the kernel (tconv_planes.hip: tconv_planes2_kernel);
 // the partial sums a thread leaves in `out` are read back by the same thread (same wave / register-pair ownership)
-template <int EPI, int OW, bool SC>
+template <int EPI, int OW, int SCM>
 __global__ __launch_bounds__(512) void fconv_planes2_kernel(FPParams p) {
   {
     FPParams q = p;
     q.colsum = nullptr;
     q.out_amax = nullptr;
     q.ci_off = 0;
-    fp_body<0, OW, false, SC>(q);
+    fp_body<0, OW, false, SCM>(q);
   }
   // (the same thread reads back what it wrote, through the same CU's write-through L1 and its XCD's L2: a
   // workgroup-scope fence orders it; a device-scope __threadfence() writes back and invalidates the whole L2 of the
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(512) void fconv_planes2_kernel(FPParams p) {
 #endif
   __syncthreads();
   p.ci_off = 32;
-  fp_body<EPI, OW, true, SC>(p);
+  fp_body<EPI, OW, true, SCM>(p);
 }
 
 // LDS: row ring + two partial-tile buffers + the fill tables ((1 + rows per fill) x 8 bytes per fill, tiles + 4 fills)
@@ -447,7 +454,7 @@ int fp_tiles_per_wg(int OW, int n_tiles, int gy) {
   return tpw;
 }
 
-template <int EPI, int OW, bool ACC, bool SC>
+template <int EPI, int OW, bool ACC, int SC>
 int fp_launch(const FPParams& p, dim3 grid, void* stream) {
   const size_t lds = (size_t)fp_ring_bytes(OW) + (size_t)(p.tiles_per_wg + 4) * fp_fill_bytes(OW);
 #ifndef ODIN_SIM
@@ -463,7 +470,7 @@ int fp_launch(const FPParams& p, dim3 grid, void* stream) {
   return odin_check_launch("fconv_planes(f16x2)");
 }
 
-template <int EPI, bool SC>
+template <int EPI, int SC>
 int fp_launch2_w(const FPParams& p, int OW, dim3 grid, void* stream) {
   const size_t lds = (size_t)fp_ring_bytes(OW) + (size_t)(p.tiles_per_wg + 4) * fp_fill_bytes(OW);
 #ifndef ODIN_SIM
@@ -499,7 +506,7 @@ bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, i
          fp_tiles_per_wg(OW, B * (OH / (32 / OW)), CO / 32) > 0;
 }
 
-template <int EPI, bool ACC, bool SC>
+template <int EPI, bool ACC, int SC>
 int fp_launch_w(const FPParams& p, int OW, dim3 grid, void* stream) {
   if (OW == 32) return fp_launch<EPI, 32, ACC, SC>(p, grid, stream);
   if (OW == 16) return fp_launch<EPI, 16, ACC, SC>(p, grid, stream);
@@ -531,7 +538,12 @@ int odin_fconv_planes_launch(const float* in, const float* w, const float* bias,
     p.in_amax = odin_range_word_of(in, (size_t)B * 2 * OH * 2 * OW * CI, in_amax, stream);
     if (p.in_amax == nullptr) return odin_fail(-3, "fconv_planes: no range word for the gradient input");
     p.out_amax = out_amax;
+  } else {
+    // forward: the activation's word, where the caller has one (scaled only outside the safe window); its output's
+    p.in_amax = in_amax;
+    p.out_amax = out_amax;
   }
+  const bool aw = epi == 1 && in_amax != nullptr;
   dim3 grid(gx, gy, 1);
   if (CI == 64) {
 #ifdef ODIN_DIAG  // diagnostics build: A/B against the two-launch form of round 3
@@ -539,13 +551,15 @@ int odin_fconv_planes_launch(const float* in, const float* w, const float* bias,
       FPParams q = p;
       q.colsum = nullptr;
       q.out_amax = nullptr;
-      const int rc = epi == 1 ? fp_launch_w<0, false, false>(q, OW, grid, stream) : fp_launch_w<0, false, true>(q, OW, grid, stream);
+      const int rc = epi == 1 ? fp_launch_w<0, false, 0>(q, OW, grid, stream) : fp_launch_w<0, false, 1>(q, OW, grid, stream);
       if (rc != 0) return rc;
       p.ci_off = 32;
-      return epi == 1 ? fp_launch_w<1, true, false>(p, OW, grid, stream) : fp_launch_w<2, true, true>(p, OW, grid, stream);
+      return epi == 1 ? fp_launch_w<1, true, 0>(p, OW, grid, stream) : fp_launch_w<2, true, 1>(p, OW, grid, stream);
     }
 #endif
-    return epi == 1 ? fp_launch2_w<1, false>(p, OW, grid, stream) : fp_launch2_w<2, true>(p, OW, grid, stream);
+    if (epi == 1) return aw ? fp_launch2_w<1, 2>(p, OW, grid, stream) : fp_launch2_w<1, 0>(p, OW, grid, stream);
+    return fp_launch2_w<2, 1>(p, OW, grid, stream);
   }
-  return epi == 1 ? fp_launch_w<1, false, false>(p, OW, grid, stream) : fp_launch_w<2, false, true>(p, OW, grid, stream);
+  if (epi == 1) return aw ? fp_launch_w<1, false, 2>(p, OW, grid, stream) : fp_launch_w<1, false, 0>(p, OW, grid, stream);
+  return fp_launch_w<2, false, 1>(p, OW, grid, stream);
 }

@@ -1600,35 +1600,43 @@ void fill_common(GParams& p, const odin_conv_desc* d) {
 
 extern "C" int odin_max_slab_rows(void) { return ODIN_MAX_COLSUM_BLOCKS; }
 
+// The forward half of the range contract (include/odin_hip.h: odin_conv_desc.x_amax / y_amax): a layer that is handed
+// a word for its output leaves a valid bound in it -- from the epilogue of the plane / implicit-GEMM / first-layer
+// families, by one pass over y behind the others.
+static int track_y(int rc, const float* y, const odin_conv_desc* d, void* stream) {
+  if (rc != 0 || y == nullptr || d->y_amax == nullptr) return rc;
+  return odin_absmax_fold(y, (size_t)d->B * d->OH * d->OW * d->Cout, d->y_amax, stream);
+}
+
 // ---- Conv2D -------------------------------------------------------------------------
 extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                                const odin_conv_desc* d, void* stream) {
-  if (odin_smallc_applicable(d)) return odin_smallc_fwd(x, w, bias, y, d, stream);
-  if (odin_pw1x1_applicable(d)) return odin_pw1x1_fwd(x, w, bias, y, d, stream);
+  if (odin_smallc_applicable(d)) return odin_smallc_fwd(x, w, bias, y, d, stream);   // (tracks y itself)
+  if (odin_pw1x1_applicable(d)) return track_y(odin_pw1x1_fwd(x, w, bias, y, d, stream), y, d, stream);
   if (d->act == ODIN_ACT_ELU && bias != nullptr &&
       odin_fconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                                    d->pad_t, d->pad_l, d->center))
     return odin_fconv_planes_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->OH, d->OW, d->Cin, d->Cout,
-                                    1, nullptr, nullptr, stream);
+                                    1, d->x_amax, d->y_amax, stream);
   if (d->act == ODIN_ACT_ELU && bias != nullptr &&
       odin_fconv_ring_applicable(d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                                  d->pad_t, d->pad_l, d->center))
-    return odin_fconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->Cin,
-                                  d->OH, d->OW, d->Cout, 1, stream);
+    return track_y(odin_fconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->Cin,
+                                          d->OH, d->OW, d->Cout, 1, stream), y, d, stream);
   if (odin_igemm_h_applicable(0, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->center))
     return odin_igemm_h_launch(0, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
-                               d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, nullptr, 0, nullptr,
+                               d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, d->x_amax, 0, d->y_amax,
                                stream);
   if (odin_igemm_applicable(0, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                             d->center))
     return odin_igemm_launch(0, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
-                             d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, nullptr, stream);
+                             d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, d->y_amax, stream);
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = y;
   p.H = d->H; p.W = d->W; p.CI = d->Cin; p.OH = d->OH; p.OW = d->OW; p.CO = d->Cout;
   p.wmode = 0; p.act = d->act; p.center = d->center;
-  return launch_gather(MODE_F, p, stream, odin_num_cus());
+  return track_y(launch_gather(MODE_F, p, stream, odin_num_cus()), y, d, stream);
 }
 
 // dx[b,ih,iw,ci] = sum_{kh,kw,co} dy[b,(ih+pt-kh)/S,(iw+pl-kw)/S,co] * W[kh,kw,ci,co];
@@ -1734,27 +1742,27 @@ extern "C" int odin_deconv2d_fwd(const float* x, const float* w, const float* bi
                                    d->pad_l, d->center, 1, 1))
     return odin_tconv_planes_launch(x, w, bias, nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->H, d->W,
-                                    d->Cin, d->Cout, 1, nullptr, nullptr, stream);
+                                    d->Cin, d->Cout, 1, d->x_amax, d->y_amax, stream);
   if (d->act == ODIN_ACT_ELU && bias != nullptr && d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_tconv_ring_applicable(d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
                                  d->pad_l, d->center))
-    return odin_tconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                  nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->H, d->W,
-                                  d->Cout, 1, stream);
+    return track_y(odin_tconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                          nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->H, d->W,
+                                          d->Cout, 1, stream), y, d, stream);
   if (odin_igemm_h_applicable(1, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->center))
     return odin_igemm_h_launch(1, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
-                               d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, nullptr, 0, nullptr,
+                               d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, d->x_amax, 0, d->y_amax,
                                stream);
   if (odin_igemm_applicable(1, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                             d->center))
     return odin_igemm_launch(1, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
-                             d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, nullptr, stream);
+                             d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, d->y_amax, stream);
   GParams p;
   fill_common(p, d);
   p.in = x; p.w = w; p.bias = bias; p.out = y;
   p.H = d->H; p.W = d->W; p.CI = d->Cin; p.OH = d->OH; p.OW = d->OW; p.CO = d->Cout;
   p.wmode = 1; p.act = d->act; p.center = d->center;
-  return launch_gather(MODE_T, p, stream, odin_num_cus());
+  return track_y(launch_gather(MODE_T, p, stream, odin_num_cus()), y, d, stream);
 }
 
 extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float* aux,
@@ -1809,18 +1817,29 @@ static bool dense_via_igemm() { return ODIN_DIAG_ENV("ODIN_NODENSEIGEMM") == nul
 // ---- Dense: y[B,N] = act(x[B,K] @ w[K,N] + b) ----------------------------------------
 extern "C" int odin_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B,
                               int K, int N, int act, void* stream) {
-  if (odin_tiny_dense_ok(B, K, N)) return odin_tiny_dense_fwd(x, w, bias, y, B, K, N, act, stream);
-  if (odin_dense_h_ok(B, K, N)) return odin_dense_h_fwd(x, w, bias, y, B, K, N, act, stream);
+  return odin_dense_fwd_ranged(x, w, bias, y, B, K, N, act, nullptr, nullptr, stream);
+}
+
+// the same with the activation range words (include/odin_hip.h: the range contract): x_amax is read by the two-plane
+// GEMM, y_amax is valid on return whatever family ran
+extern "C" int odin_dense_fwd_ranged(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,
+                                     int act, const uint32_t* x_amax, uint32_t* y_amax, void* stream) {
+  auto fold = [&](int rc) {
+    if (rc != 0 || y == nullptr || y_amax == nullptr) return rc;
+    return odin_absmax_fold(y, (size_t)B * N, y_amax, stream);
+  };
+  if (odin_tiny_dense_ok(B, K, N)) return fold(odin_tiny_dense_fwd(x, w, bias, y, B, K, N, act, stream));
+  if (odin_dense_h_ok(B, K, N)) return odin_dense_h_fwd(x, w, bias, y, B, K, N, act, x_amax, y_amax, stream);
   if (dense_via_igemm() && odin_igemm_applicable(0, B, 1, 1, K, 1, 1, N, 1, 1, 1, 0))
-    return odin_igemm_launch(0, x, w, bias, nullptr, 0, y, nullptr, B, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, act, nullptr,
+    return odin_igemm_launch(0, x, w, bias, nullptr, 0, y, nullptr, B, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, act, y_amax,
                              stream);
-  if (odin_dense_gemm_ok(B, K, N)) return odin_dense_gemm_fwd(x, w, bias, y, B, K, N, act, stream);
+  if (odin_dense_gemm_ok(B, K, N)) return fold(odin_dense_gemm_fwd(x, w, bias, y, B, K, N, act, stream));
   GParams p;
   memset(&p, 0, sizeof(p));
   p.in = x; p.w = w; p.bias = bias; p.out = y;
   p.B = B; p.H = 1; p.W = 1; p.CI = K; p.OH = 1; p.OW = 1; p.CO = N;
   p.KH = p.KW = 1; p.S = 1; p.act = act; p.wmode = 0;
-  return launch_gather(MODE_F, p, stream, odin_num_cus());
+  return fold(launch_gather(MODE_F, p, stream, odin_num_cus()));
 }
 
 // dx[B,K] = (dy[B,N] @ w[K,N]^T) * act'(aux)
@@ -1894,7 +1913,7 @@ extern "C" int odin_bernoulli_tail_fwd_bwd(int is_deconv, const float* x, const 
                                    d->pad_l, d->center, 3, C1))
     return odin_tconv_planes_launch(x, w, bias, nullptr, g_out, nullptr, slab_rows_out, w1, b1, target,
                                     logits, llk_part, n_part_out, tail_slab, scale, C1, d->B, d->H, d->W,
-                                    d->Cin, d->Cout, 3, nullptr, d->dy_amax, stream);
+                                    d->Cin, d->Cout, 3, d->x_amax, d->dy_amax, stream);
   if (is_deconv && d->act == ODIN_ACT_ELU && d->Cout == 32 && (C1 == 1 || C1 == 3) &&
       d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_tconv_ring_applicable(d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,

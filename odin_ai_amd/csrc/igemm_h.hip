@@ -54,7 +54,8 @@ struct IHParams {
   const float* bias;  // forward
   const float* aux;   // data gradient: multiply by act'(aux), aux shaped like out
   float* colsum;      // data gradient: slab [gridDim.y][CO] of column sums (may be null)
-  const unsigned* in_amax;  // SC: range word of `in` (a gradient tensor)
+  const unsigned* in_amax;  // SC: range word of `in` (a gradient tensor, or an activation: in_cond)
+  int in_cond;              // `in` is an ACTIVATION: scaled only when its bound leaves [2^-8, 2^15)
   unsigned* out_amax;       // data gradient: range word of `out` (may be null)
   int B, H, W, CI, OH, OW, CO, KH, KW, S, pt, pl;
   int gpt;            // 16-channel groups per tap = CI / 16
@@ -94,10 +95,13 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_h_kernel(IHParams p) {
   const OdinRun RO = odin_run(p.out, (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4));
   const bool has_aux = p.aux != nullptr;
   const OdinRun RX = odin_run(has_aux ? p.aux : p.in, has_aux ? (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4) : 0u);
-  // a gradient input is carried times 2^gk (its maximum lands in [2^14, 2^15)), the sums are scaled back
-  const int gk = SC ? odin_range_shift(odin_range_load(p.in_amax)) : 0;
-  const float in_s = SC ? odin_pow2(gk) : 1.f, in_s2k = SC ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
-  const float o_s = SC ? odin_pow2(-gk) : 1.f, o_sx = SC ? odin_pow2(-gk - 11) : ODIN_LO_UNSCALE;
+  // a gradient input is carried times 2^gk (its maximum lands in [2^14, 2^15)), the sums are scaled back; an ACTIVATION
+  // input (in_cond) only when its bound leaves the safe window (a wave-uniform flag around the split)
+  const unsigned in_mb = SC ? odin_range_load(p.in_amax) : 0u;
+  const bool sc_on = SC && (!p.in_cond || odin_act_needs_scale(in_mb));
+  const int gk = sc_on ? odin_range_shift(in_mb) : 0;
+  const float in_s = odin_pow2(gk), in_s2k = odin_pow2(gk + 11);
+  const float o_s = odin_pow2(-gk), o_sx = odin_pow2(-gk - 11);
   const int SS = TMODE ? p.S : 1;     // 1 or 2
   const int ssh = SS >> 1;            // x / SS = x >> ssh,  x % SS = x & (SS - 1)
   const int ohs = p.OH >> ssh, ows = p.OW >> ssh;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(IH_NW * 64) void igemm_h_kernel(IHParams p) {
     };
     auto mul = [&](const float (&av)[8], const float (&bv)[8]) {
       u32x4 ah, al, bh, bl2;
-      ih_split8<SC>(av, in_s, in_s2k, ah, al);
+      if (SC && sc_on) ih_split8<true>(av, in_s, in_s2k, ah, al); else ih_split8<false>(av, 1.f, ODIN_LO_SCALE, ah, al);
       ih_split8<false>(bv, 1.f, ODIN_LO_SCALE, bh, bl2);
       acx = mfma32_f16(ah, bl2, acx);
       acc = mfma32_f16(ah, bh, acc);
@@ -263,15 +267,14 @@ __device__ __forceinline__ void igemm_hw_body(const IHParams& p) {
   const int l31 = lane & 31, h = lane >> 5;
   const int j = blockIdx.x * 32 + l31;
   const bool b_ok = j < p.CO;
+  // (the input's range word: requested here, finished behind the weight staging -- odin_device.h: odin_range_issue)
+  const OdinRangeReq in_rq = odin_range_issue(SC ? p.in_amax : nullptr, lane);
   const float bj = (p.bias != nullptr && b_ok) ? p.bias[j] : 0.f;
   const OdinRun RA = odin_run(p.in, (unsigned)((size_t)p.B * p.H * p.W * p.CI * 4));
   const OdinRun RB = odin_run(p.w, (unsigned)((size_t)p.KH * p.KW * p.CI * p.CO * 4));
   const OdinRun RO = odin_run(p.out, (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4));
   const bool has_aux = p.aux != nullptr;
   const OdinRun RX = odin_run(has_aux ? p.aux : p.in, has_aux ? (unsigned)((size_t)p.B * p.OH * p.OW * p.CO * 4) : 0u);
-  const int gk = SC ? odin_range_shift(odin_range_load(p.in_amax)) : 0;
-  const float in_s = SC ? odin_pow2(gk) : 1.f, in_s2k = SC ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
-  const float o_s = SC ? odin_pow2(-gk) : 1.f, o_sx = SC ? odin_pow2(-gk - 11) : ODIN_LO_UNSCALE;
   const int SS = TMODE ? p.S : 1;     // 1 or 2
   const int ssh = SS >> 1;
   const int ncls = SS * SS;
@@ -326,6 +329,11 @@ __device__ __forceinline__ void igemm_hw_body(const IHParams& p) {
     *reinterpret_cast<u32x4*>(wlds + ((((s * 2 + 1) * 2 + hh) * 32 + jl) << 4)) = wl;
   }
   __syncthreads();
+  const unsigned in_mb = SC ? odin_range_finish(in_rq) : 0u;
+  const bool sc_on = SC && (!p.in_cond || odin_act_needs_scale(in_mb));
+  const int gk = sc_on ? odin_range_shift(in_mb) : 0;
+  const float in_s = odin_pow2(gk), in_s2k = odin_pow2(gk + 11);
+  const float o_s = odin_pow2(-gk), o_sx = odin_pow2(-gk - 11);
   const unsigned dbg_a = (p.dbg & 1u) ? 0xFFFFFFFFu : 0u, dbg_s = (p.dbg & 2u) ? 0xFFFFFFFFu : 0u;
   const char* wme0 = wlds + ((h * 32 + l31) << 4);   // this lane's entry of step 0, plane 0; + 2048 per step, + 1024 lo plane
   float csum = 0.f, amx = 0.f;
@@ -381,7 +389,7 @@ __device__ __forceinline__ void igemm_hw_body(const IHParams& p) {
       // (a step beyond the reduction carries zeros in A: any valid weight step will do)
       const int sc = s < ngroups ? s : ngroups - 1;
       u32x4 ah, al;
-      ih_split8<SC>(av, in_s, in_s2k, ah, al);
+      if (SC && sc_on) ih_split8<true>(av, in_s, in_s2k, ah, al); else ih_split8<false>(av, 1.f, ODIN_LO_SCALE, ah, al);
       const u32x4 bh = *reinterpret_cast<const u32x4*>(wme + (sc << 11));
       const u32x4 bl2 = *reinterpret_cast<const u32x4*>(wme + (sc << 11) + 1024);
       acx = mfma32_f16(ah, bl2, acx);
@@ -506,6 +514,7 @@ struct IHWParams {
   const float* v;   // coarse tensor [B, h, w, CV]
   float* slab;      // [gridDim.z][slab_stride]: (dW [KH*KW*CU][CV] | column sums of V [CV])
   const unsigned* g_amax;  // range word of the gradient operand (SCU: u, SCV: v)
+  const unsigned* a_amax;  // AS instances: range word of the other (activation) operand
   int slab_stride;
   int B, FH, FW, CU, h, w, CV, KH, KW, S, pt, pl;
   int M;            // B * h * w
@@ -516,7 +525,8 @@ struct IHWParams {
 constexpr int IHW_CHUNK = 2048;
 
 // NW waves split the 16-pixel steps of a workgroup's chunk; SCU / SCV: that operand is a gradient
-template <int NW, bool SCU, bool SCV>
+// AS: the activation operand comes with its range word and is carried times its own power of two
+template <int NW, bool SCU, bool SCV, bool AS = false>
 __global__ __launch_bounds__(NW * 64) void igemm_h_wgrad_kernel(IHWParams p) {
   __shared__ float red[NW > 1 ? (NW - 1) * 16 * 64 : 64];
   // per coarse pixel m of this workgroup: byte offset of the fine pixel (y S - pt, x S - pl), and the bit mask of the
@@ -559,6 +569,10 @@ __global__ __launch_bounds__(NW * 64) void igemm_h_wgrad_kernel(IHWParams p) {
   const OdinRun RV = odin_run(p.v, (unsigned)((size_t)mhi * p.CV * 4));   // (rows beyond this workgroup's pixels read zeros)
   const int gk = (SCU || SCV) ? odin_range_shift(odin_range_load(p.g_amax)) : 0;
   const float g_s = (SCU || SCV) ? odin_pow2(gk) : 1.f, g_s2k = (SCU || SCV) ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
+  const unsigned a_mb = AS ? odin_range_load(p.a_amax) : 0u;
+  const bool a_on = AS && odin_act_needs_scale(a_mb);   // (an activation is scaled only outside the safe window)
+  const int ak = a_on ? odin_range_shift(a_mb) : 0;
+  const float a_s = odin_pow2(ak), a_s2k = odin_pow2(ak + 11);
   const int nsteps = (mhi - mlo + 15) >> 4;
   f32x16 acc = f32x16_zero(), acx = f32x16_zero();
   float csum = 0.f;
@@ -583,8 +597,12 @@ __global__ __launch_bounds__(NW * 64) void igemm_h_wgrad_kernel(IHWParams p) {
   };
   auto mul = [&](const float (&av)[8], const float (&bv)[8]) {
     u32x4 ah, al, bh, bl;
-    ih_split8<SCU>(av, g_s, g_s2k, ah, al);
-    ih_split8<SCV>(bv, g_s, g_s2k, bh, bl);
+    if (SCU) ih_split8<true>(av, g_s, g_s2k, ah, al);
+    else if (AS && a_on) ih_split8<true>(av, a_s, a_s2k, ah, al);
+    else ih_split8<false>(av, 1.f, ODIN_LO_SCALE, ah, al);
+    if (SCV) ih_split8<true>(bv, g_s, g_s2k, bh, bl);
+    else if (AS && a_on) ih_split8<true>(bv, a_s, a_s2k, bh, bl);
+    else ih_split8<false>(bv, 1.f, ODIN_LO_SCALE, bh, bl);
     acx = mfma32_f16(ah, bl, acx);
     acc = mfma32_f16(ah, bh, acc);
     acx = mfma32_f16(al, bh, acx);
@@ -615,6 +633,11 @@ __global__ __launch_bounds__(NW * 64) void igemm_h_wgrad_kernel(IHWParams p) {
   f32x16 tot;
 #pragma unroll
   for (int rr = 0; rr < 16; ++rr) tot[rr] = fmaf(acx[rr], o_sx, acc[rr] * o_s);
+  if (AS) {   // (the two scales are taken back one after the other: their sum may leave one factor's exponent range)
+    const float a_o = odin_pow2(-ak);
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) tot[rr] *= a_o;
+  }
   if (NW > 1) {
     if (wave > 0) {
 #pragma unroll
@@ -721,6 +744,12 @@ int odin_igemm_h_launch(int tmode, const float* in, const float* w, const float*
   if (in_is_grad) {
     p.in_amax = odin_range_word_of(in, (size_t)B * H * W * CI, in_amax, stream);
     if (p.in_amax == nullptr) return odin_fail(-3, "igemm_h: no range word for the gradient input");
+  } else if (in_amax != nullptr) {
+    // an ACTIVATION that comes with its range word (odin_conv_desc.x_amax) takes the scaled instances too: any
+    // magnitude keeps its 22 bits; without a word the input is carried unscaled (|x| <= 65504)
+    p.in_amax = in_amax;
+    p.in_cond = 1;
+    in_is_grad = 1;
   }
   // every wave walks tiles grid-stride: the whole chip in one wave of workgroups for the big layers (and the column
   // sums stay within ODIN_MAX_COLSUM_BLOCKS rows)
@@ -817,10 +846,10 @@ int odin_igemm_h_wgrad_rows(int B, int h, int w, int KH, int KW, int CU, int CV)
 
 int odin_igemm_h_wgrad_launch(const float* u, const float* v, float* slab, int slab_stride, int B, int FH, int FW,
                               int CU, int h, int w, int CV, int KH, int KW, int S, int pt, int pl, int want_bias,
-                              int grad_u, const uint32_t* g_amax, void* stream) {
+                              int grad_u, const uint32_t* g_amax, const uint32_t* a_amax, void* stream) {
   IHWParams p;
   memset(&p, 0, sizeof(p));
-  p.u = u; p.v = v; p.slab = slab; p.slab_stride = slab_stride;
+  p.u = u; p.v = v; p.slab = slab; p.slab_stride = slab_stride; p.a_amax = a_amax;
   p.B = B; p.FH = FH; p.FW = FW; p.CU = CU; p.h = h; p.w = w; p.CV = CV;
   p.KH = KH; p.KW = KW; p.S = S; p.pt = pt; p.pl = pl; p.want_bias = want_bias;
   p.M = B * h * w;
@@ -839,7 +868,10 @@ int odin_igemm_h_wgrad_launch(const float* u, const float* v, float* slab, int s
   if (const char* e = ODIN_DIAG_ENV("ODIN_IHW_NW")) nw = atoi(e);
 #define ODIN_IHW(N_)                                                                                        \
   do {                                                                                                      \
-    if (grad_u) ODIN_LAUNCH((igemm_h_wgrad_kernel<N_, true, false>), grid, dim3(N_ * 64), 0, stream, p);   \
+    if (a_amax != nullptr) {                                                                                \
+      if (grad_u) ODIN_LAUNCH((igemm_h_wgrad_kernel<N_, true, false, true>), grid, dim3(N_ * 64), 0, stream, p);  \
+      else ODIN_LAUNCH((igemm_h_wgrad_kernel<N_, false, true, true>), grid, dim3(N_ * 64), 0, stream, p);   \
+    } else if (grad_u) ODIN_LAUNCH((igemm_h_wgrad_kernel<N_, true, false>), grid, dim3(N_ * 64), 0, stream, p);   \
     else ODIN_LAUNCH((igemm_h_wgrad_kernel<N_, false, true>), grid, dim3(N_ * 64), 0, stream, p);          \
   } while (0)
   if (nw >= 4) ODIN_IHW(4);

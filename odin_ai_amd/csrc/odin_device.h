@@ -217,12 +217,40 @@ __device__ __forceinline__ int odin_range_shift(unsigned mb) {
   if (e < 26) e = 26;     // a zero (or < 2^-101) tensor
   return 141 - e;
 }
+// ACTIVATION operands of the plane kernels (round 5): carried unscaled while their bound lies in [2^-8, 2^15) -- every
+// benchmark tensor does, and the unscaled split is 4 VALU instructions per 4 values cheaper -- and through the scaled
+// split of the gradient operands otherwise (|x| up to 3e38 and down to 1e-38 keep their 22 bits).  Wave-uniform; a
+// kernel holds both bodies and branches once.  No word, a zero tensor or a non-finite bound: unscaled.
+__device__ __forceinline__ bool odin_act_needs_scale(unsigned mb) {
+  const int e = (int)((mb >> 23) & 0xFFu);
+  return e != 0 && e != 255 && (e >= 127 + 15 || e < 127 - 8);
+}
 __device__ __forceinline__ float odin_pow2(int k) { return odin_bitsf((unsigned)(127 + k) << 23); }  // -126 <= k <= 127
-// max over the 64 lanes (every lane receives it)
+// max over the 64 lanes of NON-NEGATIVE values (every lane receives it).  On the vector ALU (quad / row DPP moves and
+// the gfx950 row swaps): the six ds_bpermute round trips of the shuffle form sat at the very end of every producing
+// kernel (the range-word commit), ~0.5 us per launch
 __device__ __forceinline__ float odin_wave_max64(float v) {
+#ifdef ODIN_SIM
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
   return v;
+#else
+  // (bit patterns of non-negative floats order like unsigned integers; a NaN bound stays the largest pattern)
+  unsigned m = __float_as_uint(v), o;
+  o = __builtin_amdgcn_update_dpp(0u, m, 0xB1, 0xF, 0xF, false); m = o > m ? o : m;    // quad_perm [1,0,3,2]
+  o = __builtin_amdgcn_update_dpp(0u, m, 0x4E, 0xF, 0xF, false); m = o > m ? o : m;    // quad_perm [2,3,0,1]
+  o = __builtin_amdgcn_update_dpp(0u, m, 0x141, 0xF, 0xF, false); m = o > m ? o : m;   // row_half_mirror
+  o = __builtin_amdgcn_update_dpp(0u, m, 0x140, 0xF, 0xF, false); m = o > m ? o : m;   // row_mirror
+  {
+    const auto q = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+    m = q[0] > q[1] ? q[0] : q[1];
+  }
+  {
+    const auto q = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+    m = q[0] > q[1] ? q[0] : q[1];
+  }
+  return __uint_as_float(m);
+#endif
 }
 // A range "word" is a BLOCK of ODIN_RANGE_SLOTS sub-words, ODIN_RANGE_STRIDE words apart (one per 256-byte
 // line): same-address atomics of a whole launch serialise at the memory side (~8 ns each measured: one atomicMax
@@ -242,6 +270,42 @@ __device__ __forceinline__ unsigned odin_range_load(const unsigned* block) {
 #ifdef ODIN_SIM
   return m;
 #else
+  return __builtin_amdgcn_readfirstlane(m);
+#endif
+}
+// The same read in two halves (round 5): ONE vector load at the top of a kernel -- lane s < 32 fetches sub-word s --
+// and the wave maximum taken where the bound is first needed (the first split, behind the prologue's loads).  The 32
+// scalar loads of odin_range_load stall the wave at their s_waitcnt for an L2 round trip (~1 us of a launch) wherever
+// the compiler puts it, and it puts it in front of the next vector load; a vector load waits in vmcnt order with the
+// weight / row loads behind it.
+struct OdinRangeReq { unsigned v; };
+__device__ __forceinline__ OdinRangeReq odin_range_issue(const unsigned* block, int lane) {
+  OdinRangeReq r;
+  r.v = 0u;
+  if (block != nullptr && lane < ODIN_RANGE_SLOTS) r.v = block[lane * ODIN_RANGE_STRIDE];
+  return r;
+}
+__device__ __forceinline__ unsigned odin_range_finish(const OdinRangeReq& r) {
+#ifdef ODIN_SIM
+  unsigned m = r.v;
+  for (int k = 32; k >= 1; k >>= 1) { const unsigned o = __shfl_xor(m, k); m = o > m ? o : m; }
+  return m;
+#else
+  // max over the 64 lanes on the vector ALU (quad / row DPP moves, then the gfx950 row swaps): no LDS round trip
+  unsigned m = r.v;
+  unsigned o;
+  o = __builtin_amdgcn_update_dpp(0u, m, 0xB1, 0xF, 0xF, false); m = o > m ? o : m;    // quad_perm [1,0,3,2]
+  o = __builtin_amdgcn_update_dpp(0u, m, 0x4E, 0xF, 0xF, false); m = o > m ? o : m;    // quad_perm [2,3,0,1]
+  o = __builtin_amdgcn_update_dpp(0u, m, 0x141, 0xF, 0xF, false); m = o > m ? o : m;   // row_half_mirror
+  o = __builtin_amdgcn_update_dpp(0u, m, 0x140, 0xF, 0xF, false); m = o > m ? o : m;   // row_mirror
+  {
+    const auto q = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+    m = q[0] > q[1] ? q[0] : q[1];
+  }
+  {
+    const auto q = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+    m = q[0] > q[1] ? q[0] : q[1];
+  }
   return __builtin_amdgcn_readfirstlane(m);
 #endif
 }

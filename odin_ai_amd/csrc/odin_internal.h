@@ -71,11 +71,11 @@ int odin_dense_gemm_wgrad(const float* x, const float* dy, float* slab, int B, i
 // Dense layers with both widths >= 256 on the f16 matrix pipe as two planes (dense_h.hip)
 bool odin_dense_h_ok(int B, int K, int N);
 int odin_dense_h_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, int act,
-                     void* stream);
+                     const uint32_t* x_amax, uint32_t* y_amax, void* stream);
 int odin_dense_h_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx, int B, int K, int N,
                        const uint32_t* dy_amax, uint32_t* dx_amax, void* stream);
 int odin_dense_h_wgrad(const float* x, const float* dy, float* slab, int B, int K, int N, const uint32_t* dy_amax,
-                       void* stream);
+                       const uint32_t* x_amax, void* stream);
 
 // 4x4 / stride-2 gather convolution over 32 channels with a rolling LDS row window (fconv_ring.hip)
 bool odin_fconv_ring_applicable(int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
@@ -112,7 +112,7 @@ bool odin_wgrad_planes_applicable(int B, int H, int W, int CI, int OH, int OW, i
                                   int S, int pt, int pl, int center);
 int odin_wgrad_planes_launch(const float* U, const float* V, float* slab, int* rows_out, int B, int OH,
                              int OW, int CI, int CO, int want_bias, int grad_u, const uint32_t* g_amax,
-                             void* stream);
+                             const uint32_t* a_amax, void* stream);
 
 // the same strided gathers through the bf16 matrix pipe, reduction split over the waves (fconv_planes.hip)
 bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
@@ -147,7 +147,7 @@ bool odin_igemm_h_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, 
 int odin_igemm_h_wgrad_rows(int B, int h, int w, int KH, int KW, int CU, int CV);
 int odin_igemm_h_wgrad_launch(const float* u, const float* v, float* slab, int slab_stride, int B, int FH, int FW,
                               int CU, int h, int w, int CV, int KH, int KW, int S, int pt, int pl, int want_bias,
-                              int grad_u, const uint32_t* g_amax, void* stream);
+                              int grad_u, const uint32_t* g_amax, const uint32_t* a_amax, void* stream);
 bool odin_igemm_wgrad_applicable(int B, int FH, int FW, int CU, int h, int w, int CV, int KH, int KW, int S,
                                  int center);
 int odin_igemm_wgrad_rows(int B, int h, int w, int KH, int KW, int CU, int CV);

@@ -20,6 +20,7 @@ struct SCParams {
   float* y;           // fwd out / wgrad slab
   int B, H, W, CI, OH, OW, CO, KH, KW, S, pt, pl, act, center;
   int pix_per_block, slab_stride;
+  unsigned* y_amax;   // fwd: optional range word of y (odin_conv_desc.y_amax)
 };
 
 // t / d for 0 <= t < 64, 1 <= d <= 8 (tap decoding: a runtime integer division is ~30 instructions, and the
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(256) void smallc_fwd_lds_kernel(SCParams p, int NR)
     }
   __syncthreads();
   const int cpr = p.OW >> 5;
+  float amx = 0.f;   // running max |y| of this lane: the range word of the activation (the plane layer above reads it)
   for (int j = wave; j < NR * cpr; j += 4) {  // wave-uniform: (row of the group, 32-pixel column block)
     const int rr = j / cpr, q0 = (j - rr * cpr) << 5;
     const int ow = q0 + l31;
@@ -400,15 +402,19 @@ __global__ __launch_bounds__(256) void smallc_fwd_lds_kernel(SCParams p, int NR)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = rb * 32 + 8 * q + 4 * h;
-        if (n + 3 < p.CO)
-          *reinterpret_cast<float4*>(outp + rb * 32 + 8 * q) =
-              make_float4(odin_act(p.act, acc[4 * q] + bias_r[rb][4 * q]),
-                          odin_act(p.act, acc[4 * q + 1] + bias_r[rb][4 * q + 1]),
-                          odin_act(p.act, acc[4 * q + 2] + bias_r[rb][4 * q + 2]),
-                          odin_act(p.act, acc[4 * q + 3] + bias_r[rb][4 * q + 3]));
+        if (n + 3 < p.CO) {
+          const float4 o = make_float4(odin_act(p.act, acc[4 * q] + bias_r[rb][4 * q]),
+                                       odin_act(p.act, acc[4 * q + 1] + bias_r[rb][4 * q + 1]),
+                                       odin_act(p.act, acc[4 * q + 2] + bias_r[rb][4 * q + 2]),
+                                       odin_act(p.act, acc[4 * q + 3] + bias_r[rb][4 * q + 3]));
+          amx = odin_amax3(odin_amax3(amx, o.x, o.y), o.z, o.w);
+          *reinterpret_cast<float4*>(outp + rb * 32 + 8 * q) = o;
+        }
       }
     }
   }
+  __shared__ float ared[16];
+  odin_amax_commit_wg(p.y_amax, amx, tid, 256, ared, blockIdx.x);
 }
 
 // Weight gradient on the matrix cores, operands straight from HBM/L2 (no LDS staging): with
@@ -542,11 +548,23 @@ static void sc_fill(SCParams& p, const odin_conv_desc* d) {
   p.act = d->act; p.center = d->center;
 }
 
+static int smallc_fwd_launch(const float* x, const float* w, const float* bias, float* y,
+                             const odin_conv_desc* d, void* stream, bool* tracked);
+
+// (the range word of y, d->y_amax: kept by the LDS-row kernel's epilogue; one pass over y behind the other variants)
 int odin_smallc_fwd(const float* x, const float* w, const float* bias, float* y,
                     const odin_conv_desc* d, void* stream) {
+  bool tracked = false;
+  const int rc = smallc_fwd_launch(x, w, bias, y, d, stream, &tracked);
+  if (rc != 0 || tracked || d->y_amax == nullptr || y == nullptr) return rc;
+  return odin_absmax_fold(y, (size_t)d->B * d->OH * d->OW * d->Cout, d->y_amax, stream);
+}
+
+static int smallc_fwd_launch(const float* x, const float* w, const float* bias, float* y,
+                             const odin_conv_desc* d, void* stream, bool* tracked) {
   SCParams p;
   sc_fill(p, d);
-  p.x = x; p.w = w; p.bias = bias; p.y = y;
+  p.x = x; p.w = w; p.bias = bias; p.y = y; p.y_amax = d->y_amax;
   const long total = (long)d->B * d->OH * d->OW * (d->Cout / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
@@ -566,10 +584,10 @@ int odin_smallc_fwd(const float* x, const float* w, const float* bias, float* y,
       const size_t l3 = (size_t)(d->stride * (NR - 1) + d->KH) * d->W * d->Cin * 4;
       const long gb = (long)d->B * (d->OH / NR);
       if (l3 <= 48 * 1024 && gb < (1L << 30)) {
-        if (nk2 == 8 && rb == 1) { ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 1>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); return odin_check_launch("smallc_fwd_lds"); }
-        if (nk2 == 8 && rb == 2) { ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 2>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); return odin_check_launch("smallc_fwd_lds"); }
-        if (nk2 == 24 && rb == 1) { ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 1>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); return odin_check_launch("smallc_fwd_lds"); }
-        if (nk2 == 24 && rb == 2) { ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 2>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); return odin_check_launch("smallc_fwd_lds"); }
+        if (nk2 == 8 && rb == 1) { ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 1>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); *tracked = true; return odin_check_launch("smallc_fwd_lds"); }
+        if (nk2 == 8 && rb == 2) { ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 2>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); *tracked = true; return odin_check_launch("smallc_fwd_lds"); }
+        if (nk2 == 24 && rb == 1) { ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 1>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); *tracked = true; return odin_check_launch("smallc_fwd_lds"); }
+        if (nk2 == 24 && rb == 2) { ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 2>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); *tracked = true; return odin_check_launch("smallc_fwd_lds"); }
       }
     }
     // persistent waves (2 x 4-wave workgroups per CU-pair ... 4 blocks per wave at batch 256)

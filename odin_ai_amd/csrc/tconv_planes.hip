@@ -124,8 +124,12 @@ struct TpItem {
 // 4 = no epilogue micro-ops
 // EPI 0: raw partial sums (first of two reduction passes over 64 input channels); ACC: add the partial
 // sums the previous pass left in `out` before the epilogue.
-// SC: the input tensor is a gradient (scaled by 2^gexp on its way into the planes, the result scaled back)
-template <int EPI, int C1, int W, int DBG = 0, bool ACC = false, bool SC = false>
+// SCM 1: the input tensor is a gradient (scaled by 2^gk on its way into the planes, the result scaled back); SCM 2: an
+// ACTIVATION that comes with its range word -- scaled the same way, but only when its bound leaves [2^-8, 2^15)
+// (odin_device.h: odin_act_needs_scale): a wave-uniform flag, one scalar branch around each split and around the
+// accumulator combine.  (Round 5's first form held two whole bodies behind ONE branch at the top of the kernel: every
+// launch then waited for the 32 scalar loads of the word before its first weight load -- +1.5 us per launch.)
+template <int EPI, int C1, int W, int DBG = 0, bool ACC = false, int SCM = 0>
 __device__ __forceinline__ void tp_body(const TPParams& p) {
   constexpr int NPL = TP_NPL;
   constexpr int RP = 64 / W;              // input rows per tile
@@ -164,6 +168,7 @@ __device__ __forceinline__ void tp_body(const TPParams& p) {
   if (T1 > p.n_tiles) T1 = p.n_tiles;
   if (T0 >= T1) return;
 
+  const OdinRangeReq in_rq = odin_range_issue(SCM != 0 ? p.in_amax : nullptr, lane);   // (finished behind the prologue's loads)
   // ---- the loads of the prologue go out FIRST: the 8 weight loads of a thread (fp32 [tap][co][32]) and the wave's
   // items of fill 0 (all rows of tile T0, offsets computed directly) are in flight while the zero fills and the table
   // arithmetic run -- the layers with 8- and 16-pixel rows run only 1-4 tiles per workgroup ----
@@ -175,17 +180,7 @@ __device__ __forceinline__ void tp_body(const TPParams& p) {
     wv[j] = *reinterpret_cast<const float4*>(p.w + ((size_t)(tap * p.CO + n0 + co) * p.CS + p.ci_off + 4 * ci4));
   }
   const OdinRun IN = odin_run(p.in, (unsigned)((size_t)p.B * p.H * W * p.CS * 4));
-  // a gradient input is carried times 2^gk (its maximum lands in [2^14, 2^15)); the two accumulators are scaled back
-#ifdef ODIN_SIM
-  const int gk = SC ? odin_range_shift(odin_range_load(p.in_amax)) : 0;
-#else
-  const int gk = SC ? odin_range_shift(odin_range_load(p.in_amax)) : 0;
-#endif
-  const float in_s = SC ? odin_pow2(gk) : 1.f;
-  const float in_s2k = SC ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
-  const float out_s = SC ? odin_pow2(-gk) : 1.f;
-  const float out_sx = SC ? odin_pow2(-gk - 11) : ODIN_LO_UNSCALE;
-  float amx = 0.f;  // running max |out| of this lane (EPI 2 / 3: `out` is a gradient tensor)
+  float amx = 0.f;  // running max |out| of this lane (the range word of `out`)
   const int f_c = wave & (CPR - 1), f_r0 = wave >> CSHIFT;
   constexpr int F_RJ = 8 >> CSHIFT;  // rows between a wave's two items
   const int f_px = 8 * f_c + (lane >> 3), f_ch4 = lane & 7, f_pc = f_px + 1;
@@ -209,6 +204,10 @@ __device__ __forceinline__ void tp_body(const TPParams& p) {
     }
   }
   ODIN_SCHED_FENCE();
+  // (the range word of the input: requested at the top, finished in front of the first split below.  A scaled input
+  // is carried times 2^gk -- its maximum lands in [2^14, 2^15) -- and the two accumulators are scaled back)
+  bool scl = SCM == 1;
+  float in_s = 1.f, in_s2k = ODIN_LO_SCALE, out_s = 1.f, out_sx = ODIN_LO_UNSCALE;   // (set where the word is finished)
 
   // ---- SAME-padding pixels (pc = 0 and pc = W + 1) of every ring row and plane: zero for ever ----
   for (int e = tid; e < NSLOT * 8 * NPL; e += 512) {
@@ -266,7 +265,8 @@ __device__ __forceinline__ void tp_body(const TPParams& p) {
   auto store_fill1 = [&](const TpItem& it) {
     if (it.ok) {
       u32x2 h, l;
-      odin_split_h4<SC>(it.v, in_s, in_s2k, h, l);
+      if (SCM == 1 || (SCM == 2 && scl)) odin_split_h4<true>(it.v, in_s, in_s2k, h, l);
+      else odin_split_h4<false>(it.v, 1.f, ODIN_LO_SCALE, h, l);
       char* d = ring + it.dst;
       *reinterpret_cast<u32x2*>(d) = h;
       *reinterpret_cast<u32x2*>(d + PB) = l;
@@ -353,6 +353,14 @@ __device__ __forceinline__ void tp_body(const TPParams& p) {
 
   // ---- prologue, second half: the weights -> planes [tap][plane][k-piece][co][8 f16], the first tile's rows ->
   // ring (both loaded at the top of the kernel), then ONE barrier publishes them together with the pads and the table
+  if (SCM != 0) {
+    // the input's range word (requested first thing in the kernel): the bound, the scale flag, the powers of two
+    const unsigned in_mb = odin_range_finish(in_rq);
+    scl = SCM == 1 || odin_act_needs_scale(in_mb);
+    const int gk = scl ? odin_range_shift(in_mb) : 0;
+    in_s = odin_pow2(gk); in_s2k = odin_pow2(gk + 11);
+    out_s = odin_pow2(-gk); out_sx = odin_pow2(-gk - 11);
+  }
   {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -401,7 +409,7 @@ __device__ __forceinline__ void tp_body(const TPParams& p) {
   auto elu_r = [&](int r) { elu_b(r, bias_r[((EPI == 1 || EPI == 3) && !CL) ? r : 0]); };
   auto store_q = [&](int q) __attribute__((always_inline)) {
     if (DBG & 1) return;
-    if (EPI >= 2) amx = odin_amax3(odin_amax3(amx, pa[4 * q], pa[4 * q + 1]), pa[4 * q + 2], pa[4 * q + 3]);
+    if (EPI >= 1) amx = odin_amax3(odin_amax3(amx, pa[4 * q], pa[4 * q + 1]), pa[4 * q + 2], pa[4 * q + 3]);
     odin_run_store4s(OUT, out_lane + 32 * q, tileP_out,
                      make_float4(pa[4 * q], pa[4 * q + 1], pa[4 * q + 2], pa[4 * q + 3]));
   };
@@ -676,8 +684,13 @@ __device__ __forceinline__ void tp_body(const TPParams& p) {
       if (M == 0 || M == 5 || M == 11 || M == 17 || M == 23) TP_STAMP(12 + (M + 1) / 6);
 #endif
     });
+    if (SCM == 1 || (SCM == 2 && scl)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) pa[r] = SC ? fmaf(acx[r], out_sx, acc[r] * out_s) : fmaf(acx[r], out_sx, acc[r]);
+      for (int r = 0; r < 16; ++r) pa[r] = fmaf(acx[r], out_sx, acc[r] * out_s);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pa[r] = fmaf(acx[r], ODIN_LO_UNSCALE, acc[r]);
+    }
     tileP_out = tile_out;
     tileP_tgt = tile_tgt;
 #pragma unroll
@@ -729,7 +742,7 @@ __device__ __forceinline__ void tp_body(const TPParams& p) {
     p.stamps[67] = wall_clock64();
   }
 #endif
-  if (EPI >= 2) {
+  if (EPI >= 1) {   // (EPI 1: the range word of the activation, odin_conv_desc.y_amax; EPI 2 / 3: of the gradient)
     __syncthreads();
     odin_amax_commit_wg(p.out_amax, amx, tid, 512, cred, blockIdx.x + gridDim.x * blockIdx.y);
     __syncthreads();  // (cred is reused below)
@@ -794,9 +807,9 @@ __device__ __forceinline__ void tp_body(const TPParams& p) {
   }
 }
 
-template <int EPI, int C1, int W, int DBG = 0, bool ACC = false, bool SC = false>
+template <int EPI, int C1, int W, int DBG = 0, bool ACC = false, int SCM = 0>
 __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
-  tp_body<EPI, C1, W, DBG, ACC, SC>(p);
+  tp_body<EPI, C1, W, DBG, ACC, SCM>(p);
 }
 
 // 64 reduction channels in ONE launch: both 32-channel passes inside the kernel (round 3 launched them separately: a
@@ -804,14 +817,14 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
 // first pass are written to `out` and read back in the second pass by the SAME thread (same wave roles, same tile
 // walk); the fence + barrier between the passes also keeps the second prologue's LDS writes behind the first pass's
 // last LDS reads.
-template <int EPI, int W, bool SC>
+template <int EPI, int W, int SCM>
 __global__ __launch_bounds__(512) void tconv_planes2_kernel(TPParams p) {
   {
     TPParams q = p;
     q.colsum = nullptr;
     q.out_amax = nullptr;
     q.ci_off = 0;
-    tp_body<0, 1, W, 0, false, SC>(q);
+    tp_body<0, 1, W, 0, false, SCM>(q);
   }
   // (the same thread reads back what it wrote, through the same CU's write-through L1 and its XCD's L2: a
   // workgroup-scope fence orders it; a device-scope __threadfence() writes back and invalidates the whole L2 of the
@@ -822,11 +835,11 @@ __global__ __launch_bounds__(512) void tconv_planes2_kernel(TPParams p) {
 #endif
   __syncthreads();
   p.ci_off = 32;
-  tp_body<EPI, 1, W, 0, true, SC>(p);
+  tp_body<EPI, 1, W, 0, true, SCM>(p);
 }
 
 // LDS: weight planes + row ring + the fill table (rows per fill x 8 bytes per fill, tiles + 3 fills); 4.3 KB are static
-constexpr int TP_LDS_MAX = 155 * 1024;
+constexpr int TP_LDS_MAX = 152 * 1024;   // (dynamic; + up to 2 x 4.3 KB static in the two-pass kernels)
 int tp_ring_bytes(int W) { return TP_WBYTES + (2 * (64 / W) + 3) * TP_NPL * (W + 2) * 64; }
 int tp_fill_bytes(int W) { return 8 * 2 * (W == 32 ? 2 : W == 16 ? 4 : 8); }
 // tiles per workgroup: the chip filled once when the table fits, more workgroups otherwise; -1: does not fit
@@ -841,7 +854,7 @@ int tp_tiles_per_wg(int W, int n_tiles, int gy) {
   return tpw;
 }
 
-template <int EPI, int C1, bool ACC, bool SC>
+template <int EPI, int C1, bool ACC, int SC>
 int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
   const size_t lds = (size_t)tp_ring_bytes(W) + (size_t)(p.tiles_per_wg + 3) * tp_fill_bytes(W);  // + the fill table
   constexpr int W3 = (EPI == 3 ? 16 : 8);  // (the fused tail has no 8-pixel geometry)
@@ -852,7 +865,7 @@ int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
                           reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 16, 0, ACC, SC>),
                           reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, W3, 0, ACC, SC>)};
     for (int i = 0; i < 3; ++i)
-      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS_MAX) != hipSuccess)
         (void)hipGetLastError();
     attr_done = true;
   }
@@ -868,7 +881,7 @@ int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
                             reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 4, ACC, SC>),
                             reinterpret_cast<const void*>(&tconv_planes_kernel<EPI, C1, 32, 7, ACC, SC>)};
       for (int i = 0; i < 4; ++i)
-        if (hipFuncSetAttribute(dfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(dfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS_MAX) != hipSuccess)
           (void)hipGetLastError();
       dattr = true;
     }
@@ -885,7 +898,7 @@ int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
   return odin_check_launch("tconv_planes(f16x2)");
 }
 
-template <int EPI, bool SC>
+template <int EPI, int SC>
 int tp_launch2_w(const TPParams& p, int W, dim3 grid, void* stream) {
   const size_t lds = (size_t)tp_ring_bytes(W) + (size_t)(p.tiles_per_wg + 3) * tp_fill_bytes(W);
 #ifndef ODIN_SIM
@@ -895,7 +908,7 @@ int tp_launch2_w(const TPParams& p, int W, dim3 grid, void* stream) {
                           reinterpret_cast<const void*>(&tconv_planes2_kernel<EPI, 16, SC>),
                           reinterpret_cast<const void*>(&tconv_planes2_kernel<EPI, 8, SC>)};
     for (int i = 0; i < 3; ++i)
-      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS_MAX) != hipSuccess)
         (void)hipGetLastError();
     attr_done = true;
   }
@@ -952,7 +965,10 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
     p.in_amax = odin_range_word_of(in, (size_t)B * H * W * CI, in_amax, stream);
     if (p.in_amax == nullptr) return odin_fail(-3, "tconv_planes: no range word for the gradient input");
   }
-  if (epi >= 2) p.out_amax = out_amax;
+  p.out_amax = out_amax;
+  // forward launches (epi 1, 3): the activation's word where the caller has one (scaled only outside the safe window)
+  const bool aw = epi != 2 && in_amax != nullptr;
+  if (aw) p.in_amax = in_amax;
   dim3 grid(gx, gy, 1);
   if (CI == 64) {
     if (epi == 3) return odin_fail(-2, "tconv_planes tail: 32 input channels only");
@@ -961,17 +977,18 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
       TPParams q = p;
       q.colsum = nullptr;
       q.out_amax = nullptr;
-      const int rc = epi == 1 ? tp_launch_w<0, 1, false, false>(q, W, grid, stream) : tp_launch_w<0, 1, false, true>(q, W, grid, stream);
+      const int rc = epi == 1 ? tp_launch_w<0, 1, false, 0>(q, W, grid, stream) : tp_launch_w<0, 1, false, 1>(q, W, grid, stream);
       if (rc != 0) return rc;
       p.ci_off = 32;
-      return epi == 1 ? tp_launch_w<1, 1, true, false>(p, W, grid, stream) : tp_launch_w<2, 1, true, true>(p, W, grid, stream);
+      return epi == 1 ? tp_launch_w<1, 1, true, 0>(p, W, grid, stream) : tp_launch_w<2, 1, true, 1>(p, W, grid, stream);
     }
 #endif
-    return epi == 1 ? tp_launch2_w<1, false>(p, W, grid, stream) : tp_launch2_w<2, true>(p, W, grid, stream);
+    if (epi == 1) return aw ? tp_launch2_w<1, 2>(p, W, grid, stream) : tp_launch2_w<1, 0>(p, W, grid, stream);
+    return tp_launch2_w<2, 1>(p, W, grid, stream);
   }
-  if (epi == 1) return tp_launch_w<1, 1, false, false>(p, W, grid, stream);
-  if (epi == 2) return tp_launch_w<2, 1, false, true>(p, W, grid, stream);
-  if (C1 == 1) return tp_launch_w<3, 1, false, false>(p, W, grid, stream);
-  if (C1 == 3) return tp_launch_w<3, 3, false, false>(p, W, grid, stream);
+  if (epi == 1) return aw ? tp_launch_w<1, 1, false, 2>(p, W, grid, stream) : tp_launch_w<1, 1, false, 0>(p, W, grid, stream);
+  if (epi == 2) return tp_launch_w<2, 1, false, 1>(p, W, grid, stream);
+  if (C1 == 1) return aw ? tp_launch_w<3, 1, false, 2>(p, W, grid, stream) : tp_launch_w<3, 1, false, 0>(p, W, grid, stream);
+  if (C1 == 3) return aw ? tp_launch_w<3, 3, false, 2>(p, W, grid, stream) : tp_launch_w<3, 3, false, 0>(p, W, grid, stream);
   return odin_fail(-2, "tconv_planes tail: one or three logit maps only");
 }

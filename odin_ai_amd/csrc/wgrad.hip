@@ -47,6 +47,7 @@ struct WParams {
   long long* stamps;
   int bias_mode;  // 0 none, 1 extra MFMA tile with A = 1, 2 summed while staging DY
   const uint32_t* g_amax;  // range word of the gradient operand (wgrad_planes only; may be null)
+  const uint32_t* a_amax;  // range word of the activation operand (plane kernels; may be null)
 };
 
 // ---- staging ------------------------------------------------------------------------
@@ -1037,12 +1038,12 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
   if (odin_wgrad_planes_applicable(p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO, p.KH, p.KW, p.S, p.pt, p.pl,
                                    p.center))
     return odin_wgrad_planes_launch(p.in, p.dy, p.slab, rows_out, p.B, p.OH, p.OW, p.CI, p.CO,
-                                    p.want_bias, p.want_bias ? 0 : 1, p.g_amax, stream);
+                                    p.want_bias, p.want_bias ? 0 : 1, p.g_amax, p.a_amax, stream);
   if (odin_igemm_h_wgrad_applicable(p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO, p.KH, p.KW, p.S, p.center)) {
     if (rows_out) *rows_out = odin_igemm_h_wgrad_rows(p.B, p.OH, p.OW, p.KH, p.KW, p.CI, p.CO);
     if (p.slab == nullptr) return 0;  // dry run
     return odin_igemm_h_wgrad_launch(p.in, p.dy, p.slab, p.slab_stride, p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO,
-                                     p.KH, p.KW, p.S, p.pt, p.pl, p.want_bias, p.want_bias ? 0 : 1, p.g_amax, stream);
+                                     p.KH, p.KW, p.S, p.pt, p.pl, p.want_bias, p.want_bias ? 0 : 1, p.g_amax, p.a_amax, stream);
   }
   if (odin_igemm_wgrad_applicable(p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO, p.KH, p.KW, p.S, p.center)) {
     if (rows_out) *rows_out = odin_igemm_wgrad_rows(p.B, p.OH, p.OW, p.KH, p.KW, p.CI, p.CO);
@@ -1274,6 +1275,7 @@ extern "C" int odin_conv2d_wgrad(const float* x, const float* dy, float* slab,
   p.KH = d->KH; p.KW = d->KW; p.S = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
   p.center = d->center; p.want_bias = 1;
   p.g_amax = d->dy_amax;
+  p.a_amax = d->x_amax;
   return launch_wgrad(p, slab_rows_out, stream);
 }
 
@@ -1287,15 +1289,41 @@ extern "C" int odin_deconv2d_wgrad(const float* x, const float* dy, float* slab,
   p.KH = d->KH; p.KW = d->KW; p.S = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
   p.center = 0; p.want_bias = 0;
   p.g_amax = d->dy_amax;
+  p.a_amax = d->x_amax;
   return launch_wgrad(p, slab_rows_out, stream);
 }
+
+// 1: some launch of this layer (forward or weight gradient, as dispatched now) is a two-plane kernel that READS the
+// range word of the layer input (odin_conv_desc.x_amax) -- a caller uses it to decide whether the layer below is asked
+// to keep that word at all (a wrong answer is harmless: a plane kernel without a word carries x unscaled, as in round 4)
+extern "C" int odin_conv2d_reads_x_range(const odin_conv_desc* d) {
+  if (odin_smallc_applicable(d) || odin_pw1x1_applicable(d)) return 0;
+  return (odin_fconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
+                                       d->pad_t, d->pad_l, d->center) ||
+          odin_igemm_h_applicable(0, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->center) ||
+          odin_wgrad_planes_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
+                                       d->pad_t, d->pad_l, d->center) ||
+          odin_igemm_h_wgrad_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
+                                        d->center)) ? 1 : 0;
+}
+extern "C" int odin_deconv2d_reads_x_range(const odin_conv_desc* d) {
+  return ((d->OH == 2 * d->H && d->OW == 2 * d->W &&
+           odin_tconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l,
+                                        d->center, 1, 1)) ||
+          odin_igemm_h_applicable(1, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->center) ||
+          odin_wgrad_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
+                                       d->pad_t, d->pad_l, 0) ||
+          odin_igemm_h_wgrad_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0))
+             ? 1 : 0;
+}
+extern "C" int odin_dense_reads_x_range(int B, int K, int N) { return odin_dense_h_ok(B, K, N) ? 1 : 0; }
 
 extern "C" int odin_dense_wgrad(const float* x, const float* dy, float* slab, int* slab_rows_out,
                                 int B, int K, int N, void* stream) {
   if (odin_dense_h_ok(B, K, N)) {  // both widths >= 256: the two-plane GEMM, ONE complete slab row
     if (slab_rows_out) *slab_rows_out = 1;
     if (slab == nullptr) return 0;  // dry run
-    return odin_dense_h_wgrad(x, dy, slab, B, K, N, nullptr, stream);
+    return odin_dense_h_wgrad(x, dy, slab, B, K, N, nullptr, nullptr, stream);
   }
   // (also the tiny layers: their forward / data gradient run on the vector ALUs, but the weight gradient
   // through the generic kernel was a 14.5 us launch for 0.001 GFLOP)
@@ -1348,6 +1376,16 @@ extern "C" int odin_dense_bwd(const float* x, const float* dy, const float* w, c
                               float* dx, float* colsum_slab, int* colsum_rows_out, float* wslab,
                               int* wslab_rows_out, int B, int K, int N, int want_wgrad, int want_dgrad,
                               const uint32_t* dy_amax, uint32_t* dx_amax, void* stream) {
+  return odin_dense_bwd_ranged(x, dy, w, aux, aux_act, dx, colsum_slab, colsum_rows_out, wslab, wslab_rows_out, B, K, N,
+                               want_wgrad, want_dgrad, dy_amax, dx_amax, nullptr, stream);
+}
+
+// + x_amax: the range word of the activation x (the weight gradient's other operand on the two-plane GEMM)
+extern "C" int odin_dense_bwd_ranged(const float* x, const float* dy, const float* w, const float* aux, int aux_act,
+                                     float* dx, float* colsum_slab, int* colsum_rows_out, float* wslab,
+                                     int* wslab_rows_out, int B, int K, int N, int want_wgrad, int want_dgrad,
+                                     const uint32_t* dy_amax, uint32_t* dx_amax, const uint32_t* x_amax,
+                                     void* stream) {
   if (odin_dense_h_ok(B, K, N) && colsum_slab == nullptr) {
     int rc = 0;
     // (a dy without a word is bounded ONCE for both halves)
@@ -1357,7 +1395,7 @@ extern "C" int odin_dense_bwd(const float* x, const float* dy, const float* w, c
     }
     if (want_wgrad) {
       if (wslab_rows_out) *wslab_rows_out = 1;
-      if (wslab != nullptr) rc = odin_dense_h_wgrad(x, dy, wslab, B, K, N, dy_amax, stream);
+      if (wslab != nullptr) rc = odin_dense_h_wgrad(x, dy, wslab, B, K, N, dy_amax, x_amax, stream);
     }
     if (rc == 0 && want_dgrad) {
       if (colsum_rows_out) *colsum_rows_out = 0;

@@ -44,6 +44,7 @@ struct WPParams {
   int slab_stride;
   int tiles_per_img, n_tiles, tiles_per_wg;
   const unsigned* g_amax;  // range word (odin_device.h) of the gradient operand (GU: U, else V)
+  const unsigned* a_amax;  // optional range word of the ACTIVATION operand (the other one): scaled when outside [2^-8, 2^15)
 };
 
 struct WPQueue {
@@ -94,6 +95,7 @@ constexpr int WP_MAXU = 4;  // 1 KB load items (8 pixels x 32 channels) of fine 
 // the multi-layer launch below
 template <int W, bool GU, int DBG = 0>
 __device__ __forceinline__ void wp_body(const WPParams& p, const int bx, const int by, const int bz) {
+  __shared__ float bred[8 * 32];
   constexpr int NPL = 2;                 // f16 planes per operand
   constexpr int TC = 32 / W;             // coarse rows per tile
   constexpr int WU = 2 * W;              // fine row length
@@ -112,8 +114,9 @@ __device__ __forceinline__ void wp_body(const WPParams& p, const int bx, const i
   ODIN_DYN_SMEM(char, smem);
   char* uring = smem;
   char* vring = smem + NSU * RBU;
-  __shared__ float bred[8 * 32];
   const int tid = threadIdx.x, lane = tid & 63;
+  // the two range words: requested first thing, finished in front of the first split (odin_device.h: odin_range_issue)
+  const OdinRangeReq g_rq = odin_range_issue(p.g_amax, lane), a_rq = odin_range_issue(p.a_amax, lane);
 #ifdef ODIN_SIM
   const int wave = tid >> 6;
 #else
@@ -243,13 +246,22 @@ __device__ __forceinline__ void wp_body(const WPParams& p, const int bx, const i
     iv.dst = (en.v.x + v_lds_item) | v_none_dst;
     iv.v = odin_run_load4(RV, ((unsigned)en.v.y + v_colb) | v_none_off);
   };
-  // the gradient operand is carried times 2^gk (its maximum lands in [2^14, 2^15)), the sums are scaled back at the end
-#ifdef ODIN_SIM
-  const int gk = odin_range_shift(odin_range_load(p.g_amax));
-#else
-  const int gk = odin_range_shift(odin_range_load(p.g_amax));
-#endif
-  const float g_s = odin_pow2(gk), g_s2k = odin_pow2(gk + 11);
+  // the gradient operand is carried times 2^gk (its maximum lands in [2^14, 2^15)), the sums are scaled back at the end.
+  // The ACTIVATION operand comes with an optional range word (round 5): carried times 2^ak as well when its bound
+  // leaves [2^-8, 2^15) (odin_device.h: odin_act_needs_scale) -- a wave-uniform flag, one scalar branch around its
+  // splits; the two scales are taken back one after the other (their sum may leave one factor's exponent range).
+  // (All set by finish_words(), in front of the first split.)
+  int gk = 0, ak = 0;
+  bool as = false;
+  float g_s = 1.f, g_s2k = ODIN_LO_SCALE, a_s = 1.f, a_s2k = ODIN_LO_SCALE;
+  auto finish_words = [&]() {
+    gk = odin_range_shift(odin_range_finish(g_rq));
+    g_s = odin_pow2(gk); g_s2k = odin_pow2(gk + 11);
+    const unsigned a_mb = p.a_amax != nullptr ? odin_range_finish(a_rq) : 0u;
+    as = odin_act_needs_scale(a_mb);
+    ak = as ? odin_range_shift(a_mb) : 0;
+    a_s = odin_pow2(ak); a_s2k = odin_pow2(ak + 11);
+  };
   auto store_item = [&](const WpItem& it, int plane_bytes, auto is_grad) {
 #ifdef ODIN_SIM
     if (it.dst < 0) return;
@@ -257,7 +269,9 @@ __device__ __forceinline__ void wp_body(const WPParams& p, const int bx, const i
     if (__builtin_amdgcn_readfirstlane(it.dst) < 0) return;  // wave-uniform: a scalar branch
 #endif
     u32x2 h, l;
-    odin_split_h4<decltype(is_grad)::value>(it.v, g_s, g_s2k, h, l);
+    if (decltype(is_grad)::value) odin_split_h4<true>(it.v, g_s, g_s2k, h, l);
+    else if (as) odin_split_h4<true>(it.v, a_s, a_s2k, h, l);
+    else odin_split_h4<false>(it.v, 1.f, ODIN_LO_SCALE, h, l);
     char* d = smem + it.dst;
     *reinterpret_cast<u32x2*>(d) = h;
     *reinterpret_cast<u32x2*>(d + plane_bytes) = l;
@@ -296,6 +310,7 @@ __device__ __forceinline__ void wp_body(const WPParams& p, const int bx, const i
   // ---- prologue: rows of the first tile into LDS; ONE barrier publishes them with the pads and the tables; then
   // the second and third tile's rows into registers ----
   FillEnt en;
+  finish_words();
   store_fill(iuA, ivA);
   __syncthreads();
   FillEnt en1, en2;
@@ -391,14 +406,15 @@ __device__ __forceinline__ void wp_body(const WPParams& p, const int bx, const i
 
   // ---- this workgroup's slab row: dW[tap][cu0 + cu][cv0 + cv], lane = column cv = l31 ----
   float* row = p.slab + (size_t)bx * p.slab_stride;
-  const float o_s = odin_pow2(-gk), o_sx = odin_pow2(-gk - 11);
+  const float o_s = odin_pow2(-gk), o_sx = odin_pow2(-gk - 11), a_o = odin_pow2(-ak);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int tap = kh * 4 + kw0 + t;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cu = (r & 3) + 8 * (r >> 2) + 4 * half;
-      row[((size_t)tap * p.CUt + cu0 + cu) * p.CVt + cv0 + l31] = fmaf(acx[t][r], o_sx, acc[t][r] * o_s);
+      const float v = fmaf(acx[t][r], o_sx, acc[t][r] * o_s);
+      row[((size_t)tap * p.CUt + cu0 + cu) * p.CVt + cv0 + l31] = v * a_o;   // (a_o = 1 for an unscaled activation)
     }
   }
   if (p.want_bias && by == 0) {
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(512) void wgrad_planes_multi_kernel(WPMulti m) {
 }
 
 // LDS: fine-row ring + coarse-row ring + the fill tables ((1 + fine rows per fill + TC) x 8 bytes per fill, tiles + 4 fills)
-constexpr int WP_LDS_MAX = 156 * 1024;
+constexpr int WP_LDS_MAX = 152 * 1024;   // (dynamic; + 1 KB of static scratch per body: 6 in the multi-layer kernel)
 int wp_ring_bytes(int W) {
   const int TC = 32 / W;
   return (4 * TC + 3) * 2 * 2 * (W + 1) * 64 + (2 * TC) * 2 * W * 64;
@@ -616,10 +632,10 @@ bool odin_wgrad_planes_applicable(int B, int H, int W, int CI, int OH, int OW, i
 // grad_u: the gradient operand is U (Conv2DTranspose) rather than V (Conv2D)
 int odin_wgrad_planes_launch(const float* U, const float* V, float* slab, int* rows_out, int B, int OH,
                              int OW, int CI, int CO, int want_bias, int grad_u, const uint32_t* g_amax,
-                             void* stream) {
+                             const uint32_t* a_amax, void* stream) {
   WPParams p;
   memset(&p, 0, sizeof(p));
-  p.U = U; p.V = V; p.slab = slab;
+  p.U = U; p.V = V; p.slab = slab; p.a_amax = a_amax;
   p.B = B; p.h = OH; p.CUt = CI; p.CVt = CO; p.want_bias = want_bias;
   p.slab_stride = 16 * CI * CO + (want_bias ? CO : 0);
   const int TC = 32 / OW;

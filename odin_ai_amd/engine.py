@@ -134,10 +134,18 @@ RANGE_WORDS = 2048  # include/odin_hip.h: ODIN_RANGE_WORDS (uint32 per range wor
 class NetProgram:
 
   def __init__(self, lib, recs: List[LayerRec], B: int, device, params: torch.Tensor,
-               grads: torch.Tensor, max_rows: int, range_words: Optional[torch.Tensor] = None):
+               grads: torch.Tensor, max_rows: int, range_words: Optional[torch.Tensor] = None,
+               act_words: Optional[torch.Tensor] = None):
     self.lib, self.recs, self.B, self.device = lib, recs, B, device
     self.params, self.grads = params, grads
     f32 = dict(dtype=torch.float32, device=device)
+    # one range word per outs[i] too (round 5, include/odin_hip.h: odin_conv_desc.x_amax / y_amax): max |activation|,
+    # kept by the layer that produces the tensor when the layer above reads it (a two-plane kernel: forward or weight
+    # gradient), so that activations beyond the f16 range -- or far below it -- keep their 22 bits; zeroed with the
+    # gradient words
+    self.act_words = (torch.zeros(len(recs) * RANGE_WORDS, dtype=torch.int32, device=device)
+                      if act_words is None else act_words)
+    assert self.act_words.numel() == len(recs) * RANGE_WORDS and self.act_words.is_contiguous()
     # one range word per gouts[i] (include/odin_hip.h: odin_conv_desc.dy_amax / dx_amax): max |gradient|, kept by the
     # kernel that produces the tensor and read by the f16-plane kernels that consume it; zeroed once per step
     self.range_words = (torch.zeros(len(recs) * RANGE_WORDS, dtype=torch.int32, device=device)
@@ -167,6 +175,18 @@ class NetProgram:
     for i, cd in enumerate(self.descs):
       if cd is not None:
         cd.dy_amax = self.dy_word[i]
+    # activation words: layer i reads the word of its input (outs[i - 1]) if one of its launches is a plane kernel;
+    # layer i - 1 is asked to keep that word only then
+    act_on = __import__('os').environ.get('ODIN_ACT_WORDS', '1') != '0'   # (engine-side A/B switch)
+    self.reads_x = [act_on and self._reads_x(i) for i in range(len(recs))]
+    self.x_word: List[Optional[int]] = [None] * len(recs)
+    self.y_word: List[Optional[int]] = [None] * len(recs)
+    for i in range(1, len(recs)):
+      if self.reads_x[i]:
+        self.x_word[i] = self.y_word[i - 1] = self.aword(i - 1)
+    for i, cd in enumerate(self.descs):
+      if cd is not None:
+        cd.x_amax, cd.y_amax = self.x_word[i], self.y_word[i]
     self.wslabs: List[Optional[torch.Tensor]] = [None] * len(recs)
     self.wrows = [0] * len(recs)
     self.bslabs: List[Optional[torch.Tensor]] = [None] * len(recs)  # deconv bias (colsum)
@@ -187,6 +207,25 @@ class NetProgram:
   def word(self, i: int) -> int:
     """device address of the range word of gouts[i]"""
     return self.range_words.data_ptr() + 4 * RANGE_WORDS * i
+
+  def aword(self, i: int) -> int:
+    """device address of the range word of outs[i]"""
+    return self.act_words.data_ptr() + 4 * RANGE_WORDS * i
+
+  def _reads_x(self, i: int) -> bool:
+    r = self.recs[i]
+    if self.descs[i] is None:
+      return bool(self.lib.odin_dense_reads_x_range(self.B, r.K, r.N))
+    fn = self.lib.odin_conv2d_reads_x_range if r.kind == 'conv' else self.lib.odin_deconv2d_reads_x_range
+    return bool(fn(C.byref(self.descs[i])))
+
+  def set_x_word(self, i: int, valid: bool) -> None:
+    """the producer of outs[i - 1] is outside this program's forward loop (the bottleneck launch writes outs[0]
+    without a word): layer i then reads no word (unscaled, as without the side channel)"""
+    w = self.aword(i - 1) if (valid and self.reads_x[i]) else None
+    self.x_word[i] = w
+    if self.descs[i] is not None:
+      self.descs[i].x_amax = w
 
   def set_top_word(self, kept: bool, n: Optional[int] = None) -> Optional[int]:
     """the producer of gouts[n] (outside this program; n = the last layer by default) says whether it keeps the
@@ -273,8 +312,8 @@ class NetProgram:
         lib.odin_deconv2d_fwd(h.data_ptr(), self.w(i).data_ptr(), self.b(i).data_ptr(),
                               y.data_ptr(), C.byref(self.descs[i]), st)
       else:
-        lib.odin_dense_fwd(h.data_ptr(), self.w(i).data_ptr(), self.b(i).data_ptr(),
-                           y.data_ptr(), B, r.K, r.N, ACT[r.act], st)
+        lib.odin_dense_fwd_ranged(h.data_ptr(), self.w(i).data_ptr(), self.b(i).data_ptr(),
+                                  y.data_ptr(), B, r.K, r.N, ACT[r.act], self.x_word[i], self.y_word[i], st)
       h = y
     return h
 
@@ -321,9 +360,9 @@ class NetProgram:
           lib.odin_deconv2d_bwd(xin.data_ptr(), g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
                                 bsp, C.byref(rows), slab.data_ptr(), C.byref(wrows), C.byref(d), st)
         else:
-          lib.odin_dense_bwd(xin.data_ptr(), g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
-                             bsp, C.byref(rows), slab.data_ptr(), C.byref(wrows), B, r.K, r.N, 1, 1,
-                             self.dy_word[i], self.dx_word[i], st)
+          lib.odin_dense_bwd_ranged(xin.data_ptr(), g.data_ptr(), self.w(i).data_ptr(), auxp, aux_act, dst.data_ptr(),
+                                    bsp, C.byref(rows), slab.data_ptr(), C.byref(wrows), B, r.K, r.N, 1, 1,
+                                    self.dy_word[i], self.dx_word[i], self.x_word[i], st)
       elif data_only:
         pass
       elif r.kind == 'conv':
@@ -333,8 +372,8 @@ class NetProgram:
         lib.odin_deconv2d_wgrad(xin.data_ptr(), g.data_ptr(), slab.data_ptr(), C.byref(wrows),
                                 C.byref(d), wst)
       else:
-        lib.odin_dense_bwd(xin.data_ptr(), g.data_ptr(), None, None, 0, None, None, None, slab.data_ptr(),
-                           C.byref(wrows), B, r.K, r.N, 1, 0, self.dy_word[i], None, wst)
+        lib.odin_dense_bwd_ranged(xin.data_ptr(), g.data_ptr(), None, None, 0, None, None, None, slab.data_ptr(),
+                                  C.byref(wrows), B, r.K, r.N, 1, 0, self.dy_word[i], None, self.x_word[i], wst)
       if not data_only:
         assert wrows.value == self.wrows[i]
         n_red = slab.shape[1]
@@ -442,11 +481,15 @@ class VAEEngine:
     B, D = self.B, self.D
     mr = self.lib.odin_max_slab_rows()
     ne = len(self.enc_recs)
-    self.range_words = torch.zeros((ne + len(self.dec_recs)) * RANGE_WORDS, dtype=torch.int32, device=self.device)
+    nl = ne + len(self.dec_recs)
+    # (gradient words | activation words: one buffer, cleared together by the step's last backward launch)
+    self.range_words = torch.zeros(2 * nl * RANGE_WORDS, dtype=torch.int32, device=self.device)
+    gw, aw = self.range_words[:nl * RANGE_WORDS], self.range_words[nl * RANGE_WORDS:]
     self.enc = NetProgram(self.lib, self.enc_recs, B, self.device, self.params, self.grads, mr,
-                          range_words=self.range_words[:ne * RANGE_WORDS])
+                          range_words=gw[:ne * RANGE_WORDS], act_words=aw[:ne * RANGE_WORDS])
     self.dec = NetProgram(self.lib, self.dec_recs, B, self.device, self.params, self.grads, mr,
-                          range_words=self.range_words[ne * RANGE_WORDS:])
+                          range_words=gw[ne * RANGE_WORDS:], act_words=aw[ne * RANGE_WORDS:])
+    self._act_words_dirty = False   # a forward pass has written activation words that no backward pass has cleared
     self.p = torch.empty(B, 2 * D, **f32)
     self.dp = torch.empty(B, 2 * D, **f32)
     self.eps = torch.zeros(B, D, **f32)
@@ -799,6 +842,15 @@ class VAEEngine:
       self._ring_filled_to = hi
     self._ring_live = True
 
+  def _clear_stale_act_words(self, st):
+    """The activation words are cleared by the step's last backward launch; a forward pass that follows another
+    forward pass (encode / decode / evaluation) clears them itself -- the words fold maxima in, a stale larger bound
+    would cost the planes precision."""
+    if self._act_words_dirty:
+      nl = len(self.enc_recs) + len(self.dec_recs)
+      self.lib.odin_range_reset(self.range_words.data_ptr() + 4 * RANGE_WORDS * nl, nl, st)
+    self._act_words_dirty = True
+
   # ---- partial passes used by the model API (encode / decode) ---------------------------
   def run_encoder(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, st=None):
     """encoder -> Dense(2D) -> (loc, softplus(raw)) -> z = loc + scale*eps; fills p, z, kl."""
@@ -806,6 +858,7 @@ class VAEEngine:
     st = self.stream() if st is None else st
     assert x.shape == (B,) + self.in_shape and x.is_contiguous()
     self.x = x
+    self._clear_stale_act_words(st)
     if eps is None:
       lib.odin_rng_normal(self.eps.data_ptr(), B * D, self.seed, self.hp(N_HYPER), st)
     elif eps is not self.eps:
@@ -823,6 +876,9 @@ class VAEEngine:
   def run_decoder(self, z: torch.Tensor, st=None):
     st = self.stream() if st is None else st
     assert z.shape == (self.B, self.D) and z.is_contiguous()
+    self._clear_stale_act_words(st)
+    if len(self.dec_recs) > 1:
+      self.dec.set_x_word(1, True)
     return self.dec.forward(z, st)
 
   def observation_llk(self, h_d: torch.Tensor, x: torch.Tensor, out: torch.Tensor, st=None):
@@ -863,6 +919,10 @@ class VAEEngine:
     lw = self.params[self.lat_w_off:]
     lb = self.params[self.lat_b_off:]
     self._used_block = self.lat_block and fused
+    self._clear_stale_act_words(st)
+    # (outs[0] of the decoder comes from the bottleneck launch in the fused step: no word for layer 1's input then)
+    if len(self.dec_recs) > 1:
+      self.dec.set_x_word(1, not self._used_block)
     if self._used_block:
       if eps is not None and eps is not self.eps:
         self.eps.copy_(eps)
@@ -1156,6 +1216,7 @@ class VAEEngine:
     # of a memset node of its own at the top of the step (4.3 us in the step timeline)
     rw = self.range_words
     jobs.append(ReduceJob(rw.data_ptr(), rw.data_ptr(), rw.numel(), 0, rw.numel(), 0))
+    self._act_words_dirty = False
     join()
     arr = (ReduceJob * len(jobs))(*jobs)
     self._jobs_keepalive = arr

@@ -1045,11 +1045,13 @@ class DiscPrograms:
     mr = lib.odin_max_slab_rows()
     # (the range words of both programs' gradient tensors in one buffer: cleared once per iteration, reset_ranges)
     nw = len(disc.recs) * RANGE_WORDS
-    self.range_words = torch.zeros(2 * nw, dtype=torch.int32, device=device)
+    # (gradient words of the two programs | their activation words, round 5: the layers' inputs keep their 22 bits
+    # at any magnitude)
+    self.range_words = torch.zeros(4 * nw, dtype=torch.int32, device=device)
     self.prog1 = NetProgram(lib, disc.recs, B1, device, disc.params, disc.grads, mr,
-                            range_words=self.range_words[:nw])
+                            range_words=self.range_words[:nw], act_words=self.range_words[2 * nw:3 * nw])
     self.prog2 = NetProgram(lib, disc.recs, 2 * B1, device, disc.params, disc.grads, mr,
-                            range_words=self.range_words[nw:])
+                            range_words=self.range_words[nw:2 * nw], act_words=self.range_words[3 * nw:])
     self.tc = torch.zeros(1, **f32)
     self.dlogit1 = torch.zeros(B1, 1, **f32)
     self.dlogit1_value = None

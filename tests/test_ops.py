@@ -362,6 +362,103 @@ def test_data_gradient_range_contract(bk, kind, shape, colsum):
     assert 0 < rows.value <= L.odin_max_slab_rows()
 
 
+@pytest.mark.parametrize('scale', [1e5, 1e-30, 3e9, 1.0])
+@pytest.mark.parametrize('family', ['fconv_planes', 'tconv_planes', 'igemm_h', 'dense_h'])
+def test_plane_kernels_beyond_f16_range(bk, request, family, scale):
+  """activations beyond what an f16 plane holds (|x| > 65504) or far below it (1e-30) through the
+  forward and weight-gradient launches of every two-plane family, against the float64 oracle at 1e-4 of the result's
+  maximum.  The layer input comes with its range word (odin_conv_desc.x_amax / odin_dense_*_ranged): the plane
+  kernels carry it times the exact power of two that brings its bound to [2^14, 2^15) -- fp32 has no such limit
+  (image_networks.py:157-174 are plain fp32 Keras layers), so neither may this.  scale 1.0: the word lies inside the
+  safe window and the kernel takes its unscaled body (same result)."""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(13)
+
+  def word_of(t):
+    w = bk.zeros(2048, dtype=torch.int32)
+    L.odin_absmax(t.data_ptr(), t.numel(), w.data_ptr(), None)
+    return w
+
+  def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / np.abs(b).max()
+
+  if family == 'dense_h':
+    B, K, N = 32, 256, 256
+    x = rng.standard_normal((B, K)) * scale
+    w, b = rng.standard_normal((K, N)) / np.sqrt(K), rng.standard_normal(N) * 0.1 * scale
+    dy = rng.standard_normal((B, N)) * 1e-3
+    tx, tw, tb, tdy = T(x), T(w), T(b), T(dy)
+    xw, yw = word_of(tx), bk.zeros(2048, dtype=torch.int32)
+    ty = bk.full((B, N), float('nan'))
+    L.odin_dense_fwd_ranged(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), B, K, N, 0, xw.data_ptr(),
+                            yw.data_ptr(), None)
+    assert 'dense_h' in L.odin_debug_last_path().decode()
+    xf = x.astype(np.float32).astype(np.float64)
+    y_ref = vo.dense(xf, w.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64))
+    assert rel(ty.cpu().numpy(), y_ref) <= 1e-4
+    assert float(yw.view(torch.float32).max()) == float(ty.abs().max())
+    rows = C.c_int(0)
+    slab = bk.full((L.odin_max_slab_rows(), K * N + N), float('nan'))
+    L.odin_dense_bwd_ranged(tx.data_ptr(), tdy.data_ptr(), None, None, 0, None, None, None, slab.data_ptr(),
+                            C.byref(rows), B, K, N, 1, 0, None, None, xw.data_ptr(), None)
+    assert 'dense_h' in L.odin_debug_last_path().decode()
+    g = reduce_slab(bk, slab, rows.value, K * N + N)
+    _, dw_ref, _ = vo.dense_bwd(xf, w, dy.astype(np.float32).astype(np.float64), need_dx=False)
+    assert rel(g[:K * N].reshape(K, N), dw_ref) <= 1e-4
+    return
+
+  if family == 'igemm_h':
+    request.addfinalizer(lambda old=L.odin_debug_igemm_h_min_flop(0.0): L.odin_debug_igemm_h_min_flop(old))
+    kind, (B, H, W, Ci, Co, K, S) = 'conv', (2, 12, 10, 32, 32, 4, 2)   # (rows of 10 / 5 pixels: no plane kernel)
+  elif family == 'fconv_planes':
+    kind, (B, H, W, Ci, Co, K, S) = 'conv', (2, 32, 32, 32, 32, 4, 2)
+  else:
+    kind, (B, H, W, Ci, Co, K, S) = 'deconv', (2, 16, 16, 32, 32, 4, 2)
+  if kind == 'conv':
+    OH, pt, _ = vo.same_pads(H, K, S)
+    OW, pl, _ = vo.same_pads(W, K, S)
+    wshape = (K, K, Ci, Co)
+  else:
+    OH, OW = H * S, W * S
+    _, pt, _ = vo.same_pads(OH, K, S)
+    _, pl, _ = vo.same_pads(OW, K, S)
+    wshape = (K, K, Co, Ci)
+  d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, 'elu')
+  x = rng.standard_normal((B, H, W, Ci)) * scale
+  w, b = rng.standard_normal(wshape) * 0.1, rng.standard_normal(Co) * 0.1 * scale
+  if scale < 1e-10:
+    # (the kernels' ELU is exp2(t log2 e) - 1, 6e-8 absolute -- nothing at unit scale, everything at 1e-30: keep the
+    # pre-activations of this case positive, where ELU is the identity)
+    b = np.abs(b) + 40.0 * scale
+  dy = rng.standard_normal((B, OH, OW, Co)) * 1e-3
+  tx, tw, tb, tdy = T(x), T(w), T(b), T(dy)
+  xw, yw, dyw = word_of(tx), bk.zeros(2048, dtype=torch.int32), word_of(tdy)
+  d.x_amax, d.y_amax, d.dy_amax = xw.data_ptr(), yw.data_ptr(), dyw.data_ptr()
+  ty = bk.full((B, OH, OW, Co), float('nan'))
+  fwd = L.odin_conv2d_fwd if kind == 'conv' else L.odin_deconv2d_fwd
+  fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
+  path = L.odin_debug_last_path().decode()
+  assert family in path, path
+  xf, wf, bf = (a.astype(np.float32).astype(np.float64) for a in (x, w, b))
+  pre = (vo.conv2d if kind == 'conv' else vo.conv2d_transpose)(xf, wf, bf, S)
+  y_ref = vo.elu(pre)
+  assert rel(ty.cpu().numpy(), y_ref) <= 1e-4, (path, rel(ty.cpu().numpy(), y_ref))
+  assert float(yw.view(torch.float32).max()) == float(ty.abs().max())
+  # the weight gradient: the activation is its other operand
+  wg = L.odin_conv2d_wgrad if kind == 'conv' else L.odin_deconv2d_wgrad
+  n = K * K * Ci * Co + (Co if kind == 'conv' else 0)
+  rows = C.c_int(0)
+  slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
+  wg(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d), None)
+  wpath = L.odin_debug_last_path().decode()
+  assert '(f16x2)' in wpath, wpath
+  g = reduce_slab(bk, slab, rows.value, n)
+  dyf = dy.astype(np.float32).astype(np.float64)
+  dw_ref = (vo.conv2d_bwd if kind == 'conv' else vo.conv2d_transpose_bwd)(xf, wf, dyf, S, need_dx=False)[1]
+  assert rel(g[:K * K * Ci * Co].reshape(wshape), dw_ref) <= 1e-4, (wpath, rel(g[:K * K * Ci * Co].reshape(wshape), dw_ref))
+
+
 def test_deferred_plane_weight_gradients(bk):
   """odin_wgrad_planes_defer_begin / _end: the plane weight gradients of several layers as ONE launch, bit-identical
   to the separate launches; odin_slab_reduce flushes what is still pending."""
