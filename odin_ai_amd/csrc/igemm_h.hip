@@ -547,6 +547,9 @@ __global__ __launch_bounds__(NW * 64) void igemm_h_wgrad_kernel(IHWParams p) {
   const unsigned tapbit = i_ok ? (unsigned)tap : 31u;   // (bit 31 of a mask is never set)
   const int mlo = blockIdx.z * p.chunk;
   const int mhi = (mlo + p.chunk < p.M) ? mlo + p.chunk : p.M;
+  // (the two range words: requested here, finished behind the table build -- odin_device.h: odin_range_issue)
+  const OdinRangeReq g_rq = odin_range_issue((SCU || SCV) ? p.g_amax : nullptr, lane);
+  const OdinRangeReq a_rq = odin_range_issue(AS ? p.a_amax : nullptr, lane);
   for (int e = tid; e < TBN; e += NW * 64) {
     const int m = mlo + e;
     int off = 0;
@@ -567,9 +570,9 @@ __global__ __launch_bounds__(NW * 64) void igemm_h_wgrad_kernel(IHWParams p) {
   __syncthreads();
   const OdinRun RU = odin_run(p.u, (unsigned)((size_t)p.B * p.FH * p.FW * p.CU * 4));
   const OdinRun RV = odin_run(p.v, (unsigned)((size_t)mhi * p.CV * 4));   // (rows beyond this workgroup's pixels read zeros)
-  const int gk = (SCU || SCV) ? odin_range_shift(odin_range_load(p.g_amax)) : 0;
+  const int gk = (SCU || SCV) ? odin_range_shift(odin_range_finish(g_rq)) : 0;
   const float g_s = (SCU || SCV) ? odin_pow2(gk) : 1.f, g_s2k = (SCU || SCV) ? odin_pow2(gk + 11) : ODIN_LO_SCALE;
-  const unsigned a_mb = AS ? odin_range_load(p.a_amax) : 0u;
+  const unsigned a_mb = AS ? odin_range_finish(a_rq) : 0u;
   const bool a_on = AS && odin_act_needs_scale(a_mb);   // (an activation is scaled only outside the safe window)
   const int ak = a_on ? odin_range_shift(a_mb) : 0;
   const float a_s = odin_pow2(ak), a_s2k = odin_pow2(ak + 11);

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void smallc_fwd_kernel(SCParams p) {
   const int cg = p.CO >> 2;  // channel groups per pixel
   const int total = p.B * p.OH * p.OW * cg;  // < 2^31 (checked on the host)
   const int ohw = p.OH * p.OW;
+  float amx = 0.f;
   for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
     const int pix = t / cg, g4 = t - pix * cg;
     const int b = pix / ohw, rem = pix - b * ohw;
@@ -62,8 +63,11 @@ __global__ __launch_bounds__(256) void smallc_fwd_kernel(SCParams p) {
     }
     acc.x = odin_act(p.act, acc.x); acc.y = odin_act(p.act, acc.y);
     acc.z = odin_act(p.act, acc.z); acc.w = odin_act(p.act, acc.w);
+    amx = odin_amax3(odin_amax3(amx, acc.x, acc.y), acc.z, acc.w);
     *reinterpret_cast<float4*>(p.y + (size_t)pix * p.CO + 4 * g4) = acc;
   }
+  __shared__ float ared[16];
+  odin_amax_commit_wg(p.y_amax, amx, threadIdx.x, 256, ared, blockIdx.x);   // (the range word of y, if asked for)
 }
 
 // forward, compile-time taps: all KH*KW*CI input taps of a thread are requested up front as
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(256) void smallc_fwd_kernel_t(SCParams p) {
   const int cg = p.CO >> 2;
   const int total = p.B * p.OH * p.OW * cg;
   const int ohw = p.OH * p.OW;
+  float amx = 0.f;
   for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
     const int pix = t / cg, g4 = t - pix * cg;
     const int b = pix / ohw, rem = pix - b * ohw;
@@ -111,8 +116,11 @@ __global__ __launch_bounds__(256) void smallc_fwd_kernel_t(SCParams p) {
     }
     acc.x = odin_act(p.act, acc.x); acc.y = odin_act(p.act, acc.y);
     acc.z = odin_act(p.act, acc.z); acc.w = odin_act(p.act, acc.w);
+    amx = odin_amax3(odin_amax3(amx, acc.x, acc.y), acc.z, acc.w);
     *reinterpret_cast<float4*>(p.y + (size_t)pix * p.CO + 4 * g4) = acc;
   }
+  __shared__ float ared[16];
+  odin_amax_commit_wg(p.y_amax, amx, threadIdx.x, 256, ared, blockIdx.x);   // (the range word of y, if asked for)
 }
 
 // weight gradient.  Workgroup = 16 waves; a wave owns 64/CW pixels per iteration (CW = 32
@@ -245,6 +253,7 @@ __global__ __launch_bounds__(256) void smallc_fwd_mfma_kernel(SCParams p) {
   // Persistent waves, the NEXT block's taps requested before the current block's MFMAs: one wave per block
   // (round 2) paid the weight fetch, the tap decoding and a full L2 round trip per 24 MFMAs -- 37 us for the
   // 64x64x3 first layer whose matrix time is 6 us.
+  float amx = 0.f;   // running max |y| of this lane: the range word of the activation
   auto gather = [&](int it, float (&b)[NK2]) {
     const int itc = it < n_it ? it : n_it - 1;          // (beyond the end: a valid block, never used)
     const int r = itc / cpr, q0 = (itc - r * cpr) << 5;
@@ -272,12 +281,14 @@ __global__ __launch_bounds__(256) void smallc_fwd_mfma_kernel(SCParams p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = rb * 32 + 8 * q + 4 * h;
-        if (n + 3 < p.CO)
-          *reinterpret_cast<float4*>(outp + rb * 32 + 8 * q) =
-              make_float4(odin_act(p.act, acc[4 * q] + bias_r[rb][4 * q]),
-                          odin_act(p.act, acc[4 * q + 1] + bias_r[rb][4 * q + 1]),
-                          odin_act(p.act, acc[4 * q + 2] + bias_r[rb][4 * q + 2]),
-                          odin_act(p.act, acc[4 * q + 3] + bias_r[rb][4 * q + 3]));
+        if (n + 3 < p.CO) {
+          const float4 o = make_float4(odin_act(p.act, acc[4 * q] + bias_r[rb][4 * q]),
+                                       odin_act(p.act, acc[4 * q + 1] + bias_r[rb][4 * q + 1]),
+                                       odin_act(p.act, acc[4 * q + 2] + bias_r[rb][4 * q + 2]),
+                                       odin_act(p.act, acc[4 * q + 3] + bias_r[rb][4 * q + 3]));
+          amx = odin_amax3(odin_amax3(amx, o.x, o.y), o.z, o.w);
+          *reinterpret_cast<float4*>(outp + rb * 32 + 8 * q) = o;
+        }
       }
     }
   };
@@ -299,6 +310,8 @@ __global__ __launch_bounds__(256) void smallc_fwd_mfma_kernel(SCParams p) {
       if (it >= n_it) break;
     }
   }
+  __shared__ float ared[16];
+  odin_amax_commit_wg(p.y_amax, amx, tid, 256, ared, blockIdx.x);   // (the range word of y, if asked for)
 }
 
 // The same forward with the input rows staged in LDS: for RGB images (K = 48) the direct gather is bound by the
@@ -551,13 +564,13 @@ static void sc_fill(SCParams& p, const odin_conv_desc* d) {
 static int smallc_fwd_launch(const float* x, const float* w, const float* bias, float* y,
                              const odin_conv_desc* d, void* stream, bool* tracked);
 
-// (the range word of y, d->y_amax: kept by the LDS-row kernel's epilogue; one pass over y behind the other variants)
+// (the range word of y, d->y_amax: kept by every variant's epilogue)
 int odin_smallc_fwd(const float* x, const float* w, const float* bias, float* y,
                     const odin_conv_desc* d, void* stream) {
   bool tracked = false;
   const int rc = smallc_fwd_launch(x, w, bias, y, d, stream, &tracked);
-  if (rc != 0 || tracked || d->y_amax == nullptr || y == nullptr) return rc;
-  return odin_absmax_fold(y, (size_t)d->B * d->OH * d->OW * d->Cout, d->y_amax, stream);
+  (void)tracked;   // (every variant folds max|y| into d->y_amax from its own epilogue)
+  return rc;
 }
 
 static int smallc_fwd_launch(const float* x, const float* w, const float* bias, float* y,
