@@ -644,6 +644,11 @@ def main():
       return eng.train_step(xb, None, lr=lr, beta=beta, global_clipnorm=100.0, use_graph=use_graph)
   elif fv is not None:
     x = synthetic_batch(args.workload, B, in_shape, device, seed=100 + rank)
+    if use_graph:
+      # (resident in the buffer the iteration graph reads, as the plain-VAE workloads: no per-iteration copy)
+      xb = fv.input_buffer(B)
+      xb.copy_(x)
+      x = xb
 
     def step():
       loss, _ = fv.optimize(x, learning_rate=lr, global_clipnorm=100.0, use_graph=use_graph)

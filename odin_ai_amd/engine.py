@@ -435,7 +435,8 @@ class VAEEngine:
                observation='bernoulli', analytic=False, free_bits=None, tc=None, lib=None,
                params: Optional[torch.Tensor] = None, world_size: int = 1, seed: int = 1,
                optim_state: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-               force_dp: bool = False, reverse: bool = True, capacity: bool = False):
+               force_dp: bool = False, reverse: bool = True, capacity: bool = False,
+               range_words: Optional[torch.Tensor] = None):
     self.lib = lib if lib is not None else _lib.load()
     self.device = torch.device(device)
     self.B, self.D = int(batch_size), int(zdim)
@@ -483,7 +484,13 @@ class VAEEngine:
     ne = len(self.enc_recs)
     nl = ne + len(self.dec_recs)
     # (gradient words | activation words: one buffer, cleared together by the step's last backward launch)
-    self.range_words = torch.zeros(2 * nl * RANGE_WORDS, dtype=torch.int32, device=self.device)
+    # `range_words`: another engine's buffer (same networks): a forward-only engine that runs between that engine's
+    # forward and backward passes (FactorVAE's second half batch) folds its maxima into the same words -- still upper
+    # bounds -- and needs no clearing launch of its own
+    self._shared_ranges = range_words is not None
+    self.range_words = (range_words if range_words is not None else
+                        torch.zeros(2 * nl * RANGE_WORDS, dtype=torch.int32, device=self.device))
+    assert self.range_words.numel() == 2 * nl * RANGE_WORDS
     gw, aw = self.range_words[:nl * RANGE_WORDS], self.range_words[nl * RANGE_WORDS:]
     self.enc = NetProgram(self.lib, self.enc_recs, B, self.device, self.params, self.grads, mr,
                           range_words=gw[:ne * RANGE_WORDS], act_words=aw[:ne * RANGE_WORDS])
@@ -516,7 +523,10 @@ class VAEEngine:
                                           C.byref(npart), None)
     self.llk_part = torch.empty(B * max(npart.value, (n_per + 1023) // 1024), **f32)
     self.llk = torch.empty(B, **f32)
-    self.out4 = torch.zeros(4, **f32)
+    # [loss, mean llk, mean beta*kl, tc | 4 spare words a model may place its own step scalars in (FactorVAE: dtc_loss),
+    # so that ONE device-to-device copy snapshots them all]
+    self.out8 = torch.zeros(8, **f32)
+    self.out4 = self.out8[:4]
     self.n_part = 0
     rows = C.c_int(0)
     self.lib.odin_dense_wgrad(None, None, None, C.byref(rows), B, self.hdim, 2 * D, None)
@@ -846,6 +856,8 @@ class VAEEngine:
     """The activation words are cleared by the step's last backward launch; a forward pass that follows another
     forward pass (encode / decode / evaluation) clears them itself -- the words fold maxima in, a stale larger bound
     would cost the planes precision."""
+    if self._shared_ranges:
+      return
     if self._act_words_dirty:
       nl = len(self.enc_recs) + len(self.dec_recs)
       self.lib.odin_range_reset(self.range_words.data_ptr() + 4 * RANGE_WORDS * nl, nl, st)
@@ -859,13 +871,28 @@ class VAEEngine:
     assert x.shape == (B,) + self.in_shape and x.is_contiguous()
     self.x = x
     self._clear_stale_act_words(st)
+    lw = self.params[self.lat_w_off:]
+    lb = self.params[self.lat_b_off:]
+    if self.lat_block:
+      # noise + projection + reparameterisation + KL as ONE launch (latent_block.hip; the decoder's first Dense it
+      # also evaluates lands in dec.outs[0], unused here): three launches less than the separate kernels
+      if eps is not None and eps is not self.eps:
+        self.eps.copy_(eps)
+      h_e = self.enc.forward(x, st)
+      r0 = self.dec_recs[0]
+      lib.odin_latent_block_fwd(h_e.data_ptr(), lw.data_ptr(), lb.data_ptr(),
+                                None if eps is None else self.eps.data_ptr(), self.eps.data_ptr(),
+                                self.seed, self.hp(N_HYPER), self.p.data_ptr(), self.z.data_ptr(),
+                                self.kl.data_ptr(), self.fbmask.data_ptr(), self.dec.w(0).data_ptr(),
+                                self.dec.b(0).data_ptr(), self.dec.outs[0].data_ptr(), B, self.hdim, D,
+                                r0.N, ACT[r0.act], int(self.analytic), self.free_bits,
+                                self.hp(H_CAP) if self.capacity_on else None, st)
+      return self.p, self.z
     if eps is None:
       lib.odin_rng_normal(self.eps.data_ptr(), B * D, self.seed, self.hp(N_HYPER), st)
     elif eps is not self.eps:
       self.eps.copy_(eps)
     h_e = self.enc.forward(x, st)
-    lw = self.params[self.lat_w_off:]
-    lb = self.params[self.lat_b_off:]
     lib.odin_dense_fwd(h_e.data_ptr(), lw.data_ptr(), lb.data_ptr(), self.p.data_ptr(), B,
                        self.hdim, 2 * D, 0, st)
     lib.odin_latent_fwd(self.p.data_ptr(), self.eps.data_ptr(), self.z.data_ptr(),

@@ -1296,6 +1296,7 @@ class FactorVAE(AnnealingVAE):
     B1 = x.shape[0] // 2
     eng, disc = self._engine(B1), self._discriminator(B1)
     eng2 = self._engine_x2(B1)
+    disc.dtc = eng.out8[4:5]   # (beside out4: one device-to-device copy snapshots the iteration's scalars)
     if training:
       self._step += 1
     eng.step_count = self._step
@@ -1322,11 +1323,11 @@ class FactorVAE(AnnealingVAE):
                       aggregate_gradients)
     if training and not self._is_pretraining:
       disc.disc.t += 1
-    out = eng.out4.clone()
+    out = eng.out8.clone()
     metrics = {f'elbo/llk_{self.observation.name}': out[1],
                f'elbo/kl_{self.latents.name}': out[2], 'elbo/tc': out[3]}
     if not self._is_pretraining:
-      metrics['disc/dtc_loss'] = disc.dtc[0].clone()
+      metrics['disc/dtc_loss'] = out[4]
     if training and track_gradients:
       for k, g in eng.grad_views().items():
         metrics['_grad/elbo/' + self.variable_name(k)] = g.clone()
@@ -1341,8 +1342,9 @@ class FactorVAE(AnnealingVAE):
     key = (B1, pol, eps is not None, eps2 is not None, explicit_perm, training, use_tc,
            aggregate_gradients, self._is_pretraining, eng.analytic, eng.free_bits)
     if key not in self._fgraphs:
-      xs = torch.empty_like(x)
-      xs.copy_(x)
+      xs = self.input_buffer(x.shape[0])
+      if x.data_ptr() != xs.data_ptr():
+        xs.copy_(x)
       if eps is not None:
         eng.eps.copy_(eps)
       if eps2 is not None:
@@ -1374,8 +1376,14 @@ class FactorVAE(AnnealingVAE):
     sg.replay()
 
   def input_buffer(self, batch_size: int) -> torch.Tensor:
-    """Static [B, H, W, C] tensor read by the captured iteration graph with default settings."""
-    raise NotImplementedError('FactorVAE copies the batch into its graph-owned buffer')
+    """Static [B, H, W, C] tensor every captured iteration graph of this batch size reads: a data pipeline that
+    writes the next batch straight into it (and passes it to optimize) saves the per-iteration device-to-device copy."""
+    if not hasattr(self, '_xs'):
+      self._xs = {}
+    B = int(batch_size)
+    if B not in self._xs:
+      self._xs[B] = torch.empty((B,) + tuple(self.input_shape), dtype=torch.float32, device=self.device)
+    return self._xs[B]
 
   def _engine_x2(self, B1: int) -> VAEEngine:
     key = -B1
@@ -1386,7 +1394,8 @@ class FactorVAE(AnnealingVAE):
                                      observation=self.observation.posterior,
                                      analytic=self.analytic, free_bits=self.free_bits,
                                      lib=self._lib, params=self._params,
-                                     seed=self.seed + 1000003 + self._rank())
+                                     seed=self.seed + 1000003 + self._rank(),
+                                     range_words=self._engines[B1].range_words)
     return self._engines[key]
 
   def total_correlation(self, qz_x, training=None):
