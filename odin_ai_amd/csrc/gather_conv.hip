@@ -1667,6 +1667,7 @@ extern "C" int odin_conv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_ac
   return odin_igemm_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0) ? 1 : 0;
 }
 extern "C" int odin_deconv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_act) {
+  if (odin_smalldeconv_applicable(d)) return 1;
   if (aux_act == ODIN_ACT_ELU &&
       odin_fconv_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
                                    d->pad_t, d->pad_l, 0))
@@ -1737,6 +1738,7 @@ extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* a
 // SAME pads of the forward conv on the OUTPUT size) ------------------------------------
 extern "C" int odin_deconv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                                  const odin_conv_desc* d, void* stream) {
+  if (bias != nullptr && odin_smalldeconv_applicable(d)) return odin_smalldeconv_fwd(x, w, bias, y, d, stream);
   if (d->act == ODIN_ACT_ELU && bias != nullptr && d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_tconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
                                    d->pad_l, d->center, 1, 1))
@@ -1769,6 +1771,11 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
                                    int aux_act, float* dx, float* colsum_slab,
                                    int* slab_rows_out, const odin_conv_desc* d, void* stream) {
   // data gradient of a Conv2DTranspose = strided gather over dY: input (OH, OW, Cout), output (H, W, Cin)
+  if (colsum_slab == nullptr && odin_smalldeconv_applicable(d)) {
+    if (slab_rows_out) *slab_rows_out = 0;
+    if (dx == nullptr) return 0;  // dry run
+    return odin_smalldeconv_bwd(nullptr, dy, w, aux, aux_act, dx, nullptr, nullptr, d, stream);
+  }
   if (aux_act == ODIN_ACT_ELU && (aux != nullptr || dx == nullptr) &&
       odin_fconv_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
                                    d->pad_t, d->pad_l, 0))

@@ -77,6 +77,15 @@ int odin_dense_h_dgrad(const float* dy, const float* w, const float* aux, int au
 int odin_dense_h_wgrad(const float* x, const float* dy, float* slab, int B, int K, int N, const uint32_t* dy_amax,
                        const uint32_t* x_amax, void* stream);
 
+// the decoders' first Conv2DTranspose (tiny image, 8 / 16 -> 64 channels) on the vector ALUs, one workgroup per
+// sample pair (smalldeconv.hip)
+bool odin_smalldeconv_applicable(const odin_conv_desc* d);
+int odin_smalldeconv_rows(const odin_conv_desc* d);
+int odin_smalldeconv_fwd(const float* x, const float* w, const float* bias, float* y, const odin_conv_desc* d,
+                         void* stream);
+int odin_smalldeconv_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                         float* slab, int* rows_out, const odin_conv_desc* d, void* stream);
+
 // 4x4 / stride-2 gather convolution over 32 channels with a rolling LDS row window (fconv_ring.hip)
 bool odin_fconv_ring_applicable(int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
                                 int pt, int pl, int center);

@@ -1282,6 +1282,8 @@ extern "C" int odin_conv2d_wgrad(const float* x, const float* dy, float* slab,
 // x = deconv input [B,H,W,Cin], dy = grad wrt deconv pre-activation output [B,OH,OW,Cout]
 extern "C" int odin_deconv2d_wgrad(const float* x, const float* dy, float* slab,
                                    int* slab_rows_out, const odin_conv_desc* d, void* stream) {
+  if (odin_smalldeconv_applicable(d))   // (dry run: slab == NULL only reports the rows)
+    return odin_smalldeconv_bwd(x, dy, nullptr, nullptr, 0, nullptr, slab, slab_rows_out, d, stream);
   WParams p;
   memset(&p, 0, sizeof(p));
   p.in = dy; p.dy = x; p.slab = slab;
@@ -1362,6 +1364,11 @@ extern "C" int odin_conv2d_bwd(const float* x, const float* dy, const float* w, 
 extern "C" int odin_deconv2d_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act,
                                  float* dx, float* colsum_slab, int* colsum_rows_out, float* wslab,
                                  int* wslab_rows_out, const odin_conv_desc* d, void* stream) {
+  if (colsum_slab == nullptr && dx != nullptr && wslab != nullptr && odin_smalldeconv_applicable(d)) {
+    // the decoders' first Conv2DTranspose: weight and data gradient in ONE launch that stages dy once (smalldeconv.hip)
+    if (colsum_rows_out) *colsum_rows_out = 0;
+    return odin_smalldeconv_bwd(x, dy, w, aux, aux_act, dx, wslab, wslab_rows_out, d, stream);
+  }
   odin_igemm_pair_begin();
   int rc = odin_deconv2d_wgrad(x, dy, wslab, wslab_rows_out, d, stream);
   if (rc == 0) rc = odin_deconv2d_dgrad(dy, w, aux, aux_act, dx, colsum_slab, colsum_rows_out, d, stream);

@@ -132,7 +132,9 @@ DECONV_CASES = [
     (3, 16, 16, 64, 32, 4, 2, 'elu'),          # fconv_ring data gradient into 64 channels; forward: tconv_planes over 64 channels in two passes (decoder3)
     (3, 8, 8, 64, 64, 4, 2, 'elu'),            # fconv_ring data gradient: 8-pixel rows, 64 reduction channels in two passes; forward: tconv_planes, 8-pixel input rows (decoder2)
     (5, 8, 8, 32, 32, 4, 2, 'elu'),            # tconv_planes forward, 8-pixel input rows, one pass
-    (3, 4, 4, 8, 64, 4, 2, 'elu'),
+    (3, 4, 4, 8, 64, 4, 2, 'elu'),             # the decoders' first Conv2DTranspose: smalldeconv.hip (dSprites: 8 channels)
+    (5, 4, 4, 16, 64, 4, 2, 'elu'),            # ... Shapes3D: 16 channels, an odd batch (the last workgroup holds one sample)
+    (2, 6, 5, 8, 64, 4, 2, 'relu'),            # ... the audio decoder's 6 x 5 image
     (2, 8, 8, 64, 32, 4, 2, 'elu'),
     (1, 16, 16, 32, 32, 4, 2, 'linear'),
     (2, 16, 16, 32, 64, 4, 2, 'elu'),          # tconv_planes forward, two 32-channel output blocks
@@ -187,6 +189,14 @@ def test_deconv2d_fwd_dgrad_wgrad(bk, request, B, H, W, Ci, Co, K, S, act):
   close(reduce_slab(bk, slab, rows.value, Ci), g_ref.sum((0, 1, 2)), 1e-4)
   if want_h:
     assert path == 'igemm_h(f16x2)', path
+  # without a column-sum slab (the layer below is no Conv2DTranspose): other kernel families take the call
+  # (smalldeconv.hip for the decoders' first Conv2DTranspose)
+  tdx2 = bk.full((B, H, W, Ci), float('nan'))
+  L.odin_deconv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, tdx2.data_ptr(), None, None, C.byref(d), None)
+  print('deconv dgrad, no column sums', (B, H, W, Ci, Co), L.odin_debug_last_path().decode())
+  if (H, W, Ci, Co, K, S) in ((4, 4, 8, 64, 4, 2), (4, 4, 16, 64, 4, 2), (6, 5, 8, 64, 4, 2)):
+    assert L.odin_debug_last_path().decode() == 'smalldeconv_bwd'
+  close(tdx2.cpu().numpy(), g_ref)
   n = K * K * Co * Ci
   slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
   L.odin_deconv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows),
@@ -243,7 +253,7 @@ def test_dense(bk, B, K, N, act):
 
 @pytest.mark.parametrize('kind,shape', [
     ('conv', (5, 8, 8, 64, 64, 4, 2)), ('conv', (16, 8, 8, 32, 64, 4, 2)), ('deconv', (6, 4, 4, 8, 64, 4, 2)),
-    ('dense', (100, 256, 40)), ('dense', (64, 1024, 128)), ('conv', (3, 16, 16, 32, 32, 4, 2)),
+    ('deconv', (257, 4, 4, 16, 64, 4, 2)), ('dense', (100, 256, 40)), ('dense', (64, 1024, 128)), ('conv', (3, 16, 16, 32, 32, 4, 2)),
     ('dense', (48, 256, 320)), ('dense', (128, 1000, 2)), ('dense', (64, 6, 1000))])
 def test_layer_bwd_in_one_call(bk, kind, shape):
   """odin_conv2d_bwd / odin_deconv2d_bwd / odin_dense_bwd = the weight gradient + the data gradient of a layer in
