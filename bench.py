@@ -699,6 +699,7 @@ def main():
   for _ in range(args.steps):
     out = step()
   torch.cuda.synchronize()
+  dt_local = time.perf_counter() - t0   # this rank's own K steps, before the closing barrier
   if use_dist:
     dist.barrier()
   torch.cuda.synchronize()
@@ -707,6 +708,12 @@ def main():
     tt = torch.tensor([dt], device=device, dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = tt.item()
+    # spread of the ranks' own clocks (a slow GPU or a late rank shows here, not in the max-over-ranks value)
+    tl = torch.tensor([dt_local], device=device, dtype=torch.float64)
+    tlo, thi = tl.clone(), tl.clone()
+    dist.all_reduce(tlo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(thi, op=dist.ReduceOp.MAX)
+    rccl['rank_ms_per_step'] = dict(min=round(tlo.item() / args.steps * 1e3, 4), max=round(thi.item() / args.steps * 1e3, 4))
     # replicas must still agree after the timed steps (same all-reduced gradients, same Adam)
     chk = eng.params.double().sum().reshape(1)
     lo, hi = chk.clone(), chk.clone()
