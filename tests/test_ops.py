@@ -254,7 +254,10 @@ def test_dense(bk, B, K, N, act):
 @pytest.mark.parametrize('kind,shape', [
     ('conv', (5, 8, 8, 64, 64, 4, 2)), ('conv', (16, 8, 8, 32, 64, 4, 2)), ('deconv', (6, 4, 4, 8, 64, 4, 2)),
     ('deconv', (257, 4, 4, 16, 64, 4, 2)), ('dense', (100, 256, 40)), ('dense', (64, 1024, 128)), ('conv', (3, 16, 16, 32, 32, 4, 2)),
-    ('dense', (48, 256, 320)), ('dense', (128, 1000, 2)), ('dense', (64, 6, 1000))])
+    ('dense', (48, 256, 320)), ('dense', (128, 1000, 2)), ('dense', (64, 6, 1000)),
+    # bwd_planes.hip: Conv2DTranspose over 32 output channels, weight + data gradient in one launch (rows of 32 / 16 / 8
+    # pixels; 64 input channels = two workgroup columns; a batch that leaves the last workgroup short)
+    ('deconv', (3, 32, 32, 32, 32, 4, 2)), ('deconv', (5, 16, 16, 64, 32, 4, 2)), ('deconv', (7, 8, 8, 32, 32, 4, 2))])
 def test_layer_bwd_in_one_call(bk, kind, shape):
   """odin_conv2d_bwd / odin_deconv2d_bwd / odin_dense_bwd = the weight gradient + the data gradient of a layer in
   one call (small layers: ONE launch shared by the two implicit-GEMM kernels): results identical, bit for bit, to
@@ -303,10 +306,37 @@ def test_layer_bwd_in_one_call(bk, kind, shape):
     s1, s2 = bk.full((L.odin_max_slab_rows(), n), float('nan')), bk.full((L.odin_max_slab_rows(), n), float('nan'))
     wg, dg, bw = ((L.odin_conv2d_wgrad, L.odin_conv2d_dgrad, L.odin_conv2d_bwd) if kind == 'conv' else
                   (L.odin_deconv2d_wgrad, L.odin_deconv2d_dgrad, L.odin_deconv2d_bwd))
-    wg(tx.data_ptr(), tdy.data_ptr(), s1.data_ptr(), C.byref(rows), C.byref(d), None)
-    dg(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx1.data_ptr(), None, None, C.byref(d), None)
-    bw(tx.data_ptr(), tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx2.data_ptr(), None, None,
-       s2.data_ptr(), C.byref(rows2), C.byref(d), None)
+    fused = kind == 'deconv' and Co == 32 and Ci % 32 == 0
+    if fused:
+      # with the column sums of dx (the bias gradient of the layer below) and every range word
+      words = bk.zeros(4 * 2048, dtype=torch.int32)
+      wp = [words[i * 2048:].data_ptr() for i in range(4)]
+      L.odin_absmax(tdy.data_ptr(), tdy.numel(), wp[0], None)
+      L.odin_absmax(tx.data_ptr(), tx.numel(), wp[1], None)
+      d.dy_amax, d.x_amax = wp[0], wp[1]
+      c1, c2 = bk.full((L.odin_max_slab_rows() * 2, Ci), float('nan')), bk.full((L.odin_max_slab_rows() * 2, Ci), float('nan'))
+      cr1, cr2 = C.c_int(0), C.c_int(0)
+      d.dx_amax = wp[2]
+      wg(tx.data_ptr(), tdy.data_ptr(), s1.data_ptr(), C.byref(rows), C.byref(d), None)
+      dg(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx1.data_ptr(), c1.data_ptr(), C.byref(cr1), C.byref(d), None)
+      assert L.odin_debug_last_path().decode().startswith('fconv_planes')
+      d.dx_amax = wp[3]
+      bw(tx.data_ptr(), tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx2.data_ptr(), c2.data_ptr(), C.byref(cr2),
+         s2.data_ptr(), C.byref(rows2), C.byref(d), None)
+      assert L.odin_debug_last_path().decode().startswith('bwd_planes')
+      assert cr1.value == cr2.value > 0 and torch.equal(c1[:cr1.value], c2[:cr2.value])
+      assert torch.equal(words[2 * 2048:3 * 2048], words[3 * 2048:])
+      assert float(words[3 * 2048:].view(torch.float32).max()) == float(dx2.abs().max())
+      # ... and against the float64 oracle
+      dx_ref, dw_ref, _ = vo.conv2d_transpose_bwd(x, w * 0.1, dy, S)
+      dx_ref = dx_ref * np.where(aux > 0, 1.0, np.minimum(aux, 0.0) + 1.0)
+      close(dx2.cpu().numpy(), dx_ref, 1e-4)
+      close(reduce_slab(bk, s2, rows2.value, n).reshape(wshape), dw_ref, 1e-4)
+    else:
+      wg(tx.data_ptr(), tdy.data_ptr(), s1.data_ptr(), C.byref(rows), C.byref(d), None)
+      dg(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx1.data_ptr(), None, None, C.byref(d), None)
+      bw(tx.data_ptr(), tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, dx2.data_ptr(), None, None,
+         s2.data_ptr(), C.byref(rows2), C.byref(d), None)
   path = L.odin_debug_last_path().decode()
   print(kind, shape, path)
   assert rows.value == rows2.value and rows.value > 0
