@@ -21,18 +21,20 @@
 #include "odin_device.h"
 #include "odin_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
 struct BPParams {
-  const float* U;      // dy [B, 2h, 2w, 32]
+  const float* U;      // dy [B, 2h, 2w, CUt]: this pass reduces over / differentiates channels cu_off .. cu_off + 31
   const float* V;      // x  [B, h, w, CVt]   (the layer's input)
-  const float* w;      // [16 taps][32][CVt]
+  const float* w;      // [16 taps][CUt][CVt]
   const float* aux;    // [B, h, w, CVt]: dx *= ELU'(aux)
   float* dx;           // [B, h, w, CVt]
   float* colsum;       // [gridDim.x][CVt] partial column sums of dx (may be null)
-  float* slab;         // [gridDim.x][16 * 32 * CVt]
+  float* slab;         // [gridDim.x][16 * CUt * CVt]
   int B, h, CVt;
+  int CUt, cu_off;
   int slab_stride;
   int tiles_per_img, n_tiles, tiles_per_wg;
   const unsigned* g_amax;  // range word of dy
@@ -46,8 +48,17 @@ struct alignas(8) BpEnt {
 
 struct BpItem {
   float4 v;
-  int dst;  // byte offset of the hi-plane store inside the LDS image; < 0: no item (wave-uniform)
+  int dst;  // WAVE-UNIFORM part of the byte offset of the hi-plane store inside the LDS image (a scalar register; the
+            // lane's part is added at the store); < 0: no item
 };
+
+__device__ __forceinline__ int bp_uniform(int v) {
+#ifdef ODIN_SIM
+  return v;
+#else
+  return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
 
 constexpr int BP_MAXU = 4;  // 1 KB load items (8 pixels x 32 channels) of fine rows per wave and fill
 
@@ -89,7 +100,10 @@ __device__ __forceinline__ u32x2 bp_tr_read_v(const char* blk, int l16) {
 
 // W = coarse row length (8, 16 or 32); NSETS = register sets of row-fill loads in flight (loads run NSETS - 1 tiles ahead
 // of their LDS stores)
-template <int W, int NSETS>
+// PASS 0: a layer with 32 output channels.  64 output channels take two passes inside one launch (bwd_planes2_kernel, as
+// fconv_planes2_kernel): PASS 1 (channels 0-31) writes its weight-gradient block and leaves the data gradient's raw
+// partial sums in dx, PASS 2 (channels 32-63) adds them in front of the epilogue.
+template <int W, int NSETS, int DBG = 0, int PASS = 0>
 __device__ __forceinline__ void bp_body(const BPParams& p) {
   constexpr int NPL = 2;                 // f16 planes per operand
   constexpr int TC = 32 / W;             // coarse rows per tile
@@ -137,17 +151,17 @@ __device__ __forceinline__ void bp_body(const BPParams& p) {
       const int tap = kh * 4 + kw0 + t;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        wv[t][kk][e] = p.w[((size_t)(tap * 32 + 16 * kk + 8 * half + e)) * p.CVt + cv0 + l31];
+        wv[t][kk][e] = p.w[((size_t)(tap * p.CUt + p.cu_off + 16 * kk + 8 * half + e)) * p.CVt + cv0 + l31];
     }
-  const OdinRun RU = odin_run(p.U, (unsigned)((size_t)p.B * HU * WU * 32 * 4));
+  const OdinRun RU = odin_run(p.U, (unsigned)((size_t)p.B * HU * WU * p.CUt * 4));
   const OdinRun RV = odin_run(p.V, (unsigned)((size_t)p.B * p.h * W * p.CVt * 4));
   const int ch4 = lane & 7, pxl = lane >> 3;
   // item j of this wave: row r0 + RJ j of the fill, 8-pixel column block cu_blk (wave constants; 32-bit offsets)
   const int r0 = wave / IPU, cu_blk = wave - r0 * IPU;
   const int pcw = 8 * cu_blk + pxl + 1;  // padded column of this lane's pixel: parity pcw & 1, slot pcw >> 1
   const int u_lds = (pcw & 1) * PARB + bp_uoff(pcw >> 1, 4 * ch4);
-  const unsigned u_g = (unsigned)(((8 * cu_blk + pxl) * 32 + 4 * ch4) * 4);
-  const unsigned u_rowbytes = (unsigned)(WU * 32 * 4), v_rowbytes = (unsigned)(W * p.CVt * 4);
+  const unsigned u_g = (unsigned)(((8 * cu_blk + pxl) * p.CUt + p.cu_off + 4 * ch4) * 4);
+  const unsigned u_rowbytes = (unsigned)(WU * p.CUt * 4), v_rowbytes = (unsigned)(W * p.CVt * 4);
   const int vr = (wave & 3) / IPV, vc = (wave & 3) - vr * IPV;
   const unsigned v_g = (unsigned)(((8 * vc + pxl) * p.CVt + cv0 + 4 * ch4) * 4);
   const int v_lds = NSU * RBU + (8 * vc + pxl) * 64 + ch4 * 8;
@@ -163,11 +177,11 @@ __device__ __forceinline__ void bp_body(const BPParams& p) {
       const bool valid = r < 2 * TC + 2;
       const int b = b0 + (2 * TC * t0 + r >= HPU ? 1 : 0), gi = G - b * HPU;
       const bool real = valid && gi != 0 && b < p.B;  // gi == 0: the zero row between images
-      iu[0][j].dst = valid ? (G - odin_div_small(G, NSU) * NSU) * RBU + u_lds : -1;
+      iu[0][j].dst = bp_uniform(valid ? (G - odin_div_small(G, NSU) * NSU) * RBU : -(1 << 24));
       iu[0][j].v = odin_run_load4(RU, real ? (unsigned)(G - b - 1) * u_rowbytes + u_g : ODIN_OOB);
     }
     const int grow = TC * T0 + vr;
-    iv[0].dst = wave < 4 ? (grow & (NSV - 1)) * RBV + v_lds : -1;
+    iv[0].dst = bp_uniform(wave < 4 ? (grow & (NSV - 1)) * RBV : -(1 << 24));
     iv[0].v = odin_run_load4(RV, (wave < 4 && grow < n_vrows) ? (unsigned)grow * v_rowbytes + v_g : ODIN_OOB);
   }
   ODIN_SCHED_FENCE();
@@ -227,19 +241,24 @@ __device__ __forceinline__ void bp_body(const BPParams& p) {
   const int v_none_dst = wave < 4 ? 0 : (int)0x80000000;
   const unsigned v_none_off = wave < 4 ? 0u : OFF_NONE;
   struct FillEnt { BpEnt u[BP_MAXU]; BpEnt v; };
+  // (wave-uniform entries: moved to scalar registers)
   auto fill_entries = [&](FillEnt& en, int f) {
 #pragma unroll
-    for (int j = 0; j < BP_MAXU; ++j) en.u[j] = tr[f * RPF + r0 + RJ * j];
-    en.v = tv[f * TC + vr];
+    for (int j = 0; j < BP_MAXU; ++j) {
+      const BpEnt e = tr[f * RPF + r0 + RJ * j];
+      en.u[j] = BpEnt{bp_uniform(e.x), bp_uniform(e.y)};
+    }
+    const BpEnt e = tv[f * TC + vr];
+    en.v = BpEnt{bp_uniform(e.x), bp_uniform(e.y)};
   };
   // (unconditional loads -- an absent item reads zeros through the range check -- keep the number in flight constant)
   auto fill_loads = [&](BpItem (&u)[BP_MAXU], BpItem& v, const FillEnt& en) {
 #pragma unroll
     for (int j = 0; j < BP_MAXU; ++j) {
-      u[j].dst = en.u[j].x + u_lds;  // negative: no row
+      u[j].dst = en.u[j].x;  // negative: no row
       u[j].v = odin_run_load4(RU, (unsigned)en.u[j].y + u_g);
     }
-    v.dst = (en.v.x + v_lds) | v_none_dst;
+    v.dst = en.v.x | v_none_dst;
     v.v = odin_run_load4(RV, ((unsigned)en.v.y + v_g) | v_none_off);
   };
   // dy is carried times 2^gk (its maximum lands in [2^14, 2^15)), x times 2^ak when its bound leaves the safe window;
@@ -263,7 +282,7 @@ __device__ __forceinline__ void bp_body(const BPParams& p) {
 #endif
     u32x2 h, l;
     odin_split_h4<true>(it.v, g_s, g_s2k, h, l);
-    char* d = smem + it.dst;
+    char* d = smem + (it.dst + u_lds);
     *reinterpret_cast<u32x2*>(d) = h;
     *reinterpret_cast<u32x2*>(d + PBU) = l;
   };
@@ -276,7 +295,7 @@ __device__ __forceinline__ void bp_body(const BPParams& p) {
     u32x2 h, l;
     if (as) odin_split_h4<true>(it.v, a_s, a_s2k, h, l);
     else odin_split_h4<false>(it.v, 1.f, ODIN_LO_SCALE, h, l);
-    char* d = smem + it.dst;
+    char* d = smem + (it.dst + v_lds);
     *reinterpret_cast<u32x2*>(d) = h;
     *reinterpret_cast<u32x2*>(d + PBV) = l;
   };
@@ -361,7 +380,7 @@ __device__ __forceinline__ void bp_body(const BPParams& p) {
   const OdinRun RX = odin_run(p.aux, out_bytes);
   const unsigned o_lane = (unsigned)(((orow * W + ocol) * p.CVt + c0) * 4);
   unsigned ooffP = ODIN_OOB;
-  float2 auxP = make_float2(0.f, 0.f);
+  float2 auxP = make_float2(0.f, 0.f), pvP = make_float2(0.f, 0.f);
 
   // fragments of one 16-pixel chunk of the weight gradient: x (2 planes) and dy for the wave's two taps
   struct Frags { u32x4 fv[NPL]; u32x4 fu[2][NPL]; };
@@ -397,12 +416,17 @@ __device__ __forceinline__ void bp_body(const BPParams& p) {
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
       const int t = m & 1, pp = m >> 1;
-      if (pp == 0) wacx[t] = mfma32_f16(F.fu[t][0], F.fv[1], wacx[t]);
-      if (pp == 1) wacx[t] = mfma32_f16(F.fu[t][1], F.fv[0], wacx[t]);
-      if (pp == 2) wacc[t] = mfma32_f16(F.fu[t][0], F.fv[0], wacc[t]);
+      if (!(DBG & 1)) {
+        if (pp == 0) wacx[t] = mfma32_f16(F.fu[t][0], F.fv[1], wacx[t]);
+        if (pp == 1) wacx[t] = mfma32_f16(F.fu[t][1], F.fv[0], wacx[t]);
+        if (pp == 2) wacc[t] = mfma32_f16(F.fu[t][0], F.fv[0], wacc[t]);
+      } else {
+        wacc[t][m] += odin_bitsf(F.fu[t][pp & 1][0] ^ F.fv[pp & 1][1]);
+      }
       if ((m & 1) == 1) {
         const int k = item0 + (m >> 1);
-        if (k <= BP_MAXU) store_fill_item(stu, stv, k);
+        if (k <= BP_MAXU && !(DBG & 4)) store_fill_item(stu, stv, k);
+        if (k <= BP_MAXU && (DBG & 4)) { const float4 tq = k < BP_MAXU ? stu[k].v : stv.v; csum[0] += tq.x + tq.y + tq.z + tq.w; }
       }
       ODIN_SCHED_FENCE();
     }
@@ -418,77 +442,144 @@ __device__ __forceinline__ void bp_body(const BPParams& p) {
 #pragma unroll
     for (int wvv = 1; wvv < 8; ++wvv) { s.x += q8[wvv].x; s.y += q8[wvv].y; }
     float v[2] = {s.x * out_s, s.y * out_s};
-    v[0] = fmaf(v[0], fminf(auxP.x, 0.f), v[0]);  // x ELU'(aux) = 1 + min(aux, 0)
-    v[1] = fmaf(v[1], fminf(auxP.y, 0.f), v[1]);
-    csum[0] += v[0];
-    csum[1] += v[1];
-    amx = odin_amax3(amx, v[0], v[1]);
+    if (PASS == 2) { v[0] += pvP.x; v[1] += pvP.y; }
+    if (PASS != 1) {
+      v[0] = fmaf(v[0], fminf(auxP.x, 0.f), v[0]);  // x ELU'(aux) = 1 + min(aux, 0)
+      v[1] = fmaf(v[1], fminf(auxP.y, 0.f), v[1]);
+      csum[0] += v[0];
+      csum[1] += v[1];
+      amx = odin_amax3(amx, v[0], v[1]);
+    }
     odin_run_store2(RO, ooffP, make_float2(v[0], v[1]));  // (range-checked: the first tile's pass has no tile T - 1)
   };
 
-  Frags F0, F1;
-  auto run_tile = [&](int T, BpItem (&ldu)[BP_MAXU], BpItem& ldv, const BpItem (&stu)[BP_MAXU], const BpItem& stv) {
-    const BpEnt th = thN;
-    su0 = th.x;
-    sv0 = (TC * T) & (NSV - 1);
-    read_chunk(0, F0);   // first thing behind the barrier
-    ODIN_SCHED_FENCE();
-    fill_loads(ldu, ldv, en);  // fill T - T0 + NSETS: its table entries were read a tile ago
-    const unsigned ooff = (unsigned)th.y + o_lane;
-    const float2 auxN = odin_run_load2(RX, ooff);
-    read_chunk(1, F1);
-    ODIN_SCHED_FENCE();
-    mfma_chunk(F0, 0, stu, stv);   // items 0, 1, 2
-    // the data gradient's fragments of this wave's tap row (F0's registers are free)
+  // the data gradient's fragments of this wave's tap row
+  auto dgrad_frags = [&](u32x4 (&fb)[2][2][NPL]) {
     int sud = su0 + 2 * orow + kh;
     sud -= sud >= NSU ? NSU : 0;
     const char* rowp = uring + sud * RBU;
-    u32x4 fb[2][2][NPL];
+    if (DBG & 2) {
 #pragma unroll
-    for (int pl = NPL - 1; pl >= 0; --pl)
+      for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-          fb[t][kk][pl] = *reinterpret_cast<const u32x4*>(rowp + t * PARB + boff[kk] + pl * PBU);
-    ODIN_SCHED_FENCE();
-    mfma_chunk(F1, 3, stu, stv);   // items 3, 4
-    fill_entries(en, T - T0 + NSETS + 1);
-    thN = tt[T - T0 + 1];
+          for (int kk = 0; kk < 2; ++kk) fb[t][kk][pl] = wf[t][kk][pl];
+    } else {
+#pragma unroll
+      for (int pl = NPL - 1; pl >= 0; --pl)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+            fb[t][kk][pl] = *reinterpret_cast<const u32x4*>(rowp + t * PARB + boff[kk] + pl * PBU);
+    }
+  };
+  // its 12 MFMAs (the previous tile's finish pass rides between them), the partial tile -> scratch [T & 1]
+  auto dgrad_tile = [&](int T, const u32x4 (&fb)[2][2][NPL]) {
     float2 q8[8];
     f32x16 acc = f32x16_zero(), acx = f32x16_zero();
 #pragma unroll
     for (int m = 0; m < 12; ++m) {
       const int t = (m >> 1) & 1, kk = m & 1, pp = m >> 2;
-      if (pp == 0) acx = mfma32_f16(wf[t][kk][0], fb[t][kk][1], acx);
-      if (pp == 1) acx = mfma32_f16(wf[t][kk][1], fb[t][kk][0], acx);
-      if (pp == 2) acc = mfma32_f16(wf[t][kk][0], fb[t][kk][0], acc);
-      if (m == 4) finish_load((T - 1) & 1, q8);  // tile T - 1: its partials are complete behind the last barrier
-      if (m == 8) finish_done(q8);
+      if (!(DBG & 1)) {
+        if (pp == 0) acx = mfma32_f16(wf[t][kk][0], fb[t][kk][1], acx);
+        if (pp == 1) acx = mfma32_f16(wf[t][kk][1], fb[t][kk][0], acx);
+        if (pp == 2) acc = mfma32_f16(wf[t][kk][0], fb[t][kk][0], acc);
+      } else {
+        acc[m] += odin_bitsf(wf[t][kk][pp & 1][0] ^ fb[t][kk][pp & 1][1]);
+      }
+      if (!(DBG & 16)) {
+        if (m == 4) finish_load((T - 1) & 1, q8);  // tile T - 1: its partials are complete behind the last barrier
+        if (m == 8) finish_done(q8);
+      }
       ODIN_SCHED_FENCE();
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = fmaf(acx[r], ODIN_LO_UNSCALE, acc[r]);
     char* d = red + (T & 1) * RED + ((wave * 64 + lane) << 3);
+    if (!(DBG & 16)) {
 #pragma unroll
-    for (int pr = 0; pr < 8; ++pr)
-      *reinterpret_cast<float2*>(d + pr * (8 * 64 * 8)) = make_float2(acc[2 * pr], acc[2 * pr + 1]);
+      for (int pr = 0; pr < 8; ++pr)
+        *reinterpret_cast<float2*>(d + pr * (8 * 64 * 8)) = make_float2(acc[2 * pr], acc[2 * pr + 1]);
+    } else {
+      float t2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t2 += acc[r];
+      csum[1] += t2;
+    }
+  };
+
+  // One tile.  Waves w and w + 4 share a SIMD, and a wave's MFMAs do not overlap with its own waits (LDS fragment
+  // reads, the barrier): ablations showed the matrix-pipe time of a tile ADDED to everything else.  So the two waves of
+  // a SIMD run the tile's two halves in OPPOSITE order -- waves 0-3 weight gradient first (36 transposed reads, then
+  // MFMAs), waves 4-7 data gradient first (8 reads, then MFMAs) -- and one wave's reads fall into the other's MFMAs.
+  Frags F0, F1;
+  // (the two-pass instances keep one order: the second body's registers do not fit beside the partial sums it adds)
+  const bool stag = ((DBG & 64) || PASS != 0) ? false : wave >= 4;
+  auto run_tile = [&](auto dfirst_c, int T, BpItem (&ldu)[BP_MAXU], BpItem& ldv, const BpItem (&stu)[BP_MAXU], const BpItem& stv) {
+    constexpr bool dfirst = decltype(dfirst_c)::value;
+    const BpEnt th = thN;
+    su0 = th.x;
+    sv0 = (TC * T) & (NSV - 1);
+    const unsigned ooff = (unsigned)th.y + o_lane;
+    float2 auxN = make_float2(0.f, 0.f), pvN = make_float2(0.f, 0.f);
+    auto loads = [&]() {
+      if (!(DBG & 8)) fill_loads(ldu, ldv, en);  // fill T - T0 + NSETS: its table entries were read a tile ago
+      else {
+#pragma unroll
+        for (int j = 0; j < BP_MAXU; ++j) ldu[j].dst = en.u[j].x;
+        ldv.dst = en.v.x | v_none_dst;
+      }
+      if (PASS != 1) auxN = (DBG & 8) ? auxP : odin_run_load2(RX, ooff);
+      if (PASS == 2) pvN = odin_run_load2(RO, ooff);
+    };
+    if (!dfirst) {
+      if (!(DBG & 2) || T == T0) read_chunk(0, F0);   // first thing behind the barrier
+      ODIN_SCHED_FENCE();
+      loads();
+      if (!(DBG & 2) || T == T0) read_chunk(1, F1);
+      ODIN_SCHED_FENCE();
+      mfma_chunk(F0, 0, stu, stv);   // items 0, 1, 2
+      u32x4 fb[2][2][NPL];
+      dgrad_frags(fb);               // (F0's registers are free)
+      ODIN_SCHED_FENCE();
+      mfma_chunk(F1, 3, stu, stv);   // items 3, 4
+      fill_entries(en, T - T0 + NSETS + 1);
+      thN = tt[T - T0 + 1];
+      dgrad_tile(T, fb);
+    } else {
+      u32x4 fb[2][2][NPL];
+      dgrad_frags(fb);
+      ODIN_SCHED_FENCE();
+      loads();
+      dgrad_tile(T, fb);
+      ODIN_SCHED_FENCE();
+      if (!(DBG & 2) || T == T0) read_chunk(0, F0);   // (the partner wave of this SIMD is in its MFMAs meanwhile)
+      if (!(DBG & 2) || T == T0) read_chunk(1, F1);
+      ODIN_SCHED_FENCE();
+      mfma_chunk(F0, 0, stu, stv);
+      fill_entries(en, T - T0 + NSETS + 1);
+      thN = tt[T - T0 + 1];
+      mfma_chunk(F1, 3, stu, stv);
+    }
     ooffP = ooff;
     auxP = auxN;
-    __syncthreads();  // partial tiles complete; every wave is past tile T's rows; tile T + 1's rows are stored
+    pvP = pvN;
+    if (!(DBG & 32)) __syncthreads();  // partial tiles complete; every wave is past tile T's rows; tile T + 1's rows are stored
   };
-  if (NSETS == 3) {
+  // (two loops, one per order: a per-tile branch between the two bodies cost the register allocator ~50 spills)
+  if (stag) {
 #pragma unroll 1
-    for (int T = T0; T < T1; T += 3) {
-      run_tile(T, iu[2 % NSETS], iv[2 % NSETS], iu[0], iv[0]);
-      if (T + 1 < T1) run_tile(T + 1, iu[0], iv[0], iu[1 % NSETS], iv[1 % NSETS]);
-      if (T + 2 < T1) run_tile(T + 2, iu[1 % NSETS], iv[1 % NSETS], iu[2 % NSETS], iv[2 % NSETS]);
+    for (int T = T0; T < T1; T += 2) {
+      run_tile(std::true_type{}, T, iu[1 % NSETS], iv[1 % NSETS], iu[0], iv[0]);
+      if (T + 1 < T1) run_tile(std::true_type{}, T + 1, iu[0], iv[0], iu[1 % NSETS], iv[1 % NSETS]);
     }
   } else {
 #pragma unroll 1
     for (int T = T0; T < T1; T += 2) {
-      run_tile(T, iu[1 % NSETS], iv[1 % NSETS], iu[0], iv[0]);
-      if (T + 1 < T1) run_tile(T + 1, iu[0], iv[0], iu[1 % NSETS], iv[1 % NSETS]);
+      run_tile(std::false_type{}, T, iu[1 % NSETS], iv[1 % NSETS], iu[0], iv[0]);
+      if (T + 1 < T1) run_tile(std::false_type{}, T + 1, iu[0], iv[0], iu[1 % NSETS], iv[1 % NSETS]);
     }
   }
   {
@@ -507,9 +598,10 @@ __device__ __forceinline__ void bp_body(const BPParams& p) {
     for (int r = 0; r < 16; ++r) {
       const int cu = (r & 3) + 8 * (r >> 2) + 4 * half;
       const float v = fmaf(wacx[t][r], o_sx, wacc[t][r] * o_s);
-      row[((size_t)tap * 32 + cu) * p.CVt + cv0 + l31] = v * a_o;   // (a_o = 1 for an unscaled activation)
+      row[((size_t)tap * p.CUt + p.cu_off + cu) * p.CVt + cv0 + l31] = v * a_o;   // (a_o = 1 for an unscaled activation)
     }
   }
+  if (PASS == 1) return;
   __syncthreads();  // (the partial-tile scratch is free: every wave is past its last finish pass)
   odin_amax_commit_wg(p.out_amax, amx, tid, 512, reinterpret_cast<float*>(red), blockIdx.x + gridDim.x * blockIdx.y);
   if (p.colsum != nullptr) {
@@ -523,12 +615,27 @@ __device__ __forceinline__ void bp_body(const BPParams& p) {
   }
 }
 
-template <int W, int NSETS>
+template <int W, int NSETS, int DBG = 0>
 __global__ __launch_bounds__(512) void bwd_planes_kernel(BPParams p) {
-  bp_body<W, NSETS>(p);
+  bp_body<W, NSETS, DBG>(p);
 }
 
-constexpr int BP_NSETS = 2;
+// 64 output channels: both 32-channel passes in ONE launch (fconv_planes.hip: fconv_planes2_kernel); the partial sums a
+// thread leaves in dx are read back by the same thread
+template <int W, int NSETS>
+__global__ __launch_bounds__(512) void bwd_planes2_kernel(BPParams p) {
+  p.cu_off = 0;
+  bp_body<W, NSETS, 0, 1>(p);
+  odin_wait_vmem();
+#ifndef ODIN_SIM
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
+  __syncthreads();
+  p.cu_off = 32;
+  bp_body<W, NSETS, 0, 2>(p);
+}
+
+constexpr int BP_NSETS = 3;   // (upper bound: sizes the fill tables)
 constexpr int BP_LDS_MAX = 160 * 1024;
 int bp_ring_bytes(int W) {
   const int TC = 32 / W;
@@ -552,28 +659,59 @@ int bp_tiles_per_wg(int W, int n_tiles, int gy) {
   return tpw;
 }
 
-template <int W>
-int bp_launch(const BPParams& p, dim3 grid, void* stream) {
+template <int W, int NS>
+int bp_launch_n(const BPParams& p, dim3 grid, void* stream) {
   const size_t lds = (size_t)bp_ring_bytes(W) + (size_t)(p.tiles_per_wg + BP_NSETS + 1) * bp_fill_bytes(W);
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_planes_kernel<W, BP_NSETS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_planes_kernel<W, NS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, BP_LDS_MAX) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((bwd_planes_kernel<W, BP_NSETS>), grid, dim3(512), lds, stream, p);
+  ODIN_LAUNCH((bwd_planes_kernel<W, NS>), grid, dim3(512), lds, stream, p);
   return odin_check_launch("bwd_planes(f16x2)");
+}
+template <int W>
+int bp_launch2(const BPParams& p, dim3 grid, void* stream) {
+  const size_t lds = (size_t)bp_ring_bytes(W) + (size_t)(p.tiles_per_wg + BP_NSETS + 1) * bp_fill_bytes(W);
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_planes2_kernel<W, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BP_LDS_MAX) != hipSuccess)
+      (void)hipGetLastError();
+    attr_done = true;
+  }
+#endif
+  ODIN_LAUNCH((bwd_planes2_kernel<W, 2>), grid, dim3(512), lds, stream, p);
+  return odin_check_launch("bwd_planes(f16x2)");
+}
+template <int W>
+int bp_launch(const BPParams& p, dim3 grid, void* stream) {
+  if (p.CUt == 64) return bp_launch2<W>(p, grid, stream);
+#if !defined(ODIN_SIM) && defined(ODIN_DIAG)
+  // diagnostics build only (make diag): instances with parts of the tile switched off -- they compute WRONG results;
+  // profiles/r05_bwd_planes_ablations.txt
+  const char* e = getenv("ODIN_BP_DBG");
+  if (e != nullptr && W == 32) {
+    const int dbg = atoi(e);
+    const size_t lds = (size_t)bp_ring_bytes(W) + (size_t)(p.tiles_per_wg + BP_NSETS + 1) * bp_fill_bytes(W);
+#define BP_DBG_CASE(D) if (dbg == D) { hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_planes_kernel<32, 2, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BP_LDS_MAX); ODIN_LAUNCH((bwd_planes_kernel<32, 2, D>), grid, dim3(512), lds, stream, p); return odin_check_launch("bwd_planes(dbg)"); }
+    BP_DBG_CASE(1) BP_DBG_CASE(2) BP_DBG_CASE(4) BP_DBG_CASE(16) BP_DBG_CASE(32) BP_DBG_CASE(3) BP_DBG_CASE(6) BP_DBG_CASE(22) BP_DBG_CASE(23) BP_DBG_CASE(55) BP_DBG_CASE(8) BP_DBG_CASE(40) BP_DBG_CASE(9) BP_DBG_CASE(64)
+  }
+#endif
+  return bp_launch_n<W, 2>(p, grid, stream);
 }
 
 }  // namespace
 
 // Conv2DTranspose(k4, s2) with Cout = 32: x [B, H, W, Cin] -> dy [B, 2H, 2W, 32]; aux: ELU activations below
 bool odin_bwd_planes_applicable(int B, int H, int W, int Cin, int Cout) {
-  if (odin_exact_fp32() || ODIN_DIAG_ENV("ODIN_NOPLANES") || getenv("ODIN_NOBWDPLANES")) return false;
-  if (!(Cout == 32 && (Cin % 32) == 0 && (W == 8 || W == 16 || W == 32) && (H % (32 / W)) == 0)) return false;
+  if (odin_exact_fp32() || ODIN_DIAG_ENV("ODIN_NOPLANES") || ODIN_DIAG_ENV("ODIN_NOBWDPLANES")) return false;
+  if (!((Cout == 32 || Cout == 64) && (Cin % 32) == 0 && (W == 8 || W == 16 || W == 32) && (H % (32 / W)) == 0)) return false;
   if (!((size_t)B * 2 * H * 2 * W * Cout * 4 < 0x7FFF0000ull && (size_t)B * H * W * Cin * 4 < 0x7FFF0000ull)) return false;
   return bp_tiles_per_wg(W, B * (H / (32 / W)), Cin / 32) > 0;
 }
@@ -585,13 +723,13 @@ int odin_bwd_planes_rows(int B, int H, int W, int Cin) {
 }
 
 int odin_bwd_planes_launch(const float* x, const float* dy, const float* w, const float* aux, float* dx, float* colsum,
-                           float* wslab, int B, int H, int W, int Cin, const uint32_t* dy_amax, const uint32_t* x_amax,
-                           uint32_t* dx_amax, void* stream) {
+                           float* wslab, int B, int H, int W, int Cin, int Cout, const uint32_t* dy_amax,
+                           const uint32_t* x_amax, uint32_t* dx_amax, void* stream) {
   BPParams p;
   memset(&p, 0, sizeof(p));
   p.U = dy; p.V = x; p.w = w; p.aux = aux; p.dx = dx; p.colsum = colsum; p.slab = wslab;
-  p.B = B; p.h = H; p.CVt = Cin;
-  p.slab_stride = 16 * 32 * Cin;
+  p.B = B; p.h = H; p.CVt = Cin; p.CUt = Cout; p.cu_off = 0;
+  p.slab_stride = 16 * Cout * Cin;
   const int TC = 32 / W;
   p.tiles_per_img = H / TC;
   p.n_tiles = B * p.tiles_per_img;
@@ -599,7 +737,7 @@ int odin_bwd_planes_launch(const float* x, const float* dy, const float* w, cons
   p.tiles_per_wg = bp_tiles_per_wg(W, p.n_tiles, gy);
   if (p.tiles_per_wg <= 0) return odin_fail(-2, "bwd_planes: not applicable");
   const int gx = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
-  p.g_amax = odin_range_word_of(dy, (size_t)B * 2 * H * 2 * W * 32, dy_amax, stream);
+  p.g_amax = odin_range_word_of(dy, (size_t)B * 2 * H * 2 * W * Cout, dy_amax, stream);
   if (p.g_amax == nullptr) return odin_fail(-3, "bwd_planes: no range word for dy");
   p.a_amax = x_amax;
   p.out_amax = dx_amax;

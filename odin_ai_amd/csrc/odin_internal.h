@@ -83,8 +83,8 @@ int odin_dense_h_wgrad(const float* x, const float* dy, float* slab, int B, int 
 bool odin_bwd_planes_applicable(int B, int H, int W, int Cin, int Cout);
 int odin_bwd_planes_rows(int B, int H, int W, int Cin);
 int odin_bwd_planes_launch(const float* x, const float* dy, const float* w, const float* aux, float* dx, float* colsum,
-                           float* wslab, int B, int H, int W, int Cin, const uint32_t* dy_amax, const uint32_t* x_amax,
-                           uint32_t* dx_amax, void* stream);
+                           float* wslab, int B, int H, int W, int Cin, int Cout, const uint32_t* dy_amax,
+                           const uint32_t* x_amax, uint32_t* dx_amax, void* stream);
 bool odin_smalldeconv_applicable(const odin_conv_desc* d);
 int odin_smalldeconv_rows(const odin_conv_desc* d);
 int odin_smalldeconv_fwd(const float* x, const float* w, const float* bias, float* y, const odin_conv_desc* d,

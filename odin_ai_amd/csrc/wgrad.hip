@@ -1369,18 +1369,23 @@ extern "C" int odin_deconv2d_bwd(const float* x, const float* dy, const float* w
     if (colsum_rows_out) *colsum_rows_out = 0;
     return odin_smalldeconv_bwd(x, dy, w, aux, aux_act, dx, wslab, wslab_rows_out, d, stream);
   }
-  if (dx != nullptr && wslab != nullptr && aux != nullptr && aux_act == ODIN_ACT_ELU && d->KH == 4 && d->KW == 4 &&
-      d->stride == 2 && d->pad_t == 1 && d->pad_l == 1 && d->OH == 2 * d->H && d->OW == 2 * d->W &&
+  // (a dry run -- dx == NULL and wslab == NULL -- reports the rows of the ONE-call form: with 64 output channels the
+  // fused launch writes more slab rows than odin_deconv2d_wgrad alone; callers size their slab for both)
+  const bool dry = dx == nullptr && wslab == nullptr;
+  if (((dx != nullptr && wslab != nullptr && aux != nullptr) || dry) && aux_act == ODIN_ACT_ELU && d->KH == 4 &&
+      d->KW == 4 && d->stride == 2 && d->pad_t == 1 && d->pad_l == 1 && d->OH == 2 * d->H && d->OW == 2 * d->W &&
       odin_bwd_planes_applicable(d->B, d->H, d->W, d->Cin, d->Cout) &&
       odin_wgrad_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t,
                                    d->pad_l, 0) &&
       odin_fconv_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t,
                                    d->pad_l, 0)) {
-    // dy is fetched, scaled and split ONCE for both gradients (bwd_planes.hip); same partial sums as the two launches
+    // dy is fetched, scaled and split ONCE for both gradients (bwd_planes.hip); with 32 output channels the same
+    // partial sums as the two launches
     const int rows = odin_bwd_planes_rows(d->B, d->H, d->W, d->Cin);
     if (colsum_rows_out) *colsum_rows_out = rows;
     if (wslab_rows_out) *wslab_rows_out = rows;
-    return odin_bwd_planes_launch(x, dy, w, aux, dx, colsum_slab, wslab, d->B, d->H, d->W, d->Cin, d->dy_amax,
+    if (dry) return 0;
+    return odin_bwd_planes_launch(x, dy, w, aux, dx, colsum_slab, wslab, d->B, d->H, d->W, d->Cin, d->Cout, d->dy_amax,
                                   d->x_amax, d->dx_amax, stream);
   }
   odin_igemm_pair_begin();

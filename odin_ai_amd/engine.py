@@ -276,6 +276,12 @@ class NetProgram:
         n = r.w_n + r.b_n
       elif r.kind == 'deconv':
         lib.odin_deconv2d_wgrad(None, None, None, C.byref(rows), C.byref(d), None)
+        # (the one-call backward may write more rows than the weight gradient alone: bwd_planes.hip with 64 output
+        # channels -- include/odin_hip.h: odin_deconv2d_bwd, dry run)
+        r1, r2 = C.c_int(0), C.c_int(0)
+        lib.odin_deconv2d_bwd(None, None, None, None, ACT[self.recs[i - 1].act] if i > 0 else 0, None, None, C.byref(r2),
+                              None, C.byref(r1), C.byref(d), None)
+        rows.value = max(rows.value, r1.value)
         n = r.w_n
       else:
         lib.odin_dense_wgrad(None, None, None, C.byref(rows), B, r.K, r.N, None)
@@ -375,7 +381,7 @@ class NetProgram:
         lib.odin_dense_bwd_ranged(xin.data_ptr(), g.data_ptr(), None, None, 0, None, None, None, slab.data_ptr(),
                                   C.byref(wrows), B, r.K, r.N, 1, 0, self.dy_word[i], None, self.x_word[i], wst)
       if not data_only:
-        assert wrows.value == self.wrows[i]
+        assert 0 < wrows.value <= self.wrows[i]
         n_red = slab.shape[1]
         if skip_bias_of_last and i == n - 1 and r.kind != 'deconv':
           n_red = r.w_n  # the fused tail already delivers this layer's bias gradient
