@@ -158,17 +158,31 @@ def profile_ops(eng, reps=20):
           dst, aux = prog.gouts[i - 1], prog.outs[i - 1]
           f_dg = lambda: lib.odin_dense_dgrad(g.data_ptr(), w.data_ptr(), aux.data_ptr(), ACT[prog.recs[i - 1].act], dst.data_ptr(), None, None, B, r.K, r.N, st)
       ops = [('fwd', f_fwd), ('wgrad', f_wg), ('dgrad', f_dg)]
+      if r.kind == 'deconv' and i > 0:
+        # the step back-propagates a Conv2DTranspose through ONE call; where that is one launch (bwd_planes.hip: dy
+        # fetched and split once for both gradients) the pair is timed -- and priced -- as the launch it is
+        dst, aux = prog.gouts[i - 1], prog.outs[i - 1]
+        bsl = prog.bslabs[i - 1]
+        wrows = C.c_int(0)
+        f_bw = lambda: lib.odin_deconv2d_bwd(xin.data_ptr(), g.data_ptr(), w.data_ptr(), aux.data_ptr(),
+                                             ACT[prog.recs[i - 1].act], dst.data_ptr(),
+                                             bsl.data_ptr() if bsl is not None else None, C.byref(rows),
+                                             prog.wslabs[i].data_ptr(), C.byref(wrows), C.byref(d), st)
+        f_bw()
+        if lib.odin_debug_last_path().decode().startswith('bwd_planes'):
+          ops = [('fwd', f_fwd), ('bwd', f_bw)]
       if in_tail:
         # inside the training step these launches are replaced by the fused tail kernel
-        ops = [] if i == nd - 1 else [('wgrad', f_wg), ('dgrad', f_dg)]
+        ops = [] if i == nd - 1 else [o for o in ops if o[0] != 'fwd']
       if head and net == 'dec' and i == nd - 1:
         ops = []  # (replaced by odin_gaussian_head_fwd_bwd, timed below)
       for tag, fn in ops:
         if fn is None:
           continue
         t = timeit(fn)
-        out.append(dict(layer=f'{net}{i}:{r.kind}', op=tag, us=t * 1e6, gflop=fl * 1e-9,
-                        tflops=fl / t * 1e-12, path=lib.odin_debug_last_path().decode()))
+        flo = 2 * fl if tag == 'bwd' else fl   # (weight + data gradient)
+        out.append(dict(layer=f'{net}{i}:{r.kind}', op=tag, us=t * 1e6, gflop=flo * 1e-9,
+                        tflops=flo / t * 1e-12, path=lib.odin_debug_last_path().decode()))
   if fused:
     a, bb = eng.dec.recs[-2], eng.dec.recs[-1]
     h = eng.z if nd == 2 else eng.dec.outs[nd - 3]
@@ -592,6 +606,10 @@ def main():
     os.environ['ODIN_DP_BUCKETS'] = str(args.dp_buckets)
   from odin_ai_amd.engine import VAEEngine
   from odin_ai_amd.networks import get_networks
+  if os.environ.get('ODIN_BENCH_IH_MIN_GF'):
+    # diagnostics: the launch size from which convolutions run on the two-plane implicit-GEMM kernels (igemm_h.hip)
+    from odin_ai_amd import _lib as _L
+    _L.load().odin_debug_igemm_h_min_flop(float(os.environ['ODIN_BENCH_IH_MIN_GF']) * 1e9)
   ds, kw, B, beta, kind = WORKLOADS[args.workload]
   nets = get_networks(ds, **kw)
   enc, dec = nets['encoder'].layers, nets['decoder'].layers

@@ -119,7 +119,13 @@ int odin_deconv2d_wgrad(const float* x, const float* dy, float* slab, int* slab_
  * colsum_slab as in *_dgrad; same argument meaning, same results bit for bit).  Where both halves run on the
  * small-layer implicit-GEMM kernels they share one launch -- each alone is a latency-bound launch of a few hundred
  * workgroups -- otherwise the call is the two calls above.  Replaces the tape.gradient of one layer
- * (odin/networks/base_networks.py:514-518). */
+ * (odin/networks/base_networks.py:514-518).
+ * Round 5: a Conv2DTranspose(k4, s2) over 32 or 64 output channels whose rows are 8 / 16 / 32 pixels wide back-propagates
+ * in ONE launch that fetches, scales and splits dy once for both gradients (bwd_planes.hip; needs aux_act = ELU).  With
+ * 32 output channels the results are still bit-identical to the two calls; with 64 the weight-gradient slab is
+ * partitioned like the data gradient's tiles (equal to rounding) and has MORE rows than odin_deconv2d_wgrad reports: a
+ * dry run of odin_deconv2d_bwd (every pointer NULL, aux_act as it will be passed) reports the rows of the one-call
+ * form -- size the slab for the larger of the two. */
 int odin_conv2d_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
                     float* colsum_slab, int* colsum_rows_out, float* wslab, int* wslab_rows_out,
                     const odin_conv_desc* d, void* stream);

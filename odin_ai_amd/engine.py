@@ -572,7 +572,6 @@ class VAEEngine:
       self._ring = [t.pin_memory() for t in self._ring]
     self._ring_i = 0
     self.hyper = torch.zeros(N_HYPER + 4, **f32)
-    self._skip_hyper_copy = __import__('os').environ.get('ODIN_SKIP_HYPER_COPY', '0') == '1'
     # Device-resident schedule (round 5): the rows of the coming steps in a device ring, loaded into `hyper` by the
     # step's last kernel (include/odin_hip.h: odin_sumsq_adam_ring) -- no per-step host copy while the caller's
     # (lr, beta, ...) follow the prediction (constant values, or the `schedule` callable of train_step); any other
@@ -773,8 +772,6 @@ class VAEEngine:
                    skip_enable=skip_enable, extra=extra, capacity=capacity)
     # (leaving this 80-byte copy out of the steady state was measured in round 4 at 0.72 ms per step: no difference;
     # at 0.52 ms it is worth 7-8 us -- profiles/r05_hyper_ring.txt -- hence the device ring of train_step)
-    if self._skip_hyper_copy and self.step_count > 60:
-      return  # (diagnostics, ODIN_SKIP_HYPER_COPY=1: what the 80-byte copy costs between two step graphs)
     self.hyper.copy_(h, non_blocking=True)
     if self.device.type == 'cuda':
       ev = torch.cuda.Event()

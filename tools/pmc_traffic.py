@@ -28,14 +28,11 @@ fetch, write = read(f'gpurun_out/{TAG}_pmc_FETCH_SIZE.txt'), read(f'gpurun_out/{
 f4 = 4
 kernels = {
     # bench op name: (kernel-name prefix, grid, description, algorithmic bytes)
-    'dec4:deconv:wgrad': ('wgrad_planes_kernel<32, true', '131072',
-                          'weight gradient of the last Conv2DTranspose (wgrad_planes, both operands as 2 f16 planes), dSprites B=256',
-                          # x [B,32,32,32] + dY [B,64,64,32] read once, slabs [256 rows][16*32*32] written
-                          (B * 32 * 32 * 32 + B * 64 * 64 * 32) * f4 + 256 * 16 * 32 * 32 * f4),
-    'dec4:deconv:dgrad': ('fconv_planes_kernel<2, 32, false, 1', '131072',
-                          'data gradient of the last Conv2DTranspose (fconv_planes, fp32 operands as 2 f16 planes)',
-                          # dY [B,64,64,32] + aux [B,32,32,32] read, dx [B,32,32,32] written
-                          (B * 64 * 64 * 32 + 2 * B * 32 * 32 * 32) * f4),
+    'dec4:deconv:bwd': ('bwd_planes_kernel<32, 2, 0', '131072',
+                        'weight + data gradient of the last Conv2DTranspose in one launch (bwd_planes: dy fetched and split once), dSprites B=256',
+                        # dY [B,64,64,32] + x [B,32,32,32] read (aux IS x in the step: one tensor), dx [B,32,32,32] + slabs
+                        # [256 rows][16*32*32] written
+                        (B * 64 * 64 * 32 + 2 * B * 32 * 32 * 32) * f4 + 256 * 16 * 32 * 32 * f4),
     'dec4+5:tail:fwd+elbo': ('tconv_planes_kernel<3, 1, 32, 0, false, 2', '131072',
                              'fused decoder tail (tconv_planes, fp32 operands as 2 f16 planes)',
                              # x [B,32,32,32] + target [B,64,64,1] read; logits + d(pre-activation) [B,64,64,32] written
@@ -44,10 +41,11 @@ kernels = {
                       'encoder3 forward (igemm: implicit GEMM, both operands straight from L2, fp32 MFMA)',
                       # x [B,8,8,64] read + y [B,4,4,64] written + weights 16*64*64
                       (B * 8 * 8 * 64 + B * 4 * 4 * 64 + 16 * 64 * 64) * f4),
-    'dec2:deconv:dgrad': ('fconv_planes2_kernel<2, 8, 1', '131072',
-                          'data gradient of decoder2: both 32-channel reduction passes in one launch (fconv_planes, fp32 operands as 2 f16 planes)',
-                          # dY [B,16,16,64] read; partial sums written and read back, aux read, dx written: [B,8,8,64] each
-                          (B * 16 * 16 * 64 + 4 * B * 8 * 8 * 64) * f4),
+    'dec2:deconv:bwd': ('bwd_planes2_kernel<8, 2', '131072',
+                        'weight + data gradient of decoder2 (64 -> 64 channels, 8x8 -> 16x16): both 32-channel passes in one launch (bwd_planes)',
+                        # dY [B,16,16,64] + x [B,8,8,64] read (twice: once per pass; aux IS x); partial sums written and read back,
+                        # dx written: [B,8,8,64] each; slabs [128 rows][16*64*64]
+                        (B * 16 * 16 * 64 + 5 * B * 8 * 8 * 64) * f4 + 128 * 16 * 64 * 64 * f4),
 }
 
 
