@@ -615,6 +615,494 @@ __device__ __forceinline__ void bp_body(const BPParams& p) {
   }
 }
 
+// ---- producer / consumer form (round 5): 12 waves.  Waves 0-7 are the MFMA waves of bp_body (same tap ownership, same
+// MFMA sequences, same results) and do NOTHING else: transposed / plain LDS reads, 24 MFMAs per tile, the partial data
+// gradient tile -> LDS.  Waves 8-11 (one per SIMD, beside two MFMA waves) own everything with vector-ALU or memory
+// work in it: the global loads of the row fills, split + LDS stores, the finish pass of the previous tile (sum of the
+// eight partial tiles, ELU', column sums, range word, store of dx).  Why: in bp_body the matrix pipe's own time of a
+// tile ADDS to everything else (profiles/r05_bwd_planes_ablations.txt) -- a wave's MFMAs overlap with the VALU
+// instructions between them but not with its waits, and every wave had both kinds of work; a VALU-only partner wave
+// runs at full speed beside an MFMA stream.  168 registers per wave (3 waves per SIMD).
+template <int W, int PASS = 0>
+__device__ __forceinline__ void bp_pc_body(const BPParams& p) {
+  constexpr int NPL = 2;
+  constexpr int TC = 32 / W;
+  constexpr int WU = 2 * W;
+  constexpr int SU = W + 1;
+  constexpr int PARB = (SU + 1) * 64;
+  constexpr int PBU = 2 * PARB;
+  constexpr int RBU = NPL * PBU;
+  constexpr int NSU = 4 * TC + 3;
+  constexpr int PBV = W * 64;
+  constexpr int RBV = NPL * PBV;
+  constexpr int NSV = 2 * TC;
+  constexpr int IPU = WU / 8;
+  constexpr int IPV = W / 8;
+  constexpr int RJ = 8 / IPU > 0 ? 8 / IPU : 1;
+  constexpr int RED = 8 * 8 * 64 * 8;
+  constexpr int NT = 768;
+  constexpr int NPU = 8;                 // fine-row items of a producer wave per fill: item j = linear item 4 j + pw
+  ODIN_DYN_SMEM(char, smem);
+  char* uring = smem;
+  char* vring = smem + NSU * RBU;
+  char* red = vring + NSV * RBV;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const OdinRangeReq g_rq = odin_range_issue(p.g_amax, lane), a_rq = odin_range_issue(p.a_amax, lane);
+#ifdef ODIN_SIM
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const bool producer = wave >= 8;
+  const int pw = wave & 3;               // producer index (waves 8-11)
+  const int l31 = lane & 31, half = lane >> 5, l16 = lane & 15;
+  const int cv0 = blockIdx.y * 32;
+  const int HU = 2 * p.h, HPU = HU + 1;
+  const int T0 = blockIdx.x * p.tiles_per_wg;
+  int T1 = T0 + p.tiles_per_wg;
+  if (T1 > p.n_tiles) T1 = p.n_tiles;
+  if (T0 >= T1) return;
+
+  constexpr int RPF = BP_MAXU * RJ;           // fine rows a fill can carry
+  constexpr int DST_NONE = -(1 << 24);
+  constexpr unsigned OFF_NONE = 0x7FFF0000u;
+  const int NF = p.tiles_per_wg + 3;
+  BpEnt* tt = reinterpret_cast<BpEnt*>(red + 2 * RED);  // [NF] tile: (first fine ring slot, byte offset of its first output)
+  BpEnt* tr = tt + NF;                                 // [NF][RPF] fine row: (LDS byte offset, global byte offset)
+  BpEnt* tv = tr + NF * RPF;                           // [NF][TC] coarse row: the same
+  const unsigned u_rowbytes = (unsigned)(WU * p.CUt * 4), v_rowbytes = (unsigned)(W * p.CVt * 4);
+  const int n_vrows = p.B * p.h;
+
+  // ---- producers: lane constants of their items; the loads of fill 0 go out first ----
+  const OdinRun RU = odin_run(p.U, (unsigned)((size_t)p.B * HU * WU * p.CUt * 4));
+  const OdinRun RV = odin_run(p.V, (unsigned)((size_t)p.B * p.h * W * p.CVt * 4));
+  const int ch4 = lane & 7, pxl = lane >> 3;
+  // item j of producer pw: linear item L = 4 j + pw of the fill -> fill row L / IPU, column block L % IPU
+  int u_lds[NPU];
+  unsigned u_g[NPU];
+#pragma unroll
+  for (int j = 0; j < NPU; ++j) {
+    const int L = 4 * j + pw, cb = L % IPU;
+    const int pcw = 8 * cb + pxl + 1;
+    u_lds[j] = (pcw & 1) * PARB + bp_uoff(pcw >> 1, 4 * ch4);
+    u_g[j] = (unsigned)(((8 * cb + pxl) * p.CUt + p.cu_off + 4 * ch4) * 4);
+  }
+  const int vr = pw / IPV, vc = pw - vr * IPV;
+  const unsigned v_g = (unsigned)(((8 * vc + pxl) * p.CVt + cv0 + 4 * ch4) * 4);
+  const int v_lds = NSU * RBU + (8 * vc + pxl) * 64 + ch4 * 8;
+  BpItem iu[2][NPU], iv[2];   // (three sets -- loads two tiles ahead of their LDS stores -- change nothing: 66.7 vs 63.6 us)
+  if (producer) {
+    const int tpi = p.tiles_per_img;
+    const int b0 = odin_div_small(T0, tpi), t0 = T0 - b0 * tpi;
+    const int start = HPU * b0 + 2 * TC * t0;
+#pragma unroll
+    for (int j = 0; j < NPU; ++j) {
+      const int r = (4 * j + pw) / IPU, G = start + r;
+      const bool valid = r < 2 * TC + 2;
+      const int b = b0 + (2 * TC * t0 + r >= HPU ? 1 : 0), gi = G - b * HPU;
+      const bool real = valid && gi != 0 && b < p.B;
+      iu[0][j].dst = bp_uniform(valid ? (G - odin_div_small(G, NSU) * NSU) * RBU : DST_NONE);
+      iu[0][j].v = odin_run_load4(RU, real ? (unsigned)(G - b - 1) * u_rowbytes + u_g[j] : ODIN_OOB);
+    }
+    const int grow = TC * T0 + vr;
+    iv[0].dst = bp_uniform((grow & (NSV - 1)) * RBV);
+    iv[0].v = odin_run_load4(RV, grow < n_vrows ? (unsigned)grow * v_rowbytes + v_g : ODIN_OOB);
+  }
+  // ---- MFMA waves: the weight fragments of the data gradient ----
+  const int kh = (wave & 7) >> 1, kw0 = 2 * (wave & 1), kws = kw0 >> 1;
+  float wv[2][2][8];
+  if (!producer) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int tap = kh * 4 + kw0 + t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          wv[t][kk][e] = p.w[((size_t)(tap * p.CUt + p.cu_off + 16 * kk + 8 * half + e)) * p.CVt + cv0 + l31];
+      }
+  }
+  ODIN_SCHED_FENCE();
+
+  // ---- all threads: pads, the zeroed partial-tile buffer of "tile T0 - 1", the fill tables ----
+  for (int e = tid; e < NSU * 8 * NPL; e += NT) {
+    const int sl = e / (8 * NPL), rem = e - sl * (8 * NPL);
+    const int pl = rem >> 3, side = (rem >> 2) & 1, piece = rem & 3;
+    *reinterpret_cast<float4*>(uring + sl * RBU + pl * PBU + (side ? PARB + W * 64 : 0) + piece * 16) =
+        make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int e = tid; e < RED / 16; e += NT)
+    *reinterpret_cast<float4*>(red + ((T0 - 1) & 1) * RED + e * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const int tpi = p.tiles_per_img;
+    for (int e = tid; e < NF; e += NT) {
+      const int T = T0 + e, b = odin_div_small(T, tpi), t = T - b * tpi;
+      const int g0 = HPU * b + 2 * TC * t;
+      tt[e] = BpEnt{g0 - odin_div_small(g0, NSU) * NSU, (int)(((size_t)(b * p.h + TC * t) * W) * p.CVt * 4)};
+    }
+    for (int e = tid; e < NF * RPF; e += NT) {
+      const int f = e / RPF, r = e - f * RPF;
+      const int T = T0 + f, b1 = odin_div_small(T, tpi), t1 = T - b1 * tpi;
+      const int end = HPU * b1 + 2 * TC * t1 + 2 * TC + 2;
+      int start = end - (2 * TC + 2);
+      if (f > 0) {
+        const int b0 = t1 > 0 ? b1 : b1 - 1, t0 = t1 > 0 ? t1 - 1 : tpi - 1;
+        start = HPU * b0 + 2 * TC * t0 + 2 * TC + 2;
+      }
+      const int G = start + r;
+      const bool valid = T < T1 && G < end;
+      const int b = odin_div_small(G, HPU), gi = G - b * HPU;
+      const bool real = valid && gi != 0 && b < p.B;
+      tr[e] = BpEnt{valid ? (G - odin_div_small(G, NSU) * NSU) * RBU : DST_NONE,
+                    real ? (int)((unsigned)(G - b - 1) * u_rowbytes) : (int)OFF_NONE};
+    }
+    for (int e = tid; e < NF * TC; e += NT) {
+      const int f = e / TC, q = e - f * TC;
+      const int T = T0 + f, grow = TC * T + q;
+      const bool valid = T < T1;
+      tv[e] = BpEnt{valid ? (grow & (NSV - 1)) * RBV : DST_NONE,
+                    valid && grow < n_vrows ? (int)((unsigned)grow * v_rowbytes) : (int)OFF_NONE};
+    }
+  }
+
+  // scales (both roles: the producers split with them, the MFMA waves scale their sums back)
+  int gk = 0, ak = 0;
+  bool as = false;
+  float g_s = 1.f, g_s2k = ODIN_LO_SCALE, a_s = 1.f, a_s2k = ODIN_LO_SCALE, out_s = 1.f;
+  {
+    gk = odin_range_shift(odin_range_finish(g_rq));
+    g_s = odin_pow2(gk); g_s2k = odin_pow2(gk + 11); out_s = odin_pow2(-gk);
+    const unsigned a_mb = p.a_amax != nullptr ? odin_range_finish(a_rq) : 0u;
+    as = odin_act_needs_scale(a_mb);
+    ak = as ? odin_range_shift(a_mb) : 0;
+    a_s = odin_pow2(ak); a_s2k = odin_pow2(ak + 11);
+  }
+  auto store_u = [&](const BpItem& it, int lds_lane) {
+#ifdef ODIN_SIM
+    if (it.dst < 0) return;
+#else
+    if (__builtin_amdgcn_readfirstlane(it.dst) < 0) return;  // wave-uniform: a scalar branch
+#endif
+    u32x2 h, l;
+    odin_split_h4<true>(it.v, g_s, g_s2k, h, l);
+    char* d = smem + (it.dst + lds_lane);
+    *reinterpret_cast<u32x2*>(d) = h;
+    *reinterpret_cast<u32x2*>(d + PBU) = l;
+  };
+  auto store_v = [&](const BpItem& it) {
+#ifdef ODIN_SIM
+    if (it.dst < 0) return;
+#else
+    if (__builtin_amdgcn_readfirstlane(it.dst) < 0) return;
+#endif
+    u32x2 h, l;
+    if (as) odin_split_h4<true>(it.v, a_s, a_s2k, h, l);
+    else odin_split_h4<false>(it.v, 1.f, ODIN_LO_SCALE, h, l);
+    char* d = smem + (it.dst + v_lds);
+    *reinterpret_cast<u32x2*>(d) = h;
+    *reinterpret_cast<u32x2*>(d + PBV) = l;
+  };
+  if (producer) {
+#pragma unroll
+    for (int j = 0; j < NPU; ++j) store_u(iu[0][j], u_lds[j]);
+    store_v(iv[0]);
+  }
+  __syncthreads();   // pads, tables and the first tile's rows are in LDS
+
+  if (producer) {
+    // =========================== producer waves ===========================
+    struct FillEnt { BpEnt u[NPU]; BpEnt v; };
+    auto fill_entries = [&](FillEnt& en, int f) {
+#pragma unroll
+      for (int j = 0; j < NPU; ++j) {
+        const BpEnt e = tr[f * RPF + (4 * j + pw) / IPU];
+        en.u[j] = BpEnt{bp_uniform(e.x), bp_uniform(e.y)};
+      }
+      const BpEnt e = tv[f * TC + vr];
+      en.v = BpEnt{bp_uniform(e.x), bp_uniform(e.y)};
+    };
+    auto fill_loads = [&](BpItem (&u)[NPU], BpItem& v, const FillEnt& en) {
+#pragma unroll
+      for (int j = 0; j < NPU; ++j) {
+        u[j].dst = en.u[j].x;
+        u[j].v = odin_run_load4(RU, (unsigned)en.u[j].y + u_g[j]);
+      }
+      v.dst = en.v.x;
+      v.v = odin_run_load4(RV, (unsigned)en.v.y + v_g);
+    };
+    // finish pass: this wave owns the accumulator register pairs 2 pw, 2 pw + 1 of every tile
+    const int orow = (W == 32) ? 0 : (W == 16) ? (l31 >> 4) : (l31 >> 3);
+    const int ocol = (W == 32) ? l31 : (W == 16) ? (l31 & 15) : (l31 & 7);
+    int c0[2];
+    unsigned o_lane[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int pr = 2 * pw + k;
+      c0[k] = cv0 + ((2 * pr) & 3) + 8 * ((2 * pr) >> 2) + 4 * half;
+      o_lane[k] = (unsigned)(((orow * W + ocol) * p.CVt + c0[k]) * 4);
+    }
+    const unsigned out_bytes = (unsigned)((size_t)p.B * p.h * W * p.CVt * 4);
+    const OdinRun RO = odin_run(p.dx, out_bytes);
+    const OdinRun RX = odin_run(p.aux, out_bytes);
+    float csum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float amx = 0.f;
+    unsigned tileoffP = ODIN_OOB;   // (the first tile's pass has no predecessor: its stores are out of range)
+    float2 auxP[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)}, pvP[2] = {auxP[0], auxP[0]};
+    auto finish = [&](int buf) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int pr = 2 * pw + k;
+        const char* q = red + buf * RED + ((pr * 8 * 64 + lane) << 3);
+        float2 q8[8];
+#pragma unroll
+        for (int wvv = 0; wvv < 8; ++wvv) q8[wvv] = *reinterpret_cast<const float2*>(q + wvv * (64 * 8));
+        float2 s2 = q8[0];
+#pragma unroll
+        for (int wvv = 1; wvv < 8; ++wvv) { s2.x += q8[wvv].x; s2.y += q8[wvv].y; }
+        float v[2] = {s2.x * out_s, s2.y * out_s};
+        if (PASS == 2) { v[0] += pvP[k].x; v[1] += pvP[k].y; }
+        if (PASS != 1) {
+          v[0] = fmaf(v[0], fminf(auxP[k].x, 0.f), v[0]);  // x ELU'(aux) = 1 + min(aux, 0)
+          v[1] = fmaf(v[1], fminf(auxP[k].y, 0.f), v[1]);
+          csum[k][0] += v[0];
+          csum[k][1] += v[1];
+          amx = odin_amax3(amx, v[0], v[1]);
+        }
+        odin_run_store2(RO, tileoffP == ODIN_OOB ? ODIN_OOB : tileoffP + o_lane[k], make_float2(v[0], v[1]));
+      }
+    };
+    FillEnt en;
+    {
+      FillEnt e1;
+      fill_entries(e1, 1);
+      fill_entries(en, 2);
+      fill_loads(iu[1], iv[1], e1);
+    }
+    // (set 1 holds fill 1 = the rows of tile T0 + 1, stored during tile T0; set 0 receives fill 2 during tile T0)
+    auto tile = [&](int T, BpItem (&ldu)[NPU], BpItem& ldv, const BpItem (&stu)[NPU], const BpItem& stv) {
+      const BpEnt th = tt[T - T0];
+      fill_loads(ldu, ldv, en);        // fill T - T0 + 2
+      float2 auxN[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)}, pvN[2] = {auxN[0], auxN[0]};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (PASS != 1) auxN[k] = odin_run_load2(RX, (unsigned)th.y + o_lane[k]);
+        if (PASS == 2) pvN[k] = odin_run_load2(RO, (unsigned)th.y + o_lane[k]);
+      }
+      finish((T - 1) & 1);             // tile T - 1: its partials are complete behind the last barrier
+      fill_entries(en, T - T0 + 3);
+#pragma unroll
+      for (int j = 0; j < NPU; ++j) store_u(stu[j], u_lds[j]);   // rows of tile T + 1
+      store_v(stv);
+      tileoffP = (unsigned)th.y;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { auxP[k] = auxN[k]; pvP[k] = pvN[k]; }
+      __syncthreads();
+    };
+#pragma unroll 1
+    for (int T = T0; T < T1; T += 2) {
+      tile(T, iu[0], iv[0], iu[1], iv[1]);
+      if (T + 1 < T1) tile(T + 1, iu[1], iv[1], iu[0], iv[0]);
+    }
+    finish((T1 - 1) & 1);
+    if (PASS == 1) return;
+    __syncthreads();  // (pairs with the MFMA waves' barrier below: the partial-tile scratch is free)
+    odin_amax_commit_wg(p.out_amax, amx, tid, NT, reinterpret_cast<float*>(red), blockIdx.x + gridDim.x * blockIdx.y);
+    if (p.colsum != nullptr) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float v = csum[k][c];
+#pragma unroll
+          for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+          if (l31 == 0) p.colsum[(size_t)blockIdx.x * p.CVt + c0[k] + c] = v;
+        }
+    }
+    return;
+  }
+
+  // =========================== MFMA waves (0-7) ===========================
+  const int q4 = l16 >> 2, g16 = (lane >> 4) & 1;
+  int krow[2], kcol[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    const int kpix = 8 * half + 4 * blk + q4;
+    krow[blk] = (W >= 16) ? 0 : (kpix >> 3);
+    kcol[blk] = (W >= 16) ? kpix : (kpix & 7);
+  }
+  const int colb = (16 * g16 + 4 * (l16 & 3)) * 2;
+  constexpr int NCH = (W == 32) ? 2 : 1;
+  int uoff[NCH][2];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) uoff[c][blk] = bp_uoff(16 * c + kcol[blk] + kws, 16 * g16 + 4 * (l16 & 3));
+  const int orow = (W == 32) ? 0 : (W == 16) ? (l31 >> 4) : (l31 >> 3);
+  const int ocol = (W == 32) ? l31 : (W == 16) ? (l31 & 15) : (l31 & 7);
+  int boff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) boff[kk] = bp_uoff(ocol + kws, 8 * (2 * kk + half));
+  u32x4 wf[2][2][NPL];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const float(&v)[8] = wv[t][kk];
+      u32x2 h0, l0, h1, l1;
+      odin_split_h4<false>(make_float4(v[0], v[1], v[2], v[3]), 1.f, ODIN_LO_SCALE, h0, l0);
+      odin_split_h4<false>(make_float4(v[4], v[5], v[6], v[7]), 1.f, ODIN_LO_SCALE, h1, l1);
+      wf[t][kk][0][0] = h0.x; wf[t][kk][0][1] = h0.y; wf[t][kk][0][2] = h1.x; wf[t][kk][0][3] = h1.y;
+      wf[t][kk][1][0] = l0.x; wf[t][kk][1][1] = l0.y; wf[t][kk][1][2] = l1.x; wf[t][kk][1][3] = l1.y;
+    }
+  f32x16 wacc[2] = {f32x16_zero(), f32x16_zero()};
+  f32x16 wacx[2] = {f32x16_zero(), f32x16_zero()};
+  int su0 = 0, sv0 = 0;
+  struct Frags { u32x4 fv[NPL]; u32x4 fu[2][NPL]; };
+  auto read_chunk = [&](int c, Frags& F) {
+    const int row0 = (W == 32) ? 0 : (W == 16) ? c : 2 * c;
+    const int j0 = (W == 32) ? 16 * c : 0;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      int sv = sv0 + row0 + krow[blk];
+      if (sv >= NSV) sv -= NSV;
+      int su = su0 + 2 * (row0 + krow[blk]) + kh;
+      if (su >= NSU) su -= NSU;
+      const char* vb = vring + sv * RBV + (j0 + kcol[blk] - q4) * 64 + colb - (l16 & 3) * 8;
+      const char* ub = uring + su * RBU;
+      const int uo = uoff[W == 32 ? c : 0][blk];
+      const int slot0 = j0 + kcol[blk] - q4 + kws;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const u32x2 tvv = bp_tr_read_v(vb + pl * PBV, l16);
+        F.fv[pl][2 * blk] = tvv.x; F.fv[pl][2 * blk + 1] = tvv.y;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const u32x2 tu = bp_tr_read_u(ub + pl * PBU + t * PARB, slot0, g16, l16, uo);
+          F.fu[t][pl][2 * blk] = tu.x; F.fu[t][pl][2 * blk + 1] = tu.y;
+        }
+      }
+    }
+  };
+  auto mfma_chunk = [&](const Frags& F) {
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      const int t = m & 1, pp = m >> 1;
+      if (pp == 0) wacx[t] = mfma32_f16(F.fu[t][0], F.fv[1], wacx[t]);
+      if (pp == 1) wacx[t] = mfma32_f16(F.fu[t][1], F.fv[0], wacx[t]);
+      if (pp == 2) wacc[t] = mfma32_f16(F.fu[t][0], F.fv[0], wacc[t]);
+    }
+  };
+  auto dgrad_frags = [&](u32x4 (&fb)[2][2][NPL]) {
+    int sud = su0 + 2 * orow + kh;
+    sud -= sud >= NSU ? NSU : 0;
+    const char* rowp = uring + sud * RBU;
+#pragma unroll
+    for (int pl = NPL - 1; pl >= 0; --pl)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          fb[t][kk][pl] = *reinterpret_cast<const u32x4*>(rowp + t * PARB + boff[kk] + pl * PBU);
+  };
+  auto dgrad_tile = [&](int T, const u32x4 (&fb)[2][2][NPL]) {
+    f32x16 acc = f32x16_zero(), acx = f32x16_zero();
+#pragma unroll
+    for (int m = 0; m < 12; ++m) {
+      const int t = (m >> 1) & 1, kk = m & 1, pp = m >> 2;
+      if (pp == 0) acx = mfma32_f16(wf[t][kk][0], fb[t][kk][1], acx);
+      if (pp == 1) acx = mfma32_f16(wf[t][kk][1], fb[t][kk][0], acx);
+      if (pp == 2) acc = mfma32_f16(wf[t][kk][0], fb[t][kk][0], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = fmaf(acx[r], ODIN_LO_UNSCALE, acc[r]);
+    char* d = red + (T & 1) * RED + (((wave & 7) * 64 + lane) << 3);
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr)
+      *reinterpret_cast<float2*>(d + pr * (8 * 64 * 8)) = make_float2(acc[2 * pr], acc[2 * pr + 1]);
+  };
+  Frags F0;
+  int suN = tt[0].x;
+  // (waves w and w + 4 share a SIMD: they run the tile's halves in opposite order, one's reads in the other's MFMAs)
+  const bool dfirst = wave >= 4;
+  auto tile = [&](auto dfirst_c, int T) {
+    constexpr bool df = decltype(dfirst_c)::value;
+    su0 = suN;
+    sv0 = (TC * T) & (NSV - 1);
+    suN = tt[T - T0 + 1].x;   // (read a tile ahead: no LDS round trip in front of the tile's first fragment reads)
+    if (!df) {
+      Frags F1;
+      read_chunk(0, F0);
+      read_chunk(1, F1);
+      ODIN_SCHED_FENCE();
+      mfma_chunk(F0);
+      ODIN_SCHED_FENCE();
+      mfma_chunk(F1);
+      ODIN_SCHED_FENCE();
+      u32x4 fb[2][2][NPL];
+      dgrad_frags(fb);
+      ODIN_SCHED_FENCE();
+      dgrad_tile(T, fb);
+    } else {
+      {
+        u32x4 fb[2][2][NPL];
+        dgrad_frags(fb);
+        ODIN_SCHED_FENCE();
+        dgrad_tile(T, fb);
+      }
+      ODIN_SCHED_FENCE();
+      Frags F1;
+      read_chunk(0, F0);
+      read_chunk(1, F1);
+      ODIN_SCHED_FENCE();
+      mfma_chunk(F0);
+      ODIN_SCHED_FENCE();
+      mfma_chunk(F1);
+    }
+    __syncthreads();
+  };
+  if (dfirst) {
+#pragma unroll 1
+    for (int T = T0; T < T1; ++T) tile(std::true_type{}, T);
+  } else {
+#pragma unroll 1
+    for (int T = T0; T < T1; ++T) tile(std::false_type{}, T);
+  }
+  // ---- this workgroup's slab row ----
+  float* row = p.slab + (size_t)blockIdx.x * p.slab_stride;
+  const float o_s = odin_pow2(-gk), o_sx = odin_pow2(-gk - 11), a_o = odin_pow2(-ak);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int tap = kh * 4 + kw0 + t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cu = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float v = fmaf(wacx[t][r], o_sx, wacc[t][r] * o_s);
+      row[((size_t)tap * p.CUt + p.cu_off + cu) * p.CVt + cv0 + l31] = v * a_o;
+    }
+  }
+  if (PASS == 1) return;
+  __syncthreads();
+  odin_amax_commit_wg(p.out_amax, 0.f, tid, NT, reinterpret_cast<float*>(red), blockIdx.x + gridDim.x * blockIdx.y);
+}
+
+template <int W>
+__global__ __launch_bounds__(768) void bwd_planes_pc_kernel(BPParams p) {
+  bp_pc_body<W, 0>(p);
+}
+
+template <int W>
+__global__ __launch_bounds__(768) void bwd_planes_pc2_kernel(BPParams p) {
+  p.cu_off = 0;
+  bp_pc_body<W, 1>(p);
+  odin_wait_vmem();
+#ifndef ODIN_SIM
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
+  __syncthreads();
+  p.cu_off = 32;
+  bp_pc_body<W, 2>(p);
+}
+
 template <int W, int NSETS, int DBG = 0>
 __global__ __launch_bounds__(512) void bwd_planes_kernel(BPParams p) {
   bp_body<W, NSETS, DBG>(p);
@@ -690,7 +1178,29 @@ int bp_launch2(const BPParams& p, dim3 grid, void* stream) {
   return odin_check_launch("bwd_planes(f16x2)");
 }
 template <int W>
+int bp_launch_pc(const BPParams& p, dim3 grid, void* stream) {
+  const size_t lds = (size_t)bp_ring_bytes(W) + (size_t)(p.tiles_per_wg + BP_NSETS + 1) * bp_fill_bytes(W);
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_planes_pc_kernel<W>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BP_LDS_MAX) != hipSuccess)
+      (void)hipGetLastError();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_planes_pc2_kernel<W>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BP_LDS_MAX) != hipSuccess)
+      (void)hipGetLastError();
+    attr_done = true;
+  }
+#endif
+  if (p.CUt == 64) ODIN_LAUNCH((bwd_planes_pc2_kernel<W>), grid, dim3(768), lds, stream, p);
+  else ODIN_LAUNCH((bwd_planes_pc_kernel<W>), grid, dim3(768), lds, stream, p);
+  return odin_check_launch("bwd_planes_pc(f16x2)");
+}
+template <int W>
 int bp_launch(const BPParams& p, dim3 grid, void* stream) {
+  // the producer / consumer form (12 waves) is the default; the 8-wave form it grew out of remains for A/Bs (diagnostics
+  // build: ODIN_BP_8WAVE) -- both give the same bits
+  if (!ODIN_DIAG_ENV("ODIN_BP_8WAVE")) return bp_launch_pc<W>(p, grid, stream);
   if (p.CUt == 64) return bp_launch2<W>(p, grid, stream);
 #if !defined(ODIN_SIM) && defined(ODIN_DIAG)
   // diagnostics build only (make diag): instances with parts of the tile switched off -- they compute WRONG results;

@@ -21,7 +21,7 @@ def timed(fn, n=REPS):
   return e0.elapsed_time(e1) / n * 1e3
 
 
-B, H, W = 256, 32, 32
+B, H, W = int(os.environ.get('KB_B', '256')), 32, 32
 d = _lib.conv_desc(B, H, W, 32, 2 * H, 2 * W, 32, 4, 2, 1, 1, 'elu')
 x = torch.randn(B, H, W, 32, device=dev); w = torch.randn(4, 4, 32, 32, device=dev) * 0.1
 b = torch.randn(32, device=dev) * 0.1
