@@ -58,17 +58,19 @@ if 'wgrad' in WHICH:
   print(f'dec4 wgrad: {timed(fn):.1f} us  [{L.odin_debug_last_path().decode()}]')
 if 'bwd' in WHICH or 'wgrad' in WHICH:
   # the same layer's two gradients in ONE launch (bwd_planes.hip: dy fetched and split once), and dec3's pair
-  for (hh, cin, name) in ((32, 32, 'dec4'), (16, 64, 'dec3')):
-    dd = _lib.conv_desc(B, hh, hh, cin, 2 * hh, 2 * hh, 32, 4, 2, 1, 1, 'elu')
-    xx = torch.randn(B, hh, hh, cin, device=dev); ww = torch.randn(4, 4, 32, cin, device=dev) * 0.1
-    gg = torch.randn(B, 2 * hh, 2 * hh, 32, device=dev); aux = torch.randn(B, hh, hh, cin, device=dev)
+  for (hh, cin, cout, name) in ((32, 32, 32, 'dec4'), (16, 64, 32, 'dec3'), (8, 64, 64, 'dec2')):
+    dd = _lib.conv_desc(B, hh, hh, cin, 2 * hh, 2 * hh, cout, 4, 2, 1, 1, 'elu')
+    xx = torch.randn(B, hh, hh, cin, device=dev); ww = torch.randn(4, 4, cout, cin, device=dev) * 0.1
+    gg = torch.randn(B, 2 * hh, 2 * hh, cout, device=dev); aux = torch.randn(B, hh, hh, cin, device=dev)
     L.odin_absmax(gg.data_ptr(), gg.numel(), words.data_ptr(), None)
     dd.dy_amax = words.data_ptr()
     dx = torch.empty(B, hh, hh, cin, device=dev)
     bs = torch.empty(L.odin_max_slab_rows() * 2, cin, device=dev)
     r1, r2 = C.c_int(0), C.c_int(0)
     L.odin_deconv2d_wgrad(None, None, None, C.byref(r1), C.byref(dd), None)
-    ws = torch.empty(max(r1.value, 1), 16 * 32 * cin, device=dev)
+    r3, r4 = C.c_int(0), C.c_int(0)
+    L.odin_deconv2d_bwd(None, None, None, None, 1, None, None, C.byref(r4), None, C.byref(r3), C.byref(dd), None)
+    ws = torch.empty(max(r1.value, r3.value, 1), 16 * cout * cin, device=dev)
     f2 = lambda: (L.odin_deconv2d_wgrad(xx.data_ptr(), gg.data_ptr(), ws.data_ptr(), C.byref(r1), C.byref(dd), None),
                   L.odin_deconv2d_dgrad(gg.data_ptr(), ww.data_ptr(), aux.data_ptr(), 1, dx.data_ptr(), bs.data_ptr(),
                                         C.byref(r2), C.byref(dd), None))

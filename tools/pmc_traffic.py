@@ -28,7 +28,7 @@ fetch, write = read(f'gpurun_out/{TAG}_pmc_FETCH_SIZE.txt'), read(f'gpurun_out/{
 f4 = 4
 kernels = {
     # bench op name: (kernel-name prefix, grid, description, algorithmic bytes)
-    'dec4:deconv:bwd': ('bwd_planes_kernel<32, 2, 0', '131072',
+    'dec4:deconv:bwd': ('bwd_planes_pc_kernel<32>', '196608',
                         'weight + data gradient of the last Conv2DTranspose in one launch (bwd_planes: dy fetched and split once), dSprites B=256',
                         # dY [B,64,64,32] + x [B,32,32,32] read (aux IS x in the step: one tensor), dx [B,32,32,32] + slabs
                         # [256 rows][16*32*32] written
