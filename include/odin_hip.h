@@ -394,6 +394,24 @@ int odin_sumsq_adam_ring(float* theta, const float* g, float* m, float* v, size_
                          float* out4, int B, const float* ring, float* cur, float* staged, int rows, int row_floats,
                          int t_word, void* stream);
 
+/* Round 5: the gradient norm's stage-1 launch rides in the slab reduction.  odin_slab_reduce_sumsq = odin_slab_reduce
+ * that also leaves sum(g^2) of what it writes as one partial per active workgroup in part[0 .. *n_parts_out): jobs whose
+ * dst lies inside [g, g + g_n) count -- the caller guarantees that they tile the flat gradient exactly once -- others
+ * (the range-word reset) do not.  stage_src / stage_dst (optional): stage_n <= 256 floats copied by the same launch
+ * (the step's hyper-parameter row: the Adam launch advances `hyper` while it still needs this step's scalars).
+ * part == NULL: dry run, only *n_parts_out (static for a given job list: capture-safe).
+ * odin_adam_ring_parts: norm from those partials, clip scale, NaN guard, Adam, the ring advance of
+ * odin_sumsq_adam_ring and (llk_part != NULL) the ELBO finalisation, in ONE launch; `staged` = the staged row,
+ * alpha_off / elbo_off = offsets of Adam's five scalars / of the ELBO weights in it.  Together they replace
+ * odin_slab_reduce + odin_sumsq_adam_ring (three launches -> two; base_networks.py:584-596). */
+int odin_slab_reduce_sumsq(const odin_reduce_job* jobs, int n_jobs, const float* g, size_t g_n, float* part,
+                           int* n_parts_out, const float* stage_src, float* stage_dst, int stage_n, void* stream);
+int odin_adam_ring_parts(float* theta, const float* g, float* m, float* v, size_t n, const float* staged,
+                         int alpha_off, int elbo_off, const float* parts, int n_parts, float* gnorm2_out, float clip,
+                         int32_t* flag, const float* llk_part, int n_part, const float* kl, const float* tc, float* llk,
+                         float* out4, int B, const float* ring, float* cur, int rows, int row_floats, int t_word,
+                         void* stream);
+
 /* odin_sumsq_adam_flat whose first launch also finalises the step's ELBO (the arguments of odin_elbo_finalize):
  * one launch less per training step; loss / norm / update bit-identical to the separate calls. */
 int odin_sumsq_adam_finalize_flat(float* theta, const float* g, float* m, float* v, size_t n,

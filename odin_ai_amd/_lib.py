@@ -108,6 +108,8 @@ SIGNATURES = {
     'odin_sumsq_adam_flat': [P, P, P, P, C.c_size_t, P, P, P, F, P, P],
     'odin_sumsq_adam_finalize_flat': [P, P, P, P, C.c_size_t, P, P, P, F, P, P, I, P, P, P, P, P, I, P],
     'odin_sumsq_adam_ring': [P, P, P, P, C.c_size_t, P, P, P, F, P, P, I, P, P, P, P, P, I, P, P, P, I, I, I, P],
+    'odin_slab_reduce_sumsq': [P, I, P, C.c_size_t, P, IP, P, P, I, P],
+    'odin_adam_ring_parts': [P, P, P, P, C.c_size_t, P, I, I, P, I, P, F, P, P, I, P, P, P, P, I, P, P, I, I, I, P],
     'odin_rng_normal': [P, C.c_size_t, C.c_uint64, P, P],
     'odin_gather_normalize_u8': [P, P, P, I, I, F, I, P],
     'odin_gather_rows_f32': [P, P, P, I, I, P],

@@ -477,6 +477,11 @@ struct HyperRing {
   int rows, row_floats, t_word;
 };
 
+struct FinArgs {
+  const float* llk_part; const float* kl; const float* hyper; const float* tcp;
+  float* llk; float* out4;
+  int n_part, B;
+};
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta,
                                                    const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
@@ -484,7 +489,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta,
                                                    const float* __restrict__ gnorm2, float clip,
                                                    int* flag, const float* __restrict__ parts,
                                                    int n_parts, float* __restrict__ gnorm2_out,
-                                                   HyperRing hr) {
+                                                   HyperRing hr, FinArgs fin) {
+  __shared__ float red[4];
+  // (odin_adam_ring_parts: one extra workgroup finalises the step's ELBO -- from the STAGED row: `hyper` itself is
+  // being advanced by workgroup 0)
+  if (fin.llk_part != nullptr && blockIdx.x + 1 == gridDim.x) {
+    elbo_finalize_body(fin.llk_part, fin.n_part, fin.kl, fin.hyper, fin.tcp, fin.llk, fin.out4, fin.B, red);
+    return;
+  }
   // (hr.ring != null: `hyper` is the staged copy of the five scalars)
   const float a = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   float gs = hyper[4];
@@ -497,8 +509,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta,
       hr.cur[threadIdx.x] = hr.ring[(size_t)slot * hr.row_floats + threadIdx.x];
     }
   }
-  __shared__ float red[4];
   __shared__ float n2_sh;
+  const int nblk = (int)gridDim.x - (fin.llk_part != nullptr ? 1 : 0);   // (workgroups that update parameters)
   if (parts != nullptr) {
     // fused second stage of the gradient-norm reduction: every block sums the stage-1 partials
     // in the same fixed order as sum_stage2 (one launch less on the critical path)
@@ -522,7 +534,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta,
     if (clip > 0.f) gs *= clip / fmaxf(sqrtf(n2), clip);
   }
   const size_t n4 = n >> 2;
-  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t stride = (size_t)nblk * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     float4 t = reinterpret_cast<float4*>(theta)[i];
     float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -565,11 +577,6 @@ __global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ g,
 
 // sumsq_stage1 whose LAST workgroup finalises the step's ELBO instead (elbo_finalize_kernel's work: 4.7 us as a
 // launch of its own, nothing in the backward pass depends on it): one launch less per training step.
-struct FinArgs {
-  const float* llk_part; const float* kl; const float* hyper; const float* tcp;
-  float* llk; float* out4;
-  int n_part, B;
-};
 __global__ __launch_bounds__(256) void sumsq_stage1_fin(const float* __restrict__ g, size_t n,
                                                         float* __restrict__ part, FinArgs f,
                                                         const float* __restrict__ adam_hyper,
@@ -1216,7 +1223,7 @@ extern "C" int odin_adam_step_flat(float* theta, const float* g, float* m, float
                                    int32_t* flag, void* stream) {
   int grid = grid_for(n / 4 + 1, 256, 2048);
   ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper, gnorm2,
-              clip, (int*)flag, (const float*)nullptr, 0, (float*)nullptr, HyperRing{});
+              clip, (int*)flag, (const float*)nullptr, 0, (float*)nullptr, HyperRing{}, FinArgs{});
   return odin_check_launch("adam");
 }
 
@@ -1287,7 +1294,7 @@ extern "C" int odin_sumsq_adam_flat(float* theta, const float* g, float* m, floa
   ODIN_LAUNCH(sumsq_stage1, dim3(g1), dim3(256), 0, stream, g, n, workspace, (const float*)nullptr, (float*)nullptr);
   int grid = grid_for(n / 4 + 1, 256, 2048);
   ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper,
-              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out, HyperRing{});
+              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out, HyperRing{}, FinArgs{});
   return odin_check_launch("sumsq_adam");
 }
 
@@ -1313,8 +1320,33 @@ extern "C" int odin_sumsq_adam_ring(float* theta, const float* g, float* m, floa
   }
   int grid = grid_for(n / 4 + 1, 256, 2048);
   ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, (const float*)staged,
-              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out, hr);
+              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out, hr, FinArgs{});
   return odin_check_launch("sumsq_adam_ring");
+}
+
+// The update of a step whose gradient-norm partials were left by odin_slab_reduce_sumsq (`parts`, n_parts) together
+// with the staged hyper-parameter row (`staged`: the whole row, alpha_off / elbo_off = the offsets of Adam's five
+// scalars and of the ELBO weights in it): ONE launch -- norm, clip scale, NaN guard, Adam, the ring advance of
+// odin_sumsq_adam_ring, and (llk_part != NULL) the step's ELBO finalisation in an extra workgroup.
+extern "C" int odin_adam_ring_parts(float* theta, const float* g, float* m, float* v, size_t n, const float* staged,
+                                    int alpha_off, int elbo_off, const float* parts, int n_parts, float* gnorm2_out,
+                                    float clip, int32_t* flag, const float* llk_part, int n_part, const float* kl,
+                                    const float* tc, float* llk, float* out4, int B, const float* ring, float* cur,
+                                    int rows, int row_floats, int t_word, void* stream) {
+  HyperRing hr;
+  if (ring == nullptr || staged == nullptr || parts == nullptr || n_parts < 1 ||
+      !hyper_ring_args(ring, cur, const_cast<float*>(staged), rows, row_floats, t_word, hr))
+    return odin_fail(-2, "odin_adam_ring_parts: bad arguments");
+  FinArgs f;
+  memset(&f, 0, sizeof(f));
+  if (llk_part != nullptr) {
+    f.llk_part = llk_part; f.kl = kl; f.hyper = staged + elbo_off; f.tcp = tc; f.llk = llk; f.out4 = out4;
+    f.n_part = n_part; f.B = B;
+  }
+  int grid = grid_for(n / 4 + 1, 256, 2048) + (llk_part != nullptr ? 1 : 0);
+  ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, staged + alpha_off,
+              (const float*)nullptr, clip, (int*)flag, parts, n_parts, gnorm2_out, hr, f);
+  return odin_check_launch("adam_ring_parts");
 }
 
 extern "C" int odin_sumsq_adam_finalize_flat(float* theta, const float* g, float* m, float* v, size_t n,
@@ -1331,7 +1363,7 @@ extern "C" int odin_sumsq_adam_finalize_flat(float* theta, const float* g, float
               (float*)nullptr);
   int grid = grid_for(n / 4 + 1, 256, 2048);
   ODIN_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper,
-              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out, HyperRing{});
+              (const float*)nullptr, clip, (int*)flag, (const float*)workspace, g1, gnorm2_out, HyperRing{}, FinArgs{});
   return odin_check_launch("sumsq_adam_finalize");
 }
 

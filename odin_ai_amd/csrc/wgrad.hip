@@ -1111,6 +1111,16 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
 constexpr int MAX_JOBS = 64;
 struct ReduceJobs {
   odin_reduce_job j[MAX_JOBS];
+  // odin_slab_reduce_sumsq: the squared norm of what the launch writes, as one partial per ACTIVE workgroup --
+  // part[poff[j] + blockIdx.x] for blockIdx.x < pcnt[j]; poff[j] < 0: job j's result is not part of the gradient
+  // (the range-word reset).  stage_src / stage_dst: `stage_n` floats copied by workgroup (0, 0) (the step's
+  // hyper-parameter row, read by the Adam launch after `hyper` itself was advanced).
+  float* part;
+  int poff[MAX_JOBS];
+  int pcnt[MAX_JOBS];
+  const float* stage_src;
+  float* stage_dst;
+  int stage_n;
 };
 
 // Vector jobs (n, stride multiples of 4, 16-byte aligned): a block owns 64 consecutive floats of
@@ -1122,6 +1132,9 @@ struct ReduceJobs {
 __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceJobs jobs) {
   const odin_reduce_job jb = jobs.j[blockIdx.y];
   const size_t st = jb.stride > 0 ? (size_t)jb.stride : (size_t)jb.n;
+  if (jobs.stage_dst != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < jobs.stage_n)
+    jobs.stage_dst[threadIdx.x] = jobs.stage_src[threadIdx.x];
+  float ss = 0.f;   // squares of what this thread writes (odin_slab_reduce_sumsq)
   const bool vec = ((jb.n & 3) == 0) && ((st & 3) == 0) &&
                    ((((size_t)jb.src | (size_t)jb.dst) & 15) == 0);
   if (vec && (jb.n >> 2) >= 1024) {
@@ -1167,12 +1180,11 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceJobs jobs) {
         t.z = (t.z + q1.z) + (q2.z + q3.z);
         t.w = (t.w + q1.w) + (q2.w + q3.w);
         reinterpret_cast<float4*>(jb.dst)[c] = t;
+        ss += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
       }
       __syncthreads();
     }
-    return;
-  }
-  if (vec) {
+  } else if (vec) {
     __shared__ float4 part[256];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int n4 = jb.n >> 2;
@@ -1221,11 +1233,11 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceJobs jobs) {
           t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
         }
         reinterpret_cast<float4*>(jb.dst)[c] = t;
+        ss += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
       }
       __syncthreads();
     }
-    return;
-  }
+  } else
   // odd-sized jobs (the fused tail's 65-float rows, 33-float heads): 32 result elements per block,
   // 8 row phases per element, 8 loads in flight per thread -- a one-thread-per-element loop walks
   // 256+ rows serially (dozens of dependent L2 round trips: it set the duration of the whole launch)
@@ -1256,9 +1268,20 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceJobs jobs) {
 #pragma unroll
         for (int u = 1; u < 8; ++u) t += parts[u * 32 + tx];
         jb.dst[i] = t;
+        ss += t * t;
       }
       __syncthreads();
     }
+  }
+  if (jobs.part != nullptr && jobs.poff[blockIdx.y] >= 0 && (int)blockIdx.x < jobs.pcnt[blockIdx.y]) {
+    // one partial per active workgroup, fixed order inside the workgroup: wave sums by shuffles, then the four waves
+    __shared__ float ssw[4];
+    float v = ss;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0) ssw[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) jobs.part[jobs.poff[blockIdx.y] + blockIdx.x] = (ssw[0] + ssw[1]) + (ssw[2] + ssw[3]);
   }
 }
 
@@ -1442,9 +1465,23 @@ extern "C" int odin_dense_bwd_ranged(const float* x, const float* dy, const floa
 // 1: the data gradient of this Dense layer (without a column-sum slab) folds max|dx| into dx_amax itself
 extern "C" int odin_dense_dgrad_keeps_range(int B, int K, int N) { return odin_dense_dgrad_tracks(B, K, N) ? 1 : 0; }
 
-extern "C" int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* stream) {
+// workgroups of job jb that write results (the kernel's three paths), for a launch gx wide
+static int reduce_active_blocks(const odin_reduce_job& jb, int gx) {
+  const size_t st = jb.stride > 0 ? (size_t)jb.stride : (size_t)jb.n;
+  const bool vec = ((jb.n & 3) == 0) && ((st & 3) == 0) && ((((size_t)jb.src | (size_t)jb.dst) & 15) == 0);
+  int nb;
+  if (vec && (jb.n >> 2) >= 1024) nb = ((jb.n >> 2) + 63) / 64;
+  else if (vec) nb = ((jb.n >> 2) + 15) / 16;
+  else nb = (jb.n + 31) / 32;
+  return nb < gx ? nb : gx;
+}
+
+static int slab_reduce_impl(const odin_reduce_job* jobs, int n_jobs, const float* g_lo, size_t g_n, float* part,
+                            int* n_parts_out, const float* stage_src, float* stage_dst, int stage_n, void* stream) {
   if (int rc = odin_wgrad_planes_flush(stream)) return rc;  // (deferred weight gradients write the slabs read here)
+  if (n_parts_out) *n_parts_out = 0;
   if (n_jobs <= 0) return 0;
+  int pnext = 0;
   for (int j0 = 0; j0 < n_jobs; j0 += MAX_JOBS) {
     ReduceJobs rj;
     memset(&rj, 0, sizeof(rj));
@@ -1457,12 +1494,39 @@ extern "C" int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* s
     int gx = (max_n + 63) / 64;  // vector jobs: 64 floats per block
     if (gx > 4096) gx = 4096;
     if (gx < 1) gx = 1;
+    rj.part = part;
+    for (int j = 0; j < nj; ++j) {
+      const odin_reduce_job& jb = rj.j[j];
+      const bool in_g = g_lo != nullptr && jb.dst >= g_lo && jb.dst + jb.n <= g_lo + g_n;
+      rj.poff[j] = in_g ? pnext : -1;
+      rj.pcnt[j] = in_g ? reduce_active_blocks(jb, gx) : 0;
+      pnext += rj.pcnt[j];
+    }
+    if (j0 == 0) { rj.stage_src = stage_src; rj.stage_dst = stage_dst; rj.stage_n = stage_n; }
+    if (part == nullptr && g_lo != nullptr) continue;  // dry run: only the number of partials
     dim3 grid(gx, nj, 1), block(256);
     ODIN_LAUNCH(slab_reduce_kernel, grid, block, 0, stream, rj);
     int rc = odin_check_launch("slab_reduce");
     if (rc) return rc;
   }
+  if (n_parts_out) *n_parts_out = pnext;
   return 0;
+}
+
+extern "C" int odin_slab_reduce(const odin_reduce_job* jobs, int n_jobs, void* stream) {
+  return slab_reduce_impl(jobs, n_jobs, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// odin_slab_reduce that also leaves the squared norm of the gradient it writes: one partial per active workgroup in
+// part[0 .. *n_parts_out) -- the stage-1 launch of the gradient norm (odin_sumsq_adam_*) rides in the reduction.  Jobs
+// whose dst lies inside [g, g + g_n) count (the caller guarantees that they tile the gradient buffer exactly once);
+// others (the range-word reset) do not.  stage_src / stage_dst (optional): stage_n <= 256 floats copied by the launch
+// (the hyper-parameter row the Adam launch reads after it advanced `hyper`).  part == NULL: dry run (*n_parts_out only).
+extern "C" int odin_slab_reduce_sumsq(const odin_reduce_job* jobs, int n_jobs, const float* g, size_t g_n, float* part,
+                                      int* n_parts_out, const float* stage_src, float* stage_dst, int stage_n,
+                                      void* stream) {
+  if (g == nullptr || stage_n < 0 || stage_n > 256) return odin_fail(-2, "odin_slab_reduce_sumsq: bad arguments");
+  return slab_reduce_impl(jobs, n_jobs, g, g_n, part, n_parts_out, stage_src, stage_dst, stage_n, stream);
 }
 
 extern "C" int odin_debug_set_wgrad_stamps(void* buf) {

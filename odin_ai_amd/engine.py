@@ -555,7 +555,7 @@ class VAEEngine:
     self._plan_fused_tail(f32)
     self._plan_gauss_head(f32)
     self._plan_latent_block(f32)
-    self.ws = torch.empty(1024, **f32)
+    self.ws = torch.empty(4096, **f32)
     self.gnorm2 = torch.zeros(1, **f32)
     self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
     # Networks.optimize gradient policies (skip_update_threshold / clipnorm / clipvalue)
@@ -579,7 +579,8 @@ class VAEEngine:
     self.ring_rows = int(__import__('os').environ.get('ODIN_HYPER_RING_ROWS', '128'))   # (a power of two; tests: 16)
     assert self.ring_rows >= 8 and self.ring_rows & (self.ring_rows - 1) == 0
     self.hyper_ring = torch.zeros(self.ring_rows, N_HYPER + 4, **f32)
-    self.hyper_staged = torch.zeros(8, **f32)
+    self.fuse_norm = __import__('os').environ.get('ODIN_FUSE_NORM', '1') != '0'   # (A/B switch)
+    self.hyper_staged = torch.zeros(32, **f32)   # (odin_slab_reduce_sumsq stages the whole row: N_HYPER + 4 floats)
     self._ring_host = torch.zeros(self.ring_rows, N_HYPER + 4, dtype=torch.float32)   # host mirror of the ring
     if self.device.type == 'cuda':
       self._ring_host = self._ring_host.pin_memory()
@@ -1254,7 +1255,44 @@ class VAEEngine:
     if self.debug_check_ranges:
       self.dec.check_range_words()
       self.enc.check_range_words()
+    self._norm_parts = 0
+    if getattr(self, '_fuse_norm_now', False) and not early:
+      # the gradient norm's stage-1 launch rides in the reduction (include/odin_hip.h: odin_slab_reduce_sumsq) -- its
+      # jobs tile the flat gradient buffer exactly once (checked on the first call) -- and the launch stages this step's
+      # hyper-parameter row for the Adam launch (odin_adam_ring_parts), which advances `hyper` itself
+      nparts = C.c_int(0)
+      if not getattr(self, '_jobs_cover_checked', False):
+        self._check_jobs_cover(jobs)
+        self._jobs_cover_checked = True
+        # every Adam workgroup re-sums the partials: beyond ~2 k of them (wide Dense layers: one per 256 result
+        # elements) that costs more than the launch it saves -- such models keep the separate stage-1 launch
+        lib.odin_slab_reduce_sumsq(arr, len(jobs), self.grads.data_ptr(), self.grads.numel(), None, C.byref(nparts),
+                                   None, None, 0, st)
+        if not 0 < nparts.value <= 2048:
+          self.fuse_norm = False
+      if not self.fuse_norm:
+        lib.odin_slab_reduce(arr, len(jobs), st)
+        return
+      lib.odin_slab_reduce_sumsq(arr, len(jobs), self.grads.data_ptr(), self.grads.numel(), self.ws.data_ptr(),
+                                 C.byref(nparts), self.hyper.data_ptr(), self.hyper_staged.data_ptr(), N_HYPER + 4, st)
+      assert 0 < nparts.value <= self.ws.numel(), (nparts.value, self.ws.numel())
+      self._norm_parts = nparts.value
+      return
     lib.odin_slab_reduce(arr, len(jobs), st)
+
+  def _check_jobs_cover(self, jobs):
+    """the reduction jobs that write into the flat gradient buffer tile it exactly once (so that the sum of their
+    squares IS the squared gradient norm)"""
+    g0, n = self.grads.data_ptr(), self.grads.numel()
+    cover = np.zeros(n, dtype=np.int32)
+    for jb in jobs:
+      off = (jb.dst - g0) // 4 if jb.dst is not None else -1
+      if 0 <= off < n:
+        assert off + jb.n <= n
+        cover[off:off + jb.n] += 1
+    end = self.n_params_end()   # (beyond it: the padding of the flat buffers to a multiple of 4, zero for ever)
+    assert int(cover[:end].min()) == 1 and int(cover.max()) == 1 and int(cover[end:].sum()) == 0, \
+        'reduction jobs do not tile the gradient buffer'
 
   # ---- optimiser ---------------------------------------------------------------------
   def grad_policies(self, st=None, clipnorm: Optional[float] = None,
@@ -1279,6 +1317,19 @@ class VAEEngine:
     lib = self.lib
     st = self.stream() if st is None else st
     fin, self._fin_pending = getattr(self, '_fin_pending', None), None
+    if ring and getattr(self, '_norm_parts', 0) > 0:
+      # the norm's partials and the staged hyper-parameter row were left by this step's slab reduction: ONE launch
+      assert clipvalue is None and (global_clipnorm is not None or check_nan)
+      lib.odin_adam_ring_parts(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                               self.params.numel(), self.hyper_staged.data_ptr(), H_ALPHA, H_BETA, self.ws.data_ptr(),
+                               self._norm_parts, self.gnorm2.data_ptr(), float(global_clipnorm or 0.0),
+                               self.flag.data_ptr() if check_nan else None,
+                               fin[0] if fin is not None else None, fin[1] if fin is not None else 0,
+                               self.kl.data_ptr(), fin[2] if fin is not None else None, self.llk.data_ptr(),
+                               self.out4.data_ptr(), self.B, self.hyper_ring.data_ptr(), self.hyper.data_ptr(),
+                               self.ring_rows, N_HYPER + 4, N_HYPER, st)
+      self._norm_parts = 0
+      return
     if ring:
       assert clipvalue is None and (global_clipnorm is not None or check_nan)
       lib.odin_sumsq_adam_ring(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
@@ -1378,7 +1429,16 @@ class VAEEngine:
       P.append(('k', lambda: self.backward(phase='enc')))
       P.append(('c', reduce_enc_and_join))
     else:
-      P.append(('k', self.backward))
+      # single device, no per-tensor policies between the reduction and Adam: the norm rides in the reduction
+      fuse = bool(len(pol) > 5 and pol[5] and not self.is_dp and pol[1] is None and pol[3] is None and self.fuse_norm)
+
+      def bwd():
+        self._fuse_norm_now = fuse
+        try:
+          self.backward()
+        finally:
+          self._fuse_norm_now = False
+      P.append(('k', bwd))
       if self.is_dp:
         P.append(('c', self.allreduce))
     P.append(('k', lambda: self._update(pol)))

@@ -119,7 +119,7 @@ def test_custom_decoders_keep_valid_range_words(L, name, enc, dec, in_shape, B):
   assert all(np.isfinite(v) for v in rep.values())
 
 
-def _run_steps(L, ring, lrs, betas, monkeypatch, schedule=None, n=None):
+def _run_steps(L, ring, lrs, betas, monkeypatch, schedule=None, n=None, clip=100.0):
   import os
   monkeypatch.setenv('ODIN_HYPER_RING', '1' if ring else '0')
   enc, dec, in_shape, zdim = tiny_conv_spec(1)
@@ -138,7 +138,7 @@ def _run_steps(L, ring, lrs, betas, monkeypatch, schedule=None, n=None):
   eng.set_hyper = counting
   outs = []
   for i in range(n or len(lrs)):
-    out = eng.train_step(x, None, lr=lrs[i % len(lrs)], beta=betas[i % len(betas)], global_clipnorm=100.0,
+    out = eng.train_step(x, None, lr=lrs[i % len(lrs)], beta=betas[i % len(betas)], global_clipnorm=clip,
                          schedule=schedule)
     outs.append(out.clone())
   return eng.params.clone(), torch.stack(outs), copies, eng
@@ -167,3 +167,27 @@ def test_hyper_ring_matches_per_step_copies(L, monkeypatch):
   sched = lambda u: dict(beta=1.0 + 0.01 * (u - 1))
   p2, o2, c2, _ = _run_steps(L, True, [1e-3], betas, monkeypatch, schedule=sched, n=8)
   assert torch.equal(p0, p2) and torch.equal(o0, o2) and c2 == 1
+
+
+def test_fused_norm_matches_separate_launch(L, monkeypatch):
+  """The gradient norm's stage-1 launch riding in the slab reduction (odin_slab_reduce_sumsq + odin_adam_ring_parts:
+  two launches where odin_slab_reduce + odin_sumsq_adam_ring are three): the same squared norm to rounding (other
+  partial sums), hence bit-identical parameters while the clip does not bind and parameters equal to rounding when it
+  does; the ELBO outputs (finalised from the STAGED hyper-parameter row) are bit-identical either way."""
+  n = 9
+  for clip, exact in ((100.0, True), (0.05, False)):
+    monkeypatch.setenv('ODIN_FUSE_NORM', '0')
+    p0, o0, _, e0 = _run_steps(L, True, [1e-3], [4.0], monkeypatch, n=n, clip=clip)
+    assert not e0.fuse_norm
+    monkeypatch.setenv('ODIN_FUSE_NORM', '1')
+    p1, o1, c1, e1 = _run_steps(L, True, [1e-3], [4.0], monkeypatch, n=n, clip=clip)
+    assert e1.fuse_norm and c1 == 1
+    n0, n1 = float(e0.gnorm2), float(e1.gnorm2)
+    assert abs(n0 - n1) <= 2e-6 * n0 and n0 > 0
+    if exact:
+      assert n0 < clip * clip
+      assert torch.equal(p0, p1) and torch.equal(o0, o1)
+    else:
+      assert n0 > clip * clip
+      assert float((p0 - p1).abs().max()) <= 1e-6 and float((o0 - o1).abs().max()) <= 1e-4 * float(o0.abs().max())
+    assert int(e1.hyper[16:17].view(torch.int32)) == n + 1
