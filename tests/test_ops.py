@@ -737,3 +737,46 @@ def test_wgrad_dry_run_reports_the_rows_the_launch_writes(bk, B, H, W, Ci, Co):
   g = reduce_slab(bk, slab, rows.value, n)
   close(g[:-Co].reshape(K, K, Ci, Co), dw_ref, 1e-4)
   close(g[-Co:], db_ref, 1e-4)
+
+
+def test_slab_reduce_sumsq(bk):
+  """odin_slab_reduce_sumsq (the gradient norm's stage-1 launch inside the slab reduction): results bit-identical to
+  odin_slab_reduce; the partials -- one per ACTIVE workgroup of the jobs that write into the gradient buffer -- sum to
+  the squared norm of what was written; a job outside the gradient buffer (the range-word reset) is reduced but not
+  counted; the dry run reports the same number of partials; the staging copy arrives."""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(11)
+  # (n, rows): wide vector path, narrow vector path, odd sizes, a single-row job, an empty job, a zero-row reset
+  shapes = [(16 * 32 * 32, 37), (2048, 256), (65, 100), (33, 7), (4096 + 64, 1), (24, 3)]
+  total = sum(n for n, _ in shapes)
+  g1, g2 = bk.full((total + 3,), float('nan')), bk.full((total + 3,), float('nan'))
+  other1, other2 = bk.full((512,), float('nan')), bk.full((512,), float('nan'))
+  slabs, jobs1, jobs2, off = [], [], [], 0
+  for n, rows in shapes:
+    stride = n + (4 if n % 4 == 0 else 3)
+    sl = T(rng.standard_normal((rows, stride)))
+    slabs.append(sl)
+    for jobs, g in ((jobs1, g1), (jobs2, g2)):
+      jobs.append(_lib.ReduceJob(sl.data_ptr(), g[off:].data_ptr(), n, rows, stride, 0))
+    off += n
+  zsl = T(np.zeros((1, 512)))
+  jobs1.append(_lib.ReduceJob(zsl.data_ptr(), other1.data_ptr(), 512, 0, 512, 0))
+  jobs2.append(_lib.ReduceJob(zsl.data_ptr(), other2.data_ptr(), 512, 0, 512, 0))
+  a1 = (_lib.ReduceJob * len(jobs1))(*jobs1)
+  a2 = (_lib.ReduceJob * len(jobs2))(*jobs2)
+  L.odin_slab_reduce(a1, len(jobs1), None)
+  nd, nr = C.c_int(0), C.c_int(0)
+  L.odin_slab_reduce_sumsq(a2, len(jobs2), g2.data_ptr(), total, None, C.byref(nd), None, None, 0, None)
+  assert 0 < nd.value < 4096 and torch.isnan(g2).all()   # (dry run: nothing written)
+  part = bk.full((nd.value + 8,), float('nan'))
+  src, dst = T(rng.standard_normal(24)), bk.full((32,), float('nan'))
+  L.odin_slab_reduce_sumsq(a2, len(jobs2), g2.data_ptr(), total, part.data_ptr(), C.byref(nr), src.data_ptr(),
+                           dst.data_ptr(), 24, None)
+  assert nr.value == nd.value
+  assert torch.equal(g1[:total], g2[:total]) and torch.isnan(g2[total:]).all()
+  assert torch.equal(other1, other2) and float(other2.abs().max()) == 0.0
+  assert torch.equal(dst[:24], src) and torch.isnan(dst[24:]).all()
+  assert torch.isfinite(part[:nr.value]).all() and torch.isnan(part[nr.value:]).all()
+  want = float((g2[:total].double() ** 2).sum())
+  got = float(part[:nr.value].double().sum())
+  assert abs(got - want) <= 1e-6 * want, (got, want)
