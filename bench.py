@@ -602,8 +602,6 @@ def main():
     dist.init_process_group(os.environ.get('ODIN_DIST_BACKEND', 'nccl'), rank=rank,
                             world_size=world, device_id=device)
 
-  if args.dp_buckets:
-    os.environ['ODIN_DP_BUCKETS'] = str(args.dp_buckets)
   from odin_ai_amd.engine import VAEEngine
   from odin_ai_amd.networks import get_networks
   if os.environ.get('ODIN_BENCH_IH_MIN_GF'):
@@ -623,13 +621,15 @@ def main():
     from odin_ai_amd.vae import FactorVAE
     fv = FactorVAE(device=device, seed=1 + rank, **nets)
     fv.force_dp = use_dist
+    if args.dp_buckets:
+      fv.engine_options = dict(dp_buckets=args.dp_buckets)
     eng = fv._engine(B // 2)
     fv._discriminator(B // 2)
     beta = 1.0
   else:
     eng = VAEEngine(enc, dec, in_shape, zdim, B, device, observation=nets['observation'].posterior,
                     tc=kind if kind == 'betatc' else None, world_size=world, seed=1 + rank,
-                    force_dp=use_dist)
+                    force_dp=use_dist, dp_buckets=args.dp_buckets or None)
   init_params_(eng, seed=1 + 1000 * rank)  # rank 0's weights win: broadcast below
   rccl = None
   if use_dist:

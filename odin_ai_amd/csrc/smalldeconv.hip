@@ -38,7 +38,14 @@ struct SDParams {
   unsigned* y_amax;    // forward: range word of y (may be null)
   unsigned* dx_amax;   // backward: range word of dx (may be null)
   int B, hh, ww, act, aux_act, S;
+  int w_al;            // w is 16-byte aligned (the flat parameter buffer packs tensors without padding: an odd latent
+                       // width puts every decoder weight at an 8-byte offset -- then four scalar loads per quad)
 };
+
+__device__ __forceinline__ float4 sd_ld4(const float* q, int al) {
+  if (al) return *reinterpret_cast<const float4*>(q);
+  return make_float4(q[0], q[1], q[2], q[3]);
+}
 
 // padded input image: [hh + 2][ww + 2][C0], zero border
 template <int C0>
@@ -68,10 +75,10 @@ __global__ __launch_bounds__(SD_NT) void smalldeconv_fwd_kernel(SDParams p) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int kh = (t >> 1) ? 3 - cr : 1 - cr, kw = (t & 1) ? 3 - cc : 1 - cc;
-    const float4* src = reinterpret_cast<const float4*>(p.w + ((size_t)((kh * 4 + kw) * SD_C1 + co)) * C0);
+    const float* src = p.w + ((size_t)((kh * 4 + kw) * SD_C1 + co)) * C0;
 #pragma unroll
     for (int v = 0; v < C0 / 4; ++v) {
-      const float4 t4 = src[v];
+      const float4 t4 = sd_ld4(src + 4 * v, p.w_al);
       wr[t][4 * v] = t4.x; wr[t][4 * v + 1] = t4.y; wr[t][4 * v + 2] = t4.z; wr[t][4 * v + 3] = t4.w;
     }
   }
@@ -148,12 +155,11 @@ __global__ __launch_bounds__(SD_NT) void smalldeconv_bwd_kernel(SDParams p) {
   // w [tap][co][ci] -> w1d [tap][k][cs][ci] with co = cs C0 + k: in the data gradient a lane (cs, ci) reads its C0 weights
   // of a tap at stride 64 floats, the 64 lanes of a wave consecutive floats
   if (p.dx != nullptr) {
-    const float4* src = reinterpret_cast<const float4*>(p.w);
     constexpr int units = 16 * SD_C1 * C0 / 4;
     for (int e = tid; e < units; e += SD_NT) {
       const int ci4 = e % (C0 / 4), tc = e / (C0 / 4), co = tc & 63, tap = tc >> 6;
       const int cs = co / C0, k = co - cs * C0;
-      *reinterpret_cast<float4*>(w1d + ((tap * C0 + k) * (SD_C1 / C0) + cs) * C0 + 4 * ci4) = src[e];
+      *reinterpret_cast<float4*>(w1d + ((tap * C0 + k) * (SD_C1 / C0) + cs) * C0 + 4 * ci4) = sd_ld4(p.w + 4 * e, p.w_al);
     }
   }
   if (p.slab != nullptr) sd_stage_x<C0>(p, xp, b0, ns, tid);   // (the weight gradient's other operand)
@@ -284,10 +290,10 @@ int odin_smalldeconv_rows(const odin_conv_desc* d) {
 
 int odin_smalldeconv_fwd(const float* x, const float* w, const float* bias, float* y, const odin_conv_desc* d,
                          void* stream) {
-  if ((((size_t)w) & 15) != 0) return odin_fail(-2, "smalldeconv: weights must be 16-byte aligned");
   SDParams p;
   sd_fill(p, d);
   p.x = x; p.w = w; p.bias = bias; p.y = y; p.y_amax = d->y_amax;
+  p.w_al = (((size_t)w) & 15) == 0;
   const int rows = odin_smalldeconv_rows(d);
   const size_t lds = (size_t)p.S * (d->H + 2) * (d->W + 2) * d->Cin * 4;
   if (d->Cin == 8) ODIN_LAUNCH((smalldeconv_fwd_kernel<8>), dim3(rows), dim3(SD_NT), lds, stream, p);
@@ -301,10 +307,11 @@ int odin_smalldeconv_bwd(const float* x, const float* dy, const float* w, const 
   const int rows = odin_smalldeconv_rows(d);
   if (rows_out) *rows_out = rows;
   if (dx == nullptr && slab == nullptr) return 0;
-  if ((((size_t)w | (size_t)dy) & 15) != 0) return odin_fail(-2, "smalldeconv: w / dy must be 16-byte aligned");
+  if ((((size_t)dy | (size_t)slab) & 15) != 0) return odin_fail(-2, "smalldeconv: dy / slab must be 16-byte aligned");
   SDParams p;
   sd_fill(p, d);
   p.x = x; p.w = w; p.dy = dy; p.dx = dx; p.slab = slab; p.dx_amax = d->dx_amax;
+  p.w_al = (((size_t)w) & 15) == 0;
   p.aux = (aux != nullptr && aux_act != 0) ? aux : nullptr; p.aux_act = aux_act;
   const size_t lds = sd_bwd_lds(p.S, d->H, d->W, d->Cin);
   if (d->Cin == 8) {

@@ -145,16 +145,28 @@ class SegmentedGraph:
 
   def capture(self, cap_stream):
     """capture every kernel segment (no kernel runs); the caller has warmed the program up"""
+    import gc
     self.graphs = []
-    for kind, f in self.segs:
-      if kind != 'k':
-        self.graphs.append(None)
-        continue
-      g = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(g, stream=cap_stream, capture_error_mode='thread_local'):
-        for fn in f:
-          fn()
-      self.graphs.append(g)
+    # No cyclic garbage collection while a stream is capturing: a collection that frees an object holding a HIP resource
+    # (an earlier engine's graph, an event, a communicator) issues HIP calls that are illegal during capture and abort
+    # the process (seen in round 6: `Garbage-collecting` inside _backward_enc under capture, "Fatal Python error:
+    # Aborted").  torch.cuda.graph() collects once before the capture begins; the launch program itself allocates
+    # Python objects (ctypes arrays, tuples), so a collection can still trigger in the middle.
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+      for kind, f in self.segs:
+        if kind != 'k':
+          self.graphs.append(None)
+          continue
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap_stream, capture_error_mode='thread_local'):
+          for fn in f:
+            fn()
+        self.graphs.append(g)
+    finally:
+      if was_enabled:
+        gc.enable()
 
   def replay(self):
     for (kind, f), g in zip(self.segs, self.graphs):

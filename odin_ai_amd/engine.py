@@ -135,7 +135,7 @@ class NetProgram:
 
   def __init__(self, lib, recs: List[LayerRec], B: int, device, params: torch.Tensor,
                grads: torch.Tensor, max_rows: int, range_words: Optional[torch.Tensor] = None,
-               act_words: Optional[torch.Tensor] = None):
+               act_words: Optional[torch.Tensor] = None, use_act_words: bool = True, small_wgrad_gf: float = 0.8):
     self.lib, self.recs, self.B, self.device = lib, recs, B, device
     self.params, self.grads = params, grads
     f32 = dict(dtype=torch.float32, device=device)
@@ -177,8 +177,7 @@ class NetProgram:
         cd.dy_amax = self.dy_word[i]
     # activation words: layer i reads the word of its input (outs[i - 1]) if one of its launches is a plane kernel;
     # layer i - 1 is asked to keep that word only then
-    act_on = __import__('os').environ.get('ODIN_ACT_WORDS', '1') != '0'   # (engine-side A/B switch)
-    self.reads_x = [act_on and self._reads_x(i) for i in range(len(recs))]
+    self.reads_x = [bool(use_act_words) and self._reads_x(i) for i in range(len(recs))]
     self.x_word: List[Optional[int]] = [None] * len(recs)
     self.y_word: List[Optional[int]] = [None] * len(recs)
     for i in range(1, len(recs)):
@@ -201,7 +200,7 @@ class NetProgram:
             d['Cin'] * d['Cout']
       else:
         mac = B * r.K * r.N
-      self.small_wgrad.append(2 * mac < float(__import__('os').environ.get('ODIN_SMALL_WGRAD_GF', '0.8')) * 1e9)
+      self.small_wgrad.append(2 * mac < float(small_wgrad_gf) * 1e9)
     self._plan_slabs()
 
   def word(self, i: int) -> int:
@@ -442,7 +441,23 @@ class VAEEngine:
                params: Optional[torch.Tensor] = None, world_size: int = 1, seed: int = 1,
                optim_state: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                force_dp: bool = False, reverse: bool = True, capacity: bool = False,
-               range_words: Optional[torch.Tensor] = None):
+               range_words: Optional[torch.Tensor] = None, *,
+               act_words: bool = True, hyper_ring: bool = True, hyper_ring_rows: int = 128, fuse_norm: bool = True,
+               overlap_wgrad: Optional[str] = None, early_reduce: bool = False, defer_wgrad: bool = False,
+               side_streams: int = 2, small_wgrad_gf: float = 0.8, dp_buckets: Optional[int] = None):
+    """The keyword-only arguments are the engine's launch-order / A-B options (tests and tools pass them; the engine
+    reads no environment variable):
+      act_words        activation range words for the two-plane consumers; False: unscaled planes
+      hyper_ring       per-step scalars from the device-resident ring; False: one 80-byte copy per step
+      hyper_ring_rows  rows of that ring (a power of two >= 8)
+      fuse_norm        the gradient norm's stage-1 sums ride in the slab reduction (odin_slab_reduce_sumsq)
+      overlap_wgrad    None | 'small': the bottleneck layers' weight gradients on side streams (slower since round 2,
+                       profiles/r05_ab_same_call.txt; kept for the multi-bucket DP step's tests)
+      early_reduce     with overlap_wgrad: the decoder's slabs reduced on a side stream beside the encoder's backward
+      defer_wgrad      the plane weight gradients of a step as ONE launch at the end of the backward pass (slower)
+      side_streams     side streams the overlaps rotate over
+      small_wgrad_gf   GFLOP below which a weight gradient counts as 'small' for overlap_wgrad
+      dp_buckets       gradient buckets of the data-parallel step (default: 2 from 4 ranks and 8 MB up, else 1)"""
     self.lib = lib if lib is not None else _lib.load()
     self.device = torch.device(device)
     self.B, self.D = int(batch_size), int(zdim)
@@ -499,9 +514,11 @@ class VAEEngine:
     assert self.range_words.numel() == 2 * nl * RANGE_WORDS
     gw, aw = self.range_words[:nl * RANGE_WORDS], self.range_words[nl * RANGE_WORDS:]
     self.enc = NetProgram(self.lib, self.enc_recs, B, self.device, self.params, self.grads, mr,
-                          range_words=gw[:ne * RANGE_WORDS], act_words=aw[:ne * RANGE_WORDS])
+                          range_words=gw[:ne * RANGE_WORDS], act_words=aw[:ne * RANGE_WORDS],
+                          use_act_words=act_words, small_wgrad_gf=small_wgrad_gf)
     self.dec = NetProgram(self.lib, self.dec_recs, B, self.device, self.params, self.grads, mr,
-                          range_words=gw[ne * RANGE_WORDS:], act_words=aw[ne * RANGE_WORDS:])
+                          range_words=gw[ne * RANGE_WORDS:], act_words=aw[ne * RANGE_WORDS:],
+                          use_act_words=act_words, small_wgrad_gf=small_wgrad_gf)
     self._act_words_dirty = False   # a forward pass has written activation words that no backward pass has cleared
     self.p = torch.empty(B, 2 * D, **f32)
     self.dp = torch.empty(B, 2 * D, **f32)
@@ -575,56 +592,53 @@ class VAEEngine:
     # Device-resident schedule (round 5): the rows of the coming steps in a device ring, loaded into `hyper` by the
     # step's last kernel (include/odin_hip.h: odin_sumsq_adam_ring) -- no per-step host copy while the caller's
     # (lr, beta, ...) follow the prediction (constant values, or the `schedule` callable of train_step); any other
-    # call falls back to the explicit 80-byte copy of round 4 for that step.  ODIN_HYPER_RING=0 switches it off.
-    self.ring_rows = int(__import__('os').environ.get('ODIN_HYPER_RING_ROWS', '128'))   # (a power of two; tests: 16)
+    # call falls back to the explicit 80-byte copy of round 4 for that step (`hyper_ring=False`: always).
+    self.ring_rows = int(hyper_ring_rows)   # (a power of two; tests: 16)
     assert self.ring_rows >= 8 and self.ring_rows & (self.ring_rows - 1) == 0
     self.hyper_ring = torch.zeros(self.ring_rows, N_HYPER + 4, **f32)
-    self.fuse_norm = __import__('os').environ.get('ODIN_FUSE_NORM', '1') != '0'   # (A/B switch)
+    self.fuse_norm = bool(fuse_norm)
     self.hyper_staged = torch.zeros(32, **f32)   # (odin_slab_reduce_sumsq stages the whole row: N_HYPER + 4 floats)
     self._ring_host = torch.zeros(self.ring_rows, N_HYPER + 4, dtype=torch.float32)   # host mirror of the ring
     if self.device.type == 'cuda':
       self._ring_host = self._ring_host.pin_memory()
     self._ring_filled_to = -1      # rows of steps <= this are in the device ring (as predicted)
+    self._ring_last_t = None       # the step whose Adam advanced `hyper` last (it loaded row _ring_last_t + 1)
     self._ring_live = False        # `hyper` on the device holds (or will hold, by the previous step's Adam) this step's row
     self._ring_args = None         # the caller's arguments the prediction was made from
     self._ring_copy_ev = [None, None]   # events of the last two refill copies (the pinned mirror is reused)
-    self.use_hyper_ring = __import__('os').environ.get('ODIN_HYPER_RING', '1') != '0'
+    self.use_hyper_ring = bool(hyper_ring)
     self.step_count = 0
     self.side_stream = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
-    n_side = int(__import__('os').environ.get('ODIN_SIDE_STREAMS', '2'))
+    n_side = int(side_streams)
     self.side_streams = ([self.side_stream] + [torch.cuda.Stream(self.device) for _ in range(n_side - 1)]
                          if self.side_stream is not None else [])
-    import os as _os
-    # weight gradients on a side stream.  'all': measured neutral-to-negative on MI355X (the
-    # big kernels are LDS-limited to one workgroup per CU and contend); 'small': only the
-    # launches that leave most CUs idle (bottleneck layers) run beside the data-gradient chain.
-    # Both overlaps are OFF by default since round 2: they paid at 1.1 ms per step (+2-3 %), but each
-    # cross-stream dependency of the captured graph costs 5-18 us of idle time on the main chain
-    # (profiles/r02_step_timeline.txt) and with the round-2 kernels the same A/B reads
-    # 0.819 ms (both on) / 0.808 (no side-stream wgrads) / 0.815 (no early slab reduce) / 0.804 (both off)
-    self.early_reduce = _os.environ.get('ODIN_EARLY_REDUCE', '0') == '1'
+    # weight gradients on a side stream ('small': only the launches that leave most CUs idle -- the bottleneck layers
+    # -- run beside the data-gradient chain; the 'all' form of rounds 1-5 lost every A/B since round 2 and is gone).
+    # OFF by default: it paid at 1.1 ms per step (+2-3 %), but each cross-stream dependency of the captured graph costs
+    # 5-18 us of idle time on the main chain (profiles/r02_step_timeline.txt, r05_ab_same_call.txt: 0.547 vs 0.484 ms)
+    assert overlap_wgrad in (None, 'small'), overlap_wgrad
+    self.overlap_wgrad = overlap_wgrad
+    self.early_reduce = bool(early_reduce)
     # the five plane weight gradients of a step as ONE multi-layer launch at the end of the backward pass
-    # (odin_wgrad_planes_defer_begin / _end): OFF -- same-box A/B, two rounds each: dSprites 0.582 ms with it, 0.564
-    # without; Shapes3D 0.631 / 0.614; CelebA 1.426 / 1.425.  Four launch floors are saved, but issued right behind
-    # the data gradient that produced its dy a weight gradient still finds that tensor in the Infinity Cache; at the
-    # end of the pass it comes from HBM
-    self.defer_wgrad = _os.environ.get('ODIN_DEFER_WGRAD', '0') == '1'
-    self.overlap_wgrad = {'0': None, '1': 'all', 'all': 'all', 'small': 'small'}.get(
-        _os.environ.get('ODIN_OVERLAP_WGRAD', '0'), None)
+    # (odin_wgrad_planes_defer_begin / _end): OFF -- same-box A/B: dSprites 0.491 ms with it, 0.484 without
+    # (r05_ab_same_call.txt).  Four launch floors are saved, but issued right behind the data gradient that produced its
+    # dy a weight gradient still finds that tensor in the Infinity Cache; at the end of the pass it comes from HBM
+    self.defer_wgrad = bool(defer_wgrad)
     self.graph = None
     # tests / debugging: verify every range word against its tensor before the slab reduction clears the words
     # (synchronises; NetProgram.check_range_words)
     self.debug_check_ranges = False
     self._jobs_keepalive = None
+    self._jobs_cover_ok: Dict[tuple, bool] = {}
     # data parallel: collectives through `dist.Comm` (RCCL via the C ABI on a GPU); gradient buckets:
     # 2 = the decoder's share of the flat gradient buffer is all-reduced on a side stream while the
     # encoder's backward pass runs.  Splitting the step costs by itself (three graph segments, two slab
     # reductions, no fused bottleneck backward): +84 us on the dSprites step (1.5 MB bucket), +23 us on the CelebA
     # step (9.6 MB) at world size 1 (profiles/r03_dp_buckets.txt) -- more than the all-reduce of a small bucket
-    # takes.  Default: two buckets only from 4 ranks up AND from 8 MB of gradients; ODIN_DP_BUCKETS overrides.
+    # takes.  Default: two buckets only from 4 ranks up AND from 8 MB of gradients; `dp_buckets` overrides.
     self.comm = None
     big = self.grads.numel() * 4 >= (8 << 20)
-    self.dp_buckets = int(_os.environ.get('ODIN_DP_BUCKETS', '0')) or (2 if (self.world_size >= 4 and big) else 1)
+    self.dp_buckets = int(dp_buckets or 0) or (2 if (self.world_size >= 4 and big) else 1)
     self.dec_start = min(o for k, _, o in self.layout.entries if k[0] == 'dec')
 
   def _comm(self):
@@ -813,10 +827,17 @@ class VAEEngine:
     row = self._ring_host[t % R]
     want = torch.zeros(N_HYPER + 4, dtype=torch.float32)
     wa = dict(args)
+    if schedule is not None:
+      wa.update(schedule(t))   # (a schedule rules the current step too: the rows it filled are the ones that run)
     if 'when_skip_update' in wa:
       wa['skip_enable'] = t >= int(wa.pop('when_skip_update'))
     self._fill_row(want, t, **wa)
-    hit = self._ring_live and self._ring_filled_to >= t and torch.equal(want.view(torch.int32), row.view(torch.int32))
+    # a hit needs the DEVICE row to hold step t: the previous ring-advanced step must have been t - 1 (its Adam loaded
+    # row t).  step_count may jump -- another batch-size engine ran steps in between, a checkpoint was restored -- and
+    # the mirror alone cannot see that
+    hit = (self._ring_live and self._ring_last_t == t - 1 and self._ring_filled_to >= t and
+           torch.equal(want.view(torch.int32), row.view(torch.int32)))
+    self._ring_last_t = t
     key = tuple(sorted((k, v if not isinstance(v, (list, tuple)) else tuple(v)) for k, v in args.items()))
     stable = schedule is not None or self._ring_args is None or key == self._ring_args
     self._ring_args = key
@@ -832,11 +853,14 @@ class VAEEngine:
     # stream-ordered behind the previous step, whose Adam has consumed every slot that is overwritten
     if self._ring_filled_to - t < R // 4:
       lo, hi = self._ring_filled_to + 1, t + R // 2
-      # the pinned mirror rows written below were last read by a copy enqueued two refills ago at the latest
+      # the pinned mirror rows written below may still be the source of an earlier refill's async copy: wait for
+      # every outstanding one (steady state: enqueued ~R / 4 steps ago, long done; after consecutive misses: the
+      # previous step's -- the host writes must not race its DMA)
+      for old in self._ring_copy_ev:
+        if old is not None:
+          old.synchronize()
       self._ring_copy_ev.append(None)
-      old = self._ring_copy_ev.pop(0)
-      if old is not None:
-        old.synchronize()
+      self._ring_copy_ev.pop(0)
       for u in range(lo, hi + 1):
         a = dict(args)
         if schedule is not None:
@@ -1114,7 +1138,6 @@ class VAEEngine:
       return None, (lambda: None)
     cur = torch.cuda.current_stream(self.device)
     sides = self.side_streams
-    mode = self.overlap_wgrad
     nxt = [0]
 
     def fork(i):
@@ -1125,7 +1148,7 @@ class VAEEngine:
       side.wait_event(ev)
       return side.cuda_stream
 
-    fork.wants = lambda small: mode == 'all' or small
+    fork.wants = lambda small: bool(small)
 
     def join():
       for side in sides:
@@ -1261,16 +1284,21 @@ class VAEEngine:
       # jobs tile the flat gradient buffer exactly once (checked on the first call) -- and the launch stages this step's
       # hyper-parameter row for the Adam launch (odin_adam_ring_parts), which advances `hyper` itself
       nparts = C.c_int(0)
-      if not getattr(self, '_jobs_cover_checked', False):
-        self._check_jobs_cover(jobs)
-        self._jobs_cover_checked = True
-        # every Adam workgroup re-sums the partials: beyond ~2 k of them (wide Dense layers: one per 256 result
-        # elements) that costs more than the launch it saves -- such models keep the separate stage-1 launch
-        lib.odin_slab_reduce_sumsq(arr, len(jobs), self.grads.data_ptr(), self.grads.numel(), None, C.byref(nparts),
-                                   None, None, 0, st)
-        if not 0 < nparts.value <= 2048:
-          self.fuse_norm = False
-      if not self.fuse_norm:
+      # (checked once per job-list signature: the fused / head / block variants of a step build different lists)
+      sig = tuple((jb.dst, jb.n) for jb in jobs)
+      ok = self._jobs_cover_ok.get(sig)
+      if ok is None:
+        ok = self._jobs_cover(jobs)
+        if ok:
+          # every Adam workgroup re-sums the partials: beyond ~2 k of them (wide Dense layers: one per 256 result
+          # elements) that costs more than the launch it saves -- such models keep the separate stage-1 launch
+          lib.odin_slab_reduce_sumsq(arr, len(jobs), self.grads.data_ptr(), self.grads.numel(), None, C.byref(nparts),
+                                     None, None, 0, st)
+          ok = 0 < nparts.value <= 2048
+        self._jobs_cover_ok[sig] = ok
+      if not ok:
+        # (a parameter whose gradient does not arrive through a slab job, or too many partials: the norm keeps its own
+        # stage-1 launch -- odin_sumsq_adam_ring in adam())
         lib.odin_slab_reduce(arr, len(jobs), st)
         return
       lib.odin_slab_reduce_sumsq(arr, len(jobs), self.grads.data_ptr(), self.grads.numel(), self.ws.data_ptr(),
@@ -1280,19 +1308,19 @@ class VAEEngine:
       return
     lib.odin_slab_reduce(arr, len(jobs), st)
 
-  def _check_jobs_cover(self, jobs):
-    """the reduction jobs that write into the flat gradient buffer tile it exactly once (so that the sum of their
-    squares IS the squared gradient norm)"""
+  def _jobs_cover(self, jobs) -> bool:
+    """do the reduction jobs that write into the flat gradient buffer tile it exactly once (so that the sum of their
+    squares IS the squared gradient norm)?"""
     g0, n = self.grads.data_ptr(), self.grads.numel()
     cover = np.zeros(n, dtype=np.int32)
     for jb in jobs:
       off = (jb.dst - g0) // 4 if jb.dst is not None else -1
       if 0 <= off < n:
-        assert off + jb.n <= n
+        if off + jb.n > n:
+          return False
         cover[off:off + jb.n] += 1
     end = self.n_params_end()   # (beyond it: the padding of the flat buffers to a multiple of 4, zero for ever)
-    assert int(cover[:end].min()) == 1 and int(cover.max()) == 1 and int(cover[end:].sum()) == 0, \
-        'reduction jobs do not tile the gradient buffer'
+    return bool(int(cover[:end].min()) == 1 and int(cover.max()) == 1 and int(cover[end:].sum()) == 0)
 
   # ---- optimiser ---------------------------------------------------------------------
   def grad_policies(self, st=None, clipnorm: Optional[float] = None,

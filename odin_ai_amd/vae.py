@@ -378,7 +378,8 @@ class VariationalAutoencoder:
                       tc=self._tc_mode, capacity=self._capacity_mode,
                       lib=self._lib, params=self._params, seed=self.seed + self._rank(),
                       optim_state=self._optim_state, world_size=self._world_size(),
-                      force_dp=bool(getattr(self, 'force_dp', False)))
+                      force_dp=bool(getattr(self, 'force_dp', False)),
+                      **getattr(self, 'engine_options', {}))
       if self._params is None:
         self._params = eng.params
         self._optim_state = (eng.m, eng.v)

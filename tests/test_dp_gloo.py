@@ -36,8 +36,6 @@ def _init(eng):
 
 def _worker(rank, world, port, out_path, tc=None, buckets=None, segmented=False):
   sys.path.insert(0, ROOT)
-  if buckets is not None:
-    os.environ['ODIN_DP_BUCKETS'] = str(buckets)
   from odin_ai_amd import _lib
   from odin_ai_amd.dist import shard_batch
   from odin_ai_amd.engine import VAEEngine
@@ -48,7 +46,7 @@ def _worker(rank, world, port, out_path, tc=None, buckets=None, segmented=False)
   enc, dec, shp, D = _spec()
   B = 8
   x, eps = _data(B)
-  eng = VAEEngine(enc, dec, shp, D, B // world, 'cpu', lib=L, world_size=world, tc=tc)
+  eng = VAEEngine(enc, dec, shp, D, B // world, 'cpu', lib=L, world_size=world, tc=tc, dp_buckets=buckets)
   _init(eng)
   xs, es = shard_batch(x, rank, world), shard_batch(eps, rank, world)
   kinds = None

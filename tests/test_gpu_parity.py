@@ -295,10 +295,10 @@ FULL = [
     # the engine's opt-in launch orders (all OFF by default, engine.py): weight gradients of the small layers on side
     # streams + the decoder's slabs reduced early; every weight gradient on side streams; the plane weight
     # gradients of the step as one deferred launch -- same arithmetic, other launch order
+    # (engine keyword arguments since round 6: the 'ENGINE' entry is passed to VAEEngine, everything else is environment)
     ('dsprites_b256_overlap_small_early_reduce', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0),
-     {'ODIN_OVERLAP_WGRAD': 'small', 'ODIN_EARLY_REDUCE': '1'}),
-    ('dsprites_b256_overlap_all', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0), {'ODIN_OVERLAP_WGRAD': 'all'}),
-    ('dsprites_b256_defer_wgrad', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0), {'ODIN_DEFER_WGRAD': '1'}),
+     {'ENGINE': dict(overlap_wgrad='small', early_reduce=True)}),
+    ('dsprites_b256_defer_wgrad', lambda: vo.dsprites_spec(1), 256, dict(beta=4.0), {'ENGINE': dict(defer_wgrad=True)}),
     ('shapes3d_b128', lambda: vo.dsprites_spec(3), 128, dict(beta=1.0), {}),
     ('celeba_b512', lambda: vo.celeba_spec(45, 3), 512, dict(beta=4.0), {}),
     ('celeba_betatc_b512', lambda: vo.celeba_spec(45, 3), 512, dict(beta=4.0, tc_beta=4.0), {}),
@@ -319,6 +319,8 @@ def test_full_batch_gradients_vs_f64_autograd(dev, L, monkeypatch, name, spec, B
   import os
   from odin_ai_amd.engine import VAEEngine
   from oracle.torch_ref import TorchVAE
+  env = dict(env)
+  eopts = env.pop('ENGINE', {})
   for k, v in env.items():
     monkeypatch.setenv(k, v)
     os.putenv(k, v)
@@ -340,7 +342,7 @@ def test_full_batch_gradients_vs_f64_autograd(dev, L, monkeypatch, name, spec, B
   torch.set_num_threads(min(32, os.cpu_count() or 1))
   out, G = ref.loss_and_grads(P, x.astype(np.float64), eps.astype(np.float64))
   eng = VAEEngine(enc, dec, in_shape, zdim, B, dev, tc='betatc' if 'tc_beta' in kw else None,
-                  observation=obs, lib=L)
+                  observation=obs, lib=L, **eopts)
   eng.load_params(P)
   eng.step_count = 1
   eng.set_hyper(lr=1e-3, beta=kw['beta'])

@@ -103,6 +103,24 @@ CUSTOM = [
 ]
 
 
+@pytest.mark.parametrize('zdim', [4, 5, 7])
+def test_first_deconv_with_any_latent_width(L, zdim):
+  """the flat parameter buffer packs tensors without padding, so an odd latent width leaves every
+  decoder weight at an 8-byte offset; the decoders' first Conv2DTranspose (Cin 8 -> 64, k4 s2: smalldeconv.hip) used to
+  refuse such weights with rc = -2 instead of reading them with scalar loads"""
+  enc = [('center',), ('conv', 8, 4, 2, 'elu'), ('conv', 16, 4, 2, 'elu'), ('flatten',), ('dense', 24, 'linear')]
+  dec = [('dense', 128, 'linear'), ('reshape', (4, 4, 8)), ('deconv', 64, 4, 2, 'elu'), ('deconv', 8, 4, 2, 'elu'),
+         ('conv', 1, 1, 1, 'linear')]
+  B = 5
+  enc, dec, in_shape, zd, x, eps = make_case((enc, dec, (16, 16, 1), zdim), 'bernoulli', B)
+  model = vo.OracleVAE(enc, dec, in_shape, zd, observation='bernoulli', beta=2.0)
+  P = model.init_params(seed=4)
+  eng = VAEEngine(enc, dec, in_shape, zd, B, 'cpu', observation='bernoulli', lib=L)
+  w_off = [r for r in eng.dec_recs if r.kind == 'deconv'][0].w_off
+  assert (w_off % 4 != 0) == (zdim % 2 == 1)   # (the odd widths do exercise the misaligned path)
+  check_engine_vs_oracle(eng, model, P, x, eps, beta=2.0, steps=2, clip=100.0)
+
+
 @pytest.mark.parametrize('name,enc,dec,in_shape,B', CUSTOM)
 def test_custom_decoders_keep_valid_range_words(L, name, enc, dec, in_shape, B):
   """every range word the engine hands to a consumer bounds its tensor (checked before the words are cleared), the
@@ -119,12 +137,12 @@ def test_custom_decoders_keep_valid_range_words(L, name, enc, dec, in_shape, B):
   assert all(np.isfinite(v) for v in rep.values())
 
 
-def _run_steps(L, ring, lrs, betas, monkeypatch, schedule=None, n=None, clip=100.0):
-  import os
-  monkeypatch.setenv('ODIN_HYPER_RING', '1' if ring else '0')
+def _run_steps(L, ring, lrs, betas, schedule=None, n=None, clip=100.0, rows=128, fuse_norm=True, jump=None):
+  """`jump` = (after step i, set step_count to v): what vae.py does when another engine ran steps in between"""
   enc, dec, in_shape, zdim = tiny_conv_spec(1)
   B = 4
-  eng = VAEEngine(enc, dec, in_shape, zdim, B, 'cpu', lib=L)
+  eng = VAEEngine(enc, dec, in_shape, zdim, B, 'cpu', lib=L, hyper_ring=ring, hyper_ring_rows=rows,
+                  fuse_norm=fuse_norm)
   assert eng.use_hyper_ring == ring
   g = torch.Generator().manual_seed(3)
   eng.params.copy_(torch.randn(eng.params.numel(), generator=g) * 0.05)
@@ -138,49 +156,67 @@ def _run_steps(L, ring, lrs, betas, monkeypatch, schedule=None, n=None, clip=100
   eng.set_hyper = counting
   outs = []
   for i in range(n or len(lrs)):
+    if jump is not None and i == jump[0]:
+      eng.step_count = jump[1]
     out = eng.train_step(x, None, lr=lrs[i % len(lrs)], beta=betas[i % len(betas)], global_clipnorm=clip,
                          schedule=schedule)
     outs.append(out.clone())
   return eng.params.clone(), torch.stack(outs), copies, eng
 
 
-def test_hyper_ring_matches_per_step_copies(L, monkeypatch):
+def test_hyper_ring_matches_per_step_copies(L):
   """The device-resident schedule (engine._ring_step, odin_sumsq_adam_ring): same parameters and losses, bit for bit,
   as the per-step host copy -- with constant hyper-parameters (no copy after the first step), across several ring
   refills, with a learning rate that changes in the middle (one more copy), with values that change every step (a copy
   per step, as before) and with a schedule known in advance (no copy after the first step)."""
-  monkeypatch.setenv('ODIN_HYPER_RING_ROWS', '16')   # (refilled 4-8 rows at a time: 26 steps wrap it)
+  R = dict(rows=16)   # (refilled 4-8 rows at a time: 26 steps wrap it)
   n = 26
-  p0, o0, c0, _ = _run_steps(L, False, [1e-3], [4.0], monkeypatch, n=n)
-  p1, o1, c1, eng = _run_steps(L, True, [1e-3], [4.0], monkeypatch, n=n)
+  p0, o0, c0, _ = _run_steps(L, False, [1e-3], [4.0], n=n, **R)
+  p1, o1, c1, eng = _run_steps(L, True, [1e-3], [4.0], n=n, **R)
   assert torch.equal(p0, p1) and torch.equal(o0, o1)
   assert c0 == n and c1 == 1
   assert int(eng.hyper[16:17].view(torch.int32)) == n + 1   # the last Adam loaded the row of the next step
   lrs = [1e-3] * 5 + [5e-4] * 9
-  p0, o0, c0, _ = _run_steps(L, False, lrs, [2.0], monkeypatch)
-  p1, o1, c1, _ = _run_steps(L, True, lrs, [2.0], monkeypatch)
+  p0, o0, c0, _ = _run_steps(L, False, lrs, [2.0], **R)
+  p1, o1, c1, _ = _run_steps(L, True, lrs, [2.0], **R)
   assert torch.equal(p0, p1) and torch.equal(o0, o1) and c1 == 3   # first step, the change, the step that confirms it
   betas = [1.0 + 0.01 * i for i in range(8)]
-  p0, o0, c0, _ = _run_steps(L, False, [1e-3], betas, monkeypatch, n=8)
-  p1, o1, c1, _ = _run_steps(L, True, [1e-3], betas, monkeypatch, n=8)
+  p0, o0, c0, _ = _run_steps(L, False, [1e-3], betas, n=8, **R)
+  p1, o1, c1, _ = _run_steps(L, True, [1e-3], betas, n=8, **R)
   assert torch.equal(p0, p1) and torch.equal(o0, o1) and c1 == 8
   sched = lambda u: dict(beta=1.0 + 0.01 * (u - 1))
-  p2, o2, c2, _ = _run_steps(L, True, [1e-3], betas, monkeypatch, schedule=sched, n=8)
+  p2, o2, c2, _ = _run_steps(L, True, [1e-3], betas, schedule=sched, n=8, **R)
   assert torch.equal(p0, p2) and torch.equal(o0, o2) and c2 == 1
+  # a schedule rules the step it is asked about too: explicit arguments that contradict it do not cause a copy per step
+  p3, o3, c3, _ = _run_steps(L, True, [1e-3], [9.0], schedule=sched, n=8, **R)
+  assert torch.equal(p0, p3) and torch.equal(o0, o3) and c3 == 1
 
 
-def test_fused_norm_matches_separate_launch(L, monkeypatch):
+def test_hyper_ring_survives_a_jump_of_the_step_counter(L):
+  """vae.py overwrites eng.step_count from the model's step on every call; when another batch-size
+  engine (an epoch's last partial batch) or a checkpoint restore ran steps in between, the device row `hyper` still
+  holds the row AFTER this engine's last step -- the mirror matches with constant hyper-parameters, so the old hit test
+  ran the step with a stale row (Adam bias correction, RNG counter and when_skip_update gating of an earlier step).
+  A hit now needs the previous ring-advanced step to be t - 1."""
+  jump = (3, 7)   # steps 1..3, then the counter says 7: the next step is 8
+  p0, o0, c0, e0 = _run_steps(L, False, [1e-3], [4.0], n=9, jump=jump)
+  p1, o1, c1, e1 = _run_steps(L, True, [1e-3], [4.0], n=9, jump=jump, rows=16)
+  assert e0.step_count == e1.step_count == 13
+  assert torch.equal(p0, p1) and torch.equal(o0, o1)
+  assert c1 == 2   # the first step and the step after the jump
+  assert int(e1.hyper[16:17].view(torch.int32)) == 14
+
+
+def test_fused_norm_matches_separate_launch(L):
   """The gradient norm's stage-1 launch riding in the slab reduction (odin_slab_reduce_sumsq + odin_adam_ring_parts:
   two launches where odin_slab_reduce + odin_sumsq_adam_ring are three): the same squared norm to rounding (other
   partial sums), hence bit-identical parameters while the clip does not bind and parameters equal to rounding when it
   does; the ELBO outputs (finalised from the STAGED hyper-parameter row) are bit-identical either way."""
   n = 9
   for clip, exact in ((100.0, True), (0.05, False)):
-    monkeypatch.setenv('ODIN_FUSE_NORM', '0')
-    p0, o0, _, e0 = _run_steps(L, True, [1e-3], [4.0], monkeypatch, n=n, clip=clip)
+    p0, o0, _, e0 = _run_steps(L, True, [1e-3], [4.0], n=n, clip=clip, fuse_norm=False)
     assert not e0.fuse_norm
-    monkeypatch.setenv('ODIN_FUSE_NORM', '1')
-    p1, o1, c1, e1 = _run_steps(L, True, [1e-3], [4.0], monkeypatch, n=n, clip=clip)
+    p1, o1, c1, e1 = _run_steps(L, True, [1e-3], [4.0], n=n, clip=clip, fuse_norm=True)
     assert e1.fuse_norm and c1 == 1
     n0, n1 = float(e0.gnorm2), float(e1.gnorm2)
     assert abs(n0 - n1) <= 2e-6 * n0 and n0 > 0

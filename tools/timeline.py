@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """One training step as a timeline from a rocprofv3 --kernel-trace CSV: start offset, duration,
-stream/queue, kernel (short).  usage: tools/timeline.py <dir> [step_index]"""
+stream/queue, kernel (short).  usage: tools/timeline.py <dir> [step_index [first_layer_launches_per_step]]
+(FactorVAE runs the encoder twice per iteration -- both half batches -- so its iteration spans 2 first-layer launches)"""
 import csv, glob, re, sys
 root = sys.argv[1]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+per = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 rows = []
 
 
@@ -24,7 +26,8 @@ rows.sort()
 starts = [i for i, r in enumerate(rows) if r[4].startswith('rng_normal_kernel')]
 if len(starts) < 10:
   starts = [i for i, r in enumerate(rows) if 'smallc_fwd' in r[4]]
-i0, i1 = starts[which], starts[which + 1]
+which = min(which, (len(starts) - 1) // per - 1)
+i0, i1 = starts[which * per], starts[(which + 1) * per]
 t0 = rows[i0][0]
 busy_end = t0
 gaps = 0
