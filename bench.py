@@ -568,11 +568,24 @@ def main():
   ap.add_argument('--dp-buckets', type=int, default=0,
                   help='gradient buckets of the data-parallel step (2: the decoder bucket is all-reduced on a '
                   'side stream beside the encoder backward; default: 2 from 4 ranks up when the bucket is >= 8 MB, else 1)')
+  ap.add_argument('--engine-opt', action='append', default=[], metavar='KEY=VALUE',
+                  help='a VAEEngine keyword argument of the main engine (A/B runs: hyper_ring=False, act_words=False, '
+                  'fuse_norm=False, overlap_wgrad=small, early_reduce=True, defer_wgrad=True, neck=False ...)')
   ap.add_argument('--force-dist', action='store_true',
                   help='initialise the RCCL process group even at world size 1, so that the '
                   'data-parallel step (graph A, RCCL all-reduce, graph B) runs on a 1-GPU box')
   args = ap.parse_args()
 
+  import ast
+  eopts = {}
+  for kv in args.engine_opt:
+    k, _, v = kv.partition('=')
+    try:
+      eopts[k] = ast.literal_eval(v)
+    except (ValueError, SyntaxError):
+      eopts[k] = v
+  if args.dp_buckets:
+    eopts['dp_buckets'] = args.dp_buckets
   if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
     # no launcher around us: become one.  Nothing in this process has touched the GPU yet.
     sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -621,15 +634,14 @@ def main():
     from odin_ai_amd.vae import FactorVAE
     fv = FactorVAE(device=device, seed=1 + rank, **nets)
     fv.force_dp = use_dist
-    if args.dp_buckets:
-      fv.engine_options = dict(dp_buckets=args.dp_buckets)
+    fv.engine_options = dict(eopts)
     eng = fv._engine(B // 2)
     fv._discriminator(B // 2)
     beta = 1.0
   else:
     eng = VAEEngine(enc, dec, in_shape, zdim, B, device, observation=nets['observation'].posterior,
                     tc=kind if kind == 'betatc' else None, world_size=world, seed=1 + rank,
-                    force_dp=use_dist, dp_buckets=args.dp_buckets or None)
+                    force_dp=use_dist, **eopts)
   init_params_(eng, seed=1 + 1000 * rank)  # rank 0's weights win: broadcast below
   rccl = None
   if use_dist:
