@@ -235,6 +235,67 @@ int odin_latent_block_bwd(const float* g0, const float* w0, const float* z, cons
                           int h_act, float* dz, float* dp, float* dh, float* slab0, float* slabl, int B,
                           int P, int D, int N0, int analytic, uint32_t* dh_amax, void* stream);
 
+/* ---- the NECK of the 64x64 stacks in one launch per direction (round 6; neck.hip): the encoder's last convolution
+ * and projection, the latent block above, the decoder's projection and first Conv2DTranspose
+ *   image_networks.py:466-471  Conv2D(64, 4, 2, 'same', act3) on [8,8,64] -> [4,4,64]; Flatten; Dense(P, act4)
+ *   dense_distribution.py:339-380 / continuous.py:443-483 / helpers.py:236-286  (as odin_latent_block_*)
+ *   image_networks.py:494-502  Dense(D -> 16 C0, act0); Reshape(4,4,C0); Conv2DTranspose(64, 4, 2, 'same', act1)
+ * i.e. odin_conv2d_fwd + odin_dense_fwd + odin_latent_block_fwd + odin_deconv2d_fwd of those layers (and in the
+ * backward pass their DATA gradients plus the weight gradients of the three small matrices; the two large weight
+ * gradients -- conv3: a reduction over all B*16 pixels, projection: over the batch -- stay odin_conv2d_wgrad /
+ * odin_dense_wgrad on dy3 / dh4, which the backward launch leaves with their range words).  No layer of the chain
+ * couples samples: a workgroup owns two samples.  Same results as the separate calls to fp32 rounding (the conv runs
+ * as two f16 planes per operand like the plane kernels: <= 3 * 2^-22 per product).
+ * odin_neck_rows: workgroups (= rows of slab1 / slab0 / slabl), 0 when the shapes are outside the fused regime
+ * (P in {128, 256}, C0 in {8, 16}, D <= 32). */
+typedef struct odin_neck_args {
+  int B, P, D, C0;                 /* batch, projection width, latent dims, channels of the decoder's first image */
+  int act2, act3, act4, act0, act1;/* activations: of the layer BELOW conv3 (backward: dx *= act2'(x)), conv3, projection, decoder projection, deconv1 */
+  int analytic;                    /* KL form as odin_latent_fwd: 0 Monte Carlo, 1 KL(q||p), 2 KL(p||q) */
+  float free_bits;                 /* < 0: off */
+  uint64_t seed;                   /* Philox key of odin_rng_normal (eps_in == NULL) */
+  const int32_t* step_dev;         /* device int: the RNG step */
+  /* ---- forward ---- */
+  const float* x;                  /* [B,8,8,64] input of conv3 (output of the layer below) */
+  const uint32_t* x_amax;          /* its activation range word or NULL */
+  const float *w3, *b3;            /* Conv2D (4,4,64,64), [64] */
+  float* y3;                       /* [B,4,4,64] */
+  const float *w4, *b4;            /* Dense (1024,P), [P] */
+  float* y4;                       /* [B,P] */
+  const float *wl, *bl;            /* DistributionDense (P,2D), [2D] */
+  const float* eps_in;             /* [B,D] or NULL: draw */
+  float* eps;                      /* [B,D] written when drawn */
+  float *p, *z, *kl, *fbmask;      /* [B,2D], [B,D], [B], [B] */
+  const float* capacity;           /* BetaCapacityVAE device scalar or NULL */
+  const float *w0, *b0;            /* Dense (D,16*C0), [16*C0] */
+  float* y0;                       /* [B,16*C0] = [B,4,4,C0] */
+  const float *w1, *b1;            /* Conv2DTranspose (4,4,64,C0), [64] */
+  float* y1;                       /* [B,8,8,64] */
+  uint32_t* y1_amax;               /* activation range word of y1 (written) or NULL */
+  /* ---- backward (forward tensors above are read) ---- */
+  const float* dy1;                /* [B,8,8,64] dL/d(pre-activation of deconv1) */
+  const float* klw;                /* device scalar: KL weight beta / B */
+  const float *dz_extra, *dloc_x, *dscale_x;   /* optional extra terms as odin_latent_bwd */
+  float *dz, *dp;                  /* [B,D], [B,2D] */
+  float* dh4;                      /* [B,P]  dL/d(pre-activation of the projection) */
+  float* dy3;                      /* [B,4,4,64] dL/d(pre-activation of conv3) */
+  float* dx;                       /* [B,8,8,64] dL/d(pre-activation of the layer below) = conv3's data gradient * act2'(x) */
+  uint32_t *dh4_amax, *dy3_amax, *dx_amax;     /* gradient range words (written) or NULL */
+  float* slab1;                    /* [rows][16*64*C0]       partial dW1 (deconv1's bias gradient: column sums of dy1, the caller's) */
+  float* slab0;                    /* [rows][D*16*C0 + 16*C0] partial (dW0 | db0) */
+  float* slabl;                    /* [rows][P*2D + 2D]       partial (dWl | dbl) */
+} odin_neck_args;
+/* Weight-gradient calls (odin_conv2d_wgrad / odin_deconv2d_wgrad / odin_dense_wgrad / odin_dense_bwd with want_dx = 0)
+ * issued between _begin and _end on ONE stream are declared independent of one another by the caller: where two of
+ * them land on the small-layer implicit-GEMM kernels they share a launch (results bit-identical to the separate
+ * launches).  _end issues a call that found no partner.  Used behind odin_neck_bwd for conv3's and the projection's
+ * weight gradients. */
+void odin_wgrad_pair_begin(void);
+int odin_wgrad_pair_end(void);
+int odin_neck_rows(int B, int P, int D, int C0);
+int odin_neck_fwd(const odin_neck_args* a, void* stream);
+int odin_neck_bwd(const odin_neck_args* a, void* stream);
+
 /* ---- observation log-likelihood fused forward+backward
  * Independent(Bernoulli(logits),3).log_prob(x) (image_networks.py:87-93;
  * variational_autoencoder.py:528-530): llk_part[b][part] partial sums (n_part per
@@ -490,6 +551,9 @@ int odin_reduce_scatter_flat(void* comm, const float* send, float* recv, size_t 
  * conv kernels' workgroup 0 (NULL disables; never set in production) */
 int odin_debug_set_stamps(void* buf);
 int odin_debug_set_wgrad_stamps(void* buf);
+/* diagnostics: workgroup 0 of odin_neck_fwd / _bwd records 100 MHz wall-clock stamps at its phase boundaries into
+ * buf[0..6] / buf[8..17] (int64, device memory); NULL: off */
+int odin_debug_set_neck_stamps(void* buf);
 
 /* ---- HIP-graph helpers (capture a sequence of the calls above, replay per step) ------- */
 int odin_graph_begin(void* stream);

@@ -31,6 +31,17 @@ class ReduceJob(C.Structure):
               ('stride', C.c_int), ('pad_', C.c_int)]
 
 
+class NeckArgs(C.Structure):
+  """mirror of ``odin_neck_args`` (include/odin_hip.h): the neck of the 64x64 stacks in one launch per direction."""
+  _fields_ = [(n, C.c_int) for n in ('B', 'P', 'D', 'C0', 'act2', 'act3', 'act4', 'act0', 'act1', 'analytic')] + \
+             [('free_bits', C.c_float), ('seed', C.c_uint64)] + \
+             [(n, C.c_void_p) for n in (
+                 'step_dev', 'x', 'x_amax', 'w3', 'b3', 'y3', 'w4', 'b4', 'y4', 'wl', 'bl', 'eps_in', 'eps', 'p', 'z',
+                 'kl', 'fbmask', 'capacity', 'w0', 'b0', 'y0', 'w1', 'b1', 'y1', 'y1_amax',
+                 'dy1', 'klw', 'dz_extra', 'dloc_x', 'dscale_x', 'dz', 'dp', 'dh4', 'dy3', 'dx',
+                 'dh4_amax', 'dy3_amax', 'dx_amax', 'slab1', 'slab0', 'slabl')]
+
+
 P = C.c_void_p
 I = C.c_int
 F = C.c_float
@@ -82,6 +93,11 @@ SIGNATURES = {
     'odin_latent_block_rows': [I, I, I, I],
     'odin_latent_block_fwd': [P, P, P, P, P, C.c_uint64, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, P],
     'odin_latent_block_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, I, I, P, P],
+    'odin_wgrad_pair_begin': [],
+    'odin_wgrad_pair_end': [],
+    'odin_neck_rows': [I, I, I, I],
+    'odin_neck_fwd': [C.POINTER(NeckArgs), P],
+    'odin_neck_bwd': [C.POINTER(NeckArgs), P],
     'odin_elbo_bernoulli_fwd_bwd': [P, P, P, P, P, I, I, IP, P],
     'odin_elbo_gaussian_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
     'odin_gaussian_head_fwd_bwd': [P, P, P, P, P, P, P, P, IP, P, IP, P, P, I, I, I, I, I, I, P, P],
@@ -117,6 +133,7 @@ SIGNATURES = {
     'odin_stft_mel_db_frames': [P, P, P, P, P, P, I, I, I, I, I, I, C.c_double, C.c_double, I, I, P, P],
     'odin_debug_set_stamps': [P],
     'odin_debug_set_wgrad_stamps': [P],
+    'odin_debug_set_neck_stamps': [P],
     'odin_graph_begin': [P],
     'odin_graph_end': [P, C.POINTER(C.c_void_p)],
     'odin_graph_launch': [P, P],
@@ -128,9 +145,9 @@ SIGNATURES = {
 VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_conv2d_dgrad_keeps_range',
                    'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_dense_dgrad_keeps_range', 'odin_conv2d_reads_x_range',
                    'odin_deconv2d_reads_x_range', 'odin_dense_reads_x_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
-                   'odin_latent_block_rows', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop')
+                   'odin_latent_block_rows', 'odin_neck_rows', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop')
 # entry points declared `void` in include/odin_hip.h
-VOID_RETURNING = ('odin_wgrad_planes_defer_begin',)
+VOID_RETURNING = ('odin_wgrad_planes_defer_begin', 'odin_wgrad_pair_begin')
 
 
 class OdinError(RuntimeError):

@@ -1836,6 +1836,9 @@ extern "C" int odin_dense_fwd_ranged(const float* x, const float* w, const float
     return odin_absmax_fold(y, (size_t)B * N, y_amax, stream);
   };
   if (odin_tiny_dense_ok(B, K, N)) return fold(odin_tiny_dense_fwd(x, w, bias, y, B, K, N, act, stream));
+  // one thin side (FactorVAE's first / last discriminator layers): streaming kernels, range word kept by the kernel
+  if (odin_thin_dense_kind(B, K, N) != 0 && ((((size_t)x | (size_t)w | (size_t)y | (size_t)bias)) & 15) == 0)
+    return odin_thin_dense_fwd(x, w, bias, y, B, K, N, act, y_amax, stream);
   if (odin_dense_h_ok(B, K, N)) return odin_dense_h_fwd(x, w, bias, y, B, K, N, act, x_amax, y_amax, stream);
   if (dense_via_igemm() && odin_igemm_applicable(0, B, 1, 1, K, 1, 1, N, 1, 1, 1, 0))
     return odin_igemm_launch(0, x, w, bias, nullptr, 0, y, nullptr, B, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, act, y_amax,
@@ -1861,7 +1864,7 @@ extern "C" int odin_dense_dgrad(const float* dy, const float* w, const float* au
 // the kernel families below (without a column-sum slab) that fold max|dx| into dx_amax
 bool odin_dense_dgrad_tracks(int B, int K, int N) {
   if (odin_tiny_dense_ok(B, K, N)) return false;
-  return odin_dense_h_ok(B, K, N) || (dense_via_igemm() && odin_igemm_applicable(1, B, 1, 1, N, 1, 1, K, 1, 1, 1, 0)) ||
+  return odin_thin_dense_kind(B, K, N) != 0 || odin_dense_h_ok(B, K, N) || (dense_via_igemm() && odin_igemm_applicable(1, B, 1, 1, N, 1, 1, K, 1, 1, 1, 0)) ||
          odin_dense_gemm_ok(B, K, N);
 }
 
@@ -1875,6 +1878,12 @@ int odin_dense_dgrad_ranged(const float* dy, const float* w, const float* aux, i
   };
   if (odin_tiny_dense_ok(B, K, N))
     return fold(odin_tiny_dense_dgrad(dy, w, aux, aux_act, dx, colsum_slab, slab_rows_out, B, K, N, stream));
+  if (colsum_slab == nullptr && odin_thin_dense_kind(B, K, N) != 0 &&
+      ((((size_t)dy | (size_t)w | (size_t)dx | (size_t)aux)) & 15) == 0) {
+    if (slab_rows_out) *slab_rows_out = 0;
+    if (dx == nullptr) return 0;
+    return odin_thin_dense_dgrad(dy, w, aux, aux_act, dx, B, K, N, dx_amax, stream);
+  }
   if (colsum_slab == nullptr && odin_dense_h_ok(B, K, N)) {
     if (slab_rows_out) *slab_rows_out = 0;
     if (dx == nullptr) return 0;

@@ -411,6 +411,24 @@ __global__ __launch_bounds__((NWA > NWB ? NWA : NWB) * 64) void igemm_pair_kerne
   }
 }
 
+// TWO weight gradients in one launch (round 6): the neck's backward pass (neck.hip) leaves conv3's and the projection's
+// weight gradients -- reductions over the whole batch, 14.6 and 7.3 us as launches of their own -- with nothing between
+// them; neither reads the other's result.  Workgroups [0, na) run the first, the rest the second.
+template <int NWA, int NWB>
+__global__ __launch_bounds__((NWA > NWB ? NWA : NWB) * 64) void igemm_wpair_kernel(IWParams a, IWParams b, int na, int gax,
+                                                                                  int gay, int gbx, int gby) {
+  const int id = (int)blockIdx.x;
+  if (id < na) {
+    if (NWA < NWB && (int)threadIdx.x >= NWA * 64) return;
+    const int bz = id / (gax * gay), q = id - bz * (gax * gay), by = q / gax;
+    igemm_wgrad_body<NWA>(a, q - by * gax, by, bz);
+  } else {
+    if (NWB < NWA && (int)threadIdx.x >= NWB * 64) return;
+    const int r = id - na, bz = r / (gbx * gby), q = r - bz * (gbx * gby), by = q / gbx;
+    igemm_wgrad_body<NWB>(b, q - by * gbx, by, bz);
+  }
+}
+
 // (read on every call: the A/B tests of the other paths switch it at run time; graph replays never get here)
 bool igemm_enabled() { return ODIN_DIAG_ENV("ODIN_NOIGEMM") == nullptr; }
 // Largest layer routed here, in FLOP (ODIN_IG_MAXGF overrides, GFLOP).  Measured against the tiled paths
@@ -426,6 +444,7 @@ double igemm_max_flop(bool wide) {
 // gradient first; when it lands here it waits for the data gradient of the same layer and shares its launch ----
 struct PendingW {
   bool defer = false, pending = false;
+  int depth = 0;   // brackets nest (odin_wgrad_pair_begin around a *_bwd entry point): only the outermost one opens / flushes
   IWParams p;
   dim3 grid;
   int nw = 0;
@@ -439,6 +458,16 @@ int iw_launch_now(const IWParams& p, dim3 grid, int nw, void* stream) {
   else if (nw == 2) ODIN_LAUNCH((igemm_wgrad_kernel<2>), grid, dim3(128), 0, stream, p);
   else ODIN_LAUNCH((igemm_wgrad_kernel<1>), grid, dim3(64), 0, stream, p);
   return odin_check_launch("igemm_wgrad");
+}
+
+template <int NWA>
+int iw_pair_b(const IWParams& a, dim3 ga, const IWParams& b, dim3 gb, int nwb, void* stream) {
+  const int na = (int)(ga.x * ga.y * ga.z), nb = (int)(gb.x * gb.y * gb.z);
+  const dim3 grid((unsigned)(na + nb));
+  if (nwb == 4) ODIN_LAUNCH((igemm_wpair_kernel<NWA, 4>), grid, dim3((NWA > 4 ? NWA : 4) * 64), 0, stream, a, b, na, (int)ga.x, (int)ga.y, (int)gb.x, (int)gb.y);
+  else if (nwb == 2) ODIN_LAUNCH((igemm_wpair_kernel<NWA, 2>), grid, dim3((NWA > 2 ? NWA : 2) * 64), 0, stream, a, b, na, (int)ga.x, (int)ga.y, (int)gb.x, (int)gb.y);
+  else ODIN_LAUNCH((igemm_wpair_kernel<NWA, 1>), grid, dim3(NWA * 64), 0, stream, a, b, na, (int)ga.x, (int)ga.y, (int)gb.x, (int)gb.y);
+  return odin_check_launch("igemm_wgrad+igemm_wgrad");
 }
 
 template <int NWA, bool TMODE, bool BKC>
@@ -586,11 +615,28 @@ int odin_igemm_wgrad_launch(const float* u, const float* v, float* slab, int sla
     g_pw.p = p; g_pw.grid = grid; g_pw.nw = nw; g_pw.stream = stream;
     return 0;
   }
+#ifndef ODIN_SIM  // (the simulator's barrier counts every thread of the block: the roles keep their own launches there)
+  if (g_pw.defer && g_pw.pending && g_pw.stream == stream && nw <= 4 && g_pw.nw <= 4) {
+    // a second weight gradient behind a pending one (odin_wgrad_pair_begin / _end): both in one launch
+    g_pw.pending = false;
+    if (g_pw.nw == 4) return iw_pair_b<4>(g_pw.p, g_pw.grid, p, grid, nw, stream);
+    if (g_pw.nw == 2) return iw_pair_b<2>(g_pw.p, g_pw.grid, p, grid, nw, stream);
+    return iw_pair_b<1>(g_pw.p, g_pw.grid, p, grid, nw, stream);
+  }
+#endif
   return iw_launch_now(p, grid, nw, stream);
 }
 
-void odin_igemm_pair_begin() { g_pw.defer = true; g_pw.pending = false; }
+// C ABI: the caller announces that the weight-gradient calls up to odin_wgrad_pair_end are independent of one another
+// (include/odin_hip.h); those that land on this kernel family share a launch two by two
+extern "C" void odin_wgrad_pair_begin(void) { odin_igemm_pair_begin(); }
+extern "C" int odin_wgrad_pair_end(void) { return odin_igemm_pair_end(); }
+
+void odin_igemm_pair_begin() {
+  if (g_pw.depth++ == 0) { g_pw.defer = true; g_pw.pending = false; }
+}
 int odin_igemm_pair_end() {
+  if (g_pw.depth > 0 && --g_pw.depth > 0) return 0;
   g_pw.defer = false;
   if (!g_pw.pending) return 0;
   g_pw.pending = false;

@@ -68,6 +68,16 @@ int odin_zero_u32(uint32_t* p, size_t n, void* stream);  // zero n words with a 
 int odin_dense_gemm_wgrad(const float* x, const float* dy, float* slab, int B, int K, int N,
                           void* stream);
 
+// Dense layers with one thin side (K <= 32 or N <= 4) as streaming kernels on the vector ALU (thin_dense.hip): kind 1 =
+// thin K, 2 = thin N, 0 = not served; pointers must be 16-byte aligned (the dispatchers check)
+int odin_thin_dense_kind(int B, int K, int N);
+int odin_thin_dense_wgrad_rows(int B, int K, int N);
+int odin_thin_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, int act,
+                        uint32_t* y_amax, void* stream);
+int odin_thin_dense_dgrad(const float* dy, const float* w, const float* aux, int aux_act, float* dx, int B, int K, int N,
+                          uint32_t* dx_amax, void* stream);
+int odin_thin_dense_wgrad(const float* x, const float* dy, float* slab, int B, int K, int N, void* stream);
+
 // Dense layers with both widths >= 256 on the f16 matrix pipe as two planes (dense_h.hip)
 bool odin_dense_h_ok(int B, int K, int N);
 int odin_dense_h_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, int act,

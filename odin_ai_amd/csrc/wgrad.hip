@@ -1350,6 +1350,13 @@ extern "C" int odin_dense_wgrad(const float* x, const float* dy, float* slab, in
     if (slab == nullptr) return 0;  // dry run
     return odin_dense_h_wgrad(x, dy, slab, B, K, N, nullptr, nullptr, stream);
   }
+  if (odin_thin_dense_wgrad_rows(B, K, N) > 0 && (slab == nullptr || ((((size_t)x | (size_t)dy | (size_t)slab)) & 15) == 0)) {
+    // one thin side: streaming kernel, slab rows = row chunks of the batch (a dry run cannot see the pointers: callers
+    // allocate at least 16-byte aligned tensors)
+    if (slab_rows_out) *slab_rows_out = odin_thin_dense_wgrad_rows(B, K, N);
+    if (slab == nullptr) return 0;  // dry run
+    return odin_thin_dense_wgrad(x, dy, slab, B, K, N, stream);
+  }
   // (also the tiny layers: their forward / data gradient run on the vector ALUs, but the weight gradient
   // through the generic kernel was a 14.5 us launch for 0.001 GFLOP)
   if (!ODIN_DIAG_ENV("ODIN_NODENSEIGEMM") && !odin_tiny_dense_ok(B, K, N) &&

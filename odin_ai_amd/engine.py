@@ -135,7 +135,8 @@ class NetProgram:
 
   def __init__(self, lib, recs: List[LayerRec], B: int, device, params: torch.Tensor,
                grads: torch.Tensor, max_rows: int, range_words: Optional[torch.Tensor] = None,
-               act_words: Optional[torch.Tensor] = None, use_act_words: bool = True, small_wgrad_gf: float = 0.8):
+               act_words: Optional[torch.Tensor] = None, use_act_words: bool = True, small_wgrad_gf: float = 0.8,
+               direct_wgrad: bool = False):
     self.lib, self.recs, self.B, self.device = lib, recs, B, device
     self.params, self.grads = params, grads
     f32 = dict(dtype=torch.float32, device=device)
@@ -187,6 +188,11 @@ class NetProgram:
       if cd is not None:
         cd.x_amax, cd.y_amax = self.x_word[i], self.y_word[i]
     self.wslabs: List[Optional[torch.Tensor]] = [None] * len(recs)
+    # `direct_wgrad`: a Dense weight gradient that arrives as ONE complete slab row is written straight into the flat
+    # gradient buffer ([W | b] is contiguous there): no slab, no reduction job (FactorVAE's discriminator: four
+    # 1000 x 1000 layers -- 16 MB copied by a 25 us reduction launch per iteration otherwise)
+    self.direct_wgrad = bool(direct_wgrad)
+    self.wdirect = [False] * len(recs)
     self.wrows = [0] * len(recs)
     self.bslabs: List[Optional[torch.Tensor]] = [None] * len(recs)  # deconv bias (colsum)
     self.brows = [0] * len(recs)
@@ -235,11 +241,11 @@ class NetProgram:
       self.descs[n].dy_amax = self.dy_word[n]
     return self.dy_word[n]
 
-  def check_range_words(self, upto: Optional[int] = None) -> None:
+  def check_range_words(self, upto: Optional[int] = None, first: int = 0) -> None:
     """Debug / tests (synchronises): every word handed to a consumer bounds its tensor -- call between backward() and
     the slab reduction that clears the words (NetProgram.backward alone does not clear them)."""
     n = len(self.recs) if upto is None else upto
-    for i in range(n):
+    for i in range(first, n):   # (gouts below `first` stay inside a fused bottleneck launch: never written)
       if self.dy_word[i] is None:
         continue
       blk = self.range_words[RANGE_WORDS * i:RANGE_WORDS * (i + 1)]
@@ -286,6 +292,11 @@ class NetProgram:
         lib.odin_dense_wgrad(None, None, None, C.byref(rows), B, r.K, r.N, None)
         n = r.w_n + r.b_n
       self.wrows[i] = rows.value
+      if (self.direct_wgrad and r.kind == 'dense' and rows.value == 1 and r.b_off == r.w_off + r.w_n and
+          self.grads[r.w_off:].data_ptr() % 16 == 0):
+        self.wslabs[i] = self.grads[r.w_off:r.w_off + n].view(1, n)
+        self.wdirect[i] = True
+        continue
       self.wslabs[i] = torch.empty((rows.value, n), **f32)
       if r.kind == 'deconv':
         # bias gradient = column sums of gouts[i], emitted by whoever produces gouts[i]:
@@ -387,8 +398,11 @@ class NetProgram:
         # (jobs whose slab was written on a side stream are kept apart: only the final reduction,
         # after the join, may read them)
         tgt = side_jobs if (side_jobs is not None and wst is not st) else jobs
-        tgt.append(ReduceJob(slab.data_ptr(), self.grads[r.w_off:].data_ptr(), n_red, wrows.value,
-                             slab.shape[1], 0))
+        if self.wdirect[i]:
+          assert wrows.value == 1   # (the launch wrote the gradient itself)
+        else:
+          tgt.append(ReduceJob(slab.data_ptr(), self.grads[r.w_off:].data_ptr(), n_red, wrows.value,
+                               slab.shape[1], 0))
       if dst is None:
         break
       if not both:
@@ -444,7 +458,8 @@ class VAEEngine:
                range_words: Optional[torch.Tensor] = None, *,
                act_words: bool = True, hyper_ring: bool = True, hyper_ring_rows: int = 128, fuse_norm: bool = True,
                overlap_wgrad: Optional[str] = None, early_reduce: bool = False, defer_wgrad: bool = False,
-               side_streams: int = 2, small_wgrad_gf: float = 0.8, dp_buckets: Optional[int] = None):
+               side_streams: int = 2, small_wgrad_gf: float = 0.8, dp_buckets: Optional[int] = None,
+               neck: bool = True, neck_bwd: Optional[bool] = None):
     """The keyword-only arguments are the engine's launch-order / A-B options (tests and tools pass them; the engine
     reads no environment variable):
       act_words        activation range words for the two-plane consumers; False: unscaled planes
@@ -457,7 +472,11 @@ class VAEEngine:
       defer_wgrad      the plane weight gradients of a step as ONE launch at the end of the backward pass (slower)
       side_streams     side streams the overlaps rotate over
       small_wgrad_gf   GFLOP below which a weight gradient counts as 'small' for overlap_wgrad
-      dp_buckets       gradient buckets of the data-parallel step (default: 2 from 4 ranks and 8 MB up, else 1)"""
+      dp_buckets       gradient buckets of the data-parallel step (default: 2 from 4 ranks and 8 MB up, else 1)
+      neck             the encoder's last convolution + projection + latent block + the decoder's projection + first
+                       Conv2DTranspose as ONE launch per direction where the shapes allow (neck.hip); False: round 5's
+                       four launches per direction
+      neck_bwd         the neck's backward launch (None: where it was measured faster)"""
     self.lib = lib if lib is not None else _lib.load()
     self.device = torch.device(device)
     self.B, self.D = int(batch_size), int(zdim)
@@ -572,6 +591,8 @@ class VAEEngine:
     self._plan_fused_tail(f32)
     self._plan_gauss_head(f32)
     self._plan_latent_block(f32)
+    self._neck_bwd_opt = neck_bwd
+    self._plan_neck(f32, bool(neck))
     self.ws = torch.empty(4096, **f32)
     self.gnorm2 = torch.zeros(1, **f32)
     self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -745,6 +766,108 @@ class VAEEngine:
     self.lb_slab0 = torch.empty(rows, D * N0 + N0, **f32)
     self.lb_slabl = torch.empty(rows, self.hdim * 2 * D + 2 * D, **f32)
 
+  def _plan_neck(self, f32, enabled: bool):
+    """Training-step fusion of the whole neck (neck.hip): Conv2D(64, k4, s2) on [8, 8, 64] -> Flatten -> Dense(P) ->
+    latent block -> Dense(D -> 16 C0) -> Reshape(4, 4, C0) -> Conv2DTranspose(64, k4, s2) as one launch per direction
+    (image_networks.py:466-471, 494-502: the dSprites / Shapes3D stacks)."""
+    self.neck = self._used_neck = False
+    er, dr = self.enc_recs, self.dec_recs
+    if not (enabled and self.lat_block and len(er) >= 3 and len(dr) >= 3):
+      return
+    c3, d4, d0, t1 = er[-2], er[-1], dr[0], dr[1]
+    if not (c3.kind == 'conv' and d4.kind == 'dense' and d0.kind == 'dense' and t1.kind == 'deconv'):
+      return
+    g = c3.desc
+    if not (g['H'] == 8 and g['W'] == 8 and g['Cin'] == 64 and g['Cout'] == 64 and g['K'] == 4 and g['stride'] == 2
+            and g['pad_t'] == 1 and g['pad_l'] == 1 and not c3.center and d4.K == 1024):
+      return
+    t = t1.desc
+    if not (t['H'] == 4 and t['W'] == 4 and t['Cout'] == 64 and t['K'] == 4 and t['stride'] == 2 and t['pad_t'] == 1
+            and t['pad_l'] == 1 and d0.N == 16 * t['Cin']):
+      return
+    rows = self.lib.odin_neck_rows(self.B, d4.N, self.D, t['Cin'])
+    if rows <= 0:
+      return
+    if self.params[d4.w_off:].data_ptr() % 16 != 0:   # (the projection's rows are read as 16-byte loads)
+      return
+    self.neck, self.nk_rows = True, rows
+    ne = len(er)
+    # the layer below the convolution keeps the activation word of its output (the neck's input planes read it)
+    self.enc.y_word[ne - 3] = self.enc.aword(ne - 3)
+    if self.enc.descs[ne - 3] is not None:
+      self.enc.descs[ne - 3].y_amax = self.enc.y_word[ne - 3]
+    A = _lib.NeckArgs()
+    A.B, A.P, A.D, A.C0 = self.B, d4.N, self.D, t['Cin']
+    A.act2, A.act3, A.act4, A.act0, A.act1 = (ACT[er[-3].act], ACT[c3.act], ACT[d4.act], ACT[d0.act], ACT[t1.act])
+    A.seed = self.seed
+    A.x, A.x_amax = self.enc.outs[ne - 3].data_ptr(), self.enc.y_word[ne - 3]
+    A.w3, A.b3, A.y3 = self.enc.w(ne - 2).data_ptr(), self.enc.b(ne - 2).data_ptr(), self.enc.outs[ne - 2].data_ptr()
+    A.w4, A.b4, A.y4 = self.enc.w(ne - 1).data_ptr(), self.enc.b(ne - 1).data_ptr(), self.enc.outs[ne - 1].data_ptr()
+    A.wl, A.bl = self.params[self.lat_w_off:].data_ptr(), self.params[self.lat_b_off:].data_ptr()
+    A.eps = self.eps.data_ptr()
+    A.p, A.kl, A.fbmask = self.p.data_ptr(), self.kl.data_ptr(), self.fbmask.data_ptr()
+    A.w0, A.b0, A.y0 = self.dec.w(0).data_ptr(), self.dec.b(0).data_ptr(), self.dec.outs[0].data_ptr()
+    A.w1, A.b1, A.y1 = self.dec.w(1).data_ptr(), self.dec.b(1).data_ptr(), self.dec.outs[1].data_ptr()
+    self._nk = A
+    C0 = t['Cin']
+    self.nk_slab1 = torch.empty(rows, 16 * 64 * C0, **f32)
+    self.nk_slab0 = torch.empty(rows, self.D * 16 * C0 + 16 * C0, **f32)
+    self.nk_slabl = torch.empty(rows, d4.N * 2 * self.D + 2 * self.D, **f32)
+
+  def _neck_fwd(self, eps, st, y1_word: bool = True):
+    """one launch: conv3 .. deconv1 (the caller has run the encoder up to the layer below conv3)"""
+    A = self._nk
+    A.analytic, A.free_bits = int(self.analytic), float(self.free_bits)
+    A.step_dev = self.hp(N_HYPER)
+    A.eps_in = None if eps is None else self.eps.data_ptr()
+    A.z = self.z.data_ptr()   # (FactorVAE re-points z into the discriminator's input buffer after construction)
+    A.capacity = self.hp(H_CAP) if self.capacity_on else None
+    A.y1_amax = self.dec.y_word[1] if y1_word else None
+    self.lib.odin_neck_fwd(C.byref(A), st)
+
+  def _dec_first(self) -> int:
+    """the decoder layers below this index are back-propagated by the fused bottleneck launches"""
+    return 2 if self._bwd_neck() else int(self._bwd_block())
+
+  def _neck_bwd(self, dzx, tl, ts, st, jobs):
+    """conv3 .. deconv1 backward: ONE launch for the data-gradient chain and the three small weight gradients, then the
+    two large weight gradients (reductions over the whole batch) on their own kernels"""
+    lib, A, ne = self.lib, self._nk, len(self.enc_recs)
+    c3, d4, d0, t1 = self.enc_recs[-2], self.enc_recs[-1], self.dec_recs[0], self.dec_recs[1]
+    A.dy1 = self.dec.gouts[1].data_ptr()
+    A.klw = self.hp(H_KLW)
+    A.dz_extra, A.dloc_x, A.dscale_x = dzx, tl, ts
+    A.dz, A.dp = self.dz.data_ptr(), self.dp.data_ptr()
+    A.dh4, A.dy3, A.dx = (self.enc.gouts[ne - 1].data_ptr(), self.enc.gouts[ne - 2].data_ptr(),
+                          self.enc.gouts[ne - 3].data_ptr())
+    A.dh4_amax, A.dy3_amax, A.dx_amax = self.enc.set_top_word(True), self.enc.word(ne - 2), self.enc.word(ne - 3)
+    A.slab1, A.slab0, A.slabl = self.nk_slab1.data_ptr(), self.nk_slab0.data_ptr(), self.nk_slabl.data_ptr()
+    lib.odin_neck_bwd(C.byref(A), st)
+    rows = self.nk_rows
+    for slab, off in ((self.nk_slab1, t1.w_off), (self.nk_slab0, d0.w_off), (self.nk_slabl, self.lat_w_off)):
+      jobs.append(ReduceJob(slab.data_ptr(), self.grads[off:].data_ptr(), slab.shape[1], rows, slab.shape[1], 0))
+    # conv3's weight gradient (a reduction over all B * 16 pixels) and the projection's (over the batch)
+    wrows = C.c_int(0)
+    lib.odin_wgrad_pair_begin()   # (independent of each other: one launch where both are small-layer implicit GEMMs)
+    slab = self.enc.wslabs[ne - 2]
+    lib.odin_conv2d_wgrad(self.enc.outs[ne - 3].data_ptr(), self.enc.gouts[ne - 2].data_ptr(), slab.data_ptr(),
+                          C.byref(wrows), C.byref(self.enc.descs[ne - 2]), st)
+    jobs.append(ReduceJob(slab.data_ptr(), self.grads[c3.w_off:].data_ptr(), slab.shape[1], wrows.value, slab.shape[1], 0))
+    slab = self.enc.wslabs[ne - 1]
+    lib.odin_dense_bwd_ranged(self.enc.outs[ne - 2].data_ptr(), self.enc.gouts[ne - 1].data_ptr(), None, None, 0, None,
+                              None, None, slab.data_ptr(), C.byref(wrows), self.B, d4.K, d4.N, 1, 0,
+                              self.enc.dy_word[ne - 1], None, None, st)
+    lib.odin_wgrad_pair_end()
+    jobs.append(ReduceJob(slab.data_ptr(), self.grads[d4.w_off:].data_ptr(), slab.shape[1], wrows.value, slab.shape[1], 0))
+
+  def _bwd_neck(self) -> bool:
+    if not (self.neck and self._used_neck) or (self.is_dp and self.dp_buckets >= 2):
+      return False
+    # (measured, same-call A/Bs of round 6: with the 128-wide projection of the dSprites stack the backward launch wins
+    # 6 us per step; with the 256-wide one -- 1 MB of W4 streamed twice per workgroup -- round 5's launches are 2-3 us
+    # faster: profiles/r06_neck.txt)
+    return self._nk.P == 128 if self._neck_bwd_opt is None else bool(self._neck_bwd_opt)
+
   def _bwd_block(self) -> bool:
     # (two gradient buckets: the decoder's first Dense belongs to the bucket that is already being
     # all-reduced while the encoder's share runs -- keep the separate launches there)
@@ -901,6 +1024,14 @@ class VAEEngine:
     self._clear_stale_act_words(st)
     lw = self.params[self.lat_w_off:]
     lb = self.params[self.lat_b_off:]
+    if self.neck:
+      # conv3 .. deconv1 as ONE launch (neck.hip; the decoder's first two layers it also evaluates land in dec.outs[0 / 1],
+      # unused here -- and without touching the decoder's activation word)
+      if eps is not None and eps is not self.eps:
+        self.eps.copy_(eps)
+      self.enc.forward(x, st, upto=len(self.enc_recs) - 2)
+      self._neck_fwd(eps, st, y1_word=False)
+      return self.p, self.z
     if self.lat_block:
       # noise + projection + reparameterisation + KL as ONE launch (latent_block.hip; the decoder's first Dense it
       # also evaluates lands in dec.outs[0], unused here): three launches less than the separate kernels
@@ -974,11 +1105,18 @@ class VAEEngine:
     lw = self.params[self.lat_w_off:]
     lb = self.params[self.lat_b_off:]
     self._used_block = self.lat_block and fused
+    self._used_neck = self.neck and fused
     self._clear_stale_act_words(st)
     # (outs[0] of the decoder comes from the bottleneck launch in the fused step: no word for layer 1's input then)
     if len(self.dec_recs) > 1:
       self.dec.set_x_word(1, not self._used_block)
-    if self._used_block:
+    if self._used_neck:
+      if eps is not None and eps is not self.eps:
+        self.eps.copy_(eps)
+      self.enc.forward(x, st, upto=len(self.enc_recs) - 2)
+      self._neck_fwd(eps, st)
+      dec_in, dec_start = self.dec.outs[1], 2
+    elif self._used_block:
       if eps is not None and eps is not self.eps:
         self.eps.copy_(eps)
       h_e = self.enc.forward(x, st)
@@ -1190,7 +1328,7 @@ class VAEEngine:
       co, c1 = a.desc['Cout'], b.desc['Cout']
       jobs = self.dec.backward(self.z, self.dec.gouts[-2], st, dx_out=self.dz, last=nd - 2,
                                skip_bias_of_last=True, fork=fork,
-                               side_jobs=late_jobs if early else None, first=int(self._bwd_block()))
+                               side_jobs=late_jobs if early else None, first=self._dec_first())
       ts, stride = self.tail_slab, self.tail_slab.shape[1]
       # (dW1 | db1) of the 1x1 conv, then the bias gradient of the fused layer
       jobs.append(ReduceJob(ts.data_ptr(), self.grads[b.w_off:].data_ptr(), co * c1 + c1,
@@ -1201,7 +1339,7 @@ class VAEEngine:
       nd = len(self.dec_recs)
       a, b = self.dec_recs[-2], self.dec_recs[-1]
       jobs = self.dec.backward(self.z, self.dec.gouts[-2], st, dx_out=self.dz, last=nd - 2, fork=fork,
-                               side_jobs=late_jobs if early else None, first=int(self._bwd_block()))
+                               side_jobs=late_jobs if early else None, first=self._dec_first())
       hs = self.head_slab
       jobs.append(ReduceJob(hs.data_ptr(), self.grads[b.w_off:].data_ptr(), hs.shape[1], self.head_rows,
                             hs.shape[1], 0))  # (dW1 | db1) of the 1x1 head
@@ -1210,7 +1348,7 @@ class VAEEngine:
         jobs.append(ReduceJob(hc.data_ptr(), self.grads[a.b_off:].data_ptr(), a.b_n, self.head_rows, hc.shape[1], 0))
     else:
       jobs = self.dec.backward(self.z, self.dec.gouts[-1], st, dx_out=self.dz, fork=fork,
-                               side_jobs=late_jobs if early else None, first=int(self._bwd_block()))
+                               side_jobs=late_jobs if early else None, first=self._dec_first())
     if early and jobs:
       # the decoder's slabs (most of the slab bytes) are complete: reduce them on a side stream
       # while the encoder's backward pass keeps the matrix cores busy (the reduction is HBM-bound)
@@ -1232,7 +1370,11 @@ class VAEEngine:
     last = self.enc_recs[-1]
     aux_act = ACT[last.act]
     lw = self.params[self.lat_w_off:]
-    if self._bwd_block():
+    if self._bwd_neck():
+      ne = len(self.enc_recs)
+      self._neck_bwd(dzx, tl, ts, st, jobs)
+      jobs += self.enc.backward(self.x, self.enc.gouts[ne - 3], st, fork=fork, last=ne - 3)
+    elif self._bwd_block():
       r0 = self.dec_recs[0]
       lib.odin_latent_block_bwd(self.dec.gouts[0].data_ptr(), self.dec.w(0).data_ptr(), self.z.data_ptr(),
                                 self.p.data_ptr(), self.eps.data_ptr(), self.fbmask.data_ptr(),
@@ -1263,7 +1405,8 @@ class VAEEngine:
       if bslab is not None:
         jobs.append(ReduceJob(bslab.data_ptr(), self.grads[last.b_off:].data_ptr(), last.b_n,
                               rows.value, last.b_n, 0))
-    jobs += self.enc.backward(self.x, self.enc.gouts[-1], st, fork=fork)
+    if not self._bwd_neck():
+      jobs += self.enc.backward(self.x, self.enc.gouts[-1], st, fork=fork)
     jobs += late_jobs
     # the range words of the gradient tensors (their producers fold in with atomicMax, so every step starts from
     # zero): cleared by the step's LAST backward launch -- a reduction over zero slab rows writes zeros -- instead
@@ -1276,7 +1419,7 @@ class VAEEngine:
     self._jobs_keepalive = arr
     lib.odin_wgrad_planes_defer_end(st)   # (no-op unless backward() opened a collection)
     if self.debug_check_ranges:
-      self.dec.check_range_words()
+      self.dec.check_range_words(first=self._dec_first() - 1 if self._bwd_neck() else 0)
       self.enc.check_range_words()
     self._norm_parts = 0
     if getattr(self, '_fuse_norm_now', False) and not early:

@@ -1052,7 +1052,8 @@ class DiscPrograms:
     self.prog1 = NetProgram(lib, disc.recs, B1, device, disc.params, disc.grads, mr,
                             range_words=self.range_words[:nw], act_words=self.range_words[2 * nw:3 * nw])
     self.prog2 = NetProgram(lib, disc.recs, 2 * B1, device, disc.params, disc.grads, mr,
-                            range_words=self.range_words[nw:2 * nw], act_words=self.range_words[3 * nw:])
+                            range_words=self.range_words[nw:2 * nw], act_words=self.range_words[3 * nw:],
+                            direct_wgrad=True)
     self.tc = torch.zeros(1, **f32)
     self.dlogit1 = torch.zeros(B1, 1, **f32)
     self.dlogit1_value = None
@@ -1214,14 +1215,22 @@ class FactorVAE(AnnealingVAE):
       st = eng.stream()
       eng.forward(x1, eps, finalize=False)
       extra = None
+      # the ELBO finalisation (llk[B], loss, mean terms: nothing in the backward pass reads them) rides in the first
+      # launch of the VAE optimiser's update when one follows (engine.adam: _fin_pending), as in the plain VAE step
+      ride = training
       if use_tc:
         lg = disc.prog1.forward(eng.z, st)
         lib.odin_mean(lg.data_ptr(), B1, disc.tc.data_ptr(), st)
-        eng.finalize(tc_ptr=disc.tc.data_ptr())
+        if ride:
+          eng._fin_pending = (eng._llk_part_used.data_ptr(), eng.n_part, disc.tc.data_ptr())
+        else:
+          eng.finalize(tc_ptr=disc.tc.data_ptr())
         disc.prog1.backward(eng.z, disc.dlogit1, st, dx_out=disc.dz, data_only=True)
         extra = disc.dz
         if not training or self._is_pretraining:  # (no discriminator step behind this one to clear the words)
           lib.odin_range_reset(disc.range_words.data_ptr(), disc.range_words.numel() // RANGE_WORDS, st)
+      elif ride:
+        eng._fin_pending = (eng._llk_part_used.data_ptr(), eng.n_part, None)
       else:
         eng.finalize()
       if training:

@@ -222,7 +222,11 @@ def test_deconv2d_fwd_dgrad_wgrad(bk, request, B, H, W, Ci, Co, K, S, act):
                                        (256, 1024, 128, 'linear'), (37, 1000, 75, 'relu'),
                                        (128, 70, 1000, 'relu'), (64, 784, 512, 'relu'), (9, 2052, 33, 'linear'),
                                        # both widths >= 256, batch a multiple of 8: the two-plane GEMM (dense_h.hip), ragged N
-                                       (40, 264, 296, 'relu'), (32, 512, 256, 'linear')])
+                                       (40, 264, 296, 'relu'), (32, 512, 256, 'linear'),
+                                       # one thin side (thin_dense.hip): FactorVAE's first / last discriminator layers,
+                                       # ragged batches, every K bucket of the thin-K kernels, 1..4 thin-N outputs
+                                       (130, 6, 1000, 'relu'), (33, 10, 64, 'elu'), (7, 16, 260, 'relu'), (66, 31, 128, 'linear'),
+                                       (129, 1000, 1, 'linear'), (5, 260, 3, 'relu'), (64, 1024, 4, 'linear')])
 def test_dense(bk, B, K, N, act):
   L, T = bk.L, bk.T
   rng = np.random.default_rng(2)
@@ -581,8 +585,8 @@ def hipbk():
     # CelebA's encoder head: the instances the benchmarks run, held to the float64 oracle (too large for the
     # CPU simulator) -- `family` is the kernel family the dispatcher must have picked (both widths >= 256: the
     # two-plane GEMM of dense_h.hip; narrower layers: the fp32 implicit GEMM)
-    (128, 1000, 1000, 'relu', 'dense_h'), (256, 1000, 1000, 'relu', 'dense_h'), (128, 6, 1000, 'relu', None),
-    (128, 1000, 1, 'linear', None), (128, 784, 512, 'relu', 'dense_h'), (128, 512, 784, 'linear', 'dense_h'),
+    (128, 1000, 1000, 'relu', 'dense_h'), (256, 1000, 1000, 'relu', 'dense_h'), (128, 6, 1000, 'relu', 'thin_dense'),
+    (256, 6, 1000, 'relu', 'thin_dense'), (128, 1000, 1, 'linear', 'thin_dense'), (256, 1000, 1, 'linear', 'thin_dense'), (128, 784, 512, 'relu', 'dense_h'), (128, 512, 784, 'linear', 'dense_h'),
     (128, 512, 512, 'relu', 'dense_h'), (512, 4096, 512, 'linear', 'dense_h'), (256, 1024, 256, 'linear', 'dense_h'),
     (256, 1024, 128, 'linear', 'igemm')])
 def test_dense_at_benchmark_sizes(hipbk, B, K, N, act, family):

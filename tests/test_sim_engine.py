@@ -121,6 +121,34 @@ def test_first_deconv_with_any_latent_width(L, zdim):
   check_engine_vs_oracle(eng, model, P, x, eps, beta=2.0, steps=2, clip=100.0)
 
 
+def neck_spec(C=1, zdim=5, proj=128):
+  """the neck of the dSprites / Shapes3D stacks (image_networks.py:466-471, 494-502) under a shortened encoder / decoder:
+  ... -> [8, 8, 64] -> Conv2D(64, 4, 2) -> Flatten -> Dense(proj) | Dense(proj) -> (4, 4, proj / 16) -> deconv 64 -> ..."""
+  enc = [('center',), ('conv', 64, 4, 2, 'elu'), ('conv', 64, 4, 2, 'elu'), ('flatten',), ('dense', proj, 'linear')]
+  dec = [('dense', proj, 'linear'), ('reshape', (4, 4, proj // 16)), ('deconv', 64, 4, 2, 'elu'),
+         ('deconv', 8, 4, 2, 'elu'), ('conv', C, 1, 1, 'linear')]
+  return enc, dec, (16, 16, C), zdim
+
+
+@pytest.mark.parametrize('B,zdim,proj,kw', [(5, 5, 128, dict(beta=2.0)), (4, 6, 256, dict(beta=1.0, analytic=True, free_bits=0.3))])
+def test_neck_step_matches_oracle(L, B, zdim, proj, kw):
+  """conv3 .. deconv1 as one launch per direction (neck.hip) inside a whole training step, odd batch (a workgroup with
+  one sample) and odd latent width (misaligned decoder weights) included"""
+  enc, dec, in_shape, zd, x, eps = make_case(neck_spec(1, zdim, proj), 'bernoulli', B)
+  model = vo.OracleVAE(enc, dec, in_shape, zd, observation='bernoulli', **kw)
+  P = model.init_params(seed=6)
+  eng = VAEEngine(enc, dec, in_shape, zd, B, 'cpu', observation='bernoulli', lib=L,
+                  analytic=kw.get('analytic', False), free_bits=kw.get('free_bits'))
+  assert eng.neck
+  eng.debug_check_ranges = True
+  check_engine_vs_oracle(eng, model, P, x, eps, beta=kw['beta'], steps=2, clip=100.0)
+  # and the same step without the fusion gives the same numbers to fp32 rounding
+  eng0 = VAEEngine(enc, dec, in_shape, zd, B, 'cpu', observation='bernoulli', lib=L, neck=False,
+                   analytic=kw.get('analytic', False), free_bits=kw.get('free_bits'))
+  assert not eng0.neck
+  check_engine_vs_oracle(eng0, model, P, x, eps, beta=kw['beta'], steps=2, clip=100.0)
+
+
 @pytest.mark.parametrize('name,enc,dec,in_shape,B', CUSTOM)
 def test_custom_decoders_keep_valid_range_words(L, name, enc, dec, in_shape, B):
   """every range word the engine hands to a consumer bounds its tensor (checked before the words are cleared), the
