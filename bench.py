@@ -127,8 +127,12 @@ def profile_ops(eng, reps=20):
     return e0.elapsed_time(e1) / reps * 1e-3
 
   nd = len(eng.dec.recs)
+  ne = len(eng.enc.recs)
   fused = getattr(eng, 'fused_tail', False)
   head = getattr(eng, 'gauss_head', False)   # the Gaussian 1x1 head runs as ONE launch inside the step
+  neck = bool(getattr(eng, 'neck', False))   # conv3 .. deconv1 run as ONE launch per direction (neck.hip)
+  neck_bwd = neck and (eng._nk.P == 128 if eng._neck_bwd_opt is None else bool(eng._neck_bwd_opt))
+  neck_fl = [0.0, 0.0]                       # FLOPs of the launches the neck replaces (forward, backward)
   for net, prog, x0 in (('enc', eng.enc, eng.x), ('dec', eng.dec, eng.z)):
     for i, r in enumerate(prog.recs):
       xin = x0 if i == 0 else prog.outs[i - 1]
@@ -176,6 +180,17 @@ def profile_ops(eng, reps=20):
         ops = [] if i == nd - 1 else [o for o in ops if o[0] != 'fwd']
       if head and net == 'dec' and i == nd - 1:
         ops = []  # (replaced by odin_gaussian_head_fwd_bwd, timed below)
+      if neck and ((net == 'enc' and i >= ne - 2) or (net == 'dec' and i <= 1)):
+        # inside the step these launches are the neck's: forward always; backward (data gradients of all four layers,
+        # weight gradients of the decoder's two) where the engine uses the neck's backward launch
+        neck_fl[0] += fl
+        keep = []
+        if neck_bwd:
+          neck_fl[1] += fl * (2 if net == 'dec' else 1)
+          keep = [o for o in ops if o[0] == 'wgrad'] if net == 'enc' else []
+        else:
+          keep = [o for o in ops if o[0] != 'fwd']
+        ops = keep
       for tag, fn in ops:
         if fn is None:
           continue
@@ -198,6 +213,21 @@ def profile_ops(eng, reps=20):
     out.append(dict(layer=f'dec{nd - 2}+{nd - 1}:tail', op='fwd+elbo', us=t * 1e6,
                     gflop=fl * 1e-9, tflops=fl / t * 1e-12, path=lib.odin_debug_last_path().decode(),
                     mfma_gflop=conv_flops(a, B) * 1e-9))
+  if neck:
+    t = timeit(lambda: eng._neck_fwd(None, st))
+    out.append(dict(layer='neck', op='fwd', us=t * 1e6, gflop=neck_fl[0] * 1e-9, tflops=neck_fl[0] / t * 1e-12,
+                    path='neck_fwd'))
+    if neck_bwd:
+      A = eng._nk
+      A.dy1, A.klw = eng.dec.gouts[1].data_ptr(), eng.hp(6)
+      A.dz_extra = A.dloc_x = A.dscale_x = None
+      A.dz, A.dp = eng.dz.data_ptr(), eng.dp.data_ptr()
+      A.dh4, A.dy3, A.dx = eng.enc.gouts[ne - 1].data_ptr(), eng.enc.gouts[ne - 2].data_ptr(), eng.enc.gouts[ne - 3].data_ptr()
+      A.dh4_amax = A.dy3_amax = A.dx_amax = None
+      A.slab1, A.slab0, A.slabl = eng.nk_slab1.data_ptr(), eng.nk_slab0.data_ptr(), eng.nk_slabl.data_ptr()
+      t = timeit(lambda: lib.odin_neck_bwd(C.byref(A), st))
+      out.append(dict(layer='neck', op='bwd', us=t * 1e6, gflop=neck_fl[1] * 1e-9, tflops=neck_fl[1] / t * 1e-12,
+                      path='neck_bwd'))
   if head:
     a, bb = eng.dec.recs[-2], eng.dec.recs[-1]
     Cc = eng.in_shape[-1]
@@ -440,16 +470,21 @@ def exact_fp32_step(device, workload='dsprites_betavae_b256', steps=50):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert math.isfinite(out[0].item()) and eng.flag.item() == 0
-    paths = sorted({o.get('path', '') for o in profile_ops(eng)})
+    ops = profile_ops(eng)
+    paths = sorted({o.get('path', '') for o in ops})
     assert not any(p.endswith('(f16x2)') for p in paths), paths
+    roof, stack = dominant_rooflines(ops)
   finally:
     if had is None:
       del os.environ['ODIN_EXACT_FP32']
     else:
       os.environ['ODIN_EXACT_FP32'] = had
   res = dict(workload=workload, ms_per_step=round(dt / steps * 1e3, 4), images_per_sec=round(B * steps / dt, 1),
-             steps=steps, kernel_families=paths,
-             note='ODIN_EXACT_FP32=1: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 everywhere (IEEE fp32 products)')
+             steps=steps, kernel_families=paths, conv_stack=stack, roofline=roof,
+             in_step_conv_frac=round(stack['gflop'] / (dt / steps) * 1e-3 / PEAK_MFMA_F32_TFLOPS, 4),
+             note='ODIN_EXACT_FP32=1: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 everywhere (IEEE fp32 products); roofline = its '
+                  'dominant launch against the dense fp32 MFMA peak (157.3 TFLOP/s), conv_stack = stand-alone sum of its '
+                  'conv / dense launches, in_step_conv_frac = the same FLOPs over the step time')
   del eng
   torch.cuda.empty_cache()
   return res
@@ -805,6 +840,13 @@ def main():
       obj['algorithmic_bytes'] = ent.get('algorithmic_bytes')
       obj['traffic_source'] = 'profiles/' + os.path.basename(pmc_file)
       obj['traffic_measured_in_this_run'] = False  # (PMC counters cannot be collected inside this process)
+      if ent.get('us_in_graph'):
+        # what the STEP pays for this launch: its average duration inside the captured graph under rocprofv3
+        # (profiles/<round>_kernel_stats.csv), a few us longer than the stand-alone HIP-event time of this run
+        obj['us_in_graph'] = ent['us_in_graph']
+        obj['us_in_graph_source'] = ent.get('us_in_graph_source')
+        if ent.get('algorithmic_bytes'):
+          obj['frac_in_graph'] = round(ent['algorithmic_bytes'] / (ent['us_in_graph'] * 1e-6) * 1e-9 / PEAK_HBM_GBS, 4)
 
   attach_traffic(roofline)
   roofline_split = None

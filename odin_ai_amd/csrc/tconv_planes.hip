@@ -58,6 +58,7 @@ struct TPParams {
   const unsigned* in_amax;  // SC instances: the input is a gradient tensor; its range word (odin_device.h)
   unsigned* out_amax;       // EPI 2 / 3: range word of `out`, a gradient tensor (may be null)
   long long* stamps;   // diagnostics: s_memtime stamps of workgroup 0 (wave 0: [0,32), wave 4: [32,64))
+  int part_off;        // PL instances: byte offset (dynamic LDS) of the partial-sum buffer [tile][q][thread] x 16 bytes
 };
 
 #if defined(ODIN_SIM) || !defined(ODIN_DIAG)  // in-kernel stamps: diagnostics build only (make diag)
@@ -129,7 +130,10 @@ struct TpItem {
 // (odin_device.h: odin_act_needs_scale): a wave-uniform flag, one scalar branch around each split and around the
 // accumulator combine.  (Round 5's first form held two whole bodies behind ONE branch at the top of the kernel: every
 // launch then waited for the 32 scalar loads of the word before its first weight load -- +1.5 us per launch.)
-template <int EPI, int C1, int W, int DBG = 0, bool ACC = false, int SCM = 0>
+// PL (round 6): the raw partial sums of the first of two reduction passes stay in LDS ([tile][q][thread] x 16 bytes, the
+// SAME thread reads them back in the second pass) instead of travelling through `out`: decoder3's forward moved 120 MB
+// for 50 MB of algorithmic traffic that way (PMC, profiles/r05_pmc_traffic.json).
+template <int EPI, int C1, int W, int DBG = 0, bool ACC = false, int SCM = 0, bool PL = false>
 __device__ __forceinline__ void tp_body(const TPParams& p) {
   constexpr int NPL = TP_NPL;
   constexpr int RP = 64 / W;              // input rows per tile
@@ -416,9 +420,16 @@ __device__ __forceinline__ void tp_body(const TPParams& p) {
   // (the bias sits in the main accumulator from the tile's first MFMA on -- biasv below -- so the epilogue adds none:
   // 16 VALU instructions less per tile and wave)
   auto elu_r = [&](int r) { elu_b(r, 0.f); };
+  char* plds = smem + p.part_off + tid * 16;   // (PL) this thread's 16-byte slot of a (tile, q) block of 512
+  int tileP_loc = 0;                            // (PL) the previous tile's index inside this workgroup
   auto store_q = [&](int q) __attribute__((always_inline)) {
     if (DBG & 1) return;
     if (EPI >= 1) amx = odin_amax3(odin_amax3(amx, pa[4 * q], pa[4 * q + 1]), pa[4 * q + 2], pa[4 * q + 3]);
+    if (PL && EPI == 0) {
+      *reinterpret_cast<float4*>(plds + (tileP_loc * 4 + q) * 8192) =
+          make_float4(pa[4 * q], pa[4 * q + 1], pa[4 * q + 2], pa[4 * q + 3]);
+      return;
+    }
     odin_run_store4s(OUT, out_lane + 32 * q, tileP_out,
                      make_float4(pa[4 * q], pa[4 * q + 1], pa[4 * q + 2], pa[4 * q + 3]));
   };
@@ -659,7 +670,11 @@ __device__ __forceinline__ void tp_body(const TPParams& p) {
 #pragma unroll
           for (int oc = 0; oc < C1; ++oc) tgtN[oc] = odin_run_load1s(TG, tgt_lane + 4 * oc, tile_tgt);
         }
-        if (ACC) {
+        if (ACC && PL) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pvN[q] = *reinterpret_cast<const float4*>(plds + ((T - T0) * 4 + q) * 8192);
+        }
+        if (ACC && !PL) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             pvN[q] = odin_run_load4s(OUT, out_lane + 32 * q, tile_out);
@@ -702,6 +717,7 @@ __device__ __forceinline__ void tp_body(const TPParams& p) {
     }
     tileP_out = tile_out;
     tileP_tgt = tile_tgt;
+    tileP_loc = T - T0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { axP[q] = axN[q]; pvP[q] = pvN[q]; }
 #pragma unroll
@@ -826,14 +842,14 @@ __global__ __launch_bounds__(512) void tconv_planes_kernel(TPParams p) {
 // first pass are written to `out` and read back in the second pass by the SAME thread (same wave roles, same tile
 // walk); the fence + barrier between the passes also keeps the second prologue's LDS writes behind the first pass's
 // last LDS reads.
-template <int EPI, int W, int SCM>
+template <int EPI, int W, int SCM, bool PL>
 __global__ __launch_bounds__(512) void tconv_planes2_kernel(TPParams p) {
   {
     TPParams q = p;
     q.colsum = nullptr;
     q.out_amax = nullptr;
     q.ci_off = 0;
-    tp_body<0, 1, W, 0, false, SCM>(q);
+    tp_body<0, 1, W, 0, false, SCM, PL>(q);
   }
   // (the same thread reads back what it wrote, through the same CU's write-through L1 and its XCD's L2: a
   // workgroup-scope fence orders it; a device-scope __threadfence() writes back and invalidates the whole L2 of the
@@ -844,7 +860,7 @@ __global__ __launch_bounds__(512) void tconv_planes2_kernel(TPParams p) {
 #endif
   __syncthreads();
   p.ci_off = 32;
-  tp_body<EPI, 1, W, 0, true, SCM>(p);
+  tp_body<EPI, 1, W, 0, true, SCM, PL>(p);
 }
 
 // LDS: weight planes + row ring + the fill table (rows per fill x 8 bytes per fill, tiles + 3 fills); 4.3 KB are static
@@ -907,24 +923,39 @@ int tp_launch_w(const TPParams& p, int W, dim3 grid, void* stream) {
   return odin_check_launch("tconv_planes(f16x2)");
 }
 
-template <int EPI, int SC>
-int tp_launch2_w(const TPParams& p, int W, dim3 grid, void* stream) {
-  const size_t lds = (size_t)tp_ring_bytes(W) + (size_t)(p.tiles_per_wg + 3) * tp_fill_bytes(W);
+// the two-pass kernels: dynamic LDS up to 160 000 bytes (2 x 1.2 KB of static arrays on top: 160 KiB per CU)
+constexpr int TP2_LDS_MAX = 160000;
+// tiles per workgroup whose first-pass partial sums (32 KB per tile) fit in LDS beside the weight planes, the ring and the
+// fill table; 0: none
+int tp_pl_tiles(int W) {
+  const int free_b = TP2_LDS_MAX - tp_ring_bytes(W) - 8 * tp_fill_bytes(W);
+  return free_b < 32768 ? 0 : free_b / 32768;
+}
+
+template <int EPI, int SC, bool PL>
+int tp_launch2_w(const TPParams& p0, int W, dim3 grid, void* stream) {
+  TPParams p = p0;
+  size_t lds = (size_t)tp_ring_bytes(W) + (size_t)(p.tiles_per_wg + 3) * tp_fill_bytes(W);
+  if (PL) {
+    lds = (lds + 15) & ~(size_t)15;
+    p.part_off = (int)lds;
+    lds += (size_t)p.tiles_per_wg * 32768;
+  }
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    const void* fns[3] = {reinterpret_cast<const void*>(&tconv_planes2_kernel<EPI, 32, SC>),
-                          reinterpret_cast<const void*>(&tconv_planes2_kernel<EPI, 16, SC>),
-                          reinterpret_cast<const void*>(&tconv_planes2_kernel<EPI, 8, SC>)};
+    const void* fns[3] = {reinterpret_cast<const void*>(&tconv_planes2_kernel<EPI, 32, SC, PL>),
+                          reinterpret_cast<const void*>(&tconv_planes2_kernel<EPI, 16, SC, PL>),
+                          reinterpret_cast<const void*>(&tconv_planes2_kernel<EPI, 8, SC, PL>)};
     for (int i = 0; i < 3; ++i)
-      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS_MAX) != hipSuccess)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, TP2_LDS_MAX) != hipSuccess)
         (void)hipGetLastError();
     attr_done = true;
   }
 #endif
-  if (W == 32) ODIN_LAUNCH((tconv_planes2_kernel<EPI, 32, SC>), grid, dim3(512), lds, stream, p);
-  else if (W == 16) ODIN_LAUNCH((tconv_planes2_kernel<EPI, 16, SC>), grid, dim3(512), lds, stream, p);
-  else ODIN_LAUNCH((tconv_planes2_kernel<EPI, 8, SC>), grid, dim3(512), lds, stream, p);
+  if (W == 32) ODIN_LAUNCH((tconv_planes2_kernel<EPI, 32, SC, PL>), grid, dim3(512), lds, stream, p);
+  else if (W == 16) ODIN_LAUNCH((tconv_planes2_kernel<EPI, 16, SC, PL>), grid, dim3(512), lds, stream, p);
+  else ODIN_LAUNCH((tconv_planes2_kernel<EPI, 8, SC, PL>), grid, dim3(512), lds, stream, p);
   return odin_check_launch("tconv_planes(f16x2)");
 }
 
@@ -966,6 +997,16 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
   const int gy = CO / 32;
   p.tiles_per_wg = tp_tiles_per_wg(W, p.n_tiles, gy);
   if (p.tiles_per_wg <= 0) return odin_fail(-2, "tconv_planes: too many tiles for the fill table");
+  // 64 reduction channels: the first pass's partial sums stay in LDS when a workgroup's tiles fit there -- with fewer
+  // tiles per workgroup (more workgroups than CUs) if need be, as long as the slab rows allow
+  bool pl = false;
+  if (CI == 64 && !ODIN_DIAG_ENV("ODIN_TP_NOPL")) {
+    const int cap = tp_pl_tiles(W);
+    if (cap >= 1) {
+      int tpw = p.tiles_per_wg < cap ? p.tiles_per_wg : cap;
+      if ((p.n_tiles + tpw - 1) / tpw <= ODIN_MAX_COLSUM_BLOCKS) { p.tiles_per_wg = tpw; pl = true; }
+    }
+  }
   const int gx = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
   if (rows_out) *rows_out = gx;
   if (n_part_out) *n_part_out = p.tiles_per_img;
@@ -992,8 +1033,12 @@ int odin_tconv_planes_launch(const float* in, const float* w, const float* bias,
       return epi == 1 ? tp_launch_w<1, 1, true, 0>(p, W, grid, stream) : tp_launch_w<2, 1, true, 1>(p, W, grid, stream);
     }
 #endif
-    if (epi == 1) return aw ? tp_launch2_w<1, 2>(p, W, grid, stream) : tp_launch2_w<1, 0>(p, W, grid, stream);
-    return tp_launch2_w<2, 1>(p, W, grid, stream);
+    if (pl) {
+      if (epi == 1) return aw ? tp_launch2_w<1, 2, true>(p, W, grid, stream) : tp_launch2_w<1, 0, true>(p, W, grid, stream);
+      return tp_launch2_w<2, 1, true>(p, W, grid, stream);
+    }
+    if (epi == 1) return aw ? tp_launch2_w<1, 2, false>(p, W, grid, stream) : tp_launch2_w<1, 0, false>(p, W, grid, stream);
+    return tp_launch2_w<2, 1, false>(p, W, grid, stream);
   }
   if (epi == 1) return aw ? tp_launch_w<1, 1, false, 2>(p, W, grid, stream) : tp_launch_w<1, 1, false, 0>(p, W, grid, stream);
   if (epi == 2) return tp_launch_w<2, 1, false, 1>(p, W, grid, stream);

@@ -130,7 +130,7 @@ def neck_spec(C=1, zdim=5, proj=128):
   return enc, dec, (16, 16, C), zdim
 
 
-@pytest.mark.parametrize('B,zdim,proj,kw', [(5, 5, 128, dict(beta=2.0)), (4, 6, 256, dict(beta=1.0, analytic=True, free_bits=0.3))])
+@pytest.mark.parametrize('B,zdim,proj,kw', [(3, 5, 128, dict(beta=2.0)), (2, 6, 256, dict(beta=1.0, analytic=True, free_bits=0.3))])
 def test_neck_step_matches_oracle(L, B, zdim, proj, kw):
   """conv3 .. deconv1 as one launch per direction (neck.hip) inside a whole training step, odd batch (a workgroup with
   one sample) and odd latent width (misaligned decoder weights) included"""
@@ -141,12 +141,16 @@ def test_neck_step_matches_oracle(L, B, zdim, proj, kw):
                   analytic=kw.get('analytic', False), free_bits=kw.get('free_bits'))
   assert eng.neck
   eng.debug_check_ranges = True
+  # (the 256-wide projection keeps round 5's backward launches by default -- measured faster -- here both directions run)
+  eng._neck_bwd_opt = True
   check_engine_vs_oracle(eng, model, P, x, eps, beta=kw['beta'], steps=2, clip=100.0)
-  # and the same step without the fusion gives the same numbers to fp32 rounding
-  eng0 = VAEEngine(enc, dec, in_shape, zd, B, 'cpu', observation='bernoulli', lib=L, neck=False,
-                   analytic=kw.get('analytic', False), free_bits=kw.get('free_bits'))
-  assert not eng0.neck
-  check_engine_vs_oracle(eng0, model, P, x, eps, beta=kw['beta'], steps=2, clip=100.0)
+  if proj == 256:
+    # the default policy for this width: neck forward, round 5's backward launches on the tensors it left
+    eng1 = VAEEngine(enc, dec, in_shape, zd, B, 'cpu', observation='bernoulli', lib=L,
+                     analytic=kw.get('analytic', False), free_bits=kw.get('free_bits'))
+    assert eng1.neck and eng1._neck_bwd_opt is None
+    check_engine_vs_oracle(eng1, model, P, x, eps, beta=kw['beta'], steps=1, clip=100.0)
+    assert not eng1._bwd_neck()
 
 
 @pytest.mark.parametrize('name,enc,dec,in_shape,B', CUSTOM)

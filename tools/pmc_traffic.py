@@ -7,7 +7,7 @@ MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts 128-byte reads at 64 by
 WRITE_SIZE exact), next to the algorithmic bytes of the launch."""
 import json, re, sys
 B = 256
-TAG = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 
 
 COUNTS = {}  # file -> {(kernel, grid): dispatches in that pass} (the passes run different numbers of steps)
@@ -30,22 +30,29 @@ kernels = {
     # bench op name: (kernel-name prefix, grid, description, algorithmic bytes)
     'dec4:deconv:bwd': ('bwd_planes_pc_kernel<32>', '196608',
                         'weight + data gradient of the last Conv2DTranspose in one launch (bwd_planes: dy fetched and split once), dSprites B=256',
-                        # dY [B,64,64,32] + x [B,32,32,32] read (aux IS x in the step: one tensor), dx [B,32,32,32] + slabs
-                        # [256 rows][16*32*32] written
-                        (B * 64 * 64 * 32 + 2 * B * 32 * 32 * 32) * f4 + 256 * 16 * 32 * 32 * f4),
+                        # dY [B,64,64,32] + x [B,32,32,32] read (aux IS x in the step: one tensor), dx [B,32,32,32] written.
+                        # (The 256 slab rows of the weight gradient -- 16.8 MB -- are an implementation artefact, not
+                        # algorithmic traffic: priced out since round 6)
+                        (B * 64 * 64 * 32 + 2 * B * 32 * 32 * 32) * f4),
     'dec4+5:tail:fwd+elbo': ('tconv_planes_kernel<3, 1, 32, 0, false, 2', '131072',
                              'fused decoder tail (tconv_planes, fp32 operands as 2 f16 planes)',
                              # x [B,32,32,32] + target [B,64,64,1] read; logits + d(pre-activation) [B,64,64,32] written
                              (B * 32 * 32 * 32 + 2 * B * 64 * 64 + B * 64 * 64 * 32) * f4),
-    'enc3:conv:fwd': ('igemm_kernel<4, false, false', '65536',
-                      'encoder3 forward (igemm: implicit GEMM, both operands straight from L2, fp32 MFMA)',
-                      # x [B,8,8,64] read + y [B,4,4,64] written + weights 16*64*64
-                      (B * 8 * 8 * 64 + B * 4 * 4 * 64 + 16 * 64 * 64) * f4),
+    'neck:fwd': ('neck_fwd_kernel<8>', '131072',
+                 'conv3 + projection + latent block + decoder projection + deconv1 in one launch (neck.hip)',
+                 # x [B,8,8,64] read; y3 [B,4,4,64], y4 [B,128], p / z / y0, y1 [B,8,8,64] written; the weights once
+                 (2 * B * 8 * 8 * 64 + B * 4 * 4 * 64 + B * (128 + 20 + 10 + 128) + 16 * 64 * 64 + 1024 * 128 +
+                  128 * 20 + 10 * 128 + 16 * 64 * 8) * f4),
     'dec2:deconv:bwd': ('bwd_planes2_kernel<8, 2', '131072',
                         'weight + data gradient of decoder2 (64 -> 64 channels, 8x8 -> 16x16): both 32-channel passes in one launch (bwd_planes)',
                         # dY [B,16,16,64] + x [B,8,8,64] read (twice: once per pass; aux IS x); partial sums written and read back,
-                        # dx written: [B,8,8,64] each; slabs [128 rows][16*64*64]
-                        (B * 16 * 16 * 64 + 5 * B * 8 * 8 * 64) * f4 + 128 * 16 * 64 * 64 * f4),
+                        # dx written: [B,8,8,64] each (slab rows priced out, see above)
+                        (B * 16 * 16 * 64 + 2 * B * 8 * 8 * 64) * f4),
+    'dec3:deconv:fwd': ('tconv_planes2_kernel<1, 16, 2', '262144',
+                        'decoder3 forward (64 -> 32 channels, 16x16 -> 32x32): both reduction passes in one launch, the first '
+                        "pass's partial sums in LDS (round 6)",
+                        # x [B,16,16,64] read, y [B,32,32,32] written
+                        (B * 16 * 16 * 64 + B * 32 * 32 * 32) * f4),
 }
 
 
@@ -53,6 +60,17 @@ def find(tab, prefix, grid):
   for (k, key), v in tab.items():
     if k.startswith(prefix) and key.split('/')[0] == grid:
       return k, v
+  return None, None
+
+
+def stats_us(prefix):
+  """average in-graph duration (us) of the kernel from the rocprofv3 --stats table of the same run"""
+  import csv, glob
+  for fn in glob.glob(f'gpurun_out/{TAG}_final_prof_kernel_stats.csv') + glob.glob(f'profiles/{TAG}_kernel_stats.csv'):
+    for r in csv.DictReader(open(fn)):
+      nm = r['Name'].replace('void ', '').replace('(anonymous namespace)::', '')
+      if nm.startswith(prefix):
+        return round(float(r['AverageNs']) / 1e3, 2), fn
   return None, None
 
 
@@ -71,6 +89,10 @@ for op, (k, key, desc, alg) in kernels.items():
                  source=f'profiles/{TAG}_pmc_FETCH_SIZE.txt + {TAG}_pmc_WRITE_SIZE.txt (separate --pmc passes of '
                         '`bench.py --steps 20 --warmup 5`); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 '
                         'reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM section)')
+  us, src = stats_us(k.split('(')[0] if '(' in k else k)
+  if us is not None:
+    res[op]['us_in_graph'] = us
+    res[op]['us_in_graph_source'] = f'profiles/{TAG}_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py: average over the replayed graphs)'
 # the whole step: every kernel of the pass that ran once (or k times) per step -- the first-layer convolution runs
 # exactly once per step and gives the step count of the pass; stand-alone probes and torch kernels have other counts
 def step_launches(fn):
