@@ -554,6 +554,12 @@ int odin_debug_set_wgrad_stamps(void* buf);
 /* diagnostics: workgroup 0 of odin_neck_fwd / _bwd records 100 MHz wall-clock stamps at its phase boundaries into
  * buf[0..6] / buf[8..17] (int64, device memory); NULL: off */
 int odin_debug_set_neck_stamps(void* buf);
+/* diagnostics: launch shape of the persistent Bernoulli ELBO kernel (workgroups, chunks in flight per wave, 1 = the
+ * software-pipelined body); a non-positive / negative field keeps its value (tools/elbo_sweep6.py) */
+int odin_debug_elbo_shape(int blocks, int U, int pipelined);
+/* diagnostics: workgroup (0, 0) of odin_stft_mel_db_frames records 100 MHz wall-clock stamps (per pass: start, staged,
+ * FFT done, power spectrum done; then the end of its last pass) into buf (int64, device memory, >= 64 entries); NULL: off */
+int odin_debug_set_mel_stamps(void* buf);
 
 /* ---- HIP-graph helpers (capture a sequence of the calls above, replay per step) ------- */
 int odin_graph_begin(void* stream);

@@ -134,6 +134,8 @@ SIGNATURES = {
     'odin_debug_set_stamps': [P],
     'odin_debug_set_wgrad_stamps': [P],
     'odin_debug_set_neck_stamps': [P],
+    'odin_debug_elbo_shape': [I, I, I],
+    'odin_debug_set_mel_stamps': [P],
     'odin_graph_begin': [P],
     'odin_graph_end': [P, C.POINTER(C.c_void_p)],
     'odin_graph_launch': [P, P],

@@ -64,7 +64,7 @@ __device__ __forceinline__ void dh_split8(const float (&v)[8], float s, float s2
 // NW waves split the k-steps of one 32 x 32 tile (step s -> wave s % NW); SCA / SCB: that operand is a gradient
 // AS (weight gradient only): the activation operand A comes with its own range word and power of two
 template <int NW, bool A_KC, bool B_KC, bool SCA, bool SCB, bool AS = false>
-__global__ __launch_bounds__(NW * 64) void dense_h_kernel(DHParams p) {
+__device__ __forceinline__ void dense_h_body(const DHParams& p, int bx, int by, int wg) {
   __shared__ float red[NW * 16 * 64];
   __shared__ float cred[NW * 32 + 16];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NW * 64) void dense_h_kernel(DHParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
   const int l31 = lane & 31, h = lane >> 5;
-  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int i0 = by * 32, j0 = bx * 32;
   const int ia = i0 + l31, jb = j0 + l31;
   const bool a_ok = ia < p.M, b_ok = jb < p.N;
   const int nsteps = (p.K + 15) >> 4;
@@ -183,11 +183,36 @@ __global__ __launch_bounds__(NW * 64) void dense_h_kernel(DHParams p) {
   }
   if (p.out_amax != nullptr) {
     __syncthreads();
-    odin_amax_commit_wg(p.out_amax, amx, tid, NW * 64, cred, blockIdx.x + gridDim.x * blockIdx.y);
-  } else if (!A_KC && !B_KC && p.colsum != nullptr && blockIdx.y == 0 && wave == 0 && h == 0 && b_ok) {
+    odin_amax_commit_wg(p.out_amax, amx, tid, NW * 64, cred, (unsigned)wg);
+  } else if (!A_KC && !B_KC && p.colsum != nullptr && by == 0 && wave == 0 && h == 0 && b_ok) {
     float t = 0.f;
     for (int w = 0; w < NW; ++w) t += cred[w * 32 + l31];
     p.colsum[jb] = t;  // (sums of the raw fp32 values: no plane scale)
+  }
+}
+
+template <int NW, bool A_KC, bool B_KC, bool SCA, bool SCB, bool AS = false>
+__global__ __launch_bounds__(NW * 64) void dense_h_kernel(DHParams p) {
+  dense_h_body<NW, A_KC, B_KC, SCA, SCB, AS>(p, (int)blockIdx.x, (int)blockIdx.y, (int)(blockIdx.x + gridDim.x * blockIdx.y));
+}
+
+// A layer's data gradient and weight gradient in ONE launch (round 6): both read dy, neither reads the other's result;
+// as launches of their own they took 9.5 + 11.5 us per 1000 x 1000 layer of FactorVAE's discriminator step, mostly
+// launch floor and the first round trip of a dependent chain.  Workgroups [0, nd) run the data gradient (NWD waves per
+// tile), the rest the weight gradient (NWW waves; the surplus waves of the wider block leave at once: a finished wave
+// does not take part in s_barrier).  The same bodies on the same tiles: results bit-identical to the two launches.
+template <int NWD, int NWW, bool AS>
+__global__ __launch_bounds__((NWD > NWW ? NWD : NWW) * 64) void dense_h_pair_kernel(DHParams pd, DHParams pw, int nd, int gdx,
+                                                                                    int gwx) {
+  const int id = (int)blockIdx.x;
+  if (id < nd) {
+    if (NWD < NWW && (int)threadIdx.x >= NWD * 64) return;
+    const int by = id / gdx;
+    dense_h_body<NWD, true, true, true, false, false>(pd, id - by * gdx, by, id);
+  } else {
+    if (NWW < NWD && (int)threadIdx.x >= NWW * 64) return;
+    const int r = id - nd, by = r / gwx;
+    dense_h_body<NWW, false, false, false, true, AS>(pw, r - by * gwx, by, r);
   }
 }
 
@@ -250,6 +275,57 @@ int odin_dense_h_dgrad(const float* dy, const float* w, const float* aux, int au
   if (p.g_amax == nullptr) return odin_fail(-3, "dense_h dgrad: no range word for dy");
   p.out_amax = dx_amax;
   return dh_launch<true, true, true, false>(p, dh_waves(B, K, N, 1), stream);
+}
+
+static void dh_fill_dgrad(DHParams& p, const float* dy, const float* w, const float* aux, int aux_act, float* dx, int B,
+                          int K, int N, const uint32_t* g_amax, uint32_t* dx_amax) {
+  memset(&p, 0, sizeof(p));
+  p.A = dy; p.B = w; p.C = dx; p.aux = (aux != nullptr && aux_act != 0) ? aux : nullptr; p.aux_act = aux_act;
+  p.M = B; p.N = K; p.K = N; p.lda = N; p.ldb = N; p.ldc = K;
+  p.g_amax = g_amax; p.out_amax = dx_amax;
+}
+static void dh_fill_wgrad(DHParams& p, const float* x, const float* dy, float* slab, int B, int K, int N,
+                          const uint32_t* g_amax, const uint32_t* x_amax) {
+  memset(&p, 0, sizeof(p));
+  p.A = x; p.B = dy; p.C = slab; p.colsum = slab + (size_t)K * N;
+  p.M = K; p.N = N; p.K = B; p.lda = K; p.ldb = N; p.ldc = N;
+  p.g_amax = g_amax; p.a_amax = x_amax;
+}
+
+// weight gradient (one complete slab row) + data gradient of a layer in ONE launch; dy_amax as the two calls
+int odin_dense_h_bwd_pair(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                          float* slab, int B, int K, int N, const uint32_t* dy_amax, uint32_t* dx_amax,
+                          const uint32_t* x_amax, void* stream) {
+  const uint32_t* g = odin_range_word_of(dy, (size_t)B * N, dy_amax, stream);
+  if (g == nullptr) return odin_fail(-3, "dense_h bwd: no range word for dy");
+  DHParams pd, pw;
+  dh_fill_dgrad(pd, dy, w, aux, aux_act, dx, B, K, N, g, dx_amax);
+  dh_fill_wgrad(pw, x, dy, slab, B, K, N, g, x_amax);
+  const int nwd = dh_waves(B, K, N, 1), nww = dh_waves(K, N, B, 2);
+#ifndef ODIN_SIM  // (the simulator's barrier counts every thread of the block: the roles keep their own launches there)
+  if ((nwd == 8 || nwd == 4) && (nww == 2 || nww == 4 || nww == 1)) {
+    const int gdx = (K + 31) / 32, gdy = (B + 31) / 32, gwx = (N + 31) / 32, gwy = (K + 31) / 32;
+    const int nd = gdx * gdy, nw = gwx * gwy;
+    const dim3 grid((unsigned)(nd + nw));
+#define DH_PAIR(NWD_, NWW_)                                                                                         \
+  do {                                                                                                              \
+    if (x_amax != nullptr) ODIN_LAUNCH((dense_h_pair_kernel<NWD_, NWW_, true>), grid, dim3((NWD_ > NWW_ ? NWD_ : NWW_) * 64), 0, stream, pd, pw, nd, gdx, gwx); \
+    else ODIN_LAUNCH((dense_h_pair_kernel<NWD_, NWW_, false>), grid, dim3((NWD_ > NWW_ ? NWD_ : NWW_) * 64), 0, stream, pd, pw, nd, gdx, gwx);                  \
+    return odin_check_launch("dense_h_pair(f16x2)");                                                                \
+  } while (0)
+    if (nwd == 8 && nww == 2) DH_PAIR(8, 2);
+    if (nwd == 8 && nww == 4) DH_PAIR(8, 4);
+    if (nwd == 8 && nww == 1) DH_PAIR(8, 1);
+    if (nwd == 4 && nww == 2) DH_PAIR(4, 2);
+    if (nwd == 4 && nww == 4) DH_PAIR(4, 4);
+    if (nwd == 4 && nww == 1) DH_PAIR(4, 1);
+#undef DH_PAIR
+  }
+#endif
+  int rc = x_amax != nullptr ? dh_launch<false, false, false, true, true>(pw, nww, stream)
+                             : dh_launch<false, false, false, true>(pw, nww, stream);
+  if (rc == 0) rc = dh_launch<true, true, true, false>(pd, nwd, stream);
+  return rc;
 }
 
 // slab row 0: dW[K, N] = x^T dy, then db[N] = column sums of dy: reduction over the batch; ONE complete row

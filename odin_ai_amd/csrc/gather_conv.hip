@@ -1751,6 +1751,9 @@ extern "C" int odin_deconv2d_fwd(const float* x, const float* w, const float* bi
     return track_y(odin_tconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr,
                                           nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->H, d->W,
                                           d->Cout, 1, stream), y, d, stream);
+  // a thin small image the implicit-GEMM families cannot take (fewer than 8 channels: MNIST's first deconvolution)
+  if (bias != nullptr && (d->Cin & 7) != 0 && odin_smalldeconv_gen_applicable(d))
+    return odin_smalldeconv_gen_fwd(x, w, bias, y, d, stream);
   if (odin_igemm_h_applicable(1, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->center))
     return odin_igemm_h_launch(1, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
                                d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, d->x_amax, 0, d->y_amax,

@@ -54,13 +54,31 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
     const double* __restrict__ fb_vals, const int* __restrict__ fb_band, float* __restrict__ out,
     int n_samples, int frame_length, int step, int n_fft, int log4, int radix2, int fpb,
     int n_frames, int n_mels, double preemph, double top_db, int log_output, int n_out,
-    float* __restrict__ bmax /* [B][gridDim.y] block maxima when the frames are split over gridDim.y > 1 */) {
+    float* __restrict__ bmax /* [B][gridDim.y] block maxima when the frames are split over gridDim.y > 1 */, int fb_cap,
+    long long* stamps /* diagnostics: wall-clock stamps of workgroup (0, 0) or null */) {
+#ifdef ODIN_SIM
+#define MEL_STAMP(i) ((void)0)
+#else
+  int stamp_n = 0;
+#define MEL_STAMP(i)                                                                                              \
+  do {                                                                                                            \
+    if (stamps != nullptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && stamp_n < 60) stamps[stamp_n++] = (long long)wall_clock64(); \
+  } while (0)
+#endif
   ODIN_DYN_SMEM(double, smem);
   const int H = n_fft / 2, nb = H + 1;
   cplx* tw = reinterpret_cast<cplx*>(smem);                 // [H]
   cplx* Z = tw + H;                                          // [fpb][H]
   double* pw = reinterpret_cast<double*>(Z + (size_t)fpb * H);  // [fpb][nb | pad]
   const int nbp = nb | 1;                                    // odd pitch
+  // Round 6: the window, the filterbank's non-zero values and its band table live in LDS.  The mel contraction read
+  // fb_vals[off + k] from GLOBAL memory inside a loop of up to 40 dependent iterations per output -- one L2 round trip
+  // each, repeated in every pass: most of the launch's 100 us.
+  double* win_s = pw + (size_t)fpb * nbp;                    // [frame_length]
+  double* fbv_s = win_s + frame_length;                      // [fb_cap]
+  int* fbb_s = reinterpret_cast<int*>(fbv_s + fb_cap);       // [3 n_mels]
+  const int nfb = fb_band[3 * (n_mels - 1) + 2] + fb_band[3 * (n_mels - 1) + 1];
+  const bool fb_lds = nfb <= fb_cap;                         // (a denser filterbank keeps the global reads)
   __shared__ float red[4];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
@@ -69,11 +87,15 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
   // (only the first n_out frames are stored; the top_db floor is still taken over the whole utterance)
   float* ob = out + (size_t)b * n_out * n_mels;
   for (int k = tid; k < H; k += 256) tw[k] = {tw_g[2 * k], tw_g[2 * k + 1]};
+  for (int k = tid; k < frame_length; k += 256) win_s[k] = window[k];
+  if (fb_lds) for (int k = tid; k < nfb; k += 256) fbv_s[k] = fb_vals[k];
+  for (int k = tid; k < 3 * n_mels; k += 256) fbb_s[k] = fb_band[k];
   float vmax = -3.0e38f;
   // (gridDim.y workgroups share an utterance: each takes every gridDim.y-th block of fpb frames; the top_db floor
   // then needs the maximum over all of them and is applied by mel_floor_kernel)
   for (int t0 = blockIdx.y * fpb; t0 < n_frames; t0 += gridDim.y * fpb) {
     __syncthreads();  // previous pass is done with Z / pw (and tw is staged)
+    MEL_STAMP(0);
     // ---- 1. stage: pre-emphasis, window, pack, digit-reverse ----
     for (int e = tid; e < fpb * H; e += 256) {
       const int f = e / H, n = e - f * H;
@@ -85,13 +107,13 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
           const int i = t * step + j0;
           double s = (double)yb[i];
           if (preemph > 0.0 && i > 0) s -= preemph * (double)yb[i - 1];
-          v.re = s * window[j0];
+          v.re = s * win_s[j0];
         }
         if (j1 < frame_length) {
           const int i = t * step + j1;
           double s = (double)yb[i];
           if (preemph > 0.0) s -= preemph * (double)yb[i - 1];
-          v.im = s * window[j1];
+          v.im = s * win_s[j1];
         }
       }
       // H = 4^log4, or 2 * 4^log4: then even points go to the first half, odd points to the
@@ -100,6 +122,7 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
       Z[(size_t)f * H + dst] = v;
     }
     __syncthreads();
+    MEL_STAMP(1);
     // ---- 2. radix-4 DIT stages: L = 4, 16, .., H ----
     for (int s = 1; s <= log4; ++s) {
       const int L = 1 << (2 * s), Q = L >> 2;
@@ -143,6 +166,7 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
       }
       __syncthreads();
     }
+    MEL_STAMP(2);
     // ---- 3. real-input split and power spectrum: X[k] = E[k] + W_N^k O[k] ----
     for (int e = tid; e < fpb * nb; e += 256) {
       const int f = e / nb, k = e - f * nb;
@@ -157,15 +181,17 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
       pw[(size_t)f * nbp + k] = X.re * X.re + X.im * X.im;
     }
     __syncthreads();
+    MEL_STAMP(3);
     // ---- 4. mel bands, dB ----
     for (int o = tid; o < fpb * n_mels; o += 256) {
       const int f = o / n_mels, m = o - f * n_mels;
       const int t = t0 + f;
       if (t >= n_frames) continue;
-      const int k0 = fb_band[3 * m], cnt = fb_band[3 * m + 1], off = fb_band[3 * m + 2];
+      const int k0 = fbb_s[3 * m], cnt = fbb_s[3 * m + 1], off = fbb_s[3 * m + 2];
       const double* P = pw + (size_t)f * nbp + k0;
+      const double* V = fb_lds ? fbv_s + off : fb_vals + off;
       double acc = 0.0;
-      for (int k = 0; k < cnt; ++k) acc = fma(fb_vals[off + k], P[k], acc);
+      for (int k = 0; k < cnt; ++k) acc = fma(V[k], P[k], acc);   // (k ascending: the oracle's summation order)
       float r;
       if (log_output == 3) r = (float)log(acc + 1e-6);  // AudioFeatureLoader(log_mels=True)
       else if (log_output) r = (float)(10.0 * log10(fmax(1e-10, acc) / ref_value));
@@ -174,6 +200,7 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
       vmax = fmaxf(vmax, r);
     }
   }
+  MEL_STAMP(4);
   if (!log_output || log_output == 3 || top_db < 0.0) return;
   // ---- per-utterance top_db floor (power2db: log_spec.max() - top_db over the whole utterance)
 #pragma unroll
@@ -218,6 +245,13 @@ __global__ __launch_bounds__(256) void mel_floor_kernel(float* __restrict__ out,
 
 }  // namespace
 
+static long long* g_mel_stamps = nullptr;
+// diagnostics: workgroup (0, 0) of the front-end launch records 100 MHz wall-clock stamps (4 per pass + 1) or NULL: off
+extern "C" int odin_debug_set_mel_stamps(void* buf) {
+  g_mel_stamps = (long long*)buf;
+  return 0;
+}
+
 extern "C" int odin_stft_mel_db_frames(const float* y, const double* window, const double* twiddles,
                                        const double* fb_vals, const int32_t* fb_band, float* out, int B,
                                        int n_samples, int frame_length, int step_length, int n_fft,
@@ -244,7 +278,9 @@ extern "C" int odin_stft_mel_db_frames(const float* y, const double* window, con
   if (fpb > 16) fpb = 16;
   if (fpb < 1) fpb = 1;
   if (const char* e = ODIN_DIAG_ENV("ODIN_MEL_FPB")) { const int v = atoi(e); if (v >= 1 && v <= fpb) fpb = v; }
-  const size_t lds = ((size_t)2 * H + (size_t)2 * fpb * H + (size_t)fpb * nbp) * 8;
+  const int fb_cap = 2 * (H + 1) + 2 * n_mels;   // (every bin lies under at most two triangles of a mel filterbank)
+  const size_t lds = ((size_t)2 * H + (size_t)2 * fpb * H + (size_t)fpb * nbp + frame_length + fb_cap) * 8 +
+                     (size_t)3 * n_mels * 4 + 8;
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
@@ -264,7 +300,7 @@ extern "C" int odin_stft_mel_db_frames(const float* y, const double* window, con
     while (gy < 8 && gy * 2 <= nblocks && (long)B * gy < 8L * odin_num_cus()) gy *= 2;
   ODIN_LAUNCH(stft_mel_f64_kernel, dim3(B, gy), dim3(256), lds, stream, y, window, twiddles, fb_vals,
               (const int*)fb_band, out, n_samples, frame_length, step_length, n_fft, log4, radix2,
-              fpb, n_frames, n_mels, preemph, top_db, log_output, n_out_frames, workspace);
+              fpb, n_frames, n_mels, preemph, top_db, log_output, n_out_frames, workspace, fb_cap, g_mel_stamps);
   if (gy > 1 && log_output != 0 && log_output != 3 && top_db >= 0.0)
     ODIN_LAUNCH(mel_floor_kernel, dim3(B), dim3(256), 0, stream, out, (const float*)workspace, gy,
                 n_out_frames * n_mels, (float)top_db, log_output);

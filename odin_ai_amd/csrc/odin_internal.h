@@ -86,6 +86,9 @@ int odin_dense_h_dgrad(const float* dy, const float* w, const float* aux, int au
                        const uint32_t* dy_amax, uint32_t* dx_amax, void* stream);
 int odin_dense_h_wgrad(const float* x, const float* dy, float* slab, int B, int K, int N, const uint32_t* dy_amax,
                        const uint32_t* x_amax, void* stream);
+int odin_dense_h_bwd_pair(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                          float* slab, int B, int K, int N, const uint32_t* dy_amax, uint32_t* dx_amax,
+                          const uint32_t* x_amax, void* stream);
 
 // the decoders' first Conv2DTranspose (tiny image, 8 / 16 -> 64 channels) on the vector ALUs, one workgroup per
 // sample pair (smalldeconv.hip)
@@ -97,6 +100,9 @@ int odin_bwd_planes_launch(const float* x, const float* dy, const float* w, cons
                            const uint32_t* x_amax, uint32_t* dx_amax, void* stream);
 bool odin_smalldeconv_applicable(const odin_conv_desc* d);
 int odin_smalldeconv_rows(const odin_conv_desc* d);
+bool odin_smalldeconv_gen_applicable(const odin_conv_desc* d);   // forward only: k <= 5, stride 2, Cin in {4, 8, 12, 16}
+int odin_smalldeconv_gen_fwd(const float* x, const float* w, const float* bias, float* y, const odin_conv_desc* d,
+                             void* stream);
 int odin_smalldeconv_fwd(const float* x, const float* w, const float* bias, float* y, const odin_conv_desc* d,
                          void* stream);
 int odin_smalldeconv_bwd(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,

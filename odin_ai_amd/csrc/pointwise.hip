@@ -274,6 +274,58 @@ __global__ __launch_bounds__(256) void elbo_bernoulli_gs_kernel(
   }
 }
 
+// The same walk software-pipelined (round 6): the loads of the NEXT U chunks are issued before the current ones are
+// evaluated (exp / log / rcp per element) and stored, unconditionally (out-of-range chunks re-read chunk 0: a
+// conditional load drains vmcnt); only the stores and the partial are guarded.
+template <int U>
+__global__ __launch_bounds__(256) void elbo_bernoulli_gsp_kernel(
+    const float4* __restrict__ logits, const float4* __restrict__ x, float* __restrict__ llk_part,
+    float4* __restrict__ dlogits, const float* __restrict__ scale, size_t n_chunks) {
+  const size_t nw = (size_t)gridDim.x * 4;
+  const int lane = threadIdx.x & 63;
+  const float sc = scale[0];
+  size_t c0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c0 >= n_chunks) return;
+  f32x4 l[U], t[U], ln[U], tn[U];
+  const f32x4* lg = reinterpret_cast<const f32x4*>(logits);
+  const f32x4* xg = reinterpret_cast<const f32x4*>(x);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t c = c0 + u * nw < n_chunks ? c0 + u * nw : 0;
+    l[u] = lg[c * 64 + lane];
+    t[u] = xg[c * 64 + lane];
+  }
+  for (;;) {
+    const size_t c1 = c0 + nw * U;
+    const bool more = c1 < n_chunks;   // (wave-uniform)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t c = (more && c1 + u * nw < n_chunks) ? c1 + u * nw : 0;
+      ln[u] = lg[c * 64 + lane];
+      tn[u] = xg[c * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t c = c0 + u * nw;
+      if (c < n_chunks) {
+        float4 g;
+        float acc = 0.f;
+        bern1(l[u].x, t[u].x, sc, acc, g.x);
+        bern1(l[u].y, t[u].y, sc, acc, g.y);
+        bern1(l[u].z, t[u].z, sc, acc, g.z);
+        bern1(l[u].w, t[u].w, sc, acc, g.w);
+        odin_store4_stream(dlogits + c * 64 + lane, g);
+        acc = odin_wave_sum64_valu(acc);
+        if (lane == 0) llk_part[c] = acc;
+      }
+    }
+    if (!more) break;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { l[u] = ln[u]; t[u] = tn[u]; }
+    c0 = c1;
+  }
+}
+
 // h [B, n_pix, 2C] (loc | raw scale), x [B, n_pix, C]; N = n_pix*C elements per sample
 __global__ __launch_bounds__(256) void elbo_gaussian_kernel(const float* __restrict__ h,
                                                             const float* __restrict__ x,
@@ -765,6 +817,19 @@ static int elbo_stream_unroll(int n_per_sample) {
   return 0;
 }
 
+// launch shape of the persistent Bernoulli ELBO kernel: {workgroups, chunks in flight per wave, software-pipelined}
+// Round 6 (profiles/r06_elbo_sweep.txt, cold buffers): the pipelined body with ONE chunk in flight per wave and a grid of
+// n_chunks / 6 workgroups (1.5 chunks per wave) reaches the stream probe's rate on both priced shapes -- 6.70 us = 0.704
+// of 8 TB/s at batch 256 (probe 0.704; round 5's shape: 0.676), 12.1 us = 0.78 at batch 512 (probe 0.80; 0.736)
+static int g_elbo_gs[3] = {0, 1, 1};   // (workgroups 0: from the tensor size)
+// diagnostics / sweeps (tools/elbo_sweep6.py): set the launch shape (a negative field keeps its value); returns 0
+extern "C" int odin_debug_elbo_shape(int blocks, int U, int pipelined) {
+  if (blocks >= 0) g_elbo_gs[0] = blocks;   // (0: from the tensor size)
+  if (U > 0) g_elbo_gs[1] = U;
+  if (pipelined >= 0) g_elbo_gs[2] = pipelined;
+  return 0;
+}
+
 extern "C" int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, float* llk_part,
                                            float* dlogits, const float* scale, int B,
                                            int n_per_sample, int* n_part_out, void* stream) {
@@ -775,8 +840,23 @@ extern "C" int odin_elbo_bernoulli_fwd_bwd(const float* logits, const float* x, 
     if (n_part_out) *n_part_out = n_part;
     if (logits == nullptr) return 0;  // dry run: reports the partial count
     const size_t n_chunks = (size_t)B * n_part;
-    int blocks = 2048, U = 2;  // (sweep of blocks x U on the 64x64x3, batch-256 shape: profiles/r04_elbo_stream_sweep.txt)
+    int blocks = g_elbo_gs[0], U = g_elbo_gs[1];  // (sweeps: profiles/r04_elbo_stream_sweep.txt, r06_elbo_sweep.txt)
+    if (blocks <= 0) {
+      blocks = (int)((n_chunks / 6 + 511) / 512) * 512;
+      blocks = blocks < 512 ? 512 : blocks > 4096 ? 4096 : blocks;
+    }
     if (const char* e = ODIN_DIAG_ENV("ODIN_ELBO_GS")) sscanf(e, "%d,%d", &blocks, &U);  // diagnostics sweep
+    if (g_elbo_gs[2]) {
+#define ODIN_ELBO_GSP_LAUNCH(UU)                                                                             \
+  ODIN_LAUNCH((elbo_bernoulli_gsp_kernel<UU>), dim3(blocks), dim3(256), 0, stream, (const float4*)logits,   \
+              (const float4*)x, llk_part, (float4*)dlogits, scale, n_chunks)
+      if (U == 1) ODIN_ELBO_GSP_LAUNCH(1);
+      else if (U == 2) ODIN_ELBO_GSP_LAUNCH(2);
+      else if (U == 3) ODIN_ELBO_GSP_LAUNCH(3);
+      else ODIN_ELBO_GSP_LAUNCH(4);
+#undef ODIN_ELBO_GSP_LAUNCH
+      return odin_check_launch("elbo_bernoulli");
+    }
 #define ODIN_ELBO_GS_LAUNCH(UU)                                                                              \
   ODIN_LAUNCH((elbo_bernoulli_gs_kernel<UU>), dim3(blocks), dim3(256), 0, stream, (const float4*)logits,    \
               (const float4*)x, llk_part, (float4*)dlogits, scale, n_chunks)

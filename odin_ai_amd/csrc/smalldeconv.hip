@@ -242,6 +242,56 @@ __global__ __launch_bounds__(SD_NT) void smalldeconv_bwd_kernel(SDParams p) {
   odin_amax_commit_wg(p.dx != nullptr ? p.dx_amax : nullptr, amx, tid, SD_NT, ared, blockIdx.x);
 }
 
+// ---- the generic form of the forward pass (round 6): any kernel size <= 5, stride 2, C0 in {4, 8, 12, 16}, any SAME pads.
+// MNIST's first Conv2DTranspose (7 x 7 x 4 -> 14 x 14 x 64, k5 s2; image_networks.py:255-258) has 4 input channels: the
+// implicit-GEMM families need multiples of 8, so it ran on the generic gather kernel followed by an absmax pass for its
+// range word: 62 + 5 us for 0.08 GFLOP (profiles/r05_bench_mnist_conv_b128_per_op.txt).  One sample per workgroup:
+// the input image and the whole weight tensor (K K 64 C0 floats, <= 100 KB) in LDS, a wave owns output pixels
+// wave, wave + 16, ... (the valid taps of a pixel are wave-uniform: no divergence), lane = output channel.
+struct SDGParams {
+  const float* x; const float* w; const float* bias; float* y; unsigned* y_amax;
+  int B, H, W, C0, K, pt, pl, act, w_al;
+};
+
+__global__ __launch_bounds__(SD_NT) void smalldeconv_gen_fwd_kernel(SDGParams p) {
+  ODIN_DYN_SMEM(float, sm);   // ws [K K][64][C0] | xs [H W][C0]
+  __shared__ float ared[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const int C0 = p.C0, K = p.K, HW = p.H * p.W, OW = 2 * p.W, NW = K * K * SD_C1 * C0;
+  float* ws = sm;
+  float* xs = sm + NW;
+  for (int e = 4 * tid; e < NW; e += 4 * SD_NT) *reinterpret_cast<float4*>(ws + e) = sd_ld4(p.w + e, p.w_al);
+  for (int e = tid; e < HW * C0; e += SD_NT) xs[e] = p.x[(size_t)b * HW * C0 + e];
+  const float bv = p.bias != nullptr ? p.bias[lane] : 0.f;
+  __syncthreads();
+  float amx = 0.f;
+  for (int pix = wave; pix < 4 * HW; pix += SD_NT / 64) {
+    const int oh = pix / OW, ow = pix - oh * OW;
+    float acc = bv;
+    // oh = 2 ih - pt + kh: kh runs over the taps of oh's parity whose ih lands inside the image
+    for (int kh = (oh + p.pt) & 1; kh < K; kh += 2) {
+      const int ih = (oh + p.pt - kh) >> 1;
+      if (ih < 0 || ih >= p.H) continue;
+      for (int kw = (ow + p.pl) & 1; kw < K; kw += 2) {
+        const int iw = (ow + p.pl - kw) >> 1;
+        if (iw < 0 || iw >= p.W) continue;
+        const float* wp = ws + ((kh * K + kw) * SD_C1 + lane) * C0;
+        const float* xp = xs + (ih * p.W + iw) * C0;
+        for (int c = 0; c < C0; c += 4) {
+          const float4 wv = *reinterpret_cast<const float4*>(wp + c);
+          const float4 xv = *reinterpret_cast<const float4*>(xp + c);   // (same address in all lanes)
+          acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc);
+          acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+        }
+      }
+    }
+    const float o = odin_act(p.act, acc);
+    amx = fmaxf(amx, fabsf(o));
+    p.y[((size_t)b * 4 * HW + pix) * SD_C1 + lane] = o;
+  }
+  odin_amax_commit_wg(p.y_amax, amx, tid, SD_NT, ared, blockIdx.x);
+}
+
 // samples per workgroup: one up to batch 256 (every CU busy, 256 slab rows), more beyond to stay within
 // ODIN_MAX_SLAB_BLOCKS rows.  Same-box sweep at batch 256 (dSprites / Shapes3D step, ms): S = 1: 0.5066 / 0.568,
 // S = 2: 0.5101 / 0.5911, S = 4: 0.5248 / 0.5807 (tools/r05_sdprobe.sh)
@@ -281,6 +331,28 @@ bool odin_smalldeconv_applicable(const odin_conv_desc* d) {
   if (d->H < 1 || d->W < 1 || d->H * d->W > 64) return false;
   if ((long)d->B * d->OH * d->OW * d->Cout >= (1L << 29)) return false;
   return sd_bwd_lds(sd_samples(d->B), d->H, d->W, d->Cin) <= 150 * 1024;
+}
+
+// the generic forward: Conv2DTranspose(64, k <= 5, stride 2, SAME) from a thin small image
+bool odin_smalldeconv_gen_applicable(const odin_conv_desc* d) {
+  if (ODIN_DIAG_ENV("ODIN_NOSMALLDECONV")) return false;
+  if (d->KH != d->KW || d->KH < 2 || d->KH > 5 || d->stride != 2 || d->center) return false;
+  if (d->Cout != SD_C1 || (d->Cin & 3) != 0 || d->Cin < 4 || d->Cin > 16 || d->OH != 2 * d->H || d->OW != 2 * d->W) return false;
+  if (d->H < 1 || d->W < 1 || d->H * d->W > 64 || d->B > 65535) return false;
+  if ((long)d->B * d->OH * d->OW * d->Cout >= (1L << 29)) return false;
+  return (size_t)(d->KH * d->KW * SD_C1 * d->Cin + d->H * d->W * d->Cin) * 4 <= 120 * 1024;
+}
+int odin_smalldeconv_gen_fwd(const float* x, const float* w, const float* bias, float* y, const odin_conv_desc* d,
+                             void* stream) {
+  SDGParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.w = w; p.bias = bias; p.y = y; p.y_amax = d->y_amax;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.C0 = d->Cin; p.K = d->KH; p.pt = d->pad_t; p.pl = d->pad_l; p.act = d->act;
+  p.w_al = (((size_t)w) & 15) == 0;
+  const size_t lds = (size_t)(d->KH * d->KW * SD_C1 * d->Cin + d->H * d->W * d->Cin) * 4;
+  sd_set_lds(&smalldeconv_gen_fwd_kernel, lds);
+  ODIN_LAUNCH(smalldeconv_gen_fwd_kernel, dim3(d->B), dim3(SD_NT), lds, stream, p);
+  return odin_check_launch("smalldeconv_gen_fwd");
 }
 
 int odin_smalldeconv_rows(const odin_conv_desc* d) {

@@ -1449,6 +1449,12 @@ extern "C" int odin_dense_bwd_ranged(const float* x, const float* dy, const floa
       dy_amax = odin_range_word_of(dy, (size_t)B * N, nullptr, stream);
       if (dy_amax == nullptr) return odin_fail(-3, "dense_bwd: no range word for dy");
     }
+    if (want_wgrad && want_dgrad && wslab != nullptr && dx != nullptr) {
+      // both halves: ONE launch (dense_h.hip: dense_h_pair_kernel), bit-identical to the two
+      if (wslab_rows_out) *wslab_rows_out = 1;
+      if (colsum_rows_out) *colsum_rows_out = 0;
+      return odin_dense_h_bwd_pair(x, dy, w, aux, aux_act, dx, wslab, B, K, N, dy_amax, dx_amax, x_amax, stream);
+    }
     if (want_wgrad) {
       if (wslab_rows_out) *wslab_rows_out = 1;
       if (wslab != nullptr) rc = odin_dense_h_wgrad(x, dy, wslab, B, K, N, dy_amax, x_amax, stream);

@@ -1272,7 +1272,7 @@ class VAEEngine:
   def _fork(self):
     """Returns (fork(i) -> raw side-stream handle ordered after everything issued so far on
     the current stream, join()).  None on CPU / when overlap is disabled."""
-    if self.side_stream is None or not self.overlap_wgrad:
+    if self.side_stream is None or not (self.overlap_wgrad or self.early_reduce):
       return None, (lambda: None)
     cur = torch.cuda.current_stream(self.device)
     sides = self.side_streams
@@ -1286,10 +1286,11 @@ class VAEEngine:
       side.wait_event(ev)
       return side.cuda_stream
 
-    fork.wants = lambda small: bool(small)
+    small_on = self.overlap_wgrad == 'small'   # (early_reduce alone forks only the decoder's slab reduction)
+    fork.wants = lambda small: small_on and bool(small)
 
     def join():
-      for side in sides:
+      for side in sides[:max(1, min(nxt[0], len(sides)))]:   # (only the side streams that were forked onto)
         cur.wait_stream(side)
 
     return fork, join
@@ -1392,7 +1393,8 @@ class VAEEngine:
                           self.dp.data_ptr(), B, D, int(self.analytic), st)
       rows = C.c_int(0)
       lib.odin_dense_wgrad(h_e.data_ptr(), self.dp.data_ptr(), self.lat_slab.data_ptr(),
-                           C.byref(rows), B, self.hdim, 2 * D, st if fork is None else fork(-1))  # small
+                           C.byref(rows), B, self.hdim, 2 * D,
+                           st if (fork is None or not fork.wants(True)) else fork(-1))  # small
       jobs.append(ReduceJob(self.lat_slab.data_ptr(), self.grads[self.lat_w_off:].data_ptr(),
                             self.lat_slab.shape[1], rows.value, self.lat_slab.shape[1], 0))
       auxp = h_e.data_ptr() if aux_act != 0 else None

@@ -135,6 +135,8 @@ DECONV_CASES = [
     (3, 4, 4, 8, 64, 4, 2, 'elu'),             # the decoders' first Conv2DTranspose: smalldeconv.hip (dSprites: 8 channels)
     (5, 4, 4, 16, 64, 4, 2, 'elu'),            # ... Shapes3D: 16 channels, an odd batch (the last workgroup holds one sample)
     (2, 6, 5, 8, 64, 4, 2, 'relu'),            # ... the audio decoder's 6 x 5 image
+    (3, 7, 7, 4, 64, 5, 2, 'elu'),             # MNIST's first Conv2DTranspose (4 channels, 5 x 5): the generic forward of smalldeconv.hip
+    (2, 5, 3, 12, 64, 3, 2, 'relu'),           # ... 12 channels, 3 x 3, a ragged image
     (2, 8, 8, 64, 32, 4, 2, 'elu'),
     (1, 16, 16, 32, 32, 4, 2, 'linear'),
     (2, 16, 16, 32, 64, 4, 2, 'elu'),          # tconv_planes forward, two 32-channel output blocks
