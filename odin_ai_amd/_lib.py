@@ -136,6 +136,7 @@ SIGNATURES = {
     'odin_debug_set_neck_stamps': [P],
     'odin_debug_elbo_shape': [I, I, I],
     'odin_debug_set_mel_stamps': [P],
+    'odin_debug_igemm_h_ldsw_steps': [I],
     'odin_graph_begin': [P],
     'odin_graph_end': [P, C.POINTER(C.c_void_p)],
     'odin_graph_launch': [P, P],
@@ -147,7 +148,7 @@ SIGNATURES = {
 VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_conv2d_dgrad_keeps_range',
                    'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_dense_dgrad_keeps_range', 'odin_conv2d_reads_x_range',
                    'odin_deconv2d_reads_x_range', 'odin_dense_reads_x_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
-                   'odin_latent_block_rows', 'odin_neck_rows', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop')
+                   'odin_latent_block_rows', 'odin_neck_rows', 'odin_debug_igemm_h_ldsw_steps', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop')
 # entry points declared `void` in include/odin_hip.h
 VOID_RETURNING = ('odin_wgrad_planes_defer_begin', 'odin_wgrad_pair_begin')
 

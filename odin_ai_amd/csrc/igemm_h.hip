@@ -687,6 +687,15 @@ double g_ih_min_flop = 1.2e9;
 
 }  // namespace
 
+static int g_ih_ldsw_steps = 32;
+// diagnostics: the largest weight slice (16-value steps of one stride class and 32 columns: 2 KB each) kept in LDS;
+// returns the previous value (negative: only read)
+extern "C" int odin_debug_igemm_h_ldsw_steps(int steps) {
+  const int old = g_ih_ldsw_steps;
+  if (steps >= 0) g_ih_ldsw_steps = steps;
+  return old;
+}
+
 // tests: the launch size from which convolutions come here (0: every applicable shape); returns the previous value
 extern "C" double odin_debug_igemm_h_min_flop(double flop) {
   const double old = g_ih_min_flop;
@@ -770,7 +779,11 @@ int odin_igemm_h_launch(int tmode, const float* in, const float* w, const float*
   dim3 grid(gx, gy, 1);
   // weight planes of one (class, column block) in LDS when they fit in 64 KB (2 KB per 16-value step)
   const int max_steps = ((KH + SS - 1) / SS) * ((KW + SS - 1) / SS) * p.gpt;
-  if (max_steps <= 32 && !ODIN_DIAG_ENV("ODIN_IH_NOLDSW")) {
+  // (round 6, measured and dropped: up to 64 steps -- 128 KB, one workgroup per CU -- so that the 5 x 5 layers over 32
+  // channels of the MNIST stack (50 steps) keep their weight planes in LDS too: MNIST conv 0.990 -> 1.005 ms, CelebA
+  // 1.165 -> 1.184 (tools/r06_ldsw_ab.py, odin_debug_igemm_h_ldsw_steps): the occupancy lost costs more than the L2
+  // reads of the weights)
+  if (max_steps <= g_ih_ldsw_steps && !ODIN_DIAG_ENV("ODIN_IH_NOLDSW")) {
     const size_t lds = (size_t)max_steps * 2048;
     // (eight tiles per workgroup there: half the rows when no column sums are asked for; with column sums the row
     // count odin_igemm_h_rows promised stays -- surplus workgroups write zero rows)

@@ -71,14 +71,12 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
   cplx* Z = tw + H;                                          // [fpb][H]
   double* pw = reinterpret_cast<double*>(Z + (size_t)fpb * H);  // [fpb][nb | pad]
   const int nbp = nb | 1;                                    // odd pitch
-  // Round 6: the window, the filterbank's non-zero values and its band table live in LDS.  The mel contraction read
-  // fb_vals[off + k] from GLOBAL memory inside a loop of up to 40 dependent iterations per output -- one L2 round trip
-  // each, repeated in every pass: most of the launch's 100 us.
-  double* win_s = pw + (size_t)fpb * nbp;                    // [frame_length]
-  double* fbv_s = win_s + frame_length;                      // [fb_cap]
-  int* fbb_s = reinterpret_cast<int*>(fbv_s + fb_cap);       // [3 n_mels]
-  const int nfb = fb_band[3 * (n_mels - 1) + 2] + fb_band[3 * (n_mels - 1) + 1];
-  const bool fb_lds = nfb <= fb_cap;                         // (a denser filterbank keeps the global reads)
+  // (Round 6, tried and dropped: the window, the filterbank values and the band table staged in LDS -- 6.7 KB more per
+  // workgroup, four instead of five workgroups per CU: 105.6 us against 100.8.  The in-kernel stamps
+  // (odin_debug_set_mel_stamps, tools/stamps_mel.py) put a pass of 4 frames at 12 us -- staging 3.0, FFT 4.1 (four
+  // barriers, 4- to 16-way bank conflicts of the 16-byte butterfly accesses), real-input split 1.8, mel + log10 2.8 --
+  // and a workgroup's four passes at 42 us: the launch is two rounds of those.)
+  (void)fb_cap;
   __shared__ float red[4];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
@@ -87,9 +85,6 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
   // (only the first n_out frames are stored; the top_db floor is still taken over the whole utterance)
   float* ob = out + (size_t)b * n_out * n_mels;
   for (int k = tid; k < H; k += 256) tw[k] = {tw_g[2 * k], tw_g[2 * k + 1]};
-  for (int k = tid; k < frame_length; k += 256) win_s[k] = window[k];
-  if (fb_lds) for (int k = tid; k < nfb; k += 256) fbv_s[k] = fb_vals[k];
-  for (int k = tid; k < 3 * n_mels; k += 256) fbb_s[k] = fb_band[k];
   float vmax = -3.0e38f;
   // (gridDim.y workgroups share an utterance: each takes every gridDim.y-th block of fpb frames; the top_db floor
   // then needs the maximum over all of them and is applied by mel_floor_kernel)
@@ -107,13 +102,13 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
           const int i = t * step + j0;
           double s = (double)yb[i];
           if (preemph > 0.0 && i > 0) s -= preemph * (double)yb[i - 1];
-          v.re = s * win_s[j0];
+          v.re = s * window[j0];
         }
         if (j1 < frame_length) {
           const int i = t * step + j1;
           double s = (double)yb[i];
           if (preemph > 0.0) s -= preemph * (double)yb[i - 1];
-          v.im = s * win_s[j1];
+          v.im = s * window[j1];
         }
       }
       // H = 4^log4, or 2 * 4^log4: then even points go to the first half, odd points to the
@@ -187,11 +182,10 @@ __global__ __launch_bounds__(256) void stft_mel_f64_kernel(
       const int f = o / n_mels, m = o - f * n_mels;
       const int t = t0 + f;
       if (t >= n_frames) continue;
-      const int k0 = fbb_s[3 * m], cnt = fbb_s[3 * m + 1], off = fbb_s[3 * m + 2];
+      const int k0 = fb_band[3 * m], cnt = fb_band[3 * m + 1], off = fb_band[3 * m + 2];
       const double* P = pw + (size_t)f * nbp + k0;
-      const double* V = fb_lds ? fbv_s + off : fb_vals + off;
       double acc = 0.0;
-      for (int k = 0; k < cnt; ++k) acc = fma(V[k], P[k], acc);   // (k ascending: the oracle's summation order)
+      for (int k = 0; k < cnt; ++k) acc = fma(fb_vals[off + k], P[k], acc);
       float r;
       if (log_output == 3) r = (float)log(acc + 1e-6);  // AudioFeatureLoader(log_mels=True)
       else if (log_output) r = (float)(10.0 * log10(fmax(1e-10, acc) / ref_value));
@@ -278,9 +272,8 @@ extern "C" int odin_stft_mel_db_frames(const float* y, const double* window, con
   if (fpb > 16) fpb = 16;
   if (fpb < 1) fpb = 1;
   if (const char* e = ODIN_DIAG_ENV("ODIN_MEL_FPB")) { const int v = atoi(e); if (v >= 1 && v <= fpb) fpb = v; }
-  const int fb_cap = 2 * (H + 1) + 2 * n_mels;   // (every bin lies under at most two triangles of a mel filterbank)
-  const size_t lds = ((size_t)2 * H + (size_t)2 * fpb * H + (size_t)fpb * nbp + frame_length + fb_cap) * 8 +
-                     (size_t)3 * n_mels * 4 + 8;
+  const int fb_cap = 0;
+  const size_t lds = ((size_t)2 * H + (size_t)2 * fpb * H + (size_t)fpb * nbp) * 8;
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
