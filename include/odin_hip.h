@@ -340,6 +340,11 @@ int odin_wgrad_planes_defer_end(void* stream);
  * two-plane implicit GEMM (igemm_h.hip) rather than the fp32 one; 0 = every applicable shape, < 0 = only report.
  * Returns the previous value. */
 double odin_debug_igemm_h_min_flop(double flop);
+/* block-window plane kernels (blk_planes.hip): the launch size from which they take a 4x4 / stride-2 layer (tests: 0), and
+ * a switch (0: off, 1: on, < 0: query) for A/B runs; both return the previous value */
+double odin_debug_blk_min_flop(double flop);
+int odin_debug_blk_planes(int enable);
+
 int odin_gaussian_head_fwd_bwd(const float* h, const float* w1, const float* b1, const float* target,
                                float* logits, float* dlogits, float* dh, float* llk_part, int* n_part_out,
                                float* wslab, int* rows_out, float* colsum_slab, const float* scale, int B,

@@ -102,6 +102,8 @@ SIGNATURES = {
     'odin_elbo_gaussian_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
     'odin_gaussian_head_fwd_bwd': [P, P, P, P, P, P, P, P, IP, P, IP, P, P, I, I, I, I, I, I, P, P],
     'odin_debug_igemm_h_min_flop': [C.c_double],
+    'odin_debug_blk_min_flop': [C.c_double],
+    'odin_debug_blk_planes': [C.c_int],
     'odin_wgrad_planes_defer_begin': [],
     'odin_wgrad_planes_defer_end': [P],
     'odin_elbo_mixqlogistic_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
@@ -148,7 +150,8 @@ SIGNATURES = {
 VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_conv2d_dgrad_keeps_range',
                    'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_dense_dgrad_keeps_range', 'odin_conv2d_reads_x_range',
                    'odin_deconv2d_reads_x_range', 'odin_dense_reads_x_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
-                   'odin_latent_block_rows', 'odin_neck_rows', 'odin_debug_igemm_h_ldsw_steps', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop')
+                   'odin_latent_block_rows', 'odin_neck_rows', 'odin_debug_igemm_h_ldsw_steps', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop', 'odin_debug_blk_min_flop',
+                   'odin_debug_blk_planes')
 # entry points declared `void` in include/odin_hip.h
 VOID_RETURNING = ('odin_wgrad_planes_defer_begin', 'odin_wgrad_pair_begin')
 
@@ -173,7 +176,7 @@ class Lib:
       fn = getattr(self.c, name)  # AttributeError if the symbol is missing: fail loudly
       fn.argtypes = args
       fn.restype = (C.c_char_p if name in ('odin_debug_last_path', 'odin_comm_library') else
-                    C.c_double if name == 'odin_debug_igemm_h_min_flop' else
+                    C.c_double if name in ('odin_debug_igemm_h_min_flop', 'odin_debug_blk_min_flop') else
                     None if name in VOID_RETURNING else
                     C.c_uint32 if name in VALUE_RETURNING else C.c_int)
 

@@ -1623,6 +1623,11 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
                                  d->pad_t, d->pad_l, d->center))
     return track_y(odin_fconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->Cin,
                                           d->OH, d->OW, d->Cout, 1, stream), y, d, stream);
+  if (bias != nullptr &&
+      odin_fconv_blk_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
+                                d->pad_l, d->center))
+    return odin_fconv_blk_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->OH, d->OW, d->Cin, d->Cout, 1,
+                                 d->act, d->x_amax, d->y_amax, stream);
   if (odin_igemm_h_applicable(0, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->center))
     return odin_igemm_h_launch(0, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
                                d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, d->x_amax, 0, d->y_amax,
@@ -1663,6 +1668,9 @@ extern "C" int odin_conv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_ac
   if (aux_act == ODIN_ACT_ELU && d->H == 2 * d->OH && d->W == 2 * d->OW &&
       odin_tconv_ring_applicable(d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0))
     return 0;
+  if (d->H == 2 * d->OH && d->W == 2 * d->OW &&
+      odin_tconv_blk_applicable(d->B, d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0))
+    return 1;
   if (odin_igemm_h_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0)) return 1;
   return odin_igemm_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0) ? 1 : 0;
 }
@@ -1671,6 +1679,9 @@ extern "C" int odin_deconv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_
   if (aux_act == ODIN_ACT_ELU &&
       odin_fconv_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
                                    d->pad_t, d->pad_l, 0))
+    return 1;
+  if (odin_fconv_blk_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t,
+                                d->pad_l, 0))
     return 1;
   if (odin_igemm_h_applicable(0, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0)) return 1;
   const bool ring_two_pass_vs_igemm =
@@ -1710,6 +1721,11 @@ extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* a
     return track_dx(odin_tconv_ring_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, nullptr, nullptr,
                                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->OH,
                                            d->OW, d->Cin, 2, stream), dx, d, stream);
+  // any other image size: 8 x 8 blocks of dy through LDS windows (blk_planes.hip)
+  if (d->H == 2 * d->OH && d->W == 2 * d->OW &&
+      odin_tconv_blk_applicable(d->B, d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0))
+    return odin_tconv_blk_launch(dy, w, nullptr, aux_act != 0 ? aux : nullptr, dx, colsum_slab, slab_rows_out, d->B,
+                                 d->OH, d->OW, d->Cout, d->Cin, 2, aux_act, d->dy_amax, d->dx_amax, stream);
   if (odin_igemm_h_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0)) {
     if (slab_rows_out) *slab_rows_out = odin_igemm_h_rows(1, d->B, d->H, d->W, d->stride);
     if (dx == nullptr) return 0;  // dry run
@@ -1754,6 +1770,10 @@ extern "C" int odin_deconv2d_fwd(const float* x, const float* w, const float* bi
   // a thin small image the implicit-GEMM families cannot take (fewer than 8 channels: MNIST's first deconvolution)
   if (bias != nullptr && (d->Cin & 7) != 0 && odin_smalldeconv_gen_applicable(d))
     return odin_smalldeconv_gen_fwd(x, w, bias, y, d, stream);
+  if (bias != nullptr && d->OH == 2 * d->H && d->OW == 2 * d->W &&
+      odin_tconv_blk_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->center))
+    return odin_tconv_blk_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->Cin, d->Cout, 1, d->act,
+                                 d->x_amax, d->y_amax, stream);
   if (odin_igemm_h_applicable(1, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->center))
     return odin_igemm_h_launch(1, x, w, bias, nullptr, 0, y, nullptr, d->B, d->H, d->W, d->Cin, d->OH, d->OW,
                                d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->act, d->x_amax, 0, d->y_amax,
@@ -1784,6 +1804,10 @@ extern "C" int odin_deconv2d_dgrad(const float* dy, const float* w, const float*
                                    d->pad_t, d->pad_l, 0))
     return odin_fconv_planes_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, d->B, d->H, d->W,
                                     d->Cout, d->Cin, 2, d->dy_amax, d->dx_amax, stream);
+  if (odin_fconv_blk_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t,
+                                d->pad_l, 0))
+    return odin_fconv_blk_launch(dy, w, nullptr, aux_act != 0 ? aux : nullptr, dx, colsum_slab, slab_rows_out, d->B, d->H,
+                                 d->W, d->Cout, d->Cin, 2, aux_act, d->dy_amax, d->dx_amax, stream);
   if (odin_igemm_h_applicable(0, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0)) {
     if (slab_rows_out) *slab_rows_out = odin_igemm_h_rows(0, d->B, d->H, d->W, d->stride);
     if (dx == nullptr) return 0;  // dry run

@@ -128,6 +128,22 @@ int odin_tconv_ring_launch(const float* in, const float* w, const float* bias, c
 
 // the same transposed gathers through the bf16 matrix pipe: fp32 operands as three exact bf16 planes,
 // split once on the way into LDS (tconv_planes.hip)
+// block-window plane kernels for the 4x4 / stride-2 layers of any image size (blk_planes.hip)
+bool odin_tconv_blk_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt, int pl, int center);
+int odin_tconv_blk_rows(int B, int H, int W, int CO);
+int odin_tconv_blk_launch(const float* in, const float* w, const float* bias, const float* aux, float* out,
+                          float* colsum, int* rows_out, int B, int H, int W, int CI, int CO, int epi, int act,
+                          const uint32_t* in_amax, uint32_t* out_amax, void* stream);
+bool odin_fconv_blk_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S, int pt, int pl,
+                               int center);
+int odin_fconv_blk_launch(const float* in, const float* w, const float* bias, const float* aux, float* out,
+                          float* colsum, int* rows_out, int B, int OH, int OW, int CI, int CO, int epi, int act,
+                          const uint32_t* in_amax, uint32_t* out_amax, void* stream);
+bool odin_wgrad_blk_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S, int pt, int pl,
+                               int center);
+int odin_wgrad_blk_launch(const float* U, const float* V, float* slab, int* rows_out, int B, int OH, int OW, int CI,
+                          int CO, int want_bias, int grad_u, const uint32_t* g_amax, const uint32_t* a_amax,
+                          void* stream);
 void odin_tconv_planes_set_stamps(void* buf);
 bool odin_tconv_planes_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt,
                                   int pl, int center, int epi, int C1);

@@ -1039,6 +1039,9 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
                                    p.center))
     return odin_wgrad_planes_launch(p.in, p.dy, p.slab, rows_out, p.B, p.OH, p.OW, p.CI, p.CO,
                                     p.want_bias, p.want_bias ? 0 : 1, p.g_amax, p.a_amax, stream);
+  if (odin_wgrad_blk_applicable(p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO, p.KH, p.KW, p.S, p.pt, p.pl, p.center))
+    return odin_wgrad_blk_launch(p.in, p.dy, p.slab, rows_out, p.B, p.OH, p.OW, p.CI, p.CO, p.want_bias,
+                                 p.want_bias ? 0 : 1, p.g_amax, p.a_amax, stream);
   if (odin_igemm_h_wgrad_applicable(p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO, p.KH, p.KW, p.S, p.center)) {
     if (rows_out) *rows_out = odin_igemm_h_wgrad_rows(p.B, p.OH, p.OW, p.KH, p.KW, p.CI, p.CO);
     if (p.slab == nullptr) return 0;  // dry run
@@ -1326,6 +1329,10 @@ extern "C" int odin_conv2d_reads_x_range(const odin_conv_desc* d) {
   return (odin_fconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                                        d->pad_t, d->pad_l, d->center) ||
           odin_igemm_h_applicable(0, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->center) ||
+          odin_fconv_blk_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
+                                    d->pad_l, d->center) ||
+          odin_wgrad_blk_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
+                                    d->pad_l, d->center) ||
           odin_wgrad_planes_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
                                        d->pad_t, d->pad_l, d->center) ||
           odin_igemm_h_wgrad_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,
@@ -1335,9 +1342,14 @@ extern "C" int odin_deconv2d_reads_x_range(const odin_conv_desc* d) {
   return ((d->OH == 2 * d->H && d->OW == 2 * d->W &&
            odin_tconv_planes_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l,
                                         d->center, 1, 1)) ||
+          (d->OH == 2 * d->H && d->OW == 2 * d->W &&
+           odin_tconv_blk_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l,
+                                     d->center)) ||
           odin_igemm_h_applicable(1, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->center) ||
           odin_wgrad_planes_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride,
                                        d->pad_t, d->pad_l, 0) ||
+          odin_wgrad_blk_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t,
+                                    d->pad_l, 0) ||
           odin_igemm_h_wgrad_applicable(d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0))
              ? 1 : 0;
 }

@@ -1,0 +1,164 @@
+"""blk_planes.hip -- the block-window plane kernels (4x4 / stride-2 layers of ANY image size: the audio VAE's 96 x 80 ...
+12 x 10 maps) through the C ABI against the float64 oracle, on both backends (fixture `bk`).  The launch-size threshold
+is lowered to 0 so that these small shapes take the path the product sends the 2-16 GFLOP layers through.
+
+Reference semantics: image_networks.py:460-513 (Conv2D / Conv2DTranspose k4 s2 `SAME`), base_networks.py:549
+(tape.gradient)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from odin_ai_amd import _lib
+from oracle import vae_oracle as vo
+
+
+def reduce_slab(bk, slab, rows, n):
+  L = bk.L
+  out = bk.zeros(n)
+  job = (_lib.ReduceJob * 1)(_lib.ReduceJob(slab.data_ptr(), out.data_ptr(), n, rows, slab.shape[1], 0))
+  L.odin_slab_reduce(job, 1, None)
+  return out.cpu().numpy()
+
+
+def close(a, b, tol=2e-5):
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  err = np.abs(a - b).max()
+  ref = max(1.0, np.abs(b).max())
+  assert err <= tol * ref, (err, ref)
+
+
+@pytest.fixture
+def blk(bk, request):
+  L = bk.L
+  request.addfinalizer(lambda old=L.odin_debug_blk_min_flop(0.0): L.odin_debug_blk_min_flop(old))
+  return bk
+
+
+def word_of(bk, t):
+  w = bk.zeros(2048, dtype=torch.int32)
+  bk.L.odin_absmax(t.data_ptr(), t.numel(), w.data_ptr(), None)
+  return w
+
+
+def word_max(w):
+  return float(w.cpu().view(torch.float32).max())
+
+
+DECONV = [
+    # B, H, W, Cin, Cout, act, scale of x, scale of dy
+    (2, 12, 10, 32, 32, 'elu', 1.0, 1.0),       # audio decoder geometry: ragged tiles in both directions
+    (1, 6, 5, 64, 64, 'elu', 1.0, 1.0),         # 64 reduction channels, two output blocks, one (ragged) tile per image
+    (3, 9, 20, 64, 32, 'relu', 1.0, 1e-9),      # odd height, 2.5 tiles per row; tiny gradients
+    (2, 24, 8, 32, 64, 'linear', 3e4, 1.0),     # activations beyond the f16 window
+    (5, 3, 3, 32, 32, 'elu', 1.0, 1.0),         # an image smaller than a tile
+]
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co,act,xs,gs', DECONV)
+def test_deconv(blk, B, H, W, Ci, Co, act, xs, gs):
+  bk = blk
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(B * 100 + H)
+  K, S = 4, 2
+  x = rng.standard_normal((B, H, W, Ci)) * xs
+  w = rng.standard_normal((K, K, Co, Ci)) * 0.2 / xs
+  b = rng.standard_normal(Co) * 0.1
+  OH, OW = H * S, W * S
+  _, pt, _ = vo.same_pads(OH, K, S)
+  _, pl, _ = vo.same_pads(OW, K, S)
+  d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, act)
+  y_ref = vo._ACT[act](vo.conv2d_transpose(x, w, b, S))
+  tx, tw, tb = T(x), T(w), T(b)
+  xw, yw = word_of(bk, tx), bk.zeros(2048, dtype=torch.int32)
+  d.x_amax, d.y_amax = xw.data_ptr(), yw.data_ptr()
+  ty = bk.full((B, OH, OW, Co), float('nan'))
+  L.odin_deconv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
+  assert L.odin_debug_last_path().decode() == 'tconv_blk(f16x2)'
+  close(ty.cpu().numpy(), y_ref)
+  assert word_max(yw) >= float(np.abs(y_ref).max()) * (1 - 1e-5) and word_max(yw) <= float(np.abs(y_ref).max()) * 1.001
+  # data gradient (strided gather over dy) and weight gradient
+  dy = rng.standard_normal((B, OH, OW, Co)) * gs
+  tdy = T(dy)
+  dyw, dxw = word_of(bk, tdy), bk.zeros(2048, dtype=torch.int32)
+  d.dy_amax, d.dx_amax = dyw.data_ptr(), dxw.data_ptr()
+  dx_ref, dw_ref, db_ref = vo.conv2d_transpose_bwd(x, w, dy, S)
+  aux = rng.standard_normal((B, H, W, Ci))
+  taux = T(aux)
+  g_ref = dx_ref * vo.elu_grad_from_output(aux.astype(np.float32).astype(np.float64))
+  tdx = bk.full((B, H, W, Ci), float('nan'))
+  rows = C.c_int(0)
+  slab = bk.full((L.odin_max_slab_rows(), Ci), float('nan'))
+  L.odin_deconv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, tdx.data_ptr(), slab.data_ptr(),
+                        C.byref(rows), C.byref(d), None)
+  assert L.odin_debug_last_path().decode() == 'fconv_blk(f16x2)' or Co != 32
+  close(tdx.cpu().numpy() / gs, g_ref / gs)
+  close(reduce_slab(bk, slab, rows.value, Ci) / gs, g_ref.sum((0, 1, 2)) / gs, 1e-4)
+  assert word_max(dxw) >= float(np.abs(g_ref).max()) * (1 - 1e-5)
+  n = K * K * Co * Ci
+  slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
+  L.odin_deconv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d), None)
+  assert L.odin_debug_last_path().decode() == ('wgrad_planes(f16x2)' if W == 8 else 'wgrad_blk(f16x2)')   # (8-pixel rows: the row-window kernel)
+  close(reduce_slab(bk, slab, rows.value, n).reshape(K, K, Co, Ci) / (gs * xs), dw_ref / (gs * xs), 1e-4)
+
+
+CONV = [
+    # B, H, W, Cin, Cout, act, scale of x, scale of dy
+    (2, 24, 20, 32, 32, 'elu', 1.0, 1.0),       # audio encoder geometry
+    (1, 12, 10, 32, 64, 'elu', 1.0, 1e-9),      # two output blocks forward = 64 reduction channels backward; tiny gradients
+    (3, 18, 40, 32, 32, 'relu', 3e4, 1.0),      # odd coarse height; activations beyond the f16 window
+    (4, 6, 6, 32, 32, 'elu', 1.0, 1.0),         # an image smaller than a tile
+]
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co,act,xs,gs', CONV)
+def test_conv(blk, B, H, W, Ci, Co, act, xs, gs):
+  bk = blk
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(B * 100 + H)
+  K, S = 4, 2
+  x = rng.standard_normal((B, H, W, Ci)) * xs
+  w = rng.standard_normal((K, K, Ci, Co)) * 0.2 / xs
+  b = rng.standard_normal(Co) * 0.1
+  OH, pt, _ = vo.same_pads(H, K, S)
+  OW, pl, _ = vo.same_pads(W, K, S)
+  d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, act)
+  y_ref = vo._ACT[act](vo.conv2d(x, w, b, S))
+  tx, tw, tb = T(x), T(w), T(b)
+  xw, yw = word_of(bk, tx), bk.zeros(2048, dtype=torch.int32)
+  d.x_amax, d.y_amax = xw.data_ptr(), yw.data_ptr()
+  ty = bk.full((B, OH, OW, Co), float('nan'))
+  L.odin_conv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
+  assert L.odin_debug_last_path().decode() == 'fconv_blk(f16x2)'
+  close(ty.cpu().numpy(), y_ref)
+  assert word_max(yw) >= float(np.abs(y_ref).max()) * (1 - 1e-5)
+  dy = rng.standard_normal((B, OH, OW, Co)) * gs
+  tdy = T(dy)
+  dyw, dxw = word_of(bk, tdy), bk.zeros(2048, dtype=torch.int32)
+  d.dy_amax, d.dx_amax = dyw.data_ptr(), dxw.data_ptr()
+  dx_ref, dw_ref, db_ref = vo.conv2d_bwd(x, w, dy, S)
+  aux = rng.standard_normal((B, H, W, Ci))
+  taux = T(aux)
+  g_ref = dx_ref * vo.elu_grad_from_output(aux.astype(np.float32).astype(np.float64))
+  tdx = bk.full((B, H, W, Ci), float('nan'))
+  rows = C.c_int(0)
+  slab = bk.full((L.odin_max_slab_rows(), Ci), float('nan'))
+  L.odin_conv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, tdx.data_ptr(), slab.data_ptr(),
+                      C.byref(rows), C.byref(d), None)
+  assert L.odin_debug_last_path().decode() == 'tconv_blk(f16x2)'
+  close(tdx.cpu().numpy() / gs, g_ref / gs)
+  close(reduce_slab(bk, slab, rows.value, Ci) / gs, g_ref.sum((0, 1, 2)) / gs, 1e-4)
+  assert word_max(dxw) >= float(np.abs(g_ref).max()) * (1 - 1e-5) and word_max(dxw) <= float(np.abs(g_ref).max()) * 1.001
+  # without an activation below (aux_act = linear) and without a column-sum slab
+  tdx2 = bk.full((B, H, W, Ci), float('nan'))
+  L.odin_conv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), None, 0, tdx2.data_ptr(), None, None, C.byref(d), None)
+  assert L.odin_debug_last_path().decode() == 'tconv_blk(f16x2)'
+  close(tdx2.cpu().numpy() / gs, dx_ref / gs)
+  n = K * K * Ci * Co + Co
+  slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
+  L.odin_conv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d), None)
+  assert L.odin_debug_last_path().decode() == 'wgrad_blk(f16x2)'
+  g = reduce_slab(bk, slab, rows.value, n)
+  close(g[:-Co].reshape(K, K, Ci, Co) / (gs * xs), dw_ref / (gs * xs), 1e-4)
+  close(g[-Co:] / gs, db_ref / gs, 1e-4)
