@@ -208,6 +208,12 @@ def profile_ops(eng, reps=20):
         eng.x.data_ptr(), eng.dec.outs[-1].data_ptr(), eng.dec.gouts[-2].data_ptr(),
         eng.tail_llk_part.data_ptr(), C.byref(npart), eng.tail_slab.data_ptr(), C.byref(rows),
         eng.hp(5), C.byref(eng.dec.descs[-2]), bb.desc['Cout'], st)
+    if getattr(eng, 'tail_mode', None) is not None:   # the Gaussian tail (blk_planes.hip)
+      fn = lambda: lib.odin_gaussian_tail_fwd_bwd(
+          h.data_ptr(), eng.dec.w(nd - 2).data_ptr(), eng.dec.b(nd - 2).data_ptr(), eng.dec.w(nd - 1).data_ptr(),
+          eng.dec.b(nd - 1).data_ptr(), eng.x.data_ptr(), eng.dec.outs[-1].data_ptr(), eng.dec.gouts[-2].data_ptr(),
+          eng.tail_llk_part.data_ptr(), C.byref(npart), eng.tail_slab.data_ptr(), C.byref(rows), eng.hp(5),
+          C.byref(eng.dec.descs[-2]), eng.in_shape[-1], eng.tail_mode, st)
     t = timeit(fn)
     fl = conv_flops(a, B) + 3 * conv_flops(bb, B)
     out.append(dict(layer=f'dec{nd - 2}+{nd - 1}:tail', op='fwd+elbo', us=t * 1e6,

@@ -345,6 +345,20 @@ double odin_debug_igemm_h_min_flop(double flop);
 double odin_debug_blk_min_flop(double flop);
 int odin_debug_blk_planes(int enable);
 
+/* ---- fused Gaussian tail of the TRAINING step (blk_planes.hip): Conv2DTranspose(k4, s2, 32 -> 32, activation d->act) ->
+ * Conv2D 1x1 linear with 2 maps (w1 [32, 2], b1 [2]: loc | raw scale) -> Independent(Normal(loc, raw | softplus1(raw)))
+ * .log_prob(target [B, OH, OW, 1]), forward AND backward in one launch, any image size: logits [B, OH, OW, 2] (optional
+ * out), g_out = dL/d(pre-activation of the layer) for L = -scale[0] * sum llk, llk_part[b][part] (n_part per sample),
+ * tail_slab[g][32 * 2 (dW1) | 2 (db1) | 32 (db of the layer)], g < *slab_rows_out; d->x_amax (optional) / d->dy_amax
+ * (optional: receives max |g_out|) as in odin_bernoulli_tail_fwd_bwd.  Replaces decoder4 -> decoder6 ->
+ * RVconf(..., 'gaus', projection=False) of the audio VAE (examples/vae/vae_audio.py:84-110; image_networks.py:505-511)
+ * + px.log_prob(x) + their tape.gradient.  softplus1: 0 = raw scale, 1 = softplus1.  g_out == NULL = dry run;
+ * -2: shapes outside the kernel (odin_gaussian_tail_applicable: C == 1, 32 -> 32 channels, k4 s2). */
+int odin_gaussian_tail_applicable(const odin_conv_desc* d, int C);
+int odin_gaussian_tail_fwd_bwd(const float* x, const float* w, const float* bias, const float* w1, const float* b1,
+                               const float* target, float* logits, float* g_out, float* llk_part, int* n_part_out,
+                               float* tail_slab, int* slab_rows_out, const float* scale, const odin_conv_desc* d, int C,
+                               int softplus1, void* stream);
 int odin_gaussian_head_fwd_bwd(const float* h, const float* w1, const float* b1, const float* target,
                                float* logits, float* dlogits, float* dh, float* llk_part, int* n_part_out,
                                float* wslab, int* rows_out, float* colsum_slab, const float* scale, int B,

@@ -100,6 +100,8 @@ SIGNATURES = {
     'odin_neck_bwd': [C.POINTER(NeckArgs), P],
     'odin_elbo_bernoulli_fwd_bwd': [P, P, P, P, P, I, I, IP, P],
     'odin_elbo_gaussian_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
+    'odin_gaussian_tail_applicable': [DP, I],
+    'odin_gaussian_tail_fwd_bwd': [P, P, P, P, P, P, P, P, P, IP, P, IP, P, DP, I, I, P],
     'odin_gaussian_head_fwd_bwd': [P, P, P, P, P, P, P, P, IP, P, IP, P, P, I, I, I, I, I, I, P, P],
     'odin_debug_igemm_h_min_flop': [C.c_double],
     'odin_debug_blk_min_flop': [C.c_double],
@@ -151,7 +153,7 @@ VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_conv2d_dgrad_keeps
                    'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_dense_dgrad_keeps_range', 'odin_conv2d_reads_x_range',
                    'odin_deconv2d_reads_x_range', 'odin_dense_reads_x_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
                    'odin_latent_block_rows', 'odin_neck_rows', 'odin_debug_igemm_h_ldsw_steps', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop', 'odin_debug_blk_min_flop',
-                   'odin_debug_blk_planes')
+                   'odin_debug_blk_planes', 'odin_gaussian_tail_applicable')
 # entry points declared `void` in include/odin_hip.h
 VOID_RETURNING = ('odin_wgrad_planes_defer_begin', 'odin_wgrad_pair_begin')
 

@@ -885,3 +885,328 @@ int odin_wgrad_blk_launch(const float* U, const float* V, float* slab, int* rows
   ODIN_LAUNCH((wgrad_blk_kernel), grid, dim3(512), (size_t)2 * WB_BUF, stream, p);
   return odin_check_launch("wgrad_blk(f16x2)");
 }
+
+// =====================================================================================================================
+// the fused Gaussian tail: Conv2DTranspose(k4, s2, 32 -> 32, act) -> Conv2D 1x1 (2 maps: loc | raw scale) ->
+// Independent(Normal(loc, raw | softplus1(raw))).log_prob(target) AND its backward in the epilogue of tconv_blk (the
+// audio VAE's decoder4 -> decoder6 -> observation, examples/vae/vae_audio.py:84-110, image_networks.py:505-511): the
+// [B, 2H, 2W, 32] activation never reaches HBM -- the layer writes dL/d(pre-activation) where odin_deconv2d_fwd +
+// odin_gaussian_head_fwd_bwd wrote the activation, read it back and wrote the gradient (3 x 251 MB at batch 256).
+// A wave owns one parity class and TWO pixel blocks with both 16-channel output blocks, so a pixel's 32 channels sit in
+// the 4 lanes (lane & 15 = pixel, lane >> 4 = channel quad of either block) that meet by two cross-lane adds.
+// =====================================================================================================================
+namespace {
+
+struct TGParams {
+  const float* in;      // [B, H, W, 32]
+  const float* w;       // [16 taps][32][32]
+  const float* bias;    // [32]
+  const float* w1;      // [32][2]
+  const float* b1;      // [2]
+  const float* target;  // [B, 2H, 2W, 1]
+  float* logits;        // [B, 2H, 2W, 2] (may be null)
+  float* out;           // [B, 2H, 2W, 32]: dL/d(pre-activation of the layer), L = -scale[0] * sum llk
+  float* llk_part;      // [n_tiles]: one partial per tile (a tile lies inside one sample)
+  float* slab;          // [gridDim.x][32 * 2 (dW1) | 2 (db1) | 32 (column sums of out)]
+  const float* scale;
+  int B, H, W, act;
+  int nty, ntx, n_tiles, tiles_per_wg;
+  const unsigned* in_amax;
+  unsigned* out_amax;
+};
+
+constexpr int TG_ROW = 32 * 2 + 2 + 32;
+
+template <int SP1>
+__global__ __launch_bounds__(512) void tconv_blk_gtail_kernel(TGParams p) {
+  ODIN_DYN_SMEM(char, smem);
+  __shared__ float cred[8 * TG_ROW + 16];
+  __shared__ float llk_red[2][8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = bk_uniform(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int cls = wave & 3, pbh = wave >> 2;
+  const int cpw = cls & 1, rpar = cls >> 1;
+  const int OH = 2 * p.H, OW = 2 * p.W;
+  const int T0 = blockIdx.x * p.tiles_per_wg;
+  int T1 = T0 + p.tiles_per_wg;
+  if (T1 > p.n_tiles) T1 = p.n_tiles;
+
+  const OdinRangeReq in_rq = odin_range_issue(p.in_amax, lane);
+  const int kh_a = rpar ? 0 : 1, kw_a = cpw ? 0 : 1;
+  float4 wv[4][2][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int tap = (kh_a + 2 * (t >> 1)) * 4 + kw_a + 2 * (t & 1);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const float* src = p.w + ((size_t)(tap * 32 + 16 * nb + l15) * 32 + 8 * lq);
+      wv[t][nb][0] = *reinterpret_cast<const float4*>(src);
+      wv[t][nb][1] = *reinterpret_cast<const float4*>(src + 4);
+    }
+  }
+  const OdinRun IN = odin_run(p.in, (unsigned)((size_t)p.B * p.H * p.W * 32 * 4));
+  int it_dst[2], it_g[2], it_wr[2], it_wc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + 512 * j;
+    const int px = e >> 3, ch4 = e & 7;
+    const int wr = odin_div_small(px, 10), wc = px - 10 * wr;
+    it_wr[j] = (e < 800) ? wr : (1 << 20);
+    it_wc[j] = wc;
+    it_dst[j] = wr * 1024 + wc * 64 + (((ch4 >> 1) ^ tb_swz(wr, wc)) << 4) + (ch4 & 1) * 8;
+    it_g[j] = ((wr * p.W + wc) * 32 + 4 * ch4) * 4;
+  }
+  float4 itv[2];
+  auto issue = [&](int b, int ty, int tx) {
+    const int base = ((b * p.H + 8 * ty - 1) * p.W + 8 * tx - 1) * 32 * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gr = 8 * ty - 1 + it_wr[j], gc = 8 * tx - 1 + it_wc[j];
+      const bool ok = gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
+      itv[j] = odin_run_load4(IN, ok ? (unsigned)(base + it_g[j]) : ODIN_OOB);
+    }
+  };
+  float in_s = 1.f, in_s2k = ODIN_LO_SCALE, out_s = 1.f, out_sx = ODIN_LO_UNSCALE;
+  auto stage = [&](char* buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (tid + 512 * j < 800) {
+        u32x2 h, l;
+        odin_split_h4<true>(itv[j], in_s, in_s2k, h, l);
+        *reinterpret_cast<u32x2*>(buf + it_dst[j]) = h;
+        *reinterpret_cast<u32x2*>(buf + it_dst[j] + TB_PLB) = l;
+      }
+    }
+  };
+  int b_c, ty_c, tx_c;
+  bk_decode(T0, p.nty, p.ntx, b_c, ty_c, tx_c);
+  if (T0 < T1) issue(b_c, ty_c, tx_c);
+  {
+    const unsigned mb = odin_range_finish(in_rq);
+    const int gk = bk_shift(mb, 0);
+    in_s = odin_pow2(gk); in_s2k = odin_pow2(gk + 11);
+    out_s = odin_pow2(-gk); out_sx = odin_pow2(-gk - 11);
+  }
+  u32x4 wh[4][2], wl[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) bk_split8(wv[t][nb][0], wv[t][nb][1], 1.f, ODIN_LO_SCALE, wh[t][nb], wl[t][nb]);
+  if (T0 < T1) stage(smem);
+  __syncthreads();
+
+  const int ri0 = l15 >> 3, cj = l15 & 7;   // pixel block pb: tile rows 2 pb + ri0
+  int boff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = ri0 + (rpar ? 2 : 1) - (t >> 1), col = cj + (cpw ? 2 : 1) - (t & 1);
+    boff[t] = row * 1024 + col * 64 + ((lq ^ tb_swz(row, col)) << 4);
+  }
+  const unsigned npix_bytes = (unsigned)((size_t)p.B * OH * OW * 4);
+  const OdinRun OUT = odin_run(p.out, npix_bytes * 32u);
+  const OdinRun TG = odin_run(p.target, npix_bytes);
+  const OdinRun LG = odin_run(p.logits, p.logits != nullptr ? npix_bytes * 2u : 0u);
+  const unsigned pix_lane = (unsigned)((2 * ri0 + rpar) * OW + 2 * cj + cpw);
+  const unsigned pix_step = (unsigned)(4 * OW);   // two tile rows = four fine rows
+  // this lane's channels: 16 nb + 4 lq + r
+  float bias_r[2][4], w1r[2][4][2], dw1[2][4][2], csum[2][4];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = 16 * nb + 4 * lq + r;
+      bias_r[nb][r] = p.bias[ch];
+      w1r[nb][r][0] = p.w1[2 * ch];
+      w1r[nb][r][1] = p.w1[2 * ch + 1];
+      dw1[nb][r][0] = dw1[nb][r][1] = 0.f;
+      csum[nb][r] = 0.f;
+    }
+  const float b1_0 = p.b1[0], b1_1 = p.b1[1];
+  float db1_0 = 0.f, db1_1 = 0.f;
+  const float sc = p.scale[0];
+  float amx = 0.f;
+
+#pragma unroll 1
+  for (int T = T0; T < T1; ++T) {
+    const char* buf = smem + ((T - T0) & 1) * TB_KPB;
+    char* nbuf = smem + (((T - T0) & 1) ^ 1) * TB_KPB;
+    int b_n = 0, ty_n = 0, tx_n = 0;
+    if (T + 1 < T1) {
+      bk_decode(T + 1, p.nty, p.ntx, b_n, ty_n, tx_n);
+      issue(b_n, ty_n, tx_n);
+    }
+    const unsigned tile_pix = (unsigned)((b_c * OH + 16 * ty_c) * OW + 16 * tx_c);
+    unsigned vpix[2];
+    float tgt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pb = 2 * pbh + i;
+      const bool ok = 8 * ty_c + 2 * pb + ri0 < p.H && 8 * tx_c + cj < p.W;
+      vpix[i] = ok ? pix_lane + pb * pix_step : 0x3FFF0000u;   // (x 4 ... x 128 bytes stays out of range, no wrap below 2^32)
+      tgt[i] = odin_run_load1s(TG, ok ? vpix[i] * 4u : ODIN_OOB_V, tile_pix * 4u);
+    }
+    f32x4 acc[2][2], acx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) { acc[i][nb] = bk_zero4(); acx[i][nb] = bk_zero4(); }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const char* a = buf + boff[t] + (2 * pbh + i) * 2048;
+        const u32x4 xh = *reinterpret_cast<const u32x4*>(a);
+        const u32x4 xl = *reinterpret_cast<const u32x4*>(a + TB_PLB);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          acx[i][nb] = mfma16_f16(wh[t][nb], xl, acx[i][nb]);
+          acc[i][nb] = mfma16_f16(wh[t][nb], xh, acc[i][nb]);
+          acx[i][nb] = mfma16_f16(wl[t][nb], xh, acx[i][nb]);
+        }
+      }
+    if (T + 1 < T1) stage(nbuf);
+    float llk_lane = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = vpix[i] != 0x3FFF0000u;
+      float y[2][4];
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          y[nb][r] = odin_act(p.act, fmaf(acx[i][nb][r], out_sx, acc[i][nb][r] * out_s) + bias_r[nb][r]);
+          t0 = fmaf(y[nb][r], w1r[nb][r][0], t0);
+          t1 = fmaf(y[nb][r], w1r[nb][r][1], t1);
+        }
+      t0 += __shfl_xor(t0, 16); t1 += __shfl_xor(t1, 16);
+      t0 += __shfl_xor(t0, 32); t1 += __shfl_xor(t1, 32);
+      const float loc = t0 + b1_0, raw = t1 + b1_1;
+      float sd, dsd;
+      if (SP1 == 1) {  // softplus1(raw) = softplus(raw + softplus^-1(1)); its derivative = sigmoid of the same
+        const float a = raw + 0.5413248546129181f;
+        const float e = odin_exp2(-1.4426950408889634f * fabsf(a));
+        const float r = odin_rcp(1.f + e);
+        sd = fmaxf(a, 0.f) + 0.6931471805599453f * odin_log2(1.f + e);
+        dsd = a >= 0.f ? r : e * r;
+      } else {
+        sd = raw;
+        dsd = 1.f;
+      }
+      const float inv = 1.f / sd;
+      const float d = (tgt[i] - loc) * inv;
+      float l1 = -0.5f * d * d - 0.6931471805599453f * odin_log2(sd) - 0.5f * 1.8378770664093453f;
+      float dl0 = -(d * inv) * sc, dl1 = -((d * d - 1.f) * inv) * dsd * sc;
+      if (!ok) { dl0 = 0.f; dl1 = 0.f; l1 = 0.f; }
+      const bool first = lq == 0;
+      llk_lane += first ? l1 : 0.f;
+      db1_0 += first ? dl0 : 0.f;
+      db1_1 += first ? dl1 : 0.f;
+      const unsigned lgoff = (ok && first) ? vpix[i] * 8u : ODIN_OOB_V;
+      odin_run_store1s(LG, lgoff, tile_pix * 8u, loc);
+      odin_run_store1s(LG, lgoff == ODIN_OOB_V ? ODIN_OOB_V : lgoff + 4u, tile_pix * 8u, raw);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        float gq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gs = fmaf(w1r[nb][r][1], dl1, w1r[nb][r][0] * dl0);
+          dw1[nb][r][0] = fmaf(y[nb][r], dl0, dw1[nb][r][0]);
+          dw1[nb][r][1] = fmaf(y[nb][r], dl1, dw1[nb][r][1]);
+          gq[r] = gs * odin_act_grad(p.act, y[nb][r]);
+          csum[nb][r] += gq[r];
+        }
+        amx = odin_amax3(odin_amax3(amx, gq[0], gq[1]), gq[2], gq[3]);
+        odin_run_store4s(OUT, ok ? vpix[i] * 128u + (unsigned)((16 * nb + 4 * lq) * 4) : ODIN_OOB_V, tile_pix * 128u,
+                         make_float4(gq[0], gq[1], gq[2], gq[3]));
+      }
+    }
+    {
+      const float tt = wave_sum64(llk_lane);
+      if (lane == 0) llk_red[(T - T0) & 1][wave] = tt;
+    }
+    b_c = b_n; ty_c = ty_n; tx_c = tx_n;
+    __syncthreads();
+    if (tid == 0) {
+      const float* q = llk_red[(T - T0) & 1];
+      p.llk_part[T] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    }
+  }
+
+  odin_amax_commit_wg(p.out_amax, amx, tid, 512, cred + 8 * TG_ROW, blockIdx.x);
+  // ---- slab row [dW1 (32 x 2) | db1 (2) | column sums of out (32)]: the 16 pixel lanes, then the 8 waves through LDS ----
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = 16 * nb + 4 * lq + r;
+      float a0 = dw1[nb][r][0], a1 = dw1[nb][r][1], cs = csum[nb][r];
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); cs += __shfl_xor(cs, m); }
+      if (l15 == 0) {
+        cred[wave * TG_ROW + 2 * ch] = a0;
+        cred[wave * TG_ROW + 2 * ch + 1] = a1;
+        cred[wave * TG_ROW + 66 + ch] = cs;
+      }
+    }
+  {
+    float d0 = db1_0, d1 = db1_1;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) { d0 += __shfl_xor(d0, m); d1 += __shfl_xor(d1, m); }
+    if (lane == 0) { cred[wave * TG_ROW + 64] = d0; cred[wave * TG_ROW + 65] = d1; }
+  }
+  __syncthreads();
+  if (tid < TG_ROW) {
+    float tt = 0.f;
+    for (int wv = 0; wv < 8; ++wv) tt += cred[wv * TG_ROW + tid];
+    p.slab[(size_t)blockIdx.x * TG_ROW + tid] = tt;
+  }
+}
+
+}  // namespace
+
+// 1: odin_gaussian_tail_fwd_bwd takes this layer (Conv2DTranspose k4 s2 32 -> 32 + 1x1 head of 2 maps, C = 1)
+extern "C" int odin_gaussian_tail_applicable(const odin_conv_desc* d, int C) {
+  return (C == 1 && d->Cin == 32 && d->Cout == 32 && d->OH == 2 * d->H && d->OW == 2 * d->W &&
+          odin_tconv_blk_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l,
+                                    d->center) &&
+          (size_t)d->B * d->OH * d->OW < 0x3FFF0000ull / 32) ? 1 : 0;
+}
+
+extern "C" int odin_gaussian_tail_fwd_bwd(const float* x, const float* w, const float* bias, const float* w1,
+                                          const float* b1, const float* target, float* logits, float* g_out,
+                                          float* llk_part, int* n_part_out, float* tail_slab, int* slab_rows_out,
+                                          const float* scale, const odin_conv_desc* d, int C, int softplus1,
+                                          void* stream) {
+  if (!odin_gaussian_tail_applicable(d, C) || (softplus1 != 0 && softplus1 != 1))
+    return odin_fail(-2, "gaussian_tail: shapes outside the kernel");
+  TGParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = x; p.w = w; p.bias = bias; p.w1 = w1; p.b1 = b1; p.target = target; p.logits = logits; p.out = g_out;
+  p.llk_part = llk_part; p.slab = tail_slab; p.scale = scale;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.act = d->act;
+  p.nty = (d->H + 7) / 8; p.ntx = (d->W + 7) / 8;
+  p.n_tiles = d->B * p.nty * p.ntx;
+  p.tiles_per_wg = tb_tiles_per_wg(p.n_tiles, 1);
+  const int gx = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+  if (slab_rows_out) *slab_rows_out = gx;
+  if (n_part_out) *n_part_out = p.nty * p.ntx;
+  if (g_out == nullptr) return 0;  // dry run
+  p.in_amax = d->x_amax;
+  p.out_amax = d->dy_amax;
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_blk_gtail_kernel<0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_KPB);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_blk_gtail_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_KPB);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+#endif
+  if (softplus1 == 1) ODIN_LAUNCH((tconv_blk_gtail_kernel<1>), dim3(gx), dim3(512), (size_t)2 * TB_KPB, stream, p);
+  else ODIN_LAUNCH((tconv_blk_gtail_kernel<0>), dim3(gx), dim3(512), (size_t)2 * TB_KPB, stream, p);
+  return odin_check_launch("tconv_blk_gtail(f16x2)");
+}

@@ -684,7 +684,11 @@ class VAEEngine:
     """Training-step fusion layer[-2](act) -> Conv2D 1x1 -> Bernoulli log-prob + backward
     (odin_bernoulli_tail_fwd_bwd) when the decoder ends that way."""
     self.fused_tail = False
+    self.tail_mode = None   # None: Bernoulli (odin_bernoulli_tail_fwd_bwd); 0 / 1: Normal with a raw / softplus1 scale
     recs = self.dec_recs
+    if len(recs) >= 2 and self.observation in ('gaussian', 'gaussian_softplus1'):
+      self._plan_gauss_tail(f32)
+      return
     if self.observation != 'bernoulli' or len(recs) < 2:
       return
     a, b = recs[-2], recs[-1]
@@ -711,6 +715,29 @@ class VAEEngine:
     self.tail_slab = torch.empty(rows.value, co * c1 + c1 + co, **f32)
     self.tail_llk_part = torch.empty(self.B * npart.value, **f32)
 
+  def _plan_gauss_tail(self, f32):
+    """Training-step fusion Conv2DTranspose(k4, s2, 32 -> 32) -> Conv2D 1x1 (loc | scale) -> Normal log-prob + backward
+    in ONE launch (odin_gaussian_tail_fwd_bwd, blk_planes.hip): the audio VAE's decoder4 -> decoder6 -> observation
+    (examples/vae/vae_audio.py:84-110) without the 32-channel activation ever reaching HBM."""
+    a, b = self.dec_recs[-2], self.dec_recs[-1]
+    Cc = self.in_shape[-1]
+    if not (b.kind == 'conv' and b.desc['K'] == 1 and b.desc['stride'] == 1 and b.act == 'linear'
+            and b.desc['Cout'] == 2 * Cc and a.kind == 'deconv'):
+      return
+    d = self.dec.descs[-2]
+    if not self.lib.odin_gaussian_tail_applicable(C.byref(d), Cc):
+      return
+    rows, npart = C.c_int(0), C.c_int(0)
+    self.lib.odin_gaussian_tail_fwd_bwd(None, None, None, None, None, None, None, None, None, C.byref(npart), None,
+                                        C.byref(rows), None, C.byref(d), Cc, OBS_MODE[self.observation], None)
+    self.fused_tail = True
+    self.tail_mode = OBS_MODE[self.observation]
+    self.tail_keeps_range = True
+    self.tail_rows, self.tail_npart = rows.value, npart.value
+    co, c1 = a.desc['Cout'], b.desc['Cout']
+    self.tail_slab = torch.empty(rows.value, co * c1 + c1 + co, **f32)
+    self.tail_llk_part = torch.empty(self.B * npart.value, **f32)
+
   def _plan_gauss_head(self, f32):
     """Training-step fusion Conv2D 1x1 -> Normal log-prob + backward (odin_gaussian_head_fwd_bwd) when the decoder
     ends in the 1x1 head of a Gaussian observation (the audio VAE, examples/vae/vae_audio.py:84-110): one pass over
@@ -725,6 +752,8 @@ class VAEEngine:
     if not (b.kind == 'conv' and b.desc['K'] == 1 and b.desc['stride'] == 1 and b.act == 'linear'
             and b.desc['Cout'] == (Cc if bern else 2 * Cc) and a.kind in ('conv', 'deconv')):
       return
+    if not bern and self.fused_tail:
+      return   # (the Gaussian tail runs inside the layer's own launch: _plan_gauss_tail)
     if bern and self.fused_tail:
       # the Bernoulli decoders whose last two layers run as ONE plane-kernel launch keep it (dSprites, Shapes3D, CelebA);
       # the generic fused tail (fp32 gather kernel) gives way to layer + head where the layer is big enough for the
@@ -1174,13 +1203,22 @@ class VAEEngine:
       h = self.dec.forward(dec_in, st, upto=nd - 2, start=dec_start)
       a, b = self.dec_recs[-2], self.dec_recs[-1]
       rows = C.c_int(0)
-      lib.odin_bernoulli_tail_fwd_bwd(
-          int(a.kind == 'deconv'), h.data_ptr(), self.dec.w(nd - 2).data_ptr(),
-          self.dec.b(nd - 2).data_ptr(), self.dec.w(nd - 1).data_ptr(),
-          self.dec.b(nd - 1).data_ptr(), x.data_ptr(), self.dec.outs[-1].data_ptr(),
-          self.dec.gouts[-2].data_ptr(), self.tail_llk_part.data_ptr(), C.byref(npart),
-          self.tail_slab.data_ptr(), C.byref(rows), self.hp(H_INVB), C.byref(self.dec.descs[-2]),
-          b.desc['Cout'], st)
+      if self.tail_mode is not None:
+        lib.odin_gaussian_tail_fwd_bwd(
+            h.data_ptr(), self.dec.w(nd - 2).data_ptr(), self.dec.b(nd - 2).data_ptr(),
+            self.dec.w(nd - 1).data_ptr(), self.dec.b(nd - 1).data_ptr(), x.data_ptr(),
+            self.dec.outs[-1].data_ptr(), self.dec.gouts[-2].data_ptr(), self.tail_llk_part.data_ptr(),
+            C.byref(npart), self.tail_slab.data_ptr(), C.byref(rows), self.hp(H_INVB),
+            C.byref(self.dec.descs[-2]), self.in_shape[-1], self.tail_mode, st)
+        assert rows.value == self.tail_rows and npart.value == self.tail_npart
+      else:
+        lib.odin_bernoulli_tail_fwd_bwd(
+            int(a.kind == 'deconv'), h.data_ptr(), self.dec.w(nd - 2).data_ptr(),
+            self.dec.b(nd - 2).data_ptr(), self.dec.w(nd - 1).data_ptr(),
+            self.dec.b(nd - 1).data_ptr(), x.data_ptr(), self.dec.outs[-1].data_ptr(),
+            self.dec.gouts[-2].data_ptr(), self.tail_llk_part.data_ptr(), C.byref(npart),
+            self.tail_slab.data_ptr(), C.byref(rows), self.hp(H_INVB), C.byref(self.dec.descs[-2]),
+            b.desc['Cout'], st)
       self._used_fused = True
       llk_part = self.tail_llk_part
       h_d = self.dec.outs[-1]

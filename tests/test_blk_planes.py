@@ -162,3 +162,61 @@ def test_conv(blk, B, H, W, Ci, Co, act, xs, gs):
   g = reduce_slab(bk, slab, rows.value, n)
   close(g[:-Co].reshape(K, K, Ci, Co) / (gs * xs), dw_ref / (gs * xs), 1e-4)
   close(g[-Co:] / gs, db_ref / gs, 1e-4)
+
+
+@pytest.mark.parametrize('B,H,W,act,sp1', [(2, 12, 10, 'elu', 1), (3, 5, 9, 'relu', 0), (1, 16, 8, 'elu', 1)])
+def test_gaussian_tail(blk, B, H, W, act, sp1):
+  """odin_gaussian_tail_fwd_bwd (Conv2DTranspose 32 -> 32 -> 1x1 head of 2 maps -> Normal log-prob, forward + backward in
+  one launch) against torch float64 autograd of the same three steps (the style of oracle/torch_ref.py)."""
+  import torch.nn.functional as F
+  bk = blk
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(7 * B + H)
+  OH, OW = 2 * H, 2 * W
+  N = dict(x=rng.standard_normal((B, H, W, 32)), w=rng.standard_normal((4, 4, 32, 32)) * 0.1,
+           b=rng.standard_normal(32) * 0.1, w1=rng.standard_normal((32, 2)) * 0.2, b1=np.array([0.1, 0.7 if sp1 else 1.5]),
+           t=rng.standard_normal((B, OH, OW, 1)))
+  if not sp1:
+    N['w1'][:, 1] *= 0.05     # (a raw scale must stay positive)
+  d = _lib.conv_desc(B, H, W, 32, OH, OW, 32, 4, 2, 1, 1, act)
+  tn = {k: T(v) for k, v in N.items()}
+  gw, xw = bk.zeros(2048, dtype=torch.int32), word_of(bk, tn['x'])
+  d.x_amax, d.dy_amax = xw.data_ptr(), gw.data_ptr()
+  assert L.odin_gaussian_tail_applicable(C.byref(d), 1) == 1
+  rows, npart = C.c_int(0), C.c_int(0)
+  L.odin_gaussian_tail_fwd_bwd(None, None, None, None, None, None, None, None, None, C.byref(npart), None, C.byref(rows),
+                               None, C.byref(d), 1, sp1, None)
+  assert npart.value == ((H + 7) // 8) * ((W + 7) // 8) and rows.value >= 1
+  logits, g = bk.full((B, OH, OW, 2), float('nan')), bk.full((B, OH, OW, 32), float('nan'))
+  llk_part, slab = bk.full((B * npart.value,), float('nan')), bk.full((rows.value, 98), float('nan'))
+  scale = T(np.array([1.0 / B]))
+  r2, n2 = C.c_int(0), C.c_int(0)
+  L.odin_gaussian_tail_fwd_bwd(tn['x'].data_ptr(), tn['w'].data_ptr(), tn['b'].data_ptr(), tn['w1'].data_ptr(),
+                               tn['b1'].data_ptr(), tn['t'].data_ptr(), logits.data_ptr(), g.data_ptr(),
+                               llk_part.data_ptr(), C.byref(n2), slab.data_ptr(), C.byref(r2), scale.data_ptr(),
+                               C.byref(d), 1, sp1, None)
+  assert (r2.value, n2.value) == (rows.value, npart.value)
+  assert L.odin_debug_last_path().decode() == 'tconv_blk_gtail(f16x2)'
+  # ---- float64 restatement
+  actf = {'elu': F.elu, 'relu': F.relu}[act]
+  tt = {k: torch.tensor(v, dtype=torch.float64) for k, v in N.items()}
+  for k in ('w1', 'b1', 'b'):
+    tt[k].requires_grad_(True)
+  pre = F.conv_transpose2d(tt['x'].permute(0, 3, 1, 2), tt['w'].permute(3, 2, 0, 1), tt['b'], stride=2, padding=1)
+  pre.retain_grad()
+  y = actf(pre).permute(0, 2, 3, 1)
+  lg = y @ tt['w1'] + tt['b1']
+  loc, raw = lg[..., :1], lg[..., 1:]
+  sd = F.softplus(raw + np.log(np.e - 1.0)) if sp1 else raw
+  llk = (-0.5 * ((tt['t'] - loc) / sd) ** 2 - torch.log(sd) - 0.5 * np.log(2 * np.pi)).sum((1, 2, 3))
+  loss = -(llk.sum() / B)
+  loss.backward()
+  close(logits.cpu().numpy(), lg.detach().numpy())
+  close(llk_part.cpu().numpy().reshape(B, -1).sum(1), llk.detach().numpy(), 1e-5)
+  g_ref = pre.grad.permute(0, 2, 3, 1).numpy()
+  close(g.cpu().numpy(), g_ref, 1e-4 * max(1e-30, float(np.abs(g_ref).max())) / max(1.0, float(np.abs(g_ref).max())))
+  row = slab.cpu().numpy().astype(np.float64).sum(0)
+  close(row[:64].reshape(32, 2), tt['w1'].grad.numpy(), 1e-4)
+  close(row[64:66], tt['b1'].grad.numpy(), 1e-4)
+  close(row[66:], tt['b'].grad.numpy(), 1e-4)
+  assert word_max(gw) >= float(np.abs(g_ref).max()) * (1 - 1e-5) and word_max(gw) <= float(np.abs(g_ref).max()) * 1.001

@@ -259,3 +259,21 @@ def test_fused_norm_matches_separate_launch(L):
       assert n0 > clip * clip
       assert float((p0 - p1).abs().max()) <= 1e-6 and float((o0 - o1).abs().max()) <= 1e-4 * float(o0.abs().max())
     assert int(e1.hyper[16:17].view(torch.int32)) == n + 1
+
+
+@pytest.mark.parametrize('obs,B', [('gaussian_softplus1', 3), ('gaussian_softplus1', 2)])
+def test_audio_stack_on_block_window_kernels(L, request, obs, B):
+  """the audio VAE's layer shapes in miniature (rows of 20 / 10 / 5 pixels; examples/vae/vae_audio.py:84-110) with the
+  block-window plane kernels taking every 32-channel 4x4 / stride-2 layer and the fused Gaussian tail (blk_planes.hip):
+  decoder4 -> 1x1 head -> Normal log-prob and its backward as one launch inside a whole training step"""
+  request.addfinalizer(lambda old=L.odin_debug_blk_min_flop(0.0): L.odin_debug_blk_min_flop(old))
+  enc = [('conv', 32, 4, 2, 'elu'), ('conv', 32, 4, 2, 'elu'), ('flatten',), ('dense', 24, 'linear')]
+  dec = [('dense', 3 * 5 * 8, 'linear'), ('reshape', (3, 5, 8)), ('deconv', 32, 4, 2, 'elu'), ('deconv', 32, 4, 2, 'elu'),
+         ('conv', 2, 1, 1, 'linear')]
+  enc, dec, in_shape, zd, x, eps = make_case((enc, dec, (12, 20, 1), 5), obs, B)
+  model = vo.OracleVAE(enc, dec, in_shape, zd, observation=obs, beta=1.0)
+  P = model.init_params(seed=9)
+  eng = VAEEngine(enc, dec, in_shape, zd, B, 'cpu', observation=obs, lib=L)
+  assert eng.fused_tail and eng.tail_mode == (1 if obs == 'gaussian_softplus1' else 0) and not eng.gauss_head
+  check_engine_vs_oracle(eng, model, P, x, eps, beta=1.0, steps=2, clip=100.0)
+  assert eng._used_fused
