@@ -63,6 +63,46 @@ __device__ __forceinline__ void bk_split8(const float4& a, const float4& b, floa
   l[0] = l0[0]; l[1] = l0[1]; l[2] = l1[0]; l[3] = l1[1];
 }
 
+// activation and its derivative (from the OUTPUT) with the function a compile-time constant -- ACT = ODIN_ACT_* -- or, ACT < 0,
+// the run-time switch of odin_act (two scalar branches per ELEMENT inside the epilogues: measured on the first build,
+// 140 branches per tile)
+template <int ACT>
+__device__ __forceinline__ float bk_act(int rt, float v) {
+  if (ACT == ODIN_ACT_ELU) {
+    const float em1 = odin_exp2(v * 1.44269504088896341f) - 1.f;
+    return v > 0.f ? v : em1;
+  }
+  if (ACT == ODIN_ACT_RELU) return fmaxf(v, 0.f);
+  if (ACT == ODIN_ACT_LINEAR) return v;
+  return odin_act(rt, v);
+}
+template <int ACT>
+__device__ __forceinline__ float bk_act_grad(int rt, float y) {
+  if (ACT == ODIN_ACT_ELU) return 1.f + fminf(y, 0.f);
+  if (ACT == ODIN_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (ACT == ODIN_ACT_LINEAR) return 1.f;
+  return odin_act_grad(rt, y);
+}
+// x + the value of lane ^ 16 / lane ^ 32 without an LDS round trip (gfx950 row swaps)
+__device__ __forceinline__ float bk_add_xor16(float x) {
+#ifdef ODIN_SIM
+  return x + __shfl_xor(x, 16);
+#else
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
+}
+__device__ __forceinline__ float bk_add_xor32(float x) {
+#ifdef ODIN_SIM
+  return x + __shfl_xor(x, 32);
+#else
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
+}
+
 // the scale of a plane operand from its range word: gradients always (odin_range_shift), activations only when their
 // bound leaves the f16 window (odin_act_needs_scale); gk = 0: carried as it is
 __device__ __forceinline__ int bk_shift(unsigned mb, int is_grad) {
@@ -93,7 +133,7 @@ constexpr int TB_PLB = 10 * 16 * 64;     // one plane
 constexpr int TB_KPB = 2 * TB_PLB;       // one 32-channel pass
 __host__ __device__ constexpr int tb_swz(int row, int col) { return ((col >> 2) + 2 * (row & 1)) & 3; }
 
-template <int EPI, int NK>
+template <int EPI, int NK, int ACT>
 __global__ __launch_bounds__(512) void tconv_blk_kernel(TBParams p) {
   constexpr int BUFB = NK * TB_KPB;
   constexpr int NIT = (800 * NK + 511) / 512;   // float4 items per thread and window
@@ -250,13 +290,13 @@ __global__ __launch_bounds__(512) void tconv_blk_kernel(TBParams p) {
       for (int r = 0; r < 4; ++r) v[r] = fmaf(acx[pb][r], out_sx, acc[pb][r] * out_s);
       if (EPI == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = odin_act(p.act, v[r] + bias_r[r]);
+        for (int r = 0; r < 4; ++r) v[r] = bk_act<ACT>(p.act, v[r] + bias_r[r]);
       } else {
         const bool ok = voff[pb] != ODIN_OOB_V;
         const float a4[4] = {ax[pb].x, ax[pb].y, ax[pb].z, ax[pb].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = ok ? v[r] * odin_act_grad(p.act, a4[r]) : 0.f;
+          v[r] = ok ? v[r] * bk_act_grad<ACT>(p.act, a4[r]) : 0.f;
           csum[r] += v[r];
         }
       }
@@ -296,20 +336,25 @@ int tb_tiles_per_wg(int n_tiles, int gy) {
   return (n_tiles + cap - 1) / cap;
 }
 
-template <int EPI, int NK>
-int tb_launch(const TBParams& p, dim3 grid, void* stream) {
+template <int EPI, int NK, int ACT>
+int tb_launch_a(const TBParams& p, dim3 grid, void* stream) {
   const size_t lds = (size_t)2 * NK * TB_KPB;
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_blk_kernel<EPI, NK>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_blk_kernel<EPI, NK, ACT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_MAX) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((tconv_blk_kernel<EPI, NK>), grid, dim3(512), lds, stream, p);
+  ODIN_LAUNCH((tconv_blk_kernel<EPI, NK, ACT>), grid, dim3(512), lds, stream, p);
   return odin_check_launch("tconv_blk(f16x2)");
+}
+// ELU (every conv layer of the reference's stacks) as a compile-time constant, anything else through the run-time switch
+template <int EPI, int NK>
+int tb_launch(const TBParams& p, dim3 grid, void* stream) {
+  return p.act == ODIN_ACT_ELU ? tb_launch_a<EPI, NK, ODIN_ACT_ELU>(p, grid, stream) : tb_launch_a<EPI, NK, -1>(p, grid, stream);
 }
 
 }  // namespace
@@ -455,7 +500,7 @@ struct FBParams {
   int in_is_grad;
 };
 
-template <int EPI>
+template <int EPI, int ACT>
 __global__ __launch_bounds__(512) void fconv_blk_kernel(FBParams p) {
   ODIN_DYN_SMEM(char, smem);
   __shared__ float cred[8 * 16 + 16];
@@ -551,12 +596,12 @@ __global__ __launch_bounds__(512) void fconv_blk_kernel(FBParams p) {
     for (int r = 0; r < 4; ++r) v[r] = fmaf(acx[0][r] + acx[1][r], out_sx, (acc[0][r] + acc[1][r]) * out_s);
     if (EPI == 1) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = odin_act(p.act, v[r] + bias_r[r]);
+      for (int r = 0; r < 4; ++r) v[r] = bk_act<ACT>(p.act, v[r] + bias_r[r]);
     } else {
       const float a4[4] = {ax.x, ax.y, ax.z, ax.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = ok ? v[r] * odin_act_grad(p.act, a4[r]) : 0.f;
+        v[r] = ok ? v[r] * bk_act_grad<ACT>(p.act, a4[r]) : 0.f;
         csum[r] += v[r];
       }
     }
@@ -585,20 +630,24 @@ __global__ __launch_bounds__(512) void fconv_blk_kernel(FBParams p) {
   }
 }
 
-template <int EPI>
-int fb_launch(const FBParams& p, dim3 grid, void* stream) {
+template <int EPI, int ACT>
+int fb_launch_a(const FBParams& p, dim3 grid, void* stream) {
   const size_t lds = (size_t)2 * FW_BYTES;
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fconv_blk_kernel<EPI>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fconv_blk_kernel<EPI, ACT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FW_BYTES) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((fconv_blk_kernel<EPI>), grid, dim3(512), lds, stream, p);
+  ODIN_LAUNCH((fconv_blk_kernel<EPI, ACT>), grid, dim3(512), lds, stream, p);
   return odin_check_launch("fconv_blk(f16x2)");
+}
+template <int EPI>
+int fb_launch(const FBParams& p, dim3 grid, void* stream) {
+  return p.act == ODIN_ACT_ELU ? fb_launch_a<EPI, ODIN_ACT_ELU>(p, grid, stream) : fb_launch_a<EPI, -1>(p, grid, stream);
 }
 
 // =====================================================================================================================
@@ -917,7 +966,7 @@ struct TGParams {
 
 constexpr int TG_ROW = 32 * 2 + 2 + 32;
 
-template <int SP1>
+template <int SP1, int ACT>
 __global__ __launch_bounds__(512) void tconv_blk_gtail_kernel(TGParams p) {
   ODIN_DYN_SMEM(char, smem);
   __shared__ float cred[8 * TG_ROW + 16];
@@ -1076,12 +1125,12 @@ __global__ __launch_bounds__(512) void tconv_blk_gtail_kernel(TGParams p) {
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          y[nb][r] = odin_act(p.act, fmaf(acx[i][nb][r], out_sx, acc[i][nb][r] * out_s) + bias_r[nb][r]);
+          y[nb][r] = bk_act<ACT>(p.act, fmaf(acx[i][nb][r], out_sx, acc[i][nb][r] * out_s) + bias_r[nb][r]);
           t0 = fmaf(y[nb][r], w1r[nb][r][0], t0);
           t1 = fmaf(y[nb][r], w1r[nb][r][1], t1);
         }
-      t0 += __shfl_xor(t0, 16); t1 += __shfl_xor(t1, 16);
-      t0 += __shfl_xor(t0, 32); t1 += __shfl_xor(t1, 32);
+      t0 = bk_add_xor32(bk_add_xor16(t0));
+      t1 = bk_add_xor32(bk_add_xor16(t1));
       const float loc = t0 + b1_0, raw = t1 + b1_1;
       float sd, dsd;
       if (SP1 == 1) {  // softplus1(raw) = softplus(raw + softplus^-1(1)); its derivative = sigmoid of the same
@@ -1114,7 +1163,7 @@ __global__ __launch_bounds__(512) void tconv_blk_gtail_kernel(TGParams p) {
           const float gs = fmaf(w1r[nb][r][1], dl1, w1r[nb][r][0] * dl0);
           dw1[nb][r][0] = fmaf(y[nb][r], dl0, dw1[nb][r][0]);
           dw1[nb][r][1] = fmaf(y[nb][r], dl1, dw1[nb][r][1]);
-          gq[r] = gs * odin_act_grad(p.act, y[nb][r]);
+          gq[r] = gs * bk_act_grad<ACT>(p.act, y[nb][r]);
           csum[nb][r] += gq[r];
         }
         amx = odin_amax3(odin_amax3(amx, gq[0], gq[1]), gq[2], gq[3]);
@@ -1198,15 +1247,23 @@ extern "C" int odin_gaussian_tail_fwd_bwd(const float* x, const float* w, const 
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_blk_gtail_kernel<0>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_KPB);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_blk_gtail_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_KPB);
-    (void)hipGetLastError();
+    const void* fns[4] = {reinterpret_cast<const void*>(&tconv_blk_gtail_kernel<0, ODIN_ACT_ELU>),
+                          reinterpret_cast<const void*>(&tconv_blk_gtail_kernel<1, ODIN_ACT_ELU>),
+                          reinterpret_cast<const void*>(&tconv_blk_gtail_kernel<0, -1>),
+                          reinterpret_cast<const void*>(&tconv_blk_gtail_kernel<1, -1>)};
+    for (int i = 0; i < 4; ++i)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_KPB) != hipSuccess)
+        (void)hipGetLastError();
     attr_done = true;
   }
 #endif
-  if (softplus1 == 1) ODIN_LAUNCH((tconv_blk_gtail_kernel<1>), dim3(gx), dim3(512), (size_t)2 * TB_KPB, stream, p);
-  else ODIN_LAUNCH((tconv_blk_gtail_kernel<0>), dim3(gx), dim3(512), (size_t)2 * TB_KPB, stream, p);
+  const size_t lds = (size_t)2 * TB_KPB;
+  if (d->act == ODIN_ACT_ELU) {
+    if (softplus1 == 1) ODIN_LAUNCH((tconv_blk_gtail_kernel<1, ODIN_ACT_ELU>), dim3(gx), dim3(512), lds, stream, p);
+    else ODIN_LAUNCH((tconv_blk_gtail_kernel<0, ODIN_ACT_ELU>), dim3(gx), dim3(512), lds, stream, p);
+  } else {
+    if (softplus1 == 1) ODIN_LAUNCH((tconv_blk_gtail_kernel<1, -1>), dim3(gx), dim3(512), lds, stream, p);
+    else ODIN_LAUNCH((tconv_blk_gtail_kernel<0, -1>), dim3(gx), dim3(512), lds, stream, p);
+  }
   return odin_check_launch("tconv_blk_gtail(f16x2)");
 }
