@@ -287,10 +287,23 @@ extern "C" int odin_stft_mel_db_frames(const float* y, const double* window, con
 #endif
   // one workgroup per utterance leaves most of the chip idle at batch 256 (208 us for 0.4 GFLOP of float64): the
   // blocks of fpb frames of an utterance are dealt to up to 8 workgroups, the floor follows in a second launch
+  // How many: every workgroup walks ceil(nblocks / gy) passes and the chip holds `slots` workgroups at a time (LDS: five
+  // per CU at 28.7 KB), so the launch takes ceil(B gy / slots) rounds of that many passes -- round 5's power-of-two
+  // choice (8 at batch 256: 2048 workgroups for 1280 slots, two rounds of 4 passes, 100 us) against 5 (one round of 5).
   const int nblocks = (n_frames + fpb - 1) / fpb;
   int gy = 1;
-  if (workspace != nullptr && !ODIN_DIAG_ENV("ODIN_MEL_NOSPLIT"))
-    while (gy < 8 && gy * 2 <= nblocks && (long)B * gy < 8L * odin_num_cus()) gy *= 2;
+  if (workspace != nullptr && !ODIN_DIAG_ENV("ODIN_MEL_NOSPLIT")) {
+    long per_cu = (long)(160 * 1024) / (long)(lds + 64);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const long slots = per_cu * odin_num_cus();
+    long best = -1;
+    for (int g = 1; g <= 8 && g <= nblocks; ++g) {
+      const long cost = (((long)B * g + slots - 1) / slots) * ((nblocks + g - 1) / g);
+      if (best < 0 || cost < best) { best = cost; gy = g; }
+    }
+    if (const char* e = ODIN_DIAG_ENV("ODIN_MEL_GY")) { const int v = atoi(e); if (v >= 1 && v <= 8) gy = v; }
+  }
   ODIN_LAUNCH(stft_mel_f64_kernel, dim3(B, gy), dim3(256), lds, stream, y, window, twiddles, fb_vals,
               (const int*)fb_band, out, n_samples, frame_length, step_length, n_fft, log4, radix2,
               fpb, n_frames, n_mels, preemph, top_db, log_output, n_out_frames, workspace, fb_cap, g_mel_stamps);
