@@ -845,6 +845,259 @@ __global__ __launch_bounds__(512) void wgrad_blk_kernel(WBParams p) {
   }
 }
 
+
+// =====================================================================================================================
+// bwd_blk: the WHOLE backward pass of a Conv2DTranspose(k4, s2) with 32 output channels in one launch (the block-window
+// form of bwd_planes.hip): the fine window of dy is fetched, scaled and split ONCE for
+//   dW[kh, kw, co, ci] = sum over pixels of dy[2 i - 1 + kh, 2 j - 1 + kw, co] * x[i, j, ci]        (wgrad_blk's waves)
+//   dx[i, j, ci] = act'(aux) * sum over (kh, kw, co) of dy[2 i - 1 + kh, 2 j - 1 + kw, co] * W[kh, kw, co, ci]
+// dy is the layer's largest tensor (251 MB for the audio VAE's last deconvolution at batch 256) and the two launches
+// read it 1.27 x each.  Registers do not hold fconv_blk's 16 taps of weights beside the 64 accumulators of the weight
+// gradient, so the data gradient splits its REDUCTION over the waves instead: wave (nb, q) owns the four taps kh = q of
+// n-block nb for all four pixel blocks (32 registers of weights), leaves its partial blocks in LDS (32 KB) and, behind a
+// barrier, finishes pixel block q.
+// =====================================================================================================================
+struct BBParams {
+  const float* U;      // dy [B, 2h, 2w, 32]
+  const float* V;      // x  [B, h, w, CVt]
+  const float* wt;     // [16 taps][32][CVt]
+  const float* aux;    // [B, h, w, CVt]: dx *= act'(aux)
+  float* dx;           // [B, h, w, CVt]
+  float* colsum;       // [gridDim.x][CVt] (may be null)
+  float* slab;         // [gridDim.x][16 * 32 * CVt]
+  int B, h, w, CVt, act;
+  int slab_stride;
+  int nty, ntx, n_tiles, tiles_per_wg;
+  const unsigned* g_amax;   // range word of dy
+  const unsigned* a_amax;   // optional range word of x
+  unsigned* out_amax;       // range word of dx (may be null)
+};
+
+constexpr int BB_RED = 8 * 4 * 64 * 16;   // partial pixel blocks: [wave][pixel block][lane] x 16 bytes
+
+template <int ACT>
+__global__ __launch_bounds__(512) void bwd_blk_kernel(BBParams p) {
+  ODIN_DYN_SMEM(char, smem);
+  __shared__ float cred[8 * 16 + 16];
+  char* red = smem + 2 * WB_BUF;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = bk_uniform(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5, l16 = lane & 15, g = (lane >> 4) & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int cv0 = blockIdx.y * 32;
+  const int FH = 2 * p.h, FWid = 2 * p.w;
+  const int T0 = blockIdx.x * p.tiles_per_wg;
+  int T1 = T0 + p.tiles_per_wg;
+  if (T1 > p.n_tiles) T1 = p.n_tiles;
+
+  const OdinRangeReq u_rq = odin_range_issue(p.g_amax, lane), v_rq = odin_range_issue(p.a_amax, lane);
+  const OdinRun RU = odin_run(p.U, (unsigned)((size_t)p.B * FH * FWid * 32 * 4));
+  const unsigned v_bytes = (unsigned)((size_t)p.B * p.h * p.w * p.CVt * 4);
+  const OdinRun RV = odin_run(p.V, v_bytes);
+  FwItems I;
+  fw_items(I, tid, FWid, 32, 0);
+  const int v_px = tid >> 3, v_ch4 = tid & 7;
+  const int v_r = v_px >> 3, v_c = v_px & 7;
+  const int v_dst = v_px * 64 + v_ch4 * 8;
+  const int v_g = ((v_r * p.w + v_c) * p.CVt + cv0 + 4 * v_ch4) * 4;
+  float4 itv[FW_NIT], vv;
+  auto issue = [&](int b, int ty, int tx) {
+    fw_issue(itv, I, RU, b, ty, tx, FH, FWid, 32);
+    const bool ok = 8 * ty + v_r < p.h && 8 * tx + v_c < p.w;
+    vv = odin_run_load4(RV, ok ? (unsigned)(((b * p.h + 8 * ty) * p.w + 8 * tx) * p.CVt * 4 + v_g) : ODIN_OOB);
+  };
+  int b_c, ty_c, tx_c;
+  bk_decode(T0, p.nty, p.ntx, b_c, ty_c, tx_c);
+  if (T0 < T1) issue(b_c, ty_c, tx_c);
+  // ---- data gradient: this wave's weights, taps (kh = tq, kw = 0 .. 3) of n-block nb; lane = (channel l15, k-piece lq) ----
+  const int nb = wave >> 2, tq = wave & 3;
+  const int n0 = cv0 + 16 * nb;
+  u32x4 dwh[4], dwl[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int tap = 4 * tq + t;
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = p.wt[((size_t)(tap * 32 + 8 * lq + j)) * p.CVt + n0 + l15];
+    bk_split8(make_float4(e[0], e[1], e[2], e[3]), make_float4(e[4], e[5], e[6], e[7]), 1.f, ODIN_LO_SCALE, dwh[t],
+              dwl[t]);
+  }
+  const unsigned umb = odin_range_finish(u_rq), vmb = odin_range_finish(v_rq);
+  const int gu = bk_shift(umb, 1), gv = bk_shift(vmb, 0);
+  const float u_s = odin_pow2(gu), u_s2k = odin_pow2(gu + 11), v_s = odin_pow2(gv), v_s2k = odin_pow2(gv + 11);
+  const float out_s = odin_pow2(-gu), out_sx = odin_pow2(-gu - 11);
+  auto stage = [&](char* buf) {
+    fw_stage(buf, itv, I, tid, u_s, u_s2k);
+    u32x2 h, l;
+    odin_split_h4<true>(vv, v_s, v_s2k, h, l);
+    *reinterpret_cast<u32x2*>(buf + FW_BYTES + v_dst) = h;
+    *reinterpret_cast<u32x2*>(buf + FW_BYTES + WB_VPLB + v_dst) = l;
+  };
+  if (T0 < T1) stage(smem);
+  __syncthreads();
+
+  // ---- weight gradient: this wave's two taps (kh, kw0), (kh, kw0 + 1) (wgrad_blk_kernel) ----
+  const int kh = wave >> 1, kw0 = 2 * (wave & 1), c1 = kw0 >> 1;
+  const int tq4 = l16 >> 2, tp = l16 & 3;
+  int uoff[2], voff[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int row = 2 * half + kh, slot = c1 + 4 * m + tq4;
+    uoff[m] = row * FW_ROWB + slot * 64 + (((2 * g + (tp >> 1)) ^ fw_swz(row, slot)) << 4) + (tp & 1) * 8;
+    voff[m] = (half * 8 + 4 * m + tq4) * 64 + (16 * g + 4 * tp) * 2;
+  }
+#ifdef ODIN_SIM
+  int vsim[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) vsim[m] = (half * 8 + 4 * m) * 64 + 32 * g;
+#endif
+  f32x16 acc[2] = {f32x16_zero(), f32x16_zero()}, acx[2] = {f32x16_zero(), f32x16_zero()};
+  // ---- data gradient: operand offsets of pixel block 0 by kw >> 1 (kh = tq fixed); the block this wave finishes ----
+  const int ri0 = l15 >> 3, cj = l15 & 7;
+  int boff[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int row = 2 * ri0 + tq, slot = cj + c;
+    boff[c] = row * FW_ROWB + slot * 64 + ((lq ^ fw_swz(row, slot)) << 4);
+  }
+  const int fri = 2 * tq + ri0;   // tile row of this lane's pixel of block tq
+  const OdinRun OUT = odin_run(p.dx, v_bytes);
+  const OdinRun AUX = odin_run(p.aux, v_bytes);
+  const unsigned out_lane = (unsigned)(((fri * p.w + cj) * p.CVt + n0 + 4 * lq) * 4);
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  float amx = 0.f;
+
+#pragma unroll 1
+  for (int T = T0; T < T1; ++T) {
+    const char* buf = smem + ((T - T0) & 1) * WB_BUF;
+    char* nbuf = smem + (((T - T0) & 1) ^ 1) * WB_BUF;
+    int b_n = 0, ty_n = 0, tx_n = 0;
+    if (T + 1 < T1) {
+      bk_decode(T + 1, p.nty, p.ntx, b_n, ty_n, tx_n);
+      issue(b_n, ty_n, tx_n);
+    }
+    const unsigned tile_out = (unsigned)(((b_c * p.h + 8 * ty_c) * p.w + 8 * tx_c) * p.CVt * 4);
+    const bool ok = 8 * ty_c + fri < p.h && 8 * tx_c + cj < p.w;
+    const unsigned vo = ok ? out_lane : ODIN_OOB_V;
+    const float4 ax = odin_run_load4s(AUX, vo, tile_out);
+    // ---- weight gradient: 4 k-steps of 16 pixels ----
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4 vb[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const char* vbase = buf + FW_BYTES + pl * WB_VPLB + s * 16 * 64;
+#ifdef ODIN_SIM
+        const u32x2 lo = wb_tr(nullptr, vbase + vsim[0], 64, l16), hi = wb_tr(nullptr, vbase + vsim[1], 64, l16);
+#else
+        const u32x2 lo = wb_tr(vbase + voff[0], nullptr, 0, 0), hi = wb_tr(vbase + voff[1], nullptr, 0, 0);
+#endif
+        vb[pl][0] = lo[0]; vb[pl][1] = lo[1]; vb[pl][2] = hi[0]; vb[pl][3] = hi[1];
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        u32x4 ua[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#ifdef ODIN_SIM
+          unsigned short e[8];
+          for (int k = 0; k < 8; ++k) {
+            const int row = 4 * s + 2 * half + kh, slot = c1 + k, c = 16 * g + l16;
+            e[k] = *reinterpret_cast<const unsigned short*>(buf + pl * FW_PLB + row * FW_ROWB + t * 576 + slot * 64 +
+                                                            (((c >> 3) ^ fw_swz(row, slot)) << 4) + (c & 7) * 2);
+          }
+          ua[pl][0] = (unsigned)e[0] | ((unsigned)e[1] << 16); ua[pl][1] = (unsigned)e[2] | ((unsigned)e[3] << 16);
+          ua[pl][2] = (unsigned)e[4] | ((unsigned)e[5] << 16); ua[pl][3] = (unsigned)e[6] | ((unsigned)e[7] << 16);
+#else
+          const char* ubase = buf + pl * FW_PLB + s * 4 * FW_ROWB + t * 576;
+          const u32x2 lo = wb_tr(ubase + uoff[0], nullptr, 0, 0), hi = wb_tr(ubase + uoff[1], nullptr, 0, 0);
+          ua[pl][0] = lo[0]; ua[pl][1] = lo[1]; ua[pl][2] = hi[0]; ua[pl][3] = hi[1];
+#endif
+        }
+        acx[t] = mfma32_f16(ua[0], vb[1], acx[t]);
+        acc[t] = mfma32_f16(ua[0], vb[0], acc[t]);
+        acx[t] = mfma32_f16(ua[1], vb[0], acx[t]);
+      }
+    }
+    // ---- data gradient: this wave's four taps over the four pixel blocks, partial blocks to LDS ----
+    {
+      f32x4 dacc[4], dacx[4];
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) { dacc[pb] = bk_zero4(); dacx[pb] = bk_zero4(); }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+          const char* a = buf + boff[t >> 1] + pb * 4 * FW_ROWB + (t & 1) * 576;
+          const u32x4 xh = *reinterpret_cast<const u32x4*>(a);
+          const u32x4 xl = *reinterpret_cast<const u32x4*>(a + FW_PLB);
+          dacx[pb] = mfma16_f16(dwh[t], xl, dacx[pb]);
+          dacc[pb] = mfma16_f16(dwh[t], xh, dacc[pb]);
+          dacx[pb] = mfma16_f16(dwl[t], xh, dacx[pb]);
+        }
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(dacx[pb][r], out_sx, dacc[pb][r] * out_s);
+        *reinterpret_cast<f32x4*>(red + ((wave * 4 + pb) * 64 + lane) * 16) = v;
+      }
+    }
+    __syncthreads();
+    {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(red + (((4 * nb + j) * 4 + tq) * 64 + lane) * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += q[r];
+      }
+      const float a4[4] = {ax.x, ax.y, ax.z, ax.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = ok ? v[r] * bk_act_grad<ACT>(p.act, a4[r]) : 0.f;
+        csum[r] += v[r];
+      }
+      amx = odin_amax3(odin_amax3(amx, v[0], v[1]), v[2], v[3]);
+      odin_run_store4s(OUT, vo, tile_out, make_float4(v[0], v[1], v[2], v[3]));
+    }
+    if (T + 1 < T1) stage(nbuf);
+    b_c = b_n; ty_c = ty_n; tx_c = tx_n;
+    __syncthreads();
+  }
+
+  // ---- weight gradient: this workgroup's slab row ----
+  float* row = p.slab + (size_t)blockIdx.x * p.slab_stride;
+  const float ou = odin_pow2(-gu), ov = odin_pow2(-gv);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int tap = kh * 4 + kw0 + t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cu = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float v = fmaf(acx[t][r], ODIN_LO_UNSCALE, acc[t][r]);
+      row[((size_t)tap * 32 + cu) * p.CVt + cv0 + l31] = (v * ou) * ov;
+    }
+  }
+  odin_amax_commit_wg(p.out_amax, amx, tid, 512, cred + 128, blockIdx.x + gridDim.x * blockIdx.y);
+  if (p.colsum != nullptr) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = csum[r];
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) t += __shfl_xor(t, m);
+      if (l15 == 0) cred[wave * 16 + 4 * lq + r] = t;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int nbk = tid >> 4, ch = tid & 15;
+      float tt = 0.f;
+      for (int c = 0; c < 4; ++c) tt += cred[(4 * nbk + c) * 16 + ch];
+      p.colsum[(size_t)blockIdx.x * p.CVt + cv0 + tid] = tt;
+    }
+  }
+}
+
 }  // namespace
 
 // Conv2D(k4, s2, SAME) forward over 32 input channels / Conv2DTranspose(k4, s2) data gradient over 32 output channels
@@ -1266,4 +1519,53 @@ extern "C" int odin_gaussian_tail_fwd_bwd(const float* x, const float* w, const 
     else ODIN_LAUNCH((tconv_blk_gtail_kernel<0, -1>), dim3(gx), dim3(512), lds, stream, p);
   }
   return odin_check_launch("tconv_blk_gtail(f16x2)");
+}
+
+// the whole backward pass of a Conv2DTranspose(k4, s2) with 32 output channels (x [B, H, W, Cin] -> dy [B, 2H, 2W, 32])
+bool odin_bwd_blk_applicable(int B, int H, int W, int Cin, int Cout) {
+  if (!blk_enabled(2.0 * B * H * W * 16.0 * Cin * Cout)) return false;
+  if (!(Cout == 32 && (Cin % 32) == 0 && H >= 1 && W >= 1 && H <= 4096 && W <= 4096)) return false;
+  return (size_t)B * 4 * H * W * Cout * 4 < 0x7FFF0000ull && (size_t)B * H * W * Cin * 4 < 0x7FFF0000ull;
+}
+
+int odin_bwd_blk_rows(int B, int H, int W, int Cin) {
+  const int n_tiles = B * ((H + 7) / 8) * ((W + 7) / 8);
+  const int tpw = wb_tiles_per_wg(n_tiles, Cin / 32);
+  return (n_tiles + tpw - 1) / tpw;
+}
+
+int odin_bwd_blk_launch(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                        float* colsum, float* wslab, int B, int H, int W, int Cin, int Cout, const uint32_t* dy_amax,
+                        const uint32_t* x_amax, uint32_t* dx_amax, void* stream) {
+  BBParams p;
+  memset(&p, 0, sizeof(p));
+  p.U = dy; p.V = x; p.wt = w; p.aux = aux; p.dx = dx; p.colsum = colsum; p.slab = wslab;
+  p.B = B; p.h = H; p.w = W; p.CVt = Cin; p.act = aux_act;
+  p.slab_stride = 16 * Cout * Cin;
+  p.nty = (H + 7) / 8; p.ntx = (W + 7) / 8;
+  p.n_tiles = B * p.nty * p.ntx;
+  const int gy = Cin / 32;
+  p.tiles_per_wg = wb_tiles_per_wg(p.n_tiles, gy);
+  const int gx = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+  if (aux == nullptr || aux_act == ODIN_ACT_LINEAR) { p.aux = x; p.act = ODIN_ACT_LINEAR; }
+  p.g_amax = odin_range_word_of(dy, (size_t)B * 4 * H * W * Cout, dy_amax, stream);
+  if (p.g_amax == nullptr) return odin_fail(-3, "bwd_blk: no range word for dy");
+  p.a_amax = x_amax;
+  p.out_amax = dx_amax;
+  const size_t lds = (size_t)2 * WB_BUF + BB_RED;
+#ifndef ODIN_SIM
+  static bool attr_done = false;
+  if (!attr_done) {
+    const void* fns[2] = {reinterpret_cast<const void*>(&bwd_blk_kernel<ODIN_ACT_ELU>),
+                          reinterpret_cast<const void*>(&bwd_blk_kernel<-1>)};
+    for (int i = 0; i < 2; ++i)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        (void)hipGetLastError();
+    attr_done = true;
+  }
+#endif
+  dim3 grid(gx, gy, 1);
+  if (p.act == ODIN_ACT_ELU) ODIN_LAUNCH((bwd_blk_kernel<ODIN_ACT_ELU>), grid, dim3(512), lds, stream, p);
+  else ODIN_LAUNCH((bwd_blk_kernel<-1>), grid, dim3(512), lds, stream, p);
+  return odin_check_launch("bwd_blk(f16x2)");
 }

@@ -144,6 +144,11 @@ bool odin_wgrad_blk_applicable(int B, int H, int W, int CI, int OH, int OW, int 
 int odin_wgrad_blk_launch(const float* U, const float* V, float* slab, int* rows_out, int B, int OH, int OW, int CI,
                           int CO, int want_bias, int grad_u, const uint32_t* g_amax, const uint32_t* a_amax,
                           void* stream);
+bool odin_bwd_blk_applicable(int B, int H, int W, int Cin, int Cout);
+int odin_bwd_blk_rows(int B, int H, int W, int Cin);
+int odin_bwd_blk_launch(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,
+                        float* colsum, float* wslab, int B, int H, int W, int Cin, int Cout, const uint32_t* dy_amax,
+                        const uint32_t* x_amax, uint32_t* dx_amax, void* stream);
 void odin_tconv_planes_set_stamps(void* buf);
 bool odin_tconv_planes_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt,
                                   int pl, int center, int epi, int C1);

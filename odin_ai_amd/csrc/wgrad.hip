@@ -1430,6 +1430,17 @@ extern "C" int odin_deconv2d_bwd(const float* x, const float* dy, const float* w
     return odin_bwd_planes_launch(x, dy, w, aux, dx, colsum_slab, wslab, d->B, d->H, d->W, d->Cin, d->Cout, d->dy_amax,
                                   d->x_amax, d->dx_amax, stream);
   }
+  // any other image size: the block-window form of the same launch (blk_planes.hip), 32 output channels
+  if (((dx != nullptr && wslab != nullptr) || dry) && d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad_t == 1 &&
+      d->pad_l == 1 && d->OH == 2 * d->H && d->OW == 2 * d->W && !d->center &&
+      odin_bwd_blk_applicable(d->B, d->H, d->W, d->Cin, d->Cout)) {
+    const int rows = odin_bwd_blk_rows(d->B, d->H, d->W, d->Cin);
+    if (colsum_rows_out) *colsum_rows_out = rows;
+    if (wslab_rows_out) *wslab_rows_out = rows;
+    if (dry) return 0;
+    return odin_bwd_blk_launch(x, dy, w, aux, aux_act, dx, colsum_slab, wslab, d->B, d->H, d->W, d->Cin, d->Cout,
+                               d->dy_amax, d->x_amax, d->dx_amax, stream);
+  }
   odin_igemm_pair_begin();
   int rc = odin_deconv2d_wgrad(x, dy, wslab, wslab_rows_out, d, stream);
   if (rc == 0) rc = odin_deconv2d_dgrad(dy, w, aux, aux_act, dx, colsum_slab, colsum_rows_out, d, stream);

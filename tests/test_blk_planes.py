@@ -101,6 +101,22 @@ def test_deconv(blk, B, H, W, Ci, Co, act, xs, gs):
   L.odin_deconv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d), None)
   assert L.odin_debug_last_path().decode() == ('wgrad_planes(f16x2)' if W == 8 else 'wgrad_blk(f16x2)')   # (8-pixel rows: the row-window kernel)
   close(reduce_slab(bk, slab, rows.value, n).reshape(K, K, Co, Ci) / (gs * xs), dw_ref / (gs * xs), 1e-4)
+  # the whole backward pass in one call: ONE launch where the layer has 32 output channels (bwd_blk)
+  tdx3 = bk.full((B, H, W, Ci), float('nan'))
+  slab3, cs3 = bk.full((L.odin_max_slab_rows(), n), float('nan')), bk.full((L.odin_max_slab_rows(), Ci), float('nan'))
+  r_w, r_c = C.c_int(0), C.c_int(0)
+  dxw.zero_()
+  L.odin_deconv2d_bwd(tx.data_ptr(), tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, tdx3.data_ptr(), cs3.data_ptr(),
+                      C.byref(r_c), slab3.data_ptr(), C.byref(r_w), C.byref(d), None)
+  if Co == 32:
+    assert L.odin_debug_last_path().decode() == 'bwd_blk(f16x2)'
+    d_w, d_c = C.c_int(0), C.c_int(0)   # the dry run reports the same rows
+    L.odin_deconv2d_bwd(None, None, None, None, 1, None, None, C.byref(d_c), None, C.byref(d_w), C.byref(d), None)
+    assert (d_w.value, d_c.value) == (r_w.value, r_c.value)
+  close(tdx3.cpu().numpy() / gs, g_ref / gs)
+  close(reduce_slab(bk, cs3, r_c.value, Ci) / gs, g_ref.sum((0, 1, 2)) / gs, 1e-4)
+  close(reduce_slab(bk, slab3, r_w.value, n).reshape(K, K, Co, Ci) / (gs * xs), dw_ref / (gs * xs), 1e-4)
+  assert word_max(dxw) >= float(np.abs(g_ref).max()) * (1 - 1e-5)
 
 
 CONV = [
