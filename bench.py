@@ -173,7 +173,7 @@ def profile_ops(eng, reps=20):
                                              bsl.data_ptr() if bsl is not None else None, C.byref(rows),
                                              prog.wslabs[i].data_ptr(), C.byref(wrows), C.byref(d), st)
         f_bw()
-        if lib.odin_debug_last_path().decode().startswith('bwd_planes'):
+        if lib.odin_debug_last_path().decode().startswith(('bwd_planes', 'bwd_blk')):
           ops = [('fwd', f_fwd), ('bwd', f_bw)]
       if in_tail:
         # inside the training step these launches are replaced by the fused tail kernel
@@ -612,6 +612,9 @@ def main():
   ap.add_argument('--engine-opt', action='append', default=[], metavar='KEY=VALUE',
                   help='a VAEEngine keyword argument of the main engine (A/B runs: hyper_ring=False, act_words=False, '
                   'fuse_norm=False, overlap_wgrad=small, early_reduce=True, defer_wgrad=True, neck=False ...)')
+  ap.add_argument('--no-blk', action='store_true',
+                  help='A/B: the 4x4 / stride-2 layers that fit no row-window plane kernel on igemm_h.hip (round 5) instead '
+                  'of the block-window kernels of blk_planes.hip (odin_debug_blk_planes(0); the audio VAE)')
   ap.add_argument('--force-dist', action='store_true',
                   help='initialise the RCCL process group even at world size 1, so that the '
                   'data-parallel step (graph A, RCCL all-reduce, graph B) runs on a 1-GPU box')
@@ -619,6 +622,9 @@ def main():
 
   import ast
   eopts = {}
+  if args.no_blk:
+    from odin_ai_amd import _lib as _l
+    _l.load().odin_debug_blk_planes(0)
   for kv in args.engine_opt:
     k, _, v = kv.partition('=')
     try:
