@@ -728,7 +728,7 @@ def main():
       x = xb
 
     def step():
-      loss, _ = fv.optimize(x, learning_rate=lr, global_clipnorm=100.0, use_graph=use_graph)
+      loss, _ = fv.optimize(x, learning_rate=lr, global_clipnorm=100.0, use_graph=use_graph, snapshot=False)
       return eng.out4
   else:
     x = synthetic_batch(args.workload, B, in_shape, device, seed=100 + rank)

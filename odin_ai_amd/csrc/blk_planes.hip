@@ -23,91 +23,10 @@
 //              dW[kh, kw, cu, cv] = sum over (b, i, j) of U[b, 2 i - 1 + kh, 2 j - 1 + kw, cu] * V[b, i, j, cv]
 #include "odin_device.h"
 #include "odin_internal.h"
+#include "blk_common.h"
 #include <cstdlib>
 
 namespace {
-
-// D(16 x 16) += A(16 x 32) * B(32 x 16) on f16 operands.  Lane l supplies A[row l & 15][k = 8 (l >> 4) + j] and
-// B[k = 8 (l >> 4) + j][col l & 15] in element j; D: col = l & 15, row = 4 (l >> 4) + r for accumulator register r.
-__device__ __forceinline__ f32x4 mfma16_f16(u32x4 a, u32x4 b, f32x4 c) {
-  typedef _Float16 bk_h8 __attribute__((ext_vector_type(8)));
-#ifdef ODIN_SIM
-  const bk_h8 ah = __builtin_bit_cast(bk_h8, a), bh = __builtin_bit_cast(bk_h8, b);
-  for (int j = 0; j < 8; ++j) c = sim::mfma_16x16x4((float)ah[j], (float)bh[j], c);
-  return c;
-#else
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(bk_h8, a), __builtin_bit_cast(bk_h8, b), c, 0, 0, 0);
-#endif
-}
-
-__device__ __forceinline__ f32x4 bk_zero4() {
-  f32x4 z;
-  z[0] = 0.f; z[1] = 0.f; z[2] = 0.f; z[3] = 0.f;
-  return z;
-}
-
-__device__ __forceinline__ int bk_uniform(int v) {
-#ifdef ODIN_SIM
-  return v;
-#else
-  return __builtin_amdgcn_readfirstlane(v);
-#endif
-}
-
-// eight consecutive fp32 values (two float4) -> one MFMA operand per plane
-__device__ __forceinline__ void bk_split8(const float4& a, const float4& b, float s, float s2k, u32x4& h, u32x4& l) {
-  u32x2 h0, l0, h1, l1;
-  odin_split_h4<true>(a, s, s2k, h0, l0);
-  odin_split_h4<true>(b, s, s2k, h1, l1);
-  h[0] = h0[0]; h[1] = h0[1]; h[2] = h1[0]; h[3] = h1[1];
-  l[0] = l0[0]; l[1] = l0[1]; l[2] = l1[0]; l[3] = l1[1];
-}
-
-// activation and its derivative (from the OUTPUT) with the function a compile-time constant -- ACT = ODIN_ACT_* -- or, ACT < 0,
-// the run-time switch of odin_act (two scalar branches per ELEMENT inside the epilogues: measured on the first build,
-// 140 branches per tile)
-template <int ACT>
-__device__ __forceinline__ float bk_act(int rt, float v) {
-  if (ACT == ODIN_ACT_ELU) {
-    const float em1 = odin_exp2(v * 1.44269504088896341f) - 1.f;
-    return v > 0.f ? v : em1;
-  }
-  if (ACT == ODIN_ACT_RELU) return fmaxf(v, 0.f);
-  if (ACT == ODIN_ACT_LINEAR) return v;
-  return odin_act(rt, v);
-}
-template <int ACT>
-__device__ __forceinline__ float bk_act_grad(int rt, float y) {
-  if (ACT == ODIN_ACT_ELU) return 1.f + fminf(y, 0.f);
-  if (ACT == ODIN_ACT_RELU) return y > 0.f ? 1.f : 0.f;
-  if (ACT == ODIN_ACT_LINEAR) return 1.f;
-  return odin_act_grad(rt, y);
-}
-// x + the value of lane ^ 16 / lane ^ 32 without an LDS round trip (gfx950 row swaps)
-__device__ __forceinline__ float bk_add_xor16(float x) {
-#ifdef ODIN_SIM
-  return x + __shfl_xor(x, 16);
-#else
-  const unsigned u = __float_as_uint(x);
-  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-#endif
-}
-__device__ __forceinline__ float bk_add_xor32(float x) {
-#ifdef ODIN_SIM
-  return x + __shfl_xor(x, 32);
-#else
-  const unsigned u = __float_as_uint(x);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-#endif
-}
-
-// the scale of a plane operand from its range word: gradients always (odin_range_shift), activations only when their
-// bound leaves the f16 window (odin_act_needs_scale); gk = 0: carried as it is
-__device__ __forceinline__ int bk_shift(unsigned mb, int is_grad) {
-  return (is_grad || odin_act_needs_scale(mb)) ? odin_range_shift(mb) : 0;
-}
 
 // =====================================================================================================================
 // tconv_blk
@@ -131,7 +50,6 @@ struct TBParams {
 // lanes of a ds_read_b128 group (two window rows x 8 columns, one k-piece) hit 16 distinct slots of the bank row
 constexpr int TB_PLB = 10 * 16 * 64;     // one plane
 constexpr int TB_KPB = 2 * TB_PLB;       // one 32-channel pass
-__host__ __device__ constexpr int tb_swz(int row, int col) { return ((col >> 2) + 2 * (row & 1)) & 3; }
 
 template <int EPI, int NK, int ACT>
 __global__ __launch_bounds__(512) void tconv_blk_kernel(TBParams p) {
@@ -373,13 +291,13 @@ extern "C" double odin_debug_blk_min_flop(double flop) {
   if (flop >= 0.0) g_blk_min_flop = flop;
   return old;
 }
-static bool blk_enabled(double flop) {
+bool odin_blk_enabled(double flop) {
   return !(g_blk_off || odin_exact_fp32() || ODIN_DIAG_ENV("ODIN_NOBLK")) && flop >= g_blk_min_flop;
 }
 
 // Conv2DTranspose(k4, s2, SAME) forward from CI in {32, 64} channels / Conv2D(k4, s2) data gradient, any H x W
 bool odin_tconv_blk_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt, int pl, int center) {
-  if (!blk_enabled(2.0 * B * H * W * 16.0 * CI * CO)) return false;
+  if (!odin_blk_enabled(2.0 * B * H * W * 16.0 * CI * CO)) return false;
   if (!(KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && !center && (CI == 32 || CI == 64) && (CO % 32) == 0))
     return false;
   if (H < 1 || W < 1 || H > 4096 || W > 4096) return false;
@@ -474,13 +392,6 @@ __device__ __forceinline__ void fw_stage(char* buf, const float4 (&v)[FW_NIT], c
   }
 }
 
-__device__ __forceinline__ void bk_decode(int T, int nty, int ntx, int& b, int& ty, int& tx) {
-  const int per = nty * ntx;
-  b = odin_div_small(T, per);
-  const int r = T - b * per;
-  ty = odin_div_small(r, ntx);
-  tx = r - ty * ntx;
-}
 
 // =====================================================================================================================
 // fconv_blk
@@ -1103,7 +1014,7 @@ __global__ __launch_bounds__(512) void bwd_blk_kernel(BBParams p) {
 // Conv2D(k4, s2, SAME) forward over 32 input channels / Conv2DTranspose(k4, s2) data gradient over 32 output channels
 bool odin_fconv_blk_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S, int pt, int pl,
                                int center) {
-  if (!blk_enabled(2.0 * B * OH * OW * 16.0 * CI * CO)) return false;
+  if (!odin_blk_enabled(2.0 * B * OH * OW * 16.0 * CI * CO)) return false;
   if (!(KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && !center && CI == 32 && (CO % 32) == 0)) return false;
   if (H != 2 * OH || W != 2 * OW || OH < 1 || OW < 1 || H > 8192 || W > 8192) return false;
   return (size_t)B * H * W * CI * 4 < 0x7FFF0000ull && (size_t)B * OH * OW * CO * 4 < 0x7FFF0000ull;
@@ -1140,7 +1051,7 @@ int odin_fconv_blk_launch(const float* in, const float* w, const float* bias, co
 // weight gradient of a 4x4 / stride-2 layer: U fine [B, 2 OH, 2 OW, CI], V coarse [B, OH, OW, CO] (names of wgrad_planes.hip)
 bool odin_wgrad_blk_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S, int pt, int pl,
                                int center) {
-  if (!blk_enabled(2.0 * B * OH * OW * 16.0 * CI * CO)) return false;
+  if (!odin_blk_enabled(2.0 * B * OH * OW * 16.0 * CI * CO)) return false;
   if (!(KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && !center && (CI % 32) == 0 && (CO % 32) == 0)) return false;
   if (H != 2 * OH || W != 2 * OW || OH < 1 || OW < 1 || H > 8192 || W > 8192) return false;
   return (size_t)B * H * W * CI * 4 < 0x7FFF0000ull && (size_t)B * OH * OW * CO * 4 < 0x7FFF0000ull;
@@ -1523,7 +1434,7 @@ extern "C" int odin_gaussian_tail_fwd_bwd(const float* x, const float* w, const 
 
 // the whole backward pass of a Conv2DTranspose(k4, s2) with 32 output channels (x [B, H, W, Cin] -> dy [B, 2H, 2W, 32])
 bool odin_bwd_blk_applicable(int B, int H, int W, int Cin, int Cout) {
-  if (!blk_enabled(2.0 * B * H * W * 16.0 * Cin * Cout)) return false;
+  if (!odin_blk_enabled(2.0 * B * H * W * 16.0 * Cin * Cout)) return false;
   if (!(Cout == 32 && (Cin % 32) == 0 && H >= 1 && W >= 1 && H <= 4096 && W <= 4096)) return false;
   return (size_t)B * 4 * H * W * Cout * 4 < 0x7FFF0000ull && (size_t)B * H * W * Cin * 4 < 0x7FFF0000ull;
 }

@@ -1623,6 +1623,11 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
                                  d->pad_t, d->pad_l, d->center))
     return track_y(odin_fconv_ring_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->Cin,
                                           d->OH, d->OW, d->Cout, 1, stream), y, d, stream);
+  // 5x5 / stride-1 layers (the MNIST conv stack): block windows with the weights in LDS (blk5_planes.hip)
+  if (bias != nullptr && d->H == d->OH && d->W == d->OW &&
+      odin_conv5_blk_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->center))
+    return odin_conv5_blk_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->Cin, d->Cout, 1, d->act,
+                                 d->x_amax, d->y_amax, stream);
   if (bias != nullptr &&
       odin_fconv_blk_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
                                 d->pad_l, d->center))
@@ -1670,6 +1675,9 @@ extern "C" int odin_conv2d_dgrad_keeps_range(const odin_conv_desc* d, int aux_ac
     return 0;
   if (d->H == 2 * d->OH && d->W == 2 * d->OW &&
       odin_tconv_blk_applicable(d->B, d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0))
+    return 1;
+  if (d->H == d->OH && d->W == d->OW &&
+      odin_conv5_blk_applicable(d->B, d->H, d->W, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0))
     return 1;
   if (odin_igemm_h_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0)) return 1;
   return odin_igemm_applicable(1, d->B, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, 0) ? 1 : 0;
@@ -1721,6 +1729,10 @@ extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* a
     return track_dx(odin_tconv_ring_launch(dy, w, nullptr, aux, dx, colsum_slab, slab_rows_out, nullptr, nullptr,
                                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d->B, d->OH,
                                            d->OW, d->Cin, 2, stream), dx, d, stream);
+  if (d->H == d->OH && d->W == d->OW &&
+      odin_conv5_blk_applicable(d->B, d->H, d->W, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0))
+    return odin_conv5_blk_launch(dy, w, nullptr, aux_act != 0 ? aux : nullptr, dx, colsum_slab, slab_rows_out, d->B,
+                                 d->H, d->W, d->Cout, d->Cin, 2, aux_act, d->dy_amax, d->dx_amax, stream);
   // any other image size: 8 x 8 blocks of dy through LDS windows (blk_planes.hip)
   if (d->H == 2 * d->OH && d->W == 2 * d->OW &&
       odin_tconv_blk_applicable(d->B, d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0))

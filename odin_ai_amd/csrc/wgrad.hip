@@ -1039,6 +1039,10 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
                                    p.center))
     return odin_wgrad_planes_launch(p.in, p.dy, p.slab, rows_out, p.B, p.OH, p.OW, p.CI, p.CO,
                                     p.want_bias, p.want_bias ? 0 : 1, p.g_amax, p.a_amax, stream);
+  if (p.H == p.OH && p.W == p.OW && p.want_bias &&
+      odin_wgrad5_blk_applicable(p.B, p.H, p.W, p.CI, p.CO, p.KH, p.KW, p.S, p.pt, p.pl, p.center))
+    return odin_wgrad5_blk_launch(p.in, p.dy, p.slab, rows_out, p.B, p.H, p.W, p.CI, p.CO, p.want_bias, p.g_amax,
+                                  p.a_amax, stream);
   if (odin_wgrad_blk_applicable(p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO, p.KH, p.KW, p.S, p.pt, p.pl, p.center))
     return odin_wgrad_blk_launch(p.in, p.dy, p.slab, rows_out, p.B, p.OH, p.OW, p.CI, p.CO, p.want_bias,
                                  p.want_bias ? 0 : 1, p.g_amax, p.a_amax, stream);
@@ -1331,6 +1335,11 @@ extern "C" int odin_conv2d_reads_x_range(const odin_conv_desc* d) {
           odin_igemm_h_applicable(0, d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->center) ||
           odin_fconv_blk_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
                                     d->pad_l, d->center) ||
+          (d->H == d->OH && d->W == d->OW &&
+           (odin_conv5_blk_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l,
+                                      d->center) ||
+            odin_wgrad5_blk_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l,
+                                       d->center))) ||
           odin_wgrad_blk_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
                                     d->pad_l, d->center) ||
           odin_wgrad_planes_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride,

@@ -1292,7 +1292,7 @@ class FactorVAE(AnnealingVAE):
                clipnorm=None, clipvalue=None, global_clipnorm=None, skip_update_threshold=None,
                when_skip_update: int = 0, nan_gradients_policy: str = 'skip',
                allow_none_gradients=False, aggregate_gradients=False, track_gradients=False,
-               eps=None, eps2=None, perm=None, use_graph: bool = False, **kwargs):
+               eps=None, eps2=None, perm=None, use_graph: bool = False, snapshot: bool = True, **kwargs):
     """Networks.optimize over FactorVAE.train_steps (factor_vae.py:239-287): the gradient
     policies apply to the VAE step's gradients (the discriminator step has its own optimiser
     and, as in the reference's default call, no clipping is configured for it separately --
@@ -1333,7 +1333,9 @@ class FactorVAE(AnnealingVAE):
                       aggregate_gradients)
     if training and not self._is_pretraining:
       disc.disc.t += 1
-    out = eng.out8.clone()
+    # (snapshot=False: the returned scalars are views of the buffer the NEXT iteration overwrites -- what
+    # VAEEngine.train_step returns; saves the per-iteration device-to-device copy of a tight training loop)
+    out = eng.out8.clone() if snapshot else eng.out8
     metrics = {f'elbo/llk_{self.observation.name}': out[1],
                f'elbo/kl_{self.latents.name}': out[2], 'elbo/tc': out[3]}
     if not self._is_pretraining:

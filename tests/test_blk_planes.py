@@ -236,3 +236,62 @@ def test_gaussian_tail(blk, B, H, W, act, sp1):
   close(row[64:66], tt['b1'].grad.numpy(), 1e-4)
   close(row[66:], tt['b'].grad.numpy(), 1e-4)
   assert word_max(gw) >= float(np.abs(g_ref).max()) * (1 - 1e-5) and word_max(gw) <= float(np.abs(g_ref).max()) * 1.001
+
+
+CONV5 = [
+    # B, H, W, Cin, Cout, act, scale of x, scale of dy   (5 x 5 / stride 1, `SAME`: blk5_planes.hip)
+    (2, 14, 14, 32, 64, 'elu', 1.0, 1.0),       # MNIST encoder2: ragged 8 x 8 tiles, two output blocks
+    (1, 28, 28, 32, 32, 'relu', 1.0, 1.0),      # MNIST decoder4
+    (2, 14, 14, 64, 64, 'elu', 1.0, 1e-9),      # MNIST decoder2: 64 reduction channels = two passes; tiny gradients
+    (3, 9, 11, 64, 32, 'linear', 3e4, 1.0),     # odd sizes; activations beyond the f16 window
+]
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co,act,xs,gs', CONV5)
+def test_conv5(blk, B, H, W, Ci, Co, act, xs, gs):
+  bk = blk
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(B * 100 + H)
+  K, S = 5, 1
+  x = rng.standard_normal((B, H, W, Ci)) * xs
+  w = rng.standard_normal((K, K, Ci, Co)) * 0.1 / xs
+  b = rng.standard_normal(Co) * 0.1
+  OH, pt, _ = vo.same_pads(H, K, S)
+  OW, pl, _ = vo.same_pads(W, K, S)
+  d = _lib.conv_desc(B, H, W, Ci, OH, OW, Co, K, S, pt, pl, act)
+  y_ref = vo._ACT[act](vo.conv2d(x, w, b, S))
+  tx, tw, tb = T(x), T(w), T(b)
+  xw, yw = word_of(bk, tx), bk.zeros(2048, dtype=torch.int32)
+  d.x_amax, d.y_amax = xw.data_ptr(), yw.data_ptr()
+  ty = bk.full((B, OH, OW, Co), float('nan'))
+  L.odin_conv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
+  assert L.odin_debug_last_path().decode() == 'conv5_blk(f16x2)'
+  close(ty.cpu().numpy(), y_ref)
+  assert word_max(yw) >= float(np.abs(y_ref).max()) * (1 - 1e-5) and word_max(yw) <= float(np.abs(y_ref).max()) * 1.001
+  dy = rng.standard_normal((B, OH, OW, Co)) * gs
+  tdy = T(dy)
+  dyw, dxw = word_of(bk, tdy), bk.zeros(2048, dtype=torch.int32)
+  d.dy_amax, d.dx_amax = dyw.data_ptr(), dxw.data_ptr()
+  dx_ref, dw_ref, db_ref = vo.conv2d_bwd(x, w, dy, S)
+  aux = rng.standard_normal((B, H, W, Ci))
+  taux = T(aux)
+  g_ref = dx_ref * vo.elu_grad_from_output(aux.astype(np.float32).astype(np.float64))
+  tdx = bk.full((B, H, W, Ci), float('nan'))
+  rows = C.c_int(0)
+  slab = bk.full((L.odin_max_slab_rows(), Ci), float('nan'))
+  L.odin_conv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, tdx.data_ptr(), slab.data_ptr(),
+                      C.byref(rows), C.byref(d), None)
+  assert L.odin_debug_last_path().decode() == 'conv5_blk(f16x2)'
+  close(tdx.cpu().numpy() / gs, g_ref / gs)
+  close(reduce_slab(bk, slab, rows.value, Ci) / gs, g_ref.sum((0, 1, 2)) / gs, 1e-4)
+  assert word_max(dxw) >= float(np.abs(g_ref).max()) * (1 - 1e-5) and word_max(dxw) <= float(np.abs(g_ref).max()) * 1.001
+  tdx2 = bk.full((B, H, W, Ci), float('nan'))
+  L.odin_conv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), None, 0, tdx2.data_ptr(), None, None, C.byref(d), None)
+  close(tdx2.cpu().numpy() / gs, dx_ref / gs)
+  n = K * K * Ci * Co + Co
+  slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
+  L.odin_conv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d), None)
+  print('conv5 wgrad', L.odin_debug_last_path().decode())
+  g = reduce_slab(bk, slab, rows.value, n)
+  close(g[:-Co].reshape(K, K, Ci, Co) / (gs * xs), dw_ref / (gs * xs), 1e-4)
+  close(g[-Co:] / gs, db_ref / gs, 1e-4)
