@@ -238,7 +238,7 @@ def test_save_best_llk_callback(L, DEV, tmp_path):
   Callback._best[id(vae)] = llk0
   # inside fit: training improves the validation likelihood and the callback checkpoints it
   seen = []
-  vae.fit(x, valid=xv, valid_freq=6, max_iter=18, batch_size=16, learning_rate=3e-3, compile_graph=False,
+  vae.fit(x, valid=xv, valid_freq=4, max_iter=9, batch_size=16, learning_rate=5e-3, compile_graph=False,
           on_valid_end=lambda: seen.append(Callback.save_best_llk(vae, xv, batch_size=8, log=None)))
   assert len(seen) >= 3 and max(seen) > llk0 and Callback._best[id(vae)] == max(seen)
   # the checkpoint on disk is the best model: reloading it reproduces the weights of that moment
