@@ -291,13 +291,17 @@ extern "C" double odin_debug_blk_min_flop(double flop) {
   if (flop >= 0.0) g_blk_min_flop = flop;
   return old;
 }
+// rows whose width is not a power of two have no tuned small-layer path (the implicit GEMMs of igemm.hip were laid out
+// on 4 / 8-pixel rows): those layers come here from a third of the size -- the audio encoder3 (12 x 10 x 64 -> 6 x 5 x 64,
+// 1.0 GFLOP): weight + data gradient 61 -> 27 us
+static double blk_scale_for_width(int W) { return (W & (W - 1)) == 0 ? 1.0 : 3.0; }
 bool odin_blk_enabled(double flop) {
   return !(g_blk_off || odin_exact_fp32() || ODIN_DIAG_ENV("ODIN_NOBLK")) && flop >= g_blk_min_flop;
 }
 
 // Conv2DTranspose(k4, s2, SAME) forward from CI in {32, 64} channels / Conv2D(k4, s2) data gradient, any H x W
 bool odin_tconv_blk_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt, int pl, int center) {
-  if (!odin_blk_enabled(2.0 * B * H * W * 16.0 * CI * CO)) return false;
+  if (!odin_blk_enabled(2.0 * B * H * W * 16.0 * CI * CO * blk_scale_for_width(W))) return false;
   if (!(KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && !center && (CI == 32 || CI == 64) && (CO % 32) == 0))
     return false;
   if (H < 1 || W < 1 || H > 4096 || W > 4096) return false;
@@ -1014,7 +1018,7 @@ __global__ __launch_bounds__(512) void bwd_blk_kernel(BBParams p) {
 // Conv2D(k4, s2, SAME) forward over 32 input channels / Conv2DTranspose(k4, s2) data gradient over 32 output channels
 bool odin_fconv_blk_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S, int pt, int pl,
                                int center) {
-  if (!odin_blk_enabled(2.0 * B * OH * OW * 16.0 * CI * CO)) return false;
+  if (!odin_blk_enabled(2.0 * B * OH * OW * 16.0 * CI * CO * blk_scale_for_width(OW))) return false;
   if (!(KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && !center && CI == 32 && (CO % 32) == 0)) return false;
   if (H != 2 * OH || W != 2 * OW || OH < 1 || OW < 1 || H > 8192 || W > 8192) return false;
   return (size_t)B * H * W * CI * 4 < 0x7FFF0000ull && (size_t)B * OH * OW * CO * 4 < 0x7FFF0000ull;
@@ -1051,7 +1055,7 @@ int odin_fconv_blk_launch(const float* in, const float* w, const float* bias, co
 // weight gradient of a 4x4 / stride-2 layer: U fine [B, 2 OH, 2 OW, CI], V coarse [B, OH, OW, CO] (names of wgrad_planes.hip)
 bool odin_wgrad_blk_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S, int pt, int pl,
                                int center) {
-  if (!odin_blk_enabled(2.0 * B * OH * OW * 16.0 * CI * CO)) return false;
+  if (!odin_blk_enabled(2.0 * B * OH * OW * 16.0 * CI * CO * blk_scale_for_width(OW))) return false;
   if (!(KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && !center && (CI % 32) == 0 && (CO % 32) == 0)) return false;
   if (H != 2 * OH || W != 2 * OW || OH < 1 || OW < 1 || H > 8192 || W > 8192) return false;
   return (size_t)B * H * W * CI * 4 < 0x7FFF0000ull && (size_t)B * OH * OW * CO * 4 < 0x7FFF0000ull;
@@ -1434,7 +1438,7 @@ extern "C" int odin_gaussian_tail_fwd_bwd(const float* x, const float* w, const 
 
 // the whole backward pass of a Conv2DTranspose(k4, s2) with 32 output channels (x [B, H, W, Cin] -> dy [B, 2H, 2W, 32])
 bool odin_bwd_blk_applicable(int B, int H, int W, int Cin, int Cout) {
-  if (!odin_blk_enabled(2.0 * B * H * W * 16.0 * Cin * Cout)) return false;
+  if (!odin_blk_enabled(2.0 * B * H * W * 16.0 * Cin * Cout * blk_scale_for_width(W))) return false;
   if (!(Cout == 32 && (Cin % 32) == 0 && H >= 1 && W >= 1 && H <= 4096 && W <= 4096)) return false;
   return (size_t)B * 4 * H * W * Cout * 4 < 0x7FFF0000ull && (size_t)B * H * W * Cin * 4 < 0x7FFF0000ull;
 }

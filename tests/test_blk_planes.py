@@ -50,7 +50,7 @@ DECONV = [
     # B, H, W, Cin, Cout, act, scale of x, scale of dy
     (2, 12, 10, 32, 32, 'elu', 1.0, 1.0),       # audio decoder geometry: ragged tiles in both directions
     (1, 6, 5, 64, 64, 'elu', 1.0, 1.0),         # 64 reduction channels, two output blocks, one (ragged) tile per image
-    (3, 9, 20, 64, 32, 'relu', 1.0, 1e-9),      # odd height, 2.5 tiles per row; tiny gradients
+    (2, 9, 20, 64, 32, 'relu', 1.0, 1e-9),      # odd height, 2.5 tiles per row; tiny gradients
     (2, 24, 8, 32, 64, 'linear', 3e4, 1.0),     # activations beyond the f16 window
     (5, 3, 3, 32, 32, 'elu', 1.0, 1.0),         # an image smaller than a tile
 ]
@@ -242,8 +242,8 @@ CONV5 = [
     # B, H, W, Cin, Cout, act, scale of x, scale of dy   (5 x 5 / stride 1, `SAME`: blk5_planes.hip)
     (2, 14, 14, 32, 64, 'elu', 1.0, 1.0),       # MNIST encoder2: ragged 8 x 8 tiles, two output blocks
     (1, 28, 28, 32, 32, 'relu', 1.0, 1.0),      # MNIST decoder4
-    (2, 14, 14, 64, 64, 'elu', 1.0, 1e-9),      # MNIST decoder2: 64 reduction channels = two passes; tiny gradients
-    (3, 9, 11, 64, 32, 'linear', 3e4, 1.0),     # odd sizes; activations beyond the f16 window
+    (1, 14, 14, 64, 64, 'elu', 1.0, 1e-9),      # MNIST decoder2: 64 reduction channels = two passes; tiny gradients
+    (2, 9, 11, 64, 32, 'linear', 3e4, 1.0),     # odd sizes; activations beyond the f16 window
 ]
 
 

@@ -201,26 +201,26 @@ def test_hyper_ring_matches_per_step_copies(L):
   as the per-step host copy -- with constant hyper-parameters (no copy after the first step), across several ring
   refills, with a learning rate that changes in the middle (one more copy), with values that change every step (a copy
   per step, as before) and with a schedule known in advance (no copy after the first step)."""
-  R = dict(rows=8)   # (refilled 2-4 rows at a time: 13 steps wrap it)
-  n = 13
+  R = dict(rows=8)   # (refilled 2-4 rows at a time: 11 steps wrap it)
+  n = 11
   p0, o0, c0, _ = _run_steps(L, False, [1e-3], [4.0], n=n, **R)
   p1, o1, c1, eng = _run_steps(L, True, [1e-3], [4.0], n=n, **R)
   assert torch.equal(p0, p1) and torch.equal(o0, o1)
   assert c0 == n and c1 == 1
   assert int(eng.hyper[16:17].view(torch.int32)) == n + 1   # the last Adam loaded the row of the next step
-  lrs = [1e-3] * 3 + [5e-4] * 5
+  lrs = [1e-3] * 2 + [5e-4] * 4
   p0, o0, c0, _ = _run_steps(L, False, lrs, [2.0], **R)
   p1, o1, c1, _ = _run_steps(L, True, lrs, [2.0], **R)
   assert torch.equal(p0, p1) and torch.equal(o0, o1) and c1 == 3   # first step, the change, the step that confirms it
-  betas = [1.0 + 0.01 * i for i in range(5)]
-  p0, o0, c0, _ = _run_steps(L, False, [1e-3], betas, n=5, **R)
-  p1, o1, c1, _ = _run_steps(L, True, [1e-3], betas, n=5, **R)
-  assert torch.equal(p0, p1) and torch.equal(o0, o1) and c1 == 5
+  betas = [1.0 + 0.01 * i for i in range(4)]
+  p0, o0, c0, _ = _run_steps(L, False, [1e-3], betas, n=4, **R)
+  p1, o1, c1, _ = _run_steps(L, True, [1e-3], betas, n=4, **R)
+  assert torch.equal(p0, p1) and torch.equal(o0, o1) and c1 == 4
   sched = lambda u: dict(beta=1.0 + 0.01 * (u - 1))
-  p2, o2, c2, _ = _run_steps(L, True, [1e-3], betas, schedule=sched, n=5, **R)
+  p2, o2, c2, _ = _run_steps(L, True, [1e-3], betas, schedule=sched, n=4, **R)
   assert torch.equal(p0, p2) and torch.equal(o0, o2) and c2 == 1
   # a schedule rules the step it is asked about too: explicit arguments that contradict it do not cause a copy per step
-  p3, o3, c3, _ = _run_steps(L, True, [1e-3], [9.0], schedule=sched, n=5, **R)
+  p3, o3, c3, _ = _run_steps(L, True, [1e-3], [9.0], schedule=sched, n=4, **R)
   assert torch.equal(p0, p3) and torch.equal(o0, o3) and c3 == 1
 
 
@@ -231,12 +231,12 @@ def test_hyper_ring_survives_a_jump_of_the_step_counter(L):
   ran the step with a stale row (Adam bias correction, RNG counter and when_skip_update gating of an earlier step).
   A hit now needs the previous ring-advanced step to be t - 1."""
   jump = (3, 7)   # steps 1..3, then the counter says 7: the next step is 8
-  p0, o0, c0, e0 = _run_steps(L, False, [1e-3], [4.0], n=9, jump=jump)
-  p1, o1, c1, e1 = _run_steps(L, True, [1e-3], [4.0], n=9, jump=jump, rows=8)
-  assert e0.step_count == e1.step_count == 13
+  p0, o0, c0, e0 = _run_steps(L, False, [1e-3], [4.0], n=6, jump=jump)
+  p1, o1, c1, e1 = _run_steps(L, True, [1e-3], [4.0], n=6, jump=jump, rows=8)
+  assert e0.step_count == e1.step_count == 10
   assert torch.equal(p0, p1) and torch.equal(o0, o1)
   assert c1 == 2   # the first step and the step after the jump
-  assert int(e1.hyper[16:17].view(torch.int32)) == 14
+  assert int(e1.hyper[16:17].view(torch.int32)) == 11
 
 
 def test_fused_norm_matches_separate_launch(L):

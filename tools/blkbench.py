@@ -29,9 +29,11 @@ def word(tn):
 
 
 LAYERS = [  # kind, H, W (layer input), Cin, Cout
-    ('conv', 48, 40, 32, 32), ('conv', 24, 20, 32, 64),
+    ('conv', 48, 40, 32, 32), ('conv', 24, 20, 32, 64), ('conv', 12, 10, 64, 64),
     ('deconv', 12, 10, 64, 64), ('deconv', 24, 20, 64, 32), ('deconv', 48, 40, 32, 32)]
 st = torch.cuda.current_stream().cuda_stream
+if os.environ.get('BLK_MIN_FLOP'):
+  L.odin_debug_blk_min_flop(float(os.environ['BLK_MIN_FLOP']))
 for kind, H, W, Ci, Co in LAYERS:
   if kind == 'conv':
     OH, OW = H // 2, W // 2
