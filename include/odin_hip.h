@@ -344,6 +344,8 @@ double odin_debug_igemm_h_min_flop(double flop);
  * a switch (0: off, 1: on, < 0: query) for A/B runs; both return the previous value */
 double odin_debug_blk_min_flop(double flop);
 int odin_debug_blk_planes(int enable);
+/* diagnostics: 1 = the block-window kernels also take the layers the row-window plane kernels serve (A/B runs) */
+int odin_debug_blk_first(int on);
 
 /* ---- fused Gaussian tail of the TRAINING step (blk_planes.hip): Conv2DTranspose(k4, s2, 32 -> 32, activation d->act) ->
  * Conv2D 1x1 linear with 2 maps (w1 [32, 2], b1 [2]: loc | raw scale) -> Independent(Normal(loc, raw | softplus1(raw)))

@@ -286,6 +286,15 @@ extern "C" int odin_debug_blk_planes(int enable) {
   if (enable >= 0) g_blk_off = enable == 0;
   return old;
 }
+// diagnostics: 1 = the row-window plane kernels step aside wherever a block-window kernel applies (A/B of the two
+// families on the 8 / 16 / 32-pixel rows; tools/blkbench.py)
+static bool g_blk_first = false;
+extern "C" int odin_debug_blk_first(int on) {
+  const int old = g_blk_first ? 1 : 0;
+  if (on >= 0) g_blk_first = on != 0;
+  return old;
+}
+bool odin_blk_first() { return g_blk_first && !g_blk_off; }
 extern "C" double odin_debug_blk_min_flop(double flop) {
   const double old = g_blk_min_flop;
   if (flop >= 0.0) g_blk_min_flop = flop;

@@ -1221,6 +1221,7 @@ int bp_launch(const BPParams& p, dim3 grid, void* stream) {
 
 // Conv2DTranspose(k4, s2) with Cout = 32: x [B, H, W, Cin] -> dy [B, 2H, 2W, 32]; aux: ELU activations below
 bool odin_bwd_planes_applicable(int B, int H, int W, int Cin, int Cout) {
+  if (odin_blk_first()) return false;   // (diagnostics: odin_debug_blk_first)
   if (odin_exact_fp32() || ODIN_DIAG_ENV("ODIN_NOPLANES") || ODIN_DIAG_ENV("ODIN_NOBWDPLANES")) return false;
   if (!((Cout == 32 || Cout == 64) && (Cin % 32) == 0 && (W == 8 || W == 16 || W == 32) && (H % (32 / W)) == 0)) return false;
   if (!((size_t)B * 2 * H * 2 * W * Cout * 4 < 0x7FFF0000ull && (size_t)B * H * W * Cin * 4 < 0x7FFF0000ull)) return false;

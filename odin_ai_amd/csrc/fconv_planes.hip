@@ -498,6 +498,7 @@ void odin_fconv_planes_set_stamps(void* buf) { g_fp_stamps = (long long*)buf; }
 
 bool odin_fconv_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW, int S,
                                   int pt, int pl, int center) {
+  if (odin_blk_first()) return false;   // (diagnostics: odin_debug_blk_first)
   // (read per call: the A/B tests switch paths inside one process; a captured graph never comes here)
   if (odin_exact_fp32() || ODIN_DIAG_ENV("ODIN_NOPLANES") || ODIN_DIAG_ENV("ODIN_SPLIT") || ODIN_DIAG_ENV("ODIN_NOFPLANES")) return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && (CI == 32 || (CI == 64 && !ODIN_DIAG_ENV("ODIN_FP_NO64"))) && (CO % 32) == 0 && !center &&

@@ -152,7 +152,8 @@ int odin_conv5_blk_launch(const float* in, const float* w, const float* bias, co
 bool odin_wgrad5_blk_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt, int pl, int center);
 int odin_wgrad5_blk_launch(const float* x, const float* dy, float* slab, int* rows_out, int B, int H, int W, int CI,
                            int CO, int want_bias, const uint32_t* g_amax, const uint32_t* a_amax, void* stream);
-bool odin_blk_enabled(double flop);   // the block-window families are on and take a launch of this many FLOP
+bool odin_blk_enabled(double flop);
+bool odin_blk_first();                 // diagnostics: the block-window kernels precede the row-window ones   // the block-window families are on and take a launch of this many FLOP
 bool odin_bwd_blk_applicable(int B, int H, int W, int Cin, int Cout);
 int odin_bwd_blk_rows(int B, int H, int W, int Cin);
 int odin_bwd_blk_launch(const float* x, const float* dy, const float* w, const float* aux, int aux_act, float* dx,

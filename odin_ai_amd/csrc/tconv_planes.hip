@@ -967,6 +967,7 @@ void odin_tconv_planes_set_stamps(void* buf) { g_tp_stamps = (long long*)buf; }
 // ODIN_SPLIT (any value) and ODIN_NOPLANES select the older instances (gather_conv.hip)
 bool odin_tconv_planes_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt,
                                   int pl, int center, int epi, int C1) {
+  if (odin_blk_first()) return false;   // (diagnostics: odin_debug_blk_first)
   // (read per call: the A/B tests switch paths inside one process; a captured graph never comes here)
   if (odin_exact_fp32() || ODIN_DIAG_ENV("ODIN_NOPLANES") || ODIN_DIAG_ENV("ODIN_SPLIT")) return false;
   if (epi == 3 && (CO != 32 || (C1 != 1 && C1 != 3) || CI != 32 || W == 8)) return false;

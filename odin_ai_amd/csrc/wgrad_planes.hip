@@ -621,6 +621,7 @@ int odin_wgrad_planes_flush(void* stream) {
 // fine tensor U [B, H, W, CI], coarse tensor V [B, OH, OW, CO] (the argument order of wgrad.hip's WParams)
 bool odin_wgrad_planes_applicable(int B, int H, int W, int CI, int OH, int OW, int CO, int KH, int KW,
                                   int S, int pt, int pl, int center) {
+  if (odin_blk_first()) return false;   // (diagnostics: odin_debug_blk_first)
   // (read per call: the A/B tests switch paths inside one process; a captured graph never comes here)
   if (odin_exact_fp32() || ODIN_DIAG_ENV("ODIN_NOPLANES") || ODIN_DIAG_ENV("ODIN_SPLIT") || ODIN_DIAG_ENV("ODIN_NOWPLANES")) return false;
   return KH == 4 && KW == 4 && S == 2 && pt == 1 && pl == 1 && !center && (CI % 32) == 0 && (CO % 32) == 0 &&

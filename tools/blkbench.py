@@ -31,6 +31,11 @@ def word(tn):
 LAYERS = [  # kind, H, W (layer input), Cin, Cout
     ('conv', 48, 40, 32, 32), ('conv', 24, 20, 32, 64), ('conv', 12, 10, 64, 64),
     ('deconv', 12, 10, 64, 64), ('deconv', 24, 20, 64, 32), ('deconv', 48, 40, 32, 32)]
+if os.environ.get('BLK_FIRST'):
+  # the 64 x 64 image stacks' mid layers: block-window kernels (blk=1) against the row-window plane kernels (blk=0)
+  L.odin_debug_blk_first(1)
+  LAYERS = [('conv', 32, 32, 32, 32), ('conv', 16, 16, 32, 64), ('deconv', 8, 8, 64, 64), ('deconv', 16, 16, 64, 32),
+            ('deconv', 32, 32, 32, 32)]
 st = torch.cuda.current_stream().cuda_stream
 if os.environ.get('BLK_MIN_FLOP'):
   L.odin_debug_blk_min_flop(float(os.environ['BLK_MIN_FLOP']))
