@@ -176,7 +176,9 @@ __global__ __launch_bounds__(512) void conv5_blk_kernel(C5Params p) {
       float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), pv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (EPI == 2 && last) ax = odin_run_load4s(AUX, voff, tile_out);
       if (kp > 0) pv = odin_run_load4s(OUT, voff, tile_out);
-      f32x4 acc[2] = {bk_zero4(), bk_zero4()}, acx[2] = {bk_zero4(), bk_zero4()};
+      // (six accumulators: main, high x low, low x high for the even and the odd taps -- MFMAs into the same accumulator
+      // six instructions apart: blk_common.h, bk_mfma16 note)
+      f32x4 acc[2] = {bk_zero4(), bk_zero4()}, acx[2] = {bk_zero4(), bk_zero4()}, acy[2] = {bk_zero4(), bk_zero4()};
 #pragma unroll
       for (int tap = 0; tap < 25; ++tap) {
         const int kh = tap / 5, kw = tap - 5 * kh;
@@ -188,13 +190,13 @@ __global__ __launch_bounds__(512) void conv5_blk_kernel(C5Params p) {
         const u32x4 xl = *reinterpret_cast<const u32x4*>(bq + C5_PLB);
         acx[tap & 1] = mfma16_f16(wh, xl, acx[tap & 1]);
         acc[tap & 1] = mfma16_f16(wh, xh, acc[tap & 1]);
-        acx[tap & 1] = mfma16_f16(wlo, xh, acx[tap & 1]);
+        acy[tap & 1] = mfma16_f16(wlo, xh, acy[tap & 1]);
       }
       if (T + 1 < T1) stage(nbuf);
       float v[4];
       const float p4[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = fmaf(acx[0][r] + acx[1][r], ODIN_LO_UNSCALE, acc[0][r] + acc[1][r]) + p4[r];
+      for (int r = 0; r < 4; ++r) v[r] = fmaf((acx[0][r] + acx[1][r]) + (acy[0][r] + acy[1][r]), ODIN_LO_UNSCALE, acc[0][r] + acc[1][r]) + p4[r];
       if (last) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= out_s;

@@ -5,6 +5,15 @@
 
 namespace {
 
+// bk_mfma16 note -- a hardware / compiler hazard found with tools/race_layer.py and tools/race_speech.py: two
+// v_mfma_f32_16x16x32_f16 into the SAME accumulator with ONE independent MFMA between them (acx += wh xl; acc += wh xh;
+// acx += wl xh -- the natural order of the three plane products) produced wrong values in lanes 12-15 of every 16-lane row
+// of one accumulator register, intermittently (7 % of the launches of the audio decoder2 forward, always in a
+// workgroup's FIRST tile, i.e. while the SIMD's other wave is not yet issuing MFMAs and the two instructions go out back
+// to back: the compiler inserts no wait state there, the second instruction reads the accumulator before the first has
+// written all of it).  An extra barrier or any other delay hides it.  Every kernel of the block-window family therefore
+// issues MFMAs into the same accumulator at least four instructions apart: sweeps over the pixel blocks, or three
+// accumulators (main, high x low, low x high) per block and tap parity.
 // D(16 x 16) += A(16 x 32) * B(32 x 16) on f16 operands.  Lane l supplies A[row l & 15][k = 8 (l >> 4) + j] and
 // B[k = 8 (l >> 4) + j][col l & 15] in element j; D: col = l & 15, row = 4 (l >> 4) + r for accumulator register r.
 __device__ __forceinline__ f32x4 mfma16_f16(u32x4 a, u32x4 b, f32x4 c) {

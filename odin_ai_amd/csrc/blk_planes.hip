@@ -191,15 +191,24 @@ __global__ __launch_bounds__(512) void tconv_blk_kernel(TBParams p) {
     for (int kp = 0; kp < NK; ++kp)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
+      {
+        // (the three plane products of a tap as three sweeps over the four pixel blocks: two MFMAs into the SAME accumulator
+        // are four instructions apart -- back to back, v_mfma_f32_16x16x32_f16's second read of an accumulator it wrote one
+        // instruction earlier came out wrong in a few lanes, intermittently: tools/race_layer.py)
+        u32x4 xh[4], xl[4];
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) {
           const char* a = buf + kp * TB_KPB + boff[t] + pb * 2048;
-          const u32x4 xh = *reinterpret_cast<const u32x4*>(a);
-          const u32x4 xl = *reinterpret_cast<const u32x4*>(a + TB_PLB);
-          acx[pb] = mfma16_f16(wh[t][kp], xl, acx[pb]);
-          acc[pb] = mfma16_f16(wh[t][kp], xh, acc[pb]);
-          acx[pb] = mfma16_f16(wl[t][kp], xh, acx[pb]);
+          xh[pb] = *reinterpret_cast<const u32x4*>(a);
+          xl[pb] = *reinterpret_cast<const u32x4*>(a + TB_PLB);
         }
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) acx[pb] = mfma16_f16(wh[t][kp], xl[pb], acx[pb]);
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) acc[pb] = mfma16_f16(wh[t][kp], xh[pb], acc[pb]);
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) acx[pb] = mfma16_f16(wl[t][kp], xh[pb], acx[pb]);
+      }
     if (T + 1 < T1) stage(nbuf);
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) {
@@ -502,8 +511,9 @@ __global__ __launch_bounds__(512) void fconv_blk_kernel(FBParams p) {
     const unsigned voff = ok ? out_lane : ODIN_OOB_V;
     float4 ax = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EPI == 2) ax = odin_run_load4s(AUX, voff, tile_out);
-    // two accumulator pairs (even / odd taps): no MFMA waits for the one before it
-    f32x4 acc[2] = {bk_zero4(), bk_zero4()}, acx[2] = {bk_zero4(), bk_zero4()};
+    // SIX accumulators -- (main, high x low, low x high) for the even and for the odd taps -- so that two MFMAs into the
+    // same accumulator are six instructions apart (bk_mfma16 note in blk_common.h: closer ones went wrong on the MI355X)
+    f32x4 acc[2] = {bk_zero4(), bk_zero4()}, acx[2] = {bk_zero4(), bk_zero4()}, acy[2] = {bk_zero4(), bk_zero4()};
 #pragma unroll
     for (int tap = 0; tap < 16; ++tap) {
       const int kh = tap >> 2, kw = tap & 3;
@@ -512,12 +522,12 @@ __global__ __launch_bounds__(512) void fconv_blk_kernel(FBParams p) {
       const u32x4 xl = *reinterpret_cast<const u32x4*>(a + FW_PLB);
       acx[tap & 1] = mfma16_f16(wh[tap], xl, acx[tap & 1]);
       acc[tap & 1] = mfma16_f16(wh[tap], xh, acc[tap & 1]);
-      acx[tap & 1] = mfma16_f16(wl[tap], xh, acx[tap & 1]);
+      acy[tap & 1] = mfma16_f16(wl[tap], xh, acy[tap & 1]);
     }
     if (T + 1 < T1) fw_stage(nbuf, itv, I, tid, in_s, in_s2k);
     float v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = fmaf(acx[0][r] + acx[1][r], out_sx, (acc[0][r] + acc[1][r]) * out_s);
+    for (int r = 0; r < 4; ++r) v[r] = fmaf((acx[0][r] + acx[1][r]) + (acy[0][r] + acy[1][r]), out_sx, (acc[0][r] + acc[1][r]) * out_s);
     if (EPI == 1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = bk_act<ACT>(p.act, v[r] + bias_r[r]);
@@ -945,9 +955,9 @@ __global__ __launch_bounds__(512) void bwd_blk_kernel(BBParams p) {
     }
     // ---- data gradient: this wave's four taps over the four pixel blocks, partial blocks to LDS ----
     {
-      f32x4 dacc[4], dacx[4];
+      f32x4 dacc[4], dacx[4], dacy[4];   // (main, high x low, low x high: an accumulator is touched once per tap)
 #pragma unroll
-      for (int pb = 0; pb < 4; ++pb) { dacc[pb] = bk_zero4(); dacx[pb] = bk_zero4(); }
+      for (int pb = 0; pb < 4; ++pb) { dacc[pb] = bk_zero4(); dacx[pb] = bk_zero4(); dacy[pb] = bk_zero4(); }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -957,13 +967,13 @@ __global__ __launch_bounds__(512) void bwd_blk_kernel(BBParams p) {
           const u32x4 xl = *reinterpret_cast<const u32x4*>(a + FW_PLB);
           dacx[pb] = mfma16_f16(dwh[t], xl, dacx[pb]);
           dacc[pb] = mfma16_f16(dwh[t], xh, dacc[pb]);
-          dacx[pb] = mfma16_f16(dwl[t], xh, dacx[pb]);
+          dacy[pb] = mfma16_f16(dwl[t], xh, dacy[pb]);
         }
 #pragma unroll
       for (int pb = 0; pb < 4; ++pb) {
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaf(dacx[pb][r], out_sx, dacc[pb][r] * out_s);
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(dacx[pb][r] + dacy[pb][r], out_sx, dacc[pb][r] * out_s);
         *reinterpret_cast<f32x4*>(red + ((wave * 4 + pb) * 64 + lane) * 16) = v;
       }
     }
@@ -1278,19 +1288,28 @@ __global__ __launch_bounds__(512) void tconv_blk_gtail_kernel(TGParams p) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) { acc[i][nb] = bk_zero4(); acx[i][nb] = bk_zero4(); }
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) {
+      // (three sweeps over the four accumulator pairs: MFMAs into the same accumulator are four instructions apart)
+      u32x4 xh[2], xl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const char* a = buf + boff[t] + (2 * pbh + i) * 2048;
-        const u32x4 xh = *reinterpret_cast<const u32x4*>(a);
-        const u32x4 xl = *reinterpret_cast<const u32x4*>(a + TB_PLB);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          acx[i][nb] = mfma16_f16(wh[t][nb], xl, acx[i][nb]);
-          acc[i][nb] = mfma16_f16(wh[t][nb], xh, acc[i][nb]);
-          acx[i][nb] = mfma16_f16(wl[t][nb], xh, acx[i][nb]);
-        }
+        xh[i] = *reinterpret_cast<const u32x4*>(a);
+        xl[i] = *reinterpret_cast<const u32x4*>(a + TB_PLB);
       }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acx[i][nb] = mfma16_f16(wh[t][nb], xl[i], acx[i][nb]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[i][nb] = mfma16_f16(wh[t][nb], xh[i], acc[i][nb]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acx[i][nb] = mfma16_f16(wl[t][nb], xh[i], acx[i][nb]);
+    }
     if (T + 1 < T1) stage(nbuf);
     float llk_lane = 0.f;
 #pragma unroll

@@ -295,3 +295,33 @@ def test_conv5(blk, B, H, W, Ci, Co, act, xs, gs):
   g = reduce_slab(bk, slab, rows.value, n)
   close(g[:-Co].reshape(K, K, Ci, Co) / (gs * xs), dw_ref / (gs * xs), 1e-4)
   close(g[-Co:] / gs, db_ref / gs, 1e-4)
+
+
+@pytest.mark.gpu
+def test_run_to_run_determinism_at_layer_size():
+  """Every launch of a block-window kernel on the same inputs gives the same bits.  The first form of these kernels issued
+  two v_mfma_f32_16x16x32_f16 into one accumulator with a single independent MFMA between them: 7 % of the launches of the
+  audio decoder2 forward came out wrong in a few hundred elements of a workgroup's first tile (blk_common.h, bk_mfma16 note;
+  tools/race_ops.py runs the whole family 150 times)."""
+  from odin_ai_amd import _lib as lib_mod
+  L = lib_mod.load()
+  dev = torch.device('cuda:0')
+  g = torch.Generator(device='cpu').manual_seed(3)
+  R = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+  st = torch.cuda.current_stream().cuda_stream
+  for B, H, W, Ci, Co in ((256, 12, 10, 64, 64), (256, 24, 20, 64, 32)):
+    d = _lib.conv_desc(B, H, W, Ci, 2 * H, 2 * W, Co, 4, 2, 1, 1, 'elu')
+    x, wt, b = R(B, H, W, Ci), R(4, 4, Co, Ci, sc=0.05), R(Co, sc=0.1)
+    ref = None
+    for it in range(40):
+      y = torch.full((B, 2 * H, 2 * W, Co), float('nan'), device=dev)
+      L.odin_deconv2d_fwd(x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), C.byref(d), st)
+      torch.cuda.synchronize()
+      assert L.odin_debug_last_path().decode() == 'tconv_blk(f16x2)'
+      if ref is None:
+        ref = y
+        yr = torch.nn.functional.elu(torch.nn.functional.conv_transpose2d(
+            x.double().permute(0, 3, 1, 2), wt.double().permute(3, 2, 0, 1), b.double(), stride=2, padding=1)).permute(0, 2, 3, 1)
+        assert float((y.double() - yr).abs().max()) <= 2e-5 * max(1.0, float(yr.abs().max()))
+      else:
+        assert torch.equal(y, ref), (it, int((y != ref).sum()))
