@@ -13,15 +13,17 @@ if os.environ.get('NO_BLK'):
   L.odin_debug_blk_planes(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-nets = get_networks('speech', n_frames=96, n_mels=80)
+DS = sys.argv[3] if len(sys.argv) > 3 else 'speech'
+nets = get_networks('speech', n_frames=96, n_mels=80) if DS == 'speech' else get_networks(DS)
+OBS = 'gaussian_softplus1' if DS == 'speech' else 'bernoulli'
 enc, dec = nets['encoder'].layers, nets['decoder'].layers
 in_shape, zdim = nets['encoder'].input_shape, nets['latents'].event_shape[0]
 rng = np.random.default_rng(5)
 x = np.clip(rng.random((B,) + tuple(in_shape)), 1e-6, 1 - 1e-6).astype(np.float32)
 eps = rng.standard_normal((B, zdim)).astype(np.float32)
-om = vo.OracleVAE(enc, dec, in_shape, zdim, observation='gaussian_softplus1', beta=1.0)
+om = vo.OracleVAE(enc, dec, in_shape, zdim, observation=OBS, beta=1.0)
 P = om.init_params(seed=9)
-eng = VAEEngine(enc, dec, in_shape, zdim, B, dev, observation='gaussian_softplus1', lib=L)
+eng = VAEEngine(enc, dec, in_shape, zdim, B, dev, observation=OBS, lib=L)
 eng.load_params({k: v.astype(np.float32).astype(np.float64) for k, v in P.items()})
 eng.step_count = 1
 eng.set_hyper(lr=1e-3, beta=1.0)
