@@ -612,6 +612,9 @@ def main():
   ap.add_argument('--engine-opt', action='append', default=[], metavar='KEY=VALUE',
                   help='a VAEEngine keyword argument of the main engine (A/B runs: hyper_ring=False, act_words=False, '
                   'fuse_norm=False, overlap_wgrad=small, early_reduce=True, defer_wgrad=True, neck=False ...)')
+  ap.add_argument('--overlap-disc', action='store_true',
+                  help="A/B (FactorVAE): the discriminator's pass over z on a side stream beside the decoder instead of "
+                  'behind the VAE forward pass on the same stream (measured slower: 0.755 vs 0.735 ms)')
   ap.add_argument('--no-blk', action='store_true',
                   help='A/B: the 4x4 / stride-2 layers that fit no row-window plane kernel on igemm_h.hip (round 5) instead '
                   'of the block-window kernels of blk_planes.hip (odin_debug_blk_planes(0); the audio VAE)')
@@ -682,6 +685,7 @@ def main():
     fv = FactorVAE(device=device, seed=1 + rank, **nets)
     fv.force_dp = use_dist
     fv.engine_options = dict(eopts)
+    fv.overlap_disc = bool(args.overlap_disc)
     eng = fv._engine(B // 2)
     fv._discriminator(B // 2)
     beta = 1.0

@@ -1124,9 +1124,10 @@ class VAEEngine:
   # ---- forward -----------------------------------------------------------------------
   def forward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, st=None,
               fused: bool = True, tc_ptr: Optional[int] = None, finalize: bool = True,
-              tc_split: bool = False):
+              tc_split: bool = False, after_latent=None):
     """Runs encode -> reparameterise -> decode -> ELBO (+ dlogits).  `eps=None` draws the
-    noise on device from the Philox stream (seed, step)."""
+    noise on device from the Philox stream (seed, step).  `after_latent()` (optional) is called once z is issued
+    on the stream -- FactorVAE forks its discriminator pass onto a side stream there, beside the decoder."""
     lib, B, D = self.lib, self.B, self.D
     st = self.stream() if st is None else st
     assert x.shape == (B,) + self.in_shape and x.is_contiguous()
@@ -1170,6 +1171,8 @@ class VAEEngine:
                           self.kl.data_ptr(), self.fbmask.data_ptr(), B, D, int(self.analytic),
                           self.free_bits, self.hp(H_CAP) if self.capacity_on else None, st)
       dec_in, dec_start = self.z, 0
+    if after_latent is not None:
+      after_latent()
     npart = C.c_int(0)
     if self.fused_tail:
       # gouts[-2] comes from the fused tail (which keeps the range word on the plane kernel) or, unfused, from the

@@ -1211,21 +1211,46 @@ class FactorVAE(AnnealingVAE):
     dp = eng.is_dp
     P = []
 
+    # The discriminator's pass over z (TC estimate + its gradient wrt z: twelve small launches, ~96 us at batch 128, none
+    # of which fills the chip) depends on z alone and is needed again only by the ENCODER's backward pass: `overlap_disc`
+    # runs it on a side stream beside the decoder's forward pass and fused tail.  Measured (round 6, same-call A/B,
+    # `bench.py --overlap-disc`): 0.755 ms per iteration against 0.735 on one stream -- the decoder's launches hold
+    # every CU with 8 waves and ~100 KB of LDS, the forked branch of the captured graph waits for them and then delays the
+    # join -- so it is OFF by default, like the engine's other overlap options.
+    side = getattr(eng, 'side_stream', None)
+    overlap = bool(getattr(self, 'overlap_disc', False)) and use_tc and training and side is not None
+
+    def disc_pass(st):
+      lg = disc.prog1.forward(eng.z, st)
+      lib.odin_mean(lg.data_ptr(), B1, disc.tc.data_ptr(), st)
+      disc.prog1.backward(eng.z, disc.dlogit1, st, dx_out=disc.dz, data_only=True)
+
     def step1():  # ELBO with the discriminator's TC estimate, backward
       st = eng.stream()
-      eng.forward(x1, eps, finalize=False)
+      if overlap:
+        cur = torch.cuda.current_stream(self.device)
+
+        def fork_disc():
+          ev = torch.cuda.Event()
+          ev.record(cur)
+          side.wait_event(ev)
+          disc_pass(side.cuda_stream)
+
+        eng.forward(x1, eps, finalize=False, after_latent=fork_disc)
+        cur.wait_stream(side)   # (dz and the TC mean are complete before the backward pass / the finalisation)
+      else:
+        eng.forward(x1, eps, finalize=False)
       extra = None
       # the ELBO finalisation (llk[B], loss, mean terms: nothing in the backward pass reads them) rides in the first
       # launch of the VAE optimiser's update when one follows (engine.adam: _fin_pending), as in the plain VAE step
       ride = training
       if use_tc:
-        lg = disc.prog1.forward(eng.z, st)
-        lib.odin_mean(lg.data_ptr(), B1, disc.tc.data_ptr(), st)
+        if not overlap:
+          disc_pass(st)
         if ride:
           eng._fin_pending = (eng._llk_part_used.data_ptr(), eng.n_part, disc.tc.data_ptr())
         else:
           eng.finalize(tc_ptr=disc.tc.data_ptr())
-        disc.prog1.backward(eng.z, disc.dlogit1, st, dx_out=disc.dz, data_only=True)
         extra = disc.dz
         if not training or self._is_pretraining:  # (no discriminator step behind this one to clear the words)
           lib.odin_range_reset(disc.range_words.data_ptr(), disc.range_words.numel() // RANGE_WORDS, st)
