@@ -33,6 +33,7 @@ struct C5Params {
   float* colsum;       // EPI 2: [gridDim.x][CO] (may be null)
   int B, H, W, CS, CO;
   int act, wmode, nk;
+  int pad;             // rows / columns of padding before the first pixel: (K - 1) / 2 forward, K - 1 - (K - 1) / 2 for the data gradient
   int nty, ntx, n_tiles, tiles_per_wg;
   const unsigned* in_amax;
   unsigned* out_amax;
@@ -40,14 +41,16 @@ struct C5Params {
 };
 
 constexpr int C5_TAPB = 2 * 4 * 32 * 16;     // one tap of the weight planes: [plane][k-piece][n 32][8 f16]
-constexpr int C5_WB = 25 * C5_TAPB;          // 102400 bytes
-constexpr int C5_PLB = 12 * 16 * 64;         // one plane of a window: [row 12][slot 16][32 f16]
+constexpr int C5_PLB = 12 * 16 * 64;         // one plane of a window: [row <= 12][slot 16][32 f16]
 constexpr int C5_WIN = 2 * C5_PLB;
-constexpr int C5_LDS = C5_WB + 2 * C5_WIN;   // 151552 bytes
-constexpr int C5_NIT = (12 * 12 * 8 + 511) / 512;
+// K = 5 (MNIST) or 4 (CelebA's Conv2D(64, 4, 1): `SAME` pads (1, 2)): K x K taps, a window of 8 + K - 1 pixels a side
+__host__ __device__ constexpr int c5_wb(int K) { return K * K * C5_TAPB; }              // weight planes: 100 KB / 64 KB
+__host__ __device__ constexpr int c5_lds(int K) { return c5_wb(K) + 2 * C5_WIN; }        // 151552 / 114688 bytes
+__host__ __device__ constexpr int c5_nit(int K) { return ((8 + K - 1) * (8 + K - 1) * 8 + 511) / 512; }
 
-template <int EPI, int ACT>
+template <int EPI, int ACT, int K>
 __global__ __launch_bounds__(512) void conv5_blk_kernel(C5Params p) {
+  constexpr int WS = 8 + K - 1, NT = K * K, C5_NIT = c5_nit(K), C5_WB = c5_wb(K);
   ODIN_DYN_SMEM(char, smem);
   __shared__ float cred[8 * 16 + 16];
   char* wl = smem;
@@ -68,8 +71,8 @@ __global__ __launch_bounds__(512) void conv5_blk_kernel(C5Params p) {
   for (int j = 0; j < C5_NIT; ++j) {
     const int e = tid + 512 * j;
     const int px = e >> 3, ch4 = e & 7;
-    const int wr = odin_div_small(px, 12), wc = px - 12 * wr;
-    it_wr[j] = (e < 12 * 12 * 8) ? wr : (1 << 20);
+    const int wr = odin_div_small(px, WS), wc = px - WS * wr;
+    it_wr[j] = (e < WS * WS * 8) ? wr : (1 << 20);
     it_wc[j] = wc;
     it_dst[j] = wr * 1024 + wc * 64 + (((ch4 >> 1) ^ tb_swz(wr, wc)) << 4) + (ch4 & 1) * 8;
     it_g[j] = ((wr * p.W + wc) * p.CS + 4 * ch4) * 4;
@@ -77,10 +80,10 @@ __global__ __launch_bounds__(512) void conv5_blk_kernel(C5Params p) {
   float4 itv[C5_NIT];
   int kp = 0;
   auto issue = [&](int b, int ty, int tx) {
-    const int base = ((b * p.H + 8 * ty - 2) * p.W + 8 * tx - 2) * p.CS * 4 + kp * 128;
+    const int base = ((b * p.H + 8 * ty - p.pad) * p.W + 8 * tx - p.pad) * p.CS * 4 + kp * 128;
 #pragma unroll
     for (int j = 0; j < C5_NIT; ++j) {
-      const int gr = 8 * ty - 2 + it_wr[j], gc = 8 * tx - 2 + it_wc[j];
+      const int gr = 8 * ty - p.pad + it_wr[j], gc = 8 * tx - p.pad + it_wc[j];
       const bool ok = gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
       itv[j] = odin_run_load4(IN, ok ? (unsigned)(base + it_g[j]) : ODIN_OOB);
     }
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(512) void conv5_blk_kernel(C5Params p) {
   auto stage = [&](char* buf) {
 #pragma unroll
     for (int j = 0; j < C5_NIT; ++j) {
-      if (tid + 512 * j < 12 * 12 * 8) {
+      if (tid + 512 * j < WS * WS * 8) {
         u32x2 h, l;
         odin_split_h4<true>(itv[j], in_s, in_s2k, h, l);
         *reinterpret_cast<u32x2*>(buf + it_dst[j]) = h;
@@ -105,11 +108,11 @@ __global__ __launch_bounds__(512) void conv5_blk_kernel(C5Params p) {
   };
   // ---- per-lane constants: the lane's output pixel (ri, cj) of the tile, operand offsets by (kh parity, kw) ----
   const int ri = 2 * pb + (l15 >> 3), cj = l15 & 7;
-  int boff[2][5];
+  int boff[2][K];
 #pragma unroll
   for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-    for (int kw = 0; kw < 5; ++kw)
+    for (int kw = 0; kw < K; ++kw)
       boff[pr][kw] = ri * 1024 + (cj + kw) * 64 + ((lq ^ tb_swz(ri + pr, cj + kw)) << 4);
   const char* wlane = wl + lq * 512 + (16 * nb + l15) * 16;
   const unsigned out_bytes = (unsigned)((size_t)p.B * p.H * p.W * p.CO * 4);
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(512) void conv5_blk_kernel(C5Params p) {
     bk_decode(T0, p.nty, p.ntx, b_c, ty_c, tx_c);
     if (T0 < T1) issue(b_c, ty_c, tx_c);
     // ---- this pass's weights -> planes: item = (tap, channel n, k-piece lq): eight reduction channels ----
-    for (int e = tid; e < 25 * 32 * 4; e += 512) {
+    for (int e = tid; e < NT * 32 * 4; e += 512) {
       const int q = e & 3, n = (e >> 2) & 31, tap = e >> 7;
       float4 a, b;
       if (p.wmode == 0) {
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(512) void conv5_blk_kernel(C5Params p) {
         a = make_float4(src[0], src[(size_t)p.CO], src[(size_t)2 * p.CO], src[(size_t)3 * p.CO]);
         b = make_float4(src[(size_t)4 * p.CO], src[(size_t)5 * p.CO], src[(size_t)6 * p.CO], src[(size_t)7 * p.CO]);
       } else {
-        const float* src = p.w + ((size_t)((24 - tap) * p.CO + n0w + n)) * p.CS + 32 * kp + 8 * q;
+        const float* src = p.w + ((size_t)((NT - 1 - tap) * p.CO + n0w + n)) * p.CS + 32 * kp + 8 * q;
         a = make_float4(src[0], src[1], src[2], src[3]);
         b = make_float4(src[4], src[5], src[6], src[7]);
       }
@@ -180,8 +183,8 @@ __global__ __launch_bounds__(512) void conv5_blk_kernel(C5Params p) {
       // six instructions apart: blk_common.h, bk_mfma16 note)
       f32x4 acc[2] = {bk_zero4(), bk_zero4()}, acx[2] = {bk_zero4(), bk_zero4()}, acy[2] = {bk_zero4(), bk_zero4()};
 #pragma unroll
-      for (int tap = 0; tap < 25; ++tap) {
-        const int kh = tap / 5, kw = tap - 5 * kh;
+      for (int tap = 0; tap < NT; ++tap) {
+        const int kh = tap / K, kw = tap - K * kh;
         const char* a = wlane + tap * C5_TAPB;
         const char* bq = buf + boff[kh & 1][kw] + kh * 1024;
         const u32x4 wh = *reinterpret_cast<const u32x4*>(a);
@@ -238,25 +241,25 @@ __global__ __launch_bounds__(512) void conv5_blk_kernel(C5Params p) {
   }
 }
 
-template <int EPI, int ACT>
+template <int EPI, int ACT, int K>
 int c5_launch_a(const C5Params& p, dim3 grid, void* stream) {
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_blk_kernel<EPI, ACT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C5_LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_blk_kernel<EPI, ACT, K>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, c5_lds(K)) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
 #endif
-  ODIN_LAUNCH((conv5_blk_kernel<EPI, ACT>), grid, dim3(512), (size_t)C5_LDS, stream, p);
-  return odin_check_launch("conv5_blk(f16x2)");
+  ODIN_LAUNCH((conv5_blk_kernel<EPI, ACT, K>), grid, dim3(512), (size_t)c5_lds(K), stream, p);
+  return odin_check_launch(K == 5 ? "conv5_blk(f16x2)" : "conv4s1_blk(f16x2)");
 }
-template <int EPI>
+template <int EPI, int K>
 int c5_launch(const C5Params& p, dim3 grid, void* stream) {
-  if (p.act == ODIN_ACT_ELU) return c5_launch_a<EPI, ODIN_ACT_ELU>(p, grid, stream);
-  if (p.act == ODIN_ACT_RELU) return c5_launch_a<EPI, ODIN_ACT_RELU>(p, grid, stream);
-  return c5_launch_a<EPI, -1>(p, grid, stream);
+  if (p.act == ODIN_ACT_ELU) return c5_launch_a<EPI, ODIN_ACT_ELU, K>(p, grid, stream);
+  if (K == 5 && p.act == ODIN_ACT_RELU) return c5_launch_a<EPI, ODIN_ACT_RELU, 5>(p, grid, stream);
+  return c5_launch_a<EPI, -1, K>(p, grid, stream);
 }
 
 int c5_tiles_per_wg(int n_tiles, int gy) {
@@ -288,7 +291,9 @@ constexpr int W5_UPLB = 12 * 16 * 64;            // one plane of the x window
 constexpr int W5_VPLB = 64 * 64;                 // one plane of the dy block
 constexpr int W5_BUF = 2 * W5_UPLB + 2 * W5_VPLB;
 
+template <int K>
 __global__ __launch_bounds__(512) void wgrad5_blk_kernel(W5Params p) {
+  constexpr int WS = 8 + K - 1, NT = K * K, C5_NIT = c5_nit(K);
   ODIN_DYN_SMEM(char, smem);
   __shared__ float bred[8 * 32];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -307,8 +312,8 @@ __global__ __launch_bounds__(512) void wgrad5_blk_kernel(W5Params p) {
   for (int j = 0; j < C5_NIT; ++j) {
     const int e = tid + 512 * j;
     const int px = e >> 3, ch4 = e & 7;
-    const int wr = odin_div_small(px, 12), wc = px - 12 * wr;
-    it_wr[j] = (e < 12 * 12 * 8) ? wr : (1 << 20);
+    const int wr = odin_div_small(px, WS), wc = px - WS * wr;
+    it_wr[j] = (e < WS * WS * 8) ? wr : (1 << 20);
     it_wc[j] = wc;
     it_dst[j] = wr * 1024 + wc * 64 + ch4 * 8;
     it_g[j] = ((wr * p.W + wc) * p.CUt + cu0 + 4 * ch4) * 4;
@@ -319,10 +324,10 @@ __global__ __launch_bounds__(512) void wgrad5_blk_kernel(W5Params p) {
   const int v_g = ((v_r * p.W + v_c) * p.CVt + cv0 + 4 * v_ch4) * 4;
   float4 itv[C5_NIT], vv;
   auto issue = [&](int b, int ty, int tx) {
-    const int base = ((b * p.H + 8 * ty - 2) * p.W + 8 * tx - 2) * p.CUt * 4;
+    const int base = ((b * p.H + 8 * ty - (K - 1) / 2) * p.W + 8 * tx - (K - 1) / 2) * p.CUt * 4;
 #pragma unroll
     for (int j = 0; j < C5_NIT; ++j) {
-      const int gr = 8 * ty - 2 + it_wr[j], gc = 8 * tx - 2 + it_wc[j];
+      const int gr = 8 * ty - (K - 1) / 2 + it_wr[j], gc = 8 * tx - (K - 1) / 2 + it_wc[j];
       const bool ok = gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
       itv[j] = odin_run_load4(RU, ok ? (unsigned)(base + it_g[j]) : ODIN_OOB);
     }
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(512) void wgrad5_blk_kernel(W5Params p) {
   auto stage = [&](char* buf) {
 #pragma unroll
     for (int j = 0; j < C5_NIT; ++j) {
-      if (tid + 512 * j < 12 * 12 * 8) {
+      if (tid + 512 * j < WS * WS * 8) {
         u32x2 h, l;
         odin_split_h4<true>(itv[j], u_s, u_s2k, h, l);
         *reinterpret_cast<u32x2*>(buf + it_dst[j]) = h;
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(512) void wgrad5_blk_kernel(W5Params p) {
 #ifdef ODIN_SIM
   const int sim_u = half * 1024 + 32 * g, sim_v = half * 512 + 32 * g;
 #endif
-  const int n_own = wave == 0 ? 4 : 3;
+  const int n_own = (NT - wave + 7) / 8;   // taps wave, wave + 8, ...: 25 taps -> 4 / 3 / 3 ..., 16 taps -> 2 each
   f32x16 acc[4], acx[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) { acc[t] = f32x16_zero(); acx[t] = f32x16_zero(); }
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(512) void wgrad5_blk_kernel(W5Params p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if (t < n_own) {   // (wave-uniform)
-          const int tap = wave + 8 * t, kh = tap / 5, kw = tap - 5 * kh;
+          const int tap = wave + 8 * t, kh = tap / K, kw = tap - K * kh;
           u32x4 ua[2];
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) {
@@ -445,18 +450,19 @@ __global__ __launch_bounds__(512) void wgrad5_blk_kernel(W5Params p) {
     if (tid < 32) {
       float t = 0.f;
       for (int wv = 0; wv < 8; ++wv) t += bred[wv * 32 + tid];
-      row[(size_t)25 * p.CUt * p.CVt + cv0 + tid] = t;
+      row[(size_t)NT * p.CUt * p.CVt + cv0 + tid] = t;
     }
   }
 }
 
 }  // namespace
 
-// Conv2D(k5, s1, SAME) over CI in {32, 64} input channels: forward (tmode 0) and data gradient (tmode 1: CI = the layer's
-// OUTPUT channels, CO its input channels)
+// Conv2D(k, s1, SAME), k = 5 (pads 2, 2) or 4 (pads 1, 2), over CI in {32, 64} reduction channels: forward and data
+// gradient (there CI = the layer's OUTPUT channels, CO its input channels)
 bool odin_conv5_blk_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt, int pl, int center) {
-  if (!odin_blk_enabled(2.0 * B * H * W * 25.0 * CI * CO)) return false;
-  if (!(KH == 5 && KW == 5 && S == 1 && pt == 2 && pl == 2 && !center && (CI == 32 || CI == 64) && (CO % 32) == 0))
+  if (!odin_blk_enabled(2.0 * B * H * W * (double)(KH * KW) * CI * CO)) return false;
+  if (!((KH == 5 || KH == 4) && KW == KH && S == 1 && pt == (KH - 1) / 2 && pl == (KW - 1) / 2 && !center &&
+        (CI == 32 || CI == 64) && (CO % 32) == 0))
     return false;
   if (H < 1 || W < 1 || H > 4096 || W > 4096) return false;
   return (size_t)B * H * W * CI * 4 < 0x7FFF0000ull && (size_t)B * H * W * CO * 4 < 0x7FFF0000ull;
@@ -464,12 +470,13 @@ bool odin_conv5_blk_applicable(int B, int H, int W, int CI, int CO, int KH, int 
 
 // epi 1: forward (bias + act); epi 2: data gradient (x act'(aux), column sums into colsum[rows][CO])
 int odin_conv5_blk_launch(const float* in, const float* w, const float* bias, const float* aux, float* out,
-                          float* colsum, int* rows_out, int B, int H, int W, int CI, int CO, int epi, int act,
+                          float* colsum, int* rows_out, int B, int H, int W, int CI, int CO, int K, int epi, int act,
                           const uint32_t* in_amax, uint32_t* out_amax, void* stream) {
   C5Params p;
   memset(&p, 0, sizeof(p));
   p.in = in; p.w = w; p.bias = bias; p.aux = aux; p.out = out; p.colsum = colsum;
   p.B = B; p.H = H; p.W = W; p.CS = CI; p.CO = CO; p.act = act; p.nk = CI / 32; p.wmode = epi == 2 ? 1 : 0;
+  p.pad = epi == 2 ? K - 1 - (K - 1) / 2 : (K - 1) / 2;
   p.nty = (H + 7) / 8; p.ntx = (W + 7) / 8;
   p.n_tiles = B * p.nty * p.ntx;
   const int gy = CO / 32;
@@ -487,24 +494,27 @@ int odin_conv5_blk_launch(const float* in, const float* w, const float* bias, co
   }
   p.out_amax = out_amax;
   dim3 grid(gx, gy, 1);
-  return epi == 1 ? c5_launch<1>(p, grid, stream) : c5_launch<2>(p, grid, stream);
+  if (K == 5) return epi == 1 ? c5_launch<1, 5>(p, grid, stream) : c5_launch<2, 5>(p, grid, stream);
+  return epi == 1 ? c5_launch<1, 4>(p, grid, stream) : c5_launch<2, 4>(p, grid, stream);
 }
 
-// weight gradient of a Conv2D(k5, s1): x [B, H, W, CI], dy [B, H, W, CO]
+// weight gradient of a Conv2D(k, s1), k = 5 or 4: x [B, H, W, CI], dy [B, H, W, CO]
 bool odin_wgrad5_blk_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt, int pl, int center) {
-  if (!odin_blk_enabled(2.0 * B * H * W * 25.0 * CI * CO)) return false;
-  if (!(KH == 5 && KW == 5 && S == 1 && pt == 2 && pl == 2 && !center && (CI % 32) == 0 && (CO % 32) == 0)) return false;
+  if (!odin_blk_enabled(2.0 * B * H * W * (double)(KH * KW) * CI * CO)) return false;
+  if (!((KH == 5 || KH == 4) && KW == KH && S == 1 && pt == (KH - 1) / 2 && pl == (KW - 1) / 2 && !center &&
+        (CI % 32) == 0 && (CO % 32) == 0))
+    return false;
   if (H < 1 || W < 1 || H > 4096 || W > 4096) return false;
   return (size_t)B * H * W * CI * 4 < 0x7FFF0000ull && (size_t)B * H * W * CO * 4 < 0x7FFF0000ull;
 }
 
 int odin_wgrad5_blk_launch(const float* x, const float* dy, float* slab, int* rows_out, int B, int H, int W, int CI,
-                           int CO, int want_bias, const uint32_t* g_amax, const uint32_t* a_amax, void* stream) {
+                           int CO, int K, int want_bias, const uint32_t* g_amax, const uint32_t* a_amax, void* stream) {
   W5Params p;
   memset(&p, 0, sizeof(p));
   p.U = x; p.V = dy; p.slab = slab;
   p.B = B; p.H = H; p.W = W; p.CUt = CI; p.CVt = CO; p.want_bias = want_bias;
-  p.slab_stride = 25 * CI * CO + (want_bias ? CO : 0);
+  p.slab_stride = K * K * CI * CO + (want_bias ? CO : 0);
   p.nty = (H + 7) / 8; p.ntx = (W + 7) / 8;
   p.n_tiles = B * p.nty * p.ntx;
   const int gy = CO / 32, gz = CI / 32;
@@ -521,13 +531,17 @@ int odin_wgrad5_blk_launch(const float* x, const float* dy, float* slab, int* ro
 #ifndef ODIN_SIM
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad5_blk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad5_blk_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * W5_BUF) != hipSuccess)
+      (void)hipGetLastError();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad5_blk_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * W5_BUF) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
 #endif
   dim3 grid(gx, gy, gz);
-  ODIN_LAUNCH((wgrad5_blk_kernel), grid, dim3(512), (size_t)2 * W5_BUF, stream, p);
-  return odin_check_launch("wgrad5_blk(f16x2)");
+  if (K == 5) ODIN_LAUNCH((wgrad5_blk_kernel<5>), grid, dim3(512), (size_t)2 * W5_BUF, stream, p);
+  else ODIN_LAUNCH((wgrad5_blk_kernel<4>), grid, dim3(512), (size_t)2 * W5_BUF, stream, p);
+  return odin_check_launch(K == 5 ? "wgrad5_blk(f16x2)" : "wgrad4s1_blk(f16x2)");
 }

@@ -1626,7 +1626,7 @@ extern "C" int odin_conv2d_fwd(const float* x, const float* w, const float* bias
   // 5x5 / stride-1 layers (the MNIST conv stack): block windows with the weights in LDS (blk5_planes.hip)
   if (bias != nullptr && d->H == d->OH && d->W == d->OW &&
       odin_conv5_blk_applicable(d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->center))
-    return odin_conv5_blk_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->Cin, d->Cout, 1, d->act,
+    return odin_conv5_blk_launch(x, w, bias, nullptr, y, nullptr, nullptr, d->B, d->H, d->W, d->Cin, d->Cout, d->KH, 1, d->act,
                                  d->x_amax, d->y_amax, stream);
   if (bias != nullptr &&
       odin_fconv_blk_applicable(d->B, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad_t,
@@ -1732,7 +1732,7 @@ extern "C" int odin_conv2d_dgrad(const float* dy, const float* w, const float* a
   if (d->H == d->OH && d->W == d->OW &&
       odin_conv5_blk_applicable(d->B, d->H, d->W, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0))
     return odin_conv5_blk_launch(dy, w, nullptr, aux_act != 0 ? aux : nullptr, dx, colsum_slab, slab_rows_out, d->B,
-                                 d->H, d->W, d->Cout, d->Cin, 2, aux_act, d->dy_amax, d->dx_amax, stream);
+                                 d->H, d->W, d->Cout, d->Cin, d->KH, 2, aux_act, d->dy_amax, d->dx_amax, stream);
   // any other image size: 8 x 8 blocks of dy through LDS windows (blk_planes.hip)
   if (d->H == 2 * d->OH && d->W == 2 * d->OW &&
       odin_tconv_blk_applicable(d->B, d->OH, d->OW, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, 0))

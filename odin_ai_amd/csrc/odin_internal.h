@@ -147,11 +147,11 @@ int odin_wgrad_blk_launch(const float* U, const float* V, float* slab, int* rows
 // 5x5 / stride-1 layers over block windows (blk5_planes.hip)
 bool odin_conv5_blk_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt, int pl, int center);
 int odin_conv5_blk_launch(const float* in, const float* w, const float* bias, const float* aux, float* out,
-                          float* colsum, int* rows_out, int B, int H, int W, int CI, int CO, int epi, int act,
+                          float* colsum, int* rows_out, int B, int H, int W, int CI, int CO, int K, int epi, int act,
                           const uint32_t* in_amax, uint32_t* out_amax, void* stream);
 bool odin_wgrad5_blk_applicable(int B, int H, int W, int CI, int CO, int KH, int KW, int S, int pt, int pl, int center);
 int odin_wgrad5_blk_launch(const float* x, const float* dy, float* slab, int* rows_out, int B, int H, int W, int CI,
-                           int CO, int want_bias, const uint32_t* g_amax, const uint32_t* a_amax, void* stream);
+                           int CO, int K, int want_bias, const uint32_t* g_amax, const uint32_t* a_amax, void* stream);
 bool odin_blk_enabled(double flop);
 bool odin_blk_first();                 // diagnostics: the block-window kernels precede the row-window ones   // the block-window families are on and take a launch of this many FLOP
 bool odin_bwd_blk_applicable(int B, int H, int W, int Cin, int Cout);

@@ -1041,7 +1041,7 @@ int launch_wgrad(WParams& p, int* rows_out, void* stream) {
                                     p.want_bias, p.want_bias ? 0 : 1, p.g_amax, p.a_amax, stream);
   if (p.H == p.OH && p.W == p.OW && p.want_bias &&
       odin_wgrad5_blk_applicable(p.B, p.H, p.W, p.CI, p.CO, p.KH, p.KW, p.S, p.pt, p.pl, p.center))
-    return odin_wgrad5_blk_launch(p.in, p.dy, p.slab, rows_out, p.B, p.H, p.W, p.CI, p.CO, p.want_bias, p.g_amax,
+    return odin_wgrad5_blk_launch(p.in, p.dy, p.slab, rows_out, p.B, p.H, p.W, p.CI, p.CO, p.KH, p.want_bias, p.g_amax,
                                   p.a_amax, stream);
   if (odin_wgrad_blk_applicable(p.B, p.H, p.W, p.CI, p.OH, p.OW, p.CO, p.KH, p.KW, p.S, p.pt, p.pl, p.center))
     return odin_wgrad_blk_launch(p.in, p.dy, p.slab, rows_out, p.B, p.OH, p.OW, p.CI, p.CO, p.want_bias,

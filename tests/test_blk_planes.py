@@ -239,20 +239,22 @@ def test_gaussian_tail(blk, B, H, W, act, sp1):
 
 
 CONV5 = [
-    # B, H, W, Cin, Cout, act, scale of x, scale of dy   (5 x 5 / stride 1, `SAME`: blk5_planes.hip)
-    (2, 14, 14, 32, 64, 'elu', 1.0, 1.0),       # MNIST encoder2: ragged 8 x 8 tiles, two output blocks
-    (1, 28, 28, 32, 32, 'relu', 1.0, 1.0),      # MNIST decoder4
-    (1, 14, 14, 64, 64, 'elu', 1.0, 1e-9),      # MNIST decoder2: 64 reduction channels = two passes; tiny gradients
-    (2, 9, 11, 64, 32, 'linear', 3e4, 1.0),     # odd sizes; activations beyond the f16 window
+    # K, B, H, W, Cin, Cout, act, scale of x, scale of dy   (K x K / stride 1, `SAME`: blk5_planes.hip)
+    (5, 2, 14, 14, 32, 64, 'elu', 1.0, 1.0),       # MNIST encoder2: ragged 8 x 8 tiles, two output blocks
+    (5, 1, 28, 28, 32, 32, 'relu', 1.0, 1.0),      # MNIST decoder4
+    (5, 1, 14, 14, 64, 64, 'elu', 1.0, 1e-9),      # MNIST decoder2: 64 reduction channels = two passes; tiny gradients
+    (5, 2, 9, 11, 64, 32, 'linear', 3e4, 1.0),     # odd sizes; activations beyond the f16 window
+    (4, 3, 8, 8, 64, 64, 'elu', 1.0, 1.0),         # CelebA encoder3: 4 x 4 / stride 1, `SAME` pads (1, 2)
+    (4, 2, 9, 13, 32, 64, 'relu', 1.0, 1e-9),      # the same kernel size on odd maps, 32 reduction channels forward
 ]
 
 
-@pytest.mark.parametrize('B,H,W,Ci,Co,act,xs,gs', CONV5)
-def test_conv5(blk, B, H, W, Ci, Co, act, xs, gs):
+@pytest.mark.parametrize('K,B,H,W,Ci,Co,act,xs,gs', CONV5)
+def test_conv5(blk, K, B, H, W, Ci, Co, act, xs, gs):
   bk = blk
   L, T = bk.L, bk.T
   rng = np.random.default_rng(B * 100 + H)
-  K, S = 5, 1
+  S = 1
   x = rng.standard_normal((B, H, W, Ci)) * xs
   w = rng.standard_normal((K, K, Ci, Co)) * 0.1 / xs
   b = rng.standard_normal(Co) * 0.1
@@ -265,7 +267,7 @@ def test_conv5(blk, B, H, W, Ci, Co, act, xs, gs):
   d.x_amax, d.y_amax = xw.data_ptr(), yw.data_ptr()
   ty = bk.full((B, OH, OW, Co), float('nan'))
   L.odin_conv2d_fwd(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), ty.data_ptr(), C.byref(d), None)
-  assert L.odin_debug_last_path().decode() == 'conv5_blk(f16x2)'
+  assert L.odin_debug_last_path().decode() == ('conv5_blk(f16x2)' if K == 5 else 'conv4s1_blk(f16x2)')
   close(ty.cpu().numpy(), y_ref)
   assert word_max(yw) >= float(np.abs(y_ref).max()) * (1 - 1e-5) and word_max(yw) <= float(np.abs(y_ref).max()) * 1.001
   dy = rng.standard_normal((B, OH, OW, Co)) * gs
@@ -281,7 +283,7 @@ def test_conv5(blk, B, H, W, Ci, Co, act, xs, gs):
   slab = bk.full((L.odin_max_slab_rows(), Ci), float('nan'))
   L.odin_conv2d_dgrad(tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), 1, tdx.data_ptr(), slab.data_ptr(),
                       C.byref(rows), C.byref(d), None)
-  assert L.odin_debug_last_path().decode() == 'conv5_blk(f16x2)'
+  assert L.odin_debug_last_path().decode() == ('conv5_blk(f16x2)' if K == 5 else 'conv4s1_blk(f16x2)')
   close(tdx.cpu().numpy() / gs, g_ref / gs)
   close(reduce_slab(bk, slab, rows.value, Ci) / gs, g_ref.sum((0, 1, 2)) / gs, 1e-4)
   assert word_max(dxw) >= float(np.abs(g_ref).max()) * (1 - 1e-5) and word_max(dxw) <= float(np.abs(g_ref).max()) * 1.001
@@ -291,7 +293,7 @@ def test_conv5(blk, B, H, W, Ci, Co, act, xs, gs):
   n = K * K * Ci * Co + Co
   slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
   L.odin_conv2d_wgrad(tx.data_ptr(), tdy.data_ptr(), slab.data_ptr(), C.byref(rows), C.byref(d), None)
-  print('conv5 wgrad', L.odin_debug_last_path().decode())
+  assert L.odin_debug_last_path().decode() == ('wgrad5_blk(f16x2)' if K == 5 else 'wgrad4s1_blk(f16x2)')
   g = reduce_slab(bk, slab, rows.value, n)
   close(g[:-Co].reshape(K, K, Ci, Co) / (gs * xs), dw_ref / (gs * xs), 1e-4)
   close(g[-Co:] / gs, db_ref / gs, 1e-4)

@@ -31,6 +31,10 @@ def word(tn):
 LAYERS = [  # kind, H, W (layer input), Cin, Cout
     ('conv', 48, 40, 32, 32), ('conv', 24, 20, 32, 64), ('conv', 12, 10, 64, 64),
     ('deconv', 12, 10, 64, 64), ('deconv', 24, 20, 64, 32), ('deconv', 48, 40, 32, 32)]
+if os.environ.get('BLK_CELEBA'):
+  # CelebA (batch 512): the 8 x 8 -> 4 x 4 encoder layer and the 4 x 4 -> 8 x 8 decoder layer
+  B = 512
+  LAYERS = [('conv', 8, 8, 64, 64), ('deconv', 4, 4, 64, 64)]
 if os.environ.get('BLK_FIRST'):
   # the 64 x 64 image stacks' mid layers: block-window kernels (blk=1) against the row-window plane kernels (blk=0)
   L.odin_debug_blk_first(1)
