@@ -320,7 +320,18 @@ __global__ __launch_bounds__(256) void smallc_fwd_mfma_kernel(SCParams p) {
 // needed by 4 taps x 2 rows.  A workgroup owns NR consecutive output rows of one image: its S (NR - 1) + KH input
 // rows arrive with coalesced 16-byte loads (CenterAt0 applied here, SAME-padding rows zeroed), the taps are
 // gathered from LDS (4-byte ds_reads, <= 2-way bank conflicts), wave w multiplies rows w, w + 4, ...
-template <int NK2, int RB>
+// the activation as a compile-time constant where it is ELU (every conv layer of the reference's stacks): the run-time
+// switch of odin_act compiles to scalar branches per ELEMENT (132 in this kernel's epilogue; round 6, cf. blk_planes.hip)
+template <bool ELU>
+__device__ __forceinline__ float sc_act(int rt, float v) {
+  if (ELU) {
+    const float em1 = odin_exp2(v * 1.44269504088896341f) - 1.f;
+    return v > 0.f ? v : em1;
+  }
+  return odin_act(rt, v);
+}
+
+template <int NK2, int RB, bool ELU>
 __global__ __launch_bounds__(256) void smallc_fwd_lds_kernel(SCParams p, int NR) {
   ODIN_DYN_SMEM(float, xs);  // [S (NR - 1) + KH rows][W * CI]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -416,10 +427,10 @@ __global__ __launch_bounds__(256) void smallc_fwd_lds_kernel(SCParams p, int NR)
       for (int q = 0; q < 4; ++q) {
         const int n = rb * 32 + 8 * q + 4 * h;
         if (n + 3 < p.CO) {
-          const float4 o = make_float4(odin_act(p.act, acc[4 * q] + bias_r[rb][4 * q]),
-                                       odin_act(p.act, acc[4 * q + 1] + bias_r[rb][4 * q + 1]),
-                                       odin_act(p.act, acc[4 * q + 2] + bias_r[rb][4 * q + 2]),
-                                       odin_act(p.act, acc[4 * q + 3] + bias_r[rb][4 * q + 3]));
+          const float4 o = make_float4(sc_act<ELU>(p.act, acc[4 * q] + bias_r[rb][4 * q]),
+                                       sc_act<ELU>(p.act, acc[4 * q + 1] + bias_r[rb][4 * q + 1]),
+                                       sc_act<ELU>(p.act, acc[4 * q + 2] + bias_r[rb][4 * q + 2]),
+                                       sc_act<ELU>(p.act, acc[4 * q + 3] + bias_r[rb][4 * q + 3]));
           amx = odin_amax3(odin_amax3(amx, o.x, o.y), o.z, o.w);
           *reinterpret_cast<float4*>(outp + rb * 32 + 8 * q) = o;
         }
@@ -597,10 +608,30 @@ static int smallc_fwd_launch(const float* x, const float* w, const float* bias, 
       const size_t l3 = (size_t)(d->stride * (NR - 1) + d->KH) * d->W * d->Cin * 4;
       const long gb = (long)d->B * (d->OH / NR);
       if (l3 <= 48 * 1024 && gb < (1L << 30)) {
-        if (nk2 == 8 && rb == 1) { ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 1>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); *tracked = true; return odin_check_launch("smallc_fwd_lds"); }
-        if (nk2 == 8 && rb == 2) { ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 2>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); *tracked = true; return odin_check_launch("smallc_fwd_lds"); }
-        if (nk2 == 24 && rb == 1) { ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 1>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); *tracked = true; return odin_check_launch("smallc_fwd_lds"); }
-        if (nk2 == 24 && rb == 2) { ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 2>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR); *tracked = true; return odin_check_launch("smallc_fwd_lds"); }
+        if (nk2 == 8 && rb == 1) {
+          if (d->act == ODIN_ACT_ELU) ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 1, true>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR);
+          else ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 1, false>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR);
+          *tracked = true;
+          return odin_check_launch("smallc_fwd_lds");
+        }
+        if (nk2 == 8 && rb == 2) {
+          if (d->act == ODIN_ACT_ELU) ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 2, true>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR);
+          else ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 2, false>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR);
+          *tracked = true;
+          return odin_check_launch("smallc_fwd_lds");
+        }
+        if (nk2 == 24 && rb == 1) {
+          if (d->act == ODIN_ACT_ELU) ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 1, true>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR);
+          else ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 1, false>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR);
+          *tracked = true;
+          return odin_check_launch("smallc_fwd_lds");
+        }
+        if (nk2 == 24 && rb == 2) {
+          if (d->act == ODIN_ACT_ELU) ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 2, true>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR);
+          else ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 2, false>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR);
+          *tracked = true;
+          return odin_check_launch("smallc_fwd_lds");
+        }
       }
     }
     // persistent waves (2 x 4-wave workgroups per CU-pair ... 4 blocks per wave at batch 256)
