@@ -618,6 +618,9 @@ def main():
   ap.add_argument('--no-blk', action='store_true',
                   help='A/B: the 4x4 / stride-2 layers that fit no row-window plane kernel on igemm_h.hip (round 5) instead '
                   'of the block-window kernels of blk_planes.hip (odin_debug_blk_planes(0); the audio VAE)')
+  ap.add_argument('--no-dense-hw', action='store_true',
+                  help='A/B: Dense weight gradients with both widths >= 256 on the 32 x 32 tiles straight from L2 (round 4) '
+                  'instead of the LDS-staged 64 x 64 tiles (dense_h.hip: dense_hw; FactorVAE, CelebA)')
   ap.add_argument('--force-dist', action='store_true',
                   help='initialise the RCCL process group even at world size 1, so that the '
                   'data-parallel step (graph A, RCCL all-reduce, graph B) runs on a 1-GPU box')
@@ -628,6 +631,9 @@ def main():
   if args.no_blk:
     from odin_ai_amd import _lib as _l
     _l.load().odin_debug_blk_planes(0)
+  if args.no_dense_hw:
+    from odin_ai_amd import _lib as _l
+    _l.load().odin_debug_dense_hw_min_tiles(1 << 30)
   for kv in args.engine_opt:
     k, _, v = kv.partition('=')
     try:

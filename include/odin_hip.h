@@ -346,6 +346,10 @@ double odin_debug_blk_min_flop(double flop);
 int odin_debug_blk_planes(int enable);
 /* diagnostics: 1 = the block-window kernels also take the layers the row-window plane kernels serve (A/B runs) */
 int odin_debug_blk_first(int on);
+/* tests / diagnostics: the number of 64 x 64 tiles from which a Dense weight gradient with both widths >= 256 runs on the
+ * LDS-staged kernel (dense_h.hip: dense_hw; default 128; tests: 1; a huge value switches it off for A/B runs); < 0 = only
+ * report.  Returns the previous value. */
+int odin_debug_dense_hw_min_tiles(int tiles);
 
 /* ---- fused Gaussian tail of the TRAINING step (blk_planes.hip): Conv2DTranspose(k4, s2, 32 -> 32, activation d->act) ->
  * Conv2D 1x1 linear with 2 maps (w1 [32, 2], b1 [2]: loc | raw scale) -> Independent(Normal(loc, raw | softplus1(raw)))

@@ -16,7 +16,7 @@
 //   wgrad   :  A = x  [B, K]  (i contiguous)   B = dy [B, N] (j contiguous)        C = dW [K, N]   B is a gradient
 // A gradient operand is scaled by the power of two of its range word on its way into the planes (odin_range_shift); the
 // data gradient keeps the range word of its output.  Reduction lengths are multiples of 8.
-#include "odin_device.h"
+#include "blk_common.h"
 #include "odin_internal.h"
 #include <cstdlib>
 
@@ -64,9 +64,8 @@ __device__ __forceinline__ void dh_split8(const float (&v)[8], float s, float s2
 // NW waves split the k-steps of one 32 x 32 tile (step s -> wave s % NW); SCA / SCB: that operand is a gradient
 // AS (weight gradient only): the activation operand A comes with its own range word and power of two
 template <int NW, bool A_KC, bool B_KC, bool SCA, bool SCB, bool AS = false>
-__device__ __forceinline__ void dense_h_body(const DHParams& p, int bx, int by, int wg) {
-  __shared__ float red[NW * 16 * 64];
-  __shared__ float cred[NW * 32 + 16];
+__device__ __forceinline__ void dense_h_body(const DHParams& p, int bx, int by, int wg, float* red, float* cred) {
+  // red: [NW * 16 * 64], cred: [NW * 32 + 16] floats of LDS (the kernel's)
   const int tid = threadIdx.x, lane = tid & 63;
 #ifdef ODIN_SIM
   const int wave = tid >> 6;
@@ -193,7 +192,10 @@ __device__ __forceinline__ void dense_h_body(const DHParams& p, int bx, int by, 
 
 template <int NW, bool A_KC, bool B_KC, bool SCA, bool SCB, bool AS = false>
 __global__ __launch_bounds__(NW * 64) void dense_h_kernel(DHParams p) {
-  dense_h_body<NW, A_KC, B_KC, SCA, SCB, AS>(p, (int)blockIdx.x, (int)blockIdx.y, (int)(blockIdx.x + gridDim.x * blockIdx.y));
+  __shared__ float red[NW * 16 * 64];
+  __shared__ float cred[NW * 32 + 16];
+  dense_h_body<NW, A_KC, B_KC, SCA, SCB, AS>(p, (int)blockIdx.x, (int)blockIdx.y, (int)(blockIdx.x + gridDim.x * blockIdx.y), red,
+                                             cred);
 }
 
 // A layer's data gradient and weight gradient in ONE launch (round 6): both read dy, neither reads the other's result;
@@ -204,15 +206,230 @@ __global__ __launch_bounds__(NW * 64) void dense_h_kernel(DHParams p) {
 template <int NWD, int NWW, bool AS>
 __global__ __launch_bounds__((NWD > NWW ? NWD : NWW) * 64) void dense_h_pair_kernel(DHParams pd, DHParams pw, int nd, int gdx,
                                                                                     int gwx) {
+  constexpr int NWM = NWD > NWW ? NWD : NWW;
+  __shared__ float red[NWM * 16 * 64];
+  __shared__ float cred[NWM * 32 + 16];
   const int id = (int)blockIdx.x;
   if (id < nd) {
     if (NWD < NWW && (int)threadIdx.x >= NWD * 64) return;
     const int by = id / gdx;
-    dense_h_body<NWD, true, true, true, false, false>(pd, id - by * gdx, by, id);
+    dense_h_body<NWD, true, true, true, false, false>(pd, id - by * gdx, by, id, red, cred);
   } else {
     if (NWW < NWD && (int)threadIdx.x >= NWW * 64) return;
     const int r = id - nd, by = r / gwx;
-    dense_h_body<NWW, false, false, false, true, AS>(pw, r - by * gwx, by, r);
+    dense_h_body<NWW, false, false, false, true, AS>(pw, r - by * gwx, by, r, red, cred);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dense_hw (round 6): the weight gradient dW[K, N] = x^T dy over 64 x 64 tiles, both operands staged ONCE through LDS.
+// The 32 x 32 tiles above give a 1000 x 1000 gradient over a 256-row batch to 1024 workgroups whose two waves each walk
+// 8 dependent (16 dword loads from L2 -> split -> 3 MFMA) steps with two steps in flight: 64 MB of L2 -> CU traffic
+// for 4 MB of operands, each 4-byte load instruction a wave of its own in the texture unit, 15 us of a 25 us
+// dense_h_pair launch (profiles/r06_step_timeline_factorvae_shapes3d_b256.txt).  Here a workgroup of eight waves
+// (2 x 2 blocks of 32 x 32, times the two halves of a chunk's k-steps) owns a 64 x 64 tile: the 64 batch rows of a chunk
+// arrive as 16-byte loads (two float4 per thread and operand), are scaled and split into the two f16 planes once, and
+// wait in LDS as [row k][column] planes
+// (128 bytes per row; the 32-byte column groups XOR-swizzled by (k >> 1) & 1 so that the four rows of a transposed read
+// land in four bank quarters).  The MFMA operands want 8 consecutive k per lane with the column as the lane index:
+// ds_read_b64_tr_b16 (blk_common.h: bk_tr) hands a lane column l of 4 rows, two of them make an operand.  Two chunks of
+// loads are in flight beside the one being multiplied; one barrier per chunk; the two k-halves meet in LDS at the end
+// (fixed order: bit reproducible).  LDS: 2 x 32 KB (the first half is the data-gradient role's reduction array in the
+// paired launch), <= 128 registers: two workgroups of either role per CU.
+constexpr int HW_ROWB = 128;           // a k-row of one plane: 64 f16
+constexpr int HW_PLB = 64 * HW_ROWB;   // one plane of a 64-row chunk
+constexpr int HW_BUF = 4 * HW_PLB;     // A high, A low, B high, B low: 32 KB
+__host__ __device__ constexpr int hw_swz(int k) { return 2 * ((k >> 1) & 1); }
+
+template <bool AS>
+__device__ __forceinline__ void dense_hw_body(const DHParams& p, int bx, int by, char* buf0, char* buf1, float* cred) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = bk_uniform(tid >> 6);
+  const int kh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5, l16 = lane & 15, cg = (lane >> 4) & 1;
+  const int i0 = by * 64, j0 = bx * 64;
+  const int n = (p.K + 63) >> 6;   // chunks of 64 batch rows
+  const OdinRun RA = odin_run(p.A, (unsigned)((size_t)p.K * p.lda * 4));
+  const OdinRun RB = odin_run(p.B, (unsigned)((size_t)p.K * p.ldb * 4));
+  // staging items: rows r0 + 32 q (q = 0, 1) of the chunk, columns 4 c4 .. 4 c4 + 3 (widths are multiples of 8)
+  const int r0 = tid >> 4, c4 = tid & 15;
+  const bool ca_ok = i0 + 4 * c4 < p.M, cb_ok = j0 + 4 * c4 < p.N;
+  const unsigned ga = (unsigned)((r0 * p.lda + i0 + 4 * c4) * 4), gb = (unsigned)((r0 * p.ldb + j0 + 4 * c4) * 4);
+  const int sdst = r0 * HW_ROWB + (((c4 >> 2) ^ hw_swz(r0)) << 5) + (c4 & 3) * 8;   // (+ 32 rows: the same swizzle)
+  float4 ra0[2], rb0[2], ra1[2], rb1[2];
+  auto issue = [&](int c, float4 (&va)[2], float4 (&vb)[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = 64 * c + 32 * q;
+      const bool ok = k + r0 < p.K;
+      va[q] = odin_run_load4(RA, (ok && ca_ok) ? ga + (unsigned)(k * p.lda * 4) : ODIN_OOB);
+      vb[q] = odin_run_load4(RB, (ok && cb_ok) ? gb + (unsigned)(k * p.ldb * 4) : ODIN_OOB);
+    }
+  };
+  issue(0, ra0, rb0);
+  if (n > 1) issue(1, ra1, rb1);
+  // the range words behind the first operand loads (dense_h_body): dy always scaled, x only outside the f16 window
+  const OdinRangeReq g_rq = odin_range_issue(p.g_amax, lane);
+  const OdinRangeReq a_rq = odin_range_issue(AS ? p.a_amax : nullptr, lane);
+  const int gk = odin_range_shift(odin_range_finish(g_rq));
+  const float g_s = odin_pow2(gk), g_s2k = odin_pow2(gk + 11);
+  int ak = 0;
+  bool a_on = false;
+  if (AS) {
+    const unsigned mb = odin_range_finish(a_rq);
+    a_on = odin_act_needs_scale(mb);
+    ak = a_on ? odin_range_shift(mb) : 0;
+  }
+  const float a_s = odin_pow2(ak), a_s2k = odin_pow2(ak + 11);
+  const bool want_cs = p.colsum != nullptr && by == 0;
+  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto stage = [&](char* buf, const float4 (&va)[2], const float4 (&vb)[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      char* d = buf + sdst + q * 32 * HW_ROWB;
+      u32x2 h, l;
+      if (AS && a_on) odin_split_h4<true>(va[q], a_s, a_s2k, h, l);
+      else odin_split_h4<false>(va[q], 1.f, ODIN_LO_SCALE, h, l);
+      *reinterpret_cast<u32x2*>(d) = h;
+      *reinterpret_cast<u32x2*>(d + HW_PLB) = l;
+      odin_split_h4<true>(vb[q], g_s, g_s2k, h, l);
+      *reinterpret_cast<u32x2*>(d + 2 * HW_PLB) = h;
+      *reinterpret_cast<u32x2*>(d + 3 * HW_PLB) = l;
+      if (want_cs) { bs.x += vb[q].x; bs.y += vb[q].y; bs.z += vb[q].z; bs.w += vb[q].w; }
+    }
+  };
+  // transposed reads: lane 4 q + t of a 16-lane group addresses row q, column quad t of the group's 16 columns
+  const int tq = l16 >> 2, tp = l16 & 3;
+  int aoff[2], boff[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int k = 8 * half + 4 * m + tq;   // (+ 16 per k-step: the same swizzle)
+    aoff[m] = k * HW_ROWB + (((2 * wi + cg) ^ hw_swz(k)) << 5) + tp * 8;
+    boff[m] = 2 * HW_PLB + k * HW_ROWB + (((2 * wj + cg) ^ hw_swz(k)) << 5) + tp * 8;
+  }
+  f32x16 acc = f32x16_zero(), acx = f32x16_zero();
+  auto compute = [&](const char* buf) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int s = 2 * t + kh;   // this wave's k-steps of the chunk
+      u32x4 a[2], b[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const char* base = buf + pl * HW_PLB + s * 16 * HW_ROWB;
+#ifdef ODIN_SIM
+        unsigned short ea[8], eb[8];
+        for (int j = 0; j < 8; ++j) {
+          const int k = 8 * half + j, ca = wi * 32 + l31, cb = wj * 32 + l31;
+          ea[j] = *reinterpret_cast<const unsigned short*>(base + k * HW_ROWB + (((ca >> 4) ^ hw_swz(k)) << 5) + (ca & 15) * 2);
+          eb[j] = *reinterpret_cast<const unsigned short*>(base + 2 * HW_PLB + k * HW_ROWB + (((cb >> 4) ^ hw_swz(k)) << 5) +
+                                                           (cb & 15) * 2);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[pl][e] = (unsigned)ea[2 * e] | ((unsigned)ea[2 * e + 1] << 16);
+          b[pl][e] = (unsigned)eb[2 * e] | ((unsigned)eb[2 * e + 1] << 16);
+        }
+        (void)aoff; (void)boff; (void)tp;
+#else
+        const u32x2 al = bk_tr(base + aoff[0], nullptr, 0, 0), ah = bk_tr(base + aoff[1], nullptr, 0, 0);
+        const u32x2 bl = bk_tr(base + boff[0], nullptr, 0, 0), bh = bk_tr(base + boff[1], nullptr, 0, 0);
+        a[pl][0] = al[0]; a[pl][1] = al[1]; a[pl][2] = ah[0]; a[pl][3] = ah[1];
+        b[pl][0] = bl[0]; b[pl][1] = bl[1]; b[pl][2] = bh[0]; b[pl][3] = bh[1];
+#endif
+      }
+      acx = mfma32_f16(a[0], b[1], acx);
+      acc = mfma32_f16(a[0], b[0], acc);
+      acx = mfma32_f16(a[1], b[0], acx);
+    }
+  };
+  stage(buf0, ra0, rb0);
+  if (n > 2) issue(2, ra0, rb0);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < n; c += 2) {
+    compute(buf0);
+    ODIN_SCHED_FENCE();
+    if (c + 1 < n) {
+      stage(buf1, ra1, rb1);
+      if (c + 3 < n) issue(c + 3, ra1, rb1);
+    }
+    __syncthreads();
+    if (c + 1 >= n) break;
+    compute(buf1);
+    ODIN_SCHED_FENCE();
+    if (c + 2 < n) {
+      stage(buf0, ra0, rb0);
+      if (c + 4 < n) issue(c + 4, ra0, rb0);
+    }
+    __syncthreads();
+  }
+  // ---- this wave pair's 32 x 32 block of the slab row (main + 2^-11 cross, the two scales one after the other): the
+  // second k-half through LDS (every wave is behind its last read of the chunk buffers) ----
+  const float o_s = odin_pow2(-gk), o_sx = odin_pow2(-gk - 11), o_a = odin_pow2(-ak);
+  float* redl = reinterpret_cast<float*>(buf0) + (wave & 3) * 16 * 64 + lane;
+  if (kh == 1) {
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const float t = fmaf(acx[rr], o_sx, acc[rr] * o_s);
+      redl[rr * 64] = AS ? t * o_a : t;
+    }
+  }
+  __syncthreads();
+  if (kh == 0) {
+    const OdinRun RC = odin_run(p.C, (unsigned)((size_t)p.M * p.ldc * 4));
+    const int jc = j0 + wj * 32 + l31;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const float t = fmaf(acx[rr], o_sx, acc[rr] * o_s);
+      const int row = i0 + wi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+      odin_run_store1(RC, (row < p.M && jc < p.N) ? (unsigned)((row * p.ldc + jc) * 4) : ODIN_OOB,
+                      (AS ? t * o_a : t) + redl[rr * 64]);
+    }
+  }
+  if (want_cs) {
+    // db[j] = column sums of dy (raw fp32 values): the 4 row groups of a wave by lane swaps, the 8 waves through LDS
+    float sv[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sv[e] += __shfl_xor(sv[e], 16);
+      sv[e] += __shfl_xor(sv[e], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cred[wave * 64 + 4 * lane + e] = sv[e];
+    }
+    __syncthreads();
+    if (tid < 64 && j0 + tid < p.N) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += cred[w * 64 + tid];
+      p.colsum[j0 + tid] = t;
+    }
+  }
+}
+
+template <bool AS>
+__global__ __launch_bounds__(512, 4) void dense_hw_kernel(DHParams p) {
+  __shared__ __attribute__((aligned(16))) float buf0[HW_BUF / 4];
+  __shared__ float cred[512];
+  ODIN_DYN_SMEM(char, buf1);
+  dense_hw_body<AS>(p, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<char*>(buf0), buf1, cred);
+}
+
+// the paired launch with the weight gradient on dense_hw: workgroups [0, nd) = data gradient (8 waves per 32 x 32 tile),
+// the rest = 64 x 64 tiles of the weight gradient (8 waves)
+template <bool AS>
+__global__ __launch_bounds__(512, 4) void dense_h_pair64_kernel(DHParams pd, DHParams pw, int nd, int gdx, int gwx) {
+  __shared__ __attribute__((aligned(16))) float red[8 * 16 * 64];   // 32 KB = HW_BUF
+  __shared__ float cred[512];
+  ODIN_DYN_SMEM(char, buf1);
+  const int id = (int)blockIdx.x;
+  if (id < nd) {
+    const int by = id / gdx;
+    dense_h_body<8, true, true, true, false, false>(pd, id - by * gdx, by, id, red, cred);
+  } else {
+    const int r = id - nd, by = r / gwx;
+    dense_hw_body<AS>(pw, r - by * gwx, by, reinterpret_cast<char*>(red), buf1, cred);
   }
 }
 
@@ -237,7 +454,37 @@ int dh_waves(int M, int N, int K, int kind = 0) {
   return nw;
 }
 
+// dense_hw instead of the 32 x 32 tiles for a weight gradient [M, N]: enough 64 x 64 tiles to put one on (about) every
+// second CU -- below that the small tiles' parallelism wins
+int g_hw_min_tiles = 128;
+bool dh_hw_ok(int M, int N) { return (long)((M + 63) / 64) * ((N + 63) / 64) >= g_hw_min_tiles; }
+void dh_hw_attr() {
+#ifndef ODIN_SIM
+  static bool done = false;
+  if (done) return;
+  const void* ks[4] = {reinterpret_cast<const void*>(&dense_hw_kernel<true>), reinterpret_cast<const void*>(&dense_hw_kernel<false>),
+                       reinterpret_cast<const void*>(&dense_h_pair64_kernel<true>),
+                       reinterpret_cast<const void*>(&dense_h_pair64_kernel<false>)};
+  for (const void* k : ks)
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, HW_BUF) != hipSuccess) (void)hipGetLastError();
+  done = true;
+#endif
+}
+int dh_hw_launch(const DHParams& p, void* stream) {
+  dh_hw_attr();
+  dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, 1);
+  if (p.a_amax != nullptr) ODIN_LAUNCH((dense_hw_kernel<true>), grid, dim3(512), (size_t)HW_BUF, stream, p);
+  else ODIN_LAUNCH((dense_hw_kernel<false>), grid, dim3(512), (size_t)HW_BUF, stream, p);
+  return odin_check_launch("dense_hw(f16x2)");
+}
+
 }  // namespace
+
+extern "C" int odin_debug_dense_hw_min_tiles(int tiles) {
+  const int old = g_hw_min_tiles;
+  if (tiles >= 0) g_hw_min_tiles = tiles;
+  return old;
+}
 
 // both layer widths >= 256, every reduction length (K, N, B) a multiple of 8
 bool odin_dense_h_ok(int B, int K, int N) {
@@ -303,6 +550,15 @@ int odin_dense_h_bwd_pair(const float* x, const float* dy, const float* w, const
   dh_fill_wgrad(pw, x, dy, slab, B, K, N, g, x_amax);
   const int nwd = dh_waves(B, K, N, 1), nww = dh_waves(K, N, B, 2);
 #ifndef ODIN_SIM  // (the simulator's barrier counts every thread of the block: the roles keep their own launches there)
+  if (nwd == 8 && dh_hw_ok(K, N)) {
+    dh_hw_attr();
+    const int gdx = (K + 31) / 32, gdy = (B + 31) / 32, gwx = (N + 63) / 64, gwy = (K + 63) / 64;
+    const int nd = gdx * gdy;
+    const dim3 grid((unsigned)(nd + gwx * gwy));
+    if (x_amax != nullptr) ODIN_LAUNCH((dense_h_pair64_kernel<true>), grid, dim3(512), (size_t)HW_BUF, stream, pd, pw, nd, gdx, gwx);
+    else ODIN_LAUNCH((dense_h_pair64_kernel<false>), grid, dim3(512), (size_t)HW_BUF, stream, pd, pw, nd, gdx, gwx);
+    return odin_check_launch("dense_h_pair64(f16x2)");
+  }
   if ((nwd == 8 || nwd == 4) && (nww == 2 || nww == 4 || nww == 1)) {
     const int gdx = (K + 31) / 32, gdy = (B + 31) / 32, gwx = (N + 31) / 32, gwy = (K + 31) / 32;
     const int nd = gdx * gdy, nw = gwx * gwy;
@@ -322,8 +578,9 @@ int odin_dense_h_bwd_pair(const float* x, const float* dy, const float* w, const
 #undef DH_PAIR
   }
 #endif
-  int rc = x_amax != nullptr ? dh_launch<false, false, false, true, true>(pw, nww, stream)
-                             : dh_launch<false, false, false, true>(pw, nww, stream);
+  int rc = dh_hw_ok(K, N)      ? dh_hw_launch(pw, stream)
+           : x_amax != nullptr ? dh_launch<false, false, false, true, true>(pw, nww, stream)
+                               : dh_launch<false, false, false, true>(pw, nww, stream);
   if (rc == 0) rc = dh_launch<true, true, true, false>(pd, nwd, stream);
   return rc;
 }
@@ -337,6 +594,10 @@ int odin_dense_h_wgrad(const float* x, const float* dy, float* slab, int B, int 
   p.M = K; p.N = N; p.K = B; p.lda = K; p.ldb = N; p.ldc = N;
   p.g_amax = odin_range_word_of(dy, (size_t)B * N, dy_amax, stream);
   if (p.g_amax == nullptr) return odin_fail(-3, "dense_h wgrad: no range word for dy");
+  if (dh_hw_ok(K, N)) {
+    p.a_amax = x_amax;
+    return dh_hw_launch(p, stream);
+  }
   if (x_amax != nullptr) {
     p.a_amax = x_amax;
     return dh_launch<false, false, false, true, true>(p, dh_waves(K, N, B, 2), stream);

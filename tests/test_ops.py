@@ -257,6 +257,54 @@ def test_dense(bk, B, K, N, act):
   close(g[-N:], db_ref, 1e-4)
 
 
+@pytest.mark.parametrize('B,K,N,scale,ranged', [
+    # one short chunk; two chunks, the second short; three (the third prefetched behind the first); five and six (the
+    # loop's own prefetches, odd and even counts); ragged widths (264 = 4 tiles + 8 columns, 296 = 4 tiles + 40)
+    (40, 264, 296, 1.0, False), (72, 264, 296, 1.0, True), (136, 296, 264, 1.0, False), (264, 256, 320, 1.0, True),
+    (328, 264, 264, 1.0, False),
+    # activations outside the f16 window with and without their range word (without: |x| <= 65504 is the contract)
+    (72, 256, 264, 3e4, True), (72, 256, 264, 1e-6, True), (64, 264, 256, 2e3, False)])
+def test_dense_weight_gradient_lds_staged(bk, request, B, K, N, scale, ranged):
+  """dense_hw (dense_h.hip): the weight gradient of a Dense layer with both widths >= 256 over 64 x 64 tiles with the
+  operands staged through LDS -- alone and as the second role of the paired launch (odin_dense_bwd), against the
+  oracle (odin/networks/base_networks.py:1002-1014 under tf.GradientTape: dW = x^T dy, db = column sums of dy)."""
+  L, T = bk.L, bk.T
+  request.addfinalizer(lambda old=L.odin_debug_dense_hw_min_tiles(1): L.odin_debug_dense_hw_min_tiles(old))
+  rng = np.random.default_rng(B + K)
+  x = rng.standard_normal((B, K)) * scale
+  w = rng.standard_normal((K, N)) / np.sqrt(K)
+  dy = rng.standard_normal((B, N)) * 1e-3
+  aux = rng.standard_normal((B, K))
+  tx, tw, tdy, taux = T(x), T(w), T(dy), T(aux)
+  xf, dyf = x.astype(np.float32).astype(np.float64), dy.astype(np.float32).astype(np.float64)
+  dx_ref, dw_ref, db_ref = vo.dense_bwd(xf, w.astype(np.float32).astype(np.float64), dyf)
+  xw = bk.zeros(2048, dtype=torch.int32)
+  L.odin_absmax(tx.data_ptr(), tx.numel(), xw.data_ptr(), None)
+  n = K * N + N
+
+  def rel(a, b):
+    return np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max()
+
+  rows = C.c_int(0)
+  slab = bk.full((L.odin_max_slab_rows(), n), float('nan'))
+  L.odin_dense_bwd_ranged(tx.data_ptr(), tdy.data_ptr(), None, None, 0, None, None, None, slab.data_ptr(), C.byref(rows),
+                          B, K, N, 1, 0, None, None, xw.data_ptr() if ranged else None, None)
+  assert 'dense_hw' in L.odin_debug_last_path().decode()
+  assert rows.value == 1
+  g = slab[0].cpu().numpy()
+  assert rel(g[:K * N].reshape(K, N), dw_ref) <= 2e-6
+  assert rel(g[K * N:], db_ref) <= 2e-6
+  # both halves in one call: the same tiles, bit for bit
+  rows2 = C.c_int(0)
+  slab2 = bk.full((L.odin_max_slab_rows(), n), float('nan'))
+  dx = bk.full((B, K), float('nan'))
+  L.odin_dense_bwd_ranged(tx.data_ptr(), tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), _lib.ACT['relu'], dx.data_ptr(), None,
+                          None, slab2.data_ptr(), C.byref(rows2), B, K, N, 1, 1, None, None, xw.data_ptr() if ranged else None,
+                          None)
+  assert torch.equal(slab2[0], slab[0])
+  assert rel(dx.cpu().numpy(), dx_ref * (aux.astype(np.float32) > 0)) <= 2e-6
+
+
 @pytest.mark.parametrize('kind,shape', [
     ('conv', (5, 8, 8, 64, 64, 4, 2)), ('conv', (16, 8, 8, 32, 64, 4, 2)), ('deconv', (6, 4, 4, 8, 64, 4, 2)),
     ('deconv', (257, 4, 4, 16, 64, 4, 2)), ('dense', (100, 256, 40)), ('dense', (64, 1024, 128)), ('conv', (3, 16, 16, 32, 32, 4, 2)),

@@ -1,0 +1,16 @@
+#!/bin/bash
+# dense_hw: parity on the GPU, stand-alone times, FactorVAE / CelebA / MNIST dense step A/B in one call
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_ops.py -q -m gpu -k "dense or layer_bwd or ranged" 2>&1 | tail -3 > gpurun_out/r06_dhw_tests.txt
+python tools/densebench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_dhw_bench.txt
+ab() { python bench.py --no-cpu-baseline --no-exact-fp32 --no-fit --no-north-star-3ch "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"; }
+{
+  for w in factorvae_shapes3d_b256 celeba_betatcvae_b512 mnist_dense_b128; do
+    for i in 1 2 3; do
+      echo "$w dense_hw      $(ab --workload $w)"
+      echo "$w --no-dense-hw $(ab --workload $w --no-dense-hw)"
+    done
+  done
+} > gpurun_out/r06_dhw_ab.txt 2>&1
+cat gpurun_out/r06_dhw_tests.txt gpurun_out/r06_dhw_bench.txt gpurun_out/r06_dhw_ab.txt
