@@ -618,6 +618,9 @@ def main():
   ap.add_argument('--no-blk', action='store_true',
                   help='A/B: the 4x4 / stride-2 layers that fit no row-window plane kernel on igemm_h.hip (round 5) instead '
                   'of the block-window kernels of blk_planes.hip (odin_debug_blk_planes(0); the audio VAE)')
+  ap.add_argument('--no-fused-disc', action='store_true',
+                  help="A/B (FactorVAE): the discriminator head's forward, loss, weight and data gradient and permute_dims as "
+                  'launches of their own (round 5) instead of odin_disc_head_fwd_bwd / odin_random_permute_dims')
   ap.add_argument('--no-dense-hw', action='store_true',
                   help='A/B: Dense weight gradients with both widths >= 256 on the 32 x 32 tiles straight from L2 (round 4) '
                   'instead of the LDS-staged 64 x 64 tiles (dense_h.hip: dense_hw; FactorVAE, CelebA)')
@@ -692,6 +695,7 @@ def main():
     fv.force_dp = use_dist
     fv.engine_options = dict(eopts)
     fv.overlap_disc = bool(args.overlap_disc)
+    fv.fuse_discriminator = not args.no_fused_disc
     eng = fv._engine(B // 2)
     fv._discriminator(B // 2)
     beta = 1.0

@@ -270,7 +270,7 @@ typedef struct odin_neck_args {
   const float *w0, *b0;            /* Dense (D,16*C0), [16*C0] */
   float* y0;                       /* [B,16*C0] = [B,4,4,C0] */
   const float *w1, *b1;            /* Conv2DTranspose (4,4,64,C0), [64] */
-  float* y1;                       /* [B,8,8,64] */
+  float* y1;                       /* [B,8,8,64]; NULL: the launch stops behind the latent block (p, z, kl, fbmask: the encoder's half) */
   uint32_t* y1_amax;               /* activation range word of y1 (written) or NULL */
   /* ---- backward (forward tensors above are read) ---- */
   const float* dy1;                /* [B,8,8,64] dL/d(pre-activation of deconv1) */
@@ -295,6 +295,23 @@ int odin_wgrad_pair_end(void);
 int odin_neck_rows(int B, int P, int D, int C0);
 int odin_neck_fwd(const odin_neck_args* a, void* stream);
 int odin_neck_bwd(const odin_neck_args* a, void* stream);
+
+/* ---- the discriminator's head with its loss in ONE launch (round 6; thin_dense.hip): Dense(K -> 1) on h [B, K]
+ * (factor_discriminator.py:60-95: the last layer of FactorDiscriminator), the mean it feeds, and the layer's backward:
+ *   logit[b] = h[b, :] . w + bias
+ *   mode 0 (total_correlation, factor_discriminator.py:169-198): out[0] = mean_b logit[b]; dlogit[b] = dlogit_in[b]
+ *   mode 1 (dtc_loss, :200-235; rows [0, B/2) = D(z), [B/2, B) = D(permute_dims(z'))):
+ *          out[0] = 0.5 (mean softplus(-logit_z) + mean softplus(logit_perm)); dlogit its gradient (-> dlogit_out, optional)
+ *   dh[b, k] = dlogit[b] w[k] act'(h[b, k]) with aux_act the activation that produced h (dh == NULL: forward + loss only);
+ *   max |dh| is folded into dh_amax (optional); wslab (optional, with dh): odin_disc_head_rows(B, K) rows of [K + 1]:
+ *   partial (dW | db), to be summed by odin_slab_reduce.
+ * workspace: 16 bytes, 8-byte aligned, zero before the FIRST launch (every launch leaves it zero): the workgroups' loss
+ * sums meet there as 64-bit fixed-point numbers (integer addition: independent of the order of arrival, bit reproducible).
+ * Replaces odin_dense_fwd + odin_mean / odin_dtc_loss_fwd_bwd + odin_dense_bwd of that layer: same values to fp32 rounding. */
+int odin_disc_head_rows(int B, int K);
+int odin_disc_head_fwd_bwd(const float* h, const float* w, const float* bias, float* logit, int mode,
+                           const float* dlogit_in, float* dlogit_out, float* out, int aux_act, float* dh,
+                           uint32_t* dh_amax, float* wslab, int* rows_out, void* workspace, int B, int K, void* stream);
 
 /* ---- observation log-likelihood fused forward+backward
  * Independent(Bernoulli(logits),3).log_prob(x) (image_networks.py:87-93;
@@ -412,6 +429,9 @@ int odin_permute_dims(const float* z, const int32_t* perm, float* out, int B, in
 /* per-column random permutations generated on device (Philox), perm int32 [B,D] */
 int odin_random_perm(int32_t* perm, int B, int D, uint64_t seed, const int32_t* step_dev,
                      void* stream);
+/* odin_random_perm followed by odin_permute_dims(z, perm, out) as ONE launch (all rows of z local: one GPU). */
+int odin_random_permute_dims(int32_t* perm, const float* z, float* out, int B, int D, uint64_t seed,
+                             const int32_t* step_dev, void* stream);
 /* dtc_loss (odin/bay/vi/autoencoder/factor_discriminator.py:200-235):
  * out[0] = 0.5*(mean softplus(-lz) + mean softplus(lperm)); grads wrt both logit vectors */
 int odin_dtc_loss_fwd_bwd(const float* logit_z, const float* logit_perm, float* out,
@@ -488,7 +508,7 @@ int odin_sumsq_adam_ring(float* theta, const float* g, float* m, float* v, size_
  * part == NULL: dry run, only *n_parts_out (static for a given job list: capture-safe).
  * odin_adam_ring_parts: norm from those partials, clip scale, NaN guard, Adam, the ring advance of
  * odin_sumsq_adam_ring and (llk_part != NULL) the ELBO finalisation, in ONE launch; `staged` = the staged row,
- * alpha_off / elbo_off = offsets of Adam's five scalars / of the ELBO weights in it.  Together they replace
+ * alpha_off / elbo_off = offsets of Adam's five scalars / of the ELBO weights in it (ring == NULL: no advance).  Together they replace
  * odin_slab_reduce + odin_sumsq_adam_ring (three launches -> two; base_networks.py:584-596). */
 int odin_slab_reduce_sumsq(const odin_reduce_job* jobs, int n_jobs, const float* g, size_t g_n, float* part,
                            int* n_parts_out, const float* stage_src, float* stage_dst, int stage_n, void* stream);

@@ -103,6 +103,8 @@ SIGNATURES = {
     'odin_gaussian_tail_applicable': [DP, I],
     'odin_gaussian_tail_fwd_bwd': [P, P, P, P, P, P, P, P, P, IP, P, IP, P, DP, I, I, P],
     'odin_gaussian_head_fwd_bwd': [P, P, P, P, P, P, P, P, IP, P, IP, P, P, I, I, I, I, I, I, P, P],
+    'odin_disc_head_rows': [I, I],
+    'odin_disc_head_fwd_bwd': [P, P, P, P, I, P, P, P, I, P, P, P, IP, P, I, I, P],
     'odin_debug_igemm_h_min_flop': [C.c_double],
     'odin_debug_blk_min_flop': [C.c_double],
     'odin_debug_blk_planes': [C.c_int],
@@ -118,6 +120,7 @@ SIGNATURES = {
     'odin_total_correlation_shard': [P, P, P, P, P, P, P, I, I, I, P],
     'odin_permute_dims': [P, P, P, I, I, P],
     'odin_random_perm': [P, I, I, C.c_uint64, P, P],
+    'odin_random_permute_dims': [P, P, P, I, I, C.c_uint64, P, P],
     'odin_dtc_loss_fwd_bwd': [P, P, P, P, P, I, P],
     'odin_adam_step_flat': [P, P, P, P, C.c_size_t, P, P, F, P, P],
     'odin_sumsq_flat': [P, C.c_size_t, P, P, P],
@@ -155,7 +158,7 @@ VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_conv2d_dgrad_keeps
                    'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_dense_dgrad_keeps_range', 'odin_conv2d_reads_x_range',
                    'odin_deconv2d_reads_x_range', 'odin_dense_reads_x_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
                    'odin_latent_block_rows', 'odin_neck_rows', 'odin_debug_igemm_h_ldsw_steps', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop', 'odin_debug_blk_min_flop',
-                   'odin_debug_blk_planes', 'odin_debug_blk_first', 'odin_debug_dense_hw_min_tiles', 'odin_gaussian_tail_applicable')
+                   'odin_debug_blk_planes', 'odin_debug_blk_first', 'odin_debug_dense_hw_min_tiles', 'odin_gaussian_tail_applicable', 'odin_disc_head_rows')
 # entry points declared `void` in include/odin_hip.h
 VOID_RETURNING = ('odin_wgrad_planes_defer_begin', 'odin_wgrad_pair_begin')
 

@@ -405,6 +405,8 @@ __global__ __launch_bounds__(NK_NT) void neck_fwd_kernel(NeckFwd q) {
       a.kl[b0 + tid] = acc;
       a.fbmask[b0 + tid] = m;
     }
+    // (y1 == NULL: the encoder's half only -- FactorVAE's second pass wants z alone)
+    if (a.y1 == nullptr) return;
     // y0[s][n] = act0(sum_d z[s][d] w0[d][n] + b0[n]) = the decoder's first image [4, 4, C0]
     for (int o2 = tid; o2 < NK_S * N0; o2 += NK_NT) {
       const int s = o2 / N0, n = o2 - s * N0;

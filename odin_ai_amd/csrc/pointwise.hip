@@ -1413,8 +1413,9 @@ extern "C" int odin_adam_ring_parts(float* theta, const float* g, float* m, floa
                                     float clip, int32_t* flag, const float* llk_part, int n_part, const float* kl,
                                     const float* tc, float* llk, float* out4, int B, const float* ring, float* cur,
                                     int rows, int row_floats, int t_word, void* stream) {
+  // (ring == NULL: no ring to advance -- a caller that writes `hyper` from the host every step, FactorVAE's iteration)
   HyperRing hr;
-  if (ring == nullptr || staged == nullptr || parts == nullptr || n_parts < 1 ||
+  if (staged == nullptr || parts == nullptr || n_parts < 1 ||
       !hyper_ring_args(ring, cur, const_cast<float*>(staged), rows, row_floats, t_word, hr))
     return odin_fail(-2, "odin_adam_ring_parts: bad arguments");
   FinArgs f;

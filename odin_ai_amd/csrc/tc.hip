@@ -204,8 +204,9 @@ __device__ __forceinline__ unsigned hash3(unsigned a, unsigned b, unsigned c) {
 }
 
 // one workgroup per latent column: random keys -> rank -> permutation (B <= 4096)
+// (z != null: out[rank][l] = z[i][l] in the same pass -- permute_dims without a launch of its own)
 __global__ __launch_bounds__(256) void random_perm_kernel(int* perm, int B, int D, unsigned k0,
-                                                          unsigned k1, const int* step_dev) {
+                                                          unsigned k1, const int* step_dev, const float* z, float* out) {
   ODIN_DYN_SMEM(unsigned, keys);
   const int l = blockIdx.x;
   const unsigned step = step_dev ? (unsigned)step_dev[0] : 0u;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void random_perm_kernel(int* perm, int B, int 
       rank += (kj < k || (kj == k && j < i)) ? 1 : 0;
     }
     perm[(size_t)rank * D + l] = i;
+    if (z != nullptr) out[(size_t)rank * D + l] = z[(size_t)i * D + l];
   }
 }
 
@@ -312,8 +314,18 @@ extern "C" int odin_random_perm(int32_t* perm, int B, int D, uint64_t seed,
                                 const int32_t* step_dev, void* stream) {
   if (B > 16384) return odin_fail(-2, "random_perm: B too large");
   ODIN_LAUNCH(random_perm_kernel, dim3(D), dim3(256), (size_t)B * 4, stream, (int*)perm, B, D,
-              (unsigned)seed, (unsigned)(seed >> 32), (const int*)step_dev);
+              (unsigned)seed, (unsigned)(seed >> 32), (const int*)step_dev, (const float*)nullptr, (float*)nullptr);
   return odin_check_launch("random_perm");
+}
+
+// odin_random_perm + odin_permute_dims(z, perm, out) in one launch (the rows of z are all local: one GPU)
+extern "C" int odin_random_permute_dims(int32_t* perm, const float* z, float* out, int B, int D, uint64_t seed,
+                                        const int32_t* step_dev, void* stream) {
+  if (B > 16384) return odin_fail(-2, "random_permute_dims: B too large");
+  if (z == nullptr || out == nullptr) return odin_fail(-2, "random_permute_dims: z / out");
+  ODIN_LAUNCH(random_perm_kernel, dim3(D), dim3(256), (size_t)B * 4, stream, (int*)perm, B, D,
+              (unsigned)seed, (unsigned)(seed >> 32), (const int*)step_dev, z, out);
+  return odin_check_launch("random_permute_dims");
 }
 
 extern "C" int odin_dtc_loss_fwd_bwd(const float* logit_z, const float* logit_perm, float* out,

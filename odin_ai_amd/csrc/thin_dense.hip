@@ -292,6 +292,144 @@ __global__ __launch_bounds__(256) void thinn_wgrad_kernel(TDParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The discriminator's HEAD with its loss in one launch (round 6).  FactorVAE's discriminator ends in Dense(1000 -> 1)
+// (factor_discriminator.py:60-95); around it the iteration ran thinn_fwd -> mean -> thinn_dgrad in the VAE step
+// (total_correlation, factor_discriminator.py:169-198) and thinn_fwd -> dtc_loss -> thinn_wgrad -> thinn_dgrad in the
+// discriminator step (dtc_loss, :200-235): seven launches of ~5 us each, every one a launch floor
+// (profiles/r06_step_timeline_factorvae_shapes3d_b256.txt).  Nothing in them couples rows except the two means:
+//   logit[b] = h[b, :] . w + bias
+//   mode 0   out = mean_b logit[b],  dlogit[b] = dlogit_in[b]  (the caller's constant tc_coef / B)
+//   mode 1   rows [0, n) are D(z), rows [n, 2 n) are D(z_perm):  out = (0.5 / n) sum softplus(-a_z) + softplus(a_perm),
+//            dlogit = -sigmoid(-a_z) 0.5 / n | sigmoid(a_perm) 0.5 / n
+//   dh[b, k] = dlogit[b] w[k] act'(h[b, k])         (+ max |dh| into its range word)
+//   slab row of this workgroup: dW[k] = sum over its rows of h[b, k] dlogit[b] | db = sum dlogit[b]
+// A workgroup owns 8 rows; a thread holds 4 k of each of them (all 8 loads in flight at once; K <= 2048).  The mean over
+// the workgroups: each adds its partial sum as a FIXED-POINT number (2^-30 units: integer addition commutes, so the result
+// does not depend on the order of arrival) together with a ticket to ONE 64-bit workspace word; the last arrival
+// converts, writes out[0] and clears the word for the next launch.  A device-scope atomic performed at the coherence
+// point -- no fence, no second launch.
+struct DHeadParams {
+  const float* h;
+  const float* w;
+  const float* bias;
+  float* logit;
+  const float* dlogit_in;
+  float* dlogit_out;
+  float* out;
+  float* dh;
+  unsigned* dh_amax;
+  float* slab;
+  unsigned long long* ws;   // [0]: fixed-point sum << 10 | tickets; zero between launches
+  int B, K, mode, aux_act;
+};
+
+__device__ __forceinline__ float td_softplus(float x) { return fmaxf(x, 0.f) + log1pf(odin_exp(-fabsf(x))); }
+__device__ __forceinline__ float td_sigmoid(float x) {
+  const float e = odin_exp(-fabsf(x)), s = 1.f / (1.f + e);
+  return x >= 0.f ? s : e * s;
+}
+
+template <int KV>   // float4 columns per thread: K <= 1024 KV
+__global__ __launch_bounds__(256) void disc_head_kernel(DHeadParams p) {
+  __shared__ float red[4 * 8];
+  __shared__ float dl[8], lsum[8];
+  __shared__ float ared[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * 8, K = p.K, k4n = K >> 2;
+  const int nb = p.B - b0 < 8 ? p.B - b0 : 8;
+  float4 wv[KV], hv[8][KV];
+#pragma unroll
+  for (int v = 0; v < KV; ++v) {
+    const int k4 = tid + 256 * v;
+    const bool ok = k4 < k4n;
+    wv[v] = ok ? reinterpret_cast<const float4*>(p.w)[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      hv[r][v] = (ok && r < nb) ? reinterpret_cast<const float4*>(p.h + (size_t)(b0 + r) * K)[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float a = 0.f;
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
+      a = fmaf(hv[r][v].x, wv[v].x, a); a = fmaf(hv[r][v].y, wv[v].y, a);
+      a = fmaf(hv[r][v].z, wv[v].z, a); a = fmaf(hv[r][v].w, wv[v].w, a);
+    }
+    a = odin_wave_sum64_valu(a);
+    if (lane == 0) red[wave * 8 + r] = a;
+  }
+  __syncthreads();
+  if (tid < 8) {
+    const int b = b0 + tid;
+    const bool valid = tid < nb;
+    const float a = ((red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid])) + (p.bias != nullptr ? p.bias[0] : 0.f);
+    float d = 0.f, ls = 0.f;
+    if (valid) {
+      p.logit[b] = a;
+      if (p.mode == 0) {
+        d = p.dlogit_in[b];
+        ls = a;
+      } else {
+        const int n = p.B >> 1;
+        const float inv = 0.5f / (float)n;
+        if (b < n) { ls = td_softplus(-a); d = -td_sigmoid(-a) * inv; }
+        else { ls = td_softplus(a); d = td_sigmoid(a) * inv; }
+        if (p.dlogit_out != nullptr) p.dlogit_out[b] = d;
+      }
+    }
+    dl[tid] = d;
+    lsum[tid] = ls;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float sacc = 0.f;
+    for (int r = 0; r < 8; ++r) sacc += lsum[r];
+    // one atomic per workgroup: the sum in 2^-30 units above a 10-bit ticket count (54 bits: |sum| < 2^23; at most 1023
+    // workgroups); the old value names the last arrival and, with its own share, the total
+    const long long fx = (long long)((double)sacc * 1073741824.0);
+    const unsigned long long mine = ((unsigned long long)fx << 10) + 1ull;
+    const unsigned long long old = atomicAdd(&p.ws[0], mine);
+    if ((old & 1023ull) == (unsigned long long)gridDim.x - 1ull) {
+      (void)atomicExch(&p.ws[0], 0ull);
+      const long long tot = (long long)(old + mine - (unsigned long long)gridDim.x) >> 10;
+      const double sum = (double)tot / 1073741824.0;
+      p.out[0] = p.mode == 0 ? (float)sum / (float)p.B : (float)sum * (0.5f / (float)(p.B >> 1));
+    }
+  }
+  float amx = 0.f;
+  if (p.dh != nullptr) {
+    float* row = p.slab != nullptr ? p.slab + (size_t)blockIdx.x * ((size_t)K + 1) : nullptr;
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
+      const int k4 = tid + 256 * v;
+      if (k4 < k4n) {
+        float4 sw = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          if (r < nb) {
+            const float d = dl[r];
+            const float4 x = hv[r][v];
+            float4 g;
+            g.x = d * wv[v].x * odin_act_grad(p.aux_act, x.x); g.y = d * wv[v].y * odin_act_grad(p.aux_act, x.y);
+            g.z = d * wv[v].z * odin_act_grad(p.aux_act, x.z); g.w = d * wv[v].w * odin_act_grad(p.aux_act, x.w);
+            reinterpret_cast<float4*>(p.dh + (size_t)(b0 + r) * K)[k4] = g;
+            amx = odin_amax3(odin_amax3(amx, g.x, g.y), g.z, g.w);
+            sw.x = fmaf(x.x, d, sw.x); sw.y = fmaf(x.y, d, sw.y); sw.z = fmaf(x.z, d, sw.z); sw.w = fmaf(x.w, d, sw.w);
+          }
+        }
+        if (row != nullptr) { row[4 * k4] = sw.x; row[4 * k4 + 1] = sw.y; row[4 * k4 + 2] = sw.z; row[4 * k4 + 3] = sw.w; }
+      }
+    }
+    if (row != nullptr && tid == 0) {
+      float sb = 0.f;
+      for (int r = 0; r < 8; ++r) sb += dl[r];
+      row[K] = sb;
+    }
+  }
+  odin_amax_commit_wg(p.dh_amax, amx, tid, 256, ared, blockIdx.x);
+}
+
 bool td_al16(const void* p) { return (((size_t)p) & 15) == 0; }
 
 void td_fill(TDParams& p, int B, int K, int N) {
@@ -377,4 +515,34 @@ int odin_thin_dense_wgrad(const float* x, const float* dy, float* slab, int B, i
     ODIN_LAUNCH(thinn_wgrad_kernel, grid, dim3(256), (size_t)p.chunk * N * 4, stream, p);
   }
   return odin_check_launch("thin_dense_wgrad");
+}
+
+// workgroups (= slab rows of the head's weight gradient) of odin_disc_head_fwd_bwd; 0: shapes outside its regime
+extern "C" int odin_disc_head_rows(int B, int K) {
+  if (B < 1 || K < 64 || (K & 3) != 0 || K > 2048) return 0;
+  const int rows = (B + 7) / 8;
+  return rows <= odin_max_slab_rows() ? rows : 0;
+}
+
+extern "C" int odin_disc_head_fwd_bwd(const float* h, const float* w, const float* bias, float* logit, int mode,
+                                      const float* dlogit_in, float* dlogit_out, float* out, int aux_act, float* dh,
+                                      uint32_t* dh_amax, float* wslab, int* rows_out, void* workspace, int B, int K,
+                                      void* stream) {
+  const int rows = odin_disc_head_rows(B, K);
+  if (rows_out) *rows_out = rows;
+  if (rows == 0 || rows > 1023) return odin_fail(-2, "disc_head: shapes outside the fused regime (K % 4 == 0, 64 <= K <= 2048)");
+  if (mode != 0 && mode != 1) return odin_fail(-2, "disc_head: mode");
+  if (mode == 1 && (B & 1)) return odin_fail(-2, "disc_head: dtc_loss wants an even number of rows ([z ; z_perm])");
+  if (mode == 0 && dlogit_in == nullptr) return odin_fail(-2, "disc_head: mode 0 reads dlogit_in");
+  if (!td_al16(h) || !td_al16(w) || (dh != nullptr && !td_al16(dh)) || (((size_t)workspace) & 7) != 0)
+    return odin_fail(-2, "disc_head: h / w / dh must be 16-byte aligned");
+  DHeadParams p;
+  memset(&p, 0, sizeof(p));
+  p.h = h; p.w = w; p.bias = bias; p.logit = logit; p.dlogit_in = dlogit_in; p.dlogit_out = dlogit_out; p.out = out;
+  p.dh = dh; p.dh_amax = dh != nullptr ? dh_amax : nullptr; p.slab = dh != nullptr ? wslab : nullptr;
+  p.ws = reinterpret_cast<unsigned long long*>(workspace);
+  p.B = B; p.K = K; p.mode = mode; p.aux_act = aux_act;
+  if (K <= 1024) ODIN_LAUNCH((disc_head_kernel<1>), dim3(rows), dim3(256), 0, stream, p);
+  else ODIN_LAUNCH((disc_head_kernel<2>), dim3(rows), dim3(256), 0, stream, p);
+  return odin_check_launch("disc_head");
 }

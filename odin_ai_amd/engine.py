@@ -843,9 +843,11 @@ class VAEEngine:
     self.nk_slab0 = torch.empty(rows, self.D * 16 * C0 + 16 * C0, **f32)
     self.nk_slabl = torch.empty(rows, d4.N * 2 * self.D + 2 * self.D, **f32)
 
-  def _neck_fwd(self, eps, st, y1_word: bool = True):
-    """one launch: conv3 .. deconv1 (the caller has run the encoder up to the layer below conv3)"""
+  def _neck_fwd(self, eps, st, y1_word: bool = True, enc_only: bool = False):
+    """one launch: conv3 .. deconv1 (the caller has run the encoder up to the layer below conv3); `enc_only`: the launch
+    stops behind the latent block (run_encoder: the decoder's first two layers are not wanted)"""
     A = self._nk
+    A.y1 = None if enc_only else self.dec.outs[1].data_ptr()
     A.analytic, A.free_bits = int(self.analytic), float(self.free_bits)
     A.step_dev = self.hp(N_HYPER)
     A.eps_in = None if eps is None else self.eps.data_ptr()
@@ -1059,7 +1061,7 @@ class VAEEngine:
       if eps is not None and eps is not self.eps:
         self.eps.copy_(eps)
       self.enc.forward(x, st, upto=len(self.enc_recs) - 2)
-      self._neck_fwd(eps, st, y1_word=False)
+      self._neck_fwd(eps, st, y1_word=False, enc_only=True)
       return self.p, self.z
     if self.lat_block:
       # noise + projection + reparameterisation + KL as ONE launch (latent_block.hip; the decoder's first Dense it
@@ -1531,8 +1533,9 @@ class VAEEngine:
     lib = self.lib
     st = self.stream() if st is None else st
     fin, self._fin_pending = getattr(self, '_fin_pending', None), None
-    if ring and getattr(self, '_norm_parts', 0) > 0:
+    if getattr(self, '_norm_parts', 0) > 0:
       # the norm's partials and the staged hyper-parameter row were left by this step's slab reduction: ONE launch
+      # (`ring` False: the caller writes `hyper` itself every step -- FactorVAE's iteration -- nothing to advance)
       assert clipvalue is None and (global_clipnorm is not None or check_nan)
       lib.odin_adam_ring_parts(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                self.params.numel(), self.hyper_staged.data_ptr(), H_ALPHA, H_BETA, self.ws.data_ptr(),
@@ -1540,8 +1543,8 @@ class VAEEngine:
                                self.flag.data_ptr() if check_nan else None,
                                fin[0] if fin is not None else None, fin[1] if fin is not None else 0,
                                self.kl.data_ptr(), fin[2] if fin is not None else None, self.llk.data_ptr(),
-                               self.out4.data_ptr(), self.B, self.hyper_ring.data_ptr(), self.hyper.data_ptr(),
-                               self.ring_rows, N_HYPER + 4, N_HYPER, st)
+                               self.out4.data_ptr(), self.B, self.hyper_ring.data_ptr() if ring else None,
+                               self.hyper.data_ptr(), self.ring_rows, N_HYPER + 4, N_HYPER, st)
       self._norm_parts = 0
       return
     if ring:

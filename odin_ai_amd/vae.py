@@ -1074,6 +1074,16 @@ class DiscPrograms:
     self.dlogit2 = torch.zeros(2 * B1, 1, **f32)
     self.dtc = torch.zeros(1, **f32)
     self._keep = None
+    # the head Dense(K -> 1) with the mean it feeds and its backward as ONE launch per pass (include/odin_hip.h:
+    # odin_disc_head_fwd_bwd) instead of forward | mean or dtc_loss | weight gradient | data gradient
+    self.fused_head = False
+    if len(disc.recs) >= 2 and disc.recs[-1].N == 1 and disc.recs[-1].act == 'linear':
+      K = disc.recs[-1].K
+      rows = int(lib.odin_disc_head_rows(2 * B1, K))
+      if rows > 0 and int(lib.odin_disc_head_rows(B1, K)) > 0:
+        self.fused_head = True   # (FactorVAE.fuse_discriminator = False before the first step: the separate launches)
+        self.head_slab = torch.empty(rows, K + 1, **f32)
+        self.head_ws = torch.zeros(8, dtype=torch.int32, device=device)   # 16 bytes per pass, zero between launches
 
   m = property(lambda self: self.disc.m)
   v = property(lambda self: self.disc.v)
@@ -1210,6 +1220,9 @@ class FactorVAE(AnnealingVAE):
     lib, B1 = eng.lib, disc.B1
     dp = eng.is_dp
     P = []
+    # A/B switch (bench.py --no-fused-disc): the head's launches and permute_dims as round 5 issued them
+    fuse = bool(getattr(self, 'fuse_discriminator', True))
+    fused_head = disc.fused_head and fuse
 
     # The discriminator's pass over z (TC estimate + its gradient wrt z: twelve small launches, ~96 us at batch 128, none
     # of which fills the chip) depends on z alone and is needed again only by the ENCODER's backward pass: `overlap_disc`
@@ -1221,9 +1234,19 @@ class FactorVAE(AnnealingVAE):
     overlap = bool(getattr(self, 'overlap_disc', False)) and use_tc and training and side is not None
 
     def disc_pass(st):
-      lg = disc.prog1.forward(eng.z, st)
+      P1 = disc.prog1
+      if fused_head:
+        n = len(P1.recs)
+        h = P1.forward(eng.z, st, upto=n - 1)
+        lib.odin_disc_head_fwd_bwd(h.data_ptr(), P1.w(n - 1).data_ptr(), P1.b(n - 1).data_ptr(), P1.outs[n - 1].data_ptr(),
+                                   0, disc.dlogit1.data_ptr(), None, disc.tc.data_ptr(), ACT[P1.recs[n - 2].act],
+                                   P1.gouts[n - 2].data_ptr(), P1.word(n - 2), None, None, disc.head_ws.data_ptr(), B1,
+                                   P1.recs[n - 1].K, st)
+        P1.backward(eng.z, P1.gouts[n - 2], st, dx_out=disc.dz, data_only=True, last=n - 2)
+        return
+      lg = P1.forward(eng.z, st)
       lib.odin_mean(lg.data_ptr(), B1, disc.tc.data_ptr(), st)
-      disc.prog1.backward(eng.z, disc.dlogit1, st, dx_out=disc.dz, data_only=True)
+      P1.backward(eng.z, disc.dlogit1, st, dx_out=disc.dz, data_only=True)
 
     def step1():  # ELBO with the discriminator's TC estimate, backward
       st = eng.stream()
@@ -1259,7 +1282,14 @@ class FactorVAE(AnnealingVAE):
       else:
         eng.finalize()
       if training:
-        eng.backward(extra_dz=extra)
+        # the gradient norm's stage-1 sums ride in the slab reduction when the update follows at once with no per-tensor
+        # policy in between (engine.VAEEngine.step_program does the same for the plain step)
+        eng._fuse_norm_now = bool(fuse and not dp and not aggregate_gradients and pol[1] is None and pol[2] is None and
+                                  pol[3] is None and (pol[0] is not None or pol[4]) and eng.fuse_norm)
+        try:
+          eng.backward(extra_dz=extra)
+        finally:
+          eng._fuse_norm_now = False
 
     P.append(('k', step1))
     if training and dp:
@@ -1271,7 +1301,10 @@ class FactorVAE(AnnealingVAE):
       def encode2():
         st = eng.stream()
         eng2.run_encoder(x2, eps2)  # z' with the encoder as step 1 left it
-        if perm is None:
+        if perm is None and not disc.gather and fuse:   # (the permutation and permute_dims(z') in one launch)
+          lib.odin_random_permute_dims(disc.perm.data_ptr(), eng2.z.data_ptr(), disc.zperm.data_ptr(), B1, self.zdim,
+                                       self.seed + 11, eng.hp(N_HYPER), st)
+        elif perm is None:
           lib.odin_random_perm(disc.perm.data_ptr(), B1 * disc.world, self.zdim, self.seed + 11,
                                eng.hp(N_HYPER), st)
 
@@ -1285,13 +1318,29 @@ class FactorVAE(AnnealingVAE):
           src, prm = disc.z2_all, disc.perm[disc.rank * B1:(disc.rank + 1) * B1]
         else:
           src, prm = eng2.z, disc.perm
-        lib.odin_permute_dims(src.data_ptr(), prm.data_ptr(), disc.zperm.data_ptr(), B1,
-                              self.zdim, st)
-        lg2 = disc.prog2.forward(disc.zcat, st)
-        lib.odin_dtc_loss_fwd_bwd(lg2.data_ptr(), lg2[B1:].data_ptr(), disc.dtc.data_ptr(),
-                                  disc.dlogit2.data_ptr(), disc.dlogit2[B1:].data_ptr(), B1, st)
+        if perm is not None or disc.gather or not fuse:
+          lib.odin_permute_dims(src.data_ptr(), prm.data_ptr(), disc.zperm.data_ptr(), B1,
+                                self.zdim, st)
+        P2 = disc.prog2
+        if fused_head:
+          n = len(P2.recs)
+          r = P2.recs[n - 1]
+          h = P2.forward(disc.zcat, st, upto=n - 1)
+          hrows = C.c_int(0)
+          lib.odin_disc_head_fwd_bwd(h.data_ptr(), P2.w(n - 1).data_ptr(), P2.b(n - 1).data_ptr(), P2.outs[n - 1].data_ptr(),
+                                     1, None, disc.dlogit2.data_ptr(), disc.dtc.data_ptr(), ACT[P2.recs[n - 2].act],
+                                     P2.gouts[n - 2].data_ptr() if training else None, P2.word(n - 2),
+                                     disc.head_slab.data_ptr(), C.byref(hrows), disc.head_ws[4:].data_ptr(), 2 * B1, r.K, st)
+          if training:
+            jobs = P2.backward(disc.zcat, P2.gouts[n - 2], st, last=n - 2)
+            jobs.append(ReduceJob(disc.head_slab.data_ptr(), disc.grads[r.w_off:].data_ptr(), r.K + 1, hrows.value, r.K + 1, 0))
+        else:
+          lg2 = P2.forward(disc.zcat, st)
+          lib.odin_dtc_loss_fwd_bwd(lg2.data_ptr(), lg2[B1:].data_ptr(), disc.dtc.data_ptr(),
+                                    disc.dlogit2.data_ptr(), disc.dlogit2[B1:].data_ptr(), B1, st)
+          if training:
+            jobs = P2.backward(disc.zcat, disc.dlogit2, st)
         if training:
-          jobs = disc.prog2.backward(disc.zcat, disc.dlogit2, st)
           jobs.append(disc.reset_job())
           arr = (ReduceJob * len(jobs))(*jobs)
           disc._keep = arr

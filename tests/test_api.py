@@ -151,7 +151,7 @@ def test_factor_vae_two_steps_match_oracle(L, DEV):
   assert not torch.equal(d_before, disc.params)
 
 
-@pytest.mark.parametrize('units', [(16, 16), (40,)])
+@pytest.mark.parametrize('units', [(16, 16), (40,), (64, 64)])   # (64: the head fused with its loss, odin_disc_head_fwd_bwd)
 def test_factor_vae_iteration_gradients_and_both_adams(L, DEV, units):
   """the step-1 dz through D, the discriminator gradients and the
   Adam(1e-5, .5, .9) update against the oracle (simulator build of the kernels)."""

@@ -305,6 +305,63 @@ def test_dense_weight_gradient_lds_staged(bk, request, B, K, N, scale, ranged):
   assert rel(dx.cpu().numpy(), dx_ref * (aux.astype(np.float32) > 0)) <= 2e-6
 
 
+@pytest.mark.parametrize('B,K,mode,act', [(128, 1000, 0, 'relu'), (256, 1000, 1, 'relu'), (20, 64, 1, 'elu'), (13, 1284, 0, 'relu'),
+                                          (66, 2048, 1, 'linear')])
+def test_discriminator_head_in_one_launch(bk, B, K, mode, act):
+  """odin_disc_head_fwd_bwd: FactorDiscriminator's last Dense(K -> 1) (factor_discriminator.py:60-95) with the mean it
+  feeds -- total_correlation (:169-198, mode 0) or dtc_loss (:200-235, mode 1) -- its data gradient and its weight
+  gradient rows, against the oracle; twice on one workspace (every launch leaves it zero), bit for bit."""
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(B + K + mode)
+  h = vo._ACT[act](rng.standard_normal((B, K)))
+  w = rng.standard_normal((K, 1)) / np.sqrt(K)
+  b = rng.standard_normal(1) * 0.1
+  hf, wf, bf = (a.astype(np.float32).astype(np.float64) for a in (h, w, b))
+  logit = (hf @ wf + bf)[:, 0]
+  n = B // 2
+  if mode == 0:
+    dl = np.full(B, 7.0 / B)
+    out_ref = logit.mean()
+  else:
+    dz, dp = vo.dtc_loss_bwd(logit[:n], logit[n:])
+    dl = np.concatenate([dz, dp])
+    out_ref = vo.dtc_loss(logit[:n], logit[n:])
+  dgrad = {'relu': (hf > 0).astype(np.float64), 'linear': np.ones_like(hf), 'elu': np.where(hf > 0, 1.0, 1.0 + hf)}[act]
+  dh_ref = dl[:, None] * wf[:, 0][None, :] * dgrad
+  dw_ref, db_ref = hf.T @ dl, dl.sum()
+  rows = L.odin_disc_head_rows(B, K)
+  assert rows == (B + 7) // 8
+  th, tw, tb, tdl = T(h), T(w), T(b), T(dl)
+  ws = bk.zeros(4, dtype=torch.int32)
+  res = []
+  for _ in range(2):
+    tlogit, tdlo, tout = bk.full((B,), float('nan')), bk.full((B,), float('nan')), bk.full((1,), float('nan'))
+    tdh, slab = bk.full((B, K), float('nan')), bk.full((rows, K + 1), float('nan'))
+    word, r_out = bk.zeros(2048, dtype=torch.int32), C.c_int(0)
+    L.odin_disc_head_fwd_bwd(th.data_ptr(), tw.data_ptr(), tb.data_ptr(), tlogit.data_ptr(), mode,
+                             tdl.data_ptr() if mode == 0 else None, tdlo.data_ptr() if mode == 1 else None, tout.data_ptr(),
+                             _lib.ACT[act], tdh.data_ptr(), word.data_ptr(), slab.data_ptr(), C.byref(r_out), ws.data_ptr(),
+                             B, K, None)
+    assert r_out.value == rows and int(ws.abs().sum()) == 0
+    res.append((tlogit.clone(), tout.clone(), tdh.clone(), slab.clone()))
+  assert all(torch.equal(a, b_) for a, b_ in zip(*res))
+  close(tlogit.cpu().numpy(), logit)
+  assert abs(float(tout) - out_ref) <= 2e-6 * max(1.0, abs(out_ref))
+  if mode == 1:
+    close(tdlo.cpu().numpy() * B, dl * B)
+  close(tdh.cpu().numpy() * B, dh_ref * B)
+  g = reduce_slab(bk, slab, rows, K + 1)
+  close(g[:K] * B / np.sqrt(K), dw_ref * B / np.sqrt(K))
+  close(g[K:] * B, [db_ref * B])
+  assert float(word.view(torch.float32).max()) == float(tdh.abs().max())
+  # forward + loss only (evaluation)
+  tout2 = bk.full((1,), float('nan'))
+  L.odin_disc_head_fwd_bwd(th.data_ptr(), tw.data_ptr(), tb.data_ptr(), tlogit.data_ptr(), mode,
+                           tdl.data_ptr() if mode == 0 else None, None, tout2.data_ptr(), _lib.ACT[act], None, None, None, None,
+                           ws.data_ptr(), B, K, None)
+  assert torch.equal(tout2, tout)
+
+
 @pytest.mark.parametrize('kind,shape', [
     ('conv', (5, 8, 8, 64, 64, 4, 2)), ('conv', (16, 8, 8, 32, 64, 4, 2)), ('deconv', (6, 4, 4, 8, 64, 4, 2)),
     ('deconv', (257, 4, 4, 16, 64, 4, 2)), ('dense', (100, 256, 40)), ('dense', (64, 1024, 128)), ('conv', (3, 16, 16, 32, 32, 4, 2)),

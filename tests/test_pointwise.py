@@ -338,6 +338,10 @@ def test_permute_and_dtc_and_rng(bk):
   close(out.cpu().numpy(), ref, 1e-7)
   assert (out.cpu().numpy() != z.astype(np.float32)).any()
   assert np.allclose(np.sort(out.cpu().numpy(), 0), np.sort(z.astype(np.float32), 0))
+  # the two as one launch: the same permutation, the same rows
+  perm2, out2 = bk.zeros(B, D, dtype=torch.int32), bk.zeros(B, D)
+  L.odin_random_permute_dims(perm2.data_ptr(), tz.data_ptr(), out2.data_ptr(), B, D, 1234, step.data_ptr(), None)
+  assert torch.equal(perm2, perm) and torch.equal(out2, out)
   # dtc loss
   lz, lp = rng.standard_normal(B) * 2, rng.standard_normal(B) * 2
   tlz, tlp = T(lz), T(lp)

@@ -42,10 +42,13 @@ for B, K, N in [(256, 1000, 1000), (128, 1000, 1000), (512, 4096, 512), (512, 10
                                          C.byref(rows), B, K, N, 1, 0, dyw.data_ptr(), None, xw.data_ptr(), st)
     dg = lambda: L.odin_dense_bwd_ranged(None, dy.data_ptr(), w.data_ptr(), aux.data_ptr(), 1, dx.data_ptr(), None, None, None,
                                          None, B, K, N, 0, 1, dyw.data_ptr(), dxw.data_ptr(), None, st)
+    y = torch.empty(B, N, device=dev); bias = torch.zeros(N, device=dev); yw = torch.zeros(2048, dtype=torch.int32, device=dev)
+    fw = lambda: L.odin_dense_fwd_ranged(x.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), B, K, N, 1, xw.data_ptr(), yw.data_ptr(), st)
+    tf = t(fw); pf = L.odin_debug_last_path().decode()
     tp = t(pair); pp = L.odin_debug_last_path().decode()
     tw = t(wg); pw = L.odin_debug_last_path().decode()
     td = t(dg); pd = L.odin_debug_last_path().decode()
     gf = 2.0 * B * K * N / 1e9
     print(f'[{B} x {K} x {N}] ({gf:.2f} GF per half) min_tiles={tiles}: pair {tp:6.1f} us [{pp}]  wgrad {tw:6.1f} us '
-          f'{gf / tw * 1e3:6.1f} TF/s [{pw}]  dgrad {td:6.1f} us [{pd}]', flush=True)
+          f'{gf / tw * 1e3:6.1f} TF/s [{pw}]  dgrad {td:6.1f} us [{pd}]  fwd {tf:6.1f} us [{pf}]', flush=True)
 L.odin_debug_dense_hw_min_tiles(128)
