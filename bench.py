@@ -621,6 +621,9 @@ def main():
   ap.add_argument('--no-fused-disc', action='store_true',
                   help="A/B (FactorVAE): the discriminator head's forward, loss, weight and data gradient and permute_dims as "
                   'launches of their own (round 5) instead of odin_disc_head_fwd_bwd / odin_random_permute_dims')
+  ap.add_argument('--no-mel-r16', action='store_true',
+                  help='A/B (speech): the n_fft = 512 front-end on the general radix-4 kernel (round 5) instead of the register '
+                  'radix-16 one (mel.hip: stft_mel512_kernel)')
   ap.add_argument('--no-dense-hw', action='store_true',
                   help='A/B: Dense weight gradients with both widths >= 256 on the 32 x 32 tiles straight from L2 (round 4) '
                   'instead of the LDS-staged 64 x 64 tiles (dense_h.hip: dense_hw; FactorVAE, CelebA)')
@@ -634,6 +637,9 @@ def main():
   if args.no_blk:
     from odin_ai_amd import _lib as _l
     _l.load().odin_debug_blk_planes(0)
+  if args.no_mel_r16:
+    from odin_ai_amd import _lib as _l
+    _l.load().odin_debug_mel_r16(0)
   if args.no_dense_hw:
     from odin_ai_amd import _lib as _l
     _l.load().odin_debug_dense_hw_min_tiles(1 << 30)
@@ -938,7 +944,7 @@ def main():
                       unit='GB/s', frac=round(nbytes / t_mel * 1e-9 / PEAK_HBM_GBS, 4),
                       us_per_launch=round(t_mel * 1e6, 2), mbytes_per_launch=round(nbytes * 1e-6, 2),
                       note='compute-bound in float64 (the precision of the reference): B workgroups of 256 threads, '
-                           'radix-4 FFT in LDS; priced against HBM as north_star asks')
+                           'n_fft 512: two radix-16 passes in registers, 16 lanes per frame (mel.hip); priced against HBM as north_star asks')
   if args.profile_ops:
     for o in ops:
       print(f"# {o['layer']:14s} {o['op']:6s} {o['us']:9.1f} us {o['gflop']:8.3f} GF "

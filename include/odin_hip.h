@@ -605,6 +605,9 @@ int odin_debug_elbo_shape(int blocks, int U, int pipelined);
 /* diagnostics: workgroup (0, 0) of odin_stft_mel_db_frames records 100 MHz wall-clock stamps (per pass: start, staged,
  * FFT done, power spectrum done; then the end of its last pass) into buf (int64, device memory, >= 64 entries); NULL: off */
 int odin_debug_set_mel_stamps(void* buf);
+/* tests / A-B runs: 0 = n_fft 512 on the general front-end kernel instead of the register radix-16 one (mel.hip); < 0 = only
+ * report.  Returns the previous value. */
+int odin_debug_mel_r16(int enable);
 /* diagnostics: the largest weight slice igemm_h keeps in LDS, in 16-value steps of 2 KB (default 32 = 64 KB; 64 measured slower);
  * returns the previous value, a negative argument only reads it */
 int odin_debug_igemm_h_ldsw_steps(int steps);

@@ -73,3 +73,32 @@ def test_unit_range_output_and_tf_variant(bk):
       assert np.abs(o[i] - r).max() < 2e-5, (log_mels, np.abs(o[i] - r).max())
   from odin_ai_amd.mel import htk_mel_weight_matrix
   np.testing.assert_allclose(htk_mel_weight_matrix(), mo.tf_linear_to_mel_weight_matrix(), atol=1e-14)
+
+
+@pytest.mark.parametrize('kw,n', [(dict(), 5203), (dict(preemphasis=None, window='hann', log=False, n_mels=24), 4001),
+                                  (dict(frame_length=512, step_length=100, n_mels=40), 3100)])
+def test_fft512_register_kernel_against_the_general_one(bk, request, kw, n):
+  """n_fft = 512 runs on stft_mel512_kernel (two radix-16 passes in registers, 16 lanes per frame, mel.hip); the general
+  radix-4 kernel serves every other size.  Same float64 arithmetic: the two agree to the rounding of the twiddle powers
+  (dB: 1e-6; power: 1e-11 relative), ragged last blocks of 16 frames, odd sample counts, frames split over workgroups,
+  and both match the oracle (signal.py:955-967, 1442-1562, 1623-1691, 636-680)."""
+  from oracle import mel_oracle as mo
+  L, DEV = bk.L, bk.dev
+  y = np.tile(G['y'][:3], (1, 2))[:, :n]
+  ex = MelsSpecExtractor(device=DEV, lib=L, **kw)
+  request.addfinalizer(lambda old=L.odin_debug_mel_r16(-1): L.odin_debug_mel_r16(old))
+  L.odin_debug_mel_r16(1)
+  a = ex(y).numpy(force=True)
+  L.odin_debug_mel_r16(0)
+  b = ex(y).numpy(force=True)
+  assert a.shape == b.shape and a.shape[0] == 3
+  if kw.get('log', True):
+    assert np.abs(a - b).max() <= 1e-6, np.abs(a - b).max()
+  else:
+    assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max(), np.abs(a - b).max()
+  okw = {k if k != 'preemphasis' else 'preemph': v for k, v in kw.items()}
+  ref = mo.mel_frontend(y[1], **okw)
+  if kw.get('log', True):
+    assert np.abs(a[1] - ref).max() < 2e-5
+  else:
+    assert np.abs(a[1] - ref).max() <= 1e-6 * np.abs(ref).max()
