@@ -105,6 +105,19 @@ __device__ __forceinline__ void dense_h_body(const DHParams& p, int bx, int by, 
   };
   f32x16 acc = f32x16_zero(), acx = f32x16_zero();
   float csum = 0.f;  // wgrad bias: column sum of B over this wave's k-steps (lane j = l31, half h)
+  // the epilogue's own operands -- the bias of this lane's column, act'(aux) of the elements this wave finishes -- are
+  // requested HERE, in front of the reduction: behind the barrier they were one more dependent L2 round trip of a launch
+  // that lasts 8 us (round 6)
+  constexpr int RPW = 16 / NW > 0 ? 16 / NW : 1;  // registers a wave finishes (NW <= 16)
+  const float bj = (p.bias != nullptr && b_ok) ? p.bias[jb] : 0.f;
+  const OdinRun RX = odin_run(p.aux != nullptr ? p.aux : p.C, p.aux != nullptr ? (unsigned)((size_t)p.M * p.ldc * 4) : 0u);
+  float auxv[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int rr = wave * RPW + q;
+    const int row = i0 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+    auxv[q] = (p.aux != nullptr && rr < 16) ? odin_run_load1(RX, (row < p.M && b_ok) ? (unsigned)((row * p.ldc + jb) * 4) : ODIN_OOB) : 0.f;
+  }
   float a0[8], b0[8], a1[8], b1[8];
   auto mul = [&](const float (&av)[8], const float (&bv)[8]) {
     u32x4 ah, al, bh, bl;
@@ -160,10 +173,7 @@ __device__ __forceinline__ void dense_h_body(const DHParams& p, int bx, int by, 
     if (h == 0) cred[wave * 32 + l31] = t;
   }
   __syncthreads();
-  constexpr int RPW = 16 / NW > 0 ? 16 / NW : 1;  // registers a wave finishes (NW <= 16)
-  const float bj = (p.bias != nullptr && b_ok) ? p.bias[jb] : 0.f;
   const OdinRun RC = odin_run(p.C, (unsigned)((size_t)p.M * p.ldc * 4));
-  const OdinRun RX = odin_run(p.aux != nullptr ? p.aux : p.C, p.aux != nullptr ? (unsigned)((size_t)p.M * p.ldc * 4) : 0u);
   float amx = 0.f;
 #pragma unroll
   for (int q = 0; q < RPW; ++q) {
@@ -175,7 +185,7 @@ __device__ __forceinline__ void dense_h_body(const DHParams& p, int bx, int by, 
       const int row = i0 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
       const unsigned off = (row < p.M && b_ok) ? (unsigned)((row * p.ldc + jb) * 4) : ODIN_OOB;
       v = odin_act(p.act, v + bj);
-      if (p.aux != nullptr) v *= odin_act_grad(p.aux_act, odin_run_load1(RX, off));
+      if (p.aux != nullptr) v *= odin_act_grad(p.aux_act, auxv[q]);
       odin_run_store1(RC, off, v);
       amx = fmaxf(amx, off != ODIN_OOB ? fabsf(v) : 0.f);
     }

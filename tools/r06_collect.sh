@@ -18,6 +18,7 @@ cp $g/r06_final_slabstat.txt $p/r06_slabstat.txt
 cp $g/r06_final_stamps_neck.txt $p/r06_stamps_neck.txt
 cp $g/r06_final_thinbench.txt $p/r06_thinbench.txt
 cp $g/r06_final_blkbench.txt $p/r06_blkbench.txt
+cp $g/r06_final_densebench.txt $p/r06_dense_hw_bench.txt
 cp $g/r06_final_ab.txt $p/r06_ab_same_call.txt
 for w in shapes3d_vae_b256 celeba_betatcvae_b512 mnist_dense_b128 mnist_conv_b128 factorvae_shapes3d_b256 speech_vae_b256; do
   cp $g/r06_final_$w.json $p/r06_bench_$w.json

@@ -24,6 +24,7 @@ python tools/stamps_neck.py > gpurun_out/r06_final_stamps_neck.txt 2>&1
 python tools/stamps_neck.py shapes3d_vae_b256 >> gpurun_out/r06_final_stamps_neck.txt 2>&1
 python tools/thinbench.py > gpurun_out/r06_final_thinbench.txt 2>&1
 python tools/blkbench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_final_blkbench.txt
+python tools/densebench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_final_densebench.txt
 for w in shapes3d_vae_b256 celeba_betatcvae_b512 mnist_dense_b128 mnist_conv_b128 factorvae_shapes3d_b256 speech_vae_b256; do
   timeout 600 python bench.py --workload $w --profile-ops --no-cpu-baseline --no-north-star-3ch > gpurun_out/r06_final_$w.json 2> gpurun_out/r06_final_$w.err
 done
@@ -54,6 +55,15 @@ ab() { python bench.py --no-cpu-baseline --no-exact-fp32 --no-fit "$@" 2>/dev/nu
   for i in 1 2; do
     echo "speech default                   $(ab --workload speech_vae_b256 --no-north-star-3ch)"
     echo "speech --no-blk (igemm_h)        $(ab --workload speech_vae_b256 --no-north-star-3ch --no-blk)"
+  done
+  for i in 1 2; do
+    echo "speech default                   $(ab --workload speech_vae_b256 --no-north-star-3ch)"
+    echo "speech --no-mel-r16              $(ab --workload speech_vae_b256 --no-north-star-3ch --no-mel-r16)"
+    echo "factorvae default                $(ab --workload factorvae_shapes3d_b256 --no-north-star-3ch)"
+    echo "factorvae --no-fused-disc        $(ab --workload factorvae_shapes3d_b256 --no-north-star-3ch --no-fused-disc)"
+    echo "factorvae --no-dense-hw          $(ab --workload factorvae_shapes3d_b256 --no-north-star-3ch --no-dense-hw)"
+    echo "celeba default                   $(ab --workload celeba_betatcvae_b512 --no-north-star-3ch)"
+    echo "celeba --no-dense-hw             $(ab --workload celeba_betatcvae_b512 --no-north-star-3ch --no-dense-hw)"
   done
   echo "dsprites early_reduce=True       $(ab --engine-opt early_reduce=True --no-north-star-3ch)"
   echo "dsprites hyper_ring=False        $(ab --engine-opt hyper_ring=False --no-north-star-3ch)"
