@@ -447,6 +447,21 @@ int odin_dtc_loss_fwd_bwd(const float* logit_z, const float* logit_perm, float* 
 int odin_adam_step_flat(float* theta, const float* g, float* m, float* v, size_t n,
                         const float* hyper, const float* gnorm2, float clip, int32_t* flag,
                         void* stream);
+/* odin_adam_step_flat (no clip, no NaN guard) whose last small gradient pieces are formed INSIDE the launch (round 6:
+ * FactorVAE's discriminator step ended in think_wgrad -> slab_reduce -> adam, two 5 us launch floors in front of the update):
+ *   x != NULL     the weight gradient of a thin-K Dense layer (K <= 32): (dW [K][N] | db [N]) = (x^T dy | column sums of dy)
+ *                 over B rows, written to g + w_off and applied (w_off and (K + 1) N multiples of 4)
+ *   slab != NULL  g[slab_off + i] = sum over slab_rows rows of slab[r * slab_stride + i], i < slab_n (rows ascending),
+ *                 written and applied (slab_off a multiple of 4)
+ *   zero != NULL  zero_n 32-bit words cleared (the step's range words)
+ * Every other parameter is updated from g as odin_adam_step_flat does. */
+typedef struct odin_adam_fold {
+  const float* x; const float* dy; int B, K, N; size_t w_off;
+  const float* slab; int slab_rows; size_t slab_stride, slab_n, slab_off;
+  void* zero; int zero_n;
+} odin_adam_fold;
+int odin_adam_step_fold(float* theta, float* g, float* m, float* v, size_t n, const float* hyper,
+                        const odin_adam_fold* fold, void* stream);
 /* ---- VariationalAutoencoder.marginal_log_prob (variational_autoencoder.py:396-513):
  * n posterior samples per input from one encoder pass: z[k,b,:] = loc_b + softplus(raw_b)*eps[k,b,:],
  * logq[k,b] = log q(z_kb | x_b), logp[k,b] = log N(z_kb; 0, I)   (p: [B,2D], eps/z: [n,B,D]);

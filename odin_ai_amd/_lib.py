@@ -31,6 +31,13 @@ class ReduceJob(C.Structure):
               ('stride', C.c_int), ('pad_', C.c_int)]
 
 
+class AdamFold(C.Structure):
+  """mirror of ``odin_adam_fold`` (include/odin_hip.h): gradient pieces formed inside the Adam launch."""
+  _fields_ = [('x', C.c_void_p), ('dy', C.c_void_p), ('B', C.c_int), ('K', C.c_int), ('N', C.c_int), ('w_off', C.c_size_t),
+              ('slab', C.c_void_p), ('slab_rows', C.c_int), ('slab_stride', C.c_size_t), ('slab_n', C.c_size_t),
+              ('slab_off', C.c_size_t), ('zero', C.c_void_p), ('zero_n', C.c_int)]
+
+
 class NeckArgs(C.Structure):
   """mirror of ``odin_neck_args`` (include/odin_hip.h): the neck of the 64x64 stacks in one launch per direction."""
   _fields_ = [(n, C.c_int) for n in ('B', 'P', 'D', 'C0', 'act2', 'act3', 'act4', 'act0', 'act1', 'analytic')] + \
@@ -124,6 +131,7 @@ SIGNATURES = {
     'odin_random_permute_dims': [P, P, P, I, I, C.c_uint64, P, P],
     'odin_dtc_loss_fwd_bwd': [P, P, P, P, P, I, P],
     'odin_adam_step_flat': [P, P, P, P, C.c_size_t, P, P, F, P, P],
+    'odin_adam_step_fold': [P, P, P, P, C.c_size_t, P, C.POINTER(AdamFold), P],
     'odin_sumsq_flat': [P, C.c_size_t, P, P, P],
     'odin_latent_sample_logprob': [P, P, P, P, P, I, I, I, P],
     'odin_logmeanexp_rows': [P, P, I, I, P],

@@ -608,6 +608,131 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// odin_adam_step_fold (round 6): an Adam step over a flat parameter buffer whose LAST small gradient pieces are formed
+// inside the launch.  FactorVAE's discriminator step ended  ... -> think_wgrad -> slab_reduce -> adam: the first layer's
+// [zdim, 1000] weight gradient (0.8 MFLOP) and the reduction of 32 slab rows of 1001 / 7000 floats, each a 5 us launch
+// floor in front of an 18 us Adam launch that does not need them until its own first / last few workgroups.  Here
+//   workgroups [0, nA)       32 columns of a thin-K Dense layer x 8 row groups: dW[k][n] = sum_b x[b][k] dy[b][n], db[n] =
+//                            sum_b dy[b][n] (16 rows of loads in flight per thread, x in LDS), the row groups through LDS in
+//                            ascending order, then Adam on the block's (K + 1) x 32 parameters
+//   workgroups [nA, nA + nB) thread = element of a slab job: the sum of its rows (ascending), Adam
+//   the rest                 the float4 grid-stride walk of adam_kernel over everything else; they also clear `zero`
+// The folded gradients are written to g as the separate launches would have left them.  No clip / NaN guard (the
+// discriminator's optimiser has none: factor_vae.py:168-176).
+struct AdamFold {
+  const float* x; const float* dy; int B, K, N; size_t offA; int nA;         // x == null: none
+  const float* slab; int rows; size_t stride, nS, offS, endS; int nB;         // slab == null: none; endS: offS + nS rounded up to 4
+  unsigned* zero; int zero_n;
+};
+
+template <int KT>   // K rounded up to 8 / 16 / 32
+__global__ __launch_bounds__(256) void adam_fold_kernel(float* __restrict__ theta, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, size_t n, const float* __restrict__ hyper,
+                                                        AdamFold f) {
+  const float a = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], gs = hyper[4];
+  const int wg = (int)blockIdx.x, tid = threadIdx.x;
+  if (wg < f.nA) {
+    // 32 columns x 8 row groups (rows rg, rg + 8, ..): a thread's chain is B / 8 rows with 16 loads in flight; x staged in
+    // LDS when it fits (broadcast reads); the row groups meet in LDS in ascending order
+    __shared__ float xs[4096];
+    __shared__ float redA[8 * (KT + 1) * 32];
+    const int c = tid & 31, rg = tid >> 5;
+    const int col = wg * 32 + c;
+    const bool xl = f.B * f.K <= 4096;
+    if (xl) {
+      for (int e = tid; e < f.B * f.K; e += 256) xs[e] = f.x[e];
+      __syncthreads();
+    }
+    float acc[KT], accb = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) acc[k] = 0.f;
+    const int colc = col < f.N ? col : f.N - 1;
+    for (int b0 = rg; b0 < f.B; b0 += 8 * 16) {
+      float dv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {   // (unconditional loads of clamped rows: thin_dense.hip)
+        const int b = b0 + 8 * u < f.B ? b0 + 8 * u : f.B - 1;
+        dv[u] = f.dy[(size_t)b * f.N + colc];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const bool ok = b0 + 8 * u < f.B;
+        const int b = ok ? b0 + 8 * u : f.B - 1;
+        const float d = ok ? dv[u] : 0.f;
+        accb += d;
+        const float* xr = xl ? xs + b * f.K : f.x + (size_t)b * f.K;   // (the same address in every lane of a row group)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) acc[k] = fmaf(k < f.K ? xr[k] : 0.f, d, acc[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) redA[(rg * (KT + 1) + k) * 32 + c] = acc[k];
+    redA[(rg * (KT + 1) + KT) * 32 + c] = accb;
+    __syncthreads();
+    for (int o = tid; o < (f.K + 1) * 32; o += 256) {
+      const int k = o >> 5, cc = o & 31, cg = wg * 32 + cc;
+      if (cg >= f.N) continue;
+      const int kk = k < f.K ? k : KT;   // (the bias sums sit behind the KT weight rows)
+      float gv = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) gv += redA[(r * (KT + 1) + kk) * 32 + cc];
+      const size_t i = f.offA + (size_t)k * f.N + cg;
+      float t = theta[i], mm = m[i], vv = v[i];
+      g[i] = gv;
+      adam1(t, gv * gs, mm, vv, a, b1, b2, eps);
+      theta[i] = t; m[i] = mm; v[i] = vv;
+    }
+    return;
+  }
+  if (wg < f.nA + f.nB) {
+    const size_t e = (size_t)(wg - f.nA) * 256 + tid;
+    const size_t i = f.offS + e;
+    if (i >= f.endS || i >= n) return;
+    float gv;
+    if (e < f.nS) {
+      gv = 0.f;
+      for (int r = 0; r < f.rows; ++r) gv += f.slab[(size_t)r * f.stride + e];
+      g[i] = gv;
+    } else {
+      gv = g[i];
+    }
+    float t = theta[i], mm = m[i], vv = v[i];
+    adam1(t, gv * gs, mm, vv, a, b1, b2, eps);
+    theta[i] = t; m[i] = mm; v[i] = vv;
+    return;
+  }
+  const int w0 = wg - f.nA - f.nB, nblk = (int)gridDim.x - f.nA - f.nB;
+  const size_t stride = (size_t)nblk * 256;
+  for (size_t z = (size_t)w0 * 256 + tid; z < (size_t)f.zero_n; z += stride) f.zero[z] = 0u;
+  const size_t a0 = f.x != nullptr ? f.offA : 0, a1 = f.x != nullptr ? f.offA + (size_t)(f.K + 1) * f.N : 0;
+  const size_t s0 = f.slab != nullptr ? f.offS : 0, s1 = f.slab != nullptr ? f.endS : 0;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)w0 * 256 + tid; i < n4; i += stride) {
+    const size_t e = i << 2;
+    if ((e >= a0 && e < a1) || (e >= s0 && e < s1)) continue;
+    float4 t = reinterpret_cast<float4*>(theta)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    adam1(t.x, gg.x * gs, mm.x, vv.x, a, b1, b2, eps);
+    adam1(t.y, gg.y * gs, mm.y, vv.y, a, b1, b2, eps);
+    adam1(t.z, gg.z * gs, mm.z, vv.z, a, b1, b2, eps);
+    adam1(t.w, gg.w * gs, mm.w, vv.w, a, b1, b2, eps);
+    reinterpret_cast<float4*>(theta)[i] = t;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (w0 == 0 && tid < (int)(n & 3)) {
+    const size_t i = (n4 << 2) + tid;
+    if (!((i >= a0 && i < a1) || (i >= s0 && i < s1))) {
+      float t = theta[i], mm = m[i], vv = v[i];
+      adam1(t, g[i] * gs, mm, vv, a, b1, b2, eps);
+      theta[i] = t; m[i] = mm; v[i] = vv;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ g, size_t n,
                                                     float* __restrict__ part, const float* __restrict__ adam_hyper,
                                                     float* __restrict__ staged) {
@@ -1308,6 +1433,40 @@ extern "C" int odin_adam_step_flat(float* theta, const float* g, float* m, float
 }
 
 
+
+// see adam_fold_kernel.  The folded ranges start at multiples of 4 floats, the Dense one also ends at one ((K + 1) N % 4
+// == 0); the slab range may end ragged (its last float4 is finished with the ordinary gradient values).
+extern "C" int odin_adam_step_fold(float* theta, float* g, float* m, float* v, size_t n, const float* hyper,
+                                   const odin_adam_fold* fo, void* stream) {
+  if (fo == nullptr) return odin_fail(-2, "adam_step_fold: no fold description");
+  AdamFold f;
+  memset(&f, 0, sizeof(f));
+  int KT = 8;
+  if (fo->x != nullptr) {
+    if (fo->dy == nullptr || fo->B < 1 || fo->K < 1 || fo->K > 32 || fo->N < 1 || (fo->w_off & 3) != 0 ||
+        (((size_t)(fo->K + 1) * fo->N) & 3) != 0 || fo->w_off + (size_t)(fo->K + 1) * fo->N > n)
+      return odin_fail(-2, "adam_step_fold: Dense piece outside the folded regime (K <= 32, 4-float aligned range)");
+    f.x = fo->x; f.dy = fo->dy; f.B = fo->B; f.K = fo->K; f.N = fo->N; f.offA = fo->w_off;
+    f.nA = (fo->N + 31) / 32;
+    KT = fo->K <= 8 ? 8 : fo->K <= 16 ? 16 : 32;
+  }
+  if (fo->slab != nullptr) {
+    if (fo->slab_rows < 1 || fo->slab_n < 1 || (fo->slab_off & 3) != 0 || fo->slab_off + fo->slab_n > n)
+      return odin_fail(-2, "adam_step_fold: slab piece outside the folded regime");
+    f.slab = fo->slab; f.rows = fo->slab_rows; f.stride = fo->slab_stride; f.nS = fo->slab_n; f.offS = fo->slab_off;
+    f.endS = (fo->slab_off + fo->slab_n + 3) & ~(size_t)3;
+    if (f.endS > n) f.endS = n;
+    f.nB = (int)((f.endS - f.offS + 255) / 256);
+    if (f.x != nullptr && f.offS < f.offA + (size_t)(f.K + 1) * f.N && f.offA < f.endS)
+      return odin_fail(-2, "adam_step_fold: the folded ranges overlap");
+  }
+  f.zero = reinterpret_cast<unsigned*>(fo->zero); f.zero_n = fo->zero != nullptr ? fo->zero_n : 0;
+  const int grid = grid_for(n / 4 + 1, 256, 2048) + f.nA + f.nB;
+  if (KT == 8) ODIN_LAUNCH((adam_fold_kernel<8>), dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper, f);
+  else if (KT == 16) ODIN_LAUNCH((adam_fold_kernel<16>), dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper, f);
+  else ODIN_LAUNCH((adam_fold_kernel<32>), dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, hyper, f);
+  return odin_check_launch("adam_fold");
+}
 
 extern "C" int odin_latent_sample_logprob(const float* p, const float* eps, float* z, float* logq,
                                           float* logp, int n, int B, int D, void* stream) {

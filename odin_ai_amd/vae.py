@@ -1223,6 +1223,13 @@ class FactorVAE(AnnealingVAE):
     # A/B switch (bench.py --no-fused-disc): the head's launches and permute_dims as round 5 issued them
     fuse = bool(getattr(self, 'fuse_discriminator', True))
     fused_head = disc.fused_head and fuse
+    # the discriminator's update with its last small gradient pieces formed inside the Adam launch (odin_adam_step_fold:
+    # the first layer's thin-K weight gradient, the sum of the head's slab rows, the range-word reset) -- one GPU only: a
+    # data-parallel step all-reduces the finished gradient buffer first
+    r0, rh = disc.prog2.recs[0], disc.prog2.recs[-1]
+    fold_adam = bool(fused_head and training and not dp and r0.kind == 'dense' and r0.K <= 32 and
+                     ((r0.K + 1) * r0.N) % 4 == 0 and r0.w_off % 4 == 0 and r0.b_off == r0.w_off + r0.K * r0.N and
+                     rh.w_off % 4 == 0 and rh.b_off == rh.w_off + rh.K)
 
     # The discriminator's pass over z (TC estimate + its gradient wrt z: twelve small launches, ~96 us at batch 128, none
     # of which fills the chip) depends on z alone and is needed again only by the ENCODER's backward pass: `overlap_disc`
@@ -1331,6 +1338,13 @@ class FactorVAE(AnnealingVAE):
                                      1, None, disc.dlogit2.data_ptr(), disc.dtc.data_ptr(), ACT[P2.recs[n - 2].act],
                                      P2.gouts[n - 2].data_ptr() if training else None, P2.word(n - 2),
                                      disc.head_slab.data_ptr(), C.byref(hrows), disc.head_ws[4:].data_ptr(), 2 * B1, r.K, st)
+          if training and fold_adam:
+            jobs = P2.backward(disc.zcat, P2.gouts[n - 2], st, last=n - 2, first=1)
+            if jobs:   # (none with the 1000-unit stack: its hidden layers write their gradients themselves)
+              arr = (ReduceJob * len(jobs))(*jobs)
+              disc._keep = arr
+              lib.odin_slab_reduce(arr, len(jobs), st)
+            return
           if training:
             jobs = P2.backward(disc.zcat, P2.gouts[n - 2], st, last=n - 2)
             jobs.append(ReduceJob(disc.head_slab.data_ptr(), disc.grads[r.w_off:].data_ptr(), r.K + 1, hrows.value, r.K + 1, 0))
@@ -1350,9 +1364,20 @@ class FactorVAE(AnnealingVAE):
       if training:
         if dp:
           P.append(('c', lambda: eng._comm().all_reduce(disc.grads)))
-        P.append(('k', lambda: lib.odin_adam_step_flat(
-            disc.params.data_ptr(), disc.grads.data_ptr(), disc.m.data_ptr(), disc.v.data_ptr(),
-            disc.params.numel(), eng.hp(H_DALPHA), None, 0.0, None, eng.stream())))
+        def disc_update():
+          if fold_adam:
+            P2 = disc.prog2
+            fo = _lib.AdamFold(disc.zcat.data_ptr(), P2.gouts[0].data_ptr(), 2 * B1, r0.K, r0.N, r0.w_off,
+                               disc.head_slab.data_ptr(), disc.head_slab.shape[0], rh.K + 1, rh.K + 1, rh.w_off,
+                               disc.range_words.data_ptr(), disc.range_words.numel())
+            disc._fold_keep = fo
+            lib.odin_adam_step_fold(disc.params.data_ptr(), disc.grads.data_ptr(), disc.m.data_ptr(), disc.v.data_ptr(),
+                                    disc.params.numel(), eng.hp(H_DALPHA), C.byref(fo), eng.stream())
+            return
+          lib.odin_adam_step_flat(disc.params.data_ptr(), disc.grads.data_ptr(), disc.m.data_ptr(), disc.v.data_ptr(),
+                                  disc.params.numel(), eng.hp(H_DALPHA), None, 0.0, None, eng.stream())
+
+        P.append(('k', disc_update))
     if training and aggregate_gradients:
       P.append(('k', lambda: eng._update(pol)))
     return P

@@ -224,6 +224,50 @@ def test_bernoulli_head(bk, B, npix, Cin, Cc, hact):
   close(cs.cpu().numpy().astype(np.float64).sum(0), dh_ref.sum((0, 1)), 1e-4)
 
 
+@pytest.mark.parametrize('B,K,N,nmid,ns,rows', [(256, 6, 1000, 4100, 1001, 32), (37, 10, 260, 12, 5, 3), (64, 32, 64, 0, 64, 1)])
+def test_adam_with_folded_gradient_pieces(bk, B, K, N, nmid, ns, rows):
+  """odin_adam_step_fold: the update of FactorVAE's discriminator (Adam(1e-5, .5, .9), factor_vae.py:168-176) with the first
+  layer's weight gradient (x^T dy | column sums, base_networks.py:1002-1014 under the tape) and the sum of the head's slab
+  rows formed inside the launch, and the range words cleared by it: parameters, moments and the gradient buffer against
+  the oracle and against the separate launches."""
+  from odin_ai_amd._lib import AdamFold
+  L, T = bk.L, bk.T
+  rng = np.random.default_rng(B + K)
+  nA = (K + 1) * N
+  offS = nA + nmid
+  n = ((offS + ns + 3) // 4) * 4
+  x, dy = rng.standard_normal((B, K)), rng.standard_normal((B, N)) * 1e-2
+  slab = rng.standard_normal((rows, ns + 3)) * 1e-2
+  th, gmid = rng.standard_normal(n), rng.standard_normal(n) * 1e-2
+  m, v = rng.standard_normal(n) * 0.01, rng.random(n) * 1e-3
+  f32 = lambda a_: np.asarray(a_, np.float32).astype(np.float64)
+  g_ref = f32(gmid).copy()
+  g_ref[:K * N] = (f32(x).T @ f32(dy)).reshape(-1)
+  g_ref[K * N:nA] = f32(dy).sum(0)
+  g_ref[offS:offS + ns] = f32(slab)[:, :ns].sum(0)
+  t, lr = 3, 1e-5
+  th_ref, m_ref, v_ref = vo.adam_keras(f32(th), g_ref, f32(m), f32(v), t, lr, b1=0.5, b2=0.9)
+  a = lr * math.sqrt(1 - 0.9 ** t) / (1 - 0.5 ** t)
+  hy = T([a, 0.5, 0.9, 1e-7, 1.0])
+  tx, tdy, tslab = T(x), T(dy), T(slab)
+  tth, tg, tm, tv = T(th), T(gmid), T(m), T(v)
+  words = bk.zeros(300, dtype=torch.int32) + 7
+  fo = AdamFold(tx.data_ptr(), tdy.data_ptr(), B, K, N, 0, tslab.data_ptr(), rows, ns + 3, ns, offS, words.data_ptr(), 299)
+  L.odin_adam_step_fold(tth.data_ptr(), tg.data_ptr(), tm.data_ptr(), tv.data_ptr(), n, hy.data_ptr(), C.byref(fo), None)
+  assert int(words[:299].abs().sum()) == 0 and int(words[299]) == 7
+  close(tg.cpu().numpy(), g_ref, 2e-6)
+  close(tm.cpu().numpy(), m_ref, 1e-6)
+  close(tv.cpu().numpy(), v_ref, 1e-6)
+  close(tth.cpu().numpy(), th_ref, 1e-6)
+  # the separate launch on the gradient buffer the fold left: the same update everywhere (two kernels: the compiler
+  # contracts their multiply-adds differently, so to rounding); the untouched gradients bit for bit
+  tth2, tg2, tm2, tv2 = T(th), tg.clone(), T(m), T(v)
+  L.odin_adam_step_flat(tth2.data_ptr(), tg2.data_ptr(), tm2.data_ptr(), tv2.data_ptr(), n, hy.data_ptr(), None, 0.0, None, None)
+  for got, want in ((tth, tth2), (tm, tm2), (tv, tv2)):
+    close(got.cpu().numpy(), want.cpu().numpy(), 1e-6)
+  assert torch.equal(tg[nA:offS], T(gmid)[nA:offS])
+
+
 def test_adam_and_sumsq(bk):
   L, T = bk.L, bk.T
   rng = np.random.default_rng(3)
