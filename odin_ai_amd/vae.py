@@ -1411,6 +1411,10 @@ class FactorVAE(AnnealingVAE):
     eng.step_count = self._step
     eng2.hyper = eng.hyper  # one hyper buffer (RNG step, beta) for both halves
     use_tc = not (self._is_pretraining and training)
+    # (Round 6, tried and dropped: two device rows for the iteration's scalars, one captured graph per row, the row of
+    # iteration t + 1 copied on a side stream while iteration t runs and the main stream waiting on its event only --
+    # to take the 80-byte copy and the gaps around it, 13 us, off the critical path.  Same-call A/B: 0.684 ms against
+    # 0.649 with the plain stream-ordered copy; the cross-stream waits cost more than the copy.)
     self._set_hyper(eng, disc, self._lr(learning_rate), use_tc, training, when_skip_update)
     val = self.tc_coef / (B1 * eng.world_size)
     if disc.dlogit1_value != val:
@@ -1451,7 +1455,8 @@ class FactorVAE(AnnealingVAE):
     from .dist import SegmentedGraph
     B1 = disc.B1
     key = (B1, pol, eps is not None, eps2 is not None, explicit_perm, training, use_tc,
-           aggregate_gradients, self._is_pretraining, eng.analytic, eng.free_bits)
+           aggregate_gradients, self._is_pretraining, eng.analytic, eng.free_bits,
+           bool(getattr(self, 'fuse_discriminator', True)))
     if key not in self._fgraphs:
       xs = self.input_buffer(x.shape[0])
       if x.data_ptr() != xs.data_ptr():
