@@ -625,8 +625,8 @@ def main():
                   help='A/B (speech): the n_fft = 512 front-end on the general radix-4 kernel (round 5) instead of the register '
                   'radix-16 one (mel.hip: stft_mel512_kernel)')
   ap.add_argument('--no-dense-hw', action='store_true',
-                  help='A/B: Dense weight gradients with both widths >= 256 on the 32 x 32 tiles straight from L2 (round 4) '
-                  'instead of the LDS-staged 64 x 64 tiles (dense_h.hip: dense_hw; FactorVAE, CelebA)')
+                  help='A/B: Dense weight / data gradients with both widths >= 256 on the 32 x 32 tiles straight from L2 (round 4) '
+                  'instead of the LDS-staged 64 x 64 tiles (dense_h.hip: dense_hw, dense_hd; FactorVAE, CelebA)')
   ap.add_argument('--force-dist', action='store_true',
                   help='initialise the RCCL process group even at world size 1, so that the '
                   'data-parallel step (graph A, RCCL all-reduce, graph B) runs on a 1-GPU box')

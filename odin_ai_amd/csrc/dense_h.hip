@@ -426,6 +426,139 @@ __global__ __launch_bounds__(512, 4) void dense_hw_kernel(DHParams p) {
   dense_hw_body<AS>(p, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<char*>(buf0), buf1, cred);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dense_hd (round 6): the DATA gradient dx[B, K] = (dy[B, N] w^T) act'(aux) over 64 x 64 tiles, both operands staged once
+// through LDS -- the sibling of dense_hw for the arrangement in which BOTH operands are k-contiguous (rows of dy, rows of
+// w).  On the 32 x 32 tiles CelebA's 4096 -> 512 projection (image_networks.py:688) at batch 512 is 2048 tiles of ONE wave
+// each that walks 32 dependent k-steps: 34-38 us (profiles/r06_dense_hw_bench.txt).  Here a chunk of 64 k of 64 rows of
+// each operand arrives as 16-byte loads, is scaled / split once and waits in LDS as [row][k] planes with a row pitch of
+// 144 bytes (the 16-byte operand reads of 16 consecutive rows then cover all 64 banks); a lane's 8 consecutive k are ONE
+// ds_read_b128.  Waves, chunk pipeline, the meeting of the two k-halves as in dense_hw; max |dx| is folded into the range word.
+constexpr int HD_ROWB = 144;           // a row of one plane: 64 f16 + 16 bytes
+constexpr int HD_PLB = 64 * HD_ROWB;   // 9216
+constexpr int HD_BUF = 4 * HD_PLB;     // A high, A low, B high, B low: 36 KB
+
+__global__ __launch_bounds__(512, 4) void dense_hd_kernel(DHParams p) {
+  ODIN_DYN_SMEM(char, smem);   // 2 x HD_BUF
+  __shared__ float cred[16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = bk_uniform(tid >> 6);
+  const int kh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  const int i0 = by * 64, j0 = bx * 64;
+  const int n = (p.K + 63) >> 6;   // chunks of 64 k
+  const OdinRun RA = odin_run(p.A, (unsigned)((size_t)p.M * p.lda * 4));
+  const OdinRun RB = odin_run(p.B, (unsigned)((size_t)p.N * p.ldb * 4));
+  // staging items: rows r0 + 32 q (q = 0, 1) of the tile, k = 4 c4 .. 4 c4 + 3 of the chunk (reduction lengths are multiples of 8)
+  const int r0 = tid >> 4, c4 = tid & 15;
+  unsigned ga[2], gb[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int ia = i0 + r0 + 32 * q, jb = j0 + r0 + 32 * q;
+    ga[q] = ia < p.M ? (unsigned)((ia * p.lda + 4 * c4) * 4) : ODIN_OOB;
+    gb[q] = jb < p.N ? (unsigned)((jb * p.ldb + 4 * c4) * 4) : ODIN_OOB;
+  }
+  const int sdst = r0 * HD_ROWB + c4 * 8;
+  float4 ra0[2], rb0[2], ra1[2], rb1[2];
+  auto issue = [&](int c, float4 (&va)[2], float4 (&vb)[2]) {
+    const bool ok = 64 * c + 4 * c4 < p.K;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      va[q] = odin_run_load4(RA, (ok && ga[q] != ODIN_OOB) ? ga[q] + (unsigned)(256 * c) : ODIN_OOB);
+      vb[q] = odin_run_load4(RB, (ok && gb[q] != ODIN_OOB) ? gb[q] + (unsigned)(256 * c) : ODIN_OOB);
+    }
+  };
+  issue(0, ra0, rb0);
+  if (n > 1) issue(1, ra1, rb1);
+  const int jc = j0 + wj * 32 + l31;
+  const OdinRangeReq g_rq = odin_range_issue(p.g_amax, lane);
+  const int gk = odin_range_shift(odin_range_finish(g_rq));
+  const float g_s = odin_pow2(gk), g_s2k = odin_pow2(gk + 11);
+  auto stage = [&](char* buf, const float4 (&va)[2], const float4 (&vb)[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      char* d = buf + sdst + q * 32 * HD_ROWB;
+      u32x2 h, l;
+      odin_split_h4<true>(va[q], g_s, g_s2k, h, l);
+      *reinterpret_cast<u32x2*>(d) = h;
+      *reinterpret_cast<u32x2*>(d + HD_PLB) = l;
+      odin_split_h4<false>(vb[q], 1.f, ODIN_LO_SCALE, h, l);
+      *reinterpret_cast<u32x2*>(d + 2 * HD_PLB) = h;
+      *reinterpret_cast<u32x2*>(d + 3 * HD_PLB) = l;
+    }
+  };
+  const int aoff = (wi * 32 + l31) * HD_ROWB + half * 16, boff = 2 * HD_PLB + (wj * 32 + l31) * HD_ROWB + half * 16;
+  f32x16 acc = f32x16_zero(), acx = f32x16_zero();
+  auto compute = [&](const char* buf) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int s = 2 * t + kh;   // this wave's k-steps of the chunk
+      const u32x4 ah = *reinterpret_cast<const u32x4*>(buf + aoff + s * 32), al = *reinterpret_cast<const u32x4*>(buf + HD_PLB + aoff + s * 32);
+      const u32x4 bh = *reinterpret_cast<const u32x4*>(buf + boff + s * 32), bl = *reinterpret_cast<const u32x4*>(buf + HD_PLB + boff + s * 32);
+      acx = mfma32_f16(ah, bl, acx);
+      acc = mfma32_f16(ah, bh, acc);
+      acx = mfma32_f16(al, bh, acx);
+    }
+  };
+  char* buf0 = smem;
+  char* buf1 = smem + HD_BUF;
+  stage(buf0, ra0, rb0);
+  if (n > 2) issue(2, ra0, rb0);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < n; c += 2) {
+    compute(buf0);
+    ODIN_SCHED_FENCE();
+    if (c + 1 < n) {
+      stage(buf1, ra1, rb1);
+      if (c + 3 < n) issue(c + 3, ra1, rb1);
+    }
+    __syncthreads();
+    if (c + 1 >= n) break;
+    compute(buf1);
+    ODIN_SCHED_FENCE();
+    if (c + 2 < n) {
+      stage(buf0, ra0, rb0);
+      if (c + 4 < n) issue(c + 4, ra0, rb0);
+    }
+    __syncthreads();
+  }
+  const float o_s = odin_pow2(-gk), o_sx = odin_pow2(-gk - 11);
+  // the epilogue's act'(aux) of the elements this wave finishes (kh == 0): requested in front of the last barrier (16
+  // registers that the main loop does not have to carry at 128 per wave)
+  const OdinRun RX = odin_run(p.aux != nullptr ? p.aux : p.C, p.aux != nullptr ? (unsigned)((size_t)p.M * p.ldc * 4) : 0u);
+  float auxv[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int row = i0 + wi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+    auxv[rr] = (p.aux != nullptr && kh == 0) ? odin_run_load1(RX, (row < p.M && jc < p.N) ? (unsigned)((row * p.ldc + jc) * 4) : ODIN_OOB) : 0.f;
+  }
+  float* redl = reinterpret_cast<float*>(buf0) + (wave & 3) * 16 * 64 + lane;
+  if (kh == 1) {
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) redl[rr * 64] = fmaf(acx[rr], o_sx, acc[rr] * o_s);
+  }
+  __syncthreads();
+  float amx = 0.f;
+  if (kh == 0) {
+    const OdinRun RC = odin_run(p.C, (unsigned)((size_t)p.M * p.ldc * 4));
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = i0 + wi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+      const unsigned off = (row < p.M && jc < p.N) ? (unsigned)((row * p.ldc + jc) * 4) : ODIN_OOB;
+      float v = fmaf(acx[rr], o_sx, acc[rr] * o_s) + redl[rr * 64];
+      if (p.aux != nullptr) v *= odin_act_grad(p.aux_act, auxv[rr]);
+      odin_run_store1(RC, off, v);
+      amx = fmaxf(amx, off != ODIN_OOB ? fabsf(v) : 0.f);
+    }
+  }
+  if (p.out_amax != nullptr) {
+    __syncthreads();
+    odin_amax_commit_wg(p.out_amax, amx, tid, 512, cred, (unsigned)(bx + (int)gridDim.x * by));
+  }
+}
+
 // the paired launch with the weight gradient on dense_hw: workgroups [0, nd) = data gradient (8 waves per 32 x 32 tile),
 // the rest = 64 x 64 tiles of the weight gradient (8 waves)
 template <bool AS>
@@ -480,6 +613,23 @@ void dh_hw_attr() {
   done = true;
 #endif
 }
+// dense_hd instead of the 32 x 32 tiles for a data gradient [M, N]: the same tile count, and a reduction long enough that
+// the small tiles would walk it with one or two waves
+// (odin_debug_dense_hw_min_tiles(1), the tests' setting: every shape)
+bool dh_hd_ok(int M, int N, int K) { return dh_hw_ok(M, N) && (g_hw_min_tiles <= 1 || dh_waves(M, N, K, 1) <= 2); }
+int dh_hd_launch(const DHParams& p, void* stream) {
+#ifndef ODIN_SIM
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_hd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HD_BUF) != hipSuccess)
+      (void)hipGetLastError();
+    done = true;
+  }
+#endif
+  dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, 1);
+  ODIN_LAUNCH((dense_hd_kernel), grid, dim3(512), (size_t)2 * HD_BUF, stream, p);
+  return odin_check_launch("dense_hd(f16x2)");
+}
 int dh_hw_launch(const DHParams& p, void* stream) {
   dh_hw_attr();
   dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, 1);
@@ -531,6 +681,7 @@ int odin_dense_h_dgrad(const float* dy, const float* w, const float* aux, int au
   p.g_amax = odin_range_word_of(dy, (size_t)B * N, dy_amax, stream);
   if (p.g_amax == nullptr) return odin_fail(-3, "dense_h dgrad: no range word for dy");
   p.out_amax = dx_amax;
+  if (dh_hd_ok(B, K, N)) return dh_hd_launch(p, stream);
   return dh_launch<true, true, true, false>(p, dh_waves(B, K, N, 1), stream);
 }
 
@@ -591,7 +742,7 @@ int odin_dense_h_bwd_pair(const float* x, const float* dy, const float* w, const
   int rc = dh_hw_ok(K, N)      ? dh_hw_launch(pw, stream)
            : x_amax != nullptr ? dh_launch<false, false, false, true, true>(pw, nww, stream)
                                : dh_launch<false, false, false, true>(pw, nww, stream);
-  if (rc == 0) rc = dh_launch<true, true, true, false>(pd, nwd, stream);
+  if (rc == 0) rc = dh_hd_ok(B, K, N) ? dh_hd_launch(pd, stream) : dh_launch<true, true, true, false>(pd, nwd, stream);
   return rc;
 }
 

@@ -303,6 +303,14 @@ def test_dense_weight_gradient_lds_staged(bk, request, B, K, N, scale, ranged):
                           None)
   assert torch.equal(slab2[0], slab[0])
   assert rel(dx.cpu().numpy(), dx_ref * (aux.astype(np.float32) > 0)) <= 2e-6
+  # the data gradient alone: dense_hd, the LDS-staged form for two k-contiguous operands (with the tests' setting every
+  # shape runs on it); its range word is max |dx| exactly
+  word, dx2 = bk.zeros(2048, dtype=torch.int32), bk.full((B, K), float('nan'))
+  L.odin_dense_bwd_ranged(None, tdy.data_ptr(), tw.data_ptr(), taux.data_ptr(), _lib.ACT['relu'], dx2.data_ptr(), None, None,
+                          None, None, B, K, N, 0, 1, None, word.data_ptr(), None, None)
+  assert 'dense_hd' in L.odin_debug_last_path().decode()
+  assert rel(dx2.cpu().numpy(), dx_ref * (aux.astype(np.float32) > 0)) <= 2e-6
+  assert float(word.view(torch.float32).max()) == float(dx2.abs().max())
 
 
 @pytest.mark.parametrize('B,K,mode,act', [(128, 1000, 0, 'relu'), (256, 1000, 1, 'relu'), (20, 64, 1, 'elu'), (13, 1284, 0, 'relu'),
