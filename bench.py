@@ -624,6 +624,8 @@ def main():
   ap.add_argument('--no-mel-r16', action='store_true',
                   help='A/B (speech): the n_fft = 512 front-end on the general radix-4 kernel (round 5) instead of the register '
                   'radix-16 one (mel.hip: stft_mel512_kernel)')
+  ap.add_argument('--no-smallc-planes', action='store_true',
+                  help='A/B: the RGB first layer forward on fp32 MFMAs (round 5) instead of two f16 planes (smallc_conv.hip)')
   ap.add_argument('--no-dense-hw', action='store_true',
                   help='A/B: Dense weight / data gradients with both widths >= 256 on the 32 x 32 tiles straight from L2 (round 4) '
                   'instead of the LDS-staged 64 x 64 tiles (dense_h.hip: dense_hw, dense_hd; FactorVAE, CelebA)')
@@ -640,6 +642,9 @@ def main():
   if args.no_mel_r16:
     from odin_ai_amd import _lib as _l
     _l.load().odin_debug_mel_r16(0)
+  if args.no_smallc_planes:
+    from odin_ai_amd import _lib as _l
+    _l.load().odin_debug_smallc_planes(0)
   if args.no_dense_hw:
     from odin_ai_amd import _lib as _l
     _l.load().odin_debug_dense_hw_min_tiles(1 << 30)

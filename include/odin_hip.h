@@ -623,6 +623,9 @@ int odin_debug_set_mel_stamps(void* buf);
 /* tests / A-B runs: 0 = n_fft 512 on the general front-end kernel instead of the register radix-16 one (mel.hip); < 0 = only
  * report.  Returns the previous value. */
 int odin_debug_mel_r16(int enable);
+/* tests / A-B runs: 0 = the RGB first layer's forward (4x4, 3 -> 32 channels) on the fp32 matrix instructions instead of two
+ * f16 planes (smallc_conv.hip); < 0 = only report.  Returns the previous value. */
+int odin_debug_smallc_planes(int enable);
 /* diagnostics: the largest weight slice igemm_h keeps in LDS, in 16-value steps of 2 KB (default 32 = 64 KB; 64 measured slower);
  * returns the previous value, a negative argument only reads it */
 int odin_debug_igemm_h_ldsw_steps(int steps);

@@ -118,6 +118,7 @@ SIGNATURES = {
     'odin_debug_blk_first': [C.c_int],
     'odin_debug_dense_hw_min_tiles': [C.c_int],
     'odin_debug_mel_r16': [C.c_int],
+    'odin_debug_smallc_planes': [C.c_int],
     'odin_wgrad_planes_defer_begin': [],
     'odin_wgrad_planes_defer_end': [P],
     'odin_elbo_mixqlogistic_fwd_bwd': [P, P, P, P, P, I, I, I, I, IP, P],
@@ -167,7 +168,7 @@ VALUE_RETURNING = ('odin_version', 'odin_comm_library', 'odin_conv2d_dgrad_keeps
                    'odin_deconv2d_dgrad_keeps_range', 'odin_bernoulli_tail_keeps_range', 'odin_dense_dgrad_keeps_range', 'odin_conv2d_reads_x_range',
                    'odin_deconv2d_reads_x_range', 'odin_dense_reads_x_range', 'odin_max_slab_rows', 'odin_debug_absmax_fallbacks', 'odin_crc32c', 'odin_debug_last_path',
                    'odin_latent_block_rows', 'odin_neck_rows', 'odin_debug_igemm_h_ldsw_steps', 'odin_total_correlation_workspace', 'odin_debug_igemm_h_min_flop', 'odin_debug_blk_min_flop',
-                   'odin_debug_blk_planes', 'odin_debug_blk_first', 'odin_debug_dense_hw_min_tiles', 'odin_gaussian_tail_applicable', 'odin_disc_head_rows', 'odin_debug_mel_r16')
+                   'odin_debug_blk_planes', 'odin_debug_blk_first', 'odin_debug_dense_hw_min_tiles', 'odin_gaussian_tail_applicable', 'odin_disc_head_rows', 'odin_debug_mel_r16', 'odin_debug_smallc_planes')
 # entry points declared `void` in include/odin_hip.h
 VOID_RETURNING = ('odin_wgrad_planes_defer_begin', 'odin_wgrad_pair_begin')
 

@@ -441,6 +441,129 @@ __global__ __launch_bounds__(256) void smallc_fwd_lds_kernel(SCParams p, int NR)
   odin_amax_commit_wg(p.y_amax, amx, tid, 256, ared, blockIdx.x);
 }
 
+// The RGB first layer (K = 4 * 4 * 3 = 48, 32 output channels) of the kernel above on the f16 matrix pipe (round 6): its 24
+// v_mfma_f32_32x32x2f32 per 32-pixel block are 1536 matrix-pipe cycles -- at batch 512 (CelebA) 10 us of fp32 MFMA time
+// under a launch whose 67 MB of output need 13 us; measured 38 us.  With the operands as two f16 planes (odin_device.h:
+// x = h + 2^-11 l, three v_mfma_f32_32x32x16_f16 per 16 k-values) the block is 9 MFMAs = 288 cycles: the weights' planes
+// live in 24 registers, a lane gathers its pixel's 24 k-values from the staged rows as before and splits them (6 x
+// odin_split_h4).  Same staging, epilogue and range word; image values and weights are inside the f16 window unscaled.
+template <bool ELU>
+__global__ __launch_bounds__(256) void smallc_fwd_lds_h_kernel(SCParams p, int NR) {
+  ODIN_DYN_SMEM(float, xs);  // [S (NR - 1) + KH rows][W * CI]
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef ODIN_SIM
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int l31 = lane & 31, h = lane >> 5;
+  const int rowf = p.W * p.CI;                 // floats per input row
+  const int nrows = p.S * (NR - 1) + p.KH;
+  const int gpi = p.OH / NR;                   // row groups per image
+  const int bb = blockIdx.x / gpi, oh0 = (blockIdx.x - bb * gpi) * NR;
+  const int ih_first = oh0 * p.S - p.pt;
+  // ---- stage the rows: all loads of a thread before its stores ----
+  {
+    const OdinRun XR = odin_run(p.x, (unsigned)((size_t)p.B * p.H * rowf * 4));
+    const int n4 = (nrows * rowf) >> 2;        // (rowf % 4 == 0: checked on the host)
+    const int r4 = rowf >> 2;
+    for (int e0 = 0; e0 < n4; e0 += 256 * 4) {
+      float4 v[4];
+      bool real[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * 256 + tid;
+        const int r = e / r4, c4 = e - r * r4;
+        const int ih = ih_first + r;
+        real[u] = e < n4 && ih >= 0 && ih < p.H;
+        v[u] = odin_run_load4(XR, real[u] ? (unsigned)((((bb * p.H + ih) * rowf) + 4 * c4) * 4) : ODIN_OOB);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * 256 + tid;
+        if (e < n4) {
+          float4 t = v[u];
+          if (p.center && real[u]) { t.x = 2.f * t.x - 1.f; t.y = 2.f * t.y - 1.f; t.z = 2.f * t.z - 1.f; t.w = 2.f * t.w - 1.f; }
+          reinterpret_cast<float4*>(xs)[e] = t;
+        }
+      }
+    }
+  }
+  // ---- weight planes (A operand: row = output channel l31, k = 16 s + 8 h + j), tap tables of this lane's 24 k ----
+  const OdinRun WR = odin_run(p.w, (unsigned)((size_t)48 * p.CO * 4));
+  u32x4 ah[3], al[3];
+  int toff[24], tkw[24];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * s + 8 * h + j;
+      const int tap = sc_smalldiv(k, 3);
+      const int c = k - tap * 3;
+      const int kh = tap >> 2;
+      tkw[8 * s + j] = tap & 3;
+      toff[8 * s + j] = (kh * p.W + (tap & 3)) * 3 + c;
+      wv[j] = odin_run_load1(WR, l31 < p.CO ? (unsigned)((k * p.CO + l31) * 4) : ODIN_OOB);
+    }
+    u32x2 h0, l0, h1, l1;
+    odin_split_h4<false>(make_float4(wv[0], wv[1], wv[2], wv[3]), 1.f, ODIN_LO_SCALE, h0, l0);
+    odin_split_h4<false>(make_float4(wv[4], wv[5], wv[6], wv[7]), 1.f, ODIN_LO_SCALE, h1, l1);
+    ah[s][0] = h0.x; ah[s][1] = h0.y; ah[s][2] = h1.x; ah[s][3] = h1.y;
+    al[s][0] = l0.x; al[s][1] = l0.y; al[s][2] = l1.x; al[s][3] = l1.y;
+  }
+  float bias_r[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+    bias_r[i] = (p.bias != nullptr && n < p.CO) ? p.bias[n] : 0.f;
+  }
+  __syncthreads();
+  const int cpr = p.OW >> 5;
+  float amx = 0.f;
+  for (int j = wave; j < NR * cpr; j += 4) {  // wave-uniform: (row of the group, 32-pixel column block)
+    const int rr = j / cpr, q0 = (j - rr * cpr) << 5;
+    const int ow = q0 + l31;
+    const int iw0 = ow * p.S - p.pl;
+    const int base = (rr * p.S * p.W + iw0) * 3;
+    f32x16 acc = f32x16_zero(), acx = f32x16_zero();
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      float b[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int iw = iw0 + tkw[8 * s + e];
+        b[e] = (iw >= 0 && iw < p.W) ? xs[base + toff[8 * s + e]] : 0.f;
+      }
+      u32x2 h0, l0, h1, l1;
+      odin_split_h4<false>(make_float4(b[0], b[1], b[2], b[3]), 1.f, ODIN_LO_SCALE, h0, l0);
+      odin_split_h4<false>(make_float4(b[4], b[5], b[6], b[7]), 1.f, ODIN_LO_SCALE, h1, l1);
+      u32x4 bh, bl;
+      bh[0] = h0.x; bh[1] = h0.y; bh[2] = h1.x; bh[3] = h1.y;
+      bl[0] = l0.x; bl[1] = l0.y; bl[2] = l1.x; bl[3] = l1.y;
+      acx = mfma32_f16(ah[s], bl, acx);
+      acc = mfma32_f16(ah[s], bh, acc);
+      acx = mfma32_f16(al[s], bh, acx);
+    }
+    float* outp = p.y + ((size_t)((bb * p.OH + oh0 + rr) * p.OW + ow)) * p.CO + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = 8 * q + 4 * h;
+      if (n + 3 < p.CO) {
+        float o4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          o4[i] = sc_act<ELU>(p.act, fmaf(acx[4 * q + i], ODIN_LO_UNSCALE, acc[4 * q + i]) + bias_r[4 * q + i]);
+        const float4 o = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        amx = odin_amax3(odin_amax3(amx, o.x, o.y), o.z, o.w);
+        *reinterpret_cast<float4*>(outp + 8 * q) = o;
+      }
+    }
+  }
+  __shared__ float ared[16];
+  odin_amax_commit_wg(p.y_amax, amx, tid, 256, ared, blockIdx.x);
+}
+
 // Weight gradient on the matrix cores, operands straight from HBM/L2 (no LDS staging): with
 // K = KH*KW*Cin <= 63 the whole dW is RB x CB accumulator tiles (rows = taps (+ one bias row whose
 // A operand is the constant 1), columns = output channels) and the MFMA reduction index is the
@@ -565,6 +688,13 @@ bool odin_smallc_applicable(const odin_conv_desc* d) {
          (size_t)16 * (K + 1) * d->Cout * 4 <= 150 * 1024;
 }
 
+static bool g_sc_planes = true;
+// tests / A-B runs: 0 = the RGB first layer's forward on the fp32 matrix instructions (round 5); < 0 = only report
+extern "C" int odin_debug_smallc_planes(int enable) {
+  const int old = g_sc_planes ? 1 : 0;
+  if (enable >= 0) g_sc_planes = enable != 0;
+  return old;
+}
 static void sc_fill(SCParams& p, const odin_conv_desc* d) {
   memset(&p, 0, sizeof(p));
   p.B = d->B; p.H = d->H; p.W = d->W; p.CI = d->Cin; p.OH = d->OH; p.OW = d->OW; p.CO = d->Cout;
@@ -619,6 +749,13 @@ static int smallc_fwd_launch(const float* x, const float* w, const float* bias, 
           else ODIN_LAUNCH((smallc_fwd_lds_kernel<8, 2, false>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR);
           *tracked = true;
           return odin_check_launch("smallc_fwd_lds");
+        }
+        if (nk2 == 24 && rb == 1 && d->Cin == 3 && d->KW == 4 && d->Cout == 32 && g_sc_planes && !odin_exact_fp32()) {
+          // the RGB first layer on two f16 planes
+          if (d->act == ODIN_ACT_ELU) ODIN_LAUNCH((smallc_fwd_lds_h_kernel<true>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR);
+          else ODIN_LAUNCH((smallc_fwd_lds_h_kernel<false>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR);
+          *tracked = true;
+          return odin_check_launch("smallc_fwd_lds(f16x2)");
         }
         if (nk2 == 24 && rb == 1) {
           if (d->act == ODIN_ACT_ELU) ODIN_LAUNCH((smallc_fwd_lds_kernel<24, 1, true>), dim3((unsigned)gb), dim3(256), l3, stream, p, NR);
