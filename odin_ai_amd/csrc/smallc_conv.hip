@@ -21,6 +21,7 @@ struct SCParams {
   int B, H, W, CI, OH, OW, CO, KH, KW, S, pt, pl, act, center;
   int pix_per_block, slab_stride;
   unsigned* y_amax;   // fwd: optional range word of y (odin_conv_desc.y_amax)
+  const unsigned* dy_amax;   // wgrad on planes: range word of dy
 };
 
 // t / d for 0 <= t < 64, 1 <= d <= 8 (tap decoding: a runtime integer division is ~30 instructions, and the
@@ -798,9 +799,13 @@ static int smallc_fwd_launch(const float* x, const float* w, const float* bias, 
 // is a per-lane constant plus the pixel step.  A row of ones feeds the bias row of the tile, a row of zeros the unused
 // tile rows.  fp32 MFMAs do not run beside VALU work: the ~6 VALU per gather of the kernel above were
 // half of its time.  The next row's loads are in flight while the current row is multiplied.
-template <int RB, int CI>
-__global__ __launch_bounds__(1024) void smallc_wgrad_lds_kernel(SCParams p) {
-  constexpr int NW = 16, U = 4, W = 64, OW = 32;
+// PL (round 6, the RGB layer): the same walk on the f16 matrix pipe -- x (image values, the ones row) unscaled, dy times the
+// power of two of its range word, both as two planes (odin_device.h), 16 pixels per k-step: 6 v_mfma_f32_32x32x16_f16 per
+// 16 pixels and row block instead of 8 v_mfma_f32_32x32x2f32 (1024 -> 384 matrix-pipe cycles per output row); 8 waves per
+// workgroup (two workgroups per CU) so that a wave may hold the main + cross accumulators beside its operands.
+template <int RB, int CI, int NW_ = 16, bool PL = false>
+__global__ __launch_bounds__(NW_ * 64) void smallc_wgrad_lds_kernel(SCParams p) {
+  constexpr int NW = NW_, U = 4, W = 64, OW = 32;
   constexpr int K = 16 * CI;
   constexpr int NCH = W * CI / 4;                 // 16-byte chunks per input row
   constexpr int NI = (4 * NCH + 63) / 64;         // chunks per lane and output row
@@ -846,9 +851,16 @@ __global__ __launch_bounds__(1024) void smallc_wgrad_lds_kernel(SCParams p) {
     cj0[i] = j == 0;
     cj3[i] = j == 3;
   }
-  f32x16 acc[RB];
+  f32x16 acc[RB], acx[RB];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x16_zero();
+  for (int rb = 0; rb < RB; ++rb) { acc[rb] = f32x16_zero(); acx[rb] = f32x16_zero(); }
+  // PL: dy is carried times 2^gk (its range word: the data gradient of the layer above kept it)
+  int gk = 0;
+  if (PL) gk = odin_range_shift(odin_range_finish(odin_range_issue(p.dy_amax, lane)));
+  const float g_s = odin_pow2(gk), g_s2k = odin_pow2(gk + 11);
+  unsigned boffp[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) boffp[j] = l31 < p.CO ? (unsigned)(((8 * h + j) * p.CO + l31) * 4) : ODIN_OOB_V;
   const int r0 = blockIdx.x * (p.pix_per_block / OW);
   int r1 = r0 + p.pix_per_block / OW;
   if (r1 > p.B * p.OH) r1 = p.B * p.OH;
@@ -876,6 +888,37 @@ __global__ __launch_bounds__(1024) void smallc_wgrad_lds_kernel(SCParams p) {
     odin_wave_sync();
     fetch(r + NW);
     const unsigned dyrow = (unsigned)(r * OW * p.CO * 4);
+    if (PL) {
+#pragma unroll
+      for (int q0 = 0; q0 < OW; q0 += 16) {
+        float bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = odin_run_load1s(DR, boffp[j], dyrow + (unsigned)(q0 * p.CO * 4));
+        u32x2 h0, l0, h1, l1;
+        odin_split_h4<true>(make_float4(bv[0], bv[1], bv[2], bv[3]), g_s, g_s2k, h0, l0);
+        odin_split_h4<true>(make_float4(bv[4], bv[5], bv[6], bv[7]), g_s, g_s2k, h1, l1);
+        u32x4 bh, bl;
+        bh[0] = h0.x; bh[1] = h0.y; bh[2] = h1.x; bh[3] = h1.y;
+        bl[0] = l0.x; bl[1] = l0.y; bl[2] = l1.x; bl[3] = l1.y;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          float av[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)   // pixel q0 + 8 h + j (abase carries h * 2 CI floats: 14 h CI more here)
+            av[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + abase[rb] +
+                                                    ((q0 + j) * 2 * CI + 14 * h * CI) * 4);
+          odin_split_h4<false>(make_float4(av[0], av[1], av[2], av[3]), 1.f, ODIN_LO_SCALE, h0, l0);
+          odin_split_h4<false>(make_float4(av[4], av[5], av[6], av[7]), 1.f, ODIN_LO_SCALE, h1, l1);
+          u32x4 ah, al;
+          ah[0] = h0.x; ah[1] = h0.y; ah[2] = h1.x; ah[3] = h1.y;
+          al[0] = l0.x; al[1] = l0.y; al[2] = l1.x; al[3] = l1.y;
+          acx[rb] = mfma32_f16(ah, bl, acx[rb]);
+          acc[rb] = mfma32_f16(ah, bh, acc[rb]);
+          acx[rb] = mfma32_f16(al, bh, acx[rb]);
+        }
+      }
+      continue;
+    }
 #pragma unroll 1
     for (int q0 = 0; q0 < OW; q0 += 2 * U) {
       float a[U][RB], b[U];
@@ -899,7 +942,8 @@ __global__ __launch_bounds__(1024) void smallc_wgrad_lds_kernel(SCParams p) {
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mine[(rb * 16 + r) * 64 + lane] = acc[rb][r];
+    for (int r = 0; r < 16; ++r)
+      mine[(rb * 16 + r) * 64 + lane] = PL ? fmaf(acx[rb][r], ODIN_LO_UNSCALE, acc[rb][r]) * odin_pow2(-gk) : acc[rb][r];
   __syncthreads();
   float* row = p.y + (size_t)blockIdx.x * p.slab_stride;
   for (int e = tid; e < RB * 16 * 64; e += NW * 64) {
@@ -946,14 +990,24 @@ int odin_smallc_wgrad(const float* x, const float* dy, float* slab, int* rows_ou
 #ifndef ODIN_SIM
       static bool attr3 = false;
       if (!attr3) {
-        const void* fns[2] = {reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<1, 1>),
-                              reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<2, 3>)};
+        const void* fns[3] = {reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<1, 1>),
+                              reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<2, 3>),
+                              reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<2, 3, 8, true>)};
         for (const void* f : fns)
           if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr3 = true;
       }
 #endif
+      if (d->Cin == 3 && g_sc_planes && !odin_exact_fp32()) {
+        // the RGB layer on two f16 planes: 8 waves per workgroup, the range word of dy (one counted pass if the caller
+        // brought none)
+        p.dy_amax = odin_range_word_of(dy, (size_t)d->B * d->OH * d->OW * d->Cout, d->dy_amax, stream);
+        if (p.dy_amax == nullptr) return odin_fail(-3, "smallc_wgrad: no range word for dy");
+        const size_t stage8 = (size_t)8 * 6 * (64 * 3 + 8) * 4, tiles8 = (size_t)8 * RB * 4096;
+        ODIN_LAUNCH((smallc_wgrad_lds_kernel<2, 3, 8, true>), dim3(rows), dim3(512), stage8 > tiles8 ? stage8 : tiles8, stream, p);
+        return odin_check_launch("smallc_wgrad_lds(f16x2)");
+      }
       if (d->Cin == 1) ODIN_LAUNCH((smallc_wgrad_lds_kernel<1, 1>), dim3(rows), dim3(1024), l3, stream, p);
       else ODIN_LAUNCH((smallc_wgrad_lds_kernel<2, 3>), dim3(rows), dim3(1024), l3, stream, p);
       return odin_check_launch("smallc_wgrad_lds");
