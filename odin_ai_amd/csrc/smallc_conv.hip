@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void smallc_fwd_lds_kernel(SCParams p, int NR)
       bias_r[rb][i] = (p.bias != nullptr && n < p.CO) ? p.bias[n] : 0.f;
     }
   __syncthreads();
-  const int cpr = p.OW >> 5;
+  const int cpr = (p.OW + 31) >> 5;   // (the last 32-pixel block of a row may be ragged: the audio VAE's 40-pixel rows)
   float amx = 0.f;   // running max |y| of this lane: the range word of the activation (the plane layer above reads it)
   for (int j = wave; j < NR * cpr; j += 4) {  // wave-uniform: (row of the group, 32-pixel column block)
     const int rr = j / cpr, q0 = (j - rr * cpr) << 5;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void smallc_fwd_lds_kernel(SCParams p, int NR)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = rb * 32 + 8 * q + 4 * h;
-        if (n + 3 < p.CO) {
+        if (n + 3 < p.CO && ow < p.OW) {
           const float4 o = make_float4(sc_act<ELU>(p.act, acc[4 * q] + bias_r[rb][4 * q]),
                                        sc_act<ELU>(p.act, acc[4 * q + 1] + bias_r[rb][4 * q + 1]),
                                        sc_act<ELU>(p.act, acc[4 * q + 2] + bias_r[rb][4 * q + 2]),
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void smallc_fwd_lds_h_kernel(SCParams p, int N
     bias_r[i] = (p.bias != nullptr && n < p.CO) ? p.bias[n] : 0.f;
   }
   __syncthreads();
-  const int cpr = p.OW >> 5;
+  const int cpr = (p.OW + 31) >> 5;
   float amx = 0.f;
   for (int j = wave; j < NR * cpr; j += 4) {  // wave-uniform: (row of the group, 32-pixel column block)
     const int rr = j / cpr, q0 = (j - rr * cpr) << 5;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void smallc_fwd_lds_h_kernel(SCParams p, int N
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = 8 * q + 4 * h;
-      if (n + 3 < p.CO) {
+      if (n + 3 < p.CO && ow < p.OW) {
         float o4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -725,7 +725,8 @@ static int smallc_fwd_launch(const float* x, const float* w, const float* bias, 
   if (blocks > 16384) blocks = 16384;
   size_t lds = (size_t)(d->KH * d->KW * d->Cin + 1) * d->Cout * 4;
   const bool small_x = (size_t)d->B * d->H * d->W * d->Cin * 4 < 0x7FFFFFF0u;
-  if (small_x && (d->OW % 32) == 0 && !ODIN_DIAG_ENV("ODIN_SMALLC_VALU")) {
+  // (rows of whole 32-pixel blocks; the LDS form also takes a ragged last block -- the audio VAE's 40-pixel rows, round 6)
+  if (small_x && ((d->OW % 32) == 0 || d->OW > 32) && !ODIN_DIAG_ENV("ODIN_SMALLC_VALU")) {
     const int K = d->KH * d->KW * d->Cin;
     const int nk2 = (K + 1) / 2, rb = (d->Cout + 31) / 32;
     const long n_it = (long)d->B * d->OH * (d->OW / 32);
@@ -773,6 +774,7 @@ static int smallc_fwd_launch(const float* x, const float* w, const float* bias, 
       }
     }
     // persistent waves (2 x 4-wave workgroups per CU-pair ... 4 blocks per wave at batch 256)
+    if ((d->OW % 32) == 0) {
     long bl = (n_it + 3) / 4;
     const long cap = ODIN_DIAG_ENV("ODIN_SMALLC_BL") ? atol(ODIN_DIAG_ENV("ODIN_SMALLC_BL")) : 4L * odin_num_cus();
     if (bl > cap) bl = cap;
@@ -780,6 +782,7 @@ static int smallc_fwd_launch(const float* x, const float* w, const float* bias, 
     if (nk2 == 8 && rb == 2) { ODIN_LAUNCH((smallc_fwd_mfma_kernel<8, 2>), dim3((unsigned)bl), dim3(256), 0, stream, p); return odin_check_launch("smallc_fwd_mfma"); }
     if (nk2 == 24 && rb == 1) { ODIN_LAUNCH((smallc_fwd_mfma_kernel<24, 1>), dim3((unsigned)bl), dim3(256), 0, stream, p); return odin_check_launch("smallc_fwd_mfma"); }
     if (nk2 == 24 && rb == 2) { ODIN_LAUNCH((smallc_fwd_mfma_kernel<24, 2>), dim3((unsigned)bl), dim3(256), 0, stream, p); return odin_check_launch("smallc_fwd_mfma"); }
+    }
   }
   if (small_x && d->KH == 4 && d->KW == 4 && d->Cin == 1)
     ODIN_LAUNCH((smallc_fwd_kernel_t<4, 4, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, p);

@@ -37,6 +37,8 @@ CONV_CASES = [
     (1, 64, 64, 3, 64, 4, 2, 'elu', True),     # first-layer matrix-core kernels, 48 taps, 64 channels
     (2, 64, 64, 3, 32, 4, 2, 'elu', True),     # RGB first layer: rows staged in LDS (forward and weight gradient), image seam
     (2, 64, 64, 1, 32, 4, 2, 'elu', False),    # the same with one channel, no centring
+    (2, 96, 80, 1, 32, 4, 2, 'elu', False),    # the audio VAE's first layer: 40-pixel output rows = a ragged second 32-pixel block
+    (1, 16, 88, 3, 32, 4, 2, 'elu', True),     # RGB on two f16 planes with a ragged block (44-pixel rows)
     (3, 12, 12, 1, 64, 5, 1, 'elu', False),    # small-Cin VALU kernels, 25 taps, 64 lanes per pixel
     (3, 8, 8, 32, 32, 4, 2, 'elu', False),
     (2, 8, 8, 32, 64, 4, 2, 'elu', False),
