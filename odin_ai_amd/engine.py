@@ -246,7 +246,7 @@ class NetProgram:
     the slab reduction that clears the words (NetProgram.backward alone does not clear them)."""
     n = len(self.recs) if upto is None else upto
     for i in range(first, n):   # (gouts below `first` stay inside a fused bottleneck launch: never written)
-      if self.dy_word[i] is None:
+      if self.dy_word[i] is None or self.dy_word[i] != self.word(i):   # (no word, or the caller's own static bound)
         continue
       blk = self.range_words[RANGE_WORDS * i:RANGE_WORDS * (i + 1)]
       bound = float(blk.view(torch.float32).max().item())
@@ -459,13 +459,15 @@ class VAEEngine:
                act_words: bool = True, hyper_ring: bool = True, hyper_ring_rows: int = 128, fuse_norm: bool = True,
                overlap_wgrad: Optional[str] = None, early_reduce: bool = False, defer_wgrad: bool = False,
                side_streams: int = 2, small_wgrad_gf: float = 0.8, dp_buckets: Optional[int] = None,
-               neck: bool = True, neck_bwd: Optional[bool] = None):
+               neck: bool = True, neck_bwd: Optional[bool] = None, static_top_word: bool = True):
     """The keyword-only arguments are the engine's launch-order / A-B options (tests and tools pass them; the engine
     reads no environment variable):
       act_words        activation range words for the two-plane consumers; False: unscaled planes
       hyper_ring       per-step scalars from the device-resident ring; False: one 80-byte copy per step
       hyper_ring_rows  rows of that ring (a power of two >= 8)
       fuse_norm        the gradient norm's stage-1 sums ride in the slab reduction (odin_slab_reduce_sumsq)
+      static_top_word  the Bernoulli ELBO kernel's gradient travels with its a-priori bound 1 / B as a static range word; False:
+                       one absmax pass per step bounds it (A/B)
       overlap_wgrad    None | 'small': the bottleneck layers' weight gradients on side streams (slower since round 2,
                        profiles/r05_ab_same_call.txt; kept for the multi-bucket DP step's tests)
       early_reduce     with overlap_wgrad: the decoder's slabs reduced on a side stream beside the encoder's backward
@@ -539,6 +541,18 @@ class VAEEngine:
                           range_words=gw[ne * RANGE_WORDS:], act_words=aw[ne * RANGE_WORDS:],
                           use_act_words=act_words, small_wgrad_gf=small_wgrad_gf)
     self._act_words_dirty = False   # a forward pass has written activation words that no backward pass has cleared
+    # The top gradient of a Bernoulli observation that is NOT produced by a fused tail comes from the stand-alone ELBO kernel
+    # (dlogits = (sigmoid(l) - x) / B_global): its bound is known a priori, |dlogits| <= 1 / B_global, so the last layer's
+    # plane kernels read a STATIC range word holding that bound instead of paying one absmax pass per step for it (the dense
+    # MNIST step: 5 of 125 us; a bound within a factor of two of the maximum costs at most one of the 22 bits).  The word is
+    # outside the buffer the step clears.
+    self._bern_word = None
+    if observation == 'bernoulli' and static_top_word:
+      self._bern_word = torch.zeros(RANGE_WORDS, dtype=torch.int32, device=self.device)
+      self._bern_word[:1] = torch.tensor([1.0 / (B * self.world_size)], dtype=torch.float32).view(torch.int32).to(self.device)
+      self.dec.dy_word[-1] = self._bern_word.data_ptr()
+      if self.dec.descs[-1] is not None:
+        self.dec.descs[-1].dy_amax = self._bern_word.data_ptr()
     self.p = torch.empty(B, 2 * D, **f32)
     self.dp = torch.empty(B, 2 * D, **f32)
     self.eps = torch.zeros(B, D, **f32)
