@@ -806,9 +806,10 @@ static int smallc_fwd_launch(const float* x, const float* w, const float* bias, 
 // power of two of its range word, both as two planes (odin_device.h), 16 pixels per k-step: 6 v_mfma_f32_32x32x16_f16 per
 // 16 pixels and row block instead of 8 v_mfma_f32_32x32x2f32 (1024 -> 384 matrix-pipe cycles per output row); 8 waves per
 // workgroup (two workgroups per CU) so that a wave may hold the main + cross accumulators beside its operands.
-template <int RB, int CI, int NW_ = 16, bool PL = false>
+// W_: input row width (64; 80 = the audio VAE's 96 x 80 patches, round 6); output rows of W_ / 2 pixels, a multiple of 8.
+template <int RB, int CI, int NW_ = 16, bool PL = false, int W_ = 64>
 __global__ __launch_bounds__(NW_ * 64) void smallc_wgrad_lds_kernel(SCParams p) {
-  constexpr int NW = NW_, U = 4, W = 64, OW = 32;
+  constexpr int NW = NW_, U = 4, W = W_, OW = W_ / 2;
   constexpr int K = 16 * CI;
   constexpr int NCH = W * CI / 4;                 // 16-byte chunks per input row
   constexpr int NI = (4 * NCH + 63) / 64;         // chunks per lane and output row
@@ -985,17 +986,19 @@ int odin_smallc_wgrad(const float* x, const float* dy, float* slab, int* rows_ou
     const int NW = (RB * CB == 4) ? 8 : 16;   // NW x RB x CB x 4 KB of LDS for the partial tiles
     const size_t l2 = (size_t)NW * RB * CB * 1024 * 4;
     // rows staged in LDS: the first layers of the image stacks
-    if ((d->Cin == 1 || d->Cin == 3) && d->W == 64 && d->OW == 32 && d->H == 2 * d->OH && d->KH == 4 && d->KW == 4 &&
+    if ((d->Cin == 1 || d->Cin == 3) && ((d->W == 64 && d->OW == 32) || (d->Cin == 1 && d->W == 80 && d->OW == 40)) &&
+        d->H == 2 * d->OH && d->KH == 4 && d->KW == 4 &&
         d->stride == 2 && d->pad_t == 1 && d->pad_l == 1 && d->Cout <= 32 && !ODIN_DIAG_ENV("ODIN_SMALLC_NOLDS") &&
         (size_t)d->B * d->OH * d->OW * d->Cout * 4 < (1ull << 31)) {
-      const size_t stage = (size_t)16 * 6 * (64 * d->Cin + 8) * 4;
+      const size_t stage = (size_t)16 * 6 * (d->W * d->Cin + 8) * 4;
       const size_t l3 = stage > (size_t)16 * RB * 4096 ? stage : (size_t)16 * RB * 4096;
 #ifndef ODIN_SIM
       static bool attr3 = false;
       if (!attr3) {
-        const void* fns[3] = {reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<1, 1>),
+        const void* fns[4] = {reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<1, 1>),
                               reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<2, 3>),
-                              reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<2, 3, 8, true>)};
+                              reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<2, 3, 8, true>),
+                              reinterpret_cast<const void*>(&smallc_wgrad_lds_kernel<1, 1, 16, false, 80>)};
         for (const void* f : fns)
           if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
@@ -1011,7 +1014,8 @@ int odin_smallc_wgrad(const float* x, const float* dy, float* slab, int* rows_ou
         ODIN_LAUNCH((smallc_wgrad_lds_kernel<2, 3, 8, true>), dim3(rows), dim3(512), stage8 > tiles8 ? stage8 : tiles8, stream, p);
         return odin_check_launch("smallc_wgrad_lds(f16x2)");
       }
-      if (d->Cin == 1) ODIN_LAUNCH((smallc_wgrad_lds_kernel<1, 1>), dim3(rows), dim3(1024), l3, stream, p);
+      if (d->Cin == 1 && d->W == 80) ODIN_LAUNCH((smallc_wgrad_lds_kernel<1, 1, 16, false, 80>), dim3(rows), dim3(1024), l3, stream, p);
+      else if (d->Cin == 1) ODIN_LAUNCH((smallc_wgrad_lds_kernel<1, 1>), dim3(rows), dim3(1024), l3, stream, p);
       else ODIN_LAUNCH((smallc_wgrad_lds_kernel<2, 3>), dim3(rows), dim3(1024), l3, stream, p);
       return odin_check_launch("smallc_wgrad_lds");
     }
